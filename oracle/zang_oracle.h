@@ -1,0 +1,88 @@
+/* zang_oracle.h -- ORACLE (test infrastructure only).  Declarations for
+ * zang_oracle.c: a scalar single-voice CPU restatement of zang's paint() path.
+ * Buffers are per-voice contiguous float[frames], exactly like the reference's []f32;
+ * (start, end) is zang.Span (src/zang/basics.zig:3-10). */
+#ifndef ZANG_ORACLE_H
+#define ZANG_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+/* zang.ConstantOrBuffer, src/zang/constant_or_buffer.zig:4-7 */
+enum { ZO_COB_CONSTANT = 0, ZO_COB_BUFFER = 1 };
+typedef struct { uint32_t tag; float constant; const float *buffer; } zo_cob;
+
+/* zang.PaintCurve, src/zang/painter.zig:25-30 */
+enum { ZO_CURVE_INSTANTANEOUS = 0, ZO_CURVE_LINEAR = 1, ZO_CURVE_SQUARED = 2, ZO_CURVE_CUBED = 3 };
+typedef struct { uint32_t tag; float duration; } zo_curve;
+
+/* zang.Painter, src/zang/painter.zig:33-44 */
+typedef struct { float t, last_value, start; } zo_painter;
+
+typedef struct { float t; } zo_sineosc;                    /* SineOsc.zig:16 */
+typedef struct { uint32_t cnt; } zo_pulseosc;              /* PulseOsc.zig:36 */
+typedef struct { uint32_t cnt; float t; } zo_trisawosc;    /* TriSawOsc.zig:36-37 */
+typedef struct { uint64_t r[4]; float b[7]; } zo_noise;    /* Noise.zig:22-23 */
+enum { ZO_NOISE_WHITE = 0, ZO_NOISE_PINK = 1 };            /* Noise.zig:11-14 */
+enum { ZO_ENV_IDLE = 0, ZO_ENV_ATTACK, ZO_ENV_DECAY, ZO_ENV_SUSTAIN, ZO_ENV_RELEASE }; /* Envelope.zig:15-21 */
+typedef struct { uint32_t state; zo_painter painter; } zo_envelope;   /* Envelope.zig:23-24 */
+typedef struct {                                            /* Envelope.zig:6-13 */
+    float sample_rate; zo_curve attack, decay, release; float sustain_volume; int32_t note_on;
+} zo_envelope_params;
+typedef struct { float l, b; } zo_filter;                  /* Filter.zig:34-35 */
+enum { ZO_FILTER_BYPASS = 0, ZO_FILTER_LOW_PASS, ZO_FILTER_BAND_PASS, ZO_FILTER_HIGH_PASS,
+       ZO_FILTER_NOTCH, ZO_FILTER_ALL_PASS };              /* Filter.zig:10-17 */
+typedef struct { float t; } zo_sampler;                    /* Sampler.zig:69 */
+enum { ZO_SAMPLE_U8 = 0, ZO_SAMPLE_S16, ZO_SAMPLE_S24, ZO_SAMPLE_S32 }; /* Sampler.zig:9-14 */
+typedef struct {                                            /* Sampler.zig:16-21, 62-67 */
+    float sample_rate;          /* Params.sample_rate (output rate) */
+    size_t num_channels;        /* Sample.num_channels */
+    size_t sample_rate_in;      /* Sample.sample_rate */
+    uint32_t format;            /* Sample.format */
+    const uint8_t *data; size_t data_len; /* Sample.data */
+    size_t channel; int32_t loop;
+} zo_sampler_params;
+typedef struct { float dval, dcount; } zo_decimator;       /* Decimator.zig:11-12 */
+enum { ZO_DISTORTION_OVERDRIVE = 0, ZO_DISTORTION_CLIP = 1 }; /* Distortion.zig:8-11 */
+typedef struct { float color; zo_pulseosc osc; zo_filter flt; zo_envelope env; } zo_nice_instrument;
+typedef struct { float release_duration; zo_sineosc carrier, modulator; zo_envelope env; } zo_pmosc_instrument;
+
+void zo_zero(size_t start, size_t end, float *dest);
+void zo_set(size_t start, size_t end, float *dest, float a);
+void zo_copy(size_t start, size_t end, float *dest, const float *src);
+void zo_add(size_t start, size_t end, float *dest, const float *a, const float *b);
+void zo_add_into(size_t start, size_t end, float *dest, const float *src);
+void zo_add_scalar(size_t start, size_t end, float *dest, const float *a, float b);
+void zo_add_scalar_into(size_t start, size_t end, float *dest, float a);
+void zo_multiply(size_t start, size_t end, float *dest, const float *a, const float *b);
+void zo_multiply_with(size_t start, size_t end, float *dest, const float *a);
+void zo_multiply_scalar(size_t start, size_t end, float *dest, const float *a, float b);
+void zo_multiply_with_scalar(size_t start, size_t end, float *dest, float a);
+
+void zo_sineosc_init(zo_sineosc *s);
+void zo_sineosc_paint(zo_sineosc *self, size_t start, size_t end, float *out0, float sample_rate, zo_cob freq, zo_cob phase);
+void zo_pulseosc_init(zo_pulseosc *s);
+void zo_pulseosc_paint(zo_pulseosc *self, size_t start, size_t end, float *out0, float sample_rate, zo_cob freq, float color);
+void zo_trisawosc_init(zo_trisawosc *s);
+void zo_trisawosc_paint(zo_trisawosc *self, size_t start, size_t end, float *out0, float sample_rate, zo_cob freq, float color);
+void zo_noise_init(zo_noise *n, uint64_t seed);
+void zo_noise_paint(zo_noise *self, size_t start, size_t end, float *out, uint32_t color);
+void zo_envelope_init(zo_envelope *e);
+void zo_envelope_paint(zo_envelope *self, size_t start, size_t end, float *out0, int note_id_changed, const zo_envelope_params *params);
+void zo_gate_paint(size_t start, size_t end, float *out0, int note_on);
+void zo_filter_init(zo_filter *f);
+float zo_filter_cutoff_from_frequency(float frequency, float sample_rate);
+void zo_filter_paint(zo_filter *self, size_t start, size_t end, float *out0, const float *input0, uint32_t type, zo_cob cutoff, zo_cob res);
+void zo_sampler_init(zo_sampler *s);
+void zo_sampler_paint(zo_sampler *self, size_t start, size_t end, float *out0, int note_id_changed, const zo_sampler_params *params);
+void zo_decimator_init(zo_decimator *d);
+void zo_decimator_paint(zo_decimator *self, size_t start, size_t end, float *output, float sample_rate, const float *input, float fake_sample_rate);
+void zo_distortion_paint(size_t start, size_t end, float *output, const float *input, uint32_t type, float ingain, float outgain, float offset);
+void zo_nice_init(zo_nice_instrument *n, float color);
+void zo_nice_paint(zo_nice_instrument *self, size_t start, size_t end, float *out0, float *temp0, float *temp1,
+                   int note_id_changed, float sample_rate, float freq, int note_on);
+void zo_pmosc_init(zo_pmosc_instrument *p, float release_duration);
+void zo_pmosc_paint(zo_pmosc_instrument *self, size_t start, size_t end, float *out0, float *temp0, float *temp1,
+                    float *temp2, int note_id_changed, float sample_rate, float freq, int note_on);
+void zo_mixdown_s16lsb(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
+void zo_mixdown_s8(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
+#endif
