@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json headline metric: voice-samples/sec of the paint() hot path.
+
+One "step" = what the reference does per 1024-frame buffer for every voice of the
+workload: `zang.zero(span, out)` then `Module.paint(span, {out}, ...)` (e.g.
+examples/modules.zig:220-225), with state carried from buffer to buffer.
+
+Default workload (N=1): BASELINE.json configs[1] -- 4096 PulseOsc voices x 1024 frames,
+constant per-voice frequency, 48 kHz.  With --gpus N each rank renders its own 4096-voice
+shard (weak scaling; voices are independent, no collective on this path: per-voice output
+images stay resident on the GPU that painted them).
+
+Output images rotate through a ring larger than the 256 MiB Infinity Cache so the stores
+really reach HBM (MI355X_MICROARCH.md "Infinity Cache").  Inputs (per-voice params, module
+state) are resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+SR = 48000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "nice", "nice_mix"])
+    ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline sample length")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+class Workload:
+    """Builds the module(s), resident params and the per-step callable for one rank."""
+
+    def __init__(self, name, ctx, V, F, first_voice, ring_bytes):
+        import torch
+        from zang_amd import modules as mod, zang, workloads
+        self.name, self.V, self.F = name, V, F
+        self.ctx = ctx
+        self.span = zang.Span(0, F)
+        cfg = {"pulseosc": 2, "noise_filter": 3, "nice": 5, "nice_mix": 5}[name]
+        freq, color, u2, u3 = workloads.voice_params(cfg, first_voice, V)
+        self.freq_h, self.color_h, self.u2_h, self.u3_h = freq, color, u2, u3
+        dev = ctx.device
+        self.freq = torch.from_numpy(freq).to(dev)
+        self.color = torch.from_numpy(color).to(dev)
+        img_bytes = V * F * 4
+        nring = max(2, min(64, (ring_bytes + img_bytes - 1) // img_bytes))
+        self.bytes_per_step = img_bytes            # algorithmic: 4 B written per voice-sample
+        self.kernel = None
+        if name == "pulseosc":
+            self.m = mod.PulseOsc(V, ctx)
+            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.params = self.m.Params(SR, zang.constant(self.freq), self.color)
+            self.kernel = "k_pulseosc_const"
+            self.step = self._step_pulse
+        elif name == "noise_filter":
+            self.noise = mod.Noise(V, ctx, first_seed=first_voice)
+            self.flt = mod.Filter(V, ctx)
+            cutoff_f = torch.from_numpy((200.0 + 7800.0 * u2)).to(dev)
+            self.cutoff = mod.Filter.cutoffFromFrequency(cutoff_f, SR, ctx)
+            self.res = torch.from_numpy((0.9 * u3)).to(dev)
+            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.temp = ctx.image(F, V)
+            self.kernel = "k_filter"
+            self.step = self._step_noise_filter
+        elif name == "nice":
+            self.m = mod.NiceInstrument(V, self.color, ctx)
+            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.kernel = "k_nice"
+            self.step = self._step_nice
+            self.nsteps = 0
+        else:
+            self.m = mod.NiceInstrument(V, self.color, ctx)
+            self.mix = torch.zeros(F, dtype=torch.float32, device=dev)
+            self.ring = []
+            self.kernel = "k_nice_mix"
+            self.step = self._step_nice_mix
+            self.nsteps = 0
+        self.nring = len(self.ring)
+        self.i = 0
+
+    def _next(self):
+        o = self.ring[self.i]
+        self.i = (self.i + 1) % self.nring
+        return o
+
+    def _step_pulse(self):
+        self.m.paint(self.span, [self._next()], [], False, self.params, zero_first=True)
+
+    def _step_noise_filter(self):
+        from zang_amd import zang
+        mod_n, mod_f = self.noise, self.flt
+        mod_n.paint(self.span, [self.temp], [], False, mod_n.Params(mod_n.white), zero_first=True)
+        mod_f.paint(self.span, [self._next()], [], False,
+                    mod_f.Params(self.temp, mod_f.low_pass, zang.constant(self.cutoff), zang.constant(self.res)),
+                    zero_first=True)
+
+    def _note_on(self):
+        # config 5: note on for buffers 0-23, then off (attack -> decay -> sustain -> release), repeating
+        k = self.nsteps % 48
+        self.nsteps += 1
+        return k < 24, k == 0
+
+    def _step_nice(self):
+        on, new = self._note_on()
+        self.m.paint(self.span, [self._next()], [], new, self.m.Params(SR, self.freq, on), zero_first=True)
+
+    def _step_nice_mix(self):
+        on, new = self._note_on()
+        self.m.paint_mix(self.span, self.mix, new, self.m.Params(SR, self.freq, on), zero_first=True)
+
+
+def cpu_baseline(args, wl):
+    """The oracle (C restatement of the reference loops; the Zig reference cannot be built
+    in this image) timed on this host, one thread -- the reference's execution model."""
+    import numpy as np
+    from oracle import pyoracle as po
+    L = po.lib()
+    V, F = wl.V, wl.F
+    if wl.name != "pulseosc":
+        return None
+    scratch = np.zeros(F, np.float32)
+    states = (po.PulseOsc * V)()
+    # calibrate on 8 buffers, then size the sample for ~cpu_seconds
+    t0 = time.perf_counter()
+    L.zo_bench_pulseosc(V, F, 8, SR, po.fptr(wl.freq_h), po.fptr(wl.color_h), states, po.fptr(scratch))
+    per = (time.perf_counter() - t0) / 8
+    nbuf = max(8, int(args.cpu_seconds / per))
+    t0 = time.perf_counter()
+    L.zo_bench_pulseosc(V, F, nbuf, SR, po.fptr(wl.freq_h), po.fptr(wl.color_h), states, po.fptr(scratch))
+    dt = time.perf_counter() - t0
+    return {"value": V * F * nbuf / dt, "unit": "voice-samples/s", "cores": 1, "kind": "port",
+            "sample": f"{nbuf} consecutive buffers of the same {V} voices x {F} frames (zero + PulseOsc.paint per voice), "
+                      f"{dt:.1f} s on 1 thread"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    import zang_amd
+    from zang_amd import abi
+    ctx = zang_amd.Context(local_rank if world > 1 else 0)
+    V, F = args.voices, args.frames
+    wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20)
+    lib = ctx.lib
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Kernel duration with HIP events on the launch stream: one event pair per launch over a
+    # second pass of the same K steps (the dominant kernel is the last launch of a step).
+    evs = []
+    for _ in range(2 * args.steps):
+        h = C.c_void_p()
+        abi.check(lib.zh_event_create(ctx.handle, C.byref(h)), "event")
+        evs.append(h)
+    for k in range(args.steps):
+        abi.check(lib.zh_event_record(ctx.handle, evs[2 * k]), "rec")
+        wl.step()
+        abi.check(lib.zh_event_record(ctx.handle, evs[2 * k + 1]), "rec")
+    torch.cuda.synchronize()
+    tot_ms = 0.0
+    ms = C.c_float()
+    for k in range(args.steps):
+        abi.check(lib.zh_event_elapsed_ms(evs[2 * k], evs[2 * k + 1], C.byref(ms)), "elapsed")
+        tot_ms += ms.value
+    for h in evs:
+        lib.zh_event_destroy(h)
+    step_ms_events = tot_ms / args.steps
+
+    total_units = world * V * F * args.steps
+    value = total_units / elapsed
+    achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
+    out = {
+        "metric": "voice-samples/sec", "value": value, "unit": "voice-samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, zero+paint per 1024-frame buffer, 48 kHz",
+                   "voices_per_gpu": V, "frames": F, "ring_images": wl.nring, "parallelism": f"voices sharded x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": wl.kernel,
+                     "algorithmic_bytes_per_launch": wl.bytes_per_step, "launch_ms_hip_events": step_ms_events},
+        "equiv_write_GBs_whole_job": value * 4 / 1e9,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cb = cpu_baseline(args, wl)
+        if cb:
+            out["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,290 @@
+/* zang_hip.h -- C ABI of libzang_hip.so: zang's module paint() hot path on MI355X (gfx950).
+ *
+ * The reference (dbandstra/zang, Zig) has no FFI boundary: a module is a Zig struct with
+ *     pub fn paint(self, span: zang.Span, outputs: [num_outputs][]f32, temps: [num_temps][]f32,
+ *                  note_id_changed: bool, params: Params) void
+ * (canonical form: src/modules/SineOsc.zig:8-31; the one type-erased form is
+ * ModuleBase.paintFn, src/zangscript/runtime.zig:149-162).  Each `zh_<module>_paint` below
+ * replaces that method for a BATCH of n independent voices (= n Zig module instances) in
+ * one call; one wavefront lane renders one voice.  Argument order and meaning follow the
+ * Zig signature: (self, span.start, span.end, outputs, temps, note_id_changed, params).
+ *
+ * Sample buffers live in device memory as images laid out [frame][voice] (voice is the
+ * fastest index, so the 64 lanes of a wavefront store 256 contiguous bytes per frame).
+ * A reference `[]f32` of voice v is column v of an image: element (f, v) = ptr[f*stride + v].
+ *
+ * Like the reference, every paint ACCUMULATES into outputs[0] (`+=`), and the caller
+ * zeroes first (e.g. examples/modules.zig:220-221).  ZH_PAINT_ZERO_FIRST fuses that
+ * `zang.zero(span, out)` into the paint kernel (bit-identical to zero-then-paint).
+ *
+ * All entry points return 0 on success, a hipError_t (> 0) when HIP failed, or a negative
+ * ZH_ERR_* for bad arguments.  Work is enqueued on the context's stream and is
+ * asynchronous unless stated; host arrays passed to get/set/upload/download calls are
+ * synchronous.  One context per host thread; a module instance must not be painted
+ * concurrently (same rule as the reference).  Nothing here allocates inside a paint.
+ */
+#ifndef ZANG_HIP_H
+#define ZANG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZH_API __attribute__((visibility("default")))
+
+enum { ZH_OK = 0, ZH_ERR_INVALID = -1, ZH_ERR_UNSUPPORTED = -2, ZH_ERR_NO_DEVICE = -3 };
+
+/* paint flags */
+enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference contract) */
+       ZH_PAINT_ZERO_FIRST = 1   /* zang.zero(span,out) then paint, in one kernel (basics.zig:12) */ };
+
+typedef struct zh_ctx zh_ctx;
+
+/* Device sample image [frame][voice]; `ptr` is a DEVICE pointer (hipMalloc / torch tensor). */
+typedef struct zh_buf {
+    float   *ptr;
+    uint32_t voices;   /* voices covered by this view                   */
+    uint32_t frames;   /* frames (rows) available; spans index into it  */
+    uint32_t stride;   /* floats between consecutive frames (>= voices) */
+    uint32_t reserved;
+} zh_buf;
+
+/* A per-voice f32 parameter: one value broadcast to every voice, or a device array[n_voices]. */
+typedef struct zh_f32 { float value; uint32_t reserved; const float *per_voice; } zh_f32;
+/* A per-voice bool parameter (note_on, note_id_changed): broadcast, or device uint8[n_voices]. */
+typedef struct zh_bool { uint32_t value; uint32_t reserved; const uint8_t *per_voice; } zh_bool;
+
+/* zang.ConstantOrBuffer (src/zang/constant_or_buffer.zig:4-15).  A buffer is indexed by
+ * ABSOLUTE frame ([span.start..span.end], e.g. SineOsc.zig:56). */
+enum { ZH_COB_CONSTANT = 0, ZH_COB_BUFFER = 1 };
+typedef struct zh_cob { uint32_t tag; uint32_t reserved; zh_f32 constant; zh_buf buffer; } zh_cob;
+
+/* zang.PaintCurve (src/zang/painter.zig:25-30); the tag is shared by all voices. */
+enum { ZH_CURVE_INSTANTANEOUS = 0, ZH_CURVE_LINEAR = 1, ZH_CURVE_SQUARED = 2, ZH_CURVE_CUBED = 3 };
+typedef struct zh_curve { uint32_t tag; uint32_t reserved; zh_f32 duration; } zh_curve;
+
+/* ---------------------------------------------------------------- context, memory */
+ZH_API int  zh_create(zh_ctx **out, int device);
+ZH_API int  zh_destroy(zh_ctx *ctx);
+ZH_API int  zh_set_stream(zh_ctx *ctx, void *hip_stream);   /* adopt an external hipStream_t (NULL = own stream) */
+ZH_API void *zh_get_stream(zh_ctx *ctx);
+ZH_API int  zh_sync(zh_ctx *ctx);
+ZH_API const char *zh_error_string(int err);
+ZH_API const char *zh_version(void);
+
+ZH_API int  zh_malloc(zh_ctx *ctx, void **dev_ptr, size_t bytes);
+ZH_API int  zh_free(zh_ctx *ctx, void *dev_ptr);
+ZH_API int  zh_upload(zh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);    /* synchronous */
+ZH_API int  zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  /* synchronous */
+
+ZH_API int  zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames);
+ZH_API int  zh_buf_free(zh_ctx *ctx, zh_buf *buf);
+/* host image [voice][frame] (one contiguous reference-style []f32 per voice) <-> device [frame][voice] */
+ZH_API int  zh_buf_upload_voices(zh_ctx *ctx, zh_buf dst, const float *host_voice_major, uint32_t frames);
+ZH_API int  zh_buf_download_voices(zh_ctx *ctx, float *host_voice_major, zh_buf src, uint32_t frames);
+/* one voice's []f32 */
+ZH_API int  zh_buf_upload_voice(zh_ctx *ctx, zh_buf dst, uint32_t voice, const float *host, uint32_t frames);
+ZH_API int  zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, uint32_t frames);
+
+/* timing helpers: HIP events on the context's stream (used by bench.py) */
+typedef struct zh_event zh_event;
+ZH_API int  zh_event_create(zh_ctx *ctx, zh_event **out);
+ZH_API int  zh_event_destroy(zh_event *ev);
+ZH_API int  zh_event_record(zh_ctx *ctx, zh_event *ev);
+ZH_API int  zh_event_elapsed_ms(zh_event *start, zh_event *stop, float *ms);  /* synchronises on `stop` */
+
+/* ---------------------------------------------------------------- basics.zig (src/zang/basics.zig:12-78)
+ * Each op acts on frames [span_start, span_end) of every voice of `dest`. */
+ZH_API int zh_zero(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest);                          /* :12 */
+ZH_API int zh_set(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_f32 a);                 /* :16 */
+ZH_API int zh_copy(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf src);              /* :20 */
+ZH_API int zh_add(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf a, zh_buf b);       /* :24 dest += a+b */
+ZH_API int zh_add_into(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf src);          /* :31 */
+ZH_API int zh_add_scalar(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf a, zh_f32 b);/* :38 dest += a+b */
+ZH_API int zh_add_scalar_into(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_f32 a);     /* :45 */
+ZH_API int zh_multiply(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf a, zh_buf b);  /* :52 dest += a*b */
+ZH_API int zh_multiply_with(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf a);       /* :59 */
+ZH_API int zh_multiply_scalar(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_buf a, zh_f32 b); /* :66 dest += a*b */
+ZH_API int zh_multiply_with_scalar(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, zh_buf dest, zh_f32 a);      /* :73 */
+
+/* Voice mixdown: dst[f] += sum over voices of src[f][v], f in the span -- what V successive
+ * zang.addInto calls onto one mix buffer do (basics.zig:31-36; example_song.zig:382-396),
+ * summed in a FIXED tree order (wave shuffle -> LDS -> block partials -> second pass) so
+ * results are reproducible run to run.  `dst` is a device float[frames]. */
+ZH_API int zh_mixdown_voices(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, float *dst, zh_buf src, uint32_t flags);
+
+/* ---------------------------------------------------------------- SineOsc (src/modules/SineOsc.zig) */
+typedef struct zh_sineosc zh_sineosc;
+typedef struct zh_sineosc_params { float sample_rate; uint32_t reserved; zh_cob freq; zh_cob phase; } zh_sineosc_params; /* :10-14 */
+typedef struct zh_sineosc_state { float t; } zh_sineosc_state;                                        /* :16 */
+ZH_API int zh_sineosc_create(zh_ctx *ctx, uint32_t n_voices, zh_sineosc **out);                       /* n x init() :18-22 */
+ZH_API int zh_sineosc_destroy(zh_sineosc *m);
+ZH_API int zh_sineosc_get_state(zh_sineosc *m, zh_sineosc_state *host);
+ZH_API int zh_sineosc_set_state(zh_sineosc *m, const zh_sineosc_state *host);
+ZH_API int zh_sineosc_paint(zh_sineosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs /*[1]*/,
+                            const zh_buf *temps /*[0]*/, zh_bool note_id_changed,
+                            const zh_sineosc_params *params, uint32_t flags);                         /* :24-87 */
+
+/* ---------------------------------------------------------------- PulseOsc (src/modules/PulseOsc.zig) */
+typedef struct zh_pulseosc zh_pulseosc;
+typedef struct zh_pulseosc_params { float sample_rate; uint32_t reserved; zh_cob freq; zh_f32 color; } zh_pulseosc_params; /* :30-34 */
+typedef struct zh_pulseosc_state { uint32_t cnt; } zh_pulseosc_state;                                 /* :36 */
+ZH_API int zh_pulseosc_create(zh_ctx *ctx, uint32_t n_voices, zh_pulseosc **out);
+ZH_API int zh_pulseosc_destroy(zh_pulseosc *m);
+ZH_API int zh_pulseosc_get_state(zh_pulseosc *m, zh_pulseosc_state *host);
+ZH_API int zh_pulseosc_set_state(zh_pulseosc *m, const zh_pulseosc_state *host);
+ZH_API int zh_pulseosc_paint(zh_pulseosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                             const zh_buf *temps, zh_bool note_id_changed,
+                             const zh_pulseosc_params *params, uint32_t flags);                       /* :44-157 */
+
+/* ---------------------------------------------------------------- TriSawOsc (src/modules/TriSawOsc.zig) */
+typedef struct zh_trisawosc zh_trisawosc;
+typedef struct zh_trisawosc_params { float sample_rate; uint32_t reserved; zh_cob freq; zh_f32 color; } zh_trisawosc_params; /* :30-34 */
+typedef struct zh_trisawosc_state { uint32_t cnt; float t; } zh_trisawosc_state;                      /* :36-37 */
+ZH_API int zh_trisawosc_create(zh_ctx *ctx, uint32_t n_voices, zh_trisawosc **out);
+ZH_API int zh_trisawosc_destroy(zh_trisawosc *m);
+ZH_API int zh_trisawosc_get_state(zh_trisawosc *m, zh_trisawosc_state *host);
+ZH_API int zh_trisawosc_set_state(zh_trisawosc *m, const zh_trisawosc_state *host);
+ZH_API int zh_trisawosc_paint(zh_trisawosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                              const zh_buf *temps, zh_bool note_id_changed,
+                              const zh_trisawosc_params *params, uint32_t flags);                     /* :46-156 */
+
+/* ---------------------------------------------------------------- Noise (src/modules/Noise.zig) */
+typedef struct zh_noise zh_noise;
+enum { ZH_NOISE_WHITE = 0, ZH_NOISE_PINK = 1 };                                                       /* :11-14 */
+typedef struct zh_noise_params { uint32_t color; } zh_noise_params;                                   /* :18-20 */
+typedef struct zh_noise_state { uint64_t r[4]; float b[7]; uint32_t reserved; } zh_noise_state;       /* :22-23 */
+/* Voice v is seeded like the (first_seed + v)-th Noise.init() of a process (:9,:26): pass the
+ * voice's GLOBAL index so that sharded and unsharded renders agree. */
+ZH_API int zh_noise_create(zh_ctx *ctx, uint32_t n_voices, uint64_t first_seed, zh_noise **out);
+ZH_API int zh_noise_destroy(zh_noise *m);
+ZH_API int zh_noise_get_state(zh_noise *m, zh_noise_state *host);
+ZH_API int zh_noise_set_state(zh_noise *m, const zh_noise_state *host);
+ZH_API int zh_noise_paint(zh_noise *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                          const zh_buf *temps, zh_bool note_id_changed,
+                          const zh_noise_params *params, uint32_t flags);                             /* :34-72 */
+
+/* ---------------------------------------------------------------- Envelope (src/modules/Envelope.zig, src/zang/painter.zig) */
+typedef struct zh_envelope zh_envelope;
+enum { ZH_ENV_IDLE = 0, ZH_ENV_ATTACK, ZH_ENV_DECAY, ZH_ENV_SUSTAIN, ZH_ENV_RELEASE };                /* :15-21 */
+typedef struct zh_envelope_params {                                                                   /* :6-13 */
+    float sample_rate; uint32_t reserved;
+    zh_curve attack, decay, release;
+    zh_f32 sustain_volume;
+    zh_bool note_on;
+} zh_envelope_params;
+typedef struct zh_envelope_state { uint32_t state; float t, last_value, start; } zh_envelope_state;   /* :23-24, painter.zig:33-36 */
+ZH_API int zh_envelope_create(zh_ctx *ctx, uint32_t n_voices, zh_envelope **out);
+ZH_API int zh_envelope_destroy(zh_envelope *m);
+ZH_API int zh_envelope_get_state(zh_envelope *m, zh_envelope_state *host);
+ZH_API int zh_envelope_set_state(zh_envelope *m, const zh_envelope_state *host);
+ZH_API int zh_envelope_paint(zh_envelope *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                             const zh_buf *temps, zh_bool note_id_changed,
+                             const zh_envelope_params *params, uint32_t flags);                       /* :92-109 */
+
+/* ---------------------------------------------------------------- Gate (src/modules/Gate.zig) -- stateless */
+typedef struct zh_gate zh_gate;
+typedef struct zh_gate_params { zh_bool note_on; } zh_gate_params;                                    /* :7-9 */
+ZH_API int zh_gate_create(zh_ctx *ctx, uint32_t n_voices, zh_gate **out);
+ZH_API int zh_gate_destroy(zh_gate *m);
+ZH_API int zh_gate_paint(zh_gate *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                         const zh_buf *temps, zh_bool note_id_changed,
+                         const zh_gate_params *params, uint32_t flags);                               /* :15-30 */
+
+/* ---------------------------------------------------------------- Filter (src/modules/Filter.zig) */
+typedef struct zh_filter zh_filter;
+enum { ZH_FILTER_BYPASS = 0, ZH_FILTER_LOW_PASS, ZH_FILTER_BAND_PASS, ZH_FILTER_HIGH_PASS,
+       ZH_FILTER_NOTCH, ZH_FILTER_ALL_PASS };                                                         /* :10-17 */
+typedef struct zh_filter_params { zh_buf input; uint32_t type; uint32_t reserved; zh_cob cutoff; zh_cob res; } zh_filter_params; /* :27-32 */
+typedef struct zh_filter_state { float l, b; } zh_filter_state;                                       /* :34-35 */
+ZH_API int zh_filter_create(zh_ctx *ctx, uint32_t n_voices, zh_filter **out);
+ZH_API int zh_filter_destroy(zh_filter *m);
+ZH_API int zh_filter_get_state(zh_filter *m, zh_filter_state *host);
+ZH_API int zh_filter_set_state(zh_filter *m, const zh_filter_state *host);
+ZH_API int zh_filter_paint(zh_filter *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                           const zh_buf *temps, zh_bool note_id_changed,
+                           const zh_filter_params *params, uint32_t flags);                           /* :44-151 */
+/* Filter.cutoffFromFrequency (:20-23) for n values, on the device (host scalar in the reference). */
+ZH_API int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out_dev,
+                                           const float *frequency_dev, float sample_rate);
+
+/* ---------------------------------------------------------------- Sampler (src/modules/Sampler.zig) */
+typedef struct zh_sampler zh_sampler;
+enum { ZH_SAMPLE_U8 = 0, ZH_SAMPLE_S16_LSB, ZH_SAMPLE_S24_LSB, ZH_SAMPLE_S32_LSB };                   /* :9-14 */
+typedef struct zh_sample {                                                                            /* :16-21 */
+    uint64_t num_channels; uint64_t sample_rate; uint32_t format; uint32_t reserved;
+    const uint8_t *data;   /* DEVICE pointer to the PCM bytes, shared read-only by all voices */
+    uint64_t data_len;     /* bytes */
+} zh_sample;
+typedef struct zh_sampler_params {                                                                    /* :62-67 */
+    zh_f32 sample_rate;    /* per-voice: example_sampler.zig varies it per note to change pitch */
+    zh_sample sample; uint64_t channel; uint32_t loop; uint32_t reserved;
+} zh_sampler_params;
+typedef struct zh_sampler_state { float t; } zh_sampler_state;                                        /* :69 */
+ZH_API int zh_sampler_create(zh_ctx *ctx, uint32_t n_voices, zh_sampler **out);
+ZH_API int zh_sampler_destroy(zh_sampler *m);
+ZH_API int zh_sampler_get_state(zh_sampler *m, zh_sampler_state *host);
+ZH_API int zh_sampler_set_state(zh_sampler *m, const zh_sampler_state *host);
+ZH_API int zh_sampler_paint(zh_sampler *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                            const zh_buf *temps, zh_bool note_id_changed,
+                            const zh_sampler_params *params, uint32_t flags);                         /* :77-136 */
+
+/* ---------------------------------------------------------------- Decimator (src/modules/Decimator.zig) */
+typedef struct zh_decimator zh_decimator;
+typedef struct zh_decimator_params { float sample_rate; uint32_t reserved; zh_buf input; zh_f32 fake_sample_rate; } zh_decimator_params; /* :5-9 */
+typedef struct zh_decimator_state { float dval, dcount; } zh_decimator_state;                         /* :11-12 */
+ZH_API int zh_decimator_create(zh_ctx *ctx, uint32_t n_voices, zh_decimator **out);
+ZH_API int zh_decimator_destroy(zh_decimator *m);
+ZH_API int zh_decimator_get_state(zh_decimator *m, zh_decimator_state *host);
+ZH_API int zh_decimator_set_state(zh_decimator *m, const zh_decimator_state *host);
+ZH_API int zh_decimator_paint(zh_decimator *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                              const zh_buf *temps, zh_bool note_id_changed,
+                              const zh_decimator_params *params, uint32_t flags);                     /* :21-57 */
+
+/* ---------------------------------------------------------------- Distortion (src/modules/Distortion.zig) -- stateless */
+typedef struct zh_distortion zh_distortion;
+enum { ZH_DISTORTION_OVERDRIVE = 0, ZH_DISTORTION_CLIP = 1 };                                         /* :8-11 */
+typedef struct zh_distortion_params { zh_buf input; uint32_t type; uint32_t reserved; zh_f32 ingain, outgain, offset; } zh_distortion_params; /* :15-21 */
+ZH_API int zh_distortion_create(zh_ctx *ctx, uint32_t n_voices, zh_distortion **out);
+ZH_API int zh_distortion_destroy(zh_distortion *m);
+ZH_API int zh_distortion_paint(zh_distortion *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                               const zh_buf *temps, zh_bool note_id_changed,
+                               const zh_distortion_params *params, uint32_t flags);                   /* :27-66 */
+
+/* ---------------------------------------------------------------- NiceInstrument (examples/modules.zig:189-248)
+ * PulseOsc -> x0.5 -> Filter(low_pass, cutoffFromFrequency(8*freq), res 0.7) -> Envelope(cubed
+ * .01/.1/.5, sustain .8) -> out += env*flt, as ONE kernel: the two temps never touch HBM. */
+typedef struct zh_nice zh_nice;
+typedef struct zh_nice_params { float sample_rate; uint32_t reserved; zh_f32 freq; zh_bool note_on; } zh_nice_params; /* :192-196 */
+typedef struct zh_nice_state { zh_pulseosc_state osc; zh_filter_state flt; zh_envelope_state env; } zh_nice_state;    /* :198-201 */
+ZH_API int zh_nice_create(zh_ctx *ctx, uint32_t n_voices, zh_f32 color, zh_nice **out);               /* init(color) :203-210 */
+ZH_API int zh_nice_destroy(zh_nice *m);
+ZH_API int zh_nice_get_state(zh_nice *m, zh_nice_state *host);
+ZH_API int zh_nice_set_state(zh_nice *m, const zh_nice_state *host);
+ZH_API int zh_nice_paint(zh_nice *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                         const zh_buf *temps /*[2], unused by the fused kernel; may be NULL*/,
+                         zh_bool note_id_changed, const zh_nice_params *params, uint32_t flags);      /* :212-247 */
+/* The same chain, then the voice mixdown, without materialising per-voice output:
+ * partial[f] (+)= sum_v voice_v[f].  `mix` is a device float[frames]. */
+ZH_API int zh_nice_paint_mix(zh_nice *m, uint32_t span_start, uint32_t span_end, float *mix,
+                             zh_bool note_id_changed, const zh_nice_params *params, uint32_t flags);
+
+/* ---------------------------------------------------------------- PMOscInstrument (examples/modules.zig:6-128) */
+typedef struct zh_pmosc zh_pmosc;
+typedef struct zh_pmosc_params { float sample_rate; uint32_t reserved; zh_f32 freq; zh_bool note_on; } zh_pmosc_params; /* :83-87 */
+typedef struct zh_pmosc_state { zh_sineosc_state carrier, modulator; zh_envelope_state env; } zh_pmosc_state;          /* :24-25, :89-91 */
+ZH_API int zh_pmosc_create(zh_ctx *ctx, uint32_t n_voices, zh_f32 release_duration, zh_pmosc **out);  /* init(release_duration) :93-99 */
+ZH_API int zh_pmosc_destroy(zh_pmosc *m);
+ZH_API int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host);
+ZH_API int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host);
+ZH_API int zh_pmosc_paint(zh_pmosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                          const zh_buf *temps /*[3], unused; may be NULL*/,
+                          zh_bool note_id_changed, const zh_pmosc_params *params, uint32_t flags);    /* :101-127 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZANG_HIP_H */

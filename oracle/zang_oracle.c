@@ -650,3 +650,24 @@ void zo_xoshiro_seq(uint64_t seed, uint64_t *state_out4, uint64_t *out, size_t n
     memcpy(state_out4, r.s, 32);
     for (size_t i = 0; i < n; i++) out[i] = zr_xoshiro_next(&r);
 }
+
+/* ------------------------------------------------------------------ cpu_baseline drivers
+ * bench.py times these on the host cores ("port" baseline: the reference binary cannot be
+ * built here).  They run the reference's per-buffer sequence for `voices` independent module
+ * instances, one voice after another on one thread -- the reference's execution model
+ * (one audio thread, examples/example.zig:35).  `scratch` is one voice's []f32 of `frames`
+ * floats, reused like the reference reuses its temp buffers; the returned value folds
+ * every sample so the work cannot be optimised away. */
+double zo_bench_pulseosc(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate,
+                         const float *freq, const float *color, zo_pulseosc *states, float *scratch) {
+    double fold = 0.0;
+    for (uint32_t b = 0; b < buffers; b++) {
+        for (uint32_t v = 0; v < voices; v++) {
+            zo_cob f = { ZO_COB_CONSTANT, freq[v], NULL };
+            zo_zero(0, frames, scratch);                                    /* examples/modules.zig:220 */
+            zo_pulseosc_paint(&states[v], 0, frames, scratch, sample_rate, f, color[v]);
+            fold += scratch[(b + v) % frames];
+        }
+    }
+    return fold;
+}

@@ -85,4 +85,6 @@ void zo_pmosc_paint(zo_pmosc_instrument *self, size_t start, size_t end, float *
                     float *temp2, int note_id_changed, float sample_rate, float freq, int note_on);
 void zo_mixdown_s16lsb(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
 void zo_mixdown_s8(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
+double zo_bench_pulseosc(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate,
+                         const float *freq, const float *color, zo_pulseosc *states, float *scratch);
 #endif

@@ -1,0 +1,113 @@
+"""GPU parity: PulseOsc / TriSawOsc kernels vs the oracle, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def _oracle_osc(po, kind, V, F, spans, freq, color, freq_buf=None, out0=None, state0=None):
+    L = po.lib()
+    out = np.zeros((V, F), np.float32) if out0 is None else out0.copy()
+    states = []
+    for v in range(V):
+        st = po.PulseOsc() if kind == "pulse" else po.TriSawOsc()
+        (L.zo_pulseosc_init if kind == "pulse" else L.zo_trisawosc_init)(C.byref(st))
+        if state0 is not None:
+            st.cnt = int(state0[v][0])
+            if kind != "pulse":
+                st.t = float(state0[v][1])
+        for (s, e) in spans:
+            f = po.constant(freq[v]) if freq_buf is None else po.buffer(freq_buf[v])
+            fn = L.zo_pulseosc_paint if kind == "pulse" else L.zo_trisawosc_paint
+            fn(C.byref(st), s, e, po.fptr(out[v]), SR, f, float(color[v]))
+        states.append((st.cnt,) if kind == "pulse" else (st.cnt, st.t))
+    return out, states
+
+
+def _gpu_osc(ctx, kind, V, F, spans, freq, color, freq_buf=None, out0=None, zero_first=False):
+    import torch
+    from zang_amd import modules as mod, zang
+    m = (mod.PulseOsc if kind == "pulse" else mod.TriSawOsc)(V, ctx)
+    out = util.to_image(np.zeros((V, F), np.float32) if out0 is None else out0)
+    fb = util.to_image(freq_buf) if freq_buf is not None else None
+    fr = util.dev(freq) if freq_buf is None else None
+    col = util.dev(color)
+    P = m.Params
+    for (s, e) in spans:
+        f = zang.constant(fr) if fb is None else zang.buffer(fb)
+        m.paint(zang.Span(s, e), [out], [], False, P(SR, f, col), zero_first=zero_first)
+    ctx.sync()
+    return util.from_image(out), m.state()
+
+
+@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+@pytest.mark.parametrize("spans", [util.SPANS_ONE, util.SPANS_THREE])
+def test_const_freq_bitexact(ctx, oracle, kind, spans):
+    from zang_amd import workloads
+    V, F = 640, 1024
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    # edge voices: silent (freq > sr/8), negative, color 0 / 1 / out of range, tiny freq
+    freq[:8] = [6000.0, 6000.5, -1.0, 0.0, 440.0, 440.0, 440.0, 0.001]
+    color[:8] = [0.5, 0.5, 0.5, 0.5, 0.0, 1.0, 1.7, 0.3]
+    out0 = util.rng_buffers(5, V, F)
+    ref, rst = _oracle_osc(oracle, kind, V, F, spans, freq, color, out0=out0)
+    got, gst = _gpu_osc(ctx, kind, V, F, spans, freq, color, out0=out0)
+    util.assert_bitexact(got, ref, f"{kind} const freq")
+    assert [int(x) for x in gst["cnt"]] == [s[0] for s in rst]
+
+
+@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+def test_const_freq_zero_first(ctx, oracle, kind):
+    from zang_amd import workloads
+    V, F = 256, 1024
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    freq[3] = 7000.0   # silent voice: ZERO_FIRST must still leave zeros
+    ref, _ = _oracle_osc(oracle, kind, V, F, util.SPANS_ONE, freq, color)
+    garbage = util.rng_buffers(6, V, F)
+    got, _ = _gpu_osc(ctx, kind, V, F, util.SPANS_ONE, freq, color, out0=garbage, zero_first=True)
+    util.assert_bitexact(got, ref, f"{kind} zero_first")
+
+
+@pytest.mark.parametrize("kind,colors", [("pulse", [0.0, 0.3, 0.5, 1.0]), ("trisaw", [0.1, 0.5, 0.9, 0.25])])
+@pytest.mark.parametrize("spans", [util.SPANS_ONE, util.SPANS_THREE])
+def test_controlled_freq(ctx, oracle, kind, colors, spans):
+    V, F = 192, 1024
+    rng = np.random.default_rng(11)
+    freq_buf = rng.uniform(-200.0, 7000.0, (V, F)).astype(np.float32)   # includes out-of-range samples
+    color = np.resize(np.array(colors, np.float32), V)
+    out0 = util.rng_buffers(7, V, F)
+    ref, rst = _oracle_osc(oracle, kind, V, F, spans, None, color, freq_buf=freq_buf, out0=out0)
+    got, gst = _gpu_osc(ctx, kind, V, F, spans, None, color, freq_buf=freq_buf, out0=out0)
+    util.assert_bitexact(got, ref, f"{kind} controlled freq")
+    if kind == "pulse":
+        assert [int(x) for x in gst["cnt"]] == [s[0] for s in rst]
+    else:
+        util.assert_bitexact(gst["t"].astype(np.float32), np.array([s[1] for s in rst], np.float32), "t")
+
+
+def test_pulseosc_config2_full(ctx, oracle):
+    """BASELINE config 2: 4096 PulseOsc voices x 1024 frames, two consecutive buffers."""
+    from zang_amd import workloads
+    V, F = 4096, 1024
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    import torch
+    from zang_amd import modules as mod, zang
+    m = mod.PulseOsc(V, ctx)
+    fr, col = util.dev(freq), util.dev(color)
+    outs = [ctx.image(F, V) for _ in range(2)]
+    for o in outs:
+        m.paint(zang.Span(0, F), [o], [], False, m.Params(SR, zang.constant(fr), col), zero_first=True)
+    ctx.sync()
+    L = oracle.lib()
+    ref = np.zeros((2, V, F), np.float32)
+    for v in range(V):
+        st = oracle.PulseOsc(); L.zo_pulseosc_init(C.byref(st))
+        for b in range(2):
+            L.zo_pulseosc_paint(C.byref(st), 0, F, oracle.fptr(ref[b, v]), SR, oracle.constant(freq[v]), float(color[v]))
+    for b in range(2):
+        util.assert_bitexact(util.from_image(outs[b]), ref[b], f"config2 buffer {b}")

@@ -1,0 +1,53 @@
+"""Helpers shared by the parity tests: layout conversion, oracle drivers, tolerances."""
+import ctypes as C
+
+import numpy as np
+
+RTOL = 1e-5          # BASELINE.json north_star: 1e-5 relative f32
+FLOOR = 1e-3         # pure-relative blows up at zero crossings
+
+
+def to_image(voice_major):
+    """numpy [voices][frames] (reference layout: one []f32 per voice) -> CUDA [frames][voices]."""
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(voice_major.T)).cuda()
+
+
+def from_image(img):
+    """CUDA [frames][voices] -> numpy [voices][frames]."""
+    return np.ascontiguousarray(img.detach().cpu().numpy().T)
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def assert_bitexact(gpu, ref, what=""):
+    gpu = np.asarray(gpu); ref = np.asarray(ref)
+    assert gpu.shape == ref.shape, (what, gpu.shape, ref.shape)
+    a = gpu.view(np.uint32) if gpu.dtype == np.float32 else gpu
+    b = ref.view(np.uint32) if ref.dtype == np.float32 else ref
+    bad = np.argwhere(a != b)
+    assert bad.size == 0, f"{what}: {len(bad)} mismatching elements, first at {bad[0]}: gpu={gpu[tuple(bad[0])]!r} ref={ref[tuple(bad[0])]!r}"
+
+
+def assert_close(gpu, ref, what="", rtol=RTOL, floor=FLOOR):
+    gpu = np.asarray(gpu, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    assert gpu.shape == ref.shape, (what, gpu.shape, ref.shape)
+    tol = rtol * np.maximum(np.abs(ref), floor)
+    err = np.abs(gpu - ref)
+    bad = np.argwhere(~(err <= tol))
+    assert bad.size == 0, f"{what}: {len(bad)} out of tolerance, first at {bad[0]}: gpu={gpu[tuple(bad[0])]!r} ref={ref[tuple(bad[0])]!r}"
+
+
+def bitexact_fraction(gpu, ref):
+    return float(np.mean(np.asarray(gpu).view(np.uint32) == np.asarray(ref).view(np.uint32)))
+
+
+def rng_buffers(seed, voices, frames, lo=-1.0, hi=1.0):
+    return np.random.default_rng(seed).uniform(lo, hi, (voices, frames)).astype(np.float32)
+
+
+SPANS_ONE = [(0, 1024)]
+SPANS_THREE = [(0, 200), (200, 777), (777, 1024)]

@@ -1,0 +1,272 @@
+"""ctypes mirror of include/zang_hip.h (the C ABI of libzang_hip.so).
+
+Loading fails loudly when the library is missing: the product has no CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzang_hip.so")
+
+u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
+
+ZH_OK = 0
+PAINT_ADD, PAINT_ZERO_FIRST = 0, 1
+COB_CONSTANT, COB_BUFFER = 0, 1
+CURVE_INSTANTANEOUS, CURVE_LINEAR, CURVE_SQUARED, CURVE_CUBED = 0, 1, 2, 3
+NOISE_WHITE, NOISE_PINK = 0, 1
+ENV_IDLE, ENV_ATTACK, ENV_DECAY, ENV_SUSTAIN, ENV_RELEASE = range(5)
+FILTER_BYPASS, FILTER_LOW_PASS, FILTER_BAND_PASS, FILTER_HIGH_PASS, FILTER_NOTCH, FILTER_ALL_PASS = range(6)
+SAMPLE_U8, SAMPLE_S16_LSB, SAMPLE_S24_LSB, SAMPLE_S32_LSB = range(4)
+DISTORTION_OVERDRIVE, DISTORTION_CLIP = 0, 1
+
+
+class Buf(C.Structure):
+    _fields_ = [("ptr", vp), ("voices", u32), ("frames", u32), ("stride", u32), ("reserved", u32)]
+
+
+class F32(C.Structure):
+    _fields_ = [("value", f32), ("reserved", u32), ("per_voice", vp)]
+
+
+class Bool(C.Structure):
+    _fields_ = [("value", u32), ("reserved", u32), ("per_voice", vp)]
+
+
+class Cob(C.Structure):
+    _fields_ = [("tag", u32), ("reserved", u32), ("constant", F32), ("buffer", Buf)]
+
+
+class Curve(C.Structure):
+    _fields_ = [("tag", u32), ("reserved", u32), ("duration", F32)]
+
+
+class SineOscParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("freq", Cob), ("phase", Cob)]
+
+
+class SineOscState(C.Structure):
+    _fields_ = [("t", f32)]
+
+
+class PulseOscParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("freq", Cob), ("color", F32)]
+
+
+class PulseOscState(C.Structure):
+    _fields_ = [("cnt", u32)]
+
+
+TriSawOscParams = PulseOscParams
+
+
+class TriSawOscState(C.Structure):
+    _fields_ = [("cnt", u32), ("t", f32)]
+
+
+class NoiseParams(C.Structure):
+    _fields_ = [("color", u32)]
+
+
+class NoiseState(C.Structure):
+    _fields_ = [("r", u64 * 4), ("b", f32 * 7), ("reserved", u32)]
+
+
+class EnvelopeParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("attack", Curve), ("decay", Curve), ("release", Curve),
+                ("sustain_volume", F32), ("note_on", Bool)]
+
+
+class EnvelopeState(C.Structure):
+    _fields_ = [("state", u32), ("t", f32), ("last_value", f32), ("start", f32)]
+
+
+class GateParams(C.Structure):
+    _fields_ = [("note_on", Bool)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("input", Buf), ("type", u32), ("reserved", u32), ("cutoff", Cob), ("res", Cob)]
+
+
+class FilterState(C.Structure):
+    _fields_ = [("l", f32), ("b", f32)]
+
+
+class Sample(C.Structure):
+    _fields_ = [("num_channels", u64), ("sample_rate", u64), ("format", u32), ("reserved", u32),
+                ("data", vp), ("data_len", u64)]
+
+
+class SamplerParams(C.Structure):
+    _fields_ = [("sample_rate", F32), ("sample", Sample), ("channel", u64), ("loop", u32), ("reserved", u32)]
+
+
+class SamplerState(C.Structure):
+    _fields_ = [("t", f32)]
+
+
+class DecimatorParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("input", Buf), ("fake_sample_rate", F32)]
+
+
+class DecimatorState(C.Structure):
+    _fields_ = [("dval", f32), ("dcount", f32)]
+
+
+class DistortionParams(C.Structure):
+    _fields_ = [("input", Buf), ("type", u32), ("reserved", u32), ("ingain", F32), ("outgain", F32), ("offset", F32)]
+
+
+class NiceParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("freq", F32), ("note_on", Bool)]
+
+
+class NiceState(C.Structure):
+    _fields_ = [("osc", PulseOscState), ("flt", FilterState), ("env", EnvelopeState)]
+
+
+PMOscParams = NiceParams
+
+
+class PMOscState(C.Structure):
+    _fields_ = [("carrier", SineOscState), ("modulator", SineOscState), ("env", EnvelopeState)]
+
+
+P = C.POINTER
+_paint = lambda params: [vp, u32, u32, P(Buf), P(Buf), Bool, P(params), u32]
+
+# name -> (restype, argtypes); must list every ZH_API symbol of include/zang_hip.h
+SIGNATURES = {
+    "zh_create": (C.c_int, [P(vp), C.c_int]),
+    "zh_destroy": (C.c_int, [vp]),
+    "zh_set_stream": (C.c_int, [vp, vp]),
+    "zh_get_stream": (vp, [vp]),
+    "zh_sync": (C.c_int, [vp]),
+    "zh_error_string": (C.c_char_p, [C.c_int]),
+    "zh_version": (C.c_char_p, []),
+    "zh_malloc": (C.c_int, [vp, P(vp), C.c_size_t]),
+    "zh_free": (C.c_int, [vp, vp]),
+    "zh_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "zh_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "zh_buf_alloc": (C.c_int, [vp, P(Buf), u32, u32]),
+    "zh_buf_free": (C.c_int, [vp, P(Buf)]),
+    "zh_buf_upload_voices": (C.c_int, [vp, Buf, vp, u32]),
+    "zh_buf_download_voices": (C.c_int, [vp, vp, Buf, u32]),
+    "zh_buf_upload_voice": (C.c_int, [vp, Buf, u32, vp, u32]),
+    "zh_buf_download_voice": (C.c_int, [vp, vp, Buf, u32, u32]),
+    "zh_event_create": (C.c_int, [vp, P(vp)]),
+    "zh_event_destroy": (C.c_int, [vp]),
+    "zh_event_record": (C.c_int, [vp, vp]),
+    "zh_event_elapsed_ms": (C.c_int, [vp, vp, P(f32)]),
+    "zh_zero": (C.c_int, [vp, u32, u32, Buf]),
+    "zh_set": (C.c_int, [vp, u32, u32, Buf, F32]),
+    "zh_copy": (C.c_int, [vp, u32, u32, Buf, Buf]),
+    "zh_add": (C.c_int, [vp, u32, u32, Buf, Buf, Buf]),
+    "zh_add_into": (C.c_int, [vp, u32, u32, Buf, Buf]),
+    "zh_add_scalar": (C.c_int, [vp, u32, u32, Buf, Buf, F32]),
+    "zh_add_scalar_into": (C.c_int, [vp, u32, u32, Buf, F32]),
+    "zh_multiply": (C.c_int, [vp, u32, u32, Buf, Buf, Buf]),
+    "zh_multiply_with": (C.c_int, [vp, u32, u32, Buf, Buf]),
+    "zh_multiply_scalar": (C.c_int, [vp, u32, u32, Buf, Buf, F32]),
+    "zh_multiply_with_scalar": (C.c_int, [vp, u32, u32, Buf, F32]),
+    "zh_mixdown_voices": (C.c_int, [vp, u32, u32, vp, Buf, u32]),
+    "zh_sineosc_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_sineosc_destroy": (C.c_int, [vp]),
+    "zh_sineosc_get_state": (C.c_int, [vp, vp]),
+    "zh_sineosc_set_state": (C.c_int, [vp, vp]),
+    "zh_sineosc_paint": (C.c_int, _paint(SineOscParams)),
+    "zh_pulseosc_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_pulseosc_destroy": (C.c_int, [vp]),
+    "zh_pulseosc_get_state": (C.c_int, [vp, vp]),
+    "zh_pulseosc_set_state": (C.c_int, [vp, vp]),
+    "zh_pulseosc_paint": (C.c_int, _paint(PulseOscParams)),
+    "zh_trisawosc_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_trisawosc_destroy": (C.c_int, [vp]),
+    "zh_trisawosc_get_state": (C.c_int, [vp, vp]),
+    "zh_trisawosc_set_state": (C.c_int, [vp, vp]),
+    "zh_trisawosc_paint": (C.c_int, _paint(TriSawOscParams)),
+    "zh_noise_create": (C.c_int, [vp, u32, u64, P(vp)]),
+    "zh_noise_destroy": (C.c_int, [vp]),
+    "zh_noise_get_state": (C.c_int, [vp, vp]),
+    "zh_noise_set_state": (C.c_int, [vp, vp]),
+    "zh_noise_paint": (C.c_int, _paint(NoiseParams)),
+    "zh_envelope_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_envelope_destroy": (C.c_int, [vp]),
+    "zh_envelope_get_state": (C.c_int, [vp, vp]),
+    "zh_envelope_set_state": (C.c_int, [vp, vp]),
+    "zh_envelope_paint": (C.c_int, _paint(EnvelopeParams)),
+    "zh_gate_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_gate_destroy": (C.c_int, [vp]),
+    "zh_gate_paint": (C.c_int, _paint(GateParams)),
+    "zh_filter_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_filter_destroy": (C.c_int, [vp]),
+    "zh_filter_get_state": (C.c_int, [vp, vp]),
+    "zh_filter_set_state": (C.c_int, [vp, vp]),
+    "zh_filter_paint": (C.c_int, _paint(FilterParams)),
+    "zh_filter_cutoff_from_frequency": (C.c_int, [vp, u32, vp, vp, f32]),
+    "zh_sampler_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_sampler_destroy": (C.c_int, [vp]),
+    "zh_sampler_get_state": (C.c_int, [vp, vp]),
+    "zh_sampler_set_state": (C.c_int, [vp, vp]),
+    "zh_sampler_paint": (C.c_int, _paint(SamplerParams)),
+    "zh_decimator_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_decimator_destroy": (C.c_int, [vp]),
+    "zh_decimator_get_state": (C.c_int, [vp, vp]),
+    "zh_decimator_set_state": (C.c_int, [vp, vp]),
+    "zh_decimator_paint": (C.c_int, _paint(DecimatorParams)),
+    "zh_distortion_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_distortion_destroy": (C.c_int, [vp]),
+    "zh_distortion_paint": (C.c_int, _paint(DistortionParams)),
+    "zh_nice_create": (C.c_int, [vp, u32, F32, P(vp)]),
+    "zh_nice_destroy": (C.c_int, [vp]),
+    "zh_nice_get_state": (C.c_int, [vp, vp]),
+    "zh_nice_set_state": (C.c_int, [vp, vp]),
+    "zh_nice_paint": (C.c_int, _paint(NiceParams)),
+    "zh_nice_paint_mix": (C.c_int, [vp, u32, u32, vp, Bool, P(NiceParams), u32]),
+    "zh_pmosc_create": (C.c_int, [vp, u32, F32, P(vp)]),
+    "zh_pmosc_destroy": (C.c_int, [vp]),
+    "zh_pmosc_get_state": (C.c_int, [vp, vp]),
+    "zh_pmosc_set_state": (C.c_int, [vp, vp]),
+    "zh_pmosc_paint": (C.c_int, _paint(PMOscParams)),
+}
+
+_lib = None
+
+
+class ZangHipError(RuntimeError):
+    pass
+
+
+def load(strict=True):
+    """Load libzang_hip.so and bind every declared entry point.
+
+    strict=True raises if any symbol of SIGNATURES is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZangHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). zang_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing and strict:
+        raise ZangHipError(f"libzang_hip.so lacks symbols: {missing}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        lib = load(strict=False)
+        msg = lib.zh_error_string(rc).decode()
+        raise ZangHipError(f"{what} failed: {rc} ({msg})")

@@ -1,0 +1,237 @@
+// basics.hip -- zang's buffer primitives (src/zang/basics.zig:12-78) over [frame][voice]
+// images, plus the voice mixdown.  Pure HBM streaming: 16 B per lane where the images
+// allow it (4 consecutive voices of one frame), scalar lanes otherwise.
+#include "common.cuh"
+
+enum EwOp { OP_ZERO, OP_SET, OP_COPY, OP_ADD, OP_ADD_INTO, OP_ADD_SCALAR, OP_ADD_SCALAR_INTO,
+            OP_MUL, OP_MUL_WITH, OP_MUL_SCALAR, OP_MUL_WITH_SCALAR };
+
+template <int OP> struct OpTraits {
+    static constexpr bool reads_dst = !(OP == OP_ZERO || OP == OP_SET || OP == OP_COPY);
+    static constexpr bool uses_a = (OP == OP_COPY || OP == OP_ADD || OP == OP_ADD_INTO || OP == OP_ADD_SCALAR ||
+                                    OP == OP_MUL || OP == OP_MUL_WITH || OP == OP_MUL_SCALAR);
+    static constexpr bool uses_b = (OP == OP_ADD || OP == OP_MUL);
+    static constexpr bool uses_s = (OP == OP_SET || OP == OP_ADD_SCALAR || OP == OP_ADD_SCALAR_INTO ||
+                                    OP == OP_MUL_SCALAR || OP == OP_MUL_WITH_SCALAR);
+};
+
+// One element of each op, in the reference's evaluation order (no fused multiply-add).
+template <int OP> __device__ __forceinline__ float ew_apply(float d, float a, float b, float s) {
+    if constexpr (OP == OP_ZERO) return 0.0f;                 // basics.zig:12-14
+    else if constexpr (OP == OP_SET) return s;                // :16-18
+    else if constexpr (OP == OP_COPY) return a;               // :20-22
+    else if constexpr (OP == OP_ADD) return d + (a + b);      // :24-29
+    else if constexpr (OP == OP_ADD_INTO) return d + a;       // :31-36
+    else if constexpr (OP == OP_ADD_SCALAR) return d + (a + s);   // :38-43
+    else if constexpr (OP == OP_ADD_SCALAR_INTO) return d + s;    // :45-50
+    else if constexpr (OP == OP_MUL) return d + a * b;        // :52-57
+    else if constexpr (OP == OP_MUL_WITH) return d * a;       // :59-64
+    else if constexpr (OP == OP_MUL_SCALAR) return d + a * s; // :66-71
+    else return d * s;                                        // :73-78
+}
+
+// VEC = 4: a thread owns 4 consecutive voices of one frame (float4); VEC = 1: one voice.
+template <int OP, int VEC>
+__global__ void __launch_bounds__(256) k_elementwise(Img dst, CImg a, CImg b, F32P s, uint32_t start,
+                                                     uint32_t nframes, uint32_t nvq /* voices / VEC */) {
+    using T = OpTraits<OP>;
+    const uint64_t total = (uint64_t)nframes * nvq;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += step) {
+        const uint32_t f = start + (uint32_t)(idx / nvq);
+        const uint32_t v = (uint32_t)(idx % nvq) * VEC;
+        if constexpr (VEC == 4) {
+            float4 d = {0, 0, 0, 0}, av = {0, 0, 0, 0}, bv = {0, 0, 0, 0}, sv = {s.value, s.value, s.value, s.value};
+            if constexpr (T::reads_dst) d = *reinterpret_cast<const float4 *>(dst.at(f, v));
+            if constexpr (T::uses_a) av = *reinterpret_cast<const float4 *>(a.at(f, v));
+            if constexpr (T::uses_b) bv = *reinterpret_cast<const float4 *>(b.at(f, v));
+            if constexpr (T::uses_s) if (s.pv) sv = *reinterpret_cast<const float4 *>(s.pv + v);
+            float4 r;
+            r.x = ew_apply<OP>(d.x, av.x, bv.x, sv.x);
+            r.y = ew_apply<OP>(d.y, av.y, bv.y, sv.y);
+            r.z = ew_apply<OP>(d.z, av.z, bv.z, sv.z);
+            r.w = ew_apply<OP>(d.w, av.w, bv.w, sv.w);
+            *reinterpret_cast<float4 *>(dst.at(f, v)) = r;
+        } else {
+            float d = 0, av = 0, bv = 0, sv = s.value;
+            if constexpr (T::reads_dst) d = *dst.at(f, v);
+            if constexpr (T::uses_a) av = *a.at(f, v);
+            if constexpr (T::uses_b) bv = *b.at(f, v);
+            if constexpr (T::uses_s) sv = s.get(v);
+            *dst.at(f, v) = ew_apply<OP>(d, av, bv, sv);
+        }
+    }
+}
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <int OP>
+static int launch_ew(zh_ctx *ctx, uint32_t start, uint32_t end, const zh_buf &dest, const zh_buf *a, const zh_buf *b,
+                     const zh_f32 *s) {
+    using T = OpTraits<OP>;
+    if (!ctx || end < start) return ZH_ERR_INVALID;
+    if (!buf_covers(dest, dest.voices, end)) return ZH_ERR_INVALID;
+    if (T::uses_a && (!a || !buf_covers(*a, dest.voices, end))) return ZH_ERR_INVALID;
+    if (T::uses_b && (!b || !buf_covers(*b, dest.voices, end))) return ZH_ERR_INVALID;
+    const uint32_t V = dest.voices, nframes = end - start;
+    if (V == 0 || nframes == 0) return ZH_OK;
+    Img d = mk_img(dest);
+    CImg ai = a ? mk_cimg(*a) : CImg{nullptr, 0}, bi = b ? mk_cimg(*b) : CImg{nullptr, 0};
+    F32P sp = s ? mk_f32(*s) : F32P{0.0f, nullptr};
+    bool vec = (V % 4 == 0) && (dest.stride % 4 == 0) && aligned16(dest.ptr);
+    if (T::uses_a) vec = vec && (a->stride % 4 == 0) && aligned16(a->ptr);
+    if (T::uses_b) vec = vec && (b->stride % 4 == 0) && aligned16(b->ptr);
+    if (T::uses_s && sp.pv) vec = vec && aligned16(sp.pv);
+    const uint32_t nvq = vec ? V / 4 : V;
+    const uint64_t total = (uint64_t)nframes * nvq;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 workgroups per CU, grid-stride the rest
+    if (vec) hipLaunchKernelGGL((k_elementwise<OP, 4>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
+    else hipLaunchKernelGGL((k_elementwise<OP, 1>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
+    return zh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------- mixdown
+// dst[f] += sum_v src[f][v].  Pass 1: a workgroup of 256 lanes owns a tile of 1024 voices
+// (float4 per lane) x MIX_FPB frames; per frame the lane adds its 4 voices left to right,
+// the wave reduces with a fixed xor-shuffle butterfly, the 4 wave sums meet in LDS and are
+// added in wave order.  Pass 2 adds the tile partials in tile order.  The order is fixed,
+// so a given (V, layout) always produces the same bits.
+constexpr int MIX_TILE = 1024;
+constexpr int MIX_FPB = 8;
+
+__device__ __forceinline__ float wave_sum64(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__global__ void __launch_bounds__(256) k_mix_pass1(CImg src, uint32_t V, uint32_t start, uint32_t end,
+                                                   float *__restrict__ partials /*[tiles][nframes]*/) {
+    __shared__ float wsum[MIX_FPB][4];
+    const uint32_t tile = blockIdx.x, f0 = start + blockIdx.y * MIX_FPB;
+    const uint32_t v = tile * MIX_TILE + threadIdx.x * 4;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nframes = end - start;
+    float acc[MIX_FPB];
+#pragma unroll
+    for (int k = 0; k < MIX_FPB; k++) {
+        const uint32_t f = f0 + k;
+        float s = 0.0f;
+        if (f < end) {
+            if (v + 3 < V) {
+                const float4 x = *reinterpret_cast<const float4 *>(src.at(f, v));
+                s = ((x.x + x.y) + x.z) + x.w;
+            } else {
+                for (uint32_t j = 0; j < 4; j++) if (v + j < V) s += *src.at(f, v + j);
+            }
+        }
+        acc[k] = wave_sum64(s);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MIX_FPB; k++) wsum[k][wave] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < MIX_FPB) {
+        const uint32_t f = f0 + threadIdx.x;
+        if (f < end) {
+            const float *w = wsum[threadIdx.x];
+            partials[(size_t)tile * nframes + (f - start)] = ((w[0] + w[1]) + w[2]) + w[3];
+        }
+    }
+}
+
+// scalar-lane variant for images whose rows are not 16 B aligned
+__global__ void __launch_bounds__(256) k_mix_pass1_scalar(CImg src, uint32_t V, uint32_t start, uint32_t end,
+                                                          float *__restrict__ partials) {
+    __shared__ float wsum[MIX_FPB][4];
+    const uint32_t tile = blockIdx.x, f0 = start + blockIdx.y * MIX_FPB;
+    const uint32_t v = tile * MIX_TILE + threadIdx.x * 4;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nframes = end - start;
+    float acc[MIX_FPB];
+#pragma unroll
+    for (int k = 0; k < MIX_FPB; k++) {
+        const uint32_t f = f0 + k;
+        float s = 0.0f;
+        if (f < end) {
+            if (v + 3 < V) {
+                const float *p = src.at(f, v);
+                s = ((p[0] + p[1]) + p[2]) + p[3];
+            } else {
+                for (uint32_t j = 0; j < 4; j++) if (v + j < V) s += *src.at(f, v + j);
+            }
+        }
+        acc[k] = wave_sum64(s);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MIX_FPB; k++) wsum[k][wave] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < MIX_FPB) {
+        const uint32_t f = f0 + threadIdx.x;
+        if (f < end) {
+            const float *w = wsum[threadIdx.x];
+            partials[(size_t)tile * nframes + (f - start)] = ((w[0] + w[1]) + w[2]) + w[3];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mix_pass2(const float *__restrict__ partials, uint32_t tiles,
+                                                   uint32_t nframes, float *__restrict__ dst, int zero_first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes) return;
+    float s = 0.0f;
+    for (uint32_t t = 0; t < tiles; t++) s += partials[(size_t)t * nframes + i];
+    dst[i] = (zero_first ? 0.0f : dst[i]) + s;
+}
+
+int zh_mix_reserve(zh_ctx *ctx, size_t floats) {
+    if (ctx->mix_partials_floats >= floats) return ZH_OK;
+    if (ctx->mix_partials) {
+        ZH_TRY(hipStreamSynchronize(ctx->stream));
+        ZH_TRY(hipFree(ctx->mix_partials));
+        ctx->mix_partials = nullptr;
+        ctx->mix_partials_floats = 0;
+    }
+    ZH_TRY(hipMalloc((void **)&ctx->mix_partials, floats * sizeof(float)));
+    ctx->mix_partials_floats = floats;
+    return ZH_OK;
+}
+
+extern "C" {
+
+int zh_zero(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest) { return launch_ew<OP_ZERO>(ctx, s, e, dest, nullptr, nullptr, nullptr); }
+int zh_set(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { return launch_ew<OP_SET>(ctx, s, e, dest, nullptr, nullptr, &a); }
+int zh_copy(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf src) { return launch_ew<OP_COPY>(ctx, s, e, dest, &src, nullptr, nullptr); }
+int zh_add(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_buf b) { return launch_ew<OP_ADD>(ctx, s, e, dest, &a, &b, nullptr); }
+int zh_add_into(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf src) { return launch_ew<OP_ADD_INTO>(ctx, s, e, dest, &src, nullptr, nullptr); }
+int zh_add_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_f32 b) { return launch_ew<OP_ADD_SCALAR>(ctx, s, e, dest, &a, nullptr, &b); }
+int zh_add_scalar_into(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { return launch_ew<OP_ADD_SCALAR_INTO>(ctx, s, e, dest, nullptr, nullptr, &a); }
+int zh_multiply(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_buf b) { return launch_ew<OP_MUL>(ctx, s, e, dest, &a, &b, nullptr); }
+int zh_multiply_with(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a) { return launch_ew<OP_MUL_WITH>(ctx, s, e, dest, &a, nullptr, nullptr); }
+int zh_multiply_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_f32 b) { return launch_ew<OP_MUL_SCALAR>(ctx, s, e, dest, &a, nullptr, &b); }
+int zh_multiply_with_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { return launch_ew<OP_MUL_WITH_SCALAR>(ctx, s, e, dest, nullptr, nullptr, &a); }
+
+int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_buf src, uint32_t flags) {
+    if (!ctx || !dst || end < start || !buf_covers(src, src.voices, end)) return ZH_ERR_INVALID;
+    const uint32_t V = src.voices, nframes = end - start;
+    if (nframes == 0) return ZH_OK;
+    const uint32_t tiles = V == 0 ? 0 : (V + MIX_TILE - 1) / MIX_TILE;
+    if (tiles) {
+        int rc = zh_mix_reserve(ctx, (size_t)tiles * nframes);
+        if (rc) return rc;
+        dim3 grid(tiles, (nframes + MIX_FPB - 1) / MIX_FPB);
+        if (src.stride % 4 == 0 && aligned16(src.ptr))
+            hipLaunchKernelGGL(k_mix_pass1, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
+        else
+            hipLaunchKernelGGL(k_mix_pass1_scalar, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
+    }
+    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 255) / 256), dim3(256), 0, ctx->stream, ctx->mix_partials, tiles,
+                       nframes, dst + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
+    return zh_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// ctx.hip -- context, memory, image upload/download, events (C ABI: include/zang_hip.h).
+#include "common.cuh"
+#include <string.h>
+#include <vector>
+
+extern "C" {
+
+const char *zh_version(void) { return "zang_hip 0.1 (gfx950)"; }
+
+const char *zh_error_string(int err) {
+    switch (err) {
+    case ZH_OK: return "ok";
+    case ZH_ERR_INVALID: return "invalid argument";
+    case ZH_ERR_UNSUPPORTED: return "unsupported";
+    case ZH_ERR_NO_DEVICE: return "no HIP device";
+    default: return err > 0 ? hipGetErrorString((hipError_t)err) : "unknown error";
+    }
+}
+
+int zh_create(zh_ctx **out, int device) {
+    if (!out) return ZH_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZH_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return ZH_ERR_INVALID;
+    ZH_TRY(hipSetDevice(device));
+    zh_ctx *c = new (std::nothrow) zh_ctx();
+    if (!c) return ZH_ERR_INVALID;
+    c->device = device;
+    c->own_stream = true;
+    c->mix_partials = nullptr;
+    c->mix_partials_floats = 0;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return (int)e; }
+    *out = c;
+    return ZH_OK;
+}
+
+int zh_destroy(zh_ctx *ctx) {
+    if (!ctx) return ZH_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->mix_partials) hipFree(ctx->mix_partials);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ZH_OK;
+}
+
+int zh_set_stream(zh_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ZH_ERR_INVALID;
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        ZH_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return ZH_OK;
+}
+
+void *zh_get_stream(zh_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int zh_sync(zh_ctx *ctx) {
+    if (!ctx) return ZH_ERR_INVALID;
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_malloc(zh_ctx *ctx, void **dev_ptr, size_t bytes) {
+    if (!ctx || !dev_ptr) return ZH_ERR_INVALID;
+    *dev_ptr = nullptr;
+    if (bytes == 0) return ZH_OK;
+    ZH_TRY(hipSetDevice(ctx->device));
+    ZH_TRY(hipMalloc(dev_ptr, bytes));
+    return ZH_OK;
+}
+
+int zh_free(zh_ctx *ctx, void *dev_ptr) {
+    if (!ctx) return ZH_ERR_INVALID;
+    if (!dev_ptr) return ZH_OK;
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    ZH_TRY(hipFree(dev_ptr));
+    return ZH_OK;
+}
+
+int zh_upload(zh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+    if (!ctx || (bytes && (!dev_dst || !host_src))) return ZH_ERR_INVALID;
+    if (!bytes) return ZH_OK;
+    ZH_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return ZH_ERR_INVALID;
+    if (!bytes) return ZH_OK;
+    ZH_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    void *p = nullptr;
+    int rc = zh_malloc(ctx, &p, (size_t)voices * frames * sizeof(float));
+    if (rc) return rc;
+    out->ptr = (float *)p;
+    out->voices = voices;
+    out->frames = frames;
+    out->stride = voices;
+    return ZH_OK;
+}
+
+int zh_buf_free(zh_ctx *ctx, zh_buf *buf) {
+    if (!ctx || !buf) return ZH_ERR_INVALID;
+    int rc = zh_free(ctx, buf->ptr);
+    memset(buf, 0, sizeof *buf);
+    return rc;
+}
+
+// Host [voice][frame] <-> device [frame][voice].  These are test/plumbing paths (PCIe
+// bound); the transpose is done on the host into a staging vector.
+int zh_buf_upload_voices(zh_ctx *ctx, zh_buf dst, const float *host, uint32_t frames) {
+    if (!ctx || !dst.ptr || !host || frames > dst.frames) return ZH_ERR_INVALID;
+    std::vector<float> stage((size_t)frames * dst.voices);
+    for (uint32_t v = 0; v < dst.voices; v++)
+        for (uint32_t f = 0; f < frames; f++) stage[(size_t)f * dst.voices + v] = host[(size_t)v * frames + f];
+    ZH_TRY(hipMemcpy2DAsync(dst.ptr, (size_t)dst.stride * 4, stage.data(), (size_t)dst.voices * 4,
+                            (size_t)dst.voices * 4, frames, hipMemcpyHostToDevice, ctx->stream));
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_buf_download_voices(zh_ctx *ctx, float *host, zh_buf src, uint32_t frames) {
+    if (!ctx || !src.ptr || !host || frames > src.frames) return ZH_ERR_INVALID;
+    std::vector<float> stage((size_t)frames * src.voices);
+    ZH_TRY(hipMemcpy2DAsync(stage.data(), (size_t)src.voices * 4, src.ptr, (size_t)src.stride * 4,
+                            (size_t)src.voices * 4, frames, hipMemcpyDeviceToHost, ctx->stream));
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t v = 0; v < src.voices; v++)
+        for (uint32_t f = 0; f < frames; f++) host[(size_t)v * frames + f] = stage[(size_t)f * src.voices + v];
+    return ZH_OK;
+}
+
+int zh_buf_upload_voice(zh_ctx *ctx, zh_buf dst, uint32_t voice, const float *host, uint32_t frames) {
+    if (!ctx || !dst.ptr || !host || frames > dst.frames || voice >= dst.voices) return ZH_ERR_INVALID;
+    ZH_TRY(hipMemcpy2DAsync(dst.ptr + voice, (size_t)dst.stride * 4, host, 4, 4, frames, hipMemcpyHostToDevice, ctx->stream));
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, uint32_t frames) {
+    if (!ctx || !src.ptr || !host || frames > src.frames || voice >= src.voices) return ZH_ERR_INVALID;
+    ZH_TRY(hipMemcpy2DAsync(host, 4, src.ptr + voice, (size_t)src.stride * 4, 4, frames, hipMemcpyDeviceToHost, ctx->stream));
+    ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_event_create(zh_ctx *ctx, zh_event **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_event *e = new (std::nothrow) zh_event();
+    if (!e) return ZH_ERR_INVALID;
+    hipError_t rc = hipEventCreate(&e->ev);
+    if (rc != hipSuccess) { delete e; return (int)rc; }
+    *out = e;
+    return ZH_OK;
+}
+
+int zh_event_destroy(zh_event *ev) {
+    if (!ev) return ZH_ERR_INVALID;
+    hipEventDestroy(ev->ev);
+    delete ev;
+    return ZH_OK;
+}
+
+int zh_event_record(zh_ctx *ctx, zh_event *ev) {
+    if (!ctx || !ev) return ZH_ERR_INVALID;
+    ZH_TRY(hipEventRecord(ev->ev, ctx->stream));
+    return ZH_OK;
+}
+
+int zh_event_elapsed_ms(zh_event *start, zh_event *stop, float *ms) {
+    if (!start || !stop || !ms) return ZH_ERR_INVALID;
+    ZH_TRY(hipEventSynchronize(stop->ev));
+    ZH_TRY(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return ZH_OK;
+}
+
+}  // extern "C"

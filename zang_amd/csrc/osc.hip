@@ -1,0 +1,377 @@
+// osc.hip -- the farbrausch-v2 band-limited oscillators: PulseOsc (src/modules/PulseOsc.zig)
+// and TriSawOsc (src/modules/TriSawOsc.zig).
+//
+// Constant-frequency paths: the phase is a wrapping u32 accumulator, cnt_i = cnt_0 + i*ifreq
+// EXACTLY (PulseOsc.zig:111, TriSawOsc.zig:115), and the rolling 2-bit `state` is a function
+// of cnt_i and cnt_i - ifreq only (:96,:100 == :141-142).  So a sample depends on nothing
+// but its index: the kernel keeps one lane per voice but also splits the span into frame
+// chunks across waves (grid.y), which is what fills the chip at small voice counts
+// (4096 voices = 64 waves otherwise).  State is double-buffered so chunk threads can read
+// cnt_0 while the chunk-0 thread publishes cnt_0 + n*ifreq.
+//
+// Controlled-frequency paths carry state sample to sample and use the sequential
+// lane-per-voice loop (seq.cuh).
+#include "common.cuh"
+#include "zmath.cuh"
+#include "seq.cuh"
+#include <stdlib.h>
+#include <vector>
+
+struct zh_pulseosc {
+    zh_ctx *ctx;
+    uint32_t n;
+    uint32_t *cnt[2];
+    int cur;
+};
+
+struct zh_trisawosc {
+    zh_ctx *ctx;
+    uint32_t n;
+    uint32_t *cnt[2];
+    float *t;
+    int cur;
+};
+
+// ------------------------------------------------------------------ PulseOsc
+struct PulseK {           // per-voice constants of PulseOsc.zig:88-95
+    uint32_t ifreq, brpt;
+    float gdf, col, cc121, cc212;
+};
+
+__device__ __forceinline__ PulseK pulse_setup(float sample_rate, float freq, float color) {
+    PulseK k;
+    const float SRfcobasefrq = 4294967296.0f / sample_rate;
+    k.ifreq = zf32_to_u32(SRfcobasefrq * freq);
+    k.brpt = zftou32(zclamp01(color));
+    const float gain = 0.7f;
+    k.gdf = gain / zutof23(k.ifreq);
+    k.col = zutof23(k.brpt);
+    k.cc121 = k.gdf * 2.0f * (k.col - 1.0f) + gain;
+    k.cc212 = k.gdf * 2.0f * k.col - gain;
+    return k;
+}
+
+// the 6-way switch of PulseOsc.zig:102-110 as value selects (never a 0/1 blend: gdf may be inf)
+__device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
+    const float gain = 0.7f;
+    const float p = zutof23(cnt);
+    const uint32_t s0 = cnt < k.brpt ? 1u : 0u;
+    const uint32_t s1 = (uint32_t)(cnt - k.ifreq) < k.brpt ? 2u : 0u;
+    const uint32_t tr = s0 | s1 | (cnt < k.ifreq ? 4u : 0u);
+    float v = 0.0f;                                   // 1 and 6 are unreachable: defined as +0
+    v = tr == 3 ? gain : v;
+    v = tr == 0 ? -gain : v;
+    v = tr == 2 ? k.gdf * 2.0f * (k.col - p) + gain : v;
+    v = tr == 5 ? k.gdf * 2.0f * p - gain : v;
+    v = tr == 7 ? k.cc121 : v;
+    v = tr == 4 ? k.cc212 : v;
+    return v;
+}
+
+// grid: x = 64-voice groups, y = groups of 4 frame chunks; block = 256 = 4 waves, each wave a
+// different chunk of the same 64 voices.
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
+                                                        uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
+                                                        float sample_rate, F32P freq_p, F32P color_p) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const uint32_t c0 = start + chunk * fc;
+    const uint32_t c1 = min(c0 + fc, end);
+    const float freq = freq_p.get(v);
+    const bool bad = freq < 0 || freq > sample_rate / 8.0f;          // PulseOsc.zig:82-84
+    const uint32_t cnt0 = cnt_in[v];
+    const PulseK k = pulse_setup(sample_rate, freq, color_p.get(v));
+    if (chunk == 0) cnt_out[v] = bad ? cnt0 : cnt0 + (end - start) * k.ifreq;
+    if (c0 >= end) return;
+    float *o = out.at(c0, v);
+    const size_t os = out.stride;
+    if (bad) {
+        if (ZF) for (uint32_t i = c0; i < c1; i++, o += os) *o = 0.0f;
+        return;
+    }
+    uint32_t cnt = cnt0 + (c0 - start) * k.ifreq;
+#pragma unroll 4
+    for (uint32_t i = c0; i < c1; i++, o += os) {
+        const float val = pulse_sample(k, cnt);
+        *o = (ZF ? 0.0f : *o) + val;
+        cnt += k.ifreq;
+    }
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restrict__ cnt_io, uint32_t V, Img out,
+                                                             uint32_t start, uint32_t end, float sample_rate,
+                                                             CImg freq_b, F32P color_p) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    uint32_t cnt = cnt_io[v];
+    const float SRfcobasefrq = 4294967296.0f / sample_rate;
+    PulseK k;
+    k.brpt = zftou32(zclamp01(color_p.get(v)));
+    k.col = zutof23(k.brpt);
+    const float gain = 0.7f;
+    const float *ins[1] = {freq_b.p + v};
+    const size_t istr[1] = {freq_b.stride};
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
+        const float s_freq = x[0];
+        if (s_freq < 0 || s_freq > sample_rate / 8.0f) return false;  // PulseOsc.zig:134-135
+        k.ifreq = zf32_to_u32(SRfcobasefrq * s_freq);
+        k.gdf = gain / zutof23(k.ifreq);
+        k.cc121 = k.gdf * 2.0f * (k.col - 1.0f) + gain;
+        k.cc212 = k.gdf * 2.0f * k.col - gain;
+        val = pulse_sample(k, cnt);
+        cnt += k.ifreq;
+        return true;
+    });
+    cnt_io[v] = cnt;
+}
+
+// ------------------------------------------------------------------ TriSawOsc
+struct TriSawK {          // TriSawOsc.zig:90-99
+    uint32_t ifreq, brpt;
+    float f, omf, rcpf, col, c1, c2;
+};
+
+__device__ __forceinline__ TriSawK trisaw_setup(float sample_rate, float freq, float color) {
+    TriSawK k;
+    const float SRfcobasefrq = 4294967296.0f / sample_rate;
+    k.ifreq = zf32_to_u32(SRfcobasefrq * freq);
+    k.brpt = zftou32(zclamp01(color));
+    const float gain = 0.7f;
+    k.f = zutof23(k.ifreq);
+    k.omf = 1.0f - k.f;
+    k.rcpf = 1.0f / k.f;
+    k.col = zutof23(k.brpt);
+    k.c1 = gain / k.col;
+    k.c2 = -gain / (1.0f - k.col);
+    return k;
+}
+
+// TriSawOsc.zig:103-114.  Each arm is evaluated only by the lanes that take it: c1 is +inf
+// when color == 0 (unused arms then), so arms must be selected, never blended.
+__device__ __forceinline__ float trisaw_sample(const TriSawK &k, uint32_t cnt) {
+    const float gain = 0.7f;
+    const float p = zutof23(cnt) - k.col;
+    const uint32_t s0 = cnt < k.brpt ? 1u : 0u;
+    const uint32_t s1 = (uint32_t)(cnt - k.ifreq) < k.brpt ? 2u : 0u;
+    const uint32_t s = s0 | s1 | (cnt < k.ifreq ? 4u : 0u);
+    float v = 0.0f;
+    if (s == 3) v = k.c1 * (p + p - k.f);
+    else if (s == 0) v = k.c2 * (p + p - k.f);
+    else if (s == 2) v = k.rcpf * (k.c2 * (p * p) - k.c1 * ((p - k.f) * (p - k.f)));
+    else if (s == 5) v = -k.rcpf * (gain + k.c2 * ((p + k.omf) * (p + k.omf)) - k.c1 * (p * p));
+    else if (s == 7) v = -k.rcpf * (gain + k.c1 * k.omf * (p + p + k.omf));
+    else if (s == 4) v = -k.rcpf * (gain + k.c2 * k.omf * (p + p + k.omf));
+    return gain + v;
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_trisawosc_const(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
+                                                         uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
+                                                         float sample_rate, F32P freq_p, F32P color_p) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const uint32_t c0 = start + chunk * fc;
+    const uint32_t c1 = min(c0 + fc, end);
+    const float freq = freq_p.get(v);
+    const bool bad = freq < 0 || freq > sample_rate / 8.0f;          // TriSawOsc.zig:84-86
+    const uint32_t cnt0 = cnt_in[v];
+    const TriSawK k = trisaw_setup(sample_rate, freq, color_p.get(v));
+    if (chunk == 0) cnt_out[v] = bad ? cnt0 : cnt0 + (end - start) * k.ifreq;
+    if (c0 >= end) return;
+    float *o = out.at(c0, v);
+    const size_t os = out.stride;
+    if (bad) {
+        if (ZF) for (uint32_t i = c0; i < c1; i++, o += os) *o = 0.0f;
+        return;
+    }
+    uint32_t cnt = cnt0 + (c0 - start) * k.ifreq;
+#pragma unroll 4
+    for (uint32_t i = c0; i < c1; i++, o += os) {
+        const float val = trisaw_sample(k, cnt);
+        *o = (ZF ? 0.0f : *o) + val;
+        cnt += k.ifreq;
+    }
+}
+
+// TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict__ t_io, uint32_t V, Img out,
+                                                              uint32_t start, uint32_t end, float sample_rate,
+                                                              CImg freq_b, F32P color_p) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    float t = t_io[v];
+    const float color = color_p.get(v);
+    const bool saw = color < 0.25f || color > 0.75f;
+    const float gain = 0.7f;
+    const float *ins[1] = {freq_b.p + v};
+    const size_t istr[1] = {freq_b.stride};
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
+        float frac;
+        if (saw) {
+            frac = (t - floorf(t)) * 2.0f - 1.0f;
+        } else {
+            frac = t - floorf(t);
+            if (frac < 0.25f) frac = frac * 4.0f;
+            else if (frac < 0.75f) frac = 1.0f - (frac - 0.25f) * 4.0f;
+            else frac = (frac - 0.75f) * 4.0f - 1.0f;
+        }
+        val = gain * frac;
+        t += x[0] / sample_rate;
+        return true;
+    });
+    t_io[v] = t - truncf(t);                                          // :155
+}
+
+// Frames per lane for the chunked kernels: enough chunks to put >= 8 waves on every SIMD
+// (256 CUs x 4 SIMDs x 8 = 8192 waves), but at least 8 frames so the per-voice setup
+// (two divides) is amortised.  ZH_OSC_FC overrides for experiments.
+static uint32_t osc_frames_per_lane(uint32_t V, uint32_t nframes) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("ZH_OSC_FC"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return (uint32_t)forced;
+    const uint64_t groups = (V + 63) / 64;
+    uint64_t fc = (groups * nframes) / 8192;
+    uint32_t p = 8;
+    while (p * 2 <= fc && p < 64) p *= 2;
+    return p;
+}
+
+template <class M> static int osc_common_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs,
+                                               float sample_rate, const zh_cob &freq) {
+    (void)sample_rate;
+    if (!m || !outputs || end < start) return ZH_ERR_INVALID;
+    if (!buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
+    if (!cob_ok(freq, m->n, end)) return ZH_ERR_INVALID;
+    return ZH_OK;
+}
+
+extern "C" {
+
+// -------- PulseOsc
+int zh_pulseosc_create(zh_ctx *ctx, uint32_t n, zh_pulseosc **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_pulseosc *m = new (std::nothrow) zh_pulseosc();
+    if (!m) return ZH_ERR_INVALID;
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr;
+    int rc = dev_alloc(&m->cnt[0], n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[0], 0, n * 4, ctx->stream);       // init(): cnt = 0 (:38-42)
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[1], 0, n * 4, ctx->stream);
+    if (rc) { hipFree(m->cnt[0]); hipFree(m->cnt[1]); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_pulseosc_destroy(zh_pulseosc *m) {
+    if (!m) return ZH_ERR_INVALID;
+    hipStreamSynchronize(m->ctx->stream);
+    hipFree(m->cnt[0]); hipFree(m->cnt[1]);
+    delete m;
+    return ZH_OK;
+}
+int zh_pulseosc_get_state(zh_pulseosc *m, zh_pulseosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_download(m->ctx, host, m->cnt[m->cur], (size_t)m->n * 4);
+}
+int zh_pulseosc_set_state(zh_pulseosc *m, const zh_pulseosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_upload(m->ctx, m->cnt[m->cur], host, (size_t)m->n * 4);
+}
+int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                             // PulseOsc.zig:52-53
+    if (!p) return ZH_ERR_INVALID;
+    int rc = osc_common_check(m, start, end, outputs, p->sample_rate, p->freq);
+    if (rc) return rc;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    Img out = mk_img(outputs[0]);
+    if (p->freq.tag == ZH_COB_CONSTANT) {
+        const uint32_t fc = osc_frames_per_lane(m->n, end - start);
+        const uint32_t chunks = (end - start + fc - 1) / fc;
+        dim3 grid((m->n + 63) / 64, (chunks + 3) / 4);
+        uint32_t *ci = m->cnt[m->cur], *co = m->cnt[m->cur ^ 1];
+        if (zf) hipLaunchKernelGGL(k_pulseosc_const<true>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
+        else hipLaunchKernelGGL(k_pulseosc_const<false>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
+        m->cur ^= 1;
+    } else {
+        uint32_t *c = m->cnt[m->cur];
+        if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+        else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+    }
+    return zh_launch_status();
+}
+
+// -------- TriSawOsc
+int zh_trisawosc_create(zh_ctx *ctx, uint32_t n, zh_trisawosc **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_trisawosc *m = new (std::nothrow) zh_trisawosc();
+    if (!m) return ZH_ERR_INVALID;
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->t = nullptr;
+    int rc = dev_alloc(&m->cnt[0], n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], n);
+    if (!rc) rc = dev_alloc(&m->t, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[0], 0, n * 4, ctx->stream);       // init() :39-44
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[1], 0, n * 4, ctx->stream);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);
+    if (rc) { hipFree(m->cnt[0]); hipFree(m->cnt[1]); hipFree(m->t); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_trisawosc_destroy(zh_trisawosc *m) {
+    if (!m) return ZH_ERR_INVALID;
+    hipStreamSynchronize(m->ctx->stream);
+    hipFree(m->cnt[0]); hipFree(m->cnt[1]); hipFree(m->t);
+    delete m;
+    return ZH_OK;
+}
+int zh_trisawosc_get_state(zh_trisawosc *m, zh_trisawosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint32_t> c(m->n);
+    std::vector<float> t(m->n);
+    int rc = zh_download(m->ctx, c.data(), m->cnt[m->cur], (size_t)m->n * 4);
+    if (!rc) rc = zh_download(m->ctx, t.data(), m->t, (size_t)m->n * 4);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < m->n; i++) { host[i].cnt = c[i]; host[i].t = t[i]; }
+    return ZH_OK;
+}
+int zh_trisawosc_set_state(zh_trisawosc *m, const zh_trisawosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint32_t> c(m->n);
+    std::vector<float> t(m->n);
+    for (uint32_t i = 0; i < m->n; i++) { c[i] = host[i].cnt; t[i] = host[i].t; }
+    int rc = zh_upload(m->ctx, m->cnt[m->cur], c.data(), (size_t)m->n * 4);
+    if (!rc) rc = zh_upload(m->ctx, m->t, t.data(), (size_t)m->n * 4);
+    return rc;
+}
+int zh_trisawosc_paint(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                             // TriSawOsc.zig:54-55
+    if (!p) return ZH_ERR_INVALID;
+    int rc = osc_common_check(m, start, end, outputs, p->sample_rate, p->freq);
+    if (rc) return rc;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    Img out = mk_img(outputs[0]);
+    if (p->freq.tag == ZH_COB_CONSTANT) {
+        const uint32_t fc = osc_frames_per_lane(m->n, end - start);
+        const uint32_t chunks = (end - start + fc - 1) / fc;
+        dim3 grid((m->n + 63) / 64, (chunks + 3) / 4);
+        uint32_t *ci = m->cnt[m->cur], *co = m->cnt[m->cur ^ 1];
+        if (zf) hipLaunchKernelGGL(k_trisawosc_const<true>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
+        else hipLaunchKernelGGL(k_trisawosc_const<false>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
+        m->cur ^= 1;
+    } else {
+        if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+        else hipLaunchKernelGGL(k_trisawosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+    }
+    return zh_launch_status();
+}
+
+}  // extern "C"

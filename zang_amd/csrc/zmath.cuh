@@ -1,0 +1,424 @@
+// zmath.cuh -- device scalar math for the paint kernels (gfx950).
+//
+// The reference takes sin/cos/atan/pow/floor/round and its PRNG from the Zig standard
+// library (call sites: SineOsc.zig:5, Filter.zig:21-22, Distortion.zig:41-50,
+// Noise.zig:22-58), which documents those routines as ports of musl libc (and of Go's
+// math.Pow).  To reproduce the reference's bits rather than "a sine", the kernels run the
+// same published algorithms: f64 polynomial kernels after a Cody-Waite / Payne-Hanek
+// reduction for sin/cos, the f32 table+polynomial atanf, frexp/ldexp square-and-multiply
+// pow, xoshiro256++.  MI355X executes f64 VALU at half the f32 rate, so one sinf costs
+// about 30 f32-equivalent lane-ops: inside the per-sample budget of an HBM-bound paint.
+//
+// Everything here must be compiled with -ffp-contract=off (no fused multiply-add: Zig
+// emits none for these loops) and without fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZD __device__ __forceinline__
+
+ZD uint32_t zf2u(float f) { return __float_as_uint(f); }
+ZD float zu2f(uint32_t u) { return __uint_as_float(u); }
+
+// @intFromFloat with NaN / out-of-range DEFINED as v_cvt_u32_f32 / v_cvt_i32_f32 behave.
+ZD uint32_t zf32_to_u32(float v) {
+    if (!(v == v)) return 0u;
+    if (v <= 0.0f) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+ZD int32_t zf32_to_i32(float v) {
+    if (!(v == v)) return 0;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    return (int32_t)v;
+}
+
+// std.math.clamp == @max(lo, @min(v, hi)) as explicit selects (first operand wins ties)
+ZD float zminf(float a, float b) { return (a <= b || b != b) ? a : b; }
+ZD float zmaxf(float a, float b) { return (a >= b || b != b) ? a : b; }
+ZD float zclampf(float v, float lo, float hi) { return zmaxf(lo, zminf(v, hi)); }
+
+// ---- sin / cos ----------------------------------------------------------------------
+ZD float zsindf(double x) {
+    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59,
+                 S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
+    double z = x * x;
+    double w = z * z;
+    double r = S3 + z * S4;
+    double s = z * x;
+    return (float)((x + s * (S1 + z * S2)) + s * w * r);
+}
+ZD float zcosdf(double x) {
+    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57,
+                 C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
+    double z = x * x;
+    double w = z * z;
+    double r = C2 + z * C3;
+    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+
+// 24-bit chunks of 2/pi and pi/2 (tools/gen_pio2_tables.py).  Only reached for
+// |x| >= 2^28*pi/2; f32 exponents need the first dozen entries at most, the rest serve the
+// recomputation loop.
+__device__ static const int32_t ZM_IPIO2[66] = {
+  0xA2F983, 0x6E4E44, 0x1529FC, 0x2757D1, 0xF534DD, 0xC0DB62,
+  0x95993C, 0x439041, 0xFE5163, 0xABDEBB, 0xC561B7, 0x246E3A,
+  0x424DD2, 0xE00649, 0x2EEA09, 0xD1921C, 0xFE1DEB, 0x1CB129,
+  0xA73EE8, 0x8235F5, 0x2EBB44, 0x84E99C, 0x7026B4, 0x5F7E41,
+  0x3991D6, 0x398353, 0x39F49C, 0x845F8B, 0xBDF928, 0x3B1FF8,
+  0x97FFDE, 0x05980F, 0xEF2F11, 0x8B5A0A, 0x6D1F6D, 0x367ECF,
+  0x27CB09, 0xB74F46, 0x3F669E, 0x5FEA2D, 0x7527BA, 0xC7EBE5,
+  0xF17B3D, 0x0739F7, 0x8A5292, 0xEA6BFB, 0x5FB11F, 0x8D5D08,
+  0x560330, 0x46FC7B, 0x6BABF0, 0xCFBC20, 0x9AF436, 0x1DA9E3,
+  0x91615E, 0xE61B08, 0x659985, 0x5F14A0, 0x68408D, 0xFFD880,
+  0x4D7327, 0x310606, 0x1556CA, 0x73A8C9, 0x60E27B, 0xC08C6B,
+};
+__device__ static const double ZM_PIO2[8] = {
+  0x1.921fb40000000p+0,  0x1.4442d00000000p-24, 0x1.8469880000000p-48,
+  0x1.8cc5160000000p-72, 0x1.01b8380000000p-96, 0x1.a252040000000p-120,
+  0x1.3822280000000p-145, 0x1.9f31d00000000p-169,
+};
+
+// Payne-Hanek reduction (musl __rem_pio2_large with nx = 1, prec = 0).  Kept out of line:
+// it is the cold path and its work arrays live in scratch.
+__device__ __noinline__ static int zrem_pio2_large1(double x0, double *y, int e0) {
+    int32_t jz, jv, carry, n, iq[20], i, j, k, q0, ih;
+    const int32_t jk = 3;
+    double z, fw, f[20], fq[20], q[20];
+    jv = (e0 - 3) / 24; if (jv < 0) jv = 0;
+    q0 = e0 - 24 * (jv + 1);
+    for (i = 0; i <= jk; i++) f[i] = (double)ZM_IPIO2[jv + i];
+    for (i = 0; i <= jk; i++) q[i] = x0 * f[i];
+    jz = jk;
+    for (;;) {
+        for (i = 0, j = jz, z = q[jz]; j > 0; i++, j--) {
+            fw = (double)(int32_t)(0x1p-24 * z);
+            iq[i] = (int32_t)(z - 0x1p24 * fw);
+            z = q[j - 1] + fw;
+        }
+        z = ldexp(z, q0);
+        z -= 8.0 * floor(z * 0.125);
+        n = (int32_t)z;
+        z -= (double)n;
+        ih = 0;
+        if (q0 > 0) {
+            i = iq[jz - 1] >> (24 - q0); n += i;
+            iq[jz - 1] -= i << (24 - q0);
+            ih = iq[jz - 1] >> (23 - q0);
+        } else if (q0 == 0) ih = iq[jz - 1] >> 23;
+        else if (z >= 0.5) ih = 2;
+        if (ih > 0) {
+            n += 1; carry = 0;
+            for (i = 0; i < jz; i++) {
+                j = iq[i];
+                if (carry == 0) {
+                    if (j != 0) { carry = 1; iq[i] = 0x1000000 - j; }
+                } else iq[i] = 0xffffff - j;
+            }
+            if (q0 == 1) iq[jz - 1] &= 0x7fffff;
+            else if (q0 == 2) iq[jz - 1] &= 0x3fffff;
+            if (ih == 2) {
+                z = 1.0 - z;
+                if (carry != 0) z -= ldexp(1.0, q0);
+            }
+        }
+        if (z == 0.0) {
+            j = 0;
+            for (i = jz - 1; i >= jk; i--) j |= iq[i];
+            if (j == 0) {
+                for (k = 1; iq[jk - k] == 0; k++) {}
+                for (i = jz + 1; i <= jz + k; i++) {
+                    f[i] = (double)ZM_IPIO2[jv + i];
+                    q[i] = x0 * f[i];
+                }
+                jz += k;
+                continue;
+            }
+        }
+        break;
+    }
+    if (z == 0.0) {
+        jz -= 1; q0 -= 24;
+        while (iq[jz] == 0) { jz--; q0 -= 24; }
+    } else {
+        z = ldexp(z, -q0);
+        if (z >= 0x1p24) {
+            fw = (double)(int32_t)(0x1p-24 * z);
+            iq[jz] = (int32_t)(z - 0x1p24 * fw);
+            jz += 1; q0 += 24;
+            iq[jz] = (int32_t)fw;
+        } else iq[jz] = (int32_t)z;
+    }
+    fw = ldexp(1.0, q0);
+    for (i = jz; i >= 0; i--) { q[i] = fw * (double)iq[i]; fw *= 0x1p-24; }
+    for (i = jz; i >= 0; i--) {
+        for (fw = 0.0, k = 0; k <= jk && k <= jz - i; k++) fw += ZM_PIO2[k] * q[i + k];
+        fq[jz - i] = fw;
+    }
+    fw = 0.0;
+    for (i = jz; i >= 0; i--) fw += fq[i];
+    y[0] = ih == 0 ? fw : -fw;
+    return n & 7;
+}
+
+ZD int zrem_pio2f(float x, double *y) {
+    const double toint = 1.5 / 2.220446049250313e-16, pio4 = 0x1.921fb6p-1,
+                 invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079631090164184570e+00,
+                 pio2_1t = 1.58932547735281966916e-08;
+    uint32_t ui = zf2u(x), ix = ui & 0x7fffffff;
+    if (ix < 0x4dc90fdb) {
+        double fn = (double)x * invpio2 + toint - toint;
+        int n = (int32_t)fn;
+        *y = x - fn * pio2_1 - fn * pio2_1t;
+        if (*y < -pio4) { n--; fn--; *y = x - fn * pio2_1 - fn * pio2_1t; }
+        else if (*y > pio4) { n++; fn++; *y = x - fn * pio2_1 - fn * pio2_1t; }
+        return n;
+    }
+    if (ix >= 0x7f800000) { *y = x - x; return 0; }
+    int sign = ui >> 31;
+    int e0 = (int)(ix >> 23) - (0x7f + 23);
+    double ty;
+    int n = zrem_pio2_large1((double)zu2f(ix - ((uint32_t)e0 << 23)), &ty, e0);
+    if (sign) { *y = -ty; return -n; }
+    *y = ty;
+    return n;
+}
+
+ZD float zsinf(float x) {
+    const double pio2 = 1.57079632679489661923;
+    uint32_t ix = zf2u(x);
+    int sign = ix >> 31;
+    double y;
+    ix &= 0x7fffffff;
+    if (ix <= 0x3f490fda) {
+        if (ix < 0x39800000) return x;
+        return zsindf(x);
+    }
+    if (ix <= 0x407b53d1) {
+        if (ix <= 0x4016cbe3) {
+            if (sign) return -zcosdf(x + 1 * pio2);
+            return zcosdf(x - 1 * pio2);
+        }
+        return zsindf(sign ? -(x + 2 * pio2) : -(x - 2 * pio2));
+    }
+    if (ix <= 0x40e231d5) {
+        if (ix <= 0x40afeddf) {
+            if (sign) return zcosdf(x + 3 * pio2);
+            return -zcosdf(x - 3 * pio2);
+        }
+        return zsindf(sign ? x + 4 * pio2 : x - 4 * pio2);
+    }
+    if (ix >= 0x7f800000) return x - x;
+    int n = zrem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return zsindf(y);
+    case 1: return zcosdf(y);
+    case 2: return zsindf(-y);
+    default: return -zcosdf(y);
+    }
+}
+
+ZD float zcosf(float x) {
+    const double pio2 = 1.57079632679489661923;
+    uint32_t ix = zf2u(x);
+    int sign = ix >> 31;
+    double y;
+    ix &= 0x7fffffff;
+    if (ix <= 0x3f490fda) {
+        if (ix < 0x39800000) return 1.0f;
+        return zcosdf(x);
+    }
+    if (ix <= 0x407b53d1) {
+        if (ix > 0x4016cbe3) return -zcosdf(sign ? x + 2 * pio2 : x - 2 * pio2);
+        if (sign) return zsindf(x + 1 * pio2);
+        return zsindf(1 * pio2 - x);
+    }
+    if (ix <= 0x40e231d5) {
+        if (ix > 0x40afeddf) return zcosdf(sign ? x + 4 * pio2 : x - 4 * pio2);
+        if (sign) return zsindf(-x - 3 * pio2);
+        return zsindf(x - 3 * pio2);
+    }
+    if (ix >= 0x7f800000) return x - x;
+    int n = zrem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return zcosdf(y);
+    case 1: return zsindf(-y);
+    case 2: return -zcosdf(y);
+    default: return zsindf(y);
+    }
+}
+
+// ---- atanf (f32 arithmetic throughout) ------------------------------------------------
+ZD float zatanf(float x) {
+    const float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f,
+                aT3 = -1.0648017377e-01f, aT4 = 6.1687607318e-02f;
+    float w, s1, s2, z, hi = 0.0f, lo = 0.0f;
+    uint32_t ix = zf2u(x), sign = ix >> 31;
+    int id;
+    ix &= 0x7fffffff;
+    if (ix >= 0x4c800000) {
+        if (x != x) return x;
+        z = 1.5707962513e+00f + 0x1p-120f;
+        return sign ? -z : z;
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x39800000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; hi = 4.6364760399e-01f; lo = 5.0121582440e-09f; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; hi = 7.8539812565e-01f; lo = 3.7748947079e-08f; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; hi = 9.8279368877e-01f; lo = 3.4473217170e-08f; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; hi = 1.5707962513e+00f; lo = 7.5497894159e-08f; x = -1.0f / x; }
+        }
+    }
+    z = x * x;
+    w = z * z;
+    s1 = z * (aT0 + w * (aT2 + w * aT4));
+    s2 = w * (aT1 + w * aT3);
+    if (id < 0) return x - x * (s1 + s2);
+    z = hi - ((x * (s1 + s2) - lo) - x);
+    return sign ? -z : z;
+}
+
+// ---- logf / expf / powf (Distortion.zig:41 calls pow(f32, 2.0, y) once per paint) -------
+ZD float zlogf(float x) {
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, Lg1 = 0xaaaaaa.0p-24f,
+                Lg2 = 0xccce13.0p-25f, Lg3 = 0x91e9ee.0p-25f, Lg4 = 0xf89e26.0p-26f;
+    uint32_t ix = zf2u(x);
+    int k = 0;
+    if (ix < 0x00800000 || ix >> 31) {
+        if (ix << 1 == 0) return -__builtin_inff();
+        if (ix >> 31) return __builtin_nanf("");
+        k -= 25; x *= 0x1p25f; ix = zf2u(x);
+    } else if (ix >= 0x7f800000) return x;
+    else if (ix == 0x3f800000) return 0;
+    ix += 0x3f800000 - 0x3f3504f3;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffff) + 0x3f3504f3;
+    x = zu2f(ix);
+    float f = x - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (Lg2 + w * Lg4);
+    float t2 = z * (Lg1 + w * Lg3);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+ZD float zexpf(float x) {
+    const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f,
+                P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    uint32_t hx = zf2u(x);
+    int sign = hx >> 31, k;
+    float hi, lo;
+    hx &= 0x7fffffff;
+    if (x != x) return x;
+    if (hx >= 0x42aeac50) {
+        if (hx > 0x7f800000) return x;
+        if (hx >= 0x42b17218 && !sign) return x * 0x1p127f;
+        if (sign && hx >= 0x42cff1b5) return 0;
+    }
+    if (hx > 0x3eb17218) {
+        if (hx > 0x3f851592) k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+        else k = 1 - sign - sign;
+        float fk = (float)k;
+        hi = x - fk * ln2hi;
+        lo = fk * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000) {
+        k = 0; hi = x; lo = 0;
+    } else return 1 + x;
+    float xx = x * x;
+    float c = x - xx * (P1 + xx * P2);
+    float y = 1 + (x * c / (2 - c) - lo + hi);
+    if (k == 0) return y;
+    return ldexpf(y, k);
+}
+
+// std.math.pow(f32, x, y) restricted to finite x > 0 (the reference's only call is x = 2).
+ZD float zpowf_pos(float x, float y) {
+    if (y == 0 || x == 1) return 1;
+    if (y != y) return __builtin_nanf("");
+    if (y == 1) return x;
+    if (__builtin_isinf(y)) {
+        if ((x < 1) == (y > 0)) return 0;
+        return __builtin_inff();
+    }
+    if (y == 0.5f) return sqrtf(x);
+    if (y == -0.5f) return 1 / sqrtf(x);
+    float ay = fabsf(y);
+    float yi = truncf(ay);
+    float yf = ay - yi;
+    if (yi >= 2147483648.0f) return zexpf(y * zlogf(x));
+    float a1 = 1.0f;
+    int ae = 0;
+    if (yf != 0) {
+        if (yf > 0.5f) { yf -= 1; yi += 1; }
+        a1 = zexpf(yf * zlogf(x));
+    }
+    int xe;
+    float x1 = frexpf(x, &xe);
+    for (int32_t i = (int32_t)yi; i != 0; i >>= 1) {
+        if (xe < -(1 << 9) || (1 << 9) < xe) { ae += xe; break; }
+        if (i & 1) { a1 *= x1; ae += xe; }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < 0.5f) { x1 += x1; xe -= 1; }
+    }
+    if (y < 0) { a1 = 1 / a1; ae = -ae; }
+    return ldexpf(a1, ae);
+}
+
+// ---- xoshiro256++ and Random.float(f32) (Noise.zig:22,29,51,58) -------------------------
+struct ZXoshiro { uint64_t s0, s1, s2, s3; };
+
+ZD uint64_t zrotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+ZD void zxoshiro_seed(ZXoshiro &r, uint64_t seed) {
+    uint64_t sm = seed, o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        sm += 0x9e3779b97f4a7c15ull;
+        uint64_t z = sm;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        o[i] = z ^ (z >> 31);
+    }
+    r.s0 = o[0]; r.s1 = o[1]; r.s2 = o[2]; r.s3 = o[3];
+}
+ZD uint64_t zxoshiro_next(ZXoshiro &r) {
+    uint64_t result = zrotl64(r.s0 + r.s3, 23) + r.s0;
+    uint64_t t = r.s1 << 17;
+    r.s2 ^= r.s0; r.s3 ^= r.s1; r.s1 ^= r.s2; r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = zrotl64(r.s3, 45);
+    return result;
+}
+ZD float zrandom_float32(ZXoshiro &r) {
+    uint64_t rnd = zxoshiro_next(r);
+    uint32_t lz = rnd ? (uint32_t)__clzll((long long)rnd) : 64u;
+    if (lz >= 41) {                       // probability 2^-41 per sample
+        uint64_t r2 = zxoshiro_next(r);
+        lz = 41 + (r2 ? (uint32_t)__clzll((long long)r2) : 64u);
+        if (lz == 41 + 64) lz += (uint32_t)__clz((int)((uint32_t)zxoshiro_next(r) | 0x7FFu));
+    }
+    return zu2f(((126u - lz) << 23) | ((uint32_t)rnd & 0x7FFFFFu));
+}
+
+// ---- v2 oscillator helpers (PulseOsc.zig:12-26, TriSawOsc.zig:8-26) ----------------------
+ZD float zclamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+ZD float zutof23(uint32_t x) { return zu2f((x >> 9) | 0x3f800000u) - 1.0f; }
+ZD uint32_t zftou32(float v) { return zf32_to_u32(v * 4294967296.0f * 0.99995f); }
+
+// Filter.cutoffFromFrequency (Filter.zig:20-23)
+ZD float zcutoff_from_frequency(float frequency, float sample_rate) {
+    const float v = 2.0f * (1.0f - zcosf(3.14159265358979323846f * frequency / sample_rate));
+    return sqrtf(zclampf(v, 0.0f, 1.0f));
+}

@@ -1,0 +1,90 @@
+"""Context and device-image plumbing above the C ABI.
+
+PyTorch is used only for device memory and streams: sample images are float32 CUDA
+tensors of shape [frames, voices] (voice contiguous), passed to the C ABI by data_ptr().
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+
+_default = None
+
+
+class Context:
+    """One zh_ctx bound to a torch device; launches go to torch's current stream."""
+
+    def __init__(self, device=0, adopt_torch_stream=True):
+        if not torch.cuda.is_available():
+            raise abi.ZangHipError("zang_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                   "there is no CPU fallback")
+        self.lib = abi.load()
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        abi.check(self.lib.zh_create(C.byref(h), device), "zh_create")
+        self.handle = h
+        if adopt_torch_stream:
+            self.use_stream(torch.cuda.current_stream(self.device))
+
+    def use_stream(self, stream):
+        abi.check(self.lib.zh_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), "zh_set_stream")
+        self._stream = stream
+
+    def sync(self):
+        abi.check(self.lib.zh_sync(self.handle), "zh_sync")
+
+    def close(self):
+        if self.handle:
+            self.lib.zh_destroy(self.handle)
+            self.handle = None
+
+    def image(self, frames, voices, fill=None):
+        """A [frame][voice] sample image (the device form of `voices` reference []f32 slices)."""
+        if fill is None:
+            return torch.empty((frames, voices), dtype=torch.float32, device=self.device)
+        return torch.full((frames, voices), float(fill), dtype=torch.float32, device=self.device)
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return _default
+
+
+def as_buf(t):
+    """torch [frames, voices] float32 CUDA tensor (row stride >= voices) -> zh_buf."""
+    if isinstance(t, abi.Buf):
+        return t
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError("sample image must be a float32 CUDA tensor [frames, voices] with contiguous voices")
+    return abi.Buf(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0), 0)
+
+
+def as_f32(x):
+    """float, or float32 CUDA tensor [n_voices] -> zh_f32."""
+    if isinstance(x, abi.F32):
+        return x
+    if isinstance(x, torch.Tensor):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 1 and x.is_contiguous()):
+            raise ValueError("per-voice f32 parameter must be a contiguous float32 CUDA tensor [n_voices]")
+        f = abi.F32(0.0, 0, x.data_ptr())
+        f._keep = x
+        return f
+    return abi.F32(float(x), 0, None)
+
+
+def as_bool(x):
+    """bool, or uint8/bool CUDA tensor [n_voices] -> zh_bool."""
+    if isinstance(x, abi.Bool):
+        return x
+    if isinstance(x, torch.Tensor):
+        if x.dtype == torch.bool:
+            x = x.view(torch.uint8)
+        if not (x.is_cuda and x.dtype == torch.uint8 and x.dim() == 1 and x.is_contiguous()):
+            raise ValueError("per-voice bool parameter must be a contiguous uint8/bool CUDA tensor [n_voices]")
+        b = abi.Bool(0, 0, x.data_ptr())
+        b._keep = x
+        return b
+    return abi.Bool(1 if x else 0, 0, None)

@@ -1,0 +1,103 @@
+"""Host-side mirror of the `zang` namespace used on the paint path (src/zang.zig:1-41):
+Span, the basics.zig buffer ops, ConstantOrBuffer and PaintCurve -- same names and
+argument order as the reference, acting on [frame][voice] device images of many voices.
+"""
+from dataclasses import dataclass
+
+from . import abi
+from .runtime import as_buf, as_bool, as_f32, default_context
+
+
+@dataclass(frozen=True)
+class Span:
+    """zang.Span (src/zang/basics.zig:3-10)."""
+    start: int
+    end: int
+
+    @staticmethod
+    def init(start, end):
+        return Span(start, end)
+
+
+# ---- ConstantOrBuffer (src/zang/constant_or_buffer.zig:4-15)
+def constant(x):
+    return abi.Cob(abi.COB_CONSTANT, 0, as_f32(x), abi.Buf())
+
+
+def buffer(buf):
+    c = abi.Cob(abi.COB_BUFFER, 0, abi.F32(), as_buf(buf))
+    c._keep = buf
+    return c
+
+
+# ---- PaintCurve (src/zang/painter.zig:25-30)
+class PaintCurve:
+    instantaneous = abi.Curve(abi.CURVE_INSTANTANEOUS, 0, abi.F32())
+
+    @staticmethod
+    def linear(duration):
+        return abi.Curve(abi.CURVE_LINEAR, 0, as_f32(duration))
+
+    @staticmethod
+    def squared(duration):
+        return abi.Curve(abi.CURVE_SQUARED, 0, as_f32(duration))
+
+    @staticmethod
+    def cubed(duration):
+        return abi.Curve(abi.CURVE_CUBED, 0, as_f32(duration))
+
+
+def _ctx(ctx):
+    return ctx or default_context()
+
+
+# ---- basics.zig:12-78, same names/argument order
+def zero(span, dest, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_zero(c.handle, span.start, span.end, as_buf(dest)), "zh_zero")
+
+
+def set(span, dest, a, ctx=None):  # noqa: A001 (mirrors zang.set)
+    c = _ctx(ctx); abi.check(c.lib.zh_set(c.handle, span.start, span.end, as_buf(dest), as_f32(a)), "zh_set")
+
+
+def copy(span, dest, src, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_copy(c.handle, span.start, span.end, as_buf(dest), as_buf(src)), "zh_copy")
+
+
+def add(span, dest, a, b, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_add(c.handle, span.start, span.end, as_buf(dest), as_buf(a), as_buf(b)), "zh_add")
+
+
+def addInto(span, dest, src, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_add_into(c.handle, span.start, span.end, as_buf(dest), as_buf(src)), "zh_add_into")
+
+
+def addScalar(span, dest, a, b, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_add_scalar(c.handle, span.start, span.end, as_buf(dest), as_buf(a), as_f32(b)), "zh_add_scalar")
+
+
+def addScalarInto(span, dest, a, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_add_scalar_into(c.handle, span.start, span.end, as_buf(dest), as_f32(a)), "zh_add_scalar_into")
+
+
+def multiply(span, dest, a, b, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_multiply(c.handle, span.start, span.end, as_buf(dest), as_buf(a), as_buf(b)), "zh_multiply")
+
+
+def multiplyWith(span, dest, a, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_multiply_with(c.handle, span.start, span.end, as_buf(dest), as_buf(a)), "zh_multiply_with")
+
+
+def multiplyScalar(span, dest, a, b, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_multiply_scalar(c.handle, span.start, span.end, as_buf(dest), as_buf(a), as_f32(b)), "zh_multiply_scalar")
+
+
+def multiplyWithScalar(span, dest, a, ctx=None):
+    c = _ctx(ctx); abi.check(c.lib.zh_multiply_with_scalar(c.handle, span.start, span.end, as_buf(dest), as_f32(a)), "zh_multiply_with_scalar")
+
+
+def mixdownVoices(span, dst, src, zero_first=False, ctx=None):
+    """dst[f] += sum over voices of src[f][v]: V x zang.addInto onto one mix buffer."""
+    c = _ctx(ctx)
+    abi.check(c.lib.zh_mixdown_voices(c.handle, span.start, span.end, dst.data_ptr(), as_buf(src),
+                                      abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD), "zh_mixdown_voices")
