@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline sample length")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     return ap.parse_args()
 
 
@@ -68,7 +69,7 @@ class Workload:
             self.m = mod.PulseOsc(V, ctx)
             self.ring = [ctx.image(F, V) for _ in range(nring)]
             self.params = self.m.Params(SR, zang.constant(self.freq), self.color)
-            self.kernel = "k_pulseosc_const"
+            self.kernel = "k_pulseosc_const4"
             self.step = self._step_pulse
         elif name == "noise_filter":
             self.noise = mod.Noise(V, ctx, first_seed=first_voice)
@@ -95,6 +96,13 @@ class Workload:
             self.nsteps = 0
         self.nring = len(self.ring)
         self.i = 0
+
+    def graph_steps(self):
+        """Steps per captured graph: a whole number of ring rotations, even (see bench main)."""
+        if self.name in ("nice", "nice_mix"):
+            return 48                       # the note on/off pattern repeats every 48 buffers
+        g = max(self.nring, 2)
+        return g if g % 2 == 0 else 2 * g
 
     def _next(self):
         o = self.ring[self.i]
@@ -176,43 +184,57 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        wl.step()
+    def make_event():
+        h = C.c_void_p()
+        abi.check(lib.zh_event_create(ctx.handle, C.byref(h)), "zh_event_create")
+        return h
+
+    # The per-buffer loop is launch-bound at 4096 voices (a 16 MiB paint takes ~6 us on the
+    # device, a Python->C->hipLaunchKernel call about as long), so G consecutive steps are
+    # captured once into a hipGraph and replayed; G = the output ring length (even, so the
+    # oscillator's double-buffered state ends where it started in the capture).
+    G = wl.graph_steps() if not args.eager else 0
+    graph = None
+    if G:
+        for _ in range(G):          # one eager pass first: lazy allocations happen outside capture
+            wl.step()
+        torch.cuda.synchronize()
+        graph = ctx.capture(lambda: [wl.step() for _ in range(G)])
+
+    def run_steps(n):
+        done = 0
+        if graph is not None:
+            while n - done >= G:
+                graph.launch()
+                done += G
+        for _ in range(n - done):
+            wl.step()
+
+    ev0, ev1 = make_event(), make_event()
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
+    # HIP events on the launch stream bracket exactly the K timed steps: device time per
+    # launch = elapsed / K (includes the ~1 us inter-kernel boundaries, so it can only
+    # under-state the kernel's own rate; profiles/ holds the rocprofv3 per-kernel average).
+    abi.check(lib.zh_event_record(ctx.handle, ev0), "zh_event_record")
+    run_steps(args.steps)
+    abi.check(lib.zh_event_record(ctx.handle, ev1), "zh_event_record")
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ms = C.c_float()
+    abi.check(lib.zh_event_elapsed_ms(ev0, ev1, C.byref(ms)), "zh_event_elapsed_ms")
+    step_ms_events = ms.value / args.steps
+    lib.zh_event_destroy(ev0)
+    lib.zh_event_destroy(ev1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # Kernel duration with HIP events on the launch stream: one event pair per launch over a
-    # second pass of the same K steps (the dominant kernel is the last launch of a step).
-    evs = []
-    for _ in range(2 * args.steps):
-        h = C.c_void_p()
-        abi.check(lib.zh_event_create(ctx.handle, C.byref(h)), "event")
-        evs.append(h)
-    for k in range(args.steps):
-        abi.check(lib.zh_event_record(ctx.handle, evs[2 * k]), "rec")
-        wl.step()
-        abi.check(lib.zh_event_record(ctx.handle, evs[2 * k + 1]), "rec")
-    torch.cuda.synchronize()
-    tot_ms = 0.0
-    ms = C.c_float()
-    for k in range(args.steps):
-        abi.check(lib.zh_event_elapsed_ms(evs[2 * k], evs[2 * k + 1], C.byref(ms)), "elapsed")
-        tot_ms += ms.value
-    for h in evs:
-        lib.zh_event_destroy(h)
-    step_ms_events = tot_ms / args.steps
 
     total_units = world * V * F * args.steps
     value = total_units / elapsed
@@ -223,7 +245,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, zero+paint per 1024-frame buffer, 48 kHz",
-                   "voices_per_gpu": V, "frames": F, "ring_images": wl.nring, "parallelism": f"voices sharded x{world}"},
+                   "voices_per_gpu": V, "frames": F, "ring_images": wl.nring, "launch": "eager" if graph is None else f"hipGraph x{G} steps", "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": wl.kernel,
                      "algorithmic_bytes_per_launch": wl.bytes_per_step, "launch_ms_hip_events": step_ms_events},

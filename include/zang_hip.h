@@ -89,6 +89,17 @@ ZH_API int  zh_buf_download_voices(zh_ctx *ctx, float *host_voice_major, zh_buf 
 ZH_API int  zh_buf_upload_voice(zh_ctx *ctx, zh_buf dst, uint32_t voice, const float *host, uint32_t frames);
 ZH_API int  zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, uint32_t frames);
 
+/* hipGraph capture of a launch sequence: everything enqueued on the context between begin and
+ * end is recorded instead of run; zh_graph_launch replays it with one host call.  A buffer
+ * loop (zero + paint + mix per 1024-frame buffer) is launch-bound at small voice counts, and
+ * this removes the per-kernel host cost.  Capture an EVEN number of paints of any chunked
+ * oscillator module (its state is double-buffered and flips per paint). */
+typedef struct zh_graph zh_graph;
+ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
+ZH_API int  zh_graph_end_capture(zh_ctx *ctx, zh_graph **out);
+ZH_API int  zh_graph_launch(zh_ctx *ctx, zh_graph *graph);
+ZH_API int  zh_graph_destroy(zh_graph *graph);
+
 /* timing helpers: HIP events on the context's stream (used by bench.py) */
 typedef struct zh_event zh_event;
 ZH_API int  zh_event_create(zh_ctx *ctx, zh_event **out);

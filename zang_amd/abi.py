@@ -155,6 +155,10 @@ SIGNATURES = {
     "zh_buf_download_voices": (C.c_int, [vp, vp, Buf, u32]),
     "zh_buf_upload_voice": (C.c_int, [vp, Buf, u32, vp, u32]),
     "zh_buf_download_voice": (C.c_int, [vp, vp, Buf, u32, u32]),
+    "zh_graph_begin_capture": (C.c_int, [vp]),
+    "zh_graph_end_capture": (C.c_int, [vp, P(vp)]),
+    "zh_graph_launch": (C.c_int, [vp, vp]),
+    "zh_graph_destroy": (C.c_int, [vp]),
     "zh_event_create": (C.c_int, [vp, P(vp)]),
     "zh_event_destroy": (C.c_int, [vp]),
     "zh_event_record": (C.c_int, [vp, vp]),

@@ -15,6 +15,11 @@ struct zh_ctx {
     size_t mix_partials_floats;
 };
 
+struct zh_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
 struct zh_event {
     hipEvent_t ev;
 };
@@ -86,3 +91,42 @@ template <typename T> static inline int dev_alloc(T **p, size_t count) {
     hipError_t e = hipMalloc((void **)p, count * sizeof(T));
     return e == hipSuccess ? ZH_OK : (int)e;
 }
+
+// ---- streaming image stores -------------------------------------------------------------
+// A paint kernel leaves its whole output image dirty in the XCD L2s; with plain stores that
+// data is written back at the kernel boundary, AFTER the compute phase (MI355X_MICROARCH.md
+// price list, row "boundary": + bytes / 6 TB/s).  Write-through (sc1) stores drain to HBM
+// while the kernel is still computing.  StoreMode selects the flavour (ZH_STORE_MODE env).
+enum StoreMode { ST_PLAIN = 0, ST_NT = 1, ST_SC1 = 2, ST_SC0SC1 = 3 };
+
+typedef float zv4f __attribute__((ext_vector_type(4)));
+typedef unsigned int zv4u __attribute__((ext_vector_type(4)));
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t zh_rsrc_t;
+// A buffer descriptor over [base, base + bytes): base must be wave-uniform.
+__device__ __forceinline__ zh_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+template <int SM>
+__device__ __forceinline__ void store4(float *p, zh_rsrc_t rsrc, uint32_t byte_off, zv4f v) {
+    if constexpr (SM == ST_PLAIN) *reinterpret_cast<zv4f *>(p) = v;
+    else if constexpr (SM == ST_NT) __builtin_nontemporal_store(v, reinterpret_cast<zv4f *>(p));
+    else if constexpr (SM == ST_SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zv4u, v), rsrc, byte_off, 0, 16);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zv4u, v), rsrc, byte_off, 0, 17);
+}
+template <int SM>
+__device__ __forceinline__ void store1(float *p, zh_rsrc_t rsrc, uint32_t byte_off, float v) {
+    if constexpr (SM == ST_PLAIN) *p = v;
+    else if constexpr (SM == ST_NT) __builtin_nontemporal_store(v, p);
+    else if constexpr (SM == ST_SC1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, byte_off, 0, 16);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, byte_off, 0, 17);
+}
+#else   // host pass: kernels are only parsed, never run
+typedef int zh_rsrc_t;
+__device__ inline zh_rsrc_t make_rsrc(const void *, uint32_t) { return 0; }
+template <int SM> __device__ inline void store4(float *, zh_rsrc_t, uint32_t, zv4f) {}
+template <int SM> __device__ inline void store1(float *, zh_rsrc_t, uint32_t, float) {}
+#endif
+
+int zh_store_mode();   // ctx.hip: ZH_STORE_MODE env (default ST_SC1)

@@ -2,6 +2,17 @@
 #include "common.cuh"
 #include <string.h>
 #include <vector>
+#include <stdlib.h>
+
+int zh_store_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("ZH_STORE_MODE");
+        mode = e ? atoi(e) : ST_SC1;
+        if (mode < 0 || mode > 3) mode = ST_SC1;
+    }
+    return mode;
+}
 
 extern "C" {
 
@@ -155,6 +166,40 @@ int zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, 
     if (!ctx || !src.ptr || !host || frames > src.frames || voice >= src.voices) return ZH_ERR_INVALID;
     ZH_TRY(hipMemcpy2DAsync(host, 4, src.ptr + voice, (size_t)src.stride * 4, 4, frames, hipMemcpyDeviceToHost, ctx->stream));
     ZH_TRY(hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+}
+
+int zh_graph_begin_capture(zh_ctx *ctx) {
+    if (!ctx) return ZH_ERR_INVALID;
+    ZH_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return ZH_OK;
+}
+
+int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    ZH_TRY(hipStreamEndCapture(ctx->stream, &g));
+    zh_graph *zg = new (std::nothrow) zh_graph();
+    if (!zg) { hipGraphDestroy(g); return ZH_ERR_INVALID; }
+    zg->graph = g;
+    hipError_t e = hipGraphInstantiate(&zg->exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(g); delete zg; return (int)e; }
+    *out = zg;
+    return ZH_OK;
+}
+
+int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) {
+    if (!ctx || !graph) return ZH_ERR_INVALID;
+    ZH_TRY(hipGraphLaunch(graph->exec, ctx->stream));
+    return ZH_OK;
+}
+
+int zh_graph_destroy(zh_graph *graph) {
+    if (!graph) return ZH_ERR_INVALID;
+    hipGraphExecDestroy(graph->exec);
+    hipGraphDestroy(graph->graph);
+    delete graph;
     return ZH_OK;
 }
 

@@ -35,37 +35,38 @@ struct zh_trisawosc {
 // ------------------------------------------------------------------ PulseOsc
 struct PulseK {           // per-voice constants of PulseOsc.zig:88-95
     uint32_t ifreq, brpt;
-    float gdf, col, cc121, cc212;
+    float gdf2 /* gdf * 2.0 */, col, cc121, cc212;
 };
 
-__device__ __forceinline__ PulseK pulse_setup(float sample_rate, float freq, float color) {
-    PulseK k;
-    const float SRfcobasefrq = 4294967296.0f / sample_rate;
-    k.ifreq = zf32_to_u32(SRfcobasefrq * freq);
-    k.brpt = zftou32(zclamp01(color));
+// `srf` = fc32bit / sample_rate (PulseOsc.zig:87) is wave-uniform: the host computes it once
+// (IEEE f32 divide, same bits as the device's correctly rounded divide).
+__device__ __forceinline__ void pulse_setup_freq(PulseK &k, float srf, float freq) {
     const float gain = 0.7f;
-    k.gdf = gain / zutof23(k.ifreq);
+    k.ifreq = zf32_to_u32(srf * freq);
+    k.gdf2 = (gain / zutof23(k.ifreq)) * 2.0f;
+    k.cc121 = k.gdf2 * (k.col - 1.0f) + gain;
+    k.cc212 = k.gdf2 * k.col - gain;
+}
+__device__ __forceinline__ void pulse_setup_color(PulseK &k, float color) {
+    k.brpt = zftou32(zclamp01(color));
     k.col = zutof23(k.brpt);
-    k.cc121 = k.gdf * 2.0f * (k.col - 1.0f) + gain;
-    k.cc212 = k.gdf * 2.0f * k.col - gain;
-    return k;
 }
 
-// the 6-way switch of PulseOsc.zig:102-110 as value selects (never a 0/1 blend: gdf may be inf)
+// The 6-way switch of PulseOsc.zig:102-110.  transition = b0 | b1<<1 | b2<<2 with
+// b0 = cnt < brpt, b1 = (cnt - ifreq) < brpt, b2 = cnt < ifreq:
+//   b0 == b1: flat -> 3: gain, 0: -gain, 7: cc121, 4: cc212
+//   b0 != b1: ramp -> 2: gdf*2*(col-p) + gain, 5: gdf*2*p - gain (x - gain == x + (-gain) exactly);
+//             1 and 6 are `unreachable` in the reference: defined as +0.
+// Values are selected, never blended (gdf is inf when ifreq < 512).
 __device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
     const float gain = 0.7f;
     const float p = zutof23(cnt);
-    const uint32_t s0 = cnt < k.brpt ? 1u : 0u;
-    const uint32_t s1 = (uint32_t)(cnt - k.ifreq) < k.brpt ? 2u : 0u;
-    const uint32_t tr = s0 | s1 | (cnt < k.ifreq ? 4u : 0u);
-    float v = 0.0f;                                   // 1 and 6 are unreachable: defined as +0
-    v = tr == 3 ? gain : v;
-    v = tr == 0 ? -gain : v;
-    v = tr == 2 ? k.gdf * 2.0f * (k.col - p) + gain : v;
-    v = tr == 5 ? k.gdf * 2.0f * p - gain : v;
-    v = tr == 7 ? k.cc121 : v;
-    v = tr == 4 ? k.cc212 : v;
-    return v;
+    const bool b0 = cnt < k.brpt;
+    const bool b1 = (uint32_t)(cnt - k.ifreq) < k.brpt;
+    const bool b2 = cnt < k.ifreq;
+    const float ramp = k.gdf2 * (b2 ? p : k.col - p) + (b2 ? -gain : gain);
+    const float flat = b2 ? (b0 ? k.cc121 : k.cc212) : (b0 ? gain : -gain);
+    return (b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f);
 }
 
 // grid: x = 64-voice groups, y = groups of 4 frame chunks; block = 256 = 4 waves, each wave a
@@ -73,16 +74,18 @@ __device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
                                                         uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
-                                                        float sample_rate, F32P freq_p, F32P color_p) {
+                                                        float srf, float sr8, F32P freq_p, F32P color_p) {
     const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (v >= V) return;
     const uint32_t c0 = start + chunk * fc;
     const uint32_t c1 = min(c0 + fc, end);
     const float freq = freq_p.get(v);
-    const bool bad = freq < 0 || freq > sample_rate / 8.0f;          // PulseOsc.zig:82-84
+    const bool bad = freq < 0 || freq > sr8;                          // PulseOsc.zig:82-84
     const uint32_t cnt0 = cnt_in[v];
-    const PulseK k = pulse_setup(sample_rate, freq, color_p.get(v));
+    PulseK k;
+    pulse_setup_color(k, color_p.get(v));
+    pulse_setup_freq(k, srf, freq);
     if (chunk == 0) cnt_out[v] = bad ? cnt0 : cnt0 + (end - start) * k.ifreq;
     if (c0 >= end) return;
     float *o = out.at(c0, v);
@@ -100,27 +103,86 @@ __global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restri
     }
 }
 
+// 4 voices per lane: one 16-byte store per frame (1 KiB per wave-instruction) and four
+// independent dependency chains per lane to cover the VALU->VCC wait states.
+// grid: x = 256-voice groups, y = groups of 4 frame chunks; each of the 4 waves of a block
+// renders a different chunk of the same 256 voices.
+template <bool ZF, int SM>
+__global__ void __launch_bounds__(256) k_pulseosc_const4(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
+                                                         uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
+                                                         float srf, float sr8, F32P freq_p, F32P color_p) {
+    const uint32_t v = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;                                   // V % 4 == 0 on this path
+    const uint32_t c0 = start + chunk * fc;
+    const uint32_t c1 = min(c0 + fc, end);
+    float4 fq = {freq_p.value, freq_p.value, freq_p.value, freq_p.value};
+    float4 cl = {color_p.value, color_p.value, color_p.value, color_p.value};
+    if (freq_p.pv) fq = *reinterpret_cast<const float4 *>(freq_p.pv + v);
+    if (color_p.pv) cl = *reinterpret_cast<const float4 *>(color_p.pv + v);
+    const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt_in + v);
+    const float freq[4] = {fq.x, fq.y, fq.z, fq.w}, color[4] = {cl.x, cl.y, cl.z, cl.w};
+    const uint32_t cnt0[4] = {c4.x, c4.y, c4.z, c4.w};
+    PulseK k[4];
+    uint32_t cnt[4];
+    bool bad[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        bad[j] = freq[j] < 0 || freq[j] > sr8;            // PulseOsc.zig:82-84
+        pulse_setup_color(k[j], color[j]);
+        pulse_setup_freq(k[j], srf, freq[j]);
+        cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq;
+    }
+    if (chunk == 0) {
+        uint4 o;
+        o.x = bad[0] ? cnt0[0] : cnt0[0] + (end - start) * k[0].ifreq;
+        o.y = bad[1] ? cnt0[1] : cnt0[1] + (end - start) * k[1].ifreq;
+        o.z = bad[2] ? cnt0[2] : cnt0[2] + (end - start) * k[2].ifreq;
+        o.w = bad[3] ? cnt0[3] : cnt0[3] + (end - start) * k[3].ifreq;
+        *reinterpret_cast<uint4 *>(cnt_out + v) = o;
+    }
+    if (c0 >= end) return;
+    float *o = out.at(c0, v);
+    const size_t os = out.stride;
+    // descriptor over this wave's rows [c0, c1) of the image (wave-uniform base)
+    const uint32_t wchunk = __builtin_amdgcn_readfirstlane(chunk);
+    const uint32_t wc0 = start + wchunk * fc;
+    const zh_rsrc_t rsrc = make_rsrc(out.p + (size_t)wc0 * out.stride, (uint32_t)((size_t)fc * out.stride * 4));
+    uint32_t boff = v * 4;
+#pragma unroll 2
+    for (uint32_t i = c0; i < c1; i++, o += os, boff += (uint32_t)os * 4) {
+        zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!ZF) acc = *reinterpret_cast<const zv4f *>(o);
+        float val[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            val[j] = pulse_sample(k[j], cnt[j]);
+            cnt[j] += k[j].ifreq;
+        }
+        // a silent voice (bad freq) paints nothing: out unchanged (ADD) / zero (ZERO_FIRST)
+        acc.x = bad[0] ? acc.x : acc.x + val[0];
+        acc.y = bad[1] ? acc.y : acc.y + val[1];
+        acc.z = bad[2] ? acc.z : acc.z + val[2];
+        acc.w = bad[3] ? acc.w : acc.w + val[3];
+        store4<SM>(o, rsrc, boff, acc);
+    }
+}
+
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restrict__ cnt_io, uint32_t V, Img out,
-                                                             uint32_t start, uint32_t end, float sample_rate,
+                                                             uint32_t start, uint32_t end, float srf, float sr8,
                                                              CImg freq_b, F32P color_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
     uint32_t cnt = cnt_io[v];
-    const float SRfcobasefrq = 4294967296.0f / sample_rate;
     PulseK k;
-    k.brpt = zftou32(zclamp01(color_p.get(v)));
-    k.col = zutof23(k.brpt);
-    const float gain = 0.7f;
+    pulse_setup_color(k, color_p.get(v));
     const float *ins[1] = {freq_b.p + v};
     const size_t istr[1] = {freq_b.stride};
     frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
         const float s_freq = x[0];
-        if (s_freq < 0 || s_freq > sample_rate / 8.0f) return false;  // PulseOsc.zig:134-135
-        k.ifreq = zf32_to_u32(SRfcobasefrq * s_freq);
-        k.gdf = gain / zutof23(k.ifreq);
-        k.cc121 = k.gdf * 2.0f * (k.col - 1.0f) + gain;
-        k.cc212 = k.gdf * 2.0f * k.col - gain;
+        if (s_freq < 0 || s_freq > sr8) return false;                 // PulseOsc.zig:134-135
+        pulse_setup_freq(k, srf, s_freq);
         val = pulse_sample(k, cnt);
         cnt += k.ifreq;
         return true;
@@ -227,18 +289,26 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict_
     t_io[v] = t - truncf(t);                                          // :155
 }
 
-// Frames per lane for the chunked kernels: enough chunks to put >= 8 waves on every SIMD
-// (256 CUs x 4 SIMDs x 8 = 8192 waves), but at least 8 frames so the per-voice setup
-// (two divides) is amortised.  ZH_OSC_FC overrides for experiments.
-static uint32_t osc_frames_per_lane(uint32_t V, uint32_t nframes) {
-    static int forced = -1;
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// Frames per lane for the chunked kernels: enough chunks to put several waves on every SIMD
+// (256 CUs x 4 SIMDs), but at least 8 frames so the per-voice setup (one divide) is
+// amortised.  ZH_OSC_FC / ZH_OSC_WAVES / ZH_OSC_SCALAR override for experiments.
+static uint32_t osc_frames_per_lane(uint32_t lanes, uint32_t nframes) {
+    static int forced = -1, waves = -1;
     if (forced < 0) { const char *e = getenv("ZH_OSC_FC"); forced = e ? atoi(e) : 0; }
+    if (waves < 0) { const char *e = getenv("ZH_OSC_WAVES"); waves = e ? atoi(e) : 4096; }
     if (forced > 0) return (uint32_t)forced;
-    const uint64_t groups = (V + 63) / 64;
-    uint64_t fc = (groups * nframes) / 8192;
+    const uint64_t groups = (lanes + 63) / 64;
+    uint64_t fc = (groups * nframes) / (uint64_t)waves;
     uint32_t p = 8;
     while (p * 2 <= fc && p < 64) p *= 2;
     return p;
+}
+static bool osc_force_scalar() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ZH_OSC_SCALAR"); v = e ? atoi(e) : 0; }
+    return v != 0;
 }
 
 template <class M> static int osc_common_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs,
@@ -291,18 +361,32 @@ int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     Img out = mk_img(outputs[0]);
+    const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:87
+    const float sr8 = p->sample_rate / 8.0f;              // :82
+    const F32P fq = mk_f32(p->freq.constant), col = mk_f32(p->color);
     if (p->freq.tag == ZH_COB_CONSTANT) {
-        const uint32_t fc = osc_frames_per_lane(m->n, end - start);
-        const uint32_t chunks = (end - start + fc - 1) / fc;
-        dim3 grid((m->n + 63) / 64, (chunks + 3) / 4);
         uint32_t *ci = m->cnt[m->cur], *co = m->cnt[m->cur ^ 1];
-        if (zf) hipLaunchKernelGGL(k_pulseosc_const<true>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
-        else hipLaunchKernelGGL(k_pulseosc_const<false>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
+        const bool vec = m->n % 4 == 0 && outputs[0].stride % 4 == 0 && aligned16(outputs[0].ptr) &&
+                         (!fq.pv || aligned16(fq.pv)) && (!col.pv || aligned16(col.pv)) && !osc_force_scalar();
+        const uint32_t lanes = vec ? m->n / 4 : m->n;
+        const uint32_t fc = osc_frames_per_lane(lanes, end - start);
+        const uint32_t chunks = (end - start + fc - 1) / fc;
+        dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
+        if (vec) {
+#define ZH_LAUNCH_P4(ZF, SM) hipLaunchKernelGGL((k_pulseosc_const4<ZF, SM>), grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, srf, sr8, fq, col)
+            const int sm = ((size_t)fc * outputs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
+            if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_P4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_P4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_P4(true, ST_SC1); else ZH_LAUNCH_P4(true, ST_SC0SC1); }
+            else    { if (sm == ST_PLAIN) ZH_LAUNCH_P4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_P4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_P4(false, ST_SC1); else ZH_LAUNCH_P4(false, ST_SC0SC1); }
+#undef ZH_LAUNCH_P4
+        } else {
+            if (zf) hipLaunchKernelGGL(k_pulseosc_const<true>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, srf, sr8, fq, col);
+            else hipLaunchKernelGGL(k_pulseosc_const<false>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, srf, sr8, fq, col);
+        }
         m->cur ^= 1;
     } else {
         uint32_t *c = m->cnt[m->cur];
-        if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
-        else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+        if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
+        else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
     }
     return zh_launch_status();
 }

@@ -39,11 +39,35 @@ class Context:
             self.lib.zh_destroy(self.handle)
             self.handle = None
 
+    def capture(self, fn):
+        """Record everything fn() enqueues on this context into a hipGraph; returns a Graph."""
+        abi.check(self.lib.zh_graph_begin_capture(self.handle), "zh_graph_begin_capture")
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = self.lib.zh_graph_end_capture(self.handle, C.byref(g))
+        abi.check(rc, "zh_graph_end_capture")
+        return Graph(self, g)
+
     def image(self, frames, voices, fill=None):
         """A [frame][voice] sample image (the device form of `voices` reference []f32 slices)."""
         if fill is None:
             return torch.empty((frames, voices), dtype=torch.float32, device=self.device)
         return torch.full((frames, voices), float(fill), dtype=torch.float32, device=self.device)
+
+
+class Graph:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def launch(self):
+        abi.check(self.ctx.lib.zh_graph_launch(self.ctx.handle, self.handle), "zh_graph_launch")
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.zh_graph_destroy(self.handle)
+            self.handle = None
 
 
 def default_context():

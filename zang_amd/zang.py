@@ -21,7 +21,9 @@ class Span:
 
 # ---- ConstantOrBuffer (src/zang/constant_or_buffer.zig:4-15)
 def constant(x):
-    return abi.Cob(abi.COB_CONSTANT, 0, as_f32(x), abi.Buf())
+    c = abi.Cob(abi.COB_CONSTANT, 0, as_f32(x), abi.Buf())
+    c._keep = x   # ctypes copies the struct by value: keep the tensor behind per_voice alive
+    return c
 
 
 def buffer(buf):
