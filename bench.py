@@ -175,6 +175,10 @@ def main():
         torch.cuda.set_device(0)
     import zang_amd
     from zang_amd import abi
+    # a side stream (graph capture is not allowed on the default stream); every torch
+    # allocation / copy / sync below happens with it current, so ordering is by stream
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
     ctx = zang_amd.Context(local_rank if world > 1 else 0)
     V, F = args.voices, args.frames
     wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20)

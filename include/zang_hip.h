@@ -69,7 +69,8 @@ typedef struct zh_curve { uint32_t tag; uint32_t reserved; zh_f32 duration; } zh
 /* ---------------------------------------------------------------- context, memory */
 ZH_API int  zh_create(zh_ctx **out, int device);
 ZH_API int  zh_destroy(zh_ctx *ctx);
-ZH_API int  zh_set_stream(zh_ctx *ctx, void *hip_stream);   /* adopt an external hipStream_t (NULL = own stream) */
+ZH_API int  zh_set_stream(zh_ctx *ctx, void *hip_stream);   /* adopt an external hipStream_t; NULL = HIP's default (null) stream.
+                                                                 zh_create starts on a private non-blocking stream. */
 ZH_API void *zh_get_stream(zh_ctx *ctx);
 ZH_API int  zh_sync(zh_ctx *ctx);
 ZH_API const char *zh_error_string(int err);

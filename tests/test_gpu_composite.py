@@ -1,0 +1,135 @@
+"""GPU parity: the fused NiceInstrument / PMOscInstrument kernels vs the oracle's UNFUSED
+composition of module paints through temps (examples/modules.zig:101-127, 212-247), and the
+fused mixdown variant."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+F = 1024
+
+# (span, note_on, note_id_changed) per paint: attack -> decay -> sustain -> release -> retrigger
+SCRIPT = [((0, 1024), 1, 1), ((0, 1024), 1, 0), ((0, 500), 1, 0), ((500, 1024), 0, 0), ((0, 1024), 0, 0),
+          ((0, 300), 0, 0), ((300, 1024), 1, 1), ((0, 1024), 1, 0)]
+
+
+def _oracle_nice(po, V, freq, color, script):
+    L = po.lib()
+    outs = []
+    st = [po.NiceInstrument() for _ in range(V)]
+    for v in range(V):
+        L.zo_nice_init(C.byref(st[v]), float(color[v]))
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    for ((s, e), on, nic) in script:
+        out = np.zeros((V, F), np.float32)
+        for v in range(V):
+            L.zo_nice_paint(C.byref(st[v]), s, e, po.fptr(out[v]), po.fptr(t0), po.fptr(t1), nic, SR, float(freq[v]), on)
+        outs.append(out)
+    return outs, st
+
+
+def test_nice_fused_equals_unfused_oracle(ctx, oracle):
+    from zang_amd import modules as mod, zang, workloads
+    V = 320
+    freq, color, _, _ = workloads.voice_params(5, 0, V)
+    freq[:3] = [7000.0, -3.0, 0.5]          # silent / silent / very low
+    refs, rst = _oracle_nice(oracle, V, freq, color, SCRIPT)
+    m = mod.NiceInstrument(V, util.dev(color), ctx)
+    gf = util.dev(freq)
+    for k, ((s, e), on, nic) in enumerate(SCRIPT):
+        out = ctx.image(F, V, fill=0.0)
+        m.paint(zang.Span(s, e), [out], None, bool(nic), m.Params(SR, gf, bool(on)))
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), refs[k], f"nice paint {k}")
+    st = m.state()
+    assert [int(x) for x in st["osc"]["cnt"]] == [r.osc.cnt for r in rst]
+    util.assert_bitexact(st["flt"]["l"].astype(np.float32), np.array([r.flt.l for r in rst], np.float32), "nice flt.l")
+    util.assert_bitexact(st["flt"]["b"].astype(np.float32), np.array([r.flt.b for r in rst], np.float32), "nice flt.b")
+    assert [int(x) for x in st["env"]["state"]] == [r.env.state for r in rst]
+    util.assert_bitexact(st["env"]["last_value"].astype(np.float32), np.array([r.env.painter.last_value for r in rst], np.float32), "nice env")
+
+
+def test_nice_equals_gpu_unfused_modules(ctx):
+    """The fused kernel against the SAME recipe run as separate GPU module paints through
+    device temps (what a reference user would write against this library)."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V = 256
+    freq, color, _, _ = workloads.voice_params(5, 0, V)
+    gf, gc = util.dev(freq), util.dev(color)
+    fused = mod.NiceInstrument(V, gc, ctx)
+    osc, flt, env = mod.PulseOsc(V, ctx), mod.Filter(V, ctx), mod.Envelope(V, ctx)
+    cutoff = mod.Filter.cutoffFromFrequency(gf * 8.0, SR, ctx)
+    t0, t1 = ctx.image(F, V), ctx.image(F, V)
+    for ((s, e), on, nic) in SCRIPT:
+        sp = zang.Span(s, e)
+        a = ctx.image(F, V, fill=0.0); b = ctx.image(F, V, fill=0.0)
+        fused.paint(sp, [a], [t0, t1], bool(nic), fused.Params(SR, gf, bool(on)))
+        zang.zero(sp, t0, ctx=ctx)
+        osc.paint(sp, [t0], [], bool(nic), osc.Params(SR, zang.constant(gf), gc))
+        zang.multiplyWithScalar(sp, t0, 0.5, ctx=ctx)
+        zang.zero(sp, t1, ctx=ctx)
+        flt.paint(sp, [t1], [], bool(nic), flt.Params(t0, flt.low_pass, zang.constant(cutoff), zang.constant(0.7)))
+        zang.zero(sp, t0, ctx=ctx)
+        env.paint(sp, [t0], [], bool(nic), env.Params(SR, zang.PaintCurve.cubed(0.01), zang.PaintCurve.cubed(0.1),
+                                                     zang.PaintCurve.cubed(0.5), 0.8, bool(on)))
+        zang.multiply(sp, b, t0, t1, ctx=ctx)
+        ctx.sync()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_nice_paint_mix(ctx, oracle):
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V = 1000          # not a multiple of 256: tail lanes
+    freq, color, _, _ = workloads.voice_params(5, 7, V)
+    m1 = mod.NiceInstrument(V, util.dev(color), ctx)
+    m2 = mod.NiceInstrument(V, util.dev(color), ctx)
+    gf = util.dev(freq)
+    for ((s, e), on, nic) in SCRIPT:
+        per_voice = ctx.image(F, V, fill=0.0)
+        m1.paint(zang.Span(s, e), [per_voice], None, bool(nic), m1.Params(SR, gf, bool(on)))
+        mix = torch.full((F,), 0.25, dtype=torch.float32, device="cuda")
+        m2.paint_mix(zang.Span(s, e), mix, bool(nic), m2.Params(SR, gf, bool(on)))
+        mix_b = torch.full((F,), 0.25, dtype=torch.float32, device="cuda")
+        ctx.sync()
+        pv = per_voice.cpu().numpy().astype(np.float64)
+        ref = 0.25 + pv.sum(axis=1)
+        ref[:s] = 0.25; ref[e:] = 0.25
+        got = mix.cpu().numpy()
+        bound = 4 * np.sqrt(V) * np.finfo(np.float32).eps * max(np.abs(pv).sum(axis=1).max(), 1.0)
+        assert np.abs(got - ref).max() <= bound
+        assert np.array_equal(got[:s], np.full(s, 0.25, np.float32))
+    assert np.array_equal(m1.state(), m2.state())
+
+
+def test_pmosc_fused_equals_unfused_oracle(ctx, oracle):
+    from zang_amd import modules as mod, zang, workloads
+    V = 192
+    freq, _, u2, _ = workloads.voice_params(4, 0, V)
+    freq = (freq * 0.5).astype(np.float32)
+    rel = (0.05 + 0.4 * u2).astype(np.float32)
+    L = oracle.lib()
+    st = [oracle.PMOscInstrument() for _ in range(V)]
+    for v in range(V):
+        L.zo_pmosc_init(C.byref(st[v]), float(rel[v]))
+    m = mod.PMOscInstrument(V, util.dev(rel), ctx)
+    gf = util.dev(freq)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32); t2 = np.zeros(F, np.float32)
+    for k, ((s, e), on, nic) in enumerate(SCRIPT):
+        ref = np.zeros((V, F), np.float32)
+        for v in range(V):
+            L.zo_pmosc_paint(C.byref(st[v]), s, e, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(t2), nic, SR, float(freq[v]), on)
+        out = ctx.image(F, V, fill=0.0)
+        m.paint(zang.Span(s, e), [out], None, bool(nic), m.Params(SR, gf, bool(on)))
+        ctx.sync()
+        got = util.from_image(out)
+        util.assert_close(got, ref, f"pmosc paint {k}")
+        util.assert_bitexact(got, ref, f"pmosc paint {k} (expected exact)")
+    gs = m.state()
+    util.assert_bitexact(gs["carrier"]["t"].astype(np.float32), np.array([r.carrier.t for r in st], np.float32), "carrier t")
+    util.assert_bitexact(gs["modulator"]["t"].astype(np.float32), np.array([r.modulator.t for r in st], np.float32), "modulator t")

@@ -1,0 +1,345 @@
+"""GPU parity: every stateful/stateless module kernel vs the oracle, through the C ABI.
+
+Bar (BASELINE.json north_star): 1e-5 relative f32 (tests/util.py FLOOR documents the
+zero-crossing floor); Gate and Decimator bit-exact.  In practice every module here is
+bit-exact because the device runs the same published algorithms without FMA contraction;
+the tests assert bit-exactness wherever that holds by construction and additionally state
+the tolerance for the libm-dependent modules (SineOsc, Distortion).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+F = 1024
+SPANS = [util.SPANS_ONE, util.SPANS_THREE]
+
+
+def _cob(po, kind, const_v, buf_v):
+    return po.constant(const_v) if kind == "c" else po.buffer(buf_v)
+
+
+def _gcob(zang, kind, const_t, buf_t):
+    return zang.constant(const_t) if kind == "c" else zang.buffer(buf_t)
+
+
+# ------------------------------------------------------------------ SineOsc
+@pytest.mark.parametrize("fk,pk", [("c", "c"), ("c", "b"), ("b", "c"), ("b", "b")])
+@pytest.mark.parametrize("spans", SPANS)
+def test_sineosc(ctx, oracle, fk, pk, spans):
+    from zang_amd import modules as mod, zang
+    V = 192
+    rng = np.random.default_rng(21)
+    freq = rng.uniform(20, 6000, V).astype(np.float32)
+    phase = rng.uniform(-1, 1, V).astype(np.float32)
+    fbuf = rng.uniform(20, 8000, (V, F)).astype(np.float32)
+    pbuf = rng.uniform(-2, 2, (V, F)).astype(np.float32)
+    out0 = util.rng_buffers(3, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rt = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st))
+        for (s, e) in spans:
+            L.zo_sineosc_paint(C.byref(st), s, e, oracle.fptr(ref[v]), SR, _cob(oracle, fk, freq[v], fbuf[v]), _cob(oracle, pk, phase[v], pbuf[v]))
+        rt[v] = st.t
+    m = mod.SineOsc(V, ctx)
+    out = util.to_image(out0); gf, gp = util.to_image(fbuf), util.to_image(pbuf)
+    cf, cp = util.dev(freq), util.dev(phase)
+    for (s, e) in spans:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(SR, _gcob(zang, fk, cf, gf), _gcob(zang, pk, cp, gp)))
+    ctx.sync()
+    got = util.from_image(out)
+    util.assert_close(got, ref, "sineosc")
+    util.assert_bitexact(got, ref, "sineosc (same algorithm, expected exact)")
+    util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sineosc t")
+
+
+def test_sineosc_large_phase_and_nan(ctx, oracle):
+    """Arguments beyond 2^28*pi/2 take the Payne-Hanek path; inf/NaN give NaN."""
+    from zang_amd import modules as mod, zang
+    V = 64
+    phase = (np.random.default_rng(5).uniform(1, 2, V) * 2.0 ** np.random.default_rng(6).integers(20, 100, V)).astype(np.float32)
+    phase[0], phase[1], phase[2] = np.inf, np.nan, -1e30
+    L = oracle.lib()
+    ref = np.zeros((V, 16), np.float32)
+    for v in range(V):
+        st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st))
+        L.zo_sineosc_paint(C.byref(st), 0, 16, oracle.fptr(ref[v]), SR, oracle.constant(440.0), oracle.constant(phase[v]))
+    m = mod.SineOsc(V, ctx)
+    out = ctx.image(16, V)
+    m.paint(zang.Span(0, 16), [out], [], False, m.Params(SR, zang.constant(440.0), zang.constant(util.dev(phase))), zero_first=True)
+    ctx.sync()
+    got = util.from_image(out)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    util.assert_bitexact(got[ok], ref[ok], "sineosc huge args")
+
+
+# ------------------------------------------------------------------ Noise
+@pytest.mark.parametrize("color", [0, 1])
+def test_noise(ctx, oracle, color):
+    """Three consecutive paints: pink must restart its taps each paint (Noise.zig:68 quirk)."""
+    from zang_amd import modules as mod, zang
+    V, first = 256, 1000
+    out0 = util.rng_buffers(8, V, F)
+    L = oracle.lib()
+    ref = out0.copy()
+    rstate = []
+    for v in range(V):
+        st = oracle.Noise(); L.zo_noise_init(C.byref(st), first + v)
+        for (s, e) in util.SPANS_THREE:
+            L.zo_noise_paint(C.byref(st), s, e, oracle.fptr(ref[v]), color)
+        rstate.append(list(st.r))
+    m = mod.Noise(V, ctx, first_seed=first)
+    out = util.to_image(out0)
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(color))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"noise color {color}")
+    gs = m.state()
+    assert [[int(x) for x in row] for row in gs["r"]] == rstate
+    assert not gs["b"].any()
+
+
+def test_noise_seed_known_answer(ctx):
+    """K1 of SURVEY.md 8c: seed 0 / seed 1 white samples."""
+    from zang_amd import modules as mod, zang
+    m = mod.Noise(2, ctx, first_seed=0)
+    out = ctx.image(4, 2)
+    m.paint(zang.Span(0, 4), [out], [], False, m.Params(m.white), zero_first=True)
+    ctx.sync()
+    got = util.from_image(out)
+    k = np.array([[-0.4564839005470276, -0.4967494606971741, -0.3965456485748291, -0.9767617583274841],
+                  [0.02937638759613037, 0.49904024600982666, -0.8330492973327637, 0.6042125225067139]], np.float32)
+    util.assert_bitexact(got, k, "noise K1")
+
+
+# ------------------------------------------------------------------ Envelope
+def _env_case(oracle, ctx, V, curves, sustain, script, dur_scale=1.0):
+    """script: list of (span, note_on[V] bool array, note_id_changed[V] bool array)."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(31)
+    dur = [(rng.uniform(0.0005, 0.02, V) * dur_scale).astype(np.float32) for _ in range(3)]
+    sus = np.full(V, sustain, np.float32)
+    out0 = util.rng_buffers(9, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rst = []
+    for v in range(V):
+        st = oracle.Envelope(); L.zo_envelope_init(C.byref(st))
+        for ((s, e), on, nic) in script:
+            p = oracle.EnvelopeParams(SR, oracle.curve(curves[0], dur[0][v]), oracle.curve(curves[1], dur[1][v]),
+                                      oracle.curve(curves[2], dur[2][v]), float(sus[v]), int(on[v]))
+            L.zo_envelope_paint(C.byref(st), s, e, oracle.fptr(ref[v]), int(nic[v]), C.byref(p))
+        rst.append((st.state, st.painter.t, st.painter.last_value, st.painter.start))
+    m = mod.Envelope(V, ctx)
+    out = util.to_image(out0)
+    mk = [None, zang.PaintCurve.linear, zang.PaintCurve.squared, zang.PaintCurve.cubed]
+    gc = [zang.PaintCurve.instantaneous if curves[i] == 0 else mk[curves[i]](util.dev(dur[i])) for i in range(3)]
+    gs = util.dev(sus)
+    for ((s, e), on, nic) in script:
+        m.paint(zang.Span(s, e), [out], [], util.dev(nic.astype(np.uint8)),
+                m.Params(SR, gc[0], gc[1], gc[2], gs, util.dev(on.astype(np.uint8))))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"envelope {curves}")
+    st = m.state()
+    assert [int(x) for x in st["state"]] == [r[0] for r in rst]
+    for name, k in (("t", 1), ("last_value", 2), ("start", 3)):
+        util.assert_bitexact(st[name].astype(np.float32), np.array([r[k] for r in rst], np.float32), f"envelope {name}")
+
+
+@pytest.mark.parametrize("curves", [(1, 1, 1), (2, 2, 2), (3, 3, 3), (0, 3, 3), (3, 0, 3), (3, 3, 0), (0, 0, 0)])
+@pytest.mark.parametrize("sustain", [0.5, 1.0])
+def test_envelope_stages(ctx, oracle, curves, sustain):
+    V = 128
+    rng = np.random.default_rng(41)
+    on = np.ones(V, bool); off = np.zeros(V, bool)
+    new = np.ones(V, bool); same = np.zeros(V, bool)
+    mixed_on = rng.random(V) < 0.5
+    # note_on voices whose envelope is in `release` need a new note id (the reference asserts it)
+    script = [((0, 200), on, new), ((200, 777), on, same), ((777, 1024), mixed_on, same),
+              ((0, 1024), off, same), ((0, 300), mixed_on, mixed_on), ((300, 300), on, new), ((300, 1024), off, same)]
+    _env_case(oracle, ctx, V, curves, sustain, script)
+
+
+def test_envelope_off_while_idle_and_release_note_on(ctx, oracle):
+    """paintOff while idle paints nothing (Envelope.zig:78-80); note_on during release without a
+    new note id is the reference's assert case -- defined as painting nothing."""
+    V = 64
+    on = np.ones(V, bool); off = np.zeros(V, bool); new = np.ones(V, bool); same = np.zeros(V, bool)
+    script = [((0, 512), off, same), ((0, 100), on, new), ((100, 150), off, same), ((150, 400), on, same), ((400, 1024), on, new)]
+    _env_case(oracle, ctx, V, (3, 3, 3), 0.8, script, dur_scale=4.0)
+
+
+# ------------------------------------------------------------------ Gate
+def test_gate_bitexact(ctx, oracle):
+    from zang_amd import modules as mod, zang
+    V = 200
+    on = np.random.default_rng(2).random(V) < 0.5
+    out0 = util.rng_buffers(4, V, F)
+    ref = out0.copy()
+    L = oracle.lib()
+    for v in range(V):
+        L.zo_gate_paint(10, 1000, oracle.fptr(ref[v]), int(on[v]))
+    m = mod.Gate(V, ctx)
+    out = util.to_image(out0)
+    m.paint(zang.Span(10, 1000), [out], [], False, m.Params(util.dev(on.astype(np.uint8))))
+    out2 = util.to_image(out0)
+    m.paint(zang.Span(10, 1000), [out2], [], False, m.Params(util.dev(on.astype(np.uint8))), zero_first=True)
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "gate")
+    ref2 = out0.copy(); ref2[:, 10:1000] = on[:, None].astype(np.float32)
+    util.assert_bitexact(util.from_image(out2), ref2, "gate zero_first")
+
+
+# ------------------------------------------------------------------ Filter
+@pytest.mark.parametrize("ftype", range(6))
+@pytest.mark.parametrize("ck,rk", [("c", "c"), ("c", "b"), ("b", "c"), ("b", "b")])
+def test_filter(ctx, oracle, ftype, ck, rk):
+    from zang_amd import modules as mod, zang
+    V = 128
+    rng = np.random.default_rng(51)
+    cut = rng.uniform(-0.1, 1.1, V).astype(np.float32)       # outside [0,1]: clamped
+    res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+    cbuf = rng.uniform(-0.1, 1.1, (V, F)).astype(np.float32)
+    rbuf = rng.uniform(-0.1, 1.1, (V, F)).astype(np.float32)
+    inp = util.rng_buffers(52, V, F)
+    out0 = util.rng_buffers(53, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rl = np.zeros(V, np.float32); rb = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st))
+        for (s, e) in util.SPANS_THREE:
+            L.zo_filter_paint(C.byref(st), s, e, oracle.fptr(ref[v]), oracle.fptr(inp[v]), ftype,
+                              _cob(oracle, ck, cut[v], cbuf[v]), _cob(oracle, rk, res[v], rbuf[v]))
+        rl[v], rb[v] = st.l, st.b
+    m = mod.Filter(V, ctx)
+    out = util.to_image(out0); gi = util.to_image(inp); gc, gr = util.to_image(cbuf), util.to_image(rbuf)
+    dc, dr = util.dev(cut), util.dev(res)
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(gi, ftype, _gcob(zang, ck, dc, gc), _gcob(zang, rk, dr, gr)))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"filter type {ftype}")
+    st = m.state()
+    util.assert_bitexact(st["l"].astype(np.float32), rl, "filter l")
+    util.assert_bitexact(st["b"].astype(np.float32), rb, "filter b")
+
+
+def test_filter_known_answer_and_cutoff(ctx, oracle):
+    """K3 of SURVEY.md 8c and Filter.cutoffFromFrequency vs the oracle."""
+    from zang_amd import modules as mod, zang
+    m = mod.Filter(1, ctx)
+    inp = util.to_image(np.array([[1, 0, 0, 0, 0, 0]], np.float32)); out = ctx.image(6, 1)
+    m.paint(zang.Span(0, 6), [out], [], False, m.Params(inp, m.low_pass, zang.constant(0.5), zang.constant(0.7)), zero_first=True)
+    ctx.sync()
+    k3 = np.array([[0.2499980926513672, 0.8275015354156494, 0.5310308337211609, -0.1411801278591156,
+                    -0.5050814747810364, -0.3323642313480377]], np.float32)
+    util.assert_bitexact(util.from_image(out), k3, "filter K3")
+    f = np.random.default_rng(1).uniform(0, 30000, 4096).astype(np.float32)
+    got = mod.Filter.cutoffFromFrequency(util.dev(f), SR, ctx).cpu().numpy()
+    L = oracle.lib()
+    ref = np.array([L.zo_filter_cutoff_from_frequency(float(x), SR) for x in f], np.float32)
+    util.assert_bitexact(got, ref, "cutoffFromFrequency")
+
+
+# ------------------------------------------------------------------ Sampler
+def _pcm(fmt, nframes, channels, seed):
+    rng = np.random.default_rng(seed)
+    bps = fmt + 1
+    return rng.integers(0, 256, nframes * channels * bps, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("fmt", range(4))
+@pytest.mark.parametrize("loop", [False, True])
+def test_sampler(ctx, oracle, fmt, loop):
+    """Per-voice output rates cover: ratio ~ 1 (integer copy), up/down-sampling, negative ratio."""
+    from zang_amd import modules as mod, zang
+    V, channels, in_rate = 96, 2, 44100
+    data = _pcm(fmt, 700, channels, 60 + fmt)
+    rng = np.random.default_rng(61)
+    rate = rng.uniform(8000, 96000, V).astype(np.float32)
+    rate[:8] = [44100.0, 44100.5, 44099.0, -44100.0, -22050.0, 22050.0, 88200.0, 44100.0]
+    nic_script = [np.zeros(V, bool), rng.random(V) < 0.3, np.zeros(V, bool)]
+    out0 = util.rng_buffers(62, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rt = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.Sampler(); L.zo_sampler_init(C.byref(st))
+        for k, (s, e) in enumerate(util.SPANS_THREE):
+            p = oracle.SamplerParams(float(rate[v]), channels, in_rate, fmt, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, 1, int(loop))
+            L.zo_sampler_paint(C.byref(st), s, e, oracle.fptr(ref[v]), int(nic_script[k][v]), C.byref(p))
+        rt[v] = st.t
+    m = mod.Sampler(V, ctx)
+    out = util.to_image(out0)
+    smp = m.Sample(channels, in_rate, fmt, util.dev(data))
+    gr = util.dev(rate)
+    for k, (s, e) in enumerate(util.SPANS_THREE):
+        m.paint(zang.Span(s, e), [out], [], util.dev(nic_script[k].astype(np.uint8)), m.Params(gr, smp, 1, loop))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"sampler fmt {fmt} loop {loop}")
+    util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sampler t")
+
+
+def test_sampler_channel_out_of_range(ctx):
+    from zang_amd import modules as mod, zang
+    m = mod.Sampler(8, ctx)
+    data = util.dev(_pcm(1, 64, 1, 3))
+    out = ctx.image(32, 8, fill=2.0)
+    st = m.state(); st["t"] = 5.0
+    m.set_state(st)
+    m.paint(zang.Span(0, 32), [out], [], True, m.Params(44100.0, m.Sample(1, 44100, 1, data), 1, False))
+    ctx.sync()
+    assert float(out.min()) == 2.0 and float(out.max()) == 2.0
+    assert (m.state()["t"] == 5.0).all()           # Sampler.zig:87-89 returns before the reset
+
+
+# ------------------------------------------------------------------ Decimator
+def test_decimator_bitexact(ctx, oracle):
+    from zang_amd import modules as mod, zang
+    V = 160
+    rng = np.random.default_rng(71)
+    fake = rng.uniform(100, 47000, V).astype(np.float32)
+    fake[:6] = [48000.0, 96000.0, 0.0, -5.0, 24000.0, 6000.0]
+    inp = util.rng_buffers(72, V, F); out0 = util.rng_buffers(73, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rs = np.zeros((V, 2), np.float32)
+    for v in range(V):
+        st = oracle.Decimator(); L.zo_decimator_init(C.byref(st))
+        for (s, e) in util.SPANS_THREE:
+            L.zo_decimator_paint(C.byref(st), s, e, oracle.fptr(ref[v]), SR, oracle.fptr(inp[v]), float(fake[v]))
+        rs[v] = (st.dval, st.dcount)
+    m = mod.Decimator(V, ctx)
+    out = util.to_image(out0); gi = util.to_image(inp); gf = util.dev(fake)
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(SR, gi, gf))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "decimator")
+    st = m.state()
+    util.assert_bitexact(st["dval"].astype(np.float32), rs[:, 0].copy(), "dval")
+    util.assert_bitexact(st["dcount"].astype(np.float32), rs[:, 1].copy(), "dcount")
+
+
+# ------------------------------------------------------------------ Distortion
+@pytest.mark.parametrize("dtype_", [0, 1])
+def test_distortion(ctx, oracle, dtype_):
+    from zang_amd import modules as mod, zang
+    V = 192
+    rng = np.random.default_rng(81)
+    ingain = rng.uniform(0, 1, V).astype(np.float32); outgain = rng.uniform(0, 1, V).astype(np.float32)
+    offset = rng.uniform(-1, 1, V).astype(np.float32)
+    ingain[:4] = [0.25, 0.3125, 0.1875, 0.375]     # pow special cases: y = 0, 0.5, -0.5, 1
+    inp = util.rng_buffers(82, V, F, -3, 3); out0 = util.rng_buffers(83, V, F)
+    L = oracle.lib()
+    ref = out0.copy()
+    for v in range(V):
+        L.zo_distortion_paint(5, 1000, oracle.fptr(ref[v]), oracle.fptr(inp[v]), dtype_, float(ingain[v]), float(outgain[v]), float(offset[v]))
+    m = mod.Distortion(V, ctx)
+    out = util.to_image(out0)
+    m.paint(zang.Span(5, 1000), [out], [], False, m.Params(util.to_image(inp), dtype_, util.dev(ingain), util.dev(outgain), util.dev(offset)))
+    ctx.sync()
+    got = util.from_image(out)
+    util.assert_close(got, ref, "distortion")
+    util.assert_bitexact(got, ref, "distortion (same algorithm, expected exact)")

@@ -7,7 +7,7 @@ package: importing it without the built library raises.
 """
 from . import abi
 
-abi.load(strict=False)  # TODO strict once every module is in
+abi.load()  # fail loudly if libzang_hip.so is missing or incomplete
 
 from . import zang, modules  # noqa: E402
 from .runtime import Context, default_context  # noqa: E402

@@ -201,6 +201,11 @@ int zh_mix_reserve(zh_ctx *ctx, size_t floats) {
     return ZH_OK;
 }
 
+void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
+    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 255) / 256), dim3(256), 0, ctx->stream, ctx->mix_partials, tiles,
+                       nframes, dst, zero_first);
+}
+
 extern "C" {
 
 int zh_zero(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest) { return launch_ew<OP_ZERO>(ctx, s, e, dest, nullptr, nullptr, nullptr); }

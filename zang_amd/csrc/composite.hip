@@ -1,0 +1,440 @@
+// composite.hip -- the reference's composite instruments as single fused kernels:
+//   NiceInstrument  (examples/modules.zig:189-248)  PulseOsc -> x0.5 -> Filter(LP) -> x Envelope
+//   PMOscInstrument (examples/modules.zig:80-128) over PhaseModOscillator (:6-77)
+// The reference runs each stage as its own loop through `temps` buffers; every hand-off is an
+// exact f32 store/load, so keeping the value in a register instead gives the same bits as
+// the unfused composition -- provided every `zero` + `+=` pair is kept as `0.0f + x` and no
+// multiply-add is fused (-ffp-contract=off).  The two temps of a NiceInstrument voice never
+// touch HBM: per voice-sample the kernel writes 4 B (or nothing, in the mix variant).
+#include "common.cuh"
+#include "zmath.cuh"
+#include "seq.cuh"
+#include "envelope.cuh"
+#include <vector>
+
+// basics.hip
+int zh_mix_reserve(zh_ctx *ctx, size_t floats);
+void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first);
+
+struct zh_nice {
+    zh_ctx *ctx;
+    uint32_t n;
+    float *color;                 // init(color), per voice
+    uint32_t *cnt;                // osc
+    float *fl, *fb;               // flt
+    uint32_t *estate;             // env
+    float *et, *elast, *estart;
+};
+
+struct zh_pmosc {
+    zh_ctx *ctx;
+    uint32_t n;
+    float *release_duration;
+    float *tc, *tm;               // carrier.t, modulator.t
+    uint32_t *estate;
+    float *et, *elast, *estart;
+};
+
+// ------------------------------------------------------------------ NiceInstrument voice
+struct NiceLane {
+    // PulseOsc
+    uint32_t cnt, ifreq, brpt;
+    float gdf2, col, cc121, cc212;
+    bool bad;
+    // Filter
+    float l, b, cut, res;
+    EnvLane env;
+
+    __device__ __forceinline__ void begin(float sample_rate, float srf, float sr8, float freq, float color, bool note_on, bool new_note) {
+        bad = freq < 0 || freq > sr8;                                  // PulseOsc.zig:82-84
+        const float gain = 0.7f;
+        ifreq = zf32_to_u32(srf * freq);
+        brpt = zftou32(zclamp01(color));
+        gdf2 = (gain / zutof23(ifreq)) * 2.0f;
+        col = zutof23(brpt);
+        cc121 = gdf2 * (col - 1.0f) + gain;
+        cc212 = gdf2 * col - gain;
+        // Filter params: cutoff = cutoffFromFrequency(freq * 8, sr), res = 0.7 (examples/modules.zig:231-235)
+        cut = zclampf(zcutoff_from_frequency(freq * 8.0f, sample_rate), 0.0f, 1.0f);
+        res = 1.0f - zclampf(0.7f, 0.0f, 1.0f);
+        // Envelope params (:238-245)
+        env.sample_rate = sample_rate;
+        env.sustain_volume = 0.8f;
+        env.attack = CurveP{ZH_CURVE_CUBED, 0.01f};
+        env.decay = CurveP{ZH_CURVE_CUBED, 0.1f};
+        env.release = CurveP{ZH_CURVE_CUBED, 0.5f};
+        env.note_on = note_on;
+        env.begin(new_note);
+    }
+
+    // one frame of examples/modules.zig:220-246; returns env*flt (the value added to out)
+    __device__ __forceinline__ float frame() {
+        const float gain = 0.7f, fcdcoffset = 3.814697265625e-6f;
+        // temps[0] = 0 (+ pulse) ; temps[0] *= 0.5
+        float t0 = 0.0f;
+        if (!bad) {
+            const float p = zutof23(cnt);
+            const bool b0 = cnt < brpt, b1 = (uint32_t)(cnt - ifreq) < brpt, b2 = cnt < ifreq;
+            const float ramp = gdf2 * (b2 ? p : col - p) + (b2 ? -gain : gain);
+            const float flat = b2 ? (b0 ? cc121 : cc212) : (b0 ? gain : -gain);
+            t0 = 0.0f + ((b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f));
+            cnt += ifreq;
+        }
+        t0 = t0 * 0.5f;                                                // multiplyWithScalar :226
+        // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
+        const float in = t0 + fcdcoffset;
+        l += cut * b - fcdcoffset;
+        b += cut * (in - b * res - l);
+        l += cut * b;
+        const float h = in - b * res - l;
+        b += cut * h;
+        const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);
+        // temps[0] = 0 (+ envelope)
+        float ev = 0.0f, e0 = 0.0f;
+        if (env.frame(true, ev)) e0 = 0.0f + ev;
+        return e0 * t1;                                                // multiply :246: out += temps[0]*temps[1]
+    }
+};
+
+struct NiceArgs {
+    float *color;
+    uint32_t *cnt;
+    float *fl, *fb;
+    uint32_t *estate;
+    float *et, *elast, *estart;
+    uint32_t V;
+    float sample_rate, srf, sr8;
+    F32P freq;
+    BoolP note_on, nic;
+};
+
+__device__ __forceinline__ void nice_load(NiceLane &n, const NiceArgs &a, uint32_t v) {
+    n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
+    n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
+    n.begin(a.sample_rate, a.srf, a.sr8, a.freq.get(v), a.color[v], a.note_on.get(v), a.nic.get(v));
+}
+__device__ __forceinline__ void nice_store(NiceLane &n, const NiceArgs &a, uint32_t v) {
+    float dummy;
+    n.env.frame(false, dummy);                                         // end-of-span cascade
+    a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
+    a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= a.V) return;
+    NiceLane n;
+    nice_load(n, a, v);
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+        val = n.frame();
+        return true;
+    });
+    nice_store(n, a, v);
+}
+
+// Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices; per chunk of MIXF frames
+// each wave reduces its 64 voices with an xor-shuffle butterfly, the 4 wave sums meet in LDS
+// and are added in wave order into partials[block][frame]; the second mixdown pass (basics.hip) adds the
+// block partials in block order.  Fixed order => reproducible bits.
+constexpr int MIXF = 8;
+
+__global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials) {
+    __shared__ float wsum[MIXF][4];
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nframes = end - start;
+    const bool live = v < a.V;
+    NiceLane n;
+    if (live) nice_load(n, a, v);
+    for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
+        float acc[MIXF];
+#pragma unroll
+        for (int k = 0; k < MIXF; k++) {
+            float x = 0.0f;
+            if (live && f0 + k < end) x = 0.0f + n.frame();            // the voice's own out (zeroed) += env*flt
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+            acc[k] = x;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < MIXF; k++) wsum[k][wave] = acc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < MIXF && f0 + threadIdx.x < end) {
+            const float *w = wsum[threadIdx.x];
+            partials[(size_t)blockIdx.x * nframes + (f0 - start) + threadIdx.x] = ((w[0] + w[1]) + w[2]) + w[3];
+        }
+        __syncthreads();
+    }
+    if (live) nice_store(n, a, v);
+}
+
+// ------------------------------------------------------------------ PMOscInstrument voice
+struct PMOscArgs {
+    float *release_duration;
+    float *tc, *tm;
+    uint32_t *estate;
+    float *et, *elast, *estart;
+    uint32_t V;
+    float sample_rate;
+    F32P freq;
+    BoolP note_on, nic;
+};
+
+__device__ __forceinline__ float pm_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }   // SineOsc.zig:4-6
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= a.V) return;
+    const float freq = a.freq.get(v);
+    float tc = a.tc[v], tm = a.tm[v];
+    EnvLane env;
+    env.state = a.estate[v]; env.t = a.et[v]; env.last_value = a.elast[v]; env.start = a.estart[v];
+    env.sample_rate = a.sample_rate;                                   // examples/modules.zig:118-125
+    env.sustain_volume = 0.5f;
+    env.attack = CurveP{ZH_CURVE_CUBED, 0.025f};
+    env.decay = CurveP{ZH_CURVE_CUBED, 0.1f};
+    env.release = CurveP{ZH_CURVE_CUBED, a.release_duration[v]};
+    env.note_on = a.note_on.get(v);
+    env.begin(a.nic.get(v));
+    const float mod_freq = freq * 1.0f;                                // set(temps[0], freq * ratio), ratio = 1 (:45)
+    const float inv_sr = 1.0f / a.sample_rate;                         // modulator: controlled-frequency path (SineOsc.zig:66)
+    const float t_step = freq / a.sample_rate;                         // carrier: constant-frequency path (:44)
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+        // modulator.paint -> temps[1] (zeroed): sin(t + 0.0), t += freq_buf[i] * inv_sr   (:59-63)
+        const float m = 0.0f + pm_sin(tm + 0.0f);
+        tm += mod_freq * inv_sr;
+        // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
+        const float ph = 0.0f + m * 1.0f;
+        // carrier.paint -> temps[1] (zeroed): sin(t + phase[i]), t += t_step   (:69-74)
+        const float c = 0.0f + pm_sin(tc + ph);
+        tc += t_step;
+        // PhaseModOscillator output (PMOsc temps[0], zeroed) += temps[1]   (:75)
+        const float osc = 0.0f + c;
+        // envelope -> temps[1] (zeroed)   (:117-125)
+        float ev = 0.0f, e0 = 0.0f;
+        if (env.frame(true, ev)) e0 = 0.0f + ev;
+        val = osc * e0;                                                // multiply(out, temps[0], temps[1]) :126
+        return true;
+    });
+    float dummy;
+    env.frame(false, dummy);
+    a.tc[v] = tc - truncf(tc);                                         // SineOsc.zig:40, once per paint
+    a.tm[v] = tm - truncf(tm);
+    a.estate[v] = env.state; a.et[v] = env.t; a.elast[v] = env.last_value; a.estart[v] = env.start;
+}
+
+__global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = src.get(i);
+}
+__global__ void k_fill_u32(uint32_t *p, uint32_t n, uint32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+template <typename T> static int up(zh_ctx *ctx, T *dev, const std::vector<T> &h) { return zh_upload(ctx, dev, h.data(), h.size() * sizeof(T)); }
+template <typename T> static int down(zh_ctx *ctx, std::vector<T> &h, const T *dev, size_t n) { h.resize(n); return zh_download(ctx, h.data(), dev, n * sizeof(T)); }
+
+static NiceArgs nice_args(zh_nice *m, const zh_nice_params *p, zh_bool nic) {
+    NiceArgs a;
+    a.color = m->color; a.cnt = m->cnt; a.fl = m->fl; a.fb = m->fb;
+    a.estate = m->estate; a.et = m->et; a.elast = m->elast; a.estart = m->estart;
+    a.V = m->n;
+    a.sample_rate = p->sample_rate;
+    a.srf = 4294967296.0f / p->sample_rate;                            // PulseOsc.zig:87
+    a.sr8 = p->sample_rate / 8.0f;                                     // :82
+    a.freq = mk_f32(p->freq);
+    a.note_on = mk_bool(p->note_on);
+    a.nic = mk_bool(nic);
+    return a;
+}
+
+static void nice_free(zh_nice *m) {
+    (void)hipFree(m->color); (void)hipFree(m->cnt); (void)hipFree(m->fl); (void)hipFree(m->fb);
+    (void)hipFree(m->estate); (void)hipFree(m->et); (void)hipFree(m->elast); (void)hipFree(m->estart);
+}
+static void pmosc_free(zh_pmosc *m) {
+    (void)hipFree(m->release_duration); (void)hipFree(m->tc); (void)hipFree(m->tm);
+    (void)hipFree(m->estate); (void)hipFree(m->et); (void)hipFree(m->elast); (void)hipFree(m->estart);
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ NiceInstrument
+int zh_nice_create(zh_ctx *ctx, uint32_t n, zh_f32 color, zh_nice **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_nice *m = new (std::nothrow) zh_nice();
+    if (!m) return ZH_ERR_INVALID;
+    *m = zh_nice{ctx, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = dev_alloc(&m->color, n);
+    if (!rc) rc = dev_alloc(&m->cnt, n);
+    if (!rc) rc = dev_alloc(&m->fl, n);
+    if (!rc) rc = dev_alloc(&m->fb, n);
+    if (!rc) rc = dev_alloc(&m->estate, n);
+    if (!rc) rc = dev_alloc(&m->et, n);
+    if (!rc) rc = dev_alloc(&m->elast, n);
+    if (!rc) rc = dev_alloc(&m->estart, n);
+    if (rc) { nice_free(m); delete m; return rc; }
+    if (n) {
+        hipStream_t st = ctx->stream;
+        hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->color, n, mk_f32(color));
+        void *zeros[] = {m->cnt, m->fl, m->fb, m->estate, m->et, m->elast, m->estart};   // sub-module init()s
+        for (void *z : zeros) { hipError_t e = hipMemsetAsync(z, 0, (size_t)n * 4, st); if (e != hipSuccess) { nice_free(m); delete m; return (int)e; } }
+    }
+    *out = m;
+    return zh_launch_status();
+}
+int zh_nice_destroy(zh_nice *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    nice_free(m);
+    delete m;
+    return ZH_OK;
+}
+int zh_nice_get_state(zh_nice *m, zh_nice_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint32_t> cnt, es;
+    std::vector<float> l, b, t, lv, sv;
+    int rc = down(m->ctx, cnt, m->cnt, m->n);
+    if (!rc) rc = down(m->ctx, l, m->fl, m->n);
+    if (!rc) rc = down(m->ctx, b, m->fb, m->n);
+    if (!rc) rc = down(m->ctx, es, m->estate, m->n);
+    if (!rc) rc = down(m->ctx, t, m->et, m->n);
+    if (!rc) rc = down(m->ctx, lv, m->elast, m->n);
+    if (!rc) rc = down(m->ctx, sv, m->estart, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) {
+        host[v].osc.cnt = cnt[v];
+        host[v].flt = zh_filter_state{l[v], b[v]};
+        host[v].env = zh_envelope_state{es[v], t[v], lv[v], sv[v]};
+    }
+    return ZH_OK;
+}
+int zh_nice_set_state(zh_nice *m, const zh_nice_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    const uint32_t n = m->n;
+    std::vector<uint32_t> cnt(n), es(n);
+    std::vector<float> l(n), b(n), t(n), lv(n), sv(n);
+    for (uint32_t v = 0; v < n; v++) {
+        cnt[v] = host[v].osc.cnt; l[v] = host[v].flt.l; b[v] = host[v].flt.b;
+        es[v] = host[v].env.state; t[v] = host[v].env.t; lv[v] = host[v].env.last_value; sv[v] = host[v].env.start;
+    }
+    int rc = up(m->ctx, m->cnt, cnt);
+    if (!rc) rc = up(m->ctx, m->fl, l);
+    if (!rc) rc = up(m->ctx, m->fb, b);
+    if (!rc) rc = up(m->ctx, m->estate, es);
+    if (!rc) rc = up(m->ctx, m->et, t);
+    if (!rc) rc = up(m->ctx, m->elast, lv);
+    if (!rc) rc = up(m->ctx, m->estart, sv);
+    return rc;
+}
+int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                  zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
+    (void)temps;   // the fused kernel keeps both temps in registers
+    if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    hipStream_t st = m->ctx->stream;
+    NiceArgs a = nice_args(m, p, note_id_changed);
+    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_nice<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    else hipLaunchKernelGGL(k_nice<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    return zh_launch_status();
+}
+int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_bool note_id_changed,
+                      const zh_nice_params *p, uint32_t flags) {
+    if (!m || !mix || !p || end < start) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    const uint32_t nframes = end - start;
+    const uint32_t blocks = (m->n + 255) / 256;
+    int rc = zh_mix_reserve(m->ctx, (size_t)blocks * (nframes ? nframes : 1));
+    if (rc) return rc;
+    hipStream_t st = m->ctx->stream;
+    NiceArgs a = nice_args(m, p, note_id_changed);
+    hipLaunchKernelGGL(k_nice_mix, dim3(blocks), dim3(256), 0, st, a, start, end, m->ctx->mix_partials);
+    if (nframes) zh_mix_pass2_launch(m->ctx, blocks, nframes, mix + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ PMOscInstrument
+int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_pmosc *m = new (std::nothrow) zh_pmosc();
+    if (!m) return ZH_ERR_INVALID;
+    *m = zh_pmosc{ctx, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = dev_alloc(&m->release_duration, n);
+    if (!rc) rc = dev_alloc(&m->tc, n);
+    if (!rc) rc = dev_alloc(&m->tm, n);
+    if (!rc) rc = dev_alloc(&m->estate, n);
+    if (!rc) rc = dev_alloc(&m->et, n);
+    if (!rc) rc = dev_alloc(&m->elast, n);
+    if (!rc) rc = dev_alloc(&m->estart, n);
+    if (rc) { pmosc_free(m); delete m; return rc; }
+    if (n) {
+        hipStream_t st = ctx->stream;
+        hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->release_duration, n, mk_f32(release_duration));
+        void *zeros[] = {m->tc, m->tm, m->estate, m->et, m->elast, m->estart};
+        for (void *z : zeros) { hipError_t e = hipMemsetAsync(z, 0, (size_t)n * 4, st); if (e != hipSuccess) { pmosc_free(m); delete m; return (int)e; } }
+    }
+    *out = m;
+    return zh_launch_status();
+}
+int zh_pmosc_destroy(zh_pmosc *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    pmosc_free(m);
+    delete m;
+    return ZH_OK;
+}
+int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint32_t> es;
+    std::vector<float> tc, tm, t, lv, sv;
+    int rc = down(m->ctx, tc, m->tc, m->n);
+    if (!rc) rc = down(m->ctx, tm, m->tm, m->n);
+    if (!rc) rc = down(m->ctx, es, m->estate, m->n);
+    if (!rc) rc = down(m->ctx, t, m->et, m->n);
+    if (!rc) rc = down(m->ctx, lv, m->elast, m->n);
+    if (!rc) rc = down(m->ctx, sv, m->estart, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) {
+        host[v].carrier.t = tc[v]; host[v].modulator.t = tm[v];
+        host[v].env = zh_envelope_state{es[v], t[v], lv[v], sv[v]};
+    }
+    return ZH_OK;
+}
+int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    const uint32_t n = m->n;
+    std::vector<uint32_t> es(n);
+    std::vector<float> tc(n), tm(n), t(n), lv(n), sv(n);
+    for (uint32_t v = 0; v < n; v++) {
+        tc[v] = host[v].carrier.t; tm[v] = host[v].modulator.t;
+        es[v] = host[v].env.state; t[v] = host[v].env.t; lv[v] = host[v].env.last_value; sv[v] = host[v].env.start;
+    }
+    int rc = up(m->ctx, m->tc, tc);
+    if (!rc) rc = up(m->ctx, m->tm, tm);
+    if (!rc) rc = up(m->ctx, m->estate, es);
+    if (!rc) rc = up(m->ctx, m->et, t);
+    if (!rc) rc = up(m->ctx, m->elast, lv);
+    if (!rc) rc = up(m->ctx, m->estart, sv);
+    return rc;
+}
+int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                   zh_bool note_id_changed, const zh_pmosc_params *p, uint32_t flags) {
+    (void)temps;
+    if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    hipStream_t st = m->ctx->stream;
+    PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, p->sample_rate,
+                mk_f32(p->freq), mk_bool(p->note_on), mk_bool(note_id_changed)};
+    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    else hipLaunchKernelGGL(k_pmosc<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    return zh_launch_status();
+}
+
+}  // extern "C"

@@ -61,12 +61,9 @@ int zh_set_stream(zh_ctx *ctx, void *hip_stream) {
     if (!ctx) return ZH_ERR_INVALID;
     ZH_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
-    if (hip_stream) {
-        ctx->stream = (hipStream_t)hip_stream;
-    } else {
-        ZH_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    // NULL is HIP's default (null) stream: work is then ordered with everything else the
+    // process enqueues there (e.g. PyTorch's default-stream copies and allocator reuse).
+    ctx->stream = (hipStream_t)hip_stream;
     return ZH_OK;
 }
 

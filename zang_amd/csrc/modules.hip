@@ -1,0 +1,770 @@
+// modules.hip -- paint kernels for SineOsc, Noise, Envelope, Gate, Filter, Sampler, Decimator
+// and Distortion (src/modules/*.zig), one wavefront lane per voice.
+//
+// Stateful modules (SineOsc, Noise, Envelope, Filter, Sampler, Decimator) carry an f32/u64
+// recurrence from sample to sample that must be replayed add by add to reproduce the
+// reference's bits, so they use the sequential frame loop of seq.cuh: state is
+// loaded into VGPRs once per span, walked over the span, stored once.  Stateless modules
+// (Gate, Distortion) are additionally split into frame chunks across waves.
+#include "common.cuh"
+#include "zmath.cuh"
+#include "seq.cuh"
+#include "envelope.cuh"
+#include <vector>
+
+static inline bool aligned16m(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// A module's device state: a few SoA arrays of n elements each.
+struct StateArrays {
+    void *p[12];
+    int count;
+    StateArrays() : count(0) { for (auto &x : p) x = nullptr; }
+    void release() { for (int i = 0; i < count; i++) if (p[i]) (void)hipFree(p[i]); count = 0; }
+};
+
+template <typename T> static int upload_field(zh_ctx *ctx, T *dev, const std::vector<T> &h) {
+    return zh_upload(ctx, dev, h.data(), h.size() * sizeof(T));
+}
+template <typename T> static int download_field(zh_ctx *ctx, std::vector<T> &h, const T *dev, size_t n) {
+    h.resize(n);
+    return zh_download(ctx, h.data(), dev, n * sizeof(T));
+}
+
+// =================================================================== SineOsc
+struct zh_sineosc { zh_ctx *ctx; uint32_t n; float *t; };
+
+// SineOsc.zig:4-6: sin((t * pi) * 2)
+__device__ __forceinline__ float sine_osc_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }
+
+template <bool ZF, bool FB, bool PB>
+__global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
+                                                       uint32_t end, float sample_rate, CobP freq, CobP phase) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    float t = t_io[v];
+    constexpr int NIN = (FB ? 1 : 0) + (PB ? 1 : 0);
+    const float *ins[2] = {nullptr, nullptr};
+    size_t istr[2] = {0, 0};
+    if (FB) { ins[0] = freq.b.p + v; istr[0] = freq.b.stride; }
+    if (PB) { ins[FB ? 1 : 0] = phase.b.p + v; istr[FB ? 1 : 0] = phase.b.stride; }
+    const float t_step = FB ? 0.0f : freq.c.get(v) / sample_rate;    // SineOsc.zig:44
+    const float inv_sr = 1.0f / sample_rate;                          // :66
+    const float phase_c = PB ? 0.0f : phase.c.get(v);
+    frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end,
+                           [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) {
+        const float ph = PB ? x[FB ? 1 : 0] : phase_c;
+        val = sine_osc_sin(t + ph);
+        if (FB) t += x[0] * inv_sr; else t += t_step;
+        return true;
+    });
+    t_io[v] = t - truncf(t);                                          // :40
+}
+
+// =================================================================== Noise
+struct zh_noise { zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *b; /* [7][n] */ };
+
+__global__ void k_noise_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, float *b, uint32_t n, uint64_t first_seed) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    ZXoshiro r;
+    zxoshiro_seed(r, first_seed + v);                                 // Noise.zig:26-29
+    s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;
+    for (int j = 0; j < 7; j++) b[(size_t)j * n + v] = 0.0f;          // :30
+}
+
+template <bool ZF, bool PINK>
+__global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
+                                                     uint64_t *__restrict__ s2, uint64_t *__restrict__ s3,
+                                                     const float *__restrict__ bst, uint32_t V, Img out,
+                                                     uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    ZXoshiro r{s0[v], s1[v], s2[v], s3[v]};
+    float b[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (PINK) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) b[j] = bst[(size_t)j * V + v];    // `var b = self.b` (Noise.zig:55)
+    }
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+        const float white = zrandom_float32(r) * 2.0f - 1.0f;         // :51 / :58
+        if (!PINK) { val = white; return true; }
+        b[0] = 0.99886f * b[0] + white * 0.0555179f;                  // :59-64
+        b[1] = 0.99332f * b[1] + white * 0.0750759f;
+        b[2] = 0.96900f * b[2] + white * 0.1538520f;
+        b[3] = 0.86650f * b[3] + white * 0.3104856f;
+        b[4] = 0.55000f * b[4] + white * 0.5329522f;
+        b[5] = -0.7616f * b[5] - white * 0.0168980f;
+        val = b[0] + b[1] + b[2] + b[3] + b[4] + b[5] + b[6] + white * 0.5362f;   // :65
+        b[6] = white * 0.115926f;                                     // :66
+        return true;
+    });
+    // Noise.zig:68 is `b = self.b;` -- the taps are never written back (reference quirk, kept)
+    s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;           // :71
+}
+
+// =================================================================== Envelope
+struct zh_envelope { zh_ctx *ctx; uint32_t n; uint32_t *state; float *t, *last_value, *start; };
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_envelope(uint32_t *__restrict__ st, float *__restrict__ t,
+                                                        float *__restrict__ lastv, float *__restrict__ startv, uint32_t V,
+                                                        Img out, uint32_t start, uint32_t end, EnvParamsP p, BoolP nic) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    EnvLane e;
+    e.state = st[v]; e.t = t[v]; e.last_value = lastv[v]; e.start = startv[v];
+    env_load(e, p, v);
+    e.begin(nic.get(v));
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end,
+                         [&](uint32_t, const float (&)[1], float &val) { return e.frame(true, val); });
+    float dummy;
+    e.frame(false, dummy);                                            // end-of-span cascade
+    st[v] = e.state; t[v] = e.t; lastv[v] = e.last_value; startv[v] = e.start;
+}
+
+// =================================================================== Gate (stateless)
+struct zh_gate { zh_ctx *ctx; uint32_t n; };
+
+// Gate.zig:28-30: if note_on, out[span] += 1.0.  grid: x = 64-voice groups, y = 32-frame chunks.
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_gate(uint32_t V, Img out, uint32_t start, uint32_t end, BoolP note_on) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const uint32_t c0 = start + chunk * 32, c1 = min(c0 + 32, end);
+    const bool on = note_on.get(v);
+    if (!on && !ZF) return;
+    float *o = out.at(c0, v);
+    for (uint32_t i = c0; i < c1; i++, o += out.stride) {
+        const float base = ZF ? 0.0f : *o;
+        *o = on ? base + 1.0f : base;
+    }
+}
+
+// =================================================================== Filter
+struct zh_filter { zh_ctx *ctx; uint32_t n; float *l, *b; };
+
+template <bool ZF, bool CB, bool RB>
+__global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out,
+                                                      CImg input, uint32_t start, uint32_t end, float l_mul, float b_mul,
+                                                      float h_mul, CobP cutoff, CobP res_p) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    const float fcdcoffset = 3.814697265625e-6f;                      // Filter.zig:8
+    constexpr int NIN = 1 + (CB ? 1 : 0) + (RB ? 1 : 0);
+    const float *ins[3] = {input.p + v, nullptr, nullptr};
+    size_t istr[3] = {input.stride, 0, 0};
+    if (CB) { ins[1] = cutoff.b.p + v; istr[1] = cutoff.b.stride; }
+    if (RB) { ins[CB ? 2 : 1] = res_p.b.p + v; istr[CB ? 2 : 1] = res_p.b.stride; }
+    float cut = CB ? 0.0f : zclampf(cutoff.c.get(v), 0.0f, 1.0f);     // :114
+    float res = RB ? 0.0f : 1.0f - zclampf(res_p.c.get(v), 0.0f, 1.0f);   // :118
+    float l = l_io[v], b = b_io[v];
+    frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) {
+        if (CB) cut = zclampf(x[1], 0.0f, 1.0f);                      // :126
+        if (RB) res = 1.0f - zclampf(x[CB ? 2 : 1], 0.0f, 1.0f);      // :128
+        const float in = x[0] + fcdcoffset;                           // :135
+        l += cut * b - fcdcoffset;                                    // :138
+        b += cut * (in - b * res - l);                                // :139
+        l += cut * b;                                                 // :142
+        const float h = in - b * res - l;                             // :143
+        b += cut * h;                                                 // :144
+        val = l * l_mul + b * b_mul + h * h_mul;                      // :146
+        return true;
+    });
+    l_io[v] = l; b_io[v] = b;
+}
+
+__global__ void k_cutoff_from_frequency(uint32_t n, float *__restrict__ out, const float *__restrict__ freq, float sample_rate) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = zcutoff_from_frequency(freq[i], sample_rate);
+}
+
+// =================================================================== Sampler
+struct zh_sampler { zh_ctx *ctx; uint32_t n; float *t; };
+
+struct SampleP {
+    const uint8_t *data;
+    uint64_t data_len;
+    uint32_t num_channels, sample_rate_in, format, channel, loop;
+    int32_t num_samples;        // data.len / bytes_per_sample / num_channels (Sampler.zig:42)
+};
+
+// Sampler.zig:23-33
+__device__ __forceinline__ float sampler_decode_signed(int byte_count, const uint8_t *p) {
+    int32_t sval;
+    if (byte_count == 2) sval = (int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8));
+    else if (byte_count == 3) {
+        const uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+        sval = (int32_t)(u << 8) >> 8;
+    } else sval = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+    const float max = (float)(1u << (byte_count * 8 - 1));
+    return (float)sval / max;
+}
+
+// Sampler.zig:35-58 (num_samples == 0 with loop: division by zero in the reference; DEFINED as silence)
+__device__ __forceinline__ float sampler_get_sample(const SampleP &s, int32_t index1) {
+    int32_t index = index1;
+    if (s.loop) {
+        if (s.num_samples == 0) return 0.0f;
+        index = index1 % s.num_samples;                               // @mod: floored
+        if (index < 0) index += s.num_samples;
+    }
+    if (index >= 0 && index < s.num_samples) {
+        const size_t i = (size_t)index * s.num_channels + s.channel;
+        switch (s.format) {
+        case ZH_SAMPLE_U8: return ((float)s.data[i] - 127.5f) / 127.5f;
+        case ZH_SAMPLE_S16_LSB: return sampler_decode_signed(2, s.data + i * 2);
+        case ZH_SAMPLE_S24_LSB: return sampler_decode_signed(3, s.data + i * 3);
+        default: return sampler_decode_signed(4, s.data + i * 4);
+        }
+    }
+    return 0.0f;
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
+                                                       uint32_t end, SampleP s, F32P out_rate, BoolP nic) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    float t = t_io[v];
+    if (nic.get(v)) t = 0.0f;                                         // Sampler.zig:91-93
+    const uint32_t len = end - start;
+    const float ratio = (float)s.sample_rate_in / out_rate.get(v);    // :97
+    const float *const *no_in = nullptr;
+    if (ratio < 0.0f && !s.loop) {                                    // :99-102 (t keeps the reset)
+        if (ZF) zero_column(out.p + v, out.stride, start, end);
+        t_io[v] = t;
+        return;
+    }
+    if (ratio > 0.9999f && ratio < 1.0001f) {                         // :105-114 no resampling
+        const int32_t t0 = zf32_to_i32(roundf(t));
+        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) {
+            val = sampler_get_sample(s, (int32_t)((uint32_t)t0 + (i - start)));
+            return true;
+        });
+        t += (float)len;
+    } else {                                                          // :116-130 linear resampling
+        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+            const int32_t t0 = zf32_to_i32(floorf(t));
+            const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
+            const float tfrac = (float)t1 - t;                        // :121
+            const float s0 = sampler_get_sample(s, t0);
+            const float s1 = sampler_get_sample(s, t1);
+            val = s0 * (1.0f - tfrac) + s1 * tfrac;
+            t += ratio;
+            return true;
+        });
+    }
+    // :133-135: compared against data.len in BYTES (reference quirk, kept)
+    if (t >= (float)s.data_len && s.loop) t -= (float)s.data_len;
+    t_io[v] = t;
+}
+
+// =================================================================== Decimator
+struct zh_decimator { zh_ctx *ctx; uint32_t n; float *dval, *dcount; };
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dval_io, float *__restrict__ dcount_io, uint32_t V,
+                                                         Img out, CImg input, uint32_t start, uint32_t end,
+                                                         float sample_rate, F32P fake_p) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    const float fake = fake_p.get(v);
+    float dval = dval_io[v], dcount = dcount_io[v];
+    const int mode = fake >= sample_rate ? 0 : (fake > 0.0f ? 1 : 2);  // Decimator.zig:34,39
+    const float ratio = fake / sample_rate;                           // :40
+    const float *ins[1] = {input.p + v};
+    const size_t istr[1] = {input.stride};
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
+        if (mode == 0) { val = x[0]; return true; }                   // :35 addInto
+        if (mode == 2) return false;                                  // fake <= 0 (or NaN): paints nothing
+        dcount += ratio;                                              // :46
+        if (dcount >= 1.0f) { dval = x[0]; dcount -= 1.0f; }          // :47-50
+        val = dval;                                                   // :51
+        return true;
+    });
+    if (mode == 0) { dval = 0.0f; dcount = 1.0f; }                    // :37-38
+    dval_io[v] = dval; dcount_io[v] = dcount;
+}
+
+// =================================================================== Distortion (stateless)
+struct zh_distortion { zh_ctx *ctx; uint32_t n; };
+
+// grid: x = 64-voice groups, y = groups of 4 chunks of DIST_FC frames; per chunk each lane
+// recomputes its voice's gain1 = pow(2, ingain*8 - 2) (Distortion.zig:41).
+constexpr uint32_t DIST_FC = 32;
+template <bool ZF, bool OVERDRIVE>
+__global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg input, uint32_t start, uint32_t end,
+                                                    F32P ingain, F32P outgain, F32P offset) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const uint32_t c0 = start + chunk * DIST_FC, c1 = min(c0 + DIST_FC, end);
+    if (c0 >= end) return;
+    const float gain1 = zpowf_pos(2.0f, ingain.get(v) * 8.0f - 2.0f);
+    const float offs = gain1 * offset.get(v);
+    const float gain2 = OVERDRIVE ? outgain.get(v) / zatanf(gain1) : outgain.get(v);   // :45 / :55
+    float *o = out.at(c0, v);
+    const float *in = input.at(c0, v);
+    for (uint32_t i = c0; i < c1; i++, o += out.stride, in += input.stride) {
+        const float a0 = *in * gain1 + offs;
+        float r;
+        if (OVERDRIVE) r = gain2 * zatanf(a0);                        // :50-51
+        else r = gain2 * (a0 < -1.0f ? -1.0f : (a0 > 1.0f ? 1.0f : a0));   // :60-62
+        *o = (ZF ? 0.0f : *o) + r;
+    }
+}
+
+// =================================================================== host side
+template <class M> static int paint_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs) {
+    if (!m || !outputs || end < start) return ZH_ERR_INVALID;
+    if (!buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
+    return ZH_OK;
+}
+
+#define ZH_ZF_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                         \
+    do {                                                                                               \
+        if (zf) hipLaunchKernelGGL((KERNEL<true>), GRID, BLOCK, 0, st, __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<false>), GRID, BLOCK, 0, st, __VA_ARGS__);                     \
+    } while (0)
+
+static bool curve_ok(const zh_curve &c) { return c.tag <= ZH_CURVE_CUBED; }
+static EnvParamsP mk_env_params(const zh_envelope_params *p) {
+    return EnvParamsP{p->sample_rate, p->attack.tag, p->decay.tag, p->release.tag, mk_f32(p->attack.duration),
+                      mk_f32(p->decay.duration), mk_f32(p->release.duration), mk_f32(p->sustain_volume), mk_bool(p->note_on)};
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ SineOsc
+int zh_sineosc_create(zh_ctx *ctx, uint32_t n, zh_sineosc **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_sineosc *m = new (std::nothrow) zh_sineosc{ctx, n, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->t, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);          // init(): t = 0 (:18-22)
+    if (rc) { (void)hipFree(m->t); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_sineosc_destroy(zh_sineosc *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->t);
+    delete m;
+    return ZH_OK;
+}
+int zh_sineosc_get_state(zh_sineosc *m, zh_sineosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
+}
+int zh_sineosc_set_state(zh_sineosc *m, const zh_sineosc_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
+}
+int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                     zh_bool note_id_changed, const zh_sineosc_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // SineOsc.zig:32-33
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || !cob_ok(p->freq, m->n, end) || !cob_ok(p->phase, m->n, end)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    const bool fb = p->freq.tag == ZH_COB_BUFFER, pb = p->phase.tag == ZH_COB_BUFFER;
+    Img out = mk_img(outputs[0]);
+    CobP f = mk_cob(p->freq), ph = mk_cob(p->phase);
+#define ZH_SINE(FB, PB)                                                                                             \
+    do {                                                                                                            \
+        if (zf) hipLaunchKernelGGL((k_sineosc<true, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, f, ph); \
+        else hipLaunchKernelGGL((k_sineosc<false, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, f, ph);  \
+    } while (0)
+    if (fb && pb) ZH_SINE(true, true);
+    else if (fb) ZH_SINE(true, false);
+    else if (pb) ZH_SINE(false, true);
+    else ZH_SINE(false, false);
+#undef ZH_SINE
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Noise
+int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_noise *m = new (std::nothrow) zh_noise{ctx, n, {nullptr, nullptr, nullptr, nullptr}, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = 0;
+    for (int i = 0; i < 4 && !rc; i++) rc = dev_alloc(&m->s[i], n);
+    if (!rc) rc = dev_alloc(&m->b, (size_t)7 * n);
+    if (rc) { for (auto &x : m->s) (void)hipFree(x); (void)hipFree(m->b); delete m; return rc; }
+    if (n) hipLaunchKernelGGL(k_noise_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], m->b, n, first_seed);
+    *out = m;
+    return zh_launch_status();
+}
+int zh_noise_destroy(zh_noise *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (auto &x : m->s) (void)hipFree(x);
+    (void)hipFree(m->b);
+    delete m;
+    return ZH_OK;
+}
+int zh_noise_get_state(zh_noise *m, zh_noise_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint64_t> s;
+    std::vector<float> b;
+    for (int i = 0; i < 4; i++) {
+        int rc = download_field(m->ctx, s, m->s[i], m->n);
+        if (rc) return rc;
+        for (uint32_t v = 0; v < m->n; v++) host[v].r[i] = s[v];
+    }
+    int rc = download_field(m->ctx, b, m->b, (size_t)7 * m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) { for (int j = 0; j < 7; j++) host[v].b[j] = b[(size_t)j * m->n + v]; host[v].reserved = 0; }
+    return ZH_OK;
+}
+int zh_noise_set_state(zh_noise *m, const zh_noise_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint64_t> s(m->n);
+    std::vector<float> b((size_t)7 * m->n);
+    for (int i = 0; i < 4; i++) {
+        for (uint32_t v = 0; v < m->n; v++) s[v] = host[v].r[i];
+        int rc = upload_field(m->ctx, m->s[i], s);
+        if (rc) return rc;
+    }
+    for (uint32_t v = 0; v < m->n; v++) for (int j = 0; j < 7; j++) b[(size_t)j * m->n + v] = host[v].b[j];
+    return upload_field(m->ctx, m->b, b);
+}
+int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                   zh_bool note_id_changed, const zh_noise_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // Noise.zig:42-43
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || p->color > ZH_NOISE_PINK) return ZH_ERR_INVALID;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    Img out = mk_img(outputs[0]);
+#define ZH_NOISE(ZF_, PINK_) hipLaunchKernelGGL((k_noise<ZF_, PINK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->b, m->n, out, start, end)
+    if (p->color == ZH_NOISE_PINK) { if (zf) ZH_NOISE(true, true); else ZH_NOISE(false, true); }
+    else { if (zf) ZH_NOISE(true, false); else ZH_NOISE(false, false); }
+#undef ZH_NOISE
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Envelope
+int zh_envelope_create(zh_ctx *ctx, uint32_t n, zh_envelope **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_envelope *m = new (std::nothrow) zh_envelope{ctx, n, nullptr, nullptr, nullptr, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->state, n);
+    if (!rc) rc = dev_alloc(&m->t, n);
+    if (!rc) rc = dev_alloc(&m->last_value, n);
+    if (!rc) rc = dev_alloc(&m->start, n);
+    if (!rc && n) {                                                                // init() :26-31: idle, painter zeros
+        rc = (int)hipMemsetAsync(m->state, 0, n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->last_value, 0, n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->start, 0, n * 4, ctx->stream);
+    }
+    if (rc) { (void)hipFree(m->state); (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_envelope_destroy(zh_envelope *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->state); (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start);
+    delete m;
+    return ZH_OK;
+}
+int zh_envelope_get_state(zh_envelope *m, zh_envelope_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint32_t> s;
+    std::vector<float> a, b, c;
+    int rc = download_field(m->ctx, s, m->state, m->n);
+    if (!rc) rc = download_field(m->ctx, a, m->t, m->n);
+    if (!rc) rc = download_field(m->ctx, b, m->last_value, m->n);
+    if (!rc) rc = download_field(m->ctx, c, m->start, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_envelope_state{s[v], a[v], b[v], c[v]};
+    return ZH_OK;
+}
+int zh_envelope_set_state(zh_envelope *m, const zh_envelope_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint32_t> s(m->n);
+    std::vector<float> a(m->n), b(m->n), c(m->n);
+    for (uint32_t v = 0; v < m->n; v++) { s[v] = host[v].state; a[v] = host[v].t; b[v] = host[v].last_value; c[v] = host[v].start; }
+    int rc = upload_field(m->ctx, m->state, s);
+    if (!rc) rc = upload_field(m->ctx, m->t, a);
+    if (!rc) rc = upload_field(m->ctx, m->last_value, b);
+    if (!rc) rc = upload_field(m->ctx, m->start, c);
+    return rc;
+}
+int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                      zh_bool note_id_changed, const zh_envelope_params *p, uint32_t flags) {
+    (void)temps;
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || !curve_ok(p->attack) || !curve_ok(p->decay) || !curve_ok(p->release)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;            // an empty span still runs the state prologue (Envelope.zig:41-50)
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    ZH_ZF_LAUNCH(k_envelope, seq_grid(m->n), dim3(kSeqBlock), m->state, m->t, m->last_value, m->start, m->n,
+                 mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Gate
+int zh_gate_create(zh_ctx *ctx, uint32_t n, zh_gate **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    *out = new (std::nothrow) zh_gate{ctx, n};
+    return *out ? ZH_OK : ZH_ERR_INVALID;
+}
+int zh_gate_destroy(zh_gate *m) {
+    if (!m) return ZH_ERR_INVALID;
+    delete m;
+    return ZH_OK;
+}
+int zh_gate_paint(zh_gate *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                  zh_bool note_id_changed, const zh_gate_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // Gate.zig:24-26
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p) return ZH_ERR_INVALID;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    const uint32_t chunks = (end - start + 31) / 32;
+    ZH_ZF_LAUNCH(k_gate, dim3((m->n + 63) / 64, (chunks + 3) / 4), dim3(256), m->n, mk_img(outputs[0]), start, end, mk_bool(p->note_on));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Filter
+int zh_filter_create(zh_ctx *ctx, uint32_t n, zh_filter **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_filter *m = new (std::nothrow) zh_filter{ctx, n, nullptr, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->l, n);
+    if (!rc) rc = dev_alloc(&m->b, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->l, 0, n * 4, ctx->stream);           // init() :37-42
+    if (!rc && n) rc = (int)hipMemsetAsync(m->b, 0, n * 4, ctx->stream);
+    if (rc) { (void)hipFree(m->l); (void)hipFree(m->b); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_filter_destroy(zh_filter *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->l); (void)hipFree(m->b);
+    delete m;
+    return ZH_OK;
+}
+int zh_filter_get_state(zh_filter *m, zh_filter_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> l, b;
+    int rc = download_field(m->ctx, l, m->l, m->n);
+    if (!rc) rc = download_field(m->ctx, b, m->b, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_filter_state{l[v], b[v]};
+    return ZH_OK;
+}
+int zh_filter_set_state(zh_filter *m, const zh_filter_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> l(m->n), b(m->n);
+    for (uint32_t v = 0; v < m->n; v++) { l[v] = host[v].l; b[v] = host[v].b; }
+    int rc = upload_field(m->ctx, m->l, l);
+    if (!rc) rc = upload_field(m->ctx, m->b, b);
+    return rc;
+}
+int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                    zh_bool note_id_changed, const zh_filter_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // Filter.zig:52-53
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || p->type > ZH_FILTER_ALL_PASS || !buf_covers(p->input, m->n, end) || !cob_ok(p->cutoff, m->n, end) ||
+        !cob_ok(p->res, m->n, end))
+        return ZH_ERR_INVALID;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    zh_buf o = outputs[0], in = p->input;
+    o.voices = m->n; in.voices = m->n;
+    if (p->type == ZH_FILTER_BYPASS) {                                             // :91-97: out += in, state untouched
+        if (zf) { rc = zh_zero(m->ctx, start, end, o); if (rc) return rc; }
+        return zh_add_into(m->ctx, start, end, o, in);
+    }
+    float l_mul = 0.0f, b_mul = 0.0f, h_mul = 0.0f;                                // :98-109
+    switch (p->type) {
+    case ZH_FILTER_LOW_PASS: l_mul = 1.0f; break;
+    case ZH_FILTER_BAND_PASS: b_mul = 1.0f; break;
+    case ZH_FILTER_HIGH_PASS: h_mul = 1.0f; break;
+    case ZH_FILTER_NOTCH: l_mul = 1.0f; h_mul = 1.0f; break;
+    default: l_mul = 1.0f; b_mul = 1.0f; h_mul = 1.0f; break;
+    }
+    const bool cb = p->cutoff.tag == ZH_COB_BUFFER, rb = p->res.tag == ZH_COB_BUFFER;
+    Img out = mk_img(outputs[0]);
+    CImg inp = mk_cimg(p->input);
+    CobP cut = mk_cob(p->cutoff), res = mk_cob(p->res);
+#define ZH_FILTER(CB, RB)                                                                                            \
+    do {                                                                                                             \
+        if (zf) hipLaunchKernelGGL((k_filter<true, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
+        else hipLaunchKernelGGL((k_filter<false, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
+    } while (0)
+    if (cb && rb) ZH_FILTER(true, true);
+    else if (cb) ZH_FILTER(true, false);
+    else if (rb) ZH_FILTER(false, true);
+    else ZH_FILTER(false, false);
+#undef ZH_FILTER
+    return zh_launch_status();
+}
+int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out, const float *frequency, float sample_rate) {
+    if (!ctx || (n && (!cutoff_out || !frequency))) return ZH_ERR_INVALID;
+    if (!n) return ZH_OK;
+    hipLaunchKernelGGL(k_cutoff_from_frequency, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, cutoff_out, frequency, sample_rate);
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Sampler
+int zh_sampler_create(zh_ctx *ctx, uint32_t n, zh_sampler **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_sampler *m = new (std::nothrow) zh_sampler{ctx, n, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->t, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);           // init() :71-75
+    if (rc) { (void)hipFree(m->t); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_sampler_destroy(zh_sampler *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->t);
+    delete m;
+    return ZH_OK;
+}
+int zh_sampler_get_state(zh_sampler *m, zh_sampler_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
+}
+int zh_sampler_set_state(zh_sampler *m, const zh_sampler_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
+}
+int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                     zh_bool note_id_changed, const zh_sampler_params *p, uint32_t flags) {
+    (void)temps;
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || p->sample.format > ZH_SAMPLE_S32_LSB || (p->sample.data_len && !p->sample.data)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    zh_buf o = outputs[0];
+    o.voices = m->n;
+    if (p->channel >= p->sample.num_channels) {                                    // :87-89: nothing, not even the t reset
+        return zf ? zh_zero(m->ctx, start, end, o) : ZH_OK;
+    }
+    const uint64_t bps = (uint64_t)p->sample.format + 1;
+    SampleP s;
+    s.data = p->sample.data;
+    s.data_len = p->sample.data_len;
+    s.num_channels = (uint32_t)p->sample.num_channels;
+    s.sample_rate_in = (uint32_t)p->sample.sample_rate;
+    s.format = p->sample.format;
+    s.channel = (uint32_t)p->channel;
+    s.loop = p->loop ? 1u : 0u;
+    s.num_samples = (int32_t)(p->sample.data_len / bps / p->sample.num_channels);
+    ZH_ZF_LAUNCH(k_sampler, seq_grid(m->n), dim3(kSeqBlock), m->t, m->n, mk_img(outputs[0]), start, end, s,
+                 mk_f32(p->sample_rate), mk_bool(note_id_changed));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Decimator
+int zh_decimator_create(zh_ctx *ctx, uint32_t n, zh_decimator **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_decimator *m = new (std::nothrow) zh_decimator{ctx, n, nullptr, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->dval, n);
+    if (!rc) rc = dev_alloc(&m->dcount, n);
+    if (!rc && n) {                                                                // init() :14-19: dval 0, dcount 1
+        std::vector<float> ones(n, 1.0f);
+        rc = (int)hipMemsetAsync(m->dval, 0, n * 4, ctx->stream);
+        if (!rc) rc = upload_field(ctx, m->dcount, ones);
+    }
+    if (rc) { (void)hipFree(m->dval); (void)hipFree(m->dcount); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_decimator_destroy(zh_decimator *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->dval); (void)hipFree(m->dcount);
+    delete m;
+    return ZH_OK;
+}
+int zh_decimator_get_state(zh_decimator *m, zh_decimator_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> a, b;
+    int rc = download_field(m->ctx, a, m->dval, m->n);
+    if (!rc) rc = download_field(m->ctx, b, m->dcount, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_decimator_state{a[v], b[v]};
+    return ZH_OK;
+}
+int zh_decimator_set_state(zh_decimator *m, const zh_decimator_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> a(m->n), b(m->n);
+    for (uint32_t v = 0; v < m->n; v++) { a[v] = host[v].dval; b[v] = host[v].dcount; }
+    int rc = upload_field(m->ctx, m->dval, a);
+    if (!rc) rc = upload_field(m->ctx, m->dcount, b);
+    return rc;
+}
+int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                       zh_bool note_id_changed, const zh_decimator_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // Decimator.zig:29-30
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || !buf_covers(p->input, m->n, end)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;            // an empty span still resets state when fake >= sample_rate (:37-38)
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    ZH_ZF_LAUNCH(k_decimator, seq_grid(m->n), dim3(kSeqBlock), m->dval, m->dcount, m->n, mk_img(outputs[0]),
+                 mk_cimg(p->input), start, end, p->sample_rate, mk_f32(p->fake_sample_rate));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Distortion
+int zh_distortion_create(zh_ctx *ctx, uint32_t n, zh_distortion **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    *out = new (std::nothrow) zh_distortion{ctx, n};
+    return *out ? ZH_OK : ZH_ERR_INVALID;
+}
+int zh_distortion_destroy(zh_distortion *m) {
+    if (!m) return ZH_ERR_INVALID;
+    delete m;
+    return ZH_OK;
+}
+int zh_distortion_paint(zh_distortion *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                        zh_bool note_id_changed, const zh_distortion_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // Distortion.zig:35-37
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || p->type > ZH_DISTORTION_CLIP || !buf_covers(p->input, m->n, end)) return ZH_ERR_INVALID;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    const uint32_t chunks = (end - start + DIST_FC - 1) / DIST_FC;
+    dim3 grid((m->n + 63) / 64, (chunks + 3) / 4);
+    Img out = mk_img(outputs[0]);
+    CImg in = mk_cimg(p->input);
+    F32P ig = mk_f32(p->ingain), og = mk_f32(p->outgain), of = mk_f32(p->offset);
+#define ZH_DIST(ZF_, OD_) hipLaunchKernelGGL((k_distortion<ZF_, OD_>), grid, dim3(256), 0, st, m->n, out, in, start, end, ig, og, of)
+    if (p->type == ZH_DISTORTION_OVERDRIVE) { if (zf) ZH_DIST(true, true); else ZH_DIST(false, true); }
+    else { if (zf) ZH_DIST(true, false); else ZH_DIST(false, false); }
+#undef ZH_DIST
+    return zh_launch_status();
+}
+
+}  // extern "C"

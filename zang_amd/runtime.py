@@ -81,9 +81,12 @@ def as_buf(t):
     """torch [frames, voices] float32 CUDA tensor (row stride >= voices) -> zh_buf."""
     if isinstance(t, abi.Buf):
         return t
-    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1)):
         raise ValueError("sample image must be a float32 CUDA tensor [frames, voices] with contiguous voices")
-    return abi.Buf(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0), 0)
+    stride = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+    b = abi.Buf(t.data_ptr(), t.shape[1], t.shape[0], max(stride, t.shape[1]), 0)
+    b._keep = t
+    return b
 
 
 def as_f32(x):

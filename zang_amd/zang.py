@@ -36,17 +36,25 @@ def buffer(buf):
 class PaintCurve:
     instantaneous = abi.Curve(abi.CURVE_INSTANTANEOUS, 0, abi.F32())
 
+    # ctypes copies nested structs by value, so the tensor behind a per-voice duration is
+    # pinned on the returned struct itself.
+    @staticmethod
+    def _mk(tag, duration):
+        c = abi.Curve(tag, 0, as_f32(duration))
+        c._keep = duration
+        return c
+
     @staticmethod
     def linear(duration):
-        return abi.Curve(abi.CURVE_LINEAR, 0, as_f32(duration))
+        return PaintCurve._mk(abi.CURVE_LINEAR, duration)
 
     @staticmethod
     def squared(duration):
-        return abi.Curve(abi.CURVE_SQUARED, 0, as_f32(duration))
+        return PaintCurve._mk(abi.CURVE_SQUARED, duration)
 
     @staticmethod
     def cubed(duration):
-        return abi.Curve(abi.CURVE_CUBED, 0, as_f32(duration))
+        return PaintCurve._mk(abi.CURVE_CUBED, duration)
 
 
 def _ctx(ctx):
