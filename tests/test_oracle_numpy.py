@@ -1,0 +1,251 @@
+"""CPU: an INDEPENDENT numpy-float32 re-derivation of the stateful modules, written from the
+cited reference lines without looking at oracle/zang_oracle.c's structure, compared with the
+C oracle.  Two restatements that agree bit for bit are the strongest pin available while
+the reference itself cannot be built.  Pure-Python loops: small cases only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from tests import util
+
+f32 = np.float32
+u32 = lambda x: int(x) & 0xFFFFFFFF
+SR = f32(48000.0)
+
+
+def utof23(x):                       # PulseOsc.zig:19-21
+    return np.array([(u32(x) >> 9) | 0x3F800000], np.uint32).view(np.float32)[0] - f32(1)
+
+
+def ftou32(v):                       # PulseOsc.zig:24-26
+    return int(f32(f32(f32(v) * f32(4294967296.0)) * f32(0.99995)))
+
+
+def clamp01(v):
+    return f32(0) if v < 0 else (f32(1) if v > 1 else f32(v))
+
+
+def np_pulse(cnt, n, freq, color):   # PulseOsc.zig:75-114
+    out = np.zeros(n, np.float32)
+    if freq < 0 or freq > SR / f32(8):
+        return out, cnt
+    ifreq = int(f32(f32(4294967296.0) / SR) * f32(freq))
+    brpt = ftou32(clamp01(color))
+    gain = f32(0.7)
+    with np.errstate(divide="ignore"):
+        gdf = gain / utof23(ifreq)
+    col = utof23(brpt)
+    cc121 = gdf * f32(2) * (col - f32(1)) + gain
+    cc212 = gdf * f32(2) * col - gain
+    state = 3 if u32(cnt - ifreq) < brpt else 0
+    for i in range(n):
+        p = utof23(cnt)
+        state = ((state << 1) | (1 if cnt < brpt else 0)) & 3
+        tr = state | ((1 if cnt < ifreq else 0) << 2)
+        out[i] = {3: gain, 0: -gain, 2: gdf * f32(2) * (col - p) + gain, 5: gdf * f32(2) * p - gain,
+                  7: cc121, 4: cc212}.get(tr, f32(0))
+        cnt = u32(cnt + ifreq)
+    return out, cnt
+
+
+def np_trisaw(cnt, n, freq, color):  # TriSawOsc.zig:77-118
+    out = np.zeros(n, np.float32)
+    if freq < 0 or freq > SR / f32(8):
+        return out, cnt
+    ifreq = int(f32(f32(4294967296.0) / SR) * f32(freq))
+    brpt = ftou32(clamp01(color))
+    gain = f32(0.7)
+    f = utof23(ifreq); omf = f32(1) - f; rcpf = f32(1) / f
+    col = utof23(brpt)
+    with np.errstate(divide="ignore"):
+        c1 = gain / col
+        c2 = -gain / (f32(1) - col)
+    state = 3 if u32(cnt - ifreq) < brpt else 0
+    sq = lambda v: v * v
+    for i in range(n):
+        p = utof23(cnt) - col
+        state = ((state << 1) | (1 if cnt < brpt else 0)) & 3
+        s = state | ((1 if cnt < ifreq else 0) << 2)
+        if s == 3: v = c1 * (p + p - f)
+        elif s == 0: v = c2 * (p + p - f)
+        elif s == 2: v = rcpf * (c2 * sq(p) - c1 * sq(p - f))
+        elif s == 5: v = -rcpf * (gain + c2 * sq(p + omf) - c1 * sq(p))
+        elif s == 7: v = -rcpf * (gain + c1 * omf * (p + p + omf))
+        elif s == 4: v = -rcpf * (gain + c2 * omf * (p + p + omf))
+        else: v = f32(0)
+        out[i] = gain + v
+        cnt = u32(cnt + ifreq)
+    return out, cnt
+
+
+def test_pulse_and_trisaw_const(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        freq = f32(rng.uniform(20, 6000)); color = f32(rng.uniform(0, 1)); cnt0 = int(rng.integers(0, 2 ** 32)); n = 300
+        if trial == 0: color = f32(0.0)
+        if trial == 1: color = f32(1.0)
+        if trial == 2: freq = f32(6000.5)
+        ref, cnt = np_pulse(cnt0, n, freq, color)
+        st = oracle.PulseOsc(cnt0); out = np.zeros(n, np.float32)
+        L.zo_pulseosc_paint(C.byref(st), 0, n, oracle.fptr(out), SR, oracle.constant(freq), float(color))
+        util.assert_bitexact(out, ref, f"pulse trial {trial}"); assert st.cnt == cnt
+        ref, cnt = np_trisaw(cnt0, n, freq, color)
+        st = oracle.TriSawOsc(cnt0, 0.0); out = np.zeros(n, np.float32)
+        L.zo_trisawosc_paint(C.byref(st), 0, n, oracle.fptr(out), SR, oracle.constant(freq), float(color))
+        util.assert_bitexact(out, ref, f"trisaw trial {trial}"); assert st.cnt == cnt
+
+
+def test_filter_all_types(oracle):   # Filter.zig:98-146
+    L = oracle.lib()
+    rng = np.random.default_rng(8)
+    n = 400
+    inp = rng.uniform(-1, 1, n).astype(np.float32)
+    dc = f32(3.814697265625e-6)
+    muls = {1: (1, 0, 0), 2: (0, 1, 0), 3: (0, 0, 1), 4: (1, 0, 1), 5: (1, 1, 1)}
+    for ftype, (lm, bm, hm) in muls.items():
+        cutoff = f32(rng.uniform(0, 1)); resp = f32(rng.uniform(0, 1))
+        cut = min(max(cutoff, f32(0)), f32(1)); res = f32(1) - min(max(resp, f32(0)), f32(1))
+        l = f32(0); b = f32(0); ref = np.zeros(n, np.float32)
+        for i in range(n):
+            x = inp[i] + dc
+            l = l + (cut * b - dc)
+            b = b + cut * (x - b * res - l)
+            l = l + cut * b
+            h = x - b * res - l
+            b = b + cut * h
+            ref[i] = l * f32(lm) + b * f32(bm) + h * f32(hm)
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st)); out = np.zeros(n, np.float32)
+        L.zo_filter_paint(C.byref(st), 0, n, oracle.fptr(out), oracle.fptr(inp), ftype, oracle.constant(cutoff), oracle.constant(resp))
+        util.assert_bitexact(out, ref, f"filter type {ftype}")
+        assert f32(st.l) == l and f32(st.b) == b
+
+
+class NpEnvelope:                    # Envelope.zig + painter.zig, stage-by-stage like the reference
+    IDLE, ATTACK, DECAY, SUSTAIN, RELEASE = range(5)
+
+    def __init__(self):
+        self.state = 0; self.t = f32(0); self.last = f32(0); self.start = f32(0)
+
+    def change(self, s):
+        self.state = s; self.start = self.last; self.t = f32(0)
+
+    def toward(self, buf, i, curve, goal):
+        tag, dur = curve
+        if self.t >= 1: return True, i
+        if tag == 0:
+            self.t = f32(1); self.last = f32(goal); return True, i
+        with np.errstate(divide="ignore"):
+            step = f32(1) / (f32(dur) * SR)
+        fin = False
+        while not fin and i < len(buf):
+            self.t = self.t + step
+            if self.t >= 1: self.t = f32(1); fin = True
+            it = f32(1) - self.t
+            tp = self.t if tag == 1 else (f32(1) - it * it if tag == 2 else f32(1) - it * it * it)
+            self.last = self.start + tp * (f32(goal) - self.start)
+            buf[i] += self.last; i += 1
+        return fin, i
+
+    def paint(self, buf, new_note, attack, decay, release, sustain, note_on):
+        i = 0
+        if note_on:
+            if new_note: self.change(self.ATTACK)
+            if self.state == self.IDLE: self.change(self.ATTACK)
+            if self.state == self.ATTACK:
+                fin, i = self.toward(buf, i, attack, 1.0)
+                if fin: self.change(self.DECAY if sustain < 1 else self.SUSTAIN)
+            if self.state == self.DECAY:
+                fin, i = self.toward(buf, i, decay, sustain)
+                if fin: self.change(self.SUSTAIN)
+            if self.state == self.SUSTAIN:
+                buf[i:] += f32(sustain)
+        else:
+            if self.state == self.IDLE: return
+            if self.state != self.RELEASE: self.change(self.RELEASE)
+            fin, i = self.toward(buf, i, release, 0.0)
+            if fin: self.change(self.IDLE)
+
+
+def test_envelope_scripts(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(9)
+    for trial in range(10):
+        curves = [(int(rng.integers(0, 4)), f32(rng.uniform(0.0005, 0.01))) for _ in range(3)]
+        sustain = f32(1.0) if trial % 3 == 0 else f32(rng.uniform(0.2, 0.9))
+        script = [(200, 1, 1), (577, 1, 0), (247, 0, 0), (1024, 0, 0), (300, 1, 1), (0, 1, 1), (724, 0, 0)]
+        ne = NpEnvelope(); st = oracle.Envelope(); L.zo_envelope_init(C.byref(st))
+        for (n, on, nic) in script:
+            ref = np.zeros(n, np.float32); out = np.zeros(max(n, 1), np.float32)
+            ne.paint(ref, nic, curves[0], curves[1], curves[2], sustain, on)
+            p = oracle.EnvelopeParams(SR, oracle.curve(*curves[0]), oracle.curve(*curves[1]), oracle.curve(*curves[2]), float(sustain), on)
+            L.zo_envelope_paint(C.byref(st), 0, n, oracle.fptr(out), nic, C.byref(p))
+            util.assert_bitexact(out[:n], ref, f"envelope trial {trial}")
+            assert (st.state, f32(st.painter.t), f32(st.painter.last_value), f32(st.painter.start)) == (ne.state, ne.t, ne.last, ne.start)
+
+
+def test_decimator_and_pink(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(10)
+    n = 500
+    inp = rng.uniform(-1, 1, n).astype(np.float32)
+    for fake in (f32(11025.0), f32(47999.0), f32(123.0)):
+        ratio = fake / SR; dcount = f32(1); dval = f32(0); ref = np.zeros(n, np.float32)
+        for i in range(n):                                     # Decimator.zig:44-52
+            dcount = dcount + ratio
+            if dcount >= 1: dval = inp[i]; dcount = dcount - f32(1)
+            ref[i] = dval
+        st = oracle.Decimator(); L.zo_decimator_init(C.byref(st)); out = np.zeros(n, np.float32)
+        L.zo_decimator_paint(C.byref(st), 0, n, oracle.fptr(out), SR, oracle.fptr(inp), fake)
+        util.assert_bitexact(out, ref, "decimator"); assert (f32(st.dval), f32(st.dcount)) == (dval, dcount)
+    # pink = Kellett filter over the same white stream (Noise.zig:58-66); white taken from the oracle
+    w = oracle.Noise(); L.zo_noise_init(C.byref(w), 42); white = np.zeros(n, np.float32)
+    L.zo_noise_paint(C.byref(w), 0, n, oracle.fptr(white), oracle.NOISE_WHITE)
+    b = [f32(0)] * 7; ref = np.zeros(n, np.float32)
+    k = [(0.99886, 0.0555179), (0.99332, 0.0750759), (0.96900, 0.1538520), (0.86650, 0.3104856), (0.55000, 0.5329522)]
+    for i in range(n):
+        wh = white[i]
+        for j, (a, c) in enumerate(k): b[j] = f32(a) * b[j] + wh * f32(c)
+        b[5] = f32(-0.7616) * b[5] - wh * f32(0.0168980)
+        ref[i] = b[0] + b[1] + b[2] + b[3] + b[4] + b[5] + b[6] + wh * f32(0.5362)
+        b[6] = wh * f32(0.115926)
+    p = oracle.Noise(); L.zo_noise_init(C.byref(p), 42); out = np.zeros(n, np.float32)
+    L.zo_noise_paint(C.byref(p), 0, n, oracle.fptr(out), oracle.NOISE_PINK)
+    util.assert_bitexact(out, ref, "pink")
+    assert list(p.r) == list(w.r) and not any(p.b)             # taps not written back (Noise.zig:68)
+
+
+def test_sineosc_phase_accumulation(oracle):
+    """t accumulates add by add and wraps once per paint (SineOsc.zig:40,51); sin is compared
+    with float64 numpy at 1 ulp."""
+    L = oracle.lib()
+    n, freq, phase = 700, f32(1234.5), f32(0.25)
+    step = freq / SR; t = f32(0.37); args = np.zeros(n, np.float32)
+    for i in range(n):
+        args[i] = (t + phase) * f32(np.pi) * f32(2.0)
+        t = t + step
+    st = oracle.SineOsc(0.37); out = np.zeros(n, np.float32)
+    L.zo_sineosc_paint(C.byref(st), 0, n, oracle.fptr(out), SR, oracle.constant(freq), oracle.constant(phase))
+    ref = np.sin(args.astype(np.float64)).astype(np.float32)
+    assert np.abs(out.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max() <= 1
+    assert f32(st.t) == t - np.trunc(t)
+
+
+def test_sampler_linear_interp(oracle):
+    """Sampler.zig:116-130: tfrac = (t0+1) - t, s = s0*(1-tfrac) + s1*tfrac (reference quirk kept)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(12)
+    pcm = rng.integers(-32768, 32767, 400).astype("<i2")
+    data = pcm.view(np.uint8).copy()
+    n, out_rate = 300, f32(30000.0)
+    ratio = f32(44100.0) / out_rate; t = f32(0); ref = np.zeros(n, np.float32)
+    get = lambda i: f32(pcm[i]) / f32(32768.0) if 0 <= i < len(pcm) else f32(0)
+    for i in range(n):
+        t0 = int(np.floor(t)); tfrac = f32(t0 + 1) - t
+        ref[i] = get(t0) * (f32(1) - tfrac) + get(t0 + 1) * tfrac
+        t = t + ratio
+    st = oracle.Sampler(); L.zo_sampler_init(C.byref(st)); out = np.zeros(n, np.float32)
+    p = oracle.SamplerParams(float(out_rate), 1, 44100, oracle.SAMPLE_S16, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, 0, 0)
+    L.zo_sampler_paint(C.byref(st), 0, n, oracle.fptr(out), 0, C.byref(p))
+    util.assert_bitexact(out, ref, "sampler interp"); assert f32(st.t) == t
