@@ -240,6 +240,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same workload
+    # (tools/summarize_pmc.py; counters cannot be read from inside the process)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_pulseosc4096.json")
+    if args.workload == "pulseosc" and V == 4096 and F == 1024 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+
     total_units = world * V * F * args.steps
     value = total_units / elapsed
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
@@ -251,7 +258,7 @@ def main():
         "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, zero+paint per 1024-frame buffer, 48 kHz",
                    "voices_per_gpu": V, "frames": F, "ring_images": wl.nring, "launch": "eager" if graph is None else f"hipGraph x{G} steps", "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": wl.kernel,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": wl.kernel,
                      "algorithmic_bytes_per_launch": wl.bytes_per_step, "launch_ms_hip_events": step_ms_events},
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }

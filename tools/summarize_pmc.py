@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (one counter per pass, as MI355X_MICROARCH.md prescribes)
+into profiles/<name>.json.  usage: summarize_pmc.py <kernel-substring> <out.json> <dir-with-WRITE_SIZE> <dir-with-FETCH_SIZE>"""
+import csv, glob, json, statistics, sys
+
+kernel, out, wdir, fdir = sys.argv[1:5]
+
+
+def mean_counter(d, name):
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return statistics.mean(v), len(v)
+
+
+w, nw = mean_counter(wdir, "WRITE_SIZE")
+f, nf = mean_counter(fdir, "FETCH_SIZE")
+res = {
+    "kernel": kernel,
+    "dispatches": {"WRITE_SIZE": nw, "FETCH_SIZE": nf},
+    "WRITE_SIZE_KiB_per_launch": w,
+    "FETCH_SIZE_KiB_per_launch_raw": f,
+    "corrections": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE exact for 16-B-per-lane streaming stores (MI355X_MICROARCH.md, HBM)",
+    "hbm_bytes_per_launch": (w + 2.0 * f) * 1024.0,
+}
+json.dump(res, open(out, "w"), indent=1)
+print(res)
