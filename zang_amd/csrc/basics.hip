@@ -179,13 +179,32 @@ __global__ void __launch_bounds__(256) k_mix_pass1_scalar(CImg src, uint32_t V, 
     }
 }
 
-__global__ void __launch_bounds__(256) k_mix_pass2(const float *__restrict__ partials, uint32_t tiles,
-                                                   uint32_t nframes, float *__restrict__ dst, int zero_first) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nframes) return;
+// Pass 2: dst[f] (+)= sum over tiles of partials[tile][f].  A workgroup owns 64 frames and
+// splits the tiles into MIX_SEG contiguous segments (one wave per segment); a lane adds its
+// segment's partials in tile order, then lane f of wave 0 adds the MIX_SEG segment sums in
+// segment order.  Loads are coalesced (64 consecutive frames per wave) and independent.
+constexpr int MIX_SEG = 16;
+__global__ void __launch_bounds__(64 * MIX_SEG) k_mix_pass2(const float *__restrict__ partials, uint32_t tiles,
+                                                            uint32_t nframes, float *__restrict__ dst, int zero_first) {
+    __shared__ float seg_sum[MIX_SEG][64];
+    const uint32_t lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.x * 64 + lane;
+    const uint32_t per = (tiles + MIX_SEG - 1) / MIX_SEG;
+    const uint32_t t0 = min(seg * per, tiles), t1 = min(t0 + per, tiles);
     float s = 0.0f;
-    for (uint32_t t = 0; t < tiles; t++) s += partials[(size_t)t * nframes + i];
-    dst[i] = (zero_first ? 0.0f : dst[i]) + s;
+    if (f < nframes) {
+        const float *p = partials + (size_t)t0 * nframes + f;
+#pragma unroll 8
+        for (uint32_t t = t0; t < t1; t++, p += nframes) s += *p;
+    }
+    seg_sum[seg][lane] = s;
+    __syncthreads();
+    if (seg == 0 && f < nframes) {
+        float tot = seg_sum[0][lane];
+#pragma unroll
+        for (int k = 1; k < MIX_SEG; k++) tot += seg_sum[k][lane];
+        dst[f] = (zero_first ? 0.0f : dst[f]) + tot;
+    }
 }
 
 int zh_mix_reserve(zh_ctx *ctx, size_t floats) {
@@ -202,7 +221,7 @@ int zh_mix_reserve(zh_ctx *ctx, size_t floats) {
 }
 
 void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
-    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 255) / 256), dim3(256), 0, ctx->stream, ctx->mix_partials, tiles,
+    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 63) / 64), dim3(64 * MIX_SEG), 0, ctx->stream, ctx->mix_partials, tiles,
                        nframes, dst, zero_first);
 }
 
@@ -234,8 +253,7 @@ int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_
         else
             hipLaunchKernelGGL(k_mix_pass1_scalar, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
     }
-    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 255) / 256), dim3(256), 0, ctx->stream, ctx->mix_partials, tiles,
-                       nframes, dst + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
+    zh_mix_pass2_launch(ctx, tiles, nframes, dst + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
     return zh_launch_status();
 }
 

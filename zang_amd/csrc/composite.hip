@@ -134,40 +134,51 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
     nice_store(n, a, v);
 }
 
-// Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices; per chunk of MIXF frames
-// each wave reduces its 64 voices with an xor-shuffle butterfly, the 4 wave sums meet in LDS
-// and are added in wave order into partials[block][frame]; the second mixdown pass (basics.hip) adds the
-// block partials in block order.  Fixed order => reproducible bits.
-constexpr int MIXF = 8;
+// Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
+// into an LDS tile [wave][frame][lane] (row stride 65 floats: conflict-free column writes and
+// row reads), then every lane sums half a row -- lane (f, h) adds voices 32h..32h+31 of frame f
+// left to right -- and lanes 0..MIXF-1 combine the 8 half-row sums in (wave, half) order into
+// partials[block][frame].  One ds_write + one ds_read + one add per lane-frame, instead of a
+// 6-step cross-lane butterfly per frame.  The second mixdown pass (basics.hip) adds the block
+// partials in block order.  Fixed order => reproducible bits.
+constexpr int MIXF = 32;
+constexpr int MIXS = 65;
 
 __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials) {
-    __shared__ float wsum[MIXF][4];
+    __shared__ float tile[4][MIXF][MIXS];
+    __shared__ float halfsum[MIXF][8];
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nframes = end - start;
     const bool live = v < a.V;
     NiceLane n;
     if (live) nice_load(n, a, v);
+    const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
-        float acc[MIXF];
-#pragma unroll
+#pragma unroll 4
         for (int k = 0; k < MIXF; k++) {
             float x = 0.0f;
             if (live && f0 + k < end) x = 0.0f + n.frame();            // the voice's own out (zeroed) += env*flt
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-            acc[k] = x;
+            tile[wave][k][lane] = x;
         }
-        if (lane == 0) {
+        __syncthreads();
+        {
+            const float *row = &tile[wave][rf][rh * 32];
+            float s = row[0];
 #pragma unroll
-            for (int k = 0; k < MIXF; k++) wsum[k][wave] = acc[k];
+            for (int j = 1; j < 32; j++) s += row[j];
+            halfsum[rf][wave * 2 + rh] = s;
         }
         __syncthreads();
         if (threadIdx.x < MIXF && f0 + threadIdx.x < end) {
-            const float *w = wsum[threadIdx.x];
-            partials[(size_t)blockIdx.x * nframes + (f0 - start) + threadIdx.x] = ((w[0] + w[1]) + w[2]) + w[3];
+            const float *w = halfsum[threadIdx.x];
+            float s = w[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) s += w[j];
+            partials[(size_t)blockIdx.x * nframes + (f0 - start) + threadIdx.x] = s;
         }
-        __syncthreads();
+        // the next chunk's tile writes are ordered behind this chunk's reads by the barrier above
+        // (rows are only read before it) and halfsum is rewritten only after the next barrier
     }
     if (live) nice_store(n, a, v);
 }
