@@ -296,6 +296,48 @@ ZH_API int zh_pmosc_paint(zh_pmosc *m, uint32_t span_start, uint32_t span_end, c
                           const zh_buf *temps /*[3], unused; may be NULL*/,
                           zh_bool note_id_changed, const zh_pmosc_params *params, uint32_t flags);    /* :101-127 */
 
+/* ---------------------------------------------------------------- event scheduling (host side; no GPU work)
+ * The immediate caller of every paint: song / key events -> impulses ->
+ * per-voice (span, params, note_id_changed) tuples.  A C++ restatement of src/zang/notes.zig and
+ * src/zang/trigger.zig behind the same call shapes; `params` are opaque blobs of `params_size`
+ * bytes (the Zig code is generic over NoteParamsType).  Slices returned by consume/dispatch stay
+ * valid until the next call on the same object, like the Zig versions' internal arrays. */
+typedef struct zh_impulse { uint64_t frame, note_id, event_id; } zh_impulse;                          /* notes.zig:58-62 */
+typedef struct zh_iap { const zh_impulse *impulses; const void *paramses; uint64_t len; } zh_iap;     /* ImpulsesAndParamses :66-70 */
+enum { ZH_MAX_IMPULSES = 32, ZH_MAX_PARAMS_SIZE = 64 };                                               /* notes.zig:73-74 */
+
+typedef struct zh_impulse_queue zh_impulse_queue;                                                     /* notes.zig:72-128 */
+ZH_API int zh_impulse_queue_create(uint32_t params_size, zh_impulse_queue **out);
+ZH_API int zh_impulse_queue_destroy(zh_impulse_queue *q);
+ZH_API int zh_impulse_queue_push(zh_impulse_queue *q, uint64_t impulse_frame, uint64_t note_id, const void *params);
+ZH_API int zh_impulse_queue_consume(zh_impulse_queue *q, zh_iap *out);
+
+typedef struct zh_note_tracker zh_note_tracker;                                                       /* notes.zig:138-207 */
+/* song: n events, each {params blob, t (seconds, f32), note_id}; given as three parallel arrays (copied) */
+ZH_API int zh_note_tracker_create(uint32_t params_size, uint64_t n_events, const void *paramses, const float *t,
+                                  const uint64_t *note_ids, zh_note_tracker **out);
+ZH_API int zh_note_tracker_destroy(zh_note_tracker *nt);
+ZH_API int zh_note_tracker_reset(zh_note_tracker *nt);
+ZH_API int zh_note_tracker_consume(zh_note_tracker *nt, float sample_rate, uint64_t span_start, uint64_t span_end, zh_iap *out);
+
+typedef struct zh_polyphony_dispatcher zh_polyphony_dispatcher;                                       /* notes.zig:209-349 */
+/* note_on is read from each params blob at byte `note_on_offset` (1 byte, non-zero = on) */
+ZH_API int zh_polyphony_dispatcher_create(uint32_t polyphony, uint32_t params_size, uint32_t note_on_offset,
+                                          zh_polyphony_dispatcher **out);
+ZH_API int zh_polyphony_dispatcher_destroy(zh_polyphony_dispatcher *pd);
+ZH_API int zh_polyphony_dispatcher_reset(zh_polyphony_dispatcher *pd);
+ZH_API int zh_polyphony_dispatcher_dispatch(zh_polyphony_dispatcher *pd, zh_iap iap, zh_iap *out /*[polyphony]*/);
+
+typedef struct zh_trigger zh_trigger;                                                                 /* trigger.zig:26-198 */
+typedef struct zh_paint_span {                                                                        /* NewPaintReturnValue :50-54 */
+    uint64_t start, end; uint32_t note_id_changed; uint32_t reserved; uint8_t params[64];
+} zh_paint_span;
+ZH_API int zh_trigger_create(uint32_t params_size, zh_trigger **out);
+ZH_API int zh_trigger_destroy(zh_trigger *t);
+ZH_API int zh_trigger_reset(zh_trigger *t);                                                           /* :62-64 */
+ZH_API int zh_trigger_counter(zh_trigger *t, uint64_t span_start, uint64_t span_end, zh_iap iap);     /* :66-78 */
+ZH_API int zh_trigger_next(zh_trigger *t, zh_paint_span *out);   /* :80-105; returns 1 = span produced, 0 = null, <0 error */
+
 #ifdef __cplusplus
 }
 #endif

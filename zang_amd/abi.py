@@ -133,6 +133,18 @@ class PMOscState(C.Structure):
     _fields_ = [("carrier", SineOscState), ("modulator", SineOscState), ("env", EnvelopeState)]
 
 
+class Impulse(C.Structure):
+    _fields_ = [("frame", u64), ("note_id", u64), ("event_id", u64)]
+
+
+class Iap(C.Structure):
+    _fields_ = [("impulses", C.POINTER(Impulse)), ("paramses", vp), ("len", u64)]
+
+
+class PaintSpan(C.Structure):
+    _fields_ = [("start", u64), ("end", u64), ("note_id_changed", u32), ("reserved", u32), ("params", C.c_uint8 * 64)]
+
+
 P = C.POINTER
 _paint = lambda params: [vp, u32, u32, P(Buf), P(Buf), Bool, P(params), u32]
 
@@ -233,6 +245,23 @@ SIGNATURES = {
     "zh_pmosc_get_state": (C.c_int, [vp, vp]),
     "zh_pmosc_set_state": (C.c_int, [vp, vp]),
     "zh_pmosc_paint": (C.c_int, _paint(PMOscParams)),
+    "zh_impulse_queue_create": (C.c_int, [u32, P(vp)]),
+    "zh_impulse_queue_destroy": (C.c_int, [vp]),
+    "zh_impulse_queue_push": (C.c_int, [vp, u64, u64, vp]),
+    "zh_impulse_queue_consume": (C.c_int, [vp, P(Iap)]),
+    "zh_note_tracker_create": (C.c_int, [u32, u64, vp, P(f32), P(u64), P(vp)]),
+    "zh_note_tracker_destroy": (C.c_int, [vp]),
+    "zh_note_tracker_reset": (C.c_int, [vp]),
+    "zh_note_tracker_consume": (C.c_int, [vp, f32, u64, u64, P(Iap)]),
+    "zh_polyphony_dispatcher_create": (C.c_int, [u32, u32, u32, P(vp)]),
+    "zh_polyphony_dispatcher_destroy": (C.c_int, [vp]),
+    "zh_polyphony_dispatcher_reset": (C.c_int, [vp]),
+    "zh_polyphony_dispatcher_dispatch": (C.c_int, [vp, Iap, P(Iap)]),
+    "zh_trigger_create": (C.c_int, [u32, P(vp)]),
+    "zh_trigger_destroy": (C.c_int, [vp]),
+    "zh_trigger_reset": (C.c_int, [vp]),
+    "zh_trigger_counter": (C.c_int, [vp, u64, u64, Iap]),
+    "zh_trigger_next": (C.c_int, [vp, P(PaintSpan)]),
 }
 
 _lib = None

@@ -111,3 +111,7 @@ def mixdownVoices(span, dst, src, zero_first=False, ctx=None):
     c = _ctx(ctx)
     abi.check(c.lib.zh_mixdown_voices(c.handle, span.start, span.end, dst.data_ptr(), as_buf(src),
                                       abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD), "zh_mixdown_voices")
+
+
+# ---- event scheduling (src/zang/notes.zig, src/zang/trigger.zig): re-exported like src/zang.zig does
+from .notes import Impulse, Notes, Trigger, ImpulsesAndParamses  # noqa: E402,F401
