@@ -127,6 +127,16 @@ ZH_API int zh_multiply_with_scalar(zh_ctx *ctx, uint32_t span_start, uint32_t sp
  * summed in a FIXED tree order (wave shuffle -> LDS -> block partials -> second pass) so
  * results are reproducible run to run.  `dst` is a device float[frames]. */
 ZH_API int zh_mixdown_voices(zh_ctx *ctx, uint32_t span_start, uint32_t span_end, float *dst, zh_buf src, uint32_t flags);
+/* flags for zh_mixdown_voices: ZH_PAINT_ZERO_FIRST, and ZH_MIX_SEQUENTIAL = add voice 0, 1, 2, ... in
+ * that order in f32 exactly like successive `+=` paints onto one buffer (example_song.zig:340-346);
+ * bit-faithful, meant for small voice counts (one lane per frame walks all voices). */
+enum { ZH_MIX_SEQUENTIAL = 2 };
+
+/* zang.mixDown (src/zang/mixdown.zig:8-86): f32 mix buffer -> interleaved signed 8 / 16-bit LE PCM with
+ * clamping.  `dst` (device bytes, n * bytes_per_sample * num_channels) and `mix` (device float[n]). */
+enum { ZH_AUDIO_SIGNED8 = 0, ZH_AUDIO_SIGNED16_LSB = 1 };                                             /* :3-6 */
+ZH_API int zh_mix_down(zh_ctx *ctx, uint8_t *dst, const float *mix, uint32_t n, uint32_t audio_format,
+                       uint32_t num_channels, uint32_t channel_index, float vol);
 
 /* ---------------------------------------------------------------- SineOsc (src/modules/SineOsc.zig) */
 typedef struct zh_sineosc zh_sineosc;
@@ -284,6 +294,22 @@ ZH_API int zh_nice_paint(zh_nice *m, uint32_t span_start, uint32_t span_end, con
 ZH_API int zh_nice_paint_mix(zh_nice *m, uint32_t span_start, uint32_t span_end, float *mix,
                              zh_bool note_id_changed, const zh_nice_params *params, uint32_t flags);
 
+/* Per-voice span table: the output of NoteTracker -> PolyphonyDispatcher -> Trigger for one buffer
+ * (examples/example_song.zig:326-349), i.e. for every voice up to `max_spans` sub-spans, ascending and
+ * non-overlapping, each with the note's params and note_id_changed.  One launch then performs, per voice,
+ * the same sequence of paint(sub_span, ..., note_id_changed, params) calls the reference's Trigger loop
+ * makes (per-call prologue/epilogue included), while all lanes stay on the same frame.  Arrays are device
+ * memory laid out [span_index][voice]. */
+typedef struct zh_span_table {
+    uint32_t max_spans, reserved;
+    const uint32_t *count;                       /* [n_voices]            */
+    const uint32_t *start, *end;                 /* [max_spans][n_voices] */
+    const float    *freq;                        /* [max_spans][n_voices] */
+    const uint8_t  *note_on, *note_id_changed;   /* [max_spans][n_voices] */
+} zh_span_table;
+ZH_API int zh_nice_paint_spans(zh_nice *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                               const zh_buf *temps, float sample_rate, const zh_span_table *table, uint32_t flags);
+
 /* ---------------------------------------------------------------- PMOscInstrument (examples/modules.zig:6-128) */
 typedef struct zh_pmosc zh_pmosc;
 typedef struct zh_pmosc_params { float sample_rate; uint32_t reserved; zh_f32 freq; zh_bool note_on; } zh_pmosc_params; /* :83-87 */
@@ -295,6 +321,8 @@ ZH_API int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host);
 ZH_API int zh_pmosc_paint(zh_pmosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                           const zh_buf *temps /*[3], unused; may be NULL*/,
                           zh_bool note_id_changed, const zh_pmosc_params *params, uint32_t flags);    /* :101-127 */
+ZH_API int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                                const zh_buf *temps, float sample_rate, const zh_span_table *table, uint32_t flags);
 
 /* ---------------------------------------------------------------- event scheduling (host side; no GPU work)
  * The immediate caller of every paint: song / key events -> impulses ->

@@ -12,6 +12,8 @@ u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 
 ZH_OK = 0
 PAINT_ADD, PAINT_ZERO_FIRST = 0, 1
+MIX_SEQUENTIAL = 2
+AUDIO_SIGNED8, AUDIO_SIGNED16_LSB = 0, 1
 COB_CONSTANT, COB_BUFFER = 0, 1
 CURVE_INSTANTANEOUS, CURVE_LINEAR, CURVE_SQUARED, CURVE_CUBED = 0, 1, 2, 3
 NOISE_WHITE, NOISE_PINK = 0, 1
@@ -133,6 +135,11 @@ class PMOscState(C.Structure):
     _fields_ = [("carrier", SineOscState), ("modulator", SineOscState), ("env", EnvelopeState)]
 
 
+class SpanTable(C.Structure):
+    _fields_ = [("max_spans", u32), ("reserved", u32), ("count", vp), ("start", vp), ("end", vp), ("freq", vp),
+                ("note_on", vp), ("note_id_changed", vp)]
+
+
 class Impulse(C.Structure):
     _fields_ = [("frame", u64), ("note_id", u64), ("event_id", u64)]
 
@@ -245,6 +252,9 @@ SIGNATURES = {
     "zh_pmosc_get_state": (C.c_int, [vp, vp]),
     "zh_pmosc_set_state": (C.c_int, [vp, vp]),
     "zh_pmosc_paint": (C.c_int, _paint(PMOscParams)),
+    "zh_mix_down": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, f32]),
+    "zh_nice_paint_spans": (C.c_int, [vp, u32, u32, P(Buf), P(Buf), f32, P(SpanTable), u32]),
+    "zh_pmosc_paint_spans": (C.c_int, [vp, u32, u32, P(Buf), P(Buf), f32, P(SpanTable), u32]),
     "zh_impulse_queue_create": (C.c_int, [u32, P(vp)]),
     "zh_impulse_queue_destroy": (C.c_int, [vp]),
     "zh_impulse_queue_push": (C.c_int, [vp, u64, u64, vp]),
@@ -278,6 +288,9 @@ def load(strict=True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64; load it first so that libzang_hip.so binds to the same HIP
+    # runtime (two runtimes in one process cannot both see the device).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ZangHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

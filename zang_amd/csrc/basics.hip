@@ -207,6 +207,44 @@ __global__ void __launch_bounds__(64 * MIX_SEG) k_mix_pass2(const float *__restr
     }
 }
 
+// ZH_MIX_SEQUENTIAL: one lane per frame adds voice 0, 1, 2, ... in f32, the exact order of successive
+// `+=` paints onto one buffer in the reference (example_song.zig:340-346).  Each lane walks its
+// own image row, so this form is for small voice counts only (17 sub-voices in example_song).
+__global__ void __launch_bounds__(64) k_mix_sequential(CImg src, uint32_t V, uint32_t start, uint32_t end,
+                                                       float *__restrict__ dst, int zero_first) {
+    const uint32_t f = start + blockIdx.x * 64 + threadIdx.x;
+    if (f >= end) return;
+    float s = zero_first ? 0.0f : dst[f];
+    const float *row = src.at(f, 0);
+    for (uint32_t v = 0; v < V; v++) s += row[v];
+    dst[f] = s;
+}
+
+// mixDown (src/zang/mixdown.zig:28-86)
+__global__ void __launch_bounds__(256) k_mix_down(uint8_t *__restrict__ dst, const float *__restrict__ mix, uint32_t n,
+                                                  int s16, uint32_t num_channels, uint32_t channel_index, float mul) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float value = mix[i] * mul;
+    if (s16) {                                                        // :40-56
+        int32_t c;
+        if (value <= -32767.0f) c = -32767;
+        else if (value >= 32766.0f) c = 32766;
+        else if (value != value) c = 0;
+        else c = (int32_t)value;
+        const size_t index = ((size_t)i * num_channels + channel_index) * 2;
+        dst[index + 0] = (uint8_t)(c & 0xFF);
+        dst[index + 1] = (uint8_t)((c >> 8) & 0xFF);
+    } else {                                                          // :71-85
+        int32_t c;
+        if (value <= -127.0f) c = -127;
+        else if (value >= 126.0f) c = 126;
+        else if (value != value) c = 0;
+        else c = (int32_t)value;
+        dst[(size_t)i * num_channels + channel_index] = (uint8_t)(int8_t)c;
+    }
+}
+
 int zh_mix_reserve(zh_ctx *ctx, size_t floats) {
     if (ctx->mix_partials_floats >= floats) return ZH_OK;
     if (ctx->mix_partials) {
@@ -243,6 +281,11 @@ int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_
     if (!ctx || !dst || end < start || !buf_covers(src, src.voices, end)) return ZH_ERR_INVALID;
     const uint32_t V = src.voices, nframes = end - start;
     if (nframes == 0) return ZH_OK;
+    if (flags & ZH_MIX_SEQUENTIAL) {
+        hipLaunchKernelGGL(k_mix_sequential, dim3((nframes + 63) / 64), dim3(64), 0, ctx->stream, mk_cimg(src), V, start, end,
+                           dst, (int)(flags & ZH_PAINT_ZERO_FIRST));
+        return zh_launch_status();
+    }
     const uint32_t tiles = V == 0 ? 0 : (V + MIX_TILE - 1) / MIX_TILE;
     if (tiles) {
         int rc = zh_mix_reserve(ctx, (size_t)tiles * nframes);
@@ -254,6 +297,17 @@ int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_
             hipLaunchKernelGGL(k_mix_pass1_scalar, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
     }
     zh_mix_pass2_launch(ctx, tiles, nframes, dst + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
+    return zh_launch_status();
+}
+
+int zh_mix_down(zh_ctx *ctx, uint8_t *dst, const float *mix, uint32_t n, uint32_t audio_format, uint32_t num_channels,
+                uint32_t channel_index, float vol) {
+    if (!ctx || (n && (!dst || !mix)) || audio_format > ZH_AUDIO_SIGNED16_LSB || num_channels == 0 || channel_index >= num_channels)
+        return ZH_ERR_INVALID;
+    if (!n) return ZH_OK;
+    const int s16 = audio_format == ZH_AUDIO_SIGNED16_LSB;
+    const float mul = vol * (s16 ? 32767.0f : 127.0f);                // mixdown.zig:37, :68
+    hipLaunchKernelGGL(k_mix_down, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dst, mix, n, s16, num_channels, channel_index, mul);
     return zh_launch_status();
 }
 

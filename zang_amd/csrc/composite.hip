@@ -11,6 +11,7 @@
 #include "seq.cuh"
 #include "envelope.cuh"
 #include <vector>
+#include <string.h>
 
 // basics.hip
 int zh_mix_reserve(zh_ctx *ctx, size_t floats);
@@ -197,26 +198,25 @@ struct PMOscArgs {
 
 __device__ __forceinline__ float pm_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }   // SineOsc.zig:4-6
 
-template <bool ZF>
-__global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint32_t start, uint32_t end) {
-    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
-    if (v >= a.V) return;
-    const float freq = a.freq.get(v);
-    float tc = a.tc[v], tm = a.tm[v];
+struct PMLane {
+    float tc, tm;                 // carrier.t, modulator.t
+    float mod_freq, inv_sr, t_step;
     EnvLane env;
-    env.state = a.estate[v]; env.t = a.et[v]; env.last_value = a.elast[v]; env.start = a.estart[v];
-    env.sample_rate = a.sample_rate;                                   // examples/modules.zig:118-125
-    env.sustain_volume = 0.5f;
-    env.attack = CurveP{ZH_CURVE_CUBED, 0.025f};
-    env.decay = CurveP{ZH_CURVE_CUBED, 0.1f};
-    env.release = CurveP{ZH_CURVE_CUBED, a.release_duration[v]};
-    env.note_on = a.note_on.get(v);
-    env.begin(a.nic.get(v));
-    const float mod_freq = freq * 1.0f;                                // set(temps[0], freq * ratio), ratio = 1 (:45)
-    const float inv_sr = 1.0f / a.sample_rate;                         // modulator: controlled-frequency path (SineOsc.zig:66)
-    const float t_step = freq / a.sample_rate;                         // carrier: constant-frequency path (:44)
-    const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+
+    __device__ __forceinline__ void begin(float sample_rate, float freq, float release_duration, bool note_on, bool new_note) {
+        env.sample_rate = sample_rate;                                 // examples/modules.zig:118-125
+        env.sustain_volume = 0.5f;
+        env.attack = CurveP{ZH_CURVE_CUBED, 0.025f};
+        env.decay = CurveP{ZH_CURVE_CUBED, 0.1f};
+        env.release = CurveP{ZH_CURVE_CUBED, release_duration};
+        env.note_on = note_on;
+        env.begin(new_note);
+        mod_freq = freq * 1.0f;                                        // set(temps[0], freq * ratio), ratio = 1 (:45)
+        inv_sr = 1.0f / sample_rate;                                   // modulator: controlled-frequency path (SineOsc.zig:66)
+        t_step = freq / sample_rate;                                   // carrier: constant-frequency path (:44)
+    }
+
+    __device__ __forceinline__ float frame() {
         // modulator.paint -> temps[1] (zeroed): sin(t + 0.0), t += freq_buf[i] * inv_sr   (:59-63)
         const float m = 0.0f + pm_sin(tm + 0.0f);
         tm += mod_freq * inv_sr;
@@ -230,14 +230,114 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
         // envelope -> temps[1] (zeroed)   (:117-125)
         float ev = 0.0f, e0 = 0.0f;
         if (env.frame(true, ev)) e0 = 0.0f + ev;
-        val = osc * e0;                                                // multiply(out, temps[0], temps[1]) :126
+        return osc * e0;                                               // multiply(out, temps[0], temps[1]) :126
+    }
+
+    // end of one paint call: envelope cascade, and both SineOsc `t - trunc(t)` wraps (SineOsc.zig:40)
+    __device__ __forceinline__ void end() {
+        float dummy;
+        env.frame(false, dummy);
+        tc = tc - truncf(tc);
+        tm = tm - truncf(tm);
+    }
+};
+
+__device__ __forceinline__ void pm_load(PMLane &n, const PMOscArgs &a, uint32_t v) {
+    n.tc = a.tc[v]; n.tm = a.tm[v];
+    n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
+}
+__device__ __forceinline__ void pm_store(const PMLane &n, const PMOscArgs &a, uint32_t v) {
+    a.tc[v] = n.tc; a.tm[v] = n.tm;
+    a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= a.V) return;
+    PMLane n;
+    pm_load(n, a, v);
+    n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+        val = n.frame();
         return true;
     });
-    float dummy;
-    env.frame(false, dummy);
-    a.tc[v] = tc - truncf(tc);                                         // SineOsc.zig:40, once per paint
-    a.tm[v] = tm - truncf(tm);
-    a.estate[v] = env.state; a.et[v] = env.t; a.elast[v] = env.last_value; a.estart[v] = env.start;
+    n.end();
+    pm_store(n, a, v);
+}
+
+// ------------------------------------------------------------------ span-table paints
+// One launch = for every voice, the reference's Trigger loop over its sub-spans
+// (examples/example_song.zig:336-347): begin() at a sub-span's first frame, end() after its last,
+// nothing painted between sub-spans.  All lanes walk the buffer frame by frame together.
+struct SpanTableP {
+    uint32_t K;
+    const uint32_t *count, *start, *end;
+    const float *freq;
+    const uint8_t *note_on, *nic;
+};
+
+template <bool ZF, class Lane, class Begin, class End>
+__device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_t V, uint32_t v, Img out,
+                                          uint32_t buf_start, uint32_t buf_end, Begin &&begin, End &&end_fn) {
+    const uint32_t cnt = min(tb.count[v], tb.K);
+    uint32_t k = 0, cur_end = 0;
+    bool active = false;
+    const float *const *no_in = nullptr;
+    auto advance = [&](uint32_t i) {
+        for (;;) {
+            if (active) {
+                if (i == cur_end) { end_fn(); active = false; k++; continue; }
+                break;
+            }
+            if (k < cnt && tb.start[(size_t)k * V + v] == i) {
+                const size_t idx = (size_t)k * V + v;
+                cur_end = tb.end[idx];
+                begin(tb.freq[idx], tb.note_on[idx] != 0, tb.nic[idx] != 0);
+                active = true;
+                continue;
+            }
+            break;
+        }
+    };
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, buf_start, buf_end, [&](uint32_t i, const float (&)[1], float &val) {
+        advance(i);
+        if (!active) return false;
+        val = n.frame();
+        return true;
+    });
+    advance(buf_end);          // a sub-span that ends with the buffer; empty sub-spans at buf_end
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_nice_spans(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= a.V) return;
+    NiceLane n;
+    n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
+    n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
+    n.bad = true; n.ifreq = 0; n.brpt = 0; n.gdf2 = n.col = n.cc121 = n.cc212 = n.cut = n.res = 0.0f;
+    const float color = a.color[v];
+    span_walk<ZF>(n, tb, a.V, v, out, start, end,
+                  [&](float freq, bool on, bool nic) { n.begin(a.sample_rate, a.srf, a.sr8, freq, color, on, nic); },
+                  [&]() { float d; n.env.frame(false, d); });
+    a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
+    a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= a.V) return;
+    PMLane n;
+    pm_load(n, a, v);
+    n.mod_freq = n.inv_sr = n.t_step = 0.0f;
+    const float rel = a.release_duration[v];
+    span_walk<ZF>(n, tb, a.V, v, out, start, end,
+                  [&](float freq, bool on, bool nic) { n.begin(a.sample_rate, freq, rel, on, nic); },
+                  [&]() { n.end(); });
+    pm_store(n, a, v);
 }
 
 __global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
@@ -371,6 +471,29 @@ int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_b
     return zh_launch_status();
 }
 
+static bool span_table_ok(const zh_span_table *t) {
+    return t && t->max_spans > 0 && t->count && t->start && t->end && t->freq && t->note_on && t->note_id_changed;
+}
+static SpanTableP mk_span_table(const zh_span_table *t) {
+    return SpanTableP{t->max_spans, t->count, t->start, t->end, t->freq, t->note_on, t->note_id_changed};
+}
+
+int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                        float sample_rate, const zh_span_table *table, uint32_t flags) {
+    (void)temps;
+    if (!m || !outputs || end < start || !buf_covers(outputs[0], m->n, end) || !span_table_ok(table)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    hipStream_t st = m->ctx->stream;
+    zh_nice_params p;
+    memset(&p, 0, sizeof p);
+    p.sample_rate = sample_rate;
+    zh_bool no = {0, 0, nullptr};
+    NiceArgs a = nice_args(m, &p, no);
+    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_nice_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    else hipLaunchKernelGGL(k_nice_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    return zh_launch_status();
+}
+
 // ------------------------------------------------------------------ PMOscInstrument
 int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc **out) {
     if (!ctx || !out) return ZH_ERR_INVALID;
@@ -445,6 +568,19 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
                 mk_f32(p->freq), mk_bool(p->note_on), mk_bool(note_id_changed)};
     if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_pmosc<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    return zh_launch_status();
+}
+
+int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                         float sample_rate, const zh_span_table *table, uint32_t flags) {
+    (void)temps;
+    if (!m || !outputs || end < start || !buf_covers(outputs[0], m->n, end) || !span_table_ok(table)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;
+    hipStream_t st = m->ctx->stream;
+    PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, sample_rate,
+                F32P{0.0f, nullptr}, BoolP{0, nullptr}, BoolP{0, nullptr}};
+    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    else hipLaunchKernelGGL(k_pmosc_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
 }
 

@@ -298,6 +298,12 @@ class NiceInstrument(_Module):
         cp = abi.NiceParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
         self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
 
+    def paint_spans(self, span, outputs, temps, sample_rate, table, zero_first=False):
+        """Render every voice's Trigger sub-spans of this buffer in one launch (zang_amd.spans.SpanTable)."""
+        rc = self.lib.zh_nice_paint_spans(self.handle, span.start, span.end, _bufarray(outputs), _bufarray(temps),
+                                          float(sample_rate), C.byref(table.c), abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+        abi.check(rc, "zh_nice_paint_spans")
+
     def paint_mix(self, span, mix, note_id_changed, params, zero_first=False):
         """The fused chain followed by the voice mixdown into mix[frames] (device float32)."""
         cp = abi.NiceParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
@@ -329,3 +335,9 @@ class PMOscInstrument(_Module):
     def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
         cp = abi.PMOscParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
         self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+
+    def paint_spans(self, span, outputs, temps, sample_rate, table, zero_first=False):
+        """Render every voice's Trigger sub-spans of this buffer in one launch (zang_amd.spans.SpanTable)."""
+        rc = self.lib.zh_pmosc_paint_spans(self.handle, span.start, span.end, _bufarray(outputs), _bufarray(temps),
+                                           float(sample_rate), C.byref(table.c), abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+        abi.check(rc, "zh_pmosc_paint_spans")

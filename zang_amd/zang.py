@@ -106,11 +106,29 @@ def multiplyWithScalar(span, dest, a, ctx=None):
     c = _ctx(ctx); abi.check(c.lib.zh_multiply_with_scalar(c.handle, span.start, span.end, as_buf(dest), as_f32(a)), "zh_multiply_with_scalar")
 
 
-def mixdownVoices(span, dst, src, zero_first=False, ctx=None):
-    """dst[f] += sum over voices of src[f][v]: V x zang.addInto onto one mix buffer."""
+def mixdownVoices(span, dst, src, zero_first=False, sequential=False, ctx=None):
+    """dst[f] += sum over voices of src[f][v]: V x zang.addInto onto one mix buffer.
+    sequential=True adds the voices in index order in f32, bit-identical to the reference's
+    successive `+=` paints (small voice counts)."""
     c = _ctx(ctx)
-    abi.check(c.lib.zh_mixdown_voices(c.handle, span.start, span.end, dst.data_ptr(), as_buf(src),
-                                      abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD), "zh_mixdown_voices")
+    flags = (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | (abi.MIX_SEQUENTIAL if sequential else 0)
+    abi.check(c.lib.zh_mixdown_voices(c.handle, span.start, span.end, dst.data_ptr(), as_buf(src), flags), "zh_mixdown_voices")
+
+
+class AudioFormat:
+    """zang.AudioFormat (src/zang/mixdown.zig:3-6)."""
+    signed8 = abi.AUDIO_SIGNED8
+    signed16_lsb = abi.AUDIO_SIGNED16_LSB
+
+
+def mixDown(dst, mix_buffer, audio_format, num_channels, channel_index, vol, ctx=None):
+    """zang.mixDown (src/zang/mixdown.zig:8-24): dst uint8 CUDA tensor, mix_buffer float32 CUDA tensor [n]."""
+    c = _ctx(ctx)
+    n = mix_buffer.numel()
+    bps = 2 if audio_format == abi.AUDIO_SIGNED16_LSB else 1
+    assert dst.numel() == n * bps * num_channels            # mixdown.zig:35,66
+    abi.check(c.lib.zh_mix_down(c.handle, dst.data_ptr(), mix_buffer.data_ptr(), n, audio_format, num_channels,
+                                channel_index, float(vol)), "zh_mix_down")
 
 
 # ---- event scheduling (src/zang/notes.zig, src/zang/trigger.zig): re-exported like src/zang.zig does
