@@ -233,6 +233,11 @@ ZH_API int zh_filter_paint(zh_filter *m, uint32_t span_start, uint32_t span_end,
 ZH_API int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out_dev,
                                            const float *frequency_dev, float sample_rate);
 
+/* std.math.pow(f32, x, y) for finite x > 0, elementwise on the device (out, x, y: device float[n]).
+ * Host callers of the paint path compute scalars with it: note frequencies a4 * pow(2, semitones/12)
+ * (examples/common/songparse1.zig:61-62), Distortion's gain1 (Distortion.zig:41). */
+ZH_API int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y);
+
 /* ---------------------------------------------------------------- Sampler (src/modules/Sampler.zig) */
 typedef struct zh_sampler zh_sampler;
 enum { ZH_SAMPLE_U8 = 0, ZH_SAMPLE_S16_LSB, ZH_SAMPLE_S24_LSB, ZH_SAMPLE_S32_LSB };                   /* :9-14 */

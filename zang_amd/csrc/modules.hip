@@ -181,6 +181,11 @@ __global__ void k_cutoff_from_frequency(uint32_t n, float *__restrict__ out, con
     if (i < n) out[i] = zcutoff_from_frequency(freq[i], sample_rate);
 }
 
+__global__ void k_pow(uint32_t n, float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ y) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = zpowf_pos(x[i], y[i]);
+}
+
 // =================================================================== Sampler
 struct zh_sampler { zh_ctx *ctx; uint32_t n; float *t; };
 
@@ -623,6 +628,13 @@ int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out, 
     if (!ctx || (n && (!cutoff_out || !frequency))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_cutoff_from_frequency, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, cutoff_out, frequency, sample_rate);
+    return zh_launch_status();
+}
+
+int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y) {
+    if (!ctx || (n && (!out || !x || !y))) return ZH_ERR_INVALID;
+    if (!n) return ZH_OK;
+    hipLaunchKernelGGL(k_pow, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x, y);
     return zh_launch_status();
 }
 
