@@ -27,7 +27,7 @@ def test_parser_tokens_and_errors():
     p = song.Parser("# c\nrate 2.5 |C-4 off|    A#3\nfoo_1", 4)
     assert p.parse_token() == ("word", "rate")
     assert p.parse_token() == ("number", np.float32(2.5))
-    assert p.parse_token() == ("notes", [-9, "off", None, -14])       # C-4 = 4*12-57+0, A#3 = 3*12-57+10
+    assert p.parse_token() == ("notes", [-9, "off", None, -11])       # C-4 = 4*12-57+0 = -9, A#3 = 3*12-57+10 = -11
     assert p.parse_token() == ("word", "foo_1") and p.parse_token() is None and p.line_index == 2
     with pytest.raises(song.SongSyntaxError):
         song.Parser("|C-4 D-4 E-4", 2).parse_token()                    # too many columns (songparse1.zig:106-108)
