@@ -24,6 +24,10 @@ struct zh_event {
     hipEvent_t ev;
 };
 
+// every per-frame lambda must be inlined into frame_loop: an outlined closure forces the lane
+// state (captured by reference) out of VGPRs into scratch
+#define ZH_INLINE_LAMBDA __attribute__((always_inline))
+
 #define ZH_TRY(expr)                                   \
     do {                                               \
         hipError_t _e = (expr);                        \

@@ -92,7 +92,7 @@ struct NiceLane {
         const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);
         // temps[0] = 0 (+ envelope)
         float ev = 0.0f, e0 = 0.0f;
-        if (env.frame(true, ev)) e0 = 0.0f + ev;
+        if (env.frame(ev)) e0 = 0.0f + ev;
         return e0 * t1;                                                // multiply :246: out += temps[0]*temps[1]
     }
 };
@@ -115,8 +115,6 @@ __device__ __forceinline__ void nice_load(NiceLane &n, const NiceArgs &a, uint32
     n.begin(a.sample_rate, a.srf, a.sr8, a.freq.get(v), a.color[v], a.note_on.get(v), a.nic.get(v));
 }
 __device__ __forceinline__ void nice_store(NiceLane &n, const NiceArgs &a, uint32_t v) {
-    float dummy;
-    n.env.frame(false, dummy);                                         // end-of-span cascade
     a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
     a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
 }
@@ -128,7 +126,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
     NiceLane n;
     nice_load(n, a, v);
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         val = n.frame();
         return true;
     });
@@ -229,14 +227,12 @@ struct PMLane {
         const float osc = 0.0f + c;
         // envelope -> temps[1] (zeroed)   (:117-125)
         float ev = 0.0f, e0 = 0.0f;
-        if (env.frame(true, ev)) e0 = 0.0f + ev;
+        if (env.frame(ev)) e0 = 0.0f + ev;
         return osc * e0;                                               // multiply(out, temps[0], temps[1]) :126
     }
 
     // end of one paint call: envelope cascade, and both SineOsc `t - trunc(t)` wraps (SineOsc.zig:40)
     __device__ __forceinline__ void end() {
-        float dummy;
-        env.frame(false, dummy);
         tc = tc - truncf(tc);
         tm = tm - truncf(tm);
     }
@@ -259,7 +255,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
     pm_load(n, a, v);
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         val = n.frame();
         return true;
     });
@@ -285,7 +281,7 @@ __device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_
     uint32_t k = 0, cur_end = 0;
     bool active = false;
     const float *const *no_in = nullptr;
-    auto advance = [&](uint32_t i) {
+    auto advance = [&](uint32_t i) ZH_INLINE_LAMBDA {
         for (;;) {
             if (active) {
                 if (i == cur_end) { end_fn(); active = false; k++; continue; }
@@ -301,7 +297,7 @@ __device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_
             break;
         }
     };
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, buf_start, buf_end, [&](uint32_t i, const float (&)[1], float &val) {
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, buf_start, buf_end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         advance(i);
         if (!active) return false;
         val = n.frame();
@@ -320,8 +316,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice_spans(NiceArgs a, SpanTableP
     n.bad = true; n.ifreq = 0; n.brpt = 0; n.gdf2 = n.col = n.cc121 = n.cc212 = n.cut = n.res = 0.0f;
     const float color = a.color[v];
     span_walk<ZF>(n, tb, a.V, v, out, start, end,
-                  [&](float freq, bool on, bool nic) { n.begin(a.sample_rate, a.srf, a.sr8, freq, color, on, nic); },
-                  [&]() { float d; n.env.frame(false, d); });
+                  [&](float freq, bool on, bool nic) ZH_INLINE_LAMBDA { n.begin(a.sample_rate, a.srf, a.sr8, freq, color, on, nic); },
+                  [&]() ZH_INLINE_LAMBDA {});
     a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
     a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
 }
@@ -335,8 +331,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
     n.mod_freq = n.inv_sr = n.t_step = 0.0f;
     const float rel = a.release_duration[v];
     span_walk<ZF>(n, tb, a.V, v, out, start, end,
-                  [&](float freq, bool on, bool nic) { n.begin(a.sample_rate, freq, rel, on, nic); },
-                  [&]() { n.end(); });
+                  [&](float freq, bool on, bool nic) ZH_INLINE_LAMBDA { n.begin(a.sample_rate, freq, rel, on, nic); },
+                  [&]() ZH_INLINE_LAMBDA { n.end(); });
     pm_store(n, a, v);
 }
 

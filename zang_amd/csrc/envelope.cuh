@@ -1,15 +1,17 @@
 // envelope.cuh -- Envelope (src/modules/Envelope.zig) over Painter (src/zang/painter.zig) as
-// a per-lane, per-frame state machine, shared by the Envelope kernel and the fused voices.
+// a per-lane state machine, shared by the Envelope kernel and the fused voices.
 //
-// The reference paints stage after stage (paintToward until finished or the buffer ends,
-// then the next stage continues where the last one stopped: Envelope.zig:52-70).  Here every
-// lane steps its own machine once per frame so that all 64 lanes stay on the same frame
-// (coalesced image rows).  Equivalence: paintToward's entry tests (`t >= 1`, instantaneous;
-// painter.zig:69-80) cannot become true in the middle of a stage, so evaluating them at
-// every frame equals evaluating them once per call; stages that finish WITHOUT painting a
-// frame cascade within the frame, exactly like the reference falls from one `if (state ==`
-// to the next; and the cascade runs once more after the last frame, because the reference
-// still calls paintToward (which may finish instantly) when no frames remain.
+// The reference paints stage after stage (paintToward until finished or the buffer ends, then
+// the next stage continues where the last one stopped: Envelope.zig:52-70).  Here every lane
+// steps once per frame so that all 64 lanes stay on the same frame (coalesced image rows).
+// The per-frame step is kept cheap and uniform: a lane is in one of three modes --
+//   TOWARD: one paintToward loop iteration (painter.zig:102-116),
+//   FLAT:   paintFlat's constant (painter.zig:53-58),
+//   NONE:   nothing is painted (idle, or the assert case below) --
+// and everything that takes zero time (state changes, paintToward's entry tests `t >= 1` and
+// `instantaneous`, painter.zig:69-80) is resolved in resolve(), which runs exactly where the
+// reference evaluates it: at the start of a paint call and whenever a stage finishes (the
+// reference then immediately calls the next stage's paintToward, even with no frames left).
 #pragma once
 #include "common.cuh"
 
@@ -18,6 +20,8 @@ struct CurveP {           // PaintCurve for one voice: shared tag, per-voice dur
     float duration;
 };
 
+enum { ENV_MODE_NONE = 0, ENV_MODE_TOWARD = 1, ENV_MODE_FLAT = 2 };
+
 struct EnvLane {
     // Envelope state (Envelope.zig:23-24; painter.zig:33-36)
     uint32_t state;
@@ -25,8 +29,10 @@ struct EnvLane {
     // per-paint parameters
     float sample_rate, sustain_volume;
     CurveP attack, decay, release;
-    float step_attack, step_decay, step_release;   // 1 / (duration * sample_rate), painter.zig:97
     bool note_on;
+    // the running stage
+    uint32_t mode, cur_tag;
+    float cur_step, cur_goal;
 
     __device__ __forceinline__ void change_state(uint32_t s) {   // Envelope.zig:33-36 + painter.zig:47-50
         state = s;
@@ -34,71 +40,75 @@ struct EnvLane {
         t = 0.0f;
     }
 
-    // Prologue of paintOn / paintOff (Envelope.zig:38-50, 77-84)
-    __device__ __forceinline__ void begin(bool new_note) {
-        step_attack = 1.0f / (attack.duration * sample_rate);
-        step_decay = 1.0f / (decay.duration * sample_rate);
-        step_release = 1.0f / (release.duration * sample_rate);
-        if (note_on) {
-            if (new_note) change_state(ZH_ENV_ATTACK);
-            // assert(state != release) at :45 is a check only; a voice in `release` that gets
-            // note_on without a new note id matches none of the stage tests: paints nothing.
-            if (state == ZH_ENV_IDLE) change_state(ZH_ENV_ATTACK);
-        } else {
-            if (state != ZH_ENV_IDLE && state != ZH_ENV_RELEASE) change_state(ZH_ENV_RELEASE);
-        }
+    // paintToward's entry (painter.zig:69-97) for the stage `on` selects; returns "finished without
+    // painting".  Written with selects only: conditional stores to different fields of the lane get
+    // sunk by LLVM into one store at a variable offset, which forces the lane out of VGPRs.
+    __device__ __forceinline__ bool enter(bool on, uint32_t tag, float duration, float goal) {
+        const bool done = t >= 1.0f;                              // :69-71
+        const bool inst = on && !done && tag == ZH_CURVE_INSTANTANEOUS;   // :76-80
+        t = inst ? 1.0f : t;
+        last_value = inst ? goal : last_value;
+        const bool fin = done || inst;
+        const bool run = on && !fin;
+        mode = run ? (uint32_t)ENV_MODE_TOWARD : mode;
+        cur_tag = run ? tag : cur_tag;
+        cur_goal = run ? goal : cur_goal;
+        cur_step = run ? 1.0f / (duration * sample_rate) : cur_step;   // :97
+        return on && fin;
     }
 
-    // One paintToward iteration (painter.zig:63-120).  Returns finished; sets painted/val.
-    __device__ __forceinline__ bool toward(const CurveP &c, float t_step, float goal, bool have_frame,
-                                           bool &painted, float &val) {
-        painted = false;
-        if (t >= 1.0f) return true;                               // :69-71
-        if (c.tag == ZH_CURVE_INSTANTANEOUS) {                    // :76-80
-            t = 1.0f;
-            last_value = goal;
+    __device__ __forceinline__ void change_state_if(bool c, uint32_t s) {
+        state = c ? s : state;
+        start = c ? last_value : start;
+        t = c ? 0.0f : t;
+    }
+
+    // Envelope.zig:52-70 / 85-89 from the current state, up to the next stage that takes time
+    __device__ __forceinline__ void resolve() {
+        mode = ENV_MODE_NONE;
+        const uint32_t after_attack = sustain_volume < 1.0f ? (uint32_t)ZH_ENV_DECAY : (uint32_t)ZH_ENV_SUSTAIN;
+        change_state_if(enter(note_on && state == ZH_ENV_ATTACK, attack.tag, attack.duration, 1.0f), after_attack);
+        change_state_if(enter(note_on && state == ZH_ENV_DECAY, decay.tag, decay.duration, sustain_volume), ZH_ENV_SUSTAIN);
+        mode = (note_on && state == ZH_ENV_SUSTAIN) ? (uint32_t)ENV_MODE_FLAT : mode;
+        // note_on && state == release is the assert case of Envelope.zig:45 (note_on without a new note
+        // id while releasing): with the assert compiled out nothing matches -> NONE.
+        change_state_if(enter(!note_on && state == ZH_ENV_RELEASE, release.tag, release.duration, 0.0f), ZH_ENV_IDLE);
+    }
+
+    // Prologue of paintOn / paintOff (Envelope.zig:38-50, 77-84), then the first stage's entry
+    __device__ __forceinline__ void begin(bool new_note) {
+        change_state_if(note_on && new_note, ZH_ENV_ATTACK);
+        change_state_if(note_on && state == ZH_ENV_IDLE, ZH_ENV_ATTACK);
+        change_state_if(!note_on && state != ZH_ENV_IDLE && state != ZH_ENV_RELEASE, ZH_ENV_RELEASE);
+        resolve();
+    }
+
+    // One frame.  Returns whether a value was painted.
+    __device__ __forceinline__ bool frame(float &val) {
+        if (mode == ENV_MODE_TOWARD) {                            // painter.zig:102-116
+            t += cur_step;
+            const bool finished = t >= 1.0f;
+            if (finished) t = 1.0f;
+            const float it = 1.0f - t;
+            float tp = t;
+            if (cur_tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
+            else if (cur_tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
+            last_value = start + tp * (cur_goal - start);         // :114
+            val = last_value;
+            if (finished) {                                       // Envelope.zig:53-58, 63-65, 86-88
+                const uint32_t after_attack = sustain_volume < 1.0f ? (uint32_t)ZH_ENV_DECAY : (uint32_t)ZH_ENV_SUSTAIN;
+                const uint32_t next = state == ZH_ENV_ATTACK ? after_attack
+                                      : (state == ZH_ENV_DECAY ? (uint32_t)ZH_ENV_SUSTAIN : (uint32_t)ZH_ENV_IDLE);
+                change_state(next);
+                resolve();
+            }
             return true;
         }
-        if (!have_frame) return false;                            // `i < buf.len` fails: not finished
-        bool finished = false;
-        t += t_step;                                              // :103
-        if (t >= 1.0f) { t = 1.0f; finished = true; }
-        const float it = 1.0f - t;
-        float tp;
-        if (c.tag == ZH_CURVE_LINEAR) tp = t;
-        else if (c.tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
-        else tp = 1.0f - it * it * it;
-        last_value = start + tp * (goal - start);                 // :114
-        val = last_value;
-        painted = true;
-        return finished;
-    }
-
-    // Advance by one frame (have_frame) or run the end-of-span cascade (!have_frame).
-    // Returns whether a value was painted for this frame.
-    __device__ __forceinline__ bool frame(bool have_frame, float &val) {
-        bool painted = false;
-        if (note_on) {
-            if (state == ZH_ENV_ATTACK) {                         // Envelope.zig:52-60
-                if (toward(attack, step_attack, 1.0f, have_frame, painted, val))
-                    change_state(sustain_volume < 1.0f ? ZH_ENV_DECAY : ZH_ENV_SUSTAIN);
-                if (painted) return true;
-            }
-            if (state == ZH_ENV_DECAY) {                          // :62-66
-                if (toward(decay, step_decay, sustain_volume, have_frame, painted, val))
-                    change_state(ZH_ENV_SUSTAIN);
-                if (painted) return true;
-            }
-            if (state == ZH_ENV_SUSTAIN && have_frame) {          // :68-70 paintFlat
-                val = sustain_volume;
-                return true;
-            }
-            return false;
+        if (mode == ENV_MODE_FLAT) {                              // Envelope.zig:68-70
+            val = sustain_volume;
+            return true;
         }
-        if (state == ZH_ENV_RELEASE) {                            // :85-89
-            if (toward(release, step_release, 0.0f, have_frame, painted, val)) change_state(ZH_ENV_IDLE);
-        }
-        return painted;
+        return false;
     }
 };
 

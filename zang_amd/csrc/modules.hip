@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
     const float inv_sr = 1.0f / sample_rate;                          // :66
     const float phase_c = PB ? 0.0f : phase.c.get(v);
     frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end,
-                           [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) {
+                           [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
         const float ph = PB ? x[FB ? 1 : 0] : phase_c;
         val = sine_osc_sin(t + ph);
         if (FB) t += x[0] * inv_sr; else t += t_step;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, 
         for (int j = 0; j < 7; j++) b[j] = bst[(size_t)j * V + v];    // `var b = self.b` (Noise.zig:55)
     }
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         const float white = zrandom_float32(r) * 2.0f - 1.0f;         // :51 / :58
         if (!PINK) { val = white; return true; }
         b[0] = 0.99886f * b[0] + white * 0.0555179f;                  // :59-64
@@ -118,9 +118,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_envelope(uint32_t *__restrict__ s
     e.begin(nic.get(v));
     const float *const *no_in = nullptr;
     frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end,
-                         [&](uint32_t, const float (&)[1], float &val) { return e.frame(true, val); });
-    float dummy;
-    e.frame(false, dummy);                                            // end-of-span cascade
+                         [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA { return e.frame(val); });
     st[v] = e.state; t[v] = e.t; lastv[v] = e.last_value; startv[v] = e.start;
 }
 
@@ -161,7 +159,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
     float cut = CB ? 0.0f : zclampf(cutoff.c.get(v), 0.0f, 1.0f);     // :114
     float res = RB ? 0.0f : 1.0f - zclampf(res_p.c.get(v), 0.0f, 1.0f);   // :118
     float l = l_io[v], b = b_io[v];
-    frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) {
+    frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) ZH_INLINE_LAMBDA {
         if (CB) cut = zclampf(x[1], 0.0f, 1.0f);                      // :126
         if (RB) res = 1.0f - zclampf(x[CB ? 2 : 1], 0.0f, 1.0f);      // :128
         const float in = x[0] + fcdcoffset;                           // :135
@@ -245,13 +243,13 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io,
     }
     if (ratio > 0.9999f && ratio < 1.0001f) {                         // :105-114 no resampling
         const int32_t t0 = zf32_to_i32(roundf(t));
-        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) {
+        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             val = sampler_get_sample(s, (int32_t)((uint32_t)t0 + (i - start)));
             return true;
         });
         t += (float)len;
     } else {                                                          // :116-130 linear resampling
-        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) {
+        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             const int32_t t0 = zf32_to_i32(floorf(t));
             const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
             const float tfrac = (float)t1 - t;                        // :121
@@ -282,7 +280,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dva
     const float ratio = fake / sample_rate;                           // :40
     const float *ins[1] = {input.p + v};
     const size_t istr[1] = {input.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
         if (mode == 0) { val = x[0]; return true; }                   // :35 addInto
         if (mode == 2) return false;                                  // fake <= 0 (or NaN): paints nothing
         dcount += ratio;                                              // :46

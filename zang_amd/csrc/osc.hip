@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restric
     pulse_setup_color(k, color_p.get(v));
     const float *ins[1] = {freq_b.p + v};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
         const float s_freq = x[0];
         if (s_freq < 0 || s_freq > sr8) return false;                 // PulseOsc.zig:134-135
         pulse_setup_freq(k, srf, s_freq);
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict_
     const float gain = 0.7f;
     const float *ins[1] = {freq_b.p + v};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) {
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
         float frac;
         if (saw) {
             frac = (t - floorf(t)) * 2.0f - 1.0f;
