@@ -137,26 +137,44 @@ class Workload:
 
 def cpu_baseline(args, wl):
     """The oracle (C restatement of the reference loops; the Zig reference cannot be built
-    in this image) timed on this host, one thread -- the reference's execution model."""
+    in this image) timed on this host, one thread -- the reference's execution model --
+    on a bounded sample: the first min(V, 4096) voices for about --cpu-seconds."""
+    import ctypes as C
     import numpy as np
     from oracle import pyoracle as po
     L = po.lib()
-    V, F = wl.V, wl.F
-    if wl.name != "pulseosc":
-        return None
-    scratch = np.zeros(F, np.float32)
-    states = (po.PulseOsc * V)()
-    # calibrate on 8 buffers, then size the sample for ~cpu_seconds
+    V, F = min(wl.V, 4096), wl.F
+    if wl.name == "pulseosc":
+        scratch = np.zeros(F, np.float32)
+        states = (po.PulseOsc * V)()
+        run = lambda n: L.zo_bench_pulseosc(V, F, n, SR, po.fptr(wl.freq_h), po.fptr(wl.color_h), states, po.fptr(scratch))
+        what = "zero + PulseOsc.paint per voice"
+    elif wl.name == "noise_filter":
+        scratch = np.zeros(2 * F, np.float32)
+        noise = (po.Noise * V)(); flt = (po.Filter * V)()
+        for v in range(V):
+            L.zo_noise_init(C.byref(noise[v]), v); L.zo_filter_init(C.byref(flt[v]))
+        cutoff = np.array([L.zo_filter_cutoff_from_frequency(float(200.0 + 7800.0 * u), SR) for u in wl.u2_h[:V]], np.float32)
+        res = (0.9 * wl.u3_h[:V]).astype(np.float32)
+        run = lambda n: L.zo_bench_noise_filter(V, F, n, po.fptr(cutoff), po.fptr(res), noise, flt, po.fptr(scratch))
+        what = "zero + Noise.paint + zero + Filter.paint per voice"
+    else:
+        scratch = np.zeros(3 * F, np.float32)
+        inst = (po.NiceInstrument * V)()
+        for v in range(V):
+            L.zo_nice_init(C.byref(inst[v]), float(wl.color_h[v]))
+        freq = np.ascontiguousarray(wl.freq_h[:V])
+        run = lambda n: L.zo_bench_nice(V, F, n, SR, po.fptr(freq), inst, po.fptr(scratch))
+        what = "NiceInstrument.paint (unfused module sequence through temps) per voice"
     t0 = time.perf_counter()
-    L.zo_bench_pulseosc(V, F, 8, SR, po.fptr(wl.freq_h), po.fptr(wl.color_h), states, po.fptr(scratch))
-    per = (time.perf_counter() - t0) / 8
-    nbuf = max(8, int(args.cpu_seconds / per))
+    run(4)                      # calibrate, then size the sample for ~cpu_seconds
+    per = (time.perf_counter() - t0) / 4
+    nbuf = max(4, int(args.cpu_seconds / per))
     t0 = time.perf_counter()
-    L.zo_bench_pulseosc(V, F, nbuf, SR, po.fptr(wl.freq_h), po.fptr(wl.color_h), states, po.fptr(scratch))
+    run(nbuf)
     dt = time.perf_counter() - t0
     return {"value": V * F * nbuf / dt, "unit": "voice-samples/s", "cores": 1, "kind": "port",
-            "sample": f"{nbuf} consecutive buffers of the same {V} voices x {F} frames (zero + PulseOsc.paint per voice), "
-                      f"{dt:.1f} s on 1 thread"}
+            "sample": f"{nbuf} consecutive buffers of {V} voices x {F} frames ({what}), {dt:.1f} s on 1 thread"}
 
 
 def main():

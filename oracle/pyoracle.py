@@ -162,6 +162,8 @@ def lib():
         "zo_math_sinf_n": (None, [_F, _F, z]), "zo_math_cosf_n": (None, [_F, _F, z]),
         "zo_math_atanf_n": (None, [_F, _F, z]), "zo_math_pow2f_n": (None, [_F, _F, z]),
         "zo_bench_pulseosc": (C.c_double, [u32, u32, u32, f, _F, _F, C.POINTER(PulseOsc), _F]),
+        "zo_bench_noise_filter": (C.c_double, [u32, u32, u32, _F, _F, C.POINTER(Noise), C.POINTER(Filter), _F]),
+        "zo_bench_nice": (C.c_double, [u32, u32, u32, f, _F, C.POINTER(NiceInstrument), _F]),
         "zo_xoshiro_seq": (None, [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), z]),
     }
     for name, (res, args) in sig.items():

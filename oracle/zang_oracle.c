@@ -671,3 +671,37 @@ double zo_bench_pulseosc(uint32_t voices, uint32_t frames, uint32_t buffers, flo
     }
     return fold;
 }
+
+/* config 3: Noise(white) -> temp -> Filter(low_pass), per voice per buffer (examples/example_stereo.zig:71-82) */
+double zo_bench_noise_filter(uint32_t voices, uint32_t frames, uint32_t buffers, const float *cutoff, const float *res,
+                             zo_noise *noise, zo_filter *flt, float *scratch /* 2*frames */) {
+    double fold = 0.0;
+    float *temp = scratch, *out = scratch + frames;
+    for (uint32_t b = 0; b < buffers; b++) {
+        for (uint32_t v = 0; v < voices; v++) {
+            zo_cob c = { ZO_COB_CONSTANT, cutoff[v], NULL }, r = { ZO_COB_CONSTANT, res[v], NULL };
+            zo_zero(0, frames, temp);
+            zo_noise_paint(&noise[v], 0, frames, temp, ZO_NOISE_WHITE);
+            zo_zero(0, frames, out);
+            zo_filter_paint(&flt[v], 0, frames, out, temp, ZO_FILTER_LOW_PASS, c, r);
+            fold += out[(b + v) % frames];
+        }
+    }
+    return fold;
+}
+
+/* config 5 voice: NiceInstrument, note on for buffers 0-23 of every 48, then off */
+double zo_bench_nice(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate, const float *freq,
+                     zo_nice_instrument *inst, float *scratch /* 3*frames */) {
+    double fold = 0.0;
+    float *t0 = scratch, *t1 = scratch + frames, *out = scratch + 2 * frames;
+    for (uint32_t b = 0; b < buffers; b++) {
+        const uint32_t k = b % 48;
+        for (uint32_t v = 0; v < voices; v++) {
+            zo_zero(0, frames, out);
+            zo_nice_paint(&inst[v], 0, frames, out, t0, t1, k == 0, sample_rate, freq[v], k < 24);
+            fold += out[(b + v) % frames];
+        }
+    }
+    return fold;
+}

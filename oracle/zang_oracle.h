@@ -87,4 +87,8 @@ void zo_mixdown_s16lsb(uint8_t *dst, const float *mix, size_t n, size_t num_chan
 void zo_mixdown_s8(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
 double zo_bench_pulseosc(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate,
                          const float *freq, const float *color, zo_pulseosc *states, float *scratch);
+double zo_bench_noise_filter(uint32_t voices, uint32_t frames, uint32_t buffers, const float *cutoff, const float *res,
+                             zo_noise *noise, zo_filter *flt, float *scratch);
+double zo_bench_nice(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate, const float *freq,
+                     zo_nice_instrument *inst, float *scratch);
 #endif

@@ -159,3 +159,14 @@ def test_song_render_matches_oracle_render(ctx, oracle):
     a = np.frombuffer(got, "<i2").astype(np.int32); b = np.frombuffer(ref, "<i2").astype(np.int32)
     assert np.abs(a).max() > 1000                   # it actually makes sound
     assert np.array_equal(a, b), f"{(a != b).sum()} of {a.size} s16 samples differ (max {np.abs(a - b).max()} LSB)"
+
+
+@pytest.mark.gpu
+def test_song_batched_render_equals_per_buffer(ctx, oracle):
+    """Many buffers per launch (SongRenderer.render_batch) must not change a bit."""
+    from zang_amd import song
+    nbuf = 45
+    ref = _oracle_song_render(oracle, song.resolve_frequencies(song.compile_song(_small()), ctx), song.EXAMPLE_SONG_INSTRUMENTS, nbuf)
+    r = song.SongRenderer(_small(), ctx)
+    got = r.render(nbuf * F / SR, batch=7)          # 6 batches of 7 + one of 3
+    assert got == ref

@@ -1,0 +1,25 @@
+#!/bin/bash
+# GPU box: rocprofv3 kernel-trace summaries for every bench workload -> gpurun_out/profiles_rNN/
+# usage: tools/collect_profiles.sh r01
+tag=${1:-r01}
+out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, bench args...
+  name=$1; shift
+  d=$GRAFT_REPO_ROOT/gpurun_out/prof_tmp_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu > $out/${name}_bench.json 2>/dev/null
+  cp $d/*/*kernel_stats.csv $out/${name}_kernel_stats.csv
+  rm -rf $d
+}
+run pulseosc4096
+run pulseosc65536 --voices 65536 --steps 100 --warmup 10
+run pulseosc1M --voices 1048576 --steps 40 --warmup 4
+run noise_filter4096 --workload noise_filter
+run noise_filter131072 --workload noise_filter --voices 131072 --steps 50 --warmup 10
+run nice4096 --workload nice --steps 96 --warmup 48
+run nice131072 --workload nice --voices 131072 --steps 96 --warmup 48
+run nice_mix131072 --workload nice_mix --voices 131072 --steps 96 --warmup 48
+run nice_mix1M --workload nice_mix --voices 1048576 --steps 48 --warmup 48
+for f in $out/*_bench.json; do tail -1 $f > $f.tmp; mv $f.tmp $f; done
+ls $out

@@ -300,14 +300,46 @@ class SongRenderer:
         zang.mixDown(self.pcm[:nframes * 2], self.mix[:nframes], zang.AudioFormat.signed16_lsb, 1, 0, self.vol, ctx=self.ctx)
         return bytes(self.pcm[:nframes * 2].cpu().numpy())
 
-    def render(self, seconds):
+    def render_batch(self, frame_counts):
+        """Several consecutive write_wav iterations in ONE set of launches.  The host schedules every
+        buffer exactly as before (NoteTracker quantises note times per 1024-frame buffer), then the
+        sub-spans of buffer b are shifted by its start frame: Trigger's carry-over already splits a
+        note at every buffer boundary, so the per-call prologue/epilogue structure -- and the bits --
+        are unchanged, while the device walks len(frame_counts)*1024 frames per launch."""
+        import torch
+        nb = len(frame_counts)
+        total = sum(frame_counts)
+        per_inst = [[[] for _ in range(i.polyphony)] for i in self.instruments]
+        base = 0
+        for n in frame_counts:
+            tables = self.sched.buffer(zang.Span(0, n))
+            for k, per_voice in enumerate(tables):
+                for v, spans in enumerate(per_voice):
+                    per_inst[k][v].extend((s + base, e + base, f, on, nic) for (s, e, f, on, nic) in spans)
+            base += n
+        if getattr(self, "_batch_frames", 0) < total:
+            self._bimage = self.ctx.image(total, self.total_voices)
+            self._bmix = torch.zeros(total, dtype=torch.float32, device=self.ctx.device)
+            self._bpcm = torch.zeros(total * 2, dtype=torch.uint8, device=self.ctx.device)
+            self._batch_frames = total
+        span = zang.Span(0, total)
+        col = 0
+        for m, inst, per_voice in zip(self.mods, self.instruments, per_inst):
+            view = self._bimage[:, col:col + inst.polyphony]
+            col += inst.polyphony
+            m.paint_spans(span, [view], None, float(AUDIO_SAMPLE_RATE), SpanTable(per_voice, self.ctx.device), zero_first=True)
+        zang.mixdownVoices(span, self._bmix, self._bimage, zero_first=True, sequential=True, ctx=self.ctx)
+        zang.mixDown(self._bpcm[:total * 2], self._bmix[:total], zang.AudioFormat.signed16_lsb, 1, 0, self.vol, ctx=self.ctx)
+        return bytes(self._bpcm[:total * 2].cpu().numpy())
+
+    def render(self, seconds, batch=64):
         total = int(seconds * AUDIO_SAMPLE_RATE)
-        chunks, start = [], 0
-        while start < total:
+        counts, start = [], 0
+        while start < total:                                   # write_wav.zig:58-59
             n = min(AUDIO_BUFFER_SIZE, total - start)
-            chunks.append(self.render_buffer(n))
+            counts.append(n)
             start += n
-        return b"".join(chunks)
+        return b"".join(self.render_batch(counts[i:i + batch]) for i in range(0, len(counts), batch))
 
 
 def wav_header(num_channels, sample_rate, bytes_per_sample, data_bytes):
