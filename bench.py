@@ -49,8 +49,9 @@ def parse():
 class Workload:
     """Builds the module(s), resident params and the per-step callable for one rank."""
 
-    def __init__(self, name, ctx, V, F, first_voice, ring_bytes):
+    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1):
         import torch
+        self.world = world
         from zang_amd import modules as mod, zang, workloads
         self.name, self.V, self.F = name, V, F
         self.ctx = ctx
@@ -99,6 +100,8 @@ class Workload:
 
     def graph_steps(self):
         """Steps per captured graph: a whole number of ring rotations, even (see bench main)."""
+        if self.name == "nice_mix" and self.world > 1:
+            return 0                        # the per-buffer all-reduce is issued by torch.distributed: eager
         if self.name in ("nice", "nice_mix"):
             return 48                       # the note on/off pattern repeats every 48 buffers
         g = max(self.nring, 2)
@@ -133,6 +136,11 @@ class Workload:
     def _step_nice_mix(self):
         on, new = self._note_on()
         self.m.paint_mix(self.span, self.mix, new, self.m.Params(SR, self.freq, on), zero_first=True)
+        if self.world > 1:
+            # config 5: the one exchange step of the path -- each GPU's [frames] partial mix (4 KiB)
+            # is summed over RCCL/xGMI; latency-bound, not link-bound
+            from zang_amd import sharding
+            sharding.allreduce_mix(self.mix)
 
 
 def cpu_baseline(args, wl):
@@ -199,7 +207,7 @@ def main():
     torch.cuda.set_stream(side)
     ctx = zang_amd.Context(local_rank if world > 1 else 0)
     V, F = args.voices, args.frames
-    wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20)
+    wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20, world=world)
     lib = ctx.lib
 
     def barrier():

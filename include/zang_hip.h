@@ -281,6 +281,32 @@ ZH_API int zh_distortion_paint(zh_distortion *m, uint32_t span_start, uint32_t s
                                const zh_buf *temps, zh_bool note_id_changed,
                                const zh_distortion_params *params, uint32_t flags);                   /* :27-66 */
 
+/* ---------------------------------------------------------------- Cycle (src/modules/Cycle.zig) */
+typedef struct zh_cycle zh_cycle;
+typedef struct zh_cycle_params { float sample_rate; uint32_t reserved; zh_cob speed; } zh_cycle_params;          /* :9-12 */
+typedef struct zh_cycle_state { float t; } zh_cycle_state;                                            /* :14 */
+ZH_API int zh_cycle_create(zh_ctx *ctx, uint32_t n_voices, zh_cycle **out);
+ZH_API int zh_cycle_destroy(zh_cycle *m);
+ZH_API int zh_cycle_get_state(zh_cycle *m, zh_cycle_state *host);
+ZH_API int zh_cycle_set_state(zh_cycle *m, const zh_cycle_state *host);
+ZH_API int zh_cycle_paint(zh_cycle *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                          const zh_buf *temps, zh_bool note_id_changed,
+                          const zh_cycle_params *params, uint32_t flags);                             /* :22-59 */
+
+/* ---------------------------------------------------------------- Portamento (src/modules/Portamento.zig) */
+typedef struct zh_portamento zh_portamento;
+typedef struct zh_portamento_params {                                                                 /* :5-11 */
+    float sample_rate; uint32_t reserved; zh_curve curve; zh_f32 goal; zh_bool note_on; zh_bool prev_note_on;
+} zh_portamento_params;
+typedef struct zh_portamento_state { float t, last_value, start; } zh_portamento_state;               /* :13, painter.zig:33-36 */
+ZH_API int zh_portamento_create(zh_ctx *ctx, uint32_t n_voices, zh_portamento **out);
+ZH_API int zh_portamento_destroy(zh_portamento *m);
+ZH_API int zh_portamento_get_state(zh_portamento *m, zh_portamento_state *host);
+ZH_API int zh_portamento_set_state(zh_portamento *m, const zh_portamento_state *host);
+ZH_API int zh_portamento_paint(zh_portamento *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                               const zh_buf *temps, zh_bool note_id_changed,
+                               const zh_portamento_params *params, uint32_t flags);                   /* :21-48 */
+
 /* ---------------------------------------------------------------- NiceInstrument (examples/modules.zig:189-248)
  * PulseOsc -> x0.5 -> Filter(low_pass, cutoffFromFrequency(8*freq), res 0.7) -> Envelope(cubed
  * .01/.1/.5, sustain .8) -> out += env*flt, as ONE kernel: the two temps never touch HBM. */

@@ -78,6 +78,14 @@ class Decimator(C.Structure):
     _fields_ = [("dval", C.c_float), ("dcount", C.c_float)]
 
 
+class Cycle(C.Structure):
+    _fields_ = [("t", C.c_float)]
+
+
+class Portamento(C.Structure):
+    _fields_ = [("painter", Painter)]
+
+
 class NiceInstrument(C.Structure):
     _fields_ = [("color", C.c_float), ("osc", PulseOsc), ("flt", Filter), ("env", Envelope)]
 
@@ -161,6 +169,10 @@ def lib():
         "zo_math_powf": (f, [f, f]), "zo_math_expf": (f, [f]), "zo_math_logf": (f, [f]),
         "zo_math_sinf_n": (None, [_F, _F, z]), "zo_math_cosf_n": (None, [_F, _F, z]),
         "zo_math_atanf_n": (None, [_F, _F, z]), "zo_math_pow2f_n": (None, [_F, _F, z]),
+        "zo_cycle_init": (None, [C.POINTER(Cycle)]),
+        "zo_cycle_paint": (None, [C.POINTER(Cycle), z, z, _F, f, Cob]),
+        "zo_portamento_init": (None, [C.POINTER(Portamento)]),
+        "zo_portamento_paint": (None, [C.POINTER(Portamento), z, z, _F, i32, f, Curve, f, i32, i32]),
         "zo_bench_pulseosc": (C.c_double, [u32, u32, u32, f, _F, _F, C.POINTER(PulseOsc), _F]),
         "zo_bench_noise_filter": (C.c_double, [u32, u32, u32, _F, _F, C.POINTER(Noise), C.POINTER(Filter), _F]),
         "zo_bench_nice": (C.c_double, [u32, u32, u32, f, _F, C.POINTER(NiceInstrument), _F]),

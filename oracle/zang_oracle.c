@@ -705,3 +705,33 @@ double zo_bench_nice(uint32_t voices, uint32_t frames, uint32_t buffers, float s
     }
     return fold;
 }
+
+/* ------------------------------------------------------------------ Cycle.zig */
+void zo_cycle_init(zo_cycle *c) { c->t = 0.0f; }                    /* Cycle.zig:16-20 */
+
+/* Cycle.zig:22-59 */
+void zo_cycle_paint(zo_cycle *self, size_t start, size_t end, float *out, float sample_rate, zo_cob speed) {
+    float t = self->t;
+    if (speed.tag == ZO_COB_CONSTANT) {
+        const float step = speed.constant / sample_rate;            /* :37 */
+        for (size_t i = start; i < end; i++) { out[i] += t; t += step; t -= truncf(t); }
+    } else {
+        const float isr = 1.0f / sample_rate;                       /* :48 */
+        for (size_t i = start; i < end; i++) { out[i] += t; t += speed.buffer[i] * isr; t -= truncf(t); }
+    }
+    self->t = t;
+}
+
+/* ------------------------------------------------------------------ Portamento.zig */
+void zo_portamento_init(zo_portamento *p) { p->painter.t = 0.0f; p->painter.last_value = 0.0f; p->painter.start = 0.0f; }
+
+/* Portamento.zig:21-48 */
+void zo_portamento_paint(zo_portamento *self, size_t start, size_t end, float *out0, int note_id_changed,
+                         float sample_rate, zo_curve curve_p, float goal, int note_on, int prev_note_on) {
+    float *output = out0 + start;
+    zo_curve curve = (note_on && prev_note_on) ? curve_p : (zo_curve){ ZO_CURVE_INSTANTANEOUS, 0.0f };   /* :33-36 */
+    if (note_on && note_id_changed) painter_new_curve(&self->painter);                                  /* :38-40 */
+    zo_paint_state ps = { output, end - start, 0, sample_rate };
+    if (painter_paint_toward(&self->painter, &ps, curve, goal))                                         /* :43 */
+        painter_paint_flat(&self->painter, &ps, goal);                                                  /* :46 */
+}

@@ -43,6 +43,8 @@ typedef struct {                                            /* Sampler.zig:16-21
 } zo_sampler_params;
 typedef struct { float dval, dcount; } zo_decimator;       /* Decimator.zig:11-12 */
 enum { ZO_DISTORTION_OVERDRIVE = 0, ZO_DISTORTION_CLIP = 1 }; /* Distortion.zig:8-11 */
+typedef struct { float t; } zo_cycle;                      /* Cycle.zig:14 */
+typedef struct { zo_painter painter; } zo_portamento;      /* Portamento.zig:13 */
 typedef struct { float color; zo_pulseosc osc; zo_filter flt; zo_envelope env; } zo_nice_instrument;
 typedef struct { float release_duration; zo_sineosc carrier, modulator; zo_envelope env; } zo_pmosc_instrument;
 
@@ -85,6 +87,11 @@ void zo_pmosc_paint(zo_pmosc_instrument *self, size_t start, size_t end, float *
                     float *temp2, int note_id_changed, float sample_rate, float freq, int note_on);
 void zo_mixdown_s16lsb(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
 void zo_mixdown_s8(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
+void zo_cycle_init(zo_cycle *c);
+void zo_cycle_paint(zo_cycle *self, size_t start, size_t end, float *out, float sample_rate, zo_cob speed);
+void zo_portamento_init(zo_portamento *p);
+void zo_portamento_paint(zo_portamento *self, size_t start, size_t end, float *out0, int note_id_changed,
+                         float sample_rate, zo_curve curve, float goal, int note_on, int prev_note_on);
 double zo_bench_pulseosc(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate,
                          const float *freq, const float *color, zo_pulseosc *states, float *scratch);
 double zo_bench_noise_filter(uint32_t voices, uint32_t frames, uint32_t buffers, const float *cutoff, const float *res,

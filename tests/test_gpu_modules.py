@@ -343,3 +343,59 @@ def test_distortion(ctx, oracle, dtype_):
     got = util.from_image(out)
     util.assert_close(got, ref, "distortion")
     util.assert_bitexact(got, ref, "distortion (same algorithm, expected exact)")
+
+
+# ------------------------------------------------------------------ Cycle / Portamento
+@pytest.mark.parametrize("kind", ["c", "b"])
+def test_cycle(ctx, oracle, kind):
+    from zang_amd import modules as mod, zang
+    V = 128
+    rng = np.random.default_rng(91)
+    speed = rng.uniform(-50, 4000, V).astype(np.float32)
+    sbuf = rng.uniform(-50, 4000, (V, F)).astype(np.float32)
+    out0 = util.rng_buffers(92, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rt = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.Cycle(); L.zo_cycle_init(C.byref(st))
+        for (s, e) in util.SPANS_THREE:
+            L.zo_cycle_paint(C.byref(st), s, e, oracle.fptr(ref[v]), SR, _cob(oracle, kind, speed[v], sbuf[v]))
+        rt[v] = st.t
+    m = mod.Cycle(V, ctx)
+    out = util.to_image(out0); gb = util.to_image(sbuf); gs = util.dev(speed)
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(SR, _gcob(zang, kind, gs, gb)))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "cycle")
+    util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "cycle t")
+
+
+@pytest.mark.parametrize("curve", [0, 1, 2, 3])
+def test_portamento(ctx, oracle, curve):
+    from zang_amd import modules as mod, zang
+    V = 128
+    rng = np.random.default_rng(93)
+    dur = rng.uniform(0.001, 0.03, V).astype(np.float32)
+    script = []
+    for (s, e) in [(0, 300), (300, 1024), (0, 1024), (0, 0), (0, 512)]:
+        script.append(((s, e), rng.uniform(100, 2000, V).astype(np.float32), rng.random(V) < 0.7, rng.random(V) < 0.7, rng.random(V) < 0.4))
+    out0 = util.rng_buffers(94, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rst = np.zeros((V, 3), np.float32)
+    for v in range(V):
+        st = oracle.Portamento(); L.zo_portamento_init(C.byref(st))
+        for ((s, e), goal, on, prev, nic) in script:
+            L.zo_portamento_paint(C.byref(st), s, e, oracle.fptr(ref[v]), int(nic[v]), SR, oracle.curve(curve, dur[v]), float(goal[v]), int(on[v]), int(prev[v]))
+        rst[v] = (st.painter.t, st.painter.last_value, st.painter.start)
+    m = mod.Portamento(V, ctx)
+    out = util.to_image(out0)
+    mk = [None, zang.PaintCurve.linear, zang.PaintCurve.squared, zang.PaintCurve.cubed]
+    gcurve = zang.PaintCurve.instantaneous if curve == 0 else mk[curve](util.dev(dur))
+    u8 = lambda a: util.dev(a.astype(np.uint8))
+    for ((s, e), goal, on, prev, nic) in script:
+        m.paint(zang.Span(s, e), [out], [], u8(nic), m.Params(SR, gcurve, util.dev(goal), u8(on), u8(prev)))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"portamento curve {curve}")
+    st = m.state()
+    for k, name in enumerate(("t", "last_value", "start")):
+        util.assert_bitexact(st[name].astype(np.float32), rst[:, k].copy(), f"portamento {name}")

@@ -120,6 +120,22 @@ class DistortionParams(C.Structure):
     _fields_ = [("input", Buf), ("type", u32), ("reserved", u32), ("ingain", F32), ("outgain", F32), ("offset", F32)]
 
 
+class CycleParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("speed", Cob)]
+
+
+class CycleState(C.Structure):
+    _fields_ = [("t", f32)]
+
+
+class PortamentoParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("reserved", u32), ("curve", Curve), ("goal", F32), ("note_on", Bool), ("prev_note_on", Bool)]
+
+
+class PortamentoState(C.Structure):
+    _fields_ = [("t", f32), ("last_value", f32), ("start", f32)]
+
+
 class NiceParams(C.Structure):
     _fields_ = [("sample_rate", f32), ("reserved", u32), ("freq", F32), ("note_on", Bool)]
 
@@ -241,6 +257,16 @@ SIGNATURES = {
     "zh_distortion_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_distortion_destroy": (C.c_int, [vp]),
     "zh_distortion_paint": (C.c_int, _paint(DistortionParams)),
+    "zh_cycle_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_cycle_destroy": (C.c_int, [vp]),
+    "zh_cycle_get_state": (C.c_int, [vp, vp]),
+    "zh_cycle_set_state": (C.c_int, [vp, vp]),
+    "zh_cycle_paint": (C.c_int, _paint(CycleParams)),
+    "zh_portamento_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_portamento_destroy": (C.c_int, [vp]),
+    "zh_portamento_get_state": (C.c_int, [vp, vp]),
+    "zh_portamento_set_state": (C.c_int, [vp, vp]),
+    "zh_portamento_paint": (C.c_int, _paint(PortamentoParams)),
     "zh_nice_create": (C.c_int, [vp, u32, F32, P(vp)]),
     "zh_nice_destroy": (C.c_int, [vp]),
     "zh_nice_get_state": (C.c_int, [vp, vp]),

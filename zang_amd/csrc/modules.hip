@@ -320,6 +320,66 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
     }
 }
 
+// =================================================================== Cycle
+struct zh_cycle { zh_ctx *ctx; uint32_t n; float *t; };
+
+template <bool ZF, bool SB>
+__global__ void __launch_bounds__(kSeqBlock) k_cycle(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
+                                                     uint32_t end, float sample_rate, CobP speed) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    float t = t_io[v];
+    const float step = SB ? 0.0f : speed.c.get(v) / sample_rate;      // Cycle.zig:37
+    const float isr = 1.0f / sample_rate;                              // :48
+    const float *ins[1] = {SB ? speed.b.p + v : nullptr};
+    const size_t istr[1] = {speed.b.stride};
+    frame_loop<8, ZF, SB ? 1 : 0>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
+        val = t;                                                       // :41
+        if (SB) t += x[0] * isr; else t += step;                       // :42 / :53
+        t -= truncf(t);                                                // :43
+        return true;
+    });
+    t_io[v] = t;
+}
+
+// =================================================================== Portamento
+struct zh_portamento { zh_ctx *ctx; uint32_t n; float *t, *last_value, *start; };
+
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_portamento(float *__restrict__ t_io, float *__restrict__ last_io,
+                                                          float *__restrict__ start_io, uint32_t V, Img out, uint32_t start,
+                                                          uint32_t end, float sample_rate, uint32_t curve_tag, F32P duration,
+                                                          F32P goal_p, BoolP note_on, BoolP prev_note_on, BoolP nic) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    float t = t_io[v], last = last_io[v], st = start_io[v];
+    const float goal = goal_p.get(v);
+    const bool on = note_on.get(v);
+    const uint32_t tag = (on && prev_note_on.get(v)) ? curve_tag : (uint32_t)ZH_CURVE_INSTANTANEOUS;   // Portamento.zig:33-36
+    if (on && nic.get(v)) { st = last; t = 0.0f; }                                                   // :38-40 newCurve
+    // paintToward's entry (painter.zig:69-80), then either the glide or paintFlat(goal) (:43-47)
+    bool flat = false;
+    if (t >= 1.0f) flat = true;
+    else if (tag == ZH_CURVE_INSTANTANEOUS) { t = 1.0f; last = goal; flat = true; }
+    const float t_step = 1.0f / (duration.get(v) * sample_rate);                                     // painter.zig:97
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        if (flat) { val = goal; return true; }
+        t += t_step;                                                   // painter.zig:103-116
+        const bool fin = t >= 1.0f;
+        t = fin ? 1.0f : t;
+        const float it = 1.0f - t;
+        float tp = t;
+        if (tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
+        else if (tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
+        last = st + tp * (goal - st);
+        val = last;
+        flat = fin;
+        return true;
+    });
+    t_io[v] = t; last_io[v] = last; start_io[v] = st;
+}
+
 // =================================================================== host side
 template <class M> static int paint_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs) {
     if (!m || !outputs || end < start) return ZH_ERR_INVALID;
@@ -742,6 +802,108 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     hipStream_t st = m->ctx->stream;
     ZH_ZF_LAUNCH(k_decimator, seq_grid(m->n), dim3(kSeqBlock), m->dval, m->dcount, m->n, mk_img(outputs[0]),
                  mk_cimg(p->input), start, end, p->sample_rate, mk_f32(p->fake_sample_rate));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Cycle
+int zh_cycle_create(zh_ctx *ctx, uint32_t n, zh_cycle **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_cycle *m = new (std::nothrow) zh_cycle{ctx, n, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->t, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);           // init() :16-20
+    if (rc) { (void)hipFree(m->t); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_cycle_destroy(zh_cycle *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->t);
+    delete m;
+    return ZH_OK;
+}
+int zh_cycle_get_state(zh_cycle *m, zh_cycle_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
+}
+int zh_cycle_set_state(zh_cycle *m, const zh_cycle_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
+}
+int zh_cycle_paint(zh_cycle *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                   zh_bool note_id_changed, const zh_cycle_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // Cycle.zig:30-31
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || !cob_ok(p->speed, m->n, end)) return ZH_ERR_INVALID;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    Img out = mk_img(outputs[0]);
+    CobP sp = mk_cob(p->speed);
+#define ZH_CYCLE(ZF_, SB_) hipLaunchKernelGGL((k_cycle<ZF_, SB_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, sp)
+    if (p->speed.tag == ZH_COB_BUFFER) { if (zf) ZH_CYCLE(true, true); else ZH_CYCLE(false, true); }
+    else { if (zf) ZH_CYCLE(true, false); else ZH_CYCLE(false, false); }
+#undef ZH_CYCLE
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Portamento
+int zh_portamento_create(zh_ctx *ctx, uint32_t n, zh_portamento **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_portamento *m = new (std::nothrow) zh_portamento{ctx, n, nullptr, nullptr, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->t, n);
+    if (!rc) rc = dev_alloc(&m->last_value, n);
+    if (!rc) rc = dev_alloc(&m->start, n);
+    if (!rc && n) {                                                                // Painter.init(), painter.zig:38-44
+        rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->last_value, 0, n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->start, 0, n * 4, ctx->stream);
+    }
+    if (rc) { (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_portamento_destroy(zh_portamento *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start);
+    delete m;
+    return ZH_OK;
+}
+int zh_portamento_get_state(zh_portamento *m, zh_portamento_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> a, b, c;
+    int rc = download_field(m->ctx, a, m->t, m->n);
+    if (!rc) rc = download_field(m->ctx, b, m->last_value, m->n);
+    if (!rc) rc = download_field(m->ctx, c, m->start, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_portamento_state{a[v], b[v], c[v]};
+    return ZH_OK;
+}
+int zh_portamento_set_state(zh_portamento *m, const zh_portamento_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> a(m->n), b(m->n), c(m->n);
+    for (uint32_t v = 0; v < m->n; v++) { a[v] = host[v].t; b[v] = host[v].last_value; c[v] = host[v].start; }
+    int rc = upload_field(m->ctx, m->t, a);
+    if (!rc) rc = upload_field(m->ctx, m->last_value, b);
+    if (!rc) rc = upload_field(m->ctx, m->start, c);
+    return rc;
+}
+int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                        zh_bool note_id_changed, const zh_portamento_params *p, uint32_t flags) {
+    (void)temps;
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || !curve_ok(p->curve)) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;            // an empty span still applies newCurve / the instantaneous jump
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    ZH_ZF_LAUNCH(k_portamento, seq_grid(m->n), dim3(kSeqBlock), m->t, m->last_value, m->start, m->n, mk_img(outputs[0]),
+                 start, end, p->sample_rate, p->curve.tag, mk_f32(p->curve.duration), mk_f32(p->goal), mk_bool(p->note_on),
+                 mk_bool(p->prev_note_on), mk_bool(note_id_changed));
     return zh_launch_status();
 }
 

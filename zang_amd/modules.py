@@ -274,6 +274,39 @@ class Distortion(_Module):
         raise AttributeError("Distortion has no state")
 
 
+class Cycle(_Module):
+    """src/modules/Cycle.zig"""
+    _prefix = "cycle"
+    _state_ctype = abi.CycleState
+
+    @dataclass
+    class Params:
+        sample_rate: float
+        speed: Any
+
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+        self._paint(span, outputs, temps, note_id_changed, abi.CycleParams(params.sample_rate, 0, params.speed), zero_first)
+
+
+class Portamento(_Module):
+    """src/modules/Portamento.zig"""
+    _prefix = "portamento"
+    _state_ctype = abi.PortamentoState
+
+    @dataclass
+    class Params:
+        sample_rate: float
+        curve: Any
+        goal: Any
+        note_on: Any
+        prev_note_on: Any
+
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+        cp = abi.PortamentoParams(params.sample_rate, 0, params.curve, as_f32(params.goal), as_bool(params.note_on),
+                                  as_bool(params.prev_note_on))
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+
+
 class NiceInstrument(_Module):
     """examples/modules.zig:189-248 as one fused kernel (temps are accepted and ignored)."""
     _prefix = "nice"
