@@ -281,6 +281,27 @@ ZH_API int zh_distortion_paint(zh_distortion *m, uint32_t span_start, uint32_t s
                                const zh_buf *temps, zh_bool note_id_changed,
                                const zh_distortion_params *params, uint32_t flags);                   /* :27-66 */
 
+/* ---------------------------------------------------------------- Curve (src/modules/Curve.zig)
+ * (entry points are named zh_curve_module_* because zh_curve is zang.PaintCurve) */
+typedef struct zh_curve_module zh_curve_module;
+enum { ZH_CURVE_FN_LINEAR = 0, ZH_CURVE_FN_SMOOTHSTEP = 1 };                                          /* :4-7 */
+typedef struct zh_curve_node { float value, t; } zh_curve_node;                                       /* zang.CurveNode, src/zang/curve.zig:3-6 */
+typedef struct zh_curve_module_params {                                                               /* :29-33 */
+    float sample_rate; uint32_t function;
+    const zh_curve_node *curve;   /* DEVICE array shared by all voices (must not be mutated while painting, :37-38) */
+    uint64_t curve_len;
+} zh_curve_module_params;
+typedef struct zh_curve_module_state {                                                                /* :36-41 */
+    float t; uint32_t current_song_note; int32_t current_song_note_offset; uint32_t next_song_note;
+} zh_curve_module_state;
+ZH_API int zh_curve_module_create(zh_ctx *ctx, uint32_t n_voices, zh_curve_module **out);
+ZH_API int zh_curve_module_destroy(zh_curve_module *m);
+ZH_API int zh_curve_module_get_state(zh_curve_module *m, zh_curve_module_state *host);
+ZH_API int zh_curve_module_set_state(zh_curve_module *m, const zh_curve_module_state *host);
+ZH_API int zh_curve_module_paint(zh_curve_module *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                                 const zh_buf *temps, zh_bool note_id_changed,
+                                 const zh_curve_module_params *params, uint32_t flags);               /* :56-128 */
+
 /* ---------------------------------------------------------------- Cycle (src/modules/Cycle.zig) */
 typedef struct zh_cycle zh_cycle;
 typedef struct zh_cycle_params { float sample_rate; uint32_t reserved; zh_cob speed; } zh_cycle_params;          /* :9-12 */

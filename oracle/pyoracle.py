@@ -78,6 +78,15 @@ class Decimator(C.Structure):
     _fields_ = [("dval", C.c_float), ("dcount", C.c_float)]
 
 
+class CurveNode(C.Structure):
+    _fields_ = [("value", C.c_float), ("t", C.c_float)]
+
+
+class CurveModule(C.Structure):
+    _fields_ = [("t", C.c_float), ("current_song_note", C.c_size_t), ("current_song_note_offset", C.c_int32),
+                ("next_song_note", C.c_size_t)]
+
+
 class Cycle(C.Structure):
     _fields_ = [("t", C.c_float)]
 
@@ -169,6 +178,8 @@ def lib():
         "zo_math_powf": (f, [f, f]), "zo_math_expf": (f, [f]), "zo_math_logf": (f, [f]),
         "zo_math_sinf_n": (None, [_F, _F, z]), "zo_math_cosf_n": (None, [_F, _F, z]),
         "zo_math_atanf_n": (None, [_F, _F, z]), "zo_math_pow2f_n": (None, [_F, _F, z]),
+        "zo_curve_init": (None, [C.POINTER(CurveModule)]),
+        "zo_curve_paint": (None, [C.POINTER(CurveModule), z, z, _F, i32, f, u32, C.POINTER(CurveNode), z]),
         "zo_cycle_init": (None, [C.POINTER(Cycle)]),
         "zo_cycle_paint": (None, [C.POINTER(Cycle), z, z, _F, f, Cob]),
         "zo_portamento_init": (None, [C.POINTER(Portamento)]),

@@ -735,3 +735,102 @@ void zo_portamento_paint(zo_portamento *self, size_t start, size_t end, float *o
     if (painter_paint_toward(&self->painter, &ps, curve, goal))                                         /* :43 */
         painter_paint_flat(&self->painter, &ps, goal);                                                  /* :46 */
 }
+
+/* ------------------------------------------------------------------ Curve.zig */
+void zo_curve_init(zo_curve_module *c) {                             /* Curve.zig:46-54 */
+    c->t = 0.0f; c->current_song_note = 0; c->current_song_note_offset = 0; c->next_song_note = 0;
+}
+
+typedef struct { int32_t frame; float value; } curve_span_node;      /* Curve.zig:11-14 */
+
+/* Curve.zig:130-184.  A 33rd node in one paint overflows the reference's [32] array (UB); DEFINED: dropped. */
+static size_t curve_get_span_nodes(zo_curve_module *self, float sample_rate, size_t out_len, const zo_curve_node *curve,
+                                   size_t n_curve, curve_span_node *nodes) {
+    size_t count = 0;
+    const float buf_time = (float)out_len / sample_rate;
+    const float end_t = self->t + buf_time;
+    if (self->current_song_note < self->next_song_note) {            /* :142-148 carry-over */
+        nodes[count].frame = self->current_song_note_offset;
+        nodes[count].value = curve[self->current_song_note].value;
+        count++;
+    }
+    int one_past = 0;
+    for (size_t k = self->next_song_note; k < n_curve; k++) {
+        const float note_t = curve[k].t;
+        if (note_t >= end_t) {                                       /* :153-160 keep one note past the end */
+            if (!one_past) one_past = 1; else break;
+        }
+        const float f = (note_t - self->t) / buf_time;
+        const int32_t rel_frame_index = zr_f32_to_i32(f * (float)out_len);
+        if (count > 0 && nodes[count - 1].frame == rel_frame_index) count--;   /* :165-167 */
+        if (count < 32) {
+            nodes[count].frame = rel_frame_index;
+            nodes[count].value = curve[k].value;
+            count++;
+        }
+        if (!one_past) {                                             /* :173-177 */
+            self->current_song_note = self->next_song_note;
+            self->current_song_note_offset = 0;
+            self->next_song_note += 1;
+        }
+    }
+    self->t += buf_time;                                             /* :180 */
+    self->current_song_note_offset -= (int32_t)out_len;              /* :181 */
+    return count;
+}
+
+typedef struct { size_t start, end; int has_values; curve_span_node a, b; } curve_span;
+
+/* Curve.zig:188-255 */
+static curve_span curve_next_span(const curve_span_node *nodes, size_t n, size_t dest_start_, size_t dest_end_) {
+    const int32_t dest_start = (int32_t)dest_start_, dest_end = (int32_t)dest_end_;
+    for (size_t i = 0; i < n; i++) {
+        const int32_t start_pos = nodes[i].frame;
+        if (start_pos >= dest_end) break;
+        const int32_t end_pos = (i + 1 < n) ? (nodes[i + 1].frame < dest_end ? nodes[i + 1].frame : dest_end) : dest_end;
+        if (end_pos <= dest_start) continue;
+        const int32_t note_start_clipped = start_pos > dest_start ? start_pos : dest_start;
+        if (note_start_clipped > dest_start)
+            return (curve_span){ (size_t)dest_start, (size_t)note_start_clipped, 0, {0, 0}, {0, 0} };
+        const int32_t note_end_clipped = end_pos > dest_end ? dest_end : end_pos;
+        curve_span s = { (size_t)note_start_clipped, (size_t)note_end_clipped, i + 1 < n, nodes[i], {0, 0} };
+        if (i + 1 < n) s.b = nodes[i + 1];
+        return s;
+    }
+    return (curve_span){ (size_t)dest_start, (size_t)dest_end, 0, {0, 0}, {0, 0} };
+}
+
+/* Curve.zig:56-128 */
+void zo_curve_paint(zo_curve_module *self, size_t span_start, size_t span_end, float *out0, int note_id_changed,
+                    float sample_rate, uint32_t function, const zo_curve_node *curve, size_t n_curve) {
+    if (note_id_changed) zo_curve_init(self);                        /* :66-71 */
+    float *out = out0 + span_start;
+    const size_t out_len = span_end - span_start;
+    curve_span_node nodes[32];
+    const size_t n = curve_get_span_nodes(self, sample_rate, out_len, curve, n_curve, nodes);
+    size_t start = 0;
+    while (start < out_len) {
+        const curve_span cs = curve_next_span(nodes, n, start, out_len);
+        if (cs.has_values) {
+            const int32_t paint_start = (int32_t)cs.start;
+            const int32_t fstart = cs.a.frame, fend = cs.b.frame;
+            const float start_x = (float)(paint_start - fstart) / (float)(fend - fstart);   /* :95 */
+            const float start_value = cs.a.value;
+            const float value_delta = cs.b.value - cs.a.value;
+            const float x_step = 1.0f / (float)(fend - fstart);      /* :100 */
+            if (function == ZO_CURVE_FN_LINEAR) {
+                float y = start_value + start_x * value_delta;
+                const float y_step = x_step * value_delta;
+                for (size_t i = cs.start; i < cs.end; i++) { out[i] += y; y += y_step; }
+            } else {
+                float x = start_x;
+                for (size_t i = cs.start; i < cs.end; i++) {
+                    const float v = x * x * (3.0f - 2.0f * x) * value_delta;   /* :118 */
+                    out[i] += start_value + v;
+                    x += x_step;
+                }
+            }
+        }
+        start = cs.end;
+    }
+}

@@ -43,6 +43,9 @@ typedef struct {                                            /* Sampler.zig:16-21
 } zo_sampler_params;
 typedef struct { float dval, dcount; } zo_decimator;       /* Decimator.zig:11-12 */
 enum { ZO_DISTORTION_OVERDRIVE = 0, ZO_DISTORTION_CLIP = 1 }; /* Distortion.zig:8-11 */
+enum { ZO_CURVE_FN_LINEAR = 0, ZO_CURVE_FN_SMOOTHSTEP = 1 };  /* Curve.zig:4-7 */
+typedef struct { float value, t; } zo_curve_node;          /* zang.CurveNode, src/zang/curve.zig:3-6 */
+typedef struct { float t; size_t current_song_note; int32_t current_song_note_offset; size_t next_song_note; } zo_curve_module; /* Curve.zig:36-41 */
 typedef struct { float t; } zo_cycle;                      /* Cycle.zig:14 */
 typedef struct { zo_painter painter; } zo_portamento;      /* Portamento.zig:13 */
 typedef struct { float color; zo_pulseosc osc; zo_filter flt; zo_envelope env; } zo_nice_instrument;
@@ -87,6 +90,9 @@ void zo_pmosc_paint(zo_pmosc_instrument *self, size_t start, size_t end, float *
                     float *temp2, int note_id_changed, float sample_rate, float freq, int note_on);
 void zo_mixdown_s16lsb(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
 void zo_mixdown_s8(uint8_t *dst, const float *mix, size_t n, size_t num_channels, size_t channel_index, float vol);
+void zo_curve_init(zo_curve_module *c);
+void zo_curve_paint(zo_curve_module *self, size_t span_start, size_t span_end, float *out0, int note_id_changed,
+                    float sample_rate, uint32_t function, const zo_curve_node *curve, size_t n_curve);
 void zo_cycle_init(zo_cycle *c);
 void zo_cycle_paint(zo_cycle *self, size_t start, size_t end, float *out, float sample_rate, zo_cob speed);
 void zo_portamento_init(zo_portamento *p);

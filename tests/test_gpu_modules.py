@@ -399,3 +399,42 @@ def test_portamento(ctx, oracle, curve):
     st = m.state()
     for k, name in enumerate(("t", "last_value", "start")):
         util.assert_bitexact(st[name].astype(np.float32), rst[:, k].copy(), f"portamento {name}")
+
+
+@pytest.mark.parametrize("function", [0, 1])
+def test_curve(ctx, oracle, function):
+    """Curve.zig: shared node list, per-voice progress; voices are desynchronised by per-voice
+    note_id_changed (restart) at different buffers; sub-span paints; runs past the last node."""
+    from zang_amd import modules as mod, zang
+    V = 96
+    rng = np.random.default_rng(97)
+    ts = np.cumsum(rng.uniform(0.0004, 0.02, 24)).astype(np.float32); ts[0] = 0.0
+    vals = rng.uniform(-1, 1, 24).astype(np.float32)
+    ts[5] = ts[4]                                    # two nodes on the same frame (:163-167)
+    nodes = np.stack([vals, ts], axis=1).astype(np.float32)
+    carr = (oracle.CurveNode * len(nodes))(*[oracle.CurveNode(float(v), float(t)) for v, t in nodes])
+    script = []
+    for b in range(6):
+        for (s, e) in (util.SPANS_THREE if b % 2 else util.SPANS_ONE):
+            script.append(((s, e), rng.random(V) < (1.0 if (b == 0 and s == 0) else 0.08)))
+    script.append(((10, 10), rng.random(V) < 0.5))   # empty span still resets on note_id_changed
+    script.append(((0, 1024), np.zeros(V, bool)))
+    out0 = util.rng_buffers(98, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rst = []
+    for v in range(V):
+        st = oracle.CurveModule(); L.zo_curve_init(C.byref(st))
+        for ((s, e), nic) in script:
+            L.zo_curve_paint(C.byref(st), s, e, oracle.fptr(ref[v]), int(nic[v]), SR, function, carr, len(nodes))
+        rst.append((st.t, st.current_song_note, st.current_song_note_offset, st.next_song_note))
+    m = mod.Curve(V, ctx)
+    out = util.to_image(out0); gnodes = util.dev(nodes)
+    for ((s, e), nic) in script:
+        m.paint(zang.Span(s, e), [out], [], util.dev(nic.astype(np.uint8)), m.Params(SR, function, gnodes))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"curve fn {function}")
+    gs = m.state()
+    util.assert_bitexact(gs["t"].astype(np.float32), np.array([r[0] for r in rst], np.float32), "curve t")
+    assert [int(x) for x in gs["current_song_note"]] == [r[1] for r in rst]
+    assert [int(x) for x in gs["current_song_note_offset"]] == [r[2] for r in rst]
+    assert [int(x) for x in gs["next_song_note"]] == [r[3] for r in rst]

@@ -249,3 +249,23 @@ def test_sampler_linear_interp(oracle):
     p = oracle.SamplerParams(float(out_rate), 1, 44100, oracle.SAMPLE_S16, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, 0, 0)
     L.zo_sampler_paint(C.byref(st), 0, n, oracle.fptr(out), 0, C.byref(p))
     util.assert_bitexact(out, ref, "sampler interp"); assert f32(st.t) == t
+
+
+def test_curve_linear_matches_closed_form(oracle):
+    """Curve.zig linear interpolation between nodes, one whole-buffer paint: out[i] follows
+    start + (i - f0)/(f1 - f0) * delta (f64 closed form, 1e-5), exact node values at node frames."""
+    L = oracle.lib()
+    nodes = [(0.0, 0.0), (0.5, 0.004), (-0.25, 0.0125), (1.0, 0.02)]
+    arr = (oracle.CurveNode * 4)(*[oracle.CurveNode(v, t) for v, t in nodes])
+    st = oracle.CurveModule(); L.zo_curve_init(C.byref(st))
+    n = 1024; out = np.zeros(n, np.float32)
+    L.zo_curve_paint(C.byref(st), 0, n, oracle.fptr(out), 1, SR, 0, arr, 4)
+    frames = [int(np.float32((np.float32(t) - np.float32(0)) / (np.float32(n) / SR)) * np.float32(n)) for _, t in nodes]
+    assert frames == [0, 192, 600, 960]
+    for (f0, f1), ((v0, _), (v1, _)) in zip(zip(frames, frames[1:]), zip(nodes, nodes[1:])):
+        i = np.arange(f0, f1)
+        want = v0 + (i - f0) / (f1 - f0) * (v1 - v0)
+        assert np.abs(out[f0:f1] - want).max() < 1e-5
+        assert out[f0] == np.float32(v0)
+    assert not out[960:].any()                      # after the last node: silent gap (:238-244)
+    assert (st.current_song_note, st.next_song_note, st.current_song_note_offset) == (3, 4, -1024)      # :175,:181: offset is reset to 0 on advance, then -= out_len

@@ -120,6 +120,18 @@ class DistortionParams(C.Structure):
     _fields_ = [("input", Buf), ("type", u32), ("reserved", u32), ("ingain", F32), ("outgain", F32), ("offset", F32)]
 
 
+class CurveNode(C.Structure):
+    _fields_ = [("value", f32), ("t", f32)]
+
+
+class CurveModuleParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("function", u32), ("curve", vp), ("curve_len", u64)]
+
+
+class CurveModuleState(C.Structure):
+    _fields_ = [("t", f32), ("current_song_note", u32), ("current_song_note_offset", C.c_int32), ("next_song_note", u32)]
+
+
 class CycleParams(C.Structure):
     _fields_ = [("sample_rate", f32), ("reserved", u32), ("speed", Cob)]
 
@@ -257,6 +269,11 @@ SIGNATURES = {
     "zh_distortion_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_distortion_destroy": (C.c_int, [vp]),
     "zh_distortion_paint": (C.c_int, _paint(DistortionParams)),
+    "zh_curve_module_create": (C.c_int, [vp, u32, P(vp)]),
+    "zh_curve_module_destroy": (C.c_int, [vp]),
+    "zh_curve_module_get_state": (C.c_int, [vp, vp]),
+    "zh_curve_module_set_state": (C.c_int, [vp, vp]),
+    "zh_curve_module_paint": (C.c_int, _paint(CurveModuleParams)),
     "zh_cycle_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_cycle_destroy": (C.c_int, [vp]),
     "zh_cycle_get_state": (C.c_int, [vp, vp]),

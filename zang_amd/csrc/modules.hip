@@ -320,6 +320,87 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
     }
 }
 
+// =================================================================== Curve
+struct zh_curve_module { zh_ctx *ctx; uint32_t n; float *t; uint32_t *cur; int32_t *off; uint32_t *next; };
+
+struct CurveSpanNode { int32_t frame; float value; };                  // Curve.zig:11-14
+
+// One lane = one voice's Curve instance.  Per paint the lane first builds its (<= 32) span nodes
+// (getCurveSpanNodes, Curve.zig:130-184), then walks the span frame by frame; whenever the running
+// curve span ends it looks up the next one (getNextCurveSpan, :188-255) -- the reference's
+// `while (start < out.len)` loop, re-expressed per frame so that all lanes stay on the same frame.
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_curve(float *__restrict__ t_io, uint32_t *__restrict__ cur_io,
+                                                     int32_t *__restrict__ off_io, uint32_t *__restrict__ next_io, uint32_t V,
+                                                     Img out, uint32_t start, uint32_t end, float sample_rate, uint32_t function,
+                                                     const zh_curve_node *__restrict__ curve, uint32_t n_curve, BoolP nic) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    float t = t_io[v];
+    uint32_t cur = cur_io[v], next = next_io[v];
+    int32_t off = off_io[v];
+    if (nic.get(v)) { cur = 0; off = 0; next = 0; t = 0.0f; }         // :66-71
+    const uint32_t out_len = end - start;
+    CurveSpanNode nodes[32];
+    uint32_t count = 0;
+    {                                                                  // getCurveSpanNodes
+        const float buf_time = (float)out_len / sample_rate;
+        const float end_t = t + buf_time;
+        if (cur < next) { nodes[count].frame = off; nodes[count].value = curve[cur].value; count++; }   // :142-148
+        bool one_past = false;
+        for (uint32_t k = next; k < n_curve; k++) {
+            const float note_t = curve[k].t;
+            if (note_t >= end_t) { if (!one_past) one_past = true; else break; }                         // :153-160
+            const float f = (note_t - t) / buf_time;
+            const int32_t rel = zf32_to_i32(f * (float)out_len);
+            if (count > 0 && nodes[count - 1].frame == rel) count--;                                    // :165-167
+            if (count < 32) { nodes[count].frame = rel; nodes[count].value = curve[k].value; count++; }
+            if (!one_past) { cur = next; off = 0; next += 1; }                                          // :173-177
+        }
+        t += buf_time;                                                 // :180
+        off -= (int32_t)out_len;                                       // :181
+    }
+    // running curve span
+    uint32_t span_end = 0;              // relative frame where the running span ends
+    bool has_values = false;
+    float acc = 0.0f, step = 0.0f, start_value = 0.0f, value_delta = 0.0f;
+    auto next_span = [&](uint32_t dest_start_) ZH_INLINE_LAMBDA {    // getNextCurveSpan + the per-span setup of :84-107
+        const int32_t dest_start = (int32_t)dest_start_, dest_end = (int32_t)out_len;
+        has_values = false;
+        span_end = out_len;
+        for (uint32_t i = 0; i < count; i++) {
+            const int32_t start_pos = nodes[i].frame;
+            if (start_pos >= dest_end) break;
+            const int32_t end_pos = (i + 1 < count) ? min(dest_end, nodes[i + 1].frame) : dest_end;
+            if (end_pos <= dest_start) continue;
+            const int32_t note_start_clipped = start_pos > dest_start ? start_pos : dest_start;
+            if (note_start_clipped > dest_start) { span_end = (uint32_t)note_start_clipped; return; }   // gap
+            span_end = (uint32_t)(end_pos > dest_end ? dest_end : end_pos);
+            if (i + 1 < count) {
+                has_values = true;
+                const int32_t fstart = nodes[i].frame, fend = nodes[i + 1].frame;
+                const float start_x = (float)(dest_start - fstart) / (float)(fend - fstart);           // :95
+                start_value = nodes[i].value;
+                value_delta = nodes[i + 1].value - nodes[i].value;
+                const float x_step = 1.0f / (float)(fend - fstart);                                     // :100
+                if (function == ZH_CURVE_FN_LINEAR) { acc = start_value + start_x * value_delta; step = x_step * value_delta; }
+                else { acc = start_x; step = x_step; }
+            }
+            return;
+        }
+    };
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        const uint32_t r = i - start;
+        if (r == span_end) next_span(r);
+        if (!has_values) return false;
+        if (function == ZH_CURVE_FN_LINEAR) { val = acc; acc += step; }                                 // :109-112
+        else { val = start_value + acc * acc * (3.0f - 2.0f * acc) * value_delta; acc += step; }       // :117-121
+        return true;
+    });
+    t_io[v] = t; cur_io[v] = cur; off_io[v] = off; next_io[v] = next;
+}
+
 // =================================================================== Cycle
 struct zh_cycle { zh_ctx *ctx; uint32_t n; float *t; };
 
@@ -802,6 +883,65 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     hipStream_t st = m->ctx->stream;
     ZH_ZF_LAUNCH(k_decimator, seq_grid(m->n), dim3(kSeqBlock), m->dval, m->dcount, m->n, mk_img(outputs[0]),
                  mk_cimg(p->input), start, end, p->sample_rate, mk_f32(p->fake_sample_rate));
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Curve
+int zh_curve_module_create(zh_ctx *ctx, uint32_t n, zh_curve_module **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_curve_module *m = new (std::nothrow) zh_curve_module{ctx, n, nullptr, nullptr, nullptr, nullptr};
+    if (!m) return ZH_ERR_INVALID;
+    int rc = dev_alloc(&m->t, n);
+    if (!rc) rc = dev_alloc(&m->cur, n);
+    if (!rc) rc = dev_alloc(&m->off, n);
+    if (!rc) rc = dev_alloc(&m->next, n);
+    if (!rc && n) {                                                                // init() :46-54
+        void *z[] = {m->t, m->cur, m->off, m->next};
+        for (void *p : z) if (!rc) rc = (int)hipMemsetAsync(p, 0, (size_t)n * 4, ctx->stream);
+    }
+    if (rc) { (void)hipFree(m->t); (void)hipFree(m->cur); (void)hipFree(m->off); (void)hipFree(m->next); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_curve_module_destroy(zh_curve_module *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->t); (void)hipFree(m->cur); (void)hipFree(m->off); (void)hipFree(m->next);
+    delete m;
+    return ZH_OK;
+}
+int zh_curve_module_get_state(zh_curve_module *m, zh_curve_module_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> t; std::vector<uint32_t> c, nx; std::vector<int32_t> o;
+    int rc = download_field(m->ctx, t, m->t, m->n);
+    if (!rc) rc = download_field(m->ctx, c, m->cur, m->n);
+    if (!rc) rc = download_field(m->ctx, o, m->off, m->n);
+    if (!rc) rc = download_field(m->ctx, nx, m->next, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_curve_module_state{t[v], c[v], o[v], nx[v]};
+    return ZH_OK;
+}
+int zh_curve_module_set_state(zh_curve_module *m, const zh_curve_module_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<float> t(m->n); std::vector<uint32_t> c(m->n), nx(m->n); std::vector<int32_t> o(m->n);
+    for (uint32_t v = 0; v < m->n; v++) { t[v] = host[v].t; c[v] = host[v].current_song_note; o[v] = host[v].current_song_note_offset; nx[v] = host[v].next_song_note; }
+    int rc = upload_field(m->ctx, m->t, t);
+    if (!rc) rc = upload_field(m->ctx, m->cur, c);
+    if (!rc) rc = upload_field(m->ctx, m->off, o);
+    if (!rc) rc = upload_field(m->ctx, m->next, nx);
+    return rc;
+}
+int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                          zh_bool note_id_changed, const zh_curve_module_params *p, uint32_t flags) {
+    (void)temps;
+    int rc = paint_check(m, start, end, outputs);
+    if (rc) return rc;
+    if (!p || p->function > ZH_CURVE_FN_SMOOTHSTEP || (p->curve_len && !p->curve) || p->curve_len > 0xFFFFFFFFull) return ZH_ERR_INVALID;
+    if (m->n == 0) return ZH_OK;            // an empty span still resets on note_id_changed (:66-71)
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    hipStream_t st = m->ctx->stream;
+    ZH_ZF_LAUNCH(k_curve, seq_grid(m->n), dim3(kSeqBlock), m->t, m->cur, m->off, m->next, m->n, mk_img(outputs[0]), start, end,
+                 p->sample_rate, p->function, p->curve, (uint32_t)p->curve_len, mk_bool(note_id_changed));
     return zh_launch_status();
 }
 

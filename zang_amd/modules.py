@@ -274,6 +274,26 @@ class Distortion(_Module):
         raise AttributeError("Distortion has no state")
 
 
+class Curve(_Module):
+    """src/modules/Curve.zig.  `curve` is a float32 CUDA tensor [n_nodes, 2] of (value, t) rows
+    (zang.CurveNode), shared by all voices."""
+    _prefix = "curve_module"
+    _state_ctype = abi.CurveModuleState
+    linear, smoothstep = 0, 1
+
+    @dataclass
+    class Params:
+        sample_rate: float
+        function: int
+        curve: Any
+
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+        c = params.curve
+        assert c.is_cuda and c.dim() == 2 and c.shape[1] == 2 and c.is_contiguous()
+        cp = abi.CurveModuleParams(params.sample_rate, params.function, c.data_ptr(), c.shape[0])
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+
+
 class Cycle(_Module):
     """src/modules/Cycle.zig"""
     _prefix = "cycle"
