@@ -1,0 +1,78 @@
+"""GPU: hipGraph capture/replay of paint sequences (what bench.py times) gives the same bits and the
+same carried state as eager launches; and the bench workload's last image equals the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+F = 1024
+
+
+def test_graph_replay_equals_eager(ctx):
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V, G = 1024, 4
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)                      # binds to the side stream (capture needs a non-default stream)
+        fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
+        me, mg = mod.PulseOsc(V, c2), mod.PulseOsc(V, c2)
+        flt_e, flt_g = mod.Filter(V, c2), mod.Filter(V, c2)
+        ring_e = [c2.image(F, V) for _ in range(G)]; ring_g = [c2.image(F, V) for _ in range(G)]
+        tmp_e, tmp_g = c2.image(F, V), c2.image(F, V)
+        sp = zang.Span(0, F)
+
+        def steps(m, flt, ring, tmp):
+            for o in ring:                            # PulseOsc -> temp -> Filter(low_pass) -> ring image
+                m.paint(sp, [tmp], [], False, m.Params(SR, zang.constant(fr), col), zero_first=True)
+                flt.paint(sp, [o], [], False, flt.Params(tmp, flt.low_pass, zang.constant(0.3), zang.constant(0.5)), zero_first=True)
+
+        for _ in range(3):
+            steps(me, flt_e, ring_e, tmp_e)           # 12 eager buffers
+        steps(mg, flt_g, ring_g, tmp_g)               # 4 eager (also warms up), then capture 4 and replay twice
+        c2.sync()
+        g = c2.capture(lambda: steps(mg, flt_g, ring_g, tmp_g))
+        g.launch(); g.launch()
+        c2.sync()
+        for a, b in zip(ring_e, ring_g):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert np.array_equal(me.state(), mg.state()) and np.array_equal(flt_e.state(), flt_g.state())
+        g.close()
+        c2.close()
+
+
+def test_bench_workload_last_image_matches_oracle(ctx, oracle):
+    """The exact step bench.py times (zero+paint of 4096 PulseOsc voices, graph replay over a ring):
+    after K steps the most recent image equals the oracle's K-th buffer."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V, K, R = 4096, 12, 4
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        m = mod.PulseOsc(V, c2)
+        fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
+        ring = [c2.image(F, V) for _ in range(R)]
+        sp = zang.Span(0, F)
+        step = lambda: [m.paint(sp, [o], [], False, m.Params(SR, zang.constant(fr), col), zero_first=True) for o in ring]
+        step(); c2.sync()
+        g = c2.capture(step)
+        g.launch(); g.launch(); c2.sync()
+        got = util.from_image(ring[-1])
+        g.close(); c2.close()
+    L = oracle.lib()
+    ref = np.zeros((V, F), np.float32)
+    for v in range(0, V, 16):                          # every 16th voice keeps the CPU side short
+        st = oracle.PulseOsc(); L.zo_pulseosc_init(C.byref(st))
+        for _ in range(K):
+            ref[v] = 0
+            L.zo_pulseosc_paint(C.byref(st), 0, F, oracle.fptr(ref[v]), SR, oracle.constant(freq[v]), float(color[v]))
+    util.assert_bitexact(got[::16], ref[::16], "bench step after 12 buffers")

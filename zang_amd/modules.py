@@ -44,6 +44,7 @@ class _Module:
         create = getattr(self.lib, f"zh_{self._prefix}_create")
         abi.check(create(self.ctx.handle, self.n_voices, *create_args, C.byref(h)), f"zh_{self._prefix}_create")
         self.handle = h
+        self.ctx._children.add(self)
 
     @classmethod
     def init(cls, n_voices, ctx=None):

@@ -4,6 +4,7 @@ PyTorch is used only for device memory and streams: sample images are float32 CU
 tensors of shape [frames, voices] (voice contiguous), passed to the C ABI by data_ptr().
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -24,6 +25,7 @@ class Context:
         h = C.c_void_p()
         abi.check(self.lib.zh_create(C.byref(h), device), "zh_create")
         self.handle = h
+        self._children = weakref.WeakSet()     # modules / graphs created on this context
         if adopt_torch_stream:
             self.use_stream(torch.cuda.current_stream(self.device))
 
@@ -35,7 +37,11 @@ class Context:
         abi.check(self.lib.zh_sync(self.handle), "zh_sync")
 
     def close(self):
+        """Destroy the context; modules and graphs created on it are closed first (their C objects
+        hold a pointer to the context)."""
         if self.handle:
+            for child in list(self._children):
+                child.close()
             self.lib.zh_destroy(self.handle)
             self.handle = None
 
@@ -60,6 +66,7 @@ class Context:
 class Graph:
     def __init__(self, ctx, handle):
         self.ctx, self.handle = ctx, handle
+        ctx._children.add(self)
 
     def launch(self):
         abi.check(self.ctx.lib.zh_graph_launch(self.ctx.handle, self.handle), "zh_graph_launch")
