@@ -70,7 +70,7 @@ class Workload:
             self.m = mod.PulseOsc(V, ctx)
             self.ring = [ctx.image(F, V) for _ in range(nring)]
             self.params = self.m.Params(SR, zang.constant(self.freq), self.color)
-            self.kernel = "k_pulseosc_const4"
+            self.kernel = "k_osc_const4<PulseOscP>"
             self.step = self._step_pulse
         elif name == "noise_filter":
             self.noise = mod.Noise(V, ctx, first_seed=first_voice)

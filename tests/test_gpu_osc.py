@@ -111,3 +111,16 @@ def test_pulseosc_config2_full(ctx, oracle):
             L.zo_pulseosc_paint(C.byref(st), 0, F, oracle.fptr(ref[b, v]), SR, oracle.constant(freq[v]), float(color[v]))
     for b in range(2):
         util.assert_bitexact(util.from_image(outs[b]), ref[b], f"config2 buffer {b}")
+
+
+@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+def test_const_freq_scalar_lane_fallback(ctx, oracle, kind):
+    """67 voices: not a multiple of 4, so the one-voice-per-lane kernel runs instead of the float4 one."""
+    from zang_amd import workloads
+    V, F = 67, 1024
+    freq, color, _, _ = workloads.voice_params(2, 100, V)
+    out0 = util.rng_buffers(15, V, F)
+    ref, rst = _oracle_osc(oracle, kind, V, F, util.SPANS_THREE, freq, color, out0=out0)
+    got, gst = _gpu_osc(ctx, kind, V, F, util.SPANS_THREE, freq, color, out0=out0)
+    util.assert_bitexact(got, ref, f"{kind} scalar-lane")
+    assert [int(x) for x in gst["cnt"]] == [s[0] for s in rst]

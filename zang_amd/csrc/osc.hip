@@ -69,10 +69,21 @@ __device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
     return (b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f);
 }
 
+struct PulseOscP {        // policy for the chunked kernels
+    using K = PulseK;
+    static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) {
+        pulse_setup_color(k, color);
+        pulse_setup_freq(k, srf, freq);
+    }
+    static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return pulse_sample(k, cnt); }
+};
+
+struct TriSawOscP;        // defined below
+
 // grid: x = 64-voice groups, y = groups of 4 frame chunks; block = 256 = 4 waves, each wave a
 // different chunk of the same 64 voices.
-template <bool ZF>
-__global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
+template <class OSC, bool ZF>
+__global__ void __launch_bounds__(256) k_osc_const(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
                                                         uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
                                                         float srf, float sr8, F32P freq_p, F32P color_p) {
     const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -83,9 +94,8 @@ __global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restri
     const float freq = freq_p.get(v);
     const bool bad = freq < 0 || freq > sr8;                          // PulseOsc.zig:82-84
     const uint32_t cnt0 = cnt_in[v];
-    PulseK k;
-    pulse_setup_color(k, color_p.get(v));
-    pulse_setup_freq(k, srf, freq);
+    typename OSC::K k;
+    OSC::setup(k, srf, freq, color_p.get(v));
     if (chunk == 0) cnt_out[v] = bad ? cnt0 : cnt0 + (end - start) * k.ifreq;
     if (c0 >= end) return;
     float *o = out.at(c0, v);
@@ -97,7 +107,7 @@ __global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restri
     uint32_t cnt = cnt0 + (c0 - start) * k.ifreq;
 #pragma unroll 4
     for (uint32_t i = c0; i < c1; i++, o += os) {
-        const float val = pulse_sample(k, cnt);
+        const float val = OSC::sample(k, cnt);
         *o = (ZF ? 0.0f : *o) + val;
         cnt += k.ifreq;
     }
@@ -107,8 +117,8 @@ __global__ void __launch_bounds__(256) k_pulseosc_const(const uint32_t *__restri
 // independent dependency chains per lane to cover the VALU->VCC wait states.
 // grid: x = 256-voice groups, y = groups of 4 frame chunks; each of the 4 waves of a block
 // renders a different chunk of the same 256 voices.
-template <bool ZF, int SM>
-__global__ void __launch_bounds__(256) k_pulseosc_const4(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
+template <class OSC, bool ZF, int SM>
+__global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
                                                          uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
                                                          float srf, float sr8, F32P freq_p, F32P color_p) {
     const uint32_t v = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -123,14 +133,13 @@ __global__ void __launch_bounds__(256) k_pulseosc_const4(const uint32_t *__restr
     const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt_in + v);
     const float freq[4] = {fq.x, fq.y, fq.z, fq.w}, color[4] = {cl.x, cl.y, cl.z, cl.w};
     const uint32_t cnt0[4] = {c4.x, c4.y, c4.z, c4.w};
-    PulseK k[4];
+    typename OSC::K k[4];
     uint32_t cnt[4];
     bool bad[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        bad[j] = freq[j] < 0 || freq[j] > sr8;            // PulseOsc.zig:82-84
-        pulse_setup_color(k[j], color[j]);
-        pulse_setup_freq(k[j], srf, freq[j]);
+        bad[j] = freq[j] < 0 || freq[j] > sr8;            // PulseOsc.zig:82-84, TriSawOsc.zig:84-86
+        OSC::setup(k[j], srf, freq[j], color[j]);
         cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq;
     }
     if (chunk == 0) {
@@ -156,7 +165,7 @@ __global__ void __launch_bounds__(256) k_pulseosc_const4(const uint32_t *__restr
         float val[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            val[j] = pulse_sample(k[j], cnt[j]);
+            val[j] = OSC::sample(k[j], cnt[j]);
             cnt[j] += k[j].ifreq;
         }
         // a silent voice (bad freq) paints nothing: out unchanged (ADD) / zero (ZERO_FIRST)
@@ -196,68 +205,44 @@ struct TriSawK {          // TriSawOsc.zig:90-99
     float f, omf, rcpf, col, c1, c2;
 };
 
-__device__ __forceinline__ TriSawK trisaw_setup(float sample_rate, float freq, float color) {
-    TriSawK k;
-    const float SRfcobasefrq = 4294967296.0f / sample_rate;
-    k.ifreq = zf32_to_u32(SRfcobasefrq * freq);
-    k.brpt = zftou32(zclamp01(color));
-    const float gain = 0.7f;
-    k.f = zutof23(k.ifreq);
-    k.omf = 1.0f - k.f;
-    k.rcpf = 1.0f / k.f;
-    k.col = zutof23(k.brpt);
-    k.c1 = gain / k.col;
-    k.c2 = -gain / (1.0f - k.col);
-    return k;
-}
-
-// TriSawOsc.zig:103-114.  Each arm is evaluated only by the lanes that take it: c1 is +inf
-// when color == 0 (unused arms then), so arms must be selected, never blended.
-__device__ __forceinline__ float trisaw_sample(const TriSawK &k, uint32_t cnt) {
-    const float gain = 0.7f;
-    const float p = zutof23(cnt) - k.col;
-    const uint32_t s0 = cnt < k.brpt ? 1u : 0u;
-    const uint32_t s1 = (uint32_t)(cnt - k.ifreq) < k.brpt ? 2u : 0u;
-    const uint32_t s = s0 | s1 | (cnt < k.ifreq ? 4u : 0u);
-    float v = 0.0f;
-    if (s == 3) v = k.c1 * (p + p - k.f);
-    else if (s == 0) v = k.c2 * (p + p - k.f);
-    else if (s == 2) v = k.rcpf * (k.c2 * (p * p) - k.c1 * ((p - k.f) * (p - k.f)));
-    else if (s == 5) v = -k.rcpf * (gain + k.c2 * ((p + k.omf) * (p + k.omf)) - k.c1 * (p * p));
-    else if (s == 7) v = -k.rcpf * (gain + k.c1 * k.omf * (p + p + k.omf));
-    else if (s == 4) v = -k.rcpf * (gain + k.c2 * k.omf * (p + p + k.omf));
-    return gain + v;
-}
-
-template <bool ZF>
-__global__ void __launch_bounds__(256) k_trisawosc_const(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
-                                                         uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
-                                                         float sample_rate, F32P freq_p, F32P color_p) {
-    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (v >= V) return;
-    const uint32_t c0 = start + chunk * fc;
-    const uint32_t c1 = min(c0 + fc, end);
-    const float freq = freq_p.get(v);
-    const bool bad = freq < 0 || freq > sample_rate / 8.0f;          // TriSawOsc.zig:84-86
-    const uint32_t cnt0 = cnt_in[v];
-    const TriSawK k = trisaw_setup(sample_rate, freq, color_p.get(v));
-    if (chunk == 0) cnt_out[v] = bad ? cnt0 : cnt0 + (end - start) * k.ifreq;
-    if (c0 >= end) return;
-    float *o = out.at(c0, v);
-    const size_t os = out.stride;
-    if (bad) {
-        if (ZF) for (uint32_t i = c0; i < c1; i++, o += os) *o = 0.0f;
-        return;
+// TriSawOsc.zig:103-114 as value selects with the mask logic of pulse_sample:
+//   b0 == b1, no wrap  (3 / 0): c1|c2 * (p + p - f)                       c1 when b0 else c2
+//   b0 == b1, wrap     (7 / 4): -rcpf * (gain + (c1|c2 * omf) * (p + p + omf))
+//   b0 != b1           (2)    : rcpf * (c2*p^2 - c1*(p - f)^2)
+//                      (5)    : -rcpf * (gain + c2*(p + omf)^2 - c1*p^2)
+//   1 and 6 are `unreachable` in the reference: defined as +0 (then `gain + 0`).
+// Every arm is the reference's own expression, so the selected value has the reference's bits;
+// unselected arms may be inf/NaN (c1 = +inf when color == 0) and are discarded, never blended.
+struct TriSawOscP {
+    using K = TriSawK;
+    static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) {   // TriSawOsc.zig:90-99
+        const float gain = 0.7f;
+        k.ifreq = zf32_to_u32(srf * freq);
+        k.brpt = zftou32(zclamp01(color));
+        k.f = zutof23(k.ifreq);
+        k.omf = 1.0f - k.f;
+        k.rcpf = 1.0f / k.f;
+        k.col = zutof23(k.brpt);
+        k.c1 = gain / k.col;
+        k.c2 = -gain / (1.0f - k.col);
     }
-    uint32_t cnt = cnt0 + (c0 - start) * k.ifreq;
-#pragma unroll 4
-    for (uint32_t i = c0; i < c1; i++, o += os) {
-        const float val = trisaw_sample(k, cnt);
-        *o = (ZF ? 0.0f : *o) + val;
-        cnt += k.ifreq;
+    static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) {
+        const float gain = 0.7f;
+        const float p = zutof23(cnt) - k.col;
+        const bool b0 = cnt < k.brpt;
+        const bool b1 = (uint32_t)(cnt - k.ifreq) < k.brpt;
+        const bool b2 = cnt < k.ifreq;
+        const float cx = b0 ? k.c1 : k.c2;
+        const float flat_nowrap = cx * (p + p - k.f);
+        const float flat_wrap = -k.rcpf * (gain + cx * k.omf * (p + p + k.omf));
+        const float ramp2 = k.rcpf * (k.c2 * (p * p) - k.c1 * ((p - k.f) * (p - k.f)));
+        const float ramp5 = -k.rcpf * (gain + k.c2 * ((p + k.omf) * (p + k.omf)) - k.c1 * (p * p));
+        const float flat = b2 ? flat_wrap : flat_nowrap;
+        const float ramp = b2 ? ramp5 : ramp2;
+        const float v = (b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f);
+        return gain + v;
     }
-}
+};
 
 // TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt
 template <bool ZF>
@@ -311,6 +296,34 @@ static bool osc_force_scalar() {
     return v != 0;
 }
 
+// Launch the chunked constant-frequency kernel of oscillator OSC (4 voices per lane with 16-byte
+// write-through stores when the image and params allow it, one voice per lane otherwise).
+template <class OSC>
+static void launch_osc_const(zh_ctx *ctx, uint32_t n, const uint32_t *ci, uint32_t *co, const zh_buf &outb, uint32_t start,
+                             uint32_t end, float sample_rate, const zh_f32 &freq, const zh_f32 &color, bool zf) {
+    hipStream_t st = ctx->stream;
+    Img out = mk_img(outb);
+    const float srf = 4294967296.0f / sample_rate;        // SRfcobasefrq, PulseOsc.zig:87 / TriSawOsc.zig:88
+    const float sr8 = sample_rate / 8.0f;                 // PulseOsc.zig:82 / TriSawOsc.zig:84
+    const F32P fq = mk_f32(freq), col = mk_f32(color);
+    const bool vec = n % 4 == 0 && outb.stride % 4 == 0 && aligned16(outb.ptr) && (!fq.pv || aligned16(fq.pv)) &&
+                     (!col.pv || aligned16(col.pv)) && !osc_force_scalar();
+    const uint32_t lanes = vec ? n / 4 : n;
+    const uint32_t fc = osc_frames_per_lane(lanes, end - start);
+    const uint32_t chunks = (end - start + fc - 1) / fc;
+    dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
+    if (vec) {
+#define ZH_LAUNCH_O4(ZF, SM) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col)
+        const int sm = ((size_t)fc * outb.stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
+        if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
+        else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
+#undef ZH_LAUNCH_O4
+    } else {
+        if (zf) hipLaunchKernelGGL((k_osc_const<OSC, true>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+        else hipLaunchKernelGGL((k_osc_const<OSC, false>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+    }
+}
+
 template <class M> static int osc_common_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs,
                                                float sample_rate, const zh_cob &freq) {
     (void)sample_rate;
@@ -361,30 +374,15 @@ int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     Img out = mk_img(outputs[0]);
-    const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:87
-    const float sr8 = p->sample_rate / 8.0f;              // :82
-    const F32P fq = mk_f32(p->freq.constant), col = mk_f32(p->color);
     if (p->freq.tag == ZH_COB_CONSTANT) {
-        uint32_t *ci = m->cnt[m->cur], *co = m->cnt[m->cur ^ 1];
-        const bool vec = m->n % 4 == 0 && outputs[0].stride % 4 == 0 && aligned16(outputs[0].ptr) &&
-                         (!fq.pv || aligned16(fq.pv)) && (!col.pv || aligned16(col.pv)) && !osc_force_scalar();
-        const uint32_t lanes = vec ? m->n / 4 : m->n;
-        const uint32_t fc = osc_frames_per_lane(lanes, end - start);
-        const uint32_t chunks = (end - start + fc - 1) / fc;
-        dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
-        if (vec) {
-#define ZH_LAUNCH_P4(ZF, SM) hipLaunchKernelGGL((k_pulseosc_const4<ZF, SM>), grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, srf, sr8, fq, col)
-            const int sm = ((size_t)fc * outputs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
-            if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_P4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_P4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_P4(true, ST_SC1); else ZH_LAUNCH_P4(true, ST_SC0SC1); }
-            else    { if (sm == ST_PLAIN) ZH_LAUNCH_P4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_P4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_P4(false, ST_SC1); else ZH_LAUNCH_P4(false, ST_SC0SC1); }
-#undef ZH_LAUNCH_P4
-        } else {
-            if (zf) hipLaunchKernelGGL(k_pulseosc_const<true>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, srf, sr8, fq, col);
-            else hipLaunchKernelGGL(k_pulseosc_const<false>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, srf, sr8, fq, col);
-        }
+        launch_osc_const<PulseOscP>(m->ctx, m->n, m->cnt[m->cur], m->cnt[m->cur ^ 1], outputs[0], start, end, p->sample_rate,
+                                    p->freq.constant, p->color, zf);
         m->cur ^= 1;
     } else {
+        const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:122
+        const float sr8 = p->sample_rate / 8.0f;              // :134
         uint32_t *c = m->cnt[m->cur];
+        const F32P col = mk_f32(p->color);
         if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
         else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
     }
@@ -444,12 +442,8 @@ int zh_trisawosc_paint(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_b
     hipStream_t st = m->ctx->stream;
     Img out = mk_img(outputs[0]);
     if (p->freq.tag == ZH_COB_CONSTANT) {
-        const uint32_t fc = osc_frames_per_lane(m->n, end - start);
-        const uint32_t chunks = (end - start + fc - 1) / fc;
-        dim3 grid((m->n + 63) / 64, (chunks + 3) / 4);
-        uint32_t *ci = m->cnt[m->cur], *co = m->cnt[m->cur ^ 1];
-        if (zf) hipLaunchKernelGGL(k_trisawosc_const<true>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
-        else hipLaunchKernelGGL(k_trisawosc_const<false>, grid, dim3(256), 0, st, ci, co, m->n, out, start, end, fc, p->sample_rate, mk_f32(p->freq.constant), mk_f32(p->color));
+        launch_osc_const<TriSawOscP>(m->ctx, m->n, m->cnt[m->cur], m->cnt[m->cur ^ 1], outputs[0], start, end, p->sample_rate,
+                                     p->freq.constant, p->color, zf);
         m->cur ^= 1;
     } else {
         if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
