@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "nice", "nice_mix"])
+    ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "noise_filter_fused", "nice", "nice_mix"])
     ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
@@ -56,7 +56,7 @@ class Workload:
         self.name, self.V, self.F = name, V, F
         self.ctx = ctx
         self.span = zang.Span(0, F)
-        cfg = {"pulseosc": 2, "noise_filter": 3, "nice": 5, "nice_mix": 5}[name]
+        cfg = {"pulseosc": 2, "noise_filter": 3, "noise_filter_fused": 3, "nice": 5, "nice_mix": 5}[name]
         freq, color, u2, u3 = workloads.voice_params(cfg, first_voice, V)
         self.freq_h, self.color_h, self.u2_h, self.u3_h = freq, color, u2, u3
         dev = ctx.device
@@ -82,6 +82,15 @@ class Workload:
             self.temp = ctx.image(F, V)
             self.kernel = "k_filter"
             self.step = self._step_noise_filter
+        elif name == "noise_filter_fused":
+            self.m = mod.NoiseFilter(V, ctx, first_seed=first_voice)
+            cutoff_f = torch.from_numpy((200.0 + 7800.0 * u2)).to(dev)
+            self.cutoff = mod.Filter.cutoffFromFrequency(cutoff_f, SR, ctx)
+            self.res = torch.from_numpy((0.9 * u3)).to(dev)
+            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
+            self.kernel = "k_noise_filter"
+            self.step = self._step_noise_filter_fused
         elif name == "nice":
             self.m = mod.NiceInstrument(V, self.color, ctx)
             self.ring = [ctx.image(F, V) for _ in range(nring)]
@@ -123,6 +132,13 @@ class Workload:
                     mod_f.Params(self.temp, mod_f.low_pass, zang.constant(self.cutoff), zang.constant(self.res)),
                     zero_first=True)
 
+    @staticmethod
+    def m_white():
+        return 0                                # Noise.Color.white
+
+    def _step_noise_filter_fused(self):
+        self.m.paint(self.span, [self._next()], None, False, self.params, zero_first=True)
+
     def _note_on(self):
         # config 5: note on for buffers 0-23, then off (attack -> decay -> sustain -> release), repeating
         k = self.nsteps % 48
@@ -157,7 +173,7 @@ def cpu_baseline(args, wl):
         states = (po.PulseOsc * V)()
         run = lambda n: L.zo_bench_pulseosc(V, F, n, SR, po.fptr(wl.freq_h), po.fptr(wl.color_h), states, po.fptr(scratch))
         what = "zero + PulseOsc.paint per voice"
-    elif wl.name == "noise_filter":
+    elif wl.name in ("noise_filter", "noise_filter_fused"):
         scratch = np.zeros(2 * F, np.float32)
         noise = (po.Noise * V)(); flt = (po.Filter * V)()
         for v in range(V):

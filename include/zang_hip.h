@@ -362,6 +362,21 @@ typedef struct zh_span_table {
 ZH_API int zh_nice_paint_spans(zh_nice *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                                const zh_buf *temps, float sample_rate, const zh_span_table *table, uint32_t flags);
 
+/* ---------------------------------------------------------------- Noise -> Filter voice (examples/example_stereo.zig:71-82)
+ * zero(temp); Noise.paint(temp); Filter.paint(out, input = temp, type, cutoff, res) as ONE kernel: the
+ * temp image stays in registers (BASELINE config 3, fused variant).  Bit-identical to the two separate
+ * paints.  cutoff / res are per-voice constants here. */
+typedef struct zh_noise_filter zh_noise_filter;
+typedef struct zh_noise_filter_params { uint32_t color; uint32_t type; zh_f32 cutoff; zh_f32 res; } zh_noise_filter_params;
+typedef struct zh_noise_filter_state { zh_noise_state noise; zh_filter_state flt; } zh_noise_filter_state;
+ZH_API int zh_noise_filter_create(zh_ctx *ctx, uint32_t n_voices, uint64_t first_seed, zh_noise_filter **out);
+ZH_API int zh_noise_filter_destroy(zh_noise_filter *m);
+ZH_API int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host);
+ZH_API int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *host);
+ZH_API int zh_noise_filter_paint(zh_noise_filter *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                                 const zh_buf *temps /*[1], unused; may be NULL*/, zh_bool note_id_changed,
+                                 const zh_noise_filter_params *params, uint32_t flags);
+
 /* ---------------------------------------------------------------- PMOscInstrument (examples/modules.zig:6-128) */
 typedef struct zh_pmosc zh_pmosc;
 typedef struct zh_pmosc_params { float sample_rate; uint32_t reserved; zh_f32 freq; zh_bool note_on; } zh_pmosc_params; /* :83-87 */

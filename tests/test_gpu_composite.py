@@ -133,3 +133,36 @@ def test_pmosc_fused_equals_unfused_oracle(ctx, oracle):
     gs = m.state()
     util.assert_bitexact(gs["carrier"]["t"].astype(np.float32), np.array([r.carrier.t for r in st], np.float32), "carrier t")
     util.assert_bitexact(gs["modulator"]["t"].astype(np.float32), np.array([r.modulator.t for r in st], np.float32), "modulator t")
+
+
+@pytest.mark.parametrize("color", [0, 1])
+@pytest.mark.parametrize("ftype", [0, 1, 3, 5])
+def test_noise_filter_fused_equals_unfused(ctx, oracle, color, ftype):
+    """The fused Noise->Filter voice vs the oracle running zero/Noise.paint/zero/Filter.paint through a temp
+    (examples/example_stereo.zig:71-82), three sub-spans, carried state; global seeds."""
+    from zang_amd import modules as mod, zang
+    V, first = 192, 5000
+    rng = np.random.default_rng(17)
+    cutoff = rng.uniform(-0.05, 1.05, V).astype(np.float32); res = rng.uniform(-0.05, 1.05, V).astype(np.float32)
+    out0 = util.rng_buffers(18, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rl = np.zeros(V, np.float32); rb = np.zeros(V, np.float32); rs = []
+    temp = np.zeros(F, np.float32)
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + v)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
+        for (s, e) in util.SPANS_THREE:
+            L.zo_zero(s, e, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nz), s, e, oracle.fptr(temp), color)
+            L.zo_filter_paint(C.byref(fl), s, e, oracle.fptr(ref[v]), oracle.fptr(temp), ftype, oracle.constant(cutoff[v]), oracle.constant(res[v]))
+        rl[v], rb[v] = fl.l, fl.b; rs.append(list(nz.r))
+    m = mod.NoiseFilter(V, ctx, first_seed=first)
+    out = util.to_image(out0)
+    gc, gr = util.dev(cutoff), util.dev(res)
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(color, ftype, gc, gr))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"noise_filter color {color} type {ftype}")
+    st = m.state()
+    util.assert_bitexact(st["flt"]["l"].astype(np.float32), rl, "l"); util.assert_bitexact(st["flt"]["b"].astype(np.float32), rb, "b")
+    assert [[int(x) for x in row] for row in st["noise"]["r"]] == rs

@@ -120,6 +120,14 @@ class DistortionParams(C.Structure):
     _fields_ = [("input", Buf), ("type", u32), ("reserved", u32), ("ingain", F32), ("outgain", F32), ("offset", F32)]
 
 
+class NoiseFilterParams(C.Structure):
+    _fields_ = [("color", u32), ("type", u32), ("cutoff", F32), ("res", F32)]
+
+
+class NoiseFilterState(C.Structure):
+    _fields_ = [("noise", NoiseState), ("flt", FilterState)]
+
+
 class CurveNode(C.Structure):
     _fields_ = [("value", f32), ("t", f32)]
 
@@ -290,6 +298,11 @@ SIGNATURES = {
     "zh_nice_set_state": (C.c_int, [vp, vp]),
     "zh_nice_paint": (C.c_int, _paint(NiceParams)),
     "zh_nice_paint_mix": (C.c_int, [vp, u32, u32, vp, Bool, P(NiceParams), u32]),
+    "zh_noise_filter_create": (C.c_int, [vp, u32, u64, P(vp)]),
+    "zh_noise_filter_destroy": (C.c_int, [vp]),
+    "zh_noise_filter_get_state": (C.c_int, [vp, vp]),
+    "zh_noise_filter_set_state": (C.c_int, [vp, vp]),
+    "zh_noise_filter_paint": (C.c_int, _paint(NoiseFilterParams)),
     "zh_pmosc_create": (C.c_int, [vp, u32, F32, P(vp)]),
     "zh_pmosc_destroy": (C.c_int, [vp]),
     "zh_pmosc_get_state": (C.c_int, [vp, vp]),

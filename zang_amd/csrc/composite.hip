@@ -336,6 +336,103 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
     pm_store(n, a, v);
 }
 
+// ------------------------------------------------------------------ Noise -> Filter voice
+struct zh_noise_filter { zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *nb; /* [7][n] */ float *l, *b; };
+
+__global__ void k_nf_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, uint32_t n, uint64_t first_seed) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    ZXoshiro r;
+    zxoshiro_seed(r, first_seed + v);                                  // Noise.zig:26-29
+    s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;
+}
+
+template <bool ZF, bool PINK>
+__global__ void __launch_bounds__(kSeqBlock) k_noise_filter(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
+                                                            uint64_t *__restrict__ s2, uint64_t *__restrict__ s3,
+                                                            const float *__restrict__ bst, float *__restrict__ l_io,
+                                                            float *__restrict__ b_io, uint32_t V, Img out, uint32_t start,
+                                                            uint32_t end, float l_mul, float b_mul, float h_mul, F32P cutoff,
+                                                            F32P res_p) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    const float fcdcoffset = 3.814697265625e-6f;                       // Filter.zig:8
+    ZXoshiro r{s0[v], s1[v], s2[v], s3[v]};
+    float pb[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (PINK) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) pb[j] = bst[(size_t)j * V + v];
+    }
+    const float cut = zclampf(cutoff.get(v), 0.0f, 1.0f);              // Filter.zig:114
+    const float res = 1.0f - zclampf(res_p.get(v), 0.0f, 1.0f);        // :118
+    float l = l_io[v], b = b_io[v];
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        const float white = zrandom_float32(r) * 2.0f - 1.0f;          // Noise.zig:51 / :58
+        float nz = white;
+        if (PINK) {                                                    // :59-66
+            pb[0] = 0.99886f * pb[0] + white * 0.0555179f;
+            pb[1] = 0.99332f * pb[1] + white * 0.0750759f;
+            pb[2] = 0.96900f * pb[2] + white * 0.1538520f;
+            pb[3] = 0.86650f * pb[3] + white * 0.3104856f;
+            pb[4] = 0.55000f * pb[4] + white * 0.5329522f;
+            pb[5] = -0.7616f * pb[5] - white * 0.0168980f;
+            nz = pb[0] + pb[1] + pb[2] + pb[3] + pb[4] + pb[5] + pb[6] + white * 0.5362f;
+            pb[6] = white * 0.115926f;
+        }
+        const float temp = 0.0f + nz;                                  // zero(temp); temp += noise
+        const float in = temp + fcdcoffset;                            // Filter.zig:135-146
+        l += cut * b - fcdcoffset;
+        b += cut * (in - b * res - l);
+        l += cut * b;
+        const float h = in - b * res - l;
+        b += cut * h;
+        val = l * l_mul + b * b_mul + h * h_mul;
+        return true;
+    });
+    s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;
+    l_io[v] = l; b_io[v] = b;
+}
+
+// bypass: out += noise, filter state untouched (Filter.zig:91-97)
+template <bool ZF, bool PINK>
+__global__ void __launch_bounds__(kSeqBlock) k_noise_filter_bypass(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
+                                                                   uint64_t *__restrict__ s2, uint64_t *__restrict__ s3,
+                                                                   const float *__restrict__ bst, uint32_t V, Img out,
+                                                                   uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= V) return;
+    ZXoshiro r{s0[v], s1[v], s2[v], s3[v]};
+    float pb[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (PINK) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) pb[j] = bst[(size_t)j * V + v];
+    }
+    const float *const *no_in = nullptr;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        const float white = zrandom_float32(r) * 2.0f - 1.0f;
+        float nz = white;
+        if (PINK) {
+            pb[0] = 0.99886f * pb[0] + white * 0.0555179f;
+            pb[1] = 0.99332f * pb[1] + white * 0.0750759f;
+            pb[2] = 0.96900f * pb[2] + white * 0.1538520f;
+            pb[3] = 0.86650f * pb[3] + white * 0.3104856f;
+            pb[4] = 0.55000f * pb[4] + white * 0.5329522f;
+            pb[5] = -0.7616f * pb[5] - white * 0.0168980f;
+            nz = pb[0] + pb[1] + pb[2] + pb[3] + pb[4] + pb[5] + pb[6] + white * 0.5362f;
+            pb[6] = white * 0.115926f;
+        }
+        val = 0.0f + nz;
+        return true;
+    });
+    s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;
+}
+
+static void nf_free(zh_noise_filter *m) {
+    for (auto &x : m->s) (void)hipFree(x);
+    (void)hipFree(m->nb); (void)hipFree(m->l); (void)hipFree(m->b);
+}
+
 __global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = src.get(i);
@@ -487,6 +584,102 @@ int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *
     NiceArgs a = nice_args(m, &p, no);
     if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_nice_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_nice_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    return zh_launch_status();
+}
+
+// ------------------------------------------------------------------ Noise -> Filter voice
+int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise_filter **out) {
+    if (!ctx || !out) return ZH_ERR_INVALID;
+    zh_noise_filter *m = new (std::nothrow) zh_noise_filter();
+    if (!m) return ZH_ERR_INVALID;
+    *m = zh_noise_filter{ctx, n, {nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr};
+    int rc = 0;
+    for (int i = 0; i < 4 && !rc; i++) rc = dev_alloc(&m->s[i], n);
+    if (!rc) rc = dev_alloc(&m->nb, (size_t)7 * n);
+    if (!rc) rc = dev_alloc(&m->l, n);
+    if (!rc) rc = dev_alloc(&m->b, n);
+    if (!rc && n) {
+        rc = (int)hipMemsetAsync(m->nb, 0, (size_t)7 * n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->l, 0, (size_t)n * 4, ctx->stream);
+        if (!rc) rc = (int)hipMemsetAsync(m->b, 0, (size_t)n * 4, ctx->stream);
+    }
+    if (rc) { nf_free(m); delete m; return rc; }
+    if (n) hipLaunchKernelGGL(k_nf_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], n, first_seed);
+    *out = m;
+    return zh_launch_status();
+}
+int zh_noise_filter_destroy(zh_noise_filter *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    nf_free(m);
+    delete m;
+    return ZH_OK;
+}
+int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    std::vector<uint64_t> s;
+    std::vector<float> nb, l, b;
+    for (int i = 0; i < 4; i++) {
+        int rc = down(m->ctx, s, m->s[i], m->n);
+        if (rc) return rc;
+        for (uint32_t v = 0; v < m->n; v++) host[v].noise.r[i] = s[v];
+    }
+    int rc = down(m->ctx, nb, m->nb, (size_t)7 * m->n);
+    if (!rc) rc = down(m->ctx, l, m->l, m->n);
+    if (!rc) rc = down(m->ctx, b, m->b, m->n);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->n; v++) {
+        for (int j = 0; j < 7; j++) host[v].noise.b[j] = nb[(size_t)j * m->n + v];
+        host[v].noise.reserved = 0;
+        host[v].flt = zh_filter_state{l[v], b[v]};
+    }
+    return ZH_OK;
+}
+int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *host) {
+    if (!m || !host) return ZH_ERR_INVALID;
+    const uint32_t n = m->n;
+    std::vector<uint64_t> s(n);
+    std::vector<float> nb((size_t)7 * n), l(n), b(n);
+    for (int i = 0; i < 4; i++) {
+        for (uint32_t v = 0; v < n; v++) s[v] = host[v].noise.r[i];
+        int rc = up(m->ctx, m->s[i], s);
+        if (rc) return rc;
+    }
+    for (uint32_t v = 0; v < n; v++) {
+        for (int j = 0; j < 7; j++) nb[(size_t)j * n + v] = host[v].noise.b[j];
+        l[v] = host[v].flt.l; b[v] = host[v].flt.b;
+    }
+    int rc = up(m->ctx, m->nb, nb);
+    if (!rc) rc = up(m->ctx, m->l, l);
+    if (!rc) rc = up(m->ctx, m->b, b);
+    return rc;
+}
+int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                          zh_bool note_id_changed, const zh_noise_filter_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;
+    if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
+    if (p->color > ZH_NOISE_PINK || p->type > ZH_FILTER_ALL_PASS) return ZH_ERR_INVALID;
+    if (m->n == 0 || end == start) return ZH_OK;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST, pink = p->color == ZH_NOISE_PINK;
+    hipStream_t st = m->ctx->stream;
+    Img out = mk_img(outputs[0]);
+    if (p->type == ZH_FILTER_BYPASS) {
+#define ZH_NFB(ZF_, PK_) hipLaunchKernelGGL((k_noise_filter_bypass<ZF_, PK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->n, out, start, end)
+        if (zf) { if (pink) ZH_NFB(true, true); else ZH_NFB(true, false); } else { if (pink) ZH_NFB(false, true); else ZH_NFB(false, false); }
+#undef ZH_NFB
+        return zh_launch_status();
+    }
+    float l_mul = 0.0f, b_mul = 0.0f, h_mul = 0.0f;                                 // Filter.zig:98-109
+    switch (p->type) {
+    case ZH_FILTER_LOW_PASS: l_mul = 1.0f; break;
+    case ZH_FILTER_BAND_PASS: b_mul = 1.0f; break;
+    case ZH_FILTER_HIGH_PASS: h_mul = 1.0f; break;
+    case ZH_FILTER_NOTCH: l_mul = 1.0f; h_mul = 1.0f; break;
+    default: l_mul = 1.0f; b_mul = 1.0f; h_mul = 1.0f; break;
+    }
+#define ZH_NF(ZF_, PK_) hipLaunchKernelGGL((k_noise_filter<ZF_, PK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
+    if (zf) { if (pink) ZH_NF(true, true); else ZH_NF(true, false); } else { if (pink) ZH_NF(false, true); else ZH_NF(false, false); }
+#undef ZH_NF
     return zh_launch_status();
 }
 

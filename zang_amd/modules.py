@@ -366,6 +366,27 @@ class NiceInstrument(_Module):
         abi.check(rc, "zh_nice_paint_mix")
 
 
+class NoiseFilter(_Module):
+    """Noise -> Filter as one fused kernel (examples/example_stereo.zig:71-82; BASELINE config 3)."""
+    _prefix = "noise_filter"
+    _state_ctype = abi.NoiseFilterState
+    num_temps = 1
+
+    @dataclass
+    class Params:
+        color: int
+        type: int
+        cutoff: Any
+        res: Any
+
+    def __init__(self, n_voices, ctx=None, first_seed=0):
+        super().__init__(n_voices, ctx, C.c_uint64(first_seed))
+
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+        cp = abi.NoiseFilterParams(params.color, params.type, as_f32(params.cutoff), as_f32(params.res))
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+
+
 class PMOscInstrument(_Module):
     """examples/modules.zig:80-128 (PhaseModOscillator :6-77 inside) as one fused kernel."""
     _prefix = "pmosc"
