@@ -208,11 +208,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ZH_BENCH_EMULATE=1: multi-process dry run on a single GPU (every rank on device 0, gloo instead
+    # of RCCL) -- used only to exercise the N>1 code path where one GPU is available.
+    emulate = os.environ.get("ZH_BENCH_EMULATE") == "1"
+    device_index = 0 if (world == 1 or emulate) else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if emulate:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
     else:
         torch.cuda.set_device(0)
     import zang_amd
@@ -221,7 +228,7 @@ def main():
     # allocation / copy / sync below happens with it current, so ordering is by stream
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
-    ctx = zang_amd.Context(local_rank if world > 1 else 0)
+    ctx = zang_amd.Context(device_index)
     V, F = args.voices, args.frames
     wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20, world=world)
     lib = ctx.lib
@@ -278,7 +285,7 @@ def main():
     lib.zh_event_destroy(ev0)
     lib.zh_event_destroy(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if emulate else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -18,5 +18,10 @@ def voice_range(total_voices, rank, world):
 def allreduce_mix(mix, group=None):
     """Sum the per-rank partial mixes in place (float32 [frames], on the rank's device)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(mix, op=dist.ReduceOp.SUM, group=group)
+        if mix.is_cuda and dist.get_backend(group) == "gloo":     # CPU-only backend (tests, dry runs): stage through host
+            host = mix.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            mix.copy_(host)
+        else:
+            dist.all_reduce(mix, op=dist.ReduceOp.SUM, group=group)
     return mix
