@@ -433,6 +433,43 @@ ZH_API int zh_trigger_reset(zh_trigger *t);                                     
 ZH_API int zh_trigger_counter(zh_trigger *t, uint64_t span_start, uint64_t span_end, zh_iap iap);     /* :66-78 */
 ZH_API int zh_trigger_next(zh_trigger *t, zh_paint_span *out);   /* :80-105; returns 1 = span produced, 0 = null, <0 error */
 
+/* ---------------------------------------------------------------- single-voice host-pointer wrappers
+ * The literal one-voice form of a Zig module call: `state` is the Zig struct (in/out), `outputs[0]` and every
+ * input buffer are HOST float[>= span_end] slices exactly like zang's []f32, params are plain values.  Each call
+ * stages through the device (upload, one-voice paint, download) and is synchronous: a drop-in for porting and
+ * for checking a Zig caller against the GPU path, not a fast path (use the batched entry points for speed). */
+typedef struct zh_hcob { uint32_t tag; float constant; const float *buffer; } zh_hcob;   /* host ConstantOrBuffer */
+typedef struct zh_hcurve { uint32_t tag; float duration; } zh_hcurve;                     /* host PaintCurve */
+
+typedef struct zh_sineosc_host_params { float sample_rate; zh_hcob freq, phase; } zh_sineosc_host_params;
+typedef struct zh_pulseosc_host_params { float sample_rate; zh_hcob freq; float color; } zh_pulseosc_host_params;
+typedef zh_pulseosc_host_params zh_trisawosc_host_params;
+typedef struct zh_noise_host_params { uint32_t color; } zh_noise_host_params;
+typedef struct zh_envelope_host_params { float sample_rate; zh_hcurve attack, decay, release; float sustain_volume; uint32_t note_on; } zh_envelope_host_params;
+typedef struct zh_gate_host_params { uint32_t note_on; } zh_gate_host_params;
+typedef struct zh_filter_host_params { const float *input; uint32_t type; zh_hcob cutoff, res; } zh_filter_host_params;
+typedef struct zh_sampler_host_params {
+    float sample_rate; uint64_t num_channels, sample_rate_in; uint32_t format; const uint8_t *data; uint64_t data_len;
+    uint64_t channel; uint32_t loop;
+} zh_sampler_host_params;
+typedef struct zh_decimator_host_params { float sample_rate; const float *input; float fake_sample_rate; } zh_decimator_host_params;
+typedef struct zh_distortion_host_params { const float *input; uint32_t type; float ingain, outgain, offset; } zh_distortion_host_params;
+
+/* init() of the two modules whose Zig init() is not all-zeros (host side, no GPU work) */
+ZH_API int zh_noise_state_init(zh_noise_state *state, uint64_t seed);          /* Noise.zig:25-32 with an explicit seed */
+ZH_API int zh_decimator_state_init(zh_decimator_state *state);                  /* Decimator.zig:14-19 */
+
+ZH_API int zh_sineosc_paint_host(zh_ctx *ctx, zh_sineosc_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_sineosc_host_params *params);
+ZH_API int zh_pulseosc_paint_host(zh_ctx *ctx, zh_pulseosc_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_pulseosc_host_params *params);
+ZH_API int zh_trisawosc_paint_host(zh_ctx *ctx, zh_trisawosc_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_trisawosc_host_params *params);
+ZH_API int zh_noise_paint_host(zh_ctx *ctx, zh_noise_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_noise_host_params *params);
+ZH_API int zh_envelope_paint_host(zh_ctx *ctx, zh_envelope_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_envelope_host_params *params);
+ZH_API int zh_gate_paint_host(zh_ctx *ctx, void *state_unused, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_gate_host_params *params);
+ZH_API int zh_filter_paint_host(zh_ctx *ctx, zh_filter_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_filter_host_params *params);
+ZH_API int zh_sampler_paint_host(zh_ctx *ctx, zh_sampler_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_sampler_host_params *params);
+ZH_API int zh_decimator_paint_host(zh_ctx *ctx, zh_decimator_state *state, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_decimator_host_params *params);
+ZH_API int zh_distortion_paint_host(zh_ctx *ctx, void *state_unused, uint32_t span_start, uint32_t span_end, float *const *outputs, float *const *temps, uint32_t note_id_changed, const zh_distortion_host_params *params);
+
 #ifdef __cplusplus
 }
 #endif

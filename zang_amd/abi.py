@@ -188,7 +188,53 @@ class PaintSpan(C.Structure):
     _fields_ = [("start", u64), ("end", u64), ("note_id_changed", u32), ("reserved", u32), ("params", C.c_uint8 * 64)]
 
 
+class HCob(C.Structure):
+    _fields_ = [("tag", u32), ("constant", f32), ("buffer", C.POINTER(f32))]
+
+
+class HCurve(C.Structure):
+    _fields_ = [("tag", u32), ("duration", f32)]
+
+
+class SineOscHostParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("freq", HCob), ("phase", HCob)]
+
+
+class PulseOscHostParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("freq", HCob), ("color", f32)]
+
+
+class NoiseHostParams(C.Structure):
+    _fields_ = [("color", u32)]
+
+
+class EnvelopeHostParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("attack", HCurve), ("decay", HCurve), ("release", HCurve), ("sustain_volume", f32), ("note_on", u32)]
+
+
+class GateHostParams(C.Structure):
+    _fields_ = [("note_on", u32)]
+
+
+class FilterHostParams(C.Structure):
+    _fields_ = [("input", C.POINTER(f32)), ("type", u32), ("cutoff", HCob), ("res", HCob)]
+
+
+class SamplerHostParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("num_channels", u64), ("sample_rate_in", u64), ("format", u32), ("data", C.POINTER(C.c_uint8)),
+                ("data_len", u64), ("channel", u64), ("loop", u32)]
+
+
+class DecimatorHostParams(C.Structure):
+    _fields_ = [("sample_rate", f32), ("input", C.POINTER(f32)), ("fake_sample_rate", f32)]
+
+
+class DistortionHostParams(C.Structure):
+    _fields_ = [("input", C.POINTER(f32)), ("type", u32), ("ingain", f32), ("outgain", f32), ("offset", f32)]
+
+
 P = C.POINTER
+_hpaint = lambda params: [vp, vp, u32, u32, C.POINTER(C.POINTER(f32)), C.POINTER(C.POINTER(f32)), u32, C.POINTER(params)]
 _paint = lambda params: [vp, u32, u32, P(Buf), P(Buf), Bool, P(params), u32]
 
 # name -> (restype, argtypes); must list every ZH_API symbol of include/zang_hip.h
@@ -312,6 +358,18 @@ SIGNATURES = {
     "zh_mix_down": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, f32]),
     "zh_nice_paint_spans": (C.c_int, [vp, u32, u32, P(Buf), P(Buf), f32, P(SpanTable), u32]),
     "zh_pmosc_paint_spans": (C.c_int, [vp, u32, u32, P(Buf), P(Buf), f32, P(SpanTable), u32]),
+    "zh_noise_state_init": (C.c_int, [vp, u64]),
+    "zh_decimator_state_init": (C.c_int, [vp]),
+    "zh_sineosc_paint_host": (C.c_int, _hpaint(SineOscHostParams)),
+    "zh_pulseosc_paint_host": (C.c_int, _hpaint(PulseOscHostParams)),
+    "zh_trisawosc_paint_host": (C.c_int, _hpaint(PulseOscHostParams)),
+    "zh_noise_paint_host": (C.c_int, _hpaint(NoiseHostParams)),
+    "zh_envelope_paint_host": (C.c_int, _hpaint(EnvelopeHostParams)),
+    "zh_gate_paint_host": (C.c_int, _hpaint(GateHostParams)),
+    "zh_filter_paint_host": (C.c_int, _hpaint(FilterHostParams)),
+    "zh_sampler_paint_host": (C.c_int, _hpaint(SamplerHostParams)),
+    "zh_decimator_paint_host": (C.c_int, _hpaint(DecimatorHostParams)),
+    "zh_distortion_paint_host": (C.c_int, _hpaint(DistortionHostParams)),
     "zh_impulse_queue_create": (C.c_int, [u32, P(vp)]),
     "zh_impulse_queue_destroy": (C.c_int, [vp]),
     "zh_impulse_queue_push": (C.c_int, [vp, u64, u64, vp]),
