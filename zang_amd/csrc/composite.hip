@@ -78,7 +78,7 @@ struct NiceLane {
             const bool b0 = cnt < brpt, b1 = (uint32_t)(cnt - ifreq) < brpt, b2 = cnt < ifreq;
             const float ramp = gdf2 * (b2 ? p : col - p) + (b2 ? -gain : gain);
             const float flat = b2 ? (b0 ? cc121 : cc212) : (b0 ? gain : -gain);
-            t0 = 0.0f + ((b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f));
+            t0 = 0.0f + ((b0 == b1) ? flat : ramp);       // transitions 1, 6 cannot occur (osc.hip, pulse_sample)
             cnt += ifreq;
         }
         t0 = t0 * 0.5f;                                                // multiplyWithScalar :226

@@ -55,8 +55,11 @@ __device__ __forceinline__ void pulse_setup_color(PulseK &k, float color) {
 // The 6-way switch of PulseOsc.zig:102-110.  transition = b0 | b1<<1 | b2<<2 with
 // b0 = cnt < brpt, b1 = (cnt - ifreq) < brpt, b2 = cnt < ifreq:
 //   b0 == b1: flat -> 3: gain, 0: -gain, 7: cc121, 4: cc212
-//   b0 != b1: ramp -> 2: gdf*2*(col-p) + gain, 5: gdf*2*p - gain (x - gain == x + (-gain) exactly);
-//             1 and 6 are `unreachable` in the reference: defined as +0.
+//   b0 != b1: ramp -> 2: gdf*2*(col-p) + gain, 5: gdf*2*p - gain (x - gain == x + (-gain) exactly).
+// Transitions 1 and 6 (`else => unreachable`, :109) cannot occur for ANY u32 cnt, ifreq, brpt:
+//   1 = (b0, !b1, !b2): !b2 means cnt >= ifreq, so cnt - ifreq does not wrap and is <= cnt < brpt => b1.
+//   6 = (!b0, b1, b2):  b2 means cnt < ifreq, so cnt - ifreq = cnt + 2^32 - ifreq >= cnt >= brpt => !b1.
+// Hence b0 != b1 implies the ramp case and no third arm is needed.
 // Values are selected, never blended (gdf is inf when ifreq < 512).
 __device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
     const float gain = 0.7f;
@@ -66,7 +69,7 @@ __device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
     const bool b2 = cnt < k.ifreq;
     const float ramp = k.gdf2 * (b2 ? p : k.col - p) + (b2 ? -gain : gain);
     const float flat = b2 ? (b0 ? k.cc121 : k.cc212) : (b0 ? gain : -gain);
-    return (b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f);
+    return (b0 == b1) ? flat : ramp;
 }
 
 struct PulseOscP {        // policy for the chunked kernels
@@ -119,29 +122,52 @@ __global__ void __launch_bounds__(256) k_osc_const(const uint32_t *__restrict__ 
 // renders a different chunk of the same 256 voices.
 template <class OSC, bool ZF, int SM>
 __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
-                                                         uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
-                                                         float srf, float sr8, F32P freq_p, F32P color_p) {
-    const uint32_t v = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+                                                    uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
+                                                    float srf, float sr8, F32P freq_p, F32P color_p) {
+    // The 4 waves of a block render 4 different frame chunks of the SAME 256 voices, so the per-voice
+    // setup (a divide and some conversions) is done once per block: thread t sets up voice base + t and
+    // parks the constants in LDS, then every lane fetches its 4 voices' constants with 16-byte reads.
+    using K = typename OSC::K;
+    constexpr int KW = sizeof(K) / 4;                     // dwords of per-voice constants
+    __shared__ __attribute__((aligned(16))) uint32_t sk[KW + 2][256];   // + cnt0, bad
+    const uint32_t vbase = blockIdx.x * 256;
+    {
+        const uint32_t sv = vbase + threadIdx.x;
+        if (sv < V) {
+            const float freq = freq_p.get(sv);
+            K k;
+            OSC::setup(k, srf, freq, color_p.get(sv));
+            const uint32_t *kw = reinterpret_cast<const uint32_t *>(&k);
+#pragma unroll
+            for (int j = 0; j < KW; j++) sk[j][threadIdx.x] = kw[j];
+            sk[KW][threadIdx.x] = cnt_in[sv];
+            sk[KW + 1][threadIdx.x] = (freq < 0 || freq > sr8) ? 1u : 0u;   // PulseOsc.zig:82-84, TriSawOsc.zig:84-86
+        }
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t v = vbase + lane * 4;
     const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (v >= V) return;                                   // V % 4 == 0 on this path
     const uint32_t c0 = start + chunk * fc;
     const uint32_t c1 = min(c0 + fc, end);
-    float4 fq = {freq_p.value, freq_p.value, freq_p.value, freq_p.value};
-    float4 cl = {color_p.value, color_p.value, color_p.value, color_p.value};
-    if (freq_p.pv) fq = *reinterpret_cast<const float4 *>(freq_p.pv + v);
-    if (color_p.pv) cl = *reinterpret_cast<const float4 *>(color_p.pv + v);
-    const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt_in + v);
-    const float freq[4] = {fq.x, fq.y, fq.z, fq.w}, color[4] = {cl.x, cl.y, cl.z, cl.w};
-    const uint32_t cnt0[4] = {c4.x, c4.y, c4.z, c4.w};
-    typename OSC::K k[4];
-    uint32_t cnt[4];
+    K k[4];
+    uint32_t cnt[4], cnt0[4];
     bool bad[4];
+    {
+        uint4 w[KW + 2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        bad[j] = freq[j] < 0 || freq[j] > sr8;            // PulseOsc.zig:82-84, TriSawOsc.zig:84-86
-        OSC::setup(k[j], srf, freq[j], color[j]);
-        cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq;
+        for (int j = 0; j < KW + 2; j++) w[j] = *reinterpret_cast<const uint4 *>(&sk[j][lane * 4]);
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            reinterpret_cast<uint32_t *>(&k[0])[j] = w[j].x; reinterpret_cast<uint32_t *>(&k[1])[j] = w[j].y;
+            reinterpret_cast<uint32_t *>(&k[2])[j] = w[j].z; reinterpret_cast<uint32_t *>(&k[3])[j] = w[j].w;
+        }
+        cnt0[0] = w[KW].x; cnt0[1] = w[KW].y; cnt0[2] = w[KW].z; cnt0[3] = w[KW].w;
+        bad[0] = w[KW + 1].x != 0; bad[1] = w[KW + 1].y != 0; bad[2] = w[KW + 1].z != 0; bad[3] = w[KW + 1].w != 0;
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq;
     if (chunk == 0) {
         uint4 o;
         o.x = bad[0] ? cnt0[0] : cnt0[0] + (end - start) * k[0].ifreq;
@@ -157,7 +183,28 @@ __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__
     const uint32_t wchunk = __builtin_amdgcn_readfirstlane(chunk);
     const uint32_t wc0 = start + wchunk * fc;
     const zh_rsrc_t rsrc = make_rsrc(out.p + (size_t)wc0 * out.stride, (uint32_t)((size_t)fc * out.stride * 4));
-    uint32_t boff = v * 4;
+    uint32_t boff = lane * 16 + (uint32_t)((size_t)vbase * 4);
+    // Common case, decided per wave: no silent voice among the wave's 256.  In ZERO_FIRST mode the
+    // stored value is then `0.0f + val`, which equals `val` bit for bit: every arm of sample() ends in
+    // `x + gain`, `x - gain` or `gain + x` with gain = 0.7, and an IEEE sum is -0.0 only if both addends
+    // are -0.0, so val is never -0.0 (the one input 0.0f + x changes); NaNs pass through unchanged.
+    if (!__any(bad[0] || bad[1] || bad[2] || bad[3])) {
+#pragma unroll 2
+        for (uint32_t i = c0; i < c1; i++, o += os, boff += (uint32_t)os * 4) {
+            zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (!ZF) acc = *reinterpret_cast<const zv4f *>(o);
+            float val[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                val[j] = OSC::sample(k[j], cnt[j]);
+                cnt[j] += k[j].ifreq;
+            }
+            if (ZF) { acc.x = val[0]; acc.y = val[1]; acc.z = val[2]; acc.w = val[3]; }
+            else { acc.x += val[0]; acc.y += val[1]; acc.z += val[2]; acc.w += val[3]; }
+            store4<SM>(o, rsrc, boff, acc);
+        }
+        return;
+    }
 #pragma unroll 2
     for (uint32_t i = c0; i < c1; i++, o += os, boff += (uint32_t)os * 4) {
         zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -210,7 +257,7 @@ struct TriSawK {          // TriSawOsc.zig:90-99
 //   b0 == b1, wrap     (7 / 4): -rcpf * (gain + (c1|c2 * omf) * (p + p + omf))
 //   b0 != b1           (2)    : rcpf * (c2*p^2 - c1*(p - f)^2)
 //                      (5)    : -rcpf * (gain + c2*(p + omf)^2 - c1*p^2)
-//   1 and 6 are `unreachable` in the reference: defined as +0 (then `gain + 0`).
+//   1 and 6 (`else => unreachable`) cannot occur for any u32 inputs (proof at pulse_sample).
 // Every arm is the reference's own expression, so the selected value has the reference's bits;
 // unselected arms may be inf/NaN (c1 = +inf when color == 0) and are discarded, never blended.
 struct TriSawOscP {
@@ -239,7 +286,7 @@ struct TriSawOscP {
         const float ramp5 = -k.rcpf * (gain + k.c2 * ((p + k.omf) * (p + k.omf)) - k.c1 * (p * p));
         const float flat = b2 ? flat_wrap : flat_nowrap;
         const float ramp = b2 ? ramp5 : ramp2;
-        const float v = (b0 == b1) ? flat : ((b0 == b2) ? ramp : 0.0f);
+        const float v = (b0 == b1) ? flat : ramp;
         return gain + v;
     }
 };
