@@ -21,7 +21,9 @@
  * ZH_ERR_* for bad arguments.  Work is enqueued on the context's stream and is
  * asynchronous unless stated; host arrays passed to get/set/upload/download calls are
  * synchronous.  One context per host thread; a module instance must not be painted
- * concurrently (same rule as the reference).  Nothing here allocates inside a paint.
+ * concurrently (same rule as the reference).  Nothing here allocates inside a paint (the voice
+ * mixdown grows a per-context scratch buffer the first time a larger size is needed).  Destroy
+ * modules and graphs before their context.
  */
 #ifndef ZANG_HIP_H
 #define ZANG_HIP_H

@@ -12,16 +12,6 @@
 #include "envelope.cuh"
 #include <vector>
 
-static inline bool aligned16m(const void *p) { return ((uintptr_t)p & 15u) == 0; }
-
-// A module's device state: a few SoA arrays of n elements each.
-struct StateArrays {
-    void *p[12];
-    int count;
-    StateArrays() : count(0) { for (auto &x : p) x = nullptr; }
-    void release() { for (int i = 0; i < count; i++) if (p[i]) (void)hipFree(p[i]); count = 0; }
-};
-
 template <typename T> static int upload_field(zh_ctx *ctx, T *dev, const std::vector<T> &h) {
     return zh_upload(ctx, dev, h.data(), h.size() * sizeof(T));
 }
