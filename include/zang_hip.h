@@ -364,6 +364,36 @@ typedef struct zh_span_table {
 ZH_API int zh_nice_paint_spans(zh_nice *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                                const zh_buf *temps, float sample_rate, const zh_span_table *table, uint32_t flags);
 
+/* ---------------------------------------------------------------- Delay(n) and its composites
+ * zang.Delay(delay_samples) (src/zang/delay.zig:7-91) is a per-voice ring buffer; on the device the rings of
+ * n voices form one image [delay_sample][voice] in HBM.  Two modules use it:
+ *   zh_delay           = SimpleDelay   (examples/modules.zig:341-386): out += ring; ring = input
+ *   zh_filtered_echoes = FilteredEchoes (examples/modules.zig:390-461): feedback*ring + input -> low-pass -> out, ring
+ * The reference moves data in chunks of <= delay_samples (read, then write); reading a slot always precedes
+ * writing it, so the per-sample form used by the kernels is equivalent.  StereoEchoes (:463-525) is the host-level
+ * composition addInto / zh_delay / zh_filtered_echoes / zh_delay. */
+typedef struct zh_delay zh_delay;
+typedef struct zh_delay_params { zh_buf input; } zh_delay_params;                                     /* :345-347 */
+ZH_API int zh_delay_create(zh_ctx *ctx, uint32_t n_voices, uint32_t delay_samples, zh_delay **out);   /* init(): ring zeros, index 0 */
+ZH_API int zh_delay_destroy(zh_delay *m);
+ZH_API int zh_delay_reset(zh_delay *m);                                                               /* delay.zig:19-22 */
+/* state: host float[n_voices][delay_samples] (one ring per voice) and uint32 index[n_voices] */
+ZH_API int zh_delay_get_state(zh_delay *m, float *rings_voice_major, uint32_t *index);
+ZH_API int zh_delay_set_state(zh_delay *m, const float *rings_voice_major, const uint32_t *index);
+ZH_API int zh_delay_paint(zh_delay *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                          const zh_buf *temps, zh_bool note_id_changed, const zh_delay_params *params, uint32_t flags);
+
+typedef struct zh_filtered_echoes zh_filtered_echoes;
+typedef struct zh_filtered_echoes_params { zh_buf input; zh_f32 feedback_volume; zh_f32 cutoff; } zh_filtered_echoes_params; /* :394-398 */
+ZH_API int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n_voices, uint32_t delay_samples, zh_filtered_echoes **out);
+ZH_API int zh_filtered_echoes_destroy(zh_filtered_echoes *m);
+ZH_API int zh_filtered_echoes_reset(zh_filtered_echoes *m);                                           /* :407-409: the delay only */
+ZH_API int zh_filtered_echoes_get_state(zh_filtered_echoes *m, float *rings_voice_major, uint32_t *index, zh_filter_state *filter);
+ZH_API int zh_filtered_echoes_set_state(zh_filtered_echoes *m, const float *rings_voice_major, const uint32_t *index, const zh_filter_state *filter);
+ZH_API int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                                    const zh_buf *temps /*[2], unused; may be NULL*/, zh_bool note_id_changed,
+                                    const zh_filtered_echoes_params *params, uint32_t flags);
+
 /* ---------------------------------------------------------------- Noise -> Filter voice (examples/example_stereo.zig:71-82)
  * zero(temp); Noise.paint(temp); Filter.paint(out, input = temp, type, cutoff, res) as ONE kernel: the
  * temp image stays in registers (BASELINE config 3, fused variant).  Bit-identical to the two separate

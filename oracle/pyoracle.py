@@ -87,6 +87,10 @@ class CurveModule(C.Structure):
                 ("next_song_note", C.c_size_t)]
 
 
+class Delay(C.Structure):
+    _fields_ = [("ring", C.POINTER(C.c_float)), ("delay_samples", C.c_size_t), ("index", C.c_size_t)]
+
+
 class Cycle(C.Structure):
     _fields_ = [("t", C.c_float)]
 
@@ -180,6 +184,9 @@ def lib():
         "zo_math_atanf_n": (None, [_F, _F, z]), "zo_math_pow2f_n": (None, [_F, _F, z]),
         "zo_curve_init": (None, [C.POINTER(CurveModule)]),
         "zo_curve_paint": (None, [C.POINTER(CurveModule), z, z, _F, i32, f, u32, C.POINTER(CurveNode), z]),
+        "zo_delay_init": (None, [C.POINTER(Delay), _F, z]),
+        "zo_simple_delay_paint": (None, [C.POINTER(Delay), z, z, _F, _F]),
+        "zo_filtered_echoes_paint": (None, [C.POINTER(Delay), C.POINTER(Filter), z, z, _F, _F, _F, _F, f, f]),
         "zo_cycle_init": (None, [C.POINTER(Cycle)]),
         "zo_cycle_paint": (None, [C.POINTER(Cycle), z, z, _F, f, Cob]),
         "zo_portamento_init": (None, [C.POINTER(Portamento)]),

@@ -834,3 +834,65 @@ void zo_curve_paint(zo_curve_module *self, size_t span_start, size_t span_end, f
         start = cs.end;
     }
 }
+
+/* ------------------------------------------------------------------ delay.zig + the delay composites
+ * zo_delay holds a caller-allocated ring of `delay_samples` floats (Delay(n), src/zang/delay.zig:7-18). */
+void zo_delay_init(zo_delay *d, float *ring, size_t delay_samples) {
+    d->ring = ring; d->delay_samples = delay_samples; d->index = 0;
+    for (size_t i = 0; i < delay_samples; i++) ring[i] = 0.0f;
+}
+
+/* delay.zig:28-57 */
+static size_t delay_read(zo_delay *d, float *out, size_t out_len) {
+    const size_t actual = out_len > d->delay_samples ? d->delay_samples : out_len;
+    const size_t index = d->index;
+    const size_t len = (d->delay_samples - index) < actual ? (d->delay_samples - index) : actual;
+    for (size_t i = 0; i < len; i++) out[i] += d->ring[index + i];
+    if (len < actual) {
+        const size_t b_len = actual - len;
+        for (size_t i = 0; i < b_len; i++) out[len + i] += d->ring[i];
+    }
+    return actual;
+}
+
+/* delay.zig:62-89 */
+static void delay_write(zo_delay *d, const float *input, size_t n) {
+    const size_t index = d->index;
+    const size_t len = (d->delay_samples - index) < n ? (d->delay_samples - index) : n;
+    memcpy(d->ring + index, input, len * sizeof(float));
+    if (len < n) {
+        const size_t b_len = n - len;
+        memcpy(d->ring, input + len, b_len * sizeof(float));
+        d->index = b_len;
+    } else {
+        d->index += len;
+        if (d->index == d->delay_samples) d->index = 0;
+    }
+}
+
+/* SimpleDelay.paint, examples/modules.zig:363-385 */
+void zo_simple_delay_paint(zo_delay *self, size_t start, size_t end, float *out0, const float *input) {
+    while (start < end) {
+        const size_t samples_read = delay_read(self, out0 + start, end - start);
+        delay_write(self, input + start, samples_read);
+        start += samples_read;
+    }
+}
+
+/* FilteredEchoes.paint, examples/modules.zig:411-460 */
+void zo_filtered_echoes_paint(zo_delay *delay, zo_filter *filter, size_t start, size_t end, float *output,
+                              float *temp0, float *temp1, const float *input, float feedback_volume, float cutoff) {
+    while (start < end) {
+        zo_zero(start, end, temp0);
+        const size_t samples_read = delay_read(delay, temp0 + start, end - start);
+        const size_t s1 = start, e1 = start + samples_read;
+        zo_multiply_with_scalar(s1, e1, temp0, feedback_volume);
+        zo_add_into(s1, e1, temp0, input);
+        zo_zero(s1, e1, temp1);
+        zo_cob c = { ZO_COB_CONSTANT, cutoff, NULL }, r = { ZO_COB_CONSTANT, 0.0f, NULL };
+        zo_filter_paint(filter, s1, e1, temp1, temp0, ZO_FILTER_LOW_PASS, c, r);
+        zo_add_into(s1, e1, output, temp1);
+        delay_write(delay, temp1 + s1, samples_read);
+        start += samples_read;
+    }
+}

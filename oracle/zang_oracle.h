@@ -48,6 +48,7 @@ typedef struct { float value, t; } zo_curve_node;          /* zang.CurveNode, sr
 typedef struct { float t; size_t current_song_note; int32_t current_song_note_offset; size_t next_song_note; } zo_curve_module; /* Curve.zig:36-41 */
 typedef struct { float t; } zo_cycle;                      /* Cycle.zig:14 */
 typedef struct { zo_painter painter; } zo_portamento;      /* Portamento.zig:13 */
+typedef struct { float *ring; size_t delay_samples; size_t index; } zo_delay;   /* Delay(n), src/zang/delay.zig:9-10 */
 typedef struct { float color; zo_pulseosc osc; zo_filter flt; zo_envelope env; } zo_nice_instrument;
 typedef struct { float release_duration; zo_sineosc carrier, modulator; zo_envelope env; } zo_pmosc_instrument;
 
@@ -98,6 +99,10 @@ void zo_cycle_paint(zo_cycle *self, size_t start, size_t end, float *out, float 
 void zo_portamento_init(zo_portamento *p);
 void zo_portamento_paint(zo_portamento *self, size_t start, size_t end, float *out0, int note_id_changed,
                          float sample_rate, zo_curve curve, float goal, int note_on, int prev_note_on);
+void zo_delay_init(zo_delay *d, float *ring, size_t delay_samples);
+void zo_simple_delay_paint(zo_delay *self, size_t start, size_t end, float *out0, const float *input);
+void zo_filtered_echoes_paint(zo_delay *delay, zo_filter *filter, size_t start, size_t end, float *output,
+                              float *temp0, float *temp1, const float *input, float feedback_volume, float cutoff);
 double zo_bench_pulseosc(uint32_t voices, uint32_t frames, uint32_t buffers, float sample_rate,
                          const float *freq, const float *color, zo_pulseosc *states, float *scratch);
 double zo_bench_noise_filter(uint32_t voices, uint32_t frames, uint32_t buffers, const float *cutoff, const float *res,

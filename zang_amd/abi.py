@@ -120,6 +120,14 @@ class DistortionParams(C.Structure):
     _fields_ = [("input", Buf), ("type", u32), ("reserved", u32), ("ingain", F32), ("outgain", F32), ("offset", F32)]
 
 
+class DelayParams(C.Structure):
+    _fields_ = [("input", Buf)]
+
+
+class FilteredEchoesParams(C.Structure):
+    _fields_ = [("input", Buf), ("feedback_volume", F32), ("cutoff", F32)]
+
+
 class NoiseFilterParams(C.Structure):
     _fields_ = [("color", u32), ("type", u32), ("cutoff", F32), ("res", F32)]
 
@@ -344,6 +352,18 @@ SIGNATURES = {
     "zh_nice_set_state": (C.c_int, [vp, vp]),
     "zh_nice_paint": (C.c_int, _paint(NiceParams)),
     "zh_nice_paint_mix": (C.c_int, [vp, u32, u32, vp, Bool, P(NiceParams), u32]),
+    "zh_delay_create": (C.c_int, [vp, u32, u32, P(vp)]),
+    "zh_delay_destroy": (C.c_int, [vp]),
+    "zh_delay_reset": (C.c_int, [vp]),
+    "zh_delay_get_state": (C.c_int, [vp, vp, vp]),
+    "zh_delay_set_state": (C.c_int, [vp, vp, vp]),
+    "zh_delay_paint": (C.c_int, _paint(DelayParams)),
+    "zh_filtered_echoes_create": (C.c_int, [vp, u32, u32, P(vp)]),
+    "zh_filtered_echoes_destroy": (C.c_int, [vp]),
+    "zh_filtered_echoes_reset": (C.c_int, [vp]),
+    "zh_filtered_echoes_get_state": (C.c_int, [vp, vp, vp, vp]),
+    "zh_filtered_echoes_set_state": (C.c_int, [vp, vp, vp, vp]),
+    "zh_filtered_echoes_paint": (C.c_int, _paint(FilteredEchoesParams)),
     "zh_noise_filter_create": (C.c_int, [vp, u32, u64, P(vp)]),
     "zh_noise_filter_destroy": (C.c_int, [vp]),
     "zh_noise_filter_get_state": (C.c_int, [vp, vp]),

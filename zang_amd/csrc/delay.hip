@@ -1,0 +1,200 @@
+// delay.hip -- zang.Delay(n) (src/zang/delay.zig) on the device, and the two modules built on it:
+// SimpleDelay and FilteredEchoes (examples/modules.zig:341-461).
+//
+// The rings of n voices are one HBM image [delay_sample][voice] (voice fastest), so the 64 lanes of
+// a wave read/write 256 contiguous bytes per frame like every other image.  The reference moves
+// data in chunks of <= delay_samples: read the ring (delay.zig:28-57), do the work, write the ring
+// (:62-89); a slot is always read before it is rewritten, so walking the span sample by sample
+// (read slot, compute, write slot, advance index modulo delay_samples) gives the same values.
+#include "common.cuh"
+#include "zmath.cuh"
+#include <vector>
+
+struct DelayState {
+    float *ring;          // [delay_samples][n]
+    uint32_t *index;      // [n]  (delay_buffer_index; equal for all voices unless set_state says otherwise)
+    uint32_t n, delay_samples;
+};
+
+struct zh_delay { zh_ctx *ctx; DelayState d; };
+struct zh_filtered_echoes { zh_ctx *ctx; DelayState d; float *l, *b; };
+
+// SimpleDelay.paint, examples/modules.zig:363-385
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_simple_delay(DelayState d, Img out, CImg input, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= d.n) return;
+    uint32_t idx = d.index[v];
+    float *ring = d.ring + v;
+    float *o = out.at(start, v);
+    const float *in = input.at(start, v);
+    for (uint32_t i = start; i < end; i++, o += out.stride, in += input.stride) {
+        float *slot = ring + (size_t)idx * d.n;
+        const float delayed = *slot;                                  // readDelayBuffer: out += ring
+        *o = (ZF ? 0.0f : *o) + delayed;
+        *slot = *in;                                                  // writeDelayBuffer: ring = input
+        idx = idx + 1 == d.delay_samples ? 0 : idx + 1;               // delay.zig:84-87
+    }
+    d.index[v] = idx;
+}
+
+// FilteredEchoes.paint, examples/modules.zig:411-460
+template <bool ZF>
+__global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, float *__restrict__ l_io, float *__restrict__ b_io,
+                                                               Img out, CImg input, uint32_t start, uint32_t end,
+                                                               F32P feedback_p, F32P cutoff_p) {
+    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    if (v >= d.n) return;
+    const float fcdcoffset = 3.814697265625e-6f;                      // Filter.zig:8
+    const float feedback = feedback_p.get(v);
+    const float cut = zclampf(cutoff_p.get(v), 0.0f, 1.0f);           // Filter.zig:114
+    const float res = 1.0f - zclampf(0.0f, 0.0f, 1.0f);               // res = constant(0.0) (:441) -> Filter.zig:118
+    uint32_t idx = d.index[v];
+    float l = l_io[v], b = b_io[v];
+    float *ring = d.ring + v;
+    float *o = out.at(start, v);
+    const float *in = input.at(start, v);
+    for (uint32_t i = start; i < end; i++, o += out.stride, in += input.stride) {
+        float *slot = ring + (size_t)idx * d.n;
+        float t0 = 0.0f + *slot;                                      // zero(temp0); readDelayBuffer (:425-428)
+        t0 = t0 * feedback;                                           // multiplyWithScalar (:433)
+        t0 = t0 + *in;                                                // addInto (:436)
+        const float x = t0 + fcdcoffset;                              // Filter.paint low_pass (Filter.zig:135-146)
+        l += cut * b - fcdcoffset;
+        b += cut * (x - b * res - l);
+        l += cut * b;
+        const float h = x - b * res - l;
+        b += cut * h;
+        const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);     // zero(temp1); += (:439)
+        *o = (ZF ? 0.0f : *o) + t1;                                   // addInto(output, temp1) (:448)
+        *slot = t1;                                                   // writeDelayBuffer(temp1) (:452)
+        idx = idx + 1 == d.delay_samples ? 0 : idx + 1;
+    }
+    d.index[v] = idx;
+    l_io[v] = l; b_io[v] = b;
+}
+
+static int delay_alloc(zh_ctx *ctx, DelayState &d, uint32_t n, uint32_t delay_samples) {
+    d.ring = nullptr; d.index = nullptr; d.n = n; d.delay_samples = delay_samples;
+    int rc = dev_alloc(&d.ring, (size_t)delay_samples * n);
+    if (!rc) rc = dev_alloc(&d.index, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(d.ring, 0, (size_t)delay_samples * n * 4, ctx->stream);   // delay.zig:12-17
+    if (!rc && n) rc = (int)hipMemsetAsync(d.index, 0, (size_t)n * 4, ctx->stream);
+    return rc;
+}
+static void delay_free(DelayState &d) { (void)hipFree(d.ring); (void)hipFree(d.index); }
+
+static int delay_reset(zh_ctx *ctx, DelayState &d) {                  // delay.zig:19-22
+    if (!d.n) return ZH_OK;
+    ZH_TRY(hipMemsetAsync(d.ring, 0, (size_t)d.delay_samples * d.n * 4, ctx->stream));
+    ZH_TRY(hipMemsetAsync(d.index, 0, (size_t)d.n * 4, ctx->stream));
+    return ZH_OK;
+}
+
+static int delay_get(zh_ctx *ctx, const DelayState &d, float *rings, uint32_t *index) {
+    if (!rings || !index) return ZH_ERR_INVALID;
+    std::vector<float> img((size_t)d.delay_samples * d.n);
+    int rc = zh_download(ctx, img.data(), d.ring, img.size() * 4);
+    if (!rc) rc = zh_download(ctx, index, d.index, (size_t)d.n * 4);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < d.n; v++)
+        for (uint32_t k = 0; k < d.delay_samples; k++) rings[(size_t)v * d.delay_samples + k] = img[(size_t)k * d.n + v];
+    return ZH_OK;
+}
+static int delay_set(zh_ctx *ctx, const DelayState &d, const float *rings, const uint32_t *index) {
+    if (!rings || !index) return ZH_ERR_INVALID;
+    for (uint32_t v = 0; v < d.n; v++) if (index[v] >= d.delay_samples) return ZH_ERR_INVALID;   // "always < delay_samples" (:10)
+    std::vector<float> img((size_t)d.delay_samples * d.n);
+    for (uint32_t v = 0; v < d.n; v++)
+        for (uint32_t k = 0; k < d.delay_samples; k++) img[(size_t)k * d.n + v] = rings[(size_t)v * d.delay_samples + k];
+    int rc = zh_upload(ctx, d.ring, img.data(), img.size() * 4);
+    if (!rc) rc = zh_upload(ctx, d.index, index, (size_t)d.n * 4);
+    return rc;
+}
+
+extern "C" {
+
+int zh_delay_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_delay **out) {
+    if (!ctx || !out || delay_samples == 0) return ZH_ERR_INVALID;    // Delay(0) never makes progress in the reference
+    zh_delay *m = new (std::nothrow) zh_delay();
+    if (!m) return ZH_ERR_INVALID;
+    m->ctx = ctx;
+    int rc = delay_alloc(ctx, m->d, n, delay_samples);
+    if (rc) { delay_free(m->d); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_delay_destroy(zh_delay *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    delay_free(m->d);
+    delete m;
+    return ZH_OK;
+}
+int zh_delay_reset(zh_delay *m) { return m ? delay_reset(m->ctx, m->d) : ZH_ERR_INVALID; }
+int zh_delay_get_state(zh_delay *m, float *rings, uint32_t *index) { return m ? delay_get(m->ctx, m->d, rings, index) : ZH_ERR_INVALID; }
+int zh_delay_set_state(zh_delay *m, const float *rings, const uint32_t *index) { return m ? delay_set(m->ctx, m->d, rings, index) : ZH_ERR_INVALID; }
+int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                   zh_bool note_id_changed, const zh_delay_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;                                            // examples/modules.zig:370-371
+    if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
+    if (m->d.n == 0 || end == start) return ZH_OK;
+    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_simple_delay<true>, seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end);
+    else hipLaunchKernelGGL(k_simple_delay<false>, seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end);
+    return zh_launch_status();
+}
+
+int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_filtered_echoes **out) {
+    if (!ctx || !out || delay_samples == 0) return ZH_ERR_INVALID;
+    zh_filtered_echoes *m = new (std::nothrow) zh_filtered_echoes();
+    if (!m) return ZH_ERR_INVALID;
+    m->ctx = ctx; m->l = m->b = nullptr;
+    int rc = delay_alloc(ctx, m->d, n, delay_samples);
+    if (!rc) rc = dev_alloc(&m->l, n);
+    if (!rc) rc = dev_alloc(&m->b, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->l, 0, (size_t)n * 4, ctx->stream);   // Filter.init()
+    if (!rc && n) rc = (int)hipMemsetAsync(m->b, 0, (size_t)n * 4, ctx->stream);
+    if (rc) { delay_free(m->d); (void)hipFree(m->l); (void)hipFree(m->b); delete m; return rc; }
+    *out = m;
+    return ZH_OK;
+}
+int zh_filtered_echoes_destroy(zh_filtered_echoes *m) {
+    if (!m) return ZH_ERR_INVALID;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    delay_free(m->d); (void)hipFree(m->l); (void)hipFree(m->b);
+    delete m;
+    return ZH_OK;
+}
+int zh_filtered_echoes_reset(zh_filtered_echoes *m) { return m ? delay_reset(m->ctx, m->d) : ZH_ERR_INVALID; }   // :407-409
+int zh_filtered_echoes_get_state(zh_filtered_echoes *m, float *rings, uint32_t *index, zh_filter_state *filter) {
+    if (!m || !filter) return ZH_ERR_INVALID;
+    int rc = delay_get(m->ctx, m->d, rings, index);
+    if (rc) return rc;
+    std::vector<float> l(m->d.n), b(m->d.n);
+    rc = zh_download(m->ctx, l.data(), m->l, (size_t)m->d.n * 4);
+    if (!rc) rc = zh_download(m->ctx, b.data(), m->b, (size_t)m->d.n * 4);
+    if (rc) return rc;
+    for (uint32_t v = 0; v < m->d.n; v++) filter[v] = zh_filter_state{l[v], b[v]};
+    return ZH_OK;
+}
+int zh_filtered_echoes_set_state(zh_filtered_echoes *m, const float *rings, const uint32_t *index, const zh_filter_state *filter) {
+    if (!m || !filter) return ZH_ERR_INVALID;
+    int rc = delay_set(m->ctx, m->d, rings, index);
+    if (rc) return rc;
+    std::vector<float> l(m->d.n), b(m->d.n);
+    for (uint32_t v = 0; v < m->d.n; v++) { l[v] = filter[v].l; b[v] = filter[v].b; }
+    rc = zh_upload(m->ctx, m->l, l.data(), (size_t)m->d.n * 4);
+    if (!rc) rc = zh_upload(m->ctx, m->b, b.data(), (size_t)m->d.n * 4);
+    return rc;
+}
+int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                             zh_bool note_id_changed, const zh_filtered_echoes_params *p, uint32_t flags) {
+    (void)temps; (void)note_id_changed;
+    if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
+    if (m->d.n == 0 || end == start) return ZH_OK;
+    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_filtered_echoes<true>, seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
+    else hipLaunchKernelGGL(k_filtered_echoes<false>, seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
+    return zh_launch_status();
+}
+
+}  // extern "C"

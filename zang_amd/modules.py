@@ -366,6 +366,69 @@ class NiceInstrument(_Module):
         abi.check(rc, "zh_nice_paint_mix")
 
 
+class SimpleDelay(_Module):
+    """examples/modules.zig:341-386 over zang.Delay(delay_samples) (src/zang/delay.zig)."""
+    _prefix = "delay"
+
+    @dataclass
+    class Params:
+        input: Any
+
+    def __init__(self, n_voices, delay_samples, ctx=None):
+        self.delay_samples = int(delay_samples)
+        super().__init__(n_voices, ctx, C.c_uint32(self.delay_samples))
+
+    @classmethod
+    def init(cls, n_voices, delay_samples, ctx=None):
+        return cls(n_voices, delay_samples, ctx)
+
+    def reset(self):
+        abi.check(self.lib.zh_delay_reset(self.handle), "zh_delay_reset")
+
+    def state(self):
+        rings = np.zeros((self.n_voices, self.delay_samples), np.float32)
+        index = np.zeros(self.n_voices, np.uint32)
+        abi.check(self.lib.zh_delay_get_state(self.handle, rings.ctypes.data, index.ctypes.data), "get_state")
+        return rings, index
+
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+        self._paint(span, outputs, temps, note_id_changed, abi.DelayParams(as_buf(params.input)), zero_first)
+
+
+class FilteredEchoes(_Module):
+    """examples/modules.zig:390-461."""
+    _prefix = "filtered_echoes"
+    num_temps = 2
+
+    @dataclass
+    class Params:
+        input: Any
+        feedback_volume: Any
+        cutoff: Any
+
+    def __init__(self, n_voices, delay_samples, ctx=None):
+        self.delay_samples = int(delay_samples)
+        super().__init__(n_voices, ctx, C.c_uint32(self.delay_samples))
+
+    @classmethod
+    def init(cls, n_voices, delay_samples, ctx=None):
+        return cls(n_voices, delay_samples, ctx)
+
+    def reset(self):
+        abi.check(self.lib.zh_filtered_echoes_reset(self.handle), "reset")
+
+    def state(self):
+        rings = np.zeros((self.n_voices, self.delay_samples), np.float32)
+        index = np.zeros(self.n_voices, np.uint32)
+        flt = np.zeros(self.n_voices, dtype=np.dtype(abi.FilterState))
+        abi.check(self.lib.zh_filtered_echoes_get_state(self.handle, rings.ctypes.data, index.ctypes.data, flt.ctypes.data), "get_state")
+        return rings, index, flt
+
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+        cp = abi.FilteredEchoesParams(as_buf(params.input), as_f32(params.feedback_volume), as_f32(params.cutoff))
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+
+
 class NoiseFilter(_Module):
     """Noise -> Filter as one fused kernel (examples/example_stereo.zig:71-82; BASELINE config 3)."""
     _prefix = "noise_filter"
