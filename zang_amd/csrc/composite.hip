@@ -8,6 +8,7 @@
 // touch HBM: per voice-sample the kernel writes 4 B (or nothing, in the mix variant).
 #include "common.cuh"
 #include "zmath.cuh"
+#include "dsp.cuh"
 #include "seq.cuh"
 #include "envelope.cuh"
 #include <vector>
@@ -39,8 +40,8 @@ struct zh_pmosc {
 // ------------------------------------------------------------------ NiceInstrument voice
 struct NiceLane {
     // PulseOsc
-    uint32_t cnt, ifreq, brpt;
-    float gdf2, col, cc121, cc212;
+    uint32_t cnt;
+    PulseK k;
     bool bad;
     // Filter
     float l, b, cut, res;
@@ -48,13 +49,8 @@ struct NiceLane {
 
     __device__ __forceinline__ void begin(float sample_rate, float srf, float sr8, float freq, float color, bool note_on, bool new_note) {
         bad = freq < 0 || freq > sr8;                                  // PulseOsc.zig:82-84
-        const float gain = 0.7f;
-        ifreq = zf32_to_u32(srf * freq);
-        brpt = zftou32(zclamp01(color));
-        gdf2 = (gain / zutof23(ifreq)) * 2.0f;
-        col = zutof23(brpt);
-        cc121 = gdf2 * (col - 1.0f) + gain;
-        cc212 = gdf2 * col - gain;
+        pulse_setup_color(k, color);
+        pulse_setup_freq(k, srf, freq);
         // Filter params: cutoff = cutoffFromFrequency(freq * 8, sr), res = 0.7 (examples/modules.zig:231-235)
         cut = zclampf(zcutoff_from_frequency(freq * 8.0f, sample_rate), 0.0f, 1.0f);
         res = 1.0f - zclampf(0.7f, 0.0f, 1.0f);
@@ -70,26 +66,16 @@ struct NiceLane {
 
     // one frame of examples/modules.zig:220-246; returns env*flt (the value added to out)
     __device__ __forceinline__ float frame() {
-        const float gain = 0.7f, fcdcoffset = 3.814697265625e-6f;
         // temps[0] = 0 (+ pulse) ; temps[0] *= 0.5
         float t0 = 0.0f;
         if (!bad) {
-            const float p = zutof23(cnt);
-            const bool b0 = cnt < brpt, b1 = (uint32_t)(cnt - ifreq) < brpt, b2 = cnt < ifreq;
-            const float ramp = gdf2 * (b2 ? p : col - p) + (b2 ? -gain : gain);
-            const float flat = b2 ? (b0 ? cc121 : cc212) : (b0 ? gain : -gain);
-            t0 = 0.0f + ((b0 == b1) ? flat : ramp);       // transitions 1, 6 cannot occur (osc.hip, pulse_sample)
-            cnt += ifreq;
+            t0 = 0.0f + pulse_sample(k, cnt);
+            cnt += k.ifreq;
         }
         t0 = t0 * 0.5f;                                                // multiplyWithScalar :226
         // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
-        const float in = t0 + fcdcoffset;
-        l += cut * b - fcdcoffset;
-        b += cut * (in - b * res - l);
-        l += cut * b;
-        const float h = in - b * res - l;
-        b += cut * h;
-        const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);
+        const SvfOut s = svf_step(l, b, t0, cut, res);
+        const float t1 = 0.0f + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
         // temps[0] = 0 (+ envelope)
         float ev = 0.0f, e0 = 0.0f;
         if (env.frame(ev)) e0 = 0.0f + ev;
@@ -313,7 +299,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice_spans(NiceArgs a, SpanTableP
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
     n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
-    n.bad = true; n.ifreq = 0; n.brpt = 0; n.gdf2 = n.col = n.cc121 = n.cc212 = n.cut = n.res = 0.0f;
+    n.bad = true; n.k = PulseK{0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; n.cut = n.res = 0.0f;
     const float color = a.color[v];
     span_walk<ZF>(n, tb, a.V, v, out, start, end,
                   [&](float freq, bool on, bool nic) ZH_INLINE_LAMBDA { n.begin(a.sample_rate, a.srf, a.sr8, freq, color, on, nic); },
@@ -356,7 +342,6 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter(uint64_t *__restrict
                                                             F32P res_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    const float fcdcoffset = 3.814697265625e-6f;                       // Filter.zig:8
     ZXoshiro r{s0[v], s1[v], s2[v], s3[v]};
     float pb[7] = {0, 0, 0, 0, 0, 0, 0};
     if (PINK) {
@@ -370,24 +355,10 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter(uint64_t *__restrict
     frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         const float white = zrandom_float32(r) * 2.0f - 1.0f;          // Noise.zig:51 / :58
         float nz = white;
-        if (PINK) {                                                    // :59-66
-            pb[0] = 0.99886f * pb[0] + white * 0.0555179f;
-            pb[1] = 0.99332f * pb[1] + white * 0.0750759f;
-            pb[2] = 0.96900f * pb[2] + white * 0.1538520f;
-            pb[3] = 0.86650f * pb[3] + white * 0.3104856f;
-            pb[4] = 0.55000f * pb[4] + white * 0.5329522f;
-            pb[5] = -0.7616f * pb[5] - white * 0.0168980f;
-            nz = pb[0] + pb[1] + pb[2] + pb[3] + pb[4] + pb[5] + pb[6] + white * 0.5362f;
-            pb[6] = white * 0.115926f;
-        }
+        if (PINK) nz = pink_step(pb, white);                           // :59-66
         const float temp = 0.0f + nz;                                  // zero(temp); temp += noise
-        const float in = temp + fcdcoffset;                            // Filter.zig:135-146
-        l += cut * b - fcdcoffset;
-        b += cut * (in - b * res - l);
-        l += cut * b;
-        const float h = in - b * res - l;
-        b += cut * h;
-        val = l * l_mul + b * b_mul + h * h_mul;
+        const SvfOut s = svf_step(l, b, temp, cut, res);               // Filter.zig:135-144
+        val = s.l * l_mul + s.b * b_mul + s.h * h_mul;                 // :146
         return true;
     });
     s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;
@@ -412,16 +383,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter_bypass(uint64_t *__r
     frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         const float white = zrandom_float32(r) * 2.0f - 1.0f;
         float nz = white;
-        if (PINK) {
-            pb[0] = 0.99886f * pb[0] + white * 0.0555179f;
-            pb[1] = 0.99332f * pb[1] + white * 0.0750759f;
-            pb[2] = 0.96900f * pb[2] + white * 0.1538520f;
-            pb[3] = 0.86650f * pb[3] + white * 0.3104856f;
-            pb[4] = 0.55000f * pb[4] + white * 0.5329522f;
-            pb[5] = -0.7616f * pb[5] - white * 0.0168980f;
-            nz = pb[0] + pb[1] + pb[2] + pb[3] + pb[4] + pb[5] + pb[6] + white * 0.5362f;
-            pb[6] = white * 0.115926f;
-        }
+        if (PINK) nz = pink_step(pb, white);
         val = 0.0f + nz;
         return true;
     });

@@ -8,6 +8,7 @@
 // (read slot, compute, write slot, advance index modulo delay_samples) gives the same values.
 #include "common.cuh"
 #include "zmath.cuh"
+#include "dsp.cuh"
 #include <vector>
 
 struct DelayState {
@@ -45,7 +46,6 @@ __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, flo
                                                                F32P feedback_p, F32P cutoff_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= d.n) return;
-    const float fcdcoffset = 3.814697265625e-6f;                      // Filter.zig:8
     const float feedback = feedback_p.get(v);
     const float cut = zclampf(cutoff_p.get(v), 0.0f, 1.0f);           // Filter.zig:114
     const float res = 1.0f - zclampf(0.0f, 0.0f, 1.0f);               // res = constant(0.0) (:441) -> Filter.zig:118
@@ -59,13 +59,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, flo
         float t0 = 0.0f + *slot;                                      // zero(temp0); readDelayBuffer (:425-428)
         t0 = t0 * feedback;                                           // multiplyWithScalar (:433)
         t0 = t0 + *in;                                                // addInto (:436)
-        const float x = t0 + fcdcoffset;                              // Filter.paint low_pass (Filter.zig:135-146)
-        l += cut * b - fcdcoffset;
-        b += cut * (x - b * res - l);
-        l += cut * b;
-        const float h = x - b * res - l;
-        b += cut * h;
-        const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);     // zero(temp1); += (:439)
+        const SvfOut s = svf_step(l, b, t0, cut, res);                // Filter.paint low_pass (Filter.zig:135-146)
+        const float t1 = 0.0f + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);   // zero(temp1); += (:439)
         *o = (ZF ? 0.0f : *o) + t1;                                   // addInto(output, temp1) (:448)
         *slot = t1;                                                   // writeDelayBuffer(temp1) (:452)
         idx = idx + 1 == d.delay_samples ? 0 : idx + 1;

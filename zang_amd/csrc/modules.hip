@@ -8,6 +8,7 @@
 // (Gate, Distortion) are additionally split into frame chunks across waves.
 #include "common.cuh"
 #include "zmath.cuh"
+#include "dsp.cuh"
 #include "seq.cuh"
 #include "envelope.cuh"
 #include <vector>
@@ -78,15 +79,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, 
     const float *const *no_in = nullptr;
     frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         const float white = zrandom_float32(r) * 2.0f - 1.0f;         // :51 / :58
-        if (!PINK) { val = white; return true; }
-        b[0] = 0.99886f * b[0] + white * 0.0555179f;                  // :59-64
-        b[1] = 0.99332f * b[1] + white * 0.0750759f;
-        b[2] = 0.96900f * b[2] + white * 0.1538520f;
-        b[3] = 0.86650f * b[3] + white * 0.3104856f;
-        b[4] = 0.55000f * b[4] + white * 0.5329522f;
-        b[5] = -0.7616f * b[5] - white * 0.0168980f;
-        val = b[0] + b[1] + b[2] + b[3] + b[4] + b[5] + b[6] + white * 0.5362f;   // :65
-        b[6] = white * 0.115926f;                                     // :66
+        val = PINK ? pink_step(b, white) : white;                     // :59-66
         return true;
     });
     // Noise.zig:68 is `b = self.b;` -- the taps are never written back (reference quirk, kept)
@@ -140,7 +133,6 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
                                                       float h_mul, CobP cutoff, CobP res_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    const float fcdcoffset = 3.814697265625e-6f;                      // Filter.zig:8
     constexpr int NIN = 1 + (CB ? 1 : 0) + (RB ? 1 : 0);
     const float *ins[3] = {input.p + v, nullptr, nullptr};
     size_t istr[3] = {input.stride, 0, 0};
@@ -152,13 +144,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
     frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) ZH_INLINE_LAMBDA {
         if (CB) cut = zclampf(x[1], 0.0f, 1.0f);                      // :126
         if (RB) res = 1.0f - zclampf(x[CB ? 2 : 1], 0.0f, 1.0f);      // :128
-        const float in = x[0] + fcdcoffset;                           // :135
-        l += cut * b - fcdcoffset;                                    // :138
-        b += cut * (in - b * res - l);                                // :139
-        l += cut * b;                                                 // :142
-        const float h = in - b * res - l;                             // :143
-        b += cut * h;                                                 // :144
-        val = l * l_mul + b * b_mul + h * h_mul;                      // :146
+        const SvfOut s = svf_step(l, b, x[0], cut, res);              // :135-144
+        val = s.l * l_mul + s.b * b_mul + s.h * h_mul;                // :146
         return true;
     });
     l_io[v] = l; b_io[v] = b;

@@ -13,6 +13,7 @@
 // lane-per-voice loop (seq.cuh).
 #include "common.cuh"
 #include "zmath.cuh"
+#include "dsp.cuh"
 #include "seq.cuh"
 #include <stdlib.h>
 #include <vector>
@@ -33,45 +34,6 @@ struct zh_trisawosc {
 };
 
 // ------------------------------------------------------------------ PulseOsc
-struct PulseK {           // per-voice constants of PulseOsc.zig:88-95
-    uint32_t ifreq, brpt;
-    float gdf2 /* gdf * 2.0 */, col, cc121, cc212;
-};
-
-// `srf` = fc32bit / sample_rate (PulseOsc.zig:87) is wave-uniform: the host computes it once
-// (IEEE f32 divide, same bits as the device's correctly rounded divide).
-__device__ __forceinline__ void pulse_setup_freq(PulseK &k, float srf, float freq) {
-    const float gain = 0.7f;
-    k.ifreq = zf32_to_u32(srf * freq);
-    k.gdf2 = (gain / zutof23(k.ifreq)) * 2.0f;
-    k.cc121 = k.gdf2 * (k.col - 1.0f) + gain;
-    k.cc212 = k.gdf2 * k.col - gain;
-}
-__device__ __forceinline__ void pulse_setup_color(PulseK &k, float color) {
-    k.brpt = zftou32(zclamp01(color));
-    k.col = zutof23(k.brpt);
-}
-
-// The 6-way switch of PulseOsc.zig:102-110.  transition = b0 | b1<<1 | b2<<2 with
-// b0 = cnt < brpt, b1 = (cnt - ifreq) < brpt, b2 = cnt < ifreq:
-//   b0 == b1: flat -> 3: gain, 0: -gain, 7: cc121, 4: cc212
-//   b0 != b1: ramp -> 2: gdf*2*(col-p) + gain, 5: gdf*2*p - gain (x - gain == x + (-gain) exactly).
-// Transitions 1 and 6 (`else => unreachable`, :109) cannot occur for ANY u32 cnt, ifreq, brpt:
-//   1 = (b0, !b1, !b2): !b2 means cnt >= ifreq, so cnt - ifreq does not wrap and is <= cnt < brpt => b1.
-//   6 = (!b0, b1, b2):  b2 means cnt < ifreq, so cnt - ifreq = cnt + 2^32 - ifreq >= cnt >= brpt => !b1.
-// Hence b0 != b1 implies the ramp case and no third arm is needed.
-// Values are selected, never blended (gdf is inf when ifreq < 512).
-__device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
-    const float gain = 0.7f;
-    const float p = zutof23(cnt);
-    const bool b0 = cnt < k.brpt;
-    const bool b1 = (uint32_t)(cnt - k.ifreq) < k.brpt;
-    const bool b2 = cnt < k.ifreq;
-    const float ramp = k.gdf2 * (b2 ? p : k.col - p) + (b2 ? -gain : gain);
-    const float flat = b2 ? (b0 ? k.cc121 : k.cc212) : (b0 ? gain : -gain);
-    return (b0 == b1) ? flat : ramp;
-}
-
 struct PulseOscP {        // policy for the chunked kernels
     using K = PulseK;
     static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) {
