@@ -67,18 +67,16 @@ struct NiceLane {
     // one frame of examples/modules.zig:220-246; returns env*flt (the value added to out)
     __device__ __forceinline__ float frame() {
         // temps[0] = 0 (+ pulse) ; temps[0] *= 0.5
-        float t0 = 0.0f;
-        if (!bad) {
-            t0 = 0.0f + pulse_sample(k, cnt);
-            cnt += k.ifreq;
-        }
-        t0 = t0 * 0.5f;                                                // multiplyWithScalar :226
+        const float pv = 0.0f + pulse_sample(k, cnt);                  // a silent voice (bad freq) leaves temps[0] = 0
+        const float t0 = (bad ? 0.0f : pv) * 0.5f;                     // multiplyWithScalar :226
+        cnt = bad ? cnt : cnt + k.ifreq;
         // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
         const SvfOut s = svf_step(l, b, t0, cut, res);
         const float t1 = 0.0f + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
         // temps[0] = 0 (+ envelope)
-        float ev = 0.0f, e0 = 0.0f;
-        if (env.frame(ev)) e0 = 0.0f + ev;
+        float ev = 0.0f;
+        const bool painted = env.frame(ev);
+        const float e0 = painted ? 0.0f + ev : 0.0f;
         return e0 * t1;                                                // multiply :246: out += temps[0]*temps[1]
     }
 };

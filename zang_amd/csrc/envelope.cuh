@@ -83,32 +83,32 @@ struct EnvLane {
         resolve();
     }
 
-    // One frame.  Returns whether a value was painted.
+    // One frame.  Returns whether a value was painted.  Straight-line: the paintToward step
+    // (painter.zig:102-116) is computed unconditionally and committed by selects -- per-lane mode
+    // branches cost more (exec-mask bookkeeping) than the ~10 VALU ops they would skip; only the
+    // rare stage end branches.
     __device__ __forceinline__ bool frame(float &val) {
-        if (mode == ENV_MODE_TOWARD) {                            // painter.zig:102-116
-            t += cur_step;
-            const bool finished = t >= 1.0f;
-            if (finished) t = 1.0f;
-            const float it = 1.0f - t;
-            float tp = t;
-            if (cur_tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
-            else if (cur_tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
-            last_value = start + tp * (cur_goal - start);         // :114
-            val = last_value;
-            if (finished) {                                       // Envelope.zig:53-58, 63-65, 86-88
-                const uint32_t after_attack = sustain_volume < 1.0f ? (uint32_t)ZH_ENV_DECAY : (uint32_t)ZH_ENV_SUSTAIN;
-                const uint32_t next = state == ZH_ENV_ATTACK ? after_attack
-                                      : (state == ZH_ENV_DECAY ? (uint32_t)ZH_ENV_SUSTAIN : (uint32_t)ZH_ENV_IDLE);
-                change_state(next);
-                resolve();
-            }
-            return true;
+        const bool toward = mode == ENV_MODE_TOWARD;
+        float tn = t + cur_step;
+        const bool finished = tn >= 1.0f;
+        tn = finished ? 1.0f : tn;
+        const float it = 1.0f - tn;
+        float tp = tn;
+        if (cur_tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
+        else if (cur_tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
+        const float lv = start + tp * (cur_goal - start);         // :114
+        t = toward ? tn : t;
+        last_value = toward ? lv : last_value;
+        val = toward ? lv : sustain_volume;                        // FLAT: Envelope.zig:68-70
+        const bool painted = mode != ENV_MODE_NONE;
+        if (toward && finished) {                                  // Envelope.zig:53-58, 63-65, 86-88
+            const uint32_t after_attack = sustain_volume < 1.0f ? (uint32_t)ZH_ENV_DECAY : (uint32_t)ZH_ENV_SUSTAIN;
+            const uint32_t next = state == ZH_ENV_ATTACK ? after_attack
+                                  : (state == ZH_ENV_DECAY ? (uint32_t)ZH_ENV_SUSTAIN : (uint32_t)ZH_ENV_IDLE);
+            change_state(next);
+            resolve();
         }
-        if (mode == ENV_MODE_FLAT) {                              // Envelope.zig:68-70
-            val = sustain_volume;
-            return true;
-        }
-        return false;
+        return painted;
     }
 };
 
