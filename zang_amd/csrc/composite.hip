@@ -13,6 +13,7 @@
 #include "envelope.cuh"
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 // basics.hip
 int zh_mix_reserve(zh_ctx *ctx, size_t floats);
@@ -38,48 +39,56 @@ struct zh_pmosc {
 };
 
 // ------------------------------------------------------------------ NiceInstrument voice
-struct NiceLane {
+// W voices per lane (lanes.cuh): W = 2 turns the f32 arithmetic of a voice pair into packed ops.
+template <int W>
+struct NiceLaneT {
+    using F = typename LaneT<W>::F;
+    using U = typename LaneT<W>::U;
+    using M = typename LaneT<W>::M;
     // PulseOsc
-    uint32_t cnt;
-    PulseK k;
-    bool bad;
+    U cnt;
+    PulseKT<W> k;
+    M bad;
     // Filter
-    float l, b, cut, res;
-    EnvLane env;
+    F l, b, cut, res;
+    EnvLaneT<W> env;
 
-    __device__ __forceinline__ void begin(float sample_rate, float srf, float sr8, float freq, float color, bool note_on, bool new_note) {
-        bad = freq < 0 || freq > sr8;                                  // PulseOsc.zig:82-84
-        pulse_setup_color(k, color);
-        pulse_setup_freq(k, srf, freq);
+    __device__ __forceinline__ void begin(float sample_rate, float srf, float sr8, F freq, F color, M note_on, M new_note) {
+        bad = zor(freq < zsplat<F>(0.0f), freq > zsplat<F>(sr8));      // PulseOsc.zig:82-84
+        pulse_setup(k, srf, freq, color);
         // Filter params: cutoff = cutoffFromFrequency(freq * 8, sr), res = 0.7 (examples/modules.zig:231-235)
-        cut = zclampf(zcutoff_from_frequency(freq * 8.0f, sample_rate), 0.0f, 1.0f);
-        res = 1.0f - zclampf(0.7f, 0.0f, 1.0f);
+        const F f8 = freq * 8.0f;
+#pragma unroll
+        for (int c = 0; c < W; c++) zput(cut, c, zclampf(zcutoff_from_frequency(zget(f8, c), sample_rate), 0.0f, 1.0f));
+        res = zsplat<F>(1.0f - zclampf(0.7f, 0.0f, 1.0f));
         // Envelope params (:238-245)
         env.sample_rate = sample_rate;
-        env.sustain_volume = 0.8f;
-        env.attack = CurveP{ZH_CURVE_CUBED, 0.01f};
-        env.decay = CurveP{ZH_CURVE_CUBED, 0.1f};
-        env.release = CurveP{ZH_CURVE_CUBED, 0.5f};
+        env.sustain_volume = zsplat<F>(0.8f);
+        env.attack = CurvePT<W>{ZH_CURVE_CUBED, zsplat<F>(0.01f)};
+        env.decay = CurvePT<W>{ZH_CURVE_CUBED, zsplat<F>(0.1f)};
+        env.release = CurvePT<W>{ZH_CURVE_CUBED, zsplat<F>(0.5f)};
         env.note_on = note_on;
         env.begin(new_note);
     }
 
     // one frame of examples/modules.zig:220-246; returns env*flt (the value added to out)
-    __device__ __forceinline__ float frame() {
+    __device__ __forceinline__ F frame() {
+        const F zero = zsplat<F>(0.0f);
         // temps[0] = 0 (+ pulse) ; temps[0] *= 0.5
-        const float pv = 0.0f + pulse_sample(k, cnt);                  // a silent voice (bad freq) leaves temps[0] = 0
-        const float t0 = (bad ? 0.0f : pv) * 0.5f;                     // multiplyWithScalar :226
-        cnt = bad ? cnt : cnt + k.ifreq;
+        const F pv = zero + pulse_sample<W>(k, cnt);                   // a silent voice (bad freq) leaves temps[0] = 0
+        const F t0 = zsel(bad, zero, pv) * 0.5f;                       // multiplyWithScalar :226
+        cnt = zsel(bad, cnt, cnt + k.ifreq);
         // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
-        const SvfOut s = svf_step(l, b, t0, cut, res);
-        const float t1 = 0.0f + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
+        const SvfOutT<F> s = svf_step(l, b, t0, cut, res);
+        const F t1 = zero + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
         // temps[0] = 0 (+ envelope)
-        float ev = 0.0f;
-        const bool painted = env.frame(ev);
-        const float e0 = painted ? 0.0f + ev : 0.0f;
+        F ev = zero;
+        const M painted = env.frame(ev);
+        const F e0 = zsel(painted, zero + ev, zero);
         return e0 * t1;                                                // multiply :246: out += temps[0]*temps[1]
     }
 };
+using NiceLane = NiceLaneT<1>;
 
 struct NiceArgs {
     float *color;
@@ -93,28 +102,47 @@ struct NiceArgs {
     BoolP note_on, nic;
 };
 
-__device__ __forceinline__ void nice_load(NiceLane &n, const NiceArgs &a, uint32_t v) {
-    n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
-    n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
-    n.begin(a.sample_rate, a.srf, a.sr8, a.freq.get(v), a.color[v], a.note_on.get(v), a.nic.get(v));
+// `v` = the lane's first voice (W = 2: even)
+template <int W>
+__device__ __forceinline__ void nice_load(NiceLaneT<W> &n, const NiceArgs &a, uint32_t v) {
+    n.cnt = zload_u<W>(a.cnt, v); n.l = zload_f<W>(a.fl, v); n.b = zload_f<W>(a.fb, v);
+    n.env.state = zload_u<W>(a.estate, v); n.env.t = zload_f<W>(a.et, v);
+    n.env.last_value = zload_f<W>(a.elast, v); n.env.start = zload_f<W>(a.estart, v);
+    n.begin(a.sample_rate, a.srf, a.sr8, zget_f32p<W>(a.freq, v), zload_f<W>(a.color, v), zget_boolp<W>(a.note_on, v), zget_boolp<W>(a.nic, v));
 }
-__device__ __forceinline__ void nice_store(NiceLane &n, const NiceArgs &a, uint32_t v) {
-    a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
-    a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
+template <int W>
+__device__ __forceinline__ void nice_store(NiceLaneT<W> &n, const NiceArgs &a, uint32_t v) {
+    zstore_u<W>(a.cnt, v, n.cnt); zstore_f<W>(a.fl, v, n.l); zstore_f<W>(a.fb, v, n.b);
+    zstore_u<W>(a.estate, v, n.env.state); zstore_f<W>(a.et, v, n.env.t);
+    zstore_f<W>(a.elast, v, n.env.last_value); zstore_f<W>(a.estart, v, n.env.start);
 }
 
-template <bool ZF>
+// Two voices per lane (W = 2, lanes.cuh) is built and parity-tested but NOT the default: measured on
+// MI355X it is slower at every voice count (131,072 voices: 211 us vs 182 us; 1 Mi voices: 1296 us vs
+// 1222 us).  tools/ubench/valu_ops.hip shows why: a v_pk_*_f32 costs 4.2 issue cycles per SIMD against
+// 2.5 for a plain v_add/v_mul/v_sub_f32, so packing saves ~15 % on the arithmetic while every compare
+// and select (4.2 cycles each, no packed form) is paid twice.  ZH_NICE_W=2 selects it for A/B timing;
+// it needs an even voice count and 8-byte aligned rows / per-voice arrays.
+static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+static bool nice_pairable(const NiceArgs &a) {
+    static const bool want2 = [] { const char *e = getenv("ZH_NICE_W"); return e && e[0] == '2'; }();
+    return want2 && a.V % 2 == 0 && aligned8(a.freq.pv) && aligned8(a.color) && aligned8(a.cnt) && aligned8(a.fl) && aligned8(a.fb) &&
+           aligned8(a.estate) && aligned8(a.et) && aligned8(a.elast) && aligned8(a.estart);
+}
+
+template <bool ZF, int W>
 __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_t start, uint32_t end) {
-    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
+    using F = typename LaneT<W>::F;
+    const uint32_t v = (blockIdx.x * kSeqBlock + threadIdx.x) * W;
     if (v >= a.V) return;
-    NiceLane n;
-    nice_load(n, a, v);
+    NiceLaneT<W> n;
+    nice_load<W>(n, a, v);
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0, W>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const F (&)[1], F &val) ZH_INLINE_LAMBDA {
         val = n.frame();
-        return true;
+        return zmask<typename LaneT<W>::M>(true);
     });
-    nice_store(n, a, v);
+    nice_store<W>(n, a, v);
 }
 
 // Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
@@ -505,8 +533,16 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     if (m->n == 0) return ZH_OK;
     hipStream_t st = m->ctx->stream;
     NiceArgs a = nice_args(m, p, note_id_changed);
-    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_nice<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
-    else hipLaunchKernelGGL(k_nice<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    const Img out = mk_img(outputs[0]);
+    const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
+    if (nice_pairable(a) && aligned8(out.p) && out.stride % 2 == 0) {
+        const dim3 grid = seq_grid(m->n / 2);
+        if (zf) hipLaunchKernelGGL((k_nice<true, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
+        else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
+    } else {
+        if (zf) hipLaunchKernelGGL((k_nice<true, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
+        else hipLaunchKernelGGL((k_nice<false, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
+    }
     return zh_launch_status();
 }
 int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_bool note_id_changed,

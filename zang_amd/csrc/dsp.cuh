@@ -2,12 +2,15 @@
 // that each of the reference's formulas exists exactly once on the device.
 #pragma once
 #include "zmath.cuh"
+#include "lanes.cuh"
 
 // ---- PulseOsc (src/modules/PulseOsc.zig) -------------------------------------------------------
-struct PulseK {           // per-voice constants of PulseOsc.zig:88-95
-    uint32_t ifreq, brpt;
-    float gdf2 /* gdf * 2.0 */, col, cc121, cc212;
+template <int W>
+struct PulseKT {          // per-voice constants of PulseOsc.zig:88-95
+    typename LaneT<W>::U ifreq, brpt;
+    typename LaneT<W>::F gdf2 /* gdf * 2.0 */, col, cc121, cc212;
 };
+using PulseK = PulseKT<1>;
 
 // `srf` = fc32bit / sample_rate (PulseOsc.zig:87) is wave-uniform: the host computes it once
 // (IEEE f32 divide, same bits as the device's correctly rounded divide).
@@ -22,6 +25,21 @@ __device__ __forceinline__ void pulse_setup_color(PulseK &k, float color) {
     k.brpt = zftou32(zclamp01(color));
     k.col = zutof23(k.brpt);
 }
+// the once-per-paint setup of a voice pair is done per component by the scalar code above
+__device__ __forceinline__ void pulse_setup(PulseKT<1> &k, float srf, float freq, float color) {
+    pulse_setup_color(k, color);
+    pulse_setup_freq(k, srf, freq);
+}
+__device__ __forceinline__ void pulse_setup(PulseKT<2> &k, float srf, zf2 freq, zf2 color) {
+    PulseK a, b;
+    pulse_setup(a, srf, freq.x, color.x);
+    pulse_setup(b, srf, freq.y, color.y);
+    k.ifreq = zu2{a.ifreq, b.ifreq}; k.brpt = zu2{a.brpt, b.brpt};
+    k.gdf2 = zf2{a.gdf2, b.gdf2}; k.col = zf2{a.col, b.col};
+    k.cc121 = zf2{a.cc121, b.cc121}; k.cc212 = zf2{a.cc212, b.cc212};
+}
+
+__device__ __forceinline__ zf2 zutof23(zu2 x) { return zbits_f((x >> 9) | 0x3f800000u) - 1.0f; }
 
 // The 6-way switch of PulseOsc.zig:102-110.  transition = b0 | b1<<1 | b2<<2 with
 // b0 = cnt < brpt, b1 = (cnt - ifreq) < brpt, b2 = cnt < ifreq:
@@ -34,28 +52,33 @@ __device__ __forceinline__ void pulse_setup_color(PulseK &k, float color) {
 // Values are selected, never blended (gdf is inf when ifreq < 512).
 // The result is never -0.0: every arm ends in `x + gain` / `x - gain` with gain = 0.7, and an IEEE
 // sum is -0.0 only when both addends are -0.0.
-__device__ __forceinline__ float pulse_sample(const PulseK &k, uint32_t cnt) {
-    const float gain = 0.7f;
-    const float p = zutof23(cnt);
-    const bool b0 = cnt < k.brpt;
-    const bool b1 = (uint32_t)(cnt - k.ifreq) < k.brpt;
-    const bool b2 = cnt < k.ifreq;
-    const float ramp = k.gdf2 * (b2 ? p : k.col - p) + (b2 ? -gain : gain);
-    const float flat = b2 ? (b0 ? k.cc121 : k.cc212) : (b0 ? gain : -gain);
-    return (b0 == b1) ? flat : ramp;
+template <int W>
+__device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k, typename LaneT<W>::U cnt) {
+    using F = typename LaneT<W>::F;
+    using M = typename LaneT<W>::M;
+    const F gain = zsplat<F>(0.7f), ngain = zsplat<F>(-0.7f);
+    const F p = zutof23(cnt);
+    const M b0 = cnt < k.brpt;
+    const M b1 = (cnt - k.ifreq) < k.brpt;
+    const M b2 = cnt < k.ifreq;
+    const F ramp = k.gdf2 * zsel(b2, p, k.col - p) + zsel(b2, ngain, gain);
+    const F flat = zsel(b2, zsel(b0, k.cc121, k.cc212), zsel(b0, gain, ngain));
+    return zsel(b0 == b1, flat, ramp);
 }
 
 // ---- Filter (src/modules/Filter.zig:130-146): one 2x-oversampled state-variable step ------------
-struct SvfOut { float l, b, h; };
-__device__ __forceinline__ SvfOut svf_step(float &l, float &b, float input, float cut, float res) {
+template <class F> struct SvfOutT { F l, b, h; };
+using SvfOut = SvfOutT<float>;
+template <class F>
+__device__ __forceinline__ SvfOutT<F> svf_step(F &l, F &b, F input, F cut, F res) {
     const float fcdcoffset = 3.814697265625e-6f;                      // Filter.zig:8
-    const float in = input + fcdcoffset;                              // :135
+    const F in = input + fcdcoffset;                                  // :135
     l += cut * b - fcdcoffset;                                        // :138
     b += cut * (in - b * res - l);                                    // :139
     l += cut * b;                                                     // :142
-    const float h = in - b * res - l;                                 // :143
+    const F h = in - b * res - l;                                     // :143
     b += cut * h;                                                     // :144
-    return SvfOut{l, b, h};
+    return SvfOutT<F>{l, b, h};
 }
 
 // ---- Noise (src/modules/Noise.zig:58-66): one sample of Paul Kellett's pink filter -------------

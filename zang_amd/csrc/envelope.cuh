@@ -14,103 +14,113 @@
 // reference then immediately calls the next stage's paintToward, even with no frames left).
 #pragma once
 #include "common.cuh"
+#include "lanes.cuh"
 
-struct CurveP {           // PaintCurve for one voice: shared tag, per-voice duration
+template <int W>
+struct CurvePT {          // PaintCurve for one lane: shared tag, per-voice duration
     uint32_t tag;
-    float duration;
+    typename LaneT<W>::F duration;
 };
+using CurveP = CurvePT<1>;
 
 enum { ENV_MODE_NONE = 0, ENV_MODE_TOWARD = 1, ENV_MODE_FLAT = 2 };
 
-struct EnvLane {
+// W voices per lane (lanes.cuh).  Everything is selects under masks: conditional stores to
+// different fields of the lane get sunk by LLVM into one store at a variable offset, which forces
+// the lane out of VGPRs -- and with W = 2 the two voices of a lane are rarely in the same stage.
+template <int W>
+struct EnvLaneT {
+    using F = typename LaneT<W>::F;
+    using U = typename LaneT<W>::U;
+    using M = typename LaneT<W>::M;
     // Envelope state (Envelope.zig:23-24; painter.zig:33-36)
-    uint32_t state;
-    float t, last_value, start;
+    U state;
+    F t, last_value, start;
     // per-paint parameters
-    float sample_rate, sustain_volume;
-    CurveP attack, decay, release;
-    bool note_on;
+    float sample_rate;
+    F sustain_volume;
+    CurvePT<W> attack, decay, release;
+    M note_on;
     // the running stage
-    uint32_t mode, cur_tag;
-    float cur_step, cur_goal;
+    U mode, cur_tag;
+    F cur_step, cur_goal;
 
-    __device__ __forceinline__ void change_state(uint32_t s) {   // Envelope.zig:33-36 + painter.zig:47-50
-        state = s;
-        start = last_value;
-        t = 0.0f;
+    static __device__ __forceinline__ U u(uint32_t x) { return zsplatu<U>(x); }
+    static __device__ __forceinline__ F f(float x) { return zsplat<F>(x); }
+
+    // Envelope.zig:33-36 + painter.zig:47-50, for the voices in `c`
+    __device__ __forceinline__ void change_state_if(M c, U s) {
+        state = zsel(c, s, state);
+        start = zsel(c, last_value, start);
+        t = zsel(c, f(0.0f), t);
     }
 
-    // paintToward's entry (painter.zig:69-97) for the stage `on` selects; returns "finished without
-    // painting".  Written with selects only: conditional stores to different fields of the lane get
-    // sunk by LLVM into one store at a variable offset, which forces the lane out of VGPRs.
-    __device__ __forceinline__ bool enter(bool on, uint32_t tag, float duration, float goal) {
-        const bool done = t >= 1.0f;                              // :69-71
-        const bool inst = on && !done && tag == ZH_CURVE_INSTANTANEOUS;   // :76-80
-        t = inst ? 1.0f : t;
-        last_value = inst ? goal : last_value;
-        const bool fin = done || inst;
-        const bool run = on && !fin;
-        mode = run ? (uint32_t)ENV_MODE_TOWARD : mode;
-        cur_tag = run ? tag : cur_tag;
-        cur_goal = run ? goal : cur_goal;
-        cur_step = run ? 1.0f / (duration * sample_rate) : cur_step;   // :97
-        return on && fin;
+    // paintToward's entry (painter.zig:69-97) for the voices in `on`; returns "finished without painting"
+    __device__ __forceinline__ M enter(M on, uint32_t tag, F duration, F goal) {
+        const M done = t >= f(1.0f);                              // :69-71
+        const M inst = zand(on, znot(done), zmask<M>(tag == ZH_CURVE_INSTANTANEOUS));   // :76-80
+        t = zsel(inst, f(1.0f), t);
+        last_value = zsel(inst, goal, last_value);
+        const M fin = zor(done, inst);
+        const M run = zand(on, znot(fin));
+        mode = zsel(run, u(ENV_MODE_TOWARD), mode);
+        cur_tag = zsel(run, u(tag), cur_tag);
+        cur_goal = zsel(run, goal, cur_goal);
+        cur_step = zsel(run, f(1.0f) / (duration * sample_rate), cur_step);   // :97
+        return zand(on, fin);
     }
 
-    __device__ __forceinline__ void change_state_if(bool c, uint32_t s) {
-        state = c ? s : state;
-        start = c ? last_value : start;
-        t = c ? 0.0f : t;
-    }
-
-    // Envelope.zig:52-70 / 85-89 from the current state, up to the next stage that takes time
-    __device__ __forceinline__ void resolve() {
-        mode = ENV_MODE_NONE;
-        const uint32_t after_attack = sustain_volume < 1.0f ? (uint32_t)ZH_ENV_DECAY : (uint32_t)ZH_ENV_SUSTAIN;
-        change_state_if(enter(note_on && state == ZH_ENV_ATTACK, attack.tag, attack.duration, 1.0f), after_attack);
-        change_state_if(enter(note_on && state == ZH_ENV_DECAY, decay.tag, decay.duration, sustain_volume), ZH_ENV_SUSTAIN);
-        mode = (note_on && state == ZH_ENV_SUSTAIN) ? (uint32_t)ENV_MODE_FLAT : mode;
+    // Envelope.zig:52-70 / 85-89 from the current state, up to the next stage that takes time,
+    // for the voices in `m`
+    __device__ __forceinline__ void resolve(M m) {
+        mode = zsel(m, u(ENV_MODE_NONE), mode);
+        const U after_attack = zsel(sustain_volume < f(1.0f), u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN));
+        const M on = zand(m, note_on), off = zand(m, znot(note_on));
+        change_state_if(enter(zand(on, state == u(ZH_ENV_ATTACK)), attack.tag, attack.duration, f(1.0f)), after_attack);
+        change_state_if(enter(zand(on, state == u(ZH_ENV_DECAY)), decay.tag, decay.duration, sustain_volume), u(ZH_ENV_SUSTAIN));
+        mode = zsel(zand(on, state == u(ZH_ENV_SUSTAIN)), u(ENV_MODE_FLAT), mode);
         // note_on && state == release is the assert case of Envelope.zig:45 (note_on without a new note
         // id while releasing): with the assert compiled out nothing matches -> NONE.
-        change_state_if(enter(!note_on && state == ZH_ENV_RELEASE, release.tag, release.duration, 0.0f), ZH_ENV_IDLE);
+        change_state_if(enter(zand(off, state == u(ZH_ENV_RELEASE)), release.tag, release.duration, f(0.0f)), u(ZH_ENV_IDLE));
     }
 
     // Prologue of paintOn / paintOff (Envelope.zig:38-50, 77-84), then the first stage's entry
-    __device__ __forceinline__ void begin(bool new_note) {
-        change_state_if(note_on && new_note, ZH_ENV_ATTACK);
-        change_state_if(note_on && state == ZH_ENV_IDLE, ZH_ENV_ATTACK);
-        change_state_if(!note_on && state != ZH_ENV_IDLE && state != ZH_ENV_RELEASE, ZH_ENV_RELEASE);
-        resolve();
+    __device__ __forceinline__ void begin(M new_note) {
+        change_state_if(zand(note_on, new_note), u(ZH_ENV_ATTACK));
+        change_state_if(zand(note_on, state == u(ZH_ENV_IDLE)), u(ZH_ENV_ATTACK));
+        change_state_if(zand(znot(note_on), state != u(ZH_ENV_IDLE), state != u(ZH_ENV_RELEASE)), u(ZH_ENV_RELEASE));
+        resolve(zmask<M>(true));
     }
 
-    // One frame.  Returns whether a value was painted.  Straight-line: the paintToward step
+    // One frame.  Returns which voices painted a value.  Straight-line: the paintToward step
     // (painter.zig:102-116) is computed unconditionally and committed by selects -- per-lane mode
     // branches cost more (exec-mask bookkeeping) than the ~10 VALU ops they would skip; only the
     // rare stage end branches.
-    __device__ __forceinline__ bool frame(float &val) {
-        const bool toward = mode == ENV_MODE_TOWARD;
-        float tn = t + cur_step;
-        const bool finished = tn >= 1.0f;
-        tn = finished ? 1.0f : tn;
-        const float it = 1.0f - tn;
-        float tp = tn;
-        if (cur_tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
-        else if (cur_tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
-        const float lv = start + tp * (cur_goal - start);         // :114
-        t = toward ? tn : t;
-        last_value = toward ? lv : last_value;
-        val = toward ? lv : sustain_volume;                        // FLAT: Envelope.zig:68-70
-        const bool painted = mode != ENV_MODE_NONE;
-        if (toward && finished) {                                  // Envelope.zig:53-58, 63-65, 86-88
-            const uint32_t after_attack = sustain_volume < 1.0f ? (uint32_t)ZH_ENV_DECAY : (uint32_t)ZH_ENV_SUSTAIN;
-            const uint32_t next = state == ZH_ENV_ATTACK ? after_attack
-                                  : (state == ZH_ENV_DECAY ? (uint32_t)ZH_ENV_SUSTAIN : (uint32_t)ZH_ENV_IDLE);
-            change_state(next);
-            resolve();
+    __device__ __forceinline__ M frame(F &val) {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        F tn = t + cur_step;
+        const M finished = tn >= f(1.0f);
+        tn = zsel(finished, f(1.0f), tn);
+        const F it = f(1.0f) - tn;
+        const F tp = zsel(cur_tag == u(ZH_CURVE_SQUARED), f(1.0f) - it * it,
+                          zsel(cur_tag == u(ZH_CURVE_CUBED), f(1.0f) - it * it * it, tn));
+        const F lv = start + tp * (cur_goal - start);              // :114
+        t = zsel(toward, tn, t);
+        last_value = zsel(toward, lv, last_value);
+        val = zsel(toward, lv, sustain_volume);                    // FLAT: Envelope.zig:68-70
+        const M painted = mode != u(ENV_MODE_NONE);
+        const M stage_end = zand(toward, finished);
+        if (zany(stage_end)) {                                     // Envelope.zig:53-58, 63-65, 86-88
+            const U after_attack = zsel(sustain_volume < f(1.0f), u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN));
+            const U next = zsel(state == u(ZH_ENV_ATTACK), after_attack,
+                                zsel(state == u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN), u(ZH_ENV_IDLE)));
+            change_state_if(stage_end, next);
+            resolve(stage_end);
         }
         return painted;
     }
 };
+using EnvLane = EnvLaneT<1>;
 
 // Envelope.Params (Envelope.zig:6-13) as the kernels see them: tags shared, values per voice.
 struct EnvParamsP {
@@ -120,12 +130,12 @@ struct EnvParamsP {
     BoolP note_on;
 };
 
-__device__ __forceinline__ void env_load(EnvLane &e, const EnvParamsP &p, uint32_t v) {
+template <int W>
+__device__ __forceinline__ void env_load(EnvLaneT<W> &e, const EnvParamsP &p, uint32_t v) {
     e.sample_rate = p.sample_rate;
-    e.sustain_volume = p.sustain_volume.get(v);
-    e.attack = CurveP{p.attack_tag, p.attack_dur.get(v)};
-    e.decay = CurveP{p.decay_tag, p.decay_dur.get(v)};
-    e.release = CurveP{p.release_tag, p.release_dur.get(v)};
-    e.note_on = p.note_on.get(v);
+    e.sustain_volume = zget_f32p<W>(p.sustain_volume, v);
+    e.attack = CurvePT<W>{p.attack_tag, zget_f32p<W>(p.attack_dur, v)};
+    e.decay = CurvePT<W>{p.decay_tag, zget_f32p<W>(p.decay_dur, v)};
+    e.release = CurvePT<W>{p.release_tag, zget_f32p<W>(p.release_dur, v)};
+    e.note_on = zget_boolp<W>(p.note_on, v);
 }
-

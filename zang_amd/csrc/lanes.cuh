@@ -1,0 +1,98 @@
+// lanes.cuh -- lane width for the sequential per-voice kernels: one voice per lane (W = 1) or two
+// adjacent voices per lane (W = 2).
+//
+// Why W = 2 exists: with two voices of one lane held in adjacent VGPRs, every f32 add/sub/mul of the
+// pair becomes one v_pk_*_f32 (two IEEE results, same bits as the scalar ops; contraction stays off).
+// Why it is not the default: tools/ubench/valu_ops.hip measures, per SIMD at full occupancy, 2.5 cycles
+// for a plain 2-operand v_add/v_mul/v_sub_f32 or integer/logic op, but 4.2 cycles for v_pk_*_f32, v_fma,
+// v_min/v_max, every v_cmp and every v_cndmask -- so a packed op is barely cheaper than the two plain
+// ops it replaces, while compares and selects (no packed form) double.  A NiceInstrument voice pair
+// measured 10-15 % SLOWER than two single-voice lanes (composite.hip).  Kept, parity-tested, because
+// the generic form costs nothing at W = 1 and documents the experiment.
+//
+// The per-sample code (dsp.cuh, envelope.cuh) is written once, over LaneT<W>::F/U/M, with the
+// helpers below for the few things that differ between `bool` and a vector mask.
+#pragma once
+#include "common.cuh"
+
+typedef float zf2 __attribute__((ext_vector_type(2)));
+typedef uint32_t zu2 __attribute__((ext_vector_type(2)));
+typedef int32_t zm2 __attribute__((ext_vector_type(2)));     // comparison result: 0 / -1 per component
+
+template <int W> struct LaneT;
+template <> struct LaneT<1> { using F = float; using U = uint32_t; using M = bool; };
+template <> struct LaneT<2> { using F = zf2; using U = zu2; using M = zm2; };
+
+#define ZL __device__ __forceinline__
+
+// select
+ZL float zsel(bool m, float a, float b) { return m ? a : b; }
+ZL uint32_t zsel(bool m, uint32_t a, uint32_t b) { return m ? a : b; }
+ZL zf2 zsel(zm2 m, zf2 a, zf2 b) { return m ? a : b; }
+ZL zu2 zsel(zm2 m, zu2 a, zu2 b) { return m ? a : b; }
+// mask logic (masks are `bool` or all-ones/zero vectors)
+ZL bool zand(bool a, bool b) { return a && b; }
+ZL zm2 zand(zm2 a, zm2 b) { return a & b; }
+template <class M> ZL M zand(M a, M b, M c) { return zand(zand(a, b), c); }
+ZL bool zor(bool a, bool b) { return a || b; }
+ZL zm2 zor(zm2 a, zm2 b) { return a | b; }
+ZL bool znot(bool m) { return !m; }
+ZL zm2 znot(zm2 m) { return ~m; }
+ZL bool zany(bool m) { return m; }
+ZL bool zany(zm2 m) { return (m.x | m.y) != 0; }
+ZL bool zall(bool m) { return m; }
+ZL bool zall(zm2 m) { return (m.x & m.y) != 0; }
+// splats
+template <class T> ZL T zsplat(float v);
+template <> ZL float zsplat<float>(float v) { return v; }
+template <> ZL zf2 zsplat<zf2>(float v) { return zf2{v, v}; }
+template <class T> ZL T zsplatu(uint32_t v);
+template <> ZL uint32_t zsplatu<uint32_t>(uint32_t v) { return v; }
+template <> ZL zu2 zsplatu<zu2>(uint32_t v) { return zu2{v, v}; }
+template <class M> ZL M zmask(bool b);
+template <> ZL bool zmask<bool>(bool b) { return b; }
+template <> ZL zm2 zmask<zm2>(bool b) { const int32_t x = b ? -1 : 0; return zm2{x, x}; }
+ZL zm2 zmask2(bool b0, bool b1) { return zm2{b0 ? -1 : 0, b1 ? -1 : 0}; }
+// bit casts
+ZL float zbits_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+ZL zf2 zbits_f(zu2 u) { return __builtin_bit_cast(zf2, u); }
+
+// component access (setup code that runs once per paint call is done per component in scalar form)
+ZL float zget(float v, int) { return v; }
+ZL float zget(zf2 v, int i) { return i ? v.y : v.x; }
+ZL uint32_t zget(uint32_t v, int) { return v; }
+ZL uint32_t zget(zu2 v, int i) { return i ? v.y : v.x; }
+ZL bool zget(bool v, int) { return v; }
+ZL bool zget(zm2 v, int i) { return (i ? v.y : v.x) != 0; }
+ZL void zput(float &d, int, float v) { d = v; }
+ZL void zput(zf2 &d, int i, float v) { if (i) d.y = v; else d.x = v; }
+ZL void zput(uint32_t &d, int, uint32_t v) { d = v; }
+ZL void zput(zu2 &d, int i, uint32_t v) { if (i) d.y = v; else d.x = v; }
+ZL void zput(bool &d, int, bool v) { d = v; }
+ZL void zput(zm2 &d, int i, bool v) { if (i) d.y = v ? -1 : 0; else d.x = v ? -1 : 0; }
+
+// loads / stores of W adjacent voices starting at voice `v` (v even and p 8-byte aligned for W = 2)
+template <int W> ZL typename LaneT<W>::F zload_f(const float *p, uint32_t v) {
+    if constexpr (W == 1) return p[v];
+    else return *reinterpret_cast<const zf2 *>(p + v);
+}
+template <int W> ZL typename LaneT<W>::U zload_u(const uint32_t *p, uint32_t v) {
+    if constexpr (W == 1) return p[v];
+    else return *reinterpret_cast<const zu2 *>(p + v);
+}
+template <int W> ZL void zstore_f(float *p, uint32_t v, typename LaneT<W>::F x) {
+    if constexpr (W == 1) p[v] = x;
+    else *reinterpret_cast<zf2 *>(p + v) = x;
+}
+template <int W> ZL void zstore_u(uint32_t *p, uint32_t v, typename LaneT<W>::U x) {
+    if constexpr (W == 1) p[v] = x;
+    else *reinterpret_cast<zu2 *>(p + v) = x;
+}
+template <int W> ZL typename LaneT<W>::F zget_f32p(const F32P &p, uint32_t v) {
+    if constexpr (W == 1) return p.get(v);
+    else return p.pv ? *reinterpret_cast<const zf2 *>(p.pv + v) : zf2{p.value, p.value};
+}
+template <int W> ZL typename LaneT<W>::M zget_boolp(const BoolP &p, uint32_t v) {
+    if constexpr (W == 1) return p.get(v);
+    else return zmask2(p.get(v), p.get(v + 1));
+}
