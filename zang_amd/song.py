@@ -278,13 +278,22 @@ class SongRenderer:
         self.image = ctx.image(F, self.total_voices)           # one column per sub-voice, in painting order
         self.mix = torch.zeros(F, dtype=torch.float32, device=ctx.device)
         self.pcm = torch.zeros(F * 2, dtype=torch.uint8, device=ctx.device)
+        # The instruments are independent until the mix (example_song.zig:340-346 adds them in order
+        # afterwards), and a handful of sub-voices is one wave walking frames serially: each instrument
+        # paints on its own stream so the three serial walks overlap instead of queueing.
+        from .runtime import Context
+        self.main_stream = getattr(ctx, "_stream", None) or torch.cuda.current_stream(ctx.device)
+        self.ictx = []
         self.mods, self.views = [], []
         col = 0
         for inst in instruments:
+            ic = Context(ctx.device.index, adopt_torch_stream=False)
+            ic.use_stream(torch.cuda.Stream(device=ctx.device))
+            self.ictx.append(ic)
             if inst.kind == "pmosc":
-                self.mods.append(mod.PMOscInstrument(inst.polyphony, inst.init_arg, ctx))
+                self.mods.append(mod.PMOscInstrument(inst.polyphony, inst.init_arg, ic))
             else:
-                self.mods.append(mod.NiceInstrument(inst.polyphony, inst.init_arg, ctx))
+                self.mods.append(mod.NiceInstrument(inst.polyphony, inst.init_arg, ic))
             self.views.append(self.image[:, col:col + inst.polyphony])
             col += inst.polyphony
         self.vol = vol
@@ -293,8 +302,13 @@ class SongRenderer:
         """One write_wav iteration (write_wav.zig:58-93): returns nframes*2 bytes of s16 mono PCM."""
         span = zang.Span(0, nframes)
         tables = self.sched.buffer(span)
-        for m, view, per_voice in zip(self.mods, self.views, tables):
-            m.paint_spans(span, [view], None, float(AUDIO_SAMPLE_RATE), SpanTable(per_voice, self.ctx.device), zero_first=True)
+        live = []                                                  # tables stay allocated until the main stream has joined
+        for m, ic, view, per_voice in zip(self.mods, self.ictx, self.views, tables):
+            live.append(SpanTable(per_voice, self.ctx.device))     # uploaded on the main stream
+            ic._stream.wait_stream(self.main_stream)
+            m.paint_spans(span, [view], None, float(AUDIO_SAMPLE_RATE), live[-1], zero_first=True)
+        for ic in self.ictx:
+            self.main_stream.wait_stream(ic._stream)
         # outputs[0] was zeroed (write_wav.zig:63-64); sub-voices accumulate in painting order
         zang.mixdownVoices(span, self.mix, self.image, zero_first=True, sequential=True, ctx=self.ctx)
         zang.mixDown(self.pcm[:nframes * 2], self.mix[:nframes], zang.AudioFormat.signed16_lsb, 1, 0, self.vol, ctx=self.ctx)
@@ -324,10 +338,15 @@ class SongRenderer:
             self._batch_frames = total
         span = zang.Span(0, total)
         col = 0
-        for m, inst, per_voice in zip(self.mods, self.instruments, per_inst):
+        live = []
+        for m, ic, inst, per_voice in zip(self.mods, self.ictx, self.instruments, per_inst):
             view = self._bimage[:, col:col + inst.polyphony]
             col += inst.polyphony
-            m.paint_spans(span, [view], None, float(AUDIO_SAMPLE_RATE), SpanTable(per_voice, self.ctx.device), zero_first=True)
+            live.append(SpanTable(per_voice, self.ctx.device))
+            ic._stream.wait_stream(self.main_stream)
+            m.paint_spans(span, [view], None, float(AUDIO_SAMPLE_RATE), live[-1], zero_first=True)
+        for ic in self.ictx:
+            self.main_stream.wait_stream(ic._stream)
         zang.mixdownVoices(span, self._bmix, self._bimage, zero_first=True, sequential=True, ctx=self.ctx)
         zang.mixDown(self._bpcm[:total * 2], self._bmix[:total], zang.AudioFormat.signed16_lsb, 1, 0, self.vol, ctx=self.ctx)
         return bytes(self._bpcm[:total * 2].cpu().numpy())
