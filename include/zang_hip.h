@@ -28,8 +28,10 @@
 #ifndef ZANG_HIP_H
 #define ZANG_HIP_H
 
+#if !defined(__HIPCC_RTC__)   /* hiprtc has no libc headers; it predefines the fixed-width types */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

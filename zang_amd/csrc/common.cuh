@@ -1,11 +1,20 @@
 // common.cuh -- shared host/device plumbing for libzang_hip.so (gfx950 only).
 #pragma once
+// Under hiprtc (the zangscript kernels, script.hip) there are no libc / libstdc++ headers and no host
+// runtime API: ZH_DEVICE_ONLY drops the host plumbing and keeps the device-side views.
+#if defined(__HIPCC_RTC__)
+#define ZH_DEVICE_ONLY 1
+#endif
 #include <hip/hip_runtime.h>
+#if !defined(ZH_DEVICE_ONLY)
 #include <stdint.h>
 #include <stddef.h>
 #include <new>
+#endif
+#include "rtc_types.cuh"
 #include "../../include/zang_hip.h"
 
+#if !defined(ZH_DEVICE_ONLY)
 struct zh_ctx {
     int device;
     hipStream_t stream;
@@ -23,11 +32,13 @@ struct zh_graph {
 struct zh_event {
     hipEvent_t ev;
 };
+#endif
 
 // every per-frame lambda must be inlined into frame_loop: an outlined closure forces the lane
 // state (captured by reference) out of VGPRs into scratch
 #define ZH_INLINE_LAMBDA __attribute__((always_inline))
 
+#if !defined(ZH_DEVICE_ONLY)
 #define ZH_TRY(expr)                                   \
     do {                                               \
         hipError_t _e = (expr);                        \
@@ -38,6 +49,7 @@ static inline int zh_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ZH_OK : (int)e;
 }
+#endif
 
 // ---- device-side views of the ABI structs -------------------------------------------
 struct Img {           // mutable [frame][voice] image
@@ -66,6 +78,7 @@ struct CobP {          // ConstantOrBuffer
     CImg b;
 };
 
+#if !defined(ZH_DEVICE_ONLY)
 static inline Img mk_img(const zh_buf &b) { return Img{b.ptr, b.stride}; }
 static inline CImg mk_cimg(const zh_buf &b) { return CImg{b.ptr, b.stride}; }
 static inline F32P mk_f32(const zh_f32 &f) { return F32P{f.value, f.per_voice}; }
@@ -95,6 +108,8 @@ template <typename T> static inline int dev_alloc(T **p, size_t count) {
     hipError_t e = hipMalloc((void **)p, count * sizeof(T));
     return e == hipSuccess ? ZH_OK : (int)e;
 }
+
+#endif   // !ZH_DEVICE_ONLY
 
 // ---- streaming image stores -------------------------------------------------------------
 // A paint kernel leaves its whole output image dirty in the XCD L2s; with plain stores that
@@ -133,4 +148,6 @@ template <int SM> __device__ inline void store4(float *, zh_rsrc_t, uint32_t, zv
 template <int SM> __device__ inline void store1(float *, zh_rsrc_t, uint32_t, float) {}
 #endif
 
+#if !defined(ZH_DEVICE_ONLY)
 int zh_store_mode();   // ctx.hip: ZH_STORE_MODE env (default ST_SC1)
+#endif

@@ -11,6 +11,7 @@
 #include "dsp.cuh"
 #include "seq.cuh"
 #include "envelope.cuh"
+#include "voices.cuh"
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -206,7 +207,6 @@ struct PMOscArgs {
     BoolP note_on, nic;
 };
 
-__device__ __forceinline__ float pm_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }   // SineOsc.zig:4-6
 
 struct PMLane {
     float tc, tm;                 // carrier.t, modulator.t
@@ -228,12 +228,12 @@ struct PMLane {
 
     __device__ __forceinline__ float frame() {
         // modulator.paint -> temps[1] (zeroed): sin(t + 0.0), t += freq_buf[i] * inv_sr   (:59-63)
-        const float m = 0.0f + pm_sin(tm + 0.0f);
+        const float m = 0.0f + sine_osc_sin(tm + 0.0f);
         tm += mod_freq * inv_sr;
         // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
         const float ph = 0.0f + m * 1.0f;
         // carrier.paint -> temps[1] (zeroed): sin(t + phase[i]), t += t_step   (:69-74)
-        const float c = 0.0f + pm_sin(tc + ph);
+        const float c = 0.0f + sine_osc_sin(tc + ph);
         tc += t_step;
         // PhaseModOscillator output (PMOsc temps[0], zeroed) += temps[1]   (:75)
         const float osc = 0.0f + c;

@@ -11,6 +11,7 @@
 #include "dsp.cuh"
 #include "seq.cuh"
 #include "envelope.cuh"
+#include "voices.cuh"
 #include <vector>
 
 template <typename T> static int upload_field(zh_ctx *ctx, T *dev, const std::vector<T> &h) {
@@ -24,31 +25,27 @@ template <typename T> static int download_field(zh_ctx *ctx, std::vector<T> &h, 
 // =================================================================== SineOsc
 struct zh_sineosc { zh_ctx *ctx; uint32_t n; float *t; };
 
-// SineOsc.zig:4-6: sin((t * pi) * 2)
-__device__ __forceinline__ float sine_osc_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }
-
 template <bool ZF, bool FB, bool PB>
 __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
                                                        uint32_t end, float sample_rate, CobP freq, CobP phase) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    float t = t_io[v];
+    SineOscLane o;
+    o.t = t_io[v];
     constexpr int NIN = (FB ? 1 : 0) + (PB ? 1 : 0);
     const float *ins[2] = {nullptr, nullptr};
     size_t istr[2] = {0, 0};
     if (FB) { ins[0] = freq.b.p + v; istr[0] = freq.b.stride; }
     if (PB) { ins[FB ? 1 : 0] = phase.b.p + v; istr[FB ? 1 : 0] = phase.b.stride; }
-    const float t_step = FB ? 0.0f : freq.c.get(v) / sample_rate;    // SineOsc.zig:44
-    const float inv_sr = 1.0f / sample_rate;                          // :66
+    o.begin(sample_rate, FB ? 0.0f : freq.c.get(v));
     const float phase_c = PB ? 0.0f : phase.c.get(v);
     frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end,
                            [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
-        const float ph = PB ? x[FB ? 1 : 0] : phase_c;
-        val = sine_osc_sin(t + ph);
-        if (FB) t += x[0] * inv_sr; else t += t_step;
+        val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
         return true;
     });
-    t_io[v] = t - truncf(t);                                          // :40
+    o.end();
+    t_io[v] = o.t;
 }
 
 // =================================================================== Noise
@@ -70,20 +67,20 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, 
                                                      uint32_t start, uint32_t end) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    ZXoshiro r{s0[v], s1[v], s2[v], s3[v]};
-    float b[7] = {0, 0, 0, 0, 0, 0, 0};
+    NoiseLane o;
+    o.r = ZXoshiro{s0[v], s1[v], s2[v], s3[v]};
+    o.begin();
     if (PINK) {
 #pragma unroll
-        for (int j = 0; j < 7; j++) b[j] = bst[(size_t)j * V + v];    // `var b = self.b` (Noise.zig:55)
+        for (int j = 0; j < 7; j++) o.b[j] = bst[(size_t)j * V + v];  // `var b = self.b` (Noise.zig:55); always 0, see :68
     }
     const float *const *no_in = nullptr;
     frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        const float white = zrandom_float32(r) * 2.0f - 1.0f;         // :51 / :58
-        val = PINK ? pink_step(b, white) : white;                     // :59-66
+        val = o.template frame<PINK>();
         return true;
     });
     // Noise.zig:68 is `b = self.b;` -- the taps are never written back (reference quirk, kept)
-    s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3;           // :71
+    s0[v] = o.r.s0; s1[v] = o.r.s1; s2[v] = o.r.s2; s3[v] = o.r.s3;   // :71
 }
 
 // =================================================================== Envelope
@@ -138,17 +135,15 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
     size_t istr[3] = {input.stride, 0, 0};
     if (CB) { ins[1] = cutoff.b.p + v; istr[1] = cutoff.b.stride; }
     if (RB) { ins[CB ? 2 : 1] = res_p.b.p + v; istr[CB ? 2 : 1] = res_p.b.stride; }
-    float cut = CB ? 0.0f : zclampf(cutoff.c.get(v), 0.0f, 1.0f);     // :114
-    float res = RB ? 0.0f : 1.0f - zclampf(res_p.c.get(v), 0.0f, 1.0f);   // :118
-    float l = l_io[v], b = b_io[v];
+    FilterLane o;
+    o.l = l_io[v]; o.b = b_io[v];
+    o.begin(ZH_FILTER_LOW_PASS, CB ? 0.0f : cutoff.c.get(v), RB ? 0.0f : res_p.c.get(v));
+    o.l_mul = l_mul; o.b_mul = b_mul; o.h_mul = h_mul;               // the host resolved the type (:98-109)
     frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) ZH_INLINE_LAMBDA {
-        if (CB) cut = zclampf(x[1], 0.0f, 1.0f);                      // :126
-        if (RB) res = 1.0f - zclampf(x[CB ? 2 : 1], 0.0f, 1.0f);      // :128
-        const SvfOut s = svf_step(l, b, x[0], cut, res);              // :135-144
-        val = s.l * l_mul + s.b * b_mul + s.h * h_mul;                // :146
+        val = o.template frame<CB, RB>(x[0], CB ? x[1] : 0.0f, RB ? x[CB ? 2 : 1] : 0.0f);
         return true;
     });
-    l_io[v] = l; b_io[v] = b;
+    l_io[v] = o.l; b_io[v] = o.b;
 }
 
 __global__ void k_cutoff_from_frequency(uint32_t n, float *__restrict__ out, const float *__restrict__ freq, float sample_rate) {
@@ -251,22 +246,15 @@ __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dva
                                                          float sample_rate, F32P fake_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    const float fake = fake_p.get(v);
-    float dval = dval_io[v], dcount = dcount_io[v];
-    const int mode = fake >= sample_rate ? 0 : (fake > 0.0f ? 1 : 2);  // Decimator.zig:34,39
-    const float ratio = fake / sample_rate;                           // :40
+    DecimatorLane o;
+    o.dval = dval_io[v]; o.dcount = dcount_io[v];
+    o.begin(sample_rate, fake_p.get(v));
     const float *ins[1] = {input.p + v};
     const size_t istr[1] = {input.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
-        if (mode == 0) { val = x[0]; return true; }                   // :35 addInto
-        if (mode == 2) return false;                                  // fake <= 0 (or NaN): paints nothing
-        dcount += ratio;                                              // :46
-        if (dcount >= 1.0f) { dval = x[0]; dcount -= 1.0f; }          // :47-50
-        val = dval;                                                   // :51
-        return true;
-    });
-    if (mode == 0) { dval = 0.0f; dcount = 1.0f; }                    // :37-38
-    dval_io[v] = dval; dcount_io[v] = dcount;
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end,
+                         [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(x[0], val); });
+    o.end();
+    dval_io[v] = o.dval; dcount_io[v] = o.dcount;
 }
 
 // =================================================================== Distortion (stateless)
@@ -283,29 +271,16 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
     if (v >= V) return;
     const uint32_t c0 = start + chunk * DIST_FC, c1 = min(c0 + DIST_FC, end);
     if (c0 >= end) return;
-    const float gain1 = zpowf_pos(2.0f, ingain.get(v) * 8.0f - 2.0f);
-    const float offs = gain1 * offset.get(v);
-    const float gain2 = OVERDRIVE ? outgain.get(v) / zatanf(gain1) : outgain.get(v);   // :45 / :55
+    DistortionLane d;
+    d.begin(OVERDRIVE ? ZH_DISTORTION_OVERDRIVE : ZH_DISTORTION_CLIP, ingain.get(v), outgain.get(v), offset.get(v));
     float *o = out.at(c0, v);
     const float *in = input.at(c0, v);
-    for (uint32_t i = c0; i < c1; i++, o += out.stride, in += input.stride) {
-        const float a0 = *in * gain1 + offs;
-        float r;
-        if (OVERDRIVE) r = gain2 * zatanf(a0);                        // :50-51
-        else r = gain2 * (a0 < -1.0f ? -1.0f : (a0 > 1.0f ? 1.0f : a0));   // :60-62
-        *o = (ZF ? 0.0f : *o) + r;
-    }
+    for (uint32_t i = c0; i < c1; i++, o += out.stride, in += input.stride) *o = (ZF ? 0.0f : *o) + d.frame(*in);
 }
 
 // =================================================================== Curve
 struct zh_curve_module { zh_ctx *ctx; uint32_t n; float *t; uint32_t *cur; int32_t *off; uint32_t *next; };
 
-struct CurveSpanNode { int32_t frame; float value; };                  // Curve.zig:11-14
-
-// One lane = one voice's Curve instance.  Per paint the lane first builds its (<= 32) span nodes
-// (getCurveSpanNodes, Curve.zig:130-184), then walks the span frame by frame; whenever the running
-// curve span ends it looks up the next one (getNextCurveSpan, :188-255) -- the reference's
-// `while (start < out.len)` loop, re-expressed per frame so that all lanes stay on the same frame.
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_curve(float *__restrict__ t_io, uint32_t *__restrict__ cur_io,
                                                      int32_t *__restrict__ off_io, uint32_t *__restrict__ next_io, uint32_t V,
@@ -313,69 +288,13 @@ __global__ void __launch_bounds__(kSeqBlock) k_curve(float *__restrict__ t_io, u
                                                      const zh_curve_node *__restrict__ curve, uint32_t n_curve, BoolP nic) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    float t = t_io[v];
-    uint32_t cur = cur_io[v], next = next_io[v];
-    int32_t off = off_io[v];
-    if (nic.get(v)) { cur = 0; off = 0; next = 0; t = 0.0f; }         // :66-71
-    const uint32_t out_len = end - start;
-    CurveSpanNode nodes[32];
-    uint32_t count = 0;
-    {                                                                  // getCurveSpanNodes
-        const float buf_time = (float)out_len / sample_rate;
-        const float end_t = t + buf_time;
-        if (cur < next) { nodes[count].frame = off; nodes[count].value = curve[cur].value; count++; }   // :142-148
-        bool one_past = false;
-        for (uint32_t k = next; k < n_curve; k++) {
-            const float note_t = curve[k].t;
-            if (note_t >= end_t) { if (!one_past) one_past = true; else break; }                         // :153-160
-            const float f = (note_t - t) / buf_time;
-            const int32_t rel = zf32_to_i32(f * (float)out_len);
-            if (count > 0 && nodes[count - 1].frame == rel) count--;                                    // :165-167
-            if (count < 32) { nodes[count].frame = rel; nodes[count].value = curve[k].value; count++; }
-            if (!one_past) { cur = next; off = 0; next += 1; }                                          // :173-177
-        }
-        t += buf_time;                                                 // :180
-        off -= (int32_t)out_len;                                       // :181
-    }
-    // running curve span
-    uint32_t span_end = 0;              // relative frame where the running span ends
-    bool has_values = false;
-    float acc = 0.0f, step = 0.0f, start_value = 0.0f, value_delta = 0.0f;
-    auto next_span = [&](uint32_t dest_start_) ZH_INLINE_LAMBDA {    // getNextCurveSpan + the per-span setup of :84-107
-        const int32_t dest_start = (int32_t)dest_start_, dest_end = (int32_t)out_len;
-        has_values = false;
-        span_end = out_len;
-        for (uint32_t i = 0; i < count; i++) {
-            const int32_t start_pos = nodes[i].frame;
-            if (start_pos >= dest_end) break;
-            const int32_t end_pos = (i + 1 < count) ? min(dest_end, nodes[i + 1].frame) : dest_end;
-            if (end_pos <= dest_start) continue;
-            const int32_t note_start_clipped = start_pos > dest_start ? start_pos : dest_start;
-            if (note_start_clipped > dest_start) { span_end = (uint32_t)note_start_clipped; return; }   // gap
-            span_end = (uint32_t)(end_pos > dest_end ? dest_end : end_pos);
-            if (i + 1 < count) {
-                has_values = true;
-                const int32_t fstart = nodes[i].frame, fend = nodes[i + 1].frame;
-                const float start_x = (float)(dest_start - fstart) / (float)(fend - fstart);           // :95
-                start_value = nodes[i].value;
-                value_delta = nodes[i + 1].value - nodes[i].value;
-                const float x_step = 1.0f / (float)(fend - fstart);                                     // :100
-                if (function == ZH_CURVE_FN_LINEAR) { acc = start_value + start_x * value_delta; step = x_step * value_delta; }
-                else { acc = start_x; step = x_step; }
-            }
-            return;
-        }
-    };
+    CurveLane o;
+    o.t = t_io[v]; o.cur = cur_io[v]; o.next = next_io[v]; o.off = off_io[v];
+    o.begin(sample_rate, function, curve, n_curve, end - start, nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        const uint32_t r = i - start;
-        if (r == span_end) next_span(r);
-        if (!has_values) return false;
-        if (function == ZH_CURVE_FN_LINEAR) { val = acc; acc += step; }                                 // :109-112
-        else { val = start_value + acc * acc * (3.0f - 2.0f * acc) * value_delta; acc += step; }       // :117-121
-        return true;
-    });
-    t_io[v] = t; cur_io[v] = cur; off_io[v] = off; next_io[v] = next;
+    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end,
+                         [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(i - start, val); });
+    t_io[v] = o.t; cur_io[v] = o.cur; off_io[v] = o.off; next_io[v] = o.next;
 }
 
 // =================================================================== Cycle
@@ -386,18 +305,16 @@ __global__ void __launch_bounds__(kSeqBlock) k_cycle(float *__restrict__ t_io, u
                                                      uint32_t end, float sample_rate, CobP speed) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    float t = t_io[v];
-    const float step = SB ? 0.0f : speed.c.get(v) / sample_rate;      // Cycle.zig:37
-    const float isr = 1.0f / sample_rate;                              // :48
+    CycleLane o;
+    o.t = t_io[v];
+    o.begin(sample_rate, SB ? 0.0f : speed.c.get(v));
     const float *ins[1] = {SB ? speed.b.p + v : nullptr};
     const size_t istr[1] = {speed.b.stride};
     frame_loop<8, ZF, SB ? 1 : 0>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
-        val = t;                                                       // :41
-        if (SB) t += x[0] * isr; else t += step;                       // :42 / :53
-        t -= truncf(t);                                                // :43
+        val = o.template frame<SB>(x[0]);
         return true;
     });
-    t_io[v] = t;
+    t_io[v] = o.t;
 }
 
 // =================================================================== Portamento
@@ -410,32 +327,15 @@ __global__ void __launch_bounds__(kSeqBlock) k_portamento(float *__restrict__ t_
                                                           F32P goal_p, BoolP note_on, BoolP prev_note_on, BoolP nic) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    float t = t_io[v], last = last_io[v], st = start_io[v];
-    const float goal = goal_p.get(v);
-    const bool on = note_on.get(v);
-    const uint32_t tag = (on && prev_note_on.get(v)) ? curve_tag : (uint32_t)ZH_CURVE_INSTANTANEOUS;   // Portamento.zig:33-36
-    if (on && nic.get(v)) { st = last; t = 0.0f; }                                                   // :38-40 newCurve
-    // paintToward's entry (painter.zig:69-80), then either the glide or paintFlat(goal) (:43-47)
-    bool flat = false;
-    if (t >= 1.0f) flat = true;
-    else if (tag == ZH_CURVE_INSTANTANEOUS) { t = 1.0f; last = goal; flat = true; }
-    const float t_step = 1.0f / (duration.get(v) * sample_rate);                                     // painter.zig:97
+    PortamentoLane o;
+    o.t = t_io[v]; o.last = last_io[v]; o.st = start_io[v];
+    o.begin(sample_rate, curve_tag, duration.get(v), goal_p.get(v), note_on.get(v), prev_note_on.get(v), nic.get(v));
     const float *const *no_in = nullptr;
     frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        if (flat) { val = goal; return true; }
-        t += t_step;                                                   // painter.zig:103-116
-        const bool fin = t >= 1.0f;
-        t = fin ? 1.0f : t;
-        const float it = 1.0f - t;
-        float tp = t;
-        if (tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
-        else if (tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
-        last = st + tp * (goal - st);
-        val = last;
-        flat = fin;
+        val = o.frame();
         return true;
     });
-    t_io[v] = t; last_io[v] = last; start_io[v] = st;
+    t_io[v] = o.t; last_io[v] = o.last; start_io[v] = o.st;
 }
 
 // =================================================================== host side

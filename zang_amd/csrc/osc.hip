@@ -15,6 +15,7 @@
 #include "zmath.cuh"
 #include "dsp.cuh"
 #include "seq.cuh"
+#include "voices.cuh"
 #include <stdlib.h>
 #include <vector>
 
@@ -192,65 +193,23 @@ __global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restric
                                                              CImg freq_b, F32P color_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    uint32_t cnt = cnt_io[v];
-    PulseK k;
-    pulse_setup_color(k, color_p.get(v));
+    PulseOscLane o;
+    o.cnt = cnt_io[v];
+    o.srf = srf; o.sr8 = sr8;                                         // host-computed (same IEEE divides)
+    pulse_setup_color(o.k, color_p.get(v));
     const float *ins[1] = {freq_b.p + v};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
-        const float s_freq = x[0];
-        if (s_freq < 0 || s_freq > sr8) return false;                 // PulseOsc.zig:134-135
-        pulse_setup_freq(k, srf, s_freq);
-        val = pulse_sample(k, cnt);
-        cnt += k.ifreq;
-        return true;
-    });
-    cnt_io[v] = cnt;
+    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end,
+                         [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame_ctrl(x[0], val); });
+    cnt_io[v] = o.cnt;
 }
 
 // ------------------------------------------------------------------ TriSawOsc
-struct TriSawK {          // TriSawOsc.zig:90-99
-    uint32_t ifreq, brpt;
-    float f, omf, rcpf, col, c1, c2;
-};
-
-// TriSawOsc.zig:103-114 as value selects with the mask logic of pulse_sample:
-//   b0 == b1, no wrap  (3 / 0): c1|c2 * (p + p - f)                       c1 when b0 else c2
-//   b0 == b1, wrap     (7 / 4): -rcpf * (gain + (c1|c2 * omf) * (p + p + omf))
-//   b0 != b1           (2)    : rcpf * (c2*p^2 - c1*(p - f)^2)
-//                      (5)    : -rcpf * (gain + c2*(p + omf)^2 - c1*p^2)
-//   1 and 6 (`else => unreachable`) cannot occur for any u32 inputs (proof at pulse_sample).
-// Every arm is the reference's own expression, so the selected value has the reference's bits;
-// unselected arms may be inf/NaN (c1 = +inf when color == 0) and are discarded, never blended.
+// the formulas live in voices.cuh (trisaw_setup / trisaw_sample / trisaw_naive)
 struct TriSawOscP {
     using K = TriSawK;
-    static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) {   // TriSawOsc.zig:90-99
-        const float gain = 0.7f;
-        k.ifreq = zf32_to_u32(srf * freq);
-        k.brpt = zftou32(zclamp01(color));
-        k.f = zutof23(k.ifreq);
-        k.omf = 1.0f - k.f;
-        k.rcpf = 1.0f / k.f;
-        k.col = zutof23(k.brpt);
-        k.c1 = gain / k.col;
-        k.c2 = -gain / (1.0f - k.col);
-    }
-    static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) {
-        const float gain = 0.7f;
-        const float p = zutof23(cnt) - k.col;
-        const bool b0 = cnt < k.brpt;
-        const bool b1 = (uint32_t)(cnt - k.ifreq) < k.brpt;
-        const bool b2 = cnt < k.ifreq;
-        const float cx = b0 ? k.c1 : k.c2;
-        const float flat_nowrap = cx * (p + p - k.f);
-        const float flat_wrap = -k.rcpf * (gain + cx * k.omf * (p + p + k.omf));
-        const float ramp2 = k.rcpf * (k.c2 * (p * p) - k.c1 * ((p - k.f) * (p - k.f)));
-        const float ramp5 = -k.rcpf * (gain + k.c2 * ((p + k.omf) * (p + k.omf)) - k.c1 * (p * p));
-        const float flat = b2 ? flat_wrap : flat_nowrap;
-        const float ramp = b2 ? ramp5 : ramp2;
-        const float v = (b0 == b1) ? flat : ramp;
-        return gain + v;
-    }
+    static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) { trisaw_setup(k, srf, freq, color); }
+    static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return trisaw_sample(k, cnt); }
 };
 
 // TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt
@@ -260,27 +219,17 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict_
                                                               CImg freq_b, F32P color_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    float t = t_io[v];
-    const float color = color_p.get(v);
-    const bool saw = color < 0.25f || color > 0.75f;
-    const float gain = 0.7f;
+    TriSawOscLane o;
+    o.t = t_io[v];
+    o.begin_ctrl(sample_rate, color_p.get(v));
     const float *ins[1] = {freq_b.p + v};
     const size_t istr[1] = {freq_b.stride};
     frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
-        float frac;
-        if (saw) {
-            frac = (t - floorf(t)) * 2.0f - 1.0f;
-        } else {
-            frac = t - floorf(t);
-            if (frac < 0.25f) frac = frac * 4.0f;
-            else if (frac < 0.75f) frac = 1.0f - (frac - 0.25f) * 4.0f;
-            else frac = (frac - 0.75f) * 4.0f - 1.0f;
-        }
-        val = gain * frac;
-        t += x[0] / sample_rate;
+        val = o.frame_ctrl(x[0]);
         return true;
     });
-    t_io[v] = t - truncf(t);                                          // :155
+    o.end_ctrl();
+    t_io[v] = o.t;
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }

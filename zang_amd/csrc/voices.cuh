@@ -1,0 +1,347 @@
+// voices.cuh -- every builtin module as a per-lane object: state + begin() (the per-paint prologue)
+// + frame() (one sample) + end() (the per-paint epilogue).  The standalone module kernels
+// (modules.hip, osc.hip) and the fused kernels the zangscript backend generates (zangscript/emit_hip.py,
+// compiled by script.hip through hiprtc) are both built from these, so each of the reference's
+// formulas exists once on the device.  frame() returns the painted value; where a module can paint
+// nothing (silent oscillator, Gate off, Envelope idle ...) it returns `bool painted` and writes `val`.
+#pragma once
+#include "common.cuh"
+#include "zmath.cuh"
+#include "dsp.cuh"
+#include "envelope.cuh"
+
+// ---- SineOsc (src/modules/SineOsc.zig) -----------------------------------------------------------
+__device__ __forceinline__ float sine_osc_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }   // :4-6
+
+struct SineOscLane {
+    float t;                                                          // state (:16-22)
+    float t_step, inv_sr;
+    __device__ __forceinline__ void begin(float sample_rate, float freq_const) {
+        t_step = freq_const / sample_rate;                            // :44 (unused when freq is a buffer)
+        inv_sr = 1.0f / sample_rate;                                  // :66
+    }
+    template <bool FB> __device__ __forceinline__ float frame(float freq_i, float phase_i) {
+        const float val = sine_osc_sin(t + phase_i);
+        if (FB) t += freq_i * inv_sr; else t += t_step;
+        return val;
+    }
+    __device__ __forceinline__ void end() { t = t - truncf(t); }      // :40
+};
+
+// ---- PulseOsc (src/modules/PulseOsc.zig) ---------------------------------------------------------
+struct PulseOscLane {
+    uint32_t cnt;                                                     // state (:36-42)
+    PulseK k;
+    float srf, sr8;
+    bool bad;
+    // constant frequency (:77-121)
+    __device__ __forceinline__ void begin_const(float sample_rate, float freq, float color) {
+        srf = 4294967296.0f / sample_rate;                            // :87
+        sr8 = sample_rate / 8.0f;                                     // :82
+        bad = freq < 0 || freq > sr8;                                 // :82-84: paints nothing
+        pulse_setup_color(k, color);
+        pulse_setup_freq(k, srf, freq);
+    }
+    __device__ __forceinline__ bool frame_const(float &val) {
+        if (bad) return false;
+        val = pulse_sample(k, cnt);
+        cnt += k.ifreq;
+        return true;
+    }
+    // controlled frequency (:123-171): the per-voice constants are recomputed every sample
+    __device__ __forceinline__ void begin_ctrl(float sample_rate, float color) {
+        srf = 4294967296.0f / sample_rate;
+        sr8 = sample_rate / 8.0f;
+        pulse_setup_color(k, color);
+    }
+    __device__ __forceinline__ bool frame_ctrl(float s_freq, float &val) {
+        if (s_freq < 0 || s_freq > sr8) return false;                 // :134-135
+        pulse_setup_freq(k, srf, s_freq);
+        val = pulse_sample(k, cnt);
+        cnt += k.ifreq;
+        return true;
+    }
+};
+
+// ---- TriSawOsc (src/modules/TriSawOsc.zig) -------------------------------------------------------
+struct TriSawK {          // :90-99
+    uint32_t ifreq, brpt;
+    float f, omf, rcpf, col, c1, c2;
+};
+
+// TriSawOsc.zig:103-114 as value selects with the mask logic of pulse_sample:
+//   b0 == b1, no wrap  (3 / 0): c1|c2 * (p + p - f)                       c1 when b0 else c2
+//   b0 == b1, wrap     (7 / 4): -rcpf * (gain + (c1|c2 * omf) * (p + p + omf))
+//   b0 != b1           (2)    : rcpf * (c2*p^2 - c1*(p - f)^2)
+//                      (5)    : -rcpf * (gain + c2*(p + omf)^2 - c1*p^2)
+//   1 and 6 (`else => unreachable`) cannot occur for any u32 inputs (proof at pulse_sample).
+// Every arm is the reference's own expression, so the selected value has the reference's bits;
+// unselected arms may be inf/NaN (c1 = +inf when color == 0) and are discarded, never blended.
+__device__ __forceinline__ void trisaw_setup(TriSawK &k, float srf, float freq, float color) {   // :90-99
+    const float gain = 0.7f;
+    k.ifreq = zf32_to_u32(srf * freq);
+    k.brpt = zftou32(zclamp01(color));
+    k.f = zutof23(k.ifreq);
+    k.omf = 1.0f - k.f;
+    k.rcpf = 1.0f / k.f;
+    k.col = zutof23(k.brpt);
+    k.c1 = gain / k.col;
+    k.c2 = -gain / (1.0f - k.col);
+}
+__device__ __forceinline__ float trisaw_sample(const TriSawK &k, uint32_t cnt) {
+    const float gain = 0.7f;
+    const float p = zutof23(cnt) - k.col;
+    const bool b0 = cnt < k.brpt;
+    const bool b1 = (uint32_t)(cnt - k.ifreq) < k.brpt;
+    const bool b2 = cnt < k.ifreq;
+    const float cx = b0 ? k.c1 : k.c2;
+    const float flat_nowrap = cx * (p + p - k.f);
+    const float flat_wrap = -k.rcpf * (gain + cx * k.omf * (p + p + k.omf));
+    const float ramp2 = k.rcpf * (k.c2 * (p * p) - k.c1 * ((p - k.f) * (p - k.f)));
+    const float ramp5 = -k.rcpf * (gain + k.c2 * ((p + k.omf) * (p + k.omf)) - k.c1 * (p * p));
+    const float flat = b2 ? flat_wrap : flat_nowrap;
+    const float ramp = b2 ? ramp5 : ramp2;
+    const float v = (b0 == b1) ? flat : ramp;
+    return gain + v;
+}
+// the naive saw / triangle of the controlled-frequency path (:120-156): uses the f32 phase, ignores cnt
+__device__ __forceinline__ float trisaw_naive(float t, bool saw) {
+    float frac;
+    if (saw) {
+        frac = (t - floorf(t)) * 2.0f - 1.0f;
+    } else {
+        frac = t - floorf(t);
+        if (frac < 0.25f) frac = frac * 4.0f;
+        else if (frac < 0.75f) frac = 1.0f - (frac - 0.25f) * 4.0f;
+        else frac = (frac - 0.75f) * 4.0f - 1.0f;
+    }
+    return 0.7f * frac;
+}
+
+struct TriSawOscLane {
+    uint32_t cnt;                                                     // state (:36-44)
+    float t;
+    TriSawK k;
+    float sample_rate;
+    bool bad, saw;
+    __device__ __forceinline__ void begin_const(float sr, float freq, float color) {
+        bad = freq < 0 || freq > sr / 8.0f;                           // :84-86
+        trisaw_setup(k, 4294967296.0f / sr, freq, color);
+    }
+    __device__ __forceinline__ bool frame_const(float &val) {
+        if (bad) return false;
+        val = trisaw_sample(k, cnt);
+        cnt += k.ifreq;
+        return true;
+    }
+    __device__ __forceinline__ void begin_ctrl(float sr, float color) {
+        sample_rate = sr;
+        saw = color < 0.25f || color > 0.75f;                         // :137-150
+    }
+    __device__ __forceinline__ float frame_ctrl(float s_freq) {
+        const float val = trisaw_naive(t, saw);
+        t += s_freq / sample_rate;
+        return val;
+    }
+    __device__ __forceinline__ void end_ctrl() { t = t - truncf(t); } // :155
+};
+
+// ---- Noise (src/modules/Noise.zig) ---------------------------------------------------------------
+struct NoiseLane {
+    ZXoshiro r;                                                       // state (:22-32)
+    float b[7];                                                       // `var b = self.b` (:55): never written back (:68) => always 0
+    __device__ __forceinline__ void begin() {
+#pragma unroll
+        for (int j = 0; j < 7; j++) b[j] = 0.0f;
+    }
+    template <bool PINK> __device__ __forceinline__ float frame() {
+        const float white = zrandom_float32(r) * 2.0f - 1.0f;         // :51 / :58
+        return PINK ? pink_step(b, white) : white;                    // :59-66
+    }
+};
+
+// ---- Filter (src/modules/Filter.zig) -------------------------------------------------------------
+struct FilterLane {
+    float l, b;                                                       // state (:34-42)
+    float cut, res, l_mul, b_mul, h_mul;
+    bool bypass;
+    __device__ __forceinline__ void begin(uint32_t type, float cutoff_const, float res_const) {
+        bypass = type == ZH_FILTER_BYPASS;                            // :91-97: out += in, state untouched
+        l_mul = (type == ZH_FILTER_LOW_PASS || type == ZH_FILTER_NOTCH || type == ZH_FILTER_ALL_PASS) ? 1.0f : 0.0f;   // :98-109
+        b_mul = (type == ZH_FILTER_BAND_PASS || type == ZH_FILTER_ALL_PASS) ? 1.0f : 0.0f;
+        h_mul = (type == ZH_FILTER_HIGH_PASS || type == ZH_FILTER_NOTCH || type == ZH_FILTER_ALL_PASS) ? 1.0f : 0.0f;
+        cut = zclampf(cutoff_const, 0.0f, 1.0f);                      // :114
+        res = 1.0f - zclampf(res_const, 0.0f, 1.0f);                  // :118
+    }
+    template <bool CB, bool RB> __device__ __forceinline__ float frame(float x, float cutoff_i, float res_i) {
+        if (bypass) return x;
+        if (CB) cut = zclampf(cutoff_i, 0.0f, 1.0f);                  // :126
+        if (RB) res = 1.0f - zclampf(res_i, 0.0f, 1.0f);              // :128
+        const SvfOut s = svf_step(l, b, x, cut, res);                 // :135-144
+        return s.l * l_mul + s.b * b_mul + s.h * h_mul;               // :146
+    }
+};
+
+// ---- Decimator (src/modules/Decimator.zig) -------------------------------------------------------
+struct DecimatorLane {
+    float dval, dcount;                                               // state (:11-19): dval = 0, dcount = 1
+    int mode;
+    float ratio;
+    __device__ __forceinline__ void begin(float sample_rate, float fake) {
+        mode = fake >= sample_rate ? 0 : (fake > 0.0f ? 1 : 2);       // :34, :39
+        ratio = fake / sample_rate;                                   // :40
+    }
+    __device__ __forceinline__ bool frame(float x, float &val) {
+        if (mode == 0) { val = x; return true; }                      // :35 addInto
+        if (mode == 2) return false;                                  // fake <= 0 (or NaN): paints nothing
+        dcount += ratio;                                              // :46
+        if (dcount >= 1.0f) { dval = x; dcount -= 1.0f; }             // :47-50
+        val = dval;                                                   // :51
+        return true;
+    }
+    __device__ __forceinline__ void end() {
+        if (mode == 0) { dval = 0.0f; dcount = 1.0f; }                // :37-38
+    }
+};
+
+// ---- Distortion (src/modules/Distortion.zig), stateless ------------------------------------------
+struct DistortionLane {
+    float gain1, offs, gain2;
+    bool overdrive;
+    __device__ __forceinline__ void begin(uint32_t type, float ingain, float outgain, float offset) {
+        overdrive = type == ZH_DISTORTION_OVERDRIVE;
+        gain1 = zpowf_pos(2.0f, ingain * 8.0f - 2.0f);                // :41
+        offs = gain1 * offset;
+        gain2 = overdrive ? outgain / zatanf(gain1) : outgain;        // :45 / :55
+    }
+    __device__ __forceinline__ float frame(float x) {
+        const float a0 = x * gain1 + offs;
+        if (overdrive) return gain2 * zatanf(a0);                     // :50-51
+        return gain2 * (a0 < -1.0f ? -1.0f : (a0 > 1.0f ? 1.0f : a0));   // :60-62
+    }
+};
+
+// ---- Cycle (src/modules/Cycle.zig) ---------------------------------------------------------------
+struct CycleLane {
+    float t;                                                          // state
+    float step, isr;
+    __device__ __forceinline__ void begin(float sample_rate, float speed_const) {
+        step = speed_const / sample_rate;                             // :37
+        isr = 1.0f / sample_rate;                                     // :48
+    }
+    template <bool SB> __device__ __forceinline__ float frame(float speed_i) {
+        const float val = t;                                          // :41
+        if (SB) t += speed_i * isr; else t += step;                   // :42 / :53
+        t -= truncf(t);                                               // :43
+        return val;
+    }
+};
+
+// ---- Portamento (src/modules/Portamento.zig over painter.zig) ------------------------------------
+struct PortamentoLane {
+    float t, last, st;                                                // state: painter {t, last_value, start}
+    float goal, t_step;
+    uint32_t tag;
+    bool flat;
+    __device__ __forceinline__ void begin(float sample_rate, uint32_t curve_tag, float duration, float goal_, bool note_on,
+                                          bool prev_note_on, bool note_id_changed) {
+        goal = goal_;
+        tag = (note_on && prev_note_on) ? curve_tag : (uint32_t)ZH_CURVE_INSTANTANEOUS;   // :33-36
+        if (note_on && note_id_changed) { st = last; t = 0.0f; }                          // :38-40 newCurve
+        // paintToward's entry (painter.zig:69-80), then either the glide or paintFlat(goal) (:43-47)
+        flat = false;
+        if (t >= 1.0f) flat = true;
+        else if (tag == ZH_CURVE_INSTANTANEOUS) { t = 1.0f; last = goal; flat = true; }
+        t_step = 1.0f / (duration * sample_rate);                                          // painter.zig:97
+    }
+    __device__ __forceinline__ float frame() {
+        if (flat) return goal;
+        t += t_step;                                                   // painter.zig:103-116
+        const bool fin = t >= 1.0f;
+        t = fin ? 1.0f : t;
+        const float it = 1.0f - t;
+        float tp = t;
+        if (tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
+        else if (tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
+        last = st + tp * (goal - st);
+        flat = fin;
+        return last;
+    }
+};
+
+// ---- Curve (src/modules/Curve.zig) ---------------------------------------------------------------
+struct CurveSpanNode { int32_t frame; float value; };                  // :11-14
+
+// Per paint the lane first builds its (<= 32) span nodes (getCurveSpanNodes, :130-184), then walks the
+// span frame by frame; whenever the running curve span ends it looks up the next one
+// (getNextCurveSpan, :188-255) -- the reference's `while (start < out.len)` loop, re-expressed per
+// frame so that all lanes stay on the same frame.
+struct CurveLane {
+    float t;                                                          // state (:36-49)
+    uint32_t cur, next;
+    int32_t off;
+    CurveSpanNode nodes[32];
+    uint32_t count, out_len, function, span_end;
+    bool has_values;
+    float acc, step, start_value, value_delta;
+
+    __device__ __forceinline__ void begin(float sample_rate, uint32_t function_, const zh_curve_node *__restrict__ curve,
+                                          uint32_t n_curve, uint32_t out_len_, bool note_id_changed) {
+        function = function_;
+        out_len = out_len_;
+        if (note_id_changed) { cur = 0; off = 0; next = 0; t = 0.0f; }   // :66-71
+        count = 0;
+        const float buf_time = (float)out_len / sample_rate;          // getCurveSpanNodes
+        const float end_t = t + buf_time;
+        if (cur < next) { nodes[count].frame = off; nodes[count].value = curve[cur].value; count++; }   // :142-148
+        bool one_past = false;
+        for (uint32_t k = next; k < n_curve; k++) {
+            const float note_t = curve[k].t;
+            if (note_t >= end_t) { if (!one_past) one_past = true; else break; }                         // :153-160
+            const float f = (note_t - t) / buf_time;
+            const int32_t rel = zf32_to_i32(f * (float)out_len);
+            if (count > 0 && nodes[count - 1].frame == rel) count--;                                    // :165-167
+            if (count < 32) { nodes[count].frame = rel; nodes[count].value = curve[k].value; count++; }
+            if (!one_past) { cur = next; off = 0; next += 1; }                                          // :173-177
+        }
+        t += buf_time;                                                 // :180
+        off -= (int32_t)out_len;                                       // :181
+        span_end = 0;
+        has_values = false;
+        acc = step = start_value = value_delta = 0.0f;
+    }
+    // getNextCurveSpan + the per-span setup of :84-107
+    __device__ __forceinline__ void next_span(uint32_t dest_start_) {
+        const int32_t dest_start = (int32_t)dest_start_, dest_end = (int32_t)out_len;
+        has_values = false;
+        span_end = out_len;
+        for (uint32_t i = 0; i < count; i++) {
+            const int32_t start_pos = nodes[i].frame;
+            if (start_pos >= dest_end) break;
+            const int32_t end_pos = (i + 1 < count) ? min(dest_end, nodes[i + 1].frame) : dest_end;
+            if (end_pos <= dest_start) continue;
+            const int32_t note_start_clipped = start_pos > dest_start ? start_pos : dest_start;
+            if (note_start_clipped > dest_start) { span_end = (uint32_t)note_start_clipped; return; }   // gap
+            span_end = (uint32_t)(end_pos > dest_end ? dest_end : end_pos);
+            if (i + 1 < count) {
+                has_values = true;
+                const int32_t fstart = nodes[i].frame, fend = nodes[i + 1].frame;
+                const float start_x = (float)(dest_start - fstart) / (float)(fend - fstart);           // :95
+                start_value = nodes[i].value;
+                value_delta = nodes[i + 1].value - nodes[i].value;
+                const float x_step = 1.0f / (float)(fend - fstart);                                     // :100
+                if (function == ZH_CURVE_FN_LINEAR) { acc = start_value + start_x * value_delta; step = x_step * value_delta; }
+                else { acc = start_x; step = x_step; }
+            }
+            return;
+        }
+    }
+    // r = frame index relative to the paint span's start
+    __device__ __forceinline__ bool frame(uint32_t r, float &val) {
+        if (r == span_end) next_span(r);
+        if (!has_values) return false;
+        if (function == ZH_CURVE_FN_LINEAR) { val = acc; acc += step; }                                 // :109-112
+        else { val = start_value + acc * acc * (3.0f - 2.0f * acc) * value_delta; acc += step; }       // :117-121
+        return true;
+    }
+};

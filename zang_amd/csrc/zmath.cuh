@@ -13,7 +13,10 @@
 // emits none for these loops) and without fast-math.
 #pragma once
 #include <hip/hip_runtime.h>
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#endif
+#include "rtc_types.cuh"
 
 #define ZD __device__ __forceinline__
 
