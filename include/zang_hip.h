@@ -425,6 +425,49 @@ ZH_API int zh_pmosc_paint(zh_pmosc *m, uint32_t span_start, uint32_t span_end, c
 ZH_API int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                                 const zh_buf *temps, float sample_rate, const zh_span_table *table, uint32_t flags);
 
+/* ---------------------------------------------------------------- zangscript modules
+ * The reference compiles its module DSL to Zig source (tools/zangc.zig -> src/zangscript/codegen_zig.zig) that is
+ * then built into the host program.  Here the same front-end (python -m zang_amd.zangc, zang_amd/zangscript/)
+ * emits HIP source with ONE fused lane-per-voice kernel per exported module -- every temp buffer of the
+ * generated Zig paint() becomes a per-frame register -- and this loader compiles it for gfx950 with hiprtc
+ * and runs it.  The call shape stays the module contract of SineOsc.zig:8-31: paint(span, outputs, temps,
+ * note_id_changed, params), with the script module's Params (codegen_zig.zig:520-527) passed as an array of
+ * zh_script_param in declaration order (index 0 is the implicit `sample_rate`, parse.zig:330-331). */
+enum { ZH_SP_CONSTANT = 0,   /* f32: `f`, or `pf` per voice                                         */
+       ZH_SP_BOOLEAN = 1,    /* bool: `u`, or `pb` per voice                                        */
+       ZH_SP_COB = 2,        /* zang.ConstantOrBuffer: is_buffer ? image pf/stride : constant f|pf   */
+       ZH_SP_BUFFER = 3,     /* []const f32 ("waveform"): image pf/stride                           */
+       ZH_SP_ENUM = 4,       /* one_of: `u` = index of the value in the enum's declaration order,
+                                `f` = its f32 payload if it has one (PaintCurve durations)          */
+       ZH_SP_CURVE = 5 };    /* []const zang.CurveNode: pf = DEVICE zh_curve_node array, u = count  */
+typedef struct zh_script_param {
+    uint32_t kind, u;
+    float f;
+    uint32_t is_buffer;
+    const float *pf;
+    const uint8_t *pb;
+    uint32_t stride, reserved;
+} zh_script_param;
+#define ZH_SCRIPT_MAX_PARAMS 16
+
+typedef struct zh_script zh_script;                 /* one compiled + loaded script (a hipModule) */
+typedef struct zh_script_module zh_script_module;   /* n_voices instances of one exported module */
+/* Compile only (no GPU needed): returns a malloc'ed gfx950 code object, or the compiler log in `log`. */
+ZH_API int zh_script_compile(const char *hip_source, void **code_out, size_t *code_size_out, char *log, size_t log_cap);
+ZH_API void zh_script_free_code(void *code);
+ZH_API int zh_script_load(zh_ctx *ctx, const char *hip_source, zh_script **out, char *log, size_t log_cap);
+ZH_API int zh_script_destroy(zh_script *s);
+/* `name` = the exported module's global name; `state_words` = 32-bit state words per voice as reported by the
+ * front-end; Noise fields are seeded first_seed + voice * n_noise_fields + k (Noise.zig:25-29: one counter tick
+ * per init(), instances created voice by voice). */
+ZH_API int zh_script_module_create(zh_script *s, const char *name, uint32_t n_voices, uint32_t state_words,
+                                   uint64_t first_seed, zh_script_module **out);
+ZH_API int zh_script_module_destroy(zh_script_module *m);
+ZH_API int zh_script_module_get_state(zh_script_module *m, uint32_t *host_words);         /* [word][voice] */
+ZH_API int zh_script_module_set_state(zh_script_module *m, const uint32_t *host_words);
+ZH_API int zh_script_module_paint(zh_script_module *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
+                                  zh_bool note_id_changed, const zh_script_param *params, uint32_t n_params, uint32_t flags);
+
 /* ---------------------------------------------------------------- event scheduling (host side; no GPU work)
  * The immediate caller of every paint: song / key events -> impulses ->
  * per-voice (span, params, note_id_changed) tuples.  A C++ restatement of src/zang/notes.zig and

@@ -1,0 +1,382 @@
+"""zangscript.
+
+CPU: the front-end against the reference's golden generated text (src/zangscript/tests.zig:44-92 -- the
+only reference-held vector for this subsystem), tokenizer / parser / codegen behaviours and error
+messages, the instruction list of the repo-authored test script, the oracle-side interpreter against
+plain numpy, and that the generated HIP compiles for gfx950 (hiprtc needs no GPU).
+GPU: every module of the test script, fused kernel vs the oracle-side interpreter, bit for bit, over
+several consecutive paints (carried state, sub-spans, note on/off, retrigger)."""
+import os
+
+import numpy as np
+import pytest
+
+from zang_amd import zangscript as zs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCRIPT = open(os.path.join(HERE, "golden", "script_modules.txt")).read()
+
+GOLDEN_SOURCE = """Instrument = defmodule
+    freq: cob,
+begin
+    out freq * 2
+end"""
+GOLDEN_ZIG = open(os.path.join(HERE, "golden", "zangscript_example_test.zig.txt")).read()
+
+
+# ------------------------------------------------------------------------------------------ CPU
+def test_reference_golden_generated_text():
+    """tests.zig "example test": only the zang builtin package, like compileScript there (:5-8)."""
+    got = zs.generate_zig(zs.compile(GOLDEN_SOURCE, packages=(zs.zang_builtin_package,)))
+    assert got == GOLDEN_ZIG
+
+
+def test_tokenizer():
+    from zang_amd.zangscript.errors import Source
+    from zang_amd.zangscript.tokenize import Tokenizer
+    t = Tokenizer(Source("t", "a_1 = .cubed(0.5) // note\n  -3*pi begin end\r\nx"))
+    kinds = []
+    while True:
+        tok = t.next()
+        kinds.append(tok.tt)
+        if tok.tt == "end_of_file":
+            break
+    assert kinds == ["name", "sym_equals", "enum_value", "sym_left_paren", "number", "sym_right_paren", "sym_minus", "number",
+                     "sym_asterisk", "name", "kw_begin", "kw_end", "name", "end_of_file"]
+    assert t.line == 2                                       # LF, CRLF
+
+
+@pytest.mark.parametrize("src,msg", [
+    ("X = defmodule\nbegin\n out .\nend", "dot must be followed by an identifier"),
+    ("X = defmodule\nbegin\n out 1.2.3\nend", "malformatted number"),
+    ("X = defmodule\n pi: constant,\nbegin\nend", "`pi` is a reserved name"),
+    ("X = defmodule\n a: constant,\n a: cob,\nbegin\nend", "redeclaration of param `a`"),
+    ("X = defmodule\n a: nothing,\nbegin\nend", "expected param type, found `nothing`"),
+    ("X = defmodule\nbegin\n out 1\n", "expected local declaration, `out`, `feedback` or `end`, found end of file"),
+    ("X = 1\nX = 2", "redeclaration of global `X`"),
+    ("X = defmodule\nbegin\n out y\nend", "use of undeclared identifier `y`"),
+    ("X = defmodule\nbegin\n out SineOsc(freq=1)\nend", "argument list is missing param `phase`"),
+    ("X = defmodule\nbegin\n out SineOsc(freq=1, phase=0, foo=1)\nend", "call target has no param called `foo`"),
+    ("X = defmodule\nbegin\n out SineOsc(freq=1, phase=0, phase=0)\nend", "param `phase` provided more than once"),
+    ("X = defmodule\nbegin\n out SineOsc(freq=true, phase=0)\nend", "expected float or buffer value"),
+    ("X = defmodule\nbegin\n out Noise(color=.purple)\nend", "expected one of 'white', 'pink'"),
+    ("X = defmodule\nbegin\n out Envelope(attack=.cubed, decay=.linear(1), release=.linear(1), sustain_volume=1, note_on=true)\nend",
+     "expected one of 'instantaneous', 'linear'(number), 'squared'(number), 'cubed'(number)"),
+    ("X = defmodule\nbegin\n out true\nend", "expected buffer value, found boolean"),
+    ("X = defmodule\nbegin\n out true + 1\nend", "arithmetic can only be performed on numeric types"),
+    ("X = defmodule\nbegin\n feedback 1\nend", "`feedback` can only be used within a `delay` operation"),
+    ("Y = 1 + 2", "constant arithmetic is not supported"),
+    ("A = B\nB = A", "circular reference in global"),
+    ("X = defmodule\nbegin\n out 3(a=1)\nend", "not a module"),
+    ("C = defcurve 0 1 0 2 end", "time value must be greater than the previous time value"),
+    ("T = deftrack f: cob, begin end", "track param cannot be cob or waveform"),
+    ("X = defmodule\nbegin\n out delay 10 begin out delay 5 begin out 1 end end\nend", "you cannot nest delay operations"),
+])
+def test_compile_errors(src, msg):
+    with pytest.raises(zs.ScriptError) as e:
+        zs.compile(src)
+    assert msg in str(e.value)
+    assert "script.txt:" in str(e.value)
+
+
+def test_error_location_and_carets():
+    with pytest.raises(zs.ScriptError) as e:
+        zs.compile("X = defmodule\nbegin\n    out foo * 2\nend")
+    text = str(e.value)
+    assert text.startswith("script.txt:3:9: use of undeclared identifier `foo`")
+    assert "    out foo * 2\n        ^^^" in text
+
+
+def test_instruction_lists_and_temps():
+    s = zs.compile(SCRIPT)
+    names = [n for n, _ in s.exported_modules]
+    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths"]
+    r = s.module_results[s.module_index("Doubler")]
+    assert (r.num_temps, r.num_temp_floats, [i.kind for i in r.instructions]) == (1, 0, ["cob_to_buffer", "arith_buffer_float"])
+    assert r.instructions[1].out.kind == "output"           # written straight into the result location
+    r = s.module_results[s.module_index("Pluck")]
+    assert [i.kind for i in r.instructions] == ["cob_to_buffer", "call", "arith_buffer_float", "arith_float_buffer", "call",
+                                                "arith_buffer_buffer", "arith_buffer_float"]
+    assert r.num_temps == 3 and [s.modules[f].builtin_name for f in r.fields] == ["SineOsc", "Envelope"]
+    # a script module calling script modules: the callee's temps are claimed from the caller (codegen.zig:540-543)
+    lead = s.module_results[s.module_index("Lead")]
+    call = [i for i in lead.instructions if i.kind == "call"][0]
+    assert len(call.temps) == s.module_results[s.module_index("Bell")].num_temps
+    # temp floats are never reused (they become `const` in Zig, codegen.zig:788-792)
+    maths = s.module_results[s.module_index("Maths")]
+    assert maths.num_temp_floats == len([i for i in maths.instructions if i.kind in ("arith_float", "arith_float_float")])
+    # shadowing: `freq = freq * 0.5` reads the param, later uses read the local
+    bell = s.module_results[s.module_index("Bell")]
+    assert bell.instructions[0].kind == "cob_to_buffer" and bell.instructions[1].kind == "arith_buffer_float"
+
+
+def test_generated_zig_of_test_script_is_stable():
+    text = zs.generate_zig(zs.compile(SCRIPT))
+    assert "pub const Lead = _module16;" in text
+    assert "zang.multiplyScalar(span, temps[0], temps[1], 0.25);" in text
+    assert ".type = params.ftype," in text                   # `type` is a primitive's name, not a Zig keyword token
+    from zang_amd.zangscript.emit_zig import ident
+    assert ident("error") == '@"error"' and ident("freq") == "freq"   # keyword escaping (codegen_zig.zig:40-46)
+    assert "std.math.pow(f32, temps[" in text and "const temp_float" in text
+
+
+def test_operator_precedence_and_negation():
+    s = zs.compile("M = defmodule\n a: constant,\nbegin\n out -a + 2 * 3 - 4 / a\nend")
+    ins = s.module_results[s.module_index("M")].instructions
+    assert [(i.kind, i.op) for i in ins] == [("arith_float", "neg"), ("arith_float_float", "mul"), ("arith_float_float", "add"),
+                                             ("arith_float_float", "div"), ("arith_float_float", "sub"), ("float_to_buffer", None)]
+
+
+def _interp_paint(script, name, params, frames=64, nic=True, voices=1, first_seed=0):
+    from oracle import zs_interp
+    vs = zs_interp.make_voices(script, name, voices, first_seed)
+    outs = []
+    for v in vs:
+        out = np.zeros(frames, np.float32)
+        v.paint(0, frames, out, nic, params)
+        outs.append(out)
+    return outs
+
+
+def test_interpreter_against_numpy(oracle):
+    s = zs.compile(SCRIPT)
+    f = np.linspace(100, 200, 64).astype(np.float32)
+    assert np.array_equal(_interp_paint(s, "Doubler", [np.float32(48000), f])[0], f * np.float32(2))
+    assert np.array_equal(_interp_paint(s, "Doubler", [np.float32(48000), np.float32(3)])[0], np.full(64, 6, np.float32))
+    x = np.linspace(-1, 1, 64).astype(np.float32)
+    k = np.float32(0.7)
+    L = oracle.lib()
+    small = zs.compile("""
+A = defmodule x: waveform, k: constant, begin out x - k end
+B = defmodule x: waveform, begin out min(x, 0.1) / (2 + cos(x)) end
+C = defmodule x: waveform, k: constant, begin out pow(abs(x), 0.5) + sqrt(k * 4) + -k end
+""")
+    z = np.zeros(64, np.float32)
+    same = lambda got, want: np.array_equal(got.view(np.uint32), np.asarray(want, np.float32).view(np.uint32))
+    assert same(_interp_paint(small, "A", [np.float32(48000), x, k])[0], z + (x - k))
+    cos = np.array([L.zo_math_cosf(float(v)) for v in x], np.float32)
+    assert same(_interp_paint(small, "B", [np.float32(48000), x])[0],
+                z + np.where(x < np.float32(0.1), x, np.float32(0.1)) / (z + (cos + np.float32(2))))
+    pw = np.array([L.zo_math_powf(float(abs(v)), 0.5) for v in x], np.float32)
+    f0 = np.float32(k * np.float32(4)); f1 = np.float32(np.sqrt(f0)); f2 = np.float32(-k)
+    assert same(_interp_paint(small, "C", [np.float32(48000), x, k])[0], z + ((z + (pw + f1)) + f2))
+
+
+def test_interpreter_matches_direct_oracle_calls(oracle):
+    """Pluck through the interpreter == the same three oracle calls made by hand."""
+    import ctypes as C
+    s = zs.compile(SCRIPT)
+    got = _interp_paint(s, "Pluck", [np.float32(48000), np.float32(440), True], frames=256)[0]
+    L = oracle.lib()
+    osc, env = oracle.SineOsc(), oracle.Envelope()
+    L.zo_sineosc_init(C.byref(osc)); L.zo_envelope_init(C.byref(env))
+    t = [np.zeros(256, np.float32) for _ in range(3)]
+    L.zo_set(0, 256, oracle.fptr(t[0]), 440.0)
+    L.zo_sineosc_paint(C.byref(osc), 0, 256, oracle.fptr(t[1]), 48000.0, oracle.buffer(t[0]), oracle.constant(0.0))
+    t[0][:] = 0; L.zo_multiply_scalar(0, 256, oracle.fptr(t[0]), oracle.fptr(t[1]), 0.25)
+    t[1] = np.where(np.float32(0) > t[0], np.float32(0), t[0]).astype(np.float32)
+    t[0][:] = 0
+    p = oracle.EnvelopeParams(48000.0, oracle.curve(3, 0.02), oracle.curve(2, 0.15), oracle.curve(1, 0.8), 0.6, 1)
+    L.zo_envelope_paint(C.byref(env), 0, 256, oracle.fptr(t[0]), 1, C.byref(p))
+    t[2][:] = 0; L.zo_multiply(0, 256, oracle.fptr(t[2]), oracle.fptr(t[1]), oracle.fptr(t[0]))
+    out = np.zeros(256, np.float32)
+    L.zo_multiply_scalar(0, 256, oracle.fptr(out), oracle.fptr(t[2]), float(np.float32(np.pi)))
+    assert np.array_equal(got.view(np.uint32), out.view(np.uint32))
+
+
+def test_generated_hip_compiles_for_gfx950():
+    from zang_amd import script
+    src, meta = zs.generate_hip(zs.compile(SCRIPT))
+    assert all("error" not in m for m in meta.values())
+    assert meta["Hiss"]["noise_fields"] == 2 and meta["Hiss"]["state_words"] == 18
+    assert meta["Lead"]["state_words"] == meta["Bell"]["state_words"] + meta["Pluck"]["state_words"]
+    assert script.compile_hip(src) > 10000
+
+
+def test_unsupported_constructs_are_reported_not_miscompiled():
+    src = """Echo = defmodule
+    input: waveform,
+begin
+    out delay 100 begin
+        out input + feedback * 0.5
+        feedback input
+    end
+end"""
+    s = zs.compile(src)                                       # the front-end handles it (4 temps, codegen.zig:628-690)
+    assert s.module_results[s.module_index("Echo")].delays == [100]
+    assert "readDelayBuffer" in zs.generate_zig(s)
+    _, meta = zs.generate_hip(s)
+    assert "not supported by the HIP backend" in meta["Echo"]["error"]
+
+
+def test_hiprtc_errors_are_reported():
+    from zang_amd import script
+    with pytest.raises(script.ScriptCompileError) as e:
+        script.compile_hip('#include "script_rt.cuh"\nextern "C" __global__ void k() { undefined_fn(); }\n')
+    assert "undefined_fn" in str(e.value)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+F = 96
+V = 70          # one full wave + a partial one
+
+
+def _per_voice(value, v):
+    if isinstance(value, np.ndarray) and value.ndim >= 1 and value.shape[0] == V:
+        x = value[v]
+        if isinstance(x, np.ndarray):
+            return x
+        return bool(x) if value.dtype == np.bool_ else np.float32(x)
+    return value
+
+
+def _device_value(kind, value):
+    import torch
+    from tests.util import to_image
+    if isinstance(value, np.ndarray) and value.ndim == 2:
+        return to_image(value)
+    if isinstance(value, np.ndarray) and value.dtype == np.bool_:
+        return torch.from_numpy(value.astype(np.uint8)).cuda()
+    if isinstance(value, np.ndarray):
+        return torch.from_numpy(value.astype(np.float32)).cuda()
+    return value
+
+
+def _parity(ctx, name, paints, first_seed=0, add_into=None):
+    """paints: [(start, end, nic, {param: value})]; value = scalar | bool | [V] array | [V][F] array |
+    (label, payload) | [(t, value)]; nic = bool or [V] bool array."""
+    import torch
+    from oracle import zs_interp
+    from tests.util import assert_bitexact, from_image, to_image
+    from zang_amd import script, zang
+    prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
+    mod = prog.module(name, V, first_seed)
+    voices = zs_interp.make_voices(prog.script, name, V, first_seed)
+    base = np.zeros((V, F), np.float32) if add_into is None else add_into.copy()
+    ref = base.copy()
+    img = to_image(base)
+    order = [p[0] for p in mod.params]
+    for start, end, nic, params in paints:
+        dev = {k: _device_value(None, v) for k, v in params.items()}
+        nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda() if isinstance(nic, np.ndarray) else nic
+        mod.paint(zang.Span(start, end), [img], None, nic_dev, dev)
+        for v in range(V):
+            voices[v].paint(start, end, ref[v], bool(nic[v]) if isinstance(nic, np.ndarray) else nic,
+                            [_per_voice(params[k], v) for k in order])
+    ctx.sync()
+    assert_bitexact(from_image(img), ref, name)
+    prog.close()
+    return ref
+
+
+def _freqs(seed=1):
+    return np.random.default_rng(seed).uniform(60, 3000, V).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_gpu_doubler_const_and_buffer(ctx):
+    rng = np.random.default_rng(0)
+    buf = rng.uniform(-2, 2, (V, F)).astype(np.float32)
+    _parity(ctx, "Doubler", [(0, F, False, {"sample_rate": 48000.0, "freq": buf})], add_into=rng.uniform(-1, 1, (V, F)).astype(np.float32))
+    _parity(ctx, "Doubler", [(0, 40, False, {"sample_rate": 48000.0, "freq": _freqs()}), (40, F, False, {"sample_rate": 48000.0, "freq": 3.5})])
+
+
+@pytest.mark.gpu
+def test_gpu_pluck_note_cycle(ctx):
+    on = np.random.default_rng(2).random(V) < 0.7
+    f = _freqs()
+    p = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
+    _parity(ctx, "Pluck", [(0, 50, True, p(on)), (50, 64, False, p(on)), (64, 80, False, p(~on | on & False)), (80, F, on, p(on))])
+
+
+@pytest.mark.gpu
+def test_gpu_cycle_sine(ctx):
+    rng = np.random.default_rng(3)
+    ph = rng.uniform(0, 1, (V, F)).astype(np.float32)
+    _parity(ctx, "CycleSine", [(0, 33, False, {"sample_rate": 44100.0, "freq": _freqs(), "phase": ph}),
+                               (33, F, False, {"sample_rate": 44100.0, "freq": rng.uniform(50, 900, (V, F)).astype(np.float32), "phase": 0.25})])
+
+
+@pytest.mark.gpu
+def test_gpu_bell_and_lead_inlined_modules(ctx):
+    on = np.ones(V, bool)
+    f = _freqs(4)
+    for name in ("Bell", "Lead"):
+        p = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
+        _parity(ctx, name, [(0, 64, True, p(on)), (64, 80, False, p(~on)), (80, F, True, p(on))])
+
+
+@pytest.mark.gpu
+def test_gpu_hiss_noise_seeds_and_runtime_filter_type(ctx):
+    cut = np.random.default_rng(5).uniform(0.05, 0.9, V).astype(np.float32)
+    for ftype in ("low_pass", "notch", "bypass"):
+        _parity(ctx, "Hiss", [(0, 48, False, {"sample_rate": 48000.0, "cut": cut, "ftype": (ftype, None)}),
+                              (48, F, False, {"sample_rate": 48000.0, "cut": 0.2, "ftype": (ftype, None)})], first_seed=1234)
+
+
+@pytest.mark.gpu
+def test_gpu_buzz_oscillators_both_paths(ctx):
+    f = _freqs(6)
+    f[:5] = [-1.0, 7000.0, 0.0, 5999.0, 6000.5]                # silent voices: freq < 0 or > sr/8 paints nothing
+    col = np.random.default_rng(6).uniform(0, 1, V).astype(np.float32)
+    col[:4] = [0.0, 1.0, 0.5, 0.2]
+    on = np.random.default_rng(7).random(V) < 0.5
+    _parity(ctx, "Buzz", [(0, 70, False, {"sample_rate": 48000.0, "freq": f, "color": col, "note_on": on}),
+                          (70, F, False, {"sample_rate": 48000.0, "freq": f, "color": col, "note_on": ~on})])
+
+
+@pytest.mark.gpu
+def test_gpu_crush_decimator_distortion(ctx):
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-1, 1, (V, F)).astype(np.float32)
+    rate = rng.uniform(-100, 60000, V).astype(np.float32)       # <= 0: silent, >= sr: bypass + reset
+    drive = rng.uniform(0, 1, V).astype(np.float32)
+    _parity(ctx, "Crush", [(0, 31, False, {"sample_rate": 48000.0, "input": x, "rate": rate, "drive": drive}),
+                           (31, F, False, {"sample_rate": 48000.0, "input": x, "rate": 8000.0, "drive": drive})])
+
+
+@pytest.mark.gpu
+def test_gpu_glide_portamento(ctx):
+    on = np.ones(V, bool)
+    g1, g2 = _freqs(9), _freqs(10)
+    p = lambda goal, a, b: {"sample_rate": 48000.0, "goal": goal, "note_on": a, "prev_note_on": b}
+    _parity(ctx, "Glide", [(0, 30, True, p(g1, on, ~on)), (30, 60, True, p(g2, on, on)), (60, F, False, p(g2, on, on))])
+
+
+@pytest.mark.gpu
+def test_gpu_sweep_curves(ctx):
+    shape = [(0.0, 440.0), (0.0005, 880.0), (0.001, 110.0), (0.0016, 660.0)]
+    p = {"sample_rate": 48000.0, "freq_mul": np.random.default_rng(11).uniform(0.5, 2, V).astype(np.float32), "shape": shape}
+    _parity(ctx, "Sweep", [(0, 40, True, p), (40, 64, False, p), (64, F, False, p)])
+
+
+@pytest.mark.gpu
+def test_gpu_maths(ctx):
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-2, 2, (V, F)).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 0.5, 2.0, -2.0, 1e-20]
+    k = rng.uniform(0.1, 3, V).astype(np.float32)
+    _parity(ctx, "Maths", [(0, F, False, {"sample_rate": 48000.0, "x": x, "k": k})])
+
+
+@pytest.mark.gpu
+def test_gpu_zero_first_and_state_roundtrip(ctx):
+    from tests.util import from_image, to_image
+    from zang_amd import script, zang
+    prog = script.ScriptProgram(SCRIPT, ctx, only=["Pluck"])
+    mod = prog.module("Pluck", V)
+    assert mod.num_temps == 3 and mod.get_state().shape == (5, V)
+    img = to_image(np.full((V, F), 9.0, np.float32))
+    p = {"sample_rate": 48000.0, "freq": 330.0, "note_on": True}
+    mod.paint(zang.Span(0, 48), [img], None, True, p, zero_first=True)
+    st = mod.get_state()
+    mod.paint(zang.Span(48, F), [img], None, False, p, zero_first=True)
+    a = from_image(img).copy()
+    assert np.all(a[:, :1] == 0.0) and np.any(a[:, 40:] != 0.0)          # the 9.0 fill is gone
+    mod.set_state(st)
+    img2 = to_image(np.zeros((V, F), np.float32))
+    mod.paint(zang.Span(48, F), [img2], None, False, p)
+    assert np.array_equal(from_image(img2)[:, 48:].view(np.uint32), a[:, 48:].view(np.uint32))
+    with pytest.raises(KeyError):
+        mod.paint(zang.Span(0, 8), [img], None, False, {"sample_rate": 48000.0, "freq": 1.0})
+    prog.close()

@@ -136,6 +136,14 @@ class NoiseFilterState(C.Structure):
     _fields_ = [("noise", NoiseState), ("flt", FilterState)]
 
 
+class ScriptParam(C.Structure):            # zh_script_param
+    _fields_ = [("kind", u32), ("u", u32), ("f", f32), ("is_buffer", u32), ("pf", vp), ("pb", vp), ("stride", u32), ("reserved", u32)]
+
+
+SP_CONSTANT, SP_BOOLEAN, SP_COB, SP_BUFFER, SP_ENUM, SP_CURVE = range(6)
+SCRIPT_MAX_PARAMS = 16
+
+
 class CurveNode(C.Structure):
     _fields_ = [("value", f32), ("t", f32)]
 
@@ -346,6 +354,15 @@ SIGNATURES = {
     "zh_portamento_get_state": (C.c_int, [vp, vp]),
     "zh_portamento_set_state": (C.c_int, [vp, vp]),
     "zh_portamento_paint": (C.c_int, _paint(PortamentoParams)),
+    "zh_script_compile": (C.c_int, [C.c_char_p, P(vp), P(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "zh_script_free_code": (None, [vp]),
+    "zh_script_load": (C.c_int, [vp, C.c_char_p, P(vp), C.c_char_p, C.c_size_t]),
+    "zh_script_destroy": (C.c_int, [vp]),
+    "zh_script_module_create": (C.c_int, [vp, C.c_char_p, u32, u32, u64, P(vp)]),
+    "zh_script_module_destroy": (C.c_int, [vp]),
+    "zh_script_module_get_state": (C.c_int, [vp, vp]),
+    "zh_script_module_set_state": (C.c_int, [vp, vp]),
+    "zh_script_module_paint": (C.c_int, [vp, u32, u32, P(Buf), Bool, P(ScriptParam), u32, u32]),
     "zh_nice_create": (C.c_int, [vp, u32, F32, P(vp)]),
     "zh_nice_destroy": (C.c_int, [vp]),
     "zh_nice_get_state": (C.c_int, [vp, vp]),

@@ -1,0 +1,97 @@
+// script_rt.cuh -- what a generated zangscript kernel (zang_amd/zangscript/emit_hip.py) is written
+// against: the launch record shared with the loader (script.hip), accessors for the script module's
+// Params, the [word][voice] state blob, and the frame loop with an accumulating output.
+#pragma once
+#include "common.cuh"
+#include "zmath.cuh"
+#include "dsp.cuh"
+#include "seq.cuh"
+#include "envelope.cuh"
+#include "voices.cuh"
+
+struct ZsLaunch {
+    uint32_t V, start, end, flags;
+    float *out;
+    uint32_t ostride, n_params;
+    uint32_t *state;                       // [word][voice]
+    BoolP nic;                             // note_id_changed
+    zh_script_param p[ZH_SCRIPT_MAX_PARAMS];
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
+__device__ const float zs_zero_row[1] = {0.0f};
+
+__device__ __forceinline__ float zs_const(const zh_script_param &p, uint32_t v) { return p.pf ? p.pf[v] : p.f; }
+__device__ __forceinline__ bool zs_bool(const zh_script_param &p, uint32_t v) { return p.pb ? p.pb[v] != 0 : p.u != 0; }
+// the frame-loop input row of a waveform param, or of a cob param (a dummy row when it is a constant)
+__device__ __forceinline__ const float *zs_row(const zh_script_param &p, uint32_t v, size_t &stride) {
+    const bool img = p.kind == ZH_SP_BUFFER || p.is_buffer;
+    stride = img ? p.stride : 0;
+    return img ? p.pf + v : zs_zero_row;
+}
+__device__ __forceinline__ float zs_ld_f(const uint32_t *st, uint32_t word, uint32_t V, uint32_t v) { return zu2f(st[(size_t)word * V + v]); }
+__device__ __forceinline__ uint32_t zs_ld_u(const uint32_t *st, uint32_t word, uint32_t V, uint32_t v) { return st[(size_t)word * V + v]; }
+__device__ __forceinline__ uint64_t zs_ld_u64(const uint32_t *st, uint32_t word, uint32_t V, uint32_t v) {
+    return (uint64_t)st[(size_t)word * V + v] | ((uint64_t)st[(size_t)(word + 1) * V + v] << 32);
+}
+__device__ __forceinline__ void zs_st_f(uint32_t *st, uint32_t word, uint32_t V, uint32_t v, float x) { st[(size_t)word * V + v] = zf2u(x); }
+__device__ __forceinline__ void zs_st_u(uint32_t *st, uint32_t word, uint32_t V, uint32_t v, uint32_t x) { st[(size_t)word * V + v] = x; }
+__device__ __forceinline__ void zs_st_u64(uint32_t *st, uint32_t word, uint32_t V, uint32_t v, uint64_t x) {
+    st[(size_t)word * V + v] = (uint32_t)x;
+    st[(size_t)(word + 1) * V + v] = (uint32_t)(x >> 32);
+}
+
+// std.math.max / min as the generated Zig calls them (codegen_zig.zig:186-187): comparison selects
+__device__ __forceinline__ float zs_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b; }
+
+// frame_loop (seq.cuh) for a body that accumulates into the output sample itself: a script module's
+// paint() may `+=` its output several times per frame.  f(frame, x[NIN], o&); `zf` = ZH_PAINT_ZERO_FIRST.
+template <int CH, int NIN, class F>
+__device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, size_t ostride, const float *const *in,
+                                              const size_t *istride, uint32_t start, uint32_t end, bool zf, F &&f) {
+    constexpr int NI = NIN > 0 ? NIN : 1;
+    const uint32_t nfull = (end - start) / CH;
+    float oc[CH], xc[NI][CH];
+    uint32_t i = start;
+    auto load = [&](uint32_t base, float (&o)[CH], float (&x)[NI][CH]) ZH_INLINE_LAMBDA {
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            o[k] = zf ? 0.0f : out[(size_t)(base + k) * ostride];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) x[j][k] = in[j][(size_t)(base + k) * istride[j]];
+        }
+    };
+    if (nfull > 0) load(i, oc, xc);
+    for (uint32_t c = 0; c < nfull; c++, i += CH) {
+        float on[CH], xn[NI][CH];
+        const bool more = c + 1 < nfull;
+        if (more) load(i + CH, on, xn);
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            float x[NI];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
+            float o = oc[k];
+            f(i + k, x, o);
+            out[(size_t)(i + k) * ostride] = o;
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                oc[k] = on[k];
+#pragma unroll
+                for (int j = 0; j < NIN; j++) xc[j][k] = xn[j][k];
+            }
+        }
+    }
+    for (; i < end; i++) {
+        float x[NI];
+#pragma unroll
+        for (int j = 0; j < NIN; j++) x[j] = in[j][(size_t)i * istride[j]];
+        float o = zf ? 0.0f : out[(size_t)i * ostride];
+        f(i, x, o);
+        out[(size_t)i * ostride] = o;
+    }
+}
+#endif

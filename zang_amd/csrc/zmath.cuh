@@ -379,6 +379,59 @@ ZD float zpowf_pos(float x, float y) {
     return ldexpf(a1, ae);
 }
 
+// std.math.pow(f32, x, y) for any arguments (zangscript's `pow`, codegen_zig.zig:185): the special cases
+// of the Go math.Pow port in front of the same core.
+ZD float zpowf(float x, float y) {
+    if (y == 0 || x == 1) return 1;
+    if (x != x || y != y) return __builtin_nanf("");
+    if (y == 1) return x;
+    if (x == 0) {
+        bool y_odd_int = false;
+        if (fabsf(y) < 16777216.0f) { const float yi = truncf(y); y_odd_int = (yi == y) && ((int32_t)yi & 1); }
+        if (y < 0) return y_odd_int ? copysignf(__builtin_inff(), x) : __builtin_inff();
+        return y_odd_int ? x : 0.0f;
+    }
+    if (__builtin_isinf(y)) {
+        if (x == -1) return 1;
+        if ((fabsf(x) < 1) == (y > 0)) return 0;
+        return __builtin_inff();
+    }
+    if (__builtin_isinf(x)) {
+        if (x < 0) {                                   // pow(1 / x, -y) with 1 / x == -0
+            const float ny = -y;
+            bool odd = false;
+            if (fabsf(ny) < 16777216.0f) { const float yi = truncf(ny); odd = (yi == ny) && ((int32_t)yi & 1); }
+            if (ny < 0) return odd ? -__builtin_inff() : __builtin_inff();
+            return odd ? -0.0f : 0.0f;
+        }
+        return y < 0 ? 0.0f : __builtin_inff();
+    }
+    if (y == 0.5f) return sqrtf(x);
+    if (y == -0.5f) return 1 / sqrtf(x);
+    float ay = fabsf(y);
+    float yi = truncf(ay);
+    float yf = ay - yi;
+    if (yf != 0 && x < 0) return __builtin_nanf("");
+    if (yi >= 2147483648.0f) return zexpf(y * zlogf(x));
+    float a1 = 1.0f;
+    int ae = 0;
+    if (yf != 0) {
+        if (yf > 0.5f) { yf -= 1; yi += 1; }
+        a1 = zexpf(yf * zlogf(x));
+    }
+    int xe;
+    float x1 = frexpf(x, &xe);
+    for (int32_t i = (int32_t)yi; i != 0; i >>= 1) {
+        if (xe < -(1 << 9) || (1 << 9) < xe) { ae += xe; break; }
+        if (i & 1) { a1 *= x1; ae += xe; }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < 0.5f) { x1 += x1; xe -= 1; }
+    }
+    if (y < 0) { a1 = 1 / a1; ae = -ae; }
+    return ldexpf(a1, ae);
+}
+
 // ---- xoshiro256++ and Random.float(f32) (Noise.zig:22,29,51,58) -------------------------
 struct ZXoshiro { uint64_t s0, s1, s2, s3; };
 

@@ -1,0 +1,434 @@
+"""zangscript -> HIP: one fused lane-per-voice kernel per exported module.
+
+The reference's backend prints Zig whose paint() is a list of whole-span buffer operations over
+numbered temps (codegen_zig.zig:110-457).  Every one of those operations is elementwise in the frame
+index, or a module whose output at frame i reads its input buffers at frame i only, so the same list
+can be evaluated one frame at a time with every temp buffer held in a register: lane = voice, the
+per-voice recurrences (oscillator phase, filter, envelope) stay in VGPRs, nothing but the module's
+output and its waveform/cob parameters touches HBM.  What does not depend on the frame -- temp floats,
+per-paint prologues and epilogues of the builtin modules -- is hoisted out of the frame loop.
+
+To keep the reference's bits the emitted code repeats its operation order literally:
+  temps are zeroed and then `+=`-ed (`zang.zero` + `zang.multiplyScalar` is `0.0f + a*s`), outputs only
+  `+=`, sub/div/pow/min/max and the unary functions assign, float (op) buffer swaps its operands for
+  add/mul (codegen_zig.zig:205-206); and the library is compiled with contraction off.
+
+Builtin modules come from csrc/voices.cuh (the same lane objects the standalone kernels use).  Script
+modules calling script modules are inlined.  `delay` and track calls (`from ... begin`) are not
+supported by this backend yet and raise HipBackendError."""
+from dataclasses import dataclass
+
+from .errors import ScriptError
+
+
+class HipBackendError(Exception):
+    pass
+
+
+@dataclass
+class Val:
+    """A value as the emitted code sees it.  kind: buf (an expression valid inside the frame body),
+    float / bool (a per-paint constant), enum (tag + optional payload), curve (pointer + count)."""
+    kind: str
+    expr: str = ""
+    tag: object = None             # enum: an int when known at compile time, else a C++ expression
+    payload: "Val" = None          # enum payload (float Val) or None
+    count: str = ""                # curve node count expression
+    enum: object = None            # BuiltinEnum
+
+
+def f32_literal(x):
+    if x != x:
+        return "__builtin_nanf(\"\")"
+    if x in (float("inf"), float("-inf")):
+        return "%s__builtin_inff()" % ("-" if x < 0 else "")
+    return float.hex(float(x)) + "f"
+
+
+# 32-bit state words per voice of each builtin, and how the lane object is loaded / stored
+STATE_WORDS = {"SineOsc": 1, "PulseOsc": 1, "TriSawOsc": 2, "Noise": 8, "Envelope": 4, "Gate": 0, "Filter": 2,
+               "Decimator": 2, "Distortion": 0, "Cycle": 1, "Portamento": 3, "Curve": 4}
+
+
+class _Kernel:
+    """Everything collected while one exported module is walked."""
+
+    def __init__(self, name):
+        self.name = name
+        self.params, self.pro, self.frame, self.epi, self.init = [], [], [], [], []
+        self.temps = []                # frame-scope float variables
+        self.rows = []                 # exported param index of every frame-loop input row
+        self.words = 0
+        self.noise_fields = 0
+        self.uid = 0
+
+    def fresh(self, stem):
+        self.uid += 1
+        return "%s%d" % (stem, self.uid)
+
+    def alloc(self, n):
+        w = self.words
+        self.words += n
+        return w
+
+
+class _ModuleCtx:
+    """One (possibly inlined) instance of a script module."""
+
+    def __init__(self, k, module_index, env, outvar, nic, prefix):
+        self.k, self.module_index, self.env, self.outvar, self.nic, self.prefix = k, module_index, env, outvar, nic, prefix
+        self.tnames, self.fnames = {}, {}
+
+    def tname(self, i):
+        if i not in self.tnames:
+            self.tnames[i] = "%st%d" % (self.prefix, i)
+            self.k.temps.append(self.tnames[i])
+        return self.tnames[i]
+
+    def fname(self, i):
+        return "%sf%d" % (self.prefix, i)
+
+
+class HipEmitter:
+    def __init__(self, script):
+        self.s = script
+
+    # ---- values
+    def val(self, mc, r):
+        k = r.kind
+        if k == "temp_buffer":
+            return Val("buf", mc.tname(r.index))
+        if k == "temp_float":
+            return Val("float", mc.fname(r.index))
+        if k == "literal_number":
+            return Val("float", f32_literal(r.value.value))
+        if k == "literal_boolean":
+            return Val("bool", "true" if r.value else "false")
+        if k == "literal_enum_value":
+            return Val("enum", tag=r.value, payload=self.val(mc, r.payload) if r.payload is not None else None)
+        if k == "literal_curve":
+            return Val("curve", "zs_curve%d" % r.index, count=str(len(self.s.curves[r.index].points)))
+        if k == "self_param":
+            return mc.env[r.index]
+        if k == "track_param":
+            raise HipBackendError("track calls are not supported by the HIP backend yet")
+        raise AssertionError(k)
+
+    @staticmethod
+    def enum_tag(v, enum):
+        """C++ expression for the index of an enum value in its declaration order."""
+        if isinstance(v.tag, str) and v.kind == "enum" and v.enum is None:
+            for i, ev in enumerate(enum.values):
+                if ev.label == v.tag:
+                    return str(i)
+            raise AssertionError(v.tag)
+        return v.tag                                           # runtime expression (exported param)
+
+    @staticmethod
+    def enum_payload(v):
+        if v.payload is not None:
+            return v.payload.expr
+        return "0.0f"
+
+    # ---- destinations
+    @staticmethod
+    def put(mc, d, expr, zero_first):
+        """`dest (+)= expr` with the reference's zeroing: temps are assigned (after zang.zero when the
+        op accumulates), outputs accumulate."""
+        if d.kind == "temp":
+            t = mc.tname(d.index)
+            if zero_first:
+                return ["%s = 0.0f;" % t, "%s = %s + (%s);" % (t, t, expr)]
+            return ["%s = %s;" % (t, expr)]
+        return ["%s = %s + (%s);" % (mc.outvar, mc.outvar, expr)]
+
+    UN = {"abs": "fabsf(%s)", "cos": "zcosf(%s)", "neg": "-(%s)", "sin": "zsinf(%s)", "sqrt": "sqrtf(%s)"}
+    BIN = {"add": "(%s) + (%s)", "sub": "(%s) - (%s)", "mul": "(%s) * (%s)", "div": "(%s) / (%s)", "pow": "zpowf(%s, %s)",
+           "max": "zs_max(%s, %s)", "min": "zs_min(%s, %s)"}
+
+    # ---- builtin module calls
+    def call_builtin(self, mc, ins, callee, args):
+        k = mc.k
+        name = callee.builtin_name
+        a = {p.name: self.val(mc, r) for p, r in zip(callee.params, args)}
+        o = k.fresh("m")
+        w = k.alloc(STATE_WORDS[name])
+        pro, frame = k.pro, []
+        ends, epi = [], []               # epilogue: the module's end() first, then its state stores
+        painted, value = None, None
+
+        def ld_f(field, word):
+            pro.append("%s.%s = zs_ld_f(L.state, %d, V, v);" % (o, field, word))
+            epi.append("zs_st_f(L.state, %d, V, v, %s.%s);" % (word, o, field))
+
+        def ld_u(field, word, cast=""):
+            pro.append("%s.%s = %szs_ld_u(L.state, %d, V, v);" % (o, field, cast, word))
+            epi.append("zs_st_u(L.state, %d, V, v, (uint32_t)%s.%s);" % (word, o, field))
+
+        def cob(v):                     # (is_buffer, constant expr, per-frame expr)
+            if v.kind == "buf":
+                return True, "0.0f", v.expr
+            return False, v.expr, v.expr
+
+        if name == "SineOsc":
+            fb, fc, fi = cob(a["freq"])
+            pb, pc, pi = cob(a["phase"])
+            pro.append("SineOscLane %s;" % o)
+            ld_f("t", w)
+            pro.append("%s.begin(%s, %s);" % (o, a["sample_rate"].expr, fc))
+            value = "%s.frame<%s>(%s, %s)" % (o, "true" if fb else "false", fi if fb else "0.0f", pi)
+            ends.append("%s.end();" % o)
+        elif name == "Cycle":
+            sb, sc, si = cob(a["speed"])
+            pro.append("CycleLane %s;" % o)
+            ld_f("t", w)
+            pro.append("%s.begin(%s, %s);" % (o, a["sample_rate"].expr, sc))
+            value = "%s.frame<%s>(%s)" % (o, "true" if sb else "false", si if sb else "0.0f")
+        elif name in ("PulseOsc", "TriSawOsc"):
+            fb, fc, fi = cob(a["freq"])
+            lane = name + "Lane"
+            pro.append("%s %s;" % (lane, o))
+            ld_u("cnt", w)
+            if name == "TriSawOsc":
+                ld_f("t", w + 1)
+            if fb:
+                pro.append("%s.begin_ctrl(%s, %s);" % (o, a["sample_rate"].expr, a["color"].expr))
+                if name == "PulseOsc":
+                    cv, cp = k.fresh("cv"), k.fresh("cp")
+                    frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame_ctrl(%s, %s);" % (cp, o, fi, cv)]
+                    painted, value = cp, cv
+                else:
+                    value = "%s.frame_ctrl(%s)" % (o, fi)
+                    ends.append("%s.end_ctrl();" % o)
+            else:
+                pro.append("%s.begin_const(%s, %s, %s);" % (o, a["sample_rate"].expr, fc, a["color"].expr))
+                cv, cp = k.fresh("cv"), k.fresh("cp")
+                frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame_const(%s);" % (cp, o, cv)]
+                painted, value = cp, cv
+        elif name == "Noise":
+            pro.append("NoiseLane %s;" % o)
+            for j in range(4):
+                pro.append("%s.r.s%d = zs_ld_u64(L.state, %d, V, v);" % (o, j, w + 2 * j))
+                epi.append("zs_st_u64(L.state, %d, V, v, %s.r.s%d);" % (w + 2 * j, o, j))
+            pro.append("%s.begin();" % o)
+            k.init.append(("noise", w, k.noise_fields))
+            k.noise_fields += 1
+            tag = self.enum_tag(a["color"], callee.params[0].param_type.enum)
+            if tag in ("0", "1"):
+                value = "%s.frame<%s>()" % (o, "true" if tag == "1" else "false")
+            else:
+                value = "((%s) == 1u ? %s.frame<true>() : %s.frame<false>())" % (tag, o, o)
+        elif name == "Envelope":
+            pro.append("EnvLane %s;" % o)
+            ld_u("state", w)
+            ld_f("t", w + 1)
+            ld_f("last_value", w + 2)
+            ld_f("start", w + 3)
+            pro.append("%s.sample_rate = %s; %s.sustain_volume = %s; %s.note_on = %s;" %
+                       (o, a["sample_rate"].expr, o, a["sustain_volume"].expr, o, a["note_on"].expr))
+            for i, stage in enumerate(("attack", "decay", "release")):
+                enum = callee.params[1 + i].param_type.enum
+                pro.append("%s.%s = CurveP{(uint32_t)(%s), %s};" % (o, stage, self.enum_tag(a[stage], enum), self.enum_payload(a[stage])))
+            pro.append("%s.begin(%s);" % (o, mc.nic))
+            cv, cp = k.fresh("cv"), k.fresh("cp")
+            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(%s);" % (cp, o, cv)]
+            painted, value = cp, cv
+        elif name == "Gate":
+            painted, value = a["note_on"].expr, "1.0f"          # Gate.zig:28-30
+        elif name == "Filter":
+            cb, cc, ci = cob(a["cutoff"])
+            rb, rc, ri = cob(a["res"])
+            pro.append("FilterLane %s;" % o)
+            ld_f("l", w)
+            ld_f("b", w + 1)
+            pro.append("%s.begin((uint32_t)(%s), %s, %s);" % (o, self.enum_tag(a["type"], callee.params[1].param_type.enum), cc, rc))
+            value = "%s.frame<%s, %s>(%s, %s, %s)" % (o, "true" if cb else "false", "true" if rb else "false", a["input"].expr,
+                                                      ci if cb else "0.0f", ri if rb else "0.0f")
+        elif name == "Decimator":
+            pro.append("DecimatorLane %s;" % o)
+            ld_f("dval", w)
+            ld_f("dcount", w + 1)
+            k.init.append(("f32", w + 1, 1.0))                   # Decimator.zig:14-19
+            pro.append("%s.begin(%s, %s);" % (o, a["sample_rate"].expr, a["fake_sample_rate"].expr))
+            cv, cp = k.fresh("cv"), k.fresh("cp")
+            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(%s, %s);" % (cp, o, a["input"].expr, cv)]
+            painted, value = cp, cv
+            ends.append("%s.end();" % o)
+        elif name == "Distortion":
+            pro.append("DistortionLane %s;" % o)
+            pro.append("%s.begin((uint32_t)(%s), %s, %s, %s);" % (o, self.enum_tag(a["type"], callee.params[1].param_type.enum),
+                                                                  a["ingain"].expr, a["outgain"].expr, a["offset"].expr))
+            value = "%s.frame(%s)" % (o, a["input"].expr)
+        elif name == "Portamento":
+            pro.append("PortamentoLane %s;" % o)
+            ld_f("t", w)
+            ld_f("last", w + 1)
+            ld_f("st", w + 2)
+            enum = callee.params[1].param_type.enum
+            pro.append("%s.begin(%s, (uint32_t)(%s), %s, %s, %s, %s, %s);" % (
+                o, a["sample_rate"].expr, self.enum_tag(a["curve"], enum), self.enum_payload(a["curve"]), a["goal"].expr,
+                a["note_on"].expr, a["prev_note_on"].expr, mc.nic))
+            value = "%s.frame()" % o
+        elif name == "Curve":
+            pro.append("CurveLane %s;" % o)
+            ld_f("t", w)
+            ld_u("cur", w + 1)
+            ld_u("off", w + 2, "(int32_t)")
+            ld_u("next", w + 3)
+            pro.append("%s.begin(%s, (uint32_t)(%s), %s, %s, SPAN_LEN, %s);" % (
+                o, a["sample_rate"].expr, self.enum_tag(a["function"], callee.params[1].param_type.enum), a["curve"].expr,
+                a["curve"].count, mc.nic))
+            cv, cp = k.fresh("cv"), k.fresh("cp")
+            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(i - L.start, %s);" % (cp, o, cv)]
+            painted, value = cp, cv
+        else:
+            raise HipBackendError("builtin module %s is not supported by the HIP backend" % name)
+
+        # zang.zero(dest) for a temp, then the module's `+=` (codegen_zig.zig:284-291)
+        d = ins.out
+        if d.kind == "temp":
+            t = mc.tname(d.index)
+            frame.insert(0, "%s = 0.0f;" % t)
+            target = t
+        else:
+            target = mc.outvar
+        add = "%s = %s + (%s);" % (target, target, value)
+        frame.append("if (%s) %s" % (painted, add) if painted else add)
+        k.frame += ["{"] + ["    " + l for l in frame] + ["}"]
+        k.epi += ends + epi
+
+    # ---- instructions
+    def instruction(self, mc, mr, ins):
+        k, kind = mc.k, ins.kind
+        if kind == "copy_buffer":
+            k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
+        elif kind == "float_to_buffer":
+            k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
+        elif kind == "cob_to_buffer":
+            k.frame += self.put(mc, ins.out, mc.env[ins.in_self_param].expr, False)
+        elif kind == "arith_float":
+            k.pro.append("const float %s = %s;" % (mc.fname(ins.out), self.UN[ins.op] % self.val(mc, ins.a).expr))
+        elif kind == "arith_float_float":
+            k.pro.append("const float %s = %s;" % (mc.fname(ins.out), self.BIN[ins.op] % (self.val(mc, ins.a).expr, self.val(mc, ins.b).expr)))
+        elif kind == "arith_buffer":
+            k.frame += self.put(mc, ins.out, self.UN[ins.op] % self.val(mc, ins.a).expr, False)
+        elif kind in ("arith_float_buffer", "arith_buffer_float", "arith_buffer_buffer"):
+            a, b = self.val(mc, ins.a).expr, self.val(mc, ins.b).expr
+            if ins.op in ("add", "mul"):
+                if kind == "arith_float_buffer":
+                    a, b = b, a                                  # addScalar / multiplyScalar(dest, buffer, float)
+                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), True)
+            else:
+                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), False)
+        elif kind == "call":
+            callee_index = mr.fields[ins.field_index]
+            callee = self.s.modules[callee_index]
+            if callee.scope is None:
+                self.call_builtin(mc, ins, callee, ins.args)
+            else:
+                env = [self.val(mc, r) for r in ins.args]
+                d = ins.out
+                if d.kind == "temp":
+                    outvar = mc.tname(d.index)
+                    k.frame.append("%s = 0.0f;" % outvar)
+                else:
+                    outvar = mc.outvar
+                sub = _ModuleCtx(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_")
+                self.module_body(sub)
+        elif kind == "track_call":
+            raise HipBackendError("track calls (`from ... begin`) are not supported by the HIP backend yet")
+        elif kind == "delay":
+            raise HipBackendError("`delay` is not supported by the HIP backend yet")
+        else:
+            raise AssertionError(kind)
+
+    def module_body(self, mc):
+        mr = self.s.module_results[mc.module_index]
+        for ins in mr.instructions:
+            self.instruction(mc, mr, ins)
+
+    # ---- one exported module
+    def kernel(self, name, module_index):
+        module = self.s.modules[module_index]
+        k = _Kernel(name)
+        env = []
+        for i, p in enumerate(module.params):
+            kind = p.param_type.kind
+            if kind == "constant":
+                k.pro.append("const float P%d = zs_const(L.p[%d], v);" % (i, i))
+                env.append(Val("float", "P%d" % i))
+            elif kind == "boolean":
+                k.pro.append("const bool P%d = zs_bool(L.p[%d], v);" % (i, i))
+                env.append(Val("bool", "P%d" % i))
+            elif kind == "buffer":
+                j = len(k.rows)
+                k.rows.append(i)
+                env.append(Val("buf", "x[%d]" % j))
+            elif kind == "constant_or_buffer":
+                j = len(k.rows)
+                k.rows.append(i)
+                k.pro.append("const bool P%d_b = L.p[%d].is_buffer != 0; const float P%d_c = zs_const(L.p[%d], v);" % (i, i, i, i))
+                env.append(Val("buf", "(P%d_b ? x[%d] : P%d_c)" % (i, j, i)))     # cob_to_buffer's switch (codegen_zig.zig:130-143)
+            elif kind == "curve":
+                env.append(Val("curve", "reinterpret_cast<const zh_curve_node *>(L.p[%d].pf)" % i, count="L.p[%d].u" % i))
+            else:
+                k.pro.append("const uint32_t P%d_tag = L.p[%d].u; const float P%d_f = L.p[%d].f;" % (i, i, i, i))
+                env.append(Val("enum", tag="P%d_tag" % i, payload=Val("float", "P%d_f" % i), enum=p.param_type.enum))
+            k.params.append((p.name, kind, p.param_type.enum.name if p.param_type.enum else None))
+        mc = _ModuleCtx(k, module_index, env, "o", "NIC", "")
+        self.module_body(mc)
+        return k
+
+    def generate(self, only=None):
+        out = ["// generated by zang_amd.zangscript (HIP backend) -- compile with zh_script_load / zh_script_compile",
+               '#include "script_rt.cuh"', ""]
+        for ci, curve in enumerate(self.s.curves):
+            pts = ", ".join("{%s, %s}" % (f32_literal(v.value), f32_literal(t.value)) for t, v in curve.points)   # {value, t}
+            out.append("__device__ const zh_curve_node zs_curve%d[] = {%s};" % (ci, pts or "{0.0f, 0.0f}"))
+        meta = {}
+        for name, mi in self.s.exported_modules:
+            if only is not None and name not in only:
+                continue
+            try:
+                k = self.kernel(name, mi)
+            except HipBackendError as e:
+                meta[name] = {"error": str(e)}
+                out += ["", "// %s: %s" % (name, e)]
+                continue
+            meta[name] = {"state_words": k.words, "params": k.params, "noise_fields": k.noise_fields}
+            nin = len(k.rows)
+            ni = max(nin, 1)
+            I = "    "
+            out += ["", 'extern "C" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {' % name,
+                    I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;", I + "if (v >= V) return;",
+                    I + "for (uint32_t w = 0; w < %du; w++) st[(size_t)w * V + v] = 0u;" % k.words]
+            for item in k.init:
+                if item[0] == "f32":
+                    out.append(I + "zs_st_f(st, %d, V, v, %s);" % (item[1], f32_literal(item[2])))
+                else:                                              # Noise.zig:25-32: seed = counter++ at init()
+                    out += [I + "{ ZXoshiro r; zxoshiro_seed(r, first_seed + (uint64_t)v * %du + %du);" % (k.noise_fields, item[2]),
+                            I + "  zs_st_u64(st, %d, V, v, r.s0); zs_st_u64(st, %d, V, v, r.s1); zs_st_u64(st, %d, V, v, r.s2); zs_st_u64(st, %d, V, v, r.s3); }"
+                            % (item[1], item[1] + 2, item[1] + 4, item[1] + 6)]
+            out += ["}", "",
+                    'extern "C" __global__ void __launch_bounds__(64) zs_paint_%s(const ZsLaunch L) {' % name,
+                    I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;", I + "const uint32_t V = L.V;", I + "if (v >= V) return;",
+                    I + "const bool NIC = L.nic.get(v);", I + "const uint32_t SPAN_LEN = L.end - L.start;",
+                    I + "(void)NIC; (void)SPAN_LEN;",
+                    I + "const float *ins[%d] = {%s};" % (ni, ", ".join(["nullptr"] * ni)), I + "size_t istr[%d] = {%s};" % (ni, ", ".join(["0"] * ni))]
+            for j, pi in enumerate(k.rows):
+                out.append(I + "ins[%d] = zs_row(L.p[%d], v, istr[%d]);" % (j, pi, j))
+            out += [I + l for l in k.pro]
+            out.append(I + "zs_frame_loop<8, %d>(L.out + v, L.ostride, ins, istr, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0," % nin)
+            out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
+            out.append(I + I + "(void)i; (void)x;")
+            if k.temps:
+                out.append(I + I + "float " + ", ".join("%s = 0.0f" % t for t in k.temps) + ";")
+            out += [I + I + l for l in k.frame]
+            out.append(I + "});")
+            out += [I + l for l in k.epi]
+            out.append("}")
+        return "\n".join(out) + "\n", meta
+
+
+def generate_hip(script, only=None):
+    return HipEmitter(script).generate(only)
