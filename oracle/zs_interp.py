@@ -29,8 +29,10 @@ class Instance:
         self.L = po.lib()
         self.mr = script.module_results[module_index]
         self.module = script.modules[module_index]
-        if self.mr.delays or self.mr.note_trackers:
-            raise NotImplementedError("delay / track calls")
+        if self.mr.note_trackers:
+            raise NotImplementedError("track calls")
+        # zang.Delay(n).init(): zeroed ring, index 0 (src/zang/delay.zig:12-17)
+        self.delays = [[np.zeros(n, F32), 0] for n in self.mr.delays]
         self.fields = []
         for callee_index in self.mr.fields:                      # init order = field order, depth first
             callee = script.modules[callee_index]
@@ -136,10 +138,11 @@ class Instance:
     def paint(self, start, end, out, nic, params):
         """params: list in declaration order (sample_rate first): f32 scalar, bool, np.float32 array
         (buffer / cob buffer), (label, payload) enum tuple, [(t, value)] curve."""
+        temps = [np.zeros(len(out), F32) for _ in range(self.mr.num_temps)]
+        self._run(self.mr.instructions, start, end, out, nic, params, temps, {})
+
+    def _run(self, instructions, start, end, out, nic, params, temps, floats):
         L = self.L
-        n = len(out)
-        temps = [np.zeros(n, F32) for _ in range(self.mr.num_temps)]
-        floats = {}
         sl = slice(start, end)
 
         def dest(d):
@@ -152,8 +155,28 @@ class Instance:
             else:
                 t[sl] = values
 
-        for ins in self.mr.instructions:
+        for ins in instructions:
             k = ins.kind
+            if k == "delay":                                     # codegen_zig.zig:391-455
+                d = dest(ins.out)
+                if ins.out.kind != "output":
+                    L.zo_zero(start, end, po.fptr(d))
+                ring, n = self.delays[ins.delay_index][0], len(self.delays[ins.delay_index][0])
+                fb, fbout = temps[ins.feedback_temp], temps[ins.feedback_out_temp]
+                pos = start
+                while pos < end:
+                    fbout[pos:end] = 0
+                    fb[pos:end] = 0
+                    cnt = min(end - pos, n)                      # readDelayBuffer (delay.zig:28-57): `+=`, wraps
+                    idx = self.delays[ins.delay_index][1]
+                    for j in range(cnt):
+                        fb[pos + j] = fb[pos + j] + ring[(idx + j) % n]
+                    self._run(ins.instructions, pos, pos + cnt, out, nic, params, temps, floats)   # body dests are explicit
+                    for j in range(cnt):                         # writeDelayBuffer (:62-89)
+                        ring[(idx + j) % n] = fbout[pos + j]
+                    self.delays[ins.delay_index][1] = (idx + cnt) % n
+                    pos += cnt
+                continue
             if k in ("copy_buffer", "float_to_buffer", "cob_to_buffer"):
                 src = params[ins.in_self_param] if k == "cob_to_buffer" else self._val(ins.src, temps, floats, params)
                 d = dest(ins.out)

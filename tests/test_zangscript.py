@@ -90,7 +90,7 @@ def test_error_location_and_carets():
 def test_instruction_lists_and_temps():
     s = zs.compile(SCRIPT)
     names = [n for n, _ in s.exported_modules]
-    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths"]
+    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead"]
     r = s.module_results[s.module_index("Doubler")]
     assert (r.num_temps, r.num_temp_floats, [i.kind for i in r.instructions]) == (1, 0, ["cob_to_buffer", "arith_buffer_float"])
     assert r.instructions[1].out.kind == "output"           # written straight into the result location
@@ -193,20 +193,38 @@ def test_generated_hip_compiles_for_gfx950():
     assert script.compile_hip(src) > 10000
 
 
+def test_delay_front_end_and_state_layout():
+    s = zs.compile(SCRIPT)
+    r = s.module_results[s.module_index("Echo")]
+    assert r.delays == [37] and r.num_temps == 4             # feedback, result, feedback-out + one working temp (codegen.zig:628-690)
+    d = r.instructions[0]
+    assert d.kind == "delay" and d.out.kind == "output" and d.feedback_temp != d.feedback_out_temp
+    assert "readDelayBuffer" in zs.generate_zig(s) and "writeDelayBuffer" in zs.generate_zig(s)
+    _, meta = zs.generate_hip(s, only=["Echo"])
+    assert meta["Echo"]["state_words"] == 1 + 37 + 2         # ring index, ring, Filter (l, b)
+
+
 def test_unsupported_constructs_are_reported_not_miscompiled():
-    src = """Echo = defmodule
-    input: waveform,
+    src = """Player = defmodule
+    freq: cob,
 begin
-    out delay 100 begin
-        out input + feedback * 0.5
-        feedback input
+    out from deftrack
+        f: constant,
+    begin
+        0.0 (f=1)
+        0.5 (f=2)
+    end, 1 begin
+        out SineOsc(freq=freq * f, phase=0)
     end
 end"""
-    s = zs.compile(src)                                       # the front-end handles it (4 temps, codegen.zig:628-690)
-    assert s.module_results[s.module_index("Echo")].delays == [100]
-    assert "readDelayBuffer" in zs.generate_zig(s)
+    s = zs.compile(src)                                       # the front-end handles it (codegen.zig:558-626)
+    r = s.module_results[s.module_index("Player")]
+    assert r.triggers == [0] and r.note_trackers == [0]
+    text = zs.generate_zig(s)
+    assert ".{ .t = 0.5, .note_id = 2, .params = .{ .f = 2.0 } }," in text
+    assert "const _new_note = note_id_changed or _result.note_id_changed;" in text
     _, meta = zs.generate_hip(s)
-    assert "not supported by the HIP backend" in meta["Echo"]["error"]
+    assert "not supported by the HIP backend" in meta["Player"]["error"]
 
 
 def test_hiprtc_errors_are_reported():
@@ -357,6 +375,21 @@ def test_gpu_maths(ctx):
     x[0, :8] = [0.0, -0.0, 1.0, -1.0, 0.5, 2.0, -2.0, 1e-20]
     k = rng.uniform(0.1, 3, V).astype(np.float32)
     _parity(ctx, "Maths", [(0, F, False, {"sample_rate": 48000.0, "x": x, "k": k})])
+
+
+@pytest.mark.gpu
+def test_gpu_delay_chunks_and_nested_delays(ctx):
+    """Spans longer than the ring (96 > 37, 20): the body's modules see one paint call per chunk."""
+    rng = np.random.default_rng(13)
+    x = rng.uniform(-1, 1, (V, F)).astype(np.float32)
+    vol = rng.uniform(0.1, 0.9, V).astype(np.float32)
+    for ftype in ("low_pass", "high_pass"):
+        p = {"sample_rate": 48000.0, "input": x, "echo_volume": vol, "ftype": (ftype, None)}
+        _parity(ctx, "Echo", [(0, F, False, p), (0, 30, False, p), (30, F, False, p)])
+    on = np.ones(V, bool)
+    f = _freqs(14)
+    q = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
+    _parity(ctx, "EchoLead", [(0, 50, True, q(on)), (50, F, False, q(on)), (0, F, False, q(~on))])
 
 
 @pytest.mark.gpu

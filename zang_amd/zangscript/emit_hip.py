@@ -14,8 +14,8 @@ To keep the reference's bits the emitted code repeats its operation order litera
   add/mul (codegen_zig.zig:205-206); and the library is compiled with contraction off.
 
 Builtin modules come from csrc/voices.cuh (the same lane objects the standalone kernels use).  Script
-modules calling script modules are inlined.  `delay` and track calls (`from ... begin`) are not
-supported by this backend yet and raise HipBackendError."""
+modules calling script modules are inlined.  `delay` keeps its ring in the per-voice state blob.  Track
+calls (`from ... begin`) are not supported by this backend yet and raise HipBackendError."""
 from dataclasses import dataclass
 
 from .errors import ScriptError
@@ -55,7 +55,7 @@ class _Kernel:
 
     def __init__(self, name):
         self.name = name
-        self.params, self.pro, self.frame, self.epi, self.init = [], [], [], [], []
+        self.params, self.pro, self.frame, self.epi_ends, self.epi_stores, self.init = [], [], [], [], [], []
         self.temps = []                # frame-scope float variables
         self.rows = []                 # exported param index of every frame-loop input row
         self.words = 0
@@ -75,9 +75,16 @@ class _Kernel:
 class _ModuleCtx:
     """One (possibly inlined) instance of a script module."""
 
-    def __init__(self, k, module_index, env, outvar, nic, prefix):
+    def __init__(self, k, module_index, env, outvar, nic, prefix, parent=None):
         self.k, self.module_index, self.env, self.outvar, self.nic, self.prefix = k, module_index, env, outvar, nic, prefix
         self.tnames, self.fnames = {}, {}
+        # where the per-paint prologue / epilogue of builtin calls goes: the kernel's own prologue and
+        # epilogue, or -- inside a `delay` body, which the reference paints chunk by chunk -- the
+        # chunk's; `rel` / `length` are the frame index within, and the length of, that paint call
+        self.begin_sink = parent.begin_sink if parent else k.pro
+        self.end_sink = parent.end_sink if parent else k.epi_ends
+        self.rel = parent.rel if parent else "(i - L.start)"
+        self.length = parent.length if parent else "SPAN_LEN"
 
     def tname(self, i):
         if i not in self.tnames:
@@ -153,16 +160,16 @@ class HipEmitter:
         a = {p.name: self.val(mc, r) for p, r in zip(callee.params, args)}
         o = k.fresh("m")
         w = k.alloc(STATE_WORDS[name])
-        pro, frame = k.pro, []
-        ends, epi = [], []               # epilogue: the module's end() first, then its state stores
+        decl, pro, frame = k.pro, mc.begin_sink, []      # lane object + state loads | per-paint prologue | per frame
+        ends, epi = mc.end_sink, k.epi_stores            # per-paint epilogue | state stores at kernel end
         painted, value = None, None
 
         def ld_f(field, word):
-            pro.append("%s.%s = zs_ld_f(L.state, %d, V, v);" % (o, field, word))
+            decl.append("%s.%s = zs_ld_f(L.state, %d, V, v);" % (o, field, word))
             epi.append("zs_st_f(L.state, %d, V, v, %s.%s);" % (word, o, field))
 
         def ld_u(field, word, cast=""):
-            pro.append("%s.%s = %szs_ld_u(L.state, %d, V, v);" % (o, field, cast, word))
+            decl.append("%s.%s = %szs_ld_u(L.state, %d, V, v);" % (o, field, cast, word))
             epi.append("zs_st_u(L.state, %d, V, v, (uint32_t)%s.%s);" % (word, o, field))
 
         def cob(v):                     # (is_buffer, constant expr, per-frame expr)
@@ -173,21 +180,21 @@ class HipEmitter:
         if name == "SineOsc":
             fb, fc, fi = cob(a["freq"])
             pb, pc, pi = cob(a["phase"])
-            pro.append("SineOscLane %s;" % o)
+            decl.append("SineOscLane %s;" % o)
             ld_f("t", w)
             pro.append("%s.begin(%s, %s);" % (o, a["sample_rate"].expr, fc))
             value = "%s.frame<%s>(%s, %s)" % (o, "true" if fb else "false", fi if fb else "0.0f", pi)
             ends.append("%s.end();" % o)
         elif name == "Cycle":
             sb, sc, si = cob(a["speed"])
-            pro.append("CycleLane %s;" % o)
+            decl.append("CycleLane %s;" % o)
             ld_f("t", w)
             pro.append("%s.begin(%s, %s);" % (o, a["sample_rate"].expr, sc))
             value = "%s.frame<%s>(%s)" % (o, "true" if sb else "false", si if sb else "0.0f")
         elif name in ("PulseOsc", "TriSawOsc"):
             fb, fc, fi = cob(a["freq"])
             lane = name + "Lane"
-            pro.append("%s %s;" % (lane, o))
+            decl.append("%s %s;" % (lane, o))
             ld_u("cnt", w)
             if name == "TriSawOsc":
                 ld_f("t", w + 1)
@@ -206,9 +213,9 @@ class HipEmitter:
                 frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame_const(%s);" % (cp, o, cv)]
                 painted, value = cp, cv
         elif name == "Noise":
-            pro.append("NoiseLane %s;" % o)
+            decl.append("NoiseLane %s;" % o)
             for j in range(4):
-                pro.append("%s.r.s%d = zs_ld_u64(L.state, %d, V, v);" % (o, j, w + 2 * j))
+                decl.append("%s.r.s%d = zs_ld_u64(L.state, %d, V, v);" % (o, j, w + 2 * j))
                 epi.append("zs_st_u64(L.state, %d, V, v, %s.r.s%d);" % (w + 2 * j, o, j))
             pro.append("%s.begin();" % o)
             k.init.append(("noise", w, k.noise_fields))
@@ -219,7 +226,7 @@ class HipEmitter:
             else:
                 value = "((%s) == 1u ? %s.frame<true>() : %s.frame<false>())" % (tag, o, o)
         elif name == "Envelope":
-            pro.append("EnvLane %s;" % o)
+            decl.append("EnvLane %s;" % o)
             ld_u("state", w)
             ld_f("t", w + 1)
             ld_f("last_value", w + 2)
@@ -238,14 +245,14 @@ class HipEmitter:
         elif name == "Filter":
             cb, cc, ci = cob(a["cutoff"])
             rb, rc, ri = cob(a["res"])
-            pro.append("FilterLane %s;" % o)
+            decl.append("FilterLane %s;" % o)
             ld_f("l", w)
             ld_f("b", w + 1)
             pro.append("%s.begin((uint32_t)(%s), %s, %s);" % (o, self.enum_tag(a["type"], callee.params[1].param_type.enum), cc, rc))
             value = "%s.frame<%s, %s>(%s, %s, %s)" % (o, "true" if cb else "false", "true" if rb else "false", a["input"].expr,
                                                       ci if cb else "0.0f", ri if rb else "0.0f")
         elif name == "Decimator":
-            pro.append("DecimatorLane %s;" % o)
+            decl.append("DecimatorLane %s;" % o)
             ld_f("dval", w)
             ld_f("dcount", w + 1)
             k.init.append(("f32", w + 1, 1.0))                   # Decimator.zig:14-19
@@ -255,12 +262,12 @@ class HipEmitter:
             painted, value = cp, cv
             ends.append("%s.end();" % o)
         elif name == "Distortion":
-            pro.append("DistortionLane %s;" % o)
+            decl.append("DistortionLane %s;" % o)
             pro.append("%s.begin((uint32_t)(%s), %s, %s, %s);" % (o, self.enum_tag(a["type"], callee.params[1].param_type.enum),
                                                                   a["ingain"].expr, a["outgain"].expr, a["offset"].expr))
             value = "%s.frame(%s)" % (o, a["input"].expr)
         elif name == "Portamento":
-            pro.append("PortamentoLane %s;" % o)
+            decl.append("PortamentoLane %s;" % o)
             ld_f("t", w)
             ld_f("last", w + 1)
             ld_f("st", w + 2)
@@ -270,16 +277,16 @@ class HipEmitter:
                 a["note_on"].expr, a["prev_note_on"].expr, mc.nic))
             value = "%s.frame()" % o
         elif name == "Curve":
-            pro.append("CurveLane %s;" % o)
+            decl.append("CurveLane %s;" % o)
             ld_f("t", w)
             ld_u("cur", w + 1)
             ld_u("off", w + 2, "(int32_t)")
             ld_u("next", w + 3)
-            pro.append("%s.begin(%s, (uint32_t)(%s), %s, %s, SPAN_LEN, %s);" % (
+            pro.append("%s.begin(%s, (uint32_t)(%s), %s, %s, %s, %s);" % (
                 o, a["sample_rate"].expr, self.enum_tag(a["function"], callee.params[1].param_type.enum), a["curve"].expr,
-                a["curve"].count, mc.nic))
+                a["curve"].count, mc.length, mc.nic))
             cv, cp = k.fresh("cv"), k.fresh("cp")
-            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(i - L.start, %s);" % (cp, o, cv)]
+            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(%s, %s);" % (cp, o, mc.rel, cv)]
             painted, value = cp, cv
         else:
             raise HipBackendError("builtin module %s is not supported by the HIP backend" % name)
@@ -295,7 +302,6 @@ class HipEmitter:
         add = "%s = %s + (%s);" % (target, target, value)
         frame.append("if (%s) %s" % (painted, add) if painted else add)
         k.frame += ["{"] + ["    " + l for l in frame] + ["}"]
-        k.epi += ends + epi
 
     # ---- instructions
     def instruction(self, mc, mr, ins):
@@ -333,14 +339,57 @@ class HipEmitter:
                     k.frame.append("%s = 0.0f;" % outvar)
                 else:
                     outvar = mc.outvar
-                sub = _ModuleCtx(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_")
+                sub = _ModuleCtx(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", parent=mc)
                 self.module_body(sub)
         elif kind == "track_call":
             raise HipBackendError("track calls (`from ... begin`) are not supported by the HIP backend yet")
         elif kind == "delay":
-            raise HipBackendError("`delay` is not supported by the HIP backend yet")
+            self.delay(mc, mr, ins)
         else:
             raise AssertionError(kind)
+
+    def delay(self, mc, mr, ins):
+        """`delay N begin ... end` (codegen_zig.zig:391-455).  The reference walks the span in chunks of
+        samples_read = min(N, remaining) frames (delay.zig:28-57): read the ring into the feedback temp,
+        paint the body over the chunk, write the body's `feedback` value back.  A slot is read before it
+        is rewritten, so the per-frame form (read slot, body, write slot, advance) gives the same values;
+        what must follow the chunks is the per-paint prologue / epilogue of the modules called in the
+        body, which the reference runs once per chunk: they are emitted under `first / last frame of the
+        chunk` conditions.  The ring is N state words per voice, [word][voice] like all state."""
+        k = mc.k
+        n = mr.delays[ins.delay_index]
+        if n < 1:
+            raise HipBackendError("delay of 0 samples")
+        w_idx = k.alloc(1)
+        w_ring = k.alloc(n)
+        d = k.fresh("d")
+        k.pro.append("uint32_t %s_idx = zs_ld_u(L.state, %d, V, v);" % (d, w_idx))
+        k.epi_stores.append("zs_st_u(L.state, %d, V, v, %s_idx);" % (w_idx, d))
+        if ins.out.kind == "temp":
+            k.frame.append("%s = 0.0f;" % mc.tname(ins.out.index))   # zang.zero(span, dest) (:396-399)
+        fb, fbout = mc.tname(ins.feedback_temp), mc.tname(ins.feedback_out_temp)
+        begins, ends, body = [], [], []
+        saved = (mc.begin_sink, mc.end_sink, mc.rel, mc.length, k.frame)
+        rel, length = "%s_rel" % d, "%s_len" % d
+        head = ["const uint32_t %s = %s %% %du;" % (rel, saved[2], n),
+                "const uint32_t %s = min(%du, %s - (%s - %s));" % (length, n, saved[3], saved[2], rel)]
+        mc.begin_sink, mc.end_sink, mc.rel, mc.length, k.frame = begins, ends, rel, length, body
+        try:
+            for sub in ins.instructions:
+                self.instruction(mc, mr, sub)
+        finally:
+            mc.begin_sink, mc.end_sink, mc.rel, mc.length, k.frame = saved
+        slot = "L.state[(size_t)(%du + %s_idx) * V + v]" % (w_ring, d)
+        k.frame += head
+        if begins:
+            k.frame += ["if (%s == 0u) {" % rel] + ["    " + l for l in begins] + ["}"]
+        k.frame += ["%s = 0.0f;" % fbout, "%s = 0.0f;" % fb,
+                    "%s = %s + zu2f(%s);" % (fb, fb, slot)]       # readDelayBuffer: `+=` (delay.zig:39-42)
+        k.frame += body
+        k.frame += ["%s = zf2u(%s);" % (slot, fbout),             # writeDelayBuffer (delay.zig:62-89)
+                    "%s_idx = %s_idx + 1u == %du ? 0u : %s_idx + 1u;" % (d, d, n, d)]
+        if ends:
+            k.frame += ["if (%s + 1u == %s) {" % (rel, length)] + ["    " + l for l in ends] + ["}"]
 
     def module_body(self, mc):
         mr = self.s.module_results[mc.module_index]
@@ -425,7 +474,7 @@ class HipEmitter:
                 out.append(I + I + "float " + ", ".join("%s = 0.0f" % t for t in k.temps) + ";")
             out += [I + I + l for l in k.frame]
             out.append(I + "});")
-            out += [I + l for l in k.epi]
+            out += [I + l for l in k.epi_ends + k.epi_stores]
             out.append("}")
         return "\n".join(out) + "\n", meta
 
