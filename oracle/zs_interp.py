@@ -20,6 +20,65 @@ def _enum_index(enum, label):
     return [v.label for v in enum.values].index(label)
 
 
+def note_tracker_consume(st, times, sample_rate, start, end):
+    """NoteTracker.consume (src/zang/notes.zig:161-205) in f32: st = {"next", "t"}; returns the impulses
+    [(frame, note index)] of the notes that fall into this span (a 33rd impulse is dropped: the reference's
+    arrays hold 32) as (frame, note id, note index)."""
+    out_len = end - start
+    buf_time = F32(F32(out_len) / F32(sample_rate))
+    t0 = F32(st["t"])
+    end_t = F32(t0 + buf_time)
+    impulses = []
+    while st["next"] < len(times):
+        note_t = F32(times[st["next"]])
+        if not (note_t < end_t):
+            break
+        with np.errstate(all="ignore"):
+            f = F32(F32(note_t - t0) / buf_time)
+            x = F32(f * F32(out_len))
+        rel = 0 if not (x == x) or x <= 0 else (0xFFFFFFFF if x >= 4294967296.0 else int(x))   # saturating, like the device
+        rel = min(rel, out_len - 1)
+        if len(impulses) < 32:
+            impulses.append((start + rel, st["next"] + 1, st["next"]))   # note id = index + 1 (codegen_zig.zig:497)
+        st["next"] += 1
+    st["t"] = end_t
+    return impulses
+
+
+def trigger_spans(cur, impulses, start, end):
+    """Trigger.counter + next() until null (src/zang/trigger.zig:66-195).  cur = the trigger's note: None
+    or (note id, params); impulses = [(frame, note id, params)].  Returns
+    ([(start, end, params, note_id_changed)], cur)."""
+    spans, ii, pos = [], 0, start
+    while pos < end:
+        span_end, note, have = end, None, False
+        if cur is not None:                                      # carryOver (:108-142)
+            if ii < len(impulses):
+                if impulses[ii][0] > pos:
+                    have, span_end, note = True, min(end, impulses[ii][0]), cur
+            else:
+                have, note = True, cur
+        if not have:                                             # getNextNoteSpan (:144-195)
+            for i in range(ii, len(impulses)):
+                fr = impulses[i][0]
+                if fr >= end:
+                    break
+                if fr > pos:
+                    span_end = fr                                # gap before the note begins
+                    break
+                ii += 1
+                end_c = min(end, impulses[i + 1][0]) if i + 1 < len(impulses) else end
+                if end_c <= pos:
+                    continue                                     # the next impulse starts at the same time
+                span_end, note = end_c, (impulses[i][1], impulses[i][2])
+                break
+        if note is not None:
+            spans.append((pos, span_end, note[1], cur is None or note[0] != cur[0]))
+            cur = note
+        pos = span_end
+    return spans, cur
+
+
 class Instance:
     """One voice of script module `module_index`: the fields of the generated struct (init():
     codegen_zig.zig:542-556) and paint()."""
@@ -29,10 +88,11 @@ class Instance:
         self.L = po.lib()
         self.mr = script.module_results[module_index]
         self.module = script.modules[module_index]
-        if self.mr.note_trackers:
-            raise NotImplementedError("track calls")
         # zang.Delay(n).init(): zeroed ring, index 0 (src/zang/delay.zig:12-17)
         self.delays = [[np.zeros(n, F32), 0] for n in self.mr.delays]
+        # NoteTracker.init(&track.notes) / Trigger.init() (codegen_zig.zig:549-554)
+        self.trackers = [{"next": 0, "t": F32(0), "cur": None} for _ in self.mr.note_trackers]
+        self.track_params = None
         self.fields = []
         for callee_index in self.mr.fields:                      # init order = field order, depth first
             callee = script.modules[callee_index]
@@ -82,6 +142,8 @@ class Instance:
             return [(t.value, v.value) for t, v in self.s.curves[r.index].points]
         if k == "self_param":
             return params[r.index]
+        if k == "track_param":
+            return self.track_params[r.index]
         raise NotImplementedError(k)
 
     @staticmethod
@@ -176,6 +238,23 @@ class Instance:
                         ring[(idx + j) % n] = fbout[pos + j]
                     self.delays[ins.delay_index][1] = (idx + cnt) % n
                     pos += cnt
+                continue
+            if k == "track_call":                                # codegen_zig.zig:359-389
+                trk = self.trackers[ins.note_tracker_index]
+                track = self.s.tracks[ins.track_index]
+                note_on = [i for i, p in enumerate(self.module.params) if p.name == "note_on"]
+                reset = bool(params[note_on[0]] and nic) if note_on else bool(nic)
+                if reset:
+                    trk["next"], trk["t"], trk["cur"] = 0, F32(0), None
+                speed = F32(self._val(ins.speed, temps, floats, params))
+                with np.errstate(all="ignore"):
+                    sr = F32(F32(params[0]) / speed)
+                impulses = note_tracker_consume(trk, [n.t.value for n in track.notes], sr, start, end)
+                spans, trk["cur"] = trigger_spans(trk["cur"], impulses, start, end)
+                for (s0, s1, note, changed) in spans:
+                    self.track_params = [self._val(r, temps, floats, params) for r in self.s.track_results[ins.track_index][note]]
+                    self._run(ins.instructions, s0, s1, out, reset or changed, params, temps, floats)
+                self.track_params = None
                 continue
             if k in ("copy_buffer", "float_to_buffer", "cob_to_buffer"):
                 src = params[ins.in_self_param] if k == "cob_to_buffer" else self._val(ins.src, temps, floats, params)

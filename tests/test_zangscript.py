@@ -90,7 +90,7 @@ def test_error_location_and_carets():
 def test_instruction_lists_and_temps():
     s = zs.compile(SCRIPT)
     names = [n for n, _ in s.exported_modules]
-    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead"]
+    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle"]
     r = s.module_results[s.module_index("Doubler")]
     assert (r.num_temps, r.num_temp_floats, [i.kind for i in r.instructions]) == (1, 0, ["cob_to_buffer", "arith_buffer_float"])
     assert r.instructions[1].out.kind == "output"           # written straight into the result location
@@ -204,25 +204,61 @@ def test_delay_front_end_and_state_layout():
     assert meta["Echo"]["state_words"] == 1 + 37 + 2         # ring index, ring, Filter (l, b)
 
 
+def test_track_call_front_end():
+    s = zs.compile(SCRIPT)
+    r = s.module_results[s.module_index("Jingle")]
+    assert r.triggers == [0] and r.note_trackers == [0] and r.num_temp_floats == 1
+    tc = [i for i in r.instructions if i.kind == "track_call"][0]
+    assert tc.out.kind == "output" and tc.speed.kind == "literal_number"
+    assert [i.kind for i in tc.instructions][:2] == ["arith_float_float", "arith_buffer_float"]      # scale = pitch / 1000, per sub-span
+    text = zs.generate_zig(s)
+    assert ".{ .t = 0.0004, .note_id = 2, .params = .{ .pitch = 1000.0, .note_on = true, .shape = .{ .cubed = 0.001 } } }," in text
+    assert "const _new_note = (params.note_on and note_id_changed) or _result.note_id_changed;" in text
+    assert "const _iap0 = self.tracker0.consume(params.sample_rate / 1.5, span);" in text
+    assert "const _new_note = note_id_changed or _result.note_id_changed;" in text            # LateJingle has no note_on param
+    _, meta = zs.generate_hip(s, only=["Jingle"])
+    assert meta["Jingle"]["state_words"] == 3 + 1 + 4 + 4     # tracker+trigger, PulseOsc, two Envelopes
+
+
+def test_oracle_trigger_against_reference_cases():
+    """The interpreter's Trigger restatement against the reference's own unit tests
+    (src/zang/trigger_test.zig, transcribed in tests/golden/scheduler_tests.json)."""
+    import json
+    from oracle import zs_interp
+    G = json.load(open(os.path.join(HERE, "golden", "scheduler_tests.json")))
+    for case in G["trigger"]:
+        cur = None
+        for step in case["steps"]:
+            impulses = [(fr, nid, p) for (fr, nid, _), p in zip(step["impulses"], step["params"])]
+            spans, cur = zs_interp.trigger_spans(cur, impulses, 0, 1024)
+            assert [list(x) for x in spans] == step["expected"], case["name"]
+
+
+def test_oracle_note_tracker_frames():
+    from oracle import zs_interp
+    st = {"next": 0, "t": np.float32(0)}
+    times = [0.0, 0.01, 0.0213, 0.5]
+    assert zs_interp.note_tracker_consume(st, times, np.float32(48000), 0, 1024) == [(0, 1, 0), (480, 2, 1), (1022, 3, 2)]
+    assert st["next"] == 3 and st["t"] == np.float32(np.float32(1024) / np.float32(48000))
+    assert zs_interp.note_tracker_consume(st, times, np.float32(48000), 100, 200) == []
+
+
 def test_unsupported_constructs_are_reported_not_miscompiled():
     src = """Player = defmodule
-    freq: cob,
+    shape: curve,
 begin
     out from deftrack
-        f: constant,
+        c: curve,
     begin
-        0.0 (f=1)
-        0.5 (f=2)
+        0.0 (c=shape)
     end, 1 begin
-        out SineOsc(freq=freq * f, phase=0)
+        out Curve(curve=c, function=.linear)
     end
 end"""
-    s = zs.compile(src)                                       # the front-end handles it (codegen.zig:558-626)
-    r = s.module_results[s.module_index("Player")]
-    assert r.triggers == [0] and r.note_trackers == [0]
-    text = zs.generate_zig(s)
-    assert ".{ .t = 0.5, .note_id = 2, .params = .{ .f = 2.0 } }," in text
-    assert "const _new_note = note_id_changed or _result.note_id_changed;" in text
+    with pytest.raises(zs.ScriptError):                       # a track note cannot reach the module's params (global context)
+        zs.compile(src)
+    src = src.replace("0.0 (c=shape)", "0.0 (c=defcurve 0 1 1 2 end)")
+    s = zs.compile(src)
     _, meta = zs.generate_hip(s)
     assert "not supported by the HIP backend" in meta["Player"]["error"]
 
@@ -390,6 +426,20 @@ def test_gpu_delay_chunks_and_nested_delays(ctx):
     f = _freqs(14)
     q = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
     _parity(ctx, "EchoLead", [(0, 50, True, q(on)), (50, F, False, q(on)), (0, F, False, q(~on))])
+
+
+@pytest.mark.gpu
+def test_gpu_track_calls(ctx):
+    """Sub-spans per note, per-note params, retrigger through note_id_changed and through the host's
+    note_on && note_id_changed reset, carried notes across paints, a gap before the first note."""
+    on = np.random.default_rng(15).random(V) < 0.8
+    f = _freqs(16)
+    p = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
+    nic = np.random.default_rng(17).random(V) < 0.5
+    _parity(ctx, "Jingle", [(0, 40, True, p(on)), (40, 90, False, p(on)), (0, F, nic, p(on)), (0, F, False, p(~on))])
+    speed = np.random.default_rng(18).uniform(0.5, 3.0, V).astype(np.float32)
+    q = {"sample_rate": 44100.0, "speed": speed}
+    _parity(ctx, "LateJingle", [(0, 50, False, q), (50, F, False, q), (0, F, True, q), (0, F, False, q)])
 
 
 @pytest.mark.gpu

@@ -345,3 +345,74 @@ struct CurveLane {
         return true;
     }
 };
+
+// ---- a canned track: NoteTracker (src/zang/notes.zig:138-207) feeding Trigger (src/zang/trigger.zig) ----
+// What zangscript's `from <track>, <speed> begin ... end` runs per paint call (codegen_zig.zig:359-389):
+// the notes that fall into this buffer become impulses, Trigger cuts the span into sub-spans that belong
+// to one note each.  The lane builds that list (<= 33 sub-spans) in begin(); frames outside every
+// sub-span (before the first note) are not painted.  A note is identified by its index in the track
+// (generated note ids are index + 1, codegen_zig.zig:497), which is all Trigger needs to remember.
+struct TrackLane {
+    uint32_t next;                                                    // NoteTracker.next_song_event
+    float t;                                                          // NoteTracker.t
+    uint32_t cur;                                                     // Trigger.note: 0 = null, else note index + 1
+    uint32_t n;                                                       // sub-spans of this paint call
+    uint32_t s_start[33], s_end[33], s_note[33];
+    bool s_new[33];
+
+    __device__ __forceinline__ void begin(const float *__restrict__ times, uint32_t n_notes, float sample_rate,
+                                          uint32_t out_len, bool reset) {
+        if (reset) { next = 0; t = 0.0f; cur = 0; }                   // tracker.reset(); trigger.reset()
+        // NoteTracker.consume (notes.zig:161-205)
+        uint32_t imp_frame[32], imp_note[32];
+        uint32_t count = 0;
+        const float buf_time = (float)out_len / sample_rate;
+        const float end_t = t + buf_time;
+        while (next < n_notes) {
+            const float note_t = times[next];
+            if (!(note_t < end_t)) break;
+            const float f = (note_t - t) / buf_time;                  // 0 to 1
+            const uint32_t rel = min(zf32_to_u32(f * (float)out_len), out_len - 1);
+            if (count < 32) { imp_frame[count] = rel; imp_note[count] = next; count++; }   // a 33rd impulse is dropped
+            next += 1;
+        }
+        t = end_t;
+        // Trigger.next until exhausted (trigger.zig:80-195)
+        n = 0;
+        uint32_t start = 0, ii = 0;
+        while (start < out_len) {
+            uint32_t span_end = out_len, note = 0;
+            bool have = false;
+            if (cur != 0) {                                           // carryOver (:108-142)
+                if (ii < count) {
+                    if (imp_frame[ii] > start) { have = true; span_end = min(out_len, imp_frame[ii]); note = cur; }
+                } else {
+                    have = true; note = cur;
+                }
+            }
+            if (!have) {                                              // getNextNoteSpan (:144-195)
+                const uint32_t ii0 = ii;
+                for (uint32_t i = ii0; i < count; i++) {
+                    const uint32_t fr = imp_frame[i];
+                    if (fr >= out_len) break;
+                    if (fr > start) { span_end = fr; break; }         // gap before the note begins
+                    ii += 1;
+                    const uint32_t end_c = (i + 1 < count) ? min(out_len, imp_frame[i + 1]) : out_len;
+                    if (end_c <= start) continue;                     // the next impulse starts at the same time
+                    span_end = end_c;
+                    note = imp_note[i] + 1;
+                    break;
+                }
+            }
+            if (note != 0) {
+                if (n < 33) {
+                    s_start[n] = start; s_end[n] = span_end; s_note[n] = note - 1;
+                    s_new[n] = cur == 0 || note != cur;               // note_id_changed (:93-96)
+                    n++;
+                }
+                cur = note;
+            }
+            start = span_end;
+        }
+    }
+};

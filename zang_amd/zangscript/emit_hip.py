@@ -14,8 +14,9 @@ To keep the reference's bits the emitted code repeats its operation order litera
   add/mul (codegen_zig.zig:205-206); and the library is compiled with contraction off.
 
 Builtin modules come from csrc/voices.cuh (the same lane objects the standalone kernels use).  Script
-modules calling script modules are inlined.  `delay` keeps its ring in the per-voice state blob.  Track
-calls (`from ... begin`) are not supported by this backend yet and raise HipBackendError."""
+modules calling script modules are inlined.  `delay` keeps its ring in the per-voice state blob; a track
+call (`from ... begin`) keeps NoteTracker + Trigger per voice and walks their sub-spans.  What the backend
+cannot express raises HipBackendError (reported per module, never miscompiled)."""
 from dataclasses import dataclass
 
 from .errors import ScriptError
@@ -48,6 +49,7 @@ def f32_literal(x):
 # 32-bit state words per voice of each builtin, and how the lane object is loaded / stored
 STATE_WORDS = {"SineOsc": 1, "PulseOsc": 1, "TriSawOsc": 2, "Noise": 8, "Envelope": 4, "Gate": 0, "Filter": 2,
                "Decimator": 2, "Distortion": 0, "Cycle": 1, "Portamento": 3, "Curve": 4}
+TRACK_WORDS = 3                       # NoteTracker {next_song_event, t} + Trigger {note}
 
 
 class _Kernel:
@@ -56,6 +58,7 @@ class _Kernel:
     def __init__(self, name):
         self.name = name
         self.params, self.pro, self.frame, self.epi_ends, self.epi_stores, self.init = [], [], [], [], [], []
+        self.tracks = set()            # track indices whose tables the kernel reads
         self.temps = []                # frame-scope float variables
         self.rows = []                 # exported param index of every frame-loop input row
         self.words = 0
@@ -85,6 +88,7 @@ class _ModuleCtx:
         self.end_sink = parent.end_sink if parent else k.epi_ends
         self.rel = parent.rel if parent else "(i - L.start)"
         self.length = parent.length if parent else "SPAN_LEN"
+        self.track = None              # inside `from <track> ... begin`: {param index: Val} of the running note
 
     def tname(self, i):
         if i not in self.tnames:
@@ -118,7 +122,7 @@ class HipEmitter:
         if k == "self_param":
             return mc.env[r.index]
         if k == "track_param":
-            raise HipBackendError("track calls are not supported by the HIP backend yet")
+            return mc.track[r.index]
         raise AssertionError(k)
 
     @staticmethod
@@ -312,10 +316,14 @@ class HipEmitter:
             k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
         elif kind == "cob_to_buffer":
             k.frame += self.put(mc, ins.out, mc.env[ins.in_self_param].expr, False)
-        elif kind == "arith_float":
-            k.pro.append("const float %s = %s;" % (mc.fname(ins.out), self.UN[ins.op] % self.val(mc, ins.a).expr))
-        elif kind == "arith_float_float":
-            k.pro.append("const float %s = %s;" % (mc.fname(ins.out), self.BIN[ins.op] % (self.val(mc, ins.a).expr, self.val(mc, ins.b).expr)))
+        elif kind in ("arith_float", "arith_float_float"):
+            expr = (self.UN[ins.op] % self.val(mc, ins.a).expr if kind == "arith_float"
+                    else self.BIN[ins.op] % (self.val(mc, ins.a).expr, self.val(mc, ins.b).expr))
+            if mc.begin_sink is k.pro:
+                k.pro.append("const float %s = %s;" % (mc.fname(ins.out), expr))
+            else:                      # inside a delay / track body: evaluated once per chunk, like the Zig `const` in the loop
+                k.pro.append("float %s = 0.0f;" % mc.fname(ins.out))
+                mc.begin_sink.append("%s = %s;" % (mc.fname(ins.out), expr))
         elif kind == "arith_buffer":
             k.frame += self.put(mc, ins.out, self.UN[ins.op] % self.val(mc, ins.a).expr, False)
         elif kind in ("arith_float_buffer", "arith_buffer_float", "arith_buffer_buffer"):
@@ -342,7 +350,7 @@ class HipEmitter:
                 sub = _ModuleCtx(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", parent=mc)
                 self.module_body(sub)
         elif kind == "track_call":
-            raise HipBackendError("track calls (`from ... begin`) are not supported by the HIP backend yet")
+            self.track_call(mc, mr, ins)
         elif kind == "delay":
             self.delay(mc, mr, ins)
         else:
@@ -391,6 +399,90 @@ class HipEmitter:
         if ends:
             k.frame += ["if (%s + 1u == %s) {" % (rel, length)] + ["    " + l for l in ends] + ["}"]
 
+    def track_call(self, mc, mr, ins):
+        """`from <track>, <speed> begin ... end` (codegen_zig.zig:359-389): NoteTracker.consume turns the
+        track's notes that fall into this paint call into impulses, Trigger cuts the span into one
+        sub-span per note, and the body is painted once per sub-span with that note's params and
+        `_new_note`.  TrackLane (voices.cuh) builds the sub-span list in the prologue; the frame loop
+        runs the body's per-paint prologue at a sub-span's first frame, its epilogue at the last, and
+        paints nothing outside the sub-spans (before the first note)."""
+        k = mc.k
+        ti = ins.track_index
+        track = self.s.tracks[ti]
+        module = self.s.modules[mc.module_index]
+        w = k.alloc(TRACK_WORDS)
+        t = k.fresh("trk")
+        k.tracks.add(ti)
+        # the running note's params: plain variables, reloaded at every sub-span start
+        env, loads = {}, []
+        for pi, p in enumerate(track.params):
+            kind = p.param_type.kind
+            if kind == "constant":
+                k.pro.append("float %s_p%d = 0.0f;" % (t, pi))
+                loads.append("%s_p%d = zs_track%d_p%d[%s_note];" % (t, pi, ti, pi, t))
+                env[pi] = Val("float", "%s_p%d" % (t, pi))
+            elif kind == "boolean":
+                k.pro.append("bool %s_p%d = false;" % (t, pi))
+                loads.append("%s_p%d = zs_track%d_p%d[%s_note] != 0;" % (t, pi, ti, pi, t))
+                env[pi] = Val("bool", "%s_p%d" % (t, pi))
+            elif kind == "one_of":
+                k.pro.append("uint32_t %s_p%d = 0u; float %s_q%d = 0.0f;" % (t, pi, t, pi))
+                loads.append("%s_p%d = zs_track%d_p%d[%s_note]; %s_q%d = zs_track%d_q%d[%s_note];" % (t, pi, ti, pi, t, t, pi, ti, pi, t))
+                env[pi] = Val("enum", tag="%s_p%d" % (t, pi), payload=Val("float", "%s_q%d" % (t, pi)), enum=p.param_type.enum)
+            else:
+                raise HipBackendError("track param `%s`: type %s is not supported by the HIP backend" % (p.name, kind))
+        has_note_on = [i for i, p in enumerate(module.params) if p.name == "note_on"]
+        reset = "(%s && %s)" % (mc.env[has_note_on[0]].expr, mc.nic) if has_note_on else mc.nic    # codegen_zig.zig:362-371
+        k.pro += ["TrackLane %s;" % t,
+                  "%s.next = zs_ld_u(L.state, %d, V, v); %s.t = zs_ld_f(L.state, %d, V, v); %s.cur = zs_ld_u(L.state, %d, V, v);" % (t, w, t, w + 1, t, w + 2),
+                  "uint32_t %s_k = 0u, %s_note = 0u; bool %s_new = false;" % (t, t, t)]
+        k.epi_stores.append("zs_st_u(L.state, %d, V, v, %s.next); zs_st_f(L.state, %d, V, v, %s.t); zs_st_u(L.state, %d, V, v, %s.cur);" % (w, t, w + 1, t, w + 2, t))
+        # tracker.consume(params.sample_rate / speed, span); trigger.counter(span, iap)
+        mc.begin_sink += ["%s.begin(zs_track%d_t, %du, (%s) / (%s), %s, %s);" % (t, ti, len(track.notes), mc.env[0].expr, self.val(mc, ins.speed).expr, mc.length, reset),
+                          "%s_k = 0u;" % t]
+        begins, ends, body = [], [], []
+        saved = (mc.begin_sink, mc.end_sink, mc.rel, mc.length, mc.nic, mc.track, k.frame)
+        outer_rel = saved[2]
+        mc.begin_sink, mc.end_sink, k.frame = begins, ends, body
+        mc.rel = "(%s_rel - %s.s_start[%s_k])" % (t, t, t)
+        mc.length = "(%s.s_end[%s_k] - %s.s_start[%s_k])" % (t, t, t, t)
+        mc.nic, mc.track = "%s_new" % t, env
+        try:
+            for sub in ins.instructions:
+                self.instruction(mc, mr, sub)
+        finally:
+            mc.begin_sink, mc.end_sink, mc.rel, mc.length, mc.nic, mc.track, k.frame = saved
+        I = "    "
+        k.frame += ["const uint32_t %s_rel = %s;" % (t, outer_rel),
+                    "if (%s_k < %s.n && %s_rel == %s.s_start[%s_k]) {" % (t, t, t, t, t),
+                    I + "%s_note = %s.s_note[%s_k];" % (t, t, t),
+                    I + "%s_new = %s || %s.s_new[%s_k];" % (t, reset, t, t)]      # _new_note (:379-383)
+        k.frame += [I + l for l in loads + begins] + ["}"]
+        k.frame += ["const bool %s_on = %s_k < %s.n && %s_rel >= %s.s_start[%s_k];" % (t, t, t, t, t, t),
+                    "if (%s_on) {" % t] + [I + l for l in body] + ["}"]
+        k.frame += ["if (%s_on && %s_rel + 1u == %s.s_end[%s_k]) {" % (t, t, t, t)] + [I + l for l in ends] + [I + "%s_k++;" % t, "}"]
+
+    def track_tables(self, ti):
+        """The track's notes as device tables: times, and one table per param (values are literals: the
+        notes are evaluated in the global context, codegen.zig:692-706)."""
+        track = self.s.tracks[ti]
+        notes = self.s.track_results[ti]
+        n = max(len(track.notes), 1)
+        out = ["__device__ const float zs_track%d_t[%d] = {%s};" % (ti, n, ", ".join(f32_literal(x.t.value) for x in track.notes) or "0.0f")]
+        for pi, p in enumerate(track.params):
+            kind = p.param_type.kind
+            vals = [notes[ni][pi] for ni in range(len(track.notes))]
+            if kind == "constant":
+                out.append("__device__ const float zs_track%d_p%d[%d] = {%s};" % (ti, pi, n, ", ".join(f32_literal(r.value.value) for r in vals) or "0.0f"))
+            elif kind == "boolean":
+                out.append("__device__ const unsigned char zs_track%d_p%d[%d] = {%s};" % (ti, pi, n, ", ".join("1" if r.value else "0" for r in vals) or "0"))
+            elif kind == "one_of":
+                labels = [v.label for v in p.param_type.enum.values]
+                out.append("__device__ const unsigned int zs_track%d_p%d[%d] = {%s};" % (ti, pi, n, ", ".join(str(labels.index(r.value)) for r in vals) or "0"))
+                out.append("__device__ const float zs_track%d_q%d[%d] = {%s};" % (
+                    ti, pi, n, ", ".join(f32_literal(r.payload.value.value) if r.payload is not None else "0.0f" for r in vals) or "0.0f"))
+        return out
+
     def module_body(self, mc):
         mr = self.s.module_results[mc.module_index]
         for ins in mr.instructions:
@@ -435,6 +527,7 @@ class HipEmitter:
             pts = ", ".join("{%s, %s}" % (f32_literal(v.value), f32_literal(t.value)) for t, v in curve.points)   # {value, t}
             out.append("__device__ const zh_curve_node zs_curve%d[] = {%s};" % (ci, pts or "{0.0f, 0.0f}"))
         meta = {}
+        used_tracks, table_at = set(), len(out)
         for name, mi in self.s.exported_modules:
             if only is not None and name not in only:
                 continue
@@ -445,6 +538,7 @@ class HipEmitter:
                 out += ["", "// %s: %s" % (name, e)]
                 continue
             meta[name] = {"state_words": k.words, "params": k.params, "noise_fields": k.noise_fields}
+            used_tracks |= k.tracks
             nin = len(k.rows)
             ni = max(nin, 1)
             I = "    "
@@ -476,6 +570,10 @@ class HipEmitter:
             out.append(I + "});")
             out += [I + l for l in k.epi_ends + k.epi_stores]
             out.append("}")
+        tables = []
+        for ti in sorted(used_tracks):
+            tables += self.track_tables(ti)
+        out[table_at:table_at] = tables
         return "\n".join(out) + "\n", meta
 
 
