@@ -31,12 +31,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 SR = 48000.0
 
 
+SCRIPT_MODULE = "Lead"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "noise_filter_fused", "nice", "nice_mix"])
+    ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "noise_filter_fused", "nice", "nice_mix", "script"])
     ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
@@ -56,7 +59,7 @@ class Workload:
         self.name, self.V, self.F = name, V, F
         self.ctx = ctx
         self.span = zang.Span(0, F)
-        cfg = {"pulseosc": 2, "noise_filter": 3, "noise_filter_fused": 3, "nice": 5, "nice_mix": 5}[name]
+        cfg = {"pulseosc": 2, "noise_filter": 3, "noise_filter_fused": 3, "nice": 5, "nice_mix": 5, "script": 5}[name]
         freq, color, u2, u3 = workloads.voice_params(cfg, first_voice, V)
         self.freq_h, self.color_h, self.u2_h, self.u3_h = freq, color, u2, u3
         dev = ctx.device
@@ -91,6 +94,17 @@ class Workload:
             self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
             self.kernel = "k_noise_filter"
             self.step = self._step_noise_filter_fused
+        elif name == "script":
+            # a zangscript module compiled to ONE fused kernel at start-up (hiprtc): `Lead` of the repo's test
+            # script = 5 SineOsc + 3 Envelope + arithmetic, two inlined script modules
+            from zang_amd import script as zscript
+            text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "script_modules.txt")).read()
+            self.program = zscript.ScriptProgram(text, ctx, only=[SCRIPT_MODULE])
+            self.m = self.program.module(SCRIPT_MODULE, V)
+            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.kernel = "zs_paint_" + SCRIPT_MODULE
+            self.step = self._step_script
+            self.nsteps = 0
         elif name == "nice":
             self.m = mod.NiceInstrument(V, self.color, ctx)
             self.ring = [ctx.image(F, V) for _ in range(nring)]
@@ -111,7 +125,7 @@ class Workload:
         """Steps per captured graph: a whole number of ring rotations, even (see bench main)."""
         if self.name == "nice_mix" and self.world > 1:
             return 0                        # the per-buffer all-reduce is issued by torch.distributed: eager
-        if self.name in ("nice", "nice_mix"):
+        if self.name in ("nice", "nice_mix", "script"):
             return 48                       # the note on/off pattern repeats every 48 buffers
         g = max(self.nring, 2)
         return g if g % 2 == 0 else 2 * g
@@ -149,6 +163,10 @@ class Workload:
         on, new = self._note_on()
         self.m.paint(self.span, [self._next()], [], new, self.m.Params(SR, self.freq, on), zero_first=True)
 
+    def _step_script(self):
+        on, new = self._note_on()
+        self.m.paint(self.span, [self._next()], None, new, {"sample_rate": SR, "freq": self.freq, "note_on": on}, zero_first=True)
+
     def _step_nice_mix(self):
         on, new = self._note_on()
         self.m.paint_mix(self.span, self.mix, new, self.m.Params(SR, self.freq, on), zero_first=True)
@@ -182,6 +200,22 @@ def cpu_baseline(args, wl):
         res = (0.9 * wl.u3_h[:V]).astype(np.float32)
         run = lambda n: L.zo_bench_noise_filter(V, F, n, po.fptr(cutoff), po.fptr(res), noise, flt, po.fptr(scratch))
         what = "zero + Noise.paint + zero + Filter.paint per voice"
+    elif wl.name == "script":
+        # the same instruction list run the way the generated Zig would run it: buffer-level ops through temps
+        from oracle import zs_interp
+        V = min(V, 64)
+        voices = zs_interp.make_voices(wl.program.script, SCRIPT_MODULE, V)
+        out = np.zeros(F, np.float32)
+        state = {"n": 0}
+
+        def run(n):
+            for _ in range(n):
+                k = state["n"] % 48
+                state["n"] += 1
+                for v in range(V):
+                    out[:] = 0
+                    voices[v].paint(0, F, out, k == 0, [np.float32(SR), np.float32(wl.freq_h[v]), k < 24])
+        what = "script module %s through the oracle-side interpreter (oracle paints + buffer ops; Python dispatch per op)" % SCRIPT_MODULE
     else:
         scratch = np.zeros(3 * F, np.float32)
         inst = (po.NiceInstrument * V)()

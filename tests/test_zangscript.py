@@ -90,7 +90,7 @@ def test_error_location_and_carets():
 def test_instruction_lists_and_temps():
     s = zs.compile(SCRIPT)
     names = [n for n, _ in s.exported_modules]
-    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle"]
+    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle", "Trig"]
     r = s.module_results[s.module_index("Doubler")]
     assert (r.num_temps, r.num_temp_floats, [i.kind for i in r.instructions]) == (1, 0, ["cob_to_buffer", "arith_buffer_float"])
     assert r.instructions[1].out.kind == "output"           # written straight into the result location
@@ -440,6 +440,22 @@ def test_gpu_track_calls(ctx):
     speed = np.random.default_rng(18).uniform(0.5, 3.0, V).astype(np.float32)
     q = {"sample_rate": 44100.0, "speed": speed}
     _parity(ctx, "LateJingle", [(0, 50, False, q), (50, F, False, q), (0, F, True, q), (0, F, False, q)])
+
+
+@pytest.mark.gpu
+def test_gpu_trig_all_argument_ranges(ctx):
+    """sin / cos across musl's magnitude ranges, both signs, the range boundaries, tiny, huge, inf, nan."""
+    edges = np.array([0x3f490fda, 0x4016cbe3, 0x407b53d1, 0x40afeddf, 0x40e231d5, 0x39800000, 0x4dc90fdb, 0x7f7fffff], np.uint32)
+    near = np.concatenate([edges - 1, edges, edges + 1]).view(np.float32)
+    special = np.array([0.0, -0.0, 1e-30, -1e-30, np.inf, -np.inf, np.nan, 1e10, -3e20, 12345.678], np.float32)
+    rng = np.random.default_rng(19)
+    x = rng.uniform(-8, 8, (V, F)).astype(np.float32)
+    x[0, :len(near)] = near
+    x[1, :len(near)] = -near
+    x[2, :len(special)] = special
+    x[3] = rng.uniform(-2000, 2000, F).astype(np.float32)
+    x[4] = (rng.standard_normal(F) * 1e-3).astype(np.float32)
+    _parity(ctx, "Trig", [(0, F, False, {"sample_rate": 48000.0, "x": x})])
 
 
 @pytest.mark.gpu

@@ -188,68 +188,47 @@ ZD int zrem_pio2f(float x, double *y) {
     return n;
 }
 
-ZD float zsinf(float x) {
+// musl sinf / cosf (what Zig's std.math.sin / cos are ported from): reduce x to y in [-pi/4, pi/4] with
+// x = y + n*pi/2 (in double), then one of two polynomial kernels picked by n & 3.  musl spells the
+// reduction out as five magnitude ranges times two signs for |x| <= 9pi/4 and a general routine above.
+// A wave's lanes sit in all of those leaves at once (oscillator phases are spread), so here the
+// leaves are folded: k from four compares, d = |x| - k*pi/2 (the same double operation as every
+// leaf's `x -+ k*pio2`, up to an exact sign), (n, y) = (+-k, +-d); larger |x| go through the general
+// reduction; then ONE evaluation of each kernel and selects.  Same operations per lane => same bits
+// (the kernels are odd / even, so moving a negation across them is exact).
+ZD int zreduce_pio2f(float x, uint32_t ix, bool sign, double &y) {
     const double pio2 = 1.57079632679489661923;
-    uint32_t ix = zf2u(x);
-    int sign = ix >> 31;
-    double y;
-    ix &= 0x7fffffff;
-    if (ix <= 0x3f490fda) {
-        if (ix < 0x39800000) return x;
-        return zsindf(x);
+    if (ix <= 0x40e231d5) {                                   // |x| <= 9pi/4
+        const uint32_t k = (ix > 0x3f490fda) + (ix > 0x4016cbe3) + (ix > 0x407b53d1) + (ix > 0x40afeddf);
+        const double d = fabs((double)x) - (double)k * pio2;  // k*pio2: exact for 1, 2, 4; 3*pio2 rounds once like musl's s3pio2
+        y = sign ? -d : d;
+        return sign ? -(int)k : (int)k;
     }
-    if (ix <= 0x407b53d1) {
-        if (ix <= 0x4016cbe3) {
-            if (sign) return -zcosdf(x + 1 * pio2);
-            return zcosdf(x - 1 * pio2);
-        }
-        return zsindf(sign ? -(x + 2 * pio2) : -(x - 2 * pio2));
-    }
-    if (ix <= 0x40e231d5) {
-        if (ix <= 0x40afeddf) {
-            if (sign) return zcosdf(x + 3 * pio2);
-            return -zcosdf(x - 3 * pio2);
-        }
-        return zsindf(sign ? x + 4 * pio2 : x - 4 * pio2);
-    }
+    return zrem_pio2f(x, &y);
+}
+
+ZD float zsinf(float x) {
+    const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
     if (ix >= 0x7f800000) return x - x;
-    int n = zrem_pio2f(x, &y);
-    switch (n & 3) {
-    case 0: return zsindf(y);
-    case 1: return zcosdf(y);
-    case 2: return zsindf(-y);
-    default: return -zcosdf(y);
-    }
+    double y;
+    const int n = zreduce_pio2f(x, ix, (ux >> 31) != 0, y);
+    // n & 3: 0 sindf(y) | 1 cosdf(y) | 2 sindf(-y) | 3 -cosdf(y)
+    const float sv = zsindf((n & 2) ? -y : y), cv = zcosdf(y);
+    float r = (n & 1) ? ((n & 2) ? -cv : cv) : sv;
+    if (ix < 0x39800000) r = x;                               // |x| < 2^-12
+    return r;
 }
 
 ZD float zcosf(float x) {
-    const double pio2 = 1.57079632679489661923;
-    uint32_t ix = zf2u(x);
-    int sign = ix >> 31;
-    double y;
-    ix &= 0x7fffffff;
-    if (ix <= 0x3f490fda) {
-        if (ix < 0x39800000) return 1.0f;
-        return zcosdf(x);
-    }
-    if (ix <= 0x407b53d1) {
-        if (ix > 0x4016cbe3) return -zcosdf(sign ? x + 2 * pio2 : x - 2 * pio2);
-        if (sign) return zsindf(x + 1 * pio2);
-        return zsindf(1 * pio2 - x);
-    }
-    if (ix <= 0x40e231d5) {
-        if (ix > 0x40afeddf) return zcosdf(sign ? x + 4 * pio2 : x - 4 * pio2);
-        if (sign) return zsindf(-x - 3 * pio2);
-        return zsindf(x - 3 * pio2);
-    }
+    const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
     if (ix >= 0x7f800000) return x - x;
-    int n = zrem_pio2f(x, &y);
-    switch (n & 3) {
-    case 0: return zcosdf(y);
-    case 1: return zsindf(-y);
-    case 2: return -zcosdf(y);
-    default: return zsindf(y);
-    }
+    double y;
+    const int n = zreduce_pio2f(x, ix, (ux >> 31) != 0, y);
+    // n & 3: 0 cosdf(y) | 1 sindf(-y) | 2 -cosdf(y) | 3 sindf(y)
+    const float sv = zsindf((n & 2) ? y : -y), cv = zcosdf(y);
+    float r = (n & 1) ? sv : ((n & 2) ? -cv : cv);
+    if (ix < 0x39800000) r = 1.0f;
+    return r;
 }
 
 // ---- atanf (f32 arithmetic throughout) ------------------------------------------------

@@ -17,6 +17,7 @@ Builtin modules come from csrc/voices.cuh (the same lane objects the standalone 
 modules calling script modules are inlined.  `delay` keeps its ring in the per-voice state blob; a track
 call (`from ... begin`) keeps NoteTracker + Trigger per voice and walks their sub-spans.  What the backend
 cannot express raises HipBackendError (reported per module, never miscompiled)."""
+import os
 from dataclasses import dataclass
 
 from .errors import ScriptError
@@ -541,6 +542,10 @@ class HipEmitter:
             used_tracks |= k.tracks
             nin = len(k.rows)
             ni = max(nin, 1)
+            # frames per unrolled chunk of the frame loop: the unroll exists to prefetch input rows; a body
+            # that is large (many inlined module calls) is not replicated 8x -- the 64 KiB instruction cache
+            # is shared by two CUs
+            unroll = int(os.environ.get("ZH_SCRIPT_UNROLL", "0")) or (8 if len(k.frame) <= 40 else 4 if len(k.frame) <= 100 else 2)
             I = "    "
             out += ["", 'extern "C" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {' % name,
                     I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;", I + "if (v >= V) return;",
@@ -561,7 +566,7 @@ class HipEmitter:
             for j, pi in enumerate(k.rows):
                 out.append(I + "ins[%d] = zs_row(L.p[%d], v, istr[%d]);" % (j, pi, j))
             out += [I + l for l in k.pro]
-            out.append(I + "zs_frame_loop<8, %d>(L.out + v, L.ostride, ins, istr, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0," % nin)
+            out.append(I + "zs_frame_loop<%d, %d>(L.out + v, L.ostride, ins, istr, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0," % (unroll, nin))
             out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
             out.append(I + I + "(void)i; (void)x;")
             if k.temps:
