@@ -44,6 +44,31 @@ pub extern fn zh_multiply_scalar(ctx: *Ctx, start: u32, end: u32, dest: Buf, a: 
 pub extern fn zh_multiply_with_scalar(ctx: *Ctx, start: u32, end: u32, dest: Buf, a: F32) c_int;
 pub extern fn zh_mixdown_voices(ctx: *Ctx, start: u32, end: u32, dst: [*]f32, src: Buf, flags: u32) c_int;
 
+// zangscript modules (include/zang_hip.h "zangscript modules"): HIP source from `python -m zang_amd.zangc`
+pub const Script = opaque {};
+pub const ScriptModule = opaque {};
+pub const SP_CONSTANT: u32 = 0;
+pub const SP_BOOLEAN: u32 = 1;
+pub const SP_COB: u32 = 2;
+pub const SP_BUFFER: u32 = 3;
+pub const SP_ENUM: u32 = 4;
+pub const SP_CURVE: u32 = 5;
+pub const ScriptParam = extern struct {
+    kind: u32,
+    u: u32 = 0,
+    f: f32 = 0,
+    is_buffer: u32 = 0,
+    pf: ?[*]const f32 = null,
+    pb: ?[*]const u8 = null,
+    stride: u32 = 0,
+    reserved: u32 = 0,
+};
+pub extern fn zh_script_load(ctx: *Ctx, hip_source: [*:0]const u8, out: *?*Script, log: ?[*]u8, log_cap: usize) c_int;
+pub extern fn zh_script_destroy(s: *Script) c_int;
+pub extern fn zh_script_module_create(s: *Script, name: [*:0]const u8, n_voices: u32, state_words: u32, first_seed: u64, out: *?*ScriptModule) c_int;
+pub extern fn zh_script_module_destroy(m: *ScriptModule) c_int;
+pub extern fn zh_script_module_paint(m: *ScriptModule, start: u32, end: u32, outputs: [*]const Buf, note_id_changed: Bool, params: [*]const ScriptParam, n_params: u32, flags: u32) c_int;
+
 // PulseOsc (src/modules/PulseOsc.zig)
 pub const PulseOscHandle = opaque {};
 pub const PulseOscParams = extern struct { sample_rate: f32, reserved: u32 = 0, freq: Cob, color: F32 };

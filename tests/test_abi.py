@@ -58,7 +58,7 @@ def test_struct_sizes_match_c_layout():
              "zh_filter_params": abi.FilterParams, "zh_sample": abi.Sample, "zh_sampler_params": abi.SamplerParams,
              "zh_decimator_params": abi.DecimatorParams, "zh_distortion_params": abi.DistortionParams,
              "zh_nice_params": abi.NiceParams, "zh_nice_state": abi.NiceState, "zh_pmosc_params": abi.PMOscParams,
-             "zh_pmosc_state": abi.PMOscState, "zh_trisawosc_state": abi.TriSawOscState}
+             "zh_pmosc_state": abi.PMOscState, "zh_trisawosc_state": abi.TriSawOscState, "zh_script_param": abi.ScriptParam}
     prog = '#include <stdio.h>\n#include "zang_hip.h"\nint main(void){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     import tempfile

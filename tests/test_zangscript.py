@@ -479,3 +479,25 @@ def test_gpu_zero_first_and_state_roundtrip(ctx):
     with pytest.raises(KeyError):
         mod.paint(zang.Span(0, 8), [img], None, False, {"sample_rate": 48000.0, "freq": 1.0})
     prog.close()
+
+
+def test_zangc_cli(tmp_path):
+    """python -m zang_amd.zangc: both backends, the dumps, error exit code (tools/zangc.zig:8-27)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    src = os.path.join(HERE, "golden", "script_modules.txt")
+    out, cg, bi = tmp_path / "o.hip", tmp_path / "cg.txt", tmp_path / "bi.txt"
+    r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", src, "-o", str(out), "--dump-codegen", str(cg), "--dump-builtins", str(bi)],
+                       cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert 'extern "C" __global__ void __launch_bounds__(64) zs_paint_Lead' in out.read_text()
+    assert "module Lead: 17 state words/voice" in r.stderr
+    assert "module Pluck: num_temps=3" in cg.read_text() and "enum FilterType: bypass, low_pass" in bi.read_text()
+    z = tmp_path / "o.zig"
+    assert subprocess.run([sys.executable, "-m", "zang_amd.zangc", src, "--backend", "zig", "-o", str(z)], cwd=root).returncode == 0
+    assert z.read_text().startswith("// THIS FILE WAS GENERATED BY THE ZANGC COMPILER")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("X = defmodule\nbegin\n out foo\nend\n")
+    r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", str(bad), "--check"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 1 and ":3:6: use of undeclared identifier `foo`" in r.stderr
