@@ -21,5 +21,7 @@ run nice4096 --workload nice --steps 96 --warmup 48
 run nice131072 --workload nice --voices 131072 --steps 96 --warmup 48
 run nice_mix131072 --workload nice_mix --voices 131072 --steps 96 --warmup 48
 run nice_mix1M --workload nice_mix --voices 1048576 --steps 48 --warmup 48
+run script131072 --workload script --voices 131072 --steps 96 --warmup 48
+run noise_filter_fused131072 --workload noise_filter_fused --voices 131072 --steps 50 --warmup 10
 for f in $out/*_bench.json; do tail -1 $f > $f.tmp; mv $f.tmp $f; done
 ls $out
