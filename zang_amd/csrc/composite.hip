@@ -286,20 +286,31 @@ struct SpanTableP {
     const uint8_t *note_on, *nic;
 };
 
+// The wave walks the buffer in segments that end at the next sub-span boundary of ANY of its lanes
+// (a wave-wide minimum): inside a segment no lane starts or ends a sub-span, so the frame loop is
+// the plain one of k_nice / k_pmosc with an `active` select -- checking every lane's boundaries on
+// every frame made this kernel 3x slower per frame than k_nice.  Boundaries mostly coincide (every
+// voice has one at each 1024-frame buffer edge), so segments are long.  `live` = the lane owns a voice;
+// all 64 lanes take part in the minimum.
 template <bool ZF, class Lane, class Begin, class End>
-__device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_t V, uint32_t v, Img out,
+__device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_t V, uint32_t v, bool live, Img out,
                                           uint32_t buf_start, uint32_t buf_end, Begin &&begin, End &&end_fn) {
-    const uint32_t cnt = min(tb.count[v], tb.K);
+    const uint32_t cnt = live ? min(tb.count[v], tb.K) : 0;
     uint32_t k = 0, cur_end = 0;
+    uint32_t next_start = cnt > 0 ? tb.start[v] : 0xffffffffu;
     bool active = false;
     const float *const *no_in = nullptr;
     auto advance = [&](uint32_t i) ZH_INLINE_LAMBDA {
         for (;;) {
             if (active) {
-                if (i == cur_end) { end_fn(); active = false; k++; continue; }
+                if (i == cur_end) {
+                    end_fn(); active = false; k++;
+                    next_start = k < cnt ? tb.start[(size_t)k * V + v] : 0xffffffffu;
+                    continue;
+                }
                 break;
             }
-            if (k < cnt && tb.start[(size_t)k * V + v] == i) {
+            if (i == next_start) {
                 const size_t idx = (size_t)k * V + v;
                 cur_end = tb.end[idx];
                 begin(tb.freq[idx], tb.note_on[idx] != 0, tb.nic[idx] != 0);
@@ -309,42 +320,57 @@ __device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_
             break;
         }
     };
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, buf_start, buf_end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        advance(i);
-        if (!active) return false;
-        val = n.frame();
-        return true;
-    });
+    uint32_t i = buf_start;
+    while (i < buf_end) {
+        advance(i);                                             // sub-spans that end / begin at frame i
+        uint32_t ev = active ? cur_end : next_start;            // this lane's next boundary (> i)
+        ev = (ev > i && ev < buf_end) ? ev : buf_end;           // unsorted / out-of-range entries never fire, as before
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ev = min(ev, (uint32_t)__shfl_xor((int)ev, off));
+        const uint32_t seg_end = __builtin_amdgcn_readfirstlane(ev);
+        if (live) {
+            frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, i, seg_end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+                if (!active) return false;
+                val = n.frame();
+                return true;
+            });
+        }
+        i = seg_end;
+    }
     advance(buf_end);          // a sub-span that ends with the buffer; empty sub-spans at buf_end
 }
 
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_nice_spans(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
-    if (v >= a.V) return;
+    const uint32_t v0 = blockIdx.x * kSeqBlock + threadIdx.x;
+    const bool live = v0 < a.V;
+    const uint32_t v = live ? v0 : 0;                           // idle lanes shadow voice 0 read-only and store nothing
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
     n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
     n.bad = true; n.k = PulseK{0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; n.cut = n.res = 0.0f;
     const float color = a.color[v];
-    span_walk<ZF>(n, tb, a.V, v, out, start, end,
+    span_walk<ZF>(n, tb, a.V, v, live, out, start, end,
                   [&](float freq, bool on, bool nic) ZH_INLINE_LAMBDA { n.begin(a.sample_rate, a.srf, a.sr8, freq, color, on, nic); },
                   [&]() ZH_INLINE_LAMBDA {});
+    if (!live) return;
     a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
     a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
 }
 
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
-    if (v >= a.V) return;
+    const uint32_t v0 = blockIdx.x * kSeqBlock + threadIdx.x;
+    const bool live = v0 < a.V;
+    const uint32_t v = live ? v0 : 0;
     PMLane n;
     pm_load(n, a, v);
     n.mod_freq = n.inv_sr = n.t_step = 0.0f;
     const float rel = a.release_duration[v];
-    span_walk<ZF>(n, tb, a.V, v, out, start, end,
+    span_walk<ZF>(n, tb, a.V, v, live, out, start, end,
                   [&](float freq, bool on, bool nic) ZH_INLINE_LAMBDA { n.begin(a.sample_rate, freq, rel, on, nic); },
                   [&]() ZH_INLINE_LAMBDA { n.end(); });
+    if (!live) return;
     pm_store(n, a, v);
 }
 
