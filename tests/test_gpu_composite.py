@@ -166,3 +166,19 @@ def test_noise_filter_fused_equals_unfused(ctx, oracle, color, ftype):
     st = m.state()
     util.assert_bitexact(st["flt"]["l"].astype(np.float32), rl, "l"); util.assert_bitexact(st["flt"]["b"].astype(np.float32), rb, "b")
     assert [[int(x) for x in row] for row in st["noise"]["r"]] == rs
+
+
+@pytest.mark.gpu
+def test_nice_two_voices_per_lane_variant_is_bit_identical():
+    """ZH_NICE_W=2 (lanes.cuh: packed-f32 voice pairs, off by default because it measured slower) must give
+    the same bits: rerun the NiceInstrument parity tests in a subprocess with the variant selected."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZH_NICE_W="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
+                        "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout
