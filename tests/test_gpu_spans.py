@@ -65,10 +65,13 @@ def test_nice_paint_spans(ctx, oracle):
     util.assert_bitexact(gs["flt"]["l"].astype(np.float32), np.array([r.flt.l for r in st], np.float32), "l")
 
 
-def test_pmosc_paint_spans_zero_first(ctx, oracle):
+@pytest.mark.parametrize("V,zero_first", [(128, True), (20, True), (20, False), (64, False), (65, False)])
+def test_pmosc_paint_spans(ctx, oracle, V, zero_first):
+    """V > 64: lane-per-voice walk (k_pmosc_spans); V <= 64: one wave per voice, lanes = frames
+    (k_pmosc_spans_wave).  zero_first on garbage / ADD onto an existing image."""
     from zang_amd import modules as mod, zang
     from zang_amd.spans import SpanTable
-    V, nbuf = 128, 3
+    nbuf = 3
     rel = np.random.default_rng(3).uniform(0.05, 0.5, V).astype(np.float32)
     bufs = _random_tables(V, nbuf, 4)
     L = oracle.lib()
@@ -77,13 +80,14 @@ def test_pmosc_paint_spans_zero_first(ctx, oracle):
         L.zo_pmosc_init(C.byref(st[v]), float(rel[v]))
     m = mod.PMOscInstrument(V, util.dev(rel), ctx)
     t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32); t2 = np.zeros(F, np.float32)
+    base = util.rng_buffers(5, V, F)
     for b in range(nbuf):
-        ref = np.zeros((V, F), np.float32)
+        ref = np.zeros((V, F), np.float32) if zero_first else base.copy()
         for v in range(V):
             for (s, e, f, on, nic) in bufs[b][v]:
                 L.zo_pmosc_paint(C.byref(st[v]), s, e, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(t2), int(nic), SR, f, int(on))
-        out = util.to_image(util.rng_buffers(5, V, F))          # garbage: ZERO_FIRST must clear unpainted frames too
-        m.paint_spans(zang.Span(0, F), [out], None, SR, SpanTable(bufs[b], ctx.device), zero_first=True)
+        out = util.to_image(base)                                # garbage: ZERO_FIRST must clear unpainted frames too
+        m.paint_spans(zang.Span(0, F), [out], None, SR, SpanTable(bufs[b], ctx.device), zero_first=zero_first)
         ctx.sync()
         util.assert_bitexact(util.from_image(out), ref, f"pmosc spans buffer {b}")
     gs = m.state()

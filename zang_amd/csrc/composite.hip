@@ -226,21 +226,30 @@ struct PMLane {
         t_step = freq / sample_rate;                                   // carrier: constant-frequency path (:44)
     }
 
-    __device__ __forceinline__ float frame() {
-        // modulator.paint -> temps[1] (zeroed): sin(t + 0.0), t += freq_buf[i] * inv_sr   (:59-63)
-        const float m = 0.0f + sine_osc_sin(tm + 0.0f);
-        tm += mod_freq * inv_sr;
-        // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
-        const float ph = 0.0f + m * 1.0f;
-        // carrier.paint -> temps[1] (zeroed): sin(t + phase[i]), t += t_step   (:69-74)
-        const float c = 0.0f + sine_osc_sin(tc + ph);
-        tc += t_step;
-        // PhaseModOscillator output (PMOsc temps[0], zeroed) += temps[1]   (:75)
-        const float osc = 0.0f + c;
-        // envelope -> temps[1] (zeroed)   (:117-125)
-        float ev = 0.0f, e0 = 0.0f;
+    // One frame in two parts.  step(): everything that carries state from frame to frame -- both phase
+    // accumulators and the envelope -- returning what this frame's sample is made from.  value(): the
+    // two sines and the products, a pure function of those three numbers (so it can be evaluated for
+    // many frames at once, k_pmosc_spans_wave).
+    __device__ __forceinline__ void step(float &tm_i, float &tc_i, float &e0) {
+        tm_i = tm;
+        tm += mod_freq * inv_sr;                                       // modulator: t += freq_buf[i] * inv_sr (:59-63)
+        tc_i = tc;
+        tc += t_step;                                                  // carrier: t += t_step (:69-74)
+        float ev = 0.0f;                                               // envelope -> temps[1] (zeroed)   (:117-125)
+        e0 = 0.0f;
         if (env.frame(ev)) e0 = 0.0f + ev;
+    }
+    static __device__ __forceinline__ float value(float tm_i, float tc_i, float e0) {
+        const float m = 0.0f + sine_osc_sin(tm_i + 0.0f);              // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
+        const float ph = 0.0f + m * 1.0f;                              // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
+        const float c = 0.0f + sine_osc_sin(tc_i + ph);                // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
+        const float osc = 0.0f + c;                                    // PhaseModOscillator output (zeroed) += temps[1]   (:75)
         return osc * e0;                                               // multiply(out, temps[0], temps[1]) :126
+    }
+    __device__ __forceinline__ float frame() {
+        float tm_i, tc_i, e0;
+        step(tm_i, tc_i, e0);
+        return value(tm_i, tc_i, e0);
     }
 
     // end of one paint call: envelope cascade, and both SineOsc `t - trunc(t)` wraps (SineOsc.zig:40)
@@ -372,6 +381,57 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
                   [&]() ZH_INLINE_LAMBDA { n.end(); });
     if (!live) return;
     pm_store(n, a, v);
+}
+
+// A handful of PMOscInstrument voices (config 4: two) cannot use lane-per-voice parallelism, and two
+// musl sines per sample in f64 make the serial walk slow (1,680 cycles per frame).  Here one WAVE owns
+// one voice and its 64 lanes are 64 consecutive frames: all lanes run the sequential part (phase
+// accumulators + envelope, ~25 instructions per frame, identical in every lane) and each keeps the
+// frame that is its own; then every lane evaluates PMLane::value for its frame -- the sines, once per
+// 64 frames instead of once per frame.  Same per-voice operations in the same order => same bits.
+// Sub-span semantics are span_walk's: begin() at a sub-span's first frame, end() after its last,
+// nothing painted in between, a malformed table entry never fires.
+template <bool ZF>
+__global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x, lane = threadIdx.x;
+    PMLane n;
+    pm_load(n, a, v);
+    n.mod_freq = n.inv_sr = n.t_step = 0.0f;
+    const float rel = a.release_duration[v];
+    const uint32_t cnt = min(tb.count[v], tb.K);
+    float *col = out.p + v;
+    const size_t os = out.stride;
+    auto zero = [&](uint32_t f0, uint32_t f1) ZH_INLINE_LAMBDA {
+        if (ZF) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
+    };
+    uint32_t i = start;
+    for (uint32_t k = 0; k < cnt; k++) {
+        const size_t idx = (size_t)k * a.V + v;
+        const uint32_t s0 = tb.start[idx], s1 = tb.end[idx];
+        if (s0 < i || s0 > end) break;                          // never reached in order: nothing further fires
+        zero(i, s0);
+        n.begin(a.sample_rate, tb.freq[idx], rel, tb.note_on[idx] != 0, tb.nic[idx] != 0);
+        const bool ends = s1 >= s0 && s1 <= end;                // otherwise the sub-span runs to the buffer end, unfinished
+        const uint32_t seg_end = ends ? s1 : end;
+        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64) {
+            const uint32_t nf = min(64u, seg_end - f0);
+            float my_tm = 0.0f, my_tc = 0.0f, my_e = 0.0f;
+            for (uint32_t j = 0; j < nf; j++) {
+                float tm_i, tc_i, e0;
+                n.step(tm_i, tc_i, e0);
+                if (j == lane) { my_tm = tm_i; my_tc = tc_i; my_e = e0; }
+            }
+            if (lane < nf) {
+                float *o = col + (size_t)(f0 + lane) * os;
+                *o = (ZF ? 0.0f : *o) + PMLane::value(my_tm, my_tc, my_e);
+            }
+        }
+        i = seg_end;
+        if (!ends) break;
+        n.end();
+    }
+    zero(i, end);
+    if (lane == 0) pm_store(n, a, v);
 }
 
 // ------------------------------------------------------------------ Noise -> Filter voice
@@ -790,7 +850,12 @@ int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf
     hipStream_t st = m->ctx->stream;
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, sample_rate,
                 F32P{0.0f, nullptr}, BoolP{0, nullptr}, BoolP{0, nullptr}};
-    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
+    static const int wave_max = [] { const char *e = getenv("ZH_PMOSC_WAVE_MAX"); return e ? atoi(e) : 64; }();
+    if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
+        if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    } else if (zf) hipLaunchKernelGGL(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_pmosc_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
 }

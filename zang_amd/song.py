@@ -314,15 +314,11 @@ class SongRenderer:
         zang.mixDown(self.pcm[:nframes * 2], self.mix[:nframes], zang.AudioFormat.signed16_lsb, 1, 0, self.vol, ctx=self.ctx)
         return bytes(self.pcm[:nframes * 2].cpu().numpy())
 
-    def render_batch(self, frame_counts):
-        """Several consecutive write_wav iterations in ONE set of launches.  The host schedules every
-        buffer exactly as before (NoteTracker quantises note times per 1024-frame buffer), then the
-        sub-spans of buffer b are shifted by its start frame: Trigger's carry-over already splits a
-        note at every buffer boundary, so the per-call prologue/epilogue structure -- and the bits --
-        are unchanged, while the device walks len(frame_counts)*1024 frames per launch."""
-        import torch
-        nb = len(frame_counts)
-        total = sum(frame_counts)
+    def _prepare_batch(self, frame_counts):
+        """Host part of a batch: schedule every buffer exactly as write_wav does (NoteTracker quantises note
+        times per 1024-frame buffer), shifting buffer b's sub-spans by its start frame.  Trigger's carry-over
+        already splits a note at every buffer boundary, so the per-call prologue/epilogue structure -- and
+        the bits -- are unchanged, while the device walks len(frame_counts)*1024 frames per launch."""
         per_inst = [[[] for _ in range(i.polyphony)] for i in self.instruments]
         base = 0
         for n in frame_counts:
@@ -331,6 +327,12 @@ class SongRenderer:
                 for v, spans in enumerate(per_voice):
                     per_inst[k][v].extend((s + base, e + base, f, on, nic) for (s, e, f, on, nic) in spans)
             base += n
+        return base, per_inst
+
+    def _launch_batch(self, prepared):
+        """Device part: upload the span tables, paint the instruments (each on its own stream), mix, convert."""
+        import torch
+        total, per_inst = prepared
         if getattr(self, "_batch_frames", 0) < total:
             self._bimage = self.ctx.image(total, self.total_voices)
             self._bmix = torch.zeros(total, dtype=torch.float32, device=self.ctx.device)
@@ -349,16 +351,33 @@ class SongRenderer:
             self.main_stream.wait_stream(ic._stream)
         zang.mixdownVoices(span, self._bmix, self._bimage, zero_first=True, sequential=True, ctx=self.ctx)
         zang.mixDown(self._bpcm[:total * 2], self._bmix[:total], zang.AudioFormat.signed16_lsb, 1, 0, self.vol, ctx=self.ctx)
+        return total, live
+
+    def _collect_batch(self, launched):
+        total, _live = launched                                  # tables stay allocated until the copy below has synchronised
         return bytes(self._bpcm[:total * 2].cpu().numpy())
 
+    def render_batch(self, frame_counts):
+        """Several consecutive write_wav iterations in ONE set of launches."""
+        return self._collect_batch(self._launch_batch(self._prepare_batch(frame_counts)))
+
     def render(self, seconds, batch=64):
+        """write_wav's loop (write_wav.zig:58-93), `batch` buffers per launch; the host schedules batch k+1
+        while the device renders batch k."""
         total = int(seconds * AUDIO_SAMPLE_RATE)
         counts, start = [], 0
         while start < total:                                   # write_wav.zig:58-59
             n = min(AUDIO_BUFFER_SIZE, total - start)
             counts.append(n)
             start += n
-        return b"".join(self.render_batch(counts[i:i + batch]) for i in range(0, len(counts), batch))
+        groups = [counts[i:i + batch] for i in range(0, len(counts), batch)]
+        out = []
+        prepared = self._prepare_batch(groups[0]) if groups else None
+        for g in range(len(groups)):
+            launched = self._launch_batch(prepared)
+            prepared = self._prepare_batch(groups[g + 1]) if g + 1 < len(groups) else None
+            out.append(self._collect_batch(launched))
+        return b"".join(out)
 
 
 def wav_header(num_channels, sample_rate, bytes_per_sample, data_bytes):
