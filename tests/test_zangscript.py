@@ -501,3 +501,24 @@ def test_zangc_cli(tmp_path):
     bad.write_text("X = defmodule\nbegin\n out foo\nend\n")
     r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", str(bad), "--check"], cwd=root, capture_output=True, text=True)
     assert r.returncode == 1 and ":3:6: use of undeclared identifier `foo`" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_loader_argument_checks(ctx):
+    import ctypes as C
+    from zang_amd import abi, script, zang
+    prog = script.ScriptProgram("M = defmodule x: waveform, begin out x * 2 end", ctx)
+    with pytest.raises(KeyError):
+        prog.module("Nope", 4)
+    h = C.c_void_p()
+    assert prog.lib.zh_script_module_create(prog.handle, b"Nope", 4, 0, 0, C.byref(h)) != 0      # no such kernel in the hipModule
+    mod = prog.module("M", 8)
+    img = ctx.image(16, 8)
+    small = ctx.image(16, 4)
+    with pytest.raises(abi.ZangHipError):                     # the waveform image must cover the module's voices
+        mod.paint(zang.Span(0, 16), [img], None, False, {"sample_rate": 48000.0, "x": small})
+    with pytest.raises(abi.ZangHipError):                     # span beyond the output image
+        mod.paint(zang.Span(0, 32), [img], None, False, {"sample_rate": 48000.0, "x": img})
+    with pytest.raises(script.ScriptCompileError):
+        script.ScriptProgram(prog.script, ctx).lib.zh_script_load and script.compile_hip("this is not HIP")
+    prog.close()
