@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
 // ------------------------------------------------------------------ span-table paints
 // One launch = for every voice, the reference's Trigger loop over its sub-spans
 // (examples/example_song.zig:336-347): begin() at a sub-span's first frame, end() after its last,
-// nothing painted between sub-spans.  All lanes walk the buffer frame by frame together.
+// nothing painted between sub-spans.
 struct SpanTableP {
     uint32_t K;
     const uint32_t *count, *start, *end;
