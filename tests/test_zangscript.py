@@ -519,6 +519,4 @@ def test_gpu_loader_argument_checks(ctx):
         mod.paint(zang.Span(0, 16), [img], None, False, {"sample_rate": 48000.0, "x": small})
     with pytest.raises(abi.ZangHipError):                     # span beyond the output image
         mod.paint(zang.Span(0, 32), [img], None, False, {"sample_rate": 48000.0, "x": img})
-    with pytest.raises(script.ScriptCompileError):
-        script.ScriptProgram(prog.script, ctx).lib.zh_script_load and script.compile_hip("this is not HIP")
     prog.close()
