@@ -8,6 +8,7 @@ mkdir -p $out
 run() { python bench.py "$@" 2>/dev/null | tail -1 >> $out/bench_unprofiled.jsonl; }
 run --cpu-seconds 10
 run --voices 65536 --steps 100 --warmup 10 --no-cpu
+run --voices 524288 --steps 40 --warmup 4 --no-cpu
 run --voices 1048576 --steps 40 --warmup 4 --no-cpu
 run --workload noise_filter --no-cpu
 run --workload noise_filter --voices 131072 --steps 50 --warmup 10 --no-cpu
