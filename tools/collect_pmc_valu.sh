@@ -1,0 +1,37 @@
+#!/bin/bash
+# GPU box: SQ counters of the VALU-bound kernels (own --pmc pass, --kernel-trace only) -> gpurun_out/pmc_valu_<tag>/
+tag=${1:-r01}
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_valu_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, bench args...
+  name=$1; shift
+  d=/tmp/pmc_$name
+  rm -rf $d
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu --no-parity --eager > /dev/null 2>&1
+  cp $d/*/*counter_collection.csv $out/${name}_counters.csv 2>/dev/null
+}
+run nice131072 --workload nice --voices 131072 --steps 20 --warmup 4
+run nice_mix1M --workload nice_mix --voices 1048576 --steps 10 --warmup 2
+run noise_filter_fused131072 --workload noise_filter_fused --voices 131072 --steps 20 --warmup 4
+python3 - $out <<'PY'
+import csv, glob, json, statistics, sys, os
+out = sys.argv[1]
+res = {}
+for f in sorted(glob.glob(out + "/*_counters.csv")):
+    rows = list(csv.DictReader(open(f)))
+    byk = {}
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0]
+        if not any(s in k for s in ("k_nice", "k_noise_filter")) or "seed" in k:
+            continue
+        byk.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, c in byk.items():
+        m = {n: statistics.mean(v) for n, v in c.items()}
+        waves = m.get("SQ_WAVES", 0)
+        m["valu_insts_per_wave"] = m.get("SQ_INSTS_VALU", 0) / waves if waves else None
+        m["salu_insts_per_wave"] = m.get("SQ_INSTS_SALU", 0) / waves if waves else None
+        res[os.path.basename(f).replace("_counters.csv", "") + ":" + k] = m
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
