@@ -510,6 +510,21 @@ ZH_API int zh_trigger_reset(zh_trigger *t);                                     
 ZH_API int zh_trigger_counter(zh_trigger *t, uint64_t span_start, uint64_t span_end, zh_iap iap);     /* :66-78 */
 ZH_API int zh_trigger_next(zh_trigger *t, zh_paint_span *out);   /* :80-105; returns 1 = span produced, 0 = null, <0 error */
 
+/* Voice(T)'s scheduling half (examples/example_song.zig:287-350): NoteTracker -> PolyphonyDispatcher(polyphony) ->
+ * one Trigger per sub-voice.  zh_poly_voice_schedule makes the scheduling calls of `n_buffers` consecutive
+ * Voice(T).paint invocations (buffer b has frames[b] frames; its sub-spans are shifted by the frames before it,
+ * Trigger's carry-over splitting notes at every buffer edge exactly as per-buffer calls do) and records per
+ * sub-voice the (span, params, note_id_changed) of every module.paint the reference would issue, laid out like
+ * zh_span_table: [span][sub_voice], `max_spans` rows, counts[sub_voice].  ZH_ERR_INVALID if a list overflows. */
+typedef struct zh_poly_voice zh_poly_voice;
+ZH_API int zh_poly_voice_create(uint32_t polyphony, uint32_t params_size, uint32_t note_on_offset, uint64_t n_events,
+                                const void *paramses, const float *t, const uint64_t *note_ids, zh_poly_voice **out);
+ZH_API int zh_poly_voice_destroy(zh_poly_voice *pv);
+ZH_API int zh_poly_voice_reset(zh_poly_voice *pv);
+ZH_API int zh_poly_voice_schedule(zh_poly_voice *pv, float sample_rate, const uint32_t *frames, uint32_t n_buffers,
+                                  uint32_t max_spans, uint32_t *counts, uint32_t *start, uint32_t *end, void *params,
+                                  uint8_t *note_id_changed);
+
 /* ---------------------------------------------------------------- single-voice host-pointer wrappers
  * The literal one-voice form of a Zig module call: `state` is the Zig struct (in/out), `outputs[0]` and every
  * input buffer are HOST float[>= span_end] slices exactly like zang's []f32, params are plain values.  Each call

@@ -170,3 +170,39 @@ def test_song_batched_render_equals_per_buffer(ctx, oracle):
     r = song.SongRenderer(_small(), ctx)
     got = r.render(nbuf * F / SR, batch=7)          # 6 batches of 7 + one of 3
     assert got == ref
+
+
+def test_native_batch_scheduler_equals_per_buffer_scheduling():
+    """zh_poly_voice (Voice(T)'s scheduling in C++, many buffers per call) == the reference's calls made one
+    by one (NoteTracker.consume -> PolyphonyDispatcher.dispatch -> Trigger.next), sub-spans shifted per buffer."""
+    from zang_amd import song, zang
+    notes = song.compile_song(_small())
+    for k, inst in enumerate(notes):
+        for e in inst:
+            e.freq = float(np.float32(100.0 + 7.5 * e.semis + k))
+    counts = [1024] * 9 + [500, 1024, 3]
+    ref = song.SongScheduler(notes)
+    per_inst = [[[] for _ in range(i.polyphony)] for i in song.EXAMPLE_SONG_INSTRUMENTS]
+    base = 0
+    for n in counts:
+        for k, per_voice in enumerate(ref.buffer(zang.Span(0, n))):
+            for v, spans in enumerate(per_voice):
+                per_inst[k][v].extend((s + base, e + base, np.float32(f), on, nic) for (s, e, f, on, nic) in spans)
+        base += n
+    nat = song.NativeSongScheduler(notes).batch(counts)
+    total = 0
+    for k, (count, start, end, freq, on, nic) in enumerate(nat):
+        for v in range(len(count)):
+            got = [(int(start[j, v]), int(end[j, v]), np.float32(freq[j, v]), bool(on[j, v]), bool(nic[j, v])) for j in range(int(count[v]))]
+            assert got == per_inst[k][v], (k, v)
+            total += len(got)
+    assert total > 40
+    # state carries across batch() calls exactly like across buffer() calls
+    a = song.NativeSongScheduler(notes)
+    first, second = a.batch(counts[:5]), a.batch(counts[5:])
+    for k in range(len(nat)):
+        for v in range(len(nat[k][0])):
+            n1, n2 = int(first[k][0][v]), int(second[k][0][v])
+            assert n1 + n2 == int(nat[k][0][v])
+            off = sum(counts[:5])
+            assert [int(x) + off for x in second[k][1][:n2, v]] == [int(x) for x in nat[k][1][n1:n1 + n2, v]]

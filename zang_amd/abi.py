@@ -354,6 +354,10 @@ SIGNATURES = {
     "zh_portamento_get_state": (C.c_int, [vp, vp]),
     "zh_portamento_set_state": (C.c_int, [vp, vp]),
     "zh_portamento_paint": (C.c_int, _paint(PortamentoParams)),
+    "zh_poly_voice_create": (C.c_int, [u32, u32, u32, u64, vp, vp, vp, P(vp)]),
+    "zh_poly_voice_destroy": (C.c_int, [vp]),
+    "zh_poly_voice_reset": (C.c_int, [vp]),
+    "zh_poly_voice_schedule": (C.c_int, [vp, f32, vp, u32, u32, vp, vp, vp, vp, vp]),
     "zh_script_compile": (C.c_int, [C.c_char_p, P(vp), P(C.c_size_t), C.c_char_p, C.c_size_t]),
     "zh_script_free_code": (None, [vp]),
     "zh_script_load": (C.c_int, [vp, C.c_char_p, P(vp), C.c_char_p, C.c_size_t]),

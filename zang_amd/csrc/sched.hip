@@ -277,4 +277,83 @@ int zh_trigger_next(zh_trigger *t, zh_paint_span *out) {                        
     return 0;
 }
 
+
+// ------------------------------------------------------------------ Voice(T)'s scheduling half
+// examples/example_song.zig:287-350: one NoteTracker -> one PolyphonyDispatcher -> one Trigger per
+// sub-voice.  zh_poly_voice_schedule makes the calls of `n_buffers` consecutive Voice(T).paint
+// invocations and records, per sub-voice, the (span, params, note_id_changed) tuples whose
+// module.paint the reference would run -- laid out like zh_span_table, [span][sub_voice].
+struct zh_poly_voice {
+    uint32_t polyphony, psize;
+    zh_note_tracker *tracker;
+    zh_polyphony_dispatcher *dispatcher;
+    std::vector<zh_trigger *> triggers;
+};
+
+int zh_poly_voice_create(uint32_t polyphony, uint32_t params_size, uint32_t note_on_offset, uint64_t n_events,
+                         const void *paramses, const float *t, const uint64_t *note_ids, zh_poly_voice **out) {
+    if (!out || polyphony == 0) return ZH_ERR_INVALID;
+    *out = nullptr;
+    zh_poly_voice *pv = new (std::nothrow) zh_poly_voice();
+    if (!pv) return ZH_ERR_INVALID;
+    pv->polyphony = polyphony; pv->psize = params_size; pv->tracker = nullptr; pv->dispatcher = nullptr;
+    int rc = zh_note_tracker_create(params_size, n_events, paramses, t, note_ids, &pv->tracker);
+    if (!rc) rc = zh_polyphony_dispatcher_create(polyphony, params_size, note_on_offset, &pv->dispatcher);
+    for (uint32_t i = 0; !rc && i < polyphony; i++) {
+        zh_trigger *tr = nullptr;
+        rc = zh_trigger_create(params_size, &tr);
+        if (!rc) pv->triggers.push_back(tr);
+    }
+    if (rc) { zh_poly_voice_destroy(pv); return rc; }
+    *out = pv;
+    return ZH_OK;
+}
+int zh_poly_voice_destroy(zh_poly_voice *pv) {
+    if (!pv) return ZH_ERR_INVALID;
+    if (pv->tracker) zh_note_tracker_destroy(pv->tracker);
+    if (pv->dispatcher) zh_polyphony_dispatcher_destroy(pv->dispatcher);
+    for (zh_trigger *t : pv->triggers) zh_trigger_destroy(t);
+    delete pv;
+    return ZH_OK;
+}
+int zh_poly_voice_reset(zh_poly_voice *pv) {                                          // example_song.zig:318-324
+    if (!pv) return ZH_ERR_INVALID;
+    zh_note_tracker_reset(pv->tracker);
+    zh_polyphony_dispatcher_reset(pv->dispatcher);
+    for (zh_trigger *t : pv->triggers) zh_trigger_reset(t);
+    return ZH_OK;
+}
+int zh_poly_voice_schedule(zh_poly_voice *pv, float sample_rate, const uint32_t *frames, uint32_t n_buffers, uint32_t max_spans,
+                           uint32_t *counts, uint32_t *start, uint32_t *end, void *params, uint8_t *note_id_changed) {
+    if (!pv || (n_buffers && !frames) || !counts || (max_spans && (!start || !end || !params || !note_id_changed))) return ZH_ERR_INVALID;
+    const uint32_t P = pv->polyphony;
+    for (uint32_t v = 0; v < P; v++) counts[v] = 0;
+    std::vector<zh_iap> poly(P);
+    uint64_t base = 0;
+    for (uint32_t b = 0; b < n_buffers; b++) {
+        zh_iap iap;
+        int rc = zh_note_tracker_consume(pv->tracker, sample_rate, 0, frames[b], &iap);       // :333
+        if (!rc) rc = zh_polyphony_dispatcher_dispatch(pv->dispatcher, iap, poly.data());     // :335
+        if (rc) return rc;
+        for (uint32_t v = 0; v < P; v++) {                                                    // :337-347
+            rc = zh_trigger_counter(pv->triggers[v], 0, frames[b], poly[v]);
+            if (rc) return rc;
+            zh_paint_span ps;
+            while ((rc = zh_trigger_next(pv->triggers[v], &ps)) == 1) {
+                const uint32_t k = counts[v];
+                if (k >= max_spans) return ZH_ERR_INVALID;
+                const size_t idx = (size_t)k * P + v;
+                start[idx] = (uint32_t)(base + ps.start);
+                end[idx] = (uint32_t)(base + ps.end);
+                memcpy((uint8_t *)params + idx * pv->psize, ps.params, pv->psize);
+                note_id_changed[idx] = (uint8_t)ps.note_id_changed;
+                counts[v] = k + 1;
+            }
+            if (rc < 0) return rc;
+        }
+        base += frames[b];
+    }
+    return ZH_OK;
+}
+
 }  // extern "C"

@@ -263,6 +263,59 @@ class SongScheduler:
         return out
 
 
+class NativeSongScheduler:
+    """The same scheduling through zh_poly_voice (Voice(T)'s scheduling half in C++, one call per instrument
+    per batch of buffers) -- what SongRenderer uses; SongScheduler above makes the reference's calls one by
+    one from Python and is what the tests read."""
+    _dtype = np.dtype({"names": ["freq", "note_on"], "formats": ["<f4", "u1"],
+                       "offsets": [MyNoteParams.freq.offset, MyNoteParams.note_on.offset], "itemsize": C.sizeof(MyNoteParams)})
+
+    def __init__(self, notes, instruments=EXAMPLE_SONG_INSTRUMENTS):
+        self.lib = abi.load()
+        self.instruments = instruments
+        self.handles = []
+        for inst, evs in zip(instruments, notes):
+            n = len(evs)
+            params = (MyNoteParams * max(n, 1))(*[MyNoteParams(e.freq, e.note_on) for e in evs])
+            t = np.array([e.t for e in evs], np.float32)
+            ids = np.array([e.note_id for e in evs], np.uint64)
+            h = C.c_void_p()
+            abi.check(self.lib.zh_poly_voice_create(inst.polyphony, C.sizeof(MyNoteParams), MyNoteParams.note_on.offset, n,
+                                                    C.cast(params, C.c_void_p), t.ctypes.data, ids.ctypes.data, C.byref(h)),
+                      "zh_poly_voice_create")
+            self.handles.append(h)
+
+    def batch(self, frame_counts):
+        """-> per instrument: (count [P], start [K][P], end, freq*freq_mul, note_on, note_id_changed), sub-spans of
+        buffer b shifted by the frames before it."""
+        frames = np.asarray(frame_counts, np.uint32)
+        out = []
+        for inst, h in zip(self.instruments, self.handles):
+            P = inst.polyphony
+            cap = 34 * len(frames) + 1                         # <= 32 impulses + carry-over per buffer per sub-voice
+            count = np.zeros(P, np.uint32)
+            start = np.zeros((cap, P), np.uint32); end = np.zeros((cap, P), np.uint32)
+            params = np.zeros((cap, P), self._dtype); nic = np.zeros((cap, P), np.uint8)
+            abi.check(self.lib.zh_poly_voice_schedule(h, float(AUDIO_SAMPLE_RATE), frames.ctypes.data, len(frames), cap, count.ctypes.data,
+                                                      start.ctypes.data, end.ctypes.data, params.ctypes.data, nic.ctypes.data),
+                      "zh_poly_voice_schedule")
+            K = int(count.max()) if P else 0
+            freq = params["freq"][:K] * np.float32(inst.freq_mul)          # makeParams (example_song.zig:35-39 etc.), f32
+            out.append((count, start[:K], end[:K], freq, params["note_on"][:K], nic[:K]))
+        return out
+
+    def close(self):
+        for h in self.handles:
+            self.lib.zh_poly_voice_destroy(h)
+        self.handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SongRenderer:
     """MainModule + write_wav's buffer loop on the GPU."""
 
@@ -272,7 +325,8 @@ class SongRenderer:
         self.ctx = ctx
         self.instruments = instruments
         self.notes = resolve_frequencies(compile_song(text, instruments), ctx)
-        self.sched = SongScheduler(self.notes, instruments)
+        self.sched = SongScheduler(self.notes, instruments)          # per-buffer path (render_buffer)
+        self.native = NativeSongScheduler(self.notes, instruments)   # batched path (render / render_batch)
         self.total_voices = sum(i.polyphony for i in instruments)
         F = AUDIO_BUFFER_SIZE
         self.image = ctx.image(F, self.total_voices)           # one column per sub-voice, in painting order
@@ -319,15 +373,7 @@ class SongRenderer:
         times per 1024-frame buffer), shifting buffer b's sub-spans by its start frame.  Trigger's carry-over
         already splits a note at every buffer boundary, so the per-call prologue/epilogue structure -- and
         the bits -- are unchanged, while the device walks len(frame_counts)*1024 frames per launch."""
-        per_inst = [[[] for _ in range(i.polyphony)] for i in self.instruments]
-        base = 0
-        for n in frame_counts:
-            tables = self.sched.buffer(zang.Span(0, n))
-            for k, per_voice in enumerate(tables):
-                for v, spans in enumerate(per_voice):
-                    per_inst[k][v].extend((s + base, e + base, f, on, nic) for (s, e, f, on, nic) in spans)
-            base += n
-        return base, per_inst
+        return int(sum(frame_counts)), self.native.batch(frame_counts)
 
     def _launch_batch(self, prepared):
         """Device part: upload the span tables, paint the instruments (each on its own stream), mix, convert."""
@@ -344,7 +390,7 @@ class SongRenderer:
         for m, ic, inst, per_voice in zip(self.mods, self.ictx, self.instruments, per_inst):
             view = self._bimage[:, col:col + inst.polyphony]
             col += inst.polyphony
-            live.append(SpanTable(per_voice, self.ctx.device))
+            live.append(SpanTable.from_arrays(*per_voice, self.ctx.device))
             ic._stream.wait_stream(self.main_stream)
             m.paint_spans(span, [view], None, float(AUDIO_SAMPLE_RATE), live[-1], zero_first=True)
         for ic in self.ictx:
