@@ -36,10 +36,13 @@ def _random_tables(V, nbuf, seed):
     return bufs
 
 
-def test_nice_paint_spans(ctx, oracle):
+@pytest.mark.parametrize("V", [200, 20, 64, 65])
+def test_nice_paint_spans(ctx, oracle, V):
+    """V > 64: lane-per-voice segment walk (k_nice_spans); V <= 64: one wave per voice, lanes = frames
+    (k_nice_spans_wave)."""
     from zang_amd import modules as mod, zang, workloads
     from zang_amd.spans import SpanTable
-    V, nbuf = 200, 4
+    nbuf = 4
     _, color, _, _ = workloads.voice_params(4, 0, V)
     bufs = _random_tables(V, nbuf, 1)
     L = oracle.lib()
