@@ -344,6 +344,18 @@ def test_gpu_pluck_note_cycle(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_empty_span_still_runs_prologues(ctx):
+    """paint over an empty span is not a no-op in the reference: Envelope's note-on prologue (Envelope.zig:41-50)
+    and Portamento's newCurve run, and the next paint continues from there."""
+    on = np.ones(V, bool)
+    f = _freqs(20)
+    p = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
+    _parity(ctx, "Pluck", [(0, 30, True, p(on)), (30, 30, False, p(~on)), (30, 60, False, p(~on)), (60, 60, True, p(on)), (60, F, False, p(on))])
+    g = lambda goal, a, b: {"sample_rate": 48000.0, "goal": goal, "note_on": a, "prev_note_on": b}
+    _parity(ctx, "Glide", [(0, 20, True, g(_freqs(21), on, ~on)), (20, 20, True, g(_freqs(22), on, on)), (20, F, False, g(_freqs(22), on, on))])
+
+
+@pytest.mark.gpu
 def test_gpu_cycle_sine(ctx):
     rng = np.random.default_rng(3)
     ph = rng.uniform(0, 1, (V, F)).astype(np.float32)
