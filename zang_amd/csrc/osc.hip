@@ -137,7 +137,10 @@ __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__
         o.y = bad[1] ? cnt0[1] : cnt0[1] + (end - start) * k[1].ifreq;
         o.z = bad[2] ? cnt0[2] : cnt0[2] + (end - start) * k[2].ifreq;
         o.w = bad[3] ? cnt0[3] : cnt0[3] + (end - start) * k[3].ifreq;
-        *reinterpret_cast<uint4 *>(cnt_out + v) = o;
+        // write-through like the image stores: a plain store would leave the line dirty in L2 and put its
+        // write-back on the kernel boundary (measured: 0.14 us of a 4.6 us launch)
+        const zh_rsrc_t crs = make_rsrc(cnt_out, V * 4u);
+        store4<SM>(reinterpret_cast<float *>(cnt_out + v), crs, v * 4u, __builtin_bit_cast(zv4f, o));
     }
     if (c0 >= end) return;
     float *o = out.at(c0, v);
