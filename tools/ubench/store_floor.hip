@@ -56,6 +56,46 @@ __global__ void k_store_alu(float *out, unsigned V, unsigned F, unsigned fc, flo
     }
 }
 
+// the sc1 store kernel with the real kernel's prologue added step by step: LEVEL 1 = every thread loads
+// its voice's freq / color / cnt (the stores depend on them), 2 = + a divide and some setup arithmetic,
+// 3 = + the LDS exchange (write, barrier, 16-byte reads) that shares the setup among the block's 4 waves
+template <int LEVEL>
+__global__ void __launch_bounds__(256) k_store_pro(float *out, unsigned V, unsigned F, unsigned fc, const float *freq, const float *color,
+                                                   const unsigned *cnt) {
+    __shared__ __attribute__((aligned(16))) float sk[4][256];
+    const unsigned lanes = V / 4;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned q = blockIdx.x * 64 + lane;
+    const unsigned chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float a = 1.0f, b = 2.0f, c = 3.0f, d = 4.0f;
+    if (LEVEL >= 1) {
+        const unsigned sv = blockIdx.x * 256 + threadIdx.x;
+        float f = freq[sv], col = color[sv];
+        unsigned cn = cnt[sv];
+        if (LEVEL >= 2) { f = 0.7f / (f * 89478.0f * 2.3283064e-10f); col = f * (col - 1.0f) + 0.7f; }
+        a = f; b = col; c = (float)cn; d = f * col;
+        if (LEVEL >= 3) {
+            sk[0][threadIdx.x] = a; sk[1][threadIdx.x] = b; sk[2][threadIdx.x] = c; sk[3][threadIdx.x] = d;
+            __syncthreads();
+            const v4f w0 = *(const v4f *)&sk[0][lane * 4], w1 = *(const v4f *)&sk[1][lane * 4];
+            const v4f w2 = *(const v4f *)&sk[2][lane * 4], w3 = *(const v4f *)&sk[3][lane * 4];
+            a = w0.x + w1.y; b = w0.y + w2.z; c = w0.z + w3.w; d = w0.w + w1.x;
+        }
+    }
+    if (q >= lanes) return;
+    const unsigned c0 = chunk * fc;
+    if (c0 >= F) return;
+    const unsigned c1 = min(c0 + fc, F);
+    const unsigned wchunk = __builtin_amdgcn_readfirstlane(chunk);
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)wchunk * fc * V, 0, fc * V * 4, 0x00020000);
+    unsigned boff = q * 16;
+    v4f x = {a, b, c, d};
+    for (unsigned i = c0; i < c1; i++, boff += V * 4) {
+        x.x += 1.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, x), rsrc, boff, 0, 16);
+    }
+}
+
 // flat grid-stride fill, 16 B per thread (what a plain memset-like kernel does)
 template <int SM>
 __global__ void k_fill(float *out, size_t n4, float val) {
@@ -110,6 +150,19 @@ int main() {
         dim3 grid((V / 4 + 63) / 64, (chunks + wpb - 1) / wpb);
 #define RUN_ALU(N) snprintf(name, sizeof name, "sc1 store + %d flops/store fc=%u", 2 * N, fc); run(name, [&](float *o) { hipLaunchKernelGGL(k_store_alu<N>, grid, dim3(tpb), 0, st, o, V, F, fc, 1.0f); });
         RUN_ALU(0) RUN_ALU(16) RUN_ALU(32) RUN_ALU(64) RUN_ALU(128)
+    }
+    {
+        float *freq, *color; unsigned *cnt;
+        CK(hipMalloc(&freq, V * 4)); CK(hipMalloc(&color, V * 4)); CK(hipMalloc(&cnt, V * 4));
+        std::vector<float> h(V, 440.0f);
+        CK(hipMemcpy(freq, h.data(), V * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(color, h.data(), V * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(cnt, 0, V * 4));
+        const unsigned fc = 8, chunks = F / fc;
+        dim3 grid((V / 4 + 63) / 64, (chunks + 3) / 4);
+        run("sc1 store fc=8 + no prologue", [&](float *o) { hipLaunchKernelGGL(k_store_pro<0>, grid, dim3(256), 0, st, o, V, F, fc, freq, color, cnt); });
+        run("sc1 store fc=8 + param loads", [&](float *o) { hipLaunchKernelGGL(k_store_pro<1>, grid, dim3(256), 0, st, o, V, F, fc, freq, color, cnt); });
+        run("sc1 store fc=8 + loads + divide", [&](float *o) { hipLaunchKernelGGL(k_store_pro<2>, grid, dim3(256), 0, st, o, V, F, fc, freq, color, cnt); });
+        run("sc1 store fc=8 + loads + divide + LDS share", [&](float *o) { hipLaunchKernelGGL(k_store_pro<3>, grid, dim3(256), 0, st, o, V, F, fc, freq, color, cnt); });
     }
     for (unsigned blocks : {1024u, 2048u, 4096u}) {
         snprintf(name, sizeof name, "flat fill plain, %u blocks x 256", blocks);
