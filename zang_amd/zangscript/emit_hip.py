@@ -492,6 +492,8 @@ class HipEmitter:
     # ---- one exported module
     def kernel(self, name, module_index):
         module = self.s.modules[module_index]
+        if len(module.params) > 16:                             # ZH_SCRIPT_MAX_PARAMS (include/zang_hip.h)
+            raise HipBackendError("module has %d params; the loader passes at most 16" % len(module.params))
         k = _Kernel(name)
         env = []
         for i, p in enumerate(module.params):
