@@ -1,0 +1,36 @@
+"""The C++ host-side API (include/zang_hip.hpp): compiles against the C ABI header here (CPU), and on a GPU
+runs tests/cpp/host_parity.cpp -- examples/modules.zig's NiceInstrument written with the C++ mirror of zang's
+namespaces, checked bit for bit against the oracle and against the fused kernel."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "host_parity.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "host_parity")
+
+
+def _build():
+    from oracle import pyoracle
+    pyoracle.build()
+    import zang_amd  # noqa: F401  (fails loudly if libzang_hip.so is missing)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"), SRC,
+           "-L" + os.path.join(ROOT, "zang_amd"), "-lzang_hip", os.path.join(ROOT, "oracle", "libzang_oracle.so"),
+           "-Wl,-rpath," + os.path.join(ROOT, "zang_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+           "-L" + rocm + "/lib", "-Wl,-rpath," + rocm + "/lib", "-o", EXE]
+    subprocess.check_call(cmd)
+
+
+def test_cpp_host_api_compiles_and_links():
+    _build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_host_parity_program():
+    _build()
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("PASS") and r.stdout.count("bit-exact") == 8
