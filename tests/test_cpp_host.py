@@ -9,9 +9,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "host_parity.cpp")
 EXE = os.path.join(ROOT, "tests", "cpp", "host_parity")
+SCRIPT_SRC = os.path.join(ROOT, "tests", "cpp", "script_host.cpp")
+SCRIPT_EXE = os.path.join(ROOT, "tests", "cpp", "script_host")
 
 
-def _build():
+def _build(SRC=SRC, EXE=EXE):
     from oracle import pyoracle
     pyoracle.build()
     import zang_amd  # noqa: F401  (fails loudly if libzang_hip.so is missing)
@@ -25,7 +27,8 @@ def _build():
 
 def test_cpp_host_api_compiles_and_links():
     _build()
-    assert os.path.exists(EXE)
+    _build(SCRIPT_SRC, SCRIPT_EXE)
+    assert os.path.exists(EXE) and os.path.exists(SCRIPT_EXE)
 
 
 @pytest.mark.gpu
@@ -34,3 +37,17 @@ def test_cpp_host_parity_program():
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("PASS") and r.stdout.count("bit-exact") == 8
+
+
+@pytest.mark.gpu
+def test_cpp_script_host_offline_flow(tmp_path):
+    """zangc offline -> script.hip -> loaded and painted by a compiled host through the C ABI alone."""
+    import sys
+    _build(SCRIPT_SRC, SCRIPT_EXE)
+    hip = tmp_path / "script.hip"
+    r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", os.path.join(ROOT, "tests", "golden", "script_modules.txt"), "-o", str(hip)],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    words = [l for l in r.stderr.splitlines() if "module Pluck:" in l][0].split("module Pluck:")[1].split()[0]
+    r = subprocess.run([SCRIPT_EXE, str(hip), words], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout + r.stderr
