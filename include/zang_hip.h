@@ -468,6 +468,26 @@ ZH_API int zh_script_module_set_state(zh_script_module *m, const uint32_t *host_
 ZH_API int zh_script_module_paint(zh_script_module *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                                   zh_bool note_id_changed, const zh_script_param *params, uint32_t n_params, uint32_t flags);
 
+/* The zangscript compiler itself (host side, no GPU work): src/zangscript/{tokenize,parse,codegen}.zig restated in
+ * C++ (csrc/zscript_front.hip) with both backends (csrc/zscript_emit.hip): the reference's Zig text
+ * (codegen_zig.zig; pins the front-end against the golden of src/zangscript/tests.zig:44-92) and the HIP source
+ * zh_script_load takes.  `packages`: bit 0 = zang_builtin_package, bit 1 = modules_builtin_package
+ * (builtins.zig:153-185).  A compile error returns ZH_ERR_INVALID with the message fail() would print
+ * (`file:line:col: message`, source line, carets) in `err`.  Texts are malloc'ed: zh_zscript_free_text. */
+typedef struct zh_zscript zh_zscript;
+ZH_API int zh_zscript_compile(const char *text, const char *filename, uint32_t packages, zh_zscript **out, char *err, size_t err_cap);
+ZH_API int zh_zscript_destroy(zh_zscript *z);
+ZH_API void zh_zscript_free_text(char *text);
+ZH_API int zh_zscript_generate_zig(zh_zscript *z, char **text_out);
+/* only_csv: comma-separated exported module names, NULL = all; unroll: frames per unrolled chunk, 0 = automatic */
+ZH_API int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unroll, char **text_out);
+/* per module of the last zh_zscript_generate_hip: what zh_script_module_create / _paint need */
+ZH_API uint32_t zh_zscript_module_count(zh_zscript *z);
+ZH_API int zh_zscript_module_info(zh_zscript *z, uint32_t i, char *name, size_t name_cap, uint32_t *state_words, uint32_t *noise_fields,
+                                  uint32_t *n_params, char *error /* non-empty: the HIP backend cannot express this module */, size_t error_cap);
+ZH_API int zh_zscript_module_param(zh_zscript *z, uint32_t i, uint32_t p, char *name, size_t name_cap, char *kind, size_t kind_cap,
+                                   char *enum_name, size_t enum_cap);
+
 /* ---------------------------------------------------------------- event scheduling (host side; no GPU work)
  * The immediate caller of every paint: song / key events -> impulses ->
  * per-voice (span, params, note_id_changed) tuples.  A C++ restatement of src/zang/notes.zig and

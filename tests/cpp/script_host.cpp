@@ -1,10 +1,11 @@
-// script_host.cpp -- the reference's zangscript flow from a compiled host: a script is compiled OFFLINE
-// (`python -m zang_amd.zangc script.txt -o script.hip`, like `zangc -o scriptgen.zig`, examples/example_script.zig:6-8),
-// this program loads the generated HIP source through the C ABI (hiprtc inside libzang_hip.so) and paints
-// module `Pluck` of tests/golden/script_modules.txt.  The same module's generated Zig
-// (python -m zang_amd.zangc --backend zig) is the sequence of calls written out below with the oracle,
-// one voice at a time, so the check is: fused kernel == the generated Zig's operations, bit for bit.
-// usage: script_host <script.hip> <state_words of Pluck>
+// script_host.cpp -- the reference's zangscript flow from a compiled host, through the C ABI alone: the script
+// TEXT is compiled by the library's own compiler (zh_zscript_compile -> zh_zscript_generate_hip, the
+// counterpart of `zangc -o scriptgen.zig`, examples/example_script.zig:6-8), the generated HIP source is built
+// and loaded (zh_script_load: hiprtc inside libzang_hip.so), and module `Pluck` of
+// tests/golden/script_modules.txt is painted.  The same module's generated Zig (zh_zscript_generate_zig) is
+// the sequence of calls written out below with the oracle, one voice at a time, so the check is:
+// fused kernel == the generated Zig's operations, bit for bit.  No Python anywhere.
+// usage: script_host <script.txt>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,12 +20,27 @@ extern "C" {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { printf("usage: %s script.hip state_words\n", argv[0]); return 2; }
+    if (argc < 2) { printf("usage: %s script.txt\n", argv[0]); return 2; }
     std::ifstream f(argv[1]);
     std::stringstream ss;
     ss << f.rdbuf();
-    const std::string src = ss.str();
-    const uint32_t V = 130, F = 512, words = (uint32_t)atoi(argv[2]);
+    const std::string text = ss.str();
+    // front-end + HIP backend
+    zh_zscript *zsc = nullptr;
+    std::vector<char> err(1 << 14);
+    if (zh_zscript_compile(text.c_str(), argv[1], 3, &zsc, err.data(), err.size()) != 0) { printf("FAIL compile:\n%s\n", err.data()); return 1; }
+    char *hip = nullptr, *zig = nullptr;
+    if (zh_zscript_generate_hip(zsc, "Pluck", 0, &hip) != 0 || zh_zscript_generate_zig(zsc, &zig) != 0) { printf("FAIL generate\n"); return 1; }
+    uint32_t words = 0, noise = 0, nparams = 0;
+    char name[64], merr[256];
+    zh_zscript_module_info(zsc, 0, name, sizeof name, &words, &noise, &nparams, merr, sizeof merr);
+    printf("compiled `%s`: %u state words/voice, %u params; generated Zig is %zu bytes, HIP %zu bytes\n", name, words, nparams, strlen(zig), strlen(hip));
+    if (strcmp(name, "Pluck") != 0 || nparams != 3 || !strstr(zig, "zang.multiplyScalar(span, temps[0], temps[1], 0.25);")) { printf("FAIL metadata\n"); return 1; }
+    const std::string src = hip;
+    zh_zscript_free_text(hip);
+    zh_zscript_free_text(zig);
+    zh_zscript_destroy(zsc);
+    const uint32_t V = 130, F = 512;
     const float SR = 48000.0f;
     try {
         zang::Context ctx(0);

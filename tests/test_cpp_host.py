@@ -40,14 +40,9 @@ def test_cpp_host_parity_program():
 
 
 @pytest.mark.gpu
-def test_cpp_script_host_offline_flow(tmp_path):
-    """zangc offline -> script.hip -> loaded and painted by a compiled host through the C ABI alone."""
-    import sys
+def test_cpp_script_host_without_python():
+    """script text -> zh_zscript_compile -> HIP -> zh_script_load -> paint, all from a compiled host."""
     _build(SCRIPT_SRC, SCRIPT_EXE)
-    hip = tmp_path / "script.hip"
-    r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", os.path.join(ROOT, "tests", "golden", "script_modules.txt"), "-o", str(hip)],
-                       cwd=ROOT, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    words = [l for l in r.stderr.splitlines() if "module Pluck:" in l][0].split("module Pluck:")[1].split()[0]
-    r = subprocess.run([SCRIPT_EXE, str(hip), words], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([SCRIPT_EXE, os.path.join(ROOT, "tests", "golden", "script_modules.txt")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout + r.stderr
+    assert "compiled `Pluck`: 5 state words/voice, 3 params" in r.stdout

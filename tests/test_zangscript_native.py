@@ -1,0 +1,98 @@
+"""The C++ zangscript compiler in libzang_hip.so (zh_zscript_*) against the reference's golden generated text
+and against the Python front-end: both implementations must print the same Zig, the same HIP, the same
+module metadata and the same compile errors."""
+import os
+
+import pytest
+
+from zang_amd import zangscript as zs
+from zang_amd.zangscript import native
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCRIPT = open(os.path.join(HERE, "golden", "script_modules.txt")).read()
+REF_SCRIPT = "/root/reference/examples/script.txt"
+
+
+def test_native_matches_reference_golden_text():
+    src = "Instrument = defmodule\n    freq: cob,\nbegin\n    out freq * 2\nend"
+    got = native.NativeScript(src, packages=(zs.zang_builtin_package,)).generate_zig()
+    assert got == open(os.path.join(HERE, "golden", "zangscript_example_test.zig.txt")).read()
+
+
+def _both(text, only=None):
+    py = zs.compile(text)
+    nat = native.NativeScript(text)
+    return py, nat
+
+
+def test_native_equals_python_on_test_script():
+    py, nat = _both(SCRIPT)
+    assert nat.generate_zig() == zs.generate_zig(py)
+    hip_py, meta_py = zs.generate_hip(py)
+    hip_nat, meta_nat = nat.generate_hip()
+    assert hip_nat == hip_py
+    assert meta_nat == meta_py
+    for only in (["Lead"], ["Jingle", "Echo"], ["Doubler"]):
+        a, ma = zs.generate_hip(py, only=only)
+        b, mb = nat.generate_hip(only=only)
+        assert a == b and ma == mb and sorted(mb) == sorted(only)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="the reference's example script only exists in the build container")
+def test_native_equals_python_on_reference_example_script():
+    text = open(REF_SCRIPT).read()
+    py, nat = _both(text)
+    assert nat.generate_zig() == zs.generate_zig(py)
+    a, ma = zs.generate_hip(py)
+    b, mb = nat.generate_hip()
+    assert a == b and ma == mb
+    assert [n for n, _ in py.exported_modules] == ["CurvePlayerInner", "CurvePlayer", "Square", "MySineOsc", "InnerInstrument", "Echoes",
+                                                  "CoinInstrument", "TrackPlayer", "DemoPlayer"]
+
+
+ERRORS = [
+    "X = defmodule\nbegin\n out .\nend",
+    "X = defmodule\nbegin\n out 1.2.3\nend",
+    "X = defmodule\n pi: constant,\nbegin\nend",
+    "X = defmodule\n a: constant,\n a: cob,\nbegin\nend",
+    "X = defmodule\n a: nothing,\nbegin\nend",
+    "X = defmodule\nbegin\n out 1\n",
+    "X = 1\nX = 2",
+    "X = defmodule\nbegin\n out y\nend",
+    "X = defmodule\nbegin\n out SineOsc(freq=1)\nend",
+    "X = defmodule\nbegin\n out SineOsc(freq=1, phase=0, foo=1)\nend",
+    "X = defmodule\nbegin\n out SineOsc(freq=1, phase=0, phase=0)\nend",
+    "X = defmodule\nbegin\n out SineOsc(freq=true, phase=0)\nend",
+    "X = defmodule\nbegin\n out Noise(color=.purple)\nend",
+    "X = defmodule\nbegin\n out Envelope(attack=.cubed, decay=.linear(1), release=.linear(1), sustain_volume=1, note_on=true)\nend",
+    "X = defmodule\nbegin\n out true\nend",
+    "X = defmodule\nbegin\n out true + 1\nend",
+    "X = defmodule\nbegin\n feedback 1\nend",
+    "Y = 1 + 2",
+    "A = B\nB = A",
+    "X = defmodule\nbegin\n out 3(a=1)\nend",
+    "C = defcurve 0 1 0 2 end",
+    "T = deftrack f: cob, begin end",
+    "X = defmodule\nbegin\n out delay 10 begin out delay 5 begin out 1 end end\nend",
+    "X = defmodule\r\nbegin\r\n    out foo * 2\r\nend",
+    "X = defmodule\nbegin\n out from 3, 1 begin out 1 end\nend",
+    "X = defmodule\n c: curve,\nbegin\n out c\nend",
+    "X = defmodule\nbegin\n out Filter(input=1, type=.low_pass, cutoff=true, res=0)\nend",
+    "X = @",
+]
+
+
+@pytest.mark.parametrize("src", ERRORS)
+def test_native_reports_the_same_errors(src):
+    with pytest.raises(zs.ScriptError) as e1:
+        zs.compile(src)
+    with pytest.raises(native.NativeScriptError) as e2:
+        native.NativeScript(src)
+    assert str(e2.value) == str(e1.value)
+
+
+def test_native_unsupported_module_is_reported():
+    src = "P = defmodule\nbegin\n out from deftrack c: curve, begin 0.0 (c=defcurve 0 1 1 2 end) end, 1 begin out Curve(curve=c, function=.linear) end\nend"
+    a, ma = zs.generate_hip(zs.compile(src))
+    b, mb = native.NativeScript(src).generate_hip()
+    assert a == b and ma == mb and "not supported by the HIP backend" in mb["P"]["error"]

@@ -358,6 +358,14 @@ SIGNATURES = {
     "zh_poly_voice_destroy": (C.c_int, [vp]),
     "zh_poly_voice_reset": (C.c_int, [vp]),
     "zh_poly_voice_schedule": (C.c_int, [vp, f32, vp, u32, u32, vp, vp, vp, vp, vp]),
+    "zh_zscript_compile": (C.c_int, [C.c_char_p, C.c_char_p, u32, P(vp), C.c_char_p, C.c_size_t]),
+    "zh_zscript_destroy": (C.c_int, [vp]),
+    "zh_zscript_free_text": (None, [vp]),
+    "zh_zscript_generate_zig": (C.c_int, [vp, P(vp)]),
+    "zh_zscript_generate_hip": (C.c_int, [vp, C.c_char_p, C.c_int, P(vp)]),
+    "zh_zscript_module_count": (u32, [vp]),
+    "zh_zscript_module_info": (C.c_int, [vp, u32, C.c_char_p, C.c_size_t, P(u32), P(u32), P(u32), C.c_char_p, C.c_size_t]),
+    "zh_zscript_module_param": (C.c_int, [vp, u32, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "zh_script_compile": (C.c_int, [C.c_char_p, P(vp), P(C.c_size_t), C.c_char_p, C.c_size_t]),
     "zh_script_free_code": (None, [vp]),
     "zh_script_load": (C.c_int, [vp, C.c_char_p, P(vp), C.c_char_p, C.c_size_t]),

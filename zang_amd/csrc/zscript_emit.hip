@@ -1,0 +1,1036 @@
+// zscript_emit.hip -- the two zangscript backends (host C++; see zscript.hpp) and the zh_zscript_* C ABI:
+//   generate_zig : the reference's own backend (src/zangscript/codegen_zig.zig), whose output pins the
+//                  front-end against the reference's golden text (src/zangscript/tests.zig:44-92);
+//   generate_hip : one fused lane-per-voice kernel per exported module (see zang_amd/zangscript/emit_hip.py
+//                  for the design notes; this file prints the same text).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/zang_hip.h"
+#include "zscript.hpp"
+
+namespace zs {
+namespace {
+
+std::string strf(const char *fmt, ...) {
+    va_list ap, ap2;
+    va_start(ap, fmt);
+    va_copy(ap2, ap);
+    const int n = vsnprintf(nullptr, 0, fmt, ap);
+    va_end(ap);
+    std::string s((size_t)n + 1, '\0');
+    vsnprintf(&s[0], s.size(), fmt, ap2);
+    va_end(ap2);
+    s.resize((size_t)n);
+    return s;
+}
+typedef std::vector<std::string> Lines;
+void append(Lines &dst, const Lines &src) { dst.insert(dst.end(), src.begin(), src.end()); }
+Lines indent(const Lines &src) { Lines o; for (const std::string &l : src) o.push_back("    " + l); return o; }
+
+// ================================================================== Zig backend
+const char *kZigKeywords[] = {"addrspace", "align", "allowzero", "and", "anyframe", "anytype", "asm", "async", "await", "break", "callconv", "catch",
+                              "comptime", "const", "continue", "defer", "else", "enum", "errdefer", "error", "export", "extern", "fn", "for", "if",
+                              "inline", "linksection", "noalias", "noinline", "nosuspend", "opaque", "or", "orelse", "packed", "pub", "resume",
+                              "return", "struct", "suspend", "switch", "test", "threadlocal", "try", "union", "unreachable", "usingnamespace",
+                              "var", "volatile", "while"};
+std::string ident(const std::string &s) {
+    for (const char *k : kZigKeywords) if (s == k) return "@\"" + s + "\"";
+    return s;
+}
+std::string number(const NumberLiteral &n) {                       // print_helper.zig:71-81
+    std::string v = n.verbatim;
+    if (v[0] >= '0' && v[0] <= '9' && v.find('.') == std::string::npos) v += ".0";
+    return v;
+}
+
+struct ZigOut {                                                    // print_helper.zig:19-100
+    std::string text;
+    int indentation = 0;
+    bool indent_next = false;
+    void p(const std::string &t) {
+        if (indent_next) {
+            indent_next = false;
+            if (!t.empty() && t[0] == '}') indentation--;
+            if (t.empty() || t[0] != '\n') for (int i = 0; i < indentation; i++) text += "    ";
+        }
+        text += t;
+        if (!t.empty() && t.back() == '\n') {
+            indent_next = true;
+            if (t.size() >= 2 && t[t.size() - 2] == '{') indentation++;
+        }
+    }
+};
+
+class ZigEmitter {
+public:
+    const CompiledScript &s;
+    ZigOut o;
+    const Module *module = nullptr;
+    explicit ZigEmitter(const CompiledScript &cs) : s(cs) {}
+
+    std::string module_name(size_t i) const {
+        const Module &m = s.pr.modules[i];
+        return m.builtin ? ident(m.zig_package_name) + "." + ident(m.builtin_name) : strf("_module%zu", i);
+    }
+    std::string res(const Res &r) const {
+        switch (r.kind) {
+        case RK::temp_buffer: return strf("temps[%zu]", r.index);
+        case RK::temp_float: return strf("temp_float%zu", r.index);
+        case RK::literal_boolean: return r.bval ? "true" : "false";
+        case RK::literal_number: return number(r.num);
+        case RK::literal_enum_value: return r.payload ? ".{ ." + ident(r.label) + " = " + res(*r.payload) + " }" : "." + ident(r.label);
+        case RK::literal_curve: return strf("&_curve%zu", r.index);
+        case RK::literal_track: return strf("_track%zu", r.index);
+        case RK::literal_module: return module_name(r.index);
+        case RK::self_param: return "params." + ident(module->params[r.index].name);
+        case RK::track_param: return "_result.params." + ident(s.pr.tracks[r.track_index].params[r.index].name);
+        default: return "";
+        }
+    }
+    static std::string dest(const Dest &d) { return strf(d.output ? "outputs[%zu]" : "temps[%zu]", d.index); }
+    void param_decls(const std::vector<ModuleParam> &params, bool skip_sample_rate) {
+        for (const ModuleParam &p : params) {
+            if (skip_sample_rate && p.name == "sample_rate") continue;
+            const char *t = "";
+            switch (p.type.kind) {
+            case PK::boolean: t = "bool"; break;
+            case PK::buffer: t = "[]const f32"; break;
+            case PK::constant: t = "f32"; break;
+            case PK::constant_or_buffer: t = "zang.ConstantOrBuffer"; break;
+            case PK::curve: t = "[]const zang.CurveNode"; break;
+            case PK::one_of: t = p.type.en->zig_name.c_str(); break;
+            }
+            o.p(ident(p.name) + ": " + t + ",\n");
+        }
+    }
+    void loop(const std::string &span, const Dest &out, const std::string &rhs) {
+        o.p("{\n");
+        o.p("var i = " + span + ".start;\n");
+        o.p("while (i < " + span + ".end) : (i += 1) {\n");
+        o.p(dest(out) + "[i] " + (out.output ? "+=" : "=") + " " + rhs + ";\n");
+        o.p("}\n");
+        o.p("}\n");
+    }
+    std::string cob_arg(const Res &arg) const {
+        if (arg.kind == RK::temp_buffer) return strf("zang.buffer(temps[%zu])", arg.index);
+        if (arg.kind == RK::temp_float) return strf("zang.constant(temp_float%zu)", arg.index);
+        if (arg.kind == RK::literal_number) return "zang.constant(" + number(arg.num) + ")";
+        if (arg.kind == RK::self_param || arg.kind == RK::track_param) {
+            const ModuleParam &param = arg.kind == RK::self_param ? module->params[arg.index] : s.pr.tracks[arg.track_index].params[arg.index];
+            const std::string prefix = arg.kind == RK::self_param ? "params." : "_result.params.";
+            if (param.type.kind == PK::buffer) return "zang.buffer(" + prefix + ident(param.name) + ")";
+            if (param.type.kind == PK::constant) return "zang.constant(" + prefix + ident(param.name) + ")";
+            return prefix + ident(param.name);
+        }
+        return "";
+    }
+    static std::string un(const std::string &op, const std::string &a) {
+        if (op == "abs") return "std.math.fabs(" + a + ")";
+        if (op == "cos") return "std.math.cos(" + a + ")";
+        if (op == "neg") return "-" + a;
+        if (op == "sin") return "std.math.sin(" + a + ")";
+        return "std.math.sqrt(" + a + ")";
+    }
+    static std::string bin(const std::string &op, const std::string &a, const std::string &b) {
+        if (op == "add") return a + " + " + b;
+        if (op == "sub") return a + " - " + b;
+        if (op == "mul") return a + " * " + b;
+        if (op == "div") return a + " / " + b;
+        if (op == "pow") return "std.math.pow(f32, " + a + ", " + b + ")";
+        if (op == "max") return "std.math.max(" + a + ", " + b + ")";
+        return "std.math.min(" + a + ", " + b + ")";
+    }
+    void instruction(const ModuleResult &inner, const Instr &ins, const std::string &span, const std::string &nic) {
+        switch (ins.kind) {
+        case IK::copy_buffer:
+            o.p(std::string("zang.") + (ins.out.output ? "addInto" : "copy") + "(" + span + ", " + dest(ins.out) + ", " + res(ins.src) + ");\n");
+            break;
+        case IK::float_to_buffer:
+            o.p(std::string("zang.") + (ins.out.output ? "addScalarInto" : "set") + "(" + span + ", " + dest(ins.out) + ", " + res(ins.src) + ");\n");
+            break;
+        case IK::cob_to_buffer:
+            o.p("switch (params." + ident(module->params[ins.in_self_param].name) + ") {\n");
+            o.p(std::string(".constant => |v| zang.") + (ins.out.output ? "addScalarInto" : "set") + "(" + span + ", " + dest(ins.out) + ", v),\n");
+            o.p(std::string(".buffer => |v| zang.") + (ins.out.output ? "addInto" : "copy") + "(" + span + ", " + dest(ins.out) + ", v),\n");
+            o.p("}\n");
+            break;
+        case IK::arith_float:
+            o.p(strf("const temp_float%zu = ", ins.out_float));
+            o.p(un(ins.op, res(ins.a)) + ";\n");
+            break;
+        case IK::arith_buffer: loop(span, ins.out, un(ins.op, res(ins.a) + "[i]")); break;
+        case IK::arith_float_float:
+            o.p(strf("const temp_float%zu = ", ins.out_float));
+            o.p(bin(ins.op, res(ins.a), res(ins.b)) + ";\n");
+            break;
+        case IK::arith_float_buffer: case IK::arith_buffer_float: case IK::arith_buffer_buffer: {
+            const std::string a = res(ins.a) + (ins.kind != IK::arith_float_buffer ? "[i]" : "");
+            const std::string b = res(ins.b) + (ins.kind != IK::arith_buffer_float ? "[i]" : "");
+            if (ins.op == "add" || ins.op == "mul") {
+                if (!ins.out.output) o.p("zang.zero(" + span + ", " + dest(ins.out) + ");\n");
+                std::string fn, x = res(ins.a), y = res(ins.b);
+                if (ins.kind == IK::arith_buffer_buffer) fn = ins.op == "add" ? "zang.add" : "zang.multiply";
+                else {
+                    fn = ins.op == "add" ? "zang.addScalar" : "zang.multiplyScalar";
+                    if (ins.kind == IK::arith_float_buffer) std::swap(x, y);   // operands swapped: the operators are commutative (:205-206)
+                }
+                o.p(fn);
+                o.p("(" + span + ", " + dest(ins.out) + ", " + x + ", " + y + ");\n");
+            } else {
+                loop(span, ins.out, bin(ins.op, a, b));
+            }
+            break;
+        }
+        case IK::call: {
+            const Module &callee = s.pr.modules[inner.fields[ins.field_index]];
+            if (!ins.out.output) o.p("zang.zero(" + span + ", " + dest(ins.out) + ");\n");
+            o.p(strf("self.field%zu.paint(", ins.field_index) + span + ", .{");
+            o.p(dest(ins.out) + "}, .{");
+            std::string temps;
+            for (size_t j = 0; j < ins.temps.size(); j++) temps += (j ? ", " : "") + strf("temps[%zu]", ins.temps[j]);
+            o.p(temps);
+            o.p("}, " + ident(nic) + ", .{\n");
+            for (size_t j = 0; j < ins.args.size(); j++) {
+                o.p("." + ident(callee.params[j].name) + " = ");
+                o.p(callee.params[j].type.kind == PK::constant_or_buffer ? cob_arg(ins.args[j]) : res(ins.args[j]));
+                o.p(",\n");
+            }
+            o.p("});\n");
+            break;
+        }
+        case IK::track_call: {
+            bool has_note_on = false;
+            for (const ModuleParam &p : module->params) has_note_on |= p.name == "note_on";
+            o.p((has_note_on ? "if (params.note_on and " : "if (") + ident(nic) + ") {\n");
+            o.p(strf("self.tracker%zu.reset();\n", ins.note_tracker_index));
+            o.p(strf("self.trigger%zu.reset();\n", ins.trigger_index));
+            o.p("}\n");
+            o.p(strf("const _iap%zu = self.tracker%zu.consume(params.sample_rate / ", ins.note_tracker_index, ins.note_tracker_index) + res(ins.speed) + ", " + span + ");\n");
+            o.p(strf("var _ctr%zu = self.trigger%zu.counter(", ins.trigger_index, ins.trigger_index) + span + strf(", _iap%zu);\n", ins.note_tracker_index));
+            o.p(strf("while (self.trigger%zu.next(&_ctr%zu)) |_result| {\n", ins.trigger_index, ins.trigger_index));
+            o.p((has_note_on ? "const _new_note = (params.note_on and " + ident(nic) + ")" : "const _new_note = " + ident(nic)) + " or _result.note_id_changed;\n");
+            for (const Instr &sub : ins.instructions) instruction(inner, sub, "_result.span", "_new_note");
+            o.p("}\n");
+            break;
+        }
+        case IK::delay:
+            if (!ins.out.output) o.p("zang.zero(" + span + ", " + dest(ins.out) + ");\n");
+            o.p("{\n");
+            o.p("var start = span.start;\n");
+            o.p("const end = span.end;\n");
+            o.p("while (start < end) {\n");
+            o.p(strf("// temps[%zu] will be the destination for writing into the feedback buffer\n", ins.feedback_out_temp));
+            o.p(strf("zang.zero(zang.Span.init(start, end), temps[%zu]);\n", ins.feedback_out_temp));
+            o.p(strf("// temps[%zu] will contain the delay buffer's previous contents\n", ins.feedback_temp));
+            o.p(strf("zang.zero(zang.Span.init(start, end), temps[%zu]);\n", ins.feedback_temp));
+            o.p(strf("const samples_read = self.delay%zu.readDelayBuffer(temps[%zu][start..end]);\n", ins.delay_index, ins.feedback_temp));
+            o.p("const inner_span = zang.Span.init(start, start + samples_read);\n");
+            o.p("\n");
+            o.p("// inner expression\n");
+            for (const Instr &sub : ins.instructions) instruction(inner, sub, "inner_span", nic);
+            o.p("\n");
+            o.p("// write expression result into the delay buffer\n");
+            o.p(strf("self.delay%zu.writeDelayBuffer(temps[%zu][start..start + samples_read]);\n", ins.delay_index, ins.feedback_out_temp));
+            o.p("start += samples_read;\n");
+            o.p("}\n");
+            o.p("}\n");
+            break;
+        }
+    }
+    std::string generate() {                                         // codegen_zig.zig:459-577
+        o.p("// THIS FILE WAS GENERATED BY THE ZANGC COMPILER\n\n");
+        o.p("const std = @import(\"std\");\n");
+        o.p("const zang = @import(\"zang\");\n");
+        for (const Package *pkg : s.packages)
+            if (pkg->zig_package_name != "zang") o.p("const " + pkg->zig_package_name + " = @import(\"" + pkg->zig_import_path + "\");\n");
+        if (!s.exported_modules.empty()) o.p("\n");
+        for (const auto &em : s.exported_modules) o.p("pub const " + ident(em.first) + " = " + module_name(em.second) + ";\n");
+        for (size_t ci = 0; ci < s.pr.curves.size(); ci++) {
+            o.p("\n");
+            o.p(strf("const _curve%zu = [_]zang.CurveNode{\n", ci));
+            for (const auto &pt : s.pr.curves[ci].points) o.p(".{ .t = " + number(pt.first) + ", .value = " + number(pt.second) + " },\n");
+            o.p("};\n");
+        }
+        for (size_t ti = 0; ti < s.pr.tracks.size(); ti++) {
+            const Track &track = s.pr.tracks[ti];
+            o.p("\n");
+            o.p(strf("const _track%zu = struct {\n", ti));
+            o.p("const Params = struct {\n");
+            param_decls(track.params, false);
+            o.p("};\n");
+            o.p("const notes = [_]zang.Notes(Params).SongEvent{\n");
+            for (size_t ni = 0; ni < track.notes.size(); ni++) {
+                o.p(".{ .t = " + number(track.notes[ni].t) + strf(", .note_id = %zu, .params = .{", ni + 1));
+                for (size_t pi = 0; pi < track.params.size(); pi++) {
+                    if (pi > 0) o.p(",");
+                    o.p(" ." + track.params[pi].name + " = " + res(s.track_results[ti][ni][pi]));
+                }
+                o.p(" } },\n");
+            }
+            o.p("};\n");
+            o.p("};\n");
+        }
+        for (size_t mi = 0; mi < s.pr.modules.size(); mi++) {
+            const ModuleResult &mr = s.module_results[mi];
+            if (mr.builtin) continue;
+            module = &s.pr.modules[mi];
+            o.p("\n");
+            o.p(strf("const _module%zu = struct {\n", mi));
+            o.p(strf("pub const num_outputs = %zu;\n", mr.num_outputs));
+            o.p(strf("pub const num_temps = %zu;\n", mr.num_temps));
+            o.p("pub const Params = struct {\n");
+            param_decls(module->params, false);
+            o.p("};\n");
+            o.p("pub const NoteParams = struct {\n");
+            param_decls(module->params, true);
+            o.p("};\n");
+            o.p("\n");
+            for (size_t j = 0; j < mr.fields.size(); j++) o.p(strf("field%zu: ", j) + module_name(mr.fields[j]) + ",\n");
+            for (size_t j = 0; j < mr.delays.size(); j++) o.p(strf("delay%zu: zang.Delay(%zu),\n", j, mr.delays[j]));
+            for (size_t j = 0; j < mr.note_trackers.size(); j++) o.p(strf("tracker%zu: zang.Notes(_track%zu.Params).NoteTracker,\n", j, mr.note_trackers[j]));
+            for (size_t j = 0; j < mr.triggers.size(); j++) o.p(strf("trigger%zu: zang.Trigger(_track%zu.Params),\n", j, mr.triggers[j]));
+            o.p("\n");
+            o.p(strf("pub fn init() _module%zu {\n", mi));
+            o.p("return .{\n");
+            for (size_t j = 0; j < mr.fields.size(); j++) o.p(strf(".field%zu = ", j) + module_name(mr.fields[j]) + ".init(),\n");
+            for (size_t j = 0; j < mr.delays.size(); j++) o.p(strf(".delay%zu = zang.Delay(%zu).init(),\n", j, mr.delays[j]));
+            for (size_t j = 0; j < mr.note_trackers.size(); j++)
+                o.p(strf(".tracker%zu = zang.Notes(_track%zu.Params).NoteTracker.init(&_track%zu.notes),\n", j, mr.note_trackers[j], mr.note_trackers[j]));
+            for (size_t j = 0; j < mr.triggers.size(); j++) o.p(strf(".trigger%zu = zang.Trigger(_track%zu.Params).init(),\n", j, mr.triggers[j]));
+            o.p("};\n");
+            o.p("}\n");
+            o.p("\n");
+            o.p(strf("pub fn paint(self: *_module%zu, span: zang.Span, outputs: [num_outputs][]f32, temps: [num_temps][]f32, note_id_changed: bool, params: Params) void {\n", mi));
+            for (const Instr &ins : mr.instructions) instruction(mr, ins, "span", "note_id_changed");
+            o.p("}\n");
+            o.p("};\n");
+        }
+        return o.text;
+    }
+};
+
+// ================================================================== HIP backend
+struct HipBackendError { std::string message; };
+
+std::string f32_literal(float xf) {                                 // Python's float.hex(x) + "f"
+    const double x = (double)xf;
+    if (x != x) return "__builtin_nanf(\"\")";
+    if (isinf(x)) return x < 0 ? "-__builtin_inff()" : "__builtin_inff()";
+    const char *sign = signbit(x) ? "-" : "";
+    if (x == 0.0) return std::string(sign) + "0x0.0p+0f";
+    int e;
+    const double m = frexp(fabs(x), &e);                             // m in [0.5, 1)
+    const uint64_t frac = (uint64_t)ldexp(m * 2.0 - 1.0, 52);        // 52 fraction bits of the [1, 2) mantissa
+    return strf("%s0x1.%013llxp%+df", sign, (unsigned long long)frac, e - 1);
+}
+
+struct Val {
+    enum Kind { buf, flt, boolean, en, curve } kind = flt;
+    std::string expr;              // buf: valid inside the frame body; flt / boolean: a per-paint constant; curve: pointer
+    std::string tag;               // enum: label (literal) or a C++ expression (runtime)
+    bool tag_literal = false;
+    std::shared_ptr<Val> payload;  // enum payload (float) or null
+    std::string count;             // curve node count expression
+};
+
+size_t state_words(const std::string &name) {
+    static const std::map<std::string, size_t> w = {{"SineOsc", 1}, {"PulseOsc", 1}, {"TriSawOsc", 2}, {"Noise", 8}, {"Envelope", 4}, {"Gate", 0},
+                                                    {"Filter", 2}, {"Decimator", 2}, {"Distortion", 0}, {"Cycle", 1}, {"Portamento", 3}, {"Curve", 4}};
+    auto it = w.find(name);
+    if (it == w.end()) throw HipBackendError{"builtin module " + name + " is not supported by the HIP backend"};
+    return it->second;
+}
+const size_t kTrackWords = 3;                                       // NoteTracker {next_song_event, t} + Trigger {note}
+
+struct InitItem { bool noise; size_t word; size_t k; float value; };
+
+struct Kernel {
+    std::string name;
+    std::vector<HipParam> params;
+    Lines pro, frame, epi_ends, epi_stores;
+    std::vector<InitItem> init;
+    std::set<size_t> tracks;
+    Lines temps;
+    std::vector<size_t> rows;
+    size_t words = 0, noise_fields = 0, uid = 0;
+    std::string fresh(const std::string &stem) { uid++; return stem + std::to_string(uid); }
+    size_t alloc(size_t n) { const size_t w = words; words += n; return w; }
+};
+
+struct ModuleCtx {
+    Kernel &k;
+    size_t module_index;
+    std::vector<Val> env;
+    std::string outvar, nic, prefix;
+    std::map<size_t, std::string> tnames;
+    Lines *begin_sink, *end_sink;
+    std::string rel = "(i - L.start)", length = "SPAN_LEN";
+    const std::map<size_t, Val> *track = nullptr;
+    ModuleCtx(Kernel &k_, size_t mi, std::vector<Val> env_, std::string outvar_, std::string nic_, std::string prefix_, const ModuleCtx *parent)
+        : k(k_), module_index(mi), env(std::move(env_)), outvar(std::move(outvar_)), nic(std::move(nic_)), prefix(std::move(prefix_)) {
+        begin_sink = parent ? parent->begin_sink : &k.pro;
+        end_sink = parent ? parent->end_sink : &k.epi_ends;
+        if (parent) { rel = parent->rel; length = parent->length; }
+    }
+    std::string tname(size_t i) {
+        auto it = tnames.find(i);
+        if (it != tnames.end()) return it->second;
+        const std::string n = prefix + "t" + std::to_string(i);
+        tnames[i] = n;
+        k.temps.push_back(n);
+        return n;
+    }
+    std::string fname(size_t i) const { return prefix + "f" + std::to_string(i); }
+};
+
+class HipEmitter {
+public:
+    const CompiledScript &s;
+    explicit HipEmitter(const CompiledScript &cs) : s(cs) {}
+
+    Val val(ModuleCtx &mc, const Res &r) {
+        Val v;
+        switch (r.kind) {
+        case RK::temp_buffer: v.kind = Val::buf; v.expr = mc.tname(r.index); return v;
+        case RK::temp_float: v.kind = Val::flt; v.expr = mc.fname(r.index); return v;
+        case RK::literal_number: v.kind = Val::flt; v.expr = f32_literal(r.num.value); return v;
+        case RK::literal_boolean: v.kind = Val::boolean; v.expr = r.bval ? "true" : "false"; return v;
+        case RK::literal_enum_value:
+            v.kind = Val::en; v.tag = r.label; v.tag_literal = true;
+            if (r.payload) v.payload = std::make_shared<Val>(val(mc, *r.payload));
+            return v;
+        case RK::literal_curve: v.kind = Val::curve; v.expr = strf("zs_curve%zu", r.index); v.count = std::to_string(s.pr.curves[r.index].points.size()); return v;
+        case RK::self_param: return mc.env[r.index];
+        case RK::track_param: return mc.track->at(r.index);
+        default: throw HipBackendError{"internal: value kind"};
+        }
+    }
+    static std::string enum_tag(const Val &v, const BuiltinEnum &en) {
+        if (v.tag_literal) {
+            for (size_t i = 0; i < en.values.size(); i++) if (en.values[i].label == v.tag) return std::to_string(i);
+            throw HipBackendError{"internal: enum label"};
+        }
+        return v.tag;
+    }
+    static std::string enum_payload(const Val &v) { return v.payload ? v.payload->expr : "0.0f"; }
+    static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first) {
+        if (!d.output) {
+            const std::string t = mc.tname(d.index);
+            if (zero_first) return {t + " = 0.0f;", t + " = " + t + " + (" + expr + ");"};
+            return {t + " = " + expr + ";"};
+        }
+        return {mc.outvar + " = " + mc.outvar + " + (" + expr + ");"};
+    }
+    static std::string un(const std::string &op, const std::string &a) {
+        if (op == "abs") return "fabsf(" + a + ")";
+        if (op == "cos") return "zcosf(" + a + ")";
+        if (op == "neg") return "-(" + a + ")";
+        if (op == "sin") return "zsinf(" + a + ")";
+        return "sqrtf(" + a + ")";
+    }
+    static std::string bin(const std::string &op, const std::string &a, const std::string &b) {
+        if (op == "add") return "(" + a + ") + (" + b + ")";
+        if (op == "sub") return "(" + a + ") - (" + b + ")";
+        if (op == "mul") return "(" + a + ") * (" + b + ")";
+        if (op == "div") return "(" + a + ") / (" + b + ")";
+        if (op == "pow") return "zpowf(" + a + ", " + b + ")";
+        if (op == "max") return "zs_max(" + a + ", " + b + ")";
+        return "zs_min(" + a + ", " + b + ")";
+    }
+
+    void call_builtin(ModuleCtx &mc, const Instr &ins, const Module &callee, const std::vector<Res> &args) {
+        Kernel &k = mc.k;
+        const std::string &name = callee.builtin_name;
+        std::map<std::string, Val> a;
+        for (size_t i = 0; i < callee.params.size(); i++) a[callee.params[i].name] = val(mc, args[i]);
+        const std::string o = k.fresh("m");
+        const size_t w = k.alloc(state_words(name));
+        Lines &decl = k.pro, &pro = *mc.begin_sink, &ends = *mc.end_sink, &epi = k.epi_stores;
+        Lines frame;
+        std::string painted, value;
+        const char *oc = o.c_str();
+        auto ld_f = [&](const char *field, size_t word) {
+            decl.push_back(strf("%s.%s = zs_ld_f(L.state, %zu, V, v);", oc, field, word));
+            epi.push_back(strf("zs_st_f(L.state, %zu, V, v, %s.%s);", word, oc, field));
+        };
+        auto ld_u = [&](const char *field, size_t word, const char *cast) {
+            decl.push_back(strf("%s.%s = %szs_ld_u(L.state, %zu, V, v);", oc, field, cast, word));
+            epi.push_back(strf("zs_st_u(L.state, %zu, V, v, (uint32_t)%s.%s);", word, oc, field));
+        };
+        struct Cob { bool is_buf; std::string c, i; };
+        auto cob = [](const Val &v) { return v.kind == Val::buf ? Cob{true, "0.0f", v.expr} : Cob{false, v.expr, v.expr}; };
+        auto tf = [](bool b) { return b ? "true" : "false"; };
+        auto painted_pair = [&]() {
+            const std::string cv = k.fresh("cv"), cp = k.fresh("cp");
+            return std::make_pair(cv, cp);
+        };
+        const std::string sr = a.count("sample_rate") ? a["sample_rate"].expr : "";
+
+        if (name == "SineOsc") {
+            const Cob f = cob(a["freq"]), ph = cob(a["phase"]);
+            decl.push_back("SineOscLane " + o + ";");
+            ld_f("t", w);
+            pro.push_back(o + ".begin(" + sr + ", " + f.c + ");");
+            value = o + ".frame<" + tf(f.is_buf) + ">(" + (f.is_buf ? f.i : "0.0f") + ", " + ph.i + ")";
+            ends.push_back(o + ".end();");
+        } else if (name == "Cycle") {
+            const Cob sp = cob(a["speed"]);
+            decl.push_back("CycleLane " + o + ";");
+            ld_f("t", w);
+            pro.push_back(o + ".begin(" + sr + ", " + sp.c + ");");
+            value = o + ".frame<" + tf(sp.is_buf) + ">(" + (sp.is_buf ? sp.i : "0.0f") + ")";
+        } else if (name == "PulseOsc" || name == "TriSawOsc") {
+            const Cob f = cob(a["freq"]);
+            decl.push_back(name + "Lane " + o + ";");
+            ld_u("cnt", w, "");
+            if (name == "TriSawOsc") ld_f("t", w + 1);
+            if (f.is_buf) {
+                pro.push_back(o + ".begin_ctrl(" + sr + ", " + a["color"].expr + ");");
+                if (name == "PulseOsc") {
+                    auto pp = painted_pair();
+                    frame.push_back("float " + pp.first + " = 0.0f;");
+                    frame.push_back("const bool " + pp.second + " = " + o + ".frame_ctrl(" + f.i + ", " + pp.first + ");");
+                    painted = pp.second; value = pp.first;
+                } else {
+                    value = o + ".frame_ctrl(" + f.i + ")";
+                    ends.push_back(o + ".end_ctrl();");
+                }
+            } else {
+                pro.push_back(o + ".begin_const(" + sr + ", " + f.c + ", " + a["color"].expr + ");");
+                auto pp = painted_pair();
+                frame.push_back("float " + pp.first + " = 0.0f;");
+                frame.push_back("const bool " + pp.second + " = " + o + ".frame_const(" + pp.first + ");");
+                painted = pp.second; value = pp.first;
+            }
+        } else if (name == "Noise") {
+            decl.push_back("NoiseLane " + o + ";");
+            for (size_t j = 0; j < 4; j++) {
+                decl.push_back(strf("%s.r.s%zu = zs_ld_u64(L.state, %zu, V, v);", oc, j, w + 2 * j));
+                epi.push_back(strf("zs_st_u64(L.state, %zu, V, v, %s.r.s%zu);", w + 2 * j, oc, j));
+            }
+            pro.push_back(o + ".begin();");
+            k.init.push_back(InitItem{true, w, k.noise_fields, 0.0f});
+            k.noise_fields++;
+            const std::string tag = enum_tag(a["color"], *callee.params[0].type.en);
+            if (tag == "0" || tag == "1") value = o + ".frame<" + tf(tag == "1") + ">()";
+            else value = "((" + tag + ") == 1u ? " + o + ".frame<true>() : " + o + ".frame<false>())";
+        } else if (name == "Envelope") {
+            decl.push_back("EnvLane " + o + ";");
+            ld_u("state", w, "");
+            ld_f("t", w + 1);
+            ld_f("last_value", w + 2);
+            ld_f("start", w + 3);
+            pro.push_back(o + ".sample_rate = " + sr + "; " + o + ".sustain_volume = " + a["sustain_volume"].expr + "; " + o + ".note_on = " + a["note_on"].expr + ";");
+            const char *stages[3] = {"attack", "decay", "release"};
+            for (int i = 0; i < 3; i++)
+                pro.push_back(o + "." + stages[i] + " = CurveP{(uint32_t)(" + enum_tag(a[stages[i]], *callee.params[1 + i].type.en) + "), " + enum_payload(a[stages[i]]) + "};");
+            pro.push_back(o + ".begin(" + mc.nic + ");");
+            auto pp = painted_pair();
+            frame.push_back("float " + pp.first + " = 0.0f;");
+            frame.push_back("const bool " + pp.second + " = " + o + ".frame(" + pp.first + ");");
+            painted = pp.second; value = pp.first;
+        } else if (name == "Gate") {
+            painted = a["note_on"].expr; value = "1.0f";                                          // Gate.zig:28-30
+        } else if (name == "Filter") {
+            const Cob c = cob(a["cutoff"]), r = cob(a["res"]);
+            decl.push_back("FilterLane " + o + ";");
+            ld_f("l", w);
+            ld_f("b", w + 1);
+            pro.push_back(o + ".begin((uint32_t)(" + enum_tag(a["type"], *callee.params[1].type.en) + "), " + c.c + ", " + r.c + ");");
+            value = o + ".frame<" + tf(c.is_buf) + ", " + tf(r.is_buf) + ">(" + a["input"].expr + ", " + (c.is_buf ? c.i : "0.0f") + ", " + (r.is_buf ? r.i : "0.0f") + ")";
+        } else if (name == "Decimator") {
+            decl.push_back("DecimatorLane " + o + ";");
+            ld_f("dval", w);
+            ld_f("dcount", w + 1);
+            k.init.push_back(InitItem{false, w + 1, 0, 1.0f});                                    // Decimator.zig:14-19
+            pro.push_back(o + ".begin(" + sr + ", " + a["fake_sample_rate"].expr + ");");
+            auto pp = painted_pair();
+            frame.push_back("float " + pp.first + " = 0.0f;");
+            frame.push_back("const bool " + pp.second + " = " + o + ".frame(" + a["input"].expr + ", " + pp.first + ");");
+            painted = pp.second; value = pp.first;
+            ends.push_back(o + ".end();");
+        } else if (name == "Distortion") {
+            decl.push_back("DistortionLane " + o + ";");
+            pro.push_back(o + ".begin((uint32_t)(" + enum_tag(a["type"], *callee.params[1].type.en) + "), " + a["ingain"].expr + ", " + a["outgain"].expr + ", " + a["offset"].expr + ");");
+            value = o + ".frame(" + a["input"].expr + ")";
+        } else if (name == "Portamento") {
+            decl.push_back("PortamentoLane " + o + ";");
+            ld_f("t", w);
+            ld_f("last", w + 1);
+            ld_f("st", w + 2);
+            pro.push_back(o + ".begin(" + sr + ", (uint32_t)(" + enum_tag(a["curve"], *callee.params[1].type.en) + "), " + enum_payload(a["curve"]) + ", " + a["goal"].expr + ", " +
+                          a["note_on"].expr + ", " + a["prev_note_on"].expr + ", " + mc.nic + ");");
+            value = o + ".frame()";
+        } else if (name == "Curve") {
+            decl.push_back("CurveLane " + o + ";");
+            ld_f("t", w);
+            ld_u("cur", w + 1, "");
+            ld_u("off", w + 2, "(int32_t)");
+            ld_u("next", w + 3, "");
+            pro.push_back(o + ".begin(" + sr + ", (uint32_t)(" + enum_tag(a["function"], *callee.params[1].type.en) + "), " + a["curve"].expr + ", " + a["curve"].count + ", " +
+                          mc.length + ", " + mc.nic + ");");
+            auto pp = painted_pair();
+            frame.push_back("float " + pp.first + " = 0.0f;");
+            frame.push_back("const bool " + pp.second + " = " + o + ".frame(" + mc.rel + ", " + pp.first + ");");
+            painted = pp.second; value = pp.first;
+        } else {
+            throw HipBackendError{"builtin module " + name + " is not supported by the HIP backend"};
+        }
+        // zang.zero(dest) for a temp, then the module's `+=` (codegen_zig.zig:284-291)
+        std::string target;
+        if (!ins.out.output) {
+            target = mc.tname(ins.out.index);
+            frame.insert(frame.begin(), target + " = 0.0f;");
+        } else {
+            target = mc.outvar;
+        }
+        const std::string addl = target + " = " + target + " + (" + value + ");";
+        frame.push_back(painted.empty() ? addl : "if (" + painted + ") " + addl);
+        k.frame.push_back("{");
+        append(k.frame, indent(frame));
+        k.frame.push_back("}");
+    }
+
+    void instruction(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
+        Kernel &k = mc.k;
+        switch (ins.kind) {
+        case IK::copy_buffer: case IK::float_to_buffer: append(k.frame, put(mc, ins.out, val(mc, ins.src).expr, false)); break;
+        case IK::cob_to_buffer: append(k.frame, put(mc, ins.out, mc.env[ins.in_self_param].expr, false)); break;
+        case IK::arith_float: case IK::arith_float_float: {
+            const std::string expr = ins.kind == IK::arith_float ? un(ins.op, val(mc, ins.a).expr) : bin(ins.op, val(mc, ins.a).expr, val(mc, ins.b).expr);
+            if (mc.begin_sink == &k.pro) {
+                k.pro.push_back("const float " + mc.fname(ins.out_float) + " = " + expr + ";");
+            } else {                   // inside a delay / track body: evaluated once per chunk, like the Zig `const` in the loop
+                k.pro.push_back("float " + mc.fname(ins.out_float) + " = 0.0f;");
+                mc.begin_sink->push_back(mc.fname(ins.out_float) + " = " + expr + ";");
+            }
+            break;
+        }
+        case IK::arith_buffer: append(k.frame, put(mc, ins.out, un(ins.op, val(mc, ins.a).expr), false)); break;
+        case IK::arith_float_buffer: case IK::arith_buffer_float: case IK::arith_buffer_buffer: {
+            std::string a = val(mc, ins.a).expr, b = val(mc, ins.b).expr;
+            if (ins.op == "add" || ins.op == "mul") {
+                if (ins.kind == IK::arith_float_buffer) std::swap(a, b);       // addScalar / multiplyScalar(dest, buffer, float)
+                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), true));
+            } else {
+                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), false));
+            }
+            break;
+        }
+        case IK::call: {
+            const size_t callee_index = mr.fields[ins.field_index];
+            const Module &callee = s.pr.modules[callee_index];
+            if (callee.builtin) { call_builtin(mc, ins, callee, ins.args); break; }
+            std::vector<Val> env;
+            for (const Res &r : ins.args) env.push_back(val(mc, r));
+            std::string outvar;
+            if (!ins.out.output) { outvar = mc.tname(ins.out.index); k.frame.push_back(outvar + " = 0.0f;"); }
+            else outvar = mc.outvar;
+            ModuleCtx sub(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", &mc);
+            module_body(sub);
+            break;
+        }
+        case IK::track_call: track_call(mc, mr, ins); break;
+        case IK::delay: delay(mc, mr, ins); break;
+        }
+    }
+
+    void delay(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
+        Kernel &k = mc.k;
+        const size_t n = mr.delays[ins.delay_index];
+        if (n < 1) throw HipBackendError{"delay of 0 samples"};
+        const size_t w_idx = k.alloc(1), w_ring = k.alloc(n);
+        const std::string d = k.fresh("d");
+        k.pro.push_back(strf("uint32_t %s_idx = zs_ld_u(L.state, %zu, V, v);", d.c_str(), w_idx));
+        k.epi_stores.push_back(strf("zs_st_u(L.state, %zu, V, v, %s_idx);", w_idx, d.c_str()));
+        if (!ins.out.output) k.frame.push_back(mc.tname(ins.out.index) + " = 0.0f;");             // zang.zero(span, dest) (:396-399)
+        const std::string fb = mc.tname(ins.feedback_temp), fbout = mc.tname(ins.feedback_out_temp);
+        Lines begins, ends, body;
+        Lines *sb = mc.begin_sink, *se = mc.end_sink;
+        const std::string srel = mc.rel, slen = mc.length;
+        const std::string rel = d + "_rel", length = d + "_len";
+        const Lines head = {"const uint32_t " + rel + " = " + srel + strf(" %% %zuu;", n),
+                            "const uint32_t " + length + strf(" = min(%zuu, ", n) + slen + " - (" + srel + " - " + rel + "));"};
+        Lines saved_frame;
+        saved_frame.swap(k.frame);
+        mc.begin_sink = &begins; mc.end_sink = &ends; mc.rel = rel; mc.length = length;
+        try {
+            for (const Instr &sub : ins.instructions) instruction(mc, mr, sub);
+        } catch (...) {
+            mc.begin_sink = sb; mc.end_sink = se; mc.rel = srel; mc.length = slen;
+            throw;
+        }
+        body.swap(k.frame);
+        k.frame.swap(saved_frame);
+        mc.begin_sink = sb; mc.end_sink = se; mc.rel = srel; mc.length = slen;
+        const std::string slot = strf("L.state[(size_t)(%zuu + %s_idx) * V + v]", w_ring, d.c_str());
+        append(k.frame, head);
+        if (!begins.empty()) { k.frame.push_back("if (" + rel + " == 0u) {"); append(k.frame, indent(begins)); k.frame.push_back("}"); }
+        k.frame.push_back(fbout + " = 0.0f;");
+        k.frame.push_back(fb + " = 0.0f;");
+        k.frame.push_back(fb + " = " + fb + " + zu2f(" + slot + ");");                            // readDelayBuffer: `+=` (delay.zig:39-42)
+        append(k.frame, body);
+        k.frame.push_back(slot + " = zf2u(" + fbout + ");");                                       // writeDelayBuffer (delay.zig:62-89)
+        k.frame.push_back(strf("%s_idx = %s_idx + 1u == %zuu ? 0u : %s_idx + 1u;", d.c_str(), d.c_str(), n, d.c_str()));
+        if (!ends.empty()) { k.frame.push_back("if (" + rel + " + 1u == " + length + ") {"); append(k.frame, indent(ends)); k.frame.push_back("}"); }
+    }
+
+    void track_call(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
+        Kernel &k = mc.k;
+        const size_t ti = ins.track_index;
+        const Track &track = s.pr.tracks[ti];
+        const Module &module = s.pr.modules[mc.module_index];
+        const size_t w = k.alloc(kTrackWords);
+        const std::string t = k.fresh("trk");
+        const char *tc = t.c_str();
+        k.tracks.insert(ti);
+        std::map<size_t, Val> env;
+        Lines loads;
+        for (size_t pi = 0; pi < track.params.size(); pi++) {
+            const ModuleParam &p = track.params[pi];
+            Val v;
+            if (p.type.kind == PK::constant) {
+                k.pro.push_back(strf("float %s_p%zu = 0.0f;", tc, pi));
+                loads.push_back(strf("%s_p%zu = zs_track%zu_p%zu[%s_note];", tc, pi, ti, pi, tc));
+                v.kind = Val::flt; v.expr = strf("%s_p%zu", tc, pi);
+            } else if (p.type.kind == PK::boolean) {
+                k.pro.push_back(strf("bool %s_p%zu = false;", tc, pi));
+                loads.push_back(strf("%s_p%zu = zs_track%zu_p%zu[%s_note] != 0;", tc, pi, ti, pi, tc));
+                v.kind = Val::boolean; v.expr = strf("%s_p%zu", tc, pi);
+            } else if (p.type.kind == PK::one_of) {
+                k.pro.push_back(strf("uint32_t %s_p%zu = 0u; float %s_q%zu = 0.0f;", tc, pi, tc, pi));
+                loads.push_back(strf("%s_p%zu = zs_track%zu_p%zu[%s_note]; %s_q%zu = zs_track%zu_q%zu[%s_note];", tc, pi, ti, pi, tc, tc, pi, ti, pi, tc));
+                v.kind = Val::en; v.tag = strf("%s_p%zu", tc, pi);
+                v.payload = std::make_shared<Val>();
+                v.payload->kind = Val::flt; v.payload->expr = strf("%s_q%zu", tc, pi);
+            } else {
+                const char *kn = p.type.kind == PK::curve ? "curve" : p.type.kind == PK::buffer ? "buffer" : "constant_or_buffer";
+                throw HipBackendError{"track param `" + p.name + "`: type " + kn + " is not supported by the HIP backend"};
+            }
+            env[pi] = v;
+        }
+        std::string reset = mc.nic;                                                               // codegen_zig.zig:362-371
+        for (size_t i = 0; i < module.params.size(); i++)
+            if (module.params[i].name == "note_on") { reset = "(" + mc.env[i].expr + " && " + mc.nic + ")"; break; }
+        k.pro.push_back("TrackLane " + t + ";");
+        k.pro.push_back(strf("%s.next = zs_ld_u(L.state, %zu, V, v); %s.t = zs_ld_f(L.state, %zu, V, v); %s.cur = zs_ld_u(L.state, %zu, V, v);", tc, w, tc, w + 1, tc, w + 2));
+        k.pro.push_back(strf("uint32_t %s_k = 0u, %s_note = 0u; bool %s_new = false;", tc, tc, tc));
+        k.epi_stores.push_back(strf("zs_st_u(L.state, %zu, V, v, %s.next); zs_st_f(L.state, %zu, V, v, %s.t); zs_st_u(L.state, %zu, V, v, %s.cur);", w, tc, w + 1, tc, w + 2, tc));
+        mc.begin_sink->push_back(t + strf(".begin(zs_track%zu_t, %zuu, (", ti, track.notes.size()) + mc.env[0].expr + ") / (" + val(mc, ins.speed).expr + "), " + mc.length + ", " + reset + ");");
+        mc.begin_sink->push_back(t + "_k = 0u;");
+        Lines begins, ends, body;
+        Lines *sb = mc.begin_sink, *se = mc.end_sink;
+        const std::string srel = mc.rel, slen = mc.length, snic = mc.nic;
+        const std::map<size_t, Val> *strack = mc.track;
+        Lines saved_frame;
+        saved_frame.swap(k.frame);
+        mc.begin_sink = &begins; mc.end_sink = &ends;
+        mc.rel = strf("(%s_rel - %s.s_start[%s_k])", tc, tc, tc);
+        mc.length = strf("(%s.s_end[%s_k] - %s.s_start[%s_k])", tc, tc, tc, tc);
+        mc.nic = t + "_new"; mc.track = &env;
+        auto restore = [&]() { mc.begin_sink = sb; mc.end_sink = se; mc.rel = srel; mc.length = slen; mc.nic = snic; mc.track = strack; };
+        try {
+            for (const Instr &sub : ins.instructions) instruction(mc, mr, sub);
+        } catch (...) { restore(); throw; }
+        body.swap(k.frame);
+        k.frame.swap(saved_frame);
+        restore();
+        const std::string I = "    ";
+        k.frame.push_back(strf("const uint32_t %s_rel = ", tc) + srel + ";");
+        k.frame.push_back(strf("if (%s_k < %s.n && %s_rel == %s.s_start[%s_k]) {", tc, tc, tc, tc, tc));
+        k.frame.push_back(I + strf("%s_note = %s.s_note[%s_k];", tc, tc, tc));
+        k.frame.push_back(I + t + "_new = " + reset + strf(" || %s.s_new[%s_k];", tc, tc));      // _new_note (:379-383)
+        append(k.frame, indent(loads));
+        append(k.frame, indent(begins));
+        k.frame.push_back("}");
+        k.frame.push_back(strf("const bool %s_on = %s_k < %s.n && %s_rel >= %s.s_start[%s_k];", tc, tc, tc, tc, tc, tc));
+        k.frame.push_back(strf("if (%s_on) {", tc));
+        append(k.frame, indent(body));
+        k.frame.push_back("}");
+        k.frame.push_back(strf("if (%s_on && %s_rel + 1u == %s.s_end[%s_k]) {", tc, tc, tc, tc));
+        append(k.frame, indent(ends));
+        k.frame.push_back(I + t + "_k++;");
+        k.frame.push_back("}");
+    }
+
+    Lines track_tables(size_t ti) {
+        const Track &track = s.pr.tracks[ti];
+        const auto &notes = s.track_results[ti];
+        const size_t n = track.notes.empty() ? 1 : track.notes.size();
+        auto join = [](const Lines &parts, const char *empty) {
+            std::string o;
+            for (size_t i = 0; i < parts.size(); i++) o += (i ? ", " : "") + parts[i];
+            return o.empty() ? std::string(empty) : o;
+        };
+        Lines out, parts;
+        for (const TrackNote &x : track.notes) parts.push_back(f32_literal(x.t.value));
+        out.push_back(strf("__device__ const float zs_track%zu_t[%zu] = {", ti, n) + join(parts, "0.0f") + "};");
+        for (size_t pi = 0; pi < track.params.size(); pi++) {
+            const ModuleParam &p = track.params[pi];
+            Lines a, b;
+            if (p.type.kind == PK::constant) {
+                for (size_t ni = 0; ni < track.notes.size(); ni++) a.push_back(f32_literal(notes[ni][pi].num.value));
+                out.push_back(strf("__device__ const float zs_track%zu_p%zu[%zu] = {", ti, pi, n) + join(a, "0.0f") + "};");
+            } else if (p.type.kind == PK::boolean) {
+                for (size_t ni = 0; ni < track.notes.size(); ni++) a.push_back(notes[ni][pi].bval ? "1" : "0");
+                out.push_back(strf("__device__ const unsigned char zs_track%zu_p%zu[%zu] = {", ti, pi, n) + join(a, "0") + "};");
+            } else if (p.type.kind == PK::one_of) {
+                for (size_t ni = 0; ni < track.notes.size(); ni++) {
+                    const Res &r = notes[ni][pi];
+                    size_t idx = 0;
+                    while (p.type.en->values[idx].label != r.label) idx++;
+                    a.push_back(std::to_string(idx));
+                    b.push_back(r.payload ? f32_literal(r.payload->num.value) : "0.0f");
+                }
+                out.push_back(strf("__device__ const unsigned int zs_track%zu_p%zu[%zu] = {", ti, pi, n) + join(a, "0") + "};");
+                out.push_back(strf("__device__ const float zs_track%zu_q%zu[%zu] = {", ti, pi, n) + join(b, "0.0f") + "};");
+            }
+        }
+        return out;
+    }
+
+    void module_body(ModuleCtx &mc) {
+        const ModuleResult &mr = s.module_results[mc.module_index];
+        for (const Instr &ins : mr.instructions) instruction(mc, mr, ins);
+    }
+
+    void kernel(Kernel &k, size_t module_index) {
+        const Module &module = s.pr.modules[module_index];
+        if (module.params.size() > ZH_SCRIPT_MAX_PARAMS)
+            throw HipBackendError{strf("module has %zu params; the loader passes at most 16", module.params.size())};
+        std::vector<Val> env;
+        for (size_t i = 0; i < module.params.size(); i++) {
+            const ModuleParam &p = module.params[i];
+            Val v;
+            const char *kind = "";
+            switch (p.type.kind) {
+            case PK::constant:
+                kind = "constant";
+                k.pro.push_back(strf("const float P%zu = zs_const(L.p[%zu], v);", i, i));
+                v.kind = Val::flt; v.expr = strf("P%zu", i);
+                break;
+            case PK::boolean:
+                kind = "boolean";
+                k.pro.push_back(strf("const bool P%zu = zs_bool(L.p[%zu], v);", i, i));
+                v.kind = Val::boolean; v.expr = strf("P%zu", i);
+                break;
+            case PK::buffer: {
+                kind = "buffer";
+                const size_t j = k.rows.size();
+                k.rows.push_back(i);
+                v.kind = Val::buf; v.expr = strf("x[%zu]", j);
+                break;
+            }
+            case PK::constant_or_buffer: {
+                kind = "constant_or_buffer";
+                const size_t j = k.rows.size();
+                k.rows.push_back(i);
+                k.pro.push_back(strf("const bool P%zu_b = L.p[%zu].is_buffer != 0; const float P%zu_c = zs_const(L.p[%zu], v);", i, i, i, i));
+                v.kind = Val::buf; v.expr = strf("(P%zu_b ? x[%zu] : P%zu_c)", i, j, i);         // cob_to_buffer's switch (codegen_zig.zig:130-143)
+                break;
+            }
+            case PK::curve:
+                kind = "curve";
+                v.kind = Val::curve; v.expr = strf("reinterpret_cast<const zh_curve_node *>(L.p[%zu].pf)", i); v.count = strf("L.p[%zu].u", i);
+                break;
+            case PK::one_of:
+                kind = "one_of";
+                k.pro.push_back(strf("const uint32_t P%zu_tag = L.p[%zu].u; const float P%zu_f = L.p[%zu].f;", i, i, i, i));
+                v.kind = Val::en; v.tag = strf("P%zu_tag", i);
+                v.payload = std::make_shared<Val>();
+                v.payload->kind = Val::flt; v.payload->expr = strf("P%zu_f", i);
+                break;
+            }
+            env.push_back(v);
+            k.params.push_back(HipParam{p.name, kind, p.type.en ? p.type.en->name : ""});
+        }
+        ModuleCtx mc(k, module_index, env, "o", "NIC", "", nullptr);
+        module_body(mc);
+    }
+
+    std::string generate(const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override) {
+        Lines out = {"// generated by zang_amd.zangscript (HIP backend) -- compile with zh_script_load / zh_script_compile",
+                     "#include \"script_rt.cuh\"", ""};
+        for (size_t ci = 0; ci < s.pr.curves.size(); ci++) {
+            std::string pts;
+            for (size_t i = 0; i < s.pr.curves[ci].points.size(); i++) {
+                const auto &p = s.pr.curves[ci].points[i];
+                pts += (i ? ", " : "") + ("{" + f32_literal(p.second.value) + ", " + f32_literal(p.first.value) + "}");       // {value, t}
+            }
+            out.push_back(strf("__device__ const zh_curve_node zs_curve%zu[] = {", ci) + (pts.empty() ? "{0.0f, 0.0f}" : pts) + "};");
+        }
+        std::set<size_t> used_tracks;
+        const size_t table_at = out.size();
+        for (const auto &em : s.exported_modules) {
+            const std::string &name = em.first;
+            if (only && !only->count(name)) continue;
+            Kernel k;
+            k.name = name;
+            HipModuleMeta m;
+            m.name = name;
+            try {
+                kernel(k, em.second);
+            } catch (const HipBackendError &e) {
+                m.error = e.message;
+                meta.push_back(m);
+                out.push_back("");
+                out.push_back("// " + name + ": " + e.message);
+                continue;
+            }
+            m.state_words = k.words; m.noise_fields = k.noise_fields; m.params = k.params;
+            meta.push_back(m);
+            used_tracks.insert(k.tracks.begin(), k.tracks.end());
+            const size_t nin = k.rows.size(), ni = nin ? nin : 1;
+            const int unroll = unroll_override ? unroll_override : (k.frame.size() <= 40 ? 8 : k.frame.size() <= 100 ? 4 : 2);
+            const std::string I = "    ";
+            const char *nc = name.c_str();
+            out.push_back("");
+            out.push_back(strf("extern \"C\" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {", nc));
+            out.push_back(I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;");
+            out.push_back(I + "if (v >= V) return;");
+            out.push_back(I + strf("for (uint32_t w = 0; w < %zuu; w++) st[(size_t)w * V + v] = 0u;", k.words));
+            for (const InitItem &it : k.init) {
+                if (!it.noise) {
+                    out.push_back(I + strf("zs_st_f(st, %zu, V, v, ", it.word) + f32_literal(it.value) + ");");
+                } else {                                          // Noise.zig:25-32: seed = counter++ at init()
+                    out.push_back(I + strf("{ ZXoshiro r; zxoshiro_seed(r, first_seed + (uint64_t)v * %zuu + %zuu);", k.noise_fields, it.k));
+                    out.push_back(I + strf("  zs_st_u64(st, %zu, V, v, r.s0); zs_st_u64(st, %zu, V, v, r.s1); zs_st_u64(st, %zu, V, v, r.s2); zs_st_u64(st, %zu, V, v, r.s3); }",
+                                           it.word, it.word + 2, it.word + 4, it.word + 6));
+                }
+            }
+            out.push_back("}");
+            out.push_back("");
+            out.push_back(strf("extern \"C\" __global__ void __launch_bounds__(64) zs_paint_%s(const ZsLaunch L) {", nc));
+            out.push_back(I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;");
+            out.push_back(I + "const uint32_t V = L.V;");
+            out.push_back(I + "if (v >= V) return;");
+            out.push_back(I + "const bool NIC = L.nic.get(v);");
+            out.push_back(I + "const uint32_t SPAN_LEN = L.end - L.start;");
+            out.push_back(I + "(void)NIC; (void)SPAN_LEN;");
+            std::string nulls, zeros;
+            for (size_t j = 0; j < ni; j++) { nulls += j ? ", nullptr" : "nullptr"; zeros += j ? ", 0" : "0"; }
+            out.push_back(I + strf("const float *ins[%zu] = {", ni) + nulls + "};");
+            out.push_back(I + strf("size_t istr[%zu] = {", ni) + zeros + "};");
+            for (size_t j = 0; j < k.rows.size(); j++) out.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu]);", j, k.rows[j], j));
+            append(out, indent(k.pro));
+            out.push_back(I + strf("zs_frame_loop<%d, %zu>(L.out + v, L.ostride, ins, istr, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0,", unroll, nin));
+            out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
+            out.push_back(I + I + "(void)i; (void)x;");
+            if (!k.temps.empty()) {
+                std::string decl = "float ";
+                for (size_t j = 0; j < k.temps.size(); j++) decl += (j ? ", " : "") + k.temps[j] + " = 0.0f";
+                out.push_back(I + I + decl + ";");
+            }
+            append(out, indent(indent(k.frame)));
+            out.push_back(I + "});");
+            append(out, indent(k.epi_ends));
+            append(out, indent(k.epi_stores));
+            out.push_back("}");
+        }
+        Lines tables;
+        for (size_t ti : used_tracks) append(tables, track_tables(ti));
+        out.insert(out.begin() + (long)table_at, tables.begin(), tables.end());
+        std::string text;
+        for (const std::string &l : out) text += l + "\n";
+        return text;
+    }
+};
+
+}  // namespace
+
+std::string generate_zig(const CompiledScript &cs) { return ZigEmitter(cs).generate(); }
+std::string generate_hip(const CompiledScript &cs, const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override) {
+    return HipEmitter(cs).generate(only, meta, unroll_override);
+}
+
+}  // namespace zs
+
+// ================================================================== C ABI
+struct zh_zscript {
+    std::unique_ptr<zs::CompiledScript> cs;
+    std::vector<zs::HipModuleMeta> meta;         // of the last zh_zscript_generate_hip
+};
+
+static void put_text(char *dst, size_t cap, const std::string &text) {
+    if (!dst || cap == 0) return;
+    const size_t n = text.size() < cap - 1 ? text.size() : cap - 1;
+    memcpy(dst, text.data(), n);
+    dst[n] = 0;
+}
+static char *dup_text(const std::string &s) {
+    char *p = (char *)malloc(s.size() + 1);
+    if (p) memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+extern "C" {
+
+int zh_zscript_compile(const char *text, const char *filename, uint32_t packages, zh_zscript **out, char *err, size_t err_cap) {
+    if (!text || !out) return ZH_ERR_INVALID;
+    *out = nullptr;
+    std::vector<const zs::Package *> pk;
+    if (packages & 1u) pk.push_back(&zs::zang_builtin_package());
+    if (packages & 2u) pk.push_back(&zs::modules_builtin_package());
+    try {
+        zh_zscript *z = new zh_zscript();
+        try {
+            z->cs = zs::compile(text, filename ? filename : "script.txt", pk);
+        } catch (...) { delete z; throw; }
+        *out = z;
+        return ZH_OK;
+    } catch (const zs::ScriptError &e) {
+        put_text(err, err_cap, e.rendered);
+        return ZH_ERR_INVALID;
+    } catch (const std::exception &e) {
+        put_text(err, err_cap, e.what());
+        return ZH_ERR_INVALID;
+    }
+}
+int zh_zscript_destroy(zh_zscript *z) { delete z; return ZH_OK; }
+void zh_zscript_free_text(char *text) { free(text); }
+
+int zh_zscript_generate_zig(zh_zscript *z, char **text_out) {
+    if (!z || !text_out) return ZH_ERR_INVALID;
+    *text_out = dup_text(zs::generate_zig(*z->cs));
+    return *text_out ? ZH_OK : ZH_ERR_INVALID;
+}
+int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unroll, char **text_out) {
+    if (!z || !text_out) return ZH_ERR_INVALID;
+    std::set<std::string> only;
+    if (only_csv) {
+        std::string cur;
+        for (const char *p = only_csv;; p++) {
+            if (*p == ',' || *p == 0) { if (!cur.empty()) only.insert(cur); cur.clear(); if (!*p) break; }
+            else cur += *p;
+        }
+    }
+    z->meta.clear();
+    *text_out = dup_text(zs::generate_hip(*z->cs, only_csv ? &only : nullptr, z->meta, unroll));
+    return *text_out ? ZH_OK : ZH_ERR_INVALID;
+}
+uint32_t zh_zscript_module_count(zh_zscript *z) { return z ? (uint32_t)z->meta.size() : 0; }
+int zh_zscript_module_info(zh_zscript *z, uint32_t i, char *name, size_t name_cap, uint32_t *state_words, uint32_t *noise_fields,
+                           uint32_t *n_params, char *error, size_t error_cap) {
+    if (!z || i >= z->meta.size()) return ZH_ERR_INVALID;
+    const zs::HipModuleMeta &m = z->meta[i];
+    put_text(name, name_cap, m.name);
+    put_text(error, error_cap, m.error);
+    if (state_words) *state_words = (uint32_t)m.state_words;
+    if (noise_fields) *noise_fields = (uint32_t)m.noise_fields;
+    if (n_params) *n_params = (uint32_t)m.params.size();
+    return ZH_OK;
+}
+int zh_zscript_module_param(zh_zscript *z, uint32_t i, uint32_t p, char *name, size_t name_cap, char *kind, size_t kind_cap, char *enum_name, size_t enum_cap) {
+    if (!z || i >= z->meta.size() || p >= z->meta[i].params.size()) return ZH_ERR_INVALID;
+    const zs::HipParam &hp = z->meta[i].params[p];
+    put_text(name, name_cap, hp.name);
+    put_text(kind, kind_cap, hp.kind);
+    put_text(enum_name, enum_cap, hp.enum_name);
+    return ZH_OK;
+}
+
+}  // extern "C"

@@ -30,10 +30,17 @@ class ScriptProgram:
     """One script: front-end result + the loaded hipModule."""
 
     def __init__(self, text, ctx=None, filename="script.txt", only=None):
+        from .zangscript import native
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
-        self.script = text if isinstance(text, zangscript.CompiledScript) else zangscript.compile(text, filename)
-        self.hip_source, self.meta = zangscript.generate_hip(self.script, only=only)
+        self.text, self.filename = text, filename
+        self._script = None
+        try:                                                    # the C++ compiler in libzang_hip.so (zh_zscript_*)
+            compiled = native.NativeScript(text, filename)
+        except native.NativeScriptError as e:
+            raise ScriptCompileError(str(e))
+        self.hip_source, self.meta = compiled.generate_hip(only=only)
+        compiled.close()
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
         rc = self.lib.zh_script_load(self.ctx.handle, self.hip_source.encode(), C.byref(h), log, len(log))
@@ -43,12 +50,21 @@ class ScriptProgram:
         self._modules = []
         self.ctx._children.add(self)
 
+    @property
+    def script(self):
+        """The Python front-end's view of the same script (instruction lists) -- what the oracle-side interpreter
+        and the tests read; the kernels above came from the C++ compiler."""
+        if self._script is None:
+            self._script = zangscript.compile(self.text, self.filename)
+        return self._script
+
     def module(self, name, n_voices, first_seed=0):
         m = self.meta.get(name)
         if m is None:
             raise KeyError("script exports no module named %r" % name)
         if "error" in m:
-            raise zangscript.emit_hip.HipBackendError("%s: %s" % (name, m["error"]))
+            from .zangscript.emit_hip import HipBackendError
+            raise HipBackendError("%s: %s" % (name, m["error"]))
         return ScriptModule(self, name, n_voices, first_seed)
 
     def close(self):
@@ -78,13 +94,18 @@ class ScriptModule:
         self.program, self.name, self.n = program, name, n_voices
         self.meta = program.meta[name]
         self.params = self.meta["params"]            # [(name, kind, enum name)], sample_rate first
-        self.num_temps = program.script.module_results[program.script.module_index(name)].num_temps
         self.lib = program.lib
         h = C.c_void_p()
         abi.check(self.lib.zh_script_module_create(program.handle, name.encode(), n_voices, self.meta["state_words"],
                                                    first_seed, C.byref(h)), "zh_script_module_create")
         self.handle = h
         program._modules.append(self)
+
+    @property
+    def num_temps(self):
+        """What the generated Zig struct would ask for (codegen_zig.zig:518); the fused kernel needs none."""
+        sc = self.program.script
+        return sc.module_results[sc.module_index(self.name)].num_temps
 
     def _param(self, kind, enum, value, keep):
         p = abi.ScriptParam()

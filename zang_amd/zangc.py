@@ -81,24 +81,26 @@ def main(argv=None):
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--color", default="auto")
     a = ap.parse_args(argv)
-    try:
-        script = zs.compile(open(a.file).read(), a.file)
-    except zs.ScriptError as e:
+    from .zangscript import native
+    text = open(a.file).read()
+    try:                                                        # the C++ compiler in libzang_hip.so
+        compiled = native.NativeScript(text, a.file)
+    except native.NativeScriptError as e:
         sys.stderr.write(str(e) + "\n\n")
         return 1
     if a.dump_builtins:
         open(a.dump_builtins, "w").write(dump_builtins(zs.DEFAULT_PACKAGES))
-    if a.dump_codegen:
-        open(a.dump_codegen, "w").write(dump_codegen(script))
+    if a.dump_codegen:                                          # the instruction lists, from the Python front-end
+        open(a.dump_codegen, "w").write(dump_codegen(zs.compile(text, a.file)))
     if a.check:
         return 0
     if not a.output:
         ap.error("-o <dest> is required unless --check is given")
     if a.backend == "zig":
-        open(a.output, "w").write(zs.generate_zig(script))
+        open(a.output, "w").write(compiled.generate_zig())
         return 0
-    text, meta = zs.generate_hip(script)
-    open(a.output, "w").write(text)
+    hip, meta = compiled.generate_hip()
+    open(a.output, "w").write(hip)
     for name, m in meta.items():
         if "error" in m:
             sys.stderr.write("%s: module %s: %s\n" % (a.file, name, m["error"]))

@@ -1,0 +1,78 @@
+"""The C++ zangscript compiler inside libzang_hip.so (csrc/zscript_front.hip, zscript_emit.hip) through its C ABI
+(zh_zscript_*).  Same results as the Python front-end in this package; the product path (zang_amd.script,
+zang_amd.zangc) uses this one, the Python one is the independent second implementation the tests hold it against."""
+import ctypes as C
+
+from .. import abi
+from .builtins import DEFAULT_PACKAGES, modules_builtin_package, zang_builtin_package
+from .errors import ScriptError
+
+
+class NativeScriptError(Exception):
+    """A compile error with the reference's rendering (file:line:col: message, source line, carets)."""
+
+
+def _package_bits(packages):
+    bits = 0
+    for p in packages:
+        if p is zang_builtin_package:
+            bits |= 1
+        elif p is modules_builtin_package:
+            bits |= 2
+        else:
+            raise ValueError("the native compiler knows the two builtin packages only")
+    return bits
+
+
+class NativeScript:
+    def __init__(self, contents, filename="script.txt", packages=DEFAULT_PACKAGES):
+        self.lib = abi.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(1 << 14)
+        rc = self.lib.zh_zscript_compile(contents.encode(), filename.encode(), _package_bits(packages), C.byref(h), err, len(err))
+        if rc != 0:
+            raise NativeScriptError(err.value.decode(errors="replace"))
+        self.handle = h
+
+    def _text(self, fn, *args):
+        p = C.c_void_p()
+        abi.check(fn(self.handle, *args, C.byref(p)), fn.__name__)
+        try:
+            return C.string_at(p).decode()
+        finally:
+            self.lib.zh_zscript_free_text(p)
+
+    def generate_zig(self):
+        return self._text(self.lib.zh_zscript_generate_zig)
+
+    def generate_hip(self, only=None, unroll=0):
+        """-> (text, meta) with meta[name] = {"state_words", "params": [(name, kind, enum name)], "noise_fields"} or {"error"}"""
+        text = self._text(self.lib.zh_zscript_generate_hip, None if only is None else ",".join(only).encode(), int(unroll))
+        meta = {}
+        name, err = C.create_string_buffer(256), C.create_string_buffer(1024)
+        kind, en = C.create_string_buffer(64), C.create_string_buffer(64)
+        for i in range(self.lib.zh_zscript_module_count(self.handle)):
+            words, noise, npar = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            abi.check(self.lib.zh_zscript_module_info(self.handle, i, name, len(name), C.byref(words), C.byref(noise), C.byref(npar), err, len(err)),
+                      "zh_zscript_module_info")
+            if err.value:
+                meta[name.value.decode()] = {"error": err.value.decode()}
+                continue
+            params = []
+            pname = C.create_string_buffer(256)
+            for p in range(npar.value):
+                abi.check(self.lib.zh_zscript_module_param(self.handle, i, p, pname, len(pname), kind, len(kind), en, len(en)), "zh_zscript_module_param")
+                params.append((pname.value.decode(), kind.value.decode(), en.value.decode() or None))
+            meta[name.value.decode()] = {"state_words": words.value, "params": params, "noise_fields": noise.value}
+        return text, meta
+
+    def close(self):
+        if self.handle:
+            self.lib.zh_zscript_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
