@@ -79,6 +79,8 @@ ERRORS = [
     "X = defmodule\n c: curve,\nbegin\n out c\nend",
     "X = defmodule\nbegin\n out Filter(input=1, type=.low_pass, cutoff=true, res=0)\nend",
     "X = @",
+    "A = defmodule\nbegin\n out A()\nend",
+    "A = defmodule\nbegin\n out B()\nend\nB = defmodule\nbegin\n out A() * 2\nend",
 ]
 
 

@@ -508,13 +508,14 @@ public:
     std::vector<Module> &modules;
     std::vector<Track> &tracks;
     std::vector<std::pair<bool, Res>> global_results;
-    std::vector<bool> global_visited, track_done, module_done;
+    std::vector<bool> global_visited, track_done, module_done, module_visiting;
 
     explicit CodeGen(CompiledScript &c) : cs(c), src(c.source), globals(c.pr.globals), modules(c.pr.modules), tracks(c.pr.tracks) {
         global_results.resize(globals.size());
         global_visited.assign(globals.size(), false);
         track_done.assign(tracks.size(), false);
         module_done.assign(modules.size(), false);
+        module_visiting.assign(modules.size(), false);
         cs.track_results.resize(tracks.size());
         cs.module_results.resize(modules.size());
     }
@@ -735,8 +736,11 @@ public:
         track_done[ti] = true;
         for (const TrackNote &n : tracks[ti].notes) cs.track_results[ti].push_back(gen_args(nullptr, n.args_sr, tracks[ti].params, n.args));
     }
-    void gen_module(size_t mi) {                                                                 // :708-767
+    void gen_module(size_t mi, const SourceRange &sr) {                                          // :708-767
         if (module_done[mi]) return;
+        // a module that (directly or not) calls itself: the reference recurses until the stack ends
+        if (module_visiting[mi]) fail(src, sr, "circular reference in module");
+        module_visiting[mi] = true;
         CMS cms;
         cms.module_index = mi;
         cms.local_results.resize(modules[mi].locals.size());
@@ -776,7 +780,7 @@ public:
         }
         case EK::literal_curve: return mk(RK::literal_curve, e.index);
         case EK::literal_track: gen_track(e.index); return mk(RK::literal_track, e.index);
-        case EK::literal_module: if (!modules[e.index].builtin) gen_module(e.index); return mk(RK::literal_module, e.index);
+        case EK::literal_module: if (!modules[e.index].builtin) gen_module(e.index, e.sr); return mk(RK::literal_module, e.index);
         case EK::name: {
             const std::string name = src.text(e.token.sr);
             if (cms) {

@@ -125,6 +125,7 @@ class CodeGen:
         self.global_visited = [False] * len(self.globals)
         self.track_results = [None] * len(self.tracks)
         self.module_results = [None] * len(self.modules)
+        self.module_visiting = set()
 
     def fail(self, sr, msg):
         return ScriptError(self.source, sr, msg)
@@ -378,9 +379,13 @@ class CodeGen:
         track = self.tracks[track_index]
         self.track_results[track_index] = [self.gen_args(None, n.args_sr, track.params, n.args) for n in track.notes]
 
-    def gen_module(self, module_index):                          # :708-767
+    def gen_module(self, module_index, sr):                      # :708-767
         if self.module_results[module_index] is not None:
             return
+        # a module that (directly or not) calls itself: the reference recurses until the stack ends
+        if module_index in self.module_visiting:
+            raise self.fail(sr, "circular reference in module")
+        self.module_visiting.add(module_index)
         module = self.modules[module_index]
         cms = _ModuleState(module_index, module)
         for st in module.scope.statements:
@@ -422,7 +427,7 @@ class CodeGen:
             return Res("literal_track", e.value)
         if k == "literal_module":
             if self.modules[e.value].scope is not None:
-                self.gen_module(e.value)
+                self.gen_module(e.value, e.sr)
             return Res("literal_module", e.value)
         if k == "name":
             name = self.source.text(e.token.sr)
