@@ -98,3 +98,39 @@ def test_native_unsupported_module_is_reported():
     a, ma = zs.generate_hip(zs.compile(src))
     b, mb = native.NativeScript(src).generate_hip()
     assert a == b and ma == mb and "not supported by the HIP backend" in mb["P"]["error"]
+
+
+def test_differential_fuzz_python_vs_native():
+    """3,000 random mutations of the test script: the two front-ends must agree on everything -- the same
+    compile error text, or the same Zig + HIP + metadata -- and the C++ one must survive malformed input."""
+    import random
+    parts = SCRIPT.split("\n\n")
+    rng = random.Random(20241002)
+    tokens = ["(", ")", ",", "=", "*", "+", "-", "/", ".", ":", "begin", "end", "out", "feedback", "delay", "from", "defmodule", "defcurve",
+              "deftrack", "true", "false", "pi", "sin", "max", "SineOsc", "Envelope", "freq", "note_on", "0.5", "3", "x", ".cubed", ".low_pass",
+              "cob", "constant", "waveform", "\n", " "]
+    ok = 0
+    for _ in range(3000):
+        src = "\n\n".join(rng.sample(parts, rng.randint(1, 3)))
+        for _ in range(rng.randint(1, 4)):
+            k, pos = rng.random(), rng.randrange(len(src) + 1)
+            if k < 0.4:
+                src = src[:pos] + rng.choice(tokens) + src[pos:]
+            elif k < 0.7:
+                src = src[:pos] + src[pos + rng.randint(1, 12):]
+            else:
+                a = rng.randrange(len(src))
+                src = src[:pos] + src[a:min(len(src), a + rng.randint(1, 30))] + src[pos:]
+        try:
+            py = zs.compile(src)
+            r1 = ("ok", zs.generate_zig(py), zs.generate_hip(py))
+        except zs.ScriptError as e:
+            r1 = ("err", str(e))
+        try:
+            nat = native.NativeScript(src)
+            r2 = ("ok", nat.generate_zig(), nat.generate_hip())
+        except native.NativeScriptError as e:
+            r2 = ("err", str(e))
+        assert r1 == r2, src
+        ok += r1[0] == "ok"
+    assert ok > 50
