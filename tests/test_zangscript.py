@@ -90,7 +90,7 @@ def test_error_location_and_carets():
 def test_instruction_lists_and_temps():
     s = zs.compile(SCRIPT)
     names = [n for n, _ in s.exported_modules]
-    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle", "Trig"]
+    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle", "Trig", "Shapes"]
     r = s.module_results[s.module_index("Doubler")]
     assert (r.num_temps, r.num_temp_floats, [i.kind for i in r.instructions]) == (1, 0, ["cob_to_buffer", "arith_buffer_float"])
     assert r.instructions[1].out.kind == "output"           # written straight into the result location
@@ -257,10 +257,9 @@ begin
 end"""
     with pytest.raises(zs.ScriptError):                       # a track note cannot reach the module's params (global context)
         zs.compile(src)
-    src = src.replace("0.0 (c=shape)", "0.0 (c=defcurve 0 1 1 2 end)")
-    s = zs.compile(src)
+    s = zs.compile("P = defmodule\nbegin\n out delay 0 begin out feedback feedback 1 end\nend")
     _, meta = zs.generate_hip(s)
-    assert "not supported by the HIP backend" in meta["Player"]["error"]
+    assert "delay of 0 samples" in meta["P"]["error"]
 
 
 def test_hiprtc_errors_are_reported():
@@ -452,6 +451,9 @@ def test_gpu_track_calls(ctx):
     speed = np.random.default_rng(18).uniform(0.5, 3.0, V).astype(np.float32)
     q = {"sample_rate": 44100.0, "speed": speed}
     _parity(ctx, "LateJingle", [(0, 50, False, q), (50, F, False, q), (0, F, True, q), (0, F, False, q)])
+    # curve-typed track params: each note carries its own defcurve, played by a Curve module inside the sub-span
+    r = {"sample_rate": 48000.0, "freq": _freqs(23)}
+    _parity(ctx, "Shapes", [(0, 30, True, r), (30, F, False, r), (0, F, nic, r)])
 
 
 @pytest.mark.gpu

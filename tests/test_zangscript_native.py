@@ -94,10 +94,10 @@ def test_native_reports_the_same_errors(src):
 
 
 def test_native_unsupported_module_is_reported():
-    src = "P = defmodule\nbegin\n out from deftrack c: curve, begin 0.0 (c=defcurve 0 1 1 2 end) end, 1 begin out Curve(curve=c, function=.linear) end\nend"
+    src = "P = defmodule\nbegin\n out delay 0 begin out feedback feedback 1 end\nend"
     a, ma = zs.generate_hip(zs.compile(src))
     b, mb = native.NativeScript(src).generate_hip()
-    assert a == b and ma == mb and "not supported by the HIP backend" in mb["P"]["error"]
+    assert a == b and ma == mb and "delay of 0 samples" in mb["P"]["error"]
 
 
 def test_differential_fuzz_python_vs_native():

@@ -707,8 +707,12 @@ public:
                 v.kind = Val::en; v.tag = strf("%s_p%zu", tc, pi);
                 v.payload = std::make_shared<Val>();
                 v.payload->kind = Val::flt; v.payload->expr = strf("%s_q%zu", tc, pi);
+            } else if (p.type.kind == PK::curve) {
+                k.pro.push_back(strf("const zh_curve_node *%s_p%zu = nullptr; uint32_t %s_q%zu = 0u;", tc, pi, tc, pi));
+                loads.push_back(strf("%s_p%zu = zs_track%zu_p%zu[%s_note]; %s_q%zu = zs_track%zu_q%zu[%s_note];", tc, pi, ti, pi, tc, tc, pi, ti, pi, tc));
+                v.kind = Val::curve; v.expr = strf("%s_p%zu", tc, pi); v.count = strf("%s_q%zu", tc, pi);
             } else {
-                const char *kn = p.type.kind == PK::curve ? "curve" : p.type.kind == PK::buffer ? "buffer" : "constant_or_buffer";
+                const char *kn = p.type.kind == PK::buffer ? "buffer" : "constant_or_buffer";
                 throw HipBackendError{"track param `" + p.name + "`: type " + kn + " is not supported by the HIP backend"};
             }
             env[pi] = v;
@@ -788,6 +792,13 @@ public:
                 }
                 out.push_back(strf("__device__ const unsigned int zs_track%zu_p%zu[%zu] = {", ti, pi, n) + join(a, "0") + "};");
                 out.push_back(strf("__device__ const float zs_track%zu_q%zu[%zu] = {", ti, pi, n) + join(b, "0.0f") + "};");
+            } else if (p.type.kind == PK::curve) {               // a note's curve is a `defcurve` literal (global context)
+                for (size_t ni = 0; ni < track.notes.size(); ni++) {
+                    a.push_back(strf("zs_curve%zu", notes[ni][pi].index));
+                    b.push_back(std::to_string(s.pr.curves[notes[ni][pi].index].points.size()));
+                }
+                out.push_back(strf("__device__ const zh_curve_node *const zs_track%zu_p%zu[%zu] = {", ti, pi, n) + join(a, "nullptr") + "};");
+                out.push_back(strf("__device__ const unsigned int zs_track%zu_q%zu[%zu] = {", ti, pi, n) + join(b, "0") + "};");
             }
         }
         return out;

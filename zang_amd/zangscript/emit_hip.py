@@ -16,7 +16,7 @@ To keep the reference's bits the emitted code repeats its operation order litera
 Builtin modules come from csrc/voices.cuh (the same lane objects the standalone kernels use).  Script
 modules calling script modules are inlined.  `delay` keeps its ring in the per-voice state blob; a track
 call (`from ... begin`) keeps NoteTracker + Trigger per voice and walks their sub-spans.  What the backend
-cannot express raises HipBackendError (reported per module, never miscompiled)."""
+cannot express (more than 16 params, a zero-sample delay) raises HipBackendError, reported per module."""
 import os
 from dataclasses import dataclass
 
@@ -430,6 +430,10 @@ class HipEmitter:
                 k.pro.append("uint32_t %s_p%d = 0u; float %s_q%d = 0.0f;" % (t, pi, t, pi))
                 loads.append("%s_p%d = zs_track%d_p%d[%s_note]; %s_q%d = zs_track%d_q%d[%s_note];" % (t, pi, ti, pi, t, t, pi, ti, pi, t))
                 env[pi] = Val("enum", tag="%s_p%d" % (t, pi), payload=Val("float", "%s_q%d" % (t, pi)), enum=p.param_type.enum)
+            elif kind == "curve":
+                k.pro.append("const zh_curve_node *%s_p%d = nullptr; uint32_t %s_q%d = 0u;" % (t, pi, t, pi))
+                loads.append("%s_p%d = zs_track%d_p%d[%s_note]; %s_q%d = zs_track%d_q%d[%s_note];" % (t, pi, ti, pi, t, t, pi, ti, pi, t))
+                env[pi] = Val("curve", "%s_p%d" % (t, pi), count="%s_q%d" % (t, pi))
             else:
                 raise HipBackendError("track param `%s`: type %s is not supported by the HIP backend" % (p.name, kind))
         has_note_on = [i for i, p in enumerate(module.params) if p.name == "note_on"]
@@ -482,6 +486,10 @@ class HipEmitter:
                 out.append("__device__ const unsigned int zs_track%d_p%d[%d] = {%s};" % (ti, pi, n, ", ".join(str(labels.index(r.value)) for r in vals) or "0"))
                 out.append("__device__ const float zs_track%d_q%d[%d] = {%s};" % (
                     ti, pi, n, ", ".join(f32_literal(r.payload.value.value) if r.payload is not None else "0.0f" for r in vals) or "0.0f"))
+            elif kind == "curve":                                 # a note's curve is a `defcurve` literal (global context)
+                out.append("__device__ const zh_curve_node *const zs_track%d_p%d[%d] = {%s};" % (ti, pi, n, ", ".join("zs_curve%d" % r.index for r in vals) or "nullptr"))
+                out.append("__device__ const unsigned int zs_track%d_q%d[%d] = {%s};" % (
+                    ti, pi, n, ", ".join(str(len(self.s.curves[r.index].points)) for r in vals) or "0"))
         return out
 
     def module_body(self, mc):
