@@ -53,6 +53,23 @@ __global__ void __launch_bounds__(64) k_ops(float *out, unsigned iters, float a,
             if constexpr (KIND == 28) asm volatile("v_lshl_add_u32 %0, %0, 1, %8\n\tv_lshl_add_u32 %1, %1, 1, %8\n\tv_lshl_add_u32 %2, %2, 1, %8\n\tv_lshl_add_u32 %3, %3, 1, %8\n\tv_lshl_add_u32 %4, %4, 1, %8\n\tv_lshl_add_u32 %5, %5, 1, %8\n\tv_lshl_add_u32 %6, %6, 1, %8\n\tv_lshl_add_u32 %7, %7, 1, %8" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
             if constexpr (KIND == 29) asm volatile("v_and_or_b32 %0, %0, %8, %8\n\tv_and_or_b32 %1, %1, %8, %8\n\tv_and_or_b32 %2, %2, %8, %8\n\tv_and_or_b32 %3, %3, %8, %8\n\tv_and_or_b32 %4, %4, %8, %8\n\tv_and_or_b32 %5, %5, %8, %8\n\tv_and_or_b32 %6, %6, %8, %8\n\tv_and_or_b32 %7, %7, %8, %8" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
             if constexpr (KIND == 30) asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
+            if constexpr (KIND == 31) asm volatile("v_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %1, 1, %1\n\tv_lshlrev_b64 %2, 1, %2\n\tv_lshlrev_b64 %3, 1, %3\n\tv_lshlrev_b64 %4, 1, %4\n\tv_lshlrev_b64 %5, 1, %5\n\tv_lshlrev_b64 %6, 1, %6\n\tv_lshlrev_b64 %7, 1, %7" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb));
+            if constexpr (KIND == 32) asm volatile("v_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %1, 1, %1\n\tv_lshrrev_b64 %2, 1, %2\n\tv_lshrrev_b64 %3, 1, %3\n\tv_lshrrev_b64 %4, 1, %4\n\tv_lshrrev_b64 %5, 1, %5\n\tv_lshrrev_b64 %6, 1, %6\n\tv_lshrrev_b64 %7, 1, %7" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb));
+            if constexpr (KIND == 33) asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n\tv_lshl_add_u64 %1, %1, 0, %8\n\tv_lshl_add_u64 %2, %2, 0, %8\n\tv_lshl_add_u64 %3, %3, 0, %8\n\tv_lshl_add_u64 %4, %4, 0, %8\n\tv_lshl_add_u64 %5, %5, 0, %8\n\tv_lshl_add_u64 %6, %6, 0, %8\n\tv_lshl_add_u64 %7, %7, 0, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb));
+            if constexpr (KIND == 34) asm volatile("v_cmp_gt_u64 vcc, %0, %8\n\tv_cmp_gt_u64 vcc, %1, %8\n\tv_cmp_gt_u64 vcc, %2, %8\n\tv_cmp_gt_u64 vcc, %3, %8\n\tv_cmp_gt_u64 vcc, %4, %8\n\tv_cmp_gt_u64 vcc, %5, %8\n\tv_cmp_gt_u64 vcc, %6, %8\n\tv_cmp_gt_u64 vcc, %7, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb) : "vcc");
+            if constexpr (KIND == 35) asm volatile("v_alignbit_b32 %0, %0, %8, 9\n\tv_alignbit_b32 %1, %1, %8, 9\n\tv_alignbit_b32 %2, %2, %8, 9\n\tv_alignbit_b32 %3, %3, %8, 9\n\tv_alignbit_b32 %4, %4, %8, 9\n\tv_alignbit_b32 %5, %5, %8, 9\n\tv_alignbit_b32 %6, %6, %8, 9\n\tv_alignbit_b32 %7, %7, %8, 9" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
+            if constexpr (KIND == 36) asm volatile("v_ffbh_u32 %0, %0\n\tv_ffbh_u32 %1, %1\n\tv_ffbh_u32 %2, %2\n\tv_ffbh_u32 %3, %3\n\tv_ffbh_u32 %4, %4\n\tv_ffbh_u32 %5, %5\n\tv_ffbh_u32 %6, %6\n\tv_ffbh_u32 %7, %7" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
+            if constexpr (KIND == 37) asm volatile("v_min3_u32 %0, %0, %8, 64\n\tv_min3_u32 %1, %1, %8, 64\n\tv_min3_u32 %2, %2, %8, 64\n\tv_min3_u32 %3, %3, %8, 64\n\tv_min3_u32 %4, %4, %8, 64\n\tv_min3_u32 %5, %5, %8, 64\n\tv_min3_u32 %6, %6, %8, 64\n\tv_min3_u32 %7, %7, %8, 64" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
+            if constexpr (KIND == 38) asm volatile("v_add_co_u32 %0, vcc, %0, %8\n\tv_addc_co_u32 %1, vcc, %1, %8, vcc\n\tv_add_co_u32 %2, vcc, %2, %8\n\tv_addc_co_u32 %3, vcc, %3, %8, vcc\n\tv_add_co_u32 %4, vcc, %4, %8\n\tv_addc_co_u32 %5, vcc, %5, %8, vcc\n\tv_add_co_u32 %6, vcc, %6, %8\n\tv_addc_co_u32 %7, vcc, %7, %8, vcc" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b) : "vcc");
+            if constexpr (KIND == 39) asm volatile("v_add_u32_e64 %0, %0, 32 clamp\n\tv_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 32 clamp\n\tv_add_u32_e64 %3, %3, 32 clamp\n\tv_add_u32_e64 %4, %4, 32 clamp\n\tv_add_u32_e64 %5, %5, 32 clamp\n\tv_add_u32_e64 %6, %6, 32 clamp\n\tv_add_u32_e64 %7, %7, 32 clamp" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
+            if constexpr (KIND == 40) asm volatile("v_mul_lo_u32 %0, %0, %8\n\tv_mul_lo_u32 %1, %1, %8\n\tv_mul_lo_u32 %2, %2, %8\n\tv_mul_lo_u32 %3, %3, %8\n\tv_mul_lo_u32 %4, %4, %8\n\tv_mul_lo_u32 %5, %5, %8\n\tv_mul_lo_u32 %6, %6, %8\n\tv_mul_lo_u32 %7, %7, %8" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(b));
+            if constexpr (KIND == 41) asm volatile("v_mul_f64 %0, %0, %8\n\tv_mul_f64 %1, %1, %8\n\tv_mul_f64 %2, %2, %8\n\tv_mul_f64 %3, %3, %8\n\tv_mul_f64 %4, %4, %8\n\tv_mul_f64 %5, %5, %8\n\tv_mul_f64 %6, %6, %8\n\tv_mul_f64 %7, %7, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb));
+            if constexpr (KIND == 42) asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 43) asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 44) asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 45) asm volatile("v_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0" : "+v"(p[0]) : "v"(bb));
+            if constexpr (KIND == 46) asm volatile("v_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 47) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(x[0]), "+v"(x[1]) : "v"(b));
         }
     }
     float s = 0;
@@ -85,7 +102,7 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     run<0>(d, "(warm-up)", 8, 8, e0, e1);
-    for (int w : {1, 8}) {
+    for (int w : {1, 2, 4, 8}) {
         run<0>(d, "v_add_f32 e32", 8, w, e0, e1);
         run<1>(d, "v_mul_f32 e32", 8, w, e0, e1);
         run<2>(d, "v_sub_f32 e32", 8, w, e0, e1);
@@ -117,6 +134,23 @@ int main() {
         run<28>(d, "v_lshl_add_u32", 8, w, e0, e1);
         run<29>(d, "v_and_or_b32", 8, w, e0, e1);
         run<30>(d, "s_nop 0 (SALU filler)", 8, w, e0, e1);
+        run<31>(d, "v_lshlrev_b64", 8, w, e0, e1);
+        run<32>(d, "v_lshrrev_b64", 8, w, e0, e1);
+        run<33>(d, "v_lshl_add_u64", 8, w, e0, e1);
+        run<34>(d, "v_cmp_gt_u64 ->vcc", 8, w, e0, e1);
+        run<35>(d, "v_alignbit_b32", 8, w, e0, e1);
+        run<36>(d, "v_ffbh_u32", 8, w, e0, e1);
+        run<37>(d, "v_min3_u32", 8, w, e0, e1);
+        run<38>(d, "v_add_co + v_addc_co pair", 8, w, e0, e1);
+        run<39>(d, "v_add_u32 e64 clamp", 8, w, e0, e1);
+        run<40>(d, "v_mul_lo_u32", 8, w, e0, e1);
+        run<41>(d, "v_mul_f64", 8, w, e0, e1);
+        run<42>(d, "dependent v_add_f32 chain", 8, w, e0, e1);
+        run<43>(d, "dependent v_xor_b32 chain", 8, w, e0, e1);
+        run<44>(d, "dependent v_fma_f32 chain", 8, w, e0, e1);
+        run<45>(d, "dependent v_lshlrev_b64 chain", 8, w, e0, e1);
+        run<46>(d, "dependent v_alignbit chain", 8, w, e0, e1);
+        run<47>(d, "2 interleaved dep add chains", 8, w, e0, e1);
     }
     return 0;
 }

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
     NiceLaneT<W> n;
     nice_load<W>(n, a, v);
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0, W>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const F (&)[1], F &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0, W>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const F (&)[1], F &val) ZH_INLINE_LAMBDA {
         val = n.frame();
         return zmask<typename LaneT<W>::M>(true);
     });
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
     pm_load(n, a, v);
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         val = n.frame();
         return true;
     });
@@ -347,7 +347,7 @@ __device__ __forceinline__ void span_walk(Lane &n, const SpanTableP &tb, uint32_
         for (int off = 32; off > 0; off >>= 1) ev = min(ev, (uint32_t)__shfl_xor((int)ev, off));
         const uint32_t seg_end = __builtin_amdgcn_readfirstlane(ev);
         if (live) {
-            frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, i, seg_end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+            frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, i, seg_end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
                 if (!active) return false;
                 val = n.frame();
                 return true;
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter(uint64_t *__restrict
     const float res = 1.0f - zclampf(res_p.get(v), 0.0f, 1.0f);        // :118
     float l = l_io[v], b = b_io[v];
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         const float white = zrandom_float32(r) * 2.0f - 1.0f;          // Noise.zig:51 / :58
         float nz = white;
         if (PINK) nz = pink_step(pb, white);                           // :59-66
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter_bypass(uint64_t *__r
         for (int j = 0; j < 7; j++) pb[j] = bst[(size_t)j * V + v];
     }
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         const float white = zrandom_float32(r) * 2.0f - 1.0f;
         float nz = white;
         if (PINK) nz = pink_step(pb, white);

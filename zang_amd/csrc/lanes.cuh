@@ -88,6 +88,29 @@ template <int W> ZL void zstore_u(uint32_t *p, uint32_t v, typename LaneT<W>::U 
     if constexpr (W == 1) p[v] = x;
     else *reinterpret_cast<zu2 *>(p + v) = x;
 }
+// ---- image rows through buffer descriptors ---------------------------------------------------------
+// A [frame][voice] image is walked row by row with a wave-uniform row pointer.  Through a buffer
+// descriptor the whole per-frame address is scalar: the descriptor's base is the first row of the
+// current chunk (rebased with two scalar adds per chunk), the row inside the chunk is `soffset` (an
+// SGPR) and the lane's voice is one constant byte offset in a VGPR -- a load or store costs no vector
+// address arithmetic.  Offsets are 32-bit: a chunk of CH rows must span < 4 GiB (CH * stride < 2^30
+// voices; an image that wide would need > 4 TiB, no such image exists on a 288 GB device).
+#if defined(__HIP_DEVICE_COMPILE__)
+ZL zh_rsrc_t zrow_rsrc(const float *base, size_t stride, uint32_t frame) { return make_rsrc(base + (size_t)frame * stride, 0xFFFFFFFFu); }
+template <int W> ZL typename LaneT<W>::F zrow_load(zh_rsrc_t r, uint32_t voff, uint32_t soff) {
+    if constexpr (W == 1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    else return __builtin_bit_cast(zf2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+template <int W> ZL void zrow_store(zh_rsrc_t r, uint32_t voff, uint32_t soff, typename LaneT<W>::F x) {
+    if constexpr (W == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(zu2, x), r, voff, soff, 0);
+}
+#else   // host pass: kernels are only parsed, never run
+ZL zh_rsrc_t zrow_rsrc(const float *, size_t, uint32_t) { return 0; }
+template <int W> ZL typename LaneT<W>::F zrow_load(zh_rsrc_t, uint32_t, uint32_t) { return typename LaneT<W>::F{}; }
+template <int W> ZL void zrow_store(zh_rsrc_t, uint32_t, uint32_t, typename LaneT<W>::F) {}
+#endif
+
 template <int W> ZL typename LaneT<W>::F zget_f32p(const F32P &p, uint32_t v) {
     if constexpr (W == 1) return p.get(v);
     else return p.pv ? *reinterpret_cast<const zf2 *>(p.pv + v) : zf2{p.value, p.value};

@@ -35,11 +35,11 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
     constexpr int NIN = (FB ? 1 : 0) + (PB ? 1 : 0);
     const float *ins[2] = {nullptr, nullptr};
     size_t istr[2] = {0, 0};
-    if (FB) { ins[0] = freq.b.p + v; istr[0] = freq.b.stride; }
-    if (PB) { ins[FB ? 1 : 0] = phase.b.p + v; istr[FB ? 1 : 0] = phase.b.stride; }
+    if (FB) { ins[0] = freq.b.p; istr[0] = freq.b.stride; }
+    if (PB) { ins[FB ? 1 : 0] = phase.b.p; istr[FB ? 1 : 0] = phase.b.stride; }
     o.begin(sample_rate, FB ? 0.0f : freq.c.get(v));
     const float phase_c = PB ? 0.0f : phase.c.get(v);
-    frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end,
+    frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, start, end,
                            [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
         val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
         return true;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, 
         for (int j = 0; j < 7; j++) o.b[j] = bst[(size_t)j * V + v];  // `var b = self.b` (Noise.zig:55); always 0, see :68
     }
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         val = o.template frame<PINK>();
         return true;
     });
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_envelope(uint32_t *__restrict__ s
     env_load(e, p, v);
     e.begin(nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end,
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end,
                          [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA { return e.frame(val); });
     st[v] = e.state; t[v] = e.t; lastv[v] = e.last_value; startv[v] = e.start;
 }
@@ -131,15 +131,15 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
     constexpr int NIN = 1 + (CB ? 1 : 0) + (RB ? 1 : 0);
-    const float *ins[3] = {input.p + v, nullptr, nullptr};
+    const float *ins[3] = {input.p, nullptr, nullptr};
     size_t istr[3] = {input.stride, 0, 0};
-    if (CB) { ins[1] = cutoff.b.p + v; istr[1] = cutoff.b.stride; }
-    if (RB) { ins[CB ? 2 : 1] = res_p.b.p + v; istr[CB ? 2 : 1] = res_p.b.stride; }
+    if (CB) { ins[1] = cutoff.b.p; istr[1] = cutoff.b.stride; }
+    if (RB) { ins[CB ? 2 : 1] = res_p.b.p; istr[CB ? 2 : 1] = res_p.b.stride; }
     FilterLane o;
     o.l = l_io[v]; o.b = b_io[v];
     o.begin(ZH_FILTER_LOW_PASS, CB ? 0.0f : cutoff.c.get(v), RB ? 0.0f : res_p.c.get(v));
     o.l_mul = l_mul; o.b_mul = b_mul; o.h_mul = h_mul;               // the host resolved the type (:98-109)
-    frame_loop<8, ZF, NIN>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[NIN], float &val) ZH_INLINE_LAMBDA {
         val = o.template frame<CB, RB>(x[0], CB ? x[1] : 0.0f, RB ? x[CB ? 2 : 1] : 0.0f);
         return true;
     });
@@ -215,13 +215,13 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io,
     }
     if (ratio > 0.9999f && ratio < 1.0001f) {                         // :105-114 no resampling
         const int32_t t0 = zf32_to_i32(roundf(t));
-        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             val = sampler_get_sample(s, (int32_t)((uint32_t)t0 + (i - start)));
             return true;
         });
         t += (float)len;
     } else {                                                          // :116-130 linear resampling
-        frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             const int32_t t0 = zf32_to_i32(floorf(t));
             const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
             const float tfrac = (float)t1 - t;                        // :121
@@ -249,9 +249,9 @@ __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dva
     DecimatorLane o;
     o.dval = dval_io[v]; o.dcount = dcount_io[v];
     o.begin(sample_rate, fake_p.get(v));
-    const float *ins[1] = {input.p + v};
+    const float *ins[1] = {input.p};
     const size_t istr[1] = {input.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end,
+    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, start, end,
                          [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(x[0], val); });
     o.end();
     dval_io[v] = o.dval; dcount_io[v] = o.dcount;
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_curve(float *__restrict__ t_io, u
     o.t = t_io[v]; o.cur = cur_io[v]; o.next = next_io[v]; o.off = off_io[v];
     o.begin(sample_rate, function, curve, n_curve, end - start, nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end,
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end,
                          [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(i - start, val); });
     t_io[v] = o.t; cur_io[v] = o.cur; off_io[v] = o.off; next_io[v] = o.next;
 }
@@ -308,9 +308,9 @@ __global__ void __launch_bounds__(kSeqBlock) k_cycle(float *__restrict__ t_io, u
     CycleLane o;
     o.t = t_io[v];
     o.begin(sample_rate, SB ? 0.0f : speed.c.get(v));
-    const float *ins[1] = {SB ? speed.b.p + v : nullptr};
+    const float *ins[1] = {SB ? speed.b.p : nullptr};
     const size_t istr[1] = {speed.b.stride};
-    frame_loop<8, ZF, SB ? 1 : 0>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, SB ? 1 : 0>(out.p, v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
         val = o.template frame<SB>(x[0]);
         return true;
     });
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_portamento(float *__restrict__ t_
     o.t = t_io[v]; o.last = last_io[v]; o.st = start_io[v];
     o.begin(sample_rate, curve_tag, duration.get(v), goal_p.get(v), note_on.get(v), prev_note_on.get(v), nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p + v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
         val = o.frame();
         return true;
     });

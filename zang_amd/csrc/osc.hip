@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restric
     o.cnt = cnt_io[v];
     o.srf = srf; o.sr8 = sr8;                                         // host-computed (same IEEE divides)
     pulse_setup_color(o.k, color_p.get(v));
-    const float *ins[1] = {freq_b.p + v};
+    const float *ins[1] = {freq_b.p};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end,
+    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, start, end,
                          [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame_ctrl(x[0], val); });
     cnt_io[v] = o.cnt;
 }
@@ -225,9 +225,9 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict_
     TriSawOscLane o;
     o.t = t_io[v];
     o.begin_ctrl(sample_rate, color_p.get(v));
-    const float *ins[1] = {freq_b.p + v};
+    const float *ins[1] = {freq_b.p};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p + v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
         val = o.frame_ctrl(x[0]);
         return true;
     });

@@ -13,37 +13,54 @@
 // f(frame, x[NIN], value&) -> painted.  Called for consecutive frames in order; it may
 // carry state by reference capture.  painted == false leaves out[frame] untouched (ADD) or
 // zero (ZERO_FIRST), like a reference loop that `continue`s or stops early.
-// W = voices per lane (lanes.cuh): with W = 2, `out` / `in` point at the lane's first voice (even,
-// 8-byte aligned), values are zf2 and `painted` is a per-voice mask.
+// `out` / `in` are the images' (wave-uniform) base pointers and `v` the lane's voice: every access is
+// row[v] with a uniform row pointer, so the row address lives in SGPRs (scalar adds per frame) and the
+// lane offset is one constant VGPR -- no per-frame 64-bit vector address arithmetic.
+// W = voices per lane (lanes.cuh): with W = 2, `v` is the lane's first voice (even, 8-byte aligned),
+// values are zf2 and `painted` is a per-voice mask.
 template <int CH, bool ZF, int NIN, int W = 1, class F>
-__device__ __forceinline__ void frame_loop(float *__restrict__ out, size_t ostride,
+__device__ __forceinline__ void frame_loop(float *__restrict__ out, uint32_t v, size_t ostride,
                                            const float *const *in, const size_t *istride,
                                            uint32_t start, uint32_t end, F &&f) {
     using T = typename LaneT<W>::F;
     constexpr int NI = NIN > 0 ? NIN : 1;
     const uint32_t n = end - start;
     const uint32_t nfull = n / CH;
+    const uint32_t voff = v * 4u;                                   // the lane's byte offset inside a row
+    const uint32_t orow = (uint32_t)ostride * 4u;                   // bytes per row (lanes.cuh: < 4 GiB / CH)
+    uint32_t irow[NI];
+#pragma unroll
+    for (int j = 0; j < NIN; j++) irow[j] = (uint32_t)istride[j] * 4u;
     T oc[CH], xc[NI][CH];
     uint32_t i = start;
     if (nfull > 0) {
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            if (!ZF) oc[k] = zload_f<W>(out + (size_t)(i + k) * ostride, 0);
+        for (int k = 0; k < CH; k++)
+            if (!ZF) oc[k] = zrow_load<W>(ro, voff, k * orow);
 #pragma unroll
-            for (int j = 0; j < NIN; j++) xc[j][k] = zload_f<W>(in[j] + (size_t)(i + k) * istride[j], 0);
+        for (int j = 0; j < NIN; j++) {
+            const zh_rsrc_t ri = zrow_rsrc(in[j], istride[j], i);
+#pragma unroll
+            for (int k = 0; k < CH; k++) xc[j][k] = zrow_load<W>(ri, voff, k * irow[j]);
         }
     }
     for (uint32_t c = 0; c < nfull; c++, i += CH) {
         T on[CH], xn[NI][CH];
         const bool more = c + 1 < nfull;
         if (more) {
+            const zh_rsrc_t rn = zrow_rsrc(out, ostride, i + CH);
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                if (!ZF) on[k] = zload_f<W>(out + (size_t)(i + CH + k) * ostride, 0);
+            for (int k = 0; k < CH; k++)
+                if (!ZF) on[k] = zrow_load<W>(rn, voff, k * orow);
 #pragma unroll
-                for (int j = 0; j < NIN; j++) xn[j][k] = zload_f<W>(in[j] + (size_t)(i + CH + k) * istride[j], 0);
+            for (int j = 0; j < NIN; j++) {
+                const zh_rsrc_t ri = zrow_rsrc(in[j], istride[j], i + CH);
+#pragma unroll
+                for (int k = 0; k < CH; k++) xn[j][k] = zrow_load<W>(ri, voff, k * irow[j]);
             }
         }
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             T x[NI];
@@ -53,7 +70,7 @@ __device__ __forceinline__ void frame_loop(float *__restrict__ out, size_t ostri
             const auto painted = f(i + k, x, val);
             T o = ZF ? zsplat<T>(0.0f) : oc[k];
             o = zsel(painted, o + val, o);
-            if (ZF || zany(painted)) zstore_f<W>(out + (size_t)(i + k) * ostride, 0, o);
+            if (ZF || zany(painted)) zrow_store<W>(ro, voff, k * orow, o);
         }
         if (more) {
 #pragma unroll
@@ -67,12 +84,13 @@ __device__ __forceinline__ void frame_loop(float *__restrict__ out, size_t ostri
     for (; i < end; i++) {
         T x[NI];
 #pragma unroll
-        for (int j = 0; j < NIN; j++) x[j] = zload_f<W>(in[j] + (size_t)i * istride[j], 0);
+        for (int j = 0; j < NIN; j++) x[j] = zrow_load<W>(zrow_rsrc(in[j], istride[j], i), voff, 0);
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
         T val = zsplat<T>(0.0f);
         const auto painted = f(i, x, val);
-        T o = ZF ? zsplat<T>(0.0f) : zload_f<W>(out + (size_t)i * ostride, 0);
+        T o = ZF ? zsplat<T>(0.0f) : zrow_load<W>(ro, voff, 0);
         o = zsel(painted, o + val, o);
-        if (ZF || zany(painted)) zstore_f<W>(out + (size_t)i * ostride, 0, o);
+        if (ZF || zany(painted)) zrow_store<W>(ro, voff, 0, o);
     }
 }
 

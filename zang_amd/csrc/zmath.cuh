@@ -437,12 +437,19 @@ ZD uint64_t zxoshiro_next(ZXoshiro &r) {
     return result;
 }
 ZD float zrandom_float32(ZXoshiro &r) {
-    uint64_t rnd = zxoshiro_next(r);
-    uint32_t lz = rnd ? (uint32_t)__clzll((long long)rnd) : 64u;
-    if (lz >= 41) {                       // probability 2^-41 per sample
-        uint64_t r2 = zxoshiro_next(r);
-        lz = 41 + (r2 ? (uint32_t)__clzll((long long)r2) : 64u);
-        if (lz == 41 + 64) lz += (uint32_t)__clz((int)((uint32_t)zxoshiro_next(r) | 0x7FFu));
+    const uint64_t rnd = zxoshiro_next(r);
+    const uint32_t hi = (uint32_t)(rnd >> 32);
+    uint32_t lz;
+    asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(hi));                   // the whole answer whenever hi != 0 (any value when hi == 0)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hi == 0u) != 0, 0)) {   // wave-uniform test: one compare + one scalar branch
+        if (hi == 0u) {                                              // probability 2^-32 per sample: the general form
+            lz = rnd ? (uint32_t)__clzll((long long)rnd) : 64u;
+            if (lz >= 41) {                                          // probability 2^-41 per sample
+                uint64_t r2 = zxoshiro_next(r);
+                lz = 41 + (r2 ? (uint32_t)__clzll((long long)r2) : 64u);
+                if (lz == 41 + 64) lz += (uint32_t)__clz((int)((uint32_t)zxoshiro_next(r) | 0x7FFu));
+            }
+        }
     }
     return zu2f(((126u - lz) << 23) | ((uint32_t)rnd & 0x7FFFFFu));
 }
