@@ -82,6 +82,11 @@ pub const FilterParams = extern struct { input: Buf, type: u32, reserved: u32 = 
 pub extern fn zh_filter_create(ctx: *Ctx, n_voices: u32, out: *?*FilterHandle) c_int;
 pub extern fn zh_filter_destroy(m: *FilterHandle) c_int;
 pub extern fn zh_filter_paint(m: *FilterHandle, start: u32, end: u32, outputs: [*]const Buf, temps: ?[*]const Buf, note_id_changed: Bool, params: *const FilterParams, flags: u32) c_int;
+pub extern fn zh_filter_cutoff_from_frequency(ctx: *Ctx, n: u32, cutoff_out_dev: [*]f32, frequency_dev: [*]const f32, sample_rate: f32) c_int;
+// std.math.sin / cos / pow (f32) elementwise on device arrays, same bits as the modules
+pub extern fn zh_sin(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32) c_int;
+pub extern fn zh_cos(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32) c_int;
+pub extern fn zh_pow(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32, y: [*]const f32) c_int;
 
 // Envelope (src/modules/Envelope.zig)
 pub const EnvelopeHandle = opaque {};

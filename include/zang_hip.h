@@ -241,6 +241,11 @@ ZH_API int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutof
  * Host callers of the paint path compute scalars with it: note frequencies a4 * pow(2, semitones/12)
  * (examples/common/songparse1.zig:61-62), Distortion's gain1 (Distortion.zig:41). */
 ZH_API int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y);
+/* std.math.sin / std.math.cos (f32), elementwise on the device for any float (inf and nan included): the
+ * functions SineOsc (SineOsc.zig:4-6), PMOscInstrument and Filter.cutoffFromFrequency (Filter.zig:21) are
+ * built on, exposed so that a host can compute its scalars with the same bits (out, x: device float[n]). */
+ZH_API int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x);
+ZH_API int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x);
 
 /* ---------------------------------------------------------------- Sampler (src/modules/Sampler.zig) */
 typedef struct zh_sampler zh_sampler;

@@ -1,0 +1,50 @@
+"""GPU parity: the device's std.math.sin / cos (zh_sin, zh_cos) against the oracle's musl restatement, bit for bit.
+
+The device folds musl's magnitude ladder into straight-line code (csrc/zmath.cuh); this sweeps every leaf of
+that ladder, both signs: the ladder's thresholds +- a few ulps, |x| < 2^-12, [-9pi/4, 9pi/4], the two-constant
+medium range, the 2^28*pi/2 boundary, huge arguments, denormals, zeros, infinities and NaNs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THRESHOLDS = [0x39800000, 0x3f490fda, 0x4016cbe3, 0x407b53d1, 0x40afeddf, 0x40e231d5, 0x4dc90fdb, 0x7f800000]
+
+
+def _inputs():
+    rng = np.random.default_rng(20260102)
+    near = np.array([t + d for t in THRESHOLDS for d in range(-4, 5)], np.uint32)
+    bits = [near, near | np.uint32(0x80000000),
+            rng.integers(0, 1 << 32, 2_000_000, dtype=np.uint64).astype(np.uint32),            # every exponent, both signs
+            np.array([0, 0x80000000, 1, 0x80000001, 0x007fffff, 0x00800000, 0x7f7fffff, 0xff7fffff,
+                      0x7f800000, 0xff800000, 0x7fc00000, 0xffc00000, 0x7f800001], np.uint32)]
+    xs = [b.view(np.float32) for b in bits]
+    xs.append(rng.uniform(-7.1, 7.1, 1_000_000).astype(np.float32))                             # the ladder
+    xs.append(rng.uniform(-900.0, 900.0, 1_000_000).astype(np.float32))                         # oscillator phases * 2pi
+    xs.append((rng.uniform(-1, 1, 200_000) * 2.0 ** rng.integers(3, 29, 200_000)).astype(np.float32))   # medium
+    xs.append((np.arange(1, 200_001, dtype=np.float64) * (np.pi / 2)).astype(np.float32))       # next to multiples of pi/2
+    xs.append((np.arange(1, 200_001, dtype=np.float64) * (np.pi / 4)).astype(np.float32))       # next to the kernel boundaries
+    return np.ascontiguousarray(np.concatenate(xs))
+
+
+@pytest.mark.parametrize("name", ["sin", "cos"])
+def test_sin_cos_bitexact(ctx, oracle, name):
+    import torch
+    from zang_amd import abi
+    xs = _inputs()
+    ref = np.zeros_like(xs)
+    getattr(oracle.lib(), "zo_math_%sf_n" % name)(oracle.fptr(xs), oracle.fptr(ref), xs.size)
+    x = torch.from_numpy(xs).to(ctx.device)
+    out = torch.empty_like(x)
+    abi.check(getattr(ctx.lib, "zh_" + name)(ctx.handle, xs.size, out.data_ptr(), x.data_ptr()), "zh_" + name)
+    ctx.sync()
+    got = out.cpu().numpy()
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    bad = np.nonzero((got.view(np.uint32) != ref.view(np.uint32)) & ~nan)[0]
+    assert bad.size == 0, (name, bad.size, [(hex(int(xs[i:i + 1].view(np.uint32)[0])), float(got[i]), float(ref[i])) for i in bad[:8]])
+
+
+def test_sin_cos_rejects_null(ctx):
+    assert ctx.lib.zh_sin(ctx.handle, 4, None, None) != 0
+    assert ctx.lib.zh_cos(ctx.handle, 0, None, None) == 0

@@ -55,6 +55,25 @@ def test_sin_cos_huge_arguments_exact_reduction(oracle):
     assert math.isnan(L.zo_math_sinf(float("inf"))) and math.isnan(L.zo_math_cosf(float("nan")))
 
 
+def test_sin_reduction_rint_equals_musl_ladder():
+    """csrc/zmath.cuh replaces musl's magnitude ladder (k = how many of four thresholds |x| exceeds) by
+    rint(|x| * 2/pi) in float64.  Both are non-decreasing step functions of |x|, so they agree on all of
+    [0, 9pi/4] iff they agree at every step point and at the ends (tools/check_sin_reduction.py sweeps all
+    1.09e9 floats); a random sample rides along."""
+    T = [0x3f490fda, 0x4016cbe3, 0x407b53d1, 0x40afeddf]
+    invpio2 = np.float64(6.36619772367581382433e-01)
+    rng = np.random.default_rng(5)
+    ix = np.concatenate([np.array([0, 1, 0x00800000, 0x40e231d5], np.uint32),
+                         np.array([t + d for t in T for d in range(-3, 4)], np.uint32),
+                         rng.integers(0, 0x40e231d6, 1 << 20, dtype=np.uint64).astype(np.uint32)])
+    k = np.rint(ix.view(np.float32).astype(np.float64) * invpio2).astype(np.int64)
+    assert np.array_equal(k, sum((ix > t).astype(np.int64) for t in T))
+    # and the 1.5*2^52 trick of the medium leaf IS rint: |x * invpio2| < 2^28 there
+    v = rng.uniform(-2.0 ** 28, 2.0 ** 28, 1 << 20) * invpio2
+    toint = np.float64(1.5) / np.float64(2.220446049250313e-16)
+    assert np.array_equal(v + toint - toint, np.rint(v))
+
+
 def test_atan_pow_exp_log(oracle):
     L = oracle.lib()
     rng = np.random.default_rng(1)

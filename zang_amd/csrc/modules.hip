@@ -156,6 +156,12 @@ __global__ void k_pow(uint32_t n, float *__restrict__ out, const float *__restri
     if (i < n) out[i] = zpowf_pos(x[i], y[i]);
 }
 
+template <bool COS>
+__global__ void k_sincos(uint32_t n, float *__restrict__ out, const float *__restrict__ x) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = COS ? zcosf(x[i]) : zsinf(x[i]);
+}
+
 // =================================================================== Sampler
 struct zh_sampler { zh_ctx *ctx; uint32_t n; float *t; };
 
@@ -651,6 +657,19 @@ int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y) 
     if (!ctx || (n && (!out || !x || !y))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_pow, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x, y);
+    return zh_launch_status();
+}
+
+int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
+    if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
+    if (!n) return ZH_OK;
+    hipLaunchKernelGGL(k_sincos<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    return zh_launch_status();
+}
+int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
+    if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
+    if (!n) return ZH_OK;
+    hipLaunchKernelGGL(k_sincos<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 

@@ -23,11 +23,13 @@ __device__ const float zs_zero_row[1] = {0.0f};
 
 __device__ __forceinline__ float zs_const(const zh_script_param &p, uint32_t v) { return p.pf ? p.pf[v] : p.f; }
 __device__ __forceinline__ bool zs_bool(const zh_script_param &p, uint32_t v) { return p.pb ? p.pb[v] != 0 : p.u != 0; }
-// the frame-loop input row of a waveform param, or of a cob param (a dummy row when it is a constant)
-__device__ __forceinline__ const float *zs_row(const zh_script_param &p, uint32_t v, size_t &stride) {
+// the frame-loop input image of a waveform param, or of a cob param (a one-sample dummy row when it is a
+// constant): the (wave-uniform) base pointer, the row stride and the lane's byte offset inside a row
+__device__ __forceinline__ const float *zs_row(const zh_script_param &p, uint32_t v, size_t &stride, uint32_t &voff) {
     const bool img = p.kind == ZH_SP_BUFFER || p.is_buffer;
     stride = img ? p.stride : 0;
-    return img ? p.pf + v : zs_zero_row;
+    voff = img ? v * 4u : 0u;
+    return img ? p.pf : zs_zero_row;
 }
 __device__ __forceinline__ float zs_ld_f(const uint32_t *st, uint32_t word, uint32_t V, uint32_t v) { return zu2f(st[(size_t)word * V + v]); }
 __device__ __forceinline__ uint32_t zs_ld_u(const uint32_t *st, uint32_t word, uint32_t V, uint32_t v) { return st[(size_t)word * V + v]; }
@@ -48,18 +50,24 @@ __device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b
 // frame_loop (seq.cuh) for a body that accumulates into the output sample itself: a script module's
 // paint() may `+=` its output several times per frame.  f(frame, x[NIN], o&); `zf` = ZH_PAINT_ZERO_FIRST.
 template <int CH, int NIN, class F>
-__device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, size_t ostride, const float *const *in,
-                                              const size_t *istride, uint32_t start, uint32_t end, bool zf, F &&f) {
+__device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t v, size_t ostride, const float *const *in,
+                                              const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, F &&f) {
     constexpr int NI = NIN > 0 ? NIN : 1;
     const uint32_t nfull = (end - start) / CH;
+    const uint32_t voff = v * 4u;                                   // rows through buffer descriptors: lanes.cuh (zrow_*)
+    const uint32_t orow = (uint32_t)ostride * 4u;
     float oc[CH], xc[NI][CH];
     uint32_t i = start;
     auto load = [&](uint32_t base, float (&o)[CH], float (&x)[NI][CH]) ZH_INLINE_LAMBDA {
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, base);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            o[k] = zf ? 0.0f : out[(size_t)(base + k) * ostride];
+        for (int k = 0; k < CH; k++) o[k] = zf ? 0.0f : zrow_load<1>(ro, voff, k * orow);
 #pragma unroll
-            for (int j = 0; j < NIN; j++) x[j][k] = in[j][(size_t)(base + k) * istride[j]];
+        for (int j = 0; j < NIN; j++) {
+            const zh_rsrc_t ri = zrow_rsrc(in[j], istride[j], base);
+            const uint32_t irow = (uint32_t)istride[j] * 4u;
+#pragma unroll
+            for (int k = 0; k < CH; k++) x[j][k] = zrow_load<1>(ri, ivoff[j], k * irow);
         }
     };
     if (nfull > 0) load(i, oc, xc);
@@ -67,6 +75,7 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, size_t os
         float on[CH], xn[NI][CH];
         const bool more = c + 1 < nfull;
         if (more) load(i + CH, on, xn);
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             float x[NI];
@@ -74,7 +83,7 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, size_t os
             for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
             float o = oc[k];
             f(i + k, x, o);
-            out[(size_t)(i + k) * ostride] = o;
+            zrow_store<1>(ro, voff, k * orow, o);
         }
         if (more) {
 #pragma unroll
@@ -88,10 +97,11 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, size_t os
     for (; i < end; i++) {
         float x[NI];
 #pragma unroll
-        for (int j = 0; j < NIN; j++) x[j] = in[j][(size_t)i * istride[j]];
-        float o = zf ? 0.0f : out[(size_t)i * ostride];
+        for (int j = 0; j < NIN; j++) x[j] = zrow_load<1>(zrow_rsrc(in[j], istride[j], i), ivoff[j], 0);
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        float o = zf ? 0.0f : zrow_load<1>(ro, voff, 0);
         f(i, x, o);
-        out[(size_t)i * ostride] = o;
+        zrow_store<1>(ro, voff, 0, o);
     }
 }
 #endif

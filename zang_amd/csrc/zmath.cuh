@@ -43,24 +43,6 @@ ZD float zmaxf(float a, float b) { return (a >= b || b != b) ? a : b; }
 ZD float zclampf(float v, float lo, float hi) { return zmaxf(lo, zminf(v, hi)); }
 
 // ---- sin / cos ----------------------------------------------------------------------
-ZD float zsindf(double x) {
-    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59,
-                 S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
-    double z = x * x;
-    double w = z * z;
-    double r = S3 + z * S4;
-    double s = z * x;
-    return (float)((x + s * (S1 + z * S2)) + s * w * r);
-}
-ZD float zcosdf(double x) {
-    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57,
-                 C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
-    double z = x * x;
-    double w = z * z;
-    double r = C2 + z * C3;
-    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
-}
-
 // 24-bit chunks of 2/pi and pi/2 (tools/gen_pio2_tables.py).  Only reached for
 // |x| >= 2^28*pi/2; f32 exponents need the first dozen entries at most, the rest serve the
 // recomputation loop.
@@ -190,44 +172,68 @@ ZD int zrem_pio2f(float x, double *y) {
 
 // musl sinf / cosf (what Zig's std.math.sin / cos are ported from): reduce x to y in [-pi/4, pi/4] with
 // x = y + n*pi/2 (in double), then one of two polynomial kernels picked by n & 3.  musl spells the
-// reduction out as five magnitude ranges times two signs for |x| <= 9pi/4 and a general routine above.
-// A wave's lanes sit in all of those leaves at once (oscillator phases are spread), so here the
-// leaves are folded: k from four compares, d = |x| - k*pi/2 (the same double operation as every
-// leaf's `x -+ k*pio2`, up to an exact sign), (n, y) = (+-k, +-d); larger |x| go through the general
-// reduction; then ONE evaluation of each kernel and selects.  Same operations per lane => same bits
-// (the kernels are odd / even, so moving a negation across them is exact).
-ZD int zreduce_pio2f(float x, uint32_t ix, bool sign, double &y) {
-    const double pio2 = 1.57079632679489661923;
-    if (ix <= 0x40e231d5) {                                   // |x| <= 9pi/4
-        const uint32_t k = (ix > 0x3f490fda) + (ix > 0x4016cbe3) + (ix > 0x407b53d1) + (ix > 0x40afeddf);
-        const double d = fabs((double)x) - (double)k * pio2;  // k*pio2: exact for 1, 2, 4; 3*pio2 rounds once like musl's s3pio2
-        y = sign ? -d : d;
-        return sign ? -(int)k : (int)k;
+// reduction out as five magnitude ranges times two signs for |x| <= 9pi/4, a two-constant form up to
+// 2^28*pi/2 and a general routine above.  A wave's lanes sit in all of those leaves at once (oscillator
+// phases are spread), so the leaves are folded into straight-line code that performs, per lane, exactly
+// the operations of that lane's leaf:
+//   fn = rint(x * 2/pi).  The medium leaf computes it as x*invpio2 + 1.5*2^52 - 1.5*2^52, which IS
+//        round-to-nearest-even for |x*invpio2| < 2^51; below 9pi/4 it equals +-k of musl's magnitude
+//        ladder for every one of the 1.09e9 floats in range (tools/check_sin_reduction.py; tests/test_oracle_math.py).
+//   small leaf  y = x - fn*pio2            (musl: x -+ k*M_PI_2, one rounding; k*pio2 is exact for
+//                                           1, 2, 4 and rounds once for 3 like musl's s3pio2)
+//   medium leaf y = x - fn*pio2_1 - fn*pio2_1t
+// and a select on |x| <= 9pi/4.  The medium leaf's two correction branches and the large-argument
+// routine sit behind one wave-uniform test and run the complete reference routine for the lanes that
+// need it.  Then ONE evaluation of each kernel on y (z = y*y and w = z*z shared) and selects: the
+// kernels are exactly odd / even in floating point, so sindf(-y) = -sindf(y) and every negation is a
+// sign-bit flip of the result.
+ZD int zreduce_pio2f(float x, uint32_t ix, double &y) {
+    const double invpio2 = 6.36619772367581382433e-01, pio2 = 1.57079632679489661923,
+                 pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08, pio4 = 0x1.921fb6p-1;
+    const double xd = (double)x;
+    const double fn = __builtin_rint(xd * invpio2);
+    const double ys = xd - fn * pio2;
+    const double ym = xd - fn * pio2_1 - fn * pio2_1t;
+    const bool small = ix <= 0x40e231d5;                              // |x| <= 9pi/4
+    int n = (int)fn;
+    y = small ? ys : ym;
+    // finite |x| >= 2^28*pi/2, or a medium y that landed outside [-pi/4, pi/4] ("matters with directed rounding")
+    const bool rare = !small && (ym < -pio4 || ym > pio4 || (ix - 0x4dc90fdbu) < (0x7f800000u - 0x4dc90fdbu));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+        if (rare) n = zrem_pio2f(x, &y);
     }
-    return zrem_pio2f(x, &y);
+    return n;
 }
 
 ZD float zsinf(float x) {
+    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
+    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57, C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
     const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
-    if (ix >= 0x7f800000) return x - x;
     double y;
-    const int n = zreduce_pio2f(x, ix, (ux >> 31) != 0, y);
-    // n & 3: 0 sindf(y) | 1 cosdf(y) | 2 sindf(-y) | 3 -cosdf(y)
-    const float sv = zsindf((n & 2) ? -y : y), cv = zcosdf(y);
-    float r = (n & 1) ? ((n & 2) ? -cv : cv) : sv;
+    const int n = zreduce_pio2f(x, ix, y);
+    const double z = y * y, w = z * z, s = z * y;
+    const float sv = (float)((y + s * (S1 + z * S2)) + s * w * (S3 + z * S4));          // __sindf(y)
+    const float cv = (float)(((1.0 + z * C0) + w * C1) + (w * z) * (C2 + z * C3));      // __cosdf(y)
+    // n & 3: 0 sindf(y) | 1 cosdf(y) | 2 sindf(-y) = -sindf(y) | 3 -cosdf(y)
+    float r = zu2f(zf2u((n & 1) ? cv : sv) ^ ((uint32_t)(n & 2) << 30));
     if (ix < 0x39800000) r = x;                               // |x| < 2^-12
+    if (ix >= 0x7f800000) r = x - x;                          // inf, nan
     return r;
 }
 
 ZD float zcosf(float x) {
+    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
+    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57, C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
     const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
-    if (ix >= 0x7f800000) return x - x;
     double y;
-    const int n = zreduce_pio2f(x, ix, (ux >> 31) != 0, y);
-    // n & 3: 0 cosdf(y) | 1 sindf(-y) | 2 -cosdf(y) | 3 sindf(y)
-    const float sv = zsindf((n & 2) ? y : -y), cv = zcosdf(y);
-    float r = (n & 1) ? sv : ((n & 2) ? -cv : cv);
+    const int n = zreduce_pio2f(x, ix, y);
+    const double z = y * y, w = z * z, s = z * y;
+    const float sv = (float)((y + s * (S1 + z * S2)) + s * w * (S3 + z * S4));
+    const float cv = (float)(((1.0 + z * C0) + w * C1) + (w * z) * (C2 + z * C3));
+    // n & 3: 0 cosdf(y) | 1 sindf(-y) = -sindf(y) | 2 -cosdf(y) | 3 sindf(y)
+    float r = zu2f(zf2u((n & 1) ? sv : cv) ^ ((uint32_t)((n + 1) & 2) << 30));
     if (ix < 0x39800000) r = 1.0f;
+    if (ix >= 0x7f800000) r = x - x;
     return r;
 }
 

@@ -926,9 +926,10 @@ public:
             for (size_t j = 0; j < ni; j++) { nulls += j ? ", nullptr" : "nullptr"; zeros += j ? ", 0" : "0"; }
             out.push_back(I + strf("const float *ins[%zu] = {", ni) + nulls + "};");
             out.push_back(I + strf("size_t istr[%zu] = {", ni) + zeros + "};");
-            for (size_t j = 0; j < k.rows.size(); j++) out.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu]);", j, k.rows[j], j));
+            out.push_back(I + strf("uint32_t ivo[%zu] = {", ni) + zeros + "};");
+            for (size_t j = 0; j < k.rows.size(); j++) out.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu], ivo[%zu]);", j, k.rows[j], j, j));
             append(out, indent(k.pro));
-            out.push_back(I + strf("zs_frame_loop<%d, %zu>(L.out + v, L.ostride, ins, istr, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0,", unroll, nin));
+            out.push_back(I + strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0,", unroll, nin));
             out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
             out.push_back(I + I + "(void)i; (void)x;");
             if (!k.temps.empty()) {

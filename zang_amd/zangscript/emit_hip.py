@@ -572,11 +572,12 @@ class HipEmitter:
                     I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;", I + "const uint32_t V = L.V;", I + "if (v >= V) return;",
                     I + "const bool NIC = L.nic.get(v);", I + "const uint32_t SPAN_LEN = L.end - L.start;",
                     I + "(void)NIC; (void)SPAN_LEN;",
-                    I + "const float *ins[%d] = {%s};" % (ni, ", ".join(["nullptr"] * ni)), I + "size_t istr[%d] = {%s};" % (ni, ", ".join(["0"] * ni))]
+                    I + "const float *ins[%d] = {%s};" % (ni, ", ".join(["nullptr"] * ni)), I + "size_t istr[%d] = {%s};" % (ni, ", ".join(["0"] * ni)),
+                    I + "uint32_t ivo[%d] = {%s};" % (ni, ", ".join(["0"] * ni))]
             for j, pi in enumerate(k.rows):
-                out.append(I + "ins[%d] = zs_row(L.p[%d], v, istr[%d]);" % (j, pi, j))
+                out.append(I + "ins[%d] = zs_row(L.p[%d], v, istr[%d], ivo[%d]);" % (j, pi, j, j))
             out += [I + l for l in k.pro]
-            out.append(I + "zs_frame_loop<%d, %d>(L.out + v, L.ostride, ins, istr, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0," % (unroll, nin))
+            out.append(I + "zs_frame_loop<%d, %d>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0," % (unroll, nin))
             out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
             out.append(I + I + "(void)i; (void)x;")
             if k.temps:
