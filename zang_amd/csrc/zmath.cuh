@@ -198,7 +198,9 @@ ZD int zreduce_pio2f(float x, uint32_t ix, double &y) {
     int n = (int)fn;
     y = small ? ys : ym;
     // finite |x| >= 2^28*pi/2, or a medium y that landed outside [-pi/4, pi/4] ("matters with directed rounding")
-    const bool rare = !small && (ym < -pio4 || ym > pio4 || (ix - 0x4dc90fdbu) < (0x7f800000u - 0x4dc90fdbu));
+    // (ints, not short-circuit logic: three compares and two scalar mask operations, no branches)
+    const int out_of_range = __builtin_fabs(ym) > pio4, large = (ix - 0x4dc90fdbu) < (0x7f800000u - 0x4dc90fdbu);
+    const bool rare = ((int)!small & (out_of_range | large)) != 0;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
         if (rare) n = zrem_pio2f(x, &y);
     }
