@@ -81,15 +81,24 @@ struct NiceLaneT {
         const F pv = zero + pulse_sample<W>(k, c);                     // temps[0] = 0 (+ pulse); a silent voice (bad freq) leaves it 0
         return zsel(bad, zero, pv) * 0.5f;                             // multiplyWithScalar :226
     }
-    __device__ __forceinline__ F tail(F t0) {
+    // tail = two chains that never read each other's state: the filter over the oscillator samples and
+    // the envelope; their product is the value added to out.
+    __device__ __forceinline__ F tail_filter(F t0) {
         const F zero = zsplat<F>(0.0f);
         // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
         const SvfOutT<F> s = svf_step(l, b, t0, cut, res);
-        const F t1 = zero + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
+        return zero + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
+    }
+    __device__ __forceinline__ F tail_env() {
+        const F zero = zsplat<F>(0.0f);
         // temps[0] = 0 (+ envelope)
         F ev = zero;
         const M painted = env.frame(ev);
-        const F e0 = zsel(painted, zero + ev, zero);
+        return zsel(painted, zero + ev, zero);
+    }
+    __device__ __forceinline__ F tail(F t0) {
+        const F t1 = tail_filter(t0);
+        const F e0 = tail_env();
         return e0 * t1;                                                // multiply :246: out += temps[0]*temps[1]
     }
     __device__ __forceinline__ F frame() {
@@ -239,14 +248,22 @@ struct PMLane {
     // accumulators and the envelope -- returning what this frame's sample is made from.  value(): the
     // two sines and the products, a pure function of those three numbers (so it can be evaluated for
     // many frames at once, k_pmosc_spans_wave).
-    __device__ __forceinline__ void step(float &tm_i, float &tc_i, float &e0) {
+    // step = step_phase + step_env: two chains that never read each other's state.
+    __device__ __forceinline__ void step_phase(float &tm_i, float &tc_i) {
         tm_i = tm;
         tm += mod_freq * inv_sr;                                       // modulator: t += freq_buf[i] * inv_sr (:59-63)
         tc_i = tc;
         tc += t_step;                                                  // carrier: t += t_step (:69-74)
+    }
+    __device__ __forceinline__ float step_env() {
         float ev = 0.0f;                                               // envelope -> temps[1] (zeroed)   (:117-125)
-        e0 = 0.0f;
+        float e0 = 0.0f;
         if (env.frame(ev)) e0 = 0.0f + ev;
+        return e0;
+    }
+    __device__ __forceinline__ void step(float &tm_i, float &tc_i, float &e0) {
+        step_phase(tm_i, tc_i);
+        e0 = step_env();
     }
     static __device__ __forceinline__ float value(float tm_i, float tc_i, float e0) {
         const float m = 0.0f + sine_osc_sin(tm_i + 0.0f);              // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
@@ -392,14 +409,24 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
     pm_store(n, a, v);
 }
 
-// NiceInstrument for a handful of voices (config 4: 10 + 4): one WAVE owns one voice, its lanes are 64
-// consecutive frames.  The oscillator half is evaluated by all lanes at once (NiceLane::osc at
-// cnt + lane*ifreq); the filter and envelope run through the 64 frames in every lane alike, picking
-// up frame j's oscillator value with a readlane, each lane keeping the result of its own frame.
-// About 45 instructions per frame instead of 70.  Sub-span semantics as in span_walk.
+// NiceInstrument for a handful of voices (config 4: 10 + 4): one workgroup of TWO waves owns one voice, and
+// a wave's lanes are 64 consecutive frames.  What limits a lone voice is the length of the dependent
+// chain per frame, so the frame's three parts are taken apart:
+//   * the oscillator is a pure function of the phase counter: wave 0 evaluates it for its 64 frames at
+//     once (NiceLane::osc at cnt + lane*ifreq);
+//   * the filter carries (l, b): wave 0 runs it through the 64 frames in every lane alike, picking up
+//     frame j's oscillator value with a readlane, each lane keeping the result of its own frame;
+//   * the envelope carries its own state and reads nothing of the filter's: wave 1 runs it through the
+//     same 64 frames at the same time and hands its 64 values over through LDS (double-buffered, one
+//     barrier per 64 frames).
+// Wave 0 then writes out += env * filtered.  About 21 dependent instructions per frame instead of 70.
+// Same per-voice operations in the same order => same bits.  Sub-span semantics as in span_walk; both
+// waves walk the table identically (it is per voice), so they reach the same barriers.
 template <bool ZF>
-__global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    const uint32_t v = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(128) k_nice_spans_wave(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    __shared__ float env_s[2][64];
+    const uint32_t v = blockIdx.x, lane = threadIdx.x & 63;
+    const bool filter_wave = threadIdx.x < 64;
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
     n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
@@ -409,9 +436,9 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
     float *col = out.p + v;
     const size_t os = out.stride;
     auto zero = [&](uint32_t f0, uint32_t f1) ZH_INLINE_LAMBDA {
-        if (ZF) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
+        if (ZF && filter_wave) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
     };
-    uint32_t i = start;
+    uint32_t i = start, blk = 0;
     for (uint32_t k = 0; k < cnt; k++) {
         const size_t idx = (size_t)k * a.V + v;
         const uint32_t s0 = tb.start[idx], s1 = tb.end[idx];
@@ -420,19 +447,28 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
         n.begin(a.sample_rate, a.srf, a.sr8, tb.freq[idx], color, tb.note_on[idx] != 0, tb.nic[idx] != 0);
         const bool ends = s1 >= s0 && s1 <= end;                // otherwise the sub-span runs to the buffer end
         const uint32_t seg_end = ends ? s1 : end;
-        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64) {
+        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64, blk ^= 1) {
             const uint32_t nf = min(64u, seg_end - f0);
-            const float t0_mine = n.osc(n.cnt + lane * n.k.ifreq);
-            if (!n.bad) n.cnt += nf * n.k.ifreq;
             float mine = 0.0f;
-            for (uint32_t j = 0; j < nf; j++) {
-                const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)j));
-                const float val = n.tail(t0);
-                if (j == lane) mine = val;
+            if (filter_wave) {
+                const float t0_mine = n.osc(n.cnt + lane * n.k.ifreq);
+                if (!n.bad) n.cnt += nf * n.k.ifreq;
+                for (uint32_t j = 0; j < nf; j++) {
+                    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)j));
+                    const float val = n.tail_filter(t0);
+                    if (j == lane) mine = val;
+                }
+            } else {
+                for (uint32_t j = 0; j < nf; j++) {
+                    const float val = n.tail_env();
+                    if (j == lane) mine = val;
+                }
+                env_s[blk][lane] = mine;
             }
-            if (lane < nf) {
+            __syncthreads();
+            if (filter_wave && lane < nf) {
                 float *o = col + (size_t)(f0 + lane) * os;
-                *o = (ZF ? 0.0f : *o) + mine;
+                *o = (ZF ? 0.0f : *o) + env_s[blk][lane] * mine;
             }
         }
         i = seg_end;
@@ -440,22 +476,26 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
     }
     zero(i, end);
     if (lane == 0) {
-        a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
-        a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
+        if (filter_wave) { a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b; }
+        else { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
     }
 }
 
-// A handful of PMOscInstrument voices (config 4: two) cannot use lane-per-voice parallelism, and two
-// musl sines per sample in f64 make the serial walk slow (1,680 cycles per frame).  Here one WAVE owns
-// one voice and its 64 lanes are 64 consecutive frames: all lanes run the sequential part (phase
-// accumulators + envelope, ~25 instructions per frame, identical in every lane) and each keeps the
-// frame that is its own; then every lane evaluates PMLane::value for its frame -- the sines, once per
-// 64 frames instead of once per frame.  Same per-voice operations in the same order => same bits.
+// A handful of PMOscInstrument voices (config 4: three) cannot use lane-per-voice parallelism, and two
+// musl sines per sample in f64 make the serial walk slow.  Here one workgroup of TWO waves owns one
+// voice and a wave's 64 lanes are 64 consecutive frames.  The state-carrying part of a frame is two
+// independent chains: the phase accumulators (two adds) run through the 64 frames in every lane of
+// wave 0, the envelope through the same frames in wave 1 at the same time, each lane keeping the frame
+// that is its own; the envelope values cross through LDS (double-buffered, one barrier per 64 frames);
+// then every lane of wave 0 evaluates PMLane::value for its frame -- the sines, once per 64 frames
+// instead of once per frame.  Same per-voice operations in the same order => same bits.
 // Sub-span semantics are span_walk's: begin() at a sub-span's first frame, end() after its last,
 // nothing painted in between, a malformed table entry never fires.
 template <bool ZF>
-__global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    const uint32_t v = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(128) k_pmosc_spans_wave(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    __shared__ float env_s[2][64];
+    const uint32_t v = blockIdx.x, lane = threadIdx.x & 63;
+    const bool phase_wave = threadIdx.x < 64;
     PMLane n;
     pm_load(n, a, v);
     n.mod_freq = n.inv_sr = n.t_step = 0.0f;
@@ -464,9 +504,9 @@ __global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP
     float *col = out.p + v;
     const size_t os = out.stride;
     auto zero = [&](uint32_t f0, uint32_t f1) ZH_INLINE_LAMBDA {
-        if (ZF) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
+        if (ZF && phase_wave) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
     };
-    uint32_t i = start;
+    uint32_t i = start, blk = 0;
     for (uint32_t k = 0; k < cnt; k++) {
         const size_t idx = (size_t)k * a.V + v;
         const uint32_t s0 = tb.start[idx], s1 = tb.end[idx];
@@ -475,17 +515,27 @@ __global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP
         n.begin(a.sample_rate, tb.freq[idx], rel, tb.note_on[idx] != 0, tb.nic[idx] != 0);
         const bool ends = s1 >= s0 && s1 <= end;                // otherwise the sub-span runs to the buffer end, unfinished
         const uint32_t seg_end = ends ? s1 : end;
-        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64) {
+        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64, blk ^= 1) {
             const uint32_t nf = min(64u, seg_end - f0);
-            float my_tm = 0.0f, my_tc = 0.0f, my_e = 0.0f;
-            for (uint32_t j = 0; j < nf; j++) {
-                float tm_i, tc_i, e0;
-                n.step(tm_i, tc_i, e0);
-                if (j == lane) { my_tm = tm_i; my_tc = tc_i; my_e = e0; }
+            float my_tm = 0.0f, my_tc = 0.0f;
+            if (phase_wave) {
+                for (uint32_t j = 0; j < nf; j++) {
+                    float tm_i, tc_i;
+                    n.step_phase(tm_i, tc_i);
+                    if (j == lane) { my_tm = tm_i; my_tc = tc_i; }
+                }
+            } else {
+                float my_e = 0.0f;
+                for (uint32_t j = 0; j < nf; j++) {
+                    const float e0 = n.step_env();
+                    if (j == lane) my_e = e0;
+                }
+                env_s[blk][lane] = my_e;
             }
-            if (lane < nf) {
+            __syncthreads();
+            if (phase_wave && lane < nf) {
                 float *o = col + (size_t)(f0 + lane) * os;
-                *o = (ZF ? 0.0f : *o) + PMLane::value(my_tm, my_tc, my_e);
+                *o = (ZF ? 0.0f : *o) + PMLane::value(my_tm, my_tc, env_s[blk][lane]);
             }
         }
         i = seg_end;
@@ -493,7 +543,10 @@ __global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP
         n.end();
     }
     zero(i, end);
-    if (lane == 0) pm_store(n, a, v);
+    if (lane == 0) {
+        if (phase_wave) { a.tc[v] = n.tc; a.tm[v] = n.tm; }
+        else { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
+    }
 }
 
 // ------------------------------------------------------------------ Noise -> Filter voice
@@ -729,8 +782,8 @@ int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
     static const int wave_max = [] { const char *e = getenv("ZH_NICE_WAVE_MAX"); return e ? atoi(e) : 64; }();
     if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
-        if (zf) hipLaunchKernelGGL(k_nice_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL(k_nice_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        if (zf) hipLaunchKernelGGL(k_nice_spans_wave<true>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else hipLaunchKernelGGL(k_nice_spans_wave<false>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     } else if (zf) hipLaunchKernelGGL(k_nice_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_nice_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
@@ -920,8 +973,8 @@ int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
     static const int wave_max = [] { const char *e = getenv("ZH_PMOSC_WAVE_MAX"); return e ? atoi(e) : 64; }();
     if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
-        if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     } else if (zf) hipLaunchKernelGGL(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_pmosc_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
