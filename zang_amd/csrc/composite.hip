@@ -409,24 +409,21 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
     pm_store(n, a, v);
 }
 
-// NiceInstrument for a handful of voices (config 4: 10 + 4): one workgroup of TWO waves owns one voice, and
-// a wave's lanes are 64 consecutive frames.  What limits a lone voice is the length of the dependent
-// chain per frame, so the frame's three parts are taken apart:
-//   * the oscillator is a pure function of the phase counter: wave 0 evaluates it for its 64 frames at
-//     once (NiceLane::osc at cnt + lane*ifreq);
-//   * the filter carries (l, b): wave 0 runs it through the 64 frames in every lane alike, picking up
-//     frame j's oscillator value with a readlane, each lane keeping the result of its own frame;
-//   * the envelope carries its own state and reads nothing of the filter's: wave 1 runs it through the
-//     same 64 frames at the same time and hands its 64 values over through LDS (double-buffered, one
-//     barrier per 64 frames).
-// Wave 0 then writes out += env * filtered.  About 21 dependent instructions per frame instead of 70.
-// Same per-voice operations in the same order => same bits.  Sub-span semantics as in span_walk; both
-// waves walk the table identically (it is per voice), so they reach the same barriers.
+// NiceInstrument for a handful of voices (config 4: 10 + 4): one WAVE owns one voice and its lanes are 64
+// consecutive frames.  What limits a lone voice is the number of instructions on the frame-to-frame
+// chain (a lone wave issues one every ~5 cycles), so a frame is taken apart by what really carries state:
+//   * the oscillator is a pure function of the phase counter: evaluated for the 64 frames at once
+//     (NiceLane::osc at cnt + lane*ifreq);
+//   * the envelope's only sequential part is its clock: EnvLane::block64 walks it (2 instructions per
+//     frame, nothing at all while idle or sustaining) and evaluates the curve in all lanes at once;
+//   * the filter carries (l, b) through every sample: it runs through the 64 frames in every lane alike,
+//     reading frame j's oscillator value with a readlane and leaving its result in LDS slot j.
+// About 24 instructions per frame instead of 70.  Same per-voice operations in the same order => same
+// bits.  Sub-span semantics as in span_walk.
 template <bool ZF>
-__global__ void __launch_bounds__(128) k_nice_spans_wave(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    __shared__ float env_s[2][64];
-    const uint32_t v = blockIdx.x, lane = threadIdx.x & 63;
-    const bool filter_wave = threadIdx.x < 64;
+__global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    __shared__ float walk_s[64], filt_s[64];
+    const uint32_t v = blockIdx.x, lane = threadIdx.x;
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
     n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
@@ -436,9 +433,9 @@ __global__ void __launch_bounds__(128) k_nice_spans_wave(NiceArgs a, SpanTableP 
     float *col = out.p + v;
     const size_t os = out.stride;
     auto zero = [&](uint32_t f0, uint32_t f1) ZH_INLINE_LAMBDA {
-        if (ZF && filter_wave) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
+        if (ZF) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
     };
-    uint32_t i = start, blk = 0;
+    uint32_t i = start;
     for (uint32_t k = 0; k < cnt; k++) {
         const size_t idx = (size_t)k * a.V + v;
         const uint32_t s0 = tb.start[idx], s1 = tb.end[idx];
@@ -447,28 +444,22 @@ __global__ void __launch_bounds__(128) k_nice_spans_wave(NiceArgs a, SpanTableP 
         n.begin(a.sample_rate, a.srf, a.sr8, tb.freq[idx], color, tb.note_on[idx] != 0, tb.nic[idx] != 0);
         const bool ends = s1 >= s0 && s1 <= end;                // otherwise the sub-span runs to the buffer end
         const uint32_t seg_end = ends ? s1 : end;
-        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64, blk ^= 1) {
+        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64) {
             const uint32_t nf = min(64u, seg_end - f0);
-            float mine = 0.0f;
-            if (filter_wave) {
-                const float t0_mine = n.osc(n.cnt + lane * n.k.ifreq);
-                if (!n.bad) n.cnt += nf * n.k.ifreq;
-                for (uint32_t j = 0; j < nf; j++) {
-                    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)j));
-                    const float val = n.tail_filter(t0);
-                    if (j == lane) mine = val;
-                }
-            } else {
-                for (uint32_t j = 0; j < nf; j++) {
-                    const float val = n.tail_env();
-                    if (j == lane) mine = val;
-                }
-                env_s[blk][lane] = mine;
+            const float t0_mine = n.osc(n.cnt + lane * n.k.ifreq);
+            if (!n.bad) n.cnt += nf * n.k.ifreq;
+            const float e0 = n.env.block64(nf, lane, walk_s);   // temps[0] = 0 (+ envelope)
+            uint32_t j = 0;
+            for (; j + 8 <= nf; j += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    filt_s[j + q] = n.tail_filter(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)(j + q))));
             }
-            __syncthreads();
-            if (filter_wave && lane < nf) {
+            for (; j < nf; j++)
+                filt_s[j] = n.tail_filter(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)j)));
+            if (lane < nf) {
                 float *o = col + (size_t)(f0 + lane) * os;
-                *o = (ZF ? 0.0f : *o) + env_s[blk][lane] * mine;
+                *o = (ZF ? 0.0f : *o) + e0 * filt_s[lane];     // multiply :246: out += temps[0]*temps[1]
             }
         }
         i = seg_end;
@@ -476,26 +467,24 @@ __global__ void __launch_bounds__(128) k_nice_spans_wave(NiceArgs a, SpanTableP 
     }
     zero(i, end);
     if (lane == 0) {
-        if (filter_wave) { a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b; }
-        else { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
+        a.cnt[v] = n.cnt; a.fl[v] = n.l; a.fb[v] = n.b;
+        a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
     }
 }
 
 // A handful of PMOscInstrument voices (config 4: three) cannot use lane-per-voice parallelism, and two
-// musl sines per sample in f64 make the serial walk slow.  Here one workgroup of TWO waves owns one
-// voice and a wave's 64 lanes are 64 consecutive frames.  The state-carrying part of a frame is two
-// independent chains: the phase accumulators (two adds) run through the 64 frames in every lane of
-// wave 0, the envelope through the same frames in wave 1 at the same time, each lane keeping the frame
-// that is its own; the envelope values cross through LDS (double-buffered, one barrier per 64 frames);
-// then every lane of wave 0 evaluates PMLane::value for its frame -- the sines, once per 64 frames
-// instead of once per frame.  Same per-voice operations in the same order => same bits.
+// musl sines per sample in f64 make the serial walk slow.  Here one WAVE owns one voice and its 64 lanes
+// are 64 consecutive frames.  The state-carrying part of a frame is three running sums -- the two phase
+// accumulators and the envelope's clock -- walked once per wave (zwalk64 / EnvLane::block64: two
+// instructions per frame each) with lane j receiving frame j's values; then every lane evaluates
+// PMLane::value for its frame: the sines and the envelope curve, once per 64 frames instead of once per
+// frame.  Same per-voice operations in the same order => same bits.
 // Sub-span semantics are span_walk's: begin() at a sub-span's first frame, end() after its last,
 // nothing painted in between, a malformed table entry never fires.
 template <bool ZF>
-__global__ void __launch_bounds__(128) k_pmosc_spans_wave(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    __shared__ float env_s[2][64];
-    const uint32_t v = blockIdx.x, lane = threadIdx.x & 63;
-    const bool phase_wave = threadIdx.x < 64;
+__global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
+    __shared__ float walk_s[64];
+    const uint32_t v = blockIdx.x, lane = threadIdx.x;
     PMLane n;
     pm_load(n, a, v);
     n.mod_freq = n.inv_sr = n.t_step = 0.0f;
@@ -504,9 +493,9 @@ __global__ void __launch_bounds__(128) k_pmosc_spans_wave(PMOscArgs a, SpanTable
     float *col = out.p + v;
     const size_t os = out.stride;
     auto zero = [&](uint32_t f0, uint32_t f1) ZH_INLINE_LAMBDA {
-        if (ZF && phase_wave) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
+        if (ZF) for (uint32_t f = f0 + lane; f < f1; f += 64) col[(size_t)f * os] = 0.0f;
     };
-    uint32_t i = start, blk = 0;
+    uint32_t i = start;
     for (uint32_t k = 0; k < cnt; k++) {
         const size_t idx = (size_t)k * a.V + v;
         const uint32_t s0 = tb.start[idx], s1 = tb.end[idx];
@@ -515,27 +504,14 @@ __global__ void __launch_bounds__(128) k_pmosc_spans_wave(PMOscArgs a, SpanTable
         n.begin(a.sample_rate, tb.freq[idx], rel, tb.note_on[idx] != 0, tb.nic[idx] != 0);
         const bool ends = s1 >= s0 && s1 <= end;                // otherwise the sub-span runs to the buffer end, unfinished
         const uint32_t seg_end = ends ? s1 : end;
-        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64, blk ^= 1) {
+        for (uint32_t f0 = s0; f0 < seg_end; f0 += 64) {
             const uint32_t nf = min(64u, seg_end - f0);
-            float my_tm = 0.0f, my_tc = 0.0f;
-            if (phase_wave) {
-                for (uint32_t j = 0; j < nf; j++) {
-                    float tm_i, tc_i;
-                    n.step_phase(tm_i, tc_i);
-                    if (j == lane) { my_tm = tm_i; my_tc = tc_i; }
-                }
-            } else {
-                float my_e = 0.0f;
-                for (uint32_t j = 0; j < nf; j++) {
-                    const float e0 = n.step_env();
-                    if (j == lane) my_e = e0;
-                }
-                env_s[blk][lane] = my_e;
-            }
-            __syncthreads();
-            if (phase_wave && lane < nf) {
+            const float my_tm = zwalk64<true>(n.tm, n.mod_freq * n.inv_sr, 0, nf, lane, walk_s);   // PMLane::step_phase, 64 frames
+            const float my_tc = zwalk64<true>(n.tc, n.t_step, 0, nf, lane, walk_s);
+            const float my_e = n.env.block64(nf, lane, walk_s);                                      // PMLane::step_env
+            if (lane < nf) {
                 float *o = col + (size_t)(f0 + lane) * os;
-                *o = (ZF ? 0.0f : *o) + PMLane::value(my_tm, my_tc, env_s[blk][lane]);
+                *o = (ZF ? 0.0f : *o) + PMLane::value(my_tm, my_tc, my_e);
             }
         }
         i = seg_end;
@@ -543,10 +519,7 @@ __global__ void __launch_bounds__(128) k_pmosc_spans_wave(PMOscArgs a, SpanTable
         n.end();
     }
     zero(i, end);
-    if (lane == 0) {
-        if (phase_wave) { a.tc[v] = n.tc; a.tm[v] = n.tm; }
-        else { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
-    }
+    if (lane == 0) pm_store(n, a, v);
 }
 
 // ------------------------------------------------------------------ Noise -> Filter voice
@@ -782,8 +755,8 @@ int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
     static const int wave_max = [] { const char *e = getenv("ZH_NICE_WAVE_MAX"); return e ? atoi(e) : 64; }();
     if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
-        if (zf) hipLaunchKernelGGL(k_nice_spans_wave<true>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL(k_nice_spans_wave<false>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        if (zf) hipLaunchKernelGGL(k_nice_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else hipLaunchKernelGGL(k_nice_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     } else if (zf) hipLaunchKernelGGL(k_nice_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_nice_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
@@ -973,8 +946,8 @@ int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
     static const int wave_max = [] { const char *e = getenv("ZH_PMOSC_WAVE_MAX"); return e ? atoi(e) : 64; }();
     if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
-        if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(128), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     } else if (zf) hipLaunchKernelGGL(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_pmosc_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();

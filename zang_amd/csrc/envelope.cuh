@@ -16,6 +16,31 @@
 #include "common.cuh"
 #include "lanes.cuh"
 
+// One voice per wave: the running sum acc_{j+1} = acc_j + step over frames [j0, nf) of a 64-frame block,
+// computed once per wave (every lane holds the same acc) and handed out through 64 floats of LDS owned by
+// the wave: lane j gets acc before (PRE) or after frame j's add.  Two instructions per frame (the add and
+// the LDS write) -- the whole inherently sequential part of a phase accumulator or an envelope's clock.
+template <bool PRE>
+__device__ __forceinline__ float zwalk64(float &acc, float step, uint32_t j0, uint32_t nf, uint32_t lane, float *scratch) {
+    float a = acc;
+    uint32_t j = j0;
+    for (; j + 8 <= nf; j += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (PRE) scratch[j + q] = a;
+            a = a + step;
+            if (!PRE) scratch[j + q] = a;
+        }
+    }
+    for (; j < nf; j++) {
+        if (PRE) scratch[j] = a;
+        a = a + step;
+        if (!PRE) scratch[j] = a;
+    }
+    acc = a;
+    return scratch[lane & 63];
+}
+
 template <int W>
 struct CurvePT {          // PaintCurve for one lane: shared tag, per-voice duration
     uint32_t tag;
@@ -118,6 +143,48 @@ struct EnvLaneT {
             resolve(stage_end);
         }
         return painted;
+    }
+
+    // ---- one voice per WAVE: the lanes are 64 consecutive frames (W = 1, every field wave-uniform) ----
+    // block64() is frame() for frames [0, nf) of such a wave in one go, returning in lane j what frame j
+    // adds to the zeroed temp (0 + value when painted, else 0).  Per frame only the time walk
+    // t += step is inherently sequential; the curve is a pure function of t and runs once, in all lanes
+    // at the same time.  Idle and sustain take no per-frame work at all.  A stage that ends inside the
+    // block (first frame whose t reaches 1) is committed exactly as frame() does -- clamp, state change,
+    // resolve() -- and the rest of the block runs in the next stage.  `scratch`: 64 floats of LDS owned
+    // by this wave.  Same operations on the same values as nf calls of frame() => same bits.
+    __device__ __forceinline__ float block64(uint32_t nf, uint32_t lane, float *scratch) {
+        static_assert(W == 1, "one voice per wave");
+        float mine = 0.0f;
+        uint32_t j0 = 0;
+        while (j0 < nf) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
+            if (m != ENV_MODE_TOWARD) {                                // nothing can change before the block ends
+                const float e = m == ENV_MODE_FLAT ? 0.0f + sustain_volume : 0.0f;   // FLAT: Envelope.zig:68-70
+                mine = lane >= j0 ? e : mine;
+                break;
+            }
+            const float tn_raw = zwalk64<false>(t, cur_step, j0, nf, lane, scratch);   // t after frame j's step, unclamped
+            const bool in = lane >= j0 && lane < nf;
+            const bool fin = in && tn_raw >= 1.0f;
+            const uint64_t fm = __builtin_amdgcn_ballot_w64(fin);
+            const uint32_t jf = fm ? (uint32_t)__builtin_ctzll(fm) : nf;   // the frame that finishes the stage (none: nf)
+            const float tn = fin ? 1.0f : tn_raw;
+            const float it = 1.0f - tn;
+            const float tp = cur_tag == ZH_CURVE_SQUARED ? 1.0f - it * it : (cur_tag == ZH_CURVE_CUBED ? 1.0f - it * it * it : tn);
+            const float lv = start + tp * (cur_goal - start);          // painter.zig:114
+            mine = (in && lane <= jf) ? 0.0f + lv : mine;
+            const uint32_t last = jf < nf ? jf : nf - 1;               // state as of the stage's last painted frame
+            t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tn), (int)last));
+            last_value = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv), (int)last));
+            if (jf >= nf) break;
+            const U after_attack = zsel(sustain_volume < f(1.0f), u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN));   // Envelope.zig:53-58, 63-65, 86-88
+            const U next = zsel(state == u(ZH_ENV_ATTACK), after_attack, zsel(state == u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN), u(ZH_ENV_IDLE)));
+            change_state_if(zmask<M>(true), next);
+            resolve(zmask<M>(true));
+            j0 = jf + 1;
+        }
+        return mine;
     }
 };
 using EnvLane = EnvLaneT<1>;
