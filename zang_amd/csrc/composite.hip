@@ -416,13 +416,14 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
 //     (NiceLane::osc at cnt + lane*ifreq);
 //   * the envelope's only sequential part is its clock: EnvLane::block64 walks it (2 instructions per
 //     frame, nothing at all while idle or sustaining) and evaluates the curve in all lanes at once;
-//   * the filter carries (l, b) through every sample: it runs through the 64 frames in every lane alike,
-//     reading frame j's oscillator value with a readlane and leaving its result in LDS slot j.
-// About 24 instructions per frame instead of 70.  Same per-voice operations in the same order => same
+//   * the filter carries (l, b) through every sample: its core (15 operations) runs through the 64 frames
+//     in every lane alike, reading frame j's input with a readlane and leaving (l, b, h) in LDS slot j;
+//     the input offset before it and the output mix after it are done for all 64 frames at once.
+// About 20 instructions per frame instead of 70.  Same per-voice operations in the same order => same
 // bits.  Sub-span semantics as in span_walk.
 template <bool ZF>
 __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    __shared__ float walk_s[64], filt_s[64];
+    __shared__ float walk_s[64], svf_l[64], svf_b[64], svf_h[64];
     const uint32_t v = blockIdx.x, lane = threadIdx.x;
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
@@ -449,17 +450,23 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
             const float t0_mine = n.osc(n.cnt + lane * n.k.ifreq);
             if (!n.bad) n.cnt += nf * n.k.ifreq;
             const float e0 = n.env.block64(nf, lane, walk_s);   // temps[0] = 0 (+ envelope)
+            // NiceLane::tail_filter with only svf_core on the chain: the input offset is added for all 64
+            // frames at once before it, the output mix after it from the captured (l, b, h) of each frame
+            const float in_mine = t0_mine + kSvfDcOffset;      // Filter.zig:135
+            auto step = [&](uint32_t j) ZH_INLINE_LAMBDA {
+                const SvfOut s = svf_core(n.l, n.b, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in_mine), (int)j)), n.cut, n.res);
+                svf_l[j] = s.l; svf_b[j] = s.b; svf_h[j] = s.h;
+            };
             uint32_t j = 0;
             for (; j + 8 <= nf; j += 8) {
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    filt_s[j + q] = n.tail_filter(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)(j + q))));
+                for (int q = 0; q < 8; q++) step(j + q);
             }
-            for (; j < nf; j++)
-                filt_s[j] = n.tail_filter(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0_mine), (int)j)));
+            for (; j < nf; j++) step(j);
             if (lane < nf) {
+                const float t1 = 0.0f + (svf_l[lane] * 1.0f + svf_b[lane] * 0.0f + svf_h[lane] * 0.0f);   // temps[1] = 0 + low-pass
                 float *o = col + (size_t)(f0 + lane) * os;
-                *o = (ZF ? 0.0f : *o) + e0 * filt_s[lane];     // multiply :246: out += temps[0]*temps[1]
+                *o = (ZF ? 0.0f : *o) + e0 * t1;               // multiply :246: out += temps[0]*temps[1]
             }
         }
         i = seg_end;

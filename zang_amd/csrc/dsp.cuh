@@ -69,16 +69,20 @@ __device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k
 // ---- Filter (src/modules/Filter.zig:130-146): one 2x-oversampled state-variable step ------------
 template <class F> struct SvfOutT { F l, b, h; };
 using SvfOut = SvfOutT<float>;
+constexpr float kSvfDcOffset = 3.814697265625e-6f;                   // fcdcoffset, Filter.zig:8
+// the state-carrying part, given in = input + fcdcoffset (:135, a function of the input sample alone)
 template <class F>
-__device__ __forceinline__ SvfOutT<F> svf_step(F &l, F &b, F input, F cut, F res) {
-    const float fcdcoffset = 3.814697265625e-6f;                      // Filter.zig:8
-    const F in = input + fcdcoffset;                                  // :135
-    l += cut * b - fcdcoffset;                                        // :138
+__device__ __forceinline__ SvfOutT<F> svf_core(F &l, F &b, F in, F cut, F res) {
+    l += cut * b - kSvfDcOffset;                                      // :138
     b += cut * (in - b * res - l);                                    // :139
     l += cut * b;                                                     // :142
     const F h = in - b * res - l;                                     // :143
     b += cut * h;                                                     // :144
     return SvfOutT<F>{l, b, h};
+}
+template <class F>
+__device__ __forceinline__ SvfOutT<F> svf_step(F &l, F &b, F input, F cut, F res) {
+    return svf_core(l, b, input + kSvfDcOffset, cut, res);
 }
 
 // ---- Noise (src/modules/Noise.zig:58-66): one sample of Paul Kellett's pink filter -------------
