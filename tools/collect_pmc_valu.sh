@@ -31,6 +31,10 @@ for f in sorted(glob.glob(out + "/*_counters.csv")):
         waves = m.get("SQ_WAVES", 0)
         m["valu_insts_per_wave"] = m.get("SQ_INSTS_VALU", 0) / waves if waves else None
         m["salu_insts_per_wave"] = m.get("SQ_INSTS_SALU", 0) / waves if waves else None
+        gui = m.get("GRBM_GUI_ACTIVE", 0) / 8.0                     # the csv holds the sum over the 8 XCDs
+        m["cycles_per_xcd"] = gui
+        m["valu_busy_pct"] = 100.0 * m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024 / gui if gui else None     # rocprof's VALUBusy, SIMD_NUM = 1024
+        m["cycles_per_valu_inst_per_simd"] = gui * 1024 / m["SQ_INSTS_VALU"] if m.get("SQ_INSTS_VALU") else None
         res[os.path.basename(f).replace("_counters.csv", "") + ":" + k] = m
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
