@@ -139,9 +139,10 @@ def test_pmosc_fused_equals_unfused_oracle(ctx, oracle):
 @pytest.mark.parametrize("ftype", [0, 1, 3, 5])
 def test_noise_filter_fused_equals_unfused(ctx, oracle, color, ftype):
     """The fused Noise->Filter voice vs the oracle running zero/Noise.paint/zero/Filter.paint through a temp
-    (examples/example_stereo.zig:71-82), three sub-spans, carried state; global seeds."""
+    (examples/example_stereo.zig:71-82), three sub-spans, carried state; global seeds.  At this voice count the
+    library picks the two-wave producer/consumer kernel; the test below reruns this one with the single-wave form."""
     from zang_amd import modules as mod, zang
-    V, first = 192, 5000
+    V, first = 150, 5000                                       # 150: the last wave has idle lanes
     rng = np.random.default_rng(17)
     cutoff = rng.uniform(-0.05, 1.05, V).astype(np.float32); res = rng.uniform(-0.05, 1.05, V).astype(np.float32)
     out0 = util.rng_buffers(18, V, F)
@@ -182,3 +183,19 @@ def test_nice_two_voices_per_lane_variant_is_bit_identical():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "2 passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_noise_filter_single_wave_form_is_bit_identical():
+    """k_noise_filter (one wave does noise and filter: the form used above ZH_NF_PC_MAX voices) against the same
+    oracle: rerun the fused Noise->Filter parity tests in a subprocess with the two-wave form switched off."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZH_NF_PC_MAX="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
+                        "noise_filter_fused_equals_unfused"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "8 passed" in r.stdout

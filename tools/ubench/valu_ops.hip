@@ -70,6 +70,11 @@ __global__ void __launch_bounds__(64) k_ops(float *out, unsigned iters, float a,
             if constexpr (KIND == 45) asm volatile("v_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %0, 1, %0" : "+v"(p[0]) : "v"(bb));
             if constexpr (KIND == 46) asm volatile("v_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9\n\tv_alignbit_b32 %0, %0, %1, 9" : "+v"(x[0]) : "v"(b));
             if constexpr (KIND == 47) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(x[0]), "+v"(x[1]) : "v"(b));
+            if constexpr (KIND == 48) asm volatile("v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 49) asm volatile("v_mul_f32 %0, %0, %1\n\tv_sub_f32 %0, %1, %0\n\tv_xor_b32 %0, %0, %1\n\tv_lshrrev_b32 %0, 1, %0\n\tv_mul_f32 %0, %0, %1\n\tv_sub_f32 %0, %1, %0\n\tv_xor_b32 %0, %0, %1\n\tv_lshrrev_b32 %0, 1, %0" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 50) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[0]) : "v"(b) : "vcc");
+            if constexpr (KIND == 51) asm volatile("v_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1" : "+v"(p[0]) : "v"(bb));
+            if constexpr (KIND == 52) asm volatile("v_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0\n\tv_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0\n\tv_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0\n\tv_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0" : "+v"(x[0]) : "v"(b));
         }
     }
     float s = 0;
@@ -151,6 +156,11 @@ int main() {
         run<45>(d, "dependent v_lshlrev_b64 chain", 8, w, e0, e1);
         run<46>(d, "dependent v_alignbit chain", 8, w, e0, e1);
         run<47>(d, "2 interleaved dep add chains", 8, w, e0, e1);
+        run<48>(d, "dependent mul,add alternating", 8, w, e0, e1);
+        run<49>(d, "dependent mul,sub,xor,shift", 8, w, e0, e1);
+        run<50>(d, "dependent cmp->cndmask chain", 8, w, e0, e1);
+        run<51>(d, "dependent f64 mul,add", 8, w, e0, e1);
+        run<52>(d, "dependent mul,add w/ literals", 8, w, e0, e1);
     }
     return 0;
 }

@@ -572,6 +572,87 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter(uint64_t *__restrict
     l_io[v] = l; b_io[v] = b;
 }
 
+// Few voices (fewer waves than the chip has SIMDs): a lone wave issues one instruction per ~5 cycles, so what
+// a voice costs is the number of instructions on its frame-to-frame chain.  The fused frame is two chains that
+// meet in a single value: the noise sample (xoshiro256++, float conversion, pink taps: ~26 instructions) and
+// the filter (~22).  Here one workgroup of TWO waves owns 64 voices: wave 0 produces noise one tile of 32
+// frames ahead into LDS ([frame][voice], conflict-free), wave 1 filters the previous tile and writes the image;
+// one barrier per 32 frames.  Same per-voice operations in the same order => same bits as k_noise_filter.
+template <bool ZF, bool PINK>
+__global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
+                                                         uint64_t *__restrict__ s2, uint64_t *__restrict__ s3,
+                                                         const float *__restrict__ bst, float *__restrict__ l_io,
+                                                         float *__restrict__ b_io, uint32_t V, Img out, uint32_t start,
+                                                         uint32_t end, float l_mul, float b_mul, float h_mul, F32P cutoff,
+                                                         F32P res_p) {
+    constexpr uint32_t CH = 32;
+    __shared__ float tile[2][CH][64];
+    const uint32_t lane = threadIdx.x & 63;
+    const bool producer = threadIdx.x < 64;
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < V;                                           // no early return: both waves meet at the barriers
+    const uint32_t vc = live ? v : V - 1;
+    const uint32_t n = end - start, nchunks = (n + CH - 1) / CH;
+    if (producer) {
+        ZXoshiro r{s0[vc], s1[vc], s2[vc], s3[vc]};
+        float pb[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (PINK) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) pb[j] = bst[(size_t)j * V + vc];
+        }
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t nf = min(CH, n - c * CH);
+            float (*t)[64] = tile[c & 1];
+            auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                const float white = zrandom_float32(r) * 2.0f - 1.0f;  // Noise.zig:51 / :58
+                t[k][lane] = PINK ? pink_step(pb, white) : white;      // :59-66
+            };
+            if (nf == CH) {
+#pragma unroll 8
+                for (uint32_t k = 0; k < CH; k++) one(k);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k);
+            }
+            __syncthreads();                                           // tile c is complete; tile c-1 has been consumed
+        }
+        if (live) { s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3; }
+    } else {
+        const float cut = zclampf(cutoff.get(vc), 0.0f, 1.0f);         // Filter.zig:114
+        const float res = 1.0f - zclampf(res_p.get(vc), 0.0f, 1.0f);   // :118
+        float l = l_io[vc], b = b_io[vc];
+        const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t nf = min(CH, n - c * CH);
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + c * CH);
+            float oc[CH];
+            if (!ZF) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) oc[k] = k < nf ? zrow_load<1>(ro, voff, k * orow) : 0.0f;
+            }
+            __syncthreads();                                           // wait for tile c
+            const float (*t)[64] = tile[c & 1];
+            float x[CH];                                               // the whole tile column first: one LDS wait per tile, not one per frame
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) x[k] = t[k][lane];
+            // lanes past the last voice run voice V-1 again (same state, same noise from the producer's twin lane):
+            // their stores repeat V-1's values at V-1's address, so nothing needs masking inside the chain
+            auto one = [&](uint32_t k, float nz, float o) ZH_INLINE_LAMBDA {
+                const float temp = 0.0f + nz;                          // zero(temp); temp += noise
+                const SvfOut sv = svf_step(l, b, temp, cut, res);      // Filter.zig:135-144
+                const float val = sv.l * l_mul + sv.b * b_mul + sv.h * h_mul;   // :146
+                zrow_store<1>(ro, voff, k * orow, o + val);
+            };
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, x[k], ZF ? 0.0f : oc[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, t[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+            }
+        }
+        if (live) { l_io[v] = l; b_io[v] = b; }
+    }
+}
+
 // bypass: out += noise, filter state untouched (Filter.zig:91-97)
 template <bool ZF, bool PINK>
 __global__ void __launch_bounds__(kSeqBlock) k_noise_filter_bypass(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
@@ -859,8 +940,17 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     case ZH_FILTER_NOTCH: l_mul = 1.0f; h_mul = 1.0f; break;
     default: l_mul = 1.0f; b_mul = 1.0f; h_mul = 1.0f; break;
     }
-#define ZH_NF(ZF_, PK_) hipLaunchKernelGGL((k_noise_filter<ZF_, PK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
-    if (zf) { if (pink) ZH_NF(true, true); else ZH_NF(true, false); } else { if (pink) ZH_NF(false, true); else ZH_NF(false, false); }
+    // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at
+    // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both
+    static const uint32_t pc_max = [] { const char *e = getenv("ZH_NF_PC_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u; }();
+#define ZH_NF(K_, BLK_, ZF_, PK_) hipLaunchKernelGGL((K_<ZF_, PK_>), seq_grid(m->n), dim3(BLK_), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
+    if (m->n <= pc_max) {
+        if (zf) { if (pink) ZH_NF(k_noise_filter_pc, 128, true, true); else ZH_NF(k_noise_filter_pc, 128, true, false); }
+        else { if (pink) ZH_NF(k_noise_filter_pc, 128, false, true); else ZH_NF(k_noise_filter_pc, 128, false, false); }
+    } else {
+        if (zf) { if (pink) ZH_NF(k_noise_filter, kSeqBlock, true, true); else ZH_NF(k_noise_filter, kSeqBlock, true, false); }
+        else { if (pink) ZH_NF(k_noise_filter, kSeqBlock, false, true); else ZH_NF(k_noise_filter, kSeqBlock, false, false); }
+    }
 #undef ZH_NF
     return zh_launch_status();
 }
