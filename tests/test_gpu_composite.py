@@ -199,3 +199,19 @@ def test_noise_filter_single_wave_form_is_bit_identical():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "8 passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_nice_single_wave_form_is_bit_identical():
+    """k_nice (one wave runs oscillator, envelope and filter: the form used above ZH_NICE_PC_MAX voices) against the
+    same oracle: rerun the NiceInstrument parity tests in a subprocess with the three-wave pipeline switched off."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZH_NICE_PC_MAX="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
+                        "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout

@@ -142,6 +142,10 @@ __device__ __forceinline__ void nice_store(NiceLaneT<W> &n, const NiceArgs &a, u
 // 2.5 for a plain v_add/v_mul/v_sub_f32, so packing saves ~15 % on the arithmetic while every compare
 // and select (4.2 cycles each, no packed form) is paid twice.  ZH_NICE_W=2 selects it for A/B timing;
 // it needs an even voice count and 8-byte aligned rows / per-voice arrays.
+static uint32_t nice_pc_max() {
+    static const uint32_t v = [] { const char *e = getenv("ZH_NICE_PC_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u; }();   // 72 vs 146 us at 4,096 voices, 107 vs 168 at 65,536; slower at 131,072
+    return v;
+}
 static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 static bool nice_pairable(const NiceArgs &a) {
     static const bool want2 = [] { const char *e = getenv("ZH_NICE_W"); return e && e[0] == '2'; }();
@@ -162,6 +166,84 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
         return zmask<typename LaneT<W>::M>(true);
     });
     nice_store<W>(n, a, v);
+}
+
+// Few voices (fewer waves than the chip has SIMDs): the frame's three chains -- oscillator (phase counter),
+// envelope (clock + state machine) and filter ((l, b) through every sample) -- only meet in values, never in
+// state.  One workgroup of THREE waves owns 64 voices: wave 0 produces the oscillator samples and wave 1 the
+// envelope values one tile of 32 frames ahead into LDS ([frame][voice]); wave 2 filters the previous tile,
+// multiplies and writes the image; one barrier per 32 frames.  The longest chain (the filter's ~27
+// instructions) sets the pace instead of the sum (~64).  Lanes past the last voice run voice V-1 again in all
+// three waves, so their stores repeat V-1's values at V-1's address and nothing inside the chains is masked.
+// Same per-voice operations in the same order => same bits as k_nice.
+template <bool ZF>
+__global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t start, uint32_t end) {
+    constexpr uint32_t CH = 32;
+    __shared__ float osc_t[2][CH][64], env_t[2][CH][64];
+    const uint32_t lane = threadIdx.x & 63, role = threadIdx.x >> 6;   // 0 oscillator, 1 envelope, 2 filter
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < a.V;
+    const uint32_t vc = live ? v : a.V - 1;
+    const uint32_t n_frames = end - start, nchunks = (n_frames + CH - 1) / CH;
+    NiceLane n;
+    nice_load<1>(n, a, vc);
+    if (role < 2) {
+        float (*tile)[CH][64] = role == 0 ? osc_t : env_t;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t nf = min(CH, n_frames - c * CH);
+            float (*t)[64] = tile[c & 1];
+            if (role == 0) {
+                auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                    t[k][lane] = n.osc(n.cnt);
+                    n.cnt = n.bad ? n.cnt : n.cnt + n.k.ifreq;
+                };
+                if (nf == CH) {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) one(k);
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) one(k);
+                }
+            } else {
+                if (nf == CH) {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) t[k][lane] = n.tail_env();
+                }
+            }
+            __syncthreads();                                           // tile c is complete; tile c-1 has been consumed
+        }
+        if (live && role == 0) a.cnt[v] = n.cnt;
+        if (live && role == 1) { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
+    } else {
+        const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t nf = min(CH, n_frames - c * CH);
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + c * CH);
+            float oc[CH];
+            if (!ZF) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) oc[k] = k < nf ? zrow_load<1>(ro, voff, k * orow) : 0.0f;
+            }
+            __syncthreads();                                           // wait for tile c
+            const float (*to)[64] = osc_t[c & 1];
+            const float (*te)[64] = env_t[c & 1];
+            float xo[CH], xe[CH];                                      // both tile columns first: one LDS wait per tile
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) { xo[k] = to[k][lane]; xe[k] = te[k][lane]; }
+            auto one = [&](uint32_t k, float t0, float e0, float o) ZH_INLINE_LAMBDA {
+                const float t1 = n.tail_filter(t0);
+                zrow_store<1>(ro, voff, k * orow, o + e0 * t1);        // multiply :246: out += temps[0]*temps[1]
+            };
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, xo[k], xe[k], ZF ? 0.0f : oc[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, to[k][lane], te[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+            }
+        }
+        if (live) { a.fl[v] = n.l; a.fb[v] = n.b; }
+    }
 }
 
 // Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
@@ -801,6 +883,10 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
         const dim3 grid = seq_grid(m->n / 2);
         if (zf) hipLaunchKernelGGL((k_nice<true, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
         else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
+    } else if (m->n <= nice_pc_max() && end > start) {
+        // up to ZH_NICE_PC_MAX voices the three chains of a frame run in three waves side by side (k_nice_pc)
+        if (zf) hipLaunchKernelGGL(k_nice_pc<true>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
+        else hipLaunchKernelGGL(k_nice_pc<false>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
     } else {
         if (zf) hipLaunchKernelGGL((k_nice<true, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
         else hipLaunchKernelGGL((k_nice<false, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
