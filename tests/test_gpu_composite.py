@@ -34,7 +34,7 @@ def _oracle_nice(po, V, freq, color, script):
 
 def test_nice_fused_equals_unfused_oracle(ctx, oracle):
     from zang_amd import modules as mod, zang, workloads
-    V = 320
+    V = 300                                  # the last wave has idle lanes (and even, for the W = 2 variant)
     freq, color, _, _ = workloads.voice_params(5, 0, V)
     freq[:3] = [7000.0, -3.0, 0.5]          # silent / silent / very low
     refs, rst = _oracle_nice(oracle, V, freq, color, SCRIPT)
@@ -51,6 +51,30 @@ def test_nice_fused_equals_unfused_oracle(ctx, oracle):
     util.assert_bitexact(st["flt"]["b"].astype(np.float32), np.array([r.flt.b for r in rst], np.float32), "nice flt.b")
     assert [int(x) for x in st["env"]["state"]] == [r.env.state for r in rst]
     util.assert_bitexact(st["env"]["last_value"].astype(np.float32), np.array([r.env.painter.last_value for r in rst], np.float32), "nice env")
+
+
+@pytest.mark.parametrize("V", [1, 65])
+@pytest.mark.parametrize("zero_first", [False, True])
+def test_nice_few_voices_short_spans(ctx, oracle, V, zero_first):
+    """One voice and one-past-a-wave, spans shorter than the pipeline's 32-frame tile, `+=` onto a non-zero image."""
+    from zang_amd import modules as mod, zang, workloads
+    freq, color, _, _ = workloads.voice_params(5, 3, V)
+    script = [((0, 7), 1, 1), ((7, 40), 1, 0), ((40, 41), 1, 0), ((41, 1000), 0, 0), ((1000, 1024), 1, 1), ((3, 3), 0, 0), ((0, 1024), 0, 0)]
+    refs, rst = _oracle_nice(oracle, V, freq, color, script)
+    m = mod.NiceInstrument(V, util.dev(color), ctx)
+    gf = util.dev(freq)
+    base = util.rng_buffers(23, V, F)
+    for k, ((s, e), on, nic) in enumerate(script):
+        out = util.to_image(base)
+        m.paint(zang.Span(s, e), [out], None, bool(nic), m.Params(SR, gf, bool(on)), zero_first=zero_first)
+        ctx.sync()
+        ref = base.copy()
+        ref[:, s:e] = (0.0 if zero_first else base[:, s:e]) + refs[k][:, s:e]
+        util.assert_bitexact(util.from_image(out), ref, f"nice V={V} paint {k}")
+    st = m.state()
+    assert [int(x) for x in st["osc"]["cnt"]] == [r.osc.cnt for r in rst]
+    util.assert_bitexact(st["flt"]["l"].astype(np.float32), np.array([r.flt.l for r in rst], np.float32), "flt.l")
+    assert [int(x) for x in st["env"]["state"]] == [r.env.state for r in rst]
 
 
 def test_nice_equals_gpu_unfused_modules(ctx):
@@ -169,6 +193,42 @@ def test_noise_filter_fused_equals_unfused(ctx, oracle, color, ftype):
     assert [[int(x) for x in row] for row in st["noise"]["r"]] == rs
 
 
+@pytest.mark.parametrize("V", [1, 65])
+@pytest.mark.parametrize("zero_first", [False, True])
+def test_noise_filter_few_voices_short_spans(ctx, oracle, V, zero_first):
+    """One voice and one-past-a-wave through the two-wave pipeline: spans shorter than its 32-frame tile, a span that is
+    not a multiple of it, an empty span; pink noise, low-pass; `+=` and ZERO_FIRST."""
+    from zang_amd import modules as mod, zang
+    first, color, ftype = 77, 1, 0
+    rng = np.random.default_rng(29)
+    cutoff = rng.uniform(0.0, 1.0, V).astype(np.float32); res = rng.uniform(0.0, 1.0, V).astype(np.float32)
+    spans = [(0, 5), (5, 37), (37, 37), (37, 38), (38, 1001), (1001, 1024)]
+    base = util.rng_buffers(31, V, F)
+    L = oracle.lib()
+    temp = np.zeros(F, np.float32)
+    nzs, fls = [], []
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + v); nzs.append(nz)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+    m = mod.NoiseFilter(V, ctx, first_seed=first)
+    gc, gr = util.dev(cutoff), util.dev(res)
+    for (s, e) in spans:
+        ref = base.copy()
+        if zero_first:
+            ref[:, s:e] = 0.0
+        for v in range(V):
+            L.zo_zero(s, e, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nzs[v]), s, e, oracle.fptr(temp), color)
+            L.zo_filter_paint(C.byref(fls[v]), s, e, oracle.fptr(ref[v]), oracle.fptr(temp), ftype, oracle.constant(cutoff[v]), oracle.constant(res[v]))
+        out = util.to_image(base)
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(color, ftype, gc, gr), zero_first=zero_first)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"noise_filter V={V} span {(s, e)}")
+    st = m.state()
+    util.assert_bitexact(st["flt"]["l"].astype(np.float32), np.array([f.l for f in fls], np.float32), "l")
+    assert [[int(x) for x in row] for row in st["noise"]["r"]] == [list(n.r) for n in nzs]
+
+
 @pytest.mark.gpu
 def test_nice_two_voices_per_lane_variant_is_bit_identical():
     """ZH_NICE_W=2 (lanes.cuh: packed-f32 voice pairs, off by default because it measured slower) must give
@@ -195,10 +255,10 @@ def test_noise_filter_single_wave_form_is_bit_identical():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZH_NF_PC_MAX="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
-                        "noise_filter_fused_equals_unfused"],
+                        "noise_filter_fused_equals_unfused or noise_filter_few_voices_short_spans"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "8 passed" in r.stdout
+    assert "12 passed" in r.stdout
 
 
 @pytest.mark.gpu
@@ -211,7 +271,7 @@ def test_nice_single_wave_form_is_bit_identical():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZH_NICE_PC_MAX="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
-                        "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules"],
+                        "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules or nice_few_voices_short_spans"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
+    assert "6 passed" in r.stdout
