@@ -407,7 +407,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, zero+paint per 1024-frame buffer, 48 kHz",
+        "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, zero+paint per {F}-frame buffer, 48 kHz",
                    "voices_per_gpu": V, "frames": F, "ring_images": wl.nring, "launch": "eager" if graph is None else f"hipGraph x{G} steps", "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": wl.kernel,
