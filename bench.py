@@ -94,7 +94,7 @@ class Workload:
             self.res = torch.from_numpy((0.9 * u3)).to(dev)
             self.ring = [ctx.image(F, V) for _ in range(nring)]
             self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
-            self.kernel = "k_noise_filter"
+            self.kernel = "k_noise_filter_pc" if V <= 65536 else "k_noise_filter"     # the library's choice by voice count
             self.step = self._step_noise_filter_fused
         elif name == "script":
             # a zangscript module compiled to ONE fused kernel at start-up (hiprtc): `Lead` of the repo's test
@@ -110,7 +110,7 @@ class Workload:
         elif name == "nice":
             self.m = mod.NiceInstrument(V, self.color, ctx)
             self.ring = [ctx.image(F, V) for _ in range(nring)]
-            self.kernel = "k_nice"
+            self.kernel = "k_nice_pc" if V <= 65536 else "k_nice"
             self.step = self._step_nice
             self.nsteps = 0
         else:
