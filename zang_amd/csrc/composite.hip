@@ -187,63 +187,56 @@ __global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t s
     const uint32_t n_frames = end - start, nchunks = (n_frames + CH - 1) / CH;
     NiceLane n;
     nice_load<1>(n, a, vc);
-    if (role < 2) {
-        float (*tile)[CH][64] = role == 0 ? osc_t : env_t;
-        for (uint32_t c = 0; c < nchunks; c++) {
+    const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
+    // software pipeline, one barrier per step in uniform control flow: in step c the producers fill tile c while the
+    // filter wave drains tile c-1 (the other LDS buffer); nchunks + 1 steps
+    for (uint32_t c = 0; c <= nchunks; c++) {
+        if (role == 0 && c < nchunks) {
             const uint32_t nf = min(CH, n_frames - c * CH);
-            float (*t)[64] = tile[c & 1];
-            if (role == 0) {
-                auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
-                    t[k][lane] = n.osc(n.cnt);
-                    n.cnt = n.bad ? n.cnt : n.cnt + n.k.ifreq;
-                };
-                if (nf == CH) {
+            float (*t)[64] = osc_t[c & 1];
+            auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                t[k][lane] = n.osc(n.cnt);
+                n.cnt = n.bad ? n.cnt : n.cnt + n.k.ifreq;
+            };
+            if (nf == CH) {
 #pragma unroll 8
-                    for (uint32_t k = 0; k < CH; k++) one(k);
-                } else {
-                    for (uint32_t k = 0; k < nf; k++) one(k);
-                }
+                for (uint32_t k = 0; k < CH; k++) one(k);
             } else {
-                if (nf == CH) {
-#pragma unroll 8
-                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
-                } else {
-                    for (uint32_t k = 0; k < nf; k++) t[k][lane] = n.tail_env();
-                }
+                for (uint32_t k = 0; k < nf; k++) one(k);
             }
-            __syncthreads();                                           // tile c is complete; tile c-1 has been consumed
-        }
-        if (live && role == 0) a.cnt[v] = n.cnt;
-        if (live && role == 1) { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
-    } else {
-        const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
-        for (uint32_t c = 0; c < nchunks; c++) {
+        } else if (role == 1 && c < nchunks) {
             const uint32_t nf = min(CH, n_frames - c * CH);
-            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + c * CH);
-            float oc[CH];
-            if (!ZF) {
-#pragma unroll
-                for (uint32_t k = 0; k < CH; k++) oc[k] = k < nf ? zrow_load<1>(ro, voff, k * orow) : 0.0f;
+            float (*t)[64] = env_t[c & 1];
+            if (nf == CH) {
+#pragma unroll 8
+                for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
+            } else {
+                for (uint32_t k = 0; k < nf; k++) t[k][lane] = n.tail_env();
             }
-            __syncthreads();                                           // wait for tile c
-            const float (*to)[64] = osc_t[c & 1];
-            const float (*te)[64] = env_t[c & 1];
-            float xo[CH], xe[CH];                                      // both tile columns first: one LDS wait per tile
-#pragma unroll
-            for (uint32_t k = 0; k < CH; k++) { xo[k] = to[k][lane]; xe[k] = te[k][lane]; }
+        } else if (role == 2 && c > 0) {
+            const uint32_t d = c - 1, nf = min(CH, n_frames - d * CH);
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
+            const float (*to)[64] = osc_t[d & 1];
+            const float (*te)[64] = env_t[d & 1];
             auto one = [&](uint32_t k, float t0, float e0, float o) ZH_INLINE_LAMBDA {
                 const float t1 = n.tail_filter(t0);
                 zrow_store<1>(ro, voff, k * orow, o + e0 * t1);        // multiply :246: out += temps[0]*temps[1]
             };
             if (nf == CH) {
+                float xo[CH], xe[CH], oc[CH];                          // both tile columns first: one LDS wait per tile
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, xo[k], xe[k], ZF ? 0.0f : oc[k]);
+                for (uint32_t k = 0; k < CH; k++) { xo[k] = to[k][lane]; xe[k] = te[k][lane]; oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow); }
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, xo[k], xe[k], oc[k]);
             } else {
                 for (uint32_t k = 0; k < nf; k++) one(k, to[k][lane], te[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
             }
         }
-        if (live) { a.fl[v] = n.l; a.fb[v] = n.b; }
+        __syncthreads();
     }
+    if (live && role == 0) a.cnt[v] = n.cnt;
+    if (live && role == 1) { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
+    if (live && role == 2) { a.fl[v] = n.l; a.fb[v] = n.b; }
 }
 
 // Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
@@ -659,7 +652,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter(uint64_t *__restrict
 // meet in a single value: the noise sample (xoshiro256++, float conversion, pink taps: ~26 instructions) and
 // the filter (~22).  Here one workgroup of TWO waves owns 64 voices: wave 0 produces noise one tile of 32
 // frames ahead into LDS ([frame][voice], conflict-free), wave 1 filters the previous tile and writes the image;
-// one barrier per 32 frames.  Same per-voice operations in the same order => same bits as k_noise_filter.
+// one barrier per 32 frames (a single call site, in uniform control flow).  Same per-voice operations in the same
+// order => same bits as k_noise_filter.
 template <bool ZF, bool PINK>
 __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
                                                          uint64_t *__restrict__ s2, uint64_t *__restrict__ s3,
@@ -675,14 +669,21 @@ __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ 
     const bool live = v < V;                                           // no early return: both waves meet at the barriers
     const uint32_t vc = live ? v : V - 1;
     const uint32_t n = end - start, nchunks = (n + CH - 1) / CH;
-    if (producer) {
-        ZXoshiro r{s0[vc], s1[vc], s2[vc], s3[vc]};
-        float pb[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (PINK) {
+    // producer state (wave 0) / consumer state (wave 1); the other wave's copy is loaded but never used
+    ZXoshiro r{s0[vc], s1[vc], s2[vc], s3[vc]};
+    float pb[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (PINK) {
 #pragma unroll
-            for (int j = 0; j < 7; j++) pb[j] = bst[(size_t)j * V + vc];
-        }
-        for (uint32_t c = 0; c < nchunks; c++) {
+        for (int j = 0; j < 7; j++) pb[j] = bst[(size_t)j * V + vc];
+    }
+    const float cut = zclampf(cutoff.get(vc), 0.0f, 1.0f);             // Filter.zig:114
+    const float res = 1.0f - zclampf(res_p.get(vc), 0.0f, 1.0f);       // :118
+    float l = l_io[vc], b = b_io[vc];
+    const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
+    // software pipeline, one barrier per step in uniform control flow: in step c the producer fills tile c while the
+    // consumer drains tile c-1 (the other LDS buffer); nchunks + 1 steps
+    for (uint32_t c = 0; c <= nchunks; c++) {
+        if (producer && c < nchunks) {
             const uint32_t nf = min(CH, n - c * CH);
             float (*t)[64] = tile[c & 1];
             auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
@@ -695,27 +696,10 @@ __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ 
             } else {
                 for (uint32_t k = 0; k < nf; k++) one(k);
             }
-            __syncthreads();                                           // tile c is complete; tile c-1 has been consumed
-        }
-        if (live) { s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3; }
-    } else {
-        const float cut = zclampf(cutoff.get(vc), 0.0f, 1.0f);         // Filter.zig:114
-        const float res = 1.0f - zclampf(res_p.get(vc), 0.0f, 1.0f);   // :118
-        float l = l_io[vc], b = b_io[vc];
-        const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            const uint32_t nf = min(CH, n - c * CH);
-            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + c * CH);
-            float oc[CH];
-            if (!ZF) {
-#pragma unroll
-                for (uint32_t k = 0; k < CH; k++) oc[k] = k < nf ? zrow_load<1>(ro, voff, k * orow) : 0.0f;
-            }
-            __syncthreads();                                           // wait for tile c
-            const float (*t)[64] = tile[c & 1];
-            float x[CH];                                               // the whole tile column first: one LDS wait per tile, not one per frame
-#pragma unroll
-            for (uint32_t k = 0; k < CH; k++) x[k] = t[k][lane];
+        } else if (!producer && c > 0) {
+            const uint32_t d = c - 1, nf = min(CH, n - d * CH);
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
+            const float (*t)[64] = tile[d & 1];
             // lanes past the last voice run voice V-1 again (same state, same noise from the producer's twin lane):
             // their stores repeat V-1's values at V-1's address, so nothing needs masking inside the chain
             auto one = [&](uint32_t k, float nz, float o) ZH_INLINE_LAMBDA {
@@ -725,14 +709,19 @@ __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ 
                 zrow_store<1>(ro, voff, k * orow, o + val);
             };
             if (nf == CH) {
+                float x[CH], oc[CH];                                   // the whole tile column first: one LDS wait per tile, not one per frame
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, x[k], ZF ? 0.0f : oc[k]);
+                for (uint32_t k = 0; k < CH; k++) { x[k] = t[k][lane]; oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow); }
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, x[k], oc[k]);
             } else {
                 for (uint32_t k = 0; k < nf; k++) one(k, t[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
             }
         }
-        if (live) { l_io[v] = l; b_io[v] = b; }
+        __syncthreads();
     }
+    if (live && producer) { s0[v] = r.s0; s1[v] = r.s1; s2[v] = r.s2; s3[v] = r.s3; }
+    if (live && !producer) { l_io[v] = l; b_io[v] = b; }
 }
 
 // bypass: out += noise, filter state untouched (Filter.zig:91-97)
