@@ -105,6 +105,64 @@ def test_noise(ctx, oracle, color):
     assert not gs["b"].any()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_noise_rare_float_paths(ctx, oracle, fused):
+    """Random.float(f32)'s rare branches, reached by crafting the xoshiro state (next() = rotl(s0+s3, 23) + s0):
+    a draw whose high word is 0 (probability 2^-32: the device takes its general leading-zero form behind a
+    wave-uniform test) with 32..40 leading zeros, and a draw below 2^23 (2^-41: a second draw refines the exponent),
+    0 included -- mixed with ordinary lanes in the same wave, in Noise and in the fused Noise->Filter voice."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(41)
+    s3 = [1, 2, 255, 256, 511, 512,                       # rnd = s3 << 23: 40, 39, 33, 32, 32 leading zeros; 512 is ordinary
+          1 << 41, 5 << 41, (2 ** 23 - 1) << 41, 0,       # rnd = s3 >> 41 < 2^23: second draw; rnd == 0
+          (1 << 41) | 1]                                  # rnd = 2^23 + 1: back to the first rare form
+    V = 64 + len(s3)
+    L = oracle.lib()
+    nzs = []
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), 900 + v)
+        if v >= 64:
+            nz.r[0] = 0; nz.r[3] = s3[v - 64]
+            nz.r[1] = int(rng.integers(1, 1 << 63)); nz.r[2] = int(rng.integers(1, 1 << 63))
+        nzs.append(nz)
+    nframes = 40
+    if fused:
+        m = mod.NoiseFilter(V, ctx, first_seed=900)
+        st = m.state()
+        for v in range(64, V):
+            st["noise"]["r"][v] = [int(x) for x in nzs[v].r]
+    else:
+        m = mod.Noise(V, ctx, first_seed=900)
+        st = m.state()
+        for v in range(64, V):
+            st["r"][v] = [int(x) for x in nzs[v].r]
+    m.set_state(st)
+    ref = np.zeros((V, F), np.float32)
+    temp = np.zeros(F, np.float32)
+    cutoff = np.full(V, 0.3, np.float32); res = np.full(V, 0.2, np.float32)
+    for v in range(V):
+        if fused:
+            fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
+            L.zo_zero(0, nframes, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nzs[v]), 0, nframes, oracle.fptr(temp), 0)
+            L.zo_filter_paint(C.byref(fl), 0, nframes, oracle.fptr(ref[v]), oracle.fptr(temp), 0, oracle.constant(cutoff[v]), oracle.constant(res[v]))
+        else:
+            L.zo_noise_paint(C.byref(nzs[v]), 0, nframes, oracle.fptr(ref[v]), 0)
+    out = ctx.image(F, V, fill=0.0)
+    if fused:
+        m.paint(zang.Span(0, nframes), [out], None, False, m.Params(0, 0, util.dev(cutoff), util.dev(res)))
+    else:
+        m.paint(zang.Span(0, nframes), [out], [], False, m.Params(0))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "noise rare float paths")
+    gs = m.state()
+    got_r = gs["noise"]["r"] if fused else gs["r"]
+    assert [[int(x) for x in row] for row in got_r] == [list(n.r) for n in nzs]      # the extra draws advanced the generator
+    first = util.from_image(out)[64:, 0] if not fused else None
+    if first is not None:
+        assert (np.abs(first[:5]) > 0.99).all()            # tiny random floats map to white ~ -1
+
+
 def test_noise_seed_known_answer(ctx):
     """K1 of SURVEY.md 8c: seed 0 / seed 1 white samples."""
     from zang_amd import modules as mod, zang
