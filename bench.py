@@ -48,13 +48,14 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of one buffer")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
+    ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
     return ap.parse_args()
 
 
 class Workload:
     """Builds the module(s), resident params and the per-step callable for one rank."""
 
-    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1):
+    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None):
         import torch
         self.world = world
         from zang_amd import modules as mod, zang, workloads
@@ -73,7 +74,7 @@ class Workload:
         self.kernel = None
         if name == "pulseosc":
             self.m = mod.PulseOsc(V, ctx)
-            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.params = self.m.Params(SR, zang.constant(self.freq), self.color)
             self.kernel = "k_osc_const4<PulseOscP>"
             self.step = self._step_pulse
@@ -83,8 +84,8 @@ class Workload:
             cutoff_f = torch.from_numpy((200.0 + 7800.0 * u2)).to(dev)
             self.cutoff = mod.Filter.cutoffFromFrequency(cutoff_f, SR, ctx)
             self.res = torch.from_numpy((0.9 * u3)).to(dev)
-            self.ring = [ctx.image(F, V) for _ in range(nring)]
-            self.temp = ctx.image(F, V)
+            self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
+            self.temp = ctx.image(F, V, pad=pad)
             self.kernel = "k_filter"
             self.step = self._step_noise_filter
         elif name == "noise_filter_fused":
@@ -92,7 +93,7 @@ class Workload:
             cutoff_f = torch.from_numpy((200.0 + 7800.0 * u2)).to(dev)
             self.cutoff = mod.Filter.cutoffFromFrequency(cutoff_f, SR, ctx)
             self.res = torch.from_numpy((0.9 * u3)).to(dev)
-            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
             self.kernel = "k_noise_filter_pc" if V <= 65536 else "k_noise_filter"     # the library's choice by voice count
             self.step = self._step_noise_filter_fused
@@ -103,13 +104,13 @@ class Workload:
             text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "script_modules.txt")).read()
             self.program = zscript.ScriptProgram(text, ctx, only=[SCRIPT_MODULE])
             self.m = self.program.module(SCRIPT_MODULE, V)
-            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.kernel = "zs_paint_" + SCRIPT_MODULE
             self.step = self._step_script
             self.nsteps = 0
         elif name == "nice":
             self.m = mod.NiceInstrument(V, self.color, ctx)
-            self.ring = [ctx.image(F, V) for _ in range(nring)]
+            self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.kernel = "k_nice_pc" if V <= 65536 else "k_nice"
             self.step = self._step_nice
             self.nsteps = 0
@@ -333,7 +334,7 @@ def main():
     torch.cuda.set_stream(side)
     ctx = zang_amd.Context(device_index)
     V, F = args.voices, args.frames
-    wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20, world=world)
+    wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20, world=world, pad=args.pad_voices)
     lib = ctx.lib
 
     def barrier():

@@ -2,6 +2,7 @@
 // written by one launch, graph-replayed over a 32-image ring?  Variants: store flavour, frames per
 // lane, threads per block.  Build: hipcc --offload-arch=gfx950 -O3 store_floor.hip -o store_floor
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -106,8 +107,12 @@ __global__ void k_fill(float *out, size_t n4, float val) {
     }
 }
 
-int main() {
-    const unsigned V = 4096, F = 1024, R = 32;
+int main(int argc, char **argv) {
+    // usage: store_floor [voices]   (default 4096 = the bench's 16 MiB image; the ring stays <= 8 GiB)
+    const unsigned V = argc > 1 ? (unsigned)strtoul(argv[1], nullptr, 10) : 4096, F = 1024;
+    const size_t img = (size_t)V * F * 4;
+    const unsigned R = (unsigned)std::max<size_t>(2, std::min<size_t>(32, ((size_t)8 << 30) / img));
+    printf("# %u voices x %u frames = %.0f MiB per launch, ring of %u images\n", V, F, img / 1048576.0, R);
     std::vector<float *> ring(R);
     for (auto &p : ring) CK(hipMalloc(&p, (size_t)V * F * 4));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

@@ -111,13 +111,17 @@ int zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) 
 int zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames) {
     if (!ctx || !out) return ZH_ERR_INVALID;
     memset(out, 0, sizeof *out);
+    // A lane-per-voice kernel's consecutive stores are one row apart.  When a row is a multiple of 64 KiB they all
+    // land on the same HBM channel and bank; 1 KiB of padding per row spreads them (measured on the chunked
+    // oscillator: 65,536 voices 57.6 -> 54.4 us, 1 Mi voices 799 -> 768 us per 1024-frame image).
+    const uint32_t stride = (voices != 0 && ((size_t)voices * sizeof(float)) % 65536 == 0) ? voices + 256 : voices;
     void *p = nullptr;
-    int rc = zh_malloc(ctx, &p, (size_t)voices * frames * sizeof(float));
+    int rc = zh_malloc(ctx, &p, (size_t)stride * frames * sizeof(float));
     if (rc) return rc;
     out->ptr = (float *)p;
     out->voices = voices;
     out->frames = frames;
-    out->stride = voices;
+    out->stride = stride;
     return ZH_OK;
 }
 

@@ -56,11 +56,21 @@ class Context:
         abi.check(rc, "zh_graph_end_capture")
         return Graph(self, g)
 
-    def image(self, frames, voices, fill=None):
-        """A [frame][voice] sample image (the device form of `voices` reference []f32 slices)."""
+    def image(self, frames, voices, fill=None, pad=None):
+        """A [frame][voice] sample image (the device form of `voices` reference []f32 slices).
+        `pad` = extra voices per row (row stride = voices + pad); None = image_row_pad(voices)."""
+        pad = image_row_pad(voices) if pad is None else int(pad)
         if fill is None:
-            return torch.empty((frames, voices), dtype=torch.float32, device=self.device)
-        return torch.full((frames, voices), float(fill), dtype=torch.float32, device=self.device)
+            t = torch.empty((frames, voices + pad), dtype=torch.float32, device=self.device)
+        else:
+            t = torch.full((frames, voices + pad), float(fill), dtype=torch.float32, device=self.device)
+        return t[:, :voices] if pad else t
+
+
+def image_row_pad(voices):
+    """Row padding (in voices) Context.image gives an image by default: zh_buf_alloc's rule (ctx.hip) -- rows that
+    are a multiple of 64 KiB get 1 KiB more, so that a lane's consecutive frames do not all map to one HBM bank."""
+    return 256 if voices and (voices * 4) % 65536 == 0 else 0
 
 
 class Graph:
