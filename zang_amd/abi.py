@@ -457,6 +457,8 @@ def load(strict=True):
     # PyTorch bundles its own libamdhip64; load it first so that libzang_hip.so binds to the same HIP
     # runtime (two runtimes in one process cannot both see the device).
     import torch  # noqa: F401
+    global LIB_PATH
+    LIB_PATH = os.environ.get("ZANG_HIP_LIB", LIB_PATH)       # A/B timing of alternative builds of the same library
     if not os.path.exists(LIB_PATH):
         raise ZangHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -61,10 +61,44 @@ __device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k
     const M b0 = cnt < k.brpt;
     const M b1 = (cnt - k.ifreq) < k.brpt;
     const M b2 = cnt < k.ifreq;
-    const F ramp = k.gdf2 * zsel(b2, p, k.col - p) + zsel(b2, ngain, gain);
-    const F flat = zsel(b2, zsel(b0, k.cc121, k.cc212), zsel(b0, gain, ngain));
+    // sg = the flat level of this half period.  In the two ramp cases b2 == b0 (table above), and the ramp's
+    // offset is -sg: `x + (-0.7)` and `x - 0.7` are the same IEEE operation, so one select serves both.
+    const F sg = zsel(b0, gain, ngain);
+    const F ramp = k.gdf2 * zsel(b0, p, k.col - p) - sg;
+    const F flat = zsel(b2, zsel(b0, k.cc121, k.cc212), sg);
     return zsel(b0 == b1, flat, ramp);
 }
+
+// The same sample for a walker that visits consecutive frames: b1 of this frame is b0 of the previous one
+// (cnt_prev = cnt - ifreq exactly, in u32), the reference's own rolling 2-bit state (PulseOsc.zig:97-101).
+// The carried bit travels as the wave's 64-bit lane mask in an SGPR pair (ballot / inverse ballot): comparing it
+// with this frame's mask is one scalar xnor, and no per-lane 0/1 value is ever materialised.  `prev` must start
+// as pulse_roll_init(k, cnt) at the first frame of a paint call (the per-voice constants may have changed since
+// the last call).  Lanes that are inactive at a ballot contribute 0 bits that only they would read.
+// (Not for hiprtc: its compiler lacks the inverse-ballot builtin; generated script kernels use pulse_sample.)
+#if !defined(__HIPCC_RTC__)
+typedef unsigned long long PulseRoll;
+__device__ __forceinline__ PulseRoll pulse_roll_init(const PulseK &k, uint32_t cnt) {
+    return __builtin_amdgcn_ballot_w64((cnt - k.ifreq) < k.brpt);
+}
+__device__ __forceinline__ float pulse_sample_roll(const PulseK &k, uint32_t cnt, PulseRoll &prev) {
+#if defined(ZH_NO_PULSE_ROLL)                                        // A/B builds: the stateless form
+    (void)prev;
+    return pulse_sample<1>(k, cnt);
+#endif
+    const float gain = 0.7f, ngain = -0.7f;
+    const float p = zutof23(cnt);
+    const bool b0 = cnt < k.brpt;
+    const bool b2 = cnt < k.ifreq;
+    const float sg = b0 ? gain : ngain;
+    const float ramp = k.gdf2 * (b0 ? p : k.col - p) - sg;
+    const float flat = b2 ? (b0 ? k.cc121 : k.cc212) : sg;
+    const PulseRoll m0 = __builtin_amdgcn_ballot_w64(b0);
+    const bool same = __builtin_amdgcn_inverse_ballot_w64(~(m0 ^ prev));   // b0 == b1
+    prev = m0;
+    return same ? flat : ramp;
+}
+#endif   // !__HIPCC_RTC__
 
 // ---- Filter (src/modules/Filter.zig:130-146): one 2x-oversampled state-variable step ------------
 template <class F> struct SvfOutT { F l, b, h; };

@@ -42,6 +42,10 @@ struct PulseOscP {        // policy for the chunked kernels
         pulse_setup_freq(k, srf, freq);
     }
     static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return pulse_sample(k, cnt); }
+    // walking consecutive frames: the previous frame's half-period bit is carried instead of recomputed
+    using R = PulseRoll;
+    static __device__ __forceinline__ R roll_init(const K &k, uint32_t cnt) { return pulse_roll_init(k, cnt); }
+    static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &r) { return pulse_sample_roll(k, cnt, r); }
 };
 
 struct TriSawOscP;        // defined below
@@ -71,9 +75,10 @@ __global__ void __launch_bounds__(256) k_osc_const(const uint32_t *__restrict__ 
         return;
     }
     uint32_t cnt = cnt0 + (c0 - start) * k.ifreq;
+    typename OSC::R roll = OSC::roll_init(k, cnt);
 #pragma unroll 4
     for (uint32_t i = c0; i < c1; i++, o += os) {
-        const float val = OSC::sample(k, cnt);
+        const float val = OSC::sample_roll(k, cnt, roll);
         *o = (ZF ? 0.0f : *o) + val;
         cnt += k.ifreq;
     }
@@ -129,8 +134,9 @@ __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__
         cnt0[0] = w[KW].x; cnt0[1] = w[KW].y; cnt0[2] = w[KW].z; cnt0[3] = w[KW].w;
         bad[0] = w[KW + 1].x != 0; bad[1] = w[KW + 1].y != 0; bad[2] = w[KW + 1].z != 0; bad[3] = w[KW + 1].w != 0;
     }
+    typename OSC::R roll[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq;
+    for (int j = 0; j < 4; j++) { cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq; roll[j] = OSC::roll_init(k[j], cnt[j]); }
     if (chunk == 0) {
         uint4 o;
         o.x = bad[0] ? cnt0[0] : cnt0[0] + (end - start) * k[0].ifreq;
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__
             float val[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                val[j] = OSC::sample(k[j], cnt[j]);
+                val[j] = OSC::sample_roll(k[j], cnt[j], roll[j]);
                 cnt[j] += k[j].ifreq;
             }
             if (ZF) { acc.x = val[0]; acc.y = val[1]; acc.z = val[2]; acc.w = val[3]; }
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__
         float val[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            val[j] = OSC::sample(k[j], cnt[j]);
+            val[j] = OSC::sample_roll(k[j], cnt[j], roll[j]);
             cnt[j] += k[j].ifreq;
         }
         // a silent voice (bad freq) paints nothing: out unchanged (ADD) / zero (ZERO_FIRST)
@@ -213,6 +219,9 @@ struct TriSawOscP {
     using K = TriSawK;
     static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) { trisaw_setup(k, srf, freq, color); }
     static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return trisaw_sample(k, cnt); }
+    using R = int;                                          // nothing carried
+    static __device__ __forceinline__ R roll_init(const K &, uint32_t) { return 0; }
+    static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &) { return trisaw_sample(k, cnt); }
 };
 
 // TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt
