@@ -363,8 +363,9 @@ ZH_API int zh_nice_paint_mix(zh_nice *m, uint32_t span_start, uint32_t span_end,
  * the same sequence of paint(sub_span, ..., note_id_changed, params) calls the reference's Trigger loop
  * makes (per-call prologue/epilogue included).  With more than 64 voices a lane owns a voice and the wave walks
  * segments between sub-span boundaries; with up to 64 voices a WAVE owns a voice and its lanes are 64 consecutive
- * frames (the sequential part runs in all lanes, the oscillator / sine part once per 64 frames) -- the same values
- * either way.  Arrays are device memory laid out [span_index][voice]; zh_poly_voice_schedule fills this layout. */
+ * frames (only what truly carries state from frame to frame -- phase and envelope clocks, the filter core -- is
+ * walked frame by frame; oscillator, envelope curve and sines are evaluated for 64 frames at once) -- the same
+ * values either way.  Arrays are device memory laid out [span_index][voice]; zh_poly_voice_schedule fills this layout. */
 typedef struct zh_span_table {
     uint32_t max_spans, reserved;
     const uint32_t *count;                       /* [n_voices]            */
