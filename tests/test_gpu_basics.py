@@ -83,3 +83,31 @@ def test_mixdown_voices(ctx, V):
     bound = 4 * np.sqrt(V) * np.finfo(np.float32).eps * np.abs(src).astype(np.float64).sum(axis=0).max()
     assert np.abs(got - ref).max() <= bound
     assert np.array_equal(got[:3], np.full(3, 0.5, np.float32))
+
+
+@pytest.mark.parametrize("V", [100, 16384])
+def test_buf_alloc_stride_and_round_trip(ctx, V):
+    """zh_buf_alloc pads rows that are a multiple of 64 KiB (stride > voices); uploads, kernels and downloads all
+    address a sample as ptr[frame * stride + voice]."""
+    import ctypes as C
+    from zang_amd import abi
+    lib = ctx.lib
+    frames = 48
+    b = abi.Buf()
+    abi.check(lib.zh_buf_alloc(ctx.handle, C.byref(b), V, frames), "zh_buf_alloc")
+    try:
+        assert b.voices == V and b.frames == frames
+        assert b.stride == (V + 256 if (V * 4) % 65536 == 0 else V)
+        rng = np.random.default_rng(V)
+        host = rng.standard_normal((V, frames)).astype(np.float32)
+        abi.check(lib.zh_buf_upload_voices(ctx.handle, b, host.ctypes.data, frames), "upload")
+        abi.check(lib.zh_multiply_with_scalar(ctx.handle, 5, 40, b, abi.F32(2.0, 0, None)), "multiplyWithScalar")
+        back = np.zeros_like(host)
+        abi.check(lib.zh_buf_download_voices(ctx.handle, back.ctypes.data, b, frames), "download")
+        want = host.copy(); want[:, 5:40] *= np.float32(2.0)
+        assert np.array_equal(back, want)
+        one = np.zeros(frames, np.float32)
+        abi.check(lib.zh_buf_download_voice(ctx.handle, one.ctypes.data, b, V - 1, frames), "download_voice")
+        assert np.array_equal(one, want[V - 1])
+    finally:
+        lib.zh_buf_free(ctx.handle, C.byref(b))
