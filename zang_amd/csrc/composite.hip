@@ -52,7 +52,7 @@ struct NiceLaneT {
     M bad;
     // Filter
     F l, b, cut, res;
-    EnvLaneT<W> env;
+    EnvLaneT<W, ZH_CURVE_CUBED> env;                                  // all three curves are cubed (:238-245)
 
     __device__ __forceinline__ void begin(float sample_rate, float srf, float sr8, F freq, F color, M note_on, M new_note) {
         bad = zor(freq < zsplat<F>(0.0f), freq > zsplat<F>(sr8));      // PulseOsc.zig:82-84
@@ -89,13 +89,7 @@ struct NiceLaneT {
         const SvfOutT<F> s = svf_step(l, b, t0, cut, res);
         return zero + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
     }
-    __device__ __forceinline__ F tail_env() {
-        const F zero = zsplat<F>(0.0f);
-        // temps[0] = 0 (+ envelope)
-        F ev = zero;
-        const M painted = env.frame(ev);
-        return zsel(painted, zero + ev, zero);
-    }
+    __device__ __forceinline__ F tail_env() { return env.frame_masked(); }   // temps[0] = 0 (+ envelope)
     __device__ __forceinline__ F tail(F t0) {
         const F t1 = tail_filter(t0);
         const F e0 = tail_env();
@@ -320,7 +314,7 @@ struct PMOscArgs {
 struct PMLane {
     float tc, tm;                 // carrier.t, modulator.t
     float mod_freq, inv_sr, t_step;
-    EnvLane env;
+    EnvLaneCubed env;                                                 // all three curves are cubed (:118-125)
 
     __device__ __forceinline__ void begin(float sample_rate, float freq, float release_duration, bool note_on, bool new_note) {
         env.sample_rate = sample_rate;                                 // examples/modules.zig:118-125
@@ -347,10 +341,7 @@ struct PMLane {
         tc += t_step;                                                  // carrier: t += t_step (:69-74)
     }
     __device__ __forceinline__ float step_env() {
-        float ev = 0.0f;                                               // envelope -> temps[1] (zeroed)   (:117-125)
-        float e0 = 0.0f;
-        if (env.frame(ev)) e0 = 0.0f + ev;
-        return e0;
+        return env.frame_masked();                                     // envelope -> temps[1] (zeroed)   (:117-125)
     }
     __device__ __forceinline__ void step(float &tm_i, float &tc_i, float &e0) {
         step_phase(tm_i, tc_i);

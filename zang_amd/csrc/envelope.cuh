@@ -53,7 +53,9 @@ enum { ENV_MODE_NONE = 0, ENV_MODE_TOWARD = 1, ENV_MODE_FLAT = 2 };
 // W voices per lane (lanes.cuh).  Everything is selects under masks: conditional stores to
 // different fields of the lane get sunk by LLVM into one store at a variable offset, which forces
 // the lane out of VGPRs -- and with W = 2 the two voices of a lane are rarely in the same stage.
-template <int W>
+// FT >= 0: all three curves are known at compile time to have tag FT (the composite instruments use cubed
+// throughout, examples/modules.zig:118-125, 238-245), so the per-frame curve needs no tag compares or selects.
+template <int W, int FT = -1>
 struct EnvLaneT {
     using F = typename LaneT<W>::F;
     using U = typename LaneT<W>::U;
@@ -69,6 +71,10 @@ struct EnvLaneT {
     // the running stage
     U mode, cur_tag;
     F cur_step, cur_goal;
+    // derived, refreshed wherever mode / start / cur_goal change (begin, stage end): cur_goal - start, and an
+    // all-ones / zero word per voice for mode != NONE (frame_masked)
+    F cur_delta;
+    U m_painted;
 
     static __device__ __forceinline__ U u(uint32_t x) { return zsplatu<U>(x); }
     static __device__ __forceinline__ F f(float x) { return zsplat<F>(x); }
@@ -83,7 +89,7 @@ struct EnvLaneT {
     // paintToward's entry (painter.zig:69-97) for the voices in `on`; returns "finished without painting"
     __device__ __forceinline__ M enter(M on, uint32_t tag, F duration, F goal) {
         const M done = t >= f(1.0f);                              // :69-71
-        const M inst = zand(on, znot(done), zmask<M>(tag == ZH_CURVE_INSTANTANEOUS));   // :76-80
+        const M inst = zand(on, znot(done), zmask<M>(FT < 0 && tag == ZH_CURVE_INSTANTANEOUS));   // :76-80
         t = zsel(inst, f(1.0f), t);
         last_value = zsel(inst, goal, last_value);
         const M fin = zor(done, inst);
@@ -115,6 +121,20 @@ struct EnvLaneT {
         change_state_if(zand(note_on, state == u(ZH_ENV_IDLE)), u(ZH_ENV_ATTACK));
         change_state_if(zand(znot(note_on), state != u(ZH_ENV_IDLE), state != u(ZH_ENV_RELEASE)), u(ZH_ENV_RELEASE));
         resolve(zmask<M>(true));
+        refresh_derived();
+    }
+    __device__ __forceinline__ void refresh_derived() {
+        cur_delta = cur_goal - start;
+        m_painted = zsel(mode != u(ENV_MODE_NONE), u(0xFFFFFFFFu), u(0u));
+    }
+    // the curve of the running stage at clock tn (painter.zig:104-112)
+    __device__ __forceinline__ F curve(F tn) const {
+        const F it = f(1.0f) - tn;
+        if constexpr (FT == ZH_CURVE_CUBED) return f(1.0f) - it * it * it;
+        else if constexpr (FT == ZH_CURVE_SQUARED) return f(1.0f) - it * it;
+        else if constexpr (FT == ZH_CURVE_LINEAR) return tn;
+        else return zsel(cur_tag == u(ZH_CURVE_SQUARED), f(1.0f) - it * it,
+                         zsel(cur_tag == u(ZH_CURVE_CUBED), f(1.0f) - it * it * it, tn));
     }
 
     // One frame.  Returns which voices painted a value.  Straight-line: the paintToward step
@@ -126,10 +146,8 @@ struct EnvLaneT {
         F tn = t + cur_step;
         const M finished = tn >= f(1.0f);
         tn = zsel(finished, f(1.0f), tn);
-        const F it = f(1.0f) - tn;
-        const F tp = zsel(cur_tag == u(ZH_CURVE_SQUARED), f(1.0f) - it * it,
-                          zsel(cur_tag == u(ZH_CURVE_CUBED), f(1.0f) - it * it * it, tn));
-        const F lv = start + tp * (cur_goal - start);              // :114
+        const F tp = curve(tn);
+        const F lv = start + tp * cur_delta;                       // :114 (cur_delta == cur_goal - start)
         t = zsel(toward, tn, t);
         last_value = zsel(toward, lv, last_value);
         val = zsel(toward, lv, sustain_volume);                    // FLAT: Envelope.zig:68-70
@@ -141,8 +159,32 @@ struct EnvLaneT {
                                 zsel(state == u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN), u(ZH_ENV_IDLE)));
             change_state_if(stage_end, next);
             resolve(stage_end);
+            refresh_derived();
         }
         return painted;
+    }
+    // frame() for the callers that want `painted ? 0.0f + value : 0.0f` (the zeroed temp a composite paints the
+    // envelope into): the select is an AND with m_painted, and no mode compare is needed for it
+    __device__ __forceinline__ F frame_masked() {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        F tn = t + cur_step;
+        const M finished = tn >= f(1.0f);
+        tn = zsel(finished, f(1.0f), tn);
+        const F lv = start + curve(tn) * cur_delta;                // :114
+        t = zsel(toward, tn, t);
+        last_value = zsel(toward, lv, last_value);
+        const F val = zsel(toward, lv, sustain_volume);            // FLAT: Envelope.zig:68-70
+        const F e0 = zbits_f(zbits_u(f(0.0f) + val) & m_painted);
+        const M stage_end = zand(toward, finished);
+        if (zany(stage_end)) {                                     // Envelope.zig:53-58, 63-65, 86-88
+            const U after_attack = zsel(sustain_volume < f(1.0f), u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN));
+            const U next = zsel(state == u(ZH_ENV_ATTACK), after_attack,
+                                zsel(state == u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN), u(ZH_ENV_IDLE)));
+            change_state_if(stage_end, next);
+            resolve(stage_end);
+            refresh_derived();
+        }
+        return e0;
     }
 
     // ---- one voice per WAVE: the lanes are 64 consecutive frames (W = 1, every field wave-uniform) ----
@@ -170,9 +212,7 @@ struct EnvLaneT {
             const uint64_t fm = __builtin_amdgcn_ballot_w64(fin);
             const uint32_t jf = fm ? (uint32_t)__builtin_ctzll(fm) : nf;   // the frame that finishes the stage (none: nf)
             const float tn = fin ? 1.0f : tn_raw;
-            const float it = 1.0f - tn;
-            const float tp = cur_tag == ZH_CURVE_SQUARED ? 1.0f - it * it : (cur_tag == ZH_CURVE_CUBED ? 1.0f - it * it * it : tn);
-            const float lv = start + tp * (cur_goal - start);          // painter.zig:114
+            const float lv = start + curve(tn) * (cur_goal - start);   // painter.zig:114
             mine = (in && lane <= jf) ? 0.0f + lv : mine;
             const uint32_t last = jf < nf ? jf : nf - 1;               // state as of the stage's last painted frame
             t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tn), (int)last));
@@ -182,12 +222,14 @@ struct EnvLaneT {
             const U next = zsel(state == u(ZH_ENV_ATTACK), after_attack, zsel(state == u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN), u(ZH_ENV_IDLE)));
             change_state_if(zmask<M>(true), next);
             resolve(zmask<M>(true));
+            refresh_derived();
             j0 = jf + 1;
         }
         return mine;
     }
 };
 using EnvLane = EnvLaneT<1>;
+using EnvLaneCubed = EnvLaneT<1, ZH_CURVE_CUBED>;      // the composite instruments' envelopes
 
 // Envelope.Params (Envelope.zig:6-13) as the kernels see them: tags shared, values per voice.
 struct EnvParamsP {

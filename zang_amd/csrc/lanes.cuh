@@ -54,6 +54,8 @@ template <> ZL bool zmask<bool>(bool b) { return b; }
 template <> ZL zm2 zmask<zm2>(bool b) { const int32_t x = b ? -1 : 0; return zm2{x, x}; }
 ZL zm2 zmask2(bool b0, bool b1) { return zm2{b0 ? -1 : 0, b1 ? -1 : 0}; }
 // bit casts
+ZL uint32_t zbits_u(float x) { return __builtin_bit_cast(uint32_t, x); }
+ZL zu2 zbits_u(zf2 x) { return __builtin_bit_cast(zu2, x); }
 ZL float zbits_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 ZL zf2 zbits_f(zu2 u) { return __builtin_bit_cast(zf2, u); }
 
