@@ -50,6 +50,7 @@ struct NiceLaneT {
     U cnt;
     PulseKT<W> k;
     M bad;
+    F g, ng;                                                          // +-0.7, or +0.0 / +0.0 for a silent voice
     // Filter
     F l, b, cut, res;
     EnvLaneT<W, ZH_CURVE_CUBED> env;                                  // all three curves are cubed (:238-245)
@@ -57,6 +58,14 @@ struct NiceLaneT {
     __device__ __forceinline__ void begin(float sample_rate, float srf, float sr8, F freq, F color, M note_on, M new_note) {
         bad = zor(freq < zsplat<F>(0.0f), freq > zsplat<F>(sr8));      // PulseOsc.zig:82-84
         pulse_setup(k, srf, freq, color);
+        // A silent voice paints nothing and keeps its phase counter.  Expressed in the constants instead of two
+        // selects per sample: with everything zeroed, b0 = b1 = b2 = false, the sample is ngain = +0.0 and
+        // cnt + ifreq == cnt.
+        const F zf = zsplat<F>(0.0f);
+        const typename LaneT<W>::U zu = zsplatu<typename LaneT<W>::U>(0u);
+        k.ifreq = zsel(bad, zu, k.ifreq); k.brpt = zsel(bad, zu, k.brpt);
+        k.gdf2 = zsel(bad, zf, k.gdf2); k.cc121 = zsel(bad, zf, k.cc121); k.cc212 = zsel(bad, zf, k.cc212);
+        g = zsel(bad, zf, zsplat<F>(0.7f)); ng = zsel(bad, zf, zsplat<F>(-0.7f));
         // Filter params: cutoff = cutoffFromFrequency(freq * 8, sr), res = 0.7 (examples/modules.zig:231-235)
         const F f8 = freq * 8.0f;
 #pragma unroll
@@ -78,8 +87,8 @@ struct NiceLaneT {
     // the envelope, which carry state from frame to frame; returns env*flt (the value added to out).
     __device__ __forceinline__ F osc(U c) const {
         const F zero = zsplat<F>(0.0f);
-        const F pv = zero + pulse_sample<W>(k, c);                     // temps[0] = 0 (+ pulse); a silent voice (bad freq) leaves it 0
-        return zsel(bad, zero, pv) * 0.5f;                             // multiplyWithScalar :226
+        const F pv = zero + pulse_sample<W>(k, c, g, ng);              // temps[0] = 0 (+ pulse); a silent voice (bad freq) leaves it 0
+        return pv * 0.5f;                                              // multiplyWithScalar :226
     }
     // tail = two chains that never read each other's state: the filter over the oscillator samples and
     // the envelope; their product is the value added to out.
@@ -97,7 +106,7 @@ struct NiceLaneT {
     }
     __device__ __forceinline__ F frame() {
         const F t0 = osc(cnt);
-        cnt = zsel(bad, cnt, cnt + k.ifreq);
+        cnt = cnt + k.ifreq;
         return tail(t0);
     }
     // The oscillator half for a walker in which every active lane takes every frame in order from a begin()
@@ -110,9 +119,9 @@ struct NiceLaneT {
     }
     __device__ __forceinline__ F osc_next(PulseRoll &roll) {
         const F zero = zsplat<F>(0.0f);
-        const F pv = zero + pulse_sample_roll(k, cnt, roll);
-        cnt = zsel(bad, cnt, cnt + k.ifreq);
-        return zsel(bad, zero, pv) * 0.5f;
+        const F pv = zero + pulse_sample_roll(k, cnt, roll, g, ng);
+        cnt = cnt + k.ifreq;
+        return pv * 0.5f;
     }
 };
 using NiceLane = NiceLaneT<1>;
@@ -465,7 +474,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice_spans(NiceArgs a, SpanTableP
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
     n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
-    n.bad = true; n.k = PulseK{0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; n.cut = n.res = 0.0f;
+    n.bad = true; n.k = PulseK{0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; n.g = n.ng = 0.0f; n.cut = n.res = 0.0f;
     const float color = a.color[v];
     span_walk<ZF>(n, tb, a.V, v, live, out, start, end,
                   [&](float freq, bool on, bool nic) ZH_INLINE_LAMBDA { n.begin(a.sample_rate, a.srf, a.sr8, freq, color, on, nic); },
@@ -510,7 +519,7 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
     n.env.state = a.estate[v]; n.env.t = a.et[v]; n.env.last_value = a.elast[v]; n.env.start = a.estart[v];
-    n.bad = true; n.k = PulseK{0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; n.cut = n.res = 0.0f;
+    n.bad = true; n.k = PulseK{0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; n.g = n.ng = 0.0f; n.cut = n.res = 0.0f;
     const float color = a.color[v];
     const uint32_t cnt = min(tb.count[v], tb.K);
     float *col = out.p + v;

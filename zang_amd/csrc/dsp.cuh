@@ -52,11 +52,13 @@ __device__ __forceinline__ zf2 zutof23(zu2 x) { return zbits_f((x >> 9) | 0x3f80
 // Values are selected, never blended (gdf is inf when ifreq < 512).
 // The result is never -0.0: every arm ends in `x + gain` / `x - gain` with gain = 0.7, and an IEEE
 // sum is -0.0 only when both addends are -0.0.
+// `gain` / `ngain` are +-0.7 (PulseOsc.zig:88); a caller may pass per-voice values to silence a voice without a
+// per-sample select: with k zeroed and gain = ngain = +0.0 every sample is +0.0 and cnt + ifreq == cnt.
 template <int W>
-__device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k, typename LaneT<W>::U cnt) {
+__device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k, typename LaneT<W>::U cnt,
+                                                             typename LaneT<W>::F gain, typename LaneT<W>::F ngain) {
     using F = typename LaneT<W>::F;
     using M = typename LaneT<W>::M;
-    const F gain = zsplat<F>(0.7f), ngain = zsplat<F>(-0.7f);
     const F p = zutof23(cnt);
     const M b0 = cnt < k.brpt;
     const M b1 = (cnt - k.ifreq) < k.brpt;
@@ -67,6 +69,12 @@ __device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k
     const F ramp = k.gdf2 * zsel(b0, p, k.col - p) - sg;
     const F flat = zsel(b2, zsel(b0, k.cc121, k.cc212), sg);
     return zsel(b0 == b1, flat, ramp);
+}
+
+template <int W>
+__device__ __forceinline__ typename LaneT<W>::F pulse_sample(const PulseKT<W> &k, typename LaneT<W>::U cnt) {
+    using F = typename LaneT<W>::F;
+    return pulse_sample<W>(k, cnt, zsplat<F>(0.7f), zsplat<F>(-0.7f));
 }
 
 // The same sample for a walker that visits consecutive frames: b1 of this frame is b0 of the previous one
@@ -81,12 +89,11 @@ typedef unsigned long long PulseRoll;
 __device__ __forceinline__ PulseRoll pulse_roll_init(const PulseK &k, uint32_t cnt) {
     return __builtin_amdgcn_ballot_w64((cnt - k.ifreq) < k.brpt);
 }
-__device__ __forceinline__ float pulse_sample_roll(const PulseK &k, uint32_t cnt, PulseRoll &prev) {
+__device__ __forceinline__ float pulse_sample_roll(const PulseK &k, uint32_t cnt, PulseRoll &prev, float gain = 0.7f, float ngain = -0.7f) {
 #if defined(ZH_NO_PULSE_ROLL)                                        // A/B builds: the stateless form
     (void)prev;
-    return pulse_sample<1>(k, cnt);
+    return pulse_sample<1>(k, cnt, gain, ngain);
 #endif
-    const float gain = 0.7f, ngain = -0.7f;
     const float p = zutof23(cnt);
     const bool b0 = cnt < k.brpt;
     const bool b2 = cnt < k.ifreq;
