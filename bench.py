@@ -124,14 +124,20 @@ class Workload:
         self.nring = len(self.ring)
         self.i = 0
 
-    def graph_steps(self):
-        """Steps per captured graph: a whole number of ring rotations, even (see bench main)."""
+    def graph_steps(self, steps=0):
+        """Steps per captured graph: at least one ring rotation, even (see bench main); when some even count
+        between one and four rotations divides the timed step count, that one, so that no remainder of the K
+        timed steps has to be launched one by one from Python (~2x slower per step at the 16 MiB size)."""
         if self.name == "nice_mix" and self.world > 1:
             return 0                        # the per-buffer all-reduce is issued by torch.distributed: eager
         if self.name in ("nice", "nice_mix", "script"):
             return 48                       # the note on/off pattern repeats every 48 buffers
         g = max(self.nring, 2)
-        return g if g % 2 == 0 else 2 * g
+        g = g if g % 2 == 0 else g + 1
+        for cand in range(g, 4 * g + 1, 2):
+            if steps and steps % cand == 0:
+                return cand
+        return g
 
     def _next(self):
         o = self.ring[self.i]
@@ -350,7 +356,7 @@ def main():
     # device, a Python->C->hipLaunchKernel call about as long), so G consecutive steps are
     # captured once into a hipGraph and replayed; G = the output ring length (even, so the
     # oscillator's double-buffered state ends where it started in the capture).
-    G = wl.graph_steps() if not args.eager else 0
+    G = wl.graph_steps(args.steps) if not args.eager else 0
     graph = None
     if G:
         for _ in range(G):          # one eager pass first: lazy allocations happen outside capture
