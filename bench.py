@@ -137,8 +137,9 @@ class Workload:
             return int(os.environ["ZH_BENCH_G"])   # experiments
         g = max(self.nring, 2)
         g = g if g % 2 == 0 else g + 1
-        if steps and steps % 2 == 0 and g <= steps <= 2048:
-            return steps                    # the whole timed region is one graph launch (measured: 4.35 vs 4.47 us/step at 40)
+        if 2 <= steps <= 2049:
+            return steps - steps % 2        # the whole timed region is one graph launch (measured: 4.35 vs 4.47 us/step at 40);
+                                            # an odd K leaves one step to launch by hand
         for cand in range(g, 4 * g + 1, 2):
             if steps and steps % cand == 0:
                 return cand
