@@ -18,7 +18,7 @@ r.render_buffer(); ctx.sync()                        # warm up (first-launch cos
 r = song.SongRenderer(text, ctx)
 t0 = time.perf_counter(); got1 = b"".join(r.render_buffer() for _ in range(nbuf)); t_gpu1 = time.perf_counter() - t0
 r = song.SongRenderer(text, ctx)
-t0 = time.perf_counter(); got = r.render(nbuf * 1024 / 48000.0, batch=128); t_gpu = time.perf_counter() - t0
+t0 = time.perf_counter(); got = r.render(nbuf * 1024 / 48000.0); t_gpu = time.perf_counter() - t0
 print(f"per-buffer launches: {t_gpu1:.2f} s; identical to batched: {got1 == got}")
 t0 = time.perf_counter(); ref = _oracle_song_render(po, r.notes, song.EXAMPLE_SONG_INSTRUMENTS, nbuf); t_cpu = time.perf_counter() - t0
 same = got == ref

@@ -407,7 +407,7 @@ class SongRenderer:
         """Several consecutive write_wav iterations in ONE set of launches."""
         return self._collect_batch(self._launch_batch(self._prepare_batch(frame_counts)))
 
-    def render(self, seconds, batch=64):
+    def render(self, seconds, batch=256):
         """write_wav's loop (write_wav.zig:58-93), `batch` buffers per launch; the host schedules batch k+1
         while the device renders batch k."""
         total = int(seconds * AUDIO_SAMPLE_RATE)
