@@ -121,18 +121,21 @@ int main(int argc, char **argv) {
         for (unsigned r = 0; r < R; r++) launch(ring[r]);
         CK(hipStreamSynchronize(st));
         hipGraph_t g; hipGraphExec_t ge;
+        // like bench.py: ONE graph holds every timed launch (a graph launch costs a ~4 us bubble on the stream)
+        const unsigned rot = std::max(1u, 384u / R);                  // ring rotations per graph
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        for (unsigned r = 0; r < R; r++) launch(ring[r]);
+        for (unsigned q = 0; q < rot; q++)
+            for (unsigned r = 0; r < R; r++) launch(ring[r]);
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        for (int w = 0; w < 3; w++) CK(hipGraphLaunch(ge, st));
+        CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
-        const int reps = 12;
-        for (int w = 0; w < reps; w++) CK(hipGraphLaunch(ge, st));
+        CK(hipGraphLaunch(ge, st));
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = ms * 1e3 / (reps * R);
+        const double us = ms * 1e3 / (rot * R);
         printf("%-44s %6.2f us/launch  %5.2f TB/s\n", name, us, (double)V * F * 4 / us / 1e6);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     };
