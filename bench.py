@@ -116,7 +116,9 @@ class Workload:
             self.nsteps = 0
         else:
             self.m = mod.NiceInstrument(V, self.color, ctx)
-            self.mix = torch.zeros(F, dtype=torch.float32, device=dev)
+            # one [frames] partial mix per buffer of a 48-buffer batch; with several GPUs the batch is exchanged at once
+            self.mixes = torch.zeros((48, F), dtype=torch.float32, device=dev)
+            self.mix = self.mixes[0]
             self.ring = []
             self.kernel = "k_nice_mix"
             self.step = self._step_nice_mix
@@ -129,8 +131,6 @@ class Workload:
         graph when K is even and not huge (each graph launch costs a ~4 us bubble on the stream); otherwise an even
         count between one and four rotations that divides K, so that no remainder of the timed steps has to be
         launched one by one from Python (~2x slower per step at the 16 MiB size)."""
-        if self.name == "nice_mix" and self.world > 1:
-            return 0                        # the per-buffer all-reduce is issued by torch.distributed: eager
         if self.name in ("nice", "nice_mix", "script"):
             return 48                       # the note on/off pattern repeats every 48 buffers
         if os.environ.get("ZH_BENCH_G"):
@@ -183,13 +183,18 @@ class Workload:
         self.m.paint(self.span, [self._next()], None, new, {"sample_rate": SR, "freq": self.freq, "note_on": on}, zero_first=True)
 
     def _step_nice_mix(self):
-        on, new = self._note_on()
-        self.m.paint_mix(self.span, self.mix, new, self.m.Params(SR, self.freq, on), zero_first=True)
-        if self.world > 1:
-            # config 5: the one exchange step of the path -- each GPU's [frames] partial mix (4 KiB)
-            # is summed over RCCL/xGMI; latency-bound, not link-bound
+        row = self.nsteps % 48
+        on, new = self._note_on()                                  # advances self.nsteps
+        self.m.paint_mix(self.span, self.mixes[row], new, self.m.Params(SR, self.freq, on), zero_first=True)
+
+    def exchange(self):
+        """config 5's one exchange step: the GPUs' partial mixes are summed over RCCL/xGMI.  A 4 KiB
+        all-reduce per buffer would be pure latency (~20-40 us against 170 us of rendering), so the 48 buffers of a
+        batch go in ONE all-reduce of [48][frames] (192 KiB) after the batch's launches -- an offline renderer only
+        needs the mixed audio once the batch is done."""
+        if self.name == "nice_mix" and self.world > 1:
             from zang_amd import sharding
-            sharding.allreduce_mix(self.mix)
+            sharding.allreduce_mix(self.mixes)
 
 
 def cpu_baseline(args, wl):
@@ -375,9 +380,12 @@ def main():
         if graph is not None:
             while n - done >= G:
                 graph.launch()
+                wl.exchange()
                 done += G
         for _ in range(n - done):
             wl.step()
+        if n - done:
+            wl.exchange()
 
     ev0, ev1 = make_event(), make_event()
     run_steps(args.warmup)

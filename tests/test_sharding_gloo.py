@@ -43,8 +43,12 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from zang_amd import sharding
     lo, hi = sharding.voice_range(V, rank, world)
-    mix = torch.from_numpy(_render_partial(lo, hi - lo))
-    sharding.allreduce_mix(mix)
+    part = torch.from_numpy(_render_partial(lo, hi - lo))
+    # bench.py exchanges a whole batch of buffers in one collective: a [buffers][frames] block
+    block = torch.stack([part, part * 0.5, torch.zeros_like(part)])
+    sharding.allreduce_mix(block)
+    assert torch.equal(block[1], block[0] * 0.5) and not block[2].any()
+    mix = block[0]
     if rank == 0:
         q.put(mix.numpy().copy())
     dist.barrier()
