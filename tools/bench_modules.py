@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""GPU box: every module kernel of SURVEY.md 8a timed on its own -- zero+paint of one 1024-frame buffer for V voices
+(default 131,072), state carried, the K timed paints replayed as one hipGraph -- and, for the ones that read an
+input image, the HBM bytes they move.  usage: tools/bench_modules.py [voices]  -> one line per module"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import zang_amd
+from zang_amd import modules as mod, zang, workloads
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+F, SR, K = 1024, 48000.0, 20
+torch.cuda.set_stream(torch.cuda.Stream())               # graph capture is not allowed on the default stream
+ctx = zang_amd.Context(0)
+dev = ctx.device
+freq_h, color_h, u2, u3 = workloads.voice_params(5, 0, V)
+freq, color = torch.from_numpy(freq_h).to(dev), torch.from_numpy(color_h).to(dev)
+span = zang.Span(0, F)
+out = [ctx.image(F, V) for _ in range(2)]
+inp = ctx.image(F, V); inp.uniform_(-1.0, 1.0)
+fbuf = ctx.image(F, V); fbuf.copy_(freq[None, :].expand(F, V))          # a frequency control image
+pcm = torch.from_numpy(np.random.default_rng(1).integers(-20000, 20000, 48000, dtype=np.int16).view(np.uint8).copy()).to(dev)
+cutoff = mod.Filter.cutoffFromFrequency(torch.from_numpy((200.0 + 7800.0 * u2)).to(dev), SR, ctx)
+res = torch.from_numpy((0.9 * u3)).to(dev)
+lin = lambda d: zang.PaintCurve.linear(d)
+cases = []
+
+
+def case(name, m, paint, reads=0):
+    cases.append((name, m, paint, reads))
+
+
+m = mod.SineOsc(V, ctx); case("SineOsc const freq / const phase", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), zang.constant(0.0)), zero_first=True))
+m = mod.SineOsc(V, ctx); case("SineOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), zang.constant(0.0)), zero_first=True), 1)
+m = mod.PulseOsc(V, ctx); case("PulseOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
+m = mod.PulseOsc(V, ctx); case("PulseOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
+m = mod.TriSawOsc(V, ctx); case("TriSawOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
+m = mod.TriSawOsc(V, ctx); case("TriSawOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
+m = mod.Noise(V, ctx); case("Noise white", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(m.white), zero_first=True))
+m = mod.Noise(V, ctx); case("Noise pink", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(m.pink), zero_first=True))
+m = mod.Envelope(V, ctx)
+_env_k = [0]
+def _env(o, m=m):
+    k = _env_k[0] % 8; _env_k[0] += 1
+    m.paint(span, [o], [], k == 0, m.Params(SR, zang.PaintCurve.cubed(0.01), zang.PaintCurve.cubed(0.1), zang.PaintCurve.cubed(0.05), 0.8, k < 4), zero_first=True)
+case("Envelope (cubed, note on 4 buffers / off 4)", m, _env)
+m = mod.Gate(V, ctx); case("Gate", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(True), zero_first=True))
+m = mod.Filter(V, ctx); case("Filter low-pass, const cutoff / res", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.low_pass, zang.constant(cutoff), zang.constant(res)), zero_first=True), 1)
+m = mod.Sampler(V, ctx); smp = m.Sample(1, 44100, m.signed16_lsb, pcm)
+case("Sampler s16 mono, resampled, loop", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, smp, 0, True), zero_first=True))
+m = mod.Decimator(V, ctx); case("Decimator", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, inp, 6000.0), zero_first=True), 1)
+m = mod.Distortion(V, ctx); case("Distortion overdrive", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.overdrive, 0.5, 0.5, 0.0), zero_first=True), 1)
+m = mod.Distortion(V, ctx); case("Distortion clip", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.clip, 0.5, 0.5, 0.0), zero_first=True), 1)
+m = mod.NiceInstrument(V, color, ctx); case("NiceInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, freq, True), zero_first=True))
+rel = torch.full((V,), 0.3, dtype=torch.float32, device=dev)
+m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True))
+
+print("# %d voices x %d frames per paint, %d paints per graph, one MI355X" % (V, F, K))
+print("%-46s %10s %12s %10s" % ("module", "us/paint", "v-samples/s", "HBM TB/s"))
+for name, m, paint, reads in cases:
+    for i in range(4):
+        paint(out[i & 1])
+    ctx.sync()
+    g = ctx.capture(lambda: [paint(out[i & 1]) for i in range(K)])
+    g.launch(); ctx.sync()
+    t0 = time.perf_counter(); g.launch(); ctx.sync(); dt = time.perf_counter() - t0
+    us = dt * 1e6 / K
+    print("%-46s %10.1f %12.3e %10.2f" % (name, us, V * F / (us * 1e-6), (1 + reads) * V * F * 4 / (us * 1e-6) / 1e12))
+    g.close()

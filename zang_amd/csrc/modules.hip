@@ -168,43 +168,60 @@ struct zh_sampler { zh_ctx *ctx; uint32_t n; float *t; };
 struct SampleP {
     const uint8_t *data;
     uint64_t data_len;
-    uint32_t num_channels, sample_rate_in, format, channel, loop;
+    uint32_t num_channels, sample_rate_in, format, channel, loop, whole;
     int32_t num_samples;        // data.len / bytes_per_sample / num_channels (Sampler.zig:42)
+    double inv_num_samples;     // 1.0 / num_samples (0 when there are none): sampler_mod
 };
 
-// Sampler.zig:23-33
-__device__ __forceinline__ float sampler_decode_signed(int byte_count, const uint8_t *p) {
-    int32_t sval;
-    if (byte_count == 2) sval = (int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8));
-    else if (byte_count == 3) {
-        const uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-        sval = (int32_t)(u << 8) >> 8;
-    } else sval = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
-    const float max = (float)(1u << (byte_count * 8 - 1));
-    return (float)sval / max;
+// Sampler.zig:23-33.  FMT is a compile-time format (the kernel is instantiated per format and loop flag): with the
+// format switch, the loop test and the bounds test as branches inside the frame loop every frame was its own basic
+// block and paid the full latency of its PCM gathers; as straight-line code the loads of a chunk's 8 frames overlap.
+// `whole`: the PCM base is aligned to the sample size, so a sample is one load instead of byte_count byte gathers.
+constexpr int kSampleEmpty = -1;                                     // no samples: every read is 0 (and nothing is loaded)
+template <int FMT>
+__device__ __forceinline__ float sampler_decode(const uint8_t *data, size_t i, bool whole) {
+    if constexpr (FMT == kSampleEmpty) return 0.0f;
+    else if constexpr (FMT == ZH_SAMPLE_U8) return ((float)data[i] - 127.5f) / 127.5f;
+    else {
+        constexpr int byte_count = FMT + 1;
+        const uint8_t *p = data + i * byte_count;
+        int32_t sval;
+        if constexpr (byte_count == 2) sval = whole ? (int16_t)*reinterpret_cast<const uint16_t *>(p) : (int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8));
+        else if constexpr (byte_count == 3) {
+            const uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            sval = (int32_t)(u << 8) >> 8;
+        } else sval = whole ? (int32_t)*reinterpret_cast<const uint32_t *>(p)
+                            : (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+        // `sval / max` with max = 2^(bits-1): dividing by a power of two and multiplying by its reciprocal are the
+        // same IEEE operation (both exact up to the one rounding of the result), so no divide sequence is needed
+        const float inv_max = 1.0f / (float)(1u << (byte_count * 8 - 1));
+        return (float)sval * inv_max;
+    }
 }
 
-// Sampler.zig:35-58 (num_samples == 0 with loop: division by zero in the reference; DEFINED as silence)
+// @mod(index, n) for n > 0 (floored, Sampler.zig:43): the quotient from one f64 multiply by 1/n (any i32 over any
+// positive i32 is far inside f64's 53 bits; the estimate is off by at most one), then two exact corrections -- a
+// dozen instructions instead of the ~40 of a 32-bit integer remainder.
+__device__ __forceinline__ int32_t sampler_mod(int32_t index, int32_t n, double inv_n) {
+    const int32_t q = (int32_t)floor((double)index * inv_n);
+    int32_t r = (int32_t)((uint32_t)index - (uint32_t)q * (uint32_t)n);
+    r = r < 0 ? r + n : r;
+    r = r >= n ? r - n : r;
+    return r;
+}
+
+// Sampler.zig:35-58 (num_samples == 0 with loop: division by zero in the reference; DEFINED as silence = kSampleEmpty)
+template <int FMT, bool LOOP>
 __device__ __forceinline__ float sampler_get_sample(const SampleP &s, int32_t index1) {
-    int32_t index = index1;
-    if (s.loop) {
-        if (s.num_samples == 0) return 0.0f;
-        index = index1 % s.num_samples;                               // @mod: floored
-        if (index < 0) index += s.num_samples;
-    }
-    if (index >= 0 && index < s.num_samples) {
-        const size_t i = (size_t)index * s.num_channels + s.channel;
-        switch (s.format) {
-        case ZH_SAMPLE_U8: return ((float)s.data[i] - 127.5f) / 127.5f;
-        case ZH_SAMPLE_S16_LSB: return sampler_decode_signed(2, s.data + i * 2);
-        case ZH_SAMPLE_S24_LSB: return sampler_decode_signed(3, s.data + i * 3);
-        default: return sampler_decode_signed(4, s.data + i * 4);
-        }
-    }
-    return 0.0f;
+    if constexpr (FMT == kSampleEmpty) return 0.0f;
+    const int32_t index = LOOP ? sampler_mod(index1, s.num_samples, s.inv_num_samples) : index1;   // @mod: floored
+    const bool in = index >= 0 && index < s.num_samples;
+    const size_t i = (size_t)(in ? index : 0) * s.num_channels + s.channel;
+    const float val = sampler_decode<FMT>(s.data, i, s.whole != 0);
+    return in ? val : 0.0f;
 }
 
-template <bool ZF>
+template <bool ZF, int FMT, bool LOOP>
 __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
                                                        uint32_t end, SampleP s, F32P out_rate, BoolP nic) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
@@ -214,7 +231,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io,
     const uint32_t len = end - start;
     const float ratio = (float)s.sample_rate_in / out_rate.get(v);    // :97
     const float *const *no_in = nullptr;
-    if (ratio < 0.0f && !s.loop) {                                    // :99-102 (t keeps the reset)
+    if (ratio < 0.0f && !LOOP) {                                      // :99-102 (t keeps the reset)
         if (ZF) zero_column(out.p + v, out.stride, start, end);
         t_io[v] = t;
         return;
@@ -222,7 +239,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io,
     if (ratio > 0.9999f && ratio < 1.0001f) {                         // :105-114 no resampling
         const int32_t t0 = zf32_to_i32(roundf(t));
         frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-            val = sampler_get_sample(s, (int32_t)((uint32_t)t0 + (i - start)));
+            val = sampler_get_sample<FMT, LOOP>(s, (int32_t)((uint32_t)t0 + (i - start)));
             return true;
         });
         t += (float)len;
@@ -231,15 +248,15 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io,
             const int32_t t0 = zf32_to_i32(floorf(t));
             const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
             const float tfrac = (float)t1 - t;                        // :121
-            const float s0 = sampler_get_sample(s, t0);
-            const float s1 = sampler_get_sample(s, t1);
+            const float s0 = sampler_get_sample<FMT, LOOP>(s, t0);
+            const float s1 = sampler_get_sample<FMT, LOOP>(s, t1);
             val = s0 * (1.0f - tfrac) + s1 * tfrac;
             t += ratio;
             return true;
         });
     }
     // :133-135: compared against data.len in BYTES (reference quirk, kept)
-    if (t >= (float)s.data_len && s.loop) t -= (float)s.data_len;
+    if (t >= (float)s.data_len && LOOP) t -= (float)s.data_len;
     t_io[v] = t;
 }
 
@@ -722,9 +739,24 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
     s.format = p->sample.format;
     s.channel = (uint32_t)p->channel;
     s.loop = p->loop ? 1u : 0u;
-    s.num_samples = (int32_t)(p->sample.data_len / bps / p->sample.num_channels);
-    ZH_ZF_LAUNCH(k_sampler, seq_grid(m->n), dim3(kSeqBlock), m->t, m->n, mk_img(outputs[0]), start, end, s,
-                 mk_f32(p->sample_rate), mk_bool(note_id_changed));
+    s.whole = ((uintptr_t)p->sample.data % bps) == 0 ? 1u : 0u;
+    const uint64_t count = p->sample.data_len / bps / p->sample.num_channels;
+    if (count > 0x7fffffffull) return ZH_ERR_INVALID;                               // the reference's @intCast(i32, ...) traps (:42)
+    s.num_samples = (int32_t)count;
+    s.inv_num_samples = s.num_samples > 0 ? 1.0 / (double)s.num_samples : 0.0;
+    const Img img = mk_img(outputs[0]);
+    const F32P rate = mk_f32(p->sample_rate);
+    const BoolP nicp = mk_bool(note_id_changed);
+    const int fmt = s.num_samples == 0 ? kSampleEmpty : (int)s.format;
+#define ZH_SMP(ZF_, F_, L_) hipLaunchKernelGGL((k_sampler<ZF_, F_, L_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, img, start, end, s, rate, nicp)
+#define ZH_SMP_L(ZF_, F_) do { if (s.loop) ZH_SMP(ZF_, F_, true); else ZH_SMP(ZF_, F_, false); } while (0)
+#define ZH_SMP_F(ZF_) do { switch (fmt) { case kSampleEmpty: ZH_SMP_L(ZF_, kSampleEmpty); break; case ZH_SAMPLE_U8: ZH_SMP_L(ZF_, ZH_SAMPLE_U8); break; \
+        case ZH_SAMPLE_S16_LSB: ZH_SMP_L(ZF_, ZH_SAMPLE_S16_LSB); break; case ZH_SAMPLE_S24_LSB: ZH_SMP_L(ZF_, ZH_SAMPLE_S24_LSB); break; \
+        default: ZH_SMP_L(ZF_, ZH_SAMPLE_S32_LSB); break; } } while (0)
+    if (zf) ZH_SMP_F(true); else ZH_SMP_F(false);
+#undef ZH_SMP_F
+#undef ZH_SMP_L
+#undef ZH_SMP
     return zh_launch_status();
 }
 

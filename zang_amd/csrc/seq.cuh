@@ -61,17 +61,25 @@ __device__ __forceinline__ void frame_loop(float *__restrict__ out, uint32_t v, 
             }
         }
         const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        // the chunk's CH frames are computed first and stored afterwards: a store through the descriptor is an
+        // opaque memory write to the compiler, and with one after every frame no load of the body (Sampler's PCM
+        // gathers, a Curve's nodes) could be issued ahead of the previous frame's store -- every frame paid its
+        // full load latency
+        T res[CH];
+        typename LaneT<W>::M pm[CH];
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             T x[NI];
 #pragma unroll
             for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
             T val = zsplat<T>(0.0f);
-            const auto painted = f(i + k, x, val);
-            T o = ZF ? zsplat<T>(0.0f) : oc[k];
-            o = zsel(painted, o + val, o);
-            if (ZF || zany(painted)) zrow_store<W>(ro, voff, k * orow, o);
+            pm[k] = f(i + k, x, val);
+            const T o = ZF ? zsplat<T>(0.0f) : oc[k];
+            res[k] = zsel(pm[k], o + val, o);
         }
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (ZF || zany(pm[k])) zrow_store<W>(ro, voff, k * orow, res[k]);
         if (more) {
 #pragma unroll
             for (int k = 0; k < CH; k++) {
