@@ -14,7 +14,7 @@ F = 1024
 SPANS = [(0, 200), (200, 777), (777, 1024), (0, 1024), (0, 1024)]
 
 
-@pytest.mark.parametrize("D", [1, 7, 100, 1024, 3000])
+@pytest.mark.parametrize("D", [1, 7, 8, 9, 100, 1024, 3000])     # < 8: frame by frame; >= 8: chunks of 8 frames
 def test_simple_delay(ctx, oracle, D):
     from zang_amd import modules as mod, zang
     V = 96
@@ -41,7 +41,31 @@ def test_simple_delay(ctx, oracle, D):
     assert not grings.any() and not gidx.any()
 
 
-@pytest.mark.parametrize("D", [5, 333, 2000])
+@pytest.mark.parametrize("D", [4, 64])
+def test_simple_delay_in_place(ctx, oracle, D):
+    """The input image IS the output image: the order of reads and writes inside a frame becomes observable (the delay
+    line is fed the sample it has just added to), so the device must not hoist a chunk's input reads above its output
+    writes -- it falls back to the frame-by-frame form.  The oracle runs the reference's chunked form on one array."""
+    from zang_amd import modules as mod, zang
+    V = 70
+    buf0 = util.rng_buffers(31, V, F)
+    L = oracle.lib()
+    ref = buf0.copy()
+    rings = np.zeros((V, D), np.float32)
+    for v in range(V):
+        d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D)
+        for (s, e) in SPANS[:3]:
+            L.zo_simple_delay_paint(C.byref(d), s, e, oracle.fptr(ref[v]), oracle.fptr(ref[v]))
+    m = mod.SimpleDelay(V, D, ctx)
+    img = util.to_image(buf0)
+    for (s, e) in SPANS[:3]:
+        m.paint(zang.Span(s, e), [img], [], False, m.Params(img))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(img), ref, f"in-place simple delay D={D}")
+    util.assert_bitexact(m.state()[0], rings, "ring")
+
+
+@pytest.mark.parametrize("D", [5, 8, 333, 2000])
 def test_filtered_echoes(ctx, oracle, D):
     from zang_amd import modules as mod, zang
     V = 96

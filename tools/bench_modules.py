@@ -60,6 +60,18 @@ m = mod.NiceInstrument(V, color, ctx); case("NiceInstrument (fused)", m, lambda 
 rel = torch.full((V,), 0.3, dtype=torch.float32, device=dev)
 m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True))
 
+m = mod.SimpleDelay(V, 300, ctx); case("SimpleDelay(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp), zero_first=True), 3)
+m = mod.FilteredEchoes(V, 300, ctx); case("FilteredEchoes(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True), 3)
+crv = torch.tensor([[0.0, 0.0], [1.0, 0.005], [0.3, 0.012], [0.8, 0.02], [0.0, 0.05]], dtype=torch.float32, device=dev)
+m = mod.Curve(V, ctx)
+_crv_k = [0]
+def _curve(o, m=m):
+    k = _crv_k[0] % 4; _crv_k[0] += 1
+    m.paint(span, [o], [], k == 0, m.Params(SR, m.smoothstep, crv), zero_first=True)
+case("Curve smoothstep, 5 nodes, retrigger every 4", m, _curve)
+m = mod.Cycle(V, ctx); case("Cycle const speed", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(3.0)), zero_first=True))
+m = mod.Portamento(V, ctx); case("Portamento cubed", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.PaintCurve.cubed(0.2), freq, True, True), zero_first=True))
+
 print("# %d voices x %d frames per paint, %d paints per graph, one MI355X" % (V, F, K))
 print("%-46s %10s %12s %10s" % ("module", "us/paint", "v-samples/s", "HBM TB/s"))
 for name, m, paint, reads in cases:
