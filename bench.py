@@ -32,7 +32,7 @@ HBM_STORE_GBS = 6200.0  # same guide: measured plain-store rate ("achievable" wr
 SR = 48000.0
 
 
-SCRIPT_MODULE = "Lead"
+SCRIPT_MODULE = os.environ.get("ZH_SCRIPT_MODULE", "Lead")    # any module of tests/golden/script_modules.txt with (freq, note_on) params
 
 
 def parse():

@@ -672,7 +672,17 @@ public:
         if (!begins.empty()) { k.frame.push_back("if (" + rel + " == 0u) {"); append(k.frame, indent(begins)); k.frame.push_back("}"); }
         k.frame.push_back(fbout + " = 0.0f;");
         k.frame.push_back(fb + " = 0.0f;");
-        k.frame.push_back(fb + " = " + fb + " + zu2f(" + slot + ");");                            // readDelayBuffer: `+=` (delay.zig:39-42)
+        if (n >= 2) {
+            // the slot of the NEXT frame is a different slot, last written n-1 frames ago: it is loaded while this
+            // frame computes, so that no frame waits out its own ring load
+            const char *dc = d.c_str();
+            k.pro.push_back(strf("float %s_pre = zu2f(L.state[(size_t)(%zuu + %s_idx) * V + v]);", dc, w_ring, dc));
+            k.frame.push_back(strf("const float %s_cur = %s_pre;", dc, dc));
+            k.frame.push_back(strf("%s_pre = zu2f(L.state[(size_t)(%zuu + (%s_idx + 1u == %zuu ? 0u : %s_idx + 1u)) * V + v]);", dc, w_ring, dc, n, dc));
+            k.frame.push_back(fb + " = " + fb + " + " + d + "_cur;");                             // readDelayBuffer: `+=` (delay.zig:39-42)
+        } else {
+            k.frame.push_back(fb + " = " + fb + " + zu2f(" + slot + ");");
+        }
         append(k.frame, body);
         k.frame.push_back(slot + " = zf2u(" + fbout + ");");                                       // writeDelayBuffer (delay.zig:62-89)
         k.frame.push_back(strf("%s_idx = %s_idx + 1u == %zuu ? 0u : %s_idx + 1u;", d.c_str(), d.c_str(), n, d.c_str()));

@@ -392,8 +392,17 @@ class HipEmitter:
         k.frame += head
         if begins:
             k.frame += ["if (%s == 0u) {" % rel] + ["    " + l for l in begins] + ["}"]
-        k.frame += ["%s = 0.0f;" % fbout, "%s = 0.0f;" % fb,
-                    "%s = %s + zu2f(%s);" % (fb, fb, slot)]       # readDelayBuffer: `+=` (delay.zig:39-42)
+        k.frame += ["%s = 0.0f;" % fbout, "%s = 0.0f;" % fb]
+        if n >= 2:
+            # the slot of the NEXT frame is a different slot, last written n-1 frames ago: it is loaded while this
+            # frame computes, so that no frame waits out its own ring load (read slot / body / write slot per frame
+            # exposes the full load latency: the write is an opaque store the next read cannot be hoisted above)
+            k.pro.append("float %s_pre = zu2f(L.state[(size_t)(%du + %s_idx) * V + v]);" % (d, w_ring, d))
+            k.frame += ["const float %s_cur = %s_pre;" % (d, d),
+                        "%s_pre = zu2f(L.state[(size_t)(%du + (%s_idx + 1u == %du ? 0u : %s_idx + 1u)) * V + v]);" % (d, w_ring, d, n, d),
+                        "%s = %s + %s_cur;" % (fb, fb, d)]           # readDelayBuffer: `+=` (delay.zig:39-42)
+        else:
+            k.frame += ["%s = %s + zu2f(%s);" % (fb, fb, slot)]
         k.frame += body
         k.frame += ["%s = zf2u(%s);" % (slot, fbout),             # writeDelayBuffer (delay.zig:62-89)
                     "%s_idx = %s_idx + 1u == %du ? 0u : %s_idx + 1u;" % (d, d, n, d)]
