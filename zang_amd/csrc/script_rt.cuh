@@ -76,15 +76,17 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
         const bool more = c + 1 < nfull;
         if (more) load(i + CH, on, xn);
         const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        // compute the chunk, then store it (seq.cuh frame_loop: a store after every frame would pin every load of the
+        // body -- delay rings, track tables -- behind the previous frame's store)
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             float x[NI];
 #pragma unroll
             for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
-            float o = oc[k];
-            f(i + k, x, o);
-            zrow_store<1>(ro, voff, k * orow, o);
+            f(i + k, x, oc[k]);
         }
+#pragma unroll
+        for (int k = 0; k < CH; k++) zrow_store<1>(ro, voff, k * orow, oc[k]);
         if (more) {
 #pragma unroll
             for (int k = 0; k < CH; k++) {
