@@ -6,8 +6,11 @@
 // math.Pow).  To reproduce the reference's bits rather than "a sine", the kernels run the
 // same published algorithms: f64 polynomial kernels after a Cody-Waite / Payne-Hanek
 // reduction for sin/cos, the f32 table+polynomial atanf, frexp/ldexp square-and-multiply
-// pow, xoshiro256++.  MI355X executes f64 VALU at half the f32 rate, so one sinf costs
-// about 30 f32-equivalent lane-ops: inside the per-sample budget of an HBM-bound paint.
+// pow, xoshiro256++.  An f64 VALU operation issues in the 4.2-cycle class on gfx950 (measured,
+// profiles/r01/ubench), a plain f32 add / mul in 2.5: one sinf is ~50 instructions, 35 of them f64.
+// What can be changed without changing bits is the control flow: a wave's lanes sit in every range
+// of a libm routine at once, so the ranges are folded into straight-line code in which each lane
+// performs exactly its range's operations (sinf / cosf, atanf below).
 //
 // Everything here must be compiled with -ffp-contract=off (no fused multiply-add: Zig
 // emits none for these loops) and without fast-math.
@@ -240,38 +243,38 @@ ZD float zcosf(float x) {
 }
 
 // ---- atanf (f32 arithmetic throughout) ------------------------------------------------
+// musl atanf: five magnitude ranges, four of them reducing x by a different quotient before one shared
+// polynomial.  Distortion's overdrive calls it per sample on arbitrary signal values, so a wave's lanes sit in all
+// ranges at once; as branches every range's divide ran for every wave.  Folded like sinf: each range's numerator
+// and denominator are computed with exactly that range's operations (a handful of adds / multiplies), ONE divide
+// serves whichever the lane selects, then the shared polynomial and selects for the tails.
 ZD float zatanf(float x) {
     const float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f,
                 aT3 = -1.0648017377e-01f, aT4 = 6.1687607318e-02f;
-    float w, s1, s2, z, hi = 0.0f, lo = 0.0f;
-    uint32_t ix = zf2u(x), sign = ix >> 31;
-    int id;
-    ix &= 0x7fffffff;
-    if (ix >= 0x4c800000) {
-        if (x != x) return x;
-        z = 1.5707962513e+00f + 0x1p-120f;
-        return sign ? -z : z;
+    const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
+    const bool sign = (ux >> 31) != 0;
+    const float ax = fabsf(x);
+    const bool r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000;   // |x| < 11/16, < 19/16, < 39/16
+    // id 0: (2x-1)/(2+x)   id 1: (x-1)/(x+1)   id 2: (x-1.5)/(1+1.5x)   id 3: -1/x
+    const float num = r1 ? (r0 ? 2.0f * ax - 1.0f : ax - 1.0f) : (r2 ? ax - 1.5f : -1.0f);
+    const float den = r1 ? (r0 ? 2.0f + ax : ax + 1.0f) : (r2 ? 1.0f + 1.5f * ax : ax);
+    const float hi = r1 ? (r0 ? 4.6364760399e-01f : 7.8539812565e-01f) : (r2 ? 9.8279368877e-01f : 1.5707962513e+00f);
+    const float lo = r1 ? (r0 ? 5.0121582440e-09f : 3.7748947079e-08f) : (r2 ? 3.4473217170e-08f : 7.5497894159e-08f);
+    const bool direct = ix < 0x3ee00000;                              // |x| < 7/16: id = -1, x itself (signed)
+    const float xr = direct ? x : num / den;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * aT4));
+    const float s2 = w * (aT1 + w * aT3);
+    const float t = xr * (s1 + s2);
+    const float zz = hi - ((t - lo) - xr);
+    float r = direct ? xr - t : (sign ? -zz : zz);
+    if (ix < 0x39800000) r = x;                                       // |x| < 2^-12
+    if (ix >= 0x4c800000) {                                           // |x| >= 2^26, inf, nan
+        const float big = 1.5707962513e+00f + 0x1p-120f;
+        r = (x != x) ? x : (sign ? -big : big);
     }
-    if (ix < 0x3ee00000) {
-        if (ix < 0x39800000) return x;
-        id = -1;
-    } else {
-        x = fabsf(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) { id = 0; hi = 4.6364760399e-01f; lo = 5.0121582440e-09f; x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else { id = 1; hi = 7.8539812565e-01f; lo = 3.7748947079e-08f; x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { id = 2; hi = 9.8279368877e-01f; lo = 3.4473217170e-08f; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else { id = 3; hi = 1.5707962513e+00f; lo = 7.5497894159e-08f; x = -1.0f / x; }
-        }
-    }
-    z = x * x;
-    w = z * z;
-    s1 = z * (aT0 + w * (aT2 + w * aT4));
-    s2 = w * (aT1 + w * aT3);
-    if (id < 0) return x - x * (s1 + s2);
-    z = hi - ((x * (s1 + s2) - lo) - x);
-    return sign ? -z : z;
+    return r;
 }
 
 // ---- logf / expf / powf (Distortion.zig:41 calls pow(f32, 2.0, y) once per paint) -------
