@@ -86,6 +86,7 @@ pub extern fn zh_filter_cutoff_from_frequency(ctx: *Ctx, n: u32, cutoff_out_dev:
 // std.math.sin / cos / pow (f32) elementwise on device arrays, same bits as the modules
 pub extern fn zh_sin(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32) c_int;
 pub extern fn zh_cos(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32) c_int;
+pub extern fn zh_atan(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32) c_int;
 pub extern fn zh_pow(ctx: *Ctx, n: u32, out: [*]f32, x: [*]const f32, y: [*]const f32) c_int;
 
 // Envelope (src/modules/Envelope.zig)

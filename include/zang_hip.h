@@ -248,6 +248,8 @@ ZH_API int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const flo
  * built on, exposed so that a host can compute its scalars with the same bits (out, x: device float[n]). */
 ZH_API int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x);
 ZH_API int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x);
+/* std.math.atan (f32), the function of Distortion's overdrive (Distortion.zig:45, 50), same contract. */
+ZH_API int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x);
 
 /* ---------------------------------------------------------------- Sampler (src/modules/Sampler.zig) */
 typedef struct zh_sampler zh_sampler;

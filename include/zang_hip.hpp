@@ -185,5 +185,6 @@ inline void cutoffFromFrequency(zang::Context &c, uint32_t n, float *cutoff_out_
 namespace zang { namespace math {
 inline void sin(zang::Context &c, uint32_t n, float *out_dev, const float *x_dev) { zang::check(zh_sin(c.get(), n, out_dev, x_dev), "sin"); }
 inline void cos(zang::Context &c, uint32_t n, float *out_dev, const float *x_dev) { zang::check(zh_cos(c.get(), n, out_dev, x_dev), "cos"); }
+inline void atan(zang::Context &c, uint32_t n, float *out_dev, const float *x_dev) { zang::check(zh_atan(c.get(), n, out_dev, x_dev), "atan"); }
 inline void pow(zang::Context &c, uint32_t n, float *out_dev, const float *x_dev, const float *y_dev) { zang::check(zh_pow(c.get(), n, out_dev, x_dev, y_dev), "pow"); }
 } }  // namespace zang::math

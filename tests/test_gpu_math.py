@@ -48,3 +48,31 @@ def test_sin_cos_bitexact(ctx, oracle, name):
 def test_sin_cos_rejects_null(ctx):
     assert ctx.lib.zh_sin(ctx.handle, 4, None, None) != 0
     assert ctx.lib.zh_cos(ctx.handle, 0, None, None) == 0
+
+
+ATAN_THRESHOLDS = [0x39800000, 0x3ee00000, 0x3f300000, 0x3f980000, 0x401c0000, 0x4c800000, 0x7f800000]
+
+
+def test_atan_bitexact(ctx, oracle):
+    """zh_atan against the oracle's musl atanf over every range of the routine (both signs): the thresholds +- a few
+    ulps, random bit patterns of every exponent, the signal range of Distortion's overdrive, zeros, infinities, NaNs."""
+    import torch
+    from zang_amd import abi
+    rng = np.random.default_rng(7)
+    near = np.array([t + d for t in ATAN_THRESHOLDS for d in range(-4, 5)], np.uint32)
+    xs = np.ascontiguousarray(np.concatenate([
+        near.view(np.float32), (near | np.uint32(0x80000000)).view(np.float32),
+        rng.integers(0, 1 << 32, 2_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        rng.uniform(-70.0, 70.0, 1_000_000).astype(np.float32), rng.uniform(-3.0, 3.0, 1_000_000).astype(np.float32),
+        np.array([0, 0x80000000, 1, 0x7f800000, 0xff800000, 0x7fc00000, 0xffc00001], np.uint32).view(np.float32)]))
+    ref = np.zeros_like(xs)
+    oracle.lib().zo_math_atanf_n(oracle.fptr(xs), oracle.fptr(ref), xs.size)
+    x = torch.from_numpy(xs).to(ctx.device)
+    out = torch.empty_like(x)
+    abi.check(ctx.lib.zh_atan(ctx.handle, xs.size, out.data_ptr(), x.data_ptr()), "zh_atan")
+    ctx.sync()
+    got = out.cpu().numpy()
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    bad = np.nonzero((got.view(np.uint32) != ref.view(np.uint32)) & ~nan)[0]
+    assert bad.size == 0, (bad.size, [(hex(int(xs[i:i + 1].view(np.uint32)[0])), float(got[i]), float(ref[i])) for i in bad[:8]])

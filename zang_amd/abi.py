@@ -406,6 +406,7 @@ SIGNATURES = {
     "zh_pow": (C.c_int, [vp, u32, vp, vp, vp]),
     "zh_sin": (C.c_int, [vp, u32, vp, vp]),
     "zh_cos": (C.c_int, [vp, u32, vp, vp]),
+    "zh_atan": (C.c_int, [vp, u32, vp, vp]),
     "zh_mix_down": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, f32]),
     "zh_nice_paint_spans": (C.c_int, [vp, u32, u32, P(Buf), P(Buf), f32, P(SpanTable), u32]),
     "zh_pmosc_paint_spans": (C.c_int, [vp, u32, u32, P(Buf), P(Buf), f32, P(SpanTable), u32]),

@@ -156,10 +156,10 @@ __global__ void k_pow(uint32_t n, float *__restrict__ out, const float *__restri
     if (i < n) out[i] = zpowf_pos(x[i], y[i]);
 }
 
-template <bool COS>
+template <int FN>   // 0 sin, 1 cos, 2 atan
 __global__ void k_sincos(uint32_t n, float *__restrict__ out, const float *__restrict__ x) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = COS ? zcosf(x[i]) : zsinf(x[i]);
+    if (i < n) out[i] = FN == 2 ? zatanf(x[i]) : (FN == 1 ? zcosf(x[i]) : zsinf(x[i]));
 }
 
 // =================================================================== Sampler
@@ -680,13 +680,20 @@ int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y) 
 int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_sincos<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    hipLaunchKernelGGL(k_sincos<0>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_sincos<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    hipLaunchKernelGGL(k_sincos<1>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    return zh_launch_status();
+}
+
+int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
+    if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
+    if (!n) return ZH_OK;
+    hipLaunchKernelGGL(k_sincos<2>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 
