@@ -298,7 +298,15 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
     d.begin(OVERDRIVE ? ZH_DISTORTION_OVERDRIVE : ZH_DISTORTION_CLIP, ingain.get(v), outgain.get(v), offset.get(v));
     float *o = out.at(c0, v);
     const float *in = input.at(c0, v);
-    for (uint32_t i = c0; i < c1; i++, o += out.stride, in += input.stride) *o = (ZF ? 0.0f : *o) + d.frame(*in);
+    uint32_t i = c0;
+    for (; i + 8 <= c1; i += 8, o += 8 * (size_t)out.stride, in += 8 * (size_t)input.stride) {   // 8 frames' loads ahead of their stores
+        float x[8], old[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[k] = in[(size_t)k * input.stride]; old[k] = ZF ? 0.0f : o[(size_t)k * out.stride]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[(size_t)k * out.stride] = old[k] + d.frame(x[k]);
+    }
+    for (; i < c1; i++, o += out.stride, in += input.stride) *o = (ZF ? 0.0f : *o) + d.frame(*in);
 }
 
 // =================================================================== Curve
