@@ -52,7 +52,7 @@ typedef struct zh_buf {
     float   *ptr;
     uint32_t voices;   /* voices covered by this view                   */
     uint32_t frames;   /* frames (rows) available; spans index into it  */
-    uint32_t stride;   /* floats between consecutive frames (>= voices) */
+    uint32_t stride;   /* floats between consecutive frames (>= voices, <= 2^26) */
     uint32_t reserved;
 } zh_buf;
 

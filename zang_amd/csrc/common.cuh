@@ -88,8 +88,12 @@ static inline CobP mk_cob(const zh_cob &c) {
 }
 
 // Argument checks shared by every paint entry point.
+// Row strides are limited to 2^26 voices (256 MiB per row): the sequential kernels address a chunk of 8 rows with
+// 32-bit byte offsets from the chunk's first row (lanes.cuh zrow_*), so 8 * stride * 4 must stay below 2^32.
+// (An image of 1024 such rows would be 256 GiB.)
+constexpr uint32_t kMaxRowStride = 1u << 26;
 static inline bool buf_covers(const zh_buf &b, uint32_t n_voices, uint32_t span_end) {
-    return b.ptr != nullptr && b.voices >= n_voices && b.frames >= span_end && b.stride >= n_voices;
+    return b.ptr != nullptr && b.voices >= n_voices && b.frames >= span_end && b.stride >= n_voices && b.stride <= kMaxRowStride;
 }
 static inline bool cob_ok(const zh_cob &c, uint32_t n_voices, uint32_t span_end) {
     if (c.tag == ZH_COB_CONSTANT) return true;

@@ -95,8 +95,8 @@ template <int W> ZL void zstore_u(uint32_t *p, uint32_t v, typename LaneT<W>::U 
 // descriptor the whole per-frame address is scalar: the descriptor's base is the first row of the
 // current chunk (rebased with two scalar adds per chunk), the row inside the chunk is `soffset` (an
 // SGPR) and the lane's voice is one constant byte offset in a VGPR -- a load or store costs no vector
-// address arithmetic.  Offsets are 32-bit: a chunk of CH rows must span < 4 GiB (CH * stride < 2^30
-// voices; an image that wide would need > 4 TiB, no such image exists on a 288 GB device).
+// address arithmetic.  Offsets are 32-bit: a chunk of CH = 8 rows must span < 4 GiB, i.e. stride < 2^27 voices;
+// the entry points accept strides up to 2^26 (common.cuh kMaxRowStride, checked in buf_covers).
 #if defined(__HIP_DEVICE_COMPILE__)
 ZL zh_rsrc_t zrow_rsrc(const float *base, size_t stride, uint32_t frame) { return make_rsrc(base + (size_t)frame * stride, 0xFFFFFFFFu); }
 template <int W> ZL typename LaneT<W>::F zrow_load(zh_rsrc_t r, uint32_t voff, uint32_t soff) {
