@@ -888,7 +888,7 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
         const dim3 grid = seq_grid(m->n / 2);
         if (zf) hipLaunchKernelGGL((k_nice<true, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
         else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
-    } else if (m->n <= nice_pc_max() && end > start) {
+    } else if (m->n <= nice_pc_max() && end > start && outputs[0].stride <= (1u << 24)) {   // (32-row tiles: 32-bit offsets)
         // up to ZH_NICE_PC_MAX voices the three chains of a frame run in three waves side by side (k_nice_pc)
         if (zf) hipLaunchKernelGGL(k_nice_pc<true>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
         else hipLaunchKernelGGL(k_nice_pc<false>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
@@ -1035,7 +1035,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both
     static const uint32_t pc_max = [] { const char *e = getenv("ZH_NF_PC_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u; }();
 #define ZH_NF(K_, BLK_, ZF_, PK_) hipLaunchKernelGGL((K_<ZF_, PK_>), seq_grid(m->n), dim3(BLK_), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
-    if (m->n <= pc_max) {
+    if (m->n <= pc_max && outputs[0].stride <= (1u << 24)) {                            // (32-row tiles: 32-bit offsets)
         if (zf) { if (pink) ZH_NF(k_noise_filter_pc, 128, true, true); else ZH_NF(k_noise_filter_pc, 128, true, false); }
         else { if (pink) ZH_NF(k_noise_filter_pc, 128, false, true); else ZH_NF(k_noise_filter_pc, 128, false, false); }
     } else {
