@@ -1,0 +1,16 @@
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import pytest
+import tests.test_gpu_fuzz as fz
+from tests import conftest
+import zang_amd
+from oracle import pyoracle
+ctx = zang_amd.Context(0)
+n = int(sys.argv[1]); bad = 0
+for seed in range(5, 5 + n):
+    for fn in (fz.test_fuzz_pulseosc, fz.test_fuzz_nice, fz.test_fuzz_noise_filter):
+        try:
+            fn(ctx, pyoracle, seed)
+        except AssertionError as e:
+            bad += 1; print("FAIL", fn.__name__, seed, str(e)[:300])
+print("seeds", n, "failures", bad)
