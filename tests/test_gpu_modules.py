@@ -286,6 +286,30 @@ def test_filter(ctx, oracle, ftype, ck, rk):
     util.assert_bitexact(st["b"].astype(np.float32), rb, "filter b")
 
 
+def test_filter_and_distortion_in_place(ctx, oracle):
+    """The input image IS the output image (`out += f(out)`): every frame's input is read before its output is written,
+    in the oracle's scalar loop and in the device's chunked loops (a chunk's loads precede its stores; the next chunk's
+    prefetched rows are not yet written) alike."""
+    from zang_amd import modules as mod, zang
+    V = 100
+    buf0 = util.rng_buffers(61, V, F)
+    L = oracle.lib()
+    ref = buf0.copy()
+    for v in range(V):
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st))
+        for (s, e) in util.SPANS_THREE:
+            L.zo_filter_paint(C.byref(st), s, e, oracle.fptr(ref[v]), oracle.fptr(ref[v]), mod.Filter.low_pass, oracle.constant(0.3), oracle.constant(0.4))
+        L.zo_distortion_paint(0, F, oracle.fptr(ref[v]), oracle.fptr(ref[v]), mod.Distortion.clip, 0.5, 0.5, 0.0)
+    img = util.to_image(buf0)
+    m = mod.Filter(V, ctx)
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [img], [], False, m.Params(img, m.low_pass, zang.constant(0.3), zang.constant(0.4)))
+    d = mod.Distortion(V, ctx)
+    d.paint(zang.Span(0, F), [img], [], False, d.Params(img, d.clip, 0.5, 0.5, 0.0))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(img), ref, "in-place filter + distortion")
+
+
 def test_filter_known_answer_and_cutoff(ctx, oracle):
     """K3 of SURVEY.md 8c and Filter.cutoffFromFrequency vs the oracle."""
     from zang_amd import modules as mod, zang
