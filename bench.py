@@ -38,8 +38,8 @@ SCRIPT_MODULE = os.environ.get("ZH_SCRIPT_MODULE", "Lead")    # any module of te
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "noise_filter_fused", "nice", "nice_mix", "script"])
     ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
     ap.add_argument("--frames", type=int, default=1024)

@@ -246,20 +246,16 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict_
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// Frames per lane for the chunked kernels: enough chunks to put several waves on every SIMD
-// (256 CUs x 4 SIMDs), but at least 4 frames (the per-voice setup is shared through LDS by the block's
-// four chunks; measured at 4,096 voices: 4 frames per lane 4.29 us, 8: 4.36, 2: 4.6).
-// ZH_OSC_FC / ZH_OSC_WAVES / ZH_OSC_SCALAR override for experiments.
+// Frames per lane for the chunked kernels.  Measured (tools/sweep_osc_fc.sh, PulseOsc, 1024-frame images): 4 frames per
+// lane is the best or within 5 % of the best at every voice count from 4,096 to 1 Mi and 11-15 % better than 64 between
+// 65,536 and 524,288 voices (short waves interleave their ALU and store phases better, and the blocks sweep the image in
+// row order); the per-voice setup is shared through LDS by the four chunks of a block, so short chunks cost little.
+// ZH_OSC_FC / ZH_OSC_SCALAR override for experiments.
 static uint32_t osc_frames_per_lane(uint32_t lanes, uint32_t nframes) {
-    static int forced = -1, waves = -1;
+    (void)lanes; (void)nframes;
+    static int forced = -1;
     if (forced < 0) { const char *e = getenv("ZH_OSC_FC"); forced = e ? atoi(e) : 0; }
-    if (waves < 0) { const char *e = getenv("ZH_OSC_WAVES"); waves = e ? atoi(e) : 4096; }
-    if (forced > 0) return (uint32_t)forced;
-    const uint64_t groups = (lanes + 63) / 64;
-    uint64_t fc = (groups * nframes) / (uint64_t)waves;
-    uint32_t p = 4;
-    while (p * 2 <= fc && p < 64) p *= 2;
-    return p;
+    return forced > 0 ? (uint32_t)forced : 4u;
 }
 static bool osc_force_scalar() {
     static int v = -1;
