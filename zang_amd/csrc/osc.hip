@@ -43,6 +43,7 @@ struct PulseOscP {        // policy for the chunked kernels
     }
     static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return pulse_sample(k, cnt); }
     // walking consecutive frames: the previous frame's half-period bit is carried instead of recomputed
+    static constexpr bool kShortChunks = true;              // osc_frames_per_lane
     using R = PulseRoll;
     static __device__ __forceinline__ R roll_init(const K &k, uint32_t cnt) { return pulse_roll_init(k, cnt); }
     static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &r) { return pulse_sample_roll(k, cnt, r); }
@@ -219,6 +220,7 @@ struct TriSawOscP {
     using K = TriSawK;
     static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) { trisaw_setup(k, srf, freq, color); }
     static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return trisaw_sample(k, cnt); }
+    static constexpr bool kShortChunks = false;
     using R = int;                                          // nothing carried
     static __device__ __forceinline__ R roll_init(const K &, uint32_t) { return 0; }
     static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &) { return trisaw_sample(k, cnt); }
@@ -246,16 +248,23 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict_
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// Frames per lane for the chunked kernels.  Measured (tools/sweep_osc_fc.sh, PulseOsc, 1024-frame images): 4 frames per
+// Frames per lane for the chunked kernels.  PulseOsc, measured (tools/sweep_osc_fc.sh, 1024-frame images): 4 frames per
 // lane is the best or within 5 % of the best at every voice count from 4,096 to 1 Mi and 11-15 % better than 64 between
 // 65,536 and 524,288 voices (short waves interleave their ALU and store phases better, and the blocks sweep the image in
 // row order); the per-voice setup is shared through LDS by the four chunks of a block, so short chunks cost little.
+// TriSawOsc's setup (three divides) and sample (~45 instructions) are heavier: it keeps longer chunks -- enough of them
+// for ~4096 waves, at least 8 frames (131,072 voices: 100 us against 131 us with 4 frames per lane).
 // ZH_OSC_FC / ZH_OSC_SCALAR override for experiments.
-static uint32_t osc_frames_per_lane(uint32_t lanes, uint32_t nframes) {
-    (void)lanes; (void)nframes;
+static uint32_t osc_frames_per_lane(bool short_chunks, uint32_t lanes, uint32_t nframes) {
     static int forced = -1;
     if (forced < 0) { const char *e = getenv("ZH_OSC_FC"); forced = e ? atoi(e) : 0; }
-    return forced > 0 ? (uint32_t)forced : 4u;
+    if (forced > 0) return (uint32_t)forced;
+    if (short_chunks) return 4u;
+    const uint64_t groups = (lanes + 63) / 64;
+    const uint64_t fc = (groups * nframes) / 4096u;
+    uint32_t p = 8;
+    while (p * 2 <= fc && p < 64) p *= 2;
+    return p;
 }
 static bool osc_force_scalar() {
     static int v = -1;
@@ -276,7 +285,7 @@ static void launch_osc_const(zh_ctx *ctx, uint32_t n, const uint32_t *ci, uint32
     const bool vec = n % 4 == 0 && outb.stride % 4 == 0 && aligned16(outb.ptr) && (!fq.pv || aligned16(fq.pv)) &&
                      (!col.pv || aligned16(col.pv)) && !osc_force_scalar();
     const uint32_t lanes = vec ? n / 4 : n;
-    const uint32_t fc = osc_frames_per_lane(lanes, end - start);
+    const uint32_t fc = osc_frames_per_lane(OSC::kShortChunks, lanes, end - start);
     const uint32_t chunks = (end - start + fc - 1) / fc;
     dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
     if (vec) {
