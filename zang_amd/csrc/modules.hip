@@ -285,7 +285,10 @@ struct zh_distortion { zh_ctx *ctx; uint32_t n; };
 
 // grid: x = 64-voice groups, y = groups of 4 chunks of DIST_FC frames; per chunk each lane
 // recomputes its voice's gain1 = pow(2, ingain*8 - 2) (Distortion.zig:41).
-constexpr uint32_t DIST_FC = 32;
+#ifndef ZH_DIST_FC
+#define ZH_DIST_FC 32
+#endif
+constexpr uint32_t DIST_FC = ZH_DIST_FC;
 template <bool ZF, bool OVERDRIVE>
 __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg input, uint32_t start, uint32_t end,
                                                     F32P ingain, F32P outgain, F32P offset) {
