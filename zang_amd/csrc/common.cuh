@@ -103,7 +103,10 @@ static inline bool cob_ok(const zh_cob &c, uint32_t n_voices, uint32_t span_end)
 
 // One wave (64 voices) per workgroup for the sequential lane-per-voice kernels: at small
 // voice counts this spreads the waves over as many CUs as possible.
-constexpr int kSeqBlock = 64;
+#ifndef ZH_SEQ_BLOCK
+#define ZH_SEQ_BLOCK 64
+#endif
+constexpr int kSeqBlock = ZH_SEQ_BLOCK;
 static inline dim3 seq_grid(uint32_t n) { return dim3((n + kSeqBlock - 1) / kSeqBlock); }
 
 template <typename T> static inline int dev_alloc(T **p, size_t count) {
