@@ -43,7 +43,15 @@ enum { ZH_OK = 0, ZH_ERR_INVALID = -1, ZH_ERR_UNSUPPORTED = -2, ZH_ERR_NO_DEVICE
 
 /* paint flags */
 enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference contract) */
-       ZH_PAINT_ZERO_FIRST = 1   /* zang.zero(span,out) then paint, in one kernel (basics.zig:12) */ };
+       ZH_PAINT_ZERO_FIRST = 1,  /* zang.zero(span,out) then paint, in one kernel (basics.zig:12) */
+       /* (2 = ZH_MIX_SEQUENTIAL, a zh_mixdown_voices flag) */
+       ZH_PAINT_PARAMS_UNCHANGED = 4
+       /* The caller states that `params` -- scalars AND the contents of every per-voice array -- are what this module's
+        * previous paint call was given.  The reference recomputes a paint's per-voice constants on every call
+        * (e.g. PulseOsc.zig:87-95); a module may instead reuse the ones that call left behind.  Honoured by the
+        * constant-frequency PulseOsc / TriSawOsc paints, ignored elsewhere; results are bit-identical either way.
+        * A paint recorded into a graph with this flag uses the constants stored by the last unflagged eager paint
+        * before the replay. */ };
 
 typedef struct zh_ctx zh_ctx;
 
@@ -99,8 +107,12 @@ ZH_API int  zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t
 /* hipGraph capture of a launch sequence: everything enqueued on the context between begin and
  * end is recorded instead of run; zh_graph_launch replays it with one host call.  A buffer
  * loop (zero + paint + mix per 1024-frame buffer) is launch-bound at small voice counts, and
- * this removes the per-kernel host cost.  Capture an EVEN number of paints of any chunked
- * oscillator module (its state is double-buffered and flips per paint). */
+ * this removes the per-kernel host cost.  (The chunked oscillators double-buffer their phase counters and
+ * flip buffers on the host at every paint; the library records which buffer a capture started from and how many
+ * flips it holds, and zh_graph_launch copies the live counters over first when eager paints or other graphs
+ * have left them in the other buffer -- any number of paints may be captured, and replays and eager paints mix freely.)
+ * The voice mixdown's scratch must already be large enough (paint once eagerly first): it cannot grow while
+ * a capture is recording (ZH_ERR_UNSUPPORTED). */
 typedef struct zh_graph zh_graph;
 ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
 ZH_API int  zh_graph_end_capture(zh_ctx *ctx, zh_graph **out);
@@ -138,6 +150,22 @@ ZH_API int zh_mixdown_voices(zh_ctx *ctx, uint32_t span_start, uint32_t span_end
  * bit-faithful, meant for small voice counts (one lane per frame walks all voices). */
 enum { ZH_MIX_SEQUENTIAL = 2 };
 
+/* ---------------------------------------------------------------- multi-GPU mixdown exchange (new; no reference counterpart)
+ * Voices shard across processes, one per GPU; the only data exchanged is each GPU's partial mix.
+ * Besides an RCCL all-reduce issued by the host binding, the partials can be written DIRECTLY into the root GPU's
+ * memory: the root allocates one slot per rank (zh_ipc_alloc) and passes the 64-byte handle to the other processes
+ * by any host channel; they map it (zh_ipc_open) and hand `slot base + rank * slot_bytes` to zh_nice_paint_mix /
+ * zh_mixdown_voices as the mix pointer -- the mixdown kernel's stores then travel over xGMI.  When every rank has
+ * synchronised its stream (host-side barrier), the root adds the slots in rank order (zh_sum_slots): a fixed
+ * order, reproducible bit for bit.  zh_free releases a zh_ipc_alloc block, zh_ipc_close a mapping. */
+ZH_API int zh_ipc_alloc(zh_ctx *ctx, size_t bytes, void **dev_ptr, uint8_t *handle64 /* out: 64 bytes */);
+ZH_API int zh_ipc_open(zh_ctx *ctx, const uint8_t *handle64, void **dev_ptr);
+ZH_API int zh_ipc_close(zh_ctx *ctx, void *dev_ptr);
+/* dst[i] (+)= ((slot_0[i] + slot_1[i]) + slot_2[i]) + ... for i < n; slot_r = slots + r * slot_stride_floats.
+ * flags: ZH_PAINT_ZERO_FIRST overwrites dst. */
+ZH_API int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_slots, size_t slot_stride_floats,
+                        size_t n, uint32_t flags);
+
 /* zang.mixDown (src/zang/mixdown.zig:8-86): f32 mix buffer -> interleaved signed 8 / 16-bit LE PCM with
  * clamping.  `dst` (device bytes, n * bytes_per_sample * num_channels) and `mix` (device float[n]). */
 enum { ZH_AUDIO_SIGNED8 = 0, ZH_AUDIO_SIGNED16_LSB = 1 };                                             /* :3-6 */
@@ -167,6 +195,11 @@ ZH_API int zh_pulseosc_set_state(zh_pulseosc *m, const zh_pulseosc_state *host);
 ZH_API int zh_pulseosc_paint(zh_pulseosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                              const zh_buf *temps, zh_bool note_id_changed,
                              const zh_pulseosc_params *params, uint32_t flags);                       /* :44-157 */
+/* n_buffers consecutive paint calls with the same span and params, buffer b into outputs[b] (what a host loop over
+ * 1024-frame buffers does, examples/write_wav.zig:58-66): with a constant frequency the phase counter of any frame is
+ * cnt + frames_before * ifreq exactly (:111), so the whole batch is one launch.  State afterwards = after the last call. */
+ZH_API int zh_pulseosc_paint_batch(zh_pulseosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs /*[n_buffers]*/,
+                                   uint32_t n_buffers, const zh_pulseosc_params *params, uint32_t flags);
 
 /* ---------------------------------------------------------------- TriSawOsc (src/modules/TriSawOsc.zig) */
 typedef struct zh_trisawosc zh_trisawosc;
@@ -179,6 +212,8 @@ ZH_API int zh_trisawosc_set_state(zh_trisawosc *m, const zh_trisawosc_state *hos
 ZH_API int zh_trisawosc_paint(zh_trisawosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,
                               const zh_buf *temps, zh_bool note_id_changed,
                               const zh_trisawosc_params *params, uint32_t flags);                     /* :46-156 */
+ZH_API int zh_trisawosc_paint_batch(zh_trisawosc *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs /*[n_buffers]*/,
+                                    uint32_t n_buffers, const zh_trisawosc_params *params, uint32_t flags);   /* see zh_pulseosc_paint_batch */
 
 /* ---------------------------------------------------------------- Noise (src/modules/Noise.zig) */
 typedef struct zh_noise zh_noise;

@@ -76,3 +76,76 @@ def test_bench_workload_last_image_matches_oracle(ctx, oracle):
             ref[v] = 0
             L.zo_pulseosc_paint(C.byref(st), 0, F, oracle.fptr(ref[v]), SR, oracle.constant(freq[v]), float(color[v]))
     util.assert_bitexact(got[::16], ref[::16], "bench step after 12 buffers")
+
+
+@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+def test_graph_with_odd_paint_count_and_eager_paints_between(ctx, kind):
+    """The chunked oscillators flip a double-buffered phase counter on the host at every paint.  A graph holding an
+    ODD number of paints, replayed back to back and mixed with eager paints, must still continue the phase exactly
+    (zh_graph_launch reconciles the buffers; ADVICE r1 osc.hip:356)."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V = 512
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
+        M = mod.PulseOsc if kind == "pulse" else mod.TriSawOsc
+        me, mg = M(V, c2), M(V, c2)
+        sp = zang.Span(0, F)
+        P = me.Params(SR, zang.constant(fr), col)
+        n_total = 1 + 3 + 3 + 1 + 3 + 2 + 3
+        imgs_e = [c2.image(F, V) for _ in range(n_total)]
+        imgs_g = [c2.image(F, V) for _ in range(n_total)]
+        for o in imgs_e:
+            me.paint(sp, [o], [], False, P, zero_first=True)
+        # graph side: images are baked into the graph, so replays overwrite the same three; copy them out after each
+        ring = [c2.image(F, V) for _ in range(3)]
+        k = 0
+        def eager(n):
+            nonlocal k
+            for _ in range(n):
+                mg.paint(sp, [imgs_g[k]], [], False, P, zero_first=True); k += 1
+        def replay(g):
+            nonlocal k
+            g.launch()
+            for o in ring:
+                imgs_g[k].copy_(o); k += 1
+        eager(1)
+        c2.sync()
+        g = c2.capture(lambda: [mg.paint(sp, [o], [], False, P, zero_first=True) for o in ring])   # 3 paints: odd
+        replay(g); replay(g); eager(1); replay(g); eager(2); replay(g)
+        c2.sync()
+        assert k == n_total
+        for i, (a, b) in enumerate(zip(imgs_e, imgs_g)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{kind}: buffer {i} differs"
+        assert np.array_equal(me.state(), mg.state())
+        g.close(); c2.close()
+
+
+def test_mixdown_scratch_cannot_grow_inside_capture(ctx):
+    """ADVICE r1 basics.hip:248: growing the mixdown scratch inside a capture is refused (ZH_ERR_UNSUPPORTED), and a
+    graph recorded with a smaller scratch stays valid after a later, larger eager mixdown grew it."""
+    import torch
+    import zang_amd
+    from zang_amd import abi, zang
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        small = torch.rand((F, 4096), device="cuda"); big = torch.rand((F, 65536), device="cuda")
+        mix_s = torch.zeros(F, device="cuda"); mix_b = torch.zeros(F, device="cuda"); mix_g = torch.zeros(F, device="cuda")
+        sp = zang.Span(0, F)
+        with pytest.raises(abi.ZangHipError):
+            c2.capture(lambda: zang.mixdownVoices(sp, mix_s, small, zero_first=True, ctx=c2))     # nothing reserved yet
+        zang.mixdownVoices(sp, mix_s, small, zero_first=True, ctx=c2)                              # reserves (eager)
+        c2.sync()
+        g = c2.capture(lambda: zang.mixdownVoices(sp, mix_g, small, zero_first=True, ctx=c2))
+        zang.mixdownVoices(sp, mix_b, big, zero_first=True, ctx=c2)                                # grows: old block retired, not freed
+        g.launch()
+        c2.sync()
+        assert torch.equal(mix_g.view(torch.int32), mix_s.view(torch.int32))
+        ref = big.double().sum(1)
+        assert torch.allclose(mix_b.double(), ref, rtol=0, atol=1e-2)
+        g.close(); c2.close()

@@ -124,3 +124,79 @@ def test_const_freq_scalar_lane_fallback(ctx, oracle, kind):
     got, gst = _gpu_osc(ctx, kind, V, F, util.SPANS_THREE, freq, color, out0=out0)
     util.assert_bitexact(got, ref, f"{kind} scalar-lane")
     assert [int(x) for x in gst["cnt"]] == [s[0] for s in rst]
+
+
+def _oracle_buffers(po, kind, V, F, span, nbuf, freq, color, out0=None):
+    """nbuf consecutive paints over `span`, each into its own buffer (a host loop over 1024-frame buffers)."""
+    L = po.lib()
+    outs = np.zeros((nbuf, V, F), np.float32) if out0 is None else np.repeat(out0[None], nbuf, 0).copy()
+    cnts = []
+    for v in range(V):
+        st = po.PulseOsc() if kind == "pulse" else po.TriSawOsc()
+        (L.zo_pulseosc_init if kind == "pulse" else L.zo_trisawosc_init)(C.byref(st))
+        fn = L.zo_pulseosc_paint if kind == "pulse" else L.zo_trisawosc_paint
+        for b in range(nbuf):
+            fn(C.byref(st), span[0], span[1], po.fptr(outs[b, v]), SR, po.constant(freq[v]), float(color[v]))
+        cnts.append(st.cnt)
+    return outs, cnts
+
+
+@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+@pytest.mark.parametrize("nbuf,span,zf", [(5, (0, 1024), True), (40, (0, 256), True), (3, (100, 901), False)])
+def test_paint_batch_equals_consecutive_paints(ctx, oracle, kind, nbuf, span, zf):
+    """zh_*_paint_batch: one launch for nbuf buffers (more than kOscMaxBatch = 32 splits into two) == nbuf paints."""
+    from zang_amd import modules as mod, zang, workloads
+    V, F = 512, 1024
+    freq, color, _, _ = workloads.voice_params(2, 7, V)
+    freq[:3] = [6000.5, -1.0, 440.0]                     # silent voices in a batch too
+    out0 = util.rng_buffers(21, V, F)
+    ref, rcnt = _oracle_buffers(oracle, kind, V, F, span, nbuf, freq, color, out0=None if zf else out0)
+    m = (mod.PulseOsc if kind == "pulse" else mod.TriSawOsc)(V, ctx)
+    imgs = [util.to_image(out0) for _ in range(nbuf)]
+    fr, col = util.dev(freq), util.dev(color)
+    m.paint_batch(zang.Span(*span), imgs, m.Params(SR, zang.constant(fr), col), zero_first=zf)
+    ctx.sync()
+    for b in range(nbuf):
+        got = util.from_image(imgs[b])[:, span[0]:span[1]]
+        util.assert_bitexact(got, ref[b][:, span[0]:span[1]], f"{kind} batch buffer {b}")
+        # frames outside the span are untouched
+        util.assert_bitexact(util.from_image(imgs[b])[:, :span[0]], out0[:, :span[0]], "before span")
+        util.assert_bitexact(util.from_image(imgs[b])[:, span[1]:], out0[:, span[1]:], "after span")
+    assert [int(x) for x in m.state()["cnt"]] == rcnt
+
+
+@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+def test_params_unchanged_flag(ctx, oracle, kind):
+    """ZH_PAINT_PARAMS_UNCHANGED: the table of per-voice constants written by the previous paint gives the same bits;
+    a flagged paint whose scalar params / pointers differ from the stored ones falls back to computing them."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V, F = 1024, 1024
+    freq, color, _, _ = workloads.voice_params(2, 3, V)
+    freq[5] = 6100.0
+    freq2 = (freq * 1.5).astype(np.float32)
+    m = (mod.PulseOsc if kind == "pulse" else mod.TriSawOsc)(V, ctx)
+    fr, col, fr2 = util.dev(freq), util.dev(color), util.dev(freq2)
+    imgs = [ctx.image(F, V) for _ in range(6)]
+    sp = zang.Span(0, F)
+    P = m.Params
+    m.paint(sp, [imgs[0]], [], False, P(SR, zang.constant(fr), col), zero_first=True)                       # stores the table
+    m.paint(sp, [imgs[1]], [], False, P(SR, zang.constant(fr), col), zero_first=True, params_unchanged=True)  # loads it
+    m.paint(sp, [imgs[2]], [], False, P(SR, zang.constant(fr), col), zero_first=True, params_unchanged=True)
+    # flagged, but another array: the stored table does not match -> computed (and stored) again
+    m.paint(sp, [imgs[3]], [], False, P(SR, zang.constant(fr2), col), zero_first=True, params_unchanged=True)
+    m.paint(sp, [imgs[4]], [], False, P(SR, zang.constant(fr2), col), zero_first=True, params_unchanged=True)
+    # flagged, another sample rate
+    m.paint(sp, [imgs[5]], [], False, P(44100.0, zang.constant(fr2), col), zero_first=True, params_unchanged=True)
+    ctx.sync()
+    L = oracle.lib()
+    ref = np.zeros((6, V, F), np.float32)
+    plan = [(SR, freq), (SR, freq), (SR, freq), (SR, freq2), (SR, freq2), (44100.0, freq2)]
+    for v in range(V):
+        st = oracle.PulseOsc() if kind == "pulse" else oracle.TriSawOsc()
+        (L.zo_pulseosc_init if kind == "pulse" else L.zo_trisawosc_init)(C.byref(st))
+        fn = L.zo_pulseosc_paint if kind == "pulse" else L.zo_trisawosc_paint
+        for b, (sr, f) in enumerate(plan):
+            fn(C.byref(st), 0, F, oracle.fptr(ref[b, v]), sr, oracle.constant(f[v]), float(color[v]))
+    for b in range(6):
+        util.assert_bitexact(util.from_image(imgs[b]), ref[b], f"{kind} params_unchanged buffer {b}")

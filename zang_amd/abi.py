@@ -12,6 +12,7 @@ u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 
 ZH_OK = 0
 PAINT_ADD, PAINT_ZERO_FIRST = 0, 1
+PAINT_PARAMS_UNCHANGED = 4
 MIX_SEQUENTIAL = 2
 AUDIO_SIGNED8, AUDIO_SIGNED16_LSB = 0, 1
 COB_CONSTANT, COB_BUFFER = 0, 1
@@ -292,6 +293,10 @@ SIGNATURES = {
     "zh_multiply_scalar": (C.c_int, [vp, u32, u32, Buf, Buf, F32]),
     "zh_multiply_with_scalar": (C.c_int, [vp, u32, u32, Buf, F32]),
     "zh_mixdown_voices": (C.c_int, [vp, u32, u32, vp, Buf, u32]),
+    "zh_ipc_alloc": (C.c_int, [vp, C.c_size_t, P(vp), vp]),
+    "zh_ipc_open": (C.c_int, [vp, vp, P(vp)]),
+    "zh_ipc_close": (C.c_int, [vp, vp]),
+    "zh_sum_slots": (C.c_int, [vp, vp, vp, u32, C.c_size_t, C.c_size_t, u32]),
     "zh_sineosc_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_sineosc_destroy": (C.c_int, [vp]),
     "zh_sineosc_get_state": (C.c_int, [vp, vp]),
@@ -302,11 +307,13 @@ SIGNATURES = {
     "zh_pulseosc_get_state": (C.c_int, [vp, vp]),
     "zh_pulseosc_set_state": (C.c_int, [vp, vp]),
     "zh_pulseosc_paint": (C.c_int, _paint(PulseOscParams)),
+    "zh_pulseosc_paint_batch": (C.c_int, [vp, u32, u32, P(Buf), u32, P(PulseOscParams), u32]),
     "zh_trisawosc_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_trisawosc_destroy": (C.c_int, [vp]),
     "zh_trisawosc_get_state": (C.c_int, [vp, vp]),
     "zh_trisawosc_set_state": (C.c_int, [vp, vp]),
     "zh_trisawosc_paint": (C.c_int, _paint(TriSawOscParams)),
+    "zh_trisawosc_paint_batch": (C.c_int, [vp, u32, u32, P(Buf), u32, P(TriSawOscParams), u32]),
     "zh_noise_create": (C.c_int, [vp, u32, u64, P(vp)]),
     "zh_noise_destroy": (C.c_int, [vp]),
     "zh_noise_get_state": (C.c_int, [vp, vp]),

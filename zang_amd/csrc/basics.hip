@@ -245,15 +245,18 @@ __global__ void __launch_bounds__(256) k_mix_down(uint8_t *__restrict__ dst, con
     }
 }
 
-int zh_mix_reserve(zh_ctx *ctx, size_t floats) {
+int zh_mix_reserve(zh_ctx *ctx, size_t floats) { ZH_GUARD(ctx);
     if (ctx->mix_partials_floats >= floats) return ZH_OK;
-    if (ctx->mix_partials) {
-        ZH_TRY(hipStreamSynchronize(ctx->stream));
-        ZH_TRY(hipFree(ctx->mix_partials));
-        ctx->mix_partials = nullptr;
-        ctx->mix_partials_floats = 0;
-    }
-    ZH_TRY(hipMalloc((void **)&ctx->mix_partials, floats * sizeof(float)));
+    // Growing: never while the stream is capturing (an allocation cannot be recorded, and a synchronise would
+    // invalidate the capture) -- reserve with an eager call of the same size first.  The old block is retired, not
+    // freed: a graph captured earlier keeps its pointer in its mixdown nodes (freed at zh_destroy).
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (ctx->capturing || (hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone))
+        return ZH_ERR_UNSUPPORTED;
+    float *p = nullptr;
+    ZH_TRY(hipMalloc((void **)&p, floats * sizeof(float)));
+    if (ctx->mix_partials) ctx->mix_retired.push_back(ctx->mix_partials);
+    ctx->mix_partials = p;
     ctx->mix_partials_floats = floats;
     return ZH_OK;
 }
@@ -265,19 +268,19 @@ void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *d
 
 extern "C" {
 
-int zh_zero(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest) { return launch_ew<OP_ZERO>(ctx, s, e, dest, nullptr, nullptr, nullptr); }
-int zh_set(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { return launch_ew<OP_SET>(ctx, s, e, dest, nullptr, nullptr, &a); }
-int zh_copy(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf src) { return launch_ew<OP_COPY>(ctx, s, e, dest, &src, nullptr, nullptr); }
-int zh_add(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_buf b) { return launch_ew<OP_ADD>(ctx, s, e, dest, &a, &b, nullptr); }
-int zh_add_into(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf src) { return launch_ew<OP_ADD_INTO>(ctx, s, e, dest, &src, nullptr, nullptr); }
-int zh_add_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_f32 b) { return launch_ew<OP_ADD_SCALAR>(ctx, s, e, dest, &a, nullptr, &b); }
-int zh_add_scalar_into(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { return launch_ew<OP_ADD_SCALAR_INTO>(ctx, s, e, dest, nullptr, nullptr, &a); }
-int zh_multiply(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_buf b) { return launch_ew<OP_MUL>(ctx, s, e, dest, &a, &b, nullptr); }
-int zh_multiply_with(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a) { return launch_ew<OP_MUL_WITH>(ctx, s, e, dest, &a, nullptr, nullptr); }
-int zh_multiply_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_f32 b) { return launch_ew<OP_MUL_SCALAR>(ctx, s, e, dest, &a, nullptr, &b); }
-int zh_multiply_with_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { return launch_ew<OP_MUL_WITH_SCALAR>(ctx, s, e, dest, nullptr, nullptr, &a); }
+int zh_zero(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest) { ZH_GUARD(ctx); return launch_ew<OP_ZERO>(ctx, s, e, dest, nullptr, nullptr, nullptr); }
+int zh_set(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { ZH_GUARD(ctx); return launch_ew<OP_SET>(ctx, s, e, dest, nullptr, nullptr, &a); }
+int zh_copy(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf src) { ZH_GUARD(ctx); return launch_ew<OP_COPY>(ctx, s, e, dest, &src, nullptr, nullptr); }
+int zh_add(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_buf b) { ZH_GUARD(ctx); return launch_ew<OP_ADD>(ctx, s, e, dest, &a, &b, nullptr); }
+int zh_add_into(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf src) { ZH_GUARD(ctx); return launch_ew<OP_ADD_INTO>(ctx, s, e, dest, &src, nullptr, nullptr); }
+int zh_add_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_f32 b) { ZH_GUARD(ctx); return launch_ew<OP_ADD_SCALAR>(ctx, s, e, dest, &a, nullptr, &b); }
+int zh_add_scalar_into(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { ZH_GUARD(ctx); return launch_ew<OP_ADD_SCALAR_INTO>(ctx, s, e, dest, nullptr, nullptr, &a); }
+int zh_multiply(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_buf b) { ZH_GUARD(ctx); return launch_ew<OP_MUL>(ctx, s, e, dest, &a, &b, nullptr); }
+int zh_multiply_with(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a) { ZH_GUARD(ctx); return launch_ew<OP_MUL_WITH>(ctx, s, e, dest, &a, nullptr, nullptr); }
+int zh_multiply_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_buf a, zh_f32 b) { ZH_GUARD(ctx); return launch_ew<OP_MUL_SCALAR>(ctx, s, e, dest, &a, nullptr, &b); }
+int zh_multiply_with_scalar(zh_ctx *ctx, uint32_t s, uint32_t e, zh_buf dest, zh_f32 a) { ZH_GUARD(ctx); return launch_ew<OP_MUL_WITH_SCALAR>(ctx, s, e, dest, nullptr, nullptr, &a); }
 
-int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_buf src, uint32_t flags) {
+int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_buf src, uint32_t flags) { ZH_GUARD(ctx);
     if (!ctx || !dst || end < start || !buf_covers(src, src.voices, end)) return ZH_ERR_INVALID;
     const uint32_t V = src.voices, nframes = end - start;
     if (nframes == 0) return ZH_OK;
@@ -301,7 +304,7 @@ int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_
 }
 
 int zh_mix_down(zh_ctx *ctx, uint8_t *dst, const float *mix, uint32_t n, uint32_t audio_format, uint32_t num_channels,
-                uint32_t channel_index, float vol) {
+                uint32_t channel_index, float vol) { ZH_GUARD(ctx);
     if (!ctx || (n && (!dst || !mix)) || audio_format > ZH_AUDIO_SIGNED16_LSB || num_channels == 0 || channel_index >= num_channels)
         return ZH_ERR_INVALID;
     if (!n) return ZH_OK;

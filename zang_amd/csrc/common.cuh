@@ -15,19 +15,62 @@
 #include "../../include/zang_hip.h"
 
 #if !defined(ZH_DEVICE_ONLY)
+#include <vector>
+// A module whose state is double-buffered and flips on the HOST at every paint (the chunked oscillators, osc.hip):
+// a captured graph bakes in both buffer pointers, so the library records which buffer a capture started from and
+// how many flips it holds, and zh_graph_launch reconciles the host-side index with that (ctx.hip).
+struct zh_flipper {
+    uint64_t id;                 // registry key (ctx.hip zh_flipper_*): a destroyed module is never dereferenced
+    zh_ctx *ctx;
+    uint32_t n;
+    uint32_t *cnt[2];
+    int cur;
+};
+struct zh_flip_use {
+    uint64_t id;
+    zh_flipper *f;
+    int first_cur;               // f->cur when the capture first painted it
+    uint32_t flips;              // paints of it inside the capture
+};
+
 struct zh_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    // scratch for the two-pass voice mixdown: [blocks][frames] partial sums
+    // scratch for the two-pass voice mixdown: [blocks][frames] partial sums.  Blocks are never freed while the
+    // context lives: a captured graph keeps the pointer it was recorded with (basics.hip zh_mix_reserve).
     float *mix_partials;
     size_t mix_partials_floats;
+    std::vector<float *> mix_retired;
+    bool capturing;
+    std::vector<zh_flip_use> capture_log;
 };
 
 struct zh_graph {
     hipGraph_t graph;
     hipGraphExec_t exec;
+    std::vector<zh_flip_use> flips;
 };
+
+// Every entry point that allocates or launches runs with the context's device current and restores the caller's
+// (two contexts on different GPUs in one process; a host that called hipSetDevice / torch.cuda.set_device elsewhere).
+struct ZhDeviceGuard {
+    int prev, want;
+    explicit ZhDeviceGuard(int device) : prev(-1), want(device) {
+        if (want < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~ZhDeviceGuard() { if (want >= 0 && prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    ZhDeviceGuard(const ZhDeviceGuard &) = delete;
+    ZhDeviceGuard &operator=(const ZhDeviceGuard &) = delete;
+};
+#define ZH_GUARD(ctxptr) const zh_ctx *_zh_gctx = (ctxptr); ZhDeviceGuard _zh_guard(_zh_gctx ? _zh_gctx->device : -1)
+
+// ctx.hip: registry of live flippers + the capture log
+void zh_flipper_register(zh_flipper *f);
+void zh_flipper_unregister(zh_flipper *f);
+void zh_flipper_painted(zh_flipper *f);      // call right BEFORE flipping f->cur in a paint
 
 struct zh_event {
     hipEvent_t ev;

@@ -808,7 +808,7 @@ static void pmosc_free(zh_pmosc *m) {
 extern "C" {
 
 // ------------------------------------------------------------------ NiceInstrument
-int zh_nice_create(zh_ctx *ctx, uint32_t n, zh_f32 color, zh_nice **out) {
+int zh_nice_create(zh_ctx *ctx, uint32_t n, zh_f32 color, zh_nice **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_nice *m = new (std::nothrow) zh_nice();
     if (!m) return ZH_ERR_INVALID;
@@ -831,14 +831,14 @@ int zh_nice_create(zh_ctx *ctx, uint32_t n, zh_f32 color, zh_nice **out) {
     *out = m;
     return zh_launch_status();
 }
-int zh_nice_destroy(zh_nice *m) {
+int zh_nice_destroy(zh_nice *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     nice_free(m);
     delete m;
     return ZH_OK;
 }
-int zh_nice_get_state(zh_nice *m, zh_nice_state *host) {
+int zh_nice_get_state(zh_nice *m, zh_nice_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint32_t> cnt, es;
     std::vector<float> l, b, t, lv, sv;
@@ -857,7 +857,7 @@ int zh_nice_get_state(zh_nice *m, zh_nice_state *host) {
     }
     return ZH_OK;
 }
-int zh_nice_set_state(zh_nice *m, const zh_nice_state *host) {
+int zh_nice_set_state(zh_nice *m, const zh_nice_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     const uint32_t n = m->n;
     std::vector<uint32_t> cnt(n), es(n);
@@ -876,7 +876,7 @@ int zh_nice_set_state(zh_nice *m, const zh_nice_state *host) {
     return rc;
 }
 int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                  zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
+                  zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;   // the fused kernel keeps both temps in registers
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
@@ -899,7 +899,7 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     return zh_launch_status();
 }
 int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_bool note_id_changed,
-                      const zh_nice_params *p, uint32_t flags) {
+                      const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !mix || !p || end < start) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
     const uint32_t nframes = end - start;
@@ -921,7 +921,7 @@ static SpanTableP mk_span_table(const zh_span_table *t) {
 }
 
 int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                        float sample_rate, const zh_span_table *table, uint32_t flags) {
+                        float sample_rate, const zh_span_table *table, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     if (!m || !outputs || end < start || !buf_covers(outputs[0], m->n, end) || !span_table_ok(table)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
@@ -942,7 +942,7 @@ int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *
 }
 
 // ------------------------------------------------------------------ Noise -> Filter voice
-int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise_filter **out) {
+int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise_filter **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_noise_filter *m = new (std::nothrow) zh_noise_filter();
     if (!m) return ZH_ERR_INVALID;
@@ -962,14 +962,14 @@ int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_nois
     *out = m;
     return zh_launch_status();
 }
-int zh_noise_filter_destroy(zh_noise_filter *m) {
+int zh_noise_filter_destroy(zh_noise_filter *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     nf_free(m);
     delete m;
     return ZH_OK;
 }
-int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host) {
+int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint64_t> s;
     std::vector<float> nb, l, b;
@@ -989,7 +989,7 @@ int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host) {
     }
     return ZH_OK;
 }
-int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *host) {
+int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     const uint32_t n = m->n;
     std::vector<uint64_t> s(n);
@@ -1009,7 +1009,7 @@ int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *h
     return rc;
 }
 int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                          zh_bool note_id_changed, const zh_noise_filter_params *p, uint32_t flags) {
+                          zh_bool note_id_changed, const zh_noise_filter_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
     if (p->color > ZH_NOISE_PINK || p->type > ZH_FILTER_ALL_PASS) return ZH_ERR_INVALID;
@@ -1047,7 +1047,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
 }
 
 // ------------------------------------------------------------------ PMOscInstrument
-int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc **out) {
+int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_pmosc *m = new (std::nothrow) zh_pmosc();
     if (!m) return ZH_ERR_INVALID;
@@ -1069,14 +1069,14 @@ int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc *
     *out = m;
     return zh_launch_status();
 }
-int zh_pmosc_destroy(zh_pmosc *m) {
+int zh_pmosc_destroy(zh_pmosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     pmosc_free(m);
     delete m;
     return ZH_OK;
 }
-int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host) {
+int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint32_t> es;
     std::vector<float> tc, tm, t, lv, sv;
@@ -1093,7 +1093,7 @@ int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host) {
     }
     return ZH_OK;
 }
-int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host) {
+int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     const uint32_t n = m->n;
     std::vector<uint32_t> es(n);
@@ -1111,7 +1111,7 @@ int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host) {
     return rc;
 }
 int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                   zh_bool note_id_changed, const zh_pmosc_params *p, uint32_t flags) {
+                   zh_bool note_id_changed, const zh_pmosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
@@ -1124,7 +1124,7 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
 }
 
 int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                         float sample_rate, const zh_span_table *table, uint32_t flags) {
+                         float sample_rate, const zh_span_table *table, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     if (!m || !outputs || end < start || !buf_covers(outputs[0], m->n, end) || !span_table_ok(table)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;

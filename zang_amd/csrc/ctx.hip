@@ -3,6 +3,30 @@
 #include <string.h>
 #include <vector>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
+
+// ---- flippers: modules with host-flipped double-buffered state (osc.hip) -------------------------------
+static std::mutex g_flip_mu;
+static std::unordered_map<uint64_t, zh_flipper *> g_flippers;
+static uint64_t g_flip_next = 1;
+
+void zh_flipper_register(zh_flipper *f) {
+    std::lock_guard<std::mutex> lk(g_flip_mu);
+    f->id = g_flip_next++;
+    g_flippers[f->id] = f;
+}
+void zh_flipper_unregister(zh_flipper *f) {
+    std::lock_guard<std::mutex> lk(g_flip_mu);
+    g_flippers.erase(f->id);
+}
+void zh_flipper_painted(zh_flipper *f) {
+    zh_ctx *c = f->ctx;
+    if (!c->capturing) return;
+    for (zh_flip_use &u : c->capture_log)
+        if (u.id == f->id) { u.flips++; return; }
+    c->capture_log.push_back(zh_flip_use{f->id, f, f->cur, 1u});
+}
 
 int zh_store_mode() {
     static int mode = -1;
@@ -34,30 +58,31 @@ int zh_create(zh_ctx **out, int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZH_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return ZH_ERR_INVALID;
-    ZH_TRY(hipSetDevice(device));
+    ZhDeviceGuard guard(device);                  // the caller's current device is restored on return
     zh_ctx *c = new (std::nothrow) zh_ctx();
     if (!c) return ZH_ERR_INVALID;
     c->device = device;
     c->own_stream = true;
     c->mix_partials = nullptr;
     c->mix_partials_floats = 0;
+    c->capturing = false;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
     *out = c;
     return ZH_OK;
 }
 
-int zh_destroy(zh_ctx *ctx) {
+int zh_destroy(zh_ctx *ctx) { ZH_GUARD(ctx);
     if (!ctx) return ZH_ERR_INVALID;
-    hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->mix_partials) hipFree(ctx->mix_partials);
+    for (float *p : ctx->mix_retired) hipFree(p);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZH_OK;
 }
 
-int zh_set_stream(zh_ctx *ctx, void *hip_stream) {
+int zh_set_stream(zh_ctx *ctx, void *hip_stream) { ZH_GUARD(ctx);
     if (!ctx) return ZH_ERR_INVALID;
     ZH_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
@@ -69,22 +94,21 @@ int zh_set_stream(zh_ctx *ctx, void *hip_stream) {
 
 void *zh_get_stream(zh_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int zh_sync(zh_ctx *ctx) {
+int zh_sync(zh_ctx *ctx) { ZH_GUARD(ctx);
     if (!ctx) return ZH_ERR_INVALID;
     ZH_TRY(hipStreamSynchronize(ctx->stream));
     return ZH_OK;
 }
 
-int zh_malloc(zh_ctx *ctx, void **dev_ptr, size_t bytes) {
+int zh_malloc(zh_ctx *ctx, void **dev_ptr, size_t bytes) { ZH_GUARD(ctx);
     if (!ctx || !dev_ptr) return ZH_ERR_INVALID;
     *dev_ptr = nullptr;
     if (bytes == 0) return ZH_OK;
-    ZH_TRY(hipSetDevice(ctx->device));
     ZH_TRY(hipMalloc(dev_ptr, bytes));
     return ZH_OK;
 }
 
-int zh_free(zh_ctx *ctx, void *dev_ptr) {
+int zh_free(zh_ctx *ctx, void *dev_ptr) { ZH_GUARD(ctx);
     if (!ctx) return ZH_ERR_INVALID;
     if (!dev_ptr) return ZH_OK;
     ZH_TRY(hipStreamSynchronize(ctx->stream));
@@ -92,7 +116,7 @@ int zh_free(zh_ctx *ctx, void *dev_ptr) {
     return ZH_OK;
 }
 
-int zh_upload(zh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+int zh_upload(zh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) { ZH_GUARD(ctx);
     if (!ctx || (bytes && (!dev_dst || !host_src))) return ZH_ERR_INVALID;
     if (!bytes) return ZH_OK;
     ZH_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -100,7 +124,7 @@ int zh_upload(zh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
     return ZH_OK;
 }
 
-int zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+int zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) { ZH_GUARD(ctx);
     if (!ctx || (bytes && (!host_dst || !dev_src))) return ZH_ERR_INVALID;
     if (!bytes) return ZH_OK;
     ZH_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -108,7 +132,7 @@ int zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) 
     return ZH_OK;
 }
 
-int zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames) {
+int zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     memset(out, 0, sizeof *out);
     // A lane-per-voice kernel's consecutive stores are one row apart.  When a row is a multiple of 64 KiB they all
@@ -125,7 +149,7 @@ int zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames) {
     return ZH_OK;
 }
 
-int zh_buf_free(zh_ctx *ctx, zh_buf *buf) {
+int zh_buf_free(zh_ctx *ctx, zh_buf *buf) { ZH_GUARD(ctx);
     if (!ctx || !buf) return ZH_ERR_INVALID;
     int rc = zh_free(ctx, buf->ptr);
     memset(buf, 0, sizeof *buf);
@@ -134,7 +158,7 @@ int zh_buf_free(zh_ctx *ctx, zh_buf *buf) {
 
 // Host [voice][frame] <-> device [frame][voice].  These are test/plumbing paths (PCIe
 // bound); the transpose is done on the host into a staging vector.
-int zh_buf_upload_voices(zh_ctx *ctx, zh_buf dst, const float *host, uint32_t frames) {
+int zh_buf_upload_voices(zh_ctx *ctx, zh_buf dst, const float *host, uint32_t frames) { ZH_GUARD(ctx);
     if (!ctx || !dst.ptr || !host || frames > dst.frames) return ZH_ERR_INVALID;
     std::vector<float> stage((size_t)frames * dst.voices);
     for (uint32_t v = 0; v < dst.voices; v++)
@@ -145,7 +169,7 @@ int zh_buf_upload_voices(zh_ctx *ctx, zh_buf dst, const float *host, uint32_t fr
     return ZH_OK;
 }
 
-int zh_buf_download_voices(zh_ctx *ctx, float *host, zh_buf src, uint32_t frames) {
+int zh_buf_download_voices(zh_ctx *ctx, float *host, zh_buf src, uint32_t frames) { ZH_GUARD(ctx);
     if (!ctx || !src.ptr || !host || frames > src.frames) return ZH_ERR_INVALID;
     std::vector<float> stage((size_t)frames * src.voices);
     ZH_TRY(hipMemcpy2DAsync(stage.data(), (size_t)src.voices * 4, src.ptr, (size_t)src.stride * 4,
@@ -156,43 +180,74 @@ int zh_buf_download_voices(zh_ctx *ctx, float *host, zh_buf src, uint32_t frames
     return ZH_OK;
 }
 
-int zh_buf_upload_voice(zh_ctx *ctx, zh_buf dst, uint32_t voice, const float *host, uint32_t frames) {
+int zh_buf_upload_voice(zh_ctx *ctx, zh_buf dst, uint32_t voice, const float *host, uint32_t frames) { ZH_GUARD(ctx);
     if (!ctx || !dst.ptr || !host || frames > dst.frames || voice >= dst.voices) return ZH_ERR_INVALID;
     ZH_TRY(hipMemcpy2DAsync(dst.ptr + voice, (size_t)dst.stride * 4, host, 4, 4, frames, hipMemcpyHostToDevice, ctx->stream));
     ZH_TRY(hipStreamSynchronize(ctx->stream));
     return ZH_OK;
 }
 
-int zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, uint32_t frames) {
+int zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, uint32_t frames) { ZH_GUARD(ctx);
     if (!ctx || !src.ptr || !host || frames > src.frames || voice >= src.voices) return ZH_ERR_INVALID;
     ZH_TRY(hipMemcpy2DAsync(host, 4, src.ptr + voice, (size_t)src.stride * 4, 4, frames, hipMemcpyDeviceToHost, ctx->stream));
     ZH_TRY(hipStreamSynchronize(ctx->stream));
     return ZH_OK;
 }
 
-int zh_graph_begin_capture(zh_ctx *ctx) {
-    if (!ctx) return ZH_ERR_INVALID;
+int zh_graph_begin_capture(zh_ctx *ctx) { ZH_GUARD(ctx);
+    if (!ctx || ctx->capturing) return ZH_ERR_INVALID;
     ZH_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    ctx->capture_log.clear();
     return ZH_OK;
 }
 
-int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) {
+int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     *out = nullptr;
     hipGraph_t g = nullptr;
+    ctx->capturing = false;
+    std::vector<zh_flip_use> log;
+    log.swap(ctx->capture_log);
+    // The paints of the capture were recorded, not run, but each flipped its module's host-side buffer index:
+    // put the indices back where the capture found them -- the module's state is still in that buffer.
+    {
+        std::lock_guard<std::mutex> lk(g_flip_mu);
+        for (const zh_flip_use &u : log) {
+            auto it = g_flippers.find(u.id);
+            if (it != g_flippers.end()) it->second->cur = u.first_cur;
+        }
+    }
     ZH_TRY(hipStreamEndCapture(ctx->stream, &g));
     zh_graph *zg = new (std::nothrow) zh_graph();
     if (!zg) { hipGraphDestroy(g); return ZH_ERR_INVALID; }
     zg->graph = g;
     hipError_t e = hipGraphInstantiate(&zg->exec, g, nullptr, nullptr, 0);
     if (e != hipSuccess) { hipGraphDestroy(g); delete zg; return (int)e; }
+    zg->flips.swap(log);
     *out = zg;
     return ZH_OK;
 }
 
-int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) {
-    if (!ctx || !graph) return ZH_ERR_INVALID;
+int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) { ZH_GUARD(ctx);
+    if (!ctx || !graph || ctx->capturing) return ZH_ERR_INVALID;
+    // A replay reads each chunked oscillator's phase counters from the buffer the capture started on.  Paints since
+    // then (eager ones, or another graph with an odd number of them) may have left the live state in the other
+    // buffer: copy it over first (n * 4 bytes, enqueued ahead of the replay), then account for the replay's flips.
+    {
+        std::lock_guard<std::mutex> lk(g_flip_mu);
+        for (const zh_flip_use &u : graph->flips)
+            if (g_flippers.find(u.id) == g_flippers.end()) return ZH_ERR_INVALID;     // module destroyed since the capture
+        for (const zh_flip_use &u : graph->flips) {
+            zh_flipper *f = u.f;
+            if (f->cur != u.first_cur) {
+                ZH_TRY(hipMemcpyAsync(f->cnt[u.first_cur], f->cnt[f->cur], (size_t)f->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                f->cur = u.first_cur;
+            }
+        }
+    }
     ZH_TRY(hipGraphLaunch(graph->exec, ctx->stream));
+    for (const zh_flip_use &u : graph->flips) u.f->cur = u.first_cur ^ (int)(u.flips & 1u);
     return ZH_OK;
 }
 
@@ -204,7 +259,7 @@ int zh_graph_destroy(zh_graph *graph) {
     return ZH_OK;
 }
 
-int zh_event_create(zh_ctx *ctx, zh_event **out) {
+int zh_event_create(zh_ctx *ctx, zh_event **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_event *e = new (std::nothrow) zh_event();
     if (!e) return ZH_ERR_INVALID;
@@ -221,7 +276,7 @@ int zh_event_destroy(zh_event *ev) {
     return ZH_OK;
 }
 
-int zh_event_record(zh_ctx *ctx, zh_event *ev) {
+int zh_event_record(zh_ctx *ctx, zh_event *ev) { ZH_GUARD(ctx);
     if (!ctx || !ev) return ZH_ERR_INVALID;
     ZH_TRY(hipEventRecord(ev->ev, ctx->stream));
     return ZH_OK;

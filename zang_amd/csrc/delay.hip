@@ -170,7 +170,7 @@ static int delay_set(zh_ctx *ctx, const DelayState &d, const float *rings, const
 
 extern "C" {
 
-int zh_delay_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_delay **out) {
+int zh_delay_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_delay **out) { ZH_GUARD(ctx);
     if (!ctx || !out || delay_samples == 0) return ZH_ERR_INVALID;    // Delay(0) never makes progress in the reference
     zh_delay *m = new (std::nothrow) zh_delay();
     if (!m) return ZH_ERR_INVALID;
@@ -180,18 +180,18 @@ int zh_delay_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_delay **
     *out = m;
     return ZH_OK;
 }
-int zh_delay_destroy(zh_delay *m) {
+int zh_delay_destroy(zh_delay *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     delay_free(m->d);
     delete m;
     return ZH_OK;
 }
-int zh_delay_reset(zh_delay *m) { return m ? delay_reset(m->ctx, m->d) : ZH_ERR_INVALID; }
-int zh_delay_get_state(zh_delay *m, float *rings, uint32_t *index) { return m ? delay_get(m->ctx, m->d, rings, index) : ZH_ERR_INVALID; }
-int zh_delay_set_state(zh_delay *m, const float *rings, const uint32_t *index) { return m ? delay_set(m->ctx, m->d, rings, index) : ZH_ERR_INVALID; }
+int zh_delay_reset(zh_delay *m) { ZH_GUARD(m ? m->ctx : nullptr); return m ? delay_reset(m->ctx, m->d) : ZH_ERR_INVALID; }
+int zh_delay_get_state(zh_delay *m, float *rings, uint32_t *index) { ZH_GUARD(m ? m->ctx : nullptr); return m ? delay_get(m->ctx, m->d, rings, index) : ZH_ERR_INVALID; }
+int zh_delay_set_state(zh_delay *m, const float *rings, const uint32_t *index) { ZH_GUARD(m ? m->ctx : nullptr); return m ? delay_set(m->ctx, m->d, rings, index) : ZH_ERR_INVALID; }
 int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                   zh_bool note_id_changed, const zh_delay_params *p, uint32_t flags) {
+                   zh_bool note_id_changed, const zh_delay_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // examples/modules.zig:370-371
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
     if (m->d.n == 0 || end == start) return ZH_OK;
@@ -203,7 +203,7 @@ int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outp
     return zh_launch_status();
 }
 
-int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_filtered_echoes **out) {
+int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, zh_filtered_echoes **out) { ZH_GUARD(ctx);
     if (!ctx || !out || delay_samples == 0) return ZH_ERR_INVALID;
     zh_filtered_echoes *m = new (std::nothrow) zh_filtered_echoes();
     if (!m) return ZH_ERR_INVALID;
@@ -217,15 +217,15 @@ int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, z
     *out = m;
     return ZH_OK;
 }
-int zh_filtered_echoes_destroy(zh_filtered_echoes *m) {
+int zh_filtered_echoes_destroy(zh_filtered_echoes *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     delay_free(m->d); (void)hipFree(m->l); (void)hipFree(m->b);
     delete m;
     return ZH_OK;
 }
-int zh_filtered_echoes_reset(zh_filtered_echoes *m) { return m ? delay_reset(m->ctx, m->d) : ZH_ERR_INVALID; }   // :407-409
-int zh_filtered_echoes_get_state(zh_filtered_echoes *m, float *rings, uint32_t *index, zh_filter_state *filter) {
+int zh_filtered_echoes_reset(zh_filtered_echoes *m) { ZH_GUARD(m ? m->ctx : nullptr); return m ? delay_reset(m->ctx, m->d) : ZH_ERR_INVALID; }   // :407-409
+int zh_filtered_echoes_get_state(zh_filtered_echoes *m, float *rings, uint32_t *index, zh_filter_state *filter) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !filter) return ZH_ERR_INVALID;
     int rc = delay_get(m->ctx, m->d, rings, index);
     if (rc) return rc;
@@ -236,7 +236,7 @@ int zh_filtered_echoes_get_state(zh_filtered_echoes *m, float *rings, uint32_t *
     for (uint32_t v = 0; v < m->d.n; v++) filter[v] = zh_filter_state{l[v], b[v]};
     return ZH_OK;
 }
-int zh_filtered_echoes_set_state(zh_filtered_echoes *m, const float *rings, const uint32_t *index, const zh_filter_state *filter) {
+int zh_filtered_echoes_set_state(zh_filtered_echoes *m, const float *rings, const uint32_t *index, const zh_filter_state *filter) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !filter) return ZH_ERR_INVALID;
     int rc = delay_set(m->ctx, m->d, rings, index);
     if (rc) return rc;
@@ -247,7 +247,7 @@ int zh_filtered_echoes_set_state(zh_filtered_echoes *m, const float *rings, cons
     return rc;
 }
 int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                             zh_bool note_id_changed, const zh_filtered_echoes_params *p, uint32_t flags) {
+                             zh_bool note_id_changed, const zh_filtered_echoes_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
     if (m->d.n == 0 || end == start) return ZH_OK;

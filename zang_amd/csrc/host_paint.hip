@@ -87,7 +87,7 @@ int zh_decimator_state_init(zh_decimator_state *state) {
 }
 
 int zh_sineosc_paint_host(zh_ctx *ctx, zh_sineosc_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                          float *const *temps, uint32_t nic, const zh_sineosc_host_params *p) {
+                          float *const *temps, uint32_t nic, const zh_sineosc_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -100,7 +100,7 @@ int zh_sineosc_paint_host(zh_ctx *ctx, zh_sineosc_state *state, uint32_t start, 
 }
 
 int zh_pulseosc_paint_host(zh_ctx *ctx, zh_pulseosc_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                           float *const *temps, uint32_t nic, const zh_pulseosc_host_params *p) {
+                           float *const *temps, uint32_t nic, const zh_pulseosc_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -113,7 +113,7 @@ int zh_pulseosc_paint_host(zh_ctx *ctx, zh_pulseosc_state *state, uint32_t start
 }
 
 int zh_trisawosc_paint_host(zh_ctx *ctx, zh_trisawosc_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                            float *const *temps, uint32_t nic, const zh_trisawosc_host_params *p) {
+                            float *const *temps, uint32_t nic, const zh_trisawosc_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -126,7 +126,7 @@ int zh_trisawosc_paint_host(zh_ctx *ctx, zh_trisawosc_state *state, uint32_t sta
 }
 
 int zh_noise_paint_host(zh_ctx *ctx, zh_noise_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                        float *const *temps, uint32_t nic, const zh_noise_host_params *p) {
+                        float *const *temps, uint32_t nic, const zh_noise_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -137,7 +137,7 @@ int zh_noise_paint_host(zh_ctx *ctx, zh_noise_state *state, uint32_t start, uint
 }
 
 int zh_envelope_paint_host(zh_ctx *ctx, zh_envelope_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                           float *const *temps, uint32_t nic, const zh_envelope_host_params *p) {
+                           float *const *temps, uint32_t nic, const zh_envelope_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -150,7 +150,7 @@ int zh_envelope_paint_host(zh_ctx *ctx, zh_envelope_state *state, uint32_t start
 }
 
 int zh_gate_paint_host(zh_ctx *ctx, void *state_unused, uint32_t start, uint32_t end, float *const *outputs,
-                       float *const *temps, uint32_t nic, const zh_gate_host_params *p) {
+                       float *const *temps, uint32_t nic, const zh_gate_host_params *p) { ZH_GUARD(ctx);
     (void)temps; (void)state_unused;
     if (!ctx || !p) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -161,7 +161,7 @@ int zh_gate_paint_host(zh_ctx *ctx, void *state_unused, uint32_t start, uint32_t
 }
 
 int zh_filter_paint_host(zh_ctx *ctx, zh_filter_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                         float *const *temps, uint32_t nic, const zh_filter_host_params *p) {
+                         float *const *temps, uint32_t nic, const zh_filter_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p || !p->input) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -174,7 +174,7 @@ int zh_filter_paint_host(zh_ctx *ctx, zh_filter_state *state, uint32_t start, ui
 }
 
 int zh_sampler_paint_host(zh_ctx *ctx, zh_sampler_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                          float *const *temps, uint32_t nic, const zh_sampler_host_params *p) {
+                          float *const *temps, uint32_t nic, const zh_sampler_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p || (p->data_len && !p->data)) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -195,7 +195,7 @@ int zh_sampler_paint_host(zh_ctx *ctx, zh_sampler_state *state, uint32_t start, 
 }
 
 int zh_decimator_paint_host(zh_ctx *ctx, zh_decimator_state *state, uint32_t start, uint32_t end, float *const *outputs,
-                            float *const *temps, uint32_t nic, const zh_decimator_host_params *p) {
+                            float *const *temps, uint32_t nic, const zh_decimator_host_params *p) { ZH_GUARD(ctx);
     (void)temps;
     if (!ctx || !state || !p || !p->input) return ZH_ERR_INVALID;
     Stage st(ctx);
@@ -208,7 +208,7 @@ int zh_decimator_paint_host(zh_ctx *ctx, zh_decimator_state *state, uint32_t sta
 }
 
 int zh_distortion_paint_host(zh_ctx *ctx, void *state_unused, uint32_t start, uint32_t end, float *const *outputs,
-                             float *const *temps, uint32_t nic, const zh_distortion_host_params *p) {
+                             float *const *temps, uint32_t nic, const zh_distortion_host_params *p) { ZH_GUARD(ctx);
     (void)temps; (void)state_unused;
     if (!ctx || !p || !p->input) return ZH_ERR_INVALID;
     Stage st(ctx);

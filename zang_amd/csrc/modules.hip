@@ -394,7 +394,7 @@ static EnvParamsP mk_env_params(const zh_envelope_params *p) {
 extern "C" {
 
 // ------------------------------------------------------------------ SineOsc
-int zh_sineosc_create(zh_ctx *ctx, uint32_t n, zh_sineosc **out) {
+int zh_sineosc_create(zh_ctx *ctx, uint32_t n, zh_sineosc **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_sineosc *m = new (std::nothrow) zh_sineosc{ctx, n, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -404,23 +404,23 @@ int zh_sineosc_create(zh_ctx *ctx, uint32_t n, zh_sineosc **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_sineosc_destroy(zh_sineosc *m) {
+int zh_sineosc_destroy(zh_sineosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->t);
     delete m;
     return ZH_OK;
 }
-int zh_sineosc_get_state(zh_sineosc *m, zh_sineosc_state *host) {
+int zh_sineosc_get_state(zh_sineosc *m, zh_sineosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
 }
-int zh_sineosc_set_state(zh_sineosc *m, const zh_sineosc_state *host) {
+int zh_sineosc_set_state(zh_sineosc *m, const zh_sineosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
 }
 int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                     zh_bool note_id_changed, const zh_sineosc_params *p, uint32_t flags) {
+                     zh_bool note_id_changed, const zh_sineosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // SineOsc.zig:32-33
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -445,7 +445,7 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
 }
 
 // ------------------------------------------------------------------ Noise
-int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) {
+int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_noise *m = new (std::nothrow) zh_noise{ctx, n, {nullptr, nullptr, nullptr, nullptr}, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -457,7 +457,7 @@ int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out
     *out = m;
     return zh_launch_status();
 }
-int zh_noise_destroy(zh_noise *m) {
+int zh_noise_destroy(zh_noise *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     for (auto &x : m->s) (void)hipFree(x);
@@ -465,7 +465,7 @@ int zh_noise_destroy(zh_noise *m) {
     delete m;
     return ZH_OK;
 }
-int zh_noise_get_state(zh_noise *m, zh_noise_state *host) {
+int zh_noise_get_state(zh_noise *m, zh_noise_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint64_t> s;
     std::vector<float> b;
@@ -479,7 +479,7 @@ int zh_noise_get_state(zh_noise *m, zh_noise_state *host) {
     for (uint32_t v = 0; v < m->n; v++) { for (int j = 0; j < 7; j++) host[v].b[j] = b[(size_t)j * m->n + v]; host[v].reserved = 0; }
     return ZH_OK;
 }
-int zh_noise_set_state(zh_noise *m, const zh_noise_state *host) {
+int zh_noise_set_state(zh_noise *m, const zh_noise_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint64_t> s(m->n);
     std::vector<float> b((size_t)7 * m->n);
@@ -492,7 +492,7 @@ int zh_noise_set_state(zh_noise *m, const zh_noise_state *host) {
     return upload_field(m->ctx, m->b, b);
 }
 int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                   zh_bool note_id_changed, const zh_noise_params *p, uint32_t flags) {
+                   zh_bool note_id_changed, const zh_noise_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // Noise.zig:42-43
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -509,7 +509,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
 }
 
 // ------------------------------------------------------------------ Envelope
-int zh_envelope_create(zh_ctx *ctx, uint32_t n, zh_envelope **out) {
+int zh_envelope_create(zh_ctx *ctx, uint32_t n, zh_envelope **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_envelope *m = new (std::nothrow) zh_envelope{ctx, n, nullptr, nullptr, nullptr, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -527,14 +527,14 @@ int zh_envelope_create(zh_ctx *ctx, uint32_t n, zh_envelope **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_envelope_destroy(zh_envelope *m) {
+int zh_envelope_destroy(zh_envelope *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->state); (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start);
     delete m;
     return ZH_OK;
 }
-int zh_envelope_get_state(zh_envelope *m, zh_envelope_state *host) {
+int zh_envelope_get_state(zh_envelope *m, zh_envelope_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint32_t> s;
     std::vector<float> a, b, c;
@@ -546,7 +546,7 @@ int zh_envelope_get_state(zh_envelope *m, zh_envelope_state *host) {
     for (uint32_t v = 0; v < m->n; v++) host[v] = zh_envelope_state{s[v], a[v], b[v], c[v]};
     return ZH_OK;
 }
-int zh_envelope_set_state(zh_envelope *m, const zh_envelope_state *host) {
+int zh_envelope_set_state(zh_envelope *m, const zh_envelope_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint32_t> s(m->n);
     std::vector<float> a(m->n), b(m->n), c(m->n);
@@ -558,7 +558,7 @@ int zh_envelope_set_state(zh_envelope *m, const zh_envelope_state *host) {
     return rc;
 }
 int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                      zh_bool note_id_changed, const zh_envelope_params *p, uint32_t flags) {
+                      zh_bool note_id_changed, const zh_envelope_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -572,18 +572,18 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
 }
 
 // ------------------------------------------------------------------ Gate
-int zh_gate_create(zh_ctx *ctx, uint32_t n, zh_gate **out) {
+int zh_gate_create(zh_ctx *ctx, uint32_t n, zh_gate **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     *out = new (std::nothrow) zh_gate{ctx, n};
     return *out ? ZH_OK : ZH_ERR_INVALID;
 }
-int zh_gate_destroy(zh_gate *m) {
+int zh_gate_destroy(zh_gate *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     delete m;
     return ZH_OK;
 }
 int zh_gate_paint(zh_gate *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                  zh_bool note_id_changed, const zh_gate_params *p, uint32_t flags) {
+                  zh_bool note_id_changed, const zh_gate_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // Gate.zig:24-26
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -597,7 +597,7 @@ int zh_gate_paint(zh_gate *m, uint32_t start, uint32_t end, const zh_buf *output
 }
 
 // ------------------------------------------------------------------ Filter
-int zh_filter_create(zh_ctx *ctx, uint32_t n, zh_filter **out) {
+int zh_filter_create(zh_ctx *ctx, uint32_t n, zh_filter **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_filter *m = new (std::nothrow) zh_filter{ctx, n, nullptr, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -609,14 +609,14 @@ int zh_filter_create(zh_ctx *ctx, uint32_t n, zh_filter **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_filter_destroy(zh_filter *m) {
+int zh_filter_destroy(zh_filter *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->l); (void)hipFree(m->b);
     delete m;
     return ZH_OK;
 }
-int zh_filter_get_state(zh_filter *m, zh_filter_state *host) {
+int zh_filter_get_state(zh_filter *m, zh_filter_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> l, b;
     int rc = download_field(m->ctx, l, m->l, m->n);
@@ -625,7 +625,7 @@ int zh_filter_get_state(zh_filter *m, zh_filter_state *host) {
     for (uint32_t v = 0; v < m->n; v++) host[v] = zh_filter_state{l[v], b[v]};
     return ZH_OK;
 }
-int zh_filter_set_state(zh_filter *m, const zh_filter_state *host) {
+int zh_filter_set_state(zh_filter *m, const zh_filter_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> l(m->n), b(m->n);
     for (uint32_t v = 0; v < m->n; v++) { l[v] = host[v].l; b[v] = host[v].b; }
@@ -634,7 +634,7 @@ int zh_filter_set_state(zh_filter *m, const zh_filter_state *host) {
     return rc;
 }
 int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                    zh_bool note_id_changed, const zh_filter_params *p, uint32_t flags) {
+                    zh_bool note_id_changed, const zh_filter_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // Filter.zig:52-53
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -674,34 +674,34 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
 #undef ZH_FILTER
     return zh_launch_status();
 }
-int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out, const float *frequency, float sample_rate) {
+int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out, const float *frequency, float sample_rate) { ZH_GUARD(ctx);
     if (!ctx || (n && (!cutoff_out || !frequency))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_cutoff_from_frequency, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, cutoff_out, frequency, sample_rate);
     return zh_launch_status();
 }
 
-int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y) {
+int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x || !y))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_pow, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x, y);
     return zh_launch_status();
 }
 
-int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
+int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_sincos<0>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
-int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
+int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_sincos<1>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 
-int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
+int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
     hipLaunchKernelGGL(k_sincos<2>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
@@ -709,7 +709,7 @@ int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x) {
 }
 
 // ------------------------------------------------------------------ Sampler
-int zh_sampler_create(zh_ctx *ctx, uint32_t n, zh_sampler **out) {
+int zh_sampler_create(zh_ctx *ctx, uint32_t n, zh_sampler **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_sampler *m = new (std::nothrow) zh_sampler{ctx, n, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -719,23 +719,23 @@ int zh_sampler_create(zh_ctx *ctx, uint32_t n, zh_sampler **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_sampler_destroy(zh_sampler *m) {
+int zh_sampler_destroy(zh_sampler *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->t);
     delete m;
     return ZH_OK;
 }
-int zh_sampler_get_state(zh_sampler *m, zh_sampler_state *host) {
+int zh_sampler_get_state(zh_sampler *m, zh_sampler_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
 }
-int zh_sampler_set_state(zh_sampler *m, const zh_sampler_state *host) {
+int zh_sampler_set_state(zh_sampler *m, const zh_sampler_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
 }
 int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                     zh_bool note_id_changed, const zh_sampler_params *p, uint32_t flags) {
+                     zh_bool note_id_changed, const zh_sampler_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -779,7 +779,7 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
 }
 
 // ------------------------------------------------------------------ Decimator
-int zh_decimator_create(zh_ctx *ctx, uint32_t n, zh_decimator **out) {
+int zh_decimator_create(zh_ctx *ctx, uint32_t n, zh_decimator **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_decimator *m = new (std::nothrow) zh_decimator{ctx, n, nullptr, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -794,14 +794,14 @@ int zh_decimator_create(zh_ctx *ctx, uint32_t n, zh_decimator **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_decimator_destroy(zh_decimator *m) {
+int zh_decimator_destroy(zh_decimator *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->dval); (void)hipFree(m->dcount);
     delete m;
     return ZH_OK;
 }
-int zh_decimator_get_state(zh_decimator *m, zh_decimator_state *host) {
+int zh_decimator_get_state(zh_decimator *m, zh_decimator_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> a, b;
     int rc = download_field(m->ctx, a, m->dval, m->n);
@@ -810,7 +810,7 @@ int zh_decimator_get_state(zh_decimator *m, zh_decimator_state *host) {
     for (uint32_t v = 0; v < m->n; v++) host[v] = zh_decimator_state{a[v], b[v]};
     return ZH_OK;
 }
-int zh_decimator_set_state(zh_decimator *m, const zh_decimator_state *host) {
+int zh_decimator_set_state(zh_decimator *m, const zh_decimator_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> a(m->n), b(m->n);
     for (uint32_t v = 0; v < m->n; v++) { a[v] = host[v].dval; b[v] = host[v].dcount; }
@@ -819,7 +819,7 @@ int zh_decimator_set_state(zh_decimator *m, const zh_decimator_state *host) {
     return rc;
 }
 int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                       zh_bool note_id_changed, const zh_decimator_params *p, uint32_t flags) {
+                       zh_bool note_id_changed, const zh_decimator_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // Decimator.zig:29-30
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -833,7 +833,7 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
 }
 
 // ------------------------------------------------------------------ Curve
-int zh_curve_module_create(zh_ctx *ctx, uint32_t n, zh_curve_module **out) {
+int zh_curve_module_create(zh_ctx *ctx, uint32_t n, zh_curve_module **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_curve_module *m = new (std::nothrow) zh_curve_module{ctx, n, nullptr, nullptr, nullptr, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -849,14 +849,14 @@ int zh_curve_module_create(zh_ctx *ctx, uint32_t n, zh_curve_module **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_curve_module_destroy(zh_curve_module *m) {
+int zh_curve_module_destroy(zh_curve_module *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->t); (void)hipFree(m->cur); (void)hipFree(m->off); (void)hipFree(m->next);
     delete m;
     return ZH_OK;
 }
-int zh_curve_module_get_state(zh_curve_module *m, zh_curve_module_state *host) {
+int zh_curve_module_get_state(zh_curve_module *m, zh_curve_module_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> t; std::vector<uint32_t> c, nx; std::vector<int32_t> o;
     int rc = download_field(m->ctx, t, m->t, m->n);
@@ -867,7 +867,7 @@ int zh_curve_module_get_state(zh_curve_module *m, zh_curve_module_state *host) {
     for (uint32_t v = 0; v < m->n; v++) host[v] = zh_curve_module_state{t[v], c[v], o[v], nx[v]};
     return ZH_OK;
 }
-int zh_curve_module_set_state(zh_curve_module *m, const zh_curve_module_state *host) {
+int zh_curve_module_set_state(zh_curve_module *m, const zh_curve_module_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> t(m->n); std::vector<uint32_t> c(m->n), nx(m->n); std::vector<int32_t> o(m->n);
     for (uint32_t v = 0; v < m->n; v++) { t[v] = host[v].t; c[v] = host[v].current_song_note; o[v] = host[v].current_song_note_offset; nx[v] = host[v].next_song_note; }
@@ -878,7 +878,7 @@ int zh_curve_module_set_state(zh_curve_module *m, const zh_curve_module_state *h
     return rc;
 }
 int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                          zh_bool note_id_changed, const zh_curve_module_params *p, uint32_t flags) {
+                          zh_bool note_id_changed, const zh_curve_module_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -892,7 +892,7 @@ int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, cons
 }
 
 // ------------------------------------------------------------------ Cycle
-int zh_cycle_create(zh_ctx *ctx, uint32_t n, zh_cycle **out) {
+int zh_cycle_create(zh_ctx *ctx, uint32_t n, zh_cycle **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_cycle *m = new (std::nothrow) zh_cycle{ctx, n, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -902,23 +902,23 @@ int zh_cycle_create(zh_ctx *ctx, uint32_t n, zh_cycle **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_cycle_destroy(zh_cycle *m) {
+int zh_cycle_destroy(zh_cycle *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->t);
     delete m;
     return ZH_OK;
 }
-int zh_cycle_get_state(zh_cycle *m, zh_cycle_state *host) {
+int zh_cycle_get_state(zh_cycle *m, zh_cycle_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
 }
-int zh_cycle_set_state(zh_cycle *m, const zh_cycle_state *host) {
+int zh_cycle_set_state(zh_cycle *m, const zh_cycle_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
 }
 int zh_cycle_paint(zh_cycle *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                   zh_bool note_id_changed, const zh_cycle_params *p, uint32_t flags) {
+                   zh_bool note_id_changed, const zh_cycle_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // Cycle.zig:30-31
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -936,7 +936,7 @@ int zh_cycle_paint(zh_cycle *m, uint32_t start, uint32_t end, const zh_buf *outp
 }
 
 // ------------------------------------------------------------------ Portamento
-int zh_portamento_create(zh_ctx *ctx, uint32_t n, zh_portamento **out) {
+int zh_portamento_create(zh_ctx *ctx, uint32_t n, zh_portamento **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_portamento *m = new (std::nothrow) zh_portamento{ctx, n, nullptr, nullptr, nullptr};
     if (!m) return ZH_ERR_INVALID;
@@ -952,14 +952,14 @@ int zh_portamento_create(zh_ctx *ctx, uint32_t n, zh_portamento **out) {
     *out = m;
     return ZH_OK;
 }
-int zh_portamento_destroy(zh_portamento *m) {
+int zh_portamento_destroy(zh_portamento *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start);
     delete m;
     return ZH_OK;
 }
-int zh_portamento_get_state(zh_portamento *m, zh_portamento_state *host) {
+int zh_portamento_get_state(zh_portamento *m, zh_portamento_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> a, b, c;
     int rc = download_field(m->ctx, a, m->t, m->n);
@@ -969,7 +969,7 @@ int zh_portamento_get_state(zh_portamento *m, zh_portamento_state *host) {
     for (uint32_t v = 0; v < m->n; v++) host[v] = zh_portamento_state{a[v], b[v], c[v]};
     return ZH_OK;
 }
-int zh_portamento_set_state(zh_portamento *m, const zh_portamento_state *host) {
+int zh_portamento_set_state(zh_portamento *m, const zh_portamento_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<float> a(m->n), b(m->n), c(m->n);
     for (uint32_t v = 0; v < m->n; v++) { a[v] = host[v].t; b[v] = host[v].last_value; c[v] = host[v].start; }
@@ -979,7 +979,7 @@ int zh_portamento_set_state(zh_portamento *m, const zh_portamento_state *host) {
     return rc;
 }
 int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                        zh_bool note_id_changed, const zh_portamento_params *p, uint32_t flags) {
+                        zh_bool note_id_changed, const zh_portamento_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps;
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;
@@ -994,18 +994,18 @@ int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh
 }
 
 // ------------------------------------------------------------------ Distortion
-int zh_distortion_create(zh_ctx *ctx, uint32_t n, zh_distortion **out) {
+int zh_distortion_create(zh_ctx *ctx, uint32_t n, zh_distortion **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     *out = new (std::nothrow) zh_distortion{ctx, n};
     return *out ? ZH_OK : ZH_ERR_INVALID;
 }
-int zh_distortion_destroy(zh_distortion *m) {
+int zh_distortion_destroy(zh_distortion *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     delete m;
     return ZH_OK;
 }
 int zh_distortion_paint(zh_distortion *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                        zh_bool note_id_changed, const zh_distortion_params *p, uint32_t flags) {
+                        zh_bool note_id_changed, const zh_distortion_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                            // Distortion.zig:35-37
     int rc = paint_check(m, start, end, outputs);
     if (rc) return rc;

@@ -19,19 +19,31 @@
 #include <stdlib.h>
 #include <vector>
 
-struct zh_pulseosc {
-    zh_ctx *ctx;
-    uint32_t n;
-    uint32_t *cnt[2];
-    int cur;
+// Per-voice constants of the constant-frequency path, kept from one paint to the next ([KW + 1][n]: the policy's K
+// words, then the bad-frequency flag).  Every constant-frequency paint that computes them also stores them; a paint
+// flagged ZH_PAINT_PARAMS_UNCHANGED whose scalar params / array pointers match the paint that stored them loads them
+// (eight 16-byte loads per lane) instead of repeating the per-voice divide, conversions and the LDS hand-off.
+struct OscTable {
+    uint32_t *words;             // [KW + 1][n]
+    bool valid;
+    float sample_rate;
+    zh_f32 freq, color;
+};
+static bool table_matches(const OscTable &t, float sample_rate, const zh_f32 &freq, const zh_f32 &color) {
+    auto same = [](const zh_f32 &a, const zh_f32 &b) {
+        return a.per_voice == b.per_voice && (a.per_voice || __builtin_bit_cast(uint32_t, a.value) == __builtin_bit_cast(uint32_t, b.value));
+    };
+    return t.valid && __builtin_bit_cast(uint32_t, t.sample_rate) == __builtin_bit_cast(uint32_t, sample_rate) &&
+           same(t.freq, freq) && same(t.color, color);
+}
+
+struct zh_pulseosc : zh_flipper {
+    OscTable tab;
 };
 
-struct zh_trisawosc {
-    zh_ctx *ctx;
-    uint32_t n;
-    uint32_t *cnt[2];
+struct zh_trisawosc : zh_flipper {
     float *t;
-    int cur;
+    OscTable tab;
 };
 
 // ------------------------------------------------------------------ PulseOsc
@@ -87,43 +99,81 @@ __global__ void __launch_bounds__(256) k_osc_const(const uint32_t *__restrict__ 
 
 // 4 voices per lane: one 16-byte store per frame (1 KiB per wave-instruction) and four
 // independent dependency chains per lane to cover the VALU->VCC wait states.
-// grid: x = 256-voice groups, y = groups of 4 frame chunks; each of the 4 waves of a block
+// grid: x = 256-voice groups, y = groups of 4 frame chunks, z = buffer of a batch; each of the 4 waves of a block
 // renders a different chunk of the same 256 voices.
-template <class OSC, bool ZF, int SM>
-__global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out,
-                                                    uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t fc,
-                                                    float srf, float sr8, F32P freq_p, F32P color_p) {
-    // The 4 waves of a block render 4 different frame chunks of the SAME 256 voices, so the per-voice
-    // setup (a divide and some conversions) is done once per block: thread t sets up voice base + t and
-    // parks the constants in LDS, then every lane fetches its 4 voices' constants with 16-byte reads.
+// A batch (zh_*_paint_batch) = nb consecutive paint calls with the same params, each over [start, end) of its own
+// image: the phase counter of frame i of buffer b is exactly cnt0 + (b * (end - start) + (i - start)) * ifreq, so
+// the buffers are independent too and share one launch's ramp and tail.
+constexpr int kOscMaxBatch = 32;
+struct OscArgs {
+    const uint32_t *cnt_in;
+    uint32_t *cnt_out;
+    uint32_t *tab;               // [KW + 1][V] or nullptr
+    uint32_t V, start, end, fc, stride, nb, prio;
+    float srf, sr8;
+    F32P freq, color;
+    float *img[kOscMaxBatch];
+};
+
+// TAB = the per-voice constants come from the module's table instead of being computed (OscTable).
+template <class OSC, bool ZF, int SM, bool TAB>
+__global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     using K = typename OSC::K;
     constexpr int KW = sizeof(K) / 4;                     // dwords of per-voice constants
-    __shared__ __attribute__((aligned(16))) uint32_t sk[KW + 2][256];   // + cnt0, bad
     const uint32_t vbase = blockIdx.x * 256;
-    {
-        const uint32_t sv = vbase + threadIdx.x;
-        if (sv < V) {
-            const float freq = freq_p.get(sv);
-            K k;
-            OSC::setup(k, srf, freq, color_p.get(sv));
-            const uint32_t *kw = reinterpret_cast<const uint32_t *>(&k);
-#pragma unroll
-            for (int j = 0; j < KW; j++) sk[j][threadIdx.x] = kw[j];
-            sk[KW][threadIdx.x] = cnt_in[sv];
-            sk[KW + 1][threadIdx.x] = (freq < 0 || freq > sr8) ? 1u : 0u;   // PulseOsc.zig:82-84, TriSawOsc.zig:84-86
-        }
-    }
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t v = vbase + lane * 4;
-    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (v >= V) return;                                   // V % 4 == 0 on this path
-    const uint32_t c0 = start + chunk * fc;
-    const uint32_t c1 = min(c0 + fc, end);
+    const uint32_t V = a.V, start = a.start, end = a.end, fc = a.fc;
+    // The block's four waves reach their first store one after the other instead of all at once (they share a SIMD's
+    // issue slots when the grid fills the chip four waves deep): the store stream starts earlier.
+    if (a.prio) {
+        if (wave == 0) __builtin_amdgcn_s_setprio(3);
+        else if (wave == 1) __builtin_amdgcn_s_setprio(2);
+        else if (wave == 2) __builtin_amdgcn_s_setprio(1);
+    }
     K k[4];
     uint32_t cnt[4], cnt0[4];
     bool bad[4];
-    {
+    if constexpr (TAB) {
+        if (v >= V) return;                               // V % 4 == 0 on this path
+        uint4 w[KW + 2];
+#pragma unroll
+        for (int j = 0; j < KW + 1; j++) w[j] = *reinterpret_cast<const uint4 *>(a.tab + (size_t)j * V + v);
+        w[KW + 1] = *reinterpret_cast<const uint4 *>(a.cnt_in + v);
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            reinterpret_cast<uint32_t *>(&k[0])[j] = w[j].x; reinterpret_cast<uint32_t *>(&k[1])[j] = w[j].y;
+            reinterpret_cast<uint32_t *>(&k[2])[j] = w[j].z; reinterpret_cast<uint32_t *>(&k[3])[j] = w[j].w;
+        }
+        bad[0] = w[KW].x != 0; bad[1] = w[KW].y != 0; bad[2] = w[KW].z != 0; bad[3] = w[KW].w != 0;
+        cnt0[0] = w[KW + 1].x; cnt0[1] = w[KW + 1].y; cnt0[2] = w[KW + 1].z; cnt0[3] = w[KW + 1].w;
+    } else {
+        // The 4 waves of a block render 4 different frame chunks of the SAME 256 voices, so the per-voice
+        // setup (a divide and some conversions) is done once per block: thread t sets up voice base + t and
+        // parks the constants in LDS, then every lane fetches its 4 voices' constants with 16-byte reads.
+        __shared__ __attribute__((aligned(16))) uint32_t sk[KW + 2][256];   // + bad, cnt0
+        {
+            const uint32_t sv = vbase + threadIdx.x;
+            if (sv < V) {
+                const float freq = a.freq.get(sv);
+                K ks;
+                OSC::setup(ks, a.srf, freq, a.color.get(sv));
+                const uint32_t *kw = reinterpret_cast<const uint32_t *>(&ks);
+                const uint32_t isbad = (freq < 0 || freq > a.sr8) ? 1u : 0u;   // PulseOsc.zig:82-84, TriSawOsc.zig:84-86
+#pragma unroll
+                for (int j = 0; j < KW; j++) sk[j][threadIdx.x] = kw[j];
+                sk[KW][threadIdx.x] = isbad;
+                sk[KW + 1][threadIdx.x] = a.cnt_in[sv];
+                if (a.tab && blockIdx.y == 0 && blockIdx.z == 0) {          // keep them for ZH_PAINT_PARAMS_UNCHANGED paints
+#pragma unroll
+                    for (int j = 0; j < KW; j++) a.tab[(size_t)j * V + sv] = kw[j];
+                    a.tab[(size_t)KW * V + sv] = isbad;
+                }
+            }
+        }
+        __syncthreads();
+        if (v >= V) return;                               // V % 4 == 0 on this path
         uint4 w[KW + 2];
 #pragma unroll
         for (int j = 0; j < KW + 2; j++) w[j] = *reinterpret_cast<const uint4 *>(&sk[j][lane * 4]);
@@ -132,30 +182,37 @@ __global__ void __launch_bounds__(256) k_osc_const4(const uint32_t *__restrict__
             reinterpret_cast<uint32_t *>(&k[0])[j] = w[j].x; reinterpret_cast<uint32_t *>(&k[1])[j] = w[j].y;
             reinterpret_cast<uint32_t *>(&k[2])[j] = w[j].z; reinterpret_cast<uint32_t *>(&k[3])[j] = w[j].w;
         }
-        cnt0[0] = w[KW].x; cnt0[1] = w[KW].y; cnt0[2] = w[KW].z; cnt0[3] = w[KW].w;
-        bad[0] = w[KW + 1].x != 0; bad[1] = w[KW + 1].y != 0; bad[2] = w[KW + 1].z != 0; bad[3] = w[KW + 1].w != 0;
+        bad[0] = w[KW].x != 0; bad[1] = w[KW].y != 0; bad[2] = w[KW].z != 0; bad[3] = w[KW].w != 0;
+        cnt0[0] = w[KW + 1].x; cnt0[1] = w[KW + 1].y; cnt0[2] = w[KW + 1].z; cnt0[3] = w[KW + 1].w;
     }
+    const uint32_t chunk = blockIdx.y * 4 + wave;
+    const uint32_t nfr = end - start;
+    const uint32_t c0 = start + chunk * fc;
+    const uint32_t c1 = min(c0 + fc, end);
+    const uint32_t fbase = blockIdx.z * nfr + (c0 - start);               // frames painted before this chunk, batch-wide
     typename OSC::R roll[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { cnt[j] = cnt0[j] + (c0 - start) * k[j].ifreq; roll[j] = OSC::roll_init(k[j], cnt[j]); }
-    if (chunk == 0) {
+    for (int j = 0; j < 4; j++) { cnt[j] = cnt0[j] + fbase * k[j].ifreq; roll[j] = OSC::roll_init(k[j], cnt[j]); }
+    if (chunk == 0 && blockIdx.z == 0) {
+        const uint32_t total = a.nb * nfr;
         uint4 o;
-        o.x = bad[0] ? cnt0[0] : cnt0[0] + (end - start) * k[0].ifreq;
-        o.y = bad[1] ? cnt0[1] : cnt0[1] + (end - start) * k[1].ifreq;
-        o.z = bad[2] ? cnt0[2] : cnt0[2] + (end - start) * k[2].ifreq;
-        o.w = bad[3] ? cnt0[3] : cnt0[3] + (end - start) * k[3].ifreq;
+        o.x = bad[0] ? cnt0[0] : cnt0[0] + total * k[0].ifreq;
+        o.y = bad[1] ? cnt0[1] : cnt0[1] + total * k[1].ifreq;
+        o.z = bad[2] ? cnt0[2] : cnt0[2] + total * k[2].ifreq;
+        o.w = bad[3] ? cnt0[3] : cnt0[3] + total * k[3].ifreq;
         // write-through like the image stores: a plain store would leave the line dirty in L2 and put its
         // write-back on the kernel boundary (measured: 0.14 us of a 4.6 us launch)
-        const zh_rsrc_t crs = make_rsrc(cnt_out, V * 4u);
-        store4<SM>(reinterpret_cast<float *>(cnt_out + v), crs, v * 4u, __builtin_bit_cast(zv4f, o));
+        const zh_rsrc_t crs = make_rsrc(a.cnt_out, V * 4u);
+        store4<SM>(reinterpret_cast<float *>(a.cnt_out + v), crs, v * 4u, __builtin_bit_cast(zv4f, o));
     }
     if (c0 >= end) return;
-    float *o = out.at(c0, v);
-    const size_t os = out.stride;
+    float *const img = a.img[blockIdx.z];
+    const size_t os = a.stride;
+    float *o = img + (size_t)c0 * os + v;
     // descriptor over this wave's rows [c0, c1) of the image (wave-uniform base)
     const uint32_t wchunk = __builtin_amdgcn_readfirstlane(chunk);
     const uint32_t wc0 = start + wchunk * fc;
-    const zh_rsrc_t rsrc = make_rsrc(out.p + (size_t)wc0 * out.stride, (uint32_t)((size_t)fc * out.stride * 4));
+    const zh_rsrc_t rsrc = make_rsrc(img + (size_t)wc0 * os, (uint32_t)((size_t)fc * os * 4));
     uint32_t boff = lane * 16 + (uint32_t)((size_t)vbase * 4);
     // Common case, decided per wave: no silent voice among the wave's 256.  In ZERO_FIRST mode the
     // stored value is then `0.0f + val`, which equals `val` bit for bit: every arm of sample() ends in
@@ -272,123 +329,186 @@ static bool osc_force_scalar() {
     return v != 0;
 }
 
-// Launch the chunked constant-frequency kernel of oscillator OSC (4 voices per lane with 16-byte
-// write-through stores when the image and params allow it, one voice per lane otherwise).
-template <class OSC>
-static void launch_osc_const(zh_ctx *ctx, uint32_t n, const uint32_t *ci, uint32_t *co, const zh_buf &outb, uint32_t start,
-                             uint32_t end, float sample_rate, const zh_f32 &freq, const zh_f32 &color, bool zf) {
+static bool osc_prio() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ZH_OSC_PRIO"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+static bool osc_no_table() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ZH_OSC_NO_TABLE"); v = e ? atoi(e) : 0; }     // A/B: ignore ZH_PAINT_PARAMS_UNCHANGED
+    return v != 0;
+}
+
+template <class OSC> static bool osc_vec_ok(uint32_t n, const zh_buf *outs, uint32_t nb, const zh_f32 &freq, const zh_f32 &color) {
+    bool vec = n % 4 == 0 && (!freq.per_voice || aligned16(freq.per_voice)) && (!color.per_voice || aligned16(color.per_voice)) &&
+               !osc_force_scalar();
+    for (uint32_t b = 0; b < nb && vec; b++)
+        vec = outs[b].stride % 4 == 0 && aligned16(outs[b].ptr) && outs[b].stride == outs[0].stride;
+    return vec;
+}
+
+// Launch the chunked constant-frequency kernel of oscillator OSC for `nb` consecutive paints (one image each, same
+// span and params): 4 voices per lane with 16-byte write-through stores when the images and params allow it (one
+// launch for the whole batch), one voice per lane and one launch per image otherwise.  Flips m->cur once per paint.
+template <class OSC, class M>
+static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t start, uint32_t end, float sample_rate,
+                             const zh_f32 &freq, const zh_f32 &color, uint32_t flags) {
+    zh_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
-    Img out = mk_img(outb);
+    const uint32_t n = m->n;
+    const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     const float srf = 4294967296.0f / sample_rate;        // SRfcobasefrq, PulseOsc.zig:87 / TriSawOsc.zig:88
     const float sr8 = sample_rate / 8.0f;                 // PulseOsc.zig:82 / TriSawOsc.zig:84
     const F32P fq = mk_f32(freq), col = mk_f32(color);
-    const bool vec = n % 4 == 0 && outb.stride % 4 == 0 && aligned16(outb.ptr) && (!fq.pv || aligned16(fq.pv)) &&
-                     (!col.pv || aligned16(col.pv)) && !osc_force_scalar();
+    const bool vec = osc_vec_ok<OSC>(n, outs, nb, freq, color);
     const uint32_t lanes = vec ? n / 4 : n;
     const uint32_t fc = osc_frames_per_lane(OSC::kShortChunks, lanes, end - start);
     const uint32_t chunks = (end - start + fc - 1) / fc;
-    dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
     if (vec) {
-#define ZH_LAUNCH_O4(ZF, SM) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col)
-        const int sm = ((size_t)fc * outb.stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
-        if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
-        else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
+        const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) && !osc_no_table();
+        const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
+        for (uint32_t b0 = 0; b0 < nb; b0 += kOscMaxBatch) {
+            const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
+            OscArgs a;
+            a.cnt_in = m->cnt[m->cur]; a.cnt_out = m->cnt[m->cur ^ 1];
+            a.tab = (use_tab || !ctx->capturing) ? m->tab.words : nullptr;   // a recorded setup-form paint never rewrites the table
+            a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.nb = cnt_b; a.prio = osc_prio() ? 1u : 0u;
+            a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
+            for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
+            dim3 grid((lanes + 63) / 64, (chunks + 3) / 4, cnt_b);
+#define ZH_LAUNCH_O4(ZF, SM) do { if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true>), grid, dim3(256), 0, st, a); \
+                                  else hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false>), grid, dim3(256), 0, st, a); } while (0)
+            if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
+            else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
 #undef ZH_LAUNCH_O4
+            // the setup form stored this call's constants (ordered before any later paint on the stream)
+            if (!use_tab && a.tab) { m->tab.valid = true; m->tab.sample_rate = sample_rate; m->tab.freq = freq; m->tab.color = color; }
+            // the batch advanced the state like cnt_b paints in a row but wrote it once, into the other buffer
+            zh_flipper_painted(m);
+            m->cur ^= 1;
+        }
     } else {
-        if (zf) hipLaunchKernelGGL((k_osc_const<OSC, true>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
-        else hipLaunchKernelGGL((k_osc_const<OSC, false>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+        dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t *ci = m->cnt[m->cur];
+            uint32_t *co = m->cnt[m->cur ^ 1];
+            Img out = mk_img(outs[b]);
+            if (zf) hipLaunchKernelGGL((k_osc_const<OSC, true>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+            else hipLaunchKernelGGL((k_osc_const<OSC, false>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+            zh_flipper_painted(m);
+            m->cur ^= 1;
+        }
     }
 }
 
-template <class M> static int osc_common_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs,
+template <class M> static int osc_common_check(M *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t nb,
                                                float sample_rate, const zh_cob &freq) {
     (void)sample_rate;
     if (!m || !outputs || end < start) return ZH_ERR_INVALID;
-    if (!buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
+    for (uint32_t b = 0; b < nb; b++)
+        if (!buf_covers(outputs[b], m->n, end)) return ZH_ERR_INVALID;
     if (!cob_ok(freq, m->n, end)) return ZH_ERR_INVALID;
     return ZH_OK;
 }
 
+template <class M> static int osc_create_common(zh_ctx *ctx, M *m, uint32_t n, int kw) {
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0;
+    m->tab.words = nullptr; m->tab.valid = false;
+    int rc = dev_alloc(&m->cnt[0], n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], n);
+    if (!rc) rc = dev_alloc(&m->tab.words, (size_t)(kw + 1) * n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[0], 0, (size_t)n * 4, ctx->stream);   // init(): cnt = 0 (PulseOsc.zig:38-42, TriSawOsc.zig:39-44)
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[1], 0, (size_t)n * 4, ctx->stream);
+    return rc;
+}
+template <class M> static void osc_free_common(M *m) { hipFree(m->cnt[0]); hipFree(m->cnt[1]); hipFree(m->tab.words); }
+
 extern "C" {
 
 // -------- PulseOsc
-int zh_pulseosc_create(zh_ctx *ctx, uint32_t n, zh_pulseosc **out) {
+int zh_pulseosc_create(zh_ctx *ctx, uint32_t n, zh_pulseosc **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_pulseosc *m = new (std::nothrow) zh_pulseosc();
     if (!m) return ZH_ERR_INVALID;
-    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr;
-    int rc = dev_alloc(&m->cnt[0], n);
-    if (!rc) rc = dev_alloc(&m->cnt[1], n);
-    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[0], 0, n * 4, ctx->stream);       // init(): cnt = 0 (:38-42)
-    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[1], 0, n * 4, ctx->stream);
-    if (rc) { hipFree(m->cnt[0]); hipFree(m->cnt[1]); delete m; return rc; }
+    int rc = osc_create_common(ctx, m, n, (int)(sizeof(PulseK) / 4));
+    if (rc) { osc_free_common(m); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
-int zh_pulseosc_destroy(zh_pulseosc *m) {
+int zh_pulseosc_destroy(zh_pulseosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     hipStreamSynchronize(m->ctx->stream);
-    hipFree(m->cnt[0]); hipFree(m->cnt[1]);
+    zh_flipper_unregister(m);
+    osc_free_common(m);
     delete m;
     return ZH_OK;
 }
-int zh_pulseosc_get_state(zh_pulseosc *m, zh_pulseosc_state *host) {
+int zh_pulseosc_get_state(zh_pulseosc *m, zh_pulseosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_download(m->ctx, host, m->cnt[m->cur], (size_t)m->n * 4);
 }
-int zh_pulseosc_set_state(zh_pulseosc *m, const zh_pulseosc_state *host) {
+int zh_pulseosc_set_state(zh_pulseosc *m, const zh_pulseosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     return zh_upload(m->ctx, m->cnt[m->cur], host, (size_t)m->n * 4);
 }
-int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) {
-    (void)temps; (void)note_id_changed;                                             // PulseOsc.zig:52-53
+static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t nb,
+                            const zh_pulseosc_params *p, uint32_t flags) {
     if (!p) return ZH_ERR_INVALID;
-    int rc = osc_common_check(m, start, end, outputs, p->sample_rate, p->freq);
+    int rc = osc_common_check(m, start, end, outputs, nb, p->sample_rate, p->freq);
     if (rc) return rc;
-    if (m->n == 0 || end == start) return ZH_OK;
+    if (m->n == 0 || end == start || nb == 0) return ZH_OK;
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
-    Img out = mk_img(outputs[0]);
     if (p->freq.tag == ZH_COB_CONSTANT) {
-        launch_osc_const<PulseOscP>(m->ctx, m->n, m->cnt[m->cur], m->cnt[m->cur ^ 1], outputs[0], start, end, p->sample_rate,
-                                    p->freq.constant, p->color, zf);
-        m->cur ^= 1;
+        launch_osc_const<PulseOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
         const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:122
         const float sr8 = p->sample_rate / 8.0f;              // :134
         uint32_t *c = m->cnt[m->cur];
         const F32P col = mk_f32(p->color);
-        if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
-        else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
+        for (uint32_t b = 0; b < nb; b++) {
+            Img out = mk_img(outputs[b]);
+            if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
+            else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
+        }
     }
     return zh_launch_status();
 }
+int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    (void)temps; (void)note_id_changed;                                             // PulseOsc.zig:52-53
+    return pulseosc_paint_n(m, start, end, outputs, 1, p, flags);
+}
+int zh_pulseosc_paint_batch(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t n_buffers,
+                            const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    return pulseosc_paint_n(m, start, end, outputs, n_buffers, p, flags);
+}
 
 // -------- TriSawOsc
-int zh_trisawosc_create(zh_ctx *ctx, uint32_t n, zh_trisawosc **out) {
+int zh_trisawosc_create(zh_ctx *ctx, uint32_t n, zh_trisawosc **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_trisawosc *m = new (std::nothrow) zh_trisawosc();
     if (!m) return ZH_ERR_INVALID;
-    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->t = nullptr;
-    int rc = dev_alloc(&m->cnt[0], n);
-    if (!rc) rc = dev_alloc(&m->cnt[1], n);
+    m->t = nullptr;
+    int rc = osc_create_common(ctx, m, n, (int)(sizeof(TriSawK) / 4));
     if (!rc) rc = dev_alloc(&m->t, n);
-    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[0], 0, n * 4, ctx->stream);       // init() :39-44
-    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[1], 0, n * 4, ctx->stream);
-    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);
-    if (rc) { hipFree(m->cnt[0]); hipFree(m->cnt[1]); hipFree(m->t); delete m; return rc; }
+    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, (size_t)n * 4, ctx->stream);
+    if (rc) { osc_free_common(m); hipFree(m->t); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
-int zh_trisawosc_destroy(zh_trisawosc *m) {
+int zh_trisawosc_destroy(zh_trisawosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     hipStreamSynchronize(m->ctx->stream);
-    hipFree(m->cnt[0]); hipFree(m->cnt[1]); hipFree(m->t);
+    zh_flipper_unregister(m);
+    osc_free_common(m); hipFree(m->t);
     delete m;
     return ZH_OK;
 }
-int zh_trisawosc_get_state(zh_trisawosc *m, zh_trisawosc_state *host) {
+int zh_trisawosc_get_state(zh_trisawosc *m, zh_trisawosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint32_t> c(m->n);
     std::vector<float> t(m->n);
@@ -398,7 +518,7 @@ int zh_trisawosc_get_state(zh_trisawosc *m, zh_trisawosc_state *host) {
     for (uint32_t i = 0; i < m->n; i++) { host[i].cnt = c[i]; host[i].t = t[i]; }
     return ZH_OK;
 }
-int zh_trisawosc_set_state(zh_trisawosc *m, const zh_trisawosc_state *host) {
+int zh_trisawosc_set_state(zh_trisawosc *m, const zh_trisawosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
     std::vector<uint32_t> c(m->n);
     std::vector<float> t(m->n);
@@ -407,25 +527,33 @@ int zh_trisawosc_set_state(zh_trisawosc *m, const zh_trisawosc_state *host) {
     if (!rc) rc = zh_upload(m->ctx, m->t, t.data(), (size_t)m->n * 4);
     return rc;
 }
-int zh_trisawosc_paint(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) {
-    (void)temps; (void)note_id_changed;                                             // TriSawOsc.zig:54-55
+static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t nb,
+                             const zh_trisawosc_params *p, uint32_t flags) {
     if (!p) return ZH_ERR_INVALID;
-    int rc = osc_common_check(m, start, end, outputs, p->sample_rate, p->freq);
+    int rc = osc_common_check(m, start, end, outputs, nb, p->sample_rate, p->freq);
     if (rc) return rc;
-    if (m->n == 0 || end == start) return ZH_OK;
+    if (m->n == 0 || end == start || nb == 0) return ZH_OK;
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
-    Img out = mk_img(outputs[0]);
     if (p->freq.tag == ZH_COB_CONSTANT) {
-        launch_osc_const<TriSawOscP>(m->ctx, m->n, m->cnt[m->cur], m->cnt[m->cur ^ 1], outputs[0], start, end, p->sample_rate,
-                                     p->freq.constant, p->color, zf);
-        m->cur ^= 1;
+        launch_osc_const<TriSawOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
-        if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
-        else hipLaunchKernelGGL(k_trisawosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+        for (uint32_t b = 0; b < nb; b++) {
+            Img out = mk_img(outputs[b]);
+            if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+            else hipLaunchKernelGGL(k_trisawosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+        }
     }
     return zh_launch_status();
+}
+int zh_trisawosc_paint(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
+                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    (void)temps; (void)note_id_changed;                                             // TriSawOsc.zig:54-55
+    return trisawosc_paint_n(m, start, end, outputs, 1, p, flags);
+}
+int zh_trisawosc_paint_batch(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t n_buffers,
+                             const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    return trisawosc_paint_n(m, start, end, outputs, n_buffers, p, flags);
 }
 
 }  // extern "C"

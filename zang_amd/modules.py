@@ -72,13 +72,20 @@ class _Module:
         assert st.shape == (self.n_voices,)
         abi.check(getattr(self.lib, f"zh_{self._prefix}_set_state")(self.handle, st.ctypes.data), "set_state")
 
-    def _paint(self, span, outputs, temps, note_id_changed, cparams, zero_first):
+    def _paint(self, span, outputs, temps, note_id_changed, cparams, zero_first, extra_flags=0):
         outs = _bufarray(outputs)
         tmps = _bufarray(temps)
         fn = getattr(self.lib, f"zh_{self._prefix}_paint")
         rc = fn(self.handle, span.start, span.end, outs, tmps, as_bool(note_id_changed), C.byref(cparams),
-                abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+                (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | extra_flags)
         abi.check(rc, f"zh_{self._prefix}_paint")
+
+    def _paint_batch(self, span, images, cparams, zero_first, extra_flags=0):
+        outs = _bufarray(images)
+        fn = getattr(self.lib, f"zh_{self._prefix}_paint_batch")
+        rc = fn(self.handle, span.start, span.end, outs, len(images), C.byref(cparams),
+                (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | extra_flags)
+        abi.check(rc, f"zh_{self._prefix}_paint_batch")
 
 
 class SineOsc(_Module):
@@ -108,9 +115,17 @@ class PulseOsc(_Module):
         freq: Any
         color: Any
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, params_unchanged=False):
+        """`params_unchanged`: the caller states that `params` (per-voice array contents included) are what the
+        previous paint of this module got (ZH_PAINT_PARAMS_UNCHANGED, include/zang_hip.h); same bits either way."""
         cp = abi.PulseOscParams(params.sample_rate, 0, params.freq, as_f32(params.color))
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_PARAMS_UNCHANGED if params_unchanged else 0)
+
+    def paint_batch(self, span, images, params, zero_first=False, params_unchanged=False):
+        """len(images) consecutive paint calls with the same span and params, call b into images[b], as one launch
+        when the frequency is constant (zh_pulseosc_paint_batch)."""
+        cp = abi.PulseOscParams(params.sample_rate, 0, params.freq, as_f32(params.color))
+        self._paint_batch(span, images, cp, zero_first, abi.PAINT_PARAMS_UNCHANGED if params_unchanged else 0)
 
 
 class TriSawOsc(_Module):
@@ -124,9 +139,17 @@ class TriSawOsc(_Module):
         freq: Any
         color: Any
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, params_unchanged=False):
+        """`params_unchanged`: the caller states that `params` (per-voice array contents included) are what the
+        previous paint of this module got (ZH_PAINT_PARAMS_UNCHANGED, include/zang_hip.h); same bits either way."""
         cp = abi.TriSawOscParams(params.sample_rate, 0, params.freq, as_f32(params.color))
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_PARAMS_UNCHANGED if params_unchanged else 0)
+
+    def paint_batch(self, span, images, params, zero_first=False, params_unchanged=False):
+        """len(images) consecutive paint calls with the same span and params, call b into images[b], as one launch
+        when the frequency is constant (zh_trisawosc_paint_batch)."""
+        cp = abi.TriSawOscParams(params.sample_rate, 0, params.freq, as_f32(params.color))
+        self._paint_batch(span, images, cp, zero_first, abi.PAINT_PARAMS_UNCHANGED if params_unchanged else 0)
 
 
 class Noise(_Module):

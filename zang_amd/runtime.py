@@ -48,12 +48,15 @@ class Context:
     def capture(self, fn):
         """Record everything fn() enqueues on this context into a hipGraph; returns a Graph."""
         abi.check(self.lib.zh_graph_begin_capture(self.handle), "zh_graph_begin_capture")
+        g = C.c_void_p()
         try:
             fn()
-        finally:
-            g = C.c_void_p()
-            rc = self.lib.zh_graph_end_capture(self.handle, C.byref(g))
-        abi.check(rc, "zh_graph_end_capture")
+        except BaseException:
+            # leave capture mode and drop the partial recording before passing the error on
+            if self.lib.zh_graph_end_capture(self.handle, C.byref(g)) == abi.ZH_OK and g:
+                self.lib.zh_graph_destroy(g)
+            raise
+        abi.check(self.lib.zh_graph_end_capture(self.handle, C.byref(g)), "zh_graph_end_capture")
         return Graph(self, g)
 
     def image(self, frames, voices, fill=None, pad=None):
