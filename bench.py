@@ -5,10 +5,18 @@ One "step" = what the reference does per 1024-frame buffer for every voice of th
 workload: `zang.zero(span, out)` then `Module.paint(span, {out}, ...)` (e.g.
 examples/modules.zig:220-225), with state carried from buffer to buffer.
 
-Default workload (N=1): BASELINE.json configs[1] -- 4096 PulseOsc voices x 1024 frames,
-constant per-voice frequency, 48 kHz.  With --gpus N each rank renders its own 4096-voice
-shard (weak scaling; voices are independent, no collective on this path: per-voice output
-images stay resident on the GPU that painted them).
+Default workload at N=1: BASELINE.json configs[1] -- 4096 PulseOsc voices x 1024 frames,
+constant per-voice frequency, 48 kHz (the configuration the HBM-roofline target is quoted on).
+Default workload at N>1: BASELINE.json configs[4] -- the NiceInstrument swarm (Osc+Env+Filter
+fused, voice mixdown in the same kernel), 131,072 voices per GPU (1,048,576 at N=8), two output
+channels, with the one exchange step of the multi-GPU path in the timed region: the GPUs'
+partial mixes are summed by an RCCL all-reduce over xGMI, one collective per 48-buffer batch.
+The N=1 line carries the same 131,072-voice shard without the collective in `config5_shard`,
+and the N>1 line times it again on every rank (`single_gpu_shard`) for the scaling factor.
+
+Launching: `python bench.py --gpus N` starts N ranks itself (fresh child processes, started
+before anything touches a GPU; rank 0's line is relayed); under `torch.distributed.run`
+(RANK / WORLD_SIZE in the environment) the process is one of the ranks.
 
 Output images rotate through a ring larger than the 256 MiB Infinity Cache so the stores
 really reach HBM (MI355X_MICROARCH.md "Infinity Cache").  Inputs (per-voice params, module
@@ -35,29 +43,92 @@ SR = 48000.0
 SCRIPT_MODULE = os.environ.get("ZH_SCRIPT_MODULE", "Lead")    # any module of tests/golden/script_modules.txt with (freq, note_on) params
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); without WORLD_SIZE in the environment N > 1 spawns them")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000; 960 for the 48-buffer-batch workloads)")
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="pulseosc", choices=["pulseosc", "noise_filter", "noise_filter_fused", "nice", "nice_mix", "script"])
-    ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
+    ap.add_argument("--workload", default=None, choices=["pulseosc", "noise_filter", "noise_filter_fused", "nice", "nice_mix", "script"],
+                    help="default: pulseosc (config 2) on one GPU, nice_mix (config 5) on several")
+    ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default 4096; 131072 for nice_mix on several GPUs)")
     ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--channels", type=int, default=2, choices=[1, 2], help="nice_mix: output channels of the mixdown (north_star: stereo)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "p2p"],
+                    help="nice_mix on several GPUs: RCCL all-reduce, or direct stores into the root's slots + fixed-order sum")
     ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline sample length")
+    ap.add_argument("--repeats", type=int, default=None, help="further K-step regions timed after the first (default: up to 30 when the region is short)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of one buffer")
+    ap.add_argument("--no-config5", action="store_true", help="N=1: skip the extra config-5 shard measurement")
+    ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write exchange measured beside the RCCL one")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never imports torch or
+    touches a GPU), relay rank 0's JSON line, exit non-zero if any rank fails."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0's stdout carries the line; the other ranks print nothing there
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    rc, out = 0, b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                if r == 0:
+                    try:
+                        o, _ = procs[0].communicate(timeout=0.2)
+                        out += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif procs[r].poll() is None:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode or 1
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for pr in procs:                         # a failed rank leaves the others waiting in a rendezvous / collective
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    if rc:
+        sys.stderr.write(f"bench.py: a rank exited with code {rc}\n")
+    return rc
 
 
 class Workload:
     """Builds the module(s), resident params and the per-step callable for one rank."""
 
-    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None):
+    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None, channels=1, exchange="rccl"):
         import torch
         self.world = world
+        self.channels, self.exchange_kind = channels, exchange
+        self.slots = None
         from zang_amd import modules as mod, zang, workloads
         self.name, self.V, self.F = name, V, F
         self.ctx = ctx
@@ -116,11 +187,20 @@ class Workload:
             self.nsteps = 0
         else:
             self.m = mod.NiceInstrument(V, self.color, ctx)
-            # one [frames] partial mix per buffer of a 48-buffer batch; with several GPUs the batch is exchanged at once
-            self.mixes = torch.zeros((48, F), dtype=torch.float32, device=dev)
-            self.mix = self.mixes[0]
+            # one [channels][frames] partial mix per buffer of a 48-buffer batch; with several GPUs the batch is exchanged at once
+            Cn = self.channels
+            self.mixes = torch.zeros((48, Cn, F), dtype=torch.float32, device=dev)
+            if Cn == 2:
+                # a constant pan per voice through the reference's scaleWave(min 0, max 1) / invertWaveInPlace
+                # (examples/example_stereo.zig:20-39,84-98): left = pan * 0.5 + 0.5, right = left * -1 + 1
+                import numpy as np
+                pan = (2.0 * u2 - 1.0).astype(np.float32)
+                gl = (np.float32(0.0) + ((np.float32(0.0) + pan * np.float32(0.5)) + np.float32(0.5))).astype(np.float32)
+                gr = (np.float32(0.0) + ((np.float32(0.0) + gl * np.float32(-1.0)) + np.float32(1.0))).astype(np.float32)
+                self.gain_l, self.gain_r = torch.from_numpy(gl).to(dev), torch.from_numpy(gr).to(dev)
+            self.targets = [[self.mixes[b, c] for c in range(Cn)] for b in range(48)]
             self.ring = []
-            self.kernel = "k_nice_mix"
+            self.kernel = "k_nice_mix<%d>" % Cn
             self.step = self._step_nice_mix
             self.nsteps = 0
         self.nring = len(self.ring)
@@ -128,20 +208,18 @@ class Workload:
         self.steps_done = 0
 
     def graph_steps(self, steps=0):
-        """Steps per captured graph: at least one ring rotation, even (see bench main).  The K timed steps as ONE
-        graph when K is even and not huge (each graph launch costs a ~4 us bubble on the stream); otherwise an even
-        count between one and four rotations that divides K, so that no remainder of the timed steps has to be
-        launched one by one from Python (~2x slower per step at the 16 MiB size)."""
+        """Steps per captured graph.  The K timed steps as ONE graph when K is not huge (each graph launch costs a
+        ~4 us bubble on the stream); otherwise a count between one and four ring rotations that divides K, so that
+        no remainder of the timed steps has to be launched one by one from Python (~2x slower per step at the
+        16 MiB size).  (Any count works: the oscillators' double-buffered state is reconciled by zh_graph_launch.)"""
         if self.name in ("nice", "nice_mix", "script"):
             return 48                       # the note on/off pattern repeats every 48 buffers
         if os.environ.get("ZH_BENCH_G"):
             return int(os.environ["ZH_BENCH_G"])   # experiments
         g = max(self.nring, 2)
-        g = g if g % 2 == 0 else g + 1
         if 2 <= steps <= 2049:
-            return steps - steps % 2        # the whole timed region is one graph launch (measured: 4.35 vs 4.47 us/step at 40);
-                                            # an odd K leaves one step to launch by hand
-        for cand in range(g, 4 * g + 1, 2):
+            return steps
+        for cand in range(g, 4 * g + 1):
             if steps and steps % cand == 0:
                 return cand
         return g
@@ -190,16 +268,46 @@ class Workload:
     def _step_nice_mix(self):
         row = self.nsteps % 48
         on, new = self._note_on()                                  # advances self.nsteps
-        self.m.paint_mix(self.span, self.mixes[row], new, self.m.Params(SR, self.freq, on), zero_first=True)
+        t = self.targets[row]
+        P = self.m.Params(SR, self.freq, on)
+        if self.channels == 2:
+            self.m.paint_mix_stereo(self.span, t[0], t[1], self.gain_l, self.gain_r, new, P, zero_first=True)
+        else:
+            self.m.paint_mix(self.span, t[0], new, P, zero_first=True)
+
+    def use_slots(self, slots):
+        """Direct-write exchange: the mixdown kernels store into this rank's slot of the root's block instead of
+        self.mixes (zang_amd.sharding.SlotExchange); call before capturing the graph."""
+        self.slots = slots
+        base, F, Cn = slots.slot(), self.F, self.channels
+        self.targets = [[base + ((b * Cn + c) * F * 4) for c in range(Cn)] for b in range(48)]
 
     def exchange(self):
         """config 5's one exchange step: the GPUs' partial mixes are summed over RCCL/xGMI.  A 4 KiB
         all-reduce per buffer would be pure latency (~20-40 us against 170 us of rendering), so the 48 buffers of a
-        batch go in ONE all-reduce of [48][frames] (192 KiB) after the batch's launches -- an offline renderer only
-        needs the mixed audio once the batch is done."""
-        if self.name == "nice_mix" and self.world > 1:
+        batch go in ONE all-reduce of [48][channels][frames] (192 KiB per channel) after the batch's launches -- an
+        offline renderer only needs the mixed audio once the batch is done."""
+        if self.name != "nice_mix" or self.world <= 1:
+            return
+        if self.slots is not None:
+            self.slots.finish(self.mixes)
+        else:
             from zang_amd import sharding
             sharding.allreduce_mix(self.mixes)
+
+
+def zig_probe():
+    """probe `zig version` at run time and record the result; nothing depends on it (the reference
+    sources never travel to the GPU box, so even with a toolchain the baseline stays the oracle)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("zig")
+    if not exe:
+        return "zig: not found on PATH"
+    try:
+        return subprocess.run([exe, "version"], capture_output=True, text=True, timeout=10).stdout.strip() or "zig: no output"
+    except Exception as e:          # noqa: BLE001
+        return f"zig: {type(e).__name__}"
 
 
 def cpu_baseline(args, wl):
@@ -256,7 +364,7 @@ def cpu_baseline(args, wl):
     t0 = time.perf_counter()
     run(nbuf)
     dt = time.perf_counter() - t0
-    res = {"value": V * F * nbuf / dt, "unit": "voice-samples/s", "cores": 1, "kind": "port",
+    res = {"value": V * F * nbuf / dt, "unit": "voice-samples/s", "cores": 1, "kind": "port", "zig_version_probe": zig_probe(),
            "sample": f"{nbuf} consecutive buffers of {V} voices x {F} frames ({what}), {dt:.1f} s on 1 thread"}
     if wl.name == "pulseosc":
         # the same loops with the voices sharded over every host core (one thread each,
@@ -327,25 +435,112 @@ def parity_check(wl, ctx):
             "mismatching_samples": int((~same).sum()), "against": "oracle from the GPU's own carried state"}
 
 
-def main():
-    args = parse()
+def traffic_record(args, V, F):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 --pmc passes of this same workload
+    (counters cannot be read from inside the process): value + where it came from."""
+    if not (args.workload == "pulseosc" and V == 4096 and F == 1024):
+        return None, None
+    for name in ("r02_pmc_pulseosc4096.json", "r01_pmc_pulseosc4096.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            src = {"file": "profiles/" + name, "collected_at_commit": rec.get("commit"), "how": "tools/collect_pmc_traffic.sh (separate --pmc passes of WRITE_SIZE / FETCH_SIZE, FETCH_SIZE x2 on gfx950)",
+                   "note": "a constant read from that file, not a counter of this run"}
+            return rec["hbm_bytes_per_launch"], src
+    return None, None
+
+
+def rocprof_record(args, V):
+    """The rocprofv3 --kernel-trace --stats average of the dominant kernel for this workload, if a committed
+    summary exists (profiles/r02 first) -- the figure `roofline.launch_ms_hip_events` should agree with."""
+    import csv
+    tag = {4096: "4096", 65536: "65536", 131072: "131072", 1048576: "1M"}.get(V)
+    if tag is None:
+        return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, f"{args.workload}{tag}_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        best = None
+        for row in csv.DictReader(open(path)):
+            if best is None or float(row.get("TotalDurationNs", 0) or 0) > float(best.get("TotalDurationNs", 0) or 0):
+                best = row
+        if best:
+            return {"file": f"profiles/{rnd}/{args.workload}{tag}_kernel_stats.csv", "kernel": best.get("Name", "")[:80],
+                    "calls": int(float(best.get("Calls", 0) or 0)), "average_us": float(best.get("AverageNs", 0) or 0) / 1e3}
+    return None
+
+
+def dry_run(args, world, rank):
+    """ZH_BENCH_EMULATE=1 on a box WITHOUT a GPU: the launcher, the rendezvous and the exchange step with host tensors
+    (gloo).  Nothing is painted and nothing is measured: `value` is 0 and the line says so.  Used by the CPU tests."""
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from zang_amd import sharding
+    dist.init_process_group("gloo")
+    F, Cn = args.frames, args.channels
+    mixes = torch.full((48, Cn, F), float(rank + 1), dtype=torch.float32)
+    t0 = time.perf_counter()
+    sharding.allreduce_mix(mixes)
+    dt = time.perf_counter() - t0
+    ok = bool((mixes == world * (world + 1) / 2).all())
+    seen = torch.ones(1); dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "voice-samples/sec", "value": 0.0, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "none", "dry_run": "no GPU on this box: launcher + rendezvous + exchange step only, nothing painted",
+                          "config": {"workload": f"{args.workload}: dry run", "parallelism": f"voices sharded x{world}"},
+                          "collective": {"backend": "gloo", "world_size_seen": int(seen.item()), "bytes": mixes.numel() * 4,
+                                         "reduce_us": dt * 1e6, "sum_correct": ok}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        sys.exit(spawn_ranks(args.gpus, argv))       # parent: nothing below runs in it
+    world = int(env_world or 1)
+    if args.gpus is not None and args.gpus != world:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
+                         f"or under torch.distributed.run with --nproc-per-node equal to --gpus\n")
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload is None:
+        args.workload = "pulseosc" if world == 1 else "nice_mix"
+    if args.voices is None:
+        args.voices = 131072 if (args.workload == "nice_mix" and world > 1) else 4096
+    if args.steps is None:
+        args.steps = 960 if args.workload in ("nice", "nice_mix", "script") else 1000
+    import torch
+    import torch.distributed as dist
     # ZH_BENCH_EMULATE=1: multi-process dry run on a single GPU (every rank on device 0, gloo instead
     # of RCCL) -- used only to exercise the N>1 code path where one GPU is available.
     emulate = os.environ.get("ZH_BENCH_EMULATE") == "1"
+    if emulate and world > 1 and not torch.cuda.is_available():
+        sys.exit(dry_run(args, world, rank))
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py: no HIP device (torch.cuda.is_available() is False); there is no CPU path to measure\n")
+        sys.exit(3)
     device_index = 0 if (world == 1 or emulate) else local_rank
+    if device_index >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} needs GPU {device_index} but this node shows {torch.cuda.device_count()}\n")
+        sys.exit(3)
+    ctl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(device_index)
         if emulate:
             dist.init_process_group("gloo")
+            ctl = dist.group.WORLD
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            ctl = dist.new_group(backend="gloo")        # host-side control channel (handle exchange, host barriers)
     else:
         torch.cuda.set_device(0)
     import zang_amd
@@ -356,7 +551,6 @@ def main():
     torch.cuda.set_stream(side)
     ctx = zang_amd.Context(device_index)
     V, F = args.voices, args.frames
-    wl = Workload(args.workload, ctx, V, F, first_voice=rank * V, ring_bytes=args.ring_mib << 20, world=world, pad=args.pad_voices)
     lib = ctx.lib
 
     def barrier():
@@ -368,90 +562,199 @@ def main():
         abi.check(lib.zh_event_create(ctx.handle, C.byref(h)), "zh_event_create")
         return h
 
-    # The per-buffer loop is launch-bound at 4096 voices (a 16 MiB paint takes ~6 us on the
-    # device, a Python->C->hipLaunchKernel call about as long), so G consecutive steps are
-    # captured once into a hipGraph and replayed; G = the output ring length (even, so the
-    # oscillator's double-buffered state ends where it started in the capture).
-    G = wl.graph_steps(args.steps) if not args.eager else 0
-    graph = None
-    if G:
-        for _ in range(G):          # one eager pass first: lazy allocations happen outside capture
-            wl.step()
-        torch.cuda.synchronize()
-        graph = ctx.capture(lambda: [wl.step() for _ in range(G)])
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if emulate else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
 
-    def run_steps(n):
-        done = 0
-        if graph is not None:
-            while n - done >= G:
-                graph.launch()
+    class Runner:
+        """One workload prepared for timing: eager pre-pass (lazy allocations), the captured graph of G steps, and
+        `region(K)` = exactly K steps bracketed by barrier + synchronize on both sides, timed by the wall clock
+        (max over ranks) and by HIP events on the launch stream."""
+
+        def __init__(self, name, voices, steps, exchange="rccl", slots=False):
+            self.wl = Workload(name, ctx, voices, F, first_voice=rank * voices, ring_bytes=args.ring_mib << 20, world=world,
+                               pad=args.pad_voices, channels=args.channels, exchange=exchange)
+            wl = self.wl
+            self.with_exchange = True
+            if slots:
+                from zang_amd import sharding
+                wl.use_slots(sharding.SlotExchange(ctx, wl.mixes.numel(), control_group=ctl))
+            # The per-buffer loop is launch-bound at 4096 voices (a 16 MiB paint takes ~4 us on the device, a
+            # Python->C->hipLaunchKernel call about as long), so G consecutive steps are captured once into a
+            # hipGraph and replayed.
+            self.G = wl.graph_steps(steps) if not args.eager else 0
+            self.graph = None
+            if self.G:
+                for _ in range(self.G):          # one eager pass first: lazy allocations happen outside capture
+                    wl.step()
+                torch.cuda.synchronize()
+                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)])
+            self.ev0, self.ev1 = make_event(), make_event()
+
+        def run_steps(self, n):
+            wl, G, done = self.wl, self.G, 0
+            if self.graph is not None:
+                while n - done >= G:
+                    self.graph.launch()
+                    if self.with_exchange:
+                        wl.exchange()
+                    done += G
+            for _ in range(n - done):
+                wl.step()
+            if n - done and self.with_exchange:
                 wl.exchange()
-                done += G
-        for _ in range(n - done):
-            wl.step()
-        if n - done:
-            wl.exchange()
 
-    ev0, ev1 = make_event(), make_event()
-    run_steps(args.warmup)
-    if graph is not None and args.warmup < G:
-        graph.launch()                      # untimed: the first replay of a graph uploads it
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # HIP events on the launch stream bracket exactly the K timed steps: device time per
-    # launch = elapsed / K (includes the ~1 us inter-kernel boundaries, so it can only
-    # under-state the kernel's own rate; profiles/ holds the rocprofv3 per-kernel average).
-    abi.check(lib.zh_event_record(ctx.handle, ev0), "zh_event_record")
-    run_steps(args.steps)
-    abi.check(lib.zh_event_record(ctx.handle, ev1), "zh_event_record")
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ms = C.c_float()
-    abi.check(lib.zh_event_elapsed_ms(ev0, ev1, C.byref(ms)), "zh_event_elapsed_ms")
-    step_ms_events = ms.value / args.steps
-    lib.zh_event_destroy(ev0)
-    lib.zh_event_destroy(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if emulate else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def warm(self, n):
+            self.run_steps(n)
+            if self.graph is not None and n < self.G:
+                self.graph.launch()                      # untimed: the first replay of a graph uploads it
+                if self.with_exchange:
+                    self.wl.exchange()
+            torch.cuda.synchronize()
 
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same workload
-    # (tools/summarize_pmc.py; counters cannot be read from inside the process)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_pulseosc4096.json")
-    if args.workload == "pulseosc" and V == 4096 and F == 1024 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+        def region(self, K):
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            # HIP events on the launch stream bracket exactly the K timed steps: device time per
+            # launch = elapsed / K (includes the ~1 us inter-kernel boundaries, so it can only
+            # under-state the kernel's own rate; profiles/ holds the rocprofv3 per-kernel average).
+            abi.check(lib.zh_event_record(ctx.handle, self.ev0), "zh_event_record")
+            self.run_steps(K)
+            abi.check(lib.zh_event_record(ctx.handle, self.ev1), "zh_event_record")
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            ms = C.c_float()
+            abi.check(lib.zh_event_elapsed_ms(self.ev0, self.ev1, C.byref(ms)), "zh_event_elapsed_ms")
+            return max_over_ranks(elapsed), ms.value
 
-    total_units = world * V * F * args.steps
+        def close(self):
+            lib.zh_event_destroy(self.ev0)
+            lib.zh_event_destroy(self.ev1)
+            if self.wl.slots is not None:
+                self.wl.slots.close()
+
+    K = args.steps
+    main_run = Runner(args.workload, V, K, exchange=args.exchange, slots=(args.exchange == "p2p" and world > 1 and args.workload == "nice_mix"))
+    wl, G, graph = main_run.wl, main_run.G, main_run.graph
+    main_run.warm(args.warmup)
+    elapsed, ev_ms = main_run.region(K)              # THE timed region of the contract: exactly K steps
+    step_ms_events = ev_ms / K
+
+    # Further regions of exactly K steps, each bracketed the same way: a short region (the driver's 20 steps of a
+    # 4 us kernel = 0.1 ms) is dominated by the launch ramp and the synchronize, and one sample of it is noisy.
+    R = args.repeats if args.repeats is not None else (min(30, max(0, int(0.5 / max(elapsed, 1e-4)))) if elapsed < 0.1 else 0)
+    reps = None
+    if R > 0:
+        import statistics
+        walls, evs = [], []
+        for _ in range(R):
+            e, m = main_run.region(K)
+            walls.append(e / K * 1e3); evs.append(m / K)
+        reps = {"regions": R, "steps_per_region": K,
+                "ms_per_step_wall": {"median": statistics.median(walls), "min": min(walls), "max": max(walls)},
+                "ms_per_step_hip_events": {"median": statistics.median(evs), "min": min(evs), "max": max(evs)},
+                "note": "`value`, `ms_per_step` and `roofline` come from the first region only"}
+
+    traffic, traffic_src = traffic_record(args, V, F)
+    total_units = world * V * F * K
     value = total_units / elapsed
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
+    mixdown = args.workload == "nice_mix"
     out = {
         "metric": "voice-samples/sec", "value": value, "unit": "voice-samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, zero+paint per {F}-frame buffer, 48 kHz",
-                   "voices_per_gpu": V, "frames": F, "ring_images": wl.nring, "launch": "eager" if graph is None else f"hipGraph x{G} steps", "parallelism": f"voices sharded x{world}"},
+        "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, " +
+                               (f"fused Osc+Env+Filter voices + {args.channels}-channel voice mixdown per {F}-frame buffer, 48 kHz (BASELINE configs[4])" if mixdown
+                                else f"zero+paint per {F}-frame buffer, 48 kHz"),
+                   "voices_per_gpu": V, "total_voices": V * world, "frames": F, "ring_images": wl.nring,
+                   "launch": "eager" if graph is None else f"hipGraph x{G} steps", "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": wl.kernel,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": wl.kernel,
                      "frac_of_measured_store_rate": achieved / HBM_STORE_GBS,   # SURVEY 8d: also quote / 6200 "achievable"
-                     "algorithmic_bytes_per_launch": wl.bytes_per_step, "launch_ms_hip_events": step_ms_events},
+                     "algorithmic_bytes_per_launch": wl.bytes_per_step, "launch_ms_hip_events": step_ms_events,
+                     "rocprofv3_kernel_average": rocprof_record(args, V)},
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }
+    if mixdown:
+        out["config"]["channels"] = args.channels
+        out["roofline"]["note"] = ("the mixdown workload writes 4 KiB per channel per buffer: `achieved` is the EQUIVALENT write rate "
+                                   "(4 B per voice-sample that the unfused path would store); the kernel is VALU-issue-bound (SURVEY.md 8d)")
+    if reps:
+        out["repeats"] = reps
+
+    if world > 1 and mixdown:
+        # ---- the exchange step on its own, and the same shard without it (scaling factor) ----
+        nbytes = wl.mixes.numel() * 4
+        n_ex = 20
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_ex):
+            wl.exchange()
+        torch.cuda.synchronize()
+        reduce_us = max_over_ranks((time.perf_counter() - t0) / n_ex) * 1e6
+        seen = torch.ones(1, device="cpu" if emulate else "cuda"); dist.all_reduce(seen)
+        kind = "direct stores into the root's slots + rank-ordered sum (zh_sum_slots), host barriers" if wl.slots is not None else "all_reduce(sum)"
+        out["collective"] = {"backend": "host barriers + HIP IPC" if wl.slots is not None else dist.get_backend(), "kind": kind,
+                             "world_size_seen": int(seen.item()),
+                             "bytes": nbytes, "per": "48-buffer batch", "reduce_us": reduce_us, "in_timed_region": True,
+                             "reduce_us_per_buffer": reduce_us / 48}
+        main_run.with_exchange = False
+        e1, _ = main_run.region(K)
+        main_run.with_exchange = True
+        single = V * F * K / e1
+        out["single_gpu_shard"] = {"value": single, "ms_per_step": e1 / K * 1e3,
+                                   "what": "the same K steps on every rank without the exchange (slowest rank)"}
+        out["scaling_factor"] = value / single
+        out["realtime_voices_48k"] = value / SR
+        if not args.no_p2p and wl.slots is None:
+            # the alternative SURVEY.md 8e asks to measure beside the collective
+            try:
+                alt = Runner("nice_mix", V, K, exchange="p2p", slots=True)
+                alt.warm(48)
+                e2, _ = alt.region(K)
+                torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_ex):
+                    alt.wl.exchange()
+                torch.cuda.synchronize()
+                p2p_us = max_over_ranks((time.perf_counter() - t0) / n_ex) * 1e6
+                out["p2p_direct"] = {"value": world * V * F * K / e2, "ms_per_step": e2 / K * 1e3, "reduce_us": p2p_us, "bytes": nbytes,
+                                     "what": "mixdown kernels store into the root GPU's per-rank slots (HIP IPC mapping); per batch: stream sync + host "
+                                             "barrier, root adds the slots in rank order, host barrier; bit-reproducible"}
+                alt.close()
+            except Exception as e:          # noqa: BLE001  (reported, never fatal: it is the comparison, not the measurement)
+                out["p2p_direct"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    if world == 1 and not args.no_config5 and args.workload == "pulseosc" and V == 4096:
+        # the 1-GPU shard of config 5 (what every rank of the N>1 run renders), for the scaling ratio
+        c5 = Runner("nice_mix", 131072, 96)
+        c5.warm(48)
+        e5, m5 = c5.region(96)
+        out["config5_shard"] = {"workload": f"nice_mix: 131072 voices x {F} frames, {args.channels}-channel mixdown, no exchange (one GPU)",
+                                "value": 131072 * F * 96 / e5, "ms_per_step": e5 / 96 * 1e3, "steps": 96, "launch_ms_hip_events": m5 / 96,
+                                "realtime_voices_48k": 131072 * F * 96 / e5 / SR}
+        c5.close()
+
     if rank == 0 and world == 1 and not args.no_parity:
         out["parity"] = parity_check(wl, ctx)
     if rank == 0 and world == 1 and not args.no_cpu:
         cb = cpu_baseline(args, wl)
         if cb:
             out["cpu_baseline"] = cb
+    main_run.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -393,6 +393,14 @@ ZH_API int zh_nice_paint(zh_nice *m, uint32_t span_start, uint32_t span_end, con
  * partial[f] (+)= sum_v voice_v[f].  `mix` is a device float[frames]. */
 ZH_API int zh_nice_paint_mix(zh_nice *m, uint32_t span_start, uint32_t span_end, float *mix,
                              zh_bool note_id_changed, const zh_nice_params *params, uint32_t flags);
+/* Two output channels (a module with num_outputs = 2, examples/example_stereo.zig:42-43): every voice is added to each
+ * channel scaled by that voice's channel gain, `outputs[c] += voice * pan_c` (example_stereo.zig:92-98, zang.multiply:
+ * product rounded to f32, then added), and each channel is mixed down over the voices:
+ * mix_c[f] (+)= sum_v voice_v[f] * gain_c[v].  mix_left / mix_right are device float[frames] (zh_mix_down then
+ * interleaves them, examples/write_wav.zig:71-78). */
+ZH_API int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t span_start, uint32_t span_end, float *mix_left, float *mix_right,
+                                    zh_f32 gain_left, zh_f32 gain_right, zh_bool note_id_changed,
+                                    const zh_nice_params *params, uint32_t flags);
 
 /* Per-voice span table: the output of NoteTracker -> PolyphonyDispatcher -> Trigger for one buffer
  * (examples/example_song.zig:326-349), i.e. for every voice up to `max_spans` sub-spans, ascending and

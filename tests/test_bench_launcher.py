@@ -1,0 +1,88 @@
+"""CPU: bench.py's launcher.  `--gpus N` must really start N ranks (it was a dead flag), relay rank 0's
+line, and fail loudly when a rank fails or when the flag disagrees with the launcher's WORLD_SIZE.  On this box there is
+no GPU: ZH_BENCH_EMULATE=1 turns the ranks into a dry run (rendezvous + the exchange step on host tensors over gloo;
+nothing is painted, `value` is 0 and the line says so)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def _gpu_here():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(_gpu_here(), reason="the dry run is the no-GPU form of the emulation")
+def test_gpus_flag_spawns_ranks_dry_run():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5"], env=_env(ZH_BENCH_EMULATE="1"),
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["collective"]["world_size_seen"] == 2 and line["collective"]["sum_correct"] is True
+    assert line["value"] == 0.0 and "dry_run" in line            # nothing was painted and the line says so
+    assert line["config"]["workload"].startswith("nice_mix")     # N > 1 defaults to config 5
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(_gpu_here(), reason="the dry run is the no-GPU form of the emulation")
+def test_under_torch_distributed_run_dry_run():
+    """The driver's own command line for N > 1."""
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       env=_env(ZH_BENCH_EMULATE="1"), capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["collective"]["world_size_seen"] == 2
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(_gpu_here(), reason="needs a box without a GPU")
+def test_failed_rank_gives_nonzero_exit():
+    """Without the emulation switch a rank on a GPU-less box must refuse (there is no CPU path to measure), and the
+    parent must pass the failure on instead of printing a line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "0"], env=_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "no HIP device" in r.stderr
+
+
+@pytest.mark.timeout(120)
+def test_gpus_flag_must_agree_with_world_size():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", ZH_BENCH_EMULATE="1"),
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.skipif(_gpu_here(), reason="needs a box without a GPU")
+def test_single_rank_without_gpu_fails_loudly():
+    r = subprocess.run([sys.executable, BENCH, "--steps", "4", "--warmup", "0"], env=_env(), capture_output=True, text=True, timeout=100)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and not r.stdout.strip()

@@ -131,6 +131,47 @@ def test_nice_paint_mix(ctx, oracle):
     assert np.array_equal(m1.state(), m2.state())
 
 
+def test_nice_paint_mix_stereo(ctx, oracle):
+    """Two channels (examples/example_stereo.zig:84-98 with a constant pan per voice): every voice is added to the left
+    channel times its left gain and to the right channel times (1 - left); the per-voice products are f32, their sum
+    over the voices is checked against the f64 sum with the sqrt(V) * eps bound; with both gains 1.0 the two channels
+    equal the mono mixdown bit for bit (x * 1.0 == x, same summation order)."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V = 1000
+    freq, color, u2, _ = workloads.voice_params(5, 7, V)
+    pan = (2.0 * u2 - 1.0).astype(np.float32)
+    # scaleWave(min 0, max 1) and invertWaveInPlace of the reference, on the per-voice constant (example_stereo.zig:20-39)
+    gl = (np.float32(0.0) + ((np.float32(0.0) + pan * np.float32(0.5)) + np.float32(0.5))).astype(np.float32)
+    gr = (np.float32(0.0) + ((np.float32(0.0) + gl * np.float32(-1.0)) + np.float32(1.0))).astype(np.float32)
+    m1 = mod.NiceInstrument(V, util.dev(color), ctx)
+    m2 = mod.NiceInstrument(V, util.dev(color), ctx)
+    m3 = mod.NiceInstrument(V, util.dev(color), ctx)
+    m4 = mod.NiceInstrument(V, util.dev(color), ctx)
+    gf, dgl, dgr = util.dev(freq), util.dev(gl), util.dev(gr)
+    for ((s, e), on, nic) in SCRIPT:
+        per_voice = ctx.image(F, V, fill=0.0)
+        P = m1.Params(SR, gf, bool(on))
+        m1.paint(zang.Span(s, e), [per_voice], None, bool(nic), P)
+        left = torch.full((F,), 0.25, dtype=torch.float32, device="cuda"); right = torch.full((F,), -0.5, dtype=torch.float32, device="cuda")
+        m2.paint_mix_stereo(zang.Span(s, e), left, right, dgl, dgr, bool(nic), P)
+        mono = torch.zeros(F, device="cuda"); l1 = torch.zeros(F, device="cuda"); r1 = torch.zeros(F, device="cuda")
+        m3.paint_mix(zang.Span(s, e), mono, bool(nic), P, zero_first=True)
+        m4.paint_mix_stereo(zang.Span(s, e), l1, r1, 1.0, 1.0, bool(nic), P, zero_first=True)
+        ctx.sync()
+        pv = per_voice.cpu().numpy()                                       # [frames][voices]
+        for got_t, g, base in ((left, gl, 0.25), (right, gr, -0.5)):
+            prod = (pv * g[None, :]).astype(np.float32).astype(np.float64)  # f32 products, summed in f64
+            ref = base + prod.sum(axis=1)
+            ref[:s] = base; ref[e:] = base
+            got = got_t.cpu().numpy()
+            bound = 4 * np.sqrt(V) * np.finfo(np.float32).eps * max(np.abs(prod).sum(axis=1).max(), 1.0)
+            assert np.abs(got - ref).max() <= bound
+            assert np.array_equal(got[:s], np.full(s, base, np.float32)) and np.array_equal(got[e:], np.full(F - e, base, np.float32))
+        assert torch.equal(l1.view(torch.int32), mono.view(torch.int32)) and torch.equal(r1.view(torch.int32), mono.view(torch.int32))
+    assert np.array_equal(m1.state(), m2.state()) and np.array_equal(m1.state(), m4.state())
+
+
 def test_pmosc_fused_equals_unfused_oracle(ctx, oracle):
     from zang_amd import modules as mod, zang, workloads
     V = 192

@@ -388,6 +388,7 @@ SIGNATURES = {
     "zh_nice_set_state": (C.c_int, [vp, vp]),
     "zh_nice_paint": (C.c_int, _paint(NiceParams)),
     "zh_nice_paint_mix": (C.c_int, [vp, u32, u32, vp, Bool, P(NiceParams), u32]),
+    "zh_nice_paint_mix_stereo": (C.c_int, [vp, u32, u32, vp, vp, F32, F32, Bool, P(NiceParams), u32]),
     "zh_delay_create": (C.c_int, [vp, u32, u32, P(vp)]),
     "zh_delay_destroy": (C.c_int, [vp]),
     "zh_delay_reset": (C.c_int, [vp]),

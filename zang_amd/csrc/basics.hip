@@ -261,9 +261,12 @@ int zh_mix_reserve(zh_ctx *ctx, size_t floats) { ZH_GUARD(ctx);
     return ZH_OK;
 }
 
-void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
-    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 63) / 64), dim3(64 * MIX_SEG), 0, ctx->stream, ctx->mix_partials, tiles,
+void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
+    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 63) / 64), dim3(64 * MIX_SEG), 0, ctx->stream, partials, tiles,
                        nframes, dst, zero_first);
+}
+void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
+    zh_mix_pass2_launch_at(ctx, ctx->mix_partials, tiles, nframes, dst, zero_first);
 }
 
 extern "C" {

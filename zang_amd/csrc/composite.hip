@@ -19,6 +19,7 @@
 // basics.hip
 int zh_mix_reserve(zh_ctx *ctx, size_t floats);
 void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first);
+void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, uint32_t nframes, float *dst, int zero_first);
 
 struct zh_nice {
     zh_ctx *ctx;
@@ -268,9 +269,15 @@ __global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t s
 constexpr int MIXF = 32;
 constexpr int MIXS = 65;
 
-__global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials) {
+// C = output channels.  C = 1: partials[block][frame] = sum of the block's voices.  C = 2 (stereo,
+// examples/example_stereo.zig:92-98: `outputs[c] += voice * pan_c` per voice): the sum phase multiplies each
+// voice's sample by that voice's channel gain first -- a lane's 32 voices are the same in every chunk, so their
+// 2 x 32 gains sit in registers -- and partials are [channel][block][frame].
+template <int C>
+__global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
+                                                  F32P gain_l, F32P gain_r) {
     __shared__ float tile[4][MIXF][MIXS];
-    __shared__ float halfsum[MIXF][8];
+    __shared__ float halfsum[C][MIXF][8];
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nframes = end - start;
@@ -278,6 +285,16 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     NiceLane n;
     if (live) nice_load(n, a, v);                                       // (the carried-mask oscillator measured 10 % slower here)
     const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
+    float gl[C == 2 ? 32 : 1], gr[C == 2 ? 32 : 1];
+    if constexpr (C == 2) {
+        const uint32_t v0 = blockIdx.x * 256 + wave * 64 + rh * 32;     // first of the 32 voices this lane adds up
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const bool in = v0 + j < a.V;                               // (their tile entries are 0.0f; the gain is never read out of range)
+            gl[j] = in ? gain_l.get(v0 + j) : 0.0f;
+            gr[j] = in ? gain_r.get(v0 + j) : 0.0f;
+        }
+    }
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
 #pragma unroll 4
         for (int k = 0; k < MIXF; k++) {
@@ -288,18 +305,27 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
         __syncthreads();
         {
             const float *row = &tile[wave][rf][rh * 32];
-            float s = row[0];
+            if constexpr (C == 1) {
+                float s = row[0];
 #pragma unroll
-            for (int j = 1; j < 32; j++) s += row[j];
-            halfsum[rf][wave * 2 + rh] = s;
+                for (int j = 1; j < 32; j++) s += row[j];
+                halfsum[0][rf][wave * 2 + rh] = s;
+            } else {
+                float sl = row[0] * gl[0], sr = row[0] * gr[0];        // zang.multiply: dest += a * b, no fused multiply-add
+#pragma unroll
+                for (int j = 1; j < 32; j++) { sl += row[j] * gl[j]; sr += row[j] * gr[j]; }
+                halfsum[0][rf][wave * 2 + rh] = sl;
+                halfsum[1][rf][wave * 2 + rh] = sr;
+            }
         }
         __syncthreads();
-        if (threadIdx.x < MIXF && f0 + threadIdx.x < end) {
-            const float *w = halfsum[threadIdx.x];
+        if (threadIdx.x < MIXF * C && f0 + (threadIdx.x & (MIXF - 1)) < end) {
+            const uint32_t c = threadIdx.x / MIXF, fr = threadIdx.x & (MIXF - 1);
+            const float *w = halfsum[c][fr];
             float s = w[0];
 #pragma unroll
             for (int j = 1; j < 8; j++) s += w[j];
-            partials[(size_t)blockIdx.x * nframes + (f0 - start) + threadIdx.x] = s;
+            partials[((size_t)c * gridDim.x + blockIdx.x) * nframes + (f0 - start) + fr] = s;
         }
         // the next chunk's tile writes are ordered behind this chunk's reads by the barrier above
         // (rows are only read before it) and halfsum is rewritten only after the next barrier
@@ -898,19 +924,41 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     }
     return zh_launch_status();
 }
-int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_bool note_id_changed,
-                      const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
-    if (!m || !mix || !p || end < start) return ZH_ERR_INVALID;
+static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
+                            const zh_f32 *gain_r, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
+    const bool stereo = mix_r != nullptr;
+    if (!m || !mix_l || !p || end < start) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
     const uint32_t nframes = end - start;
     const uint32_t blocks = (m->n + 255) / 256;
-    int rc = zh_mix_reserve(m->ctx, (size_t)blocks * (nframes ? nframes : 1));
+    const size_t per_channel = (size_t)blocks * (nframes ? nframes : 1);
+    int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1));
     if (rc) return rc;
     hipStream_t st = m->ctx->stream;
     NiceArgs a = nice_args(m, p, note_id_changed);
-    hipLaunchKernelGGL(k_nice_mix, dim3(blocks), dim3(256), 0, st, a, start, end, m->ctx->mix_partials);
-    if (nframes) zh_mix_pass2_launch(m->ctx, blocks, nframes, mix + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
+    float *part = m->ctx->mix_partials;
+    const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
+    if (stereo) {
+        hipLaunchKernelGGL(k_nice_mix<2>, dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        if (nframes) {
+            zh_mix_pass2_launch_at(m->ctx, part, blocks, nframes, mix_l + start, zf);
+            zh_mix_pass2_launch_at(m->ctx, part + per_channel, blocks, nframes, mix_r + start, zf);
+        }
+    } else {
+        const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
+        hipLaunchKernelGGL(k_nice_mix<1>, dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
+        if (nframes) zh_mix_pass2_launch_at(m->ctx, part, blocks, nframes, mix_l + start, zf);
+    }
     return zh_launch_status();
+}
+int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_bool note_id_changed,
+                      const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    return nice_paint_mix_n(m, start, end, mix, nullptr, nullptr, nullptr, note_id_changed, p, flags);
+}
+int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mix_left, float *mix_right, zh_f32 gain_left,
+                             zh_f32 gain_right, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    if (!mix_right) return ZH_ERR_INVALID;
+    return nice_paint_mix_n(m, start, end, mix_left, mix_right, &gain_left, &gain_right, note_id_changed, p, flags);
 }
 
 static bool span_table_ok(const zh_span_table *t) {

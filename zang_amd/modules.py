@@ -388,6 +388,14 @@ class NiceInstrument(_Module):
                                         C.byref(cp), abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
         abi.check(rc, "zh_nice_paint_mix")
 
+    def paint_mix_stereo(self, span, mix_left, mix_right, gain_left, gain_right, note_id_changed, params, zero_first=False):
+        """Two channels: mix_c[f] (+)= sum over voices of voice[f] * gain_c[voice] (examples/example_stereo.zig:92-98)."""
+        cp = abi.NiceParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
+        rc = self.lib.zh_nice_paint_mix_stereo(self.handle, span.start, span.end, mix_left.data_ptr(), mix_right.data_ptr(),
+                                               as_f32(gain_left), as_f32(gain_right), as_bool(note_id_changed), C.byref(cp),
+                                               abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+        abi.check(rc, "zh_nice_paint_mix_stereo")
+
 
 class SimpleDelay(_Module):
     """examples/modules.zig:341-386 over zang.Delay(delay_samples) (src/zang/delay.zig)."""

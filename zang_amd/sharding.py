@@ -2,9 +2,16 @@
 
 Voices share nothing (module state is per instance; Noise is seeded by GLOBAL voice index),
 so painting needs no inter-GPU traffic.  The only exchange is the final mixdown: each rank
-reduces its own voices to a [frames] partial on its GPU, then ONE sum all-reduce of that
-4 KiB vector (RCCL over xGMI on GPUs; gloo in the CPU tests).
+reduces its own voices to a [channels][frames] partial on its GPU, and the partials are summed.
+Two forms of that one step:
+
+* `allreduce_mix`  -- a sum all-reduce (RCCL over xGMI on GPUs; gloo in the CPU tests);
+* `SlotExchange`   -- the root GPU owns one slot per rank in its own HBM, every rank's mixdown kernel stores its
+  partial STRAIGHT into its slot (peer stores over xGMI, HIP IPC mapping, csrc/xchg.hip), and the root adds the
+  slots in rank order: a fixed order, so the mix is reproducible bit for bit whatever the link timing.
 """
+import ctypes as C
+
 import torch.distributed as dist
 
 
@@ -16,7 +23,7 @@ def voice_range(total_voices, rank, world):
 
 
 def allreduce_mix(mix, group=None):
-    """Sum the per-rank partial mixes in place (float32 [frames], on the rank's device)."""
+    """Sum the per-rank partial mixes in place (float32 [..., frames], on the rank's device)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if mix.is_cuda and dist.get_backend(group) == "gloo":     # CPU-only backend (tests, dry runs): stage through host
             host = mix.cpu()
@@ -25,3 +32,78 @@ def allreduce_mix(mix, group=None):
         else:
             dist.all_reduce(mix, op=dist.ReduceOp.SUM, group=group)
     return mix
+
+
+class DevicePtr:
+    """A raw device address with the one method the module wrappers use of a tensor."""
+
+    def __init__(self, addr):
+        self.addr = int(addr)
+
+    def data_ptr(self):
+        return self.addr
+
+    def __add__(self, nbytes):
+        return DevicePtr(self.addr + int(nbytes))
+
+
+class SlotExchange:
+    """Direct-write exchange of the partial mixes.
+
+    `floats` = floats of one rank's partial block (e.g. 48 buffers x 2 channels x 1024 frames).  Rank 0 allocates
+    world x floats in its HBM (zh_ipc_alloc) and hands the 64-byte IPC handle to the other ranks over the host
+    control group (gloo); they map it (zh_ipc_open).  Per batch:
+
+        paint ... into  self.slot()        (device address of this rank's slot; float offsets are the caller's)
+        self.finish(dst)                   every rank: stream sync, host barrier; root: dst (+)= slot_0 + slot_1 + ...
+                                           in rank order, stream sync; host barrier (the slots may be rewritten)
+
+    Host barriers order the processes (two per batch); no collective library is involved in the data path.
+    """
+
+    def __init__(self, ctx, floats, control_group=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.floats = int(floats)
+        self.stride = (self.floats + 63) // 64 * 64                      # slots 256-byte aligned
+        self.ctl = control_group if control_group is not None else dist.new_group(backend="gloo")
+        from . import abi
+        self._abi = abi
+        base = C.c_void_p()
+        handle = (C.c_uint8 * 64)()
+        payload = [None]
+        if self.rank == 0:
+            abi.check(self.lib.zh_ipc_alloc(ctx.handle, self.world * self.stride * 4, C.byref(base), handle), "zh_ipc_alloc")
+            payload = [bytes(handle)]
+        dist.broadcast_object_list(payload, src=0, group=self.ctl)
+        if self.rank != 0:
+            C.memmove(handle, payload[0], 64)
+            abi.check(self.lib.zh_ipc_open(ctx.handle, handle, C.byref(base)), "zh_ipc_open")
+        self.base = base.value
+        self.owner = self.rank == 0
+
+    def slot(self, rank=None):
+        r = self.rank if rank is None else rank
+        return DevicePtr(self.base + r * self.stride * 4)
+
+    def finish(self, dst=None, zero_first=True):
+        """All ranks call it after enqueueing their paints.  On return the root's `dst` (float32 CUDA tensor of
+        `floats` elements; root only) holds the rank-ordered sum and the slots may be written again."""
+        abi = self._abi
+        self.ctx.sync()                                                    # this rank's stores have landed in the root's HBM
+        dist.barrier(group=self.ctl)
+        if self.owner and dst is not None:
+            abi.check(self.lib.zh_sum_slots(self.ctx.handle, dst.data_ptr(), C.c_void_p(self.base), self.world, self.stride,
+                                            self.floats, abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD), "zh_sum_slots")
+            self.ctx.sync()
+        dist.barrier(group=self.ctl)
+
+    def close(self):
+        if self.base:
+            if self.owner:
+                dist.barrier(group=self.ctl)                               # every mapping is closed before the block is freed
+                self.lib.zh_free(self.ctx.handle, C.c_void_p(self.base))
+            else:
+                self.lib.zh_ipc_close(self.ctx.handle, C.c_void_p(self.base))
+                dist.barrier(group=self.ctl)
+            self.base = 0
