@@ -78,6 +78,133 @@ def test_nice_131072_voices_sampled_and_mix_property(ctx, oracle):
     assert np.abs((a + b).cpu().numpy() - total).max() <= bound
 
 
+def test_config3_full_size_unfused_and_fused(ctx, oracle):
+    """BASELINE configs[2] at its stated size and parameters: 4,096 voices, Noise(white, seed = voice)
+    -> temp -> Filter(low_pass, cutoff = cutoffFromFrequency(200 + 7800 u, 48000), res = 0.9 u, both constant), recipe
+    examples/example_stereo.zig:71-82; two consecutive buffers with carried state; the unfused module pair and the
+    fused NoiseFilter kernel, every voice against the oracle, bit for bit."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V = 4096
+    _, _, u2, u3 = workloads.voice_params(3, 0, V)
+    cutoff_hz = (200.0 + 7800.0 * u2).astype(np.float32)
+    res = (0.9 * u3).astype(np.float32)
+    L = oracle.lib()
+    cutoff = np.array([L.zo_filter_cutoff_from_frequency(float(f), SR) for f in cutoff_hz], np.float32)
+    g_cut = mod.Filter.cutoffFromFrequency(util.dev(cutoff_hz), SR, ctx)
+    util.assert_bitexact(g_cut.cpu().numpy(), cutoff, "cutoffFromFrequency at 4096 voices")
+    g_res = util.dev(res)
+    # oracle: zero(temp); noise.paint(temp); zero(out); flt.paint(out) per voice and buffer
+    ref = np.zeros((2, V, F), np.float32)
+    temp = np.zeros(F, np.float32)
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), v)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
+        for b in range(2):
+            L.zo_zero(0, F, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nz), 0, F, oracle.fptr(temp), 0)
+            L.zo_filter_paint(C.byref(fl), 0, F, oracle.fptr(ref[b, v]), oracle.fptr(temp), 1, oracle.constant(cutoff[v]), oracle.constant(res[v]))
+    sp = zang.Span(0, F)
+    noise, flt = mod.Noise(V, ctx, first_seed=0), mod.Filter(V, ctx)
+    fused = mod.NoiseFilter(V, ctx, first_seed=0)
+    tmp = ctx.image(F, V)
+    for b in range(2):
+        out_u, out_f = ctx.image(F, V), ctx.image(F, V)
+        noise.paint(sp, [tmp], [], False, noise.Params(noise.white), zero_first=True)
+        flt.paint(sp, [out_u], [], False, flt.Params(tmp, flt.low_pass, zang.constant(g_cut), zang.constant(g_res)), zero_first=True)
+        fused.paint(sp, [out_f], None, False, fused.Params(0, mod.Filter.low_pass, g_cut, g_res), zero_first=True)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out_u), ref[b], f"config 3 unfused, buffer {b}")
+        util.assert_bitexact(util.from_image(out_f), ref[b], f"config 3 fused, buffer {b}")
+    assert np.abs(ref[1]).max() > 0.05                                    # it makes sound
+
+
+def test_config4_full_song_385s(ctx, oracle):
+    """BASELINE configs[3] at its stated size: a repo-authored song in the reference's tracker grammar with the
+    reference song's statistics (tools/gen_song.py: 2,900 rows, 385 s), 17 sub-voices (3 PMOsc + 10 + 4
+    NiceInstrument), 385 s x 48 kHz = 18,480,000 frames = 18,047 buffers with a partial last one
+    (examples/write_wav.zig:7,58-59): the GPU render's s16 payload equals the oracle render's, byte for byte."""
+    import contextlib
+    import hashlib
+    import io
+    import importlib.util
+    import os
+    from zang_amd import song
+    from tests.test_song import _oracle_song_render
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_song", os.path.join(root, "tools", "gen_song.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gen.main(2900, 20240915)
+    text = buf.getvalue()
+    seconds = 385.0
+    total = int(seconds * 48000)
+    nbuf, last = (total + F - 1) // F, total - (total - 1) // F * F
+    assert (nbuf, last) == (18047, 896)
+    r = song.SongRenderer(text, ctx)
+    got = r.render(seconds)
+    assert len(got) == total * 2
+    ref = _oracle_song_render(oracle, r.notes, song.EXAMPLE_SONG_INSTRUMENTS, nbuf, last_frames=last)
+    assert len(ref) == total * 2
+    if got != ref:
+        a = np.frombuffer(got, "<i2").astype(np.int32); b = np.frombuffer(ref, "<i2").astype(np.int32)
+        raise AssertionError(f"{(a != b).sum()} of {a.size} s16 samples differ (max {np.abs(a - b).max()} LSB), first at {np.argmax(a != b)}")
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(ref).hexdigest()
+    assert np.abs(np.frombuffer(got, "<i2").astype(np.int32)).max() > 1000
+
+
+def test_config5_shard_48_buffer_cycle(ctx, oracle):
+    """BASELINE configs[4], one GPU's shard at its stated size: 131,072 NiceInstrument voices over the whole 48-buffer
+    note cycle of the bench (note on for buffers 0-23, then off: attack -> decay -> sustain -> release), mono and
+    stereo mixdown kernels against the f64 sum of the per-voice image (sqrt(V) eps bound), 256 sampled voices
+    against the oracle bit for bit at four points of the cycle."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V = 131072
+    freq, color, u2, _ = workloads.voice_params(5, 0, V)
+    pan = (2.0 * u2 - 1.0).astype(np.float32)
+    gl = (np.float32(0.0) + ((np.float32(0.0) + pan * np.float32(0.5)) + np.float32(0.5))).astype(np.float32)
+    gr = (np.float32(0.0) + ((np.float32(0.0) + gl * np.float32(-1.0)) + np.float32(1.0))).astype(np.float32)
+    gf, gc, dgl, dgr = util.dev(freq), util.dev(color), util.dev(gl), util.dev(gr)
+    m, mm, ms = mod.NiceInstrument(V, gc, ctx), mod.NiceInstrument(V, gc, ctx), mod.NiceInstrument(V, gc, ctx)
+    out = ctx.image(F, V)
+    mono = torch.zeros(F, device="cuda"); left = torch.zeros(F, device="cuda"); right = torch.zeros(F, device="cuda")
+    idx = np.arange(0, V, V // 256)
+    gidx = torch.from_numpy(idx).cuda()
+    L = oracle.lib()
+    sts = []
+    for v in idx:
+        st = oracle.NiceInstrument(); L.zo_nice_init(C.byref(st), float(color[v])); sts.append(st)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    ref = np.zeros((len(idx), F), np.float32)
+    sp = zang.Span(0, F)
+    eps = np.finfo(np.float32).eps
+    peak = 0.0
+    for b in range(48):
+        on, nic = b < 24, b == 0
+        P = m.Params(SR, gf, on)
+        m.paint(sp, [out], None, nic, P, zero_first=True)
+        mm.paint_mix(sp, mono, nic, P, zero_first=True)
+        ms.paint_mix_stereo(sp, left, right, dgl, dgr, nic, P, zero_first=True)
+        ctx.sync()
+        for k, v in enumerate(idx):
+            ref[k] = 0
+            L.zo_nice_paint(C.byref(sts[k]), 0, F, oracle.fptr(ref[k]), oracle.fptr(t0), oracle.fptr(t1), int(nic), SR, float(freq[v]), int(on))
+        if b in (0, 23, 24, 47):
+            util.assert_bitexact(out[:, gidx].cpu().numpy().T, ref, f"config 5 sampled voices, buffer {b}")
+        o64 = out.double()
+        absmax = float(out.abs().double().sum(dim=1).max())
+        bound = 8 * np.sqrt(V) * eps * max(absmax, 1.0)
+        assert np.abs(mono.cpu().numpy() - o64.sum(dim=1).cpu().numpy()).max() <= bound, f"mono mix, buffer {b}"
+        for got, g in ((left, dgl), (right, dgr)):
+            prod = (out * g[None, :]).double()                                # f32 products (torch multiplies in f32), f64 sum
+            assert np.abs(got.cpu().numpy() - prod.sum(dim=1).cpu().numpy()).max() <= bound, f"stereo mix, buffer {b}"
+        peak = max(peak, float(mono.abs().max()))
+    assert peak > 1.0
+    assert np.array_equal(m.state(), mm.state()) and np.array_equal(m.state(), ms.state())
+
+
 def test_zero_voices_and_empty_spans(ctx):
     """Empty inputs: a module with 0 voices and 0-length spans are no-ops, not errors."""
     import torch

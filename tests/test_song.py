@@ -116,8 +116,9 @@ def test_config1_on_gpu_matches_golden(ctx):
     assert bytes(pcm.cpu().numpy()) == open(os.path.join(GOLD, "config1_sine440_s16.bin"), "rb").read()
 
 
-def _oracle_song_render(oracle, notes, instruments, nbuf):
-    """The reference's MainModule.paint + write_wav loop with the oracle's module paints."""
+def _oracle_song_render(oracle, notes, instruments, nbuf, last_frames=F):
+    """The reference's MainModule.paint + write_wav loop with the oracle's module paints; the last of the nbuf
+    buffers may be shorter (write_wav.zig:58-59)."""
     from zang_amd import song, zang
     L = oracle.lib()
     sched = song.SongScheduler(notes, instruments)
@@ -132,10 +133,11 @@ def _oracle_song_render(oracle, notes, instruments, nbuf):
             subs.append(m)
         mods.append(subs)
     t0, t1, t2 = (np.zeros(F, np.float32) for _ in range(3))
-    payload = b""
-    for _ in range(nbuf):
+    payload = []
+    for b in range(nbuf):
+        n = last_frames if b == nbuf - 1 else F
         out = np.zeros(F, np.float32)                                   # write_wav.zig:63-64
-        tables = sched.buffer(zang.Span(0, F))
+        tables = sched.buffer(zang.Span(0, n))
         for inst, subs, per_voice in zip(instruments, mods, tables):
             for m, spans in zip(subs, per_voice):
                 for (s, e, f, on, nic) in spans:                         # example_song.zig:336-347
@@ -143,10 +145,10 @@ def _oracle_song_render(oracle, notes, instruments, nbuf):
                         L.zo_pmosc_paint(C.byref(m), s, e, oracle.fptr(out), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(t2), int(nic), SR, f, int(on))
                     else:
                         L.zo_nice_paint(C.byref(m), s, e, oracle.fptr(out), oracle.fptr(t0), oracle.fptr(t1), int(nic), SR, f, int(on))
-        dst = np.zeros(2 * F, np.uint8)
-        L.zo_mixdown_s16lsb(dst.ctypes.data_as(C.POINTER(C.c_uint8)), oracle.fptr(out), F, 1, 0, 0.25)   # write_wav.zig:71-78
-        payload += dst.tobytes()
-    return payload
+        dst = np.zeros(2 * n, np.uint8)
+        L.zo_mixdown_s16lsb(dst.ctypes.data_as(C.POINTER(C.c_uint8)), oracle.fptr(out), n, 1, 0, 0.25)   # write_wav.zig:71-78
+        payload.append(dst.tobytes())
+    return b"".join(payload)
 
 
 @pytest.mark.gpu
