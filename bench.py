@@ -337,7 +337,8 @@ def cpu_baseline(args, wl):
         # the same instruction list run the way the generated Zig would run it: buffer-level ops through temps
         from oracle import zs_interp
         V = min(V, 64)
-        voices = zs_interp.make_voices(wl.program.script, SCRIPT_MODULE, V)
+        from oracle import zangscript as ozs              # the oracle-side front-end (test infrastructure), for the interpreter
+        voices = zs_interp.make_voices(ozs.compile(wl.program.text, wl.program.filename), SCRIPT_MODULE, V)
         out = np.zeros(F, np.float32)
         state = {"n": 0}
 

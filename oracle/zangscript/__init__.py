@@ -1,5 +1,8 @@
-"""zangscript: the reference's module DSL (src/zangscript/), with a second backend beside
-`generateZig`: one fused HIP kernel per exported module.
+"""TEST INFRASTRUCTURE (lives beside the oracle; the product never imports it).  A Python restatement of the
+reference's zangscript front-end (src/zangscript/{tokenize,parse,codegen,codegen_zig}.zig), kept as the independent
+second implementation the library's C++ front-end (zang_amd/csrc/zscript_front.hip, zscript_emit.hip) is held against
+(differential fuzz, tests/test_zangscript_native.py) and as the source of the instruction lists the oracle-side
+interpreter (oracle/zs_interp.py) executes.
 
     script = zangscript.compile(text)                  # tokenize -> parse -> codegen (compile.zig:40-64)
     zig_text = zangscript.generate_zig(script)         # the reference's backend, pinned by its golden test

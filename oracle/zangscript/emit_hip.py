@@ -13,7 +13,7 @@ To keep the reference's bits the emitted code repeats its operation order litera
   `+=`, sub/div/pow/min/max and the unary functions assign, float (op) buffer swaps its operands for
   add/mul (codegen_zig.zig:205-206); and the library is compiled with contraction off.
 
-Builtin modules come from csrc/voices.cuh (the same lane objects the standalone kernels use).  Script
+Builtin modules come from csrc/voices.hip.h (the same lane objects the standalone kernels use).  Script
 modules calling script modules are inlined.  `delay` keeps its ring in the per-voice state blob; a track
 call (`from ... begin`) keeps NoteTracker + Trigger per voice and walks their sub-spans.  What the backend
 cannot express (more than 16 params, a zero-sample delay) raises HipBackendError, reported per module."""
@@ -413,7 +413,7 @@ class HipEmitter:
         """`from <track>, <speed> begin ... end` (codegen_zig.zig:359-389): NoteTracker.consume turns the
         track's notes that fall into this paint call into impulses, Trigger cuts the span into one
         sub-span per note, and the body is painted once per sub-span with that note's params and
-        `_new_note`.  TrackLane (voices.cuh) builds the sub-span list in the prologue; the frame loop
+        `_new_note`.  TrackLane (voices.hip.h) builds the sub-span list in the prologue; the frame loop
         runs the body's per-paint prologue at a sub-span's first frame, its epilogue at the last, and
         paints nothing outside the sub-spans (before the first note)."""
         k = mc.k
@@ -542,7 +542,7 @@ class HipEmitter:
 
     def generate(self, only=None):
         out = ["// generated by zang_amd.zangscript (HIP backend) -- compile with zh_script_load / zh_script_compile",
-               '#include "script_rt.cuh"', ""]
+               '#include "script_rt.hip.h"', ""]
         for ci, curve in enumerate(self.s.curves):
             pts = ", ".join("{%s, %s}" % (f32_literal(v.value), f32_literal(t.value)) for t, v in curve.points)   # {value, t}
             out.append("__device__ const zh_curve_node zs_curve%d[] = {%s};" % (ci, pts or "{0.0f, 0.0f}"))

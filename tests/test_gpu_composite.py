@@ -272,7 +272,7 @@ def test_noise_filter_few_voices_short_spans(ctx, oracle, V, zero_first):
 
 @pytest.mark.gpu
 def test_nice_two_voices_per_lane_variant_is_bit_identical():
-    """ZH_NICE_W=2 (lanes.cuh: packed-f32 voice pairs, off by default because it measured slower) must give
+    """ZH_NICE_W=2 (lanes.hip.h: packed-f32 voice pairs, off by default because it measured slower) must give
     the same bits: rerun the NiceInstrument parity tests in a subprocess with the variant selected."""
     import os
     import subprocess

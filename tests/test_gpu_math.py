@@ -1,6 +1,6 @@
 """GPU parity: the device's std.math.sin / cos (zh_sin, zh_cos) against the oracle's musl restatement, bit for bit.
 
-The device folds musl's magnitude ladder into straight-line code (csrc/zmath.cuh); this sweeps every leaf of
+The device folds musl's magnitude ladder into straight-line code (csrc/zmath.hip.h); this sweeps every leaf of
 that ladder, both signs: the ladder's thresholds +- a few ulps, |x| < 2^-12, [-9pi/4, 9pi/4], the two-constant
 medium range, the 2^28*pi/2 boundary, huge arguments, denormals, zeros, infinities and NaNs."""
 import numpy as np

@@ -56,7 +56,7 @@ def test_sin_cos_huge_arguments_exact_reduction(oracle):
 
 
 def test_sin_reduction_rint_equals_musl_ladder():
-    """csrc/zmath.cuh replaces musl's magnitude ladder (k = how many of four thresholds |x| exceeds) by
+    """csrc/zmath.hip.h replaces musl's magnitude ladder (k = how many of four thresholds |x| exceeds) by
     rint(|x| * 2/pi) in float64.  Both are non-decreasing step functions of |x|, so they agree on all of
     [0, 9pi/4] iff they agree at every step point and at the ends (tools/check_sin_reduction.py sweeps all
     1.09e9 floats); a random sample rides along."""
@@ -93,10 +93,10 @@ def test_atan_pow_exp_log(oracle):
 
 
 def test_pio2_tables_rederived():
-    """The 2/pi and pi/2 chunk tables pasted into zmath_ref.h / zmath.cuh equal a fresh derivation."""
+    """The 2/pi and pi/2 chunk tables pasted into zmath_ref.h / zmath.hip.h equal a fresh derivation."""
     ipio2, pio2 = gen_pio2_tables.tables()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for path in ("oracle/zmath_ref.h", "zang_amd/csrc/zmath.cuh"):
+    for path in ("oracle/zmath_ref.h", "zang_amd/csrc/zmath.hip.h"):
         text = open(os.path.join(root, path)).read()
         for e in ipio2:
             assert ("0x%06X" % e) in text, (path, hex(e))

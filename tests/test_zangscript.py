@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from zang_amd import zangscript as zs
+from oracle import zangscript as zs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCRIPT = open(os.path.join(HERE, "golden", "script_modules.txt")).read()
@@ -32,8 +32,8 @@ def test_reference_golden_generated_text():
 
 
 def test_tokenizer():
-    from zang_amd.zangscript.errors import Source
-    from zang_amd.zangscript.tokenize import Tokenizer
+    from oracle.zangscript.errors import Source
+    from oracle.zangscript.tokenize import Tokenizer
     t = Tokenizer(Source("t", "a_1 = .cubed(0.5) // note\n  -3*pi begin end\r\nx"))
     kinds = []
     while True:
@@ -115,7 +115,7 @@ def test_generated_zig_of_test_script_is_stable():
     assert "pub const Lead = _module16;" in text
     assert "zang.multiplyScalar(span, temps[0], temps[1], 0.25);" in text
     assert ".type = params.ftype," in text                   # `type` is a primitive's name, not a Zig keyword token
-    from zang_amd.zangscript.emit_zig import ident
+    from oracle.zangscript.emit_zig import ident
     assert ident("error") == '@"error"' and ident("freq") == "freq"   # keyword escaping (codegen_zig.zig:40-46)
     assert "std.math.pow(f32, temps[" in text and "const temp_float" in text
 
@@ -265,7 +265,7 @@ end"""
 def test_hiprtc_errors_are_reported():
     from zang_amd import script
     with pytest.raises(script.ScriptCompileError) as e:
-        script.compile_hip('#include "script_rt.cuh"\nextern "C" __global__ void k() { undefined_fn(); }\n')
+        script.compile_hip('#include "script_rt.hip.h"\nextern "C" __global__ void k() { undefined_fn(); }\n')
     assert "undefined_fn" in str(e.value)
 
 
@@ -304,7 +304,7 @@ def _parity(ctx, name, paints, first_seed=0, add_into=None):
     from zang_amd import script, zang
     prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
     mod = prog.module(name, V, first_seed)
-    voices = zs_interp.make_voices(prog.script, name, V, first_seed)
+    voices = zs_interp.make_voices(zs.compile(prog.text, prog.filename), name, V, first_seed)
     base = np.zeros((V, F), np.float32) if add_into is None else add_into.copy()
     ref = base.copy()
     img = to_image(base)
@@ -496,24 +496,24 @@ def test_gpu_zero_first_and_state_roundtrip(ctx):
 
 
 def test_zangc_cli(tmp_path):
-    """python -m zang_amd.zangc: both backends, the dumps, error exit code (tools/zangc.zig:8-27)."""
+    """tools/zangc.py: both backends, the dumps, error exit code (tools/zangc.zig:8-27)."""
     import subprocess
     import sys
     root = os.path.dirname(HERE)
     src = os.path.join(HERE, "golden", "script_modules.txt")
     out, cg, bi = tmp_path / "o.hip", tmp_path / "cg.txt", tmp_path / "bi.txt"
-    r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", src, "-o", str(out), "--dump-codegen", str(cg), "--dump-builtins", str(bi)],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "zangc.py"), src, "-o", str(out), "--dump-codegen", str(cg), "--dump-builtins", str(bi)],
                        cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert 'extern "C" __global__ void __launch_bounds__(64) zs_paint_Lead' in out.read_text()
     assert "module Lead: 17 state words/voice" in r.stderr
     assert "module Pluck: num_temps=3" in cg.read_text() and "enum FilterType: bypass, low_pass" in bi.read_text()
     z = tmp_path / "o.zig"
-    assert subprocess.run([sys.executable, "-m", "zang_amd.zangc", src, "--backend", "zig", "-o", str(z)], cwd=root).returncode == 0
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "zangc.py"), src, "--backend", "zig", "-o", str(z)], cwd=root).returncode == 0
     assert z.read_text().startswith("// THIS FILE WAS GENERATED BY THE ZANGC COMPILER")
     bad = tmp_path / "bad.txt"
     bad.write_text("X = defmodule\nbegin\n out foo\nend\n")
-    r = subprocess.run([sys.executable, "-m", "zang_amd.zangc", str(bad), "--check"], cwd=root, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "zangc.py"), str(bad), "--check"], cwd=root, capture_output=True, text=True)
     assert r.returncode == 1 and ":3:6: use of undeclared identifier `foo`" in r.stderr
 
 
@@ -534,3 +534,39 @@ def test_gpu_loader_argument_checks(ctx):
     with pytest.raises(abi.ZangHipError):                     # span beyond the output image
         mod.paint(zang.Span(0, 32), [img], None, False, {"sample_rate": 48000.0, "x": img})
     prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_paintcurve_param_takes_library_values(ctx):
+    """A script module with a PaintCurve param painted with the library's own zang.PaintCurve.* values (ADVICE r1
+    script.py:154: the enum branch unpacked the value before testing for abi.Curve) and with the (label, payload)
+    form: both equal the built-in Envelope module given the same curve, bit for bit."""
+    import torch
+    from zang_amd import modules as mod, script as zscript, zang
+    text = """
+Shaped = defmodule
+    attack: PaintCurve,
+    note_on: boolean,
+begin
+    out Envelope(attack=attack, decay=.cubed(0.004), release=.linear(0.003), sustain_volume=0.6, note_on)
+end
+"""
+    prog = zscript.ScriptProgram(text, ctx)
+    n, frames = 192, 512
+    on = torch.from_numpy((np.random.default_rng(3).random(n) < 0.6).astype(np.uint8)).cuda()
+    sp = zang.Span(0, frames)
+    for curve, tup in ((zang.PaintCurve.cubed(0.002), ("cubed", 0.002)), (zang.PaintCurve.linear(0.001), (".linear", 0.001)),
+                       (zang.PaintCurve.instantaneous, "instantaneous")):
+        ref_m = mod.Envelope(n, ctx)
+        ref = ctx.image(frames, n, fill=0.0)
+        ref_m.paint(sp, [ref], [], True, ref_m.Params(48000.0, curve, zang.PaintCurve.cubed(0.004), zang.PaintCurve.linear(0.003), 0.6, on))
+        for value in (curve, tup):
+            m = prog.module("Shaped", n)
+            out = ctx.image(frames, n, fill=0.0)
+            m.paint(sp, [out], None, True, {"sample_rate": 48000.0, "attack": value, "note_on": on})
+            ctx.sync()
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (curve.tag, value)
+            m.close()
+    with pytest.raises(ValueError):                                   # a per-voice duration is not a script-module value
+        per_voice = zang.PaintCurve.cubed(torch.full((n,), 0.002, device="cuda"))
+        prog.module("Shaped", n).paint(sp, [ctx.image(frames, n, fill=0.0)], None, True, {"sample_rate": 48000.0, "attack": per_voice, "note_on": on})

@@ -5,8 +5,8 @@ import os
 
 import pytest
 
-from zang_amd import zangscript as zs
-from zang_amd.zangscript import native
+from oracle import zangscript as zs
+from zang_amd import zscript_native as native
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCRIPT = open(os.path.join(HERE, "golden", "script_modules.txt")).read()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Exhaustive check behind csrc/zmath.cuh's folded sinf/cosf reduction: for EVERY float with |x| <= 9pi/4
+"""Exhaustive check behind csrc/zmath.hip.h's folded sinf/cosf reduction: for EVERY float with |x| <= 9pi/4
 (1.09e9 bit patterns), rint(|x| * 2/pi) in float64 equals k, the number of musl's ladder thresholds
 (sinf.c: 0x3f490fda, 0x4016cbe3, 0x407b53d1, 0x40afeddf) that |x| exceeds.  Takes a minute or two; the test
 suite checks the step points only (tests/test_oracle_math.py), which covers the range by monotonicity."""

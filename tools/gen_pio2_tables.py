@@ -4,7 +4,7 @@ Payne-Hanek large-argument reduction (published musl/FreeBSD `__rem_pio2_large`
 algorithm) from first principles with big-integer arithmetic (Machin's formula).
 
 Usage: python tools/gen_pio2_tables.py > /tmp/tables.h
-The output is pasted into oracle/zmath_ref.h and zang_amd/csrc/zmath.cuh; a CPU
+The output is pasted into oracle/zmath_ref.h and zang_amd/csrc/zmath.hip.h; a CPU
 test (tests/test_oracle_math.py) re-derives the tables and compares.
 """
 

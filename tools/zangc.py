@@ -1,7 +1,10 @@
 """zangc: compile a zangscript file (the reference's tools/zangc.zig:1-27 compiles to Zig source that
 is built into the host program; this one also writes the fused HIP kernels for zh_script_load).
 
-    python -m zang_amd.zangc [options] -o <dest> <file>
+    python tools/zangc.py [options] -o <dest> <file>
+
+A developer tool, not part of the product package: the kernels come from the library's C++ front-end
+(zang_amd.zscript_native); the --dump-* listings come from the oracle-side Python front-end (oracle/zangscript).
 
       --backend hip|zig       what to write to <dest> (default: hip)
       --dump-codegen <file>   the instruction list of every script module
@@ -12,7 +15,10 @@ is built into the host program; this one also writes the fused HIP kernels for z
 import argparse
 import sys
 
-from . import zangscript as zs
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import zangscript as zs  # noqa: E402
 
 
 def dump_codegen(script):
@@ -81,7 +87,7 @@ def main(argv=None):
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--color", default="auto")
     a = ap.parse_args(argv)
-    from .zangscript import native
+    from zang_amd import zscript_native as native
     text = open(a.file).read()
     try:                                                        # the C++ compiler in libzang_hip.so
         compiled = native.NativeScript(text, a.file)

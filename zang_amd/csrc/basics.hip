@@ -1,7 +1,7 @@
 // basics.hip -- zang's buffer primitives (src/zang/basics.zig:12-78) over [frame][voice]
 // images, plus the voice mixdown.  Pure HBM streaming: 16 B per lane where the images
 // allow it (4 consecutive voices of one frame), scalar lanes otherwise.
-#include "common.cuh"
+#include "common.hip.h"
 
 enum EwOp { OP_ZERO, OP_SET, OP_COPY, OP_ADD, OP_ADD_INTO, OP_ADD_SCALAR, OP_ADD_SCALAR_INTO,
             OP_MUL, OP_MUL_WITH, OP_MUL_SCALAR, OP_MUL_WITH_SCALAR };

@@ -1,4 +1,4 @@
-// common.cuh -- shared host/device plumbing for libzang_hip.so (gfx950 only).
+// common.hip.h -- shared host/device plumbing for libzang_hip.so (gfx950 only).
 #pragma once
 // Under hiprtc (the zangscript kernels, script.hip) there are no libc / libstdc++ headers and no host
 // runtime API: ZH_DEVICE_ONLY drops the host plumbing and keeps the device-side views.
@@ -11,7 +11,7 @@
 #include <stddef.h>
 #include <new>
 #endif
-#include "rtc_types.cuh"
+#include "rtc_types.hip.h"
 #include "../../include/zang_hip.h"
 
 #if !defined(ZH_DEVICE_ONLY)
@@ -132,7 +132,7 @@ static inline CobP mk_cob(const zh_cob &c) {
 
 // Argument checks shared by every paint entry point.
 // Row strides are limited to 2^26 voices (256 MiB per row): the sequential kernels address a chunk of 8 rows with
-// 32-bit byte offsets from the chunk's first row (lanes.cuh zrow_*), so 8 * stride * 4 must stay below 2^32.
+// 32-bit byte offsets from the chunk's first row (lanes.hip.h zrow_*), so 8 * stride * 4 must stay below 2^32.
 // (An image of 1024 such rows would be 256 GiB.)
 constexpr uint32_t kMaxRowStride = 1u << 26;
 static inline bool buf_covers(const zh_buf &b, uint32_t n_voices, uint32_t span_end) {

@@ -6,12 +6,12 @@
 // the unfused composition -- provided every `zero` + `+=` pair is kept as `0.0f + x` and no
 // multiply-add is fused (-ffp-contract=off).  The two temps of a NiceInstrument voice never
 // touch HBM: per voice-sample the kernel writes 4 B (or nothing, in the mix variant).
-#include "common.cuh"
-#include "zmath.cuh"
-#include "dsp.cuh"
-#include "seq.cuh"
-#include "envelope.cuh"
-#include "voices.cuh"
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
+#include "seq.hip.h"
+#include "envelope.hip.h"
+#include "voices.hip.h"
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -41,7 +41,7 @@ struct zh_pmosc {
 };
 
 // ------------------------------------------------------------------ NiceInstrument voice
-// W voices per lane (lanes.cuh): W = 2 turns the f32 arithmetic of a voice pair into packed ops.
+// W voices per lane (lanes.hip.h): W = 2 turns the f32 arithmetic of a voice pair into packed ops.
 template <int W>
 struct NiceLaneT {
     using F = typename LaneT<W>::F;
@@ -113,7 +113,7 @@ struct NiceLaneT {
     // The oscillator half for a walker in which every active lane takes every frame in order from a begin()
     // executed by all of them together (k_nice, k_nice_pc -- not the span kernels, whose lanes begin sub-spans
     // at different frames): the previous frame's half-period bit is carried as the wave's lane
-    // mask (dsp.cuh pulse_sample_roll) instead of being recomputed.  roll_begin() after begin().
+    // mask (dsp.hip.h pulse_sample_roll) instead of being recomputed.  roll_begin() after begin().
     __device__ __forceinline__ void roll_begin(PulseRoll &roll) const {
         static_assert(W == 1, "lane masks: one voice per lane");
         roll = pulse_roll_init(k, cnt);
@@ -154,7 +154,7 @@ __device__ __forceinline__ void nice_store(NiceLaneT<W> &n, const NiceArgs &a, u
     zstore_f<W>(a.elast, v, n.env.last_value); zstore_f<W>(a.estart, v, n.env.start);
 }
 
-// Two voices per lane (W = 2, lanes.cuh) is built and parity-tested but NOT the default: measured on
+// Two voices per lane (W = 2, lanes.hip.h) is built and parity-tested but NOT the default: measured on
 // MI355X it is slower at every voice count (131,072 voices: 211 us vs 182 us; 1 Mi voices: 1296 us vs
 // 1222 us).  tools/ubench/valu_ops.hip shows why: a v_pk_*_f32 costs 4.2 issue cycles per SIMD against
 // 2.5 for a plain v_add/v_mul/v_sub_f32, so packing saves ~15 % on the arithmetic while every compare

@@ -1,5 +1,5 @@
 // ctx.hip -- context, memory, image upload/download, events (C ABI: include/zang_hip.h).
-#include "common.cuh"
+#include "common.hip.h"
 #include <string.h>
 #include <vector>
 #include <stdlib.h>

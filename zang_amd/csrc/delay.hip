@@ -6,9 +6,9 @@
 // data in chunks of <= delay_samples: read the ring (delay.zig:28-57), do the work, write the ring
 // (:62-89); a slot is always read before it is rewritten, so walking the span sample by sample
 // (read slot, compute, write slot, advance index modulo delay_samples) gives the same values.
-#include "common.cuh"
-#include "zmath.cuh"
-#include "dsp.cuh"
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
 #include <vector>
 
 struct DelayState {

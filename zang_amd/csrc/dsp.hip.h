@@ -1,8 +1,8 @@
-// dsp.cuh -- the per-sample building blocks shared by the module kernels and the fused voices, so
+// dsp.hip.h -- the per-sample building blocks shared by the module kernels and the fused voices, so
 // that each of the reference's formulas exists exactly once on the device.
 #pragma once
-#include "zmath.cuh"
-#include "lanes.cuh"
+#include "zmath.hip.h"
+#include "lanes.hip.h"
 
 // ---- PulseOsc (src/modules/PulseOsc.zig) -------------------------------------------------------
 template <int W>

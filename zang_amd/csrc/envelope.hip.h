@@ -1,4 +1,4 @@
-// envelope.cuh -- Envelope (src/modules/Envelope.zig) over Painter (src/zang/painter.zig) as
+// envelope.hip.h -- Envelope (src/modules/Envelope.zig) over Painter (src/zang/painter.zig) as
 // a per-lane state machine, shared by the Envelope kernel and the fused voices.
 //
 // The reference paints stage after stage (paintToward until finished or the buffer ends, then
@@ -13,8 +13,8 @@
 // reference evaluates it: at the start of a paint call and whenever a stage finishes (the
 // reference then immediately calls the next stage's paintToward, even with no frames left).
 #pragma once
-#include "common.cuh"
-#include "lanes.cuh"
+#include "common.hip.h"
+#include "lanes.hip.h"
 
 // One voice per wave: the running sum acc_{j+1} = acc_j + step over frames [j0, nf) of a 64-frame block,
 // computed once per wave (every lane holds the same acc) and handed out through 64 floats of LDS owned by
@@ -50,7 +50,7 @@ using CurveP = CurvePT<1>;
 
 enum { ENV_MODE_NONE = 0, ENV_MODE_TOWARD = 1, ENV_MODE_FLAT = 2 };
 
-// W voices per lane (lanes.cuh).  Everything is selects under masks: conditional stores to
+// W voices per lane (lanes.hip.h).  Everything is selects under masks: conditional stores to
 // different fields of the lane get sunk by LLVM into one store at a variable offset, which forces
 // the lane out of VGPRs -- and with W = 2 the two voices of a lane are rarely in the same stage.
 // FT >= 0: all three curves are known at compile time to have tag FT (the composite instruments use cubed

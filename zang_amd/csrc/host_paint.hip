@@ -1,7 +1,7 @@
 // host_paint.hip -- single-voice, host-pointer wrappers over the batched paint entry points
 // (include/zang_hip.h, "single-voice host-pointer wrappers").  Host code only: stage the voice's
 // []f32 slices into one-voice device images, run the batched paint with n = 1, copy back.
-#include "common.cuh"
+#include "common.hip.h"
 #include <vector>
 
 namespace {

@@ -1,4 +1,4 @@
-// lanes.cuh -- lane width for the sequential per-voice kernels: one voice per lane (W = 1) or two
+// lanes.hip.h -- lane width for the sequential per-voice kernels: one voice per lane (W = 1) or two
 // adjacent voices per lane (W = 2).
 //
 // Why W = 2 exists: with two voices of one lane held in adjacent VGPRs, every f32 add/sub/mul of the
@@ -10,10 +10,10 @@
 // measured 10-15 % SLOWER than two single-voice lanes (composite.hip).  Kept, parity-tested, because
 // the generic form costs nothing at W = 1 and documents the experiment.
 //
-// The per-sample code (dsp.cuh, envelope.cuh) is written once, over LaneT<W>::F/U/M, with the
+// The per-sample code (dsp.hip.h, envelope.hip.h) is written once, over LaneT<W>::F/U/M, with the
 // helpers below for the few things that differ between `bool` and a vector mask.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 typedef float zf2 __attribute__((ext_vector_type(2)));
 typedef uint32_t zu2 __attribute__((ext_vector_type(2)));
@@ -96,7 +96,7 @@ template <int W> ZL void zstore_u(uint32_t *p, uint32_t v, typename LaneT<W>::U 
 // current chunk (rebased with two scalar adds per chunk), the row inside the chunk is `soffset` (an
 // SGPR) and the lane's voice is one constant byte offset in a VGPR -- a load or store costs no vector
 // address arithmetic.  Offsets are 32-bit: a chunk of CH = 8 rows must span < 4 GiB, i.e. stride < 2^27 voices;
-// the entry points accept strides up to 2^26 (common.cuh kMaxRowStride, checked in buf_covers).
+// the entry points accept strides up to 2^26 (common.hip.h kMaxRowStride, checked in buf_covers).
 #if defined(__HIP_DEVICE_COMPILE__)
 ZL zh_rsrc_t zrow_rsrc(const float *base, size_t stride, uint32_t frame) { return make_rsrc(base + (size_t)frame * stride, 0xFFFFFFFFu); }
 template <int W> ZL typename LaneT<W>::F zrow_load(zh_rsrc_t r, uint32_t voff, uint32_t soff) {

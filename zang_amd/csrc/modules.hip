@@ -3,15 +3,15 @@
 //
 // Stateful modules (SineOsc, Noise, Envelope, Filter, Sampler, Decimator) carry an f32/u64
 // recurrence from sample to sample that must be replayed add by add to reproduce the
-// reference's bits, so they use the sequential frame loop of seq.cuh: state is
+// reference's bits, so they use the sequential frame loop of seq.hip.h: state is
 // loaded into VGPRs once per span, walked over the span, stored once.  Stateless modules
 // (Gate, Distortion) are additionally split into frame chunks across waves.
-#include "common.cuh"
-#include "zmath.cuh"
-#include "dsp.cuh"
-#include "seq.cuh"
-#include "envelope.cuh"
-#include "voices.cuh"
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
+#include "seq.hip.h"
+#include "envelope.hip.h"
+#include "voices.hip.h"
 #include <vector>
 
 template <typename T> static int upload_field(zh_ctx *ctx, T *dev, const std::vector<T> &h) {

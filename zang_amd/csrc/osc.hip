@@ -10,12 +10,12 @@
 // cnt_0 while the chunk-0 thread publishes cnt_0 + n*ifreq.
 //
 // Controlled-frequency paths carry state sample to sample and use the sequential
-// lane-per-voice loop (seq.cuh).
-#include "common.cuh"
-#include "zmath.cuh"
-#include "dsp.cuh"
-#include "seq.cuh"
-#include "voices.cuh"
+// lane-per-voice loop (seq.hip.h).
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
+#include "seq.hip.h"
+#include "voices.hip.h"
 #include <stdlib.h>
 #include <vector>
 
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restric
 }
 
 // ------------------------------------------------------------------ TriSawOsc
-// the formulas live in voices.cuh (trisaw_setup / trisaw_sample / trisaw_naive)
+// the formulas live in voices.hip.h (trisaw_setup / trisaw_sample / trisaw_naive)
 struct TriSawOscP {
     using K = TriSawK;
     static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) { trisaw_setup(k, srf, freq, color); }

@@ -1,4 +1,4 @@
-// rtc_types.cuh -- under hiprtc there is no <stdint.h>: the fixed-width types live in __hip_internal.
+// rtc_types.hip.h -- under hiprtc there is no <stdint.h>: the fixed-width types live in __hip_internal.
 #pragma once
 #if defined(__HIPCC_RTC__)
 typedef __hip_internal::int8_t int8_t;

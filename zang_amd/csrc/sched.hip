@@ -7,7 +7,7 @@
 // Defined where the reference is undefined: a 33rd impulse in one buffer is dropped (the Zig
 // arrays hold 32, notes.zig:73-74,142-143; ImpulseQueue.push already drops, :108-111);
 // NoteTracker events out of chronological order (assert :177) clamp to frame 0.
-#include "common.cuh"
+#include "common.hip.h"
 #include <string.h>
 #include <vector>
 #include <algorithm>

@@ -1,13 +1,13 @@
-// script_rt.cuh -- what a generated zangscript kernel (zang_amd/zangscript/emit_hip.py) is written
+// script_rt.hip.h -- what a generated zangscript kernel (zang_amd/zangscript/emit_hip.py) is written
 // against: the launch record shared with the loader (script.hip), accessors for the script module's
 // Params, the [word][voice] state blob, and the frame loop with an accumulating output.
 #pragma once
-#include "common.cuh"
-#include "zmath.cuh"
-#include "dsp.cuh"
-#include "seq.cuh"
-#include "envelope.cuh"
-#include "voices.cuh"
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
+#include "seq.hip.h"
+#include "envelope.hip.h"
+#include "voices.hip.h"
 
 struct ZsLaunch {
     uint32_t V, start, end, flags;
@@ -47,14 +47,14 @@ __device__ __forceinline__ void zs_st_u64(uint32_t *st, uint32_t word, uint32_t 
 __device__ __forceinline__ float zs_max(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b; }
 
-// frame_loop (seq.cuh) for a body that accumulates into the output sample itself: a script module's
+// frame_loop (seq.hip.h) for a body that accumulates into the output sample itself: a script module's
 // paint() may `+=` its output several times per frame.  f(frame, x[NIN], o&); `zf` = ZH_PAINT_ZERO_FIRST.
 template <int CH, int NIN, class F>
 __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t v, size_t ostride, const float *const *in,
                                               const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, F &&f) {
     constexpr int NI = NIN > 0 ? NIN : 1;
     const uint32_t nfull = (end - start) / CH;
-    const uint32_t voff = v * 4u;                                   // rows through buffer descriptors: lanes.cuh (zrow_*)
+    const uint32_t voff = v * 4u;                                   // rows through buffer descriptors: lanes.hip.h (zrow_*)
     const uint32_t orow = (uint32_t)ostride * 4u;
     float oc[CH], xc[NI][CH];
     uint32_t i = start;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
         const bool more = c + 1 < nfull;
         if (more) load(i + CH, on, xn);
         const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
-        // compute the chunk, then store it (seq.cuh frame_loop: a store after every frame would pin every load of the
+        // compute the chunk, then store it (seq.hip.h frame_loop: a store after every frame would pin every load of the
         // body -- delay rings, track tables -- behind the previous frame's store)
 #pragma unroll
         for (int k = 0; k < CH; k++) {

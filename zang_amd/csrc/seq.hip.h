@@ -1,4 +1,4 @@
-// seq.cuh -- the lane-per-voice sequential frame loop shared by the stateful paint kernels.
+// seq.hip.h -- the lane-per-voice sequential frame loop shared by the stateful paint kernels.
 //
 // One lane owns one voice and walks the span frame by frame (the reference's scalar loop
 // with its loop-carried state, e.g. Filter.zig:124-147), state in VGPRs.  Images are
@@ -7,8 +7,8 @@
 // output and up to NIN input images) are issued before chunk k is computed, so HBM latency
 // hides behind the dependent ALU chain instead of adding to it.
 #pragma once
-#include "common.cuh"
-#include "lanes.cuh"
+#include "common.hip.h"
+#include "lanes.hip.h"
 
 // f(frame, x[NIN], value&) -> painted.  Called for consecutive frames in order; it may
 // carry state by reference capture.  painted == false leaves out[frame] untouched (ADD) or
@@ -16,7 +16,7 @@
 // `out` / `in` are the images' (wave-uniform) base pointers and `v` the lane's voice: every access is
 // row[v] with a uniform row pointer, so the row address lives in SGPRs (scalar adds per frame) and the
 // lane offset is one constant VGPR -- no per-frame 64-bit vector address arithmetic.
-// W = voices per lane (lanes.cuh): with W = 2, `v` is the lane's first voice (even, 8-byte aligned),
+// W = voices per lane (lanes.hip.h): with W = 2, `v` is the lane's first voice (even, 8-byte aligned),
 // values are zf2 and `painted` is a per-voice mask.
 template <int CH, bool ZF, int NIN, int W = 1, class F>
 __device__ __forceinline__ void frame_loop(float *__restrict__ out, uint32_t v, size_t ostride,
@@ -27,7 +27,7 @@ __device__ __forceinline__ void frame_loop(float *__restrict__ out, uint32_t v, 
     const uint32_t n = end - start;
     const uint32_t nfull = n / CH;
     const uint32_t voff = v * 4u;                                   // the lane's byte offset inside a row
-    const uint32_t orow = (uint32_t)ostride * 4u;                   // bytes per row (lanes.cuh: < 4 GiB / CH)
+    const uint32_t orow = (uint32_t)ostride * 4u;                   // bytes per row (lanes.hip.h: < 4 GiB / CH)
     uint32_t irow[NI];
 #pragma unroll
     for (int j = 0; j < NIN; j++) irow[j] = (uint32_t)istride[j] * 4u;

@@ -1,14 +1,14 @@
-// voices.cuh -- every builtin module as a per-lane object: state + begin() (the per-paint prologue)
+// voices.hip.h -- every builtin module as a per-lane object: state + begin() (the per-paint prologue)
 // + frame() (one sample) + end() (the per-paint epilogue).  The standalone module kernels
 // (modules.hip, osc.hip) and the fused kernels the zangscript backend generates (zangscript/emit_hip.py,
 // compiled by script.hip through hiprtc) are both built from these, so each of the reference's
 // formulas exists once on the device.  frame() returns the painted value; where a module can paint
 // nothing (silent oscillator, Gate off, Envelope idle ...) it returns `bool painted` and writes `val`.
 #pragma once
-#include "common.cuh"
-#include "zmath.cuh"
-#include "dsp.cuh"
-#include "envelope.cuh"
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
+#include "envelope.hip.h"
 
 // ---- SineOsc (src/modules/SineOsc.zig) -----------------------------------------------------------
 __device__ __forceinline__ float sine_osc_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }   // :4-6

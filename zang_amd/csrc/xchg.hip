@@ -5,7 +5,7 @@
 // mixdown kernels store their partials STRAIGHT into their slot (4 KiB per buffer over xGMI, no staging copy, no
 // collective), and the root adds the slots in rank order: a fixed order, so the mix is reproducible bit for bit.
 // Cross-process ordering is the host's job (each rank synchronises its stream, then signals; sharding.py).
-#include "common.cuh"
+#include "common.hip.h"
 #include <string.h>
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "zh_ipc_* pass a 64-byte handle");

@@ -1,4 +1,4 @@
-// zmath.cuh -- device scalar math for the paint kernels (gfx950).
+// zmath.hip.h -- device scalar math for the paint kernels (gfx950).
 //
 // The reference takes sin/cos/atan/pow/floor/round and its PRNG from the Zig standard
 // library (call sites: SineOsc.zig:5, Filter.zig:21-22, Distortion.zig:41-50,
@@ -19,7 +19,7 @@
 #if !defined(__HIPCC_RTC__)
 #include <stdint.h>
 #endif
-#include "rtc_types.cuh"
+#include "rtc_types.hip.h"
 
 #define ZD __device__ __forceinline__
 

@@ -875,7 +875,7 @@ public:
 
     std::string generate(const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override) {
         Lines out = {"// generated by zang_amd.zangscript (HIP backend) -- compile with zh_script_load / zh_script_compile",
-                     "#include \"script_rt.cuh\"", ""};
+                     "#include \"script_rt.hip.h\"", ""};
         for (size_t ci = 0; ci < s.pr.curves.size(); ci++) {
             std::string pts;
             for (size_t i = 0; i < s.pr.curves[ci].points.size(); i++) {

@@ -1,4 +1,4 @@
-"""zangscript modules on the GPU: compile a script (zang_amd.zangscript), load its fused kernels
+"""zangscript modules on the GPU: compile a script (the C++ front-end in libzang_hip.so), load its fused kernels
 (zh_script_load -> hiprtc) and paint them through the module call shape of the reference
 (SineOsc.zig:22-31; generated modules: codegen_zig.zig:558-563)."""
 import ctypes as C
@@ -6,12 +6,16 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import abi, zangscript
+from . import abi, zscript_native as native
 from .runtime import as_bool, as_buf, default_context
 
 
 class ScriptCompileError(Exception):
     pass
+
+
+class HipBackendError(Exception):
+    """The script compiled, but this module uses something the HIP backend does not generate (the message says what)."""
 
 
 def compile_hip(hip_source):
@@ -30,11 +34,9 @@ class ScriptProgram:
     """One script: front-end result + the loaded hipModule."""
 
     def __init__(self, text, ctx=None, filename="script.txt", only=None):
-        from .zangscript import native
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.text, self.filename = text, filename
-        self._script = None
         try:                                                    # the C++ compiler in libzang_hip.so (zh_zscript_*)
             compiled = native.NativeScript(text, filename)
         except native.NativeScriptError as e:
@@ -50,20 +52,11 @@ class ScriptProgram:
         self._modules = []
         self.ctx._children.add(self)
 
-    @property
-    def script(self):
-        """The Python front-end's view of the same script (instruction lists) -- what the oracle-side interpreter
-        and the tests read; the kernels above came from the C++ compiler."""
-        if self._script is None:
-            self._script = zangscript.compile(self.text, self.filename)
-        return self._script
-
     def module(self, name, n_voices, first_seed=0):
         m = self.meta.get(name)
         if m is None:
             raise KeyError("script exports no module named %r" % name)
         if "error" in m:
-            from .zangscript.emit_hip import HipBackendError
             raise HipBackendError("%s: %s" % (name, m["error"]))
         return ScriptModule(self, name, n_voices, first_seed)
 
@@ -81,8 +74,7 @@ class ScriptProgram:
             pass
 
 
-_ENUM_LABELS = {e.name: [v.label for v in e.values]
-                for pkg in zangscript.DEFAULT_PACKAGES for e in pkg.enums}
+_ENUM_LABELS = native.ENUM_LABELS
 
 
 class ScriptModule:
@@ -151,10 +143,14 @@ class ScriptModule:
                 p.pf, p.u = tns.data_ptr(), len(value); keep.append(tns)
         else:                                                   # one_of
             p.kind = abi.SP_ENUM
-            label, payload = (value, None) if isinstance(value, str) else value
-            if isinstance(value, abi.Curve):                    # zang.PaintCurve.*
+            if isinstance(value, abi.Curve):                    # the library's own zang.PaintCurve.* values
+                if enum != "PaintCurve":
+                    raise TypeError("a PaintCurve value for a %s param" % enum)
+                if value.duration.per_voice:
+                    raise ValueError("a script module takes one PaintCurve duration for all voices, not a per-voice array")
                 p.u, p.f = value.tag, value.duration.value
-            else:
+            else:                                               # ".label" or (".label", payload)
+                label, payload = (value, None) if isinstance(value, str) else value
                 p.u = _ENUM_LABELS[enum].index(label.lstrip("."))
                 p.f = float(payload) if payload is not None else 0.0
         return p

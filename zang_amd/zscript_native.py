@@ -1,11 +1,23 @@
-"""The C++ zangscript compiler inside libzang_hip.so (csrc/zscript_front.hip, zscript_emit.hip) through its C ABI
-(zh_zscript_*).  Same results as the Python front-end in this package; the product path (zang_amd.script,
-zang_amd.zangc) uses this one, the Python one is the independent second implementation the tests hold it against."""
+"""The zangscript compiler inside libzang_hip.so (csrc/zscript_front.hip, zscript_emit.hip) through its C ABI
+(zh_zscript_*): the one front-end of the product (zang_amd.script).  (oracle/zangscript/ holds an independent Python
+restatement of the reference's front-end; it is test infrastructure and is never imported from here.)"""
 import ctypes as C
 
-from .. import abi
-from .builtins import DEFAULT_PACKAGES, modules_builtin_package, zang_builtin_package
-from .errors import ScriptError
+from . import abi
+
+# the reference's two builtin packages (src/zangscript/builtins.zig:145-185), as the bits zh_zscript_compile takes
+PACKAGE_ZANG, PACKAGE_MODULES = 1, 2
+DEFAULT_PACKAGES = PACKAGE_ZANG | PACKAGE_MODULES
+
+# enum labels in declaration order = the values include/zang_hip.h gives them (builtins.zig:147-159; painter.zig:25-30,
+# Curve.zig:6-9, Distortion.zig:8-11, Filter.zig:10-17, Noise.zig:11-14)
+ENUM_LABELS = {
+    "PaintCurve": ["instantaneous", "linear", "squared", "cubed"],
+    "InterpolationFunction": ["linear", "smoothstep"],
+    "DistortionType": ["overdrive", "clip"],
+    "FilterType": ["bypass", "low_pass", "band_pass", "high_pass", "notch", "all_pass"],
+    "NoiseColor": ["white", "pink"],
+}
 
 
 class NativeScriptError(Exception):
@@ -13,12 +25,15 @@ class NativeScriptError(Exception):
 
 
 def _package_bits(packages):
+    if isinstance(packages, int):
+        return packages
     bits = 0
-    for p in packages:
-        if p is zang_builtin_package:
-            bits |= 1
-        elif p is modules_builtin_package:
-            bits |= 2
+    for p in packages:                                   # objects with the reference's package names ("zang", "mod")
+        name = getattr(p, "zig_package_name", p)
+        if name == "zang":
+            bits |= PACKAGE_ZANG
+        elif name == "mod":
+            bits |= PACKAGE_MODULES
         else:
             raise ValueError("the native compiler knows the two builtin packages only")
     return bits
