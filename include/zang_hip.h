@@ -230,6 +230,12 @@ ZH_API int zh_noise_paint(zh_noise *m, uint32_t span_start, uint32_t span_end, c
                           const zh_buf *temps, zh_bool note_id_changed,
                           const zh_noise_params *params, uint32_t flags);                             /* :34-72 */
 
+/* Host-only self-test of the xoshiro256++ jump tables behind the frame-range form of white noise (few voices: a span is
+ * painted as many frame ranges at once, each from a state jumped T^(32 j) ahead; csrc/noise_jump.hip): for n_states
+ * random states, table j applied to the state must equal 32 (j + 1) sequential transitions, j = 0..62.  Returns the
+ * number of mismatching state words (0 = pass).  Needs no device. */
+ZH_API int zh_selftest_noise_jump(uint64_t seed, uint32_t n_states);
+
 /* ---------------------------------------------------------------- Envelope (src/modules/Envelope.zig, src/zang/painter.zig) */
 typedef struct zh_envelope zh_envelope;
 enum { ZH_ENV_IDLE = 0, ZH_ENV_ATTACK, ZH_ENV_DECAY, ZH_ENV_SUSTAIN, ZH_ENV_RELEASE };                /* :15-21 */
@@ -540,6 +546,9 @@ ZH_API int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unro
 ZH_API uint32_t zh_zscript_module_count(zh_zscript *z);
 ZH_API int zh_zscript_module_info(zh_zscript *z, uint32_t i, char *name, size_t name_cap, uint32_t *state_words, uint32_t *noise_fields,
                                   uint32_t *n_params, char *error /* non-empty: the HIP backend cannot express this module */, size_t error_cap);
+/* `pub const num_temps` of the generated Zig struct (codegen_zig.zig:518): what a reference host would allocate for this
+ * module; the fused kernel itself needs none. */
+ZH_API int zh_zscript_module_num_temps(zh_zscript *z, uint32_t i, uint32_t *num_temps);
 ZH_API int zh_zscript_module_param(zh_zscript *z, uint32_t i, uint32_t p, char *name, size_t name_cap, char *kind, size_t kind_cap,
                                    char *enum_name, size_t enum_cap);
 

@@ -163,6 +163,66 @@ def test_noise_rare_float_paths(ctx, oracle, fused):
         assert (np.abs(first[:5]) > 0.99).all()            # tiny random floats map to white ~ -1
 
 
+def _xoshiro_step_back(st, k):
+    """The state k transitions BEFORE `st` (xoshiro256++'s transition is invertible: a = rotr(n3, 45) = s3 ^ s1,
+    s0 = n0 ^ a, n1 ^ n2 = s1 ^ (s1 << 17), ...)."""
+    M = (1 << 64) - 1
+    n0, n1, n2, n3 = st
+    for _ in range(k):
+        a = ((n3 >> 45) | (n3 << 19)) & M
+        s0 = n0 ^ a
+        x = n1 ^ n2
+        s1 = (x ^ (x << 17) ^ (x << 34) ^ (x << 51)) & M
+        s3 = a ^ s1
+        s2 = n1 ^ s1 ^ s0
+        n0, n1, n2, n3 = s0, s1, s2, s3
+    return [n0, n1, n2, n3]
+
+
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("V", [300, 4096])
+def test_noise_white_frame_ranges(ctx, oracle, zero_first, V):
+    """Few voices: white noise is painted as many frame ranges at once, each from a state jumped ahead with the
+    T^(32 j) tables (csrc/noise_jump.hip).  Bit for bit the oracle's sequential walk, states included -- also for voices
+    whose span holds one of Random.float's multi-draw samples (2^-41 per sample; crafted here by stepping a state with
+    s0 = 0, s3 = 2^41 BACK k transitions, so that the sample lands on frame k of the first span: in the first range, at
+    a range boundary, in a middle range, on the last frame), which the ranges flag and k_noise_fix repaints."""
+    from zang_amd import modules as mod, zang
+    first = 4242
+    rng = np.random.default_rng(77)
+    L = oracle.lib()
+    ks = [0, 31, 32, 500, 777, 1023]
+    nzs = []
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + v)
+        nzs.append(nz)
+    crafted = {10 + 37 * i: k for i, k in enumerate(ks)}
+    for v, k in crafted.items():
+        target = [0, int(rng.integers(1, 1 << 63)), int(rng.integers(1, 1 << 63)), 1 << 41]     # next(): rnd = 1 -> 63 leading zeros
+        back = _xoshiro_step_back(target, k)
+        for i in range(4):
+            nzs[v].r[i] = back[i]
+    m = mod.Noise(V, ctx, first_seed=first)
+    st = m.state()
+    for v in crafted:
+        st["r"][v] = [int(x) for x in nzs[v].r]
+    m.set_state(st)
+    out0 = util.rng_buffers(12, V, F)
+    spans = [(0, 1024), (0, 1024), (100, 612), (612, 1000)]          # full buffers, then two shorter spans (carried state)
+    for (s, e) in spans:
+        ref = out0.copy()
+        if zero_first:
+            ref[:, s:e] = 0.0
+        for v in range(V):
+            L.zo_noise_paint(C.byref(nzs[v]), s, e, oracle.fptr(ref[v]), 0)
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(m.white), zero_first=zero_first)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"white noise ranges, span {(s, e)}")
+        gs = m.state()
+        assert [[int(x) for x in row] for row in gs["r"]] == [list(n.r) for n in nzs], f"states after span {(s, e)}"
+
+
 def test_noise_seed_known_answer(ctx):
     """K1 of SURVEY.md 8c: seed 0 / seed 1 white samples."""
     from zang_amd import modules as mod, zang

@@ -318,6 +318,7 @@ SIGNATURES = {
     "zh_noise_destroy": (C.c_int, [vp]),
     "zh_noise_get_state": (C.c_int, [vp, vp]),
     "zh_noise_set_state": (C.c_int, [vp, vp]),
+    "zh_selftest_noise_jump": (C.c_int, [u64, u32]),
     "zh_noise_paint": (C.c_int, _paint(NoiseParams)),
     "zh_envelope_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_envelope_destroy": (C.c_int, [vp]),
@@ -373,6 +374,7 @@ SIGNATURES = {
     "zh_zscript_module_count": (u32, [vp]),
     "zh_zscript_module_info": (C.c_int, [vp, u32, C.c_char_p, C.c_size_t, P(u32), P(u32), P(u32), C.c_char_p, C.c_size_t]),
     "zh_zscript_module_param": (C.c_int, [vp, u32, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "zh_zscript_module_num_temps": (C.c_int, [vp, u32, P(u32)]),
     "zh_script_compile": (C.c_int, [C.c_char_p, P(vp), P(C.c_size_t), C.c_char_p, C.c_size_t]),
     "zh_script_free_code": (None, [vp]),
     "zh_script_load": (C.c_int, [vp, C.c_char_p, P(vp), C.c_char_p, C.c_size_t]),

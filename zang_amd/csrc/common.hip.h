@@ -44,6 +44,7 @@ struct zh_ctx {
     std::vector<float *> mix_retired;
     bool capturing;
     std::vector<zh_flip_use> capture_log;
+    void *noise_jump;            // xoshiro256++ jump tables (noise_jump.hip), built on first use, freed with the context
 };
 
 struct zh_graph {

@@ -66,6 +66,7 @@ int zh_create(zh_ctx **out, int device) {
     c->mix_partials = nullptr;
     c->mix_partials_floats = 0;
     c->capturing = false;
+    c->noise_jump = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
     *out = c;
@@ -77,6 +78,7 @@ int zh_destroy(zh_ctx *ctx) { ZH_GUARD(ctx);
     hipStreamSynchronize(ctx->stream);
     if (ctx->mix_partials) hipFree(ctx->mix_partials);
     for (float *p : ctx->mix_retired) hipFree(p);
+    if (ctx->noise_jump) hipFree(ctx->noise_jump);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZH_OK;

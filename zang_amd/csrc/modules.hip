@@ -7,6 +7,7 @@
 // loaded into VGPRs once per span, walked over the span, stored once.  Stateless modules
 // (Gate, Distortion) are additionally split into frame chunks across waves.
 #include "common.hip.h"
+#include <string.h>
 #include "zmath.hip.h"
 #include "dsp.hip.h"
 #include "seq.hip.h"
@@ -49,7 +50,17 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
 }
 
 // =================================================================== Noise
-struct zh_noise { zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *b; /* [7][n] */ };
+struct zh_noise {
+    zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *b; /* [7][n] */
+    // the frame-range form of white noise (noise_jump.hip): states after the span, multi-draw flags, and the image an
+    // ADD paint is rendered into before it is added to the output
+    uint64_t *nx[4]; uint32_t *flag; zh_buf scratch;
+};
+// noise_jump.hip
+uint32_t zh_noise_range_frames(uint32_t V, uint32_t n);
+int zh_noise_paint_ranges(zh_ctx *ctx, uint64_t *const s[4], uint64_t *const next[4], uint32_t *flag, uint32_t V, const zh_buf &outb,
+                          uint32_t start, uint32_t end, uint32_t ch);
+const uint4 *zh_noise_jump_tables(zh_ctx *ctx);
 
 __global__ void k_noise_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, float *b, uint32_t n, uint64_t first_seed) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,23 +456,35 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
 }
 
 // ------------------------------------------------------------------ Noise
+static void noise_free(zh_noise *m) {
+    for (auto &x : m->s) (void)hipFree(x);
+    for (auto &x : m->nx) (void)hipFree(x);
+    (void)hipFree(m->b); (void)hipFree(m->flag); (void)hipFree(m->scratch.ptr);
+}
 int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_noise *m = new (std::nothrow) zh_noise{ctx, n, {nullptr, nullptr, nullptr, nullptr}, nullptr};
+    zh_noise *m = new (std::nothrow) zh_noise();
     if (!m) return ZH_ERR_INVALID;
+    m->ctx = ctx; m->n = n; m->b = nullptr; m->flag = nullptr;
+    for (int i = 0; i < 4; i++) m->s[i] = m->nx[i] = nullptr;
+    memset(&m->scratch, 0, sizeof m->scratch);
     int rc = 0;
     for (int i = 0; i < 4 && !rc; i++) rc = dev_alloc(&m->s[i], n);
+    for (int i = 0; i < 4 && !rc; i++) rc = dev_alloc(&m->nx[i], n);
     if (!rc) rc = dev_alloc(&m->b, (size_t)7 * n);
-    if (rc) { for (auto &x : m->s) (void)hipFree(x); (void)hipFree(m->b); delete m; return rc; }
+    if (!rc) rc = dev_alloc(&m->flag, n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->flag, 0, (size_t)n * 4, ctx->stream);
+    if (rc) { noise_free(m); delete m; return rc; }
     if (n) hipLaunchKernelGGL(k_noise_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], m->b, n, first_seed);
+    // the jump tables are per context and built on first use; doing that here keeps it out of paint (and out of any capture)
+    if (n && zh_noise_range_frames(n, 1024)) (void)zh_noise_jump_tables(ctx);
     *out = m;
     return zh_launch_status();
 }
 int zh_noise_destroy(zh_noise *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (auto &x : m->s) (void)hipFree(x);
-    (void)hipFree(m->b);
+    noise_free(m);
     delete m;
     return ZH_OK;
 }
@@ -500,6 +523,31 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (m->n == 0 || end == start) return ZH_OK;
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
+    // Few voices, white noise: many frame ranges of the span at once (noise_jump.hip).  A zero + paint call writes the
+    // output directly; the reference's `+=` onto existing content renders into a module-owned image first and adds it
+    // (the repair of a multi-draw voice needs the noise on its own).
+    if (p->color == ZH_NOISE_WHITE) {
+        const uint32_t ch = zh_noise_range_frames(m->n, end - start);
+        if (ch) {
+            if (zf) {
+                rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, outputs[0], start, end, ch);
+                if (rc != ZH_ERR_UNSUPPORTED) return rc;
+            } else {
+                if ((m->scratch.frames < end || !m->scratch.ptr) && !m->ctx->capturing) {
+                    zh_buf nb;
+                    if (zh_buf_alloc(m->ctx, &nb, m->n, end) == ZH_OK) {
+                        if (m->scratch.ptr) m->ctx->mix_retired.push_back(m->scratch.ptr);   // a captured graph may still name it: freed with the context
+                        m->scratch = nb;
+                    }
+                }
+                if (m->scratch.ptr && m->scratch.frames >= end) {
+                    rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, m->scratch, start, end, ch);
+                    if (rc == ZH_OK) return zh_add_into(m->ctx, start, end, outputs[0], m->scratch);
+                    if (rc != ZH_ERR_UNSUPPORTED) return rc;
+                }
+            }
+        }
+    }
     Img out = mk_img(outputs[0]);
 #define ZH_NOISE(ZF_, PINK_) hipLaunchKernelGGL((k_noise<ZF_, PINK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->b, m->n, out, start, end)
     if (p->color == ZH_NOISE_PINK) { if (zf) ZH_NOISE(true, true); else ZH_NOISE(false, true); }

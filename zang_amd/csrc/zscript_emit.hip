@@ -893,6 +893,7 @@ public:
             k.name = name;
             HipModuleMeta m;
             m.name = name;
+            m.num_temps = s.module_results[em.second].num_temps;       // what the generated Zig struct declares (codegen_zig.zig:518)
             try {
                 kernel(k, em.second);
             } catch (const HipBackendError &e) {
@@ -1044,6 +1045,11 @@ int zh_zscript_module_info(zh_zscript *z, uint32_t i, char *name, size_t name_ca
     if (state_words) *state_words = (uint32_t)m.state_words;
     if (noise_fields) *noise_fields = (uint32_t)m.noise_fields;
     if (n_params) *n_params = (uint32_t)m.params.size();
+    return ZH_OK;
+}
+int zh_zscript_module_num_temps(zh_zscript *z, uint32_t i, uint32_t *num_temps) {
+    if (!z || i >= z->meta.size() || !num_temps) return ZH_ERR_INVALID;
+    *num_temps = (uint32_t)z->meta[i].num_temps;
     return ZH_OK;
 }
 int zh_zscript_module_param(zh_zscript *z, uint32_t i, uint32_t p, char *name, size_t name_cap, char *kind, size_t kind_cap, char *enum_name, size_t enum_cap) {

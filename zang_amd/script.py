@@ -96,8 +96,7 @@ class ScriptModule:
     @property
     def num_temps(self):
         """What the generated Zig struct would ask for (codegen_zig.zig:518); the fused kernel needs none."""
-        sc = self.program.script
-        return sc.module_results[sc.module_index(self.name)].num_temps
+        return self.meta["num_temps"]
 
     def _param(self, kind, enum, value, keep):
         p = abi.ScriptParam()

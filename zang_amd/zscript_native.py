@@ -78,7 +78,9 @@ class NativeScript:
             for p in range(npar.value):
                 abi.check(self.lib.zh_zscript_module_param(self.handle, i, p, pname, len(pname), kind, len(kind), en, len(en)), "zh_zscript_module_param")
                 params.append((pname.value.decode(), kind.value.decode(), en.value.decode() or None))
-            meta[name.value.decode()] = {"state_words": words.value, "params": params, "noise_fields": noise.value}
+            nt = C.c_uint32()
+            abi.check(self.lib.zh_zscript_module_num_temps(self.handle, i, C.byref(nt)), "zh_zscript_module_num_temps")
+            meta[name.value.decode()] = {"state_words": words.value, "params": params, "noise_fields": noise.value, "num_temps": nt.value}
         return text, meta
 
     def close(self):
