@@ -557,7 +557,8 @@ class HipEmitter:
                 meta[name] = {"error": str(e)}
                 out += ["", "// %s: %s" % (name, e)]
                 continue
-            meta[name] = {"state_words": k.words, "params": k.params, "noise_fields": k.noise_fields}
+            meta[name] = {"state_words": k.words, "params": k.params, "noise_fields": k.noise_fields,
+                          "num_temps": self.s.module_results[mi].num_temps}
             used_tracks |= k.tracks
             nin = len(k.rows)
             ni = max(nin, 1)
