@@ -166,7 +166,7 @@ class Workload:
             self.res = torch.from_numpy((0.9 * u3)).to(dev)
             self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
-            self.kernel = "k_noise_filter_pc" if V <= 65536 else "k_noise_filter"     # the library's choice by voice count
+            self.kernel = "k_noise_filter_ring" if V <= 16384 else ("k_noise_filter_pc" if V <= 65536 else "k_noise_filter")     # the library's choice by voice count
             self.step = self._step_noise_filter_fused
         elif name == "script":
             # a zangscript module compiled to ONE fused kernel at start-up (hiprtc): `Lead` of the repo's test

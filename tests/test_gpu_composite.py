@@ -234,6 +234,56 @@ def test_noise_filter_fused_equals_unfused(ctx, oracle, color, ftype):
     assert [[int(x) for x in row] for row in st["noise"]["r"]] == rs
 
 
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("V,ftype", [(300, 1), (4096, 4)])
+def test_noise_filter_three_wave_form_with_multi_draw_voices(ctx, oracle, zero_first, V, ftype):
+    """White noise -> Filter at small voice counts runs as two noise producer waves (alternate 32-frame tiles, T^32 jump
+    between them) and one filter wave (k_noise_filter_pc2).  Every voice equals the oracle's zero / Noise.paint / Filter.paint
+    sequence bit for bit over full buffers and shorter spans with carried state -- including voices crafted so that one of
+    Random.float's multi-draw samples (2^-41 per sample) lands on a chosen frame of the first span (first tile, tile
+    edges, a middle tile, the last frame): the consumer stops such a voice after the tile and k_noise_filter_fix
+    continues it sequentially from the recorded generator / filter state."""
+    from zang_amd import modules as mod, zang
+    from tests.test_gpu_modules import _xoshiro_step_back
+    first = 7000
+    rng = np.random.default_rng(91)
+    L = oracle.lib()
+    cutoff = rng.uniform(0.02, 0.6, V).astype(np.float32); res = rng.uniform(0.0, 0.9, V).astype(np.float32)
+    nzs, fls = [], []
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + v); nzs.append(nz)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+    crafted = {5 + 41 * i: k for i, k in enumerate([0, 31, 32, 63, 64, 500, 1023])}
+    for v, k in crafted.items():
+        back = _xoshiro_step_back([0, int(rng.integers(1, 1 << 63)), int(rng.integers(1, 1 << 63)), 1 << 41], k)
+        for i in range(4):
+            nzs[v].r[i] = back[i]
+    m = mod.NoiseFilter(V, ctx, first_seed=first)
+    st = m.state()
+    for v in crafted:
+        st["noise"]["r"][v] = [int(x) for x in nzs[v].r]
+    m.set_state(st)
+    gc, gr = util.dev(cutoff), util.dev(res)
+    out0 = util.rng_buffers(13, V, F)
+    temp = np.zeros(F, np.float32)
+    for (s, e) in [(0, 1024), (0, 1024), (100, 612), (612, 1001), (0, 70)]:
+        ref = out0.copy()
+        if zero_first:
+            ref[:, s:e] = 0.0
+        for v in range(V):
+            L.zo_zero(s, e, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nzs[v]), s, e, oracle.fptr(temp), 0)
+            L.zo_filter_paint(C.byref(fls[v]), s, e, oracle.fptr(ref[v]), oracle.fptr(temp), ftype, oracle.constant(cutoff[v]), oracle.constant(res[v]))
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(0, ftype, gc, gr), zero_first=zero_first)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"noise_filter three-wave form, span {(s, e)}")
+        gs = m.state()
+        assert [[int(x) for x in row] for row in gs["noise"]["r"]] == [list(n.r) for n in nzs], f"generator states after span {(s, e)}"
+        util.assert_bitexact(gs["flt"]["l"].astype(np.float32), np.array([f.l for f in fls], np.float32), "l")
+        util.assert_bitexact(gs["flt"]["b"].astype(np.float32), np.array([f.b for f in fls], np.float32), "b")
+
+
 @pytest.mark.parametrize("V", [1, 65])
 @pytest.mark.parametrize("zero_first", [False, True])
 def test_noise_filter_few_voices_short_spans(ctx, oracle, V, zero_first):

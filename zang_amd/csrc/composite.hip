@@ -12,6 +12,7 @@
 #include "seq.hip.h"
 #include "envelope.hip.h"
 #include "voices.hip.h"
+#include "noise_jump.hip.h"
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -647,7 +648,10 @@ __global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP
 }
 
 // ------------------------------------------------------------------ Noise -> Filter voice
-struct zh_noise_filter { zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *nb; /* [7][n] */ float *l, *b; };
+struct zh_noise_filter {
+    zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *nb; /* [7][n] */ float *l, *b;
+    uint32_t *err;               // k_noise_filter_ring: a ring wait ran into its bound (reported by get_state)
+};
 
 __global__ void k_nf_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, uint32_t n, uint64_t first_seed) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -766,6 +770,215 @@ __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ 
     if (live && !producer) { l_io[v] = l; b_io[v] = b; }
 }
 
+// White noise, few voices, FIVE waves per 64 voices, decoupled by LDS rings instead of barriers.
+// At 64 waves on 1,024 SIMDs a wave issues one VALU instruction per ~5 cycles whatever it is (an LDS instruction costs it
+// ~15), so a voice costs the instructions on the busiest wave's per-sample path.  The frame's work is cut where its values meet:
+//   producers 0-2     xoshiro256++ -> Random.float -> `in = (0 + white) + fcdcoffset` (~30 instructions per sample, the longest
+//                     piece, hence three of them): they take 128-frame stretches in turn and hop over the other two's
+//                     stretches with the T^128 jump table applied twice (noise_jump.hip.h; ~950 instructions per application);
+//   filter            the state-variable recurrence alone (svf_core: 15 instructions) -> (l, b, h) per sample;
+//   writer            the output mix, the `+=` and the image store (everything after the recurrence).
+// Rings: noise tiles [8][32 frames][64 voices] producer -> filter, (l, b, h) tiles [2][3][32][64] filter -> writer;
+// monotonic tile counters in LDS, polled (bounded) with s_sleep.  Measured per wave (s_memtime, 4,096 voices): the filter
+// wave is the busiest, 3,500 cycles per 32-frame tile of which 2,400 are its 481 VALU instructions.
+// A tile that holds one of Random.float's multi-draw samples (2^-41 per sample) leaves the other producers' stretches
+// misaligned from there on: the filter wave finishes that tile, keeps where the voice stands (frame, generator state
+// after the tile, filter state), the writer drops that lane's later stores, and at the end of the kernel the lane walks
+// the rest of its span sequentially.  Same per-voice operations in the same order => the bits of k_noise_filter.
+struct NfArgs {
+    uint64_t *s[4];
+    float *l, *b;
+    uint32_t *err;               // set when a ring wait ran into its bound (never in a correct run)
+    const uint4 *table128;       // T^128
+    uint32_t V, start, end;
+    Img out;
+    float l_mul, b_mul, h_mul;
+    F32P cutoff, res;
+};
+constexpr uint32_t kNfProducers = 3;
+
+// Ring counters live in LDS and only LDS data is handed over: a wave's LDS instructions are performed in issue order (a
+// tile's ds_writes before the counter's ds_write; a slot's ds_reads, whose data the wave has consumed, before the counter
+// that frees the slot), and a reader's accesses to a tile are control-dependent on the counter it polled.  The asm
+// statements are compiler barriers.
+__device__ __forceinline__ bool ring_wait_ge(const uint32_t *counter, uint32_t want) {
+    for (uint32_t it = 0; it < (1u << 22); it++) {
+        const uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(counter, __ATOMIC_RELAXED));
+        if ((int32_t)(seen - want) >= 0) { asm volatile("" ::: "memory"); return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+__device__ __forceinline__ void ring_publish(uint32_t *counter, uint32_t value, uint32_t lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // this wave's LDS reads have returned, its writes are queued in order
+    if (lane == 0) __atomic_store_n(counter, value, __ATOMIC_RELAXED);
+    asm volatile("" ::: "memory");
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(const NfArgs a) {
+    constexpr uint32_t CH = 32, NS = 8, ST = 4, NONE = 0xFFFFFFFFu, NP = kNfProducers, NT = 64 * (NP + 2);   // ST = tiles per stretch
+    __shared__ uint4 tbl[kNoiseJumpEntries];
+    __shared__ float tile[NS][CH][64];
+    __shared__ float lbh[2][3][CH][64];
+    __shared__ uint64_t after[NP][4][64];                              // per producer: generator state after its first multi-draw tile
+    __shared__ uint32_t first_multi[NP][64];                           // per producer: that tile's index
+    __shared__ uint32_t dead_from[64];                                 // first tile the writer must not store (NONE: all)
+    __shared__ uint32_t ready[NS];                                     // ready[slot] = tile + 1 once the tile is in the slot
+    __shared__ uint32_t filt_done, lbh_ready, writ_done;               // tiles consumed by the filter / published to / written by the writer
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 0 .. NP-1: producers; NP: filter; NP+1: writer
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < a.V;
+    const uint32_t vc = live ? v : a.V - 1;                            // lanes past the last voice run voice V-1 again
+    const uint32_t n = a.end - a.start, nt = (n + CH - 1) / CH;
+    noise_jump_load(tbl, a.table128, threadIdx.x, NT);
+    if (threadIdx.x < 64) {
+        dead_from[threadIdx.x] = NONE;
+        for (uint32_t q = 0; q < NP; q++) first_multi[q][threadIdx.x] = NONE;
+    }
+    if (threadIdx.x < NS) ready[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) { filt_done = 0u; lbh_ready = 0u; writ_done = 0u; }
+    __syncthreads();
+    const uint32_t orow = (uint32_t)a.out.stride * 4u;
+    const float cut = zclampf(a.cutoff.get(vc), 0.0f, 1.0f);           // Filter.zig:114
+    const float res = 1.0f - zclampf(a.res.get(vc), 0.0f, 1.0f);       // :118
+    bool ok = true;
+    ZXoshiro r{0, 0, 0, 0};
+    float l = 0.0f, b = 0.0f;
+    uint32_t dead_tile = NONE;                                         // filter wave: the multi-draw tile of this lane
+    if (wave < NP) {
+        // ---------------------------------------------------------------- producer `wave`: stretches wave, wave + NP, ...
+        r = ZXoshiro{a.s[0][vc], a.s[1][vc], a.s[2][vc], a.s[3][vc]};
+        for (uint32_t q = 0; q < wave; q++) noise_jump_apply(r, tbl);  // producer p starts 128 p draws in
+        bool had_multi = false;
+        for (uint32_t j = wave; ST * j < nt && ok; j += NP) {
+            for (uint32_t q = 0; q < ST && ok; q++) {
+                const uint32_t c = ST * j + q;
+                if (c >= nt) break;
+                if (c >= NS) ok = ring_wait_ge(&filt_done, c + 1 - NS);          // the slot's previous tile has been read
+                const uint32_t nf = min(CH, n - c * CH), slot = c & (NS - 1);
+                float (*t)[64] = tile[slot];
+                bool multi = false;
+                // the tile without Random.float's rare-branch test per sample; a draw with a zero high word anywhere in it
+                // (2^-32 per sample) sends the whole wave through the tile again in the careful form
+                const ZXoshiro r_tile = r;
+                uint32_t hmin = 0xFFFFFFFFu;
+                auto fast = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                    const float white = zrandom_float32_common(r, hmin) * 2.0f - 1.0f;   // Noise.zig:51
+                    t[k][lane] = (0.0f + white) + kSvfDcOffset;        // zero(temp); temp += noise; in = temp + fcdcoffset (Filter.zig:135)
+                };
+                if (nf == CH) {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) fast(k);
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) fast(k);
+                }
+                if (__builtin_amdgcn_ballot_w64(hmin == 0u) != 0) {
+                    r = r_tile;
+                    for (uint32_t k = 0; k < nf; k++) {
+                        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
+                        t[k][lane] = (0.0f + white) + kSvfDcOffset;
+                    }
+                }
+                if (multi && !had_multi) {
+                    had_multi = true;
+                    first_multi[wave][lane] = c;
+                    after[wave][0][lane] = r.s0; after[wave][1][lane] = r.s1; after[wave][2][lane] = r.s2; after[wave][3][lane] = r.s3;
+                }
+                ring_publish(&ready[slot], c + 1, lane);
+            }
+            if (ST * (j + NP) < nt)                                    // over the other producers' stretches
+                for (uint32_t q = 0; q + 1 < NP; q++) noise_jump_apply(r, tbl);
+        }
+    } else if (wave == NP) {
+        // ---------------------------------------------------------------- filter: the recurrence alone
+        l = a.l[vc]; b = a.b[vc];
+        for (uint32_t c = 0; c < nt && ok; c++) {
+            const uint32_t nf = min(CH, n - c * CH), slot = c & (NS - 1), p = (c / ST) % NP;
+            ok = ring_wait_ge(&ready[slot], c + 1);
+            float x[CH];
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) x[k] = tile[slot][k][lane];
+            } else {
+                for (uint32_t k = 0; k < nf; k++) x[k] = tile[slot][k][lane];
+            }
+            const bool multi = first_multi[p][lane] == c;
+            ring_publish(&filt_done, c + 1, lane);
+            if (c >= 2 && ok) ok = ring_wait_ge(&writ_done, c - 1);    // the (l, b, h) slot's previous tile has been written out
+            float (*o)[CH][64] = lbh[c & 1];
+            auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                const SvfOut sv = svf_core(l, b, x[k], cut, res);      // Filter.zig:138-144
+                o[0][k][lane] = sv.l; o[1][k][lane] = sv.b; o[2][k][lane] = sv.h;
+            };
+            if (dead_tile != NONE) {
+                // stopped: (l, b) stay as they were after the multi-draw tile; the lane's later stores are dropped anyway
+            } else if (nf == CH) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k);
+            }
+            ring_publish(&lbh_ready, c + 1, lane);
+            if (multi && dead_tile == NONE) {                          // this tile drew more than once per sample somewhere
+                dead_tile = c;
+                dead_from[lane] = c + 1;                               // (reaches the writer before tile c + 1 does)
+            }
+        }
+    } else {
+        // ---------------------------------------------------------------- writer: mix, +=, store
+        for (uint32_t c = 0; c < nt && ok; c++) {
+            const uint32_t nf = min(CH, n - c * CH);
+            ok = ring_wait_ge(&lbh_ready, c + 1);
+            // descriptor over exactly this tile's rows: a lane that has stopped (offset 2^31) is out of its range, its
+            // loads return 0 and its stores are dropped
+            const uint32_t voff = c >= dead_from[lane] ? 0x80000000u : vc * 4u;
+            const zh_rsrc_t ro = make_rsrc(a.out.p + (size_t)(a.start + c * CH) * a.out.stride, CH * orow);
+            const float (*in)[CH][64] = lbh[c & 1];
+            auto one = [&](uint32_t k, float o) ZH_INLINE_LAMBDA {
+                const float val = in[0][k][lane] * a.l_mul + in[1][k][lane] * a.b_mul + in[2][k][lane] * a.h_mul;   // :146
+                zrow_store<1>(ro, voff, k * orow, o + val);
+            };
+            if (nf == CH) {
+                float oc[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, oc[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+            }
+            ring_publish(&writ_done, c + 1, lane);
+        }
+    }
+    if (!ok && lane == 0) *a.err = 1u;
+    __syncthreads();
+    // the span's last tile belongs to stretch (nt - 1) / ST: its producer holds the generator state after the span
+    if (live && wave == ((nt - 1) / ST) % NP && dead_from[lane] == NONE) { a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3; }
+    if (wave == NP) {
+        if (dead_tile != NONE) {
+            // the rest of a stopped voice's span, walked like k_noise_filter from where the multi-draw tile left it
+            // (the writer's stores of the earlier tiles are complete: they precede the barrier above in its program order,
+            // and the frames written here are disjoint from them)
+            const uint32_t p = (dead_tile / ST) % NP;
+            ZXoshiro rr{after[p][0][lane], after[p][1][lane], after[p][2][lane], after[p][3][lane]};
+            const uint32_t f0 = min(a.start + (dead_tile + 1) * CH, a.end);
+            if (live) {
+                const float *const *no_in = nullptr;
+                frame_loop<8, ZF, 0>(a.out.p, v, a.out.stride, no_in, nullptr, f0, a.end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+                    const float white = zrandom_float32(rr) * 2.0f - 1.0f;
+                    const float temp = 0.0f + white;
+                    const SvfOut s = svf_step(l, b, temp, cut, res);
+                    val = s.l * a.l_mul + s.b * a.b_mul + s.h * a.h_mul;
+                    return true;
+                });
+                a.s[0][v] = rr.s0; a.s[1][v] = rr.s1; a.s[2][v] = rr.s2; a.s[3][v] = rr.s3;
+            }
+        }
+        if (live) { a.l[v] = l; a.b[v] = b; }
+    }
+}
+
 // bypass: out += noise, filter state untouched (Filter.zig:91-97)
 template <bool ZF, bool PINK>
 __global__ void __launch_bounds__(kSeqBlock) k_noise_filter_bypass(uint64_t *__restrict__ s0, uint64_t *__restrict__ s1,
@@ -794,6 +1007,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise_filter_bypass(uint64_t *__r
 static void nf_free(zh_noise_filter *m) {
     for (auto &x : m->s) (void)hipFree(x);
     (void)hipFree(m->nb); (void)hipFree(m->l); (void)hipFree(m->b);
+    (void)hipFree(m->err);
 }
 
 __global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
@@ -994,12 +1208,15 @@ int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_nois
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_noise_filter *m = new (std::nothrow) zh_noise_filter();
     if (!m) return ZH_ERR_INVALID;
-    *m = zh_noise_filter{ctx, n, {nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr};
+    memset(m, 0, sizeof *m);
+    m->ctx = ctx; m->n = n;
     int rc = 0;
     for (int i = 0; i < 4 && !rc; i++) rc = dev_alloc(&m->s[i], n);
     if (!rc) rc = dev_alloc(&m->nb, (size_t)7 * n);
     if (!rc) rc = dev_alloc(&m->l, n);
     if (!rc) rc = dev_alloc(&m->b, n);
+    if (!rc) rc = dev_alloc(&m->err, 1);
+    if (!rc) rc = (int)hipMemsetAsync(m->err, 0, 4, ctx->stream);
     if (!rc && n) {
         rc = (int)hipMemsetAsync(m->nb, 0, (size_t)7 * n * 4, ctx->stream);
         if (!rc) rc = (int)hipMemsetAsync(m->l, 0, (size_t)n * 4, ctx->stream);
@@ -1007,6 +1224,7 @@ int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_nois
     }
     if (rc) { nf_free(m); delete m; return rc; }
     if (n) hipLaunchKernelGGL(k_nf_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], n, first_seed);
+    if (n) (void)zh_noise_jump_tables(ctx);                       // built on first use per context: here, not inside a paint (or a capture)
     *out = m;
     return zh_launch_status();
 }
@@ -1019,6 +1237,8 @@ int zh_noise_filter_destroy(zh_noise_filter *m) { ZH_GUARD(m ? m->ctx : nullptr)
 }
 int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
+    uint32_t ring_error = 0;
+    if (zh_download(m->ctx, &ring_error, m->err, 4) != ZH_OK || ring_error) return ZH_ERR_INVALID;
     std::vector<uint64_t> s;
     std::vector<float> nb, l, b;
     for (int i = 0; i < 4; i++) {
@@ -1082,6 +1302,24 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at
     // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both
     static const uint32_t pc_max = [] { const char *e = getenv("ZH_NF_PC_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u; }();
+    // White noise at small voice counts: three producer waves, a filter wave and a writer wave per 64 voices
+    // (k_noise_filter_ring).  ZH_NF_RING_MAX: largest voice count that takes it.
+    static const uint32_t ring_max = [] { const char *e = getenv("ZH_NF_RING_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u; }();
+    if (!pink && m->n <= ring_max && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
+        const uint4 *tables = zh_noise_jump_tables(m->ctx);
+        if (tables) {
+            NfArgs a;
+            for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
+            a.l = m->l; a.b = m->b; a.err = m->err;
+            a.table128 = tables + (size_t)3 * kNoiseJumpEntries;         // table j - 1 holds T^(32 j)
+            a.V = m->n; a.start = start; a.end = end; a.out = out;
+            a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
+            const dim3 grid((m->n + 63) / 64), block(64 * (kNfProducers + 2));
+            if (zf) hipLaunchKernelGGL(k_noise_filter_ring<true>, grid, block, 0, st, a);
+            else hipLaunchKernelGGL(k_noise_filter_ring<false>, grid, block, 0, st, a);
+            return zh_launch_status();
+        }
+    }
 #define ZH_NF(K_, BLK_, ZF_, PK_) hipLaunchKernelGGL((K_<ZF_, PK_>), seq_grid(m->n), dim3(BLK_), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
     if (m->n <= pc_max && outputs[0].stride <= (1u << 24)) {                            // (32-row tiles: 32-bit offsets)
         if (zf) { if (pink) ZH_NF(k_noise_filter_pc, 128, true, true); else ZH_NF(k_noise_filter_pc, 128, true, false); }

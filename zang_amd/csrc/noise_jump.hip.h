@@ -31,18 +31,34 @@ __device__ __forceinline__ void noise_jump_load(uint4 *lds, const uint4 *__restr
     for (uint32_t i = tid; i < (uint32_t)kNoiseJumpEntries; i += nthreads) lds[i] = table[i];
 }
 
-// r = T^k * r with T^k's table in LDS
+// r = T^k * r with T^k's table in LDS.  The 128 reads go out in four batches of 32 (16 nibble positions each) before any
+// of a batch is consumed -- left to itself the compiler issues a pair of reads and waits for it, 64 exposed LDS
+// latencies per jump (measured: ~10,000 cycles per jump against ~3,000 in this form).
 __device__ __forceinline__ void noise_jump_apply(ZXoshiro &r, const uint4 *lds) {
     const uint32_t w[8] = {(uint32_t)r.s0, (uint32_t)(r.s0 >> 32), (uint32_t)r.s1, (uint32_t)(r.s1 >> 32),
                            (uint32_t)r.s2, (uint32_t)(r.s2 >> 32), (uint32_t)r.s3, (uint32_t)(r.s3 >> 32)};
     uint4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int pos = 0; pos < 64; pos++) {
-        const uint32_t nib = (w[pos >> 3] >> ((pos & 7) * 4)) & 15u;
-        const uint4 x = lds[pos * 16 + nib];
-        const uint4 y = lds[64 * 16 + pos * 16 + nib];
-        a.x ^= x.x; a.y ^= x.y; a.z ^= x.z; a.w ^= x.w;
-        b.x ^= y.x; b.y ^= y.y; b.z ^= y.z; b.w ^= y.w;
+    for (int p0 = 0; p0 < 64; p0 += 16) {
+        uint4 x[16], y[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int pos = p0 + q;
+            const uint32_t nib = (w[pos >> 3] >> ((pos & 7) * 4)) & 15u;
+            x[q] = lds[pos * 16 + nib];
+            y[q] = lds[64 * 16 + pos * 16 + nib];
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);                           // nothing moves across: every read of the batch is in flight first
+#endif
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            a.x ^= x[q].x; a.y ^= x[q].y; a.z ^= x[q].z; a.w ^= x[q].w;
+            b.x ^= y[q].x; b.y ^= y[q].y; b.z ^= y[q].z; b.w ^= y[q].w;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     r.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32); r.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
     r.s2 = (uint64_t)b.x | ((uint64_t)b.y << 32); r.s3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
@@ -65,5 +81,16 @@ __device__ __forceinline__ float zrandom_float32_multi(ZXoshiro &r, bool &multi)
             }
         }
     }
+    return zu2f(((126u - lz) << 23) | ((uint32_t)rnd & 0x7FFFFFu));
+}
+
+// The common case of zrandom_float32 without its test: valid whenever the draw's high word is non-zero; `hmin` collects the
+// minimum high word so that a caller can test a whole tile at once (and redo it with the careful form when it is 0).
+__device__ __forceinline__ float zrandom_float32_common(ZXoshiro &r, uint32_t &hmin) {
+    const uint64_t rnd = zxoshiro_next(r);
+    const uint32_t hi = (uint32_t)(rnd >> 32);
+    hmin = hi < hmin ? hi : hmin;
+    uint32_t lz;
+    asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(hi));
     return zu2f(((126u - lz) << 23) | ((uint32_t)rnd & 0x7FFFFFu));
 }
