@@ -735,6 +735,36 @@ def main():
             except Exception as e:          # noqa: BLE001  (reported, never fatal: it is the comparison, not the measurement)
                 out["p2p_direct"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    if world == 1 and args.workload == "pulseosc" and not args.eager:
+        # The same buffers painted through zh_pulseosc_paint_batch: B consecutive 1024-frame paints (same span and params,
+        # buffer b into its own image) as ONE launch -- the phase of any frame is cnt + frames_before * ifreq exactly, so the
+        # buffers of a batch are independent and share one launch's ramp and tail.  Extra key only: a step of `value` stays
+        # one buffer per launch.
+        B = 8
+        nb_steps = max(B, (K // B) * B)
+        imgs = [wl.ring[i % wl.nring] for i in range(nb_steps)]
+        def batch_steps():
+            for i in range(0, nb_steps, B):
+                wl.m.paint_batch(wl.span, imgs[i:i + B], wl.params, zero_first=True, params_unchanged=True)
+        batch_steps()
+        torch.cuda.synchronize()
+        bgraph = ctx.capture(batch_steps)
+        bgraph.launch(); torch.cuda.synchronize()
+        e0, e1 = make_event(), make_event()
+        abi.check(lib.zh_event_record(ctx.handle, e0), "zh_event_record")
+        bgraph.launch()
+        abi.check(lib.zh_event_record(ctx.handle, e1), "zh_event_record")
+        torch.cuda.synchronize()
+        bms = C.c_float()
+        abi.check(lib.zh_event_elapsed_ms(e0, e1, C.byref(bms)), "zh_event_elapsed_ms")
+        per_buf = bms.value / nb_steps
+        out["batched_launches"] = {"buffers_per_launch": B, "buffers": nb_steps, "ms_per_buffer_hip_events": per_buf,
+                                   "achieved_GBs": wl.bytes_per_step / (per_buf * 1e-3) / 1e9,
+                                   "frac": wl.bytes_per_step / (per_buf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "what": "zh_pulseosc_paint_batch: 8 consecutive buffers per launch (same results, state after the last)"}
+        lib.zh_event_destroy(e0); lib.zh_event_destroy(e1)
+        bgraph.close()
+
     if world == 1 and not args.no_config5 and args.workload == "pulseosc" and V == 4096:
         # the 1-GPU shard of config 5 (what every rank of the N>1 run renders), for the scaling ratio
         c5 = Runner("nice_mix", 131072, 96)

@@ -116,7 +116,8 @@ struct OscArgs {
 };
 
 // TAB = the per-voice constants come from the module's table instead of being computed (OscTable).
-template <class OSC, bool ZF, int SM, bool TAB>
+// FC4 = every wave renders exactly four frames (fc == 4 and the span is a multiple of 4): the frame loop unrolls completely.
+template <class OSC, bool ZF, int SM, bool TAB, bool FC4 = false>
 __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     using K = typename OSC::K;
     constexpr int KW = sizeof(K) / 4;                     // dwords of per-voice constants
@@ -185,7 +186,8 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
         bad[0] = w[KW].x != 0; bad[1] = w[KW].y != 0; bad[2] = w[KW].z != 0; bad[3] = w[KW].w != 0;
         cnt0[0] = w[KW + 1].x; cnt0[1] = w[KW + 1].y; cnt0[2] = w[KW + 1].z; cnt0[3] = w[KW + 1].w;
     }
-    const uint32_t chunk = blockIdx.y * 4 + wave;
+    // (wave-uniform: said so explicitly, or the frame loops below become per-lane exec-mask loops that cannot be unrolled)
+    const uint32_t chunk = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave);
     const uint32_t nfr = end - start;
     const uint32_t c0 = start + chunk * fc;
     const uint32_t c1 = min(c0 + fc, end);
@@ -219,6 +221,23 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     // `x + gain`, `x - gain` or `gain + x` with gain = 0.7, and an IEEE sum is -0.0 only if both addends
     // are -0.0, so val is never -0.0 (the one input 0.0f + x changes); NaNs pass through unchanged.
     if (!__any(bad[0] || bad[1] || bad[2] || bad[3])) {
+        if constexpr (FC4) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++, o += os, boff += (uint32_t)os * 4) {
+                zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (!ZF) acc = *reinterpret_cast<const zv4f *>(o);
+                float val[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    val[j] = OSC::sample_roll(k[j], cnt[j], roll[j]);
+                    cnt[j] += k[j].ifreq;
+                }
+                if (ZF) { acc.x = val[0]; acc.y = val[1]; acc.z = val[2]; acc.w = val[3]; }
+                else { acc.x += val[0]; acc.y += val[1]; acc.z += val[2]; acc.w += val[3]; }
+                store4<SM>(o, rsrc, boff, acc);
+            }
+            return;
+        }
 #pragma unroll 2
         for (uint32_t i = c0; i < c1; i++, o += os, boff += (uint32_t)os * 4) {
             zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -334,6 +353,11 @@ static bool osc_prio() {
     if (v < 0) { const char *e = getenv("ZH_OSC_PRIO"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
+static bool osc_no_fc4() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ZH_OSC_NO_FC4"); v = e ? atoi(e) : 0; }         // A/B: the runtime-length frame loop
+    return v != 0;
+}
 static bool osc_no_table() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("ZH_OSC_NO_TABLE"); v = e ? atoi(e) : 0; }     // A/B: ignore ZH_PAINT_PARAMS_UNCHANGED
@@ -377,7 +401,10 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
             a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
             for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
             dim3 grid((lanes + 63) / 64, (chunks + 3) / 4, cnt_b);
-#define ZH_LAUNCH_O4(ZF, SM) do { if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true>), grid, dim3(256), 0, st, a); \
+            const bool fc4 = fc == 4 && (end - start) % 4 == 0 && !osc_no_fc4();
+#define ZH_LAUNCH_O4(ZF, SM) do { if (use_tab && fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, true>), grid, dim3(256), 0, st, a); \
+                                  else if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true>), grid, dim3(256), 0, st, a); \
+                                  else if (fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, true>), grid, dim3(256), 0, st, a); \
                                   else hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false>), grid, dim3(256), 0, st, a); } while (0)
             if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
             else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
