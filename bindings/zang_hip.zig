@@ -21,6 +21,7 @@ pub const Curve = extern struct { tag: u32, reserved: u32 = 0, duration: F32 = .
 
 pub const PAINT_ADD: u32 = 0;
 pub const PAINT_ZERO_FIRST: u32 = 1;
+pub const PAINT_PARAMS_UNCHANGED: u32 = 4; // params are what this module's previous paint got (include/zang_hip.h)
 
 pub extern fn zh_create(out: *?*Ctx, device: c_int) c_int;
 pub extern fn zh_destroy(ctx: *Ctx) c_int;
@@ -43,6 +44,13 @@ pub extern fn zh_multiply_with(ctx: *Ctx, start: u32, end: u32, dest: Buf, a: Bu
 pub extern fn zh_multiply_scalar(ctx: *Ctx, start: u32, end: u32, dest: Buf, a: Buf, b: F32) c_int;
 pub extern fn zh_multiply_with_scalar(ctx: *Ctx, start: u32, end: u32, dest: Buf, a: F32) c_int;
 pub extern fn zh_mixdown_voices(ctx: *Ctx, start: u32, end: u32, dst: [*]f32, src: Buf, flags: u32) c_int;
+
+// multi-GPU mixdown exchange without a collective library: the root process owns one slot per rank in its GPU's memory,
+// the other processes map it (64-byte handle over any host channel) and point their mixdown at `base + rank * slot_bytes`
+pub extern fn zh_ipc_alloc(ctx: *Ctx, bytes: usize, dev_ptr: *?*anyopaque, handle64: *[64]u8) c_int;
+pub extern fn zh_ipc_open(ctx: *Ctx, handle64: *const [64]u8, dev_ptr: *?*anyopaque) c_int;
+pub extern fn zh_ipc_close(ctx: *Ctx, dev_ptr: ?*anyopaque) c_int;
+pub extern fn zh_sum_slots(ctx: *Ctx, dst: [*]f32, slots: [*]const f32, n_slots: u32, slot_stride_floats: usize, n: usize, flags: u32) c_int;
 
 // zangscript modules (include/zang_hip.h "zangscript modules"): HIP source from `python -m zang_amd.zangc`
 pub const Script = opaque {};
@@ -75,6 +83,9 @@ pub const PulseOscParams = extern struct { sample_rate: f32, reserved: u32 = 0, 
 pub extern fn zh_pulseosc_create(ctx: *Ctx, n_voices: u32, out: *?*PulseOscHandle) c_int;
 pub extern fn zh_pulseosc_destroy(m: *PulseOscHandle) c_int;
 pub extern fn zh_pulseosc_paint(m: *PulseOscHandle, start: u32, end: u32, outputs: [*]const Buf, temps: ?[*]const Buf, note_id_changed: Bool, params: *const PulseOscParams, flags: u32) c_int;
+// n_buffers consecutive paint calls with the same span and params (the host's loop over 1024-frame buffers,
+// examples/write_wav.zig:58-66), buffer b into outputs[b]: one launch when the frequency is constant
+pub extern fn zh_pulseosc_paint_batch(m: *PulseOscHandle, start: u32, end: u32, outputs: [*]const Buf, n_buffers: u32, params: *const PulseOscParams, flags: u32) c_int;
 
 // Filter (src/modules/Filter.zig)
 pub const FilterHandle = opaque {};

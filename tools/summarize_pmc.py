@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes (one counter per pass, as MI355X_MICROARCH.md prescribes)
-into profiles/<name>.json.  usage: summarize_pmc.py <kernel-substring> <out.json> <dir-with-WRITE_SIZE> <dir-with-FETCH_SIZE>"""
+into profiles/<name>.json.  usage: summarize_pmc.py <kernel-substring> <out.json> <dir-with-WRITE_SIZE> <dir-with-FETCH_SIZE> [commit]"""
 import csv, glob, json, statistics, sys
 
 kernel, out, wdir, fdir = sys.argv[1:5]
+commit = sys.argv[5] if len(sys.argv) > 5 else None
 
 
 def mean_counter(d, name):
@@ -16,6 +17,8 @@ w, nw = mean_counter(wdir, "WRITE_SIZE")
 f, nf = mean_counter(fdir, "FETCH_SIZE")
 res = {
     "kernel": kernel,
+    "commit": commit,
+    "command": "bench.py --steps 64 --warmup 8 --eager (default workload: 4096 PulseOsc voices x 1024 frames), one rocprofv3 --pmc pass per counter",
     "dispatches": {"WRITE_SIZE": nw, "FETCH_SIZE": nf},
     "WRITE_SIZE_KiB_per_launch": w,
     "FETCH_SIZE_KiB_per_launch_raw": f,

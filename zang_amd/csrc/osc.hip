@@ -117,7 +117,9 @@ struct OscArgs {
 
 // TAB = the per-voice constants come from the module's table instead of being computed (OscTable).
 // FC4 = every wave renders exactly four frames (fc == 4 and the span is a multiple of 4): the frame loop unrolls completely.
-template <class OSC, bool ZF, int SM, bool TAB, bool FC4 = false>
+// BATCH only names the instantiation a multi-buffer launch uses (same code): a profiler's per-kernel statistics then keep
+// one-buffer launches and batches apart.
+template <class OSC, bool ZF, int SM, bool TAB, bool FC4 = false, bool BATCH = false>
 __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     using K = typename OSC::K;
     constexpr int KW = sizeof(K) / 4;                     // dwords of per-voice constants
@@ -390,7 +392,12 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
     const uint32_t fc = osc_frames_per_lane(OSC::kShortChunks, lanes, end - start);
     const uint32_t chunks = (end - start + fc - 1) / fc;
     if (vec) {
-        const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) && !osc_no_table();
+        // The table is read by every frame-chunk wave of a voice group, always on the same XCD (grid.x is a multiple of 8), so
+        // it pays while an XCD's eighth of it stays in that XCD's 4 MiB L2: measured +3 ... +10 % up to 524,288 voices
+        // (81 % of the HBM peak there), -20 % at 1,048,576 (3.7 MB per XCD: it thrashes) -- hence the size limit.
+        constexpr size_t kw1 = sizeof(typename OSC::K) / 4 + 1;
+        const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) &&
+                             (size_t)n * kw1 * 4 <= ((size_t)16 << 20) && !osc_no_table();
         const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
         for (uint32_t b0 = 0; b0 < nb; b0 += kOscMaxBatch) {
             const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
@@ -402,13 +409,15 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
             for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
             dim3 grid((lanes + 63) / 64, (chunks + 3) / 4, cnt_b);
             const bool fc4 = fc == 4 && (end - start) % 4 == 0 && !osc_no_fc4();
-#define ZH_LAUNCH_O4(ZF, SM) do { if (use_tab && fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, true>), grid, dim3(256), 0, st, a); \
-                                  else if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true>), grid, dim3(256), 0, st, a); \
-                                  else if (fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, true>), grid, dim3(256), 0, st, a); \
-                                  else hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false>), grid, dim3(256), 0, st, a); } while (0)
+#define ZH_LAUNCH_O4B(ZF, SM, B) do { if (use_tab && fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, true, B>), grid, dim3(256), 0, st, a); \
+                                      else if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, false, B>), grid, dim3(256), 0, st, a); \
+                                      else if (fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, true, B>), grid, dim3(256), 0, st, a); \
+                                      else hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, false, B>), grid, dim3(256), 0, st, a); } while (0)
+#define ZH_LAUNCH_O4(ZF, SM) do { if (cnt_b > 1) ZH_LAUNCH_O4B(ZF, SM, true); else ZH_LAUNCH_O4B(ZF, SM, false); } while (0)
             if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
             else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
 #undef ZH_LAUNCH_O4
+#undef ZH_LAUNCH_O4B
             // the setup form stored this call's constants (ordered before any later paint on the stream)
             if (!use_tab && a.tab) { m->tab.valid = true; m->tab.sample_rate = sample_rate; m->tab.freq = freq; m->tab.color = color; }
             // the batch advanced the state like cnt_b paints in a row but wrote it once, into the other buffer
