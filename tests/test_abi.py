@@ -88,3 +88,10 @@ def test_context_refuses_without_gpu():
     import zang_amd
     with pytest.raises(zang_amd.abi.ZangHipError):
         zang_amd.Context(0)
+
+
+def test_noise_jump_tables_selftest():
+    """Host-only: the xoshiro256++ jump tables behind the frame-range form of white Noise (csrc/noise_jump.hip) -- table j
+    applied to a state equals 32 (j + 1) sequential transitions, for all 63 tables and 64 random states."""
+    from zang_amd import abi
+    assert abi.load().zh_selftest_noise_jump(20260517, 64) == 0
