@@ -149,3 +149,60 @@ def test_mixdown_scratch_cannot_grow_inside_capture(ctx):
         ref = big.double().sum(1)
         assert torch.allclose(mix_b.double(), ref, rtol=0, atol=1e-2)
         g.close(); c2.close()
+
+
+def test_sineosc_frame_ranges_in_graphs_and_eager(ctx, oracle):
+    """SineOsc at a small voice count paints a span as many frame ranges at once (k_sineosc_ranges: every range replays the
+    f32 phase additions of the frames before it) and double-buffers its phase like the chunked oscillators: an odd number
+    of paints in a graph, replays mixed with eager paints, all four param paths -- equal to the oracle's sequential
+    paints bit for bit, phase state included."""
+    import ctypes as C
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang
+    V = 320
+    rng = np.random.default_rng(5)
+    freq = rng.uniform(30.0, 3000.0, V).astype(np.float32)
+    fbuf = rng.uniform(20.0, 2000.0, (V, F)).astype(np.float32)
+    pbuf = rng.uniform(-1.0, 1.0, (V, F)).astype(np.float32)
+    L = oracle.lib()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        for fb, pb in ((False, False), (True, False), (False, True), (True, True)):
+            m = mod.SineOsc(V, c2)
+            gf = zang.buffer(util.to_image(fbuf)) if fb else zang.constant(util.dev(freq))
+            gp = zang.buffer(util.to_image(pbuf)) if pb else zang.constant(0.25)
+            P = m.Params(SR, gf, gp)
+            spans = [(0, F), (0, F), (0, F), (100, 900), (0, F), (0, F), (0, F), (900, 1024), (0, F), (0, F), (0, F)]
+            ring = [c2.image(F, V) for _ in range(3)]
+            got = []
+            def eager(s, e):
+                o = c2.image(F, V, fill=0.0)
+                m.paint(zang.Span(s, e), [o], [], False, P)               # `+=` onto zeros
+                got.append(o)
+            eager(0, F)                                                    # allocate / warm
+            c2.sync()
+            g = c2.capture(lambda: [m.paint(zang.Span(0, F), [o], [], False, P, zero_first=True) for o in ring])   # 3 paints: odd
+            def replay():
+                g.launch()
+                for o in ring:
+                    got.append(o.clone())
+            replay(); eager(100, 900); replay(); eager(900, 1024); replay()
+            c2.sync()
+            order = [(0, F)] + [(0, F)] * 3 + [(100, 900)] + [(0, F)] * 3 + [(900, 1024)] + [(0, F)] * 3
+            ref_t = np.zeros(V, np.float32)
+            for v in range(0, V, 7):                                       # every 7th voice keeps the CPU side short
+                st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st))
+                for k, (s, e) in enumerate(order):
+                    buf = np.zeros(F, np.float32)
+                    L.zo_sineosc_paint(C.byref(st), s, e, oracle.fptr(buf), SR,
+                                       oracle.buffer(fbuf[v]) if fb else oracle.constant(freq[v]),
+                                       oracle.buffer(pbuf[v]) if pb else oracle.constant(0.25))
+                    g_col = got[k][:, v].cpu().numpy()
+                    util.assert_bitexact(g_col[s:e], buf[s:e], f"sineosc ranges fb={fb} pb={pb} paint {k} voice {v}")
+                ref_t[v] = st.t
+            t = m.state()["t"].astype(np.float32)
+            util.assert_bitexact(t[::7], ref_t[::7], "phase after the sequence")
+            g.close(); m.close()
+        c2.close()

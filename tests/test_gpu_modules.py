@@ -28,9 +28,20 @@ def _gcob(zang, kind, const_t, buf_t):
 
 
 # ------------------------------------------------------------------ SineOsc
+@pytest.fixture(params=["ranges", "sequential"])
+def replay_form(request, monkeypatch):
+    """SineOsc / Sampler at a small voice count paint a span as many frame ranges at once (each range replays the f32 state
+    additions of the frames before it); ZH_*_RANGES=0 selects the lane-per-voice walk instead.  Both forms must give the
+    oracle's bits (the library reads the variables at every paint)."""
+    if request.param == "sequential":
+        monkeypatch.setenv("ZH_SINE_RANGES", "0")
+        monkeypatch.setenv("ZH_SAMPLER_RANGES", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("fk,pk", [("c", "c"), ("c", "b"), ("b", "c"), ("b", "b")])
 @pytest.mark.parametrize("spans", SPANS)
-def test_sineosc(ctx, oracle, fk, pk, spans):
+def test_sineosc(ctx, oracle, fk, pk, spans, replay_form):
     from zang_amd import modules as mod, zang
     V = 192
     rng = np.random.default_rng(21)
@@ -396,7 +407,7 @@ def _pcm(fmt, nframes, channels, seed):
 
 @pytest.mark.parametrize("fmt", range(4))
 @pytest.mark.parametrize("loop", [False, True])
-def test_sampler(ctx, oracle, fmt, loop):
+def test_sampler(ctx, oracle, fmt, loop, replay_form):
     """Per-voice output rates cover: ratio ~ 1 (integer copy), up/down-sampling, negative ratio."""
     from zang_amd import modules as mod, zang
     V, channels, in_rate = 96, 2, 44100

@@ -24,7 +24,12 @@ template <typename T> static int download_field(zh_ctx *ctx, std::vector<T> &h, 
 }
 
 // =================================================================== SineOsc
-struct zh_sineosc { zh_ctx *ctx; uint32_t n; float *t; };
+// The phase `t` is double-buffered like the chunked oscillators' counters (zh_flipper: a captured graph bakes both pointers
+// in, zh_graph_launch reconciles): the frame-range kernel's ranges all read the span's start phase while the last range
+// publishes the end phase.  cnt[] holds the f32 bits.
+struct zh_sineosc : zh_flipper {
+    float *t() const { return reinterpret_cast<float *>(cnt[cur]); }
+};
 
 template <bool ZF, bool FB, bool PB>
 __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
@@ -47,6 +52,68 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
     });
     o.end();
     t_io[v] = o.t;
+}
+
+// Few voices: the span as many frame ranges at once, one wave per (64 voices, range).  The phase that reaches frame f0 is
+// the span's start phase after f0 - start additions of `t_step` (or of `freq[i] * inv_sr`), each rounded to f32 -- so a
+// range first REPLAYS those additions (one dependent add per earlier frame: cheap beside the ~50 instructions of a musl
+// sine) and then paints its own frames exactly like k_sineosc; the range that ends the span publishes the wrapped phase.
+// Every frame is written once, so `+=` paints need no scratch.  147 -> see DESIGN.md 5a at 4,096 voices.
+template <bool ZF, bool FB, bool PB>
+__global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
+                                                       uint32_t start, uint32_t end, uint32_t ch, float sample_rate, CobP freq, CobP phase) {
+    const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
+    SineOscLane o;
+    o.t = t_in[v];
+    o.begin(sample_rate, FB ? 0.0f : freq.c.get(v));
+    if (FB) {
+        const float *fp = freq.b.p + (size_t)start * freq.b.stride + v;
+        uint32_t i = start;
+        for (; i + 8 <= f0; i += 8, fp += 8 * freq.b.stride) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = fp[(size_t)k * freq.b.stride];
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.t += x[k] * o.inv_sr;                  // SineOsc.zig:73 / :83
+        }
+        for (; i < f0; i++, fp += freq.b.stride) o.t += *fp * o.inv_sr;
+    } else {
+        // (ranges start at multiples of 8 frames from the span start: eight dependent adds per loop round)
+        uint32_t i = start;
+        for (; i + 8 <= f0; i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.t += o.t_step;                          // :50 / :59
+        }
+        for (; i < f0; i++) o.t += o.t_step;
+    }
+    constexpr int NIN = (FB ? 1 : 0) + (PB ? 1 : 0);
+    const float *ins[2] = {nullptr, nullptr};
+    size_t istr[2] = {0, 0};
+    if (FB) { ins[0] = freq.b.p; istr[0] = freq.b.stride; }
+    if (PB) { ins[FB ? 1 : 0] = phase.b.p; istr[FB ? 1 : 0] = phase.b.stride; }
+    const float phase_c = PB ? 0.0f : phase.c.get(v);
+    frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, f0, f1,
+                           [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
+        val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
+        return true;
+    });
+    if (f1 == end) { o.end(); t_out[v] = o.t; }
+}
+
+// Frames per range for the frame-range forms of the stateful-but-cheap-to-replay modules, or 0 = sequential kernel:
+// enough ranges for about one wave per SIMD, ranges a multiple of 8 frames (frame_loop's chunk).
+static uint32_t replay_range_frames(uint32_t V, uint32_t n, const char *env_name) {
+    const char *e = getenv(env_name);
+    const int forced = e ? atoi(e) : -1;                                          // 0 = off, k = k ranges
+    if (forced == 0 || V == 0 || n < 128 || V > 16384) return 0;
+    const uint32_t waves = (V + 63) / 64;
+    uint32_t want = forced > 0 ? (uint32_t)forced : 2048u / waves;                // two waves per SIMD: 16 / 32 / 64 ranges measured 19.5 / 16.7 / 16.6 us (SineOsc, 4,096 voices)
+    if (want < 2) return 0;
+    if (want > 64) want = 64;
+    const uint32_t ch = ((n + want - 1) / want + 7) / 8 * 8;
+    return (n + ch - 1) / ch >= 2 ? ch : 0;
 }
 
 // =================================================================== Noise
@@ -174,7 +241,11 @@ __global__ void k_sincos(uint32_t n, float *__restrict__ out, const float *__res
 }
 
 // =================================================================== Sampler
-struct zh_sampler { zh_ctx *ctx; uint32_t n; float *t; };
+// `t` double-buffered (cnt[] holds the f32 bits), like zh_sineosc: the frame-range kernel's ranges read the start position
+// while the last range publishes the end position
+struct zh_sampler : zh_flipper {
+    float *t() const { return reinterpret_cast<float *>(cnt[cur]); }
+};
 
 struct SampleP {
     const uint8_t *data;
@@ -232,30 +303,43 @@ __device__ __forceinline__ float sampler_get_sample(const SampleP &s, int32_t in
     return in ? val : 0.0f;
 }
 
+// One kernel, two launch shapes.  Sequential: grid.y = 1, ch = the whole span, t_in == t_out.  Few voices: grid.y frame
+// ranges of `ch` frames at once, one wave per (64 voices, range) -- the play position that reaches frame f0 is the start
+// position after f0 - start additions of `ratio`, each rounded to f32, so a range first REPLAYS those additions (the
+// no-resampling path needs none: its index is t0 + frame), then paints its frames; the range that ends the span
+// publishes the position (t_out is the other half of the double buffer).
 template <bool ZF, int FMT, bool LOOP>
-__global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
-                                                       uint32_t end, SampleP s, F32P out_rate, BoolP nic) {
+__global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
+                                                       uint32_t start, uint32_t end, uint32_t ch, SampleP s, F32P out_rate, BoolP nic) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    float t = t_io[v];
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
+    const bool last = f1 == end;
+    float t = t_in[v];
     if (nic.get(v)) t = 0.0f;                                         // Sampler.zig:91-93
     const uint32_t len = end - start;
     const float ratio = (float)s.sample_rate_in / out_rate.get(v);    // :97
     const float *const *no_in = nullptr;
     if (ratio < 0.0f && !LOOP) {                                      // :99-102 (t keeps the reset)
-        if (ZF) zero_column(out.p + v, out.stride, start, end);
-        t_io[v] = t;
+        if (ZF) zero_column(out.p + v, out.stride, f0, f1);
+        if (last) t_out[v] = t;
         return;
     }
     if (ratio > 0.9999f && ratio < 1.0001f) {                         // :105-114 no resampling
         const int32_t t0 = zf32_to_i32(roundf(t));
-        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             val = sampler_get_sample<FMT, LOOP>(s, (int32_t)((uint32_t)t0 + (i - start)));
             return true;
         });
         t += (float)len;
     } else {                                                          // :116-130 linear resampling
-        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        uint32_t i = start;
+        for (; i + 8 <= f0; i += 8) {                                 // the earlier frames' `self.t += ratio` (:129), add by add
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += ratio;
+        }
+        for (; i < f0; i++) t += ratio;
+        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             const int32_t t0 = zf32_to_i32(floorf(t));
             const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
             const float tfrac = (float)t1 - t;                        // :121
@@ -266,9 +350,10 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(float *__restrict__ t_io,
             return true;
         });
     }
+    if (!last) return;
     // :133-135: compared against data.len in BYTES (reference quirk, kept)
     if (t >= (float)s.data_len && LOOP) t -= (float)s.data_len;
-    t_io[v] = t;
+    t_out[v] = t;
 }
 
 // =================================================================== Decimator
@@ -402,33 +487,42 @@ static EnvParamsP mk_env_params(const zh_envelope_params *p) {
                       mk_f32(p->decay.duration), mk_f32(p->release.duration), mk_f32(p->sustain_volume), mk_bool(p->note_on)};
 }
 
-extern "C" {
-
-// ------------------------------------------------------------------ SineOsc
-int zh_sineosc_create(zh_ctx *ctx, uint32_t n, zh_sineosc **out) { ZH_GUARD(ctx);
+// shared by the modules whose state is one double-buffered 32-bit word per voice (zh_sineosc, zh_sampler)
+template <class M> static int flip1_create(zh_ctx *ctx, uint32_t n, M **out) {
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_sineosc *m = new (std::nothrow) zh_sineosc{ctx, n, nullptr};
+    M *m = new (std::nothrow) M();
     if (!m) return ZH_ERR_INVALID;
-    int rc = dev_alloc(&m->t, n);
-    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);          // init(): t = 0 (:18-22)
-    if (rc) { (void)hipFree(m->t); delete m; return rc; }
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0;
+    int rc = dev_alloc(&m->cnt[0], n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], n);
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[0], 0, (size_t)n * 4, ctx->stream);   // init(): 0.0
+    if (!rc && n) rc = (int)hipMemsetAsync(m->cnt[1], 0, (size_t)n * 4, ctx->stream);
+    if (rc) { (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
-int zh_sineosc_destroy(zh_sineosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
+template <class M> static int flip1_destroy(M *m) {
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->t);
+    zh_flipper_unregister(m);
+    (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]);
     delete m;
     return ZH_OK;
 }
+
+extern "C" {
+
+// ------------------------------------------------------------------ SineOsc
+int zh_sineosc_create(zh_ctx *ctx, uint32_t n, zh_sineosc **out) { ZH_GUARD(ctx); return flip1_create(ctx, n, out); }   // init(): t = 0 (SineOsc.zig:18-22)
+int zh_sineosc_destroy(zh_sineosc *m) { ZH_GUARD(m ? m->ctx : nullptr); return flip1_destroy(m); }
 int zh_sineosc_get_state(zh_sineosc *m, zh_sineosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
+    return zh_download(m->ctx, host, m->t(), (size_t)m->n * 4);
 }
 int zh_sineosc_set_state(zh_sineosc *m, const zh_sineosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
+    return zh_upload(m->ctx, m->t(), host, (size_t)m->n * 4);
 }
 int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
                      zh_bool note_id_changed, const zh_sineosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
@@ -442,10 +536,30 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     const bool fb = p->freq.tag == ZH_COB_BUFFER, pb = p->phase.tag == ZH_COB_BUFFER;
     Img out = mk_img(outputs[0]);
     CobP f = mk_cob(p->freq), ph = mk_cob(p->phase);
+    // few voices: frame ranges at once (k_sineosc_ranges); ZH_SINE_RANGES = number of ranges, 0 = never
+    const uint32_t ch = end > start ? replay_range_frames(m->n, end - start, "ZH_SINE_RANGES") : 0;
+    if (ch) {
+        const float *t_in = m->t();
+        float *t_out = reinterpret_cast<float *>(m->cnt[m->cur ^ 1]);
+        const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
+#define ZH_SINE_R(FB, PB)                                                                                           \
+    do {                                                                                                            \
+        if (zf) hipLaunchKernelGGL((k_sineosc_ranges<true, FB, PB>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph); \
+        else hipLaunchKernelGGL((k_sineosc_ranges<false, FB, PB>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph);  \
+    } while (0)
+        if (fb && pb) ZH_SINE_R(true, true);
+        else if (fb) ZH_SINE_R(true, false);
+        else if (pb) ZH_SINE_R(false, true);
+        else ZH_SINE_R(false, false);
+#undef ZH_SINE_R
+        zh_flipper_painted(m);
+        m->cur ^= 1;
+        return zh_launch_status();
+    }
 #define ZH_SINE(FB, PB)                                                                                             \
     do {                                                                                                            \
-        if (zf) hipLaunchKernelGGL((k_sineosc<true, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, f, ph); \
-        else hipLaunchKernelGGL((k_sineosc<false, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, f, ph);  \
+        if (zf) hipLaunchKernelGGL((k_sineosc<true, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph); \
+        else hipLaunchKernelGGL((k_sineosc<false, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph);  \
     } while (0)
     if (fb && pb) ZH_SINE(true, true);
     else if (fb) ZH_SINE(true, false);
@@ -757,30 +871,15 @@ int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx)
 }
 
 // ------------------------------------------------------------------ Sampler
-int zh_sampler_create(zh_ctx *ctx, uint32_t n, zh_sampler **out) { ZH_GUARD(ctx);
-    if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_sampler *m = new (std::nothrow) zh_sampler{ctx, n, nullptr};
-    if (!m) return ZH_ERR_INVALID;
-    int rc = dev_alloc(&m->t, n);
-    if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);           // init() :71-75
-    if (rc) { (void)hipFree(m->t); delete m; return rc; }
-    *out = m;
-    return ZH_OK;
-}
-int zh_sampler_destroy(zh_sampler *m) { ZH_GUARD(m ? m->ctx : nullptr);
-    if (!m) return ZH_ERR_INVALID;
-    (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->t);
-    delete m;
-    return ZH_OK;
-}
+int zh_sampler_create(zh_ctx *ctx, uint32_t n, zh_sampler **out) { ZH_GUARD(ctx); return flip1_create(ctx, n, out); }   // init() :71-75
+int zh_sampler_destroy(zh_sampler *m) { ZH_GUARD(m ? m->ctx : nullptr); return flip1_destroy(m); }
 int zh_sampler_get_state(zh_sampler *m, zh_sampler_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    return zh_download(m->ctx, host, m->t, (size_t)m->n * 4);
+    return zh_download(m->ctx, host, m->t(), (size_t)m->n * 4);
 }
 int zh_sampler_set_state(zh_sampler *m, const zh_sampler_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    return zh_upload(m->ctx, m->t, host, (size_t)m->n * 4);
+    return zh_upload(m->ctx, m->t(), host, (size_t)m->n * 4);
 }
 int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
                      zh_bool note_id_changed, const zh_sampler_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
@@ -814,7 +913,14 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
     const F32P rate = mk_f32(p->sample_rate);
     const BoolP nicp = mk_bool(note_id_changed);
     const int fmt = s.num_samples == 0 ? kSampleEmpty : (int)s.format;
-#define ZH_SMP(ZF_, F_, L_) hipLaunchKernelGGL((k_sampler<ZF_, F_, L_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, img, start, end, s, rate, nicp)
+    // few voices: the span as frame ranges at once (see k_sampler); ZH_SAMPLER_RANGES = number of ranges, 0 = never
+    uint32_t ch = end > start ? replay_range_frames(m->n, end - start, "ZH_SAMPLER_RANGES") : 0;
+    const bool ranges = ch != 0;
+    if (!ranges) ch = end > start ? end - start : 1;
+    const float *t_in = m->t();
+    float *t_out = ranges ? reinterpret_cast<float *>(m->cnt[m->cur ^ 1]) : m->t();
+    const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, ranges ? (end - start + ch - 1) / ch : 1);
+#define ZH_SMP(ZF_, F_, L_) hipLaunchKernelGGL((k_sampler<ZF_, F_, L_>), grid, dim3(kSeqBlock), 0, st, t_in, t_out, m->n, img, start, end, ch, s, rate, nicp)
 #define ZH_SMP_L(ZF_, F_) do { if (s.loop) ZH_SMP(ZF_, F_, true); else ZH_SMP(ZF_, F_, false); } while (0)
 #define ZH_SMP_F(ZF_) do { switch (fmt) { case kSampleEmpty: ZH_SMP_L(ZF_, kSampleEmpty); break; case ZH_SAMPLE_U8: ZH_SMP_L(ZF_, ZH_SAMPLE_U8); break; \
         case ZH_SAMPLE_S16_LSB: ZH_SMP_L(ZF_, ZH_SAMPLE_S16_LSB); break; case ZH_SAMPLE_S24_LSB: ZH_SMP_L(ZF_, ZH_SAMPLE_S24_LSB); break; \
@@ -823,6 +929,7 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
 #undef ZH_SMP_F
 #undef ZH_SMP_L
 #undef ZH_SMP
+    if (ranges) { zh_flipper_painted(m); m->cur ^= 1; }
     return zh_launch_status();
 }
 

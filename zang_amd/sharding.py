@@ -72,15 +72,38 @@ class SlotExchange:
         base = C.c_void_p()
         handle = (C.c_uint8 * 64)()
         payload = [None]
+        err = None
         if self.rank == 0:
-            abi.check(self.lib.zh_ipc_alloc(ctx.handle, self.world * self.stride * 4, C.byref(base), handle), "zh_ipc_alloc")
-            payload = [bytes(handle)]
-        dist.broadcast_object_list(payload, src=0, group=self.ctl)
+            rc = self.lib.zh_ipc_alloc(ctx.handle, self.world * self.stride * 4, C.byref(base), handle)
+            if rc == abi.ZH_OK:
+                payload = [bytes(handle)]
+            else:
+                err = "zh_ipc_alloc failed: %d" % rc
+        dist.broadcast_object_list(payload, src=0, group=self.ctl)         # None = the root could not allocate
         if self.rank != 0:
-            C.memmove(handle, payload[0], 64)
-            abi.check(self.lib.zh_ipc_open(ctx.handle, handle, C.byref(base)), "zh_ipc_open")
-        self.base = base.value
+            if payload[0] is None:
+                err = "the root rank could not allocate the slot block"
+            else:
+                C.memmove(handle, payload[0], 64)
+                rc = self.lib.zh_ipc_open(ctx.handle, handle, C.byref(base))
+                if rc != abi.ZH_OK:
+                    err = "zh_ipc_open failed: %d" % rc
+                    base = C.c_void_p()
+        # every rank learns whether EVERY rank is set up: a rank that failed alone would otherwise leave the others
+        # waiting for it in the first host barrier of finish()
+        import torch
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.ctl)
+        self.base = base.value or 0
         self.owner = self.rank == 0
+        if int(ok.item()) == 0:
+            if self.base:
+                if self.owner:
+                    self.lib.zh_free(ctx.handle, C.c_void_p(self.base))
+                else:
+                    self.lib.zh_ipc_close(ctx.handle, C.c_void_p(self.base))
+                self.base = 0
+            raise abi.ZangHipError("SlotExchange: " + (err or "another rank could not map the root's slot block"))
 
     def slot(self, rank=None):
         r = self.rank if rank is None else rank
