@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of one buffer")
     ap.add_argument("--no-config5", action="store_true", help="N=1: skip the extra config-5 shard measurement")
     ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write exchange measured beside the RCCL one")
+    ap.add_argument("--p2p-timeout", type=float, default=180.0, help="N>1: seconds the direct-write comparison may take before the run is ended with the line measured so far")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
     return ap.parse_args(argv)
@@ -717,7 +718,19 @@ def main():
         out["scaling_factor"] = value / single
         out["realtime_voices_48k"] = value / SR
         if not args.no_p2p and wl.slots is None:
-            # the alternative SURVEY.md 8e asks to measure beside the collective
+            # the alternative SURVEY.md 8e asks to measure beside the collective.  It is the comparison, not the
+            # measurement: if it stalls (a peer mapping or a host barrier that never returns on some machine), a watchdog
+            # on EVERY rank ends the run after `--p2p-timeout` seconds -- rank 0 prints the line it already has first.
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out["p2p_direct"] = {"error": f"no result within {args.p2p_timeout:.0f} s; the run was ended by the watchdog"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            dog = threading.Timer(args.p2p_timeout, give_up)
+            dog.daemon = True
+            dog.start()
             try:
                 alt = Runner("nice_mix", V, K, exchange="p2p", slots=True)
                 alt.warm(48)
@@ -732,8 +745,9 @@ def main():
                                      "what": "mixdown kernels store into the root GPU's per-rank slots (HIP IPC mapping); per batch: stream sync + host "
                                              "barrier, root adds the slots in rank order, host barrier; bit-reproducible"}
                 alt.close()
-            except Exception as e:          # noqa: BLE001  (reported, never fatal: it is the comparison, not the measurement)
+            except Exception as e:          # noqa: BLE001  (reported, never fatal)
                 out["p2p_direct"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            dog.cancel()
 
     if world == 1 and args.workload == "pulseosc" and not args.eager:
         # The same buffers painted through zh_pulseosc_paint_batch: B consecutive 1024-frame paints (same span and params,
