@@ -132,16 +132,133 @@ def test_fuzz_noise_filter(ctx, oracle, seed):
     assert [[int(x) for x in row] for row in gs["noise"]["r"]] == [list(n.r) for n in nzs]
 
 
+def _calls_long(rng, n):
+    """Like _calls, biased towards spans of 128 frames and more (the frame-range forms need them) with short and empty ones mixed in."""
+    out = []
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.35:
+            a, b = 0, F
+        elif r < 0.75:
+            a = int(rng.integers(0, F - 128)); b = int(rng.integers(a + 128, F + 1))
+        elif r < 0.9:
+            a, b = sorted(int(x) for x in rng.integers(0, F + 1, 2))
+        else:
+            a = b = int(rng.integers(0, F + 1))
+        out.append((a, b, bool(rng.random() < 0.5)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_noise(ctx, oracle, seed):
+    """Noise module: white (frame ranges with jump-ahead for long spans, sequential for short ones) and pink, += and ZERO_FIRST."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(4000 + seed)
+    V = int(rng.choice([1, 5, 64, 100, 257, 300]))
+    first = int(rng.integers(0, 100000))
+    L = oracle.lib()
+    nzs = []
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + v); nzs.append(nz)
+    m = mod.Noise(V, ctx, first_seed=first)
+    img = util.rng_buffers(seed + 120, V, F)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 7)):
+        color = int(rng.random() < 0.3)
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        for v in range(V):
+            L.zo_noise_paint(C.byref(nzs[v]), a, b, oracle.fptr(ref[v]), color)
+        out = util.to_image(img)
+        m.paint(zang.Span(a, b), [out], [], False, m.Params(color), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"noise seed {seed} call {k} V={V} span {(a, b)} zf={zf} color={color}")
+        img = ref
+    assert [[int(x) for x in row] for row in m.state()["r"]] == [list(n.r) for n in nzs]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_sineosc(ctx, oracle, seed):
+    """SineOsc: the four param paths, per-voice frequencies that change between calls, long and short spans (frame ranges /
+    sequential), the phase wrapped once per paint."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(5000 + seed)
+    V = int(rng.choice([1, 7, 64, 130, 260]))
+    L = oracle.lib()
+    sts = []
+    for v in range(V):
+        st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st)); sts.append(st)
+    m = mod.SineOsc(V, ctx)
+    img = util.rng_buffers(seed + 150, V, F)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 7)):
+        fb, pb = bool(rng.random() < 0.4), bool(rng.random() < 0.4)
+        freq = rng.uniform(-50.0, 6000.0, V).astype(np.float32)
+        fbuf = rng.uniform(0.0, 4000.0, (V, F)).astype(np.float32); pbuf = rng.uniform(-2.0, 2.0, (V, F)).astype(np.float32)
+        ph = float(rng.uniform(-1, 1))
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        for v in range(V):
+            L.zo_sineosc_paint(C.byref(sts[v]), a, b, oracle.fptr(ref[v]), SR, oracle.buffer(fbuf[v]) if fb else oracle.constant(freq[v]),
+                               oracle.buffer(pbuf[v]) if pb else oracle.constant(ph))
+        out = util.to_image(img)
+        m.paint(zang.Span(a, b), [out], [], False,
+                m.Params(SR, zang.buffer(util.to_image(fbuf)) if fb else zang.constant(util.dev(freq)),
+                         zang.buffer(util.to_image(pbuf)) if pb else zang.constant(ph)), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"sineosc seed {seed} call {k} V={V} span {(a, b)} zf={zf} fb={fb} pb={pb}")
+        img = ref
+    util.assert_bitexact(m.state()["t"].astype(np.float32), np.array([s.t for s in sts], np.float32), "t")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_sampler(ctx, oracle, seed):
+    """Sampler: formats, loop / no loop, per-voice output rates (ratio ~ 1, resampling both ways, negative), note restarts."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(6000 + seed)
+    V = int(rng.choice([1, 9, 64, 96, 200]))
+    fmt = int(rng.integers(0, 4)); loop = bool(rng.random() < 0.5); channels = int(rng.integers(1, 3)); in_rate = 44100
+    nbytes = (fmt + 1) * channels * int(rng.integers(200, 1500))
+    data = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    L = oracle.lib()
+    sts = []
+    for v in range(V):
+        st = oracle.Sampler(); L.zo_sampler_init(C.byref(st)); sts.append(st)
+    m = mod.Sampler(V, ctx)
+    smp = m.Sample(channels, in_rate, fmt, util.dev(data))
+    img = util.rng_buffers(seed + 170, V, F)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 6)):
+        rate = rng.uniform(8000, 96000, V).astype(np.float32)
+        rate[rng.random(V) < 0.2] = np.float32(44100.0)
+        rate[rng.random(V) < 0.1] = np.float32(-30000.0)
+        nic = rng.random(V) < 0.25
+        ch = int(rng.integers(0, channels))
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        for v in range(V):
+            p = oracle.SamplerParams(float(rate[v]), channels, in_rate, fmt, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, ch, int(loop))
+            L.zo_sampler_paint(C.byref(sts[v]), a, b, oracle.fptr(ref[v]), int(nic[v]), C.byref(p))
+        out = util.to_image(img)
+        m.paint(zang.Span(a, b), [out], [], util.dev(nic.astype(np.uint8)), m.Params(util.dev(rate), smp, ch, loop), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"sampler seed {seed} call {k} V={V} span {(a, b)} zf={zf} fmt={fmt} loop={loop}")
+        img = ref
+    util.assert_bitexact(m.state()["t"].astype(np.float32), np.array([s.t for s in sts], np.float32), "t")
+
+
 def test_fuzz_again_with_the_single_wave_forms():
-    """The same random cases through k_nice / k_noise_filter (the forms used above 65,536 voices)."""
+    """The same random cases through the lane-per-voice sequential forms (k_nice, k_noise_filter, k_noise, k_sineosc, the
+    one-range k_sampler: what runs above the voice-count limits of the pipelined / frame-range forms)."""
     import os
     import subprocess
     import sys
     if os.environ.get("ZH_FUZZ_CHILD"):
         pytest.skip("already the rerun")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZH_NICE_PC_MAX="0", ZH_NF_PC_MAX="0", ZH_FUZZ_CHILD="1")
+    env = dict(os.environ, ZH_NICE_PC_MAX="0", ZH_NF_PC_MAX="0", ZH_NF_RING_MAX="0", ZH_NOISE_RANGES="0", ZH_SINE_RANGES="0",
+               ZH_SAMPLER_RANGES="0", ZH_FUZZ_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fuzz.py", "-q", "-m", "gpu"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "14 passed" in r.stdout
+    assert "25 passed" in r.stdout
