@@ -275,21 +275,51 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     }
 }
 
+// Controlled frequency (PulseOsc.zig:116-157).  One kernel, two launch shapes: sequential (grid.y = 1, ch = the span,
+// cnt_in == cnt_out), or -- few voices -- the span as grid.y frame ranges of `ch` frames at once, one wave per
+// (64 voices, range): the phase counter that reaches frame f0 is the start counter plus the `ifreq` of every earlier frame
+// whose frequency is in range (:134-136; u32 wrap-around adds, exact in any order), so a range first sums those (a multiply,
+// a conversion and an add per earlier frame against the divide and ~25 instructions of a painted sample), then paints
+// its frames; the range that ends the span publishes the counter into the other half of the double buffer.
 template <bool ZF>
-__global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(uint32_t *__restrict__ cnt_io, uint32_t V, Img out,
-                                                             uint32_t start, uint32_t end, float srf, float sr8,
+__global__ void __launch_bounds__(kSeqBlock) k_pulseosc_ctrl(const uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ cnt_out, uint32_t V,
+                                                             Img out, uint32_t start, uint32_t end, uint32_t ch, float srf, float sr8,
                                                              CImg freq_b, F32P color_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
     PulseOscLane o;
-    o.cnt = cnt_io[v];
+    o.cnt = cnt_in[v];
     o.srf = srf; o.sr8 = sr8;                                         // host-computed (same IEEE divides)
     pulse_setup_color(o.k, color_p.get(v));
+    {
+        const float *fp = freq_b.p + (size_t)start * freq_b.stride + v;
+        auto skip = [&](float f) ZH_INLINE_LAMBDA {
+            const uint32_t ifreq = zf32_to_u32(srf * f);              // pulse_setup_freq's k.ifreq (dsp.hip.h), PulseOsc.zig:136
+            o.cnt += (f < 0 || f > sr8) ? 0u : ifreq;                 // :134-135: a sample out of range neither paints nor advances
+        };
+        uint32_t i = start;
+        for (; i + 32 <= f0; i += 32, fp += 32 * freq_b.stride) {       // 32 rows in flight: the replay is load-latency-bound otherwise
+            float x[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) x[k] = fp[(size_t)k * freq_b.stride];
+#pragma unroll
+            for (int k = 0; k < 32; k++) skip(x[k]);
+        }
+        for (; i + 8 <= f0; i += 8, fp += 8 * freq_b.stride) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = fp[(size_t)k * freq_b.stride];
+#pragma unroll
+            for (int k = 0; k < 8; k++) skip(x[k]);
+        }
+        for (; i < f0; i++, fp += freq_b.stride) skip(*fp);
+    }
     const float *ins[1] = {freq_b.p};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, start, end,
+    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, f0, f1,
                          [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame_ctrl(x[0], val); });
-    cnt_io[v] = o.cnt;
+    if (f1 == end) cnt_out[v] = o.cnt;
 }
 
 // ------------------------------------------------------------------ TriSawOsc
@@ -354,6 +384,19 @@ static bool osc_prio() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("ZH_OSC_PRIO"); v = e ? atoi(e) : 1; }
     return v != 0;
+}
+// frames per range for the controlled-frequency PulseOsc at small voice counts (0 = sequential); ZH_PULSE_CTRL_RANGES = number
+// of ranges, 0 = never
+static uint32_t osc_ctrl_range_frames(uint32_t V, uint32_t n) {
+    const char *e = getenv("ZH_PULSE_CTRL_RANGES");
+    const int forced = e ? atoi(e) : -1;
+    if (forced == 0 || V == 0 || n < 128 || V > 16384) return 0;
+    const uint32_t waves = (V + 63) / 64;
+    uint32_t want = forced > 0 ? (uint32_t)forced : 2048u / waves;
+    if (want < 2) return 0;
+    if (want > 64) want = 64;
+    const uint32_t ch = ((n + want - 1) / want + 7) / 8 * 8;
+    return (n + ch - 1) / ch >= 2 ? ch : 0;
 }
 static bool osc_no_fc4() {
     static int v = -1;
@@ -502,12 +545,17 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
     } else {
         const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:122
         const float sr8 = p->sample_rate / 8.0f;              // :134
-        uint32_t *c = m->cnt[m->cur];
         const F32P col = mk_f32(p->color);
+        const uint32_t chr = osc_ctrl_range_frames(m->n, end - start);
         for (uint32_t b = 0; b < nb; b++) {
             Img out = mk_img(outputs[b]);
-            if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
-            else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, c, m->n, out, start, end, srf, sr8, mk_cimg(p->freq.buffer), col);
+            const uint32_t *ci = m->cnt[m->cur];
+            uint32_t *co = chr ? m->cnt[m->cur ^ 1] : m->cnt[m->cur];
+            const uint32_t ch = chr ? chr : end - start;
+            const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
+            if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col);
+            else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col);
+            if (chr) { zh_flipper_painted(m); m->cur ^= 1; }
         }
     }
     return zh_launch_status();

@@ -26,18 +26,32 @@
 ZD uint32_t zf2u(float f) { return __float_as_uint(f); }
 ZD float zu2f(uint32_t u) { return __uint_as_float(u); }
 
-// @intFromFloat with NaN / out-of-range DEFINED as v_cvt_u32_f32 / v_cvt_i32_f32 behave.
+// @intFromFloat with NaN / out-of-range DEFINED as v_cvt_u32_f32 / v_cvt_i32_f32 behave (NaN -> 0, saturating).  On the
+// device it IS that one instruction: written out as C++ the three guards became three exec-mask branches per conversion
+// (the controlled-frequency PulseOsc and the Sampler convert once or twice per sample).
 ZD uint32_t zf32_to_u32(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
     if (!(v == v)) return 0u;
     if (v <= 0.0f) return 0u;
     if (v >= 4294967296.0f) return 0xFFFFFFFFu;
     return (uint32_t)v;
+#endif
 }
 ZD int32_t zf32_to_i32(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
     if (!(v == v)) return 0;
     if (v <= -2147483648.0f) return INT32_MIN;
     if (v >= 2147483648.0f) return INT32_MAX;
     return (int32_t)v;
+#endif
 }
 
 // std.math.clamp == @max(lo, @min(v, hi)) as explicit selects (first operand wins ties)
