@@ -172,7 +172,12 @@ def test_nice_paint_mix_stereo(ctx, oracle):
     assert np.array_equal(m1.state(), m2.state()) and np.array_equal(m1.state(), m4.state())
 
 
-def test_pmosc_fused_equals_unfused_oracle(ctx, oracle):
+@pytest.mark.parametrize("form", ["ranges", "sequential"])
+def test_pmosc_fused_equals_unfused_oracle(ctx, oracle, form, monkeypatch):
+    """(At a small voice count a span is painted as frame ranges at once, each range replaying the phase / envelope walk of
+    the earlier frames -- k_pmosc_ranges; ZH_PMOSC_RANGES=0 is the lane-per-voice walk k_pmosc.)"""
+    if form == "sequential":
+        monkeypatch.setenv("ZH_PMOSC_RANGES", "0")
     from zang_amd import modules as mod, zang, workloads
     V = 192
     freq, _, u2, _ = workloads.voice_params(4, 0, V)
