@@ -524,6 +524,9 @@ ZH_API int zh_script_destroy(zh_script *s);
 ZH_API int zh_script_module_create(zh_script *s, const char *name, uint32_t n_voices, uint32_t state_words,
                                    uint64_t first_seed, zh_script_module **out);
 ZH_API int zh_script_module_destroy(zh_script_module *m);
+/* 1 when this module's kernel may be launched as frame ranges at small voice counts (its frame body writes no memory: no
+ * delay ring), 0 otherwise */
+ZH_API int zh_script_module_ranges_ok(zh_script_module *m);
 ZH_API int zh_script_module_get_state(zh_script_module *m, uint32_t *host_words);         /* [word][voice] */
 ZH_API int zh_script_module_set_state(zh_script_module *m, const uint32_t *host_words);
 ZH_API int zh_script_module_paint(zh_script_module *m, uint32_t span_start, uint32_t span_end, const zh_buf *outputs,

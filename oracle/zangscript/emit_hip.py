@@ -37,6 +37,7 @@ class Val:
     payload: "Val" = None          # enum payload (float Val) or None
     count: str = ""                # curve node count expression
     enum: object = None            # BuiltinEnum
+    computed: bool = False         # buf: derives from a module's output or a transcendental function (not just params / constants / + - * /)
 
 
 def f32_literal(x):
@@ -51,6 +52,9 @@ def f32_literal(x):
 STATE_WORDS = {"SineOsc": 1, "PulseOsc": 1, "TriSawOsc": 2, "Noise": 8, "Envelope": 4, "Gate": 0, "Filter": 2,
                "Decimator": 2, "Distortion": 0, "Cycle": 1, "Portamento": 3, "Curve": 4}
 TRACK_WORDS = 3                       # NoteTracker {next_song_event, t} + Trigger {note}
+# the params of a builtin that its state recurrence reads every frame
+STATE_INPUTS = {"SineOsc": ("freq",), "PulseOsc": ("freq",), "TriSawOsc": ("freq",), "Cycle": ("speed",),
+                "Filter": ("input", "cutoff", "res"), "Decimator": ("input",)}
 
 
 class _Kernel:
@@ -65,6 +69,8 @@ class _Kernel:
         self.words = 0
         self.noise_fields = 0
         self.uid = 0
+        self.rings = False             # a delay ring lives in the state blob and is read and written inside the frame body
+        self.walk_reads_computed = False   # a builtin's frame-to-frame state is fed by a value computed in the frame body
 
     def fresh(self, stem):
         self.uid += 1
@@ -82,6 +88,7 @@ class _ModuleCtx:
     def __init__(self, k, module_index, env, outvar, nic, prefix, parent=None):
         self.k, self.module_index, self.env, self.outvar, self.nic, self.prefix = k, module_index, env, outvar, nic, prefix
         self.tnames, self.fnames = {}, {}
+        self.heavy = {}                # temp index -> its current value derives from a module output / transcendental (Val.computed)
         # where the per-paint prologue / epilogue of builtin calls goes: the kernel's own prologue and
         # epilogue, or -- inside a `delay` body, which the reference paints chunk by chunk -- the
         # chunk's; `rel` / `length` are the frame index within, and the length of, that paint call
@@ -109,7 +116,7 @@ class HipEmitter:
     def val(self, mc, r):
         k = r.kind
         if k == "temp_buffer":
-            return Val("buf", mc.tname(r.index))
+            return Val("buf", mc.tname(r.index), computed=mc.heavy.get(r.index, True))
         if k == "temp_float":
             return Val("float", mc.fname(r.index))
         if k == "literal_number":
@@ -144,10 +151,11 @@ class HipEmitter:
 
     # ---- destinations
     @staticmethod
-    def put(mc, d, expr, zero_first):
+    def put(mc, d, expr, zero_first, heavy=False):
         """`dest (+)= expr` with the reference's zeroing: temps are assigned (after zang.zero when the
-        op accumulates), outputs accumulate."""
+        op accumulates), outputs accumulate.  `heavy`: Val.computed of the value written."""
         if d.kind == "temp":
+            mc.heavy[d.index] = heavy
             t = mc.tname(d.index)
             if zero_first:
                 return ["%s = 0.0f;" % t, "%s = %s + (%s);" % (t, t, expr)]
@@ -163,6 +171,12 @@ class HipEmitter:
         k = mc.k
         name = callee.builtin_name
         a = {p.name: self.val(mc, r) for p, r in zip(callee.params, args)}
+        # Launching the kernel as frame ranges pays only when replaying the state walk is cheap: not when a computed
+        # buffer (an oscillator's output, a filtered signal ...) feeds a builtin's state -- an oscillator's or a cycle's
+        # frequency, a filter's or a decimator's input.
+        for pname in STATE_INPUTS.get(name, ()):
+            if a[pname].kind == "buf" and a[pname].computed:
+                k.walk_reads_computed = True
         o = k.fresh("m")
         w = k.alloc(STATE_WORDS[name])
         decl, pro, frame = k.pro, mc.begin_sink, []      # lane object + state loads | per-paint prologue | per frame
@@ -299,6 +313,7 @@ class HipEmitter:
         # zang.zero(dest) for a temp, then the module's `+=` (codegen_zig.zig:284-291)
         d = ins.out
         if d.kind == "temp":
+            mc.heavy[d.index] = True                                 # a module's output
             t = mc.tname(d.index)
             frame.insert(0, "%s = 0.0f;" % t)
             target = t
@@ -312,11 +327,12 @@ class HipEmitter:
     def instruction(self, mc, mr, ins):
         k, kind = mc.k, ins.kind
         if kind == "copy_buffer":
-            k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
+            src = self.val(mc, ins.src)
+            k.frame += self.put(mc, ins.out, src.expr, False, src.computed)
         elif kind == "float_to_buffer":
             k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
         elif kind == "cob_to_buffer":
-            k.frame += self.put(mc, ins.out, mc.env[ins.in_self_param].expr, False)
+            k.frame += self.put(mc, ins.out, mc.env[ins.in_self_param].expr, False, mc.env[ins.in_self_param].computed)
         elif kind in ("arith_float", "arith_float_float"):
             expr = (self.UN[ins.op] % self.val(mc, ins.a).expr if kind == "arith_float"
                     else self.BIN[ins.op] % (self.val(mc, ins.a).expr, self.val(mc, ins.b).expr))
@@ -326,15 +342,18 @@ class HipEmitter:
                 k.pro.append("float %s = 0.0f;" % mc.fname(ins.out))
                 mc.begin_sink.append("%s = %s;" % (mc.fname(ins.out), expr))
         elif kind == "arith_buffer":
-            k.frame += self.put(mc, ins.out, self.UN[ins.op] % self.val(mc, ins.a).expr, False)
+            va = self.val(mc, ins.a)
+            k.frame += self.put(mc, ins.out, self.UN[ins.op] % va.expr, False, va.computed or ins.op in ("sin", "cos"))
         elif kind in ("arith_float_buffer", "arith_buffer_float", "arith_buffer_buffer"):
-            a, b = self.val(mc, ins.a).expr, self.val(mc, ins.b).expr
+            va, vb = self.val(mc, ins.a), self.val(mc, ins.b)
+            a, b = va.expr, vb.expr
+            heavy = va.computed or vb.computed or ins.op == "pow"
             if ins.op in ("add", "mul"):
                 if kind == "arith_float_buffer":
                     a, b = b, a                                  # addScalar / multiplyScalar(dest, buffer, float)
-                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), True)
+                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), True, heavy)
             else:
-                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), False)
+                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), False, heavy)
         elif kind == "call":
             callee_index = mr.fields[ins.field_index]
             callee = self.s.modules[callee_index]
@@ -344,6 +363,7 @@ class HipEmitter:
                 env = [self.val(mc, r) for r in ins.args]
                 d = ins.out
                 if d.kind == "temp":
+                    mc.heavy[d.index] = True
                     outvar = mc.tname(d.index)
                     k.frame.append("%s = 0.0f;" % outvar)
                 else:
@@ -388,6 +408,7 @@ class HipEmitter:
                 self.instruction(mc, mr, sub)
         finally:
             mc.begin_sink, mc.end_sink, mc.rel, mc.length, k.frame = saved
+        k.rings = True
         slot = "L.state[(size_t)(%du + %s_idx) * V + v]" % (w_ring, d)
         k.frame += head
         if begins:
@@ -567,7 +588,8 @@ class HipEmitter:
             # is shared by two CUs
             unroll = int(os.environ.get("ZH_SCRIPT_UNROLL", "0")) or (8 if len(k.frame) <= 40 else 4 if len(k.frame) <= 100 else 2)
             I = "    "
-            out += ["", 'extern "C" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {' % name,
+            out += ["", 'extern "C" __device__ const uint32_t zs_ranges_ok_%s = %du;' % (name, 0 if (k.rings or k.walk_reads_computed) else 1),
+                    'extern "C" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {' % name,
                     I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;", I + "if (v >= V) return;",
                     I + "for (uint32_t w = 0; w < %du; w++) st[(size_t)w * V + v] = 0u;" % k.words]
             for item in k.init:

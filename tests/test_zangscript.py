@@ -570,3 +570,64 @@ end
     with pytest.raises(ValueError):                                   # a per-voice duration is not a script-module value
         per_voice = zang.PaintCurve.cubed(torch.full((n,), 0.002, device="cuda"))
         prog.module("Shaped", n).paint(sp, [ctx.image(frames, n, fill=0.0)], None, True, {"sample_rate": 48000.0, "attack": per_voice, "note_on": on})
+
+
+def _random_params(mod, rng, nv, nf):
+    """A plausible random value for every exported param of a script module (by declared kind)."""
+    vals = {}
+    for name, kind, enum in mod.params:
+        if name == "sample_rate":
+            vals[name] = 48000.0
+        elif kind == "constant":
+            vals[name] = rng.uniform(0.05, 0.95, nv).astype(np.float32) if name in ("color", "cut", "drive", "mix") else \
+                rng.uniform(40.0, 3000.0, nv).astype(np.float32)
+        elif kind == "boolean":
+            vals[name] = rng.random(nv) < 0.6
+        elif kind == "constant_or_buffer":
+            vals[name] = rng.uniform(40.0, 3000.0, (nv, nf)).astype(np.float32) if rng.random() < 0.5 else rng.uniform(40.0, 3000.0, nv).astype(np.float32)
+        elif kind == "buffer":
+            vals[name] = rng.uniform(-1.0, 1.0, (nv, nf)).astype(np.float32)
+        elif kind == "curve":
+            vals[name] = [(0.0, 440.0), (0.001, 880.0), (0.003, 110.0), (0.005, 660.0)]
+        else:                                                            # one_of
+            label = {"PaintCurve": ("cubed", 0.002), "FilterType": ("low_pass", None), "NoiseColor": ("white", None),
+                     "DistortionType": ("overdrive", None), "InterpolationFunction": ("smoothstep", None)}[enum]
+            vals[name] = label
+    return vals
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Jingle",
+                                  "LateJingle", "Trig", "Shapes", "Echo", "EchoLead"])
+def test_gpu_script_kernels_as_frame_ranges(ctx, name, monkeypatch):
+    """A generated kernel at a small voice count is launched as frame ranges at once (gridDim.y > 1): every range runs the
+    frame body over the earlier frames with the output discarded (the state walk survives, the output math is dead code)
+    and then paints its own frames.  Same module, same calls, once with ZH_SCRIPT_RANGES=0 (the lane-per-voice walk that the
+    other tests hold against the interpreter) and once ranged: images and state blobs must be identical.  Modules whose
+    body writes a delay ring (Echo, EchoLead) or whose state walk reads computed signals (Bell's FM, Hiss's filter ...) are
+    flagged by the emitter and always take the sequential launch (both paints are then the same launch)."""
+    import torch
+    from tests.util import to_image
+    from zang_amd import script, zang
+    nv, nf = 200, 416
+    prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
+    a, b = prog.module(name, nv, 77), prog.module(name, nv, 77)
+    # ranged: no delay ring, and no module output / transcendental feeding a builtin's state (an FM oscillator, a filter's
+    # input): replaying such a walk costs as much as painting, so the emitter leaves those kernels sequential
+    assert b.frame_ranges_ok == (name in ("Pluck", "CycleSine", "Crush", "Maths", "Jingle", "LateJingle", "Trig", "Shapes"))
+    rng = np.random.default_rng(sum(ord(c) for c in name))
+    base = rng.uniform(-1, 1, (nv, nf)).astype(np.float32)
+    img_a, img_b = to_image(base), to_image(base)
+    for k, (s, e, zf) in enumerate([(0, nf, True), (0, nf, False), (40, 300, False), (300, nf, True), (0, nf, False)]):
+        vals = _random_params(a, rng, nv, nf)
+        nic = rng.random(nv) < 0.3
+        dev = {kk: _device_value(None, vv) for kk, vv in vals.items()}
+        nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda()
+        monkeypatch.setenv("ZH_SCRIPT_RANGES", "0")
+        a.paint(zang.Span(s, e), [img_a], None, nic_dev, dev, zero_first=zf)
+        monkeypatch.delenv("ZH_SCRIPT_RANGES")
+        b.paint(zang.Span(s, e), [img_b], None, nic_dev, dev, zero_first=zf)
+        ctx.sync()
+        assert torch.equal(img_a.view(torch.int32), img_b.view(torch.int32)), f"{name}: image differs after paint {k}"
+        assert np.array_equal(a.get_state(), b.get_state()), f"{name}: state differs after paint {k}"
+    prog.close()

@@ -381,6 +381,7 @@ SIGNATURES = {
     "zh_script_destroy": (C.c_int, [vp]),
     "zh_script_module_create": (C.c_int, [vp, C.c_char_p, u32, u32, u64, P(vp)]),
     "zh_script_module_destroy": (C.c_int, [vp]),
+    "zh_script_module_ranges_ok": (C.c_int, [vp]),
     "zh_script_module_get_state": (C.c_int, [vp, vp]),
     "zh_script_module_set_state": (C.c_int, [vp, vp]),
     "zh_script_module_paint": (C.c_int, [vp, u32, u32, P(Buf), Bool, P(ScriptParam), u32, u32]),

@@ -9,14 +9,28 @@
 #include "envelope.hip.h"
 #include "voices.hip.h"
 
+// The [word][voice] state blob of a script module.  A kernel launched with gridDim.y > 1 paints the span as gridDim.y
+// frame ranges at once (zs_frame_loop below): every range loads the span's start state from `cur`, and only the range
+// that ends the span stores -- into `next`, which the loader copies over `cur` afterwards (script.hip).
+struct ZsState {
+    uint32_t *cur, *next;
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
+    __device__ __forceinline__ uint32_t &operator[](size_t i) const { return cur[i]; }     // delay rings: read and written in place
+#endif
+};
+
 struct ZsLaunch {
     uint32_t V, start, end, flags;
     float *out;
     uint32_t ostride, n_params;
-    uint32_t *state;                       // [word][voice]
+    ZsState state;
     BoolP nic;                             // note_id_changed
     zh_script_param p[ZH_SCRIPT_MAX_PARAMS];
 };
+
+// frames per range of a launch with `ranges` = gridDim.y > 1 frame ranges over n frames (the loader picks `ranges` so that
+// this reproduces the length it planned with, script.hip)
+__host__ __device__ inline uint32_t zs_range_frames(uint32_t n, uint32_t ranges) { return ((n + ranges - 1) / ranges + 7) / 8 * 8; }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
 __device__ const float zs_zero_row[1] = {0.0f};
@@ -43,6 +57,18 @@ __device__ __forceinline__ void zs_st_u64(uint32_t *st, uint32_t word, uint32_t 
     st[(size_t)(word + 1) * V + v] = (uint32_t)(x >> 32);
 }
 
+// the paint kernels' accessors (the generated text says `L.state`): loads from the start state; stores as described at ZsState
+__device__ __forceinline__ float zs_ld_f(const ZsState &s, uint32_t word, uint32_t V, uint32_t v) { return zs_ld_f(s.cur, word, V, v); }
+__device__ __forceinline__ uint32_t zs_ld_u(const ZsState &s, uint32_t word, uint32_t V, uint32_t v) { return zs_ld_u(s.cur, word, V, v); }
+__device__ __forceinline__ uint64_t zs_ld_u64(const ZsState &s, uint32_t word, uint32_t V, uint32_t v) { return zs_ld_u64(s.cur, word, V, v); }
+__device__ __forceinline__ uint32_t *zs_store_target(const ZsState &s) {
+    if (gridDim.y > 1) return blockIdx.y + 1 == gridDim.y ? s.next : nullptr;
+    return s.cur;
+}
+__device__ __forceinline__ void zs_st_f(const ZsState &s, uint32_t word, uint32_t V, uint32_t v, float x) { if (uint32_t *p = zs_store_target(s)) zs_st_f(p, word, V, v, x); }
+__device__ __forceinline__ void zs_st_u(const ZsState &s, uint32_t word, uint32_t V, uint32_t v, uint32_t x) { if (uint32_t *p = zs_store_target(s)) zs_st_u(p, word, V, v, x); }
+__device__ __forceinline__ void zs_st_u64(const ZsState &s, uint32_t word, uint32_t V, uint32_t v, uint64_t x) { if (uint32_t *p = zs_store_target(s)) zs_st_u64(p, word, V, v, x); }
+
 // std.math.max / min as the generated Zig calls them (codegen_zig.zig:186-187): comparison selects
 __device__ __forceinline__ float zs_max(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b; }
@@ -53,9 +79,26 @@ template <int CH, int NIN, class F>
 __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t v, size_t ostride, const float *const *in,
                                               const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, F &&f) {
     constexpr int NI = NIN > 0 ? NIN : 1;
-    const uint32_t nfull = (end - start) / CH;
     const uint32_t voff = v * 4u;                                   // rows through buffer descriptors: lanes.hip.h (zrow_*)
     const uint32_t orow = (uint32_t)ostride * 4u;
+    if (gridDim.y > 1) {
+        // Few voices: this workgroup paints one frame range [f0, f1) of the span.  The state that reaches f0 is the start
+        // state after the frames before it, so the body first runs over those frames with its output discarded: what only
+        // feeds the output (a sine, a curve, the mix) is dead code there and the compiler drops it; what feeds the state
+        // (phase additions, envelope clocks, filter recurrences, generators) stays.  Same operations on the same values as
+        // the sequential walk => same state => same bits.
+        const uint32_t ch = zs_range_frames(end - start, gridDim.y);
+        const uint32_t f0 = min(start + blockIdx.y * ch, end), f1 = min(f0 + ch, end);
+        for (uint32_t r = start; r < f0; r++) {
+            float x[NI];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) x[j] = zrow_load<1>(zrow_rsrc(in[j], istride[j], r), ivoff[j], 0);
+            float o = 0.0f;
+            f(r, x, o);
+        }
+        start = f0; end = f1;
+    }
+    const uint32_t nfull = (end - start) / CH;
     float oc[CH], xc[NI][CH];
     uint32_t i = start;
     auto load = [&](uint32_t base, float (&o)[CH], float (&x)[NI][CH]) ZH_INLINE_LAMBDA {

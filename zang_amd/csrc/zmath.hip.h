@@ -83,8 +83,12 @@ __device__ static const double ZM_PIO2[8] = {
 };
 
 // Payne-Hanek reduction (musl __rem_pio2_large with nx = 1, prec = 0).  Kept out of line:
-// it is the cold path and its work arrays live in scratch.
-__device__ __noinline__ static int zrem_pio2_large1(double x0, double *y, int e0) {
+// it is the cold path and its work arrays live in scratch.  Result by value and declared `pure` (it reads its arguments
+// and the constant tables, writes nothing the caller can see): a call whose result is unused can then be deleted -- the
+// frame-range launches of generated kernels rely on that to drop a sine that only feeds the discarded output
+// (script_rt.hip.h zs_frame_loop); through an out-pointer the call kept every such sine alive.
+struct ZRemLarge { int n; double y; };
+__device__ __noinline__ __attribute__((pure)) static ZRemLarge zrem_pio2_large1(double x0, int e0) {
     int32_t jz, jv, carry, n, iq[20], i, j, k, q0, ih;
     const int32_t jk = 3;
     double z, fw, f[20], fq[20], q[20];
@@ -160,8 +164,7 @@ __device__ __noinline__ static int zrem_pio2_large1(double x0, double *y, int e0
     }
     fw = 0.0;
     for (i = jz; i >= 0; i--) fw += fq[i];
-    y[0] = ih == 0 ? fw : -fw;
-    return n & 7;
+    return ZRemLarge{n & 7, ih == 0 ? fw : -fw};
 }
 
 ZD int zrem_pio2f(float x, double *y) {
@@ -180,11 +183,10 @@ ZD int zrem_pio2f(float x, double *y) {
     if (ix >= 0x7f800000) { *y = x - x; return 0; }
     int sign = ui >> 31;
     int e0 = (int)(ix >> 23) - (0x7f + 23);
-    double ty;
-    int n = zrem_pio2_large1((double)zu2f(ix - ((uint32_t)e0 << 23)), &ty, e0);
-    if (sign) { *y = -ty; return -n; }
-    *y = ty;
-    return n;
+    const ZRemLarge big = zrem_pio2_large1((double)zu2f(ix - ((uint32_t)e0 << 23)), e0);
+    if (sign) { *y = -big.y; return -big.n; }
+    *y = big.y;
+    return big.n;
 }
 
 // musl sinf / cosf (what Zig's std.math.sin / cos are ported from): reduce x to y in [-pi/4, pi/4] with

@@ -335,6 +335,7 @@ struct Val {
     bool tag_literal = false;
     std::shared_ptr<Val> payload;  // enum payload (float) or null
     std::string count;             // curve node count expression
+    bool computed = false;         // buf: derives from a module's output or a transcendental function (not just params / constants / + - * /)
 };
 
 size_t state_words(const std::string &name) {
@@ -357,6 +358,8 @@ struct Kernel {
     Lines temps;
     std::vector<size_t> rows;
     size_t words = 0, noise_fields = 0, uid = 0;
+    bool rings = false;            // a delay ring lives in the state blob and is read and written inside the frame body
+    bool walk_reads_computed = false;   // a builtin's frame-to-frame state is fed by a value computed in the frame body
     std::string fresh(const std::string &stem) { uid++; return stem + std::to_string(uid); }
     size_t alloc(size_t n) { const size_t w = words; words += n; return w; }
 };
@@ -367,6 +370,7 @@ struct ModuleCtx {
     std::vector<Val> env;
     std::string outvar, nic, prefix;
     std::map<size_t, std::string> tnames;
+    std::map<size_t, bool> heavy;  // temp index -> its current value derives from a module output / transcendental (Val.computed)
     Lines *begin_sink, *end_sink;
     std::string rel = "(i - L.start)", length = "SPAN_LEN";
     const std::map<size_t, Val> *track = nullptr;
@@ -395,7 +399,12 @@ public:
     Val val(ModuleCtx &mc, const Res &r) {
         Val v;
         switch (r.kind) {
-        case RK::temp_buffer: v.kind = Val::buf; v.expr = mc.tname(r.index); return v;
+        case RK::temp_buffer: {
+            v.kind = Val::buf; v.expr = mc.tname(r.index);
+            auto it = mc.heavy.find(r.index);
+            v.computed = it == mc.heavy.end() ? true : it->second;
+            return v;
+        }
         case RK::temp_float: v.kind = Val::flt; v.expr = mc.fname(r.index); return v;
         case RK::literal_number: v.kind = Val::flt; v.expr = f32_literal(r.num.value); return v;
         case RK::literal_boolean: v.kind = Val::boolean; v.expr = r.bval ? "true" : "false"; return v;
@@ -417,8 +426,9 @@ public:
         return v.tag;
     }
     static std::string enum_payload(const Val &v) { return v.payload ? v.payload->expr : "0.0f"; }
-    static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first) {
+    static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy = false) {
         if (!d.output) {
+            mc.heavy[d.index] = heavy;
             const std::string t = mc.tname(d.index);
             if (zero_first) return {t + " = 0.0f;", t + " = " + t + " + (" + expr + ");"};
             return {t + " = " + expr + ";"};
@@ -447,6 +457,20 @@ public:
         const std::string &name = callee.builtin_name;
         std::map<std::string, Val> a;
         for (size_t i = 0; i < callee.params.size(); i++) a[callee.params[i].name] = val(mc, args[i]);
+        // Launching the kernel as frame ranges pays only when replaying the state walk is cheap: not when a computed
+        // buffer (an oscillator's output, a filtered signal ...) feeds a builtin's state -- an oscillator's or a cycle's
+        // frequency, a filter's or a decimator's input.
+        {
+            static const std::map<std::string, std::vector<std::string>> state_inputs = {
+                {"SineOsc", {"freq"}}, {"PulseOsc", {"freq"}}, {"TriSawOsc", {"freq"}}, {"Cycle", {"speed"}},
+                {"Filter", {"input", "cutoff", "res"}}, {"Decimator", {"input"}}};
+            auto si = state_inputs.find(name);
+            if (si != state_inputs.end())
+                for (const std::string &pn : si->second) {
+                    auto it = a.find(pn);
+                    if (it != a.end() && it->second.kind == Val::buf && it->second.computed) k.walk_reads_computed = true;
+                }
+        }
         const std::string o = k.fresh("m");
         const size_t w = k.alloc(state_words(name));
         Lines &decl = k.pro, &pro = *mc.begin_sink, &ends = *mc.end_sink, &epi = k.epi_stores;
@@ -583,6 +607,7 @@ public:
         // zang.zero(dest) for a temp, then the module's `+=` (codegen_zig.zig:284-291)
         std::string target;
         if (!ins.out.output) {
+            mc.heavy[ins.out.index] = true;                          // a module's output
             target = mc.tname(ins.out.index);
             frame.insert(frame.begin(), target + " = 0.0f;");
         } else {
@@ -598,8 +623,9 @@ public:
     void instruction(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
         Kernel &k = mc.k;
         switch (ins.kind) {
-        case IK::copy_buffer: case IK::float_to_buffer: append(k.frame, put(mc, ins.out, val(mc, ins.src).expr, false)); break;
-        case IK::cob_to_buffer: append(k.frame, put(mc, ins.out, mc.env[ins.in_self_param].expr, false)); break;
+        case IK::copy_buffer: { const Val src = val(mc, ins.src); append(k.frame, put(mc, ins.out, src.expr, false, src.computed)); break; }
+        case IK::float_to_buffer: append(k.frame, put(mc, ins.out, val(mc, ins.src).expr, false)); break;
+        case IK::cob_to_buffer: append(k.frame, put(mc, ins.out, mc.env[ins.in_self_param].expr, false, mc.env[ins.in_self_param].computed)); break;
         case IK::arith_float: case IK::arith_float_float: {
             const std::string expr = ins.kind == IK::arith_float ? un(ins.op, val(mc, ins.a).expr) : bin(ins.op, val(mc, ins.a).expr, val(mc, ins.b).expr);
             if (mc.begin_sink == &k.pro) {
@@ -610,14 +636,20 @@ public:
             }
             break;
         }
-        case IK::arith_buffer: append(k.frame, put(mc, ins.out, un(ins.op, val(mc, ins.a).expr), false)); break;
+        case IK::arith_buffer: {
+            const Val va = val(mc, ins.a);
+            append(k.frame, put(mc, ins.out, un(ins.op, va.expr), false, va.computed || ins.op == "sin" || ins.op == "cos"));
+            break;
+        }
         case IK::arith_float_buffer: case IK::arith_buffer_float: case IK::arith_buffer_buffer: {
-            std::string a = val(mc, ins.a).expr, b = val(mc, ins.b).expr;
+            const Val va = val(mc, ins.a), vb = val(mc, ins.b);
+            std::string a = va.expr, b = vb.expr;
+            const bool heavy = va.computed || vb.computed || ins.op == "pow";
             if (ins.op == "add" || ins.op == "mul") {
                 if (ins.kind == IK::arith_float_buffer) std::swap(a, b);       // addScalar / multiplyScalar(dest, buffer, float)
-                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), true));
+                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), true, heavy));
             } else {
-                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), false));
+                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), false, heavy));
             }
             break;
         }
@@ -628,7 +660,7 @@ public:
             std::vector<Val> env;
             for (const Res &r : ins.args) env.push_back(val(mc, r));
             std::string outvar;
-            if (!ins.out.output) { outvar = mc.tname(ins.out.index); k.frame.push_back(outvar + " = 0.0f;"); }
+            if (!ins.out.output) { mc.heavy[ins.out.index] = true; outvar = mc.tname(ins.out.index); k.frame.push_back(outvar + " = 0.0f;"); }
             else outvar = mc.outvar;
             ModuleCtx sub(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", &mc);
             module_body(sub);
@@ -667,6 +699,7 @@ public:
         body.swap(k.frame);
         k.frame.swap(saved_frame);
         mc.begin_sink = sb; mc.end_sink = se; mc.rel = srel; mc.length = slen;
+        k.rings = true;
         const std::string slot = strf("L.state[(size_t)(%zuu + %s_idx) * V + v]", w_ring, d.c_str());
         append(k.frame, head);
         if (!begins.empty()) { k.frame.push_back("if (" + rel + " == 0u) {"); append(k.frame, indent(begins)); k.frame.push_back("}"); }
@@ -911,6 +944,9 @@ public:
             const std::string I = "    ";
             const char *nc = name.c_str();
             out.push_back("");
+            // 1: the paint kernel may be launched as frame ranges (script_rt.hip.h zs_frame_loop); 0: its frame body writes memory
+            // (a delay ring), or replaying its state walk would cost as much as painting (see call_builtin)
+            out.push_back(strf("extern \"C\" __device__ const uint32_t zs_ranges_ok_%s = %uu;", nc, (k.rings || k.walk_reads_computed) ? 0u : 1u));
             out.push_back(strf("extern \"C\" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {", nc));
             out.push_back(I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;");
             out.push_back(I + "if (v >= V) return;");

@@ -172,6 +172,11 @@ class ScriptModule:
                   "zh_script_module_paint")
         self._keep = (keep, outputs, note_id_changed)
 
+    @property
+    def frame_ranges_ok(self):
+        """True when the library may launch this module's kernel as frame ranges at small voice counts (no delay ring)."""
+        return bool(self.lib.zh_script_module_ranges_ok(self.handle))
+
     def get_state(self):
         a = np.zeros((self.meta["state_words"], self.n), np.uint32)
         abi.check(self.lib.zh_script_module_get_state(self.handle, a.ctypes.data_as(C.c_void_p)), "zh_script_module_get_state")
