@@ -112,6 +112,16 @@ struct NiceLaneT {
         cnt = cnt + k.ifreq;
         return tail(t0);
     }
+    // While no voice of a wave is inside a timed envelope stage (sustain: paintFlat's constant, Envelope.zig:68-70; idle or
+    // the assert case: nothing painted) the envelope's frame changes no state and yields the same value every frame:
+    // env_quiet() is that value, frame_quiet() the frame without the envelope's ~12 instructions.  Exactly what frame()
+    // computes and commits in those modes (frame_masked: every update is a select on `toward`).
+    __device__ __forceinline__ F env_quiet() const { return zbits_f(zbits_u(zsplat<F>(0.0f) + env.sustain_volume) & env.m_painted); }
+    __device__ __forceinline__ F frame_quiet(F e0) {
+        const F t0 = osc(cnt);
+        cnt = cnt + k.ifreq;
+        return e0 * tail_filter(t0);
+    }
     // The oscillator half for a walker in which every active lane takes every frame in order from a begin()
     // executed by all of them together (k_nice, k_nice_pc -- not the span kernels, whose lanes begin sub-spans
     // at different frames): the previous frame's half-period bit is carried as the wave's lane
@@ -298,11 +308,23 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
         }
     }
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
+        // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
+        // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
+        if (!__any(live && n.env.mode == ENV_MODE_TOWARD)) {
+            const float e0 = live ? n.env_quiet() : 0.0f;
 #pragma unroll 4
-        for (int k = 0; k < MIXF; k++) {
-            float x = 0.0f;
-            if (live && f0 + k < end) x = 0.0f + n.frame();            // the voice's own out (zeroed) += env*flt
-            tile[wave][k][lane] = x;
+            for (int k = 0; k < MIXF; k++) {
+                float x = 0.0f;
+                if (live && f0 + k < end) x = 0.0f + n.frame_quiet(e0);
+                tile[wave][k][lane] = x;
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < MIXF; k++) {
+                float x = 0.0f;
+                if (live && f0 + k < end) x = 0.0f + n.frame();        // the voice's own out (zeroed) += env*flt
+                tile[wave][k][lane] = x;
+            }
         }
         __syncthreads();
         {
