@@ -122,6 +122,9 @@ struct NiceLaneT {
         cnt = cnt + k.ifreq;
         return e0 * tail_filter(t0);
     }
+    // the same two with the carried-mask oscillator (roll_begin() first; every lane takes every frame)
+    __device__ __forceinline__ F frame_roll(PulseRoll &roll) { return tail(osc_next(roll)); }
+    __device__ __forceinline__ F frame_quiet_roll(F e0, PulseRoll &roll) { return e0 * tail_filter(osc_next(roll)); }
     // The oscillator half for a walker in which every active lane takes every frame in order from a begin()
     // executed by all of them together (k_nice, k_nice_pc -- not the span kernels, whose lanes begin sub-spans
     // at different frames): the previous frame's half-period bit is carried as the wave's lane
@@ -285,7 +288,8 @@ constexpr int MIXS = 65;
 // examples/example_stereo.zig:92-98: `outputs[c] += voice * pan_c` per voice): the sum phase multiplies each
 // voice's sample by that voice's channel gain first -- a lane's 32 voices are the same in every chunk, so their
 // 2 x 32 gains sit in registers -- and partials are [channel][block][frame].
-template <int C>
+// ROLL: the oscillator carries the previous frame's half-period bit as a lane mask (dsp.hip.h pulse_sample_roll).
+template <int C, bool ROLL>
 __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
                                                   F32P gain_l, F32P gain_r) {
     __shared__ float tile[4][MIXF][MIXS];
@@ -294,9 +298,13 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nframes = end - start;
     const bool live = v < a.V;
+    // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
+    // exec-mask region (an s_and_saveexec / branch / restore per frame: ~10 of ~85 instructions)
     NiceLane n;
-    if (live) nice_load(n, a, v);                                       // (the carried-mask oscillator measured 10 % slower here)
+    nice_load(n, a, live ? v : a.V - 1);
     const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
+    PulseRoll roll;
+    n.roll_begin(roll);
     float gl[C == 2 ? 32 : 1], gr[C == 2 ? 32 : 1];
     if constexpr (C == 2) {
         const uint32_t v0 = blockIdx.x * 256 + wave * 64 + rh * 32;     // first of the 32 voices this lane adds up
@@ -310,20 +318,33 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
         // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
         // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
-        if (!__any(live && n.env.mode == ENV_MODE_TOWARD)) {
-            const float e0 = live ? n.env_quiet() : 0.0f;
+        const bool whole = f0 + MIXF <= end;                            // (block-uniform)
+        if (!__any(n.env.mode == ENV_MODE_TOWARD)) {
+            const float e0 = n.env_quiet();
+            if (whole) {
+#pragma unroll 4
+                for (int k = 0; k < MIXF; k++) {
+                    const float x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
+                    tile[wave][k][lane] = live ? x : 0.0f;
+                }
+            } else {
+                for (int k = 0; k < MIXF; k++) {
+                    float x = 0.0f;
+                    if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
+                    tile[wave][k][lane] = live ? x : 0.0f;
+                }
+            }
+        } else if (whole) {
 #pragma unroll 4
             for (int k = 0; k < MIXF; k++) {
-                float x = 0.0f;
-                if (live && f0 + k < end) x = 0.0f + n.frame_quiet(e0);
-                tile[wave][k][lane] = x;
+                const float x = 0.0f + (ROLL ? n.frame_roll(roll) : n.frame());   // the voice's own out (zeroed) += env*flt
+                tile[wave][k][lane] = live ? x : 0.0f;
             }
         } else {
-#pragma unroll 4
             for (int k = 0; k < MIXF; k++) {
                 float x = 0.0f;
-                if (live && f0 + k < end) x = 0.0f + n.frame();        // the voice's own out (zeroed) += env*flt
-                tile[wave][k][lane] = x;
+                if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.frame_roll(roll) : n.frame());
+                tile[wave][k][lane] = live ? x : 0.0f;
             }
         }
         __syncthreads();
@@ -1199,6 +1220,10 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     }
     return zh_launch_status();
 }
+static bool nice_mix_roll() {
+    static const bool v = [] { const char *e = getenv("ZH_NICE_MIX_ROLL"); return e ? atoi(e) != 0 : true; }();   // A/B switch: 149.6 vs 148.2 us at 131,072 voices, 908 vs 890 us at 1,048,576
+    return v;
+}
 static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
                             const zh_f32 *gain_r, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
     const bool stereo = mix_r != nullptr;
@@ -1214,14 +1239,16 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     float *part = m->ctx->mix_partials;
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
     if (stereo) {
-        hipLaunchKernelGGL(k_nice_mix<2>, dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<2, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        else hipLaunchKernelGGL((k_nice_mix<2, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
         if (nframes) {
             zh_mix_pass2_launch_at(m->ctx, part, blocks, nframes, mix_l + start, zf);
             zh_mix_pass2_launch_at(m->ctx, part + per_channel, blocks, nframes, mix_r + start, zf);
         }
     } else {
         const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
-        hipLaunchKernelGGL(k_nice_mix<1>, dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
+        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<1, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
+        else hipLaunchKernelGGL((k_nice_mix<1, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
         if (nframes) zh_mix_pass2_launch_at(m->ctx, part, blocks, nframes, mix_l + start, zf);
     }
     return zh_launch_status();
