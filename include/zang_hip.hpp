@@ -118,6 +118,16 @@ inline void multiplyWith(Context &c, Span s, zh_buf dest, zh_buf a) { check(zh_m
 inline void multiplyScalar(Context &c, Span s, zh_buf dest, zh_buf a, float b) { check(zh_multiply_scalar(c.get(), s.start, s.end, dest, a, f32(b)), "multiplyScalar"); }
 inline void multiplyWithScalar(Context &c, Span s, zh_buf dest, float a) { check(zh_multiply_with_scalar(c.get(), s.start, s.end, dest, f32(a)), "multiplyWithScalar"); }
 
+// the sum of all voices of an image: dst_dev[f] (+)= sum_v src[f][v] (V x zang.addInto, basics.zig:31-36; fixed-order tree sum)
+inline void mixdownVoices(Context &c, Span s, float *dst_dev, zh_buf src, uint32_t flags = ZH_PAINT_ADD) {
+    check(zh_mixdown_voices(c.get(), s.start, s.end, dst_dev, src, flags), "mixdownVoices");
+}
+// zang.mixDown (src/zang/mixdown.zig:8-86): f32 mix -> interleaved s8 / s16 LE PCM with clamping, on the device
+inline void mixDown(Context &c, uint8_t *dst_dev, const float *mix_dev, uint32_t n, uint32_t audio_format, uint32_t num_channels,
+                    uint32_t channel_index, float vol) {
+    check(zh_mix_down(c.get(), dst_dev, mix_dev, n, audio_format, num_channels, channel_index, vol), "mixDown");
+}
+
 }  // namespace zang
 
 namespace mod {
@@ -173,6 +183,25 @@ ZANG_HIP_MODULE(PMOscInstrument, pmosc, 3, ZANG_HIP_COMMA_F32, ZANG_HIP_USE_F32)
 #undef ZANG_HIP_USE_SEED
 #undef ZANG_HIP_COMMA_F32
 #undef ZANG_HIP_USE_F32
+
+// NiceInstrument painted and mixed down over its voices without materialising per-voice output: mono, or two channels with a
+// per-voice gain each (a two-output module fed `voice * pan_c`, examples/example_stereo.zig:92-98)
+inline void paintMix(NiceInstrument &m, zang::Span span, float *mix_dev, zh_bool note_id_changed, const NiceInstrument::Params &params,
+                     uint32_t flags = ZH_PAINT_ADD) {
+    zang::check(zh_nice_paint_mix(m.get(), span.start, span.end, mix_dev, note_id_changed, &params, flags), "zh_nice_paint_mix");
+}
+inline void paintMixStereo(NiceInstrument &m, zang::Span span, float *mix_left_dev, float *mix_right_dev, zh_f32 gain_left, zh_f32 gain_right,
+                           zh_bool note_id_changed, const NiceInstrument::Params &params, uint32_t flags = ZH_PAINT_ADD) {
+    zang::check(zh_nice_paint_mix_stereo(m.get(), span.start, span.end, mix_left_dev, mix_right_dev, gain_left, gain_right, note_id_changed,
+                                         &params, flags), "zh_nice_paint_mix_stereo");
+}
+// n consecutive paints of a constant-frequency oscillator (same span and params, buffer b into outputs[b]) as one launch
+inline void paintBatch(PulseOsc &m, zang::Span span, const std::vector<zh_buf> &outputs, const PulseOsc::Params &params, uint32_t flags = ZH_PAINT_ADD) {
+    zang::check(zh_pulseosc_paint_batch(m.get(), span.start, span.end, outputs.data(), (uint32_t)outputs.size(), &params, flags), "zh_pulseosc_paint_batch");
+}
+inline void paintBatch(TriSawOsc &m, zang::Span span, const std::vector<zh_buf> &outputs, const TriSawOsc::Params &params, uint32_t flags = ZH_PAINT_ADD) {
+    zang::check(zh_trisawosc_paint_batch(m.get(), span.start, span.end, outputs.data(), (uint32_t)outputs.size(), &params, flags), "zh_trisawosc_paint_batch");
+}
 
 // mod.Filter.cutoffFromFrequency (Filter.zig:20-23), elementwise on the device
 inline void cutoffFromFrequency(zang::Context &c, uint32_t n, float *cutoff_out_dev, const float *frequency_dev, float sample_rate) {
