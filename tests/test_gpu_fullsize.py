@@ -205,6 +205,64 @@ def test_config5_shard_48_buffer_cycle(ctx, oracle):
     assert np.array_equal(m.state(), mm.state()) and np.array_equal(m.state(), ms.state())
 
 
+@pytest.mark.parametrize("V", [24576, 49152])
+def test_frame_range_forms_at_mid_voice_counts(ctx, oracle, monkeypatch, V):
+    """Between 16,384 and ~131,072 voices SineOsc, Sampler, the controlled-frequency PulseOsc and PMOscInstrument paint a span
+    as a few frame ranges (zh_range_frames, ctx.hip: more waves per SIMD).  Two carried buffers in the default form equal the
+    sequential form (ZH_*_RANGES=0) bit for bit, images and states; sampled SineOsc voices equal the oracle."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    freq, color, u2, _ = workloads.voice_params(5, 0, V)
+    gf, gc = util.dev(freq), util.dev(color)
+    fbuf = ctx.image(F, V); fbuf.copy_(gf[None, :].expand(F, V)); fbuf.mul_(1.0 + 0.25 * torch.rand(F, 1, device="cuda"))
+    pcm = util.dev(np.random.default_rng(4).integers(-20000, 20000, 9000, dtype=np.int16).view(np.uint8).copy())
+    rel = util.dev((0.1 + 0.4 * u2).astype(np.float32))
+    span = zang.Span(0, F)
+
+    def render():
+        outs, states = [], []
+        m = mod.SineOsc(V, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(SR, zang.constant(gf), zang.constant(0.0)), zero_first=True)
+        outs.append(o); states.append(m.state()["t"])
+        m = mod.SineOsc(V, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), zang.constant(0.25)), zero_first=True)
+        outs.append(o); states.append(m.state()["t"])
+        m = mod.Sampler(V, ctx); o = ctx.image(F, V); smp = m.Sample(1, 44100, m.signed16_lsb, pcm)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(gf * 40.0, smp, 0, True), zero_first=True)
+        outs.append(o); states.append(m.state()["t"])
+        m = mod.PulseOsc(V, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), gc), zero_first=True)
+        outs.append(o); states.append(m.state()["cnt"])
+        m = mod.PMOscInstrument(V, rel, ctx); o = ctx.image(F, V)
+        for k in range(2):
+            m.paint(span, [o], None, k == 0, m.Params(SR, gf, k == 0), zero_first=True)
+        outs.append(o); states.append(m.state())
+        ctx.sync()
+        return outs, states
+
+    a_out, a_st = render()
+    for name in ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_PMOSC_RANGES"):
+        monkeypatch.setenv(name, "0")
+    b_out, b_st = render()
+    for name, x, y, sx, sy in zip(("sineosc const", "sineosc image", "sampler", "pulseosc image", "pmosc"), a_out, b_out, a_st, b_st):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
+        assert np.asarray(sx).tobytes() == np.asarray(sy).tobytes(), name + " state"
+    idx = np.arange(0, V, V // 64)
+    got = a_out[0][:, torch.from_numpy(idx).cuda()].cpu().numpy().T
+    L = oracle.lib()
+    ref = np.zeros((len(idx), F), np.float32)
+    for k, v in enumerate(idx):
+        st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st))
+        for _ in range(2):
+            ref[k] = 0
+            L.zo_sineosc_paint(C.byref(st), 0, F, oracle.fptr(ref[k]), SR, oracle.constant(freq[v]), oracle.constant(0.0))
+    util.assert_bitexact(got, ref, "sineosc sampled vs oracle")
+
+
 def test_zero_voices_and_empty_spans(ctx):
     """Empty inputs: a module with 0 voices and 0-length spans are no-ops, not errors."""
     import torch

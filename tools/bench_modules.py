@@ -74,7 +74,10 @@ m = mod.Portamento(V, ctx); case("Portamento cubed", m, lambda o, m=m: m.paint(s
 
 print("# %d voices x %d frames per paint, %d paints per graph, one MI355X" % (V, F, K))
 print("%-46s %10s %12s %10s" % ("module", "us/paint", "v-samples/s", "HBM TB/s"))
+ONLY = os.environ.get("ZH_BENCH_ONLY", "")                  # substring filter on the case names, "|"-separated
 for name, m, paint, reads in cases:
+    if ONLY and not any(k in name for k in ONLY.split("|")):
+        continue
     for i in range(4):
         paint(out[i & 1])
     ctx.sync()

@@ -1494,17 +1494,9 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, p->sample_rate,
                 mk_f32(p->freq), mk_bool(p->note_on), mk_bool(note_id_changed)};
     // few voices: frame ranges at once (k_pmosc_ranges); ZH_PMOSC_RANGES = number of ranges, 0 = never
-    uint32_t ch = 0;
-    if (end - start >= 128 && m->n <= 16384) {
-        const char *e = getenv("ZH_PMOSC_RANGES");
-        const int forced = e ? atoi(e) : -1;
-        uint32_t want = forced >= 0 ? (uint32_t)forced : 2048u / ((m->n + 63) / 64);   // 16 / 32 / 64 ranges: 75.5 / 70.9 / 80.7 us at 4,096 voices (the replay costs the same whatever the count)
-        if (want > 64) want = 64;
-        if (want >= 2) {
-            ch = ((end - start + want - 1) / want + 7) / 8 * 8;
-            if ((end - start + ch - 1) / ch < 2) ch = 0;
-        }
-    }
+    // 16 / 32 / 64 ranges: 75.5 / 70.9 / 80.7 us at 4,096 voices (the replay costs the same whatever the count); 24,576 /
+    // 32,768 / 65,536 / 131,072 voices, sequential -> ranges: 370 -> 150, 370 -> 176, 353 -> 277, 499 -> 476 us
+    const uint32_t ch = zh_range_frames(m->n, end - start, "ZH_PMOSC_RANGES", m->n <= 16384 ? 2048 : 4096, 131072);
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
         if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, m->next, mk_img(outputs[0]), start, end, ch);

@@ -28,6 +28,21 @@ void zh_flipper_painted(zh_flipper *f) {
     c->capture_log.push_back(zh_flip_use{f->id, f, f->cur, 1u});
 }
 
+uint32_t zh_range_frames(uint32_t V, uint32_t n, const char *env_name, uint32_t target_waves, uint32_t max_voices) {
+    const char *e = getenv(env_name);
+    const int forced = e ? atoi(e) : -1;                                          // 0 = off, k = k ranges
+    const char *ew = getenv("ZH_REPLAY_WAVES"), *ev = getenv("ZH_REPLAY_MAXV");   // experiments: override every caller's tuning
+    if (ew) target_waves = (uint32_t)atoi(ew);
+    if (ev) max_voices = (uint32_t)atoi(ev);
+    if (forced == 0 || V == 0 || n < 128 || V > max_voices) return 0;
+    const uint32_t waves = (V + 63) / 64;
+    uint32_t want = forced > 0 ? (uint32_t)forced : target_waves / waves;
+    if (want < 2) return 0;
+    if (want > 64) want = 64;
+    const uint32_t ch = ((n + want - 1) / want + 7) / 8 * 8;
+    return (n + ch - 1) / ch >= 2 ? ch : 0;
+}
+
 int zh_store_mode() {
     static int mode = -1;
     if (mode < 0) {

@@ -109,20 +109,6 @@ __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__
     if (f1 == end) { o.end(); t_out[v] = o.t; }
 }
 
-// Frames per range for the frame-range forms of the stateful-but-cheap-to-replay modules, or 0 = sequential kernel:
-// enough ranges for about one wave per SIMD, ranges a multiple of 8 frames (frame_loop's chunk).
-static uint32_t replay_range_frames(uint32_t V, uint32_t n, const char *env_name) {
-    const char *e = getenv(env_name);
-    const int forced = e ? atoi(e) : -1;                                          // 0 = off, k = k ranges
-    if (forced == 0 || V == 0 || n < 128 || V > 16384) return 0;
-    const uint32_t waves = (V + 63) / 64;
-    uint32_t want = forced > 0 ? (uint32_t)forced : 2048u / waves;                // two waves per SIMD: 16 / 32 / 64 ranges measured 19.5 / 16.7 / 16.6 us (SineOsc, 4,096 voices)
-    if (want < 2) return 0;
-    if (want > 64) want = 64;
-    const uint32_t ch = ((n + want - 1) / want + 7) / 8 * 8;
-    return (n + ch - 1) / ch >= 2 ? ch : 0;
-}
-
 // =================================================================== Noise
 struct zh_noise {
     zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *b; /* [7][n] */
@@ -544,7 +530,10 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     Img out = mk_img(outputs[0]);
     CobP f = mk_cob(p->freq), ph = mk_cob(p->phase);
     // few voices: frame ranges at once (k_sineosc_ranges); ZH_SINE_RANGES = number of ranges, 0 = never
-    const uint32_t ch = end > start ? replay_range_frames(m->n, end - start, "ZH_SINE_RANGES") : 0;
+    // constant frequency and phase: the replay is two adds a frame, ranges pay up to 4 waves per SIMD at any voice count
+    // (24,576 / 32,768 / 65,536 / 131,072 voices: 162 -> 58, 165 -> 68, 174 -> 141, 266 -> 246 us); with a control image the
+    // replay re-reads the image (32,768 voices: 166 -> 90 us with 4 ranges, no gain from 65,536 on)
+    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_SINE_RANGES", fb || pb ? 2048 : 4096, fb || pb ? 65536 : 1u << 20) : 0;
     if (ch) {
         const float *t_in = m->t();
         float *t_out = reinterpret_cast<float *>(m->cnt[m->cur ^ 1]);
@@ -921,7 +910,8 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
     const BoolP nicp = mk_bool(note_id_changed);
     const int fmt = s.num_samples == 0 ? kSampleEmpty : (int)s.format;
     // few voices: the span as frame ranges at once (see k_sampler); ZH_SAMPLER_RANGES = number of ranges, 0 = never
-    uint32_t ch = end > start ? replay_range_frames(m->n, end - start, "ZH_SAMPLER_RANGES") : 0;
+    // 24,576 / 32,768 / 65,536 / 131,072 / 262,144 voices, sequential -> ranges: 145 -> 43, 145 -> 55, 143 -> 96, 212 -> 187, 377 -> 349 us
+    uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_SAMPLER_RANGES", 16384, 1u << 20) : 0;
     const bool ranges = ch != 0;
     if (!ranges) ch = end > start ? end - start : 1;
     const float *t_in = m->t();

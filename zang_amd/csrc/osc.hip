@@ -385,19 +385,6 @@ static bool osc_prio() {
     if (v < 0) { const char *e = getenv("ZH_OSC_PRIO"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
-// frames per range for the controlled-frequency PulseOsc at small voice counts (0 = sequential); ZH_PULSE_CTRL_RANGES = number
-// of ranges, 0 = never
-static uint32_t osc_ctrl_range_frames(uint32_t V, uint32_t n) {
-    const char *e = getenv("ZH_PULSE_CTRL_RANGES");
-    const int forced = e ? atoi(e) : -1;
-    if (forced == 0 || V == 0 || n < 128 || V > 16384) return 0;
-    const uint32_t waves = (V + 63) / 64;
-    uint32_t want = forced > 0 ? (uint32_t)forced : 2048u / waves;
-    if (want < 2) return 0;
-    if (want > 64) want = 64;
-    const uint32_t ch = ((n + want - 1) / want + 7) / 8 * 8;
-    return (n + ch - 1) / ch >= 2 ? ch : 0;
-}
 static bool osc_no_fc4() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("ZH_OSC_NO_FC4"); v = e ? atoi(e) : 0; }         // A/B: the runtime-length frame loop
@@ -546,7 +533,8 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
         const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:122
         const float sr8 = p->sample_rate / 8.0f;              // :134
         const F32P col = mk_f32(p->color);
-        const uint32_t chr = osc_ctrl_range_frames(m->n, end - start);
+        // 24,576 / 32,768 voices: 122 -> 61, 123 -> 77 us; from 65,536 voices the replay's re-read of the frequency image loses
+        const uint32_t chr = zh_range_frames(m->n, end - start, "ZH_PULSE_CTRL_RANGES", 2048, 40960);
         for (uint32_t b = 0; b < nb; b++) {
             Img out = mk_img(outputs[b]);
             const uint32_t *ci = m->cnt[m->cur];
