@@ -297,15 +297,16 @@ class HipEmitter:
             value = "%s.frame()" % o
         elif name == "Curve":
             decl.append("CurveLane %s;" % o)
+            decl.append("CurveTable %s_tb;" % o)
             ld_f("t", w)
             ld_u("cur", w + 1)
             ld_u("off", w + 2, "(int32_t)")
             ld_u("next", w + 3)
-            pro.append("%s.begin(%s, (uint32_t)(%s), %s, %s, %s, %s);" % (
-                o, a["sample_rate"].expr, self.enum_tag(a["function"], callee.params[1].param_type.enum), a["curve"].expr,
+            pro.append("%s.begin(%s_tb, %s, (uint32_t)(%s), %s, %s, %s, %s);" % (
+                o, o, a["sample_rate"].expr, self.enum_tag(a["function"], callee.params[1].param_type.enum), a["curve"].expr,
                 a["curve"].count, mc.length, mc.nic))
             cv, cp = k.fresh("cv"), k.fresh("cp")
-            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(%s, %s);" % (cp, o, mc.rel, cv)]
+            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(%s_tb, %s, %s);" % (cp, o, o, mc.rel, cv)]
             painted, value = cp, cv
         else:
             raise HipBackendError("builtin module %s is not supported by the HIP backend" % name)

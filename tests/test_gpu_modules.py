@@ -28,14 +28,18 @@ def _gcob(zang, kind, const_t, buf_t):
 
 
 # ------------------------------------------------------------------ SineOsc
+RANGE_SWITCHES = ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_DECIMATOR_RANGES", "ZH_ENVELOPE_RANGES",
+                  "ZH_PORTAMENTO_RANGES", "ZH_TRISAW_CTRL_RANGES", "ZH_PULSE_CTRL_RANGES")
+
+
 @pytest.fixture(params=["ranges", "sequential"])
 def replay_form(request, monkeypatch):
     """SineOsc / Sampler at a small voice count paint a span as many frame ranges at once (each range replays the f32 state
     additions of the frames before it); ZH_*_RANGES=0 selects the lane-per-voice walk instead.  Both forms must give the
     oracle's bits (the library reads the variables at every paint)."""
     if request.param == "sequential":
-        monkeypatch.setenv("ZH_SINE_RANGES", "0")
-        monkeypatch.setenv("ZH_SAMPLER_RANGES", "0")
+        for name in RANGE_SWITCHES:
+            monkeypatch.setenv(name, "0")
     return request.param
 
 
@@ -282,7 +286,7 @@ def _env_case(oracle, ctx, V, curves, sustain, script, dur_scale=1.0):
 
 @pytest.mark.parametrize("curves", [(1, 1, 1), (2, 2, 2), (3, 3, 3), (0, 3, 3), (3, 0, 3), (3, 3, 0), (0, 0, 0)])
 @pytest.mark.parametrize("sustain", [0.5, 1.0])
-def test_envelope_stages(ctx, oracle, curves, sustain):
+def test_envelope_stages(ctx, oracle, curves, sustain, replay_form):
     V = 128
     rng = np.random.default_rng(41)
     on = np.ones(V, bool); off = np.zeros(V, bool)
@@ -450,7 +454,7 @@ def test_sampler_channel_out_of_range(ctx):
 
 
 # ------------------------------------------------------------------ Decimator
-def test_decimator_bitexact(ctx, oracle):
+def test_decimator_bitexact(ctx, oracle, replay_form):
     from zang_amd import modules as mod, zang
     V = 160
     rng = np.random.default_rng(71)
@@ -524,7 +528,7 @@ def test_cycle(ctx, oracle, kind):
 
 
 @pytest.mark.parametrize("curve", [0, 1, 2, 3])
-def test_portamento(ctx, oracle, curve):
+def test_portamento(ctx, oracle, curve, replay_form):
     from zang_amd import modules as mod, zang
     V = 128
     rng = np.random.default_rng(93)

@@ -144,6 +144,14 @@ constexpr uint32_t kMaxRowStride = 1u << 26;
 static inline bool buf_covers(const zh_buf &b, uint32_t n_voices, uint32_t span_end) {
     return b.ptr != nullptr && b.voices >= n_voices && b.frames >= span_end && b.stride >= n_voices && b.stride <= kMaxRowStride;
 }
+// do two images share memory?  (a frame-range kernel re-reads input rows that another range may be writing when an
+// input aliases the output; the sequential forms read a frame before they write it, as the reference's loops do)
+static inline bool bufs_alias(const zh_buf &a, const zh_buf &b) {
+    if (!a.ptr || !b.ptr) return false;
+    const float *ae = a.ptr + (size_t)a.frames * a.stride, *be = b.ptr + (size_t)b.frames * b.stride;
+    return a.ptr < be && b.ptr < ae;
+}
+static inline bool cob_aliases(const zh_cob &c, const zh_buf &b) { return c.tag == ZH_COB_BUFFER && bufs_alias(c.buffer, b); }
 static inline bool cob_ok(const zh_cob &c, uint32_t n_voices, uint32_t span_end) {
     if (c.tag == ZH_COB_CONSTANT) return true;
     if (c.tag == ZH_COB_BUFFER) return buf_covers(c.buffer, n_voices, span_end);

@@ -163,6 +163,23 @@ struct EnvLaneT {
         }
         return painted;
     }
+    // frame_loop_gen (seq.hip.h): true = no voice ends a stage within the next n frames.  A TOWARD voice's clock after k
+    // steps is at most t + k * step + k half-ulps of 1, so t + (n + 1) * step < 0.999 keeps it below 1 with a wide margin
+    // (a NaN or infinite step fails the test and takes the exact path).
+    __device__ __forceinline__ bool quiet(int n) const {
+        const M risky = zand(mode == u(ENV_MODE_TOWARD), znot(t + f((float)(n + 1)) * cur_step < f(0.999f)));
+        return !zany_wave(risky);
+    }
+    // frame() where quiet() holds: the stage cannot finish, so the clamp, the stage-end test and its branch are gone
+    __device__ __forceinline__ M frame_quiet(F &val) {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        const F tn = t + cur_step;
+        const F lv = start + curve(tn) * cur_delta;                // :114
+        t = zsel(toward, tn, t);
+        last_value = zsel(toward, lv, last_value);
+        val = zsel(toward, lv, sustain_volume);
+        return mode != u(ENV_MODE_NONE);
+    }
     // frame() for the callers that want `painted ? 0.0f + value : 0.0f` (the zeroed temp a composite paints the
     // envelope into): the select is an AND with m_painted, and no mode compare is needed for it
     __device__ __forceinline__ F frame_masked() {
@@ -239,8 +256,8 @@ struct EnvParamsP {
     BoolP note_on;
 };
 
-template <int W>
-__device__ __forceinline__ void env_load(EnvLaneT<W> &e, const EnvParamsP &p, uint32_t v) {
+template <int W, int FT>
+__device__ __forceinline__ void env_load(EnvLaneT<W, FT> &e, const EnvParamsP &p, uint32_t v) {
     e.sample_rate = p.sample_rate;
     e.sustain_volume = zget_f32p<W>(p.sustain_volume, v);
     e.attack = CurvePT<W>{p.attack_tag, zget_f32p<W>(p.attack_dur, v)};

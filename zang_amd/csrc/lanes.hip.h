@@ -30,6 +30,17 @@ ZL float zsel(bool m, float a, float b) { return m ? a : b; }
 ZL uint32_t zsel(bool m, uint32_t a, uint32_t b) { return m ? a : b; }
 ZL zf2 zsel(zm2 m, zf2 a, zf2 b) { return m ? a : b; }
 ZL zu2 zsel(zm2 m, zu2 a, zu2 b) { return m ? a : b; }
+// m ? a : b as ONE v_cndmask, whatever the optimizer thinks: given a select between two computed values LLVM often
+// rebuilds a branch -- an exec-mask region of ~6 scalar instructions per frame where a compare and a select would do
+#if defined(__HIP_DEVICE_COMPILE__)
+ZL float zsel_hard(bool m, float a, float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(__builtin_amdgcn_ballot_w64(m)));
+    return r;
+}
+#else
+ZL float zsel_hard(bool m, float a, float b) { return m ? a : b; }
+#endif
 // mask logic (masks are `bool` or all-ones/zero vectors)
 ZL bool zand(bool a, bool b) { return a && b; }
 ZL zm2 zand(zm2 a, zm2 b) { return a & b; }
@@ -40,6 +51,9 @@ ZL bool znot(bool m) { return !m; }
 ZL zm2 znot(zm2 m) { return ~m; }
 ZL bool zany(bool m) { return m; }
 ZL bool zany(zm2 m) { return (m.x | m.y) != 0; }
+// any lane of the WAVE (wave-uniform, for a scalar branch)
+ZL bool zany_wave(bool m) { return __builtin_amdgcn_ballot_w64(m) != 0; }
+ZL bool zany_wave(zm2 m) { return __builtin_amdgcn_ballot_w64((m.x | m.y) != 0) != 0; }
 ZL bool zall(bool m) { return m; }
 ZL bool zall(zm2 m) { return (m.x & m.y) != 0; }
 // splats

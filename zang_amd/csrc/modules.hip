@@ -157,19 +157,22 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, 
 // =================================================================== Envelope
 struct zh_envelope { zh_ctx *ctx; uint32_t n; uint32_t *state; float *t, *last_value, *start; };
 
-template <bool ZF>
+// FT >= 0: the three curves share that tag (the usual case; the host checks), so the per-frame curve needs no selects.
+// Chunks of 8 frames in which no voice of the wave can end a stage run EnvLane::frame_quiet (frame_loop_gen).
+// 4,096 voices: 84.6 us with the generic frame() in every frame (54 instructions), XX us now.
+template <bool ZF, int FT>
 __global__ void __launch_bounds__(kSeqBlock) k_envelope(uint32_t *__restrict__ st, float *__restrict__ t,
                                                         float *__restrict__ lastv, float *__restrict__ startv, uint32_t V,
                                                         Img out, uint32_t start, uint32_t end, EnvParamsP p, BoolP nic) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
-    EnvLane e;
+    EnvLaneT<1, FT> e;
     e.state = st[v]; e.t = t[v]; e.last_value = lastv[v]; e.start = startv[v];
     env_load(e, p, v);
     e.begin(nic.get(v));
-    const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end,
-                         [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA { return e.frame(val); });
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t) ZH_INLINE_LAMBDA { return e.quiet(8); },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { return e.frame_quiet(val); },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { return e.frame(val); });
     st[v] = e.state; t[v] = e.t; lastv[v] = e.last_value; startv[v] = e.start;
 }
 
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
 }
 
 // =================================================================== Decimator
-struct zh_decimator { zh_ctx *ctx; uint32_t n; float *dval, *dcount; };
+struct zh_decimator { zh_ctx *ctx; uint32_t n; float *dval, *dcount; float *next; /* [2][n], k_decimator_ranges */ };
 
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dval_io, float *__restrict__ dcount_io, uint32_t V,
@@ -367,6 +370,47 @@ __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dva
                          [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(x[0], val); });
     o.end();
     dval_io[v] = o.dval; dcount_io[v] = o.dcount;
+}
+
+// A span as frame ranges (grid.y): the walk from frame to frame is the fractional counter alone (four instructions,
+// no loads) -- a range replays it for the frames before it, remembering the latest frame that sampled, fetches that one
+// input sample, and paints its own frames like k_decimator.  The range that ends the span writes the end state to `next`;
+// k_commit2 moves it into place (stream order: after every range has read the start state).
+template <bool ZF>
+__global__ void __launch_bounds__(64) k_decimator_ranges(const float *__restrict__ dval_in, const float *__restrict__ dcount_in,
+                                                         float *__restrict__ next, uint32_t V, Img out, CImg input, uint32_t start,
+                                                         uint32_t end, uint32_t ch, float sample_rate, F32P fake_p) {
+    const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
+    DecimatorLane o;
+    o.dval = dval_in[v]; o.dcount = dcount_in[v];
+    o.begin(sample_rate, fake_p.get(v));
+    if (f0 > start) {
+        const float dcount0 = o.dcount;
+        uint32_t last = 0xFFFFFFFFu;
+        uint32_t i = start;
+        for (; i + 8 <= f0; i += 8) {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) o.step(i + q, last);
+        }
+        for (; i < f0; i++) o.step(i, last);
+        const float held = *input.at(last == 0xFFFFFFFFu ? start : last, v);
+        if (o.mode == 1) { if (last != 0xFFFFFFFFu) o.dval = held; } else o.dcount = dcount0;
+    }
+    const float *ins[1] = {input.p};
+    const size_t istr[1] = {input.stride};
+    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, f0, f1,
+                         [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(x[0], val); });
+    if (f1 == end) {
+        o.end();
+        next[v] = o.dval; next[(size_t)V + v] = o.dcount;
+    }
+}
+__global__ void __launch_bounds__(256) k_commit2(float *__restrict__ a, float *__restrict__ b, const float *__restrict__ next, uint32_t V) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    a[v] = next[v]; b[v] = next[(size_t)V + v];
 }
 
 // =================================================================== Distortion (stateless)
@@ -412,11 +456,12 @@ __global__ void __launch_bounds__(kSeqBlock) k_curve(float *__restrict__ t_io, u
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
     CurveLane o;
+    CurveTable tb;
     o.t = t_io[v]; o.cur = cur_io[v]; o.next = next_io[v]; o.off = off_io[v];
-    o.begin(sample_rate, function, curve, n_curve, end - start, nic.get(v));
-    const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end,
-                         [&](uint32_t i, const float (&)[1], float &val) ZH_INLINE_LAMBDA { return o.frame(i - start, val); });
+    o.begin(tb, sample_rate, function, curve, n_curve, end - start, nic.get(v));
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t i) ZH_INLINE_LAMBDA { return o.quiet(i - start, 8); },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { return o.frame_in_span(val); },
+                          [&](uint32_t i, float &val) ZH_INLINE_LAMBDA { return o.frame(tb, i - start, val); });
     t_io[v] = o.t; cur_io[v] = o.cur; off_io[v] = o.off; next_io[v] = o.next;
 }
 
@@ -453,11 +498,9 @@ __global__ void __launch_bounds__(kSeqBlock) k_portamento(float *__restrict__ t_
     PortamentoLane o;
     o.t = t_io[v]; o.last = last_io[v]; o.st = start_io[v];
     o.begin(sample_rate, curve_tag, duration.get(v), goal_p.get(v), note_on.get(v), prev_note_on.get(v), nic.get(v));
-    const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        val = o.frame();
-        return true;
-    });
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t) ZH_INLINE_LAMBDA { return o.all_flat(); },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.goal; return true; },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.frame(); return true; });
     t_io[v] = o.t; last_io[v] = o.last; start_io[v] = o.st;
 }
 
@@ -533,7 +576,8 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     // constant frequency and phase: the replay is two adds a frame, ranges pay up to 4 waves per SIMD at any voice count
     // (24,576 / 32,768 / 65,536 / 131,072 voices: 162 -> 58, 165 -> 68, 174 -> 141, 266 -> 246 us); with a control image the
     // replay re-reads the image (32,768 voices: 166 -> 90 us with 4 ranges, no gain from 65,536 on)
-    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_SINE_RANGES", fb || pb ? 2048 : 4096, fb || pb ? 65536 : 1u << 20) : 0;
+    const bool aliased = cob_aliases(p->freq, outputs[0]) || cob_aliases(p->phase, outputs[0]);
+    const uint32_t ch = end > start && !aliased ? zh_range_frames(m->n, end - start, "ZH_SINE_RANGES", fb || pb ? 2048 : 4096, fb || pb ? 65536 : 1u << 20) : 0;
     if (ch) {
         const float *t_in = m->t();
         float *t_out = reinterpret_cast<float *>(m->cnt[m->cur ^ 1]);
@@ -724,8 +768,21 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
     if (m->n == 0) return ZH_OK;            // an empty span still runs the state prologue (Envelope.zig:41-50)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
-    ZH_ZF_LAUNCH(k_envelope, seq_grid(m->n), dim3(kSeqBlock), m->state, m->t, m->last_value, m->start, m->n,
-                 mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));
+    const int ft = p->attack.tag == p->decay.tag && p->decay.tag == p->release.tag && p->attack.tag != ZH_CURVE_INSTANTANEOUS ? (int)p->attack.tag : -1;
+#define ZH_ENV(FT_)                                                                                                          \
+    do {                                                                                                                     \
+        if (zf) hipLaunchKernelGGL((k_envelope<true, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->state, m->t, m->last_value, m->start, m->n, \
+                                   mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));             \
+        else hipLaunchKernelGGL((k_envelope<false, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->state, m->t, m->last_value, m->start, m->n, \
+                                mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));                \
+    } while (0)
+    switch (ft) {
+    case ZH_CURVE_LINEAR: ZH_ENV(ZH_CURVE_LINEAR); break;
+    case ZH_CURVE_SQUARED: ZH_ENV(ZH_CURVE_SQUARED); break;
+    case ZH_CURVE_CUBED: ZH_ENV(ZH_CURVE_CUBED); break;
+    default: ZH_ENV(-1); break;
+    }
+#undef ZH_ENV
     return zh_launch_status();
 }
 
@@ -933,23 +990,24 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
 // ------------------------------------------------------------------ Decimator
 int zh_decimator_create(zh_ctx *ctx, uint32_t n, zh_decimator **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_decimator *m = new (std::nothrow) zh_decimator{ctx, n, nullptr, nullptr};
+    zh_decimator *m = new (std::nothrow) zh_decimator{ctx, n, nullptr, nullptr, nullptr};
     if (!m) return ZH_ERR_INVALID;
     int rc = dev_alloc(&m->dval, n);
     if (!rc) rc = dev_alloc(&m->dcount, n);
+    if (!rc) rc = dev_alloc(&m->next, (size_t)n * 2);
     if (!rc && n) {                                                                // init() :14-19: dval 0, dcount 1
         std::vector<float> ones(n, 1.0f);
         rc = (int)hipMemsetAsync(m->dval, 0, n * 4, ctx->stream);
         if (!rc) rc = upload_field(ctx, m->dcount, ones);
     }
-    if (rc) { (void)hipFree(m->dval); (void)hipFree(m->dcount); delete m; return rc; }
+    if (rc) { (void)hipFree(m->dval); (void)hipFree(m->dcount); (void)hipFree(m->next); delete m; return rc; }
     *out = m;
     return ZH_OK;
 }
 int zh_decimator_destroy(zh_decimator *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->dval); (void)hipFree(m->dcount);
+    (void)hipFree(m->dval); (void)hipFree(m->dcount); (void)hipFree(m->next);
     delete m;
     return ZH_OK;
 }
@@ -979,6 +1037,16 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     if (m->n == 0) return ZH_OK;            // an empty span still resets state when fake >= sample_rate (:37-38)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
+    // 4,096 voices: 94 us sequential with per-lane branches, 39 straight-line, 31 as 16 frame ranges (the replay is 8 issue
+    // slots a frame against 13.5 for a painted frame: 4 / 8 / 16 / 32 / 64 ranges = 32.4 / 31.5 / 30.6 / 31.5 / 35.4 us)
+    const uint32_t ch = end > start && !bufs_alias(p->input, outputs[0]) ? zh_range_frames(m->n, end - start, "ZH_DECIMATOR_RANGES", 1024, 32768) : 0;
+    if (ch) {
+        const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
+        ZH_ZF_LAUNCH(k_decimator_ranges, grid, dim3(64), m->dval, m->dcount, m->next, m->n, mk_img(outputs[0]), mk_cimg(p->input),
+                     start, end, ch, p->sample_rate, mk_f32(p->fake_sample_rate));
+        hipLaunchKernelGGL(k_commit2, dim3((m->n + 255) / 256), dim3(256), 0, st, m->dval, m->dcount, m->next, m->n);
+        return zh_launch_status();
+    }
     ZH_ZF_LAUNCH(k_decimator, seq_grid(m->n), dim3(kSeqBlock), m->dval, m->dcount, m->n, mk_img(outputs[0]),
                  mk_cimg(p->input), start, end, p->sample_rate, mk_f32(p->fake_sample_rate));
     return zh_launch_status();
@@ -1038,6 +1106,9 @@ int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, cons
     if (m->n == 0) return ZH_OK;            // an empty span still resets on note_id_changed (:66-71)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
+    // 4,096 voices: 89 us with a span search behind a per-lane test in every unrolled frame; 36.5 us with the spans streamed
+    // into a table in begin() and chunks without a span change running without the test (seq.hip.h frame_loop_gen).  Painted
+    // as frame ranges it took 28 us whatever the range count: begin() is the floor, so the sequential form stays.
     ZH_ZF_LAUNCH(k_curve, seq_grid(m->n), dim3(kSeqBlock), m->t, m->cur, m->off, m->next, m->n, mk_img(outputs[0]), start, end,
                  p->sample_rate, p->function, p->curve, (uint32_t)p->curve_len, mk_bool(note_id_changed));
     return zh_launch_status();

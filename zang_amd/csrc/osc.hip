@@ -534,7 +534,9 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
         const float sr8 = p->sample_rate / 8.0f;              // :134
         const F32P col = mk_f32(p->color);
         // 24,576 / 32,768 voices: 122 -> 61, 123 -> 77 us; from 65,536 voices the replay's re-read of the frequency image loses
-        const uint32_t chr = zh_range_frames(m->n, end - start, "ZH_PULSE_CTRL_RANGES", 2048, 40960);
+        bool aliased = false;
+        for (uint32_t b = 0; b < nb; b++) aliased = aliased || bufs_alias(p->freq.buffer, outputs[b]);
+        const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, "ZH_PULSE_CTRL_RANGES", 2048, 40960);
         for (uint32_t b = 0; b < nb; b++) {
             Img out = mk_img(outputs[b]);
             const uint32_t *ci = m->cnt[m->cur];

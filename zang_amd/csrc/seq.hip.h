@@ -102,6 +102,71 @@ __device__ __forceinline__ void frame_loop(float *__restrict__ out, uint32_t v, 
     }
 }
 
+// frame_loop for a generator (no input images) whose per-frame body has a rare event -- a curve span or an envelope stage
+// ending -- that costs a compare, an exec-mask region and a branch in EVERY frame of an unrolled chunk.  `quiet(i)` is
+// asked once per chunk of CH frames and must be wave-uniform: true promises that no lane has the event in frames
+// [i, i + CH), and the chunk then runs `fast` (the body without the test); otherwise, and for the tail, `slow`.
+// Both are f(frame, value&) -> painted, with the same results wherever `quiet` holds.
+template <int CH, bool ZF, class Q, class FF, class FS>
+__device__ __forceinline__ void frame_loop_gen(float *__restrict__ out, uint32_t v, size_t ostride, uint32_t start, uint32_t end,
+                                               Q &&quiet, FF &&fast, FS &&slow) {
+    const uint32_t n = end - start;
+    const uint32_t nfull = n / CH;
+    const uint32_t voff = v * 4u;
+    const uint32_t orow = (uint32_t)ostride * 4u;
+    float oc[CH];
+    uint32_t i = start;
+    if (nfull > 0 && !ZF) {
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+#pragma unroll
+        for (int k = 0; k < CH; k++) oc[k] = zrow_load<1>(ro, voff, k * orow);
+    }
+    for (uint32_t c = 0; c < nfull; c++, i += CH) {
+        float on[CH];
+        const bool more = c + 1 < nfull;
+        if (more && !ZF) {
+            const zh_rsrc_t rn = zrow_rsrc(out, ostride, i + CH);
+#pragma unroll
+            for (int k = 0; k < CH; k++) on[k] = zrow_load<1>(rn, voff, k * orow);
+        }
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        float res[CH];
+        bool pm[CH];
+        if (quiet(i)) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float val = 0.0f;
+                pm[k] = fast(i + k, val);
+                const float o = ZF ? 0.0f : oc[k];
+                res[k] = pm[k] ? o + val : o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float val = 0.0f;
+                pm[k] = slow(i + k, val);
+                const float o = ZF ? 0.0f : oc[k];
+                res[k] = pm[k] ? o + val : o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (ZF || zany(pm[k])) zrow_store<1>(ro, voff, k * orow, res[k]);
+        if (more && !ZF) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) oc[k] = on[k];
+        }
+    }
+    for (; i < end; i++) {
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        float val = 0.0f;
+        const bool painted = slow(i, val);
+        float o = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
+        o = painted ? o + val : o;
+        if (ZF || zany(painted)) zrow_store<1>(ro, voff, 0, o);
+    }
+}
+
 // zero the span of one voice column (used when a ZERO_FIRST paint paints nothing)
 __device__ __forceinline__ void zero_column(float *__restrict__ out, size_t ostride, uint32_t start, uint32_t end) {
     for (uint32_t i = start; i < end; i++) out[(size_t)i * ostride] = 0.0f;

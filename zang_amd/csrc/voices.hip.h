@@ -105,17 +105,16 @@ __device__ __forceinline__ float trisaw_sample(const TriSawK &k, uint32_t cnt) {
     return gain + v;
 }
 // the naive saw / triangle of the controlled-frequency path (:120-156): uses the f32 phase, ignores cnt
+// (every arm computed, then selected: `saw` and the triangle's three pieces differ from lane to lane, and per-lane
+// branches cost more exec-mask instructions than the two multiplies an arm is)
 __device__ __forceinline__ float trisaw_naive(float t, bool saw) {
-    float frac;
-    if (saw) {
-        frac = (t - floorf(t)) * 2.0f - 1.0f;
-    } else {
-        frac = t - floorf(t);
-        if (frac < 0.25f) frac = frac * 4.0f;
-        else if (frac < 0.75f) frac = 1.0f - (frac - 0.25f) * 4.0f;
-        else frac = (frac - 0.75f) * 4.0f - 1.0f;
-    }
-    return 0.7f * frac;
+    const float fr = t - floorf(t);
+    const float sawv = fr * 2.0f - 1.0f;                              // :128
+    const float up = fr * 4.0f;                                       // :137-143
+    const float down = 1.0f - (fr - 0.25f) * 4.0f;
+    const float up2 = (fr - 0.75f) * 4.0f - 1.0f;
+    const float tri = zsel_hard(fr < 0.25f, up, zsel_hard(fr < 0.75f, down, up2));
+    return 0.7f * zsel_hard(saw, sawv, tri);
 }
 
 struct TriSawOscLane {
@@ -191,13 +190,24 @@ struct DecimatorLane {
         mode = fake >= sample_rate ? 0 : (fake > 0.0f ? 1 : 2);       // :34, :39
         ratio = fake / sample_rate;                                   // :40
     }
+    // straight-line (per-lane branches on mode and on the trigger cost ~30 exec-mask instructions a frame): mode 0 is
+    // addInto (:35), mode 2 (fake <= 0 or NaN) paints nothing, mode 1 is the sample-and-hold of :46-51
     __device__ __forceinline__ bool frame(float x, float &val) {
-        if (mode == 0) { val = x; return true; }                      // :35 addInto
-        if (mode == 2) return false;                                  // fake <= 0 (or NaN): paints nothing
-        dcount += ratio;                                              // :46
-        if (dcount >= 1.0f) { dval = x; dcount -= 1.0f; }             // :47-50
-        val = dval;                                                   // :51
-        return true;
+        const float dc = dcount + ratio;                              // :46
+        const bool trig = dc >= 1.0f;                                 // :47
+        const float dcn = trig ? dc - 1.0f : dc;                      // :49
+        const bool run = mode == 1;
+        dval = (run && trig) ? x : dval;                              // :48
+        dcount = run ? dcn : dcount;
+        val = mode == 0 ? x : dval;                                   // :35 / :51
+        return mode != 2;
+    }
+    // the walk of frame() without the input: `last` = index of the latest frame that sampled (unchanged if none)
+    __device__ __forceinline__ void step(uint32_t i, uint32_t &last) {
+        const float dc = dcount + ratio;
+        const bool trig = dc >= 1.0f;
+        dcount = trig ? dc - 1.0f : dc;
+        last = trig ? i : last;
     }
     __device__ __forceinline__ void end() {
         if (mode == 0) { dval = 0.0f; dcount = 1.0f; }                // :37-38
@@ -254,95 +264,143 @@ struct PortamentoLane {
         else if (tag == ZH_CURVE_INSTANTANEOUS) { t = 1.0f; last = goal; flat = true; }
         t_step = 1.0f / (duration * sample_rate);                                          // painter.zig:97
     }
-    __device__ __forceinline__ float frame() {
-        if (flat) return goal;
-        t += t_step;                                                   // painter.zig:103-116
-        const bool fin = t >= 1.0f;
-        t = fin ? 1.0f : t;
-        const float it = 1.0f - t;
-        float tp = t;
-        if (tag == ZH_CURVE_SQUARED) tp = 1.0f - it * it;
-        else if (tag == ZH_CURVE_CUBED) tp = 1.0f - it * it * it;
-        last = st + tp * (goal - st);
-        flat = fin;
-        return last;
+    // one paintToward step (painter.zig:103-116) or paintFlat's goal, as selects: per-lane branches on `flat` and on the
+    // curve tag cost more exec-mask instructions than the arithmetic they skip
+    __device__ __forceinline__ float curve_at(float tn) const {
+        const float it = 1.0f - tn;
+        const float sq = it * it;
+        return zsel_hard(tag == ZH_CURVE_SQUARED, 1.0f - sq, zsel_hard(tag == ZH_CURVE_CUBED, 1.0f - sq * it, tn));
     }
+    __device__ __forceinline__ float frame() {
+        float tn = t + t_step;
+        const bool fin = tn >= 1.0f;
+        tn = fin ? 1.0f : tn;
+        const float lv = st + curve_at(tn) * (goal - st);
+        const float val = flat ? goal : lv;
+        t = flat ? t : tn;
+        last = flat ? last : lv;
+        flat = flat || fin;
+        return val;
+    }
+    // frame_loop_gen (seq.hip.h): once every voice of the wave has arrived (paintFlat, Portamento.zig:43-47) a frame is the
+    // goal itself and nothing changes
+    __device__ __forceinline__ bool all_flat() const { return __builtin_amdgcn_ballot_w64(!flat) == 0; }
 };
 
 // ---- Curve (src/modules/Curve.zig) ---------------------------------------------------------------
 struct CurveSpanNode { int32_t frame; float value; };                  // :11-14
 
-// Per paint the lane first builds its (<= 32) span nodes (getCurveSpanNodes, :130-184), then walks the
-// span frame by frame; whenever the running curve span ends it looks up the next one
-// (getNextCurveSpan, :188-255) -- the reference's `while (start < out.len)` loop, re-expressed per
-// frame so that all lanes stay on the same frame.
+// The reference builds the paint's (<= 32) span nodes (getCurveSpanNodes, :130-184) and then asks for one curve span after
+// the other (getNextCurveSpan, :188-255: at frame 0 and wherever a span ends -- its `while (start < out.len)` loop).  Both
+// walk the node list front to back and a span depends on two neighbouring nodes only, so begin() streams: a node is final
+// once its successor lies on a different frame (:165-167 replaces a node that shares its frame), and a final pair (node,
+// successor) yields that node's spans -- a gap up to its frame, if any, then its segment.  The first span becomes the
+// running span, in registers; the ones after it go to a per-lane table (CurveTable, scratch memory) that the frame walk
+// reads at span changes.  All lanes stay on the same frame.
+constexpr uint32_t kCurveSpans = 36;                                   // <= 32 nodes: a gap + 31 segments + the last node's span + the tail
+struct CurveTable {                                                   // its own object: one dynamic index keeps a whole object in scratch
+    uint32_t s_end[kCurveSpans];                                      // bit 31: the span has values
+    float s_acc[kCurveSpans], s_step[kCurveSpans], s_sv[kCurveSpans], s_vd[kCurveSpans];
+};
 struct CurveLane {
     float t;                                                          // state (:36-49)
     uint32_t cur, next;
     int32_t off;
-    CurveSpanNode nodes[32];
-    uint32_t count, out_len, function, span_end;
+    uint32_t out_len, function;
+    uint32_t n_spans, k;                                              // spans of this paint, the running one's index
+    // the running span
+    uint32_t span_end;
     bool has_values;
     float acc, step, start_value, value_delta;
+    // begin()'s stream
+    uint32_t dest_start;
+    bool nodes_done;
 
-    __device__ __forceinline__ void begin(float sample_rate, uint32_t function_, const zh_curve_node *__restrict__ curve,
+    __device__ __forceinline__ void add_span(CurveTable &tb, uint32_t end_, bool values, float acc_, float step_, float sv_, float vd_) {
+        dest_start = end_;
+        if (n_spans == 0) { span_end = end_; has_values = values; acc = acc_; step = step_; start_value = sv_; value_delta = vd_; }
+        if (n_spans < kCurveSpans) {
+            tb.s_end[n_spans] = end_ | (values ? 0x80000000u : 0u);
+            tb.s_acc[n_spans] = acc_; tb.s_step[n_spans] = step_; tb.s_sv[n_spans] = sv_; tb.s_vd[n_spans] = vd_;
+            n_spans++;
+        }
+    }
+    // getNextCurveSpan's loop body for node `a` (successor `b` when has_b), from the current dest_start on (:196-250)
+    __device__ __forceinline__ void node_spans(CurveTable &tb, CurveSpanNode a, bool has_b, CurveSpanNode b) {
+        const int32_t dest_end = (int32_t)out_len;
+        if (nodes_done || (int32_t)dest_start >= dest_end) return;
+        if (a.frame >= dest_end) { nodes_done = true; return; }                                        // `break`: the rest is the tail
+        const int32_t end_pos = has_b ? min(dest_end, b.frame) : dest_end;
+        if (end_pos <= (int32_t)dest_start) return;                                                    // `continue`
+        if (a.frame > (int32_t)dest_start) add_span(tb, (uint32_t)a.frame, false, 0.0f, 0.0f, 0.0f, 0.0f);   // the gap before the node
+        float acc_ = 0.0f, step_ = 0.0f, sv_ = 0.0f, vd_ = 0.0f;
+        if (has_b) {                                                                                    // :84-107
+            const float start_x = (float)((int32_t)dest_start - a.frame) / (float)(b.frame - a.frame);   // :95
+            sv_ = a.value;
+            vd_ = b.value - a.value;
+            const float x_step = 1.0f / (float)(b.frame - a.frame);                                     // :100
+            if (function == ZH_CURVE_FN_LINEAR) { acc_ = sv_ + start_x * vd_; step_ = x_step * vd_; }
+            else { acc_ = start_x; step_ = x_step; }
+        }
+        add_span(tb, (uint32_t)end_pos, has_b, acc_, step_, sv_, vd_);
+    }
+
+    __device__ __forceinline__ void begin(CurveTable &tb, float sample_rate, uint32_t function_, const zh_curve_node *__restrict__ curve,
                                           uint32_t n_curve, uint32_t out_len_, bool note_id_changed) {
         function = function_;
         out_len = out_len_;
         if (note_id_changed) { cur = 0; off = 0; next = 0; t = 0.0f; }   // :66-71
-        count = 0;
+        n_spans = 0; dest_start = 0; nodes_done = false;
+        span_end = out_len; has_values = false;
+        acc = step = start_value = value_delta = 0.0f;
         const float buf_time = (float)out_len / sample_rate;          // getCurveSpanNodes
         const float end_t = t + buf_time;
-        if (cur < next) { nodes[count].frame = off; nodes[count].value = curve[cur].value; count++; }   // :142-148
+        // a = the latest final node, b = the latest node (final once a node on another frame follows)
+        CurveSpanNode a{0, 0.0f}, b{0, 0.0f};
+        bool has_a = false, has_b = false;
+        uint32_t count = 0;
+        if (cur < next) { b.frame = off; b.value = curve[cur].value; has_b = true; count = 1; }   // :142-148
         bool one_past = false;
-        for (uint32_t k = next; k < n_curve; k++) {
-            const float note_t = curve[k].t;
-            if (note_t >= end_t) { if (!one_past) one_past = true; else break; }                         // :153-160
-            const float f = (note_t - t) / buf_time;
+        for (uint32_t i = next; i < n_curve; i++) {
+            const zh_curve_node nd = curve[i];
+            if (nd.t >= end_t) { if (!one_past) one_past = true; else break; }                           // :153-160
+            const float f = (nd.t - t) / buf_time;
             const int32_t rel = zf32_to_i32(f * (float)out_len);
-            if (count > 0 && nodes[count - 1].frame == rel) count--;                                    // :165-167
-            if (count < 32) { nodes[count].frame = rel; nodes[count].value = curve[k].value; count++; }
+            const CurveSpanNode nn{rel, nd.value};
+            if (has_b && b.frame == rel) b = nn;                                                        // :165-167: replaces the node on its frame
+            else if (count < 32) {
+                if (has_b) { if (has_a) node_spans(tb, a, true, b); a = b; has_a = true; }
+                b = nn; has_b = true; count++;
+            }
             if (!one_past) { cur = next; off = 0; next += 1; }                                          // :173-177
         }
+        if (has_b) {
+            if (has_a) node_spans(tb, a, true, b);
+            node_spans(tb, b, false, b);
+        }
+        if (dest_start < out_len) add_span(tb, out_len, false, 0.0f, 0.0f, 0.0f, 0.0f);                 // the tail (no node left: :252-254)
         t += buf_time;                                                 // :180
         off -= (int32_t)out_len;                                       // :181
-        span_end = 0;
-        has_values = false;
-        acc = step = start_value = value_delta = 0.0f;
+        k = 0;
     }
-    // getNextCurveSpan + the per-span setup of :84-107
-    __device__ __forceinline__ void next_span(uint32_t dest_start_) {
-        const int32_t dest_start = (int32_t)dest_start_, dest_end = (int32_t)out_len;
-        has_values = false;
-        span_end = out_len;
-        for (uint32_t i = 0; i < count; i++) {
-            const int32_t start_pos = nodes[i].frame;
-            if (start_pos >= dest_end) break;
-            const int32_t end_pos = (i + 1 < count) ? min(dest_end, nodes[i + 1].frame) : dest_end;
-            if (end_pos <= dest_start) continue;
-            const int32_t note_start_clipped = start_pos > dest_start ? start_pos : dest_start;
-            if (note_start_clipped > dest_start) { span_end = (uint32_t)note_start_clipped; return; }   // gap
-            span_end = (uint32_t)(end_pos > dest_end ? dest_end : end_pos);
-            if (i + 1 < count) {
-                has_values = true;
-                const int32_t fstart = nodes[i].frame, fend = nodes[i + 1].frame;
-                const float start_x = (float)(dest_start - fstart) / (float)(fend - fstart);           // :95
-                start_value = nodes[i].value;
-                value_delta = nodes[i + 1].value - nodes[i].value;
-                const float x_step = 1.0f / (float)(fend - fstart);                                     // :100
-                if (function == ZH_CURVE_FN_LINEAR) { acc = start_value + start_x * value_delta; step = x_step * value_delta; }
-                else { acc = start_x; step = x_step; }
-            }
-            return;
-        }
+    __device__ __forceinline__ void advance_span(const CurveTable &tb) {
+        k = k + 1 < kCurveSpans ? k + 1 : k;
+        span_end = tb.s_end[k] & 0x7FFFFFFFu; has_values = (tb.s_end[k] >> 31) != 0;
+        acc = tb.s_acc[k]; step = tb.s_step[k]; start_value = tb.s_sv[k]; value_delta = tb.s_vd[k];
     }
-    // r = frame index relative to the paint span's start
-    __device__ __forceinline__ bool frame(uint32_t r, float &val) {
-        if (r == span_end) next_span(r);
-        if (!has_values) return false;
-        if (function == ZH_CURVE_FN_LINEAR) { val = acc; acc += step; }                                 // :109-112
-        else { val = start_value + acc * acc * (3.0f - 2.0f * acc) * value_delta; acc += step; }       // :117-121
-        return true;
+    // r = frame index relative to the paint span's start.  Straight-line apart from the (rare) span change: `function` is
+    // the same for every voice, and a span without values (a gap) never reads acc, so the accumulator runs unconditionally
+    __device__ __forceinline__ bool frame(const CurveTable &tb, uint32_t r, float &val) {
+        if (r == span_end) advance_span(tb);
+        return frame_in_span(val);
+    }
+    // frame() where the running span is known not to end (seq.hip.h frame_loop_gen): no lane's span ends in [r, r + n)
+    __device__ __forceinline__ bool quiet(uint32_t r, uint32_t n) const { return __builtin_amdgcn_ballot_w64(span_end - r < n) == 0; }
+    __device__ __forceinline__ bool frame_in_span(float &val) {
+        if (function == ZH_CURVE_FN_LINEAR) val = acc;                                                  // :109-112
+        else val = start_value + acc * acc * (3.0f - 2.0f * acc) * value_delta;                         // :117-121
+        acc += step;
+        return has_values;
     }
 };
 

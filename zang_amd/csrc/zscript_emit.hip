@@ -591,15 +591,16 @@ public:
             value = o + ".frame()";
         } else if (name == "Curve") {
             decl.push_back("CurveLane " + o + ";");
+            decl.push_back("CurveTable " + o + "_tb;");
             ld_f("t", w);
             ld_u("cur", w + 1, "");
             ld_u("off", w + 2, "(int32_t)");
             ld_u("next", w + 3, "");
-            pro.push_back(o + ".begin(" + sr + ", (uint32_t)(" + enum_tag(a["function"], *callee.params[1].type.en) + "), " + a["curve"].expr + ", " + a["curve"].count + ", " +
+            pro.push_back(o + ".begin(" + o + "_tb, " + sr + ", (uint32_t)(" + enum_tag(a["function"], *callee.params[1].type.en) + "), " + a["curve"].expr + ", " + a["curve"].count + ", " +
                           mc.length + ", " + mc.nic + ");");
             auto pp = painted_pair();
             frame.push_back("float " + pp.first + " = 0.0f;");
-            frame.push_back("const bool " + pp.second + " = " + o + ".frame(" + mc.rel + ", " + pp.first + ");");
+            frame.push_back("const bool " + pp.second + " = " + o + ".frame(" + o + "_tb, " + mc.rel + ", " + pp.first + ");");
             painted = pp.second; value = pp.first;
         } else {
             throw HipBackendError{"builtin module " + name + " is not supported by the HIP backend"};
