@@ -77,10 +77,11 @@ def test_const_freq_zero_first(ctx, oracle, kind):
 @pytest.mark.parametrize("kind,colors", [("pulse", [0.0, 0.3, 0.5, 1.0]), ("trisaw", [0.1, 0.5, 0.9, 0.25])])
 @pytest.mark.parametrize("spans", [util.SPANS_ONE, util.SPANS_THREE])
 def test_controlled_freq(ctx, oracle, kind, colors, spans, form, monkeypatch):
-    """(PulseOsc at a small voice count paints a controlled-frequency span as frame ranges at once, each range first
-    summing the earlier frames' phase increments; ZH_PULSE_CTRL_RANGES=0 is the lane-per-voice walk.)"""
+    """(Both oscillators at a small voice count paint a controlled-frequency span as frame ranges at once, each range first
+    summing the earlier frames' phase increments; ZH_PULSE_CTRL_RANGES=0 / ZH_TRISAW_CTRL_RANGES=0 is the lane-per-voice walk.)"""
     if form == "sequential":
         monkeypatch.setenv("ZH_PULSE_CTRL_RANGES", "0")
+        monkeypatch.setenv("ZH_TRISAW_CTRL_RANGES", "0")
     V, F = 192, 1024
     rng = np.random.default_rng(11)
     freq_buf = rng.uniform(-200.0, 7000.0, (V, F)).astype(np.float32)   # includes out-of-range samples

@@ -43,6 +43,7 @@ struct zh_pulseosc : zh_flipper {
 
 struct zh_trisawosc : zh_flipper {
     float *t;
+    float *t_next;            // k_trisawosc_ctrl's frame ranges: the phase after the span, moved into `t` by k_commit_f32
     OscTable tab;
 };
 
@@ -335,23 +336,47 @@ struct TriSawOscP {
 };
 
 // TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt
+// One lane per voice walks the span (grid.y == 1, ch = the span, t_in == t_out), or -- few voices -- the span as grid.y
+// frame ranges at once: the phase that reaches frame f0 is the start phase plus freq / sample_rate of every earlier frame,
+// added in frame order (f32), so a range replays that (a load, the divide and an add per frame; the naive waveform is another
+// ~20 instructions) and then paints its own frames.  The range that ends the span writes the phase to t_out (a buffer of
+// its own; k_commit_f32 moves it into place once every range has read the start phase).
 template <bool ZF>
-__global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(float *__restrict__ t_io, uint32_t V, Img out,
-                                                              uint32_t start, uint32_t end, float sample_rate,
+__global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
+                                                              uint32_t start, uint32_t end, uint32_t ch, float sample_rate,
                                                               CImg freq_b, F32P color_p) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
     TriSawOscLane o;
-    o.t = t_io[v];
+    o.t = t_in[v];
     o.begin_ctrl(sample_rate, color_p.get(v));
+    {
+        const float *fp = freq_b.p + (size_t)start * freq_b.stride + v;
+        uint32_t i = start;
+        for (; i + 16 <= f0; i += 16, fp += 16 * freq_b.stride) {       // 16 rows in flight
+            float x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fp[(size_t)k * freq_b.stride];
+#pragma unroll
+            for (int k = 0; k < 16; k++) o.t += x[k] / sample_rate;     // frame_ctrl's step (TriSawOsc.zig:151)
+        }
+        for (; i < f0; i++, fp += freq_b.stride) o.t += *fp / sample_rate;
+    }
     const float *ins[1] = {freq_b.p};
     const size_t istr[1] = {freq_b.stride};
-    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, start, end, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
+    frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, f0, f1, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
         val = o.frame_ctrl(x[0]);
         return true;
     });
-    o.end_ctrl();
-    t_io[v] = o.t;
+    if (f1 == end) {
+        o.end_ctrl();
+        t_out[v] = o.t;
+    }
+}
+__global__ void __launch_bounds__(256) k_commit_f32(float *__restrict__ dst, const float *__restrict__ src, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
@@ -565,11 +590,12 @@ int zh_trisawosc_create(zh_ctx *ctx, uint32_t n, zh_trisawosc **out) { ZH_GUARD(
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_trisawosc *m = new (std::nothrow) zh_trisawosc();
     if (!m) return ZH_ERR_INVALID;
-    m->t = nullptr;
+    m->t = nullptr; m->t_next = nullptr;
     int rc = osc_create_common(ctx, m, n, (int)(sizeof(TriSawK) / 4));
     if (!rc) rc = dev_alloc(&m->t, n);
+    if (!rc) rc = dev_alloc(&m->t_next, n);
     if (!rc && n) rc = (int)hipMemsetAsync(m->t, 0, (size_t)n * 4, ctx->stream);
-    if (rc) { osc_free_common(m); hipFree(m->t); delete m; return rc; }
+    if (rc) { osc_free_common(m); hipFree(m->t); hipFree(m->t_next); delete m; return rc; }
     zh_flipper_register(m);
     *out = m;
     return ZH_OK;
@@ -578,7 +604,7 @@ int zh_trisawosc_destroy(zh_trisawosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     hipStreamSynchronize(m->ctx->stream);
     zh_flipper_unregister(m);
-    osc_free_common(m); hipFree(m->t);
+    osc_free_common(m); hipFree(m->t); hipFree(m->t_next);
     delete m;
     return ZH_OK;
 }
@@ -612,10 +638,19 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
     if (p->freq.tag == ZH_COB_CONSTANT) {
         launch_osc_const<TriSawOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
+        bool aliased = false;
+        for (uint32_t b = 0; b < nb; b++) aliased = aliased || bufs_alias(p->freq.buffer, outputs[b]);
+        // 4,096 voices: 106.6 us with per-lane branches in the waveform, 71.3 straight-line, 46.4 as 16 frame ranges (8 / 32 /
+        // 64 ranges: 47.9 / 54.7 / 77.2 -- the replay's divide is half of a painted frame); 16,384 voices: 73.7 -> 66.2 with 8
+        const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, "ZH_TRISAW_CTRL_RANGES", 1024, 16384);
         for (uint32_t b = 0; b < nb; b++) {
             Img out = mk_img(outputs[b]);
-            if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
-            else hipLaunchKernelGGL(k_trisawosc_ctrl<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t, m->n, out, start, end, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+            float *to = chr ? m->t_next : m->t;
+            const uint32_t ch = chr ? chr : end - start;
+            const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
+            if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+            else hipLaunchKernelGGL(k_trisawosc_ctrl<false>, grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+            if (chr) hipLaunchKernelGGL(k_commit_f32, dim3((m->n + 255) / 256), dim3(256), 0, st, m->t, m->t_next, m->n);
         }
     }
     return zh_launch_status();
