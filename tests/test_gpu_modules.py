@@ -251,6 +251,55 @@ def test_noise_seed_known_answer(ctx):
     util.assert_bitexact(got, k, "noise K1")
 
 
+@pytest.mark.parametrize("form", ["pipeline", "sequential"])
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("V", [300, 4096])
+def test_noise_pink_pipeline(ctx, oracle, zero_first, V, form, monkeypatch):
+    """Few voices: pink noise = the white samples painted as frame ranges into a module-owned image, then Kellett's filter
+    as a seven-wave pipeline per 64 voices (six taps adding into a running sum through LDS, a final wave; k_pink_pipe).
+    Bit for bit the oracle's one loop -- with non-zero taps in the state (the reference starts every paint from self.b and
+    never writes it back, Noise.zig:55/68), a voice whose span holds a multi-draw sample, ragged spans; ZH_PINK_PIPE_MAX=0 is
+    the lane-per-voice kernel."""
+    from zang_amd import modules as mod, zang
+    if form == "sequential":
+        monkeypatch.setenv("ZH_PINK_PIPE_MAX", "0")
+    first = 777
+    rng = np.random.default_rng(78)
+    L = oracle.lib()
+    nzs = []
+    for v in range(V):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + v)
+        nzs.append(nz)
+    target = [0, int(rng.integers(1, 1 << 63)), int(rng.integers(1, 1 << 63)), 1 << 41]
+    back = _xoshiro_step_back(target, 333)
+    for i in range(4):
+        nzs[17].r[i] = back[i]
+    taps = rng.uniform(-0.5, 0.5, (V, 7)).astype(np.float32)
+    taps[::3] = 0.0
+    for v in range(V):
+        for j in range(7):
+            nzs[v].b[j] = float(taps[v, j])
+    m = mod.Noise(V, ctx, first_seed=first)
+    st = m.state()
+    st["r"][17] = [int(x) for x in nzs[17].r]
+    st["b"][:] = taps
+    m.set_state(st)
+    out0 = util.rng_buffers(13, V, F)
+    for (s, e) in [(0, 1024), (0, 1024), (100, 612), (612, 1000), (5, 170)]:
+        ref = out0.copy()
+        if zero_first:
+            ref[:, s:e] = 0.0
+        for v in range(V):
+            L.zo_noise_paint(C.byref(nzs[v]), s, e, oracle.fptr(ref[v]), 1)
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(m.pink), zero_first=zero_first)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"pink noise {form}, span {(s, e)}")
+        gs = m.state()
+        assert [[int(x) for x in row] for row in gs["r"]] == [list(n.r) for n in nzs], f"states after span {(s, e)}"
+        util.assert_bitexact(gs["b"].astype(np.float32), taps, "taps are never written back")
+
+
 # ------------------------------------------------------------------ Envelope
 def _env_case(oracle, ctx, V, curves, sustain, script, dur_scale=1.0):
     """script: list of (span, note_on[V] bool array, note_id_changed[V] bool array)."""

@@ -7,6 +7,7 @@
 // loaded into VGPRs once per span, walked over the span, stored once.  Stateless modules
 // (Gate, Distortion) are additionally split into frame chunks across waves.
 #include "common.hip.h"
+#include "ring.hip.h"
 #include <string.h>
 #include "zmath.hip.h"
 #include "dsp.hip.h"
@@ -115,6 +116,7 @@ struct zh_noise {
     // the frame-range form of white noise (noise_jump.hip): states after the span, multi-draw flags, and the image an
     // ADD paint is rendered into before it is added to the output
     uint64_t *nx[4]; uint32_t *flag; zh_buf scratch;
+    uint32_t *err;               // k_pink_pipe: a ring wait ran into its bound (never in a correct run; reported by get_state)
 };
 // noise_jump.hip
 uint32_t zh_noise_range_frames(uint32_t V, uint32_t n);
@@ -152,6 +154,150 @@ __global__ void __launch_bounds__(kSeqBlock) k_noise(uint64_t *__restrict__ s0, 
     });
     // Noise.zig:68 is `b = self.b;` -- the taps are never written back (reference quirk, kept)
     s0[v] = o.r.s0; s1[v] = o.r.s1; s2[v] = o.r.s2; s3[v] = o.r.s3;   // :71
+}
+
+// Pink noise at a small voice count, from a rendered white image (the frame-range kernel of noise_jump.hip paints it first).
+// Paul Kellett's filter (Noise.zig:58-66) is six independent one-pole taps over the white samples plus a sum in a fixed order
+// -- ~30 dependent-issue instructions per sample for one wave.  Here seven waves per 64 voices form a pipeline through LDS:
+// wave k = 0..5 runs tap k and adds it to the running sum of the taps before it (s_k = s_{k-1} + b_k, the reference's
+// left-to-right order), the last wave adds b[6] and white * 0.5362, steps b[6] and does the `+=` into the output image.
+// 32-frame tiles, two slots per stage boundary, monotonic tile counters polled in LDS (ring.hip.h).  Per tile a stage reads
+// the incoming sums in one batch (read by read the compiler waits out the LDS latency in every frame), frees the slot, runs
+// its 3-4 VALU instructions and one ds_write per sample, and publishes.  Every wave fetches the white rows it needs from the
+// image itself (L2), one tile ahead: the ring waits are compiler barriers, nothing else would move a load across them.
+constexpr uint32_t kPinkWaves = 7, kPinkCH = 32, kPinkNS = 2;         // (16-frame tiles with 4 slots: 67 -> 77 us at 4,096 voices)
+struct PinkShared {
+    float sums[6][kPinkNS][kPinkCH][64];
+    uint32_t ready[6], freed[6];                                      // boundary k: tiles stage k has written / stage k + 1 has read
+};
+struct PinkTiles {
+    uint32_t n, nt, lane, voice;                                      // voice = the lane's (clamped) voice: its offset inside a row
+    __device__ __forceinline__ uint32_t frames(uint32_t c) const { return c < nt ? min(kPinkCH, n - c * kPinkCH) : 0; }
+    // rows [c * CH, c * CH + frames(c)) of one voice column; a full tile runs unguarded, fully unrolled code
+    // (`base` = the span's first row, wave-uniform)
+    __device__ __forceinline__ void load(float (&dst)[kPinkCH], const float *base, size_t stride, uint32_t c) const {
+        const uint32_t nf = frames(c);
+        const float *p0 = base + voice + (size_t)(c * kPinkCH) * stride;
+        if (nf == kPinkCH) {                                          // (plain global loads: through a buffer descriptor with scalar row offsets the kernel measured 5 % slower)
+#pragma unroll
+            for (uint32_t k = 0; k < kPinkCH; k++) dst[k] = p0[(size_t)k * stride];
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < kPinkCH; k++) dst[k] = k < nf ? p0[(size_t)k * stride] : 0.0f;
+        }
+    }
+};
+// KIND 0: tap 0 (nothing to add to), 1: taps 1..4, 2: tap 5 (`-0.7616 * b - white * 0.0168980`, :64)
+template <int KIND>
+__device__ __forceinline__ bool pink_tap_stage(PinkShared &sh, const PinkTiles &t, uint32_t stage, float cc, float dd, float b, const float *wp, size_t wstride) {
+    constexpr uint32_t CH = kPinkCH, NS = kPinkNS;
+    bool ok = true;
+    auto tile = [&](const float (&w)[CH], float (&wn)[CH], uint32_t c) ZH_INLINE_LAMBDA {
+        const uint32_t nf = t.frames(c), slot = c & (NS - 1);
+        if (KIND > 0) ok = ring_wait_ge(&sh.ready[stage - 1], c + 1);
+        if (c >= NS) ok = ok && ring_wait_ge(&sh.freed[stage], c + 1 - NS);
+        float sp[CH];
+        if (KIND > 0) {
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) sp[k] = sh.sums[stage - 1][slot][k][t.lane];
+            ring_publish(&sh.freed[stage - 1], c + 1, t.lane);
+        }
+        float (*sout)[64] = sh.sums[stage][slot];
+        auto tap = [&](uint32_t k) ZH_INLINE_LAMBDA {
+            const float m1 = cc * b, m2 = w[k] * dd;                  // :59-64
+            b = KIND == 2 ? m1 - m2 : m1 + m2;
+            sout[k][t.lane] = KIND > 0 ? sp[k] + b : b;               // :65, left to right
+        };
+        // the next tile's white rows are requested right after this tile's first use of its own: the compiler waits for
+        // EVERY outstanding load at that first use (vmcnt(0)), so a request made earlier would be waited out on the spot
+        if (nf == CH) {
+            tap(0);
+            __builtin_amdgcn_sched_barrier(0);
+            t.load(wn, wp, wstride, c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t k = 1; k < CH; k++) tap(k);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) if (k < nf) tap(k);
+        }
+        ring_publish(&sh.ready[stage], c + 1, t.lane);
+    };
+    float wa[CH], wb[CH];
+    t.load(wa, wp, wstride, 0);
+    for (uint32_t c = 0; c < t.nt && ok; c += 2) {                    // two tiles per turn: the white rows ping-pong between wa and wb
+        tile(wa, wb, c);
+        if (c + 1 < t.nt && ok) tile(wb, wa, c + 1);
+    }
+    return ok;
+}
+template <bool ZF>
+__global__ void __launch_bounds__(64 * kPinkWaves) k_pink_pipe(const float *__restrict__ bst, uint32_t V, Img out, CImg white, uint32_t start,
+                                                               uint32_t end, uint32_t *__restrict__ err) {
+    constexpr uint32_t CH = kPinkCH, NS = kPinkNS;
+    __shared__ PinkShared sh;
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t v = blockIdx.x * 64 + lane, vc = min(v, V - 1);
+    if (threadIdx.x < 6) { sh.ready[threadIdx.x] = 0; sh.freed[threadIdx.x] = 0; }
+    __syncthreads();
+    const uint32_t n = end - start;
+    const PinkTiles t{n, (n + CH - 1) / CH, lane, vc};
+    const float *wp = white.p + (size_t)start * white.stride;         // wave-uniform; the lane adds its voice
+    bool ok = true;
+    if (wave < 6) {
+        // Noise.zig:59-64
+        const float cc = wave == 0 ? 0.99886f : wave == 1 ? 0.99332f : wave == 2 ? 0.96900f : wave == 3 ? 0.86650f : wave == 4 ? 0.55000f : -0.7616f;
+        const float dd = wave == 0 ? 0.0555179f : wave == 1 ? 0.0750759f : wave == 2 ? 0.1538520f : wave == 3 ? 0.3104856f : wave == 4 ? 0.5329522f : 0.0168980f;
+        const float b = bst[(size_t)wave * V + vc];                   // `var b = self.b` (:55)
+        if (wave == 0) ok = pink_tap_stage<0>(sh, t, wave, cc, dd, b, wp, white.stride);
+        else if (wave == 5) ok = pink_tap_stage<2>(sh, t, wave, cc, dd, b, wp, white.stride);
+        else ok = pink_tap_stage<1>(sh, t, wave, cc, dd, b, wp, white.stride);
+    } else {
+        float b6 = bst[(size_t)6 * V + vc];
+        float *ob = out.p + (size_t)start * out.stride, *op = ob + vc;
+        auto tile = [&](const float (&w)[CH], float (&wn)[CH], const float (&base)[CH], float (&basen)[CH], uint32_t c) ZH_INLINE_LAMBDA {
+            const uint32_t nf = t.frames(c), slot = c & (NS - 1);
+            ok = ring_wait_ge(&sh.ready[5], c + 1);
+            float res[CH], sp[CH];
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) sp[k] = sh.sums[5][slot][k][lane];
+            ring_publish(&sh.freed[5], c + 1, lane);
+            auto fin = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                const float val = (sp[k] + b6) + w[k] * 0.5362f;      // :65
+                b6 = w[k] * 0.115926f;                                // :66
+                res[k] = (ZF ? 0.0f : base[k]) + val;
+            };
+            float *o0 = op + (size_t)(c * CH) * out.stride;
+            if (nf == CH) {
+                fin(0);
+                __builtin_amdgcn_sched_barrier(0);
+                t.load(wn, wp, white.stride, c + 1);                  // (see pink_tap_stage)
+                if (!ZF) t.load(basen, ob, out.stride, c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (uint32_t k = 1; k < CH; k++) fin(k);
+                if (v < V) {
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) o0[(size_t)k * out.stride] = res[k];
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) if (k < nf) fin(k);
+                if (v < V) {
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) if (k < nf) o0[(size_t)k * out.stride] = res[k];
+                }
+            }
+        };
+        float wa[CH], wb[CH], ba[CH], bb[CH];
+        t.load(wa, wp, white.stride, 0);
+        if (!ZF) t.load(ba, ob, out.stride, 0);
+        for (uint32_t c = 0; c < t.nt && ok; c += 2) {
+            tile(wa, wb, ba, bb, c);
+            if (c + 1 < t.nt && ok) tile(wb, wa, bb, ba, c + 1);
+        }
+    }
+    if (!ok && lane == 0) *err = 1u;
 }
 
 // =================================================================== Envelope
@@ -613,13 +759,13 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
 static void noise_free(zh_noise *m) {
     for (auto &x : m->s) (void)hipFree(x);
     for (auto &x : m->nx) (void)hipFree(x);
-    (void)hipFree(m->b); (void)hipFree(m->flag); (void)hipFree(m->scratch.ptr);
+    (void)hipFree(m->b); (void)hipFree(m->flag); (void)hipFree(m->scratch.ptr); (void)hipFree(m->err);
 }
 int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_noise *m = new (std::nothrow) zh_noise();
     if (!m) return ZH_ERR_INVALID;
-    m->ctx = ctx; m->n = n; m->b = nullptr; m->flag = nullptr;
+    m->ctx = ctx; m->n = n; m->b = nullptr; m->flag = nullptr; m->err = nullptr;
     for (int i = 0; i < 4; i++) m->s[i] = m->nx[i] = nullptr;
     memset(&m->scratch, 0, sizeof m->scratch);
     int rc = 0;
@@ -628,6 +774,8 @@ int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out
     if (!rc) rc = dev_alloc(&m->b, (size_t)7 * n);
     if (!rc) rc = dev_alloc(&m->flag, n);
     if (!rc && n) rc = (int)hipMemsetAsync(m->flag, 0, (size_t)n * 4, ctx->stream);
+    if (!rc) rc = dev_alloc(&m->err, 1);
+    if (!rc) rc = (int)hipMemsetAsync(m->err, 0, 4, ctx->stream);
     if (rc) { noise_free(m); delete m; return rc; }
     if (n) hipLaunchKernelGGL(k_noise_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], m->b, n, first_seed);
     // the jump tables are per context and built on first use; doing that here keeps it out of paint (and out of any capture)
@@ -644,6 +792,8 @@ int zh_noise_destroy(zh_noise *m) { ZH_GUARD(m ? m->ctx : nullptr);
 }
 int zh_noise_get_state(zh_noise *m, zh_noise_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
+    uint32_t ring_error = 0;
+    if (zh_download(m->ctx, &ring_error, m->err, 4) != ZH_OK || ring_error) return ZH_ERR_INVALID;
     std::vector<uint64_t> s;
     std::vector<float> b;
     for (int i = 0; i < 4; i++) {
@@ -677,28 +827,37 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (m->n == 0 || end == start) return ZH_OK;
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
-    // Few voices, white noise: many frame ranges of the span at once (noise_jump.hip).  A zero + paint call writes the
-    // output directly; the reference's `+=` onto existing content renders into a module-owned image first and adds it
-    // (the repair of a multi-draw voice needs the noise on its own).
-    if (p->color == ZH_NOISE_WHITE) {
-        const uint32_t ch = zh_noise_range_frames(m->n, end - start);
-        if (ch) {
-            if (zf) {
-                rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, outputs[0], start, end, ch);
+    // Few voices: the white samples as many frame ranges of the span at once (noise_jump.hip).  White noise with zero +
+    // paint writes the output directly; the reference's `+=` onto existing content, and pink noise, render the white into a
+    // module-owned image first (the repair of a multi-draw voice needs the noise on its own) and add / filter it from there.
+    const uint32_t ch = zh_noise_range_frames(m->n, end - start);
+    const bool pink = p->color == ZH_NOISE_PINK;
+    // pink, 1,024 / 4,096 / 16,384 voices: 124 / 116 / 118 us in one loop, 57 / 67 / 84 us as white ranges + pipeline (the
+    // white kernel is 10-29 us of that); at 32,768 voices the pipeline loses (161 against 129)
+    const char *pe = pink ? getenv("ZH_PINK_PIPE_MAX") : nullptr;     // read at every paint (tests switch forms)
+    const uint32_t pink_max = pe ? (uint32_t)atoi(pe) : 16384u;
+    if (ch && (!pink || m->n <= pink_max)) {
+        if (zf && !pink) {
+            rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, outputs[0], start, end, ch);
+            if (rc != ZH_ERR_UNSUPPORTED) return rc;
+        } else {
+            if ((m->scratch.frames < end || !m->scratch.ptr) && !m->ctx->capturing) {
+                zh_buf nb;
+                if (zh_buf_alloc(m->ctx, &nb, m->n, end) == ZH_OK) {
+                    if (m->scratch.ptr) m->ctx->mix_retired.push_back(m->scratch.ptr);   // a captured graph may still name it: freed with the context
+                    m->scratch = nb;
+                }
+            }
+            if (m->scratch.ptr && m->scratch.frames >= end) {
+                rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, m->scratch, start, end, ch);
+                if (rc == ZH_OK && !pink) return zh_add_into(m->ctx, start, end, outputs[0], m->scratch);
+                if (rc == ZH_OK) {
+                    const dim3 grid((m->n + 63) / 64);
+                    if (zf) hipLaunchKernelGGL(k_pink_pipe<true>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                    else hipLaunchKernelGGL(k_pink_pipe<false>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                    return zh_launch_status();
+                }
                 if (rc != ZH_ERR_UNSUPPORTED) return rc;
-            } else {
-                if ((m->scratch.frames < end || !m->scratch.ptr) && !m->ctx->capturing) {
-                    zh_buf nb;
-                    if (zh_buf_alloc(m->ctx, &nb, m->n, end) == ZH_OK) {
-                        if (m->scratch.ptr) m->ctx->mix_retired.push_back(m->scratch.ptr);   // a captured graph may still name it: freed with the context
-                        m->scratch = nb;
-                    }
-                }
-                if (m->scratch.ptr && m->scratch.frames >= end) {
-                    rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, m->scratch, start, end, ch);
-                    if (rc == ZH_OK) return zh_add_into(m->ctx, start, end, outputs[0], m->scratch);
-                    if (rc != ZH_ERR_UNSUPPORTED) return rc;
-                }
             }
         }
     }
