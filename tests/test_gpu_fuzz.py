@@ -247,9 +247,135 @@ def test_fuzz_sampler(ctx, oracle, seed):
     util.assert_bitexact(m.state()["t"].astype(np.float32), np.array([s.t for s in sts], np.float32), "t")
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_envelope(ctx, oracle, seed):
+    """Envelope: random curve tags (shared-tag kernels, the generic one, instantaneous), per-voice durations from a few frames
+    to several buffers (stages end anywhere inside an 8-frame chunk, or not at all), random note scripts; ragged spans."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(7000 + seed)
+    V = int(rng.choice([1, 64, 100, 257]))
+    tags = [int(x) for x in (rng.integers(0, 4, 3) if rng.random() < 0.5 else [int(rng.integers(1, 4))] * 3)]
+    dur = [np.exp(rng.uniform(np.log(0.0001), np.log(0.08), V)).astype(np.float32) for _ in range(3)]
+    sus = rng.choice(np.array([0.0, 0.3, 0.8, 1.0], np.float32), V).astype(np.float32)
+    L = oracle.lib()
+    sts = []
+    for v in range(V):
+        st = oracle.Envelope(); L.zo_envelope_init(C.byref(st)); sts.append(st)
+    m = mod.Envelope(V, ctx)
+    mk = [None, zang.PaintCurve.linear, zang.PaintCurve.squared, zang.PaintCurve.cubed]
+    gc = [zang.PaintCurve.instantaneous if tags[i] == 0 else mk[tags[i]](util.dev(dur[i])) for i in range(3)]
+    img = util.rng_buffers(seed + 200, V, F)
+    on_prev = np.zeros(V, bool)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 8)):
+        on = np.where(rng.random(V) < 0.3, ~on_prev, on_prev)
+        nic = on & (~on_prev | (rng.random(V) < 0.2))            # a note that starts gets a new id (the reference asserts it)
+        on_prev = on
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        for v in range(V):
+            p = oracle.EnvelopeParams(SR, oracle.curve(tags[0], dur[0][v]), oracle.curve(tags[1], dur[1][v]),
+                                      oracle.curve(tags[2], dur[2][v]), float(sus[v]), int(on[v]))
+            L.zo_envelope_paint(C.byref(sts[v]), a, b, oracle.fptr(ref[v]), int(nic[v]), C.byref(p))
+        out = util.to_image(img)
+        m.paint(zang.Span(a, b), [out], [], util.dev(nic.astype(np.uint8)),
+                m.Params(SR, gc[0], gc[1], gc[2], util.dev(sus), util.dev(on.astype(np.uint8))), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"envelope seed {seed} call {k} V={V} span {(a, b)} zf={zf} tags={tags}")
+        img = ref
+    st = m.state()
+    assert [int(x) for x in st["state"]] == [s.state for s in sts]
+    util.assert_bitexact(st["t"].astype(np.float32), np.array([s.painter.t for s in sts], np.float32), "envelope t")
+    util.assert_bitexact(st["last_value"].astype(np.float32), np.array([s.painter.last_value for s in sts], np.float32), "envelope last_value")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_decimator_portamento(ctx, oracle, seed):
+    """Decimator (all three modes in one wave, rates from 1/200 to above the sample rate; frame ranges for long spans) and
+    Portamento (random curves / durations / goals, glides that arrive mid-chunk, waves that are flat throughout)."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(8000 + seed)
+    V = int(rng.choice([1, 64, 96, 200]))
+    L = oracle.lib()
+    fake = np.exp(rng.uniform(np.log(240.0), np.log(60000.0), V)).astype(np.float32)
+    fake[rng.random(V) < 0.1] = np.float32(0.0)
+    fake[rng.random(V) < 0.1] = np.float32(48000.0)
+    inp = util.rng_buffers(seed + 230, V, F)
+    dsts, psts = [], []
+    for v in range(V):
+        d = oracle.Decimator(); L.zo_decimator_init(C.byref(d)); dsts.append(d)
+        q = oracle.Portamento(); L.zo_portamento_init(C.byref(q)); psts.append(q)
+    md, mp = mod.Decimator(V, ctx), mod.Portamento(V, ctx)
+    gi = util.to_image(inp)
+    tag = int(rng.integers(0, 4))
+    dur = np.exp(rng.uniform(np.log(0.0002), np.log(0.05), V)).astype(np.float32)
+    mk = [None, zang.PaintCurve.linear, zang.PaintCurve.squared, zang.PaintCurve.cubed]
+    gcurve = zang.PaintCurve.instantaneous if tag == 0 else mk[tag](util.dev(dur))
+    img_d = util.rng_buffers(seed + 231, V, F); img_p = util.rng_buffers(seed + 232, V, F)
+    u8 = lambda x: util.dev(x.astype(np.uint8))
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 7)):
+        goal = rng.uniform(50, 3000, V).astype(np.float32)
+        on, prev, nic = rng.random(V) < 0.7, rng.random(V) < 0.7, rng.random(V) < 0.3
+        ref_d, ref_p = img_d.copy(), img_p.copy()
+        if zf:
+            ref_d[:, a:b] = 0.0; ref_p[:, a:b] = 0.0
+        for v in range(V):
+            L.zo_decimator_paint(C.byref(dsts[v]), a, b, oracle.fptr(ref_d[v]), SR, oracle.fptr(inp[v]), float(fake[v]))
+            L.zo_portamento_paint(C.byref(psts[v]), a, b, oracle.fptr(ref_p[v]), int(nic[v]), SR, oracle.curve(tag, dur[v]), float(goal[v]), int(on[v]), int(prev[v]))
+        od, op = util.to_image(img_d), util.to_image(img_p)
+        md.paint(zang.Span(a, b), [od], [], False, md.Params(SR, gi, util.dev(fake)), zero_first=zf)
+        mp.paint(zang.Span(a, b), [op], [], u8(nic), mp.Params(SR, gcurve, util.dev(goal), u8(on), u8(prev)), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(od), ref_d, f"decimator seed {seed} call {k} V={V} span {(a, b)} zf={zf}")
+        util.assert_bitexact(util.from_image(op), ref_p, f"portamento seed {seed} call {k} V={V} span {(a, b)} zf={zf} tag={tag}")
+        img_d, img_p = ref_d, ref_p
+    st = md.state()
+    util.assert_bitexact(st["dval"].astype(np.float32), np.array([d.dval for d in dsts], np.float32), "dval")
+    util.assert_bitexact(st["dcount"].astype(np.float32), np.array([d.dcount for d in dsts], np.float32), "dcount")
+    st = mp.state()
+    util.assert_bitexact(st["t"].astype(np.float32), np.array([q.painter.t for q in psts], np.float32), "portamento t")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_osc_control_images(ctx, oracle, seed):
+    """PulseOsc / TriSawOsc with a frequency image (out-of-range samples included): frame ranges for long spans, the walk for
+    short ones, += and ZERO_FIRST, state carried from call to call."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(9000 + seed)
+    V = int(rng.choice([1, 64, 130, 192]))
+    L = oracle.lib()
+    color = rng.uniform(0.0, 1.0, V).astype(np.float32)
+    ps, ts = [], []
+    for v in range(V):
+        a_ = oracle.PulseOsc(); L.zo_pulseosc_init(C.byref(a_)); ps.append(a_)
+        b_ = oracle.TriSawOsc(); L.zo_trisawosc_init(C.byref(b_)); ts.append(b_)
+    mp_, mt_ = mod.PulseOsc(V, ctx), mod.TriSawOsc(V, ctx)
+    img_p = util.rng_buffers(seed + 260, V, F); img_t = util.rng_buffers(seed + 261, V, F)
+    gc = util.dev(color)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 6)):
+        fbuf = rng.uniform(-300.0, 7000.0, (V, F)).astype(np.float32)
+        ref_p, ref_t = img_p.copy(), img_t.copy()
+        if zf:
+            ref_p[:, a:b] = 0.0; ref_t[:, a:b] = 0.0
+        for v in range(V):
+            L.zo_pulseosc_paint(C.byref(ps[v]), a, b, oracle.fptr(ref_p[v]), SR, oracle.buffer(fbuf[v]), float(color[v]))
+            L.zo_trisawosc_paint(C.byref(ts[v]), a, b, oracle.fptr(ref_t[v]), SR, oracle.buffer(fbuf[v]), float(color[v]))
+        gf = util.to_image(fbuf)
+        op, ot = util.to_image(img_p), util.to_image(img_t)
+        mp_.paint(zang.Span(a, b), [op], [], False, mp_.Params(SR, zang.buffer(gf), gc), zero_first=zf)
+        mt_.paint(zang.Span(a, b), [ot], [], False, mt_.Params(SR, zang.buffer(gf), gc), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(op), ref_p, f"pulseosc image seed {seed} call {k} V={V} span {(a, b)} zf={zf}")
+        util.assert_bitexact(util.from_image(ot), ref_t, f"trisawosc image seed {seed} call {k} V={V} span {(a, b)} zf={zf}")
+        img_p, img_t = ref_p, ref_t
+    assert [int(x) for x in mp_.state()["cnt"]] == [x.cnt for x in ps]
+    util.assert_bitexact(mt_.state()["t"].astype(np.float32), np.array([x.t for x in ts], np.float32), "trisaw t")
+
+
 def test_fuzz_again_with_the_single_wave_forms():
     """The same random cases through the lane-per-voice sequential forms (k_nice, k_noise_filter, k_noise, k_sineosc, the
-    one-range k_sampler: what runs above the voice-count limits of the pipelined / frame-range forms)."""
+    one-range k_sampler / k_decimator / oscillator control kernels: what runs above the voice-count limits of the pipelined /
+    frame-range forms)."""
     import os
     import subprocess
     import sys
@@ -257,8 +383,9 @@ def test_fuzz_again_with_the_single_wave_forms():
         pytest.skip("already the rerun")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZH_NICE_PC_MAX="0", ZH_NF_PC_MAX="0", ZH_NF_RING_MAX="0", ZH_NOISE_RANGES="0", ZH_SINE_RANGES="0",
-               ZH_SAMPLER_RANGES="0", ZH_FUZZ_CHILD="1")
+               ZH_SAMPLER_RANGES="0", ZH_DECIMATOR_RANGES="0", ZH_PULSE_CTRL_RANGES="0", ZH_TRISAW_CTRL_RANGES="0", ZH_PINK_PIPE_MAX="0",
+               ZH_FUZZ_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fuzz.py", "-q", "-m", "gpu"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "25 passed" in r.stdout
+    assert "36 passed" in r.stdout

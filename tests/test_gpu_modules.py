@@ -333,7 +333,7 @@ def _env_case(oracle, ctx, V, curves, sustain, script, dur_scale=1.0):
         util.assert_bitexact(st[name].astype(np.float32), np.array([r[k] for r in rst], np.float32), f"envelope {name}")
 
 
-@pytest.mark.parametrize("curves", [(1, 1, 1), (2, 2, 2), (3, 3, 3), (0, 3, 3), (3, 0, 3), (3, 3, 0), (0, 0, 0)])
+@pytest.mark.parametrize("curves", [(1, 1, 1), (2, 2, 2), (3, 3, 3), (1, 2, 3), (0, 3, 3), (3, 0, 3), (3, 3, 0), (0, 0, 0)])
 @pytest.mark.parametrize("sustain", [0.5, 1.0])
 def test_envelope_stages(ctx, oracle, curves, sustain, replay_form):
     V = 128
