@@ -14,9 +14,16 @@ F = 1024
 SPANS = [(0, 200), (200, 777), (777, 1024), (0, 1024), (0, 1024)]
 
 
-@pytest.mark.parametrize("D", [1, 7, 8, 9, 100, 1024, 3000])     # < 8: frame by frame; >= 8: chunks of 8 frames
-def test_simple_delay(ctx, oracle, D):
+@pytest.mark.parametrize("form", ["frames", "walk"])
+@pytest.mark.parametrize("zero_first", [False, True])
+@pytest.mark.parametrize("D", [1, 7, 8, 9, 100, 300, 577, 1024, 3000])     # < 8: frame by frame; >= 8: chunks of 8 frames
+def test_simple_delay(ctx, oracle, D, zero_first, form, monkeypatch):
+    """(Few voices, delay >= 8, spans >= 64 frames: the frames of a span are painted independently, k_delay_frames +
+    k_delay_store + k_delay_advance -- delays shorter than, equal to and longer than the span; ZH_DELAY_FRAMES_MAX=0 is the
+    per-voice walk.)"""
     from zang_amd import modules as mod, zang
+    if form == "walk":
+        monkeypatch.setenv("ZH_DELAY_FRAMES_MAX", "0")
     V = 96
     inp = [util.rng_buffers(10 + k, V, F) for k in range(len(SPANS))]
     out0 = util.rng_buffers(3, V, F)
@@ -26,12 +33,14 @@ def test_simple_delay(ctx, oracle, D):
     for v in range(V):
         d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D)
         for k, (s, e) in enumerate(SPANS):
+            if zero_first:
+                ref[k][v][s:e] = 0.0
             L.zo_simple_delay_paint(C.byref(d), s, e, oracle.fptr(ref[k][v]), oracle.fptr(inp[k][v]))
         ridx.append(d.index)
     m = mod.SimpleDelay(V, D, ctx)
     for k, (s, e) in enumerate(SPANS):
         out = util.to_image(out0)
-        m.paint(zang.Span(s, e), [out], [], False, m.Params(util.to_image(inp[k])))
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(util.to_image(inp[k])), zero_first=zero_first)
         ctx.sync()
         util.assert_bitexact(util.from_image(out), ref[k], f"simple delay D={D} paint {k}")
     grings, gidx = m.state()

@@ -68,6 +68,54 @@ __global__ void __launch_bounds__(kSeqBlock) k_simple_delay(DelayState d, Img ou
     d.index[v] = idx;
 }
 
+// SimpleDelay has no feedback: a frame's output is the ring slot it reads (the input of delay_samples frames ago) and the ring
+// afterwards holds the span's last delay_samples inputs, so the frames of a span are independent.  Few voices (a lone
+// wave per 64 voices walks 1,024 frames at ~10 issue slots each): the span as a grid of (64 voices x 32 frames) pieces --
+// frame j reads slot (index + j) mod n, which holds the old ring for j < delay_samples and input[j - delay_samples] after
+// that (read straight from the input image).  Then the ring is brought up to date from the input image and the indices
+// advance -- in kernels of their own, stream-ordered after every piece has read the old ring and the old index.
+// WRITE: the span is no longer than the delay, so every slot is touched by exactly one frame and that frame stores its input
+// right after reading (no k_delay_store launch).
+template <bool ZF, bool WRITE>
+__global__ void __launch_bounds__(256) k_delay_frames(DelayState d, Img out, CImg input, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t piece = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= d.n) return;
+    const uint32_t j0 = piece * 32, n = end - start;
+    if (j0 >= n) return;
+    const uint32_t j1 = min(j0 + 32, n), D = d.delay_samples;
+    uint32_t slot = (uint32_t)(((uint64_t)d.index[v] + j0) % D);
+    float *o = out.at(start + j0, v);
+    const float *in = input.at(start + j0, v);
+    for (uint32_t j = j0; j < j1; j++, o += out.stride, in += input.stride) {
+        float *rs = d.ring + (size_t)slot * d.n + v;
+        const float delayed = j < D ? *rs : *(in - (size_t)D * input.stride);   // readDelayBuffer (delay.zig:28-57)
+        *o = (ZF ? 0.0f : *o) + delayed;
+        if (WRITE) *rs = *in;                                         // writeDelayBuffer (:62-89)
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+}
+// the ring after the span: its last min(n, delay_samples) inputs, at the slots the frame walk would have left them in
+__global__ void __launch_bounds__(256) k_delay_store(DelayState d, CImg input, uint32_t start, uint32_t end) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t piece = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= d.n) return;
+    const uint32_t n = end - start, D = d.delay_samples, first = n > D ? n - D : 0;
+    const uint32_t j0 = first + piece * 32;
+    if (j0 >= n) return;
+    const uint32_t j1 = min(j0 + 32, n);
+    uint32_t slot = (uint32_t)(((uint64_t)d.index[v] + j0) % D);
+    const float *in = input.at(start + j0, v);
+    for (uint32_t j = j0; j < j1; j++, in += input.stride) {
+        d.ring[(size_t)slot * d.n + v] = *in;
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_delay_advance(DelayState d, uint32_t frames) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v < d.n) d.index[v] = (uint32_t)(((uint64_t)d.index[v] + frames) % d.delay_samples);
+}
+
 // FilteredEchoes.paint, examples/modules.zig:411-460
 template <bool ZF, uint32_t CH>
 __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, float *__restrict__ l_io, float *__restrict__ b_io,
@@ -196,6 +244,23 @@ int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
     if (m->d.n == 0 || end == start) return ZH_OK;
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
+    // delay 300, 1,024 frames, walk -> independent frames (three launches): 57 -> 28 us at 4,096 voices, 75 -> 37 at 16,384,
+    // 143 -> 96 at 32,768, 423 -> 320 at 131,072: at every voice count
+    const char *fe = getenv("ZH_DELAY_FRAMES_MAX");                     // read at every paint (tests switch forms)
+    const uint32_t frames_max = fe ? (uint32_t)atoi(fe) : 0xFFFFFFFFu;
+    if (chunked && m->d.n <= frames_max && end - start >= 64) {
+        hipStream_t st = m->ctx->stream;
+        const uint32_t n = end - start, D = m->d.delay_samples, stored = n < D ? n : D;
+        const bool fused = n <= D, zf = flags & ZH_PAINT_ZERO_FIRST;
+        const dim3 grid((m->d.n + 63) / 64, ((n + 31) / 32 + 3) / 4);
+#define ZH_DF(ZF_, W_) hipLaunchKernelGGL((k_delay_frames<ZF_, W_>), grid, dim3(256), 0, st, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end)
+        if (zf) { if (fused) ZH_DF(true, true); else ZH_DF(true, false); }
+        else { if (fused) ZH_DF(false, true); else ZH_DF(false, false); }
+#undef ZH_DF
+        if (!fused) hipLaunchKernelGGL(k_delay_store, dim3((m->d.n + 63) / 64, ((stored + 31) / 32 + 3) / 4), dim3(256), 0, st, m->d, mk_cimg(p->input), start, end);
+        hipLaunchKernelGGL(k_delay_advance, dim3((m->d.n + 255) / 256), dim3(256), 0, st, m->d, n);
+        return zh_launch_status();
+    }
 #define ZH_DL(ZF_, CH_) hipLaunchKernelGGL((k_simple_delay<ZF_, CH_>), seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end)
     if (flags & ZH_PAINT_ZERO_FIRST) { if (chunked) ZH_DL(true, 8); else ZH_DL(true, 1); }
     else { if (chunked) ZH_DL(false, 8); else ZH_DL(false, 1); }
