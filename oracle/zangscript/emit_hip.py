@@ -245,7 +245,11 @@ class HipEmitter:
             else:
                 value = "((%s) == 1u ? %s.frame<true>() : %s.frame<false>())" % (tag, o, o)
         elif name == "Envelope":
-            decl.append("EnvLane %s;" % o)
+            # three literal curves with one tag (not instantaneous): the tag-specialised lane, whose per-frame curve has no selects
+            tags = [self.enum_tag(a[st], callee.params[1 + i].param_type.enum) for i, st in enumerate(("attack", "decay", "release"))]
+            literal = all(isinstance(a[st].tag, str) and a[st].kind == "enum" and a[st].enum is None for st in ("attack", "decay", "release"))
+            one_tag = literal and tags[0] == tags[1] == tags[2] and tags[0] != "0"
+            decl.append("EnvLaneT<1, %s> %s;" % (tags[0], o) if one_tag else "EnvLane %s;" % o)
             ld_u("state", w)
             ld_f("t", w + 1)
             ld_f("last_value", w + 2)

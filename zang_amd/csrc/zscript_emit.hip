@@ -543,7 +543,11 @@ public:
             if (tag == "0" || tag == "1") value = o + ".frame<" + tf(tag == "1") + ">()";
             else value = "((" + tag + ") == 1u ? " + o + ".frame<true>() : " + o + ".frame<false>())";
         } else if (name == "Envelope") {
-            decl.push_back("EnvLane " + o + ";");
+            // three literal curves with one tag (not instantaneous): the tag-specialised lane, whose per-frame curve has no selects
+            const std::string t0 = enum_tag(a["attack"], *callee.params[1].type.en), t1 = enum_tag(a["decay"], *callee.params[2].type.en),
+                              t2 = enum_tag(a["release"], *callee.params[3].type.en);
+            const bool one_tag = a["attack"].tag_literal && a["decay"].tag_literal && a["release"].tag_literal && t0 == t1 && t1 == t2 && t0 != "0";
+            decl.push_back(one_tag ? "EnvLaneT<1, " + t0 + "> " + o + ";" : "EnvLane " + o + ";");
             ld_u("state", w, "");
             ld_f("t", w + 1);
             ld_f("last_value", w + 2);
