@@ -275,6 +275,101 @@ __global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t s
     if (live && role == 2) { a.fl[v] = n.l; a.fb[v] = n.b; }
 }
 
+// k_nice_pc with the filter wave reduced to the recurrence itself: the oscillator wave also adds the filter's input offset
+// (in = temps[0] + fcdcoffset, Filter.zig:135 -- a function of the sample alone), the filter wave runs svf_core (15 VALU
+// instructions per sample) and hands (l, b, h) on through LDS, and a FOURTH wave does the low-pass mix, the multiply with the
+// envelope, the `+=` and the store, two tiles behind the producers.  Same operations on the same values => same bits.
+// Measured at 4,096 voices with one wave's arithmetic compiled out at a time: 71 us as four waves with the full envelope
+// frame, 57.5 without the envelope's (it was the slowest wave: hence the quiet tiles below), then 57 -> 53.4 without the
+// oscillator's, 54.7 without the filter's, 42.9 without both (LDS traffic, barriers and the writer).
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t start, uint32_t end) {
+    constexpr uint32_t CH = 32;
+    __shared__ float in_t[2][CH][64], env_t[3][CH][64], lbh_t[2][3][CH][64];
+    const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 oscillator, 1 envelope, 2 filter, 3 writer
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < a.V;
+    const uint32_t vc = live ? v : a.V - 1;
+    const uint32_t n_frames = end - start, nchunks = (n_frames + CH - 1) / CH;
+    NiceLane n;
+    nice_load<1>(n, a, vc);
+    PulseRoll roll;
+    n.roll_begin(roll);
+    const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
+    for (uint32_t c = 0; c <= nchunks + 1; c++) {
+        if (role == 0 && c < nchunks) {
+            const uint32_t nf = min(CH, n_frames - c * CH);
+            float (*t)[64] = in_t[c & 1];
+            auto one = [&](uint32_t k) ZH_INLINE_LAMBDA { t[k][lane] = n.osc_next(roll) + kSvfDcOffset; };
+            if (nf == CH) {
+#pragma unroll 8
+                for (uint32_t k = 0; k < CH; k++) one(k);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k);
+            }
+        } else if (role == 1 && c < nchunks) {
+            const uint32_t nf = min(CH, n_frames - c * CH);
+            float (*t)[64] = env_t[c % 3];
+            if (nf == CH) {
+                // the envelope wave was the slowest of the four (compiled out: 71 -> 57 us): a tile in which no voice is inside
+                // a timed stage is one constant per voice, one in which no stage can end runs without the stage-end test
+                if (!zany_wave(n.env.mode == ENV_MODE_TOWARD)) {
+                    const float e0 = n.env_quiet();
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = e0;
+                } else if (n.env.quiet(CH)) {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.env.frame_masked_quiet();
+                } else {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
+                }
+            } else {
+                for (uint32_t k = 0; k < nf; k++) t[k][lane] = n.tail_env();
+            }
+        } else if (role == 2 && c > 0 && c <= nchunks) {
+            const uint32_t d = c - 1, nf = min(CH, n_frames - d * CH);
+            const float (*ti)[64] = in_t[d & 1];
+            float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
+            auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
+                const SvfOut s = svf_core(n.l, n.b, in, n.cut, n.res);
+                tl[k][lane] = s.l; tb[k][lane] = s.b; th[k][lane] = s.h;
+            };
+            if (nf == CH) {
+                float x[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) x[k] = ti[k][lane];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, x[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, ti[k][lane]);
+            }
+        } else if (role == 3 && c > 1) {
+            const uint32_t d = c - 2, nf = min(CH, n_frames - d * CH);
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
+            const float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
+            const float (*te)[64] = env_t[d % 3];
+            auto one = [&](uint32_t k, float l, float b, float h, float e0, float o) ZH_INLINE_LAMBDA {
+                const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);      // NiceLane::tail_filter's mix
+                zrow_store<1>(ro, voff, k * orow, o + e0 * t1);                // multiply :246: out += temps[0]*temps[1]
+            };
+            if (nf == CH) {
+                float xl[CH], xb[CH], xh[CH], xe[CH], oc[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; xe[k] = te[k][lane]; oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow); }
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], xe[k], oc[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], te[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+            }
+        }
+        __syncthreads();
+    }
+    if (live && role == 0) a.cnt[v] = n.cnt;
+    if (live && role == 1) { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
+    if (live && role == 2) { a.fl[v] = n.l; a.fb[v] = n.b; }
+}
+
 // Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
 // into an LDS tile [wave][frame][lane] (row stride 65 floats: conflict-free column writes and
 // row reads), then every lane sums half a row -- lane (f, h) adds voices 32h..32h+31 of frame f
@@ -1195,8 +1290,17 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
         else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
     } else if (m->n <= nice_pc_max() && end > start && outputs[0].stride <= (1u << 24)) {   // (32-row tiles: 32-bit offsets)
         // up to ZH_NICE_PC_MAX voices the three chains of a frame run in three waves side by side (k_nice_pc)
-        if (zf) hipLaunchKernelGGL(k_nice_pc<true>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
-        else hipLaunchKernelGGL(k_nice_pc<false>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
+        // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 1,024 / 4,096 / 16,384 voices 67 / 68 / 72 -> 55 / 57 / 60 us;
+        // its 56 KB of LDS per workgroup cost occupancy from 32,768 voices on (79 -> 114 us), where the three-wave form stays
+        static int pc4_max = -1;
+        if (pc4_max < 0) { const char *e = getenv("ZH_NICE_PC4_MAX"); pc4_max = e ? atoi(e) : 16384; }
+        if (m->n <= (uint32_t)pc4_max) {
+            if (zf) hipLaunchKernelGGL(k_nice_pc4<true>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
+            else hipLaunchKernelGGL(k_nice_pc4<false>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
+        } else {
+            if (zf) hipLaunchKernelGGL(k_nice_pc<true>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
+            else hipLaunchKernelGGL(k_nice_pc<false>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
+        }
     } else {
         if (zf) hipLaunchKernelGGL((k_nice<true, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
         else hipLaunchKernelGGL((k_nice<false, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);

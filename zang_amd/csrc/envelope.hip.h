@@ -180,6 +180,16 @@ struct EnvLaneT {
         val = zsel(toward, lv, sustain_volume);
         return mode != u(ENV_MODE_NONE);
     }
+    // frame_masked() where quiet() holds
+    __device__ __forceinline__ F frame_masked_quiet() {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        const F tn = t + cur_step;
+        const F lv = start + curve(tn) * cur_delta;                // :114
+        t = zsel(toward, tn, t);
+        last_value = zsel(toward, lv, last_value);
+        const F val = zsel(toward, lv, sustain_volume);
+        return zbits_f(zbits_u(f(0.0f) + val) & m_painted);
+    }
     // frame() for the callers that want `painted ? 0.0f + value : 0.0f` (the zeroed temp a composite paints the
     // envelope into): the select is an AND with m_painted, and no mode compare is needed for it
     __device__ __forceinline__ F frame_masked() {
