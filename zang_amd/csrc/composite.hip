@@ -581,7 +581,20 @@ __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__re
     PMLane n;
     pm_load(n, a, v);
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
-    for (uint32_t i = start; i < f0; i++) {
+    // the replay: 8 frames at a time where no voice of the wave can end an envelope stage (EnvLaneT::quiet) -- then only the
+    // three clocks step (the envelope's value is evaluated once per chunk, for the state it leaves) -- frame by frame otherwise
+    uint32_t i = start;
+    for (; i + 8 <= f0; i += 8) {
+        if (n.env.quiet(8)) {
+            n.env.template skip_quiet<8>();
+#pragma unroll
+            for (int k = 0; k < 8; k++) { float tm_i, tc_i; n.step_phase(tm_i, tc_i); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { float tm_i, tc_i, e0; n.step(tm_i, tc_i, e0); }
+        }
+    }
+    for (; i < f0; i++) {
         float tm_i, tc_i, e0;
         n.step(tm_i, tc_i, e0);
     }

@@ -190,6 +190,16 @@ struct EnvLaneT {
         const F val = zsel(toward, lv, sustain_volume);
         return zbits_f(zbits_u(f(0.0f) + val) & m_painted);
     }
+    // N calls of frame() / frame_masked() with the values discarded, where quiet(N) holds (a frame-range kernel's replay):
+    // the clock is stepped N times, the curve is evaluated once, for the last of them
+    template <int N> __device__ __forceinline__ void skip_quiet() {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        F tt = t;
+#pragma unroll
+        for (int k = 0; k < N; k++) tt = tt + cur_step;
+        t = zsel(toward, tt, t);
+        last_value = zsel(toward, start + curve(tt) * cur_delta, last_value);
+    }
     // frame() for the callers that want `painted ? 0.0f + value : 0.0f` (the zeroed temp a composite paints the
     // envelope into): the select is an AND with m_painted, and no mode compare is needed for it
     __device__ __forceinline__ F frame_masked() {
