@@ -196,12 +196,31 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
     nice_load<W>(n, a, v);
     const float *const *no_in = nullptr;
     PulseRoll roll = 0;
-    if constexpr (W == 1) n.roll_begin(roll);
-    frame_loop<8, ZF, 0, W>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const F (&)[1], F &val) ZH_INLINE_LAMBDA {
-        if constexpr (W == 1) val = n.tail(n.osc_next(roll));
-        else val = n.frame();
-        return zmask<typename LaneT<W>::M>(true);
-    });
+    if constexpr (W == 1) {
+        // 8-frame chunks (frame_loop_gen): one in which no voice of the wave is inside a timed envelope stage multiplies by one
+        // constant per voice (sustain, idle: the envelope's frame changes nothing), one in which no stage can end runs the
+        // envelope without its stage-end test; the others take the full frame
+        n.roll_begin(roll);
+        bool flat = false;
+        float e0c = 0.0f;
+        frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end,
+            [&](uint32_t) ZH_INLINE_LAMBDA {
+                flat = !zany_wave(n.env.mode == ENV_MODE_TOWARD);
+                if (flat) { e0c = n.env_quiet(); return true; }
+                return n.env.quiet(8);
+            },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+                const float t1 = n.tail_filter(n.osc_next(roll));
+                val = (flat ? e0c : n.env.frame_masked_quiet()) * t1;   // NiceLane::tail
+                return true;
+            },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.tail(n.osc_next(roll)); return true; });
+    } else {
+        frame_loop<8, ZF, 0, W>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const F (&)[1], F &val) ZH_INLINE_LAMBDA {
+            val = n.frame();
+            return zmask<typename LaneT<W>::M>(true);
+        });
+    }
     nice_store<W>(n, a, v);
 }
 
