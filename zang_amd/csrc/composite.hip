@@ -263,8 +263,17 @@ __global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t s
             const uint32_t nf = min(CH, n_frames - c * CH);
             float (*t)[64] = env_t[c & 1];
             if (nf == CH) {
+                if (!zany_wave(n.env.mode == ENV_MODE_TOWARD)) {       // (see k_nice_pc4)
+                    const float e0 = n.env_quiet();
 #pragma unroll 8
-                for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = e0;
+                } else if (n.env.quiet(CH)) {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.env.frame_masked_quiet();
+                } else {
+#pragma unroll 8
+                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
+                }
             } else {
                 for (uint32_t k = 0; k < nf; k++) t[k][lane] = n.tail_env();
             }
@@ -1322,8 +1331,9 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
         else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
     } else if (m->n <= nice_pc_max() && end > start && outputs[0].stride <= (1u << 24)) {   // (32-row tiles: 32-bit offsets)
         // up to ZH_NICE_PC_MAX voices the three chains of a frame run in three waves side by side (k_nice_pc)
-        // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 1,024 / 4,096 / 16,384 voices 67 / 68 / 72 -> 55 / 57 / 60 us;
-        // its 56 KB of LDS per workgroup cost occupancy from 32,768 voices on (79 -> 114 us), where the three-wave form stays
+        // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 1,024 / 4,096 / 16,384 voices 67 / 68 / 72 -> 55 / 57 / 60 us (the
+        // three-wave form with the same quiet envelope tiles: 60.5 / 62.5 at 4,096 / 16,384); its 56 KB of LDS per workgroup cost
+        // occupancy from 24,576 voices on (64 -> 111 us), where the three-wave form stays (32,768 / 65,536 voices: 65 / 89 us)
         static int pc4_max = -1;
         if (pc4_max < 0) { const char *e = getenv("ZH_NICE_PC4_MAX"); pc4_max = e ? atoi(e) : 16384; }
         if (m->n <= (uint32_t)pc4_max) {
