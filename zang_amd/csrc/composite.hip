@@ -458,6 +458,13 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
                     tile[wave][k][lane] = live ? x : 0.0f;
                 }
             }
+        } else if (whole && n.env.quiet(MIXF)) {                          // no stage can end in this chunk: the envelope without its stage-end test
+#pragma unroll 4
+            for (int k = 0; k < MIXF; k++) {
+                const float e0 = n.env.frame_masked_quiet();
+                const float x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
+                tile[wave][k][lane] = live ? x : 0.0f;
+            }
         } else if (whole) {
 #pragma unroll 4
             for (int k = 0; k < MIXF; k++) {
