@@ -305,7 +305,8 @@ struct zh_envelope { zh_ctx *ctx; uint32_t n; uint32_t *state; float *t, *last_v
 
 // FT >= 0: the three curves share that tag (the usual case; the host checks), so the per-frame curve needs no selects.
 // Chunks of 8 frames in which no voice of the wave can end a stage run EnvLane::frame_quiet (frame_loop_gen).
-// 4,096 voices: 84.6 us with the generic frame() in every frame (54 instructions), XX us now.
+// 4,096 voices: 84.6 us with the generic frame() in every frame (54 instructions), 35 us with quiet chunks (a third form for
+// chunks without any voice in a timed stage -- a constant per voice -- made it 48: the uniform test inside the unrolled frames cost more than it saved).
 template <bool ZF, int FT>
 __global__ void __launch_bounds__(kSeqBlock) k_envelope(uint32_t *__restrict__ st, float *__restrict__ t,
                                                         float *__restrict__ lastv, float *__restrict__ startv, uint32_t V,
