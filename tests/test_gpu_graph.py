@@ -206,3 +206,61 @@ def test_sineosc_frame_ranges_in_graphs_and_eager(ctx, oracle):
             util.assert_bitexact(t[::7], ref_t[::7], "phase after the sequence")
             g.close(); m.close()
         c2.close()
+
+
+def test_round2_forms_in_graphs_equal_eager(ctx):
+    """The kernel forms added in round 2 that keep an end state aside or use module-owned scratch -- Decimator and the
+    TriSawOsc control path as frame ranges (`next` buffer + commit kernel), pink noise (white image + tap pipeline),
+    SimpleDelay as independent frames (store + advance kernels), PMOscInstrument ranges, Curve, Envelope, Portamento --
+    captured once and replayed give the bits and the states of the same paints launched eagerly."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V = 512
+    freq, color, u2, _ = workloads.voice_params(5, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        gf, gc = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
+        inp = c2.image(F, V); inp.uniform_(-1.0, 1.0)
+        fbuf = c2.image(F, V); fbuf.copy_(gf[None, :].expand(F, V))
+        rel = torch.from_numpy((0.1 + 0.3 * u2).astype(np.float32)).cuda()
+        crv = torch.tensor([[0.0, 0.0], [1.0, 0.005], [0.3, 0.012], [0.8, 0.02], [0.0, 0.05]], dtype=torch.float32, device="cuda")
+        sp = zang.Span(0, F)
+
+        def build():
+            ms = dict(dec=mod.Decimator(V, c2), tri=mod.TriSawOsc(V, c2), pink=mod.Noise(V, c2, first_seed=5), dly=mod.SimpleDelay(V, 300, c2),
+                      pm=mod.PMOscInstrument(V, rel, c2), crv=mod.Curve(V, c2), env=mod.Envelope(V, c2), por=mod.Portamento(V, c2))
+            outs = {k: c2.image(F, V, fill=0.0) for k in ms}
+            return ms, outs
+
+        def step(ms, outs, k):
+            ms["dec"].paint(sp, [outs["dec"]], [], False, ms["dec"].Params(SR, inp, 6000.0))
+            ms["tri"].paint(sp, [outs["tri"]], [], False, ms["tri"].Params(SR, zang.buffer(fbuf), gc))
+            ms["pink"].paint(sp, [outs["pink"]], [], False, ms["pink"].Params(ms["pink"].pink))
+            ms["dly"].paint(sp, [outs["dly"]], [], False, ms["dly"].Params(inp))
+            ms["pm"].paint(sp, [outs["pm"]], None, k == 0, ms["pm"].Params(SR, gf, k < 2))
+            ms["crv"].paint(sp, [outs["crv"]], [], k == 0, ms["crv"].Params(SR, ms["crv"].smoothstep, crv))
+            ms["env"].paint(sp, [outs["env"]], [], k == 0, ms["env"].Params(SR, zang.PaintCurve.cubed(0.01), zang.PaintCurve.cubed(0.03), zang.PaintCurve.cubed(0.02), 0.7, k < 2))
+            ms["por"].paint(sp, [outs["por"]], [], k == 0, ms["por"].Params(SR, zang.PaintCurve.squared(0.03), gf, True, k > 0))
+
+        me, oe = build(); mg, og = build()
+        for ms, outs in ((me, oe), (mg, og)):                     # one eager pass first: module-owned scratch (the white image of
+            for k in range(3):                                    # pink noise) is allocated outside a capture
+                step(ms, outs, k)
+        c2.sync()
+        g = c2.capture(lambda: [step(mg, og, k) for k in range(3)])
+        for _ in range(2):
+            for k in range(3):
+                step(me, oe, k)
+        g.launch(); g.launch()
+        c2.sync()
+        for name in oe:
+            assert torch.equal(oe[name].view(torch.int32), og[name].view(torch.int32)), name
+            se, sg = me[name].state(), mg[name].state()
+            if isinstance(se, tuple):
+                assert all(np.array_equal(a, b) for a, b in zip(se, sg)), name
+            else:
+                assert se.tobytes() == sg.tobytes(), name
+        g.close()
+        c2.close()
