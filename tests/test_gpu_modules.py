@@ -378,6 +378,44 @@ def test_gate_bitexact(ctx, oracle):
 
 
 # ------------------------------------------------------------------ Filter
+@pytest.mark.parametrize("form", ["pipeline", "walk"])
+@pytest.mark.parametrize("zero_first", [False, True])
+@pytest.mark.parametrize("ftype", range(6))
+def test_filter_const_params_both_forms(ctx, oracle, ftype, zero_first, form, monkeypatch):
+    """Constant cutoff / resonance at a small voice count: the three-wave pipeline k_filter_pc (loader, recurrence, writer)
+    and the one-wave walk (ZH_FILTER_PC_MAX=0) against the oracle -- every filter type, += and ZERO_FIRST, ragged spans
+    (a span shorter than 64 frames takes the walk anyway), a voice count that is not a multiple of 64, carried state."""
+    from zang_amd import modules as mod, zang
+    if form == "walk":
+        monkeypatch.setenv("ZH_FILTER_PC_MAX", "0")
+    V = 200
+    rng = np.random.default_rng(54)
+    cut = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+    res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+    inp = util.rng_buffers(55, V, F)
+    out0 = util.rng_buffers(56, V, F)
+    spans = [(0, 1024), (0, 1024), (100, 612), (612, 1000), (5, 170), (170, 200), (200, 329)]
+    L = oracle.lib()
+    ref = out0.copy(); rl = np.zeros(V, np.float32); rb = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st))
+        for (s, e) in spans:
+            if zero_first:
+                ref[v][s:e] = 0.0
+            L.zo_filter_paint(C.byref(st), s, e, oracle.fptr(ref[v]), oracle.fptr(inp[v]), ftype, oracle.constant(cut[v]), oracle.constant(res[v]))
+        rl[v], rb[v] = st.l, st.b
+    m = mod.Filter(V, ctx)
+    out = util.to_image(out0); gi = util.to_image(inp)
+    dc, dr = util.dev(cut), util.dev(res)
+    for (s, e) in spans:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(gi, ftype, zang.constant(dc), zang.constant(dr)), zero_first=zero_first)
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"filter type {ftype} {form}")
+    st = m.state()
+    util.assert_bitexact(st["l"].astype(np.float32), rl, "filter l")
+    util.assert_bitexact(st["b"].astype(np.float32), rb, "filter b")
+
+
 @pytest.mark.parametrize("ftype", range(6))
 @pytest.mark.parametrize("ck,rk", [("c", "c"), ("c", "b"), ("b", "c"), ("b", "b")])
 def test_filter(ctx, oracle, ftype, ck, rk):

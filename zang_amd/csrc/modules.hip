@@ -367,6 +367,96 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
     l_io[v] = o.l; b_io[v] = o.b;
 }
 
+// Few voices, constant cutoff and resonance: the frame's work spread over THREE waves per 64 voices (the form of
+// composite.hip's k_nice_pc4).  Wave 0 fetches the input rows one tile ahead and adds the filter's input offset
+// (in = x + fcdcoffset, Filter.zig:135: a function of the sample alone); wave 1 runs the state-variable recurrence alone
+// (svf_core, 15 VALU instructions per sample) and hands (l, b, h) on through LDS; wave 2 does the output mix (:146), the `+=`
+// and the store, two tiles behind the loader.  One barrier per 32-frame tile.  Same operations on the same values as
+// k_filter => same bits.
+template <bool ZF>
+__global__ void __launch_bounds__(192) k_filter_pc(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out, CImg input,
+                                                   uint32_t start, uint32_t end, float l_mul, float b_mul, float h_mul, F32P cutoff, F32P res_p) {
+    constexpr uint32_t CH = 32;
+    __shared__ float in_t[2][CH][64], lbh_t[2][3][CH][64];
+    const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < V;
+    const uint32_t vc = live ? v : V - 1;                             // lanes past the last voice repeat voice V-1 (and store nothing)
+    const uint32_t n = end - start, nchunks = (n + CH - 1) / CH;
+    const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u, irow = (uint32_t)input.stride * 4u;
+    FilterLane o;
+    o.l = l_io[vc]; o.b = b_io[vc];
+    o.begin(ZH_FILTER_LOW_PASS, cutoff.get(vc), res_p.get(vc));        // cut / res (:114, :118); the mix coefficients come from the host
+    auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n - c * CH) : 0u; };
+    float xn[CH], bn[CH];                                             // the loader's / the writer's rows of the tile after the one in hand
+    if (role == 0 && frames(0) == CH) {
+        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start);
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) xn[k] = zrow_load<1>(ri, voff, k * irow);
+    }
+    for (uint32_t c = 0; c <= nchunks + 1; c++) {
+        if (role == 0 && c < nchunks) {
+            const uint32_t nf = frames(c);
+            float (*t)[64] = in_t[c & 1];
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) t[k][lane] = xn[k] + kSvfDcOffset;
+            } else {
+                const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
+                for (uint32_t k = 0; k < nf; k++) t[k][lane] = zrow_load<1>(ri, voff, k * irow) + kSvfDcOffset;
+            }
+            if (frames(c + 1) == CH) {
+                const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + (c + 1) * CH);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) xn[k] = zrow_load<1>(ri, voff, k * irow);
+            }
+        } else if (role == 1 && c > 0 && c <= nchunks) {
+            const uint32_t d = c - 1, nf = frames(d);
+            const float (*ti)[64] = in_t[d & 1];
+            float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
+            auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
+                const SvfOut sv = svf_core(o.l, o.b, in, o.cut, o.res);
+                tl[k][lane] = sv.l; tb[k][lane] = sv.b; th[k][lane] = sv.h;
+            };
+            if (nf == CH) {
+                float x[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) x[k] = ti[k][lane];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, x[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, ti[k][lane]);
+            }
+        } else if (role == 2) {
+            if (c > 1) {
+                const uint32_t d = c - 2, nf = frames(d);
+                const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
+                const float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
+                auto one = [&](uint32_t k, float l, float b, float h, float base) ZH_INLINE_LAMBDA {
+                    const float val = l * l_mul + b * b_mul + h * h_mul;    // :146
+                    if (live) zrow_store<1>(ro, voff, k * orow, base + val);
+                };
+                if (nf == CH) {
+                    float xl[CH], xb[CH], xh[CH];
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; }
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], ZF ? 0.0f : bn[k]);
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                }
+            }
+            if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step
+                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 1) * CH);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) bn[k] = zrow_load<1>(rn, voff, k * orow);
+            }
+        }
+        __syncthreads();
+    }
+    if (live && role == 1) { l_io[v] = o.l; b_io[v] = o.b; }
+}
+
 __global__ void k_cutoff_from_frequency(uint32_t n, float *__restrict__ out, const float *__restrict__ freq, float sample_rate) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = zcutoff_from_frequency(freq[i], sample_rate);
@@ -1042,6 +1132,15 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
         if (zf) hipLaunchKernelGGL((k_filter<true, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
         else hipLaunchKernelGGL((k_filter<false, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
     } while (0)
+    // few voices, constant cutoff / resonance: the three-wave pipeline (1,024 / 4,096 / 16,384 / 32,768 voices: 54.5 / 56.1 /
+    // 57.3 / 75.8 us in one wave, 47.6 / 48.8 / 51.3 / 63.6 us; from 49,152 voices its 64 KB of LDS per workgroup lose: 104 -> 117)
+    const char *pe = getenv("ZH_FILTER_PC_MAX");                        // read at every paint (tests switch forms)
+    const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 32768u;
+    if (!cb && !rb && m->n <= pc_max && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
+        if (zf) hipLaunchKernelGGL(k_filter_pc<true>, dim3((m->n + 63) / 64), dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+        else hipLaunchKernelGGL(k_filter_pc<false>, dim3((m->n + 63) / 64), dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+        return zh_launch_status();
+    }
     if (cb && rb) ZH_FILTER(true, true);
     else if (cb) ZH_FILTER(true, false);
     else if (rb) ZH_FILTER(false, true);
