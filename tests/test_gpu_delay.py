@@ -74,9 +74,15 @@ def test_simple_delay_in_place(ctx, oracle, D):
     util.assert_bitexact(m.state()[0], rings, "ring")
 
 
-@pytest.mark.parametrize("D", [5, 8, 333, 2000])
-def test_filtered_echoes(ctx, oracle, D):
+@pytest.mark.parametrize("form", ["pipeline", "walk"])
+@pytest.mark.parametrize("zero_first", [False, True])
+@pytest.mark.parametrize("D", [5, 8, 192, 200, 333, 1024, 2000])
+def test_filtered_echoes(ctx, oracle, D, zero_first, form, monkeypatch):
+    """(Few voices, delay >= 192: three waves per 64 voices -- loader, filter recurrence, writer -- k_filtered_echoes_pc;
+    ZH_ECHOES_PC_MAX=0 is the one-wave walk.)"""
     from zang_amd import modules as mod, zang
+    if form == "walk":
+        monkeypatch.setenv("ZH_ECHOES_PC_MAX", "0")
     V = 96
     rng = np.random.default_rng(4)
     fb = rng.uniform(0.1, 0.9, V).astype(np.float32); cutoff = rng.uniform(0.05, 1.0, V).astype(np.float32)
@@ -90,6 +96,8 @@ def test_filtered_echoes(ctx, oracle, D):
         d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D)
         fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
         for k, (s, e) in enumerate(SPANS):
+            if zero_first:
+                ref[k][v][s:e] = 0.0
             L.zo_filtered_echoes_paint(C.byref(d), C.byref(fl), s, e, oracle.fptr(ref[k][v]), oracle.fptr(t0), oracle.fptr(t1),
                                        oracle.fptr(inp[k][v]), float(fb[v]), float(cutoff[v]))
         rst.append((d.index, fl.l, fl.b))
@@ -97,7 +105,7 @@ def test_filtered_echoes(ctx, oracle, D):
     gfb, gc = util.dev(fb), util.dev(cutoff)
     for k, (s, e) in enumerate(SPANS):
         out = util.to_image(out0)
-        m.paint(zang.Span(s, e), [out], None, False, m.Params(util.to_image(inp[k]), gfb, gc))
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(util.to_image(inp[k]), gfb, gc), zero_first=zero_first)
         ctx.sync()
         util.assert_bitexact(util.from_image(out), ref[k], f"filtered echoes D={D} paint {k}")
     grings, gidx, gflt = m.state()

@@ -170,6 +170,117 @@ __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, flo
     l_io[v] = l; b_io[v] = b;
 }
 
+// FilteredEchoes at a small voice count, delay >= 192 frames: three waves per 64 voices (the form of modules.hip's
+// k_filter_pc).  Wave 0 fetches a tile's ring slots and input rows one tile ahead and forms the filter's input
+// (in = ((0 + delayed) * feedback + x) + fcdcoffset); wave 1 runs the state-variable recurrence alone and hands (l, b, h) on
+// through LDS; wave 2 forms temp1, does the `+=` into the output image and writes temp1 into the ring, two tiles behind the
+// loader.  A slot is read delay_samples frames after it was written; the loader runs at most 4 tiles (128 frames) ahead of the
+// writer, hence the minimum delay.  Same operations on the same values as k_filtered_echoes => same bits.
+template <bool ZF>
+__global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float *__restrict__ l_io, float *__restrict__ b_io, Img out, CImg input,
+                                                            uint32_t start, uint32_t end, F32P feedback_p, F32P cutoff_p) {
+    constexpr uint32_t CH = 32;
+    __shared__ float in_t[2][CH][64], lbh_t[2][3][CH][64];
+    const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < d.n;
+    const uint32_t vc = live ? v : d.n - 1;
+    const uint32_t n = end - start, nchunks = (n + CH - 1) / CH, D = d.delay_samples;
+    const float feedback = feedback_p.get(vc);
+    const float cut = zclampf(cutoff_p.get(vc), 0.0f, 1.0f);          // Filter.zig:114
+    const float res = 1.0f - zclampf(0.0f, 0.0f, 1.0f);               // res = constant(0.0) (:441) -> Filter.zig:118
+    const uint32_t idx0 = d.index[vc];
+    float l = l_io[vc], b = b_io[vc];
+    float *ring = d.ring + vc;
+    auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n - c * CH) : 0u; };
+    auto slot_of = [&](uint32_t j) ZH_INLINE_LAMBDA { return (uint32_t)(((uint64_t)idx0 + j) % D); };   // the slot frame j of the span uses
+    float dn[CH], xn[CH], bn[CH];                                     // the tile after the one in hand: delayed samples, input rows (loader), output rows (writer)
+    auto fetch = [&](uint32_t c) ZH_INLINE_LAMBDA {
+        uint32_t sl = slot_of(c * CH);
+        const float *ip = input.at(start + c * CH, vc);
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) {
+            dn[k] = ring[(size_t)sl * d.n];
+            xn[k] = ip[(size_t)k * input.stride];
+            sl = sl + 1 == D ? 0 : sl + 1;
+        }
+    };
+    if (role == 0 && frames(0) == CH) fetch(0);
+    for (uint32_t c = 0; c <= nchunks + 1; c++) {
+        if (role == 0 && c < nchunks) {
+            const uint32_t nf = frames(c);
+            float (*t)[64] = in_t[c & 1];
+            auto in_of = [&](float delayed, float x) ZH_INLINE_LAMBDA {
+                float t0 = 0.0f + delayed;                            // zero(temp0); readDelayBuffer (:425-428)
+                t0 = t0 * feedback;                                   // multiplyWithScalar (:433)
+                t0 = t0 + x;                                          // addInto (:436)
+                return t0 + kSvfDcOffset;                             // Filter.zig:135
+            };
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) t[k][lane] = in_of(dn[k], xn[k]);
+            } else {
+                uint32_t sl = slot_of(c * CH);
+                const float *ip = input.at(start + c * CH, vc);
+                for (uint32_t k = 0; k < nf; k++) {
+                    t[k][lane] = in_of(ring[(size_t)sl * d.n], ip[(size_t)k * input.stride]);
+                    sl = sl + 1 == D ? 0 : sl + 1;
+                }
+            }
+            if (frames(c + 1) == CH) fetch(c + 1);
+        } else if (role == 1 && c > 0 && c <= nchunks) {
+            const uint32_t dd = c - 1, nf = frames(dd);
+            const float (*ti)[64] = in_t[dd & 1];
+            float (*tl)[64] = lbh_t[dd & 1][0], (*tb)[64] = lbh_t[dd & 1][1], (*th)[64] = lbh_t[dd & 1][2];
+            auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
+                const SvfOut sv = svf_core(l, b, in, cut, res);
+                tl[k][lane] = sv.l; tb[k][lane] = sv.b; th[k][lane] = sv.h;
+            };
+            if (nf == CH) {
+                float x[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) x[k] = ti[k][lane];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) one(k, x[k]);
+            } else {
+                for (uint32_t k = 0; k < nf; k++) one(k, ti[k][lane]);
+            }
+        } else if (role == 2) {
+            if (c > 1) {
+                const uint32_t dd = c - 2, nf = frames(dd);
+                const float (*tl)[64] = lbh_t[dd & 1][0], (*tb)[64] = lbh_t[dd & 1][1], (*th)[64] = lbh_t[dd & 1][2];
+                float *op = out.at(start + dd * CH, vc);
+                uint32_t sl = slot_of(dd * CH);
+                auto one = [&](uint32_t k, float fl, float fb, float fh, float base) ZH_INLINE_LAMBDA {
+                    const float t1 = 0.0f + (fl * 1.0f + fb * 0.0f + fh * 0.0f);    // zero(temp1); += low-pass (:439, Filter.zig:146)
+                    if (live) {
+                        op[(size_t)k * out.stride] = base + t1;       // addInto(output, temp1) (:448)
+                        ring[(size_t)sl * d.n] = t1;                  // writeDelayBuffer(temp1) (:452)
+                    }
+                    sl = sl + 1 == D ? 0 : sl + 1;
+                };
+                if (nf == CH) {
+                    float xl[CH], xb[CH], xh[CH];
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; }
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], ZF ? 0.0f : bn[k]);
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], ZF ? 0.0f : op[(size_t)k * out.stride]);
+                }
+            }
+            if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step
+                const float *on = out.at(start + (c - 1) * CH, vc);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) bn[k] = on[(size_t)k * out.stride];
+            }
+        }
+        __syncthreads();
+    }
+    if (live && role == 0) d.index[v] = slot_of(n);
+    if (live && role == 1) { l_io[v] = l; b_io[v] = b; }
+}
+
 // the chunked form needs a delay of at least a chunk and an input image that does not overlap the output image
 static bool delay_can_chunk(const DelayState &d, const zh_buf &out, const zh_buf &in) {
     if (d.delay_samples < 8) return false;
@@ -317,6 +428,15 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
     if (m->d.n == 0 || end == start) return ZH_OK;
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
+    // delay 300, one wave per 64 voices -> three: 1,024 / 4,096 / 16,384 / 32,768 / 65,536 voices 88 / 91 / 103 / 194 / 263 ->
+    // 70 / 72 / 74 / 113 / 235 us; at 131,072 voices the one-wave form is ahead (406 against 461)
+    const char *pe = getenv("ZH_ECHOES_PC_MAX");                        // read at every paint (tests switch forms)
+    const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 65536u;
+    if (chunked && m->d.n <= pc_max && m->d.delay_samples >= 192 && end - start >= 64) {
+        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_filtered_echoes_pc<true>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
+        else hipLaunchKernelGGL(k_filtered_echoes_pc<false>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
+        return zh_launch_status();
+    }
 #define ZH_FE(ZF_, CH_) hipLaunchKernelGGL((k_filtered_echoes<ZF_, CH_>), seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff))
     if (flags & ZH_PAINT_ZERO_FIRST) { if (chunked) ZH_FE(true, 8); else ZH_FE(true, 1); }
     else { if (chunked) ZH_FE(false, 8); else ZH_FE(false, 1); }
