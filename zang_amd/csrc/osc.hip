@@ -46,6 +46,7 @@ constexpr uint32_t kPulsePartMaxVoices = 40960;
 struct zh_trisawosc : zh_flipper {
     float *t;
     float *t_next;            // k_trisawosc_ctrl's frame ranges: the phase after the span, moved into `t` by k_commit_f32
+    zh_buf quot;              // ... and their freq / sample_rate image (k_div_image), so that the replay is a load and an add
     OscTable tab;
 };
 
@@ -368,7 +369,20 @@ struct TriSawOscP {
 // added in frame order (f32), so a range replays that (a load, the divide and an add per frame; the naive waveform is another
 // ~20 instructions) and then paints its own frames.  The range that ends the span writes the phase to t_out (a buffer of
 // its own; k_commit_f32 moves it into place once every range has read the start phase).
-template <bool ZF>
+// QUOT: freq_b holds freq / sample_rate already (k_div_image painted it, frame-parallel): the divide -- eleven of the
+// replay's thirteen instructions per frame -- is done once per sample instead of once per sample per later range.
+__global__ void __launch_bounds__(256) k_div_image(Img q, CImg x, uint32_t V, uint32_t start, uint32_t end, float d) {
+    const uint32_t v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t piece = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const uint32_t f0 = start + piece * 32;
+    if (f0 >= end) return;
+    const uint32_t f1 = min(f0 + 32, end);
+    float *qp = q.at(f0, v);
+    const float *xp = x.at(f0, v);
+    for (uint32_t f = f0; f < f1; f++, qp += q.stride, xp += x.stride) *qp = *xp / d;
+}
+template <bool ZF, bool QUOT>
 __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
                                                               uint32_t start, uint32_t end, uint32_t ch, float sample_rate,
                                                               CImg freq_b, F32P color_p) {
@@ -386,14 +400,14 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(const float *__res
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = fp[(size_t)k * freq_b.stride];
 #pragma unroll
-            for (int k = 0; k < 16; k++) o.t += x[k] / sample_rate;     // frame_ctrl's step (TriSawOsc.zig:151)
+            for (int k = 0; k < 16; k++) o.t += QUOT ? x[k] : x[k] / sample_rate;   // frame_ctrl's step (TriSawOsc.zig:151)
         }
-        for (; i < f0; i++, fp += freq_b.stride) o.t += *fp / sample_rate;
+        for (; i < f0; i++, fp += freq_b.stride) o.t += QUOT ? *fp : *fp / sample_rate;
     }
     const float *ins[1] = {freq_b.p};
     const size_t istr[1] = {freq_b.stride};
     frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, f0, f1, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {
-        val = o.frame_ctrl(x[0]);
+        val = QUOT ? o.frame_ctrl_q(x[0]) : o.frame_ctrl(x[0]);
         return true;
     });
     if (f1 == end) {
@@ -625,7 +639,7 @@ int zh_trisawosc_create(zh_ctx *ctx, uint32_t n, zh_trisawosc **out) { ZH_GUARD(
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_trisawosc *m = new (std::nothrow) zh_trisawosc();
     if (!m) return ZH_ERR_INVALID;
-    m->t = nullptr; m->t_next = nullptr;
+    m->t = nullptr; m->t_next = nullptr; m->quot = zh_buf{};
     int rc = osc_create_common(ctx, m, n, (int)(sizeof(TriSawK) / 4));
     if (!rc) rc = dev_alloc(&m->t, n);
     if (!rc) rc = dev_alloc(&m->t_next, n);
@@ -639,7 +653,7 @@ int zh_trisawosc_destroy(zh_trisawosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     hipStreamSynchronize(m->ctx->stream);
     zh_flipper_unregister(m);
-    osc_free_common(m); hipFree(m->t); hipFree(m->t_next);
+    osc_free_common(m); hipFree(m->t); hipFree(m->t_next); hipFree(m->quot.ptr);
     delete m;
     return ZH_OK;
 }
@@ -678,13 +692,35 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
         // 4,096 voices: 106.6 us with per-lane branches in the waveform, 71.3 straight-line, 46.4 as 16 frame ranges (8 / 32 /
         // 64 ranges: 47.9 / 54.7 / 77.2 -- the replay's divide is half of a painted frame); 16,384 voices: 73.7 -> 66.2 with 8
         const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, "ZH_TRISAW_CTRL_RANGES", 1024, 16384);
+        // ... and 39.3 us (1,024 voices: 43 -> 26) with the quotients painted first (module-owned image, allocated outside a
+        // capture; ZH_TRISAW_CTRL_QUOT=0: never).  (Tried: two or four batches of 32 rows kept in flight by an explicit rotation in
+        // these replays -- SineOsc 27 -> 40 / 60 us, TriSawOsc 39 -> 45 / 53: slower; the plain batch loops stay.)
+        static int want_quot = -1;
+        if (want_quot < 0) { const char *e = getenv("ZH_TRISAW_CTRL_QUOT"); want_quot = e ? atoi(e) : 1; }
+        bool quot = false;
+        if (chr && want_quot) {
+            if ((m->quot.frames < end || !m->quot.ptr) && !m->ctx->capturing) {
+                zh_buf nbuf;
+                if (zh_buf_alloc(m->ctx, &nbuf, m->n, end) == ZH_OK) {
+                    if (m->quot.ptr) m->ctx->mix_retired.push_back(m->quot.ptr);   // a captured graph may still name it: freed with the context
+                    m->quot = nbuf;
+                }
+            }
+            quot = m->quot.ptr && m->quot.frames >= end;
+        }
+        if (quot)
+            hipLaunchKernelGGL(k_div_image, dim3((m->n + 63) / 64, ((end - start + 31) / 32 + 3) / 4), dim3(256), 0, st, mk_img(m->quot), mk_cimg(p->freq.buffer),
+                               m->n, start, end, p->sample_rate);
+        const CImg fimg = quot ? mk_cimg(m->quot) : mk_cimg(p->freq.buffer);
         for (uint32_t b = 0; b < nb; b++) {
             Img out = mk_img(outputs[b]);
             float *to = chr ? m->t_next : m->t;
             const uint32_t ch = chr ? chr : end - start;
             const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
-            if (zf) hipLaunchKernelGGL(k_trisawosc_ctrl<true>, grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
-            else hipLaunchKernelGGL(k_trisawosc_ctrl<false>, grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, mk_cimg(p->freq.buffer), mk_f32(p->color));
+#define ZH_TSC(ZF_, Q_) hipLaunchKernelGGL((k_trisawosc_ctrl<ZF_, Q_>), grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, fimg, mk_f32(p->color))
+            if (zf) { if (quot) ZH_TSC(true, true); else ZH_TSC(true, false); }
+            else { if (quot) ZH_TSC(false, true); else ZH_TSC(false, false); }
+#undef ZH_TSC
             if (chr) hipLaunchKernelGGL(k_commit_f32, dim3((m->n + 255) / 256), dim3(256), 0, st, m->t, m->t_next, m->n);
         }
     }

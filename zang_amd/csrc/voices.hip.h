@@ -142,6 +142,11 @@ struct TriSawOscLane {
         t += s_freq / sample_rate;
         return val;
     }
+    __device__ __forceinline__ float frame_ctrl_q(float q) {         // frame_ctrl with q = s_freq / sample_rate computed beforehand
+        const float val = trisaw_naive(t, saw);
+        t += q;
+        return val;
+    }
     __device__ __forceinline__ void end_ctrl() { t = t - truncf(t); } // :155
 };
 
