@@ -380,7 +380,15 @@ __global__ void __launch_bounds__(256) k_div_image(Img q, CImg x, uint32_t V, ui
     const uint32_t f1 = min(f0 + 32, end);
     float *qp = q.at(f0, v);
     const float *xp = x.at(f0, v);
-    for (uint32_t f = f0; f < f1; f++, qp += q.stride, xp += x.stride) *qp = *xp / d;
+    uint32_t f = f0;
+    for (; f + 8 <= f1; f += 8, qp += 8 * (size_t)q.stride, xp += 8 * (size_t)x.stride) {   // 8 rows' loads ahead of their stores
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = xp[(size_t)k * x.stride];
+#pragma unroll
+        for (int k = 0; k < 8; k++) qp[(size_t)k * q.stride] = a[k] / d;
+    }
+    for (; f < f1; f++, qp += q.stride, xp += x.stride) *qp = *xp / d;
 }
 template <bool ZF, bool QUOT>
 __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
