@@ -377,7 +377,15 @@ __global__ void __launch_bounds__(256) k_gate(uint32_t V, Img out, uint32_t star
     const bool on = note_on.get(v);
     if (!on && !ZF) return;
     float *o = out.at(c0, v);
-    for (uint32_t i = c0; i < c1; i++, o += out.stride) {
+    uint32_t i = c0;
+    for (; i + 8 <= c1; i += 8, o += 8 * (size_t)out.stride) {        // `+=`: 8 rows' loads ahead of their stores
+        float base[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) base[k] = ZF ? 0.0f : o[(size_t)k * out.stride];
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[(size_t)k * out.stride] = on ? base[k] + 1.0f : base[k];
+    }
+    for (; i < c1; i++, o += out.stride) {
         const float base = ZF ? 0.0f : *o;
         *o = on ? base + 1.0f : base;
     }
