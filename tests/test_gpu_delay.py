@@ -113,6 +113,61 @@ def test_filtered_echoes(ctx, oracle, D, zero_first, form, monkeypatch):
     util.assert_bitexact(gflt["l"].astype(np.float32), np.array([r[1] for r in rst], np.float32), "l")
 
 
+@pytest.mark.parametrize("D", [200, 333])
+def test_delays_with_per_voice_ring_indices(ctx, oracle, D):
+    """set_state may give every voice its own ring index and ring content: the frame-parallel SimpleDelay and the three-wave
+    FilteredEchoes then take their per-lane slot arithmetic (no wave-uniform row addressing), wraps at different frames per
+    voice included."""
+    from zang_amd import abi, modules as mod, zang
+    V = 130
+    rng = np.random.default_rng(31)
+    idx = rng.integers(0, D, V).astype(np.uint32)
+    rings0 = rng.uniform(-1, 1, (V, D)).astype(np.float32)
+    inp = util.rng_buffers(40, V, F); out0 = util.rng_buffers(41, V, F)
+    fb = rng.uniform(0.1, 0.9, V).astype(np.float32); cutoff = rng.uniform(0.05, 1.0, V).astype(np.float32)
+    L = oracle.lib()
+    spans = [(0, 1024), (100, 612), (612, 1000)]
+    # SimpleDelay
+    ref = out0.copy(); rings = rings0.copy(); ridx = []
+    for v in range(V):
+        d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D)
+        rings[v] = rings0[v]; d.index = int(idx[v])
+        for (s, e) in spans:
+            L.zo_simple_delay_paint(C.byref(d), s, e, oracle.fptr(ref[v]), oracle.fptr(inp[v]))
+        ridx.append(d.index)
+    m = mod.SimpleDelay(V, D, ctx)
+    abi.check(ctx.lib.zh_delay_set_state(m.handle, rings0.ctypes.data, idx.ctypes.data), "set_state")
+    out = util.to_image(out0); gi = util.to_image(inp)
+    for (s, e) in spans:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(gi))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "simple delay, per-voice indices")
+    grings, gidx = m.state()
+    util.assert_bitexact(grings, rings, "ring"); assert [int(x) for x in gidx] == ridx
+    # FilteredEchoes
+    ref = out0.copy(); rings = rings0.copy(); rst = []
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    for v in range(V):
+        d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D)
+        rings[v] = rings0[v]; d.index = int(idx[v])
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
+        for (s, e) in spans:
+            L.zo_filtered_echoes_paint(C.byref(d), C.byref(fl), s, e, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1),
+                                       oracle.fptr(inp[v]), float(fb[v]), float(cutoff[v]))
+        rst.append((d.index, fl.l, fl.b))
+    m = mod.FilteredEchoes(V, D, ctx)
+    flt = np.zeros(V, dtype=np.dtype(abi.FilterState))
+    abi.check(ctx.lib.zh_filtered_echoes_set_state(m.handle, rings0.ctypes.data, idx.ctypes.data, flt.ctypes.data), "set_state")
+    out = util.to_image(out0)
+    for (s, e) in spans:
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(gi, util.dev(fb), util.dev(cutoff)))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "filtered echoes, per-voice indices")
+    grings, gidx, gflt = m.state()
+    util.assert_bitexact(grings, rings, "ring"); assert [int(x) for x in gidx] == [r[0] for r in rst]
+    util.assert_bitexact(gflt["l"].astype(np.float32), np.array([r[1] for r in rst], np.float32), "l")
+
+
 def test_stereo_echoes_composition(ctx, oracle):
     """StereoEchoes (examples/modules.zig:463-525) as a host-level composition of C-ABI calls:
     addInto x2, SimpleDelay, FilteredEchoes, addInto, SimpleDelay -- vs the same composition of oracle calls."""

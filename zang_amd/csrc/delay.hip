@@ -224,14 +224,30 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
     auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n - c * CH) : 0u; };
     auto slot_of = [&](uint32_t j) ZH_INLINE_LAMBDA { return (uint32_t)(((uint64_t)idx0 + j) % D); };   // the slot frame j of the span uses
     float dn[CH], xn[CH], bn[CH];                                     // the tile after the one in hand: delayed samples, input rows (loader), output rows (writer)
+    // The voices of a wave normally share one ring index (set_state can make them differ): then a tile whose 32 slots do not
+    // wrap is 32 consecutive ring rows, addressed like image rows (one descriptor, scalar row offsets) instead of a 64-bit
+    // multiply-add and a wrap test per lane and frame.
+    const bool uni = __builtin_amdgcn_ballot_w64(idx0 != (uint32_t)__builtin_amdgcn_readfirstlane((int)idx0)) == 0;
+    const uint32_t voff = vc * 4u, rrow = d.n * 4u, irow = (uint32_t)input.stride * 4u, orow = (uint32_t)out.stride * 4u;
+    auto rows_ok = [&](uint32_t c) ZH_INLINE_LAMBDA {                   // wave-uniform: tile c's slots are consecutive rows for every lane
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_of(c * CH));
+        return uni && s0 + CH <= D;
+    };
     auto fetch = [&](uint32_t c) ZH_INLINE_LAMBDA {
-        uint32_t sl = slot_of(c * CH);
-        const float *ip = input.at(start + c * CH, vc);
+        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
+        if (rows_ok(c)) {
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_of(c * CH));
+            const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, s0);
 #pragma unroll
-        for (uint32_t k = 0; k < CH; k++) {
-            dn[k] = ring[(size_t)sl * d.n];
-            xn[k] = ip[(size_t)k * input.stride];
-            sl = sl + 1 == D ? 0 : sl + 1;
+            for (uint32_t k = 0; k < CH; k++) { dn[k] = zrow_load<1>(rr, voff, k * rrow); xn[k] = zrow_load<1>(ri, voff, k * irow); }
+        } else {
+            uint32_t sl = slot_of(c * CH);
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) {
+                dn[k] = ring[(size_t)sl * d.n];
+                xn[k] = zrow_load<1>(ri, voff, k * irow);
+                sl = sl + 1 == D ? 0 : sl + 1;
+            }
         }
     };
     if (role == 0 && frames(0) == CH) fetch(0);
@@ -292,16 +308,29 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
                     float xl[CH], xb[CH], xh[CH];
 #pragma unroll
                     for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; }
+                    if (rows_ok(dd)) {
+                        const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + dd * CH);
+                        const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, (uint32_t)__builtin_amdgcn_readfirstlane((int)sl));
 #pragma unroll
-                    for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], ZF ? 0.0f : bn[k]);
+                        for (uint32_t k = 0; k < CH; k++) {
+                            const float t1 = 0.0f + (xl[k] * 1.0f + xb[k] * 0.0f + xh[k] * 0.0f);   // as in one()
+                            if (live) {
+                                zrow_store<1>(ro, voff, k * orow, (ZF ? 0.0f : bn[k]) + t1);
+                                zrow_store<1>(rr, voff, k * rrow, t1);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], ZF ? 0.0f : bn[k]);
+                    }
                 } else {
                     for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], ZF ? 0.0f : op[(size_t)k * out.stride]);
                 }
             }
             if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step
-                const float *on = out.at(start + (c - 1) * CH, vc);
+                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 1) * CH);
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) bn[k] = on[(size_t)k * out.stride];
+                for (uint32_t k = 0; k < CH; k++) bn[k] = zrow_load<1>(rn, voff, k * orow);
             }
         }
         __syncthreads();
@@ -458,7 +487,7 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     if (m->d.n == 0 || end == start) return ZH_OK;
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
     // delay 300, one wave per 64 voices -> three: 1,024 / 4,096 / 16,384 / 32,768 / 65,536 voices 88 / 91 / 103 / 194 / 263 ->
-    // 70 / 72 / 74 / 113 / 235 us; at 131,072 voices the one-wave form is ahead (406 against 461)
+    // 56 / 57 / 62 / 110 / 215 us; at 131,072 voices the one-wave form is ahead (406 against 461)
     const char *pe = getenv("ZH_ECHOES_PC_MAX");                        // read at every paint (tests switch forms)
     const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 65536u;
     if (chunked && m->d.n <= pc_max && m->d.delay_samples >= 192 && end - start >= 64) {
