@@ -25,6 +25,7 @@ struct zh_flipper {
     uint32_t n;
     uint32_t *cnt[2];
     int cur;
+    uint32_t words = 1;          // 32-bit words of state per voice in each of the two buffers (a buffer is [words][n])
 };
 struct zh_flip_use {
     uint64_t id;

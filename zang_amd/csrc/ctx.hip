@@ -258,7 +258,7 @@ int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) { ZH_GUARD(ctx);
         for (const zh_flip_use &u : graph->flips) {
             zh_flipper *f = u.f;
             if (f->cur != u.first_cur) {
-                ZH_TRY(hipMemcpyAsync(f->cnt[u.first_cur], f->cnt[f->cur], (size_t)f->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                ZH_TRY(hipMemcpyAsync(f->cnt[u.first_cur], f->cnt[f->cur], (size_t)f->n * f->words * 4, hipMemcpyDeviceToDevice, ctx->stream));
                 f->cur = u.first_cur;
             }
         }

@@ -301,7 +301,13 @@ __global__ void __launch_bounds__(64 * kPinkWaves) k_pink_pipe(const float *__re
 }
 
 // =================================================================== Envelope
-struct zh_envelope { zh_ctx *ctx; uint32_t n; uint32_t *state; float *t, *last_value, *start; uint32_t *next; /* [4][n], k_envelope_ranges */ };
+// The state is double-buffered (zh_flipper, 4 words per voice: state, t, last_value, start as [4][n]): the frame-range kernel
+// reads the start state from one buffer while its last range writes the end state into the other, and the host flips (what a
+// captured graph baked in is reconciled at launch, ctx.hip).  The one-wave walk updates the current buffer in place.
+struct zh_envelope : zh_flipper {
+    uint32_t *st(int b) const { return cnt[b]; }
+    float *f(int b, int k) const { return reinterpret_cast<float *>(cnt[b] + (size_t)k * n); }
+};
 
 // FT >= 0: the three curves share that tag (the usual case; the host checks), so the per-frame curve needs no selects.
 // Chunks of 8 frames in which no voice of the wave can end a stage run EnvLane::frame_quiet (frame_loop_gen).
@@ -326,8 +332,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_envelope(uint32_t *__restrict__ s
 // A span as frame ranges (grid.y) at small voice counts.  The envelope's walk from frame to frame is its clock: a range
 // replays the frames before it 8 at a time where no voice of the wave can end a stage (EnvLaneT::quiet / skip_quiet<8>: eight
 // additions and one curve evaluation per chunk), frame by frame around a stage end, then paints its own frames like
-// k_envelope.  The range that ends the span writes the state to `next`; k_envelope_commit moves it into place (stream order:
-// after every range has read the start state).
+// k_envelope.  The range that ends the span writes the state into the other half of the double buffer (`next`, [4][V]).
 template <bool ZF, int FT>
 __global__ void __launch_bounds__(64) k_envelope_ranges(const uint32_t *__restrict__ st, const float *__restrict__ t, const float *__restrict__ lastv,
                                                         const float *__restrict__ startv, uint32_t *__restrict__ next, uint32_t V, Img out,
@@ -356,14 +361,6 @@ __global__ void __launch_bounds__(64) k_envelope_ranges(const uint32_t *__restri
         next[(size_t)2 * V + v] = __builtin_bit_cast(uint32_t, e.last_value); next[(size_t)3 * V + v] = __builtin_bit_cast(uint32_t, e.start);
     }
 }
-__global__ void __launch_bounds__(256) k_envelope_commit(uint32_t *__restrict__ st, float *__restrict__ t, float *__restrict__ lastv,
-                                                         float *__restrict__ startv, const uint32_t *__restrict__ next, uint32_t V) {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    st[v] = next[v]; t[v] = __builtin_bit_cast(float, next[(size_t)V + v]);
-    lastv[v] = __builtin_bit_cast(float, next[(size_t)2 * V + v]); startv[v] = __builtin_bit_cast(float, next[(size_t)3 * V + v]);
-}
-
 // =================================================================== Gate (stateless)
 struct zh_gate { zh_ctx *ctx; uint32_t n; };
 
@@ -1012,52 +1009,48 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
 // ------------------------------------------------------------------ Envelope
 int zh_envelope_create(zh_ctx *ctx, uint32_t n, zh_envelope **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_envelope *m = new (std::nothrow) zh_envelope{ctx, n, nullptr, nullptr, nullptr, nullptr, nullptr};
+    zh_envelope *m = new (std::nothrow) zh_envelope();
     if (!m) return ZH_ERR_INVALID;
-    int rc = dev_alloc(&m->state, n);
-    if (!rc) rc = dev_alloc(&m->next, (size_t)4 * n);
-    if (!rc) rc = dev_alloc(&m->t, n);
-    if (!rc) rc = dev_alloc(&m->last_value, n);
-    if (!rc) rc = dev_alloc(&m->start, n);
-    if (!rc && n) {                                                                // init() :26-31: idle, painter zeros
-        rc = (int)hipMemsetAsync(m->state, 0, n * 4, ctx->stream);
-        if (!rc) rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);
-        if (!rc) rc = (int)hipMemsetAsync(m->last_value, 0, n * 4, ctx->stream);
-        if (!rc) rc = (int)hipMemsetAsync(m->start, 0, n * 4, ctx->stream);
-    }
-    if (rc) { (void)hipFree(m->state); (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start); (void)hipFree(m->next); delete m; return rc; }
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0; m->words = 4;
+    int rc = dev_alloc(&m->cnt[0], (size_t)4 * n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], (size_t)4 * n);
+    for (int b = 0; b < 2 && !rc && n; b++) rc = (int)hipMemsetAsync(m->cnt[b], 0, (size_t)4 * n * 4, ctx->stream);   // init() :26-31: idle, painter zeros
+    if (rc) { (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
 int zh_envelope_destroy(zh_envelope *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->state); (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start); (void)hipFree(m->next);
+    zh_flipper_unregister(m);
+    (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]);
     delete m;
     return ZH_OK;
 }
 int zh_envelope_get_state(zh_envelope *m, zh_envelope_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<uint32_t> s;
-    std::vector<float> a, b, c;
-    int rc = download_field(m->ctx, s, m->state, m->n);
-    if (!rc) rc = download_field(m->ctx, a, m->t, m->n);
-    if (!rc) rc = download_field(m->ctx, b, m->last_value, m->n);
-    if (!rc) rc = download_field(m->ctx, c, m->start, m->n);
+    std::vector<uint32_t> w;
+    int rc = download_field(m->ctx, w, m->cnt[m->cur], (size_t)4 * m->n);
     if (rc) return rc;
-    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_envelope_state{s[v], a[v], b[v], c[v]};
+    const size_t n = m->n;
+    for (uint32_t v = 0; v < m->n; v++) {
+        zh_envelope_state e;
+        e.state = w[v];
+        memcpy(&e.t, &w[n + v], 4); memcpy(&e.last_value, &w[2 * n + v], 4); memcpy(&e.start, &w[3 * n + v], 4);
+        host[v] = e;
+    }
     return ZH_OK;
 }
 int zh_envelope_set_state(zh_envelope *m, const zh_envelope_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<uint32_t> s(m->n);
-    std::vector<float> a(m->n), b(m->n), c(m->n);
-    for (uint32_t v = 0; v < m->n; v++) { s[v] = host[v].state; a[v] = host[v].t; b[v] = host[v].last_value; c[v] = host[v].start; }
-    int rc = upload_field(m->ctx, m->state, s);
-    if (!rc) rc = upload_field(m->ctx, m->t, a);
-    if (!rc) rc = upload_field(m->ctx, m->last_value, b);
-    if (!rc) rc = upload_field(m->ctx, m->start, c);
-    return rc;
+    const size_t n = m->n;
+    std::vector<uint32_t> w(4 * n);
+    for (uint32_t v = 0; v < m->n; v++) {
+        w[v] = host[v].state;
+        memcpy(&w[n + v], &host[v].t, 4); memcpy(&w[2 * n + v], &host[v].last_value, 4); memcpy(&w[3 * n + v], &host[v].start, 4);
+    }
+    return upload_field(m->ctx, m->cnt[m->cur], w);
 }
 int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
                       zh_bool note_id_changed, const zh_envelope_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
@@ -1069,6 +1062,7 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     const int ft = p->attack.tag == p->decay.tag && p->decay.tag == p->release.tag && p->attack.tag != ZH_CURVE_INSTANTANEOUS ? (int)p->attack.tag : -1;
+    const int c = m->cur;
     // few voices: frame ranges with a replay of the clock (4,096 / 8,192 / 16,384 / 32,768 voices: 35 / 35 / 36 / 42 us as one
     // walk, 22.4 / 23.9 / 25.8 / 33.3 us; wave targets 1,024 / 2,048 / 4,096 measured, 2,048 best or level everywhere)
     const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_ENVELOPE_RANGES", 2048, 40960) : 0;
@@ -1076,9 +1070,9 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
 #define ZH_ENVR(FT_)                                                                                                         \
     do {                                                                                                                     \
-        if (zf) hipLaunchKernelGGL((k_envelope_ranges<true, FT_>), grid, dim3(64), 0, st, m->state, m->t, m->last_value, m->start, m->next, m->n, \
+        if (zf) hipLaunchKernelGGL((k_envelope_ranges<true, FT_>), grid, dim3(64), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->cnt[c ^ 1], m->n, \
                                    mk_img(outputs[0]), start, end, ch, mk_env_params(p), mk_bool(note_id_changed));         \
-        else hipLaunchKernelGGL((k_envelope_ranges<false, FT_>), grid, dim3(64), 0, st, m->state, m->t, m->last_value, m->start, m->next, m->n, \
+        else hipLaunchKernelGGL((k_envelope_ranges<false, FT_>), grid, dim3(64), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->cnt[c ^ 1], m->n, \
                                 mk_img(outputs[0]), start, end, ch, mk_env_params(p), mk_bool(note_id_changed));            \
     } while (0)
         switch (ft) {
@@ -1088,14 +1082,15 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
         default: ZH_ENVR(-1); break;
         }
 #undef ZH_ENVR
-        hipLaunchKernelGGL(k_envelope_commit, dim3((m->n + 255) / 256), dim3(256), 0, st, m->state, m->t, m->last_value, m->start, m->next, m->n);
+        zh_flipper_painted(m);
+        m->cur ^= 1;
         return zh_launch_status();
     }
 #define ZH_ENV(FT_)                                                                                                          \
     do {                                                                                                                     \
-        if (zf) hipLaunchKernelGGL((k_envelope<true, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->state, m->t, m->last_value, m->start, m->n, \
+        if (zf) hipLaunchKernelGGL((k_envelope<true, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->n, \
                                    mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));             \
-        else hipLaunchKernelGGL((k_envelope<false, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->state, m->t, m->last_value, m->start, m->n, \
+        else hipLaunchKernelGGL((k_envelope<false, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->n, \
                                 mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));                \
     } while (0)
     switch (ft) {
