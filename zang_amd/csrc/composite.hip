@@ -33,14 +33,21 @@ struct zh_nice {
     float *et, *elast, *estart;
 };
 
-struct zh_pmosc {
-    zh_ctx *ctx;
-    uint32_t n;
+// The six state words per voice (carrier.t, modulator.t, envelope {state, t, last_value, start}) are one [6][n] block, double-
+// buffered through the flipper registry (common.hip.h): the frame-range kernel reads the start state from the current block
+// while its last range writes the end state into the other one, and the host flips.  view() points the named fields at the
+// current block; every entry point calls it first (a graph launch may have flipped).
+struct zh_pmosc : zh_flipper {
     float *release_duration;
     float *tc, *tm;               // carrier.t, modulator.t
     uint32_t *estate;
     float *et, *elast, *estart;
-    uint32_t *next;               // [6][n]: the state after a span painted as frame ranges (k_pmosc_ranges), moved into place by k_pmosc_commit
+    void view() {
+        uint32_t *b = cnt[cur];
+        const size_t N = n;
+        tc = reinterpret_cast<float *>(b); tm = reinterpret_cast<float *>(b + N); estate = b + 2 * N;
+        et = reinterpret_cast<float *>(b + 3 * N); elast = reinterpret_cast<float *>(b + 4 * N); estart = reinterpret_cast<float *>(b + 5 * N);
+    }
 };
 
 // ------------------------------------------------------------------ NiceInstrument voice
@@ -607,7 +614,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
 // frame to frame is two f32 phase accumulators and the envelope's state machine -- ~16 instructions per frame -- while the
 // frame's value is two musl sines on top of them (~150): a range REPLAYS the walk of the frames before it (step(), values
 // discarded) and then paints its own frames exactly like k_pmosc.  The range that ends the span writes the end state to
-// `next` ([6][V]); k_pmosc_commit moves it into place when every range has read the start state (stream order).
+// `next` ([6][V]), the other half of the module's double buffer (the host flips: zh_flipper).
 template <bool ZF>
 __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__restrict__ next, Img out, uint32_t start, uint32_t end, uint32_t ch) {
     const uint32_t v = blockIdx.x * 64 + threadIdx.x;
@@ -645,15 +652,6 @@ __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__re
     next[2 * V + v] = n.env.state; next[3 * V + v] = __builtin_bit_cast(uint32_t, n.env.t);
     next[4 * V + v] = __builtin_bit_cast(uint32_t, n.env.last_value); next[5 * V + v] = __builtin_bit_cast(uint32_t, n.env.start);
 }
-__global__ void __launch_bounds__(256) k_pmosc_commit(PMOscArgs a, const uint32_t *__restrict__ next) {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= a.V) return;
-    const size_t V = a.V;
-    a.tc[v] = __builtin_bit_cast(float, next[v]); a.tm[v] = __builtin_bit_cast(float, next[V + v]);
-    a.estate[v] = next[2 * V + v]; a.et[v] = __builtin_bit_cast(float, next[3 * V + v]);
-    a.elast[v] = __builtin_bit_cast(float, next[4 * V + v]); a.estart[v] = __builtin_bit_cast(float, next[5 * V + v]);
-}
-
 // ------------------------------------------------------------------ span-table paints
 // One launch = for every voice, the reference's Trigger loop over its sub-spans
 // (examples/example_song.zig:336-347): begin() at a sub-span's first frame, end() after its last,
@@ -1248,10 +1246,7 @@ static void nice_free(zh_nice *m) {
     (void)hipFree(m->color); (void)hipFree(m->cnt); (void)hipFree(m->fl); (void)hipFree(m->fb);
     (void)hipFree(m->estate); (void)hipFree(m->et); (void)hipFree(m->elast); (void)hipFree(m->estart);
 }
-static void pmosc_free(zh_pmosc *m) {
-    (void)hipFree(m->release_duration); (void)hipFree(m->tc); (void)hipFree(m->tm);
-    (void)hipFree(m->estate); (void)hipFree(m->et); (void)hipFree(m->elast); (void)hipFree(m->estart); (void)hipFree(m->next);
-}
+static void pmosc_free(zh_pmosc *m) { (void)hipFree(m->release_duration); (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); }
 
 extern "C" {
 
@@ -1561,34 +1556,33 @@ int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc *
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_pmosc *m = new (std::nothrow) zh_pmosc();
     if (!m) return ZH_ERR_INVALID;
-    *m = zh_pmosc{ctx, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0; m->words = 6;
+    m->release_duration = nullptr;
     int rc = dev_alloc(&m->release_duration, n);
-    if (!rc) rc = dev_alloc(&m->next, (size_t)6 * n);
-    if (!rc) rc = dev_alloc(&m->tc, n);
-    if (!rc) rc = dev_alloc(&m->tm, n);
-    if (!rc) rc = dev_alloc(&m->estate, n);
-    if (!rc) rc = dev_alloc(&m->et, n);
-    if (!rc) rc = dev_alloc(&m->elast, n);
-    if (!rc) rc = dev_alloc(&m->estart, n);
+    if (!rc) rc = dev_alloc(&m->cnt[0], (size_t)6 * n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], (size_t)6 * n);
     if (rc) { pmosc_free(m); delete m; return rc; }
     if (n) {
         hipStream_t st = ctx->stream;
         hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->release_duration, n, mk_f32(release_duration));
-        void *zeros[] = {m->tc, m->tm, m->estate, m->et, m->elast, m->estart};
-        for (void *z : zeros) { hipError_t e = hipMemsetAsync(z, 0, (size_t)n * 4, st); if (e != hipSuccess) { pmosc_free(m); delete m; return (int)e; } }
+        for (int b = 0; b < 2; b++) { hipError_t e = hipMemsetAsync(m->cnt[b], 0, (size_t)6 * n * 4, st); if (e != hipSuccess) { pmosc_free(m); delete m; return (int)e; } }
     }
+    m->view();
+    zh_flipper_register(m);
     *out = m;
     return zh_launch_status();
 }
 int zh_pmosc_destroy(zh_pmosc *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
+    zh_flipper_unregister(m);
     pmosc_free(m);
     delete m;
     return ZH_OK;
 }
 int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
+    m->view();
     std::vector<uint32_t> es;
     std::vector<float> tc, tm, t, lv, sv;
     int rc = down(m->ctx, tc, m->tc, m->n);
@@ -1606,6 +1600,7 @@ int zh_pmosc_get_state(zh_pmosc *m, zh_pmosc_state *host) { ZH_GUARD(m ? m->ctx 
 }
 int zh_pmosc_set_state(zh_pmosc *m, const zh_pmosc_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
+    m->view();
     const uint32_t n = m->n;
     std::vector<uint32_t> es(n);
     std::vector<float> tc(n), tm(n), t(n), lv(n), sv(n);
@@ -1627,6 +1622,7 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
     hipStream_t st = m->ctx->stream;
+    m->view();
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, p->sample_rate,
                 mk_f32(p->freq), mk_bool(p->note_on), mk_bool(note_id_changed)};
     // few voices: frame ranges at once (k_pmosc_ranges); ZH_PMOSC_RANGES = number of ranges, 0 = never
@@ -1635,9 +1631,12 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
     const uint32_t ch = zh_range_frames(m->n, end - start, "ZH_PMOSC_RANGES", m->n <= 16384 ? 2048 : 4096, 131072);
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
-        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, m->next, mk_img(outputs[0]), start, end, ch);
-        else hipLaunchKernelGGL(k_pmosc_ranges<false>, grid, dim3(64), 0, st, a, m->next, mk_img(outputs[0]), start, end, ch);
-        hipLaunchKernelGGL(k_pmosc_commit, dim3((m->n + 255) / 256), dim3(256), 0, st, a, m->next);
+        uint32_t *next = m->cnt[m->cur ^ 1];
+        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+        else hipLaunchKernelGGL(k_pmosc_ranges<false>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+        zh_flipper_painted(m);
+        m->cur ^= 1;
+        m->view();
         return zh_launch_status();
     }
     if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
@@ -1651,6 +1650,7 @@ int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf
     if (!m || !outputs || end < start || !buf_covers(outputs[0], m->n, end) || !span_table_ok(table)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
     hipStream_t st = m->ctx->stream;
+    m->view();
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, sample_rate,
                 F32P{0.0f, nullptr}, BoolP{0, nullptr}, BoolP{0, nullptr}};
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;

@@ -636,7 +636,11 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
 }
 
 // =================================================================== Decimator
-struct zh_decimator { zh_ctx *ctx; uint32_t n; float *dval, *dcount; float *next; /* [2][n], k_decimator_ranges */ };
+// state double-buffered like zh_envelope's: two words per voice, [dval n][dcount n]
+struct zh_decimator : zh_flipper {
+    float *dval(int b) const { return reinterpret_cast<float *>(cnt[b]); }
+    float *dcount(int b) const { return reinterpret_cast<float *>(cnt[b] + n); }
+};
 
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dval_io, float *__restrict__ dcount_io, uint32_t V,
@@ -657,8 +661,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_decimator(float *__restrict__ dva
 
 // A span as frame ranges (grid.y): the walk from frame to frame is the fractional counter alone (four instructions,
 // no loads) -- a range replays it for the frames before it, remembering the latest frame that sampled, fetches that one
-// input sample, and paints its own frames like k_decimator.  The range that ends the span writes the end state to `next`;
-// k_commit2 moves it into place (stream order: after every range has read the start state).
+// input sample, and paints its own frames like k_decimator.  The range that ends the span writes the end state to `next`,
+// the other half of the module's double buffer (the host flips: zh_flipper).
 template <bool ZF>
 __global__ void __launch_bounds__(64) k_decimator_ranges(const float *__restrict__ dval_in, const float *__restrict__ dcount_in,
                                                          float *__restrict__ next, uint32_t V, Img out, CImg input, uint32_t start,
@@ -690,12 +694,6 @@ __global__ void __launch_bounds__(64) k_decimator_ranges(const float *__restrict
         next[v] = o.dval; next[(size_t)V + v] = o.dcount;
     }
 }
-__global__ void __launch_bounds__(256) k_commit2(float *__restrict__ a, float *__restrict__ b, const float *__restrict__ next, uint32_t V) {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    a[v] = next[v]; b[v] = next[(size_t)V + v];
-}
-
 // =================================================================== Distortion (stateless)
 struct zh_distortion { zh_ctx *ctx; uint32_t n; };
 
@@ -1316,43 +1314,43 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
 // ------------------------------------------------------------------ Decimator
 int zh_decimator_create(zh_ctx *ctx, uint32_t n, zh_decimator **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_decimator *m = new (std::nothrow) zh_decimator{ctx, n, nullptr, nullptr, nullptr};
+    zh_decimator *m = new (std::nothrow) zh_decimator();
     if (!m) return ZH_ERR_INVALID;
-    int rc = dev_alloc(&m->dval, n);
-    if (!rc) rc = dev_alloc(&m->dcount, n);
-    if (!rc) rc = dev_alloc(&m->next, (size_t)n * 2);
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0; m->words = 2;
+    int rc = dev_alloc(&m->cnt[0], (size_t)2 * n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], (size_t)2 * n);
     if (!rc && n) {                                                                // init() :14-19: dval 0, dcount 1
-        std::vector<float> ones(n, 1.0f);
-        rc = (int)hipMemsetAsync(m->dval, 0, n * 4, ctx->stream);
-        if (!rc) rc = upload_field(ctx, m->dcount, ones);
+        std::vector<float> init((size_t)2 * n, 0.0f);
+        for (uint32_t v = 0; v < n; v++) init[(size_t)n + v] = 1.0f;
+        rc = upload_field(ctx, m->dval(0), init);
+        if (!rc) rc = upload_field(ctx, m->dval(1), init);
     }
-    if (rc) { (void)hipFree(m->dval); (void)hipFree(m->dcount); (void)hipFree(m->next); delete m; return rc; }
+    if (rc) { (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
 int zh_decimator_destroy(zh_decimator *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->dval); (void)hipFree(m->dcount); (void)hipFree(m->next);
+    zh_flipper_unregister(m);
+    (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]);
     delete m;
     return ZH_OK;
 }
 int zh_decimator_get_state(zh_decimator *m, zh_decimator_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<float> a, b;
-    int rc = download_field(m->ctx, a, m->dval, m->n);
-    if (!rc) rc = download_field(m->ctx, b, m->dcount, m->n);
+    std::vector<float> w;
+    int rc = download_field(m->ctx, w, m->dval(m->cur), (size_t)2 * m->n);
     if (rc) return rc;
-    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_decimator_state{a[v], b[v]};
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_decimator_state{w[v], w[(size_t)m->n + v]};
     return ZH_OK;
 }
 int zh_decimator_set_state(zh_decimator *m, const zh_decimator_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<float> a(m->n), b(m->n);
-    for (uint32_t v = 0; v < m->n; v++) { a[v] = host[v].dval; b[v] = host[v].dcount; }
-    int rc = upload_field(m->ctx, m->dval, a);
-    if (!rc) rc = upload_field(m->ctx, m->dcount, b);
-    return rc;
+    std::vector<float> w((size_t)2 * m->n);
+    for (uint32_t v = 0; v < m->n; v++) { w[v] = host[v].dval; w[(size_t)m->n + v] = host[v].dcount; }
+    return upload_field(m->ctx, m->dval(m->cur), w);
 }
 int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
                        zh_bool note_id_changed, const zh_decimator_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
@@ -1368,12 +1366,14 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     const uint32_t ch = end > start && !bufs_alias(p->input, outputs[0]) ? zh_range_frames(m->n, end - start, "ZH_DECIMATOR_RANGES", 1024, 32768) : 0;
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
-        ZH_ZF_LAUNCH(k_decimator_ranges, grid, dim3(64), m->dval, m->dcount, m->next, m->n, mk_img(outputs[0]), mk_cimg(p->input),
+        const int c = m->cur;
+        ZH_ZF_LAUNCH(k_decimator_ranges, grid, dim3(64), m->dval(c), m->dcount(c), m->dval(c ^ 1), m->n, mk_img(outputs[0]), mk_cimg(p->input),
                      start, end, ch, p->sample_rate, mk_f32(p->fake_sample_rate));
-        hipLaunchKernelGGL(k_commit2, dim3((m->n + 255) / 256), dim3(256), 0, st, m->dval, m->dcount, m->next, m->n);
+        zh_flipper_painted(m);
+        m->cur ^= 1;
         return zh_launch_status();
     }
-    ZH_ZF_LAUNCH(k_decimator, seq_grid(m->n), dim3(kSeqBlock), m->dval, m->dcount, m->n, mk_img(outputs[0]),
+    ZH_ZF_LAUNCH(k_decimator, seq_grid(m->n), dim3(kSeqBlock), m->dval(m->cur), m->dcount(m->cur), m->n, mk_img(outputs[0]),
                  mk_cimg(p->input), start, end, p->sample_rate, mk_f32(p->fake_sample_rate));
     return zh_launch_status();
 }
