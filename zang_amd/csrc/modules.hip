@@ -572,14 +572,19 @@ __device__ __forceinline__ int32_t sampler_mod(int32_t index, int32_t n, double 
 }
 
 // Sampler.zig:35-58 (num_samples == 0 with loop: division by zero in the reference; DEFINED as silence = kSampleEmpty)
-template <int FMT, bool LOOP>
-__device__ __forceinline__ float sampler_get_sample(const SampleP &s, int32_t index1) {
+// the sample at an index that is already resolved (looped: inside [0, num_samples); else tested here)
+template <int FMT>
+__device__ __forceinline__ float sampler_at(const SampleP &s, int32_t index) {
     if constexpr (FMT == kSampleEmpty) return 0.0f;
-    const int32_t index = LOOP ? sampler_mod(index1, s.num_samples, s.inv_num_samples) : index1;   // @mod: floored
     const bool in = index >= 0 && index < s.num_samples;
     const size_t i = (size_t)(in ? index : 0) * s.num_channels + s.channel;
     const float val = sampler_decode<FMT>(s.data, i, s.whole != 0);
     return in ? val : 0.0f;
+}
+template <int FMT, bool LOOP>
+__device__ __forceinline__ float sampler_get_sample(const SampleP &s, int32_t index1) {
+    if constexpr (FMT == kSampleEmpty) return 0.0f;
+    return sampler_at<FMT>(s, LOOP ? sampler_mod(index1, s.num_samples, s.inv_num_samples) : index1);   // @mod: floored
 }
 
 // One kernel, two launch shapes.  Sequential: grid.y = 1, ch = the whole span, t_in == t_out.  Few voices: grid.y frame
@@ -618,12 +623,24 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
             for (int k = 0; k < 8; k++) t += ratio;
         }
         for (; i < f0; i++) t += ratio;
+        // looped: @mod(t0 + 1, n) is @mod(t0, n) + 1, wrapped once -- except where t0 + 1 itself wraps (t0 = INT32_MAX: the
+        // conversion's saturation value), whose remainder is the same for every frame
+        const int32_t r_wrap = (LOOP && FMT != kSampleEmpty) ? sampler_mod(INT32_MIN, s.num_samples, s.inv_num_samples) : 0;
         frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
             const int32_t t0 = zf32_to_i32(floorf(t));
             const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
             const float tfrac = (float)t1 - t;                        // :121
-            const float s0 = sampler_get_sample<FMT, LOOP>(s, t0);
-            const float s1 = sampler_get_sample<FMT, LOOP>(s, t1);
+            float s0, s1;
+            if constexpr (LOOP && FMT != kSampleEmpty) {
+                const int32_t r0 = sampler_mod(t0, s.num_samples, s.inv_num_samples);
+                int32_t r1 = r0 + 1 == s.num_samples ? 0 : r0 + 1;
+                r1 = t0 == INT32_MAX ? r_wrap : r1;
+                s0 = sampler_at<FMT>(s, r0);
+                s1 = sampler_at<FMT>(s, r1);
+            } else {
+                s0 = sampler_get_sample<FMT, LOOP>(s, t0);
+                s1 = sampler_get_sample<FMT, LOOP>(s, t1);
+            }
             val = s0 * (1.0f - tfrac) + s1 * tfrac;
             t += ratio;
             return true;
