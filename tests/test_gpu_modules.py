@@ -527,6 +527,37 @@ def test_sampler(ctx, oracle, fmt, loop, replay_form):
     util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sampler t")
 
 
+@pytest.mark.parametrize("fmt", [1, 3])
+def test_sampler_huge_play_positions(ctx, oracle, fmt, replay_form):
+    """Play positions beyond the i32 range (set through the state): floor(t) converts to the saturation value, t0 + 1 wraps
+    to INT32_MIN -- the looped second tap's index is NOT the first one's + 1 there (the device derives it that way in every
+    other case) -- and positions just below, negative ones, and ordinary ones in the same wave."""
+    from zang_amd import modules as mod, zang
+    V, channels, in_rate = 70, 1, 44100
+    data = _pcm(fmt, 333, channels, 77)
+    t0 = np.linspace(-5000.0, 5000.0, V).astype(np.float32)
+    t0[:10] = [3.0e9, 2.2e9, 2147483520.0, 2147483648.0, -3.0e9, -2147483648.0, 4.0e9, 1.0e10, -1.0e10, 2147483392.0]
+    rate = np.full(V, 30000.0, np.float32); rate[::3] = 50000.0
+    out0 = util.rng_buffers(91, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rt = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.Sampler(); L.zo_sampler_init(C.byref(st)); st.t = float(t0[v])
+        p = oracle.SamplerParams(float(rate[v]), channels, in_rate, fmt, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, 0, 1)
+        for (s, e) in [(0, 1024), (100, 700)]:
+            L.zo_sampler_paint(C.byref(st), s, e, oracle.fptr(ref[v]), 0, C.byref(p))
+        rt[v] = st.t
+    m = mod.Sampler(V, ctx)
+    st = m.state(); st["t"] = t0; m.set_state(st)
+    out = util.to_image(out0)
+    smp = m.Sample(channels, in_rate, fmt, util.dev(data))
+    for (s, e) in [(0, 1024), (100, 700)]:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(util.dev(rate), smp, 0, True))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"sampler huge positions fmt {fmt}")
+    util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "t")
+
+
 def test_sampler_channel_out_of_range(ctx):
     from zang_amd import modules as mod, zang
     m = mod.Sampler(8, ctx)
