@@ -207,9 +207,11 @@ def test_config5_shard_48_buffer_cycle(ctx, oracle):
 
 @pytest.mark.parametrize("V", [24576, 49152])
 def test_frame_range_forms_at_mid_voice_counts(ctx, oracle, monkeypatch, V):
-    """Between 16,384 and ~131,072 voices SineOsc, Sampler, the controlled-frequency PulseOsc and PMOscInstrument paint a span
-    as a few frame ranges (zh_range_frames, ctx.hip: more waves per SIMD).  Two carried buffers in the default form equal the
-    sequential form (ZH_*_RANGES=0) bit for bit, images and states; sampled SineOsc voices equal the oracle."""
+    """Between 16,384 and ~131,072 voices SineOsc, Sampler, the controlled-frequency oscillators, PMOscInstrument, Envelope and
+    Decimator paint a span as a few frame ranges (zh_range_frames, ctx.hip: more waves per SIMD), and Filter, FilteredEchoes,
+    NiceInstrument run as wave pipelines, SimpleDelay as independent frames -- each up to its own voice-count limit.  Two
+    carried buffers in the default form equal the one-wave walks (every switch off) bit for bit, images and states; sampled
+    SineOsc voices equal the oracle."""
     import torch
     from zang_amd import modules as mod, zang, workloads
     freq, color, u2, _ = workloads.voice_params(5, 0, V)
@@ -241,14 +243,47 @@ def test_frame_range_forms_at_mid_voice_counts(ctx, oracle, monkeypatch, V):
         for k in range(2):
             m.paint(span, [o], None, k == 0, m.Params(SR, gf, k == 0), zero_first=True)
         outs.append(o); states.append(m.state())
+        # the wave pipelines and the other frame-range forms of round 2, against their one-wave walks
+        m = mod.Envelope(V, ctx); o = ctx.image(F, V)
+        for k in range(2):
+            m.paint(span, [o], [], k == 0, m.Params(SR, zang.PaintCurve.cubed(0.004), zang.PaintCurve.cubed(0.02), zang.PaintCurve.cubed(0.03), 0.6, k == 0), zero_first=True)
+        outs.append(o); states.append(m.state())
+        m = mod.Decimator(V, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(SR, fbuf, gf * 8.0), zero_first=True)
+        outs.append(o); states.append(m.state())
+        m = mod.Filter(V, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(fbuf, m.band_pass, zang.constant(gc), zang.constant(0.4)), zero_first=True)
+        outs.append(o); states.append(m.state())
+        m = mod.FilteredEchoes(V, 300, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], None, False, m.Params(fbuf, 0.5, 0.2), zero_first=True)
+        outs.append(o); states.append(np.concatenate([np.asarray(x).ravel().view(np.uint8) for x in m.state()]))
+        m = mod.SimpleDelay(V, 300, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(fbuf), zero_first=True)
+        outs.append(o); states.append(np.concatenate([np.asarray(x).ravel().view(np.uint8) for x in m.state()]))
+        m = mod.NiceInstrument(V, gc, ctx); o = ctx.image(F, V)
+        for k in range(2):
+            m.paint(span, [o], None, k == 0, m.Params(SR, gf, k == 0), zero_first=True)
+        outs.append(o); states.append(m.state())
+        m = mod.TriSawOsc(V, ctx); o = ctx.image(F, V)
+        for _ in range(2):
+            m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), gc), zero_first=True)
+        outs.append(o); states.append(m.state())
         ctx.sync()
         return outs, states
 
     a_out, a_st = render()
-    for name in ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_PMOSC_RANGES"):
+    for name in ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_PMOSC_RANGES", "ZH_ENVELOPE_RANGES", "ZH_DECIMATOR_RANGES",
+                 "ZH_TRISAW_CTRL_RANGES", "ZH_FILTER_PC_MAX", "ZH_ECHOES_PC_MAX", "ZH_DELAY_FRAMES_MAX", "ZH_NICE_PC_MAX", "ZH_NICE_PC4_MAX"):
         monkeypatch.setenv(name, "0")
     b_out, b_st = render()
-    for name, x, y, sx, sy in zip(("sineosc const", "sineosc image", "sampler", "pulseosc image", "pmosc"), a_out, b_out, a_st, b_st):
+    names = ("sineosc const", "sineosc image", "sampler", "pulseosc image", "pmosc", "envelope", "decimator", "filter", "filtered echoes",
+             "simple delay", "nice", "trisawosc image")
+    assert len(a_out) == len(names)
+    for name, x, y, sx, sy in zip(names, a_out, b_out, a_st, b_st):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
         assert np.asarray(sx).tobytes() == np.asarray(sy).tobytes(), name + " state"
     idx = np.arange(0, V, V // 64)
