@@ -784,7 +784,10 @@ __global__ void __launch_bounds__(kSeqBlock) k_cycle(float *__restrict__ t_io, u
 }
 
 // =================================================================== Portamento
-struct zh_portamento { zh_ctx *ctx; uint32_t n; float *t, *last_value, *start; };
+// state double-buffered like zh_envelope's: three words per voice, [t n][last_value n][start n]
+struct zh_portamento : zh_flipper {
+    float *f(int b, int k) const { return reinterpret_cast<float *>(cnt[b] + (size_t)k * n); }
+};
 
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_portamento(float *__restrict__ t_io, float *__restrict__ last_io,
@@ -800,6 +803,37 @@ __global__ void __launch_bounds__(kSeqBlock) k_portamento(float *__restrict__ t_
                           [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.goal; return true; },
                           [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.frame(); return true; });
     t_io[v] = o.t; last_io[v] = o.last; start_io[v] = o.st;
+}
+
+// A span as frame ranges (few voices): a range replays the glide's clock for the frames before it -- nothing for a wave whose
+// voices have all arrived, 8 additions per chunk while none can arrive, frame by frame around an arrival -- then paints its
+// own frames like k_portamento; the range that ends the span writes the state into the other half of the double buffer.
+template <bool ZF>
+__global__ void __launch_bounds__(64) k_portamento_ranges(const float *__restrict__ t_in, const float *__restrict__ last_in, const float *__restrict__ start_in,
+                                                          float *__restrict__ next, uint32_t V, Img out, uint32_t start, uint32_t end, uint32_t ch,
+                                                          float sample_rate, uint32_t curve_tag, F32P duration, F32P goal_p, BoolP note_on,
+                                                          BoolP prev_note_on, BoolP nic) {
+    const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
+    PortamentoLane o;
+    o.t = t_in[v]; o.last = last_in[v]; o.st = start_in[v];
+    o.begin(sample_rate, curve_tag, duration.get(v), goal_p.get(v), note_on.get(v), prev_note_on.get(v), nic.get(v));
+    if (!o.all_flat()) {
+        uint32_t i = start;
+        for (; i + 8 <= f0; i += 8) {
+            if (o.quiet(8)) o.template skip_quiet<8>();
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) (void)o.frame();
+            }
+        }
+        for (; i < f0; i++) (void)o.frame();
+    }
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1, [&](uint32_t) ZH_INLINE_LAMBDA { return o.all_flat(); },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.goal; return true; },
+                          [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.frame(); return true; });
+    if (f1 == end) { next[v] = o.t; next[(size_t)V + v] = o.last; next[(size_t)2 * V + v] = o.st; }
 }
 
 // =================================================================== host side
@@ -1504,45 +1538,40 @@ int zh_cycle_paint(zh_cycle *m, uint32_t start, uint32_t end, const zh_buf *outp
 // ------------------------------------------------------------------ Portamento
 int zh_portamento_create(zh_ctx *ctx, uint32_t n, zh_portamento **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_portamento *m = new (std::nothrow) zh_portamento{ctx, n, nullptr, nullptr, nullptr};
+    zh_portamento *m = new (std::nothrow) zh_portamento();
     if (!m) return ZH_ERR_INVALID;
-    int rc = dev_alloc(&m->t, n);
-    if (!rc) rc = dev_alloc(&m->last_value, n);
-    if (!rc) rc = dev_alloc(&m->start, n);
-    if (!rc && n) {                                                                // Painter.init(), painter.zig:38-44
-        rc = (int)hipMemsetAsync(m->t, 0, n * 4, ctx->stream);
-        if (!rc) rc = (int)hipMemsetAsync(m->last_value, 0, n * 4, ctx->stream);
-        if (!rc) rc = (int)hipMemsetAsync(m->start, 0, n * 4, ctx->stream);
-    }
-    if (rc) { (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start); delete m; return rc; }
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0; m->words = 3;
+    int rc = dev_alloc(&m->cnt[0], (size_t)3 * n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], (size_t)3 * n);
+    for (int b = 0; b < 2 && !rc && n; b++) rc = (int)hipMemsetAsync(m->cnt[b], 0, (size_t)3 * n * 4, ctx->stream);   // Painter.init(), painter.zig:38-44
+    if (rc) { (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
 int zh_portamento_destroy(zh_portamento *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->t); (void)hipFree(m->last_value); (void)hipFree(m->start);
+    zh_flipper_unregister(m);
+    (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]);
     delete m;
     return ZH_OK;
 }
 int zh_portamento_get_state(zh_portamento *m, zh_portamento_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<float> a, b, c;
-    int rc = download_field(m->ctx, a, m->t, m->n);
-    if (!rc) rc = download_field(m->ctx, b, m->last_value, m->n);
-    if (!rc) rc = download_field(m->ctx, c, m->start, m->n);
+    std::vector<float> w;
+    int rc = download_field(m->ctx, w, m->f(m->cur, 0), (size_t)3 * m->n);
     if (rc) return rc;
-    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_portamento_state{a[v], b[v], c[v]};
+    const size_t n = m->n;
+    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_portamento_state{w[v], w[n + v], w[2 * n + v]};
     return ZH_OK;
 }
 int zh_portamento_set_state(zh_portamento *m, const zh_portamento_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<float> a(m->n), b(m->n), c(m->n);
-    for (uint32_t v = 0; v < m->n; v++) { a[v] = host[v].t; b[v] = host[v].last_value; c[v] = host[v].start; }
-    int rc = upload_field(m->ctx, m->t, a);
-    if (!rc) rc = upload_field(m->ctx, m->last_value, b);
-    if (!rc) rc = upload_field(m->ctx, m->start, c);
-    return rc;
+    const size_t n = m->n;
+    std::vector<float> w(3 * n);
+    for (uint32_t v = 0; v < m->n; v++) { w[v] = host[v].t; w[n + v] = host[v].last_value; w[2 * n + v] = host[v].start; }
+    return upload_field(m->ctx, m->f(m->cur, 0), w);
 }
 int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
                         zh_bool note_id_changed, const zh_portamento_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
@@ -1553,7 +1582,19 @@ int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh
     if (m->n == 0) return ZH_OK;            // an empty span still applies newCurve / the instantaneous jump
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
-    ZH_ZF_LAUNCH(k_portamento, seq_grid(m->n), dim3(kSeqBlock), m->t, m->last_value, m->start, m->n, mk_img(outputs[0]),
+    const int c = m->cur;
+    // few voices: frame ranges (1,024 / 4,096 / 16,384 / 32,768 voices: 14.8 / 16.5 / 17.7 / 27.1 us as one walk per voice, 3.4 / 6.0 / 13.0 / 26.4 us)
+    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_PORTAMENTO_RANGES", 2048, 32768) : 0;
+    if (ch) {
+        const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
+        ZH_ZF_LAUNCH(k_portamento_ranges, grid, dim3(64), m->f(c, 0), m->f(c, 1), m->f(c, 2), m->f(c ^ 1, 0), m->n, mk_img(outputs[0]), start, end, ch,
+                     p->sample_rate, p->curve.tag, mk_f32(p->curve.duration), mk_f32(p->goal), mk_bool(p->note_on), mk_bool(p->prev_note_on),
+                     mk_bool(note_id_changed));
+        zh_flipper_painted(m);
+        m->cur ^= 1;
+        return zh_launch_status();
+    }
+    ZH_ZF_LAUNCH(k_portamento, seq_grid(m->n), dim3(kSeqBlock), m->f(c, 0), m->f(c, 1), m->f(c, 2), m->n, mk_img(outputs[0]),
                  start, end, p->sample_rate, p->curve.tag, mk_f32(p->curve.duration), mk_f32(p->goal), mk_bool(p->note_on),
                  mk_bool(p->prev_note_on), mk_bool(note_id_changed));
     return zh_launch_status();

@@ -290,6 +290,19 @@ struct PortamentoLane {
     // frame_loop_gen (seq.hip.h): once every voice of the wave has arrived (paintFlat, Portamento.zig:43-47) a frame is the
     // goal itself and nothing changes
     __device__ __forceinline__ bool all_flat() const { return __builtin_amdgcn_ballot_w64(!flat) == 0; }
+    // N frames with the values discarded (a frame-range kernel's replay), for a wave in which no gliding voice can arrive
+    // within them (the margin argument of EnvLaneT::quiet): the clock steps N times, the value it leaves is evaluated once
+    __device__ __forceinline__ bool quiet(int n) const {
+        return __builtin_amdgcn_ballot_w64(!flat && !(t + (float)(n + 1) * t_step < 0.999f)) == 0;
+    }
+    template <int N> __device__ __forceinline__ void skip_quiet() {
+        float tt = t;
+#pragma unroll
+        for (int k = 0; k < N; k++) tt = tt + t_step;
+        const float lv = st + curve_at(tt) * (goal - st);
+        t = flat ? t : tt;
+        last = flat ? last : lv;
+    }
 };
 
 // ---- Curve (src/modules/Curve.zig) ---------------------------------------------------------------
