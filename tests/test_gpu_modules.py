@@ -29,7 +29,7 @@ def _gcob(zang, kind, const_t, buf_t):
 
 # ------------------------------------------------------------------ SineOsc
 RANGE_SWITCHES = ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_DECIMATOR_RANGES", "ZH_ENVELOPE_RANGES",
-                  "ZH_PORTAMENTO_RANGES", "ZH_TRISAW_CTRL_RANGES", "ZH_PULSE_CTRL_RANGES")
+                  "ZH_PORTAMENTO_RANGES", "ZH_TRISAW_CTRL_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_CYCLE_RANGES")
 
 
 @pytest.fixture(params=["ranges", "sequential"])
@@ -622,7 +622,7 @@ def test_distortion(ctx, oracle, dtype_):
 
 # ------------------------------------------------------------------ Cycle / Portamento
 @pytest.mark.parametrize("kind", ["c", "b"])
-def test_cycle(ctx, oracle, kind):
+def test_cycle(ctx, oracle, kind, replay_form):
     from zang_amd import modules as mod, zang
     V = 128
     rng = np.random.default_rng(91)
