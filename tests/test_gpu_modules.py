@@ -29,7 +29,7 @@ def _gcob(zang, kind, const_t, buf_t):
 
 # ------------------------------------------------------------------ SineOsc
 RANGE_SWITCHES = ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_DECIMATOR_RANGES", "ZH_ENVELOPE_RANGES",
-                  "ZH_PORTAMENTO_RANGES", "ZH_TRISAW_CTRL_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_CYCLE_RANGES")
+                  "ZH_PORTAMENTO_RANGES", "ZH_TRISAW_CTRL_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_CYCLE_RANGES", "ZH_CURVE_RANGES")
 
 
 @pytest.fixture(params=["ranges", "sequential"])
@@ -677,7 +677,7 @@ def test_portamento(ctx, oracle, curve, replay_form):
 
 
 @pytest.mark.parametrize("function", [0, 1])
-def test_curve(ctx, oracle, function):
+def test_curve(ctx, oracle, function, replay_form):
     """Curve.zig: shared node list, per-voice progress; voices are desynchronised by per-voice
     note_id_changed (restart) at different buffers; sub-span paints; runs past the last node."""
     from zang_amd import modules as mod, zang

@@ -744,23 +744,32 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
 }
 
 // =================================================================== Curve
-struct zh_curve_module { zh_ctx *ctx; uint32_t n; float *t; uint32_t *cur; int32_t *off; uint32_t *next; };
+// state double-buffered like zh_envelope's: four words per voice, [t n][current_song_note n][offset n][next_song_note n]
+struct zh_curve_module : zh_flipper {};
 
+// One lane per voice walks the span (grid.y == 1, ch = the span, st_in == st_out), or -- few voices -- the span as grid.y frame
+// ranges.  What a paint leaves behind (t, cur, off, next) is decided in begin(), before the first frame; the frame walk only
+// carries the running curve span and its accumulator, which begin(r0) sets up for a range's first frame (spans that end
+// before it are dropped as they stream by, the running span's accumulator is stepped from its own first frame).  The range
+// that ends the span writes the state (into the other half of the double buffer when there are several).
 template <bool ZF>
-__global__ void __launch_bounds__(kSeqBlock) k_curve(float *__restrict__ t_io, uint32_t *__restrict__ cur_io,
-                                                     int32_t *__restrict__ off_io, uint32_t *__restrict__ next_io, uint32_t V,
-                                                     Img out, uint32_t start, uint32_t end, float sample_rate, uint32_t function,
+__global__ void __launch_bounds__(kSeqBlock) k_curve(const uint32_t *__restrict__ st_in, uint32_t *__restrict__ st_out, uint32_t V,
+                                                     Img out, uint32_t start, uint32_t end, uint32_t ch, float sample_rate, uint32_t function,
                                                      const zh_curve_node *__restrict__ curve, uint32_t n_curve, BoolP nic) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= V) return;
+    const uint32_t f0 = start + blockIdx.y * ch, f1 = min(f0 + ch, end);
+    const size_t N = V;
     CurveLane o;
     CurveTable tb;
-    o.t = t_io[v]; o.cur = cur_io[v]; o.next = next_io[v]; o.off = off_io[v];
-    o.begin(tb, sample_rate, function, curve, n_curve, end - start, nic.get(v));
-    frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t i) ZH_INLINE_LAMBDA { return o.quiet(i - start, 8); },
+    o.t = __builtin_bit_cast(float, st_in[v]); o.cur = st_in[N + v]; o.off = (int32_t)st_in[2 * N + v]; o.next = st_in[3 * N + v];
+    o.begin(tb, sample_rate, function, curve, n_curve, end - start, nic.get(v), f0 - start);
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1, [&](uint32_t i) ZH_INLINE_LAMBDA { return o.quiet(i - start, 8); },
                           [&](uint32_t, float &val) ZH_INLINE_LAMBDA { return o.frame_in_span(val); },
                           [&](uint32_t i, float &val) ZH_INLINE_LAMBDA { return o.frame(tb, i - start, val); });
-    t_io[v] = o.t; cur_io[v] = o.cur; off_io[v] = o.off; next_io[v] = o.next;
+    if (f1 == end) {
+        st_out[v] = __builtin_bit_cast(uint32_t, o.t); st_out[N + v] = o.cur; st_out[2 * N + v] = (uint32_t)o.off; st_out[3 * N + v] = o.next;
+    }
 }
 
 // =================================================================== Cycle
@@ -1447,47 +1456,48 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
 // ------------------------------------------------------------------ Curve
 int zh_curve_module_create(zh_ctx *ctx, uint32_t n, zh_curve_module **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
-    zh_curve_module *m = new (std::nothrow) zh_curve_module{ctx, n, nullptr, nullptr, nullptr, nullptr};
+    zh_curve_module *m = new (std::nothrow) zh_curve_module();
     if (!m) return ZH_ERR_INVALID;
-    int rc = dev_alloc(&m->t, n);
-    if (!rc) rc = dev_alloc(&m->cur, n);
-    if (!rc) rc = dev_alloc(&m->off, n);
-    if (!rc) rc = dev_alloc(&m->next, n);
-    if (!rc && n) {                                                                // init() :46-54
-        void *z[] = {m->t, m->cur, m->off, m->next};
-        for (void *p : z) if (!rc) rc = (int)hipMemsetAsync(p, 0, (size_t)n * 4, ctx->stream);
-    }
-    if (rc) { (void)hipFree(m->t); (void)hipFree(m->cur); (void)hipFree(m->off); (void)hipFree(m->next); delete m; return rc; }
+    m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0; m->words = 4;
+    int rc = dev_alloc(&m->cnt[0], (size_t)4 * n);
+    if (!rc) rc = dev_alloc(&m->cnt[1], (size_t)4 * n);
+    for (int b = 0; b < 2 && !rc && n; b++) rc = (int)hipMemsetAsync(m->cnt[b], 0, (size_t)4 * n * 4, ctx->stream);   // init() :46-54
+    if (rc) { (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); delete m; return rc; }
+    zh_flipper_register(m);
     *out = m;
     return ZH_OK;
 }
 int zh_curve_module_destroy(zh_curve_module *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->t); (void)hipFree(m->cur); (void)hipFree(m->off); (void)hipFree(m->next);
+    zh_flipper_unregister(m);
+    (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]);
     delete m;
     return ZH_OK;
 }
 int zh_curve_module_get_state(zh_curve_module *m, zh_curve_module_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<float> t; std::vector<uint32_t> c, nx; std::vector<int32_t> o;
-    int rc = download_field(m->ctx, t, m->t, m->n);
-    if (!rc) rc = download_field(m->ctx, c, m->cur, m->n);
-    if (!rc) rc = download_field(m->ctx, o, m->off, m->n);
-    if (!rc) rc = download_field(m->ctx, nx, m->next, m->n);
+    std::vector<uint32_t> w;
+    int rc = download_field(m->ctx, w, m->cnt[m->cur], (size_t)4 * m->n);
     if (rc) return rc;
-    for (uint32_t v = 0; v < m->n; v++) host[v] = zh_curve_module_state{t[v], c[v], o[v], nx[v]};
+    const size_t n = m->n;
+    for (uint32_t v = 0; v < m->n; v++) {
+        zh_curve_module_state e;
+        memcpy(&e.t, &w[v], 4);
+        e.current_song_note = w[n + v]; e.current_song_note_offset = (int32_t)w[2 * n + v]; e.next_song_note = w[3 * n + v];
+        host[v] = e;
+    }
     return ZH_OK;
 }
 int zh_curve_module_set_state(zh_curve_module *m, const zh_curve_module_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
-    std::vector<float> t(m->n); std::vector<uint32_t> c(m->n), nx(m->n); std::vector<int32_t> o(m->n);
-    for (uint32_t v = 0; v < m->n; v++) { t[v] = host[v].t; c[v] = host[v].current_song_note; o[v] = host[v].current_song_note_offset; nx[v] = host[v].next_song_note; }
-    int rc = upload_field(m->ctx, m->t, t);
-    if (!rc) rc = upload_field(m->ctx, m->cur, c);
-    if (!rc) rc = upload_field(m->ctx, m->off, o);
-    if (!rc) rc = upload_field(m->ctx, m->next, nx);
-    return rc;
+    const size_t n = m->n;
+    std::vector<uint32_t> w(4 * n);
+    for (uint32_t v = 0; v < m->n; v++) {
+        memcpy(&w[v], &host[v].t, 4);
+        w[n + v] = host[v].current_song_note; w[2 * n + v] = (uint32_t)host[v].current_song_note_offset; w[3 * n + v] = host[v].next_song_note;
+    }
+    return upload_field(m->ctx, m->cnt[m->cur], w);
 }
 int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
                           zh_bool note_id_changed, const zh_curve_module_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
@@ -1500,9 +1510,17 @@ int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, cons
     hipStream_t st = m->ctx->stream;
     // 4,096 voices: 89 us with a span search behind a per-lane test in every unrolled frame; 36.5 us with the spans streamed
     // into a table in begin() and chunks without a span change running without the test (seq.hip.h frame_loop_gen).  Painted
-    // as frame ranges it took 28 us whatever the range count: begin() is the floor, so the sequential form stays.
-    ZH_ZF_LAUNCH(k_curve, seq_grid(m->n), dim3(kSeqBlock), m->t, m->cur, m->off, m->next, m->n, mk_img(outputs[0]), start, end,
+    // as frame ranges it first took 28 us whatever the range count -- not begin() (3 us: a paint of 8 frames is 3.8 us in all) but
+    // the accumulator replay as a rolled scalar loop and a second begin() in a state-advance kernel;
+    // done properly (running span set up by begin(r0), unrolled replay, state in a flipped double buffer) frame ranges take
+    // 9.2 / 11.7 / 17.0 / 29.4 us at 1,024 / 4,096 / 16,384 / 32,768 voices against 34.9 / 36.5 / 37.9 / 43.2 (an empty span still
+    // runs begin(): the one-range form)
+    const uint32_t chr = end > start ? zh_range_frames(m->n, end - start, "ZH_CURVE_RANGES", 2048, 32768) : 0;
+    const uint32_t ch = chr ? chr : (end > start ? end - start : 1);
+    const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
+    ZH_ZF_LAUNCH(k_curve, grid, dim3(kSeqBlock), m->cnt[m->cur], m->cnt[chr ? m->cur ^ 1 : m->cur], m->n, mk_img(outputs[0]), start, end, ch,
                  p->sample_rate, p->function, p->curve, (uint32_t)p->curve_len, mk_bool(note_id_changed));
+    if (chr) { zh_flipper_painted(m); m->cur ^= 1; }
     return zh_launch_status();
 }
 

@@ -331,12 +331,14 @@ struct CurveLane {
     bool has_values;
     float acc, step, start_value, value_delta;
     // begin()'s stream
-    uint32_t dest_start;
+    uint32_t dest_start, r0, run_start;                               // r0: the first relative frame the walk will ask for; run_start: where the running span began
     bool nodes_done;
 
     __device__ __forceinline__ void add_span(CurveTable &tb, uint32_t end_, bool values, float acc_, float step_, float sv_, float vd_) {
+        const uint32_t from = dest_start;
         dest_start = end_;
-        if (n_spans == 0) { span_end = end_; has_values = values; acc = acc_; step = step_; start_value = sv_; value_delta = vd_; }
+        if (end_ <= r0) return;                                       // over before the first frame wanted (a frame range's begin)
+        if (n_spans == 0) { run_start = from; span_end = end_; has_values = values; acc = acc_; step = step_; start_value = sv_; value_delta = vd_; }
         if (n_spans < kCurveSpans) {
             tb.s_end[n_spans] = end_ | (values ? 0x80000000u : 0u);
             tb.s_acc[n_spans] = acc_; tb.s_step[n_spans] = step_; tb.s_sv[n_spans] = sv_; tb.s_vd[n_spans] = vd_;
@@ -363,10 +365,12 @@ struct CurveLane {
         add_span(tb, (uint32_t)end_pos, has_b, acc_, step_, sv_, vd_);
     }
 
+    // r0_ = relative frame the walk starts at (a frame range; 0 = the whole paint): frame() is then called for r0_, r0_ + 1, ...
     __device__ __forceinline__ void begin(CurveTable &tb, float sample_rate, uint32_t function_, const zh_curve_node *__restrict__ curve,
-                                          uint32_t n_curve, uint32_t out_len_, bool note_id_changed) {
+                                          uint32_t n_curve, uint32_t out_len_, bool note_id_changed, uint32_t r0_ = 0) {
         function = function_;
         out_len = out_len_;
+        r0 = r0_; run_start = 0;
         if (note_id_changed) { cur = 0; off = 0; next = 0; t = 0.0f; }   // :66-71
         n_spans = 0; dest_start = 0; nodes_done = false;
         span_end = out_len; has_values = false;
@@ -400,6 +404,13 @@ struct CurveLane {
         t += buf_time;                                                 // :180
         off -= (int32_t)out_len;                                       // :181
         k = 0;
+        // the running span's frames before r0: its accumulator stepped as frame() would have (a gap's is never read)
+        uint32_t i = run_start;
+        for (; i + 8 <= r0; i += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc += step;
+        }
+        for (; i < r0; i++) acc += step;
     }
     __device__ __forceinline__ void advance_span(const CurveTable &tb) {
         k = k + 1 < kCurveSpans ? k + 1 : k;
