@@ -401,14 +401,35 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(const float *__res
     o.t = t_in[v];
     o.begin_ctrl(sample_rate, color_p.get(v));
     {
+        // two batches of 16 rows: one is consumed while the next is in flight (named arrays, ping-pong by two: a rotation over
+        // an array of arrays ended up in scratch memory and was slower than no overlap at all)
         const float *fp = freq_b.p + (size_t)start * freq_b.stride + v;
-        uint32_t i = start;
-        for (; i + 16 <= f0; i += 16, fp += 16 * freq_b.stride) {       // 16 rows in flight
-            float x[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp[(size_t)k * freq_b.stride];
+        const size_t st16 = 16 * (size_t)freq_b.stride;
+        auto eat = [&](const float (&x)[16]) ZH_INLINE_LAMBDA {
 #pragma unroll
             for (int k = 0; k < 16; k++) o.t += QUOT ? x[k] : x[k] / sample_rate;   // frame_ctrl's step (TriSawOsc.zig:151)
+        };
+        uint32_t i = start;
+        if (i + 16 <= f0) {
+            float xa[16], xb[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) xa[k] = fp[(size_t)k * freq_b.stride];
+            fp += st16; i += 16;
+            for (; i + 32 <= f0; i += 32, fp += 2 * st16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) xb[k] = fp[(size_t)k * freq_b.stride];
+                eat(xa);
+#pragma unroll
+                for (int k = 0; k < 16; k++) xa[k] = (fp + st16)[(size_t)k * freq_b.stride];
+                eat(xb);
+            }
+            if (i + 16 <= f0) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) xb[k] = fp[(size_t)k * freq_b.stride];
+                eat(xa);
+                eat(xb);
+                fp += st16; i += 16;
+            } else eat(xa);
         }
         for (; i < f0; i++, fp += freq_b.stride) o.t += QUOT ? *fp : *fp / sample_rate;
     }
