@@ -70,23 +70,8 @@ __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__
     o.t = t_in[v];
     o.begin(sample_rate, FB ? 0.0f : freq.c.get(v));
     if (FB) {
-        const float *fp = freq.b.p + (size_t)start * freq.b.stride + v;
-        uint32_t i = start;
-        for (; i + 32 <= f0; i += 32, fp += 32 * freq.b.stride) {                 // 32 rows in flight: the replay is load-latency-bound otherwise
-            float x[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) x[k] = fp[(size_t)k * freq.b.stride];
-#pragma unroll
-            for (int k = 0; k < 32; k++) o.t += x[k] * o.inv_sr;                  // SineOsc.zig:73 / :83
-        }
-        for (; i + 8 <= f0; i += 8, fp += 8 * freq.b.stride) {
-            float x[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = fp[(size_t)k * freq.b.stride];
-#pragma unroll
-            for (int k = 0; k < 8; k++) o.t += x[k] * o.inv_sr;
-        }
-        for (; i < f0; i++, fp += freq.b.stride) o.t += *fp * o.inv_sr;
+        replay_rows(freq.b.p + (size_t)start * freq.b.stride + v, freq.b.stride, f0 - start,
+                    [&](float x) ZH_INLINE_LAMBDA { o.t += x * o.inv_sr; });                // SineOsc.zig:73 / :83
     } else {
         // (ranges start at multiples of 8 frames from the span start: eight dependent adds per loop round)
         uint32_t i = start;

@@ -400,39 +400,8 @@ __global__ void __launch_bounds__(kSeqBlock) k_trisawosc_ctrl(const float *__res
     TriSawOscLane o;
     o.t = t_in[v];
     o.begin_ctrl(sample_rate, color_p.get(v));
-    {
-        // two batches of 16 rows: one is consumed while the next is in flight (named arrays, ping-pong by two: a rotation over
-        // an array of arrays ended up in scratch memory and was slower than no overlap at all)
-        const float *fp = freq_b.p + (size_t)start * freq_b.stride + v;
-        const size_t st16 = 16 * (size_t)freq_b.stride;
-        auto eat = [&](const float (&x)[16]) ZH_INLINE_LAMBDA {
-#pragma unroll
-            for (int k = 0; k < 16; k++) o.t += QUOT ? x[k] : x[k] / sample_rate;   // frame_ctrl's step (TriSawOsc.zig:151)
-        };
-        uint32_t i = start;
-        if (i + 16 <= f0) {
-            float xa[16], xb[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) xa[k] = fp[(size_t)k * freq_b.stride];
-            fp += st16; i += 16;
-            for (; i + 32 <= f0; i += 32, fp += 2 * st16) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) xb[k] = fp[(size_t)k * freq_b.stride];
-                eat(xa);
-#pragma unroll
-                for (int k = 0; k < 16; k++) xa[k] = (fp + st16)[(size_t)k * freq_b.stride];
-                eat(xb);
-            }
-            if (i + 16 <= f0) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) xb[k] = fp[(size_t)k * freq_b.stride];
-                eat(xa);
-                eat(xb);
-                fp += st16; i += 16;
-            } else eat(xa);
-        }
-        for (; i < f0; i++, fp += freq_b.stride) o.t += QUOT ? *fp : *fp / sample_rate;
-    }
+    replay_rows(freq_b.p + (size_t)start * freq_b.stride + v, freq_b.stride, f0 - start,
+                [&](float x) ZH_INLINE_LAMBDA { o.t += QUOT ? x : x / sample_rate; });   // frame_ctrl's step (TriSawOsc.zig:151)
     const float *ins[1] = {freq_b.p};
     const size_t istr[1] = {freq_b.stride};
     frame_loop<8, ZF, 1>(out.p, v, out.stride, ins, istr, f0, f1, [&](uint32_t, const float (&x)[1], float &val) ZH_INLINE_LAMBDA {

@@ -167,6 +167,45 @@ __device__ __forceinline__ void frame_loop_gen(float *__restrict__ out, uint32_t
     }
 }
 
+// A frame-range kernel's replay over an input image: consume(x) for rows 0 .. count-1 of one voice column, in order.  Two
+// batches of 16 rows: one is consumed while the next is in flight (two NAMED arrays, ping-pong by two -- a rotation over an
+// array of arrays ended up in scratch memory and was slower than no overlap at all).
+template <class C>
+__device__ __forceinline__ void replay_rows(const float *__restrict__ fp, size_t stride, uint32_t count, C &&consume) {
+    constexpr int B = 16;
+    const size_t stb = B * stride;
+    uint32_t i = 0;
+    if (count >= (uint32_t)B) {
+        float xa[B], xb[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) xa[k] = fp[(size_t)k * stride];
+        fp += stb; i = B;
+        for (; i + 2 * B <= count; i += 2 * B, fp += 2 * stb) {
+#pragma unroll
+            for (int k = 0; k < B; k++) xb[k] = fp[(size_t)k * stride];
+#pragma unroll
+            for (int k = 0; k < B; k++) consume(xa[k]);
+#pragma unroll
+            for (int k = 0; k < B; k++) xa[k] = (fp + stb)[(size_t)k * stride];
+#pragma unroll
+            for (int k = 0; k < B; k++) consume(xb[k]);
+        }
+        if (i + B <= count) {
+#pragma unroll
+            for (int k = 0; k < B; k++) xb[k] = fp[(size_t)k * stride];
+#pragma unroll
+            for (int k = 0; k < B; k++) consume(xa[k]);
+#pragma unroll
+            for (int k = 0; k < B; k++) consume(xb[k]);
+            fp += stb; i += B;
+        } else {
+#pragma unroll
+            for (int k = 0; k < B; k++) consume(xa[k]);
+        }
+    }
+    for (; i < count; i++, fp += stride) consume(*fp);
+}
+
 // zero the span of one voice column (used when a ZERO_FIRST paint paints nothing)
 __device__ __forceinline__ void zero_column(float *__restrict__ out, size_t ostride, uint32_t start, uint32_t end) {
     for (uint32_t i = start; i < end; i++) out[(size_t)i * ostride] = 0.0f;
