@@ -597,6 +597,36 @@ def test_decimator_bitexact(ctx, oracle, replay_form):
     util.assert_bitexact(st["dcount"].astype(np.float32), rs[:, 1].copy(), "dcount")
 
 
+def test_decimator_unusual_states(ctx, oracle, replay_form):
+    """States the module never produces itself (set through set_state): dcount above 1, negative, huge -- the frame-range
+    replay's one-instruction wrap (dc - floor(dc)) does not apply and the wave takes the reference's compare-and-subtract."""
+    from zang_amd import modules as mod, zang
+    V = 96
+    rng = np.random.default_rng(74)
+    fake = rng.uniform(300, 47000, V).astype(np.float32)
+    dcount0 = rng.uniform(0, 1, V).astype(np.float32)
+    dcount0[:8] = [5.0, -3.0, 1.0, 0.0, 2.5, 1.0e6, -0.25, 1.5]
+    dval0 = rng.uniform(-1, 1, V).astype(np.float32)
+    inp = util.rng_buffers(75, V, F); out0 = util.rng_buffers(76, V, F)
+    L = oracle.lib()
+    ref = out0.copy(); rs = np.zeros((V, 2), np.float32)
+    for v in range(V):
+        st = oracle.Decimator(); L.zo_decimator_init(C.byref(st)); st.dval = float(dval0[v]); st.dcount = float(dcount0[v])
+        for (s, e) in [(0, 1024), (100, 700)]:
+            L.zo_decimator_paint(C.byref(st), s, e, oracle.fptr(ref[v]), SR, oracle.fptr(inp[v]), float(fake[v]))
+        rs[v] = (st.dval, st.dcount)
+    m = mod.Decimator(V, ctx)
+    st = m.state(); st["dval"] = dval0; st["dcount"] = dcount0; m.set_state(st)
+    out = util.to_image(out0); gi = util.to_image(inp); gf = util.dev(fake)
+    for (s, e) in [(0, 1024), (100, 700)]:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(SR, gi, gf))
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "decimator, unusual states")
+    st = m.state()
+    util.assert_bitexact(st["dval"].astype(np.float32), rs[:, 0].copy(), "dval")
+    util.assert_bitexact(st["dcount"].astype(np.float32), rs[:, 1].copy(), "dcount")
+
+
 # ------------------------------------------------------------------ Distortion
 @pytest.mark.parametrize("dtype_", [0, 1])
 def test_distortion(ctx, oracle, dtype_):

@@ -679,11 +679,20 @@ __global__ void __launch_bounds__(64) k_decimator_ranges(const float *__restrict
         const float dcount0 = o.dcount;
         uint32_t last = 0xFFFFFFFFu;
         uint32_t i = start;
-        for (; i + 8 <= f0; i += 8) {
+        if (__builtin_amdgcn_ballot_w64(!o.walk_is_plain()) == 0) {   // (wave-uniform) every state the module produces itself
+            uint32_t idx = start;
+            for (; i + 8 <= f0; i += 8) {
 #pragma unroll
-            for (uint32_t q = 0; q < 8; q++) o.step(i + q, last);
+                for (uint32_t q = 0; q < 8; q++) o.step_plain(idx, last);
+            }
+            for (; i < f0; i++) o.step_plain(idx, last);
+        } else {
+            for (; i + 8 <= f0; i += 8) {
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) o.step(i + q, last);
+            }
+            for (; i < f0; i++) o.step(i, last);
         }
-        for (; i < f0; i++) o.step(i, last);
         const float held = *input.at(last == 0xFFFFFFFFu ? start : last, v);
         if (o.mode == 1) { if (last != 0xFFFFFFFFu) o.dval = held; } else o.dcount = dcount0;
     }

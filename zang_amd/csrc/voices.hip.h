@@ -214,6 +214,16 @@ struct DecimatorLane {
         dcount = trig ? dc - 1.0f : dc;
         last = trig ? i : last;
     }
+    // step() for 0 <= dcount <= 1 and 0 < ratio < 1 (every state the module itself produces): then dcount + ratio is below 2 and
+    // `dc >= 1 ? dc - 1 : dc` is dc - floor(dc), one v_fract_f32 (exact: the subtraction of 1 from a value in [1, 2) is); the
+    // frame index rides in a VGPR so that the whole step is five VALU instructions and no scalar ones
+    __device__ __forceinline__ bool walk_is_plain() const { return mode != 1 || (dcount >= 0.0f && dcount <= 1.0f && ratio > 0.0f && ratio < 1.0f); }
+    __device__ __forceinline__ void step_plain(uint32_t &idx, uint32_t &last) {
+        const float dc = dcount + ratio;
+        last = dc >= 1.0f ? idx : last;
+        dcount = __builtin_amdgcn_fractf(dc);
+        idx += 1;
+    }
     __device__ __forceinline__ void end() {
         if (mode == 0) { dval = 0.0f; dcount = 1.0f; }                // :37-38
     }
