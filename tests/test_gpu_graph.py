@@ -78,11 +78,12 @@ def test_bench_workload_last_image_matches_oracle(ctx, oracle):
     util.assert_bitexact(got[::16], ref[::16], "bench step after 12 buffers")
 
 
-@pytest.mark.parametrize("kind", ["pulse", "trisaw"])
+@pytest.mark.parametrize("kind", ["pulse", "trisaw", "envelope", "decimator", "curve", "portamento", "cycle", "pmosc", "sampler"])
 def test_graph_with_odd_paint_count_and_eager_paints_between(ctx, kind):
-    """The chunked oscillators flip a double-buffered phase counter on the host at every paint.  A graph holding an
-    ODD number of paints, replayed back to back and mixed with eager paints, must still continue the phase exactly
-    (zh_graph_launch reconciles the buffers; ADVICE r1 osc.hip:356)."""
+    """The chunked oscillators -- and every module whose frame-range form writes its end state into the other half of a double
+    buffer (1-6 words per voice) -- flip on the host at every such paint.  A graph holding an ODD number of paints, replayed
+    back to back and mixed with eager paints, must still continue the state exactly (zh_graph_launch reconciles the
+    buffers; ADVICE r1 osc.hip:356)."""
     import torch
     import zang_amd
     from zang_amd import modules as mod, zang, workloads
@@ -92,22 +93,47 @@ def test_graph_with_odd_paint_count_and_eager_paints_between(ctx, kind):
     with torch.cuda.stream(side):
         c2 = zang_amd.Context(0)
         fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
-        M = mod.PulseOsc if kind == "pulse" else mod.TriSawOsc
-        me, mg = M(V, c2), M(V, c2)
         sp = zang.Span(0, F)
-        P = me.Params(SR, zang.constant(fr), col)
+        inp = c2.image(F, V); inp.uniform_(-1.0, 1.0)
+        crv = torch.tensor([[0.0, 0.0], [1.0, 0.02], [0.3, 0.07], [0.8, 0.11], [0.0, 0.3]], dtype=torch.float32, device="cuda")
+        pcm = torch.from_numpy(np.random.default_rng(2).integers(-20000, 20000, 5000, dtype=np.int16).view(np.uint8).copy()).cuda()
+        rel = torch.full((V,), 0.3, dtype=torch.float32, device="cuda")
+        make = {"pulse": lambda: mod.PulseOsc(V, c2), "trisaw": lambda: mod.TriSawOsc(V, c2), "envelope": lambda: mod.Envelope(V, c2),
+                "decimator": lambda: mod.Decimator(V, c2), "curve": lambda: mod.Curve(V, c2), "portamento": lambda: mod.Portamento(V, c2),
+                "cycle": lambda: mod.Cycle(V, c2), "pmosc": lambda: mod.PMOscInstrument(V, rel, c2), "sampler": lambda: mod.Sampler(V, c2)}[kind]
+        me, mg = make(), make()
+
+        def paint_one(m, o, n):
+            """one paint (the same params at every position: a graph bakes them in and is replayed at several)"""
+            if kind in ("pulse", "trisaw"):
+                m.paint(sp, [o], [], False, m.Params(SR, zang.constant(fr), col), zero_first=True)
+            elif kind == "envelope":
+                m.paint(sp, [o], [], False, m.Params(SR, zang.PaintCurve.cubed(0.03), zang.PaintCurve.cubed(0.12), zang.PaintCurve.cubed(0.04), 0.6, True), zero_first=True)
+            elif kind == "decimator":
+                m.paint(sp, [o], [], False, m.Params(SR, inp, fr * 4.0), zero_first=True)
+            elif kind == "curve":
+                m.paint(sp, [o], [], False, m.Params(SR, m.smoothstep, crv), zero_first=True)
+            elif kind == "portamento":
+                m.paint(sp, [o], [], False, m.Params(SR, zang.PaintCurve.squared(0.2), fr, True, True), zero_first=True)
+            elif kind == "cycle":
+                m.paint(sp, [o], [], False, m.Params(SR, zang.constant(3.0)), zero_first=True)
+            elif kind == "pmosc":
+                m.paint(sp, [o], None, False, m.Params(SR, fr, True), zero_first=True)
+            else:
+                m.paint(sp, [o], [], False, m.Params(SR * 0.9, m.Sample(1, 44100, m.signed16_lsb, pcm), 0, True), zero_first=True)
+
         n_total = 1 + 3 + 3 + 1 + 3 + 2 + 3
         imgs_e = [c2.image(F, V) for _ in range(n_total)]
         imgs_g = [c2.image(F, V) for _ in range(n_total)]
-        for o in imgs_e:
-            me.paint(sp, [o], [], False, P, zero_first=True)
+        for n, o in enumerate(imgs_e):
+            paint_one(me, o, n)
         # graph side: images are baked into the graph, so replays overwrite the same three; copy them out after each
         ring = [c2.image(F, V) for _ in range(3)]
         k = 0
         def eager(n):
             nonlocal k
             for _ in range(n):
-                mg.paint(sp, [imgs_g[k]], [], False, P, zero_first=True); k += 1
+                paint_one(mg, imgs_g[k], k); k += 1
         def replay(g):
             nonlocal k
             g.launch()
@@ -115,13 +141,14 @@ def test_graph_with_odd_paint_count_and_eager_paints_between(ctx, kind):
                 imgs_g[k].copy_(o); k += 1
         eager(1)
         c2.sync()
-        g = c2.capture(lambda: [mg.paint(sp, [o], [], False, P, zero_first=True) for o in ring])   # 3 paints: odd
+        g = c2.capture(lambda: [paint_one(mg, o, 0) for o in ring])   # 3 paints: odd
         replay(g); replay(g); eager(1); replay(g); eager(2); replay(g)
         c2.sync()
         assert k == n_total
         for i, (a, b) in enumerate(zip(imgs_e, imgs_g)):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{kind}: buffer {i} differs"
-        assert np.array_equal(me.state(), mg.state())
+        se, sg = me.state(), mg.state()
+        assert se.tobytes() == sg.tobytes()
         g.close(); c2.close()
 
 
