@@ -89,7 +89,26 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
         // the sequential walk => same state => same bits.
         const uint32_t ch = zs_range_frames(end - start, gridDim.y);
         const uint32_t f0 = min(start + blockIdx.y * ch, end), f1 = min(f0 + ch, end);
-        for (uint32_t r = start; r < f0; r++) {
+        uint32_t r = start;
+        for (; r + CH <= f0; r += CH) {                               // CH frames' input rows requested together, then their bodies
+            float xr[NI][CH];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) {
+                const zh_rsrc_t ri = zrow_rsrc(in[j], istride[j], r);
+                const uint32_t irow = (uint32_t)istride[j] * 4u;
+#pragma unroll
+                for (int k = 0; k < CH; k++) xr[j][k] = zrow_load<1>(ri, ivoff[j], k * irow);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float x[NI];
+#pragma unroll
+                for (int j = 0; j < NIN; j++) x[j] = xr[j][k];
+                float o = 0.0f;
+                f(r + k, x, o);
+            }
+        }
+        for (; r < f0; r++) {
             float x[NI];
 #pragma unroll
             for (int j = 0; j < NIN; j++) x[j] = zrow_load<1>(zrow_rsrc(in[j], istride[j], r), ivoff[j], 0);
