@@ -261,7 +261,10 @@ class HipEmitter:
                 pro.append("%s.%s = CurveP{(uint32_t)(%s), %s};" % (o, stage, self.enum_tag(a[stage], enum), self.enum_payload(a[stage])))
             pro.append("%s.begin(%s);" % (o, mc.nic))
             cv, cp = k.fresh("cv"), k.fresh("cp")
-            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.frame(%s);" % (cp, o, cv)]
+            # begin() only in the kernel's prologue (not per delay chunk / track sub-span): the frames a frame range
+            # replays step the clock and the stage ends only (envelope.hip.h frame_walk)
+            step = "frame_s(%s, zs_walk)" % cv if mc.begin_sink is k.pro else "frame(%s)" % cv
+            frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.%s;" % (cp, o, step)]
             painted, value = cp, cv
         elif name == "Gate":
             painted, value = a["note_on"].expr, "1.0f"          # Gate.zig:28-30
@@ -614,7 +617,8 @@ class HipEmitter:
             for j, pi in enumerate(k.rows):
                 out.append(I + "ins[%d] = zs_row(L.p[%d], v, istr[%d], ivo[%d]);" % (j, pi, j, j))
             out += [I + l for l in k.pro]
-            out.append(I + "zs_frame_loop<%d, %d>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0," % (unroll, nin))
+            out.append(I + "bool zs_walk = false; (void)zs_walk;")
+            out.append(I + "zs_frame_loop<%d, %d>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk," % (unroll, nin))
             out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
             out.append(I + I + "(void)i; (void)x;")
             if k.temps:

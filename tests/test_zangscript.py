@@ -631,3 +631,57 @@ def test_gpu_script_kernels_as_frame_ranges(ctx, name, monkeypatch):
         assert torch.equal(img_a.view(torch.int32), img_b.view(torch.int32)), f"{name}: image differs after paint {k}"
         assert np.array_equal(a.get_state(), b.get_state()), f"{name}: state differs after paint {k}"
     prog.close()
+
+
+STAGES_SCRIPT = """
+Stages = defmodule
+    freq: cob,
+    note_on: boolean,
+begin
+    a = Envelope(attack=.cubed(0.01), decay=.cubed(0.02), release=.cubed(0.03), sustain_volume=0.5, note_on)
+    b = Envelope(attack=.linear(0.004), decay=.squared(0.05), release=.instantaneous, sustain_volume=0.25, note_on)
+    c = Envelope(attack=.instantaneous, decay=.linear(0.015), release=.squared(0.011), sustain_volume=1, note_on)
+    out SineOsc(freq, phase=0) * a + b * 0.5 + c * TriSawOsc(freq, color=0.3)
+end
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranges", [None, "0", "3"])
+def test_gpu_script_envelope_stage_ends_inside_replays(ctx, ranges, monkeypatch):
+    """Three envelopes (one tag-specialised lane, two generic with instantaneous stages) whose stages last 32-400 frames at
+    the 8 kHz this test paints at, over 512-frame paints with notes going on and off between them: a frame-range launch
+    replays the earlier frames with the envelope's state-only step (envelope.hip.h frame_walk), stage ends included.
+    Against the interpreter, voice by voice, image and (through the following paints) state."""
+    import torch
+    from oracle import zs_interp
+    from tests.util import assert_bitexact, from_image, to_image
+    from zang_amd import script, zang
+    if ranges is None:
+        monkeypatch.delenv("ZH_SCRIPT_RANGES", raising=False)
+    else:
+        monkeypatch.setenv("ZH_SCRIPT_RANGES", ranges)
+    nv, nf = 70, 512
+    prog = script.ScriptProgram(STAGES_SCRIPT, ctx, only=["Stages"])
+    mod = prog.module("Stages", nv, 0)
+    assert mod.frame_ranges_ok
+    voices = zs_interp.make_voices(zs.compile(prog.text, prog.filename), "Stages", nv, 0)
+    rng = np.random.default_rng(11)
+    ref = np.zeros((nv, nf), np.float32)
+    img = to_image(ref)
+    order = [p[0] for p in mod.params]
+    on = rng.random(nv) < 0.8
+    for k, (s, e) in enumerate([(0, nf), (0, nf), (100, 420), (0, nf), (0, 130), (130, nf), (0, nf)]):
+        nic = rng.random(nv) < (1.0 if k == 0 else 0.25)
+        prev_on = on
+        on = np.where(rng.random(nv) < 0.35, ~on, on)
+        params = {"sample_rate": 8000.0, "freq": rng.uniform(60, 900, nv).astype(np.float32), "note_on": on}
+        # Envelope.zig:45 asserts against note_on without a new note while releasing: a voice that comes back on is a new note
+        nic = nic | (on & ~prev_on)
+        dev = {kk: _device_value(None, vv) for kk, vv in params.items()}
+        mod.paint(zang.Span(s, e), [img], None, torch.from_numpy(nic.astype(np.uint8)).cuda(), dev)
+        for v in range(nv):
+            voices[v].paint(s, e, ref[v], bool(nic[v]), [_per_voice(params[kk], v) for kk in order])
+        ctx.sync()
+        assert_bitexact(from_image(img), ref, "Stages paint %d" % k)
+    prog.close()

@@ -72,6 +72,19 @@ case("Curve smoothstep, 5 nodes, retrigger every 4", m, _curve)
 m = mod.Cycle(V, ctx); case("Cycle const speed", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(3.0)), zero_first=True))
 m = mod.Portamento(V, ctx); case("Portamento cubed", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.PaintCurve.cubed(0.2), freq, True, True), zero_first=True))
 
+# generated script kernels (tests/golden/script_modules.txt): compiled at run time through hiprtc
+from zang_amd import script as zscript
+_prog = zscript.ScriptProgram(open(os.path.join(ROOT, "tests", "golden", "script_modules.txt")).read(), ctx, only=["Pluck", "CycleSine"])
+on_dev = torch.ones(V, dtype=torch.uint8, device=dev)
+off_dev = torch.zeros(V, dtype=torch.uint8, device=dev)
+m = _prog.module("Pluck", V, 0)
+_pl_k = [0]
+def _pluck(o, m=m):
+    k = _pl_k[0] % 8; _pl_k[0] += 1
+    m.paint(span, [o], None, k == 0, {"sample_rate": SR, "freq": freq, "note_on": on_dev if k < 4 else off_dev}, zero_first=True)
+case("script Pluck (note on 4 buffers / off 4)", m, _pluck)
+m = _prog.module("CycleSine", V, 0); case("script CycleSine (sin of Cycle + phase)", m, lambda o, m=m: m.paint(span, [o], None, False, {"sample_rate": SR, "freq": 3.0, "phase": 0.25}, zero_first=True))
+
 print("# %d voices x %d frames per paint, %d paints per graph, one MI355X" % (V, F, K))
 print("%-46s %10s %12s %10s" % ("module", "us/paint", "v-samples/s", "HBM TB/s"))
 ONLY = os.environ.get("ZH_BENCH_ONLY", "")                  # substring filter on the case names, "|"-separated

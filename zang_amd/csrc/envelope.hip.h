@@ -163,6 +163,33 @@ struct EnvLaneT {
         }
         return painted;
     }
+    // frame() with the value discarded, for a replay that walks several stages (a generated script kernel's frame range,
+    // script_rt.hip.h): the clock and the stage ends as in frame(); last_value, which frame() rewrites every TOWARD frame, is
+    // only brought up to date where the replay reads it -- at a stage end (change_state_if: start = last_value).  Valid where
+    // begin() is not called between the replayed frames (begin() reads last_value too) and a frame() follows the walk before
+    // the state is stored (it rewrites last_value of every TOWARD voice; the others' is untouched by either form).
+    __device__ __forceinline__ void frame_walk() {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        F tn = t + cur_step;
+        const M finished = tn >= f(1.0f);
+        tn = zsel(finished, f(1.0f), tn);
+        t = zsel(toward, tn, t);
+        const M stage_end = zand(toward, finished);
+        if (zany(stage_end)) {
+            last_value = zsel(stage_end, start + curve(tn) * cur_delta, last_value);
+            const U after_attack = zsel(sustain_volume < f(1.0f), u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN));
+            const U next = zsel(state == u(ZH_ENV_ATTACK), after_attack,
+                                zsel(state == u(ZH_ENV_DECAY), u(ZH_ENV_SUSTAIN), u(ZH_ENV_IDLE)));
+            change_state_if(stage_end, next);
+            resolve(stage_end);
+            refresh_derived();
+        }
+    }
+    // frame(), or frame_walk() while `walk` (the flag zs_frame_loop raises over the frames it replays)
+    __device__ __forceinline__ M frame_s(F &val, bool walk) {
+        if (walk) { frame_walk(); return zmask<M>(false); }
+        return frame(val);
+    }
     // frame_loop_gen (seq.hip.h): true = no voice ends a stage within the next n frames.  A TOWARD voice's clock after k
     // steps is at most t + k * step + k half-ulps of 1, so t + (n + 1) * step < 0.999 keeps it below 1 with a wide margin
     // (a NaN or infinite step fails the test and takes the exact path).

@@ -74,10 +74,11 @@ __device__ __forceinline__ float zs_max(float a, float b) { return a > b ? a : b
 __device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b; }
 
 // frame_loop (seq.hip.h) for a body that accumulates into the output sample itself: a script module's
-// paint() may `+=` its output several times per frame.  f(frame, x[NIN], o&); `zf` = ZH_PAINT_ZERO_FIRST.
+// paint() may `+=` its output several times per frame.  f(frame, x[NIN], o&); `zf` = ZH_PAINT_ZERO_FIRST; `walk` is a flag
+// of the caller's that the body reads: true while the frames before a frame range are replayed for their state only.
 template <int CH, int NIN, class F>
 __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t v, size_t ostride, const float *const *in,
-                                              const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, F &&f) {
+                                              const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, bool &walk, F &&f) {
     constexpr int NI = NIN > 0 ? NIN : 1;
     const uint32_t voff = v * 4u;                                   // rows through buffer descriptors: lanes.hip.h (zrow_*)
     const uint32_t orow = (uint32_t)ostride * 4u;
@@ -90,6 +91,7 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
         const uint32_t ch = zs_range_frames(end - start, gridDim.y);
         const uint32_t f0 = min(start + blockIdx.y * ch, end), f1 = min(f0 + ch, end);
         uint32_t r = start;
+        walk = true;                                                  // the body's state-only forms (EnvLaneT::frame_s)
         for (; r + CH <= f0; r += CH) {                               // CH frames' input rows requested together, then their bodies
             float xr[NI][CH];
 #pragma unroll
@@ -115,6 +117,7 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
             float o = 0.0f;
             f(r, x, o);
         }
+        walk = false;
         start = f0; end = f1;
     }
     const uint32_t nfull = (end - start) / CH;

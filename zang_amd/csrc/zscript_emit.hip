@@ -559,7 +559,10 @@ public:
             pro.push_back(o + ".begin(" + mc.nic + ");");
             auto pp = painted_pair();
             frame.push_back("float " + pp.first + " = 0.0f;");
-            frame.push_back("const bool " + pp.second + " = " + o + ".frame(" + pp.first + ");");
+            // begin() only in the kernel's prologue (not per delay chunk / track sub-span): the frames a frame range
+            // replays step the clock and the stage ends only (envelope.hip.h frame_walk)
+            const std::string step = mc.begin_sink == &k.pro ? "frame_s(" + pp.first + ", zs_walk)" : "frame(" + pp.first + ")";
+            frame.push_back("const bool " + pp.second + " = " + o + "." + step + ";");
             painted = pp.second; value = pp.first;
         } else if (name == "Gate") {
             painted = a["note_on"].expr; value = "1.0f";                                          // Gate.zig:28-30
@@ -981,7 +984,8 @@ public:
             out.push_back(I + strf("uint32_t ivo[%zu] = {", ni) + zeros + "};");
             for (size_t j = 0; j < k.rows.size(); j++) out.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu], ivo[%zu]);", j, k.rows[j], j, j));
             append(out, indent(k.pro));
-            out.push_back(I + strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0,", unroll, nin));
+            out.push_back(I + "bool zs_walk = false; (void)zs_walk;");
+            out.push_back(I + strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk,", unroll, nin));
             out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
             out.push_back(I + I + "(void)i; (void)x;");
             if (!k.temps.empty()) {
