@@ -371,3 +371,54 @@ def test_nice_single_wave_form_is_bit_identical():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "6 passed" in r.stdout
+
+
+@pytest.mark.parametrize("form", ["default", "three_waves", "one_wave"])
+def test_nice_with_non_finite_and_huge_filter_states(ctx, oracle, form, monkeypatch):
+    """The low-pass mix into the zeroed temp is computed as `0 + (l + b*0)` (dsp.hip.h svf_lowpass_into_zero): voices whose
+    filter state is infinite, NaN, huge (overflowing inside the step), denormal or a signed zero must still give what the
+    reference's `l*1 + b*0 + h*0` gives -- NaN where it gives NaN (payloads aside), the same bits everywhere else --
+    in every kernel form, and in the mixdown form."""
+    from zang_amd import modules as mod, zang, workloads
+    if form == "three_waves":
+        monkeypatch.setenv("ZH_NICE_PC4_MAX", "0")
+    elif form == "one_wave":
+        monkeypatch.setenv("ZH_NICE_PC_MAX", "0")
+    V = 200
+    freq, color, _, _ = workloads.voice_params(5, 9, V)
+    L = oracle.lib()
+    st = [oracle.NiceInstrument() for _ in range(V)]
+    for v in range(V):
+        L.zo_nice_init(C.byref(st[v]), float(color[v]))
+    vals = [np.inf, -np.inf, np.nan, 3.0e38, -3.0e38, 1e-45, -0.0, 0.0, 1e30, -1e25]
+    for i, v in enumerate(range(3, V, 7)):
+        st[v].flt.l = vals[i % len(vals)]
+        st[v].flt.b = vals[(i // 3 + 1) % len(vals)]
+    m = mod.NiceInstrument(V, util.dev(color), ctx)
+    gs = m.state()
+    for v in range(V):
+        gs["flt"]["l"][v] = st[v].flt.l
+        gs["flt"]["b"][v] = st[v].flt.b
+    m.set_state(gs)
+    gf = util.dev(freq)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+
+    def same(got, ref, what):
+        ng, nr = np.isnan(got), np.isnan(ref)
+        assert np.array_equal(ng, nr), what + ": NaN positions"
+        assert np.array_equal(got[~ng].view(np.uint32), ref[~nr].view(np.uint32)), what
+        return int(nr.sum())
+
+    nans = 0
+    for k, ((s, e), on, nic) in enumerate([((0, 1024), 1, 1), ((0, 700), 1, 0), ((700, 1024), 0, 0)]):
+        ref = np.zeros((V, F), np.float32)
+        for v in range(V):
+            L.zo_nice_paint(C.byref(st[v]), s, e, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1), nic, SR, float(freq[v]), on)
+        out = ctx.image(F, V, fill=0.0)
+        m.paint(zang.Span(s, e), [out], None, bool(nic), m.Params(SR, gf, bool(on)))
+        ctx.sync()
+        nans += same(util.from_image(out), ref, f"nice {form} paint {k}")
+        g2 = m.state()
+        same(g2["flt"]["l"].astype(np.float32), np.array([r.flt.l for r in st], np.float32), "flt.l")
+        same(g2["flt"]["b"].astype(np.float32), np.array([r.flt.b for r in st], np.float32), "flt.b")
+    assert nans > 1000

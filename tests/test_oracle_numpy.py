@@ -269,3 +269,41 @@ def test_curve_linear_matches_closed_form(oracle):
         assert out[f0] == np.float32(v0)
     assert not out[960:].any()                      # after the last node: silent gap (:238-244)
     assert (st.current_song_note, st.next_song_note, st.current_song_note_offset) == (3, 4, -1024)      # :175,:181: offset is reset to 0 on advance, then -= out_len
+
+
+def test_lowpass_mix_into_a_zeroed_temp_in_three_operations():
+    """dsp.hip.h svf_lowpass_into_zero: `0 + (l*1 + b*0 + h*0)` (Filter.zig:146 with the low-pass multipliers, added into a
+    zeroed temp as NiceInstrument and FilteredEchoes do) equals `0 + (l + b*0)` bit for bit for every (l, b, h) that a
+    filter step (Filter.zig:135-144) can leave behind -- vectorised numpy float32 over random and extreme states, inputs
+    and coefficients: zeros of both signs, denormals, huge values that overflow inside the step, infinities, NaNs."""
+    rng = np.random.default_rng(5)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 1.0, -1.0, 3e38, -3e38, 3.4028235e38, -3.4028235e38,
+                        np.inf, -np.inf, np.nan, 1e19, -1e19, 1e30, -1e30], np.float32)
+    n = 400000
+
+    def draw():
+        x = rng.uniform(-2, 2, n).astype(np.float32)
+        x = np.where(rng.random(n) < 0.15, x * f32(1e37), x)
+        pick = rng.random(n) < 0.35
+        return np.where(pick, special[rng.integers(0, len(special), n)], x).astype(np.float32)
+
+    l, b, x = draw(), draw(), draw()
+    cut = np.where(rng.random(n) < 0.2, rng.choice(np.array([0.0, 1.0], np.float32), n), rng.uniform(0, 1, n)).astype(np.float32)
+    res = np.where(rng.random(n) < 0.2, rng.choice(np.array([0.0, 1.0], np.float32), n), rng.uniform(0, 1, n)).astype(np.float32)
+    dc = f32(3.814697265625e-6)
+    zero = f32(0.0)
+    with np.errstate(all="ignore"):
+        for _ in range(4):                                              # a few steps: states the recurrence itself produces
+            inp = x + dc
+            l = l + cut * b - dc
+            b = b + cut * (inp - b * res - l)
+            l = l + cut * b
+            h = inp - b * res - l
+            b = b + cut * h
+            six = zero + (l * f32(1.0) + b * f32(0.0) + h * f32(0.0))
+            three = zero + (l + b * f32(0.0))
+            nan6, nan3 = np.isnan(six), np.isnan(three)
+            assert np.array_equal(nan6, nan3)
+            assert np.array_equal(six[~nan6].view(np.uint32), three[~nan3].view(np.uint32))
+            assert nan6.any() and (six == 0).any() and np.isinf(l[~np.isnan(l)]).any()   # the corners are really visited
+            x = draw()

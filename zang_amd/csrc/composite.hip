@@ -104,10 +104,9 @@ struct NiceLaneT {
     // tail = two chains that never read each other's state: the filter over the oscillator samples and
     // the envelope; their product is the value added to out.
     __device__ __forceinline__ F tail_filter(F t0) {
-        const F zero = zsplat<F>(0.0f);
         // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
         const SvfOutT<F> s = svf_step(l, b, t0, cut, res);
-        return zero + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);
+        return svf_lowpass_into_zero(s.l, s.b);
     }
     __device__ __forceinline__ F tail_env() { return env.frame_masked(); }   // temps[0] = 0 (+ envelope)
     __device__ __forceinline__ F tail(F t0) {
@@ -320,7 +319,7 @@ __global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t s
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t start, uint32_t end) {
     constexpr uint32_t CH = 32;
-    __shared__ float in_t[2][CH][64], env_t[3][CH][64], lbh_t[2][3][CH][64];
+    __shared__ float in_t[2][CH][64], env_t[3][CH][64], lb_t[2][2][CH][64];
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 oscillator, 1 envelope, 2 filter, 3 writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < a.V;
@@ -365,10 +364,10 @@ __global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t 
         } else if (role == 2 && c > 0 && c <= nchunks) {
             const uint32_t d = c - 1, nf = min(CH, n_frames - d * CH);
             const float (*ti)[64] = in_t[d & 1];
-            float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
+            float (*tl)[64] = lb_t[d & 1][0], (*tb)[64] = lb_t[d & 1][1];
             auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
                 const SvfOut s = svf_core(n.l, n.b, in, n.cut, n.res);
-                tl[k][lane] = s.l; tb[k][lane] = s.b; th[k][lane] = s.h;
+                tl[k][lane] = s.l; tb[k][lane] = s.b;                          // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
             };
             if (nf == CH) {
                 float x[CH];
@@ -382,20 +381,20 @@ __global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t 
         } else if (role == 3 && c > 1) {
             const uint32_t d = c - 2, nf = min(CH, n_frames - d * CH);
             const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
-            const float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
+            const float (*tl)[64] = lb_t[d & 1][0], (*tb)[64] = lb_t[d & 1][1];
             const float (*te)[64] = env_t[d % 3];
-            auto one = [&](uint32_t k, float l, float b, float h, float e0, float o) ZH_INLINE_LAMBDA {
-                const float t1 = 0.0f + (l * 1.0f + b * 0.0f + h * 0.0f);      // NiceLane::tail_filter's mix
+            auto one = [&](uint32_t k, float l, float b, float e0, float o) ZH_INLINE_LAMBDA {
+                const float t1 = svf_lowpass_into_zero(l, b);                  // NiceLane::tail_filter's mix
                 zrow_store<1>(ro, voff, k * orow, o + e0 * t1);                // multiply :246: out += temps[0]*temps[1]
             };
             if (nf == CH) {
-                float xl[CH], xb[CH], xh[CH], xe[CH], oc[CH];
+                float xl[CH], xb[CH], xe[CH], oc[CH];
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; xe[k] = te[k][lane]; oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow); }
+                for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xe[k] = te[k][lane]; oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow); }
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], xe[k], oc[k]);
+                for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xe[k], oc[k]);
             } else {
-                for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], te[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], te[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
             }
         }
         __syncthreads();
@@ -765,7 +764,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc_spans(PMOscArgs a, SpanTabl
 // bits.  Sub-span semantics as in span_walk.
 template <bool ZF>
 __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP tb, Img out, uint32_t start, uint32_t end) {
-    __shared__ float walk_s[64], svf_l[64], svf_b[64], svf_h[64];
+    __shared__ float walk_s[64], svf_l[64], svf_b[64];
     const uint32_t v = blockIdx.x, lane = threadIdx.x;
     NiceLane n;
     n.cnt = a.cnt[v]; n.l = a.fl[v]; n.b = a.fb[v];
@@ -797,7 +796,7 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
             const float in_mine = t0_mine + kSvfDcOffset;      // Filter.zig:135
             auto step = [&](uint32_t j) ZH_INLINE_LAMBDA {
                 const SvfOut s = svf_core(n.l, n.b, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in_mine), (int)j)), n.cut, n.res);
-                svf_l[j] = s.l; svf_b[j] = s.b; svf_h[j] = s.h;
+                svf_l[j] = s.l; svf_b[j] = s.b;
             };
             uint32_t j = 0;
             for (; j + 8 <= nf; j += 8) {
@@ -806,7 +805,7 @@ __global__ void __launch_bounds__(64) k_nice_spans_wave(NiceArgs a, SpanTableP t
             }
             for (; j < nf; j++) step(j);
             if (lane < nf) {
-                const float t1 = 0.0f + (svf_l[lane] * 1.0f + svf_b[lane] * 0.0f + svf_h[lane] * 0.0f);   // temps[1] = 0 + low-pass
+                const float t1 = svf_lowpass_into_zero(svf_l[lane], svf_b[lane]);   // temps[1] = 0 + low-pass
                 float *o = col + (size_t)(f0 + lane) * os;
                 *o = (ZF ? 0.0f : *o) + e0 * t1;               // multiply :246: out += temps[0]*temps[1]
             }

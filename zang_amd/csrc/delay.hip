@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, flo
         t0 = t0 * feedback;                                           // multiplyWithScalar (:433)
         t0 = t0 + x;                                                  // addInto (:436)
         const SvfOut s = svf_step(l, b, t0, cut, res);                // Filter.paint low_pass (Filter.zig:135-146)
-        return 0.0f + (s.l * 1.0f + s.b * 0.0f + s.h * 0.0f);         // zero(temp1); += (:439)
+        return svf_lowpass_into_zero(s.l, s.b);                       // zero(temp1); += (:439)
     };
     uint32_t i = start;
     if constexpr (CH > 1)                                             // CH == 1: only the frame-by-frame loop below, in the reference's order
@@ -209,7 +209,7 @@ template <bool ZF>
 __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float *__restrict__ l_io, float *__restrict__ b_io, Img out, CImg input,
                                                             uint32_t start, uint32_t end, F32P feedback_p, F32P cutoff_p) {
     constexpr uint32_t CH = 32;
-    __shared__ float in_t[2][CH][64], lbh_t[2][3][CH][64];
+    __shared__ float in_t[2][CH][64], lb_t[2][2][CH][64];
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < d.n;
@@ -276,10 +276,10 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
         } else if (role == 1 && c > 0 && c <= nchunks) {
             const uint32_t dd = c - 1, nf = frames(dd);
             const float (*ti)[64] = in_t[dd & 1];
-            float (*tl)[64] = lbh_t[dd & 1][0], (*tb)[64] = lbh_t[dd & 1][1], (*th)[64] = lbh_t[dd & 1][2];
+            float (*tl)[64] = lb_t[dd & 1][0], (*tb)[64] = lb_t[dd & 1][1];
             auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
                 const SvfOut sv = svf_core(l, b, in, cut, res);
-                tl[k][lane] = sv.l; tb[k][lane] = sv.b; th[k][lane] = sv.h;
+                tl[k][lane] = sv.l; tb[k][lane] = sv.b;                        // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
             };
             if (nf == CH) {
                 float x[CH];
@@ -293,11 +293,11 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
         } else if (role == 2) {
             if (c > 1) {
                 const uint32_t dd = c - 2, nf = frames(dd);
-                const float (*tl)[64] = lbh_t[dd & 1][0], (*tb)[64] = lbh_t[dd & 1][1], (*th)[64] = lbh_t[dd & 1][2];
+                const float (*tl)[64] = lb_t[dd & 1][0], (*tb)[64] = lb_t[dd & 1][1];
                 float *op = out.at(start + dd * CH, vc);
                 uint32_t sl = slot_of(dd * CH);
-                auto one = [&](uint32_t k, float fl, float fb, float fh, float base) ZH_INLINE_LAMBDA {
-                    const float t1 = 0.0f + (fl * 1.0f + fb * 0.0f + fh * 0.0f);    // zero(temp1); += low-pass (:439, Filter.zig:146)
+                auto one = [&](uint32_t k, float fl, float fb, float base) ZH_INLINE_LAMBDA {
+                    const float t1 = svf_lowpass_into_zero(fl, fb);   // zero(temp1); += low-pass (:439, Filter.zig:146)
                     if (live) {
                         op[(size_t)k * out.stride] = base + t1;       // addInto(output, temp1) (:448)
                         ring[(size_t)sl * d.n] = t1;                  // writeDelayBuffer(temp1) (:452)
@@ -305,15 +305,15 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
                     sl = sl + 1 == D ? 0 : sl + 1;
                 };
                 if (nf == CH) {
-                    float xl[CH], xb[CH], xh[CH];
+                    float xl[CH], xb[CH];
 #pragma unroll
-                    for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; }
+                    for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; }
                     if (rows_ok(dd)) {
                         const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + dd * CH);
                         const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, (uint32_t)__builtin_amdgcn_readfirstlane((int)sl));
 #pragma unroll
                         for (uint32_t k = 0; k < CH; k++) {
-                            const float t1 = 0.0f + (xl[k] * 1.0f + xb[k] * 0.0f + xh[k] * 0.0f);   // as in one()
+                            const float t1 = svf_lowpass_into_zero(xl[k], xb[k]);   // as in one()
                             if (live) {
                                 zrow_store<1>(ro, voff, k * orow, (ZF ? 0.0f : bn[k]) + t1);
                                 zrow_store<1>(rr, voff, k * rrow, t1);
@@ -321,10 +321,10 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
                         }
                     } else {
 #pragma unroll
-                        for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], ZF ? 0.0f : bn[k]);
+                        for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], ZF ? 0.0f : bn[k]);
                     }
                 } else {
-                    for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], ZF ? 0.0f : op[(size_t)k * out.stride]);
+                    for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], ZF ? 0.0f : op[(size_t)k * out.stride]);
                 }
             }
             if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step

@@ -125,6 +125,14 @@ template <class F>
 __device__ __forceinline__ SvfOutT<F> svf_step(F &l, F &b, F input, F cut, F res) {
     return svf_core(l, b, input + kSvfDcOffset, cut, res);
 }
+// `0 + (l * 1 + b * 0 + h * 0)`: the low-pass mix (Filter.zig:98-109, 146: l_mul = 1, b_mul = h_mul = 0) added into a ZEROED temp,
+// as the composites do (examples/modules.zig:229-236, 439) -- in three operations instead of six, same bits for every input:
+// l * 1 is l.  After a step h is non-finite only if b is (:144 comes last: finite + cut * non-finite is non-finite for every
+// cut in [0, 1], 0 * inf = NaN included), so b * 0 alone decides between a NaN and zeros; with b finite the two products are
+// zeros, l plus zeros of any sign is l for l != 0 (infinities included) and some zero otherwise, and the outer `0 +` turns
+// that zero into +0 whatever its sign.  (Not for a mix added into a live output: there the sign of a zero sum shows.)
+template <class F>
+__device__ __forceinline__ F svf_lowpass_into_zero(F l, F b) { return zsplat<F>(0.0f) + (l + b * 0.0f); }
 
 // ---- Noise (src/modules/Noise.zig:58-66): one sample of Paul Kellett's pink filter -------------
 __device__ __forceinline__ float pink_step(float (&b)[7], float white) {
