@@ -209,7 +209,8 @@ template <bool ZF>
 __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float *__restrict__ l_io, float *__restrict__ b_io, Img out, CImg input,
                                                             uint32_t start, uint32_t end, F32P feedback_p, F32P cutoff_p) {
     constexpr uint32_t CH = 32;
-    __shared__ float in_t[2][CH][64], lb_t[2][2][CH][64];
+    __shared__ float in_t[2][CH][64];
+    __shared__ float2 lb_t[2][CH][64];                                  // (l, b) of a frame side by side: one 8-byte LDS access each way
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < d.n;
@@ -276,10 +277,10 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
         } else if (role == 1 && c > 0 && c <= nchunks) {
             const uint32_t dd = c - 1, nf = frames(dd);
             const float (*ti)[64] = in_t[dd & 1];
-            float (*tl)[64] = lb_t[dd & 1][0], (*tb)[64] = lb_t[dd & 1][1];
+            float2 (*tlb)[64] = lb_t[dd & 1];
             auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
                 const SvfOut sv = svf_core(l, b, in, cut, res);
-                tl[k][lane] = sv.l; tb[k][lane] = sv.b;                        // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
+                tlb[k][lane] = make_float2(sv.l, sv.b);                        // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
             };
             if (nf == CH) {
                 float x[CH];
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
         } else if (role == 2) {
             if (c > 1) {
                 const uint32_t dd = c - 2, nf = frames(dd);
-                const float (*tl)[64] = lb_t[dd & 1][0], (*tb)[64] = lb_t[dd & 1][1];
+                const float2 (*tlb)[64] = lb_t[dd & 1];
                 float *op = out.at(start + dd * CH, vc);
                 uint32_t sl = slot_of(dd * CH);
                 auto one = [&](uint32_t k, float fl, float fb, float base) ZH_INLINE_LAMBDA {
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
                 if (nf == CH) {
                     float xl[CH], xb[CH];
 #pragma unroll
-                    for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; }
+                    for (uint32_t k = 0; k < CH; k++) { const float2 q = tlb[k][lane]; xl[k] = q.x; xb[k] = q.y; }
                     if (rows_ok(dd)) {
                         const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + dd * CH);
                         const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, (uint32_t)__builtin_amdgcn_readfirstlane((int)sl));
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
                         for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], ZF ? 0.0f : bn[k]);
                     }
                 } else {
-                    for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], ZF ? 0.0f : op[(size_t)k * out.stride]);
+                    for (uint32_t k = 0; k < nf; k++) one(k, tlb[k][lane].x, tlb[k][lane].y, ZF ? 0.0f : op[(size_t)k * out.stride]);
                 }
             }
             if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step

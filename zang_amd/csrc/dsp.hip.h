@@ -121,6 +121,26 @@ __device__ __forceinline__ SvfOutT<F> svf_core(F &l, F &b, F in, F cut, F res) {
     b += cut * h;                                                     // :144
     return SvfOutT<F>{l, b, h};
 }
+// svf_core in two parts for the wave pipelines (k_filter_pc): the recurrence wave runs svf_core_mid, which carries (l, b)
+// through the whole step but hands on only l after :142 and b after :139; the writer wave redoes :143-144 from them
+// (svf_finish: the same operations on the same values) for the h and the final b of the output mix.
+template <class F> struct SvfMidT { F l, b1; };
+using SvfMid = SvfMidT<float>;
+template <class F>
+__device__ __forceinline__ SvfMidT<F> svf_core_mid(F &l, F &b, F in, F cut, F res) {
+    l += cut * b - kSvfDcOffset;                                      // :138
+    b += cut * (in - b * res - l);                                    // :139
+    l += cut * b;                                                     // :142
+    const F b1 = b;
+    const F h = in - b * res - l;                                     // :143
+    b += cut * h;                                                     // :144
+    return SvfMidT<F>{l, b1};
+}
+template <class F>
+__device__ __forceinline__ SvfOutT<F> svf_finish(F l, F b1, F in, F cut, F res) {
+    const F h = in - b1 * res - l;                                    // :143
+    return SvfOutT<F>{l, b1 + cut * h, h};                            // :144
+}
 template <class F>
 __device__ __forceinline__ SvfOutT<F> svf_step(F &l, F &b, F input, F cut, F res) {
     return svf_core(l, b, input + kSvfDcOffset, cut, res);

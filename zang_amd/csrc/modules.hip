@@ -399,16 +399,20 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
 }
 
 // Few voices, constant cutoff and resonance: the frame's work spread over THREE waves per 64 voices (the form of
-// composite.hip's k_nice_pc4).  Wave 0 fetches the input rows one tile ahead and adds the filter's input offset
+// composite.hip's k_nice_pc4).  Wave 0 fetches the input rows two tiles ahead and adds the filter's input offset
 // (in = x + fcdcoffset, Filter.zig:135: a function of the sample alone); wave 1 runs the state-variable recurrence alone
-// (svf_core, 15 VALU instructions per sample) and hands (l, b, h) on through LDS; wave 2 does the output mix (:146), the `+=`
-// and the store, two tiles behind the loader.  One barrier per 32-frame tile.  Same operations on the same values as
-// k_filter => same bits.
+// (svf_core_mid, 15 VALU instructions per sample) and hands on l and the b of :139; wave 2 redoes :143-144 from them for h
+// and the final b (svf_finish), then the output mix (:146), the `+=` and the store, three tiles behind the loader.  One
+// barrier per 32-frame tile.  Same operations on the same values as k_filter => same bits.
+// What the recurrence wave costs beyond its 15 instructions is its LDS traffic: alone with its barriers it takes 29 us for
+// 1,024 frames, 34 us with its tile reads and 44 us with three values written per frame as two-dword instructions -- an LDS
+// instruction costs a lone wave about three VALU issues.  Hence tiles of float4 (four frames of a lane side by side: one
+// 16-byte instruction per four frames) and two values per frame instead of three.
 template <bool ZF>
 __global__ void __launch_bounds__(192) k_filter_pc(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out, CImg input,
                                                    uint32_t start, uint32_t end, float l_mul, float b_mul, float h_mul, F32P cutoff, F32P res_p) {
-    constexpr uint32_t CH = 32;
-    __shared__ float in_t[2][CH][64], lbh_t[2][3][CH][64];
+    constexpr uint32_t CH = 32, Q = CH / 4;
+    __shared__ float4 in_q[4][Q][64], l_q[2][Q][64], b_q[2][Q][64];
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < V;
@@ -419,71 +423,117 @@ __global__ void __launch_bounds__(192) k_filter_pc(float *__restrict__ l_io, flo
     o.l = l_io[vc]; o.b = b_io[vc];
     o.begin(ZH_FILTER_LOW_PASS, cutoff.get(vc), res_p.get(vc));        // cut / res (:114, :118); the mix coefficients come from the host
     auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n - c * CH) : 0u; };
-    float xn[CH], bn[CH];                                             // the loader's / the writer's rows of the tile after the one in hand
-    if (role == 0 && frames(0) == CH) {
-        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start);
+    // frame k of this lane inside a tile of float4 (the scalar path of a partial last tile)
+    auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
+    // Step c: the loader publishes tile c (its rows were requested two steps earlier); the filter wave computes tile c - 2
+    // out of registers while it fetches tile c - 1 from LDS for the next step; the writer finishes and stores tile c - 3.
+    // Every role runs its own copy of the step loop (the same number of barriers in each): as branches of one loop body the
+    // roles' register arrays were merged at the join behind an `s_waitcnt vmcnt(0)`.  Two steps per iteration, so that the
+    // arrays that alternate between steps keep their registers.
+    const uint32_t last = nchunks + 2;
+    if (role == 0) {
+        float xa[CH], xb[CH];                                         // rows of the tiles c (even / odd), then c + 2
+        auto request = [&](uint32_t c, float (&x)[CH]) ZH_INLINE_LAMBDA {
+            if (frames(c) == CH) {
+                const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
 #pragma unroll
-        for (uint32_t k = 0; k < CH; k++) xn[k] = zrow_load<1>(ri, voff, k * irow);
-    }
-    for (uint32_t c = 0; c <= nchunks + 1; c++) {
-        if (role == 0 && c < nchunks) {
+                for (uint32_t k = 0; k < CH; k++) x[k] = zrow_load<1>(ri, voff, k * irow);
+            }
+        };
+        auto publish = [&](uint32_t c, float (&x)[CH]) ZH_INLINE_LAMBDA {
             const uint32_t nf = frames(c);
-            float (*t)[64] = in_t[c & 1];
+            float4 (*t)[64] = in_q[c & 3];
             if (nf == CH) {
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) t[k][lane] = xn[k] + kSvfDcOffset;
+                for (uint32_t q = 0; q < Q; q++)
+                    t[q][lane] = make_float4(x[4 * q] + kSvfDcOffset, x[4 * q + 1] + kSvfDcOffset, x[4 * q + 2] + kSvfDcOffset, x[4 * q + 3] + kSvfDcOffset);
             } else {
                 const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
-                for (uint32_t k = 0; k < nf; k++) t[k][lane] = zrow_load<1>(ri, voff, k * irow) + kSvfDcOffset;
+                for (uint32_t k = 0; k < nf; k++) at(t, k) = zrow_load<1>(ri, voff, k * irow) + kSvfDcOffset;
             }
-            if (frames(c + 1) == CH) {
-                const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + (c + 1) * CH);
+            request(c + 2, x);
+        };
+        request(0, xa); request(1, xb);
+        for (uint32_t c = 0; c <= last; c += 2) {
+            if (c < nchunks) publish(c, xa);
+            __syncthreads();
+            if (c + 1 <= last) {
+                if (c + 1 < nchunks) publish(c + 1, xb);
+                __syncthreads();
+            }
+        }
+    } else if (role == 1) {
+        float4 fa[Q], fb[Q];                                          // the tile in hand / the next one
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) xn[k] = zrow_load<1>(ri, voff, k * irow);
-            }
-        } else if (role == 1 && c > 0 && c <= nchunks) {
-            const uint32_t d = c - 1, nf = frames(d);
-            const float (*ti)[64] = in_t[d & 1];
-            float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
-            auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
-                const SvfOut sv = svf_core(o.l, o.b, in, o.cut, o.res);
-                tl[k][lane] = sv.l; tb[k][lane] = sv.b; th[k][lane] = sv.h;
-            };
+        for (uint32_t q = 0; q < Q; q++) fa[q] = fb[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto step = [&](uint32_t c, float4 (&cur)[Q], float4 (&nxt)[Q]) ZH_INLINE_LAMBDA {
+            if (c == 0 || c > nchunks + 1) return;
+            const float4 (*tn)[64] = in_q[(c - 1) & 3];              // (complete only if that tile is a whole one: otherwise unused)
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) nxt[q] = tn[q][lane];
+            if (c == 1) return;
+            const uint32_t d = c - 2, nf = frames(d);
+            float4 (*tl)[64] = l_q[d & 1], (*tb)[64] = b_q[d & 1];
             if (nf == CH) {
-                float x[CH];
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) x[k] = ti[k][lane];
-#pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, x[k]);
-            } else {
-                for (uint32_t k = 0; k < nf; k++) one(k, ti[k][lane]);
+                for (uint32_t q = 0; q < Q; q++) {
+                    const SvfMid m0 = svf_core_mid(o.l, o.b, cur[q].x, o.cut, o.res);
+                    const SvfMid m1 = svf_core_mid(o.l, o.b, cur[q].y, o.cut, o.res);
+                    const SvfMid m2 = svf_core_mid(o.l, o.b, cur[q].z, o.cut, o.res);
+                    const SvfMid m3 = svf_core_mid(o.l, o.b, cur[q].w, o.cut, o.res);
+                    tl[q][lane] = make_float4(m0.l, m1.l, m2.l, m3.l);
+                    tb[q][lane] = make_float4(m0.b1, m1.b1, m2.b1, m3.b1);
+                }
+            } else {                                                  // (the last tile: the loader has stopped, its buffer stays)
+                float4 (*ti)[64] = in_q[d & 3];
+                for (uint32_t k = 0; k < nf; k++) {
+                    const SvfMid m = svf_core_mid(o.l, o.b, at(ti, k), o.cut, o.res);
+                    at(tl, k) = m.l; at(tb, k) = m.b1;
+                }
             }
-        } else if (role == 2) {
-            if (c > 1) {
-                const uint32_t d = c - 2, nf = frames(d);
+        };
+        for (uint32_t c = 0; c <= last; c += 2) {
+            step(c, fa, fb);
+            __syncthreads();
+            if (c + 1 <= last) {
+                step(c + 1, fb, fa);
+                __syncthreads();
+            }
+        }
+    } else {
+        float bn[CH];                                                 // the output rows of the tile after the one in hand
+        for (uint32_t c = 0; c <= last; c++) {
+            if (c > 2) {
+                const uint32_t d = c - 3, nf = frames(d);
                 const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
-                const float (*tl)[64] = lbh_t[d & 1][0], (*tb)[64] = lbh_t[d & 1][1], (*th)[64] = lbh_t[d & 1][2];
-                auto one = [&](uint32_t k, float l, float b, float h, float base) ZH_INLINE_LAMBDA {
-                    const float val = l * l_mul + b * b_mul + h * h_mul;    // :146
+                float4 (*ti)[64] = in_q[d & 3], (*tl)[64] = l_q[d & 1], (*tb)[64] = b_q[d & 1];
+                auto one = [&](uint32_t k, float in, float l, float b1, float base) ZH_INLINE_LAMBDA {
+                    const SvfOut sv = svf_finish(l, b1, in, o.cut, o.res);
+                    const float val = sv.l * l_mul + sv.b * b_mul + sv.h * h_mul;    // :146
                     if (live) zrow_store<1>(ro, voff, k * orow, base + val);
                 };
                 if (nf == CH) {
-                    float xl[CH], xb[CH], xh[CH];
+                    float4 xi[Q], xl[Q], xb[Q];
 #pragma unroll
-                    for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xh[k] = th[k][lane]; }
+                    for (uint32_t q = 0; q < Q; q++) { xi[q] = ti[q][lane]; xl[q] = tl[q][lane]; xb[q] = tb[q][lane]; }
 #pragma unroll
-                    for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xh[k], ZF ? 0.0f : bn[k]);
+                    for (uint32_t q = 0; q < Q; q++) {
+                        one(4 * q, xi[q].x, xl[q].x, xb[q].x, ZF ? 0.0f : bn[4 * q]);
+                        one(4 * q + 1, xi[q].y, xl[q].y, xb[q].y, ZF ? 0.0f : bn[4 * q + 1]);
+                        one(4 * q + 2, xi[q].z, xl[q].z, xb[q].z, ZF ? 0.0f : bn[4 * q + 2]);
+                        one(4 * q + 3, xi[q].w, xl[q].w, xb[q].w, ZF ? 0.0f : bn[4 * q + 3]);
+                    }
                 } else {
-                    for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], th[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                    for (uint32_t k = 0; k < nf; k++) one(k, at(ti, k), at(tl, k), at(tb, k), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
                 }
             }
-            if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step
-                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 1) * CH);
+            if (!ZF && c >= 2 && frames(c - 2) == CH) {               // the output rows of the tile written at the next step
+                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 2) * CH);
 #pragma unroll
                 for (uint32_t k = 0; k < CH; k++) bn[k] = zrow_load<1>(rn, voff, k * orow);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (live && role == 1) { l_io[v] = o.l; b_io[v] = o.b; }
 }
