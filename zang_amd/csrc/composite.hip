@@ -316,10 +316,15 @@ __global__ void __launch_bounds__(192) k_nice_pc(NiceArgs a, Img out, uint32_t s
 // Measured at 4,096 voices with one wave's arithmetic compiled out at a time: 71 us as four waves with the full envelope
 // frame, 57.5 without the envelope's (it was the slowest wave: hence the quiet tiles below), then 57 -> 53.4 without the
 // oscillator's, 54.7 without the filter's, 42.9 without both (LDS traffic, barriers and the writer).
+// Round 2, later: what the filter wave costs beyond its 15 instructions is its LDS traffic (k_filter_pc, modules.hip: an LDS
+// instruction costs a lone wave about three VALU issues), so the tiles are float4 -- four frames of a lane side by side, one
+// 16-byte access per four frames -- the filter wave fetches its next tile while it computes (the producers run a step further
+// ahead), and every role runs its own copy of the step loop (as branches of one loop body the roles' register arrays were
+// merged at the join behind an `s_waitcnt vmcnt(0)`: the writer waited out its stores every step).
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t start, uint32_t end) {
-    constexpr uint32_t CH = 32;
-    __shared__ float in_t[2][CH][64], env_t[3][CH][64], lb_t[2][2][CH][64];
+    constexpr uint32_t CH = 32, Q = CH / 4;
+    __shared__ float4 in_q[2][Q][64], env_q[2][Q][64], l_q[2][Q][64], b_q[2][Q][64];
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 oscillator, 1 envelope, 2 filter, 3 writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < a.V;
@@ -327,81 +332,140 @@ __global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t 
     const uint32_t n_frames = end - start, nchunks = (n_frames + CH - 1) / CH;
     NiceLane n;
     nice_load<1>(n, a, vc);
-    PulseRoll roll;
-    n.roll_begin(roll);
     const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u;
-    for (uint32_t c = 0; c <= nchunks + 1; c++) {
-        if (role == 0 && c < nchunks) {
-            const uint32_t nf = min(CH, n_frames - c * CH);
-            float (*t)[64] = in_t[c & 1];
-            auto one = [&](uint32_t k) ZH_INLINE_LAMBDA { t[k][lane] = n.osc_next(roll) + kSvfDcOffset; };
-            if (nf == CH) {
-#pragma unroll 8
-                for (uint32_t k = 0; k < CH; k++) one(k);
-            } else {
-                for (uint32_t k = 0; k < nf; k++) one(k);
-            }
-        } else if (role == 1 && c < nchunks) {
-            const uint32_t nf = min(CH, n_frames - c * CH);
-            float (*t)[64] = env_t[c % 3];
-            if (nf == CH) {
-                // the envelope wave was the slowest of the four (compiled out: 71 -> 57 us): a tile in which no voice is inside
-                // a timed stage is one constant per voice, one in which no stage can end runs without the stage-end test
-                if (!zany_wave(n.env.mode == ENV_MODE_TOWARD)) {
-                    const float e0 = n.env_quiet();
-#pragma unroll 8
-                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = e0;
-                } else if (n.env.quiet(CH)) {
-#pragma unroll 8
-                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.env.frame_masked_quiet();
+    auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n_frames - c * CH) : 0u; };
+    // frame k of this lane inside a tile of float4 (the scalar path of a partial last tile)
+    auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
+    // Step c: the oscillator wave publishes tile c; the filter wave computes tile c - 2 out of registers while it fetches
+    // tile c - 1; the envelope wave (which reads nobody's output) paints tile c - 2; the writer mixes and stores tile c - 3.
+    const uint32_t last = nchunks + 2;
+    if (role == 0) {
+        PulseRoll roll;
+        n.roll_begin(roll);
+        for (uint32_t c = 0; c <= last; c++) {
+            if (c < nchunks) {
+                const uint32_t nf = frames(c);
+                float4 (*t)[64] = in_q[c & 1];
+                if (nf == CH) {
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++) {
+                        const float x0 = n.osc_next(roll) + kSvfDcOffset, x1 = n.osc_next(roll) + kSvfDcOffset;
+                        const float x2 = n.osc_next(roll) + kSvfDcOffset, x3 = n.osc_next(roll) + kSvfDcOffset;
+                        t[q][lane] = make_float4(x0, x1, x2, x3);
+                    }
                 } else {
-#pragma unroll 8
-                    for (uint32_t k = 0; k < CH; k++) t[k][lane] = n.tail_env();
+                    for (uint32_t k = 0; k < nf; k++) at(t, k) = n.osc_next(roll) + kSvfDcOffset;
                 }
-            } else {
-                for (uint32_t k = 0; k < nf; k++) t[k][lane] = n.tail_env();
             }
-        } else if (role == 2 && c > 0 && c <= nchunks) {
-            const uint32_t d = c - 1, nf = min(CH, n_frames - d * CH);
-            const float (*ti)[64] = in_t[d & 1];
-            float (*tl)[64] = lb_t[d & 1][0], (*tb)[64] = lb_t[d & 1][1];
-            auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
-                const SvfOut s = svf_core(n.l, n.b, in, n.cut, n.res);
-                tl[k][lane] = s.l; tb[k][lane] = s.b;                          // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
-            };
-            if (nf == CH) {
-                float x[CH];
+            __syncthreads();
+        }
+        if (live) a.cnt[v] = n.cnt;
+    } else if (role == 1) {
+        for (uint32_t c = 0; c <= last; c++) {
+            if (c >= 2 && c - 2 < nchunks) {
+                const uint32_t d = c - 2, nf = frames(d);
+                float4 (*t)[64] = env_q[d & 1];
+                if (nf == CH) {
+                    // the envelope wave was the slowest of the four (compiled out: 71 -> 57 us): a tile in which no voice is inside
+                    // a timed stage is one constant per voice, one in which no stage can end runs without the stage-end test
+                    if (!zany_wave(n.env.mode == ENV_MODE_TOWARD)) {
+                        const float e0 = n.env_quiet();
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) x[k] = ti[k][lane];
+                        for (uint32_t q = 0; q < Q; q++) t[q][lane] = make_float4(e0, e0, e0, e0);
+                    } else if (n.env.quiet(CH)) {
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, x[k]);
-            } else {
-                for (uint32_t k = 0; k < nf; k++) one(k, ti[k][lane]);
+                        for (uint32_t q = 0; q < Q; q++) {
+                            const float e0 = n.env.frame_masked_quiet(), e1 = n.env.frame_masked_quiet();
+                            const float e2 = n.env.frame_masked_quiet(), e3 = n.env.frame_masked_quiet();
+                            t[q][lane] = make_float4(e0, e1, e2, e3);
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t q = 0; q < Q; q++) {
+                            const float e0 = n.tail_env(), e1 = n.tail_env(), e2 = n.tail_env(), e3 = n.tail_env();
+                            t[q][lane] = make_float4(e0, e1, e2, e3);
+                        }
+                    }
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) at(t, k) = n.tail_env();
+                }
             }
-        } else if (role == 3 && c > 1) {
-            const uint32_t d = c - 2, nf = min(CH, n_frames - d * CH);
-            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
-            const float (*tl)[64] = lb_t[d & 1][0], (*tb)[64] = lb_t[d & 1][1];
-            const float (*te)[64] = env_t[d % 3];
-            auto one = [&](uint32_t k, float l, float b, float e0, float o) ZH_INLINE_LAMBDA {
-                const float t1 = svf_lowpass_into_zero(l, b);                  // NiceLane::tail_filter's mix
-                zrow_store<1>(ro, voff, k * orow, o + e0 * t1);                // multiply :246: out += temps[0]*temps[1]
-            };
+            __syncthreads();
+        }
+        if (live) { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
+    } else if (role == 2) {
+        float4 fa[Q], fb[Q];                                          // the tile in hand / the next one
+#pragma unroll
+        for (uint32_t q = 0; q < Q; q++) fa[q] = fb[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto step = [&](uint32_t c, float4 (&cur)[Q], float4 (&nxt)[Q]) ZH_INLINE_LAMBDA {
+            if (c == 0 || c > nchunks + 1) return;
+            const float4 (*tn)[64] = in_q[(c - 1) & 1];              // (complete only if that tile is a whole one: otherwise unused)
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) nxt[q] = tn[q][lane];
+            if (c == 1) return;
+            const uint32_t d = c - 2, nf = frames(d);
+            float4 (*tl)[64] = l_q[d & 1], (*tb)[64] = b_q[d & 1];
             if (nf == CH) {
-                float xl[CH], xb[CH], xe[CH], oc[CH];
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) { xl[k] = tl[k][lane]; xb[k] = tb[k][lane]; xe[k] = te[k][lane]; oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow); }
-#pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], xe[k], oc[k]);
-            } else {
-                for (uint32_t k = 0; k < nf; k++) one(k, tl[k][lane], tb[k][lane], te[k][lane], ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                for (uint32_t q = 0; q < Q; q++) {
+                    const SvfOut s0 = svf_core(n.l, n.b, cur[q].x, n.cut, n.res);
+                    const SvfOut s1 = svf_core(n.l, n.b, cur[q].y, n.cut, n.res);
+                    const SvfOut s2 = svf_core(n.l, n.b, cur[q].z, n.cut, n.res);
+                    const SvfOut s3 = svf_core(n.l, n.b, cur[q].w, n.cut, n.res);
+                    tl[q][lane] = make_float4(s0.l, s1.l, s2.l, s3.l);     // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
+                    tb[q][lane] = make_float4(s0.b, s1.b, s2.b, s3.b);
+                }
+            } else {                                                  // (the last tile: the oscillator wave has stopped, its buffer stays)
+                float4 (*ti)[64] = in_q[d & 1];
+                for (uint32_t k = 0; k < nf; k++) {
+                    const SvfOut s = svf_core(n.l, n.b, at(ti, k), n.cut, n.res);
+                    at(tl, k) = s.l; at(tb, k) = s.b;
+                }
+            }
+        };
+        for (uint32_t c = 0; c <= last; c += 2) {
+            step(c, fa, fb);
+            __syncthreads();
+            if (c + 1 <= last) {
+                step(c + 1, fb, fa);
+                __syncthreads();
             }
         }
-        __syncthreads();
+        if (live) { a.fl[v] = n.l; a.fb[v] = n.b; }
+    } else {
+        float bn[CH];                                                 // the output rows of the tile after the one in hand
+        for (uint32_t c = 0; c <= last; c++) {
+            if (c > 2) {
+                const uint32_t d = c - 3, nf = frames(d);
+                const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
+                float4 (*tl)[64] = l_q[d & 1], (*tb)[64] = b_q[d & 1], (*te)[64] = env_q[d & 1];
+                auto one = [&](uint32_t k, float l, float b, float e0, float o) ZH_INLINE_LAMBDA {
+                    const float t1 = svf_lowpass_into_zero(l, b);              // NiceLane::tail_filter's mix
+                    zrow_store<1>(ro, voff, k * orow, o + e0 * t1);            // multiply :246: out += temps[0]*temps[1]
+                };
+                if (nf == CH) {
+                    float4 xl[Q], xb[Q], xe[Q];
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++) { xl[q] = tl[q][lane]; xb[q] = tb[q][lane]; xe[q] = te[q][lane]; }
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++) {
+                        one(4 * q, xl[q].x, xb[q].x, xe[q].x, ZF ? 0.0f : bn[4 * q]);
+                        one(4 * q + 1, xl[q].y, xb[q].y, xe[q].y, ZF ? 0.0f : bn[4 * q + 1]);
+                        one(4 * q + 2, xl[q].z, xb[q].z, xe[q].z, ZF ? 0.0f : bn[4 * q + 2]);
+                        one(4 * q + 3, xl[q].w, xb[q].w, xe[q].w, ZF ? 0.0f : bn[4 * q + 3]);
+                    }
+                } else {
+                    for (uint32_t k = 0; k < nf; k++) one(k, at(tl, k), at(tb, k), at(te, k), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                }
+            }
+            if (!ZF && c >= 2 && frames(c - 2) == CH) {               // the output rows of the tile written at the next step
+                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 2) * CH);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) bn[k] = zrow_load<1>(rn, voff, k * orow);
+            }
+            __syncthreads();
+        }
     }
-    if (live && role == 0) a.cnt[v] = n.cnt;
-    if (live && role == 1) { a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start; }
-    if (live && role == 2) { a.fl[v] = n.l; a.fb[v] = n.b; }
 }
 
 // Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
@@ -1332,11 +1396,11 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
         else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
     } else if (m->n <= nice_pc_max() && end > start && outputs[0].stride <= (1u << 24)) {   // (32-row tiles: 32-bit offsets)
         // up to ZH_NICE_PC_MAX voices the three chains of a frame run in three waves side by side (k_nice_pc)
-        // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 1,024 / 4,096 / 16,384 voices 67 / 68 / 72 -> 55 / 57 / 60 us (the
-        // three-wave form with the same quiet envelope tiles: 60.5 / 62.5 at 4,096 / 16,384); its 56 KB of LDS per workgroup cost
-        // occupancy from 24,576 voices on (64 -> 111 us), where the three-wave form stays (32,768 / 65,536 voices: 65 / 89 us)
+        // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 4,096 / 16,384 / 32,768 voices 44 / 47 / 53.5 us against 60.5 / 62.5 /
+        // 63 for the three-wave form; its 64 KB of LDS per workgroup allow two workgroups per CU = 32,768 voices, beyond that
+        // the three-wave form stays (65,536 voices: 82 us against 111)
         static int pc4_max = -1;
-        if (pc4_max < 0) { const char *e = getenv("ZH_NICE_PC4_MAX"); pc4_max = e ? atoi(e) : 16384; }
+        if (pc4_max < 0) { const char *e = getenv("ZH_NICE_PC4_MAX"); pc4_max = e ? atoi(e) : 32768; }
         if (m->n <= (uint32_t)pc4_max) {
             if (zf) hipLaunchKernelGGL(k_nice_pc4<true>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
             else hipLaunchKernelGGL(k_nice_pc4<false>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);

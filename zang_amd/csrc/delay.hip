@@ -200,17 +200,18 @@ __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, flo
 }
 
 // FilteredEchoes at a small voice count, delay >= 192 frames: three waves per 64 voices (the form of modules.hip's
-// k_filter_pc).  Wave 0 fetches a tile's ring slots and input rows one tile ahead and forms the filter's input
-// (in = ((0 + delayed) * feedback + x) + fcdcoffset); wave 1 runs the state-variable recurrence alone and hands (l, b, h) on
-// through LDS; wave 2 forms temp1, does the `+=` into the output image and writes temp1 into the ring, two tiles behind the
-// loader.  A slot is read delay_samples frames after it was written; the loader runs at most 4 tiles (128 frames) ahead of the
-// writer, hence the minimum delay.  Same operations on the same values as k_filtered_echoes => same bits.
+// k_filter_pc: float4 LDS tiles, per-role step loops).  Wave 0 requests a tile's ring slots and input rows two tiles ahead and
+// forms the filter's input (in = ((0 + delayed) * feedback + x) + fcdcoffset); wave 1 runs the state-variable recurrence alone
+// (fetching its next tile from LDS meanwhile) and hands (l, b) on; wave 2 forms temp1, does the `+=` into the output image
+// and writes temp1 into the ring, three tiles behind the loader.  A slot is read delay_samples frames after it was written:
+// when the loader requests tile c + 2 the writer is certain to have stored tile c - 4, six tiles = 192 frames earlier --
+// hence the minimum delay (with it a slot being read is also never one the writer is filling in the same step).  Same
+// operations on the same values as k_filtered_echoes => same bits.
 template <bool ZF>
 __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float *__restrict__ l_io, float *__restrict__ b_io, Img out, CImg input,
                                                             uint32_t start, uint32_t end, F32P feedback_p, F32P cutoff_p) {
-    constexpr uint32_t CH = 32;
-    __shared__ float in_t[2][CH][64];
-    __shared__ float2 lb_t[2][CH][64];                                  // (l, b) of a frame side by side: one 8-byte LDS access each way
+    constexpr uint32_t CH = 32, Q = CH / 4;
+    __shared__ float4 in_q[2][Q][64], l_q[2][Q][64], b_q[2][Q][64];
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < d.n;
@@ -220,11 +221,11 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
     const float cut = zclampf(cutoff_p.get(vc), 0.0f, 1.0f);          // Filter.zig:114
     const float res = 1.0f - zclampf(0.0f, 0.0f, 1.0f);               // res = constant(0.0) (:441) -> Filter.zig:118
     const uint32_t idx0 = d.index[vc];
-    float l = l_io[vc], b = b_io[vc];
     float *ring = d.ring + vc;
     auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n - c * CH) : 0u; };
     auto slot_of = [&](uint32_t j) ZH_INLINE_LAMBDA { return (uint32_t)(((uint64_t)idx0 + j) % D); };   // the slot frame j of the span uses
-    float dn[CH], xn[CH], bn[CH];                                     // the tile after the one in hand: delayed samples, input rows (loader), output rows (writer)
+    // frame k of this lane inside a tile of float4 (the scalar path of a partial last tile)
+    auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
     // The voices of a wave normally share one ring index (set_state can make them differ): then a tile whose 32 slots do not
     // wrap is 32 consecutive ring rows, addressed like image rows (one descriptor, scalar row offsets) instead of a 64-bit
     // multiply-add and a wrap test per lane and frame.
@@ -234,67 +235,111 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
         const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_of(c * CH));
         return uni && s0 + CH <= D;
     };
-    auto fetch = [&](uint32_t c) ZH_INLINE_LAMBDA {
-        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
-        if (rows_ok(c)) {
-            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_of(c * CH));
-            const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, s0);
+    // Step c: the loader publishes tile c (requested two steps earlier); the filter wave computes tile c - 2 out of registers
+    // while it fetches tile c - 1 from LDS; the writer finishes and stores tile c - 3.  Two steps per iteration where arrays
+    // alternate between steps, so that they keep their registers.
+    const uint32_t last = nchunks + 2;
+    if (role == 0) {
+        float da[CH], xa[CH], db[CH], xb[CH];                         // delayed samples and input rows of the tiles c (even / odd), then c + 2
+        auto request = [&](uint32_t c, float (&dn)[CH], float (&xn)[CH]) ZH_INLINE_LAMBDA {
+            if (frames(c) != CH) return;
+            const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
+            if (rows_ok(c)) {
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_of(c * CH));
+                const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, s0);
 #pragma unroll
-            for (uint32_t k = 0; k < CH; k++) { dn[k] = zrow_load<1>(rr, voff, k * rrow); xn[k] = zrow_load<1>(ri, voff, k * irow); }
-        } else {
-            uint32_t sl = slot_of(c * CH);
-#pragma unroll
-            for (uint32_t k = 0; k < CH; k++) {
-                dn[k] = ring[(size_t)sl * d.n];
-                xn[k] = zrow_load<1>(ri, voff, k * irow);
-                sl = sl + 1 == D ? 0 : sl + 1;
-            }
-        }
-    };
-    if (role == 0 && frames(0) == CH) fetch(0);
-    for (uint32_t c = 0; c <= nchunks + 1; c++) {
-        if (role == 0 && c < nchunks) {
-            const uint32_t nf = frames(c);
-            float (*t)[64] = in_t[c & 1];
-            auto in_of = [&](float delayed, float x) ZH_INLINE_LAMBDA {
-                float t0 = 0.0f + delayed;                            // zero(temp0); readDelayBuffer (:425-428)
-                t0 = t0 * feedback;                                   // multiplyWithScalar (:433)
-                t0 = t0 + x;                                          // addInto (:436)
-                return t0 + kSvfDcOffset;                             // Filter.zig:135
-            };
-            if (nf == CH) {
-#pragma unroll
-                for (uint32_t k = 0; k < CH; k++) t[k][lane] = in_of(dn[k], xn[k]);
+                for (uint32_t k = 0; k < CH; k++) { dn[k] = zrow_load<1>(rr, voff, k * rrow); xn[k] = zrow_load<1>(ri, voff, k * irow); }
             } else {
                 uint32_t sl = slot_of(c * CH);
-                const float *ip = input.at(start + c * CH, vc);
-                for (uint32_t k = 0; k < nf; k++) {
-                    t[k][lane] = in_of(ring[(size_t)sl * d.n], ip[(size_t)k * input.stride]);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) {
+                    dn[k] = ring[(size_t)sl * d.n];
+                    xn[k] = zrow_load<1>(ri, voff, k * irow);
                     sl = sl + 1 == D ? 0 : sl + 1;
                 }
             }
-            if (frames(c + 1) == CH) fetch(c + 1);
-        } else if (role == 1 && c > 0 && c <= nchunks) {
-            const uint32_t dd = c - 1, nf = frames(dd);
-            const float (*ti)[64] = in_t[dd & 1];
-            float2 (*tlb)[64] = lb_t[dd & 1];
-            auto one = [&](uint32_t k, float in) ZH_INLINE_LAMBDA {
-                const SvfOut sv = svf_core(l, b, in, cut, res);
-                tlb[k][lane] = make_float2(sv.l, sv.b);                        // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
-            };
+        };
+        auto in_of = [&](float delayed, float x) ZH_INLINE_LAMBDA {
+            float t0 = 0.0f + delayed;                                // zero(temp0); readDelayBuffer (:425-428)
+            t0 = t0 * feedback;                                       // multiplyWithScalar (:433)
+            t0 = t0 + x;                                              // addInto (:436)
+            return t0 + kSvfDcOffset;                                 // Filter.zig:135
+        };
+        auto publish = [&](uint32_t c, float (&dn)[CH], float (&xn)[CH]) ZH_INLINE_LAMBDA {
+            const uint32_t nf = frames(c);
+            float4 (*t)[64] = in_q[c & 1];
             if (nf == CH) {
-                float x[CH];
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) x[k] = ti[k][lane];
-#pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, x[k]);
+                for (uint32_t q = 0; q < Q; q++)
+                    t[q][lane] = make_float4(in_of(dn[4 * q], xn[4 * q]), in_of(dn[4 * q + 1], xn[4 * q + 1]), in_of(dn[4 * q + 2], xn[4 * q + 2]), in_of(dn[4 * q + 3], xn[4 * q + 3]));
             } else {
-                for (uint32_t k = 0; k < nf; k++) one(k, ti[k][lane]);
+                // (a partial tile is the last one: the writer has stored every tile up to c - 4 and the slots of this one were
+                // written at least 192 frames before its first frame)
+                uint32_t sl = slot_of(c * CH);
+                const float *ip = input.at(start + c * CH, vc);
+                for (uint32_t k = 0; k < nf; k++) {
+                    at(t, k) = in_of(ring[(size_t)sl * d.n], ip[(size_t)k * input.stride]);
+                    sl = sl + 1 == D ? 0 : sl + 1;
+                }
             }
-        } else if (role == 2) {
-            if (c > 1) {
-                const uint32_t dd = c - 2, nf = frames(dd);
-                const float2 (*tlb)[64] = lb_t[dd & 1];
+            request(c + 2, dn, xn);
+        };
+        request(0, da, xa); request(1, db, xb);
+        for (uint32_t c = 0; c <= last; c += 2) {
+            if (c < nchunks) publish(c, da, xa);
+            __syncthreads();
+            if (c + 1 <= last) {
+                if (c + 1 < nchunks) publish(c + 1, db, xb);
+                __syncthreads();
+            }
+        }
+        if (live) d.index[v] = slot_of(n);
+    } else if (role == 1) {
+        float l = l_io[vc], b = b_io[vc];
+        float4 fa[Q], fb[Q];                                          // the tile in hand / the next one
+#pragma unroll
+        for (uint32_t q = 0; q < Q; q++) fa[q] = fb[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto step = [&](uint32_t c, float4 (&cur)[Q], float4 (&nxt)[Q]) ZH_INLINE_LAMBDA {
+            if (c == 0 || c > nchunks + 1) return;
+            const float4 (*tn)[64] = in_q[(c - 1) & 1];              // (complete only if that tile is a whole one: otherwise unused)
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) nxt[q] = tn[q][lane];
+            if (c == 1) return;
+            const uint32_t dd = c - 2, nf = frames(dd);
+            float4 (*tl)[64] = l_q[dd & 1], (*tb)[64] = b_q[dd & 1];
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) {
+                    const SvfOut s0 = svf_core(l, b, cur[q].x, cut, res);
+                    const SvfOut s1 = svf_core(l, b, cur[q].y, cut, res);
+                    const SvfOut s2 = svf_core(l, b, cur[q].z, cut, res);
+                    const SvfOut s3 = svf_core(l, b, cur[q].w, cut, res);
+                    tl[q][lane] = make_float4(s0.l, s1.l, s2.l, s3.l);     // (h is not needed: dsp.hip.h svf_lowpass_into_zero)
+                    tb[q][lane] = make_float4(s0.b, s1.b, s2.b, s3.b);
+                }
+            } else {                                                  // (the last tile: the loader has stopped, its buffer stays)
+                float4 (*ti)[64] = in_q[dd & 1];
+                for (uint32_t k = 0; k < nf; k++) {
+                    const SvfOut sv = svf_core(l, b, at(ti, k), cut, res);
+                    at(tl, k) = sv.l; at(tb, k) = sv.b;
+                }
+            }
+        };
+        for (uint32_t c = 0; c <= last; c += 2) {
+            step(c, fa, fb);
+            __syncthreads();
+            if (c + 1 <= last) {
+                step(c + 1, fb, fa);
+                __syncthreads();
+            }
+        }
+        if (live) { l_io[v] = l; b_io[v] = b; }
+    } else {
+        float bn[CH];                                                 // the output rows of the tile after the one in hand
+        for (uint32_t c = 0; c <= last; c++) {
+            if (c > 2) {
+                const uint32_t dd = c - 3, nf = frames(dd);
+                float4 (*tl)[64] = l_q[dd & 1], (*tb)[64] = b_q[dd & 1];
                 float *op = out.at(start + dd * CH, vc);
                 uint32_t sl = slot_of(dd * CH);
                 auto one = [&](uint32_t k, float fl, float fb, float base) ZH_INLINE_LAMBDA {
@@ -306,38 +351,43 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
                     sl = sl + 1 == D ? 0 : sl + 1;
                 };
                 if (nf == CH) {
-                    float xl[CH], xb[CH];
+                    float4 xl[Q], xb[Q];
 #pragma unroll
-                    for (uint32_t k = 0; k < CH; k++) { const float2 q = tlb[k][lane]; xl[k] = q.x; xb[k] = q.y; }
+                    for (uint32_t q = 0; q < Q; q++) { xl[q] = tl[q][lane]; xb[q] = tb[q][lane]; }
                     if (rows_ok(dd)) {
                         const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + dd * CH);
                         const zh_rsrc_t rr = zrow_rsrc(d.ring, d.n, (uint32_t)__builtin_amdgcn_readfirstlane((int)sl));
-#pragma unroll
-                        for (uint32_t k = 0; k < CH; k++) {
-                            const float t1 = svf_lowpass_into_zero(xl[k], xb[k]);   // as in one()
+                        auto fast = [&](uint32_t k, float fl, float fb) ZH_INLINE_LAMBDA {
+                            const float t1 = svf_lowpass_into_zero(fl, fb);         // as in one()
                             if (live) {
                                 zrow_store<1>(ro, voff, k * orow, (ZF ? 0.0f : bn[k]) + t1);
                                 zrow_store<1>(rr, voff, k * rrow, t1);
                             }
+                        };
+#pragma unroll
+                        for (uint32_t q = 0; q < Q; q++) {
+                            fast(4 * q, xl[q].x, xb[q].x); fast(4 * q + 1, xl[q].y, xb[q].y);
+                            fast(4 * q + 2, xl[q].z, xb[q].z); fast(4 * q + 3, xl[q].w, xb[q].w);
                         }
                     } else {
 #pragma unroll
-                        for (uint32_t k = 0; k < CH; k++) one(k, xl[k], xb[k], ZF ? 0.0f : bn[k]);
+                        for (uint32_t q = 0; q < Q; q++) {
+                            one(4 * q, xl[q].x, xb[q].x, ZF ? 0.0f : bn[4 * q]); one(4 * q + 1, xl[q].y, xb[q].y, ZF ? 0.0f : bn[4 * q + 1]);
+                            one(4 * q + 2, xl[q].z, xb[q].z, ZF ? 0.0f : bn[4 * q + 2]); one(4 * q + 3, xl[q].w, xb[q].w, ZF ? 0.0f : bn[4 * q + 3]);
+                        }
                     }
                 } else {
-                    for (uint32_t k = 0; k < nf; k++) one(k, tlb[k][lane].x, tlb[k][lane].y, ZF ? 0.0f : op[(size_t)k * out.stride]);
+                    for (uint32_t k = 0; k < nf; k++) one(k, at(tl, k), at(tb, k), ZF ? 0.0f : op[(size_t)k * out.stride]);
                 }
             }
-            if (!ZF && c >= 1 && frames(c - 1) == CH) {               // the output rows of the tile written at the next step
-                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 1) * CH);
+            if (!ZF && c >= 2 && frames(c - 2) == CH) {               // the output rows of the tile written at the next step
+                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 2) * CH);
 #pragma unroll
                 for (uint32_t k = 0; k < CH; k++) bn[k] = zrow_load<1>(rn, voff, k * orow);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (live && role == 0) d.index[v] = slot_of(n);
-    if (live && role == 1) { l_io[v] = l; b_io[v] = b; }
 }
 
 // the chunked form needs a delay of at least a chunk and an input image that does not overlap the output image
