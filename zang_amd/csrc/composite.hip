@@ -1088,13 +1088,13 @@ template <bool ZF>
 __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(const NfArgs a) {
     constexpr uint32_t CH = 32, NS = 8, ST = 4, NONE = 0xFFFFFFFFu, NP = kNfProducers, NT = 64 * (NP + 2);   // ST = tiles per stretch
     __shared__ uint4 tbl[kNoiseJumpEntries];
-    __shared__ float tile[NS][CH][64];
-    __shared__ float lbh[2][3][CH][64];
+    __shared__ float4 tile[NS][CH / 4][64];                            // float4 = four frames of a lane side by side (one 16-byte access)
+    __shared__ float4 l_q[2][CH / 4][64], b_q[2][CH / 4][64];
     __shared__ uint64_t after[NP][4][64];                              // per producer: generator state after its first multi-draw tile
     __shared__ uint32_t first_multi[NP][64];                           // per producer: that tile's index
     __shared__ uint32_t dead_from[64];                                 // first tile the writer must not store (NONE: all)
     __shared__ uint32_t ready[NS];                                     // ready[slot] = tile + 1 once the tile is in the slot
-    __shared__ uint32_t filt_done, lbh_ready, writ_done;               // tiles consumed by the filter / published to / written by the writer
+    __shared__ uint32_t lbh_ready, writ_done;                          // tiles published to / written out by the writer (which also frees the noise slot)
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 0 .. NP-1: producers; NP: filter; NP+1: writer
     const uint32_t v = blockIdx.x * 64 + lane;
     const bool live = v < a.V;
@@ -1106,9 +1106,12 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
         for (uint32_t q = 0; q < NP; q++) first_multi[q][threadIdx.x] = NONE;
     }
     if (threadIdx.x < NS) ready[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) { filt_done = 0u; lbh_ready = 0u; writ_done = 0u; }
+    if (threadIdx.x == 0) { lbh_ready = 0u; writ_done = 0u; }
     __syncthreads();
     const uint32_t orow = (uint32_t)a.out.stride * 4u;
+    constexpr uint32_t Q = CH / 4;
+    // frame k of this lane inside a tile of float4 (partial tiles, the careful form)
+    auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
     const float cut = zclampf(a.cutoff.get(vc), 0.0f, 1.0f);           // Filter.zig:114
     const float res = 1.0f - zclampf(a.res.get(vc), 0.0f, 1.0f);       // :118
     bool ok = true;
@@ -1124,29 +1127,32 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
             for (uint32_t q = 0; q < ST && ok; q++) {
                 const uint32_t c = ST * j + q;
                 if (c >= nt) break;
-                if (c >= NS) ok = ring_wait_ge(&filt_done, c + 1 - NS);          // the slot's previous tile has been read
+                if (c >= NS) ok = ring_wait_ge(&writ_done, c + 1 - NS);          // the slot's previous tile has been read (by the filter, then the writer)
                 const uint32_t nf = min(CH, n - c * CH), slot = c & (NS - 1);
-                float (*t)[64] = tile[slot];
+                float4 (*t)[64] = tile[slot];
                 bool multi = false;
                 // the tile without Random.float's rare-branch test per sample; a draw with a zero high word anywhere in it
                 // (2^-32 per sample) sends the whole wave through the tile again in the careful form
                 const ZXoshiro r_tile = r;
                 uint32_t hmin = 0xFFFFFFFFu;
-                auto fast = [&](uint32_t k) ZH_INLINE_LAMBDA {
+                auto fast = [&]() ZH_INLINE_LAMBDA {
                     const float white = zrandom_float32_common(r, hmin) * 2.0f - 1.0f;   // Noise.zig:51
-                    t[k][lane] = (0.0f + white) + kSvfDcOffset;        // zero(temp); temp += noise; in = temp + fcdcoffset (Filter.zig:135)
+                    return (0.0f + white) + kSvfDcOffset;              // zero(temp); temp += noise; in = temp + fcdcoffset (Filter.zig:135)
                 };
                 if (nf == CH) {
-#pragma unroll 8
-                    for (uint32_t k = 0; k < CH; k++) fast(k);
+#pragma unroll 2
+                    for (uint32_t q = 0; q < Q; q++) {
+                        const float x0 = fast(), x1 = fast(), x2 = fast(), x3 = fast();
+                        t[q][lane] = make_float4(x0, x1, x2, x3);
+                    }
                 } else {
-                    for (uint32_t k = 0; k < nf; k++) fast(k);
+                    for (uint32_t k = 0; k < nf; k++) at(t, k) = fast();
                 }
                 if (__builtin_amdgcn_ballot_w64(hmin == 0u) != 0) {
                     r = r_tile;
                     for (uint32_t k = 0; k < nf; k++) {
                         const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
-                        t[k][lane] = (0.0f + white) + kSvfDcOffset;
+                        at(t, k) = (0.0f + white) + kSvfDcOffset;
                     }
                 }
                 if (multi && !had_multi) {
@@ -1161,41 +1167,54 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
         }
     } else if (wave == NP) {
         // ---------------------------------------------------------------- filter: the recurrence alone
+        // (l after Filter.zig:142 and b after :139 go on to the writer, which redoes :143-144 from them and the noise tile:
+        // two values per frame through LDS instead of three -- an LDS instruction costs a lone wave about three VALU issues)
         l = a.l[vc]; b = a.b[vc];
-        for (uint32_t c = 0; c < nt && ok; c++) {
-            const uint32_t nf = min(CH, n - c * CH), slot = c & (NS - 1), p = (c / ST) % NP;
-            ok = ring_wait_ge(&ready[slot], c + 1);
-            float x[CH];
-            if (nf == CH) {
+        float4 fa[Q], fb[Q];                                           // the tile in hand / the next one
+        auto fetch = [&](uint32_t c, float4 (&x)[Q]) ZH_INLINE_LAMBDA {
+            if (c >= nt || !ok) return;
+            ok = ring_wait_ge(&ready[c & (NS - 1)], c + 1);
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) x[k] = tile[slot][k][lane];
-            } else {
-                for (uint32_t k = 0; k < nf; k++) x[k] = tile[slot][k][lane];
-            }
+            for (uint32_t q = 0; q < Q; q++) x[q] = tile[c & (NS - 1)][q][lane];
+        };
+        auto step = [&](uint32_t c, float4 (&cur)[Q], float4 (&nxt)[Q]) ZH_INLINE_LAMBDA {
+            const uint32_t nf = min(CH, n - c * CH), p = (c / ST) % NP;
+            fetch(c + 1, nxt);                                         // (the producers run up to NS tiles ahead: rarely a wait)
             const bool multi = first_multi[p][lane] == c;
-            ring_publish(&filt_done, c + 1, lane);
-            if (c >= 2 && ok) ok = ring_wait_ge(&writ_done, c - 1);    // the (l, b, h) slot's previous tile has been written out
-            float (*o)[CH][64] = lbh[c & 1];
-            auto one = [&](uint32_t k) ZH_INLINE_LAMBDA {
-                const SvfOut sv = svf_core(l, b, x[k], cut, res);      // Filter.zig:138-144
-                o[0][k][lane] = sv.l; o[1][k][lane] = sv.b; o[2][k][lane] = sv.h;
-            };
+            if (c >= 2 && ok) ok = ring_wait_ge(&writ_done, c - 1);    // the (l, b) slot's previous tile has been written out
+            float4 (*tl)[64] = l_q[c & 1], (*tb)[64] = b_q[c & 1];
             if (dead_tile != NONE) {
                 // stopped: (l, b) stay as they were after the multi-draw tile; the lane's later stores are dropped anyway
             } else if (nf == CH) {
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k);
+                for (uint32_t q = 0; q < Q; q++) {
+                    const SvfMid m0 = svf_core_mid(l, b, cur[q].x, cut, res);   // Filter.zig:138-144
+                    const SvfMid m1 = svf_core_mid(l, b, cur[q].y, cut, res);
+                    const SvfMid m2 = svf_core_mid(l, b, cur[q].z, cut, res);
+                    const SvfMid m3 = svf_core_mid(l, b, cur[q].w, cut, res);
+                    tl[q][lane] = make_float4(m0.l, m1.l, m2.l, m3.l);
+                    tb[q][lane] = make_float4(m0.b1, m1.b1, m2.b1, m3.b1);
+                }
             } else {
-                for (uint32_t k = 0; k < nf; k++) one(k);
+                float4 (*ti)[64] = tile[c & (NS - 1)];                 // (not freed before the writer has read it)
+                for (uint32_t k = 0; k < nf; k++) {
+                    const SvfMid m = svf_core_mid(l, b, at(ti, k), cut, res);
+                    at(tl, k) = m.l; at(tb, k) = m.b1;
+                }
             }
             ring_publish(&lbh_ready, c + 1, lane);
             if (multi && dead_tile == NONE) {                          // this tile drew more than once per sample somewhere
                 dead_tile = c;
                 dead_from[lane] = c + 1;                               // (reaches the writer before tile c + 1 does)
             }
+        };
+        fetch(0, fa);
+        for (uint32_t c = 0; c < nt && ok; c += 2) {
+            step(c, fa, fb);
+            if (c + 1 < nt && ok) step(c + 1, fb, fa);
         }
     } else {
-        // ---------------------------------------------------------------- writer: mix, +=, store
+        // ---------------------------------------------------------------- writer: Filter.zig:143-144 again, mix, +=, store
         for (uint32_t c = 0; c < nt && ok; c++) {
             const uint32_t nf = min(CH, n - c * CH);
             ok = ring_wait_ge(&lbh_ready, c + 1);
@@ -1203,19 +1222,28 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
             // loads return 0 and its stores are dropped
             const uint32_t voff = c >= dead_from[lane] ? 0x80000000u : vc * 4u;
             const zh_rsrc_t ro = make_rsrc(a.out.p + (size_t)(a.start + c * CH) * a.out.stride, CH * orow);
-            const float (*in)[CH][64] = lbh[c & 1];
-            auto one = [&](uint32_t k, float o) ZH_INLINE_LAMBDA {
-                const float val = in[0][k][lane] * a.l_mul + in[1][k][lane] * a.b_mul + in[2][k][lane] * a.h_mul;   // :146
+            float4 (*ti)[64] = tile[c & (NS - 1)], (*tl)[64] = l_q[c & 1], (*tb)[64] = b_q[c & 1];
+            auto one = [&](uint32_t k, float in, float lv, float b1, float o) ZH_INLINE_LAMBDA {
+                const SvfOut sv = svf_finish(lv, b1, in, cut, res);
+                const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
                 zrow_store<1>(ro, voff, k * orow, o + val);
             };
             if (nf == CH) {
+                float4 xi[Q], xl[Q], xb[Q];
                 float oc[CH];
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) { xi[q] = ti[q][lane]; xl[q] = tl[q][lane]; xb[q] = tb[q][lane]; }
 #pragma unroll
                 for (uint32_t k = 0; k < CH; k++) oc[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow);
 #pragma unroll
-                for (uint32_t k = 0; k < CH; k++) one(k, oc[k]);
+                for (uint32_t q = 0; q < Q; q++) {
+                    one(4 * q, xi[q].x, xl[q].x, xb[q].x, oc[4 * q]);
+                    one(4 * q + 1, xi[q].y, xl[q].y, xb[q].y, oc[4 * q + 1]);
+                    one(4 * q + 2, xi[q].z, xl[q].z, xb[q].z, oc[4 * q + 2]);
+                    one(4 * q + 3, xi[q].w, xl[q].w, xb[q].w, oc[4 * q + 3]);
+                }
             } else {
-                for (uint32_t k = 0; k < nf; k++) one(k, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                for (uint32_t k = 0; k < nf; k++) one(k, at(ti, k), at(tl, k), at(tb, k), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
             }
             ring_publish(&writ_done, c + 1, lane);
         }
