@@ -383,7 +383,7 @@ def test_fuzz_again_with_the_single_wave_forms():
         pytest.skip("already the rerun")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZH_NICE_PC_MAX="0", ZH_NF_PC_MAX="0", ZH_NF_RING_MAX="0", ZH_NOISE_RANGES="0", ZH_SINE_RANGES="0",
-               ZH_SAMPLER_RANGES="0", ZH_DECIMATOR_RANGES="0", ZH_ENVELOPE_RANGES="0", ZH_PORTAMENTO_RANGES="0", ZH_PULSE_CTRL_RANGES="0", ZH_TRISAW_CTRL_RANGES="0", ZH_PINK_PIPE_MAX="0",
+               ZH_SAMPLER_RANGES="0", ZH_PINK_TAPS="0", ZH_DECIMATOR_RANGES="0", ZH_ENVELOPE_RANGES="0", ZH_PORTAMENTO_RANGES="0", ZH_PULSE_CTRL_RANGES="0", ZH_TRISAW_CTRL_RANGES="0", ZH_PINK_PIPE_MAX="0",
                ZH_FUZZ_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fuzz.py", "-q", "-m", "gpu"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)

@@ -251,7 +251,7 @@ def test_noise_seed_known_answer(ctx):
     util.assert_bitexact(got, k, "noise K1")
 
 
-@pytest.mark.parametrize("form", ["pipeline", "sequential"])
+@pytest.mark.parametrize("form", ["taps", "chain", "sequential"])
 @pytest.mark.parametrize("zero_first", [True, False])
 @pytest.mark.parametrize("V", [300, 4096])
 def test_noise_pink_pipeline(ctx, oracle, zero_first, V, form, monkeypatch):
@@ -263,6 +263,8 @@ def test_noise_pink_pipeline(ctx, oracle, zero_first, V, form, monkeypatch):
     from zang_amd import modules as mod, zang
     if form == "sequential":
         monkeypatch.setenv("ZH_PINK_PIPE_MAX", "0")
+    elif form == "chain":
+        monkeypatch.setenv("ZH_PINK_TAPS", "0")                   # the seven-stage chain k_pink_pipe instead of the four-wave k_pink_taps
     first = 777
     rng = np.random.default_rng(78)
     L = oracle.lib()

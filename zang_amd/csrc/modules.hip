@@ -285,6 +285,136 @@ __global__ void __launch_bounds__(64 * kPinkWaves) k_pink_pipe(const float *__re
     if (!ok && lane == 0) *err = 1u;
 }
 
+// The pipeline above puts seven waves on a CU's four SIMDs (waves that share a SIMD share its one VALU issue per four cycles)
+// and a stage's tile costs ~1.5 us -- 48 us for 1,024 frames.  Here FOUR waves per 64 voices, one per SIMD, one barrier per
+// 32-frame step, every role in its own copy of the step loop, tiles of float4 (four frames of a lane side by side: a 16-byte
+// LDS access per four frames), white rows requested ahead UNCONDITIONALLY (a request inside a branch makes the row arrays
+// meet at the join, where the compiler waits for every outstanding load):
+//   wave 0   taps 0, 1                s1 = b0 + b1
+//   wave 1   taps 2, 3                s3 = (s1 + b2) + b3          one step behind
+//   wave 2   taps 4, 5                s5 = (s3 + b4) + b5          two steps behind
+//   wave 3   (s5 + b6) + white * 0.5362, b6, `+=`, the store (Noise.zig:65-66), three steps behind
+// The sums are the reference's left-to-right chain cut at three places => same operations on the same values, same bits.
+// Needs one whole tile in the span (n >= 32): requests past the last whole tile re-read it.
+template <uint32_t LAG>
+__device__ __forceinline__ void pink_pair_role(float4 (*sin)[8][64], float4 (*sout)[8][64], uint32_t lane, uint32_t n, uint32_t nt, uint32_t steps,
+                                               float ca, float da, float ba, float cb, float db, float bb, const CImg &white, uint32_t start, uint32_t voff) {
+    constexpr uint32_t CH = 32, Q = 8;
+    constexpr bool MINUS = LAG == 2;                                  // tap 5: `-0.7616 * b - white * 0.0168980` (:64)
+    const uint32_t wrow = (uint32_t)white.stride * 4u, whole = n / CH;
+    auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nt ? min(CH, n - c * CH) : 0u; };
+    auto request = [&](uint32_t c, float (&w)[CH]) ZH_INLINE_LAMBDA {
+        const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + min(c, whole - 1) * CH);
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) w[k] = zrow_load<1>(rw, voff, k * wrow);
+    };
+    auto pair = [&](float w, float s) ZH_INLINE_LAMBDA {              // Noise.zig:59-65: two taps, added to the sum so far
+        ba = ca * ba + w * da;
+        const float m1 = cb * bb, m2 = w * db;
+        bb = MINUS ? m1 - m2 : m1 + m2;
+        return LAG == 0 ? ba + bb : (s + ba) + bb;
+    };
+    auto tile = [&](uint32_t c, const float (&w)[CH]) ZH_INLINE_LAMBDA {
+        const uint32_t nf = frames(c);
+        float4 (*ti)[64] = sin[c & 1], (*to)[64] = sout[c & 1];
+        if (nf == CH) {
+            float4 xs[Q];
+            if (LAG > 0) {
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) xs[q] = ti[q][lane];
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) {
+                const float s0 = pair(w[4 * q], LAG > 0 ? xs[q].x : 0.0f), s1 = pair(w[4 * q + 1], LAG > 0 ? xs[q].y : 0.0f);
+                const float s2 = pair(w[4 * q + 2], LAG > 0 ? xs[q].z : 0.0f), s3 = pair(w[4 * q + 3], LAG > 0 ? xs[q].w : 0.0f);
+                to[q][lane] = make_float4(s0, s1, s2, s3);
+            }
+        } else if (nf > 0) {
+            const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + c * CH);
+            for (uint32_t k = 0; k < nf; k++) {
+                const float s = LAG > 0 ? reinterpret_cast<const float *>(&ti[k >> 2][lane])[k & 3] : 0.0f;
+                reinterpret_cast<float *>(&to[k >> 2][lane])[k & 3] = pair(zrow_load<1>(rw, voff, k * wrow), s);
+            }
+        }
+    };
+    float w0[CH], w1[CH];                                             // the white rows of the even / odd tiles
+    request(0, w0); request(1, w1);
+    // step c: tile c - LAG (an index past the span, or wrapped below zero, has no frames), then the request for the tile two on
+    for (uint32_t c = 0; c < steps; c += 2) {                         // two steps per turn: the arrays keep their registers
+        if constexpr ((LAG & 1) == 0) {
+            tile(c - LAG, w0); request(c - LAG + 2, w0); __syncthreads();
+            tile(c + 1 - LAG, w1); request(c + 1 - LAG + 2, w1); __syncthreads();
+        } else {
+            tile(c - LAG, w1); request(c - LAG + 2, w1); __syncthreads();
+            tile(c + 1 - LAG, w0); request(c + 1 - LAG + 2, w0); __syncthreads();
+        }
+    }
+}
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_pink_taps(const float *__restrict__ bst, uint32_t V, Img out, CImg white, uint32_t start, uint32_t end) {
+    constexpr uint32_t CH = 32, Q = 8;
+    __shared__ float4 s_q[3][2][Q][64];                               // s1, s3, s5: two tiles each
+    const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t v = blockIdx.x * 64 + lane, vc = min(v, V - 1);
+    const uint32_t n = end - start, nt = (n + CH - 1) / CH, whole = n / CH;
+    const uint32_t steps = (nt + 3 + 1) / 2 * 2;                      // tile t leaves the last wave at step t + 3; an even count, the same for every role
+    const uint32_t voff = vc * 4u;
+    auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nt ? min(CH, n - c * CH) : 0u; };
+    auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
+    auto tap_b = [&](uint32_t k) ZH_INLINE_LAMBDA { return bst[(size_t)k * V + vc]; };   // `var b = self.b` (:55)
+    // Noise.zig:59-64
+    if (role == 0) pink_pair_role<0>(s_q[0], s_q[0], lane, n, nt, steps, 0.99886f, 0.0555179f, tap_b(0), 0.99332f, 0.0750759f, tap_b(1), white, start, voff);
+    else if (role == 1) pink_pair_role<1>(s_q[0], s_q[1], lane, n, nt, steps, 0.96900f, 0.1538520f, tap_b(2), 0.86650f, 0.3104856f, tap_b(3), white, start, voff);
+    else if (role == 2) pink_pair_role<2>(s_q[1], s_q[2], lane, n, nt, steps, 0.55000f, 0.5329522f, tap_b(4), -0.7616f, 0.0168980f, tap_b(5), white, start, voff);
+    else {
+        float b6 = tap_b(6);
+        const uint32_t wrow = (uint32_t)white.stride * 4u, orow = (uint32_t)out.stride * 4u;
+        auto request = [&](uint32_t c, float (&w)[CH], float (&base)[CH]) ZH_INLINE_LAMBDA {
+            const uint32_t cc = min(c, whole - 1);
+            const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + cc * CH);
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + cc * CH);
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) { w[k] = zrow_load<1>(rw, voff, k * wrow); if (!ZF) base[k] = zrow_load<1>(ro, voff, k * orow); }
+        };
+        auto tile = [&](uint32_t c, const float (&w)[CH], const float (&base)[CH]) ZH_INLINE_LAMBDA {
+            const uint32_t nf = frames(c);
+            float4 (*si)[64] = s_q[2][c & 1];
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + min(c, nt - 1) * CH);
+            auto fin = [&](float s5, float wk, float bk) ZH_INLINE_LAMBDA {
+                const float val = (s5 + b6) + wk * 0.5362f;           // :65
+                b6 = wk * 0.115926f;                                  // :66
+                return (ZF ? 0.0f : bk) + val;
+            };
+            if (nf == CH) {
+                float4 xs[Q];
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) xs[q] = si[q][lane];
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) {
+                    const float r0 = fin(xs[q].x, w[4 * q], base[4 * q]), r1 = fin(xs[q].y, w[4 * q + 1], base[4 * q + 1]);
+                    const float r2 = fin(xs[q].z, w[4 * q + 2], base[4 * q + 2]), r3 = fin(xs[q].w, w[4 * q + 3], base[4 * q + 3]);
+                    if (v < V) {
+                        zrow_store<1>(ro, voff, (4 * q) * orow, r0); zrow_store<1>(ro, voff, (4 * q + 1) * orow, r1);
+                        zrow_store<1>(ro, voff, (4 * q + 2) * orow, r2); zrow_store<1>(ro, voff, (4 * q + 3) * orow, r3);
+                    }
+                }
+            } else if (nf > 0) {
+                const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + c * CH);
+                for (uint32_t k = 0; k < nf; k++) {
+                    const float r = fin(at(si, k), zrow_load<1>(rw, voff, k * wrow), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                    if (v < V) zrow_store<1>(ro, voff, k * orow, r);
+                }
+            }
+        };
+        float wa[CH], wb[CH], ba[CH], bb[CH];                         // white and output rows of the even / odd tiles
+        request(0, wa, ba); request(1, wb, bb);
+        for (uint32_t c = 0; c < steps; c += 2) {                     // step c: tile c - 3 (odd for even c)
+            tile(c - 3, wb, bb); request(c - 3 + 2, wb, bb); __syncthreads();
+            tile(c - 2, wa, ba); request(c - 2 + 2, wa, ba); __syncthreads();
+        }
+    }
+}
+
 // =================================================================== Envelope
 // The state is double-buffered (zh_flipper, 4 words per voice: state, t, last_value, start as [4][n]): the frame-range kernel
 // reads the start state from one buffer while its last range writes the end state into the other, and the host flips (what a
@@ -1086,10 +1216,10 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     // module-owned image first (the repair of a multi-draw voice needs the noise on its own) and add / filter it from there.
     const uint32_t ch = zh_noise_range_frames(m->n, end - start);
     const bool pink = p->color == ZH_NOISE_PINK;
-    // pink, 1,024 / 4,096 / 16,384 voices: 124 / 116 / 118 us in one loop, 57 / 67 / 84 us as white ranges + pipeline (the
-    // white kernel is 10-29 us of that); at 32,768 voices the pipeline loses (161 against 129)
+    // pink, 1,024 / 4,096 / 16,384 / 32,768 voices: 124 / 116 / 118 / 130 us in one loop, 57 / 67 / 84 / 161 us as white ranges +
+    // the seven-stage chain (the white kernel is 10-29 us of that), 50 / 60 / 75 / 118 us as white ranges + k_pink_taps
     const char *pe = pink ? getenv("ZH_PINK_PIPE_MAX") : nullptr;     // read at every paint (tests switch forms)
-    const uint32_t pink_max = pe ? (uint32_t)atoi(pe) : 16384u;
+    const uint32_t pink_max = pe ? (uint32_t)atoi(pe) : 32768u;
     if (ch && (!pink || m->n <= pink_max)) {
         if (zf && !pink) {
             rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, outputs[0], start, end, ch);
@@ -1107,8 +1237,15 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                 if (rc == ZH_OK && !pink) return zh_add_into(m->ctx, start, end, outputs[0], m->scratch);
                 if (rc == ZH_OK) {
                     const dim3 grid((m->n + 63) / 64);
-                    if (zf) hipLaunchKernelGGL(k_pink_pipe<true>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
-                    else hipLaunchKernelGGL(k_pink_pipe<false>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                    const char *te = getenv("ZH_PINK_TAPS");              // 0 = the chain of seven stages (k_pink_pipe)
+                    const bool taps = (!te || atoi(te) != 0) && end - start >= 32 && outputs[0].stride <= (1u << 24) && m->scratch.stride <= (1u << 24);   // (32-row tiles: 32-bit offsets)
+                    if (taps) {
+                        if (zf) hipLaunchKernelGGL(k_pink_taps<true>, grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                        else hipLaunchKernelGGL(k_pink_taps<false>, grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                    } else {
+                        if (zf) hipLaunchKernelGGL(k_pink_pipe<true>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                        else hipLaunchKernelGGL(k_pink_pipe<false>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                    }
                     return zh_launch_status();
                 }
                 if (rc != ZH_ERR_UNSUPPORTED) return rc;
