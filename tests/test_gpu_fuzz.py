@@ -372,6 +372,76 @@ def test_fuzz_osc_control_images(ctx, oracle, seed):
     util.assert_bitexact(mt_.state()["t"].astype(np.float32), np.array([x.t for x in ts], np.float32), "trisaw t")
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_filter_and_echoes(ctx, oracle, seed):
+    """Filter (every type, constant parameters = the three-wave pipeline, or a cutoff image = the one-wave walk; inputs with
+    huge and tiny samples) and FilteredEchoes (delays either side of the pipeline's 192-frame minimum) over random spans."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(9000 + seed)
+    V = int(rng.choice([1, 3, 64, 70, 150]))
+    L = oracle.lib()
+    fls = []
+    for v in range(V):
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+    m = mod.Filter(V, ctx)
+    img = util.rng_buffers(seed + 190, V, F)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 6)):
+        ftype = int(rng.integers(0, 6))
+        inp = rng.uniform(-1, 1, (V, F)).astype(np.float32)
+        inp[rng.random((V, F)) < 0.01] *= np.float32(1e30)
+        inp[rng.random((V, F)) < 0.01] *= np.float32(1e-30)
+        res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+        cut_image = rng.random() < 0.3
+        cutoff = rng.uniform(-0.1, 1.1, (V, F) if cut_image else V).astype(np.float32)
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        with np.errstate(all="ignore"):
+            for v in range(V):
+                L.zo_filter_paint(C.byref(fls[v]), a, b, oracle.fptr(ref[v]), oracle.fptr(inp[v]), ftype,
+                                  oracle.buffer(cutoff[v]) if cut_image else oracle.constant(cutoff[v]), oracle.constant(res[v]))
+        out = util.to_image(img)
+        gc = zang.buffer(util.to_image(cutoff)) if cut_image else zang.constant(util.dev(cutoff))
+        m.paint(zang.Span(a, b), [out], [], False, m.Params(util.to_image(inp), ftype, gc, zang.constant(util.dev(res))), zero_first=zf)
+        ctx.sync()
+        got = util.from_image(out)
+        nan = np.isnan(ref)
+        assert np.array_equal(np.isnan(got), nan), f"filter seed {seed} call {k}: NaN positions"
+        util.assert_bitexact(np.where(nan, np.float32(0), got), np.where(nan, np.float32(0), ref), f"filter seed {seed} call {k} V={V} span {(a, b)} zf={zf} type={ftype} image={cut_image}")
+        img = np.where(nan, np.float32(0), ref)                       # (the next call adds onto finite values again)
+        fl_l = np.array([f.l for f in fls], np.float32)
+        if not np.all(np.isfinite(fl_l)) or not np.all(np.isfinite(np.array([f.b for f in fls], np.float32))):
+            for v in range(V):                                        # a voice that blew up starts over, on both sides
+                L.zo_filter_init(C.byref(fls[v]))
+            m.close(); m = mod.Filter(V, ctx)
+    D = int(rng.choice([5, 191, 192, 193, 300, 777]))
+    fb = rng.uniform(0.1, 0.9, V).astype(np.float32); cutoff = rng.uniform(0.05, 1.0, V).astype(np.float32)
+    rings = np.zeros((V, D), np.float32)
+    ds, fl2 = [], []
+    for v in range(V):
+        d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D); ds.append(d)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fl2.append(fl)
+    e = mod.FilteredEchoes(V, D, ctx)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    img = util.rng_buffers(seed + 290, V, F)
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 6)):
+        inp = rng.uniform(-1, 1, (V, F)).astype(np.float32)
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        for v in range(V):
+            L.zo_filtered_echoes_paint(C.byref(ds[v]), C.byref(fl2[v]), a, b, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1),
+                                       oracle.fptr(inp[v]), float(fb[v]), float(cutoff[v]))
+        out = util.to_image(img)
+        e.paint(zang.Span(a, b), [out], None, False, e.Params(util.to_image(inp), util.dev(fb), util.dev(cutoff)), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"echoes seed {seed} call {k} V={V} D={D} span {(a, b)} zf={zf}")
+        img = ref
+    grings, gidx, gflt = e.state()
+    util.assert_bitexact(grings, rings, "ring")
+    assert [int(x) for x in gidx] == [d.index for d in ds]
+
+
 def test_fuzz_again_with_the_single_wave_forms():
     """The same random cases through the lane-per-voice sequential forms (k_nice, k_noise_filter, k_noise, k_sineosc, the
     one-range k_sampler / k_decimator / oscillator control kernels: what runs above the voice-count limits of the pipelined /
@@ -383,9 +453,9 @@ def test_fuzz_again_with_the_single_wave_forms():
         pytest.skip("already the rerun")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZH_NICE_PC_MAX="0", ZH_NF_PC_MAX="0", ZH_NF_RING_MAX="0", ZH_NOISE_RANGES="0", ZH_SINE_RANGES="0",
-               ZH_SAMPLER_RANGES="0", ZH_PINK_TAPS="0", ZH_DECIMATOR_RANGES="0", ZH_ENVELOPE_RANGES="0", ZH_PORTAMENTO_RANGES="0", ZH_PULSE_CTRL_RANGES="0", ZH_TRISAW_CTRL_RANGES="0", ZH_PINK_PIPE_MAX="0",
+               ZH_SAMPLER_RANGES="0", ZH_PINK_TAPS="0", ZH_DECIMATOR_RANGES="0", ZH_ENVELOPE_RANGES="0", ZH_PORTAMENTO_RANGES="0", ZH_PULSE_CTRL_RANGES="0", ZH_TRISAW_CTRL_RANGES="0", ZH_PINK_PIPE_MAX="0", ZH_FILTER_PC_MAX="0", ZH_ECHOES_PC_MAX="0",
                ZH_FUZZ_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fuzz.py", "-q", "-m", "gpu"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "36 passed" in r.stdout
+    assert "40 passed" in r.stdout
