@@ -600,6 +600,16 @@ def _random_params(mod, rng, nv, nf):
 @pytest.mark.parametrize("name", ["Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Jingle",
                                   "LateJingle", "Trig", "Shapes", "Echo", "EchoLead"])
 def test_gpu_script_kernels_as_frame_ranges(ctx, name, monkeypatch):
+    _script_ranges_equal_sequential(ctx, name, 200, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_gpu_script_frame_ranges_at_a_mid_voice_count(ctx, monkeypatch):
+    """40,000 voices = 625 waves: three frame ranges per 64 voices (the count is 2048 / waves up to 65,536 voices)."""
+    _script_ranges_equal_sequential(ctx, "Pluck", 40000, monkeypatch)
+
+
+def _script_ranges_equal_sequential(ctx, name, nv, monkeypatch):
     """A generated kernel at a small voice count is launched as frame ranges at once (gridDim.y > 1): every range runs the
     frame body over the earlier frames with the output discarded (the state walk survives, the output math is dead code)
     and then paints its own frames.  Same module, same calls, once with ZH_SCRIPT_RANGES=0 (the lane-per-voice walk that the
@@ -609,7 +619,7 @@ def test_gpu_script_kernels_as_frame_ranges(ctx, name, monkeypatch):
     import torch
     from tests.util import to_image
     from zang_amd import script, zang
-    nv, nf = 200, 416
+    nf = 416
     prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
     a, b = prog.module(name, nv, 77), prog.module(name, nv, 77)
     # ranged: no delay ring, and no module output / transcendental feeding a builtin's state (an FM oscillator, a filter's
