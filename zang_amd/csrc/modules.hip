@@ -288,71 +288,55 @@ __global__ void __launch_bounds__(64 * kPinkWaves) k_pink_pipe(const float *__re
 // The pipeline above puts seven waves on a CU's four SIMDs (waves that share a SIMD share its one VALU issue per four cycles)
 // and a stage's tile costs ~1.5 us -- 48 us for 1,024 frames.  Here FOUR waves per 64 voices, one per SIMD, one barrier per
 // 32-frame step, every role in its own copy of the step loop, tiles of float4 (four frames of a lane side by side: a 16-byte
-// LDS access per four frames), white rows requested ahead UNCONDITIONALLY (a request inside a branch makes the row arrays
-// meet at the join, where the compiler waits for every outstanding load):
+// LDS access per four frames):
 //   wave 0   taps 0, 1                s1 = b0 + b1
 //   wave 1   taps 2, 3                s3 = (s1 + b2) + b3          one step behind
 //   wave 2   taps 4, 5                s5 = (s3 + b4) + b5          two steps behind
-//   wave 3   (s5 + b6) + white * 0.5362, b6, `+=`, the store (Noise.zig:65-66), three steps behind
+//   wave 3   (s5 + b6) + white * 0.5362, b6, `+=`, the store (Noise.zig:65-66), three steps behind; it also fetches the white
+//            rows for everybody: requested three tiles ahead -- UNCONDITIONALLY: a request inside a branch makes the row arrays
+//            meet at the join, where the compiler waits for every outstanding load -- and published as a float4 tile a step
+//            before wave 0 needs it (every wave fetching its own rows was a quarter of the instructions of each: kernel 40 -> 34 us)
 // The sums are the reference's left-to-right chain cut at three places => same operations on the same values, same bits.
 // Needs one whole tile in the span (n >= 32): requests past the last whole tile re-read it.
+constexpr uint32_t kPinkWhiteSlots = 8;
 template <uint32_t LAG>
-__device__ __forceinline__ void pink_pair_role(float4 (*sin)[8][64], float4 (*sout)[8][64], uint32_t lane, uint32_t n, uint32_t nt, uint32_t steps,
-                                               float ca, float da, float ba, float cb, float db, float bb, const CImg &white, uint32_t start, uint32_t voff) {
+__device__ __forceinline__ void pink_pair_role(float4 (*wq)[8][64], float4 (*sin)[8][64], float4 (*sout)[8][64], uint32_t lane, uint32_t n, uint32_t nt,
+                                               uint32_t steps, float ca, float da, float ba, float cb, float db, float bb) {
     constexpr uint32_t CH = 32, Q = 8;
     constexpr bool MINUS = LAG == 2;                                  // tap 5: `-0.7616 * b - white * 0.0168980` (:64)
-    const uint32_t wrow = (uint32_t)white.stride * 4u, whole = n / CH;
     auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nt ? min(CH, n - c * CH) : 0u; };
-    auto request = [&](uint32_t c, float (&w)[CH]) ZH_INLINE_LAMBDA {
-        const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + min(c, whole - 1) * CH);
-#pragma unroll
-        for (uint32_t k = 0; k < CH; k++) w[k] = zrow_load<1>(rw, voff, k * wrow);
-    };
     auto pair = [&](float w, float s) ZH_INLINE_LAMBDA {              // Noise.zig:59-65: two taps, added to the sum so far
         ba = ca * ba + w * da;
         const float m1 = cb * bb, m2 = w * db;
         bb = MINUS ? m1 - m2 : m1 + m2;
         return LAG == 0 ? ba + bb : (s + ba) + bb;
     };
-    auto tile = [&](uint32_t c, const float (&w)[CH]) ZH_INLINE_LAMBDA {
-        const uint32_t nf = frames(c);
-        float4 (*ti)[64] = sin[c & 1], (*to)[64] = sout[c & 1];
+    for (uint32_t c = 0; c < steps; c++) {                            // step c: tile c - LAG (an index wrapped below zero has no frames)
+        const uint32_t t = c - LAG, nf = frames(t);
+        float4 (*tw)[64] = wq[t & (kPinkWhiteSlots - 1)], (*ti)[64] = sin[t & 1], (*to)[64] = sout[t & 1];
         if (nf == CH) {
-            float4 xs[Q];
-            if (LAG > 0) {
+            float4 w[Q], xs[Q];
 #pragma unroll
-                for (uint32_t q = 0; q < Q; q++) xs[q] = ti[q][lane];
-            }
+            for (uint32_t q = 0; q < Q; q++) { w[q] = tw[q][lane]; if (LAG > 0) xs[q] = ti[q][lane]; }
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) {
-                const float s0 = pair(w[4 * q], LAG > 0 ? xs[q].x : 0.0f), s1 = pair(w[4 * q + 1], LAG > 0 ? xs[q].y : 0.0f);
-                const float s2 = pair(w[4 * q + 2], LAG > 0 ? xs[q].z : 0.0f), s3 = pair(w[4 * q + 3], LAG > 0 ? xs[q].w : 0.0f);
+                const float s0 = pair(w[q].x, LAG > 0 ? xs[q].x : 0.0f), s1 = pair(w[q].y, LAG > 0 ? xs[q].y : 0.0f);
+                const float s2 = pair(w[q].z, LAG > 0 ? xs[q].z : 0.0f), s3 = pair(w[q].w, LAG > 0 ? xs[q].w : 0.0f);
                 to[q][lane] = make_float4(s0, s1, s2, s3);
             }
-        } else if (nf > 0) {
-            const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + c * CH);
+        } else {
             for (uint32_t k = 0; k < nf; k++) {
                 const float s = LAG > 0 ? reinterpret_cast<const float *>(&ti[k >> 2][lane])[k & 3] : 0.0f;
-                reinterpret_cast<float *>(&to[k >> 2][lane])[k & 3] = pair(zrow_load<1>(rw, voff, k * wrow), s);
+                reinterpret_cast<float *>(&to[k >> 2][lane])[k & 3] = pair(reinterpret_cast<const float *>(&tw[k >> 2][lane])[k & 3], s);
             }
         }
-    };
-    float w0[CH], w1[CH];                                             // the white rows of the even / odd tiles
-    request(0, w0); request(1, w1);
-    // step c: tile c - LAG (an index past the span, or wrapped below zero, has no frames), then the request for the tile two on
-    for (uint32_t c = 0; c < steps; c += 2) {                         // two steps per turn: the arrays keep their registers
-        if constexpr ((LAG & 1) == 0) {
-            tile(c - LAG, w0); request(c - LAG + 2, w0); __syncthreads();
-            tile(c + 1 - LAG, w1); request(c + 1 - LAG + 2, w1); __syncthreads();
-        } else {
-            tile(c - LAG, w1); request(c - LAG + 2, w1); __syncthreads();
-            tile(c + 1 - LAG, w0); request(c + 1 - LAG + 2, w0); __syncthreads();
-        }
+        __syncthreads();
     }
 }
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_pink_taps(const float *__restrict__ bst, uint32_t V, Img out, CImg white, uint32_t start, uint32_t end) {
-    constexpr uint32_t CH = 32, Q = 8;
+    constexpr uint32_t CH = 32, Q = 8, NW = kPinkWhiteSlots;
+    __shared__ float4 w_q[NW][Q][64];                                 // white tiles: written a step before wave 0 reads them, last read by wave 3 four steps later
     __shared__ float4 s_q[3][2][Q][64];                               // s1, s3, s5: two tiles each
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t v = blockIdx.x * 64 + lane, vc = min(v, V - 1);
@@ -362,23 +346,40 @@ __global__ void __launch_bounds__(256) k_pink_taps(const float *__restrict__ bst
     auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nt ? min(CH, n - c * CH) : 0u; };
     auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
     auto tap_b = [&](uint32_t k) ZH_INLINE_LAMBDA { return bst[(size_t)k * V + vc]; };   // `var b = self.b` (:55)
-    // Noise.zig:59-64
-    if (role == 0) pink_pair_role<0>(s_q[0], s_q[0], lane, n, nt, steps, 0.99886f, 0.0555179f, tap_b(0), 0.99332f, 0.0750759f, tap_b(1), white, start, voff);
-    else if (role == 1) pink_pair_role<1>(s_q[0], s_q[1], lane, n, nt, steps, 0.96900f, 0.1538520f, tap_b(2), 0.86650f, 0.3104856f, tap_b(3), white, start, voff);
-    else if (role == 2) pink_pair_role<2>(s_q[1], s_q[2], lane, n, nt, steps, 0.55000f, 0.5329522f, tap_b(4), -0.7616f, 0.0168980f, tap_b(5), white, start, voff);
-    else {
+    if (role < 3) {
+        __syncthreads();                                              // (tile 0 of the white rows is in place)
+        // Noise.zig:59-64
+        if (role == 0) pink_pair_role<0>(w_q, s_q[0], s_q[0], lane, n, nt, steps, 0.99886f, 0.0555179f, tap_b(0), 0.99332f, 0.0750759f, tap_b(1));
+        else if (role == 1) pink_pair_role<1>(w_q, s_q[0], s_q[1], lane, n, nt, steps, 0.96900f, 0.1538520f, tap_b(2), 0.86650f, 0.3104856f, tap_b(3));
+        else pink_pair_role<2>(w_q, s_q[1], s_q[2], lane, n, nt, steps, 0.55000f, 0.5329522f, tap_b(4), -0.7616f, 0.0168980f, tap_b(5));
+    } else {
         float b6 = tap_b(6);
         const uint32_t wrow = (uint32_t)white.stride * 4u, orow = (uint32_t)out.stride * 4u;
-        auto request = [&](uint32_t c, float (&w)[CH], float (&base)[CH]) ZH_INLINE_LAMBDA {
-            const uint32_t cc = min(c, whole - 1);
-            const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + cc * CH);
-            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + cc * CH);
+        auto request_w = [&](uint32_t c, float (&w)[CH]) ZH_INLINE_LAMBDA {
+            const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + min(c, whole - 1) * CH);
 #pragma unroll
-            for (uint32_t k = 0; k < CH; k++) { w[k] = zrow_load<1>(rw, voff, k * wrow); if (!ZF) base[k] = zrow_load<1>(ro, voff, k * orow); }
+            for (uint32_t k = 0; k < CH; k++) w[k] = zrow_load<1>(rw, voff, k * wrow);
         };
-        auto tile = [&](uint32_t c, const float (&w)[CH], const float (&base)[CH]) ZH_INLINE_LAMBDA {
+        auto request_b = [&](uint32_t c, float (&base)[CH]) ZH_INLINE_LAMBDA {
+            if (ZF) return;
+            const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + min(c, whole - 1) * CH);
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) base[k] = zrow_load<1>(ro, voff, k * orow);
+        };
+        auto publish = [&](uint32_t c, const float (&w)[CH]) ZH_INLINE_LAMBDA {
             const uint32_t nf = frames(c);
-            float4 (*si)[64] = s_q[2][c & 1];
+            float4 (*t)[64] = w_q[c & (NW - 1)];
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) t[q][lane] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+            } else if (nf > 0) {
+                const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + c * CH);
+                for (uint32_t k = 0; k < nf; k++) at(t, k) = zrow_load<1>(rw, voff, k * wrow);
+            }
+        };
+        auto tile = [&](uint32_t c, const float (&base)[CH]) ZH_INLINE_LAMBDA {
+            const uint32_t nf = frames(c);
+            float4 (*si)[64] = s_q[2][c & 1], (*tw)[64] = w_q[c & (NW - 1)];
             const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + min(c, nt - 1) * CH);
             auto fin = [&](float s5, float wk, float bk) ZH_INLINE_LAMBDA {
                 const float val = (s5 + b6) + wk * 0.5362f;           // :65
@@ -386,31 +387,38 @@ __global__ void __launch_bounds__(256) k_pink_taps(const float *__restrict__ bst
                 return (ZF ? 0.0f : bk) + val;
             };
             if (nf == CH) {
-                float4 xs[Q];
+                float4 xs[Q], w[Q];
 #pragma unroll
-                for (uint32_t q = 0; q < Q; q++) xs[q] = si[q][lane];
+                for (uint32_t q = 0; q < Q; q++) { xs[q] = si[q][lane]; w[q] = tw[q][lane]; }
 #pragma unroll
                 for (uint32_t q = 0; q < Q; q++) {
-                    const float r0 = fin(xs[q].x, w[4 * q], base[4 * q]), r1 = fin(xs[q].y, w[4 * q + 1], base[4 * q + 1]);
-                    const float r2 = fin(xs[q].z, w[4 * q + 2], base[4 * q + 2]), r3 = fin(xs[q].w, w[4 * q + 3], base[4 * q + 3]);
+                    const float r0 = fin(xs[q].x, w[q].x, base[4 * q]), r1 = fin(xs[q].y, w[q].y, base[4 * q + 1]);
+                    const float r2 = fin(xs[q].z, w[q].z, base[4 * q + 2]), r3 = fin(xs[q].w, w[q].w, base[4 * q + 3]);
                     if (v < V) {
                         zrow_store<1>(ro, voff, (4 * q) * orow, r0); zrow_store<1>(ro, voff, (4 * q + 1) * orow, r1);
                         zrow_store<1>(ro, voff, (4 * q + 2) * orow, r2); zrow_store<1>(ro, voff, (4 * q + 3) * orow, r3);
                     }
                 }
-            } else if (nf > 0) {
-                const zh_rsrc_t rw = zrow_rsrc(white.p, white.stride, start + c * CH);
+            } else {
                 for (uint32_t k = 0; k < nf; k++) {
-                    const float r = fin(at(si, k), zrow_load<1>(rw, voff, k * wrow), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                    const float r = fin(at(si, k), at(tw, k), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
                     if (v < V) zrow_store<1>(ro, voff, k * orow, r);
                 }
             }
         };
-        float wa[CH], wb[CH], ba[CH], bb[CH];                         // white and output rows of the even / odd tiles
-        request(0, wa, ba); request(1, wb, bb);
-        for (uint32_t c = 0; c < steps; c += 2) {                     // step c: tile c - 3 (odd for even c)
-            tile(c - 3, wb, bb); request(c - 3 + 2, wb, bb); __syncthreads();
-            tile(c - 2, wa, ba); request(c - 2 + 2, wa, ba); __syncthreads();
+        float wa[CH], wb[CH], ba[CH], bb[CH];                         // white rows on their way to LDS and output rows, of the even / odd tiles
+        request_w(0, wa); request_w(1, wb);
+        request_b(0, ba); request_b(1, bb);
+        publish(0, wa); request_w(2, wa);
+        __syncthreads();
+        for (uint32_t c = 0; c < steps; c += 2) {
+            // step c (even): white tile c + 1 goes to LDS, tile c + 3 is requested; this wave's own tile is c - 3 (odd)
+            publish(c + 1, wb); request_w(c + 3, wb);
+            tile(c - 3, bb); request_b(c - 3 + 2, bb);
+            __syncthreads();
+            publish(c + 2, wa); request_w(c + 4, wa);
+            tile(c - 2, ba); request_b(c - 2 + 2, ba);
+            __syncthreads();
         }
     }
 }
@@ -1217,7 +1225,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     const uint32_t ch = zh_noise_range_frames(m->n, end - start);
     const bool pink = p->color == ZH_NOISE_PINK;
     // pink, 1,024 / 4,096 / 16,384 / 32,768 voices: 124 / 116 / 118 / 130 us in one loop, 57 / 67 / 84 / 161 us as white ranges +
-    // the seven-stage chain (the white kernel is 10-29 us of that), 50 / 60 / 75 / 118 us as white ranges + k_pink_taps
+    // the seven-stage chain (the white kernel is 10-29 us of that), 43 / 54 / 68 / 123 us as white ranges + k_pink_taps
     const char *pe = pink ? getenv("ZH_PINK_PIPE_MAX") : nullptr;     // read at every paint (tests switch forms)
     const uint32_t pink_max = pe ? (uint32_t)atoi(pe) : 32768u;
     if (ch && (!pink || m->n <= pink_max)) {
