@@ -496,6 +496,15 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     // exec-mask region (an s_and_saveexec / branch / restore per frame: ~10 of ~85 instructions)
     NiceLane n;
     nice_load(n, a, live ? v : a.V - 1);
+    if (!live) {
+        // a lane past the last voice contributes +0.0 by construction rather than through a select per frame: a silent
+        // oscillator, a filter at rest (finite whatever voice V-1's state is) and an envelope that paints nothing --
+        // frame_masked() ANDs its value with m_painted, a mode of NONE never leaves NONE inside a paint, and
+        // 0.0f + (+0.0f * finite) = +0.0f
+        n.k.ifreq = 0u; n.k.brpt = 0u; n.k.gdf2 = 0.0f; n.k.cc121 = 0.0f; n.k.cc212 = 0.0f; n.g = n.ng = 0.0f;   // (as begin() silences a bad frequency)
+        n.l = n.b = 0.0f;
+        n.env.mode = ENV_MODE_NONE; n.env.m_painted = 0u;
+    }
     const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
     PulseRoll roll;
     n.roll_begin(roll);
@@ -519,13 +528,13 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
 #pragma unroll 4
                 for (int k = 0; k < MIXF; k++) {
                     const float x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
-                    tile[wave][k][lane] = live ? x : 0.0f;
+                    tile[wave][k][lane] = x;
                 }
             } else {
                 for (int k = 0; k < MIXF; k++) {
                     float x = 0.0f;
                     if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
-                    tile[wave][k][lane] = live ? x : 0.0f;
+                    tile[wave][k][lane] = x;
                 }
             }
         } else if (whole && n.env.quiet(MIXF)) {                          // no stage can end in this chunk: the envelope without its stage-end test
@@ -533,19 +542,19 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
             for (int k = 0; k < MIXF; k++) {
                 const float e0 = n.env.frame_masked_quiet();
                 const float x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
-                tile[wave][k][lane] = live ? x : 0.0f;
+                tile[wave][k][lane] = x;
             }
         } else if (whole) {
 #pragma unroll 4
             for (int k = 0; k < MIXF; k++) {
                 const float x = 0.0f + (ROLL ? n.frame_roll(roll) : n.frame());   // the voice's own out (zeroed) += env*flt
-                tile[wave][k][lane] = live ? x : 0.0f;
+                tile[wave][k][lane] = x;
             }
         } else {
             for (int k = 0; k < MIXF; k++) {
                 float x = 0.0f;
                 if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.frame_roll(roll) : n.frame());
-                tile[wave][k][lane] = live ? x : 0.0f;
+                tile[wave][k][lane] = x;
             }
         }
         __syncthreads();
