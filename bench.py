@@ -183,7 +183,7 @@ class Workload:
         elif name == "nice":
             self.m = mod.NiceInstrument(V, self.color, ctx)
             self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
-            self.kernel = "k_nice_pc" if V <= 65536 else "k_nice"
+            self.kernel = "k_nice_pc4" if V <= 32768 else ("k_nice_pc" if V <= 65536 else "k_nice")     # the library's choice by voice count
             self.step = self._step_nice
             self.nsteps = 0
         else:
