@@ -380,16 +380,19 @@ def test_gate_bitexact(ctx, oracle):
 
 
 # ------------------------------------------------------------------ Filter
-@pytest.mark.parametrize("form", ["pipeline", "walk"])
+@pytest.mark.parametrize("form", ["pipeline", "pipeline16", "walk"])
 @pytest.mark.parametrize("zero_first", [False, True])
 @pytest.mark.parametrize("ftype", range(6))
 def test_filter_const_params_both_forms(ctx, oracle, ftype, zero_first, form, monkeypatch):
     """Constant cutoff / resonance at a small voice count: the three-wave pipeline k_filter_pc (loader, recurrence, writer)
-    and the one-wave walk (ZH_FILTER_PC_MAX=0) against the oracle -- every filter type, += and ZERO_FIRST, ragged spans
-    (a span shorter than 64 frames takes the walk anyway), a voice count that is not a multiple of 64, carried state."""
+    with 32-frame tiles, with the 16-frame tiles it takes between 32,768 and 65,536 voices (forced here: ZH_FILTER_PC_MAX=1)
+    and the one-wave walk (ZH_FILTER_PC_MAX=0) against the oracle -- every filter type, += and ZERO_FIRST,
+    ragged spans (a span shorter than 64 frames takes the walk anyway), a voice count that is not a multiple of 64, carried state."""
     from zang_amd import modules as mod, zang
     if form == "walk":
         monkeypatch.setenv("ZH_FILTER_PC_MAX", "0")
+    elif form == "pipeline16":
+        monkeypatch.setenv("ZH_FILTER_PC_MAX", "1")
     V = 200
     rng = np.random.default_rng(54)
     cut = rng.uniform(-0.1, 1.1, V).astype(np.float32)

@@ -546,10 +546,11 @@ __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, 
 // 1,024 frames, 34 us with its tile reads and 44 us with three values written per frame as two-dword instructions -- an LDS
 // instruction costs a lone wave about three VALU issues.  Hence tiles of float4 (four frames of a lane side by side: one
 // 16-byte instruction per four frames) and two values per frame instead of three.
-template <bool ZF>
+// CH = frames per tile: 32 (64 KB of LDS: two workgroups per CU = 32,768 voices) or 16 (32 KB: five per CU).
+template <bool ZF, uint32_t CH>
 __global__ void __launch_bounds__(192) k_filter_pc(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out, CImg input,
                                                    uint32_t start, uint32_t end, float l_mul, float b_mul, float h_mul, F32P cutoff, F32P res_p) {
-    constexpr uint32_t CH = 32, Q = CH / 4;
+    constexpr uint32_t Q = CH / 4;
     __shared__ float4 in_q[4][Q][64], l_q[2][Q][64], b_q[2][Q][64];
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
     const uint32_t v = blockIdx.x * 64 + lane;
@@ -1465,9 +1466,17 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     // 57.3 / 75.8 us in one wave, 47.6 / 48.8 / 51.3 / 63.6 us; from 49,152 voices its 64 KB of LDS per workgroup lose: 104 -> 117)
     const char *pe = getenv("ZH_FILTER_PC_MAX");                        // read at every paint (tests switch forms)
     const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 32768u;
-    if (!cb && !rb && m->n <= pc_max && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
-        if (zf) hipLaunchKernelGGL(k_filter_pc<true>, dim3((m->n + 63) / 64), dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
-        else hipLaunchKernelGGL(k_filter_pc<false>, dim3((m->n + 63) / 64), dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+    const char *pe16 = getenv("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
+    const uint32_t pc16_max = pe16 ? (uint32_t)atoi(pe16) : (pe && pc_max == 0 ? 0u : 65536u);   // (ZH_FILTER_PC_MAX=0 alone switches both off)     // 36,864 / 49,152 / 65,536 voices: 97 / 103 / 116 us in one wave, 72 / 79 / 104; 81,920: 126 against 168
+    if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
+        const dim3 grid((m->n + 63) / 64);
+        if (m->n <= pc_max) {
+            if (zf) hipLaunchKernelGGL((k_filter_pc<true, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+            else hipLaunchKernelGGL((k_filter_pc<false, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+        } else {
+            if (zf) hipLaunchKernelGGL((k_filter_pc<true, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+            else hipLaunchKernelGGL((k_filter_pc<false, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+        }
         return zh_launch_status();
     }
     if (cb && rb) ZH_FILTER(true, true);
