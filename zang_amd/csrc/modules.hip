@@ -1636,7 +1636,7 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     hipStream_t st = m->ctx->stream;
     // 4,096 voices: 94 us sequential with per-lane branches, 39 straight-line, 31 as 16 frame ranges (the replay is 8 issue
     // slots a frame against 13.5 for a painted frame: 4 / 8 / 16 / 32 / 64 ranges = 32.4 / 31.5 / 30.6 / 31.5 / 35.4 us)
-    const uint32_t ch = end > start && !bufs_alias(p->input, outputs[0]) ? zh_range_frames(m->n, end - start, "ZH_DECIMATOR_RANGES", 1024, 32768) : 0;
+    const uint32_t ch = end > start && !bufs_alias(p->input, outputs[0]) ? zh_range_frames(m->n, end - start, "ZH_DECIMATOR_RANGES", m->n <= 32768 ? 1024 : 2048, 65536) : 0;   // (40,960 / 49,152 / 65,536 voices: 97 / 100 / 110 -> 69 / 77 / 106 us)
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
         const int c = m->cur;
@@ -1713,7 +1713,7 @@ int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, cons
     // done properly (running span set up by begin(r0), unrolled replay, state in a flipped double buffer) frame ranges take
     // 9.2 / 11.7 / 17.0 / 29.4 us at 1,024 / 4,096 / 16,384 / 32,768 voices against 34.9 / 36.5 / 37.9 / 43.2 (an empty span still
     // runs begin(): the one-range form)
-    const uint32_t chr = end > start ? zh_range_frames(m->n, end - start, "ZH_CURVE_RANGES", 2048, 32768) : 0;
+    const uint32_t chr = end > start ? zh_range_frames(m->n, end - start, "ZH_CURVE_RANGES", 2048, 40960) : 0;   // (40,960 voices: 45.7 -> 36.9 us; no gain from 49,152)
     const uint32_t ch = chr ? chr : (end > start ? end - start : 1);
     const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
     ZH_ZF_LAUNCH(k_curve, grid, dim3(kSeqBlock), m->cnt[m->cur], m->cnt[chr ? m->cur ^ 1 : m->cur], m->n, mk_img(outputs[0]), start, end, ch,
