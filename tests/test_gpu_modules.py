@@ -251,7 +251,7 @@ def test_noise_seed_known_answer(ctx):
     util.assert_bitexact(got, k, "noise K1")
 
 
-@pytest.mark.parametrize("form", ["taps", "chain", "sequential"])
+@pytest.mark.parametrize("form", ["taps", "taps16", "chain", "sequential"])
 @pytest.mark.parametrize("zero_first", [True, False])
 @pytest.mark.parametrize("V", [300, 4096])
 def test_noise_pink_pipeline(ctx, oracle, zero_first, V, form, monkeypatch):
@@ -265,6 +265,8 @@ def test_noise_pink_pipeline(ctx, oracle, zero_first, V, form, monkeypatch):
         monkeypatch.setenv("ZH_PINK_PIPE_MAX", "0")
     elif form == "chain":
         monkeypatch.setenv("ZH_PINK_TAPS", "0")                   # the seven-stage chain k_pink_pipe instead of the four-wave k_pink_taps
+    elif form == "taps16":
+        monkeypatch.setenv("ZH_PINK_TAPS", "16")                  # k_pink_taps with the 16-frame tiles it takes above 16,384 voices
     first = 777
     rng = np.random.default_rng(78)
     L = oracle.lib()

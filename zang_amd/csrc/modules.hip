@@ -299,10 +299,10 @@ __global__ void __launch_bounds__(64 * kPinkWaves) k_pink_pipe(const float *__re
 // The sums are the reference's left-to-right chain cut at three places => same operations on the same values, same bits.
 // Needs one whole tile in the span (n >= 32): requests past the last whole tile re-read it.
 constexpr uint32_t kPinkWhiteSlots = 8;
-template <uint32_t LAG>
-__device__ __forceinline__ void pink_pair_role(float4 (*wq)[8][64], float4 (*sin)[8][64], float4 (*sout)[8][64], uint32_t lane, uint32_t n, uint32_t nt,
+template <uint32_t LAG, uint32_t CH>
+__device__ __forceinline__ void pink_pair_role(float4 (*wq)[CH / 4][64], float4 (*sin)[CH / 4][64], float4 (*sout)[CH / 4][64], uint32_t lane, uint32_t n, uint32_t nt,
                                                uint32_t steps, float ca, float da, float ba, float cb, float db, float bb) {
-    constexpr uint32_t CH = 32, Q = 8;
+    constexpr uint32_t Q = CH / 4;
     constexpr bool MINUS = LAG == 2;                                  // tap 5: `-0.7616 * b - white * 0.0168980` (:64)
     auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nt ? min(CH, n - c * CH) : 0u; };
     auto pair = [&](float w, float s) ZH_INLINE_LAMBDA {              // Noise.zig:59-65: two taps, added to the sum so far
@@ -333,9 +333,10 @@ __device__ __forceinline__ void pink_pair_role(float4 (*wq)[8][64], float4 (*sin
         __syncthreads();
     }
 }
-template <bool ZF>
+// CH = frames per tile: 32 (112 KB of LDS: one workgroup per CU = 16,384 voices at once) or 16 (56 KB: two per CU)
+template <bool ZF, uint32_t CH>
 __global__ void __launch_bounds__(256) k_pink_taps(const float *__restrict__ bst, uint32_t V, Img out, CImg white, uint32_t start, uint32_t end) {
-    constexpr uint32_t CH = 32, Q = 8, NW = kPinkWhiteSlots;
+    constexpr uint32_t Q = CH / 4, NW = kPinkWhiteSlots;
     __shared__ float4 w_q[NW][Q][64];                                 // white tiles: written a step before wave 0 reads them, last read by wave 3 four steps later
     __shared__ float4 s_q[3][2][Q][64];                               // s1, s3, s5: two tiles each
     const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -349,9 +350,9 @@ __global__ void __launch_bounds__(256) k_pink_taps(const float *__restrict__ bst
     if (role < 3) {
         __syncthreads();                                              // (tile 0 of the white rows is in place)
         // Noise.zig:59-64
-        if (role == 0) pink_pair_role<0>(w_q, s_q[0], s_q[0], lane, n, nt, steps, 0.99886f, 0.0555179f, tap_b(0), 0.99332f, 0.0750759f, tap_b(1));
-        else if (role == 1) pink_pair_role<1>(w_q, s_q[0], s_q[1], lane, n, nt, steps, 0.96900f, 0.1538520f, tap_b(2), 0.86650f, 0.3104856f, tap_b(3));
-        else pink_pair_role<2>(w_q, s_q[1], s_q[2], lane, n, nt, steps, 0.55000f, 0.5329522f, tap_b(4), -0.7616f, 0.0168980f, tap_b(5));
+        if (role == 0) pink_pair_role<0, CH>(w_q, s_q[0], s_q[0], lane, n, nt, steps, 0.99886f, 0.0555179f, tap_b(0), 0.99332f, 0.0750759f, tap_b(1));
+        else if (role == 1) pink_pair_role<1, CH>(w_q, s_q[0], s_q[1], lane, n, nt, steps, 0.96900f, 0.1538520f, tap_b(2), 0.86650f, 0.3104856f, tap_b(3));
+        else pink_pair_role<2, CH>(w_q, s_q[1], s_q[2], lane, n, nt, steps, 0.55000f, 0.5329522f, tap_b(4), -0.7616f, 0.0168980f, tap_b(5));
     } else {
         float b6 = tap_b(6);
         const uint32_t wrow = (uint32_t)white.stride * 4u, orow = (uint32_t)out.stride * 4u;
@@ -1248,9 +1249,12 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                     const dim3 grid((m->n + 63) / 64);
                     const char *te = getenv("ZH_PINK_TAPS");              // 0 = the chain of seven stages (k_pink_pipe)
                     const bool taps = (!te || atoi(te) != 0) && end - start >= 32 && outputs[0].stride <= (1u << 24) && m->scratch.stride <= (1u << 24);   // (32-row tiles: 32-bit offsets)
-                    if (taps) {
-                        if (zf) hipLaunchKernelGGL(k_pink_taps<true>, grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
-                        else hipLaunchKernelGGL(k_pink_taps<false>, grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                    if (taps && m->n <= 16384 && !(te && atoi(te) == 16)) {   // (ZH_PINK_TAPS=16 forces the 16-frame tiles)
+                        if (zf) hipLaunchKernelGGL((k_pink_taps<true, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                        else hipLaunchKernelGGL((k_pink_taps<false, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                    } else if (taps) {                                    // 16-frame tiles: two workgroups per CU
+                        if (zf) hipLaunchKernelGGL((k_pink_taps<true, 16>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                        else hipLaunchKernelGGL((k_pink_taps<false, 16>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
                     } else {
                         if (zf) hipLaunchKernelGGL(k_pink_pipe<true>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
                         else hipLaunchKernelGGL(k_pink_pipe<false>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
