@@ -1467,7 +1467,8 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
         else hipLaunchKernelGGL((k_filter<false, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
     } while (0)
     // few voices, constant cutoff / resonance: the three-wave pipeline (1,024 / 4,096 / 16,384 / 32,768 voices: 54.5 / 56.1 /
-    // 57.3 / 75.8 us in one wave, 47.6 / 48.8 / 51.3 / 63.6 us; from 49,152 voices its 64 KB of LDS per workgroup lose: 104 -> 117)
+    // 57.3 / 75.8 us in one wave, 41 / 41.8 / 45 / 51 us; its 64 KB of LDS per workgroup allow 32,768 voices at once, with
+    // 16-frame tiles it goes on to 65,536 voices)
     const char *pe = getenv("ZH_FILTER_PC_MAX");                        // read at every paint (tests switch forms)
     const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 32768u;
     const char *pe16 = getenv("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
