@@ -1071,7 +1071,7 @@ __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ 
 // ~15), so a voice costs the instructions on the busiest wave's per-sample path.  The frame's work is cut where its values meet:
 //   producers 0-2     xoshiro256++ -> Random.float -> `in = (0 + white) + fcdcoffset` (~30 instructions per sample, the longest
 //                     piece, hence three of them): they take 128-frame stretches in turn and hop over the other two's
-//                     stretches with the T^128 jump table applied twice (noise_jump.hip.h; ~950 instructions per application);
+//                     stretches with one application of the T^256 jump table (noise_jump.hip.h; ~950 instructions);
 //   filter            the state-variable recurrence alone (svf_core: 15 instructions) -> (l, b, h) per sample;
 //   writer            the output mix, the `+=` and the image store (everything after the recurrence).
 // Rings: noise tiles [8][32 frames][64 voices] producer -> filter, (l, b, h) tiles [2][3][32][64] filter -> writer;
@@ -1085,7 +1085,7 @@ struct NfArgs {
     uint64_t *s[4];
     float *l, *b;
     uint32_t *err;               // set when a ring wait ran into its bound (never in a correct run)
-    const uint4 *table128;       // T^128
+    const uint4 *table256;       // T^256: one application hops the other two producers' 128-draw stretches
     uint32_t V, start, end;
     Img out;
     float l_mul, b_mul, h_mul;
@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
     const bool live = v < a.V;
     const uint32_t vc = live ? v : a.V - 1;                            // lanes past the last voice run voice V-1 again
     const uint32_t n = a.end - a.start, nt = (n + CH - 1) / CH;
-    noise_jump_load(tbl, a.table128, threadIdx.x, NT);
+    noise_jump_load(tbl, a.table256, threadIdx.x, NT);
     if (threadIdx.x < 64) {
         dead_from[threadIdx.x] = NONE;
         for (uint32_t q = 0; q < NP; q++) first_multi[q][threadIdx.x] = NONE;
@@ -1130,7 +1130,11 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
     if (wave < NP) {
         // ---------------------------------------------------------------- producer `wave`: stretches wave, wave + NP, ...
         r = ZXoshiro{a.s[0][vc], a.s[1][vc], a.s[2][vc], a.s[3][vc]};
-        for (uint32_t q = 0; q < wave; q++) noise_jump_apply(r, tbl);  // producer p starts 128 p draws in
+        // producer p starts 128 p draws in: producer 1 steps the generator 128 times (the table in LDS is T^256; this wave has
+        // the time: it shares its SIMD with nobody), producer 2 applies the table once
+        static_assert(kNfProducers == 3 && CH * ST == 128, "the T^256 table hops two 128-draw stretches");
+        if (wave == 1) { for (uint32_t q = 0; q < CH * ST; q++) (void)zxoshiro_next(r); }
+        else if (wave == 2) noise_jump_apply(r, tbl);
         bool had_multi = false;
         for (uint32_t j = wave; ST * j < nt && ok; j += NP) {
             for (uint32_t q = 0; q < ST && ok; q++) {
@@ -1171,8 +1175,7 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
                 }
                 ring_publish(&ready[slot], c + 1, lane);
             }
-            if (ST * (j + NP) < nt)                                    // over the other producers' stretches
-                for (uint32_t q = 0; q + 1 < NP; q++) noise_jump_apply(r, tbl);
+            if (ST * (j + NP) < nt) noise_jump_apply(r, tbl);          // over the other two producers' stretches: 256 draws
         }
     } else if (wave == NP) {
         // ---------------------------------------------------------------- filter: the recurrence alone
@@ -1630,7 +1633,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             NfArgs a;
             for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
             a.l = m->l; a.b = m->b; a.err = m->err;
-            a.table128 = tables + (size_t)3 * kNoiseJumpEntries;         // table j - 1 holds T^(32 j)
+            a.table256 = tables + (size_t)7 * kNoiseJumpEntries;         // table j - 1 holds T^(32 j)
             a.V = m->n; a.start = start; a.end = end; a.out = out;
             a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
             const dim3 grid((m->n + 63) / 64), block(64 * (kNfProducers + 2));
