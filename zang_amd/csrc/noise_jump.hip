@@ -120,9 +120,9 @@ __global__ void __launch_bounds__(64) k_noise_fix(uint64_t *__restrict__ s0, uin
 // (profiles/r02/noise_ranges.txt): enough ranges for about one wave per SIMD (1,024), at least 32 frames each.
 uint32_t zh_noise_range_frames(uint32_t V, uint32_t n) {
     static const int forced = [] { const char *e = getenv("ZH_NOISE_RANGES"); return e ? atoi(e) : -1; }();   // 0 = off, k = k ranges
-    if (forced == 0 || V == 0 || n < 128 || n > 2048 || V > 32768) return 0;
+    if (forced == 0 || V == 0 || n < 128 || n > 2048 || V > 65536) return 0;
     const uint32_t waves = (V + 63) / 64;
-    uint32_t want = forced > 0 ? (uint32_t)forced : 1024u / waves;
+    uint32_t want = forced > 0 ? (uint32_t)forced : (V <= 32768 ? 1024u : 2048u) / waves;
     if (want < 2) return 0;
     if (want > 32) want = 32;
     uint32_t ch = ((n + want - 1) / want + 31) / 32 * 32;
