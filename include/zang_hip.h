@@ -39,7 +39,9 @@ extern "C" {
 
 #define ZH_API __attribute__((visibility("default")))
 
-enum { ZH_OK = 0, ZH_ERR_INVALID = -1, ZH_ERR_UNSUPPORTED = -2, ZH_ERR_NO_DEVICE = -3 };
+enum { ZH_OK = 0, ZH_ERR_INVALID = -1, ZH_ERR_UNSUPPORTED = -2, ZH_ERR_NO_DEVICE = -3,
+       ZH_ERR_COMM = -4,          /* librccl could not be loaded (zh_comm_last_error says why) */
+       ZH_ERR_RCCL_BASE = -100    /* an RCCL call failed: the code is ZH_ERR_RCCL_BASE - ncclResult_t */ };
 
 /* paint flags */
 enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference contract) */
@@ -165,6 +167,33 @@ ZH_API int zh_ipc_close(zh_ctx *ctx, void *dev_ptr);
  * flags: ZH_PAINT_ZERO_FIRST overwrites dst. */
 ZH_API int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_slots, size_t slot_stride_floats,
                         size_t n, uint32_t flags);
+
+/* The same exchange as a COLLECTIVE: an RCCL communicator over the GPUs of the node (xGMI), one rank per process, and
+ * the partial mixes summed in place on the context's stream, right behind the mixdown kernels that produced them --
+ * north_star's "single RCCL reduce over xGMI for the final stereo mixdown".  It replaces the host-side accumulation of
+ * the reference's buffer loop (examples/write_wav.zig:58-93: per buffer, every voice paints `+=` into the output
+ * channels, then zang.mixDown; examples/example_stereo.zig:84-100 for the two channels), across GPUs.
+ * librccl is opened with dlopen on first use (env ZH_RCCL_LIB overrides the search: the copy already in the process,
+ * then the sibling of the loaded HIP runtime, then the ROCm installation's).
+ *   rank 0:      zh_comm_unique_id(id)  -> hand the 128 bytes to every other process (any host channel)
+ *   every rank:  zh_comm_create(ctx, world, rank, id, &comm)     (blocks until all `world` ranks have called it)
+ *   per batch:   zh_nice_paint_mix[_stereo] ... ; zh_allreduce_mix(comm, mix, n)  or  zh_reduce_mix(..., root)
+ * `mix` is a device float[n] of this rank's GPU (e.g. [buffers][channels][frames]); the sum order is RCCL's (ring /
+ * tree by size), so unlike zh_sum_slots the bits may differ between world sizes.  Calls on one communicator must be
+ * issued in the same order on every rank.  zh_comm_available() = 1 when librccl and its symbols were found. */
+enum { ZH_COMM_ID_BYTES = 128 };
+typedef struct zh_comm zh_comm;
+ZH_API int  zh_comm_available(void);
+ZH_API const char *zh_comm_library(void);      /* path librccl was opened from ("" if none) */
+ZH_API int  zh_comm_version(void);             /* ncclGetVersion, 0 if unavailable */
+ZH_API const char *zh_comm_last_error(void);   /* text of this thread's last ZH_ERR_COMM / ZH_ERR_RCCL_BASE-x result */
+ZH_API int  zh_comm_unique_id(uint8_t *id128 /* out: ZH_COMM_ID_BYTES */);
+ZH_API int  zh_comm_create(zh_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t *id128, zh_comm **out);
+ZH_API int  zh_comm_destroy(zh_comm *comm);    /* synchronises the context's stream first */
+ZH_API int  zh_comm_world(const zh_comm *comm);
+ZH_API int  zh_comm_rank(const zh_comm *comm);
+ZH_API int  zh_allreduce_mix(zh_comm *comm, float *mix, size_t n);                 /* every rank ends with the sum */
+ZH_API int  zh_reduce_mix(zh_comm *comm, float *mix, size_t n, uint32_t root);     /* only `root` ends with the sum */
 
 /* zang.mixDown (src/zang/mixdown.zig:8-86): f32 mix buffer -> interleaved signed 8 / 16-bit LE PCM with
  * clamping.  `dst` (device bytes, n * bytes_per_sample * num_channels) and `mix` (device float[n]). */

@@ -11,6 +11,16 @@ SRC = os.path.join(ROOT, "tests", "cpp", "host_parity.cpp")
 EXE = os.path.join(ROOT, "tests", "cpp", "host_parity")
 SCRIPT_SRC = os.path.join(ROOT, "tests", "cpp", "script_host.cpp")
 SCRIPT_EXE = os.path.join(ROOT, "tests", "cpp", "script_host")
+COMM_SRC = os.path.join(ROOT, "tests", "cpp", "comm_host.c")
+COMM_EXE = os.path.join(ROOT, "tests", "cpp", "comm_host")
+
+
+def _build_c(src, exe):
+    import zang_amd  # noqa: F401
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src,
+                           "-L" + os.path.join(ROOT, "zang_amd"), "-lzang_hip", "-Wl,-rpath," + os.path.join(ROOT, "zang_amd"),
+                           "-L" + rocm + "/lib", "-Wl,-rpath," + rocm + "/lib", "-o", exe])
 
 
 def _build(SRC=SRC, EXE=EXE):
@@ -28,7 +38,8 @@ def _build(SRC=SRC, EXE=EXE):
 def test_cpp_host_api_compiles_and_links():
     _build()
     _build(SCRIPT_SRC, SCRIPT_EXE)
-    assert os.path.exists(EXE) and os.path.exists(SCRIPT_EXE)
+    _build_c(COMM_SRC, COMM_EXE)
+    assert os.path.exists(EXE) and os.path.exists(SCRIPT_EXE) and os.path.exists(COMM_EXE)
 
 
 @pytest.mark.gpu
@@ -46,3 +57,14 @@ def test_cpp_script_host_without_python():
     r = subprocess.run([SCRIPT_EXE, os.path.join(ROOT, "tests", "golden", "script_modules.txt")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout + r.stderr
     assert "compiled `Pluck`: 5 state words/voice, 3 params" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_comm_host_one_rank_without_python():
+    """zh_comm_* from a plain C host: RCCL loaded by the library (the ROCm installation's copy here, not torch's), one
+    rank per process, id handed over a pipe.  One GPU per box: one rank; `tests/cpp/comm_host 8` on a full node."""
+    _build_c(COMM_SRC, COMM_EXE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([COMM_EXE, "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout + r.stderr
+    assert "world 1" in r.stdout

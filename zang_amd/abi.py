@@ -11,6 +11,9 @@ LIB_PATH = os.path.join(_HERE, "libzang_hip.so")
 u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 
 ZH_OK = 0
+ZH_ERR_INVALID, ZH_ERR_UNSUPPORTED, ZH_ERR_NO_DEVICE = -1, -2, -3
+ZH_ERR_COMM, ZH_ERR_RCCL_BASE = -4, -100
+COMM_ID_BYTES = 128
 PAINT_ADD, PAINT_ZERO_FIRST = 0, 1
 PAINT_PARAMS_UNCHANGED = 4
 MIX_SEQUENTIAL = 2
@@ -297,6 +300,17 @@ SIGNATURES = {
     "zh_ipc_open": (C.c_int, [vp, vp, P(vp)]),
     "zh_ipc_close": (C.c_int, [vp, vp]),
     "zh_sum_slots": (C.c_int, [vp, vp, vp, u32, C.c_size_t, C.c_size_t, u32]),
+    "zh_comm_available": (C.c_int, []),
+    "zh_comm_library": (C.c_char_p, []),
+    "zh_comm_version": (C.c_int, []),
+    "zh_comm_last_error": (C.c_char_p, []),
+    "zh_comm_unique_id": (C.c_int, [vp]),
+    "zh_comm_create": (C.c_int, [vp, u32, u32, vp, P(vp)]),
+    "zh_comm_destroy": (C.c_int, [vp]),
+    "zh_comm_world": (C.c_int, [vp]),
+    "zh_comm_rank": (C.c_int, [vp]),
+    "zh_allreduce_mix": (C.c_int, [vp, vp, C.c_size_t]),
+    "zh_reduce_mix": (C.c_int, [vp, vp, C.c_size_t, u32]),
     "zh_sineosc_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_sineosc_destroy": (C.c_int, [vp]),
     "zh_sineosc_get_state": (C.c_int, [vp, vp]),
@@ -495,4 +509,6 @@ def check(rc, what=""):
     if rc != 0:
         lib = load(strict=False)
         msg = lib.zh_error_string(rc).decode()
+        if rc == ZH_ERR_COMM or rc <= ZH_ERR_RCCL_BASE:
+            msg += ": " + lib.zh_comm_last_error().decode()
         raise ZangHipError(f"{what} failed: {rc} ({msg})")

@@ -5,7 +5,10 @@ so painting needs no inter-GPU traffic.  The only exchange is the final mixdown:
 reduces its own voices to a [channels][frames] partial on its GPU, and the partials are summed.
 Two forms of that one step:
 
-* `allreduce_mix`  -- a sum all-reduce (RCCL over xGMI on GPUs; gloo in the CPU tests);
+* `Comm`           -- the library's own RCCL communicator (C ABI zh_comm_* / zh_allreduce_mix / zh_reduce_mix,
+  csrc/comm.hip): the collective is enqueued on the context's stream; torch.distributed is only the host channel
+  that carries rank 0's 128-byte id to the other ranks (a Zig / C++ host uses whatever channel it has);
+* `allreduce_mix`  -- the same sum through torch.distributed (RCCL over xGMI on GPUs; gloo in the CPU tests);
 * `SlotExchange`   -- the root GPU owns one slot per rank in its own HBM, every rank's mixdown kernel stores its
   partial STRAIGHT into its slot (peer stores over xGMI, HIP IPC mapping, csrc/xchg.hip), and the root adds the
   slots in rank order: a fixed order, so the mix is reproducible bit for bit whatever the link timing.
@@ -32,6 +35,62 @@ def allreduce_mix(mix, group=None):
         else:
             dist.all_reduce(mix, op=dist.ReduceOp.SUM, group=group)
     return mix
+
+
+class Comm:
+    """RCCL communicator of libzang_hip.so (include/zang_hip.h zh_comm_*), one rank per process.
+
+    `Comm(ctx)` with an initialised torch.distributed process group: rank 0 makes the id, `control_group` (any backend
+    that can broadcast Python objects; default: the world group) carries it, every rank creates its communicator.
+    `Comm(ctx, world=1, rank=0)` needs no process group (a one-rank communicator: RCCL init + launch, the sum is the
+    identity).  Every rank first learns whether EVERY rank found librccl, so that none waits alone in RCCL's bootstrap."""
+
+    def __init__(self, ctx, world=None, rank=None, control_group=None):
+        from . import abi
+        self._abi, self.ctx, self.lib = abi, ctx, ctx.lib
+        self.handle = None
+        use_dist = world is None
+        if use_dist:
+            world, rank = dist.get_world_size(control_group), dist.get_rank(control_group)
+        self.world, self.rank = int(world), int(rank)
+        ok = int(self.lib.zh_comm_available())
+        if use_dist and self.world > 1:
+            import torch
+            t = torch.tensor([ok], dtype=torch.int32)
+            if dist.get_backend(control_group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group)
+            ok = int(t.item())
+        if not ok:
+            raise abi.ZangHipError("zh_comm: librccl is not available on every rank: " + self.lib.zh_comm_last_error().decode())
+        uid = (C.c_uint8 * abi.COMM_ID_BYTES)()
+        payload = [None]
+        if self.rank == 0:
+            abi.check(self.lib.zh_comm_unique_id(uid), "zh_comm_unique_id")
+            payload = [bytes(uid)]
+        if self.world > 1:
+            if not use_dist:
+                raise abi.ZangHipError("Comm(world > 1) needs torch.distributed as the host channel for the id")
+            dist.broadcast_object_list(payload, src=0, group=control_group)
+            C.memmove(uid, payload[0], abi.COMM_ID_BYTES)
+        h = C.c_void_p()
+        abi.check(self.lib.zh_comm_create(ctx.handle, self.world, self.rank, uid, C.byref(h)), "zh_comm_create")
+        self.handle = h
+
+    def allreduce_mix(self, mix):
+        """Sum `mix` (contiguous float32 tensor on the context's device) over the ranks in place, on the context's stream."""
+        self._abi.check(self.lib.zh_allreduce_mix(self.handle, C.c_void_p(mix.data_ptr()), mix.numel()), "zh_allreduce_mix")
+        return mix
+
+    def reduce_mix(self, mix, root=0):
+        """Like allreduce_mix, but only `root` ends up with the sum (the other ranks' `mix` is unspecified)."""
+        self._abi.check(self.lib.zh_reduce_mix(self.handle, C.c_void_p(mix.data_ptr()), mix.numel(), root), "zh_reduce_mix")
+        return mix
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.zh_comm_destroy(self.handle)
+            self.handle = None
 
 
 class DevicePtr:
