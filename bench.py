@@ -53,16 +53,20 @@ def parse(argv=None):
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default 4096; 131072 for nice_mix on several GPUs)")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--channels", type=int, default=2, choices=[1, 2], help="nice_mix: output channels of the mixdown (north_star: stereo)")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "p2p"],
-                    help="nice_mix on several GPUs: RCCL all-reduce, or direct stores into the root's slots + fixed-order sum")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch", "p2p"],
+                    help="nice_mix on several GPUs: RCCL all-reduce through the library's own communicator (C ABI zh_comm_* / "
+                         "zh_allreduce_mix, on the launch stream), the same through torch.distributed, or direct stores into the "
+                         "root's slots + fixed-order sum")
     ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline sample length")
     ap.add_argument("--repeats", type=int, default=None, help="further K-step regions timed after the first (default: up to 30 when the region is short)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of one buffer")
     ap.add_argument("--no-config5", action="store_true", help="N=1: skip the extra config-5 shard measurement")
-    ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write exchange measured beside the RCCL one")
-    ap.add_argument("--p2p-timeout", type=float, default=180.0, help="N>1: seconds the direct-write comparison may take before the run is ended with the line measured so far")
+    ap.add_argument("--p2p-compare", action="store_true",
+                    help="N>1: after the line is complete, also measure the direct-write exchange beside the RCCL one (opt-in: a stalled "
+                         "peer mapping ends the run with exit code 4 after --p2p-timeout, the line printed first)")
+    ap.add_argument("--p2p-timeout", type=float, default=180.0, help="N>1 with --p2p-compare: seconds the comparison may take")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
     return ap.parse_args(argv)
@@ -130,6 +134,8 @@ class Workload:
         self.world = world
         self.channels, self.exchange_kind = channels, exchange
         self.slots = None
+        self.comm = None                # sharding.Comm (the library's RCCL communicator) when --exchange rccl
+        self.batch_rows = 48            # rows of self.mixes one batch fills (a graph shorter than the note pattern fills fewer)
         from zang_amd import modules as mod, zang, workloads
         self.name, self.V, self.F = name, V, F
         self.ctx = ctx
@@ -214,7 +220,10 @@ class Workload:
         no remainder of the timed steps has to be launched one by one from Python (~2x slower per step at the
         16 MiB size).  (Any count works: the oscillators' double-buffered state is reconciled by zh_graph_launch.)"""
         if self.name in ("nice", "nice_mix", "script"):
-            return 48                       # the note on/off pattern repeats every 48 buffers
+            # the note on/off pattern repeats every 48 buffers; a timed region shorter than that (the driver's 20 steps)
+            # is captured whole -- buffers 0..K-1 of the pattern (note on: attack, decay, sustain) -- so that it replays
+            # as one graph instead of K launches from Python
+            return steps if 2 <= steps < 48 else 48
         if os.environ.get("ZH_BENCH_G"):
             return int(os.environ["ZH_BENCH_G"])   # experiments
         g = max(self.nring, 2)
@@ -290,11 +299,24 @@ class Workload:
         offline renderer only needs the mixed audio once the batch is done."""
         if self.name != "nice_mix" or self.world <= 1:
             return
+        block = self.mixes[:self.batch_rows]
         if self.slots is not None:
             self.slots.finish(self.mixes)
+        elif self.comm is not None:
+            self.comm.allreduce_mix(block)          # zh_allreduce_mix: RCCL on the launch stream, right behind the batch's kernels
         else:
             from zang_amd import sharding
-            sharding.allreduce_mix(self.mixes)
+            sharding.allreduce_mix(block)
+
+    def exchange_per_buffer(self):
+        """The other granularity SURVEY.md 8e asks about: one collective per buffer ([channels][frames], 4-8 KiB) the way
+        the reference's loop mixes per buffer (examples/write_wav.zig:58-93) -- `batch_rows` collectives instead of one."""
+        for b in range(self.batch_rows):
+            if self.comm is not None:
+                self.comm.allreduce_mix(self.mixes[b])
+            else:
+                from zang_amd import sharding
+                sharding.allreduce_mix(self.mixes[b])
 
 
 def zig_probe():
@@ -459,7 +481,7 @@ def rocprof_record(args, V):
     tag = {4096: "4096", 65536: "65536", 131072: "131072", 1048576: "1M"}.get(V)
     if tag is None:
         return None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, f"{args.workload}{tag}_kernel_stats.csv")
         if not os.path.exists(path):
             continue
@@ -471,6 +493,24 @@ def rocprof_record(args, V):
             return {"file": f"profiles/{rnd}/{args.workload}{tag}_kernel_stats.csv", "kernel": best.get("Name", "")[:80],
                     "calls": int(float(best.get("Calls", 0) or 0)), "average_us": float(best.get("AverageNs", 0) or 0) / 1e3}
     return None
+
+
+def build_record(lib):
+    """What was measured: the library's version string, the commit and flags __graft_entry__.build() recorded beside the
+    library (zang_amd/build_info.json -- .git does not travel to the GPU box), whether an alternative library was forced."""
+    rec = {"zh_version": lib.zh_version().decode(), "build_mode": "in-tree make (zang_amd/csrc/Makefile: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize)"}
+    if os.environ.get("ZANG_HIP_LIB"):
+        rec["build_mode"] = "ZANG_HIP_LIB=" + os.environ["ZANG_HIP_LIB"] + " (an alternative build forced through the environment)"
+    info = os.path.join(ROOT, "zang_amd", "build_info.json")
+    if os.path.exists(info):
+        try:
+            rec.update(json.load(open(info)))
+        except ValueError:
+            pass
+    switches = sorted(k for k in os.environ if k.startswith("ZH_") and k not in ("ZH_BENCH_EMULATE",))
+    if switches:
+        rec["switches_in_environment"] = {k: os.environ[k] for k in switches}
+    return rec
 
 
 def dry_run(args, world, rank):
@@ -554,6 +594,19 @@ def main():
     ctx = zang_amd.Context(device_index)
     V, F = args.voices, args.frames
     lib = ctx.lib
+    # --exchange rccl: the library's own communicator (zh_comm_*, librccl opened by libzang_hip.so); torch.distributed only
+    # carries rank 0's 128-byte id.  Two ranks emulated on one device cannot form an RCCL communicator: gloo stays there.
+    comm, comm_note = None, None
+    if world > 1 and args.exchange == "rccl" and args.workload == "nice_mix":
+        if emulate:
+            comm_note = "ZH_BENCH_EMULATE: ranks share one device, no RCCL communicator; torch.distributed gloo instead"
+        else:
+            from zang_amd import sharding
+            try:
+                comm = sharding.Comm(ctx, control_group=ctl)
+            except Exception as e:      # noqa: BLE001  (every rank raises together: Comm agrees on availability first)
+                comm_note = f"zh_comm unavailable ({type(e).__name__}: {e}); torch.distributed nccl instead"[:300]
+                sys.stderr.write(f"bench.py rank {rank}: {comm_note}\n")
 
     def barrier():
         if world > 1:
@@ -580,6 +633,7 @@ def main():
             self.wl = Workload(name, ctx, voices, F, first_voice=rank * voices, ring_bytes=args.ring_mib << 20, world=world,
                                pad=args.pad_voices, channels=args.channels, exchange=exchange)
             wl = self.wl
+            wl.comm = comm if exchange == "rccl" else None
             self.with_exchange = True
             if slots:
                 from zang_amd import sharding
@@ -593,6 +647,9 @@ def main():
                 for _ in range(self.G):          # one eager pass first: lazy allocations happen outside capture
                     wl.step()
                 torch.cuda.synchronize()
+                if hasattr(wl, "nsteps"):
+                    wl.nsteps = 0               # the graph holds buffers 0..G-1 of the note pattern
+                wl.batch_rows = min(self.G, 48)
                 self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)])
             self.ev0, self.ev1 = make_event(), make_event()
 
@@ -695,20 +752,44 @@ def main():
 
     if world > 1 and mixdown:
         # ---- the exchange step on its own, and the same shard without it (scaling factor) ----
-        nbytes = wl.mixes.numel() * 4
+        rows = wl.batch_rows
+        nbytes = wl.mixes[:rows].numel() * 4
         n_ex = 20
-        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_ex):
-            wl.exchange()
-        torch.cuda.synchronize()
-        reduce_us = max_over_ranks((time.perf_counter() - t0) / n_ex) * 1e6
+
+        def time_exchange(fn):
+            fn(); torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_ex):
+                fn()
+            torch.cuda.synchronize()
+            return max_over_ranks((time.perf_counter() - t0) / n_ex) * 1e6
+        reduce_us = time_exchange(wl.exchange)
         seen = torch.ones(1, device="cpu" if emulate else "cuda"); dist.all_reduce(seen)
-        kind = "direct stores into the root's slots + rank-ordered sum (zh_sum_slots), host barriers" if wl.slots is not None else "all_reduce(sum)"
-        out["collective"] = {"backend": "host barriers + HIP IPC" if wl.slots is not None else dist.get_backend(), "kind": kind,
-                             "world_size_seen": int(seen.item()),
-                             "bytes": nbytes, "per": "48-buffer batch", "reduce_us": reduce_us, "in_timed_region": True,
-                             "reduce_us_per_buffer": reduce_us / 48}
+        if wl.slots is not None:
+            backend, kind = "host barriers + HIP IPC", "direct stores into the root's slots + rank-ordered sum (zh_sum_slots), host barriers"
+        elif wl.comm is not None:
+            backend = "rccl %d via zh_allreduce_mix (libzang_hip.so opened %s)" % (lib.zh_comm_version(), lib.zh_comm_library().decode())
+            kind = "all_reduce(sum) on the launch stream (C ABI zh_comm_*; torch.distributed carried the 128-byte id only)"
+        else:
+            backend, kind = "torch.distributed " + dist.get_backend(), "all_reduce(sum)"
+        out["collective"] = {"backend": backend, "kind": kind, "world_size_seen": int(seen.item()),
+                             "bytes": nbytes, "per": f"{rows}-buffer batch", "reduce_us": reduce_us, "in_timed_region": True,
+                             "reduce_us_per_buffer": reduce_us / rows}
+        if comm_note:
+            out["collective"]["note"] = comm_note
+        if wl.slots is None:
+            # the same sum as ONE COLLECTIVE PER BUFFER (4-8 KiB each, the reference's per-buffer mix) -- which
+            # granularity is latency-bound: `rows` small collectives against one of rows x the bytes
+            per_buf_us = time_exchange(wl.exchange_per_buffer) / rows
+            out["collective"]["per_buffer_form"] = {"bytes": nbytes // rows, "reduce_us": per_buf_us,
+                                                    "x_batch_form_per_buffer": per_buf_us / (reduce_us / rows),
+                                                    "what": f"one all-reduce per buffer, {rows} back to back on the launch stream, per collective"}
+            if wl.comm is not None:
+                # and the torch.distributed form of the batch collective beside the library's
+                keep = wl.comm
+                wl.comm = None
+                out["collective"]["torch_distributed_form_reduce_us"] = time_exchange(wl.exchange)
+                wl.comm = keep
         main_run.with_exchange = False
         e1, _ = main_run.region(K)
         main_run.with_exchange = True
@@ -717,17 +798,18 @@ def main():
                                    "what": "the same K steps on every rank without the exchange (slowest rank)"}
         out["scaling_factor"] = value / single
         out["realtime_voices_48k"] = value / SR
-        if not args.no_p2p and wl.slots is None:
+        if args.p2p_compare and wl.slots is None:
             # the alternative SURVEY.md 8e asks to measure beside the collective.  It is the comparison, not the
-            # measurement: if it stalls (a peer mapping or a host barrier that never returns on some machine), a watchdog
-            # on EVERY rank ends the run after `--p2p-timeout` seconds -- rank 0 prints the line it already has first.
+            # measurement, and opt-in (--p2p-compare): if it stalls (a peer mapping or a host barrier that never returns on some
+            # machine), a watchdog on EVERY rank ends the run after `--p2p-timeout` seconds with exit code 4 -- rank 0 prints the
+            # line it already has first.
             import threading
 
             def give_up():
                 if rank == 0:
                     out["p2p_direct"] = {"error": f"no result within {args.p2p_timeout:.0f} s; the run was ended by the watchdog"}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(4)                      # distinct from a crash: the line is complete, the opt-in comparison stalled
             dog = threading.Timer(args.p2p_timeout, give_up)
             dog.daemon = True
             dog.start()
@@ -796,6 +878,9 @@ def main():
         if cb:
             out["cpu_baseline"] = cb
     main_run.close()
+    if comm is not None:
+        comm.close()
+    out["build"] = build_record(lib)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

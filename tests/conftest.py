@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# libzang_hip.so remembers its form switches (ZH_*_RANGES, ZH_*_PC_MAX, ...) after the first look-up unless this is set when
+# it is loaded: the parity tests flip switches between paints to force every kernel form (csrc/ctx.hip zh_env)
+os.environ["ZH_ENV_LIVE"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -19,7 +19,7 @@ def _sources():
 def test_environment_switches_are_documented():
     doc = set(re.findall(r"ZH_[A-Z0-9_]+", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
     src = _sources()
-    read = set(re.findall(r'getenv\("(ZH_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ(?:\.get\(|\[)"(ZH_[A-Z0-9_]+)"', src))
+    read = set(re.findall(r'(?:getenv|zh_env)\("(ZH_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ(?:\.get\(|\[)"(ZH_[A-Z0-9_]+)"', src))
     assert read, "no getenv found: the scan is broken"
     undocumented = sorted(read - doc)
     assert not undocumented, f"read but not in INTEGRATION.md: {undocumented}"

@@ -291,3 +291,47 @@ def test_round2_forms_in_graphs_equal_eager(ctx):
                 assert se.tobytes() == sg.tobytes(), name
         g.close()
         c2.close()
+
+
+def test_graph_of_in_place_paints_survives_flipping_paints_between_replays(ctx):
+    """A graph that holds ONLY short-span paints of double-buffered modules (spans under 128 frames take the in-place
+    one-walk form and do not flip the state buffers) bakes in the buffer the capture saw.  An eager 1024-frame paint
+    in between takes the frame-range form and flips: the replay must first find the live state where it was baked
+    (zh_flipper_used / zh_graph_launch).  Twin modules doing the same sequence eagerly are the reference."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V = 512
+    freq, _, _, _ = workloads.voice_params(2, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        fr = torch.from_numpy(freq).cuda()
+        on = torch.from_numpy((np.arange(V) % 3 != 0).astype(np.uint8)).cuda()
+        off = torch.zeros(V, dtype=torch.uint8, device="cuda")
+        short, full = zang.Span(0, 64), zang.Span(0, F)
+
+        def make():
+            return mod.SineOsc(V, c2), mod.Envelope(V, c2)
+
+        def paint(ms, span, img, note_on, new):
+            osc, env = ms
+            osc.paint(span, [img], [], False, osc.Params(SR, zang.constant(fr), zang.constant(0.0)), zero_first=True)
+            env.paint(span, [img], [], new, env.Params(SR, zang.PaintCurve.cubed(0.05), zang.PaintCurve.linear(0.2), zang.PaintCurve.squared(0.1), 0.6, note_on))
+
+        me, mg = make(), make()
+        img_e, img_g = [c2.image(F, V) for _ in range(2)], [c2.image(F, V) for _ in range(2)]
+        paint(me, short, img_e[0], on, True); paint(mg, short, img_g[0], on, True)     # warm (and note on)
+        c2.sync()
+        g = c2.capture(lambda: paint(mg, short, img_g[0], on, False))                  # in-place forms only: no flips recorded
+        for k in range(3):
+            paint(me, short, img_e[0], on, False); g.launch()
+            paint(me, full, img_e[1], on if k != 1 else off, False)                    # frame-range forms: flip the state buffers
+            paint(mg, full, img_g[1], on if k != 1 else off, False)
+            paint(me, short, img_e[0], on, False); g.launch()
+            c2.sync()
+            for a, b in zip(img_e, img_g):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), k
+            for a, b in zip(me, mg):
+                assert a.state().tobytes() == b.state().tobytes(), k
+        g.close(); c2.close()

@@ -695,3 +695,40 @@ def test_gpu_script_envelope_stage_ends_inside_replays(ctx, ranges, monkeypatch)
         ctx.sync()
         assert_bitexact(from_image(img), ref, "Stages paint %d" % k)
     prog.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranges", [None, "0", "5"])
+def test_gpu_script_in_place_param_image_keeps_one_walk(ctx, ranges, monkeypatch):
+    """A cob param whose image IS the output image (an in-place use): a frame-range launch would replay input rows that
+    another range is overwriting, so zh_script_module_paint must keep the one-walk form for such a paint (as the builtin
+    modules do with bufs_alias).  Against the interpreter, which paints sample by sample like the reference."""
+    import torch
+    from oracle import zs_interp
+    from tests.util import assert_bitexact, from_image, to_image
+    from zang_amd import script, zang
+    if ranges is None:
+        monkeypatch.delenv("ZH_SCRIPT_RANGES", raising=False)
+    else:
+        monkeypatch.setenv("ZH_SCRIPT_RANGES", ranges)
+    nv, nf = 200, 512
+    prog = script.ScriptProgram(STAGES_SCRIPT, ctx, only=["Stages"])
+    mod = prog.module("Stages", nv, 0)
+    assert mod.frame_ranges_ok
+    voices = zs_interp.make_voices(zs.compile(prog.text, prog.filename), "Stages", nv, 0)
+    rng = np.random.default_rng(5)
+    ref = rng.uniform(60, 900, (nv, nf)).astype(np.float32)          # the image holds the frequencies and receives `+=`
+    img = to_image(ref)
+    order = [p[0] for p in mod.params]
+    for k, (s, e) in enumerate([(0, nf), (0, nf), (64, 400)]):
+        on = rng.random(nv) < 0.7
+        nic = np.ones(nv, bool)
+        mod.paint(zang.Span(s, e), [img], None, torch.from_numpy(nic.astype(np.uint8)).cuda(),
+                  {"sample_rate": 8000.0, "freq": img, "note_on": _device_value(None, on)})
+        for v in range(nv):
+            # the reference reads freq[i] before it adds into out[i] of the same frame: a copy of the row as it was
+            vals = {"sample_rate": np.float32(8000.0), "freq": ref[v].copy(), "note_on": bool(on[v])}
+            voices[v].paint(s, e, ref[v], True, [vals[kk] for kk in order])
+        ctx.sync()
+        assert_bitexact(from_image(img), ref, "in-place Stages paint %d" % k)
+    prog.close()

@@ -72,11 +72,13 @@ struct ZhDeviceGuard {
 // ctx.hip: registry of live flippers + the capture log
 void zh_flipper_register(zh_flipper *f);
 void zh_flipper_unregister(zh_flipper *f);
+void zh_flipper_used(zh_flipper *f);         // call at the start of EVERY paint of a flipper module (in-place forms too)
 void zh_flipper_painted(zh_flipper *f);      // call right BEFORE flipping f->cur in a paint
 
 // ctx.hip: frames per range for a kernel that paints a span as several frame ranges at once, each replaying the cheap state
 // walk of the frames before it (0 = paint sequentially).  `env_name` = number of ranges, 0 = never; `target_waves` = waves
 // the launch should reach (ranges = target_waves / waves of one range); `max_voices` = above it the sequential form wins.
+const char *zh_env(const char *name);       // getenv for the form switches read on the paint path: cached unless ZH_ENV_LIVE=1 (ctx.hip)
 uint32_t zh_range_frames(uint32_t V, uint32_t n, const char *env_name, uint32_t target_waves, uint32_t max_voices);
 
 struct zh_event {

@@ -183,12 +183,14 @@ __device__ __forceinline__ void nice_store(NiceLaneT<W> &n, const NiceArgs &a, u
 // and select (4.2 cycles each, no packed form) is paid twice.  ZH_NICE_W=2 selects it for A/B timing;
 // it needs an even voice count and 8-byte aligned rows / per-voice arrays.
 static uint32_t nice_pc_max() {
-    static const uint32_t v = [] { const char *e = getenv("ZH_NICE_PC_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u; }();   // 72 vs 146 us at 4,096 voices, 107 vs 168 at 65,536; slower at 131,072
+    const char *e = zh_env("ZH_NICE_PC_MAX");
+    const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u;   // 72 vs 146 us at 4,096 voices, 107 vs 168 at 65,536; slower at 131,072
     return v;
 }
 static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 static bool nice_pairable(const NiceArgs &a) {
-    static const bool want2 = [] { const char *e = getenv("ZH_NICE_W"); return e && e[0] == '2'; }();
+    const char *we = zh_env("ZH_NICE_W");
+    const bool want2 = we && we[0] == '2';
     return want2 && a.V % 2 == 0 && aligned8(a.freq.pv) && aligned8(a.color) && aligned8(a.cnt) && aligned8(a.fl) && aligned8(a.fb) &&
            aligned8(a.estate) && aligned8(a.et) && aligned8(a.elast) && aligned8(a.estart);
 }
@@ -1439,8 +1441,8 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
         // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 4,096 / 16,384 / 32,768 voices 44 / 47 / 53.5 us against 60.5 / 62.5 /
         // 63 for the three-wave form; its 64 KB of LDS per workgroup allow two workgroups per CU = 32,768 voices, beyond that
         // the three-wave form stays (65,536 voices: 82 us against 111)
-        static int pc4_max = -1;
-        if (pc4_max < 0) { const char *e = getenv("ZH_NICE_PC4_MAX"); pc4_max = e ? atoi(e) : 32768; }
+        const char *pe = zh_env("ZH_NICE_PC4_MAX");
+        const int pc4_max = pe ? atoi(pe) : 32768;
         if (m->n <= (uint32_t)pc4_max) {
             if (zf) hipLaunchKernelGGL(k_nice_pc4<true>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
             else hipLaunchKernelGGL(k_nice_pc4<false>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
@@ -1455,7 +1457,8 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     return zh_launch_status();
 }
 static bool nice_mix_roll() {
-    static const bool v = [] { const char *e = getenv("ZH_NICE_MIX_ROLL"); return e ? atoi(e) != 0 : true; }();   // A/B switch: 149.6 vs 148.2 us at 131,072 voices, 908 vs 890 us at 1,048,576
+    const char *e = zh_env("ZH_NICE_MIX_ROLL");
+    const bool v = e ? atoi(e) != 0 : true;   // A/B switch: 149.6 vs 148.2 us at 131,072 voices, 908 vs 890 us at 1,048,576
     return v;
 }
 static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
@@ -1516,7 +1519,8 @@ int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *
     zh_bool no = {0, 0, nullptr};
     NiceArgs a = nice_args(m, &p, no);
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
-    static const int wave_max = [] { const char *e = getenv("ZH_NICE_WAVE_MAX"); return e ? atoi(e) : 64; }();
+    const char *wme = zh_env("ZH_NICE_WAVE_MAX");
+    const int wave_max = wme ? atoi(wme) : 64;
     if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
         if (zf) hipLaunchKernelGGL(k_nice_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
         else hipLaunchKernelGGL(k_nice_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
@@ -1623,10 +1627,12 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     }
     // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at
     // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both
-    static const uint32_t pc_max = [] { const char *e = getenv("ZH_NF_PC_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u; }();
+    const char *pce = zh_env("ZH_NF_PC_MAX");
+    const uint32_t pc_max = pce ? (uint32_t)strtoul(pce, nullptr, 10) : 65536u;
     // White noise at small voice counts: three producer waves, a filter wave and a writer wave per 64 voices
     // (k_noise_filter_ring).  ZH_NF_RING_MAX: largest voice count that takes it.
-    static const uint32_t ring_max = [] { const char *e = getenv("ZH_NF_RING_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u; }();
+    const char *rge = zh_env("ZH_NF_RING_MAX");
+    const uint32_t ring_max = rge ? (uint32_t)strtoul(rge, nullptr, 10) : 16384u;
     if (!pink && m->n <= ring_max && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
         const uint4 *tables = zh_noise_jump_tables(m->ctx);
         if (tables) {
@@ -1724,6 +1730,7 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
     (void)temps;
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     hipStream_t st = m->ctx->stream;
     m->view();
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, p->sample_rate,
@@ -1752,12 +1759,14 @@ int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf
     (void)temps;
     if (!m || !outputs || end < start || !buf_covers(outputs[0], m->n, end) || !span_table_ok(table)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     hipStream_t st = m->ctx->stream;
     m->view();
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, sample_rate,
                 F32P{0.0f, nullptr}, BoolP{0, nullptr}, BoolP{0, nullptr}};
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
-    static const int wave_max = [] { const char *e = getenv("ZH_PMOSC_WAVE_MAX"); return e ? atoi(e) : 64; }();
+    const char *wme = zh_env("ZH_PMOSC_WAVE_MAX");
+    const int wave_max = wme ? atoi(wme) : 64;
     if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
         if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
         else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);

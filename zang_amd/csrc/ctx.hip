@@ -2,6 +2,7 @@
 #include "common.hip.h"
 #include <string.h>
 #include <vector>
+#include <string>
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
@@ -20,6 +21,16 @@ void zh_flipper_unregister(zh_flipper *f) {
     std::lock_guard<std::mutex> lk(g_flip_mu);
     g_flippers.erase(f->id);
 }
+// A paint of a flipper module during a capture, whether it will flip or paint in place on cnt[cur]: the graph bakes in
+// cnt[cur as of now], so a replay must find the live state there (zh_graph_launch copies it over when later flipping
+// paints -- eager range-form paints, other graphs -- have moved it to the other buffer).
+void zh_flipper_used(zh_flipper *f) {
+    zh_ctx *c = f->ctx;
+    if (!c->capturing) return;
+    for (const zh_flip_use &u : c->capture_log)
+        if (u.id == f->id) return;
+    c->capture_log.push_back(zh_flip_use{f->id, f, f->cur, 0u});
+}
 void zh_flipper_painted(zh_flipper *f) {
     zh_ctx *c = f->ctx;
     if (!c->capturing) return;
@@ -28,10 +39,30 @@ void zh_flipper_painted(zh_flipper *f) {
     c->capture_log.push_back(zh_flip_use{f->id, f, f->cur, 1u});
 }
 
+// Form switches (ZH_*_RANGES, ZH_*_PC_MAX, ...) are looked up on the paint path: a paint at 4,096 voices is ~4 us of
+// launch, and every getenv is a walk over the whole environment.  A switch is therefore read from the environment ONCE
+// and remembered -- unless ZH_ENV_LIVE=1 was set when the library was loaded (tests/conftest.py does: the parity tests
+// flip switches between paints to force every kernel form).
+const char *zh_env(const char *name) {
+    static const bool live = [] { const char *e = getenv("ZH_ENV_LIVE"); return e && e[0] == '1'; }();
+    if (live) return getenv(name);
+    struct Entry { const char *name; std::string value; bool set; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry &e : seen)
+        if (e.name == name || strcmp(e.name, name) == 0) return e.set ? e.value.c_str() : nullptr;
+    if (seen.capacity() < 64) seen.reserve(64);               // entries never move: the returned pointers stay valid
+    if (seen.size() >= 64) return getenv(name);
+    const char *v = getenv(name);
+    seen.push_back(Entry{name, v ? v : "", v != nullptr});
+    return seen.back().set ? seen.back().value.c_str() : nullptr;
+}
+
 uint32_t zh_range_frames(uint32_t V, uint32_t n, const char *env_name, uint32_t target_waves, uint32_t max_voices) {
-    const char *e = getenv(env_name);
+    const char *e = zh_env(env_name);
     const int forced = e ? atoi(e) : -1;                                          // 0 = off, k = k ranges
-    const char *ew = getenv("ZH_REPLAY_WAVES"), *ev = getenv("ZH_REPLAY_MAXV");   // experiments: override every caller's tuning
+    const char *ew = zh_env("ZH_REPLAY_WAVES"), *ev = zh_env("ZH_REPLAY_MAXV");   // experiments: override every caller's tuning
     if (ew) target_waves = (uint32_t)atoi(ew);
     if (ev) max_voices = (uint32_t)atoi(ev);
     if (forced == 0 || V == 0 || n < 128 || V > max_voices) return 0;

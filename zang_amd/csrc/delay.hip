@@ -466,7 +466,7 @@ int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outp
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
     // delay 300, 1,024 frames, walk -> independent frames (three launches): 57 -> 13 us at 4,096 voices, 75 -> 31 at 16,384,
     // 423 -> 271 at 131,072: at every voice count
-    const char *fe = getenv("ZH_DELAY_FRAMES_MAX");                     // read at every paint (tests switch forms)
+    const char *fe = zh_env("ZH_DELAY_FRAMES_MAX");                     // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
     const uint32_t frames_max = fe ? (uint32_t)atoi(fe) : 0xFFFFFFFFu;
     if (chunked && m->d.n <= frames_max && end - start >= 64) {
         hipStream_t st = m->ctx->stream;
@@ -539,7 +539,7 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
     // delay 300, one wave per 64 voices -> three: 1,024 / 4,096 / 16,384 / 32,768 / 65,536 voices 88 / 91 / 103 / 194 / 263 ->
     // 56 / 57 / 62 / 110 / 215 us; at 131,072 voices the one-wave form is ahead (406 against 461)
-    const char *pe = getenv("ZH_ECHOES_PC_MAX");                        // read at every paint (tests switch forms)
+    const char *pe = zh_env("ZH_ECHOES_PC_MAX");                        // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
     const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 65536u;
     if (chunked && m->d.n <= pc_max && m->d.delay_samples >= 192 && end - start >= 64) {
         if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_filtered_echoes_pc<true>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));

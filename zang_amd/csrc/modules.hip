@@ -1107,6 +1107,7 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     if (rc) return rc;
     if (!p || !cob_ok(p->freq, m->n, end) || !cob_ok(p->phase, m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     const bool fb = p->freq.tag == ZH_COB_BUFFER, pb = p->phase.tag == ZH_COB_BUFFER;
@@ -1228,7 +1229,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     const bool pink = p->color == ZH_NOISE_PINK;
     // pink, 1,024 / 4,096 / 16,384 / 32,768 voices: 124 / 116 / 118 / 130 us in one loop, 57 / 67 / 84 / 161 us as white ranges +
     // the seven-stage chain (the white kernel is 10-29 us of that), 43 / 54 / 68 / 123 us as white ranges + k_pink_taps
-    const char *pe = pink ? getenv("ZH_PINK_PIPE_MAX") : nullptr;     // read at every paint (tests switch forms)
+    const char *pe = pink ? zh_env("ZH_PINK_PIPE_MAX") : nullptr;     // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
     const uint32_t pink_max = pe ? (uint32_t)atoi(pe) : 32768u;
     if (ch && (!pink || m->n <= pink_max)) {
         if (zf && !pink) {
@@ -1247,7 +1248,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                 if (rc == ZH_OK && !pink) return zh_add_into(m->ctx, start, end, outputs[0], m->scratch);
                 if (rc == ZH_OK) {
                     const dim3 grid((m->n + 63) / 64);
-                    const char *te = getenv("ZH_PINK_TAPS");              // 0 = the chain of seven stages (k_pink_pipe)
+                    const char *te = zh_env("ZH_PINK_TAPS");              // 0 = the chain of seven stages (k_pink_pipe)
                     const bool taps = (!te || atoi(te) != 0) && end - start >= 32 && outputs[0].stride <= (1u << 24) && m->scratch.stride <= (1u << 24);   // (32-row tiles: 32-bit offsets)
                     if (taps && m->n <= 16384 && !(te && atoi(te) == 16)) {   // (ZH_PINK_TAPS=16 forces the 16-frame tiles)
                         if (zf) hipLaunchKernelGGL((k_pink_taps<true, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
@@ -1326,6 +1327,7 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
     if (rc) return rc;
     if (!p || !curve_ok(p->attack) || !curve_ok(p->decay) || !curve_ok(p->release)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;            // an empty span still runs the state prologue (Envelope.zig:41-50)
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     const int ft = p->attack.tag == p->decay.tag && p->decay.tag == p->release.tag && p->attack.tag != ZH_CURVE_INSTANTANEOUS ? (int)p->attack.tag : -1;
@@ -1469,9 +1471,9 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     // few voices, constant cutoff / resonance: the three-wave pipeline (1,024 / 4,096 / 16,384 / 32,768 voices: 54.5 / 56.1 /
     // 57.3 / 75.8 us in one wave, 41 / 41.8 / 45 / 51 us; its 64 KB of LDS per workgroup allow 32,768 voices at once, with
     // 16-frame tiles it goes on to 65,536 voices)
-    const char *pe = getenv("ZH_FILTER_PC_MAX");                        // read at every paint (tests switch forms)
+    const char *pe = zh_env("ZH_FILTER_PC_MAX");                        // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
     const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 32768u;
-    const char *pe16 = getenv("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
+    const char *pe16 = zh_env("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
     const uint32_t pc16_max = pe16 ? (uint32_t)atoi(pe16) : (pe && pc_max == 0 ? 0u : 65536u);   // (ZH_FILTER_PC_MAX=0 alone switches both off)     // 36,864 / 49,152 / 65,536 voices: 97 / 103 / 116 us in one wave, 72 / 79 / 104; 81,920: 126 against 168
     if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
         const dim3 grid((m->n + 63) / 64);
@@ -1543,6 +1545,7 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
     if (rc) return rc;
     if (!p || p->sample.format > ZH_SAMPLE_S32_LSB || (p->sample.data_len && !p->sample.data)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     zh_buf o = outputs[0];
@@ -1637,6 +1640,7 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     if (rc) return rc;
     if (!p || !buf_covers(p->input, m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;            // an empty span still resets state when fake >= sample_rate (:37-38)
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     // 4,096 voices: 94 us sequential with per-lane branches, 39 straight-line, 31 as 16 frame ranges (the replay is 8 issue
@@ -1709,6 +1713,7 @@ int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, cons
     if (rc) return rc;
     if (!p || p->function > ZH_CURVE_FN_SMOOTHSTEP || (p->curve_len && !p->curve) || p->curve_len > 0xFFFFFFFFull) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;            // an empty span still resets on note_id_changed (:66-71)
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     // 4,096 voices: 89 us with a span search behind a per-lane test in every unrolled frame; 36.5 us with the spans streamed
@@ -1745,6 +1750,7 @@ int zh_cycle_paint(zh_cycle *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (rc) return rc;
     if (!p || !cob_ok(p->speed, m->n, end)) return ZH_ERR_INVALID;
     if (m->n == 0 || end == start) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     Img out = mk_img(outputs[0]);
@@ -1809,6 +1815,7 @@ int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh
     if (rc) return rc;
     if (!p || !curve_ok(p->curve)) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;            // an empty span still applies newCurve / the instantaneous jump
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     const int c = m->cur;

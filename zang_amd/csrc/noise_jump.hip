@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(64) k_noise_fix(uint64_t *__restrict__ s0, uin
 // Frames per range for V voices over n frames, or 0 = use the sequential kernel.  Measured on MI355X
 // (profiles/r02/noise_ranges.txt): enough ranges for about one wave per SIMD (1,024), at least 32 frames each.
 uint32_t zh_noise_range_frames(uint32_t V, uint32_t n) {
-    static const int forced = [] { const char *e = getenv("ZH_NOISE_RANGES"); return e ? atoi(e) : -1; }();   // 0 = off, k = k ranges
+    const char *fe = zh_env("ZH_NOISE_RANGES");                          // 0 = off, k = k ranges; live under ZH_ENV_LIVE=1 like the other switches
+    const int forced = fe ? atoi(fe) : -1;
     if (forced == 0 || V == 0 || n < 128 || n > 2048 || V > 65536) return 0;
     const uint32_t waves = (V + 63) / 64;
     uint32_t want = forced > 0 ? (uint32_t)forced : (V <= 32768 ? 1024u : 2048u) / waves;

@@ -591,6 +591,7 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
     int rc = osc_common_check(m, start, end, outputs, nb, p->sample_rate, p->freq);
     if (rc) return rc;
     if (m->n == 0 || end == start || nb == 0) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     if (p->freq.tag == ZH_COB_CONSTANT) {
@@ -611,8 +612,8 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
             const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
             // the ranges' own sums first (1,024 / 4,096 / 16,384 voices: 28.6 / 36.7 / 49.3 -> 14.6 / 16.0 / 37.9 us; level from
             // 32,768 voices on); ZH_PULSE_CTRL_SUMS=0: every range replays the frames before it
-            static int sums = -1;
-            if (sums < 0) { const char *e = getenv("ZH_PULSE_CTRL_SUMS"); sums = e ? atoi(e) : 1; }
+            const char *se = zh_env("ZH_PULSE_CTRL_SUMS");
+            const int sums = se ? atoi(se) : 1;
             const uint32_t *part = chr && sums && m->part && grid.y <= 64 ? m->part : nullptr;
             if (part) hipLaunchKernelGGL(k_pulseosc_ctrl_sums, grid, dim3(kSeqBlock), 0, st, m->part, m->n, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer));
             if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col, part);
@@ -680,6 +681,7 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
     int rc = osc_common_check(m, start, end, outputs, nb, p->sample_rate, p->freq);
     if (rc) return rc;
     if (m->n == 0 || end == start || nb == 0) return ZH_OK;
+    zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
     hipStream_t st = m->ctx->stream;
     if (p->freq.tag == ZH_COB_CONSTANT) {
@@ -693,8 +695,8 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
         // ... and 39.3 us (1,024 voices: 43 -> 26) with the quotients painted first (module-owned image, allocated outside a
         // capture; ZH_TRISAW_CTRL_QUOT=0: never).  (Tried: two or four batches of 32 rows kept in flight by an explicit rotation in
         // these replays -- SineOsc 27 -> 40 / 60 us, TriSawOsc 39 -> 45 / 53: slower; the plain batch loops stay.)
-        static int want_quot = -1;
-        if (want_quot < 0) { const char *e = getenv("ZH_TRISAW_CTRL_QUOT"); want_quot = e ? atoi(e) : 1; }
+        const char *qe = zh_env("ZH_TRISAW_CTRL_QUOT");
+        const int want_quot = qe ? atoi(qe) : 1;
         bool quot = false;
         if (chr && want_quot) {
             if ((m->quot.frames < end || !m->quot.ptr) && !m->ctx->capturing) {
