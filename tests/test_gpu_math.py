@@ -45,6 +45,51 @@ def test_sin_cos_bitexact(ctx, oracle, name):
     assert bad.size == 0, (name, bad.size, [(hex(int(xs[i:i + 1].view(np.uint32)[0])), float(got[i]), float(ref[i])) for i in bad[:8]])
 
 
+@pytest.mark.parametrize("name", ["sin", "cos"])
+def test_sin_cos_stratified_2_to_28(ctx, oracle, name):
+    """Round 3: the device's sinf / cosf fuse multiply-add pairs and take fn from musl's magic-number rounding (csrc/zmath.hip.h
+    zsincos_kernels / zreduce_pio2f) -- forms that tools/ubench/sin_exhaustive.hip holds against musl's operation order for ALL
+    2^32 arguments on the device.  Here a 2^28-argument stratified subset (every 16th bit pattern, the offset rotating so that
+    all 16 residues are visited) against the ORACLE's musl restatement on the host: every exponent, both signs, every leaf."""
+    import concurrent.futures as cf
+    import torch
+    from zang_amd import abi
+    L = oracle.lib()
+    fn = getattr(L, "zo_math_%sf_n" % name)
+    n = 1 << 24
+    base = torch.arange(n, dtype=torch.int64, device=ctx.device) * 16
+
+    def chunk(c):
+        bits = (base + (c << 28) + ((c * 7 + 3) % 16)).to(torch.int32)           # patterns [c * 2^28, (c + 1) * 2^28), stride 16
+        x = bits.view(torch.float32)
+        out = torch.empty_like(x)
+        abi.check(getattr(ctx.lib, "zh_" + name)(ctx.handle, n, out.data_ptr(), x.data_ptr()), "zh_" + name)
+        ctx.sync()
+        return x.cpu().numpy(), out.cpu().numpy()
+
+    def check(c, xs, got):
+        ref = np.empty_like(xs)
+        parts = 4
+        for k in range(parts):                                                    # (ctypes releases the GIL: the pool runs these side by side)
+            a, b = k * n // parts, (k + 1) * n // parts
+            fn(oracle.fptr(xs[a:b]), oracle.fptr(ref[a:b]), b - a)
+        nan = np.isnan(ref)
+        assert np.array_equal(np.isnan(got), nan), (name, c)
+        bad = np.nonzero((got.view(np.uint32) != ref.view(np.uint32)) & ~nan)[0]
+        assert bad.size == 0, (name, c, bad.size, [(hex(int(xs[i:i + 1].view(np.uint32)[0])), float(got[i]), float(ref[i])) for i in bad[:8]])
+        return n
+
+    done = 0
+    with cf.ThreadPoolExecutor(max_workers=8) as pool:
+        futs = []
+        for c in range(16):
+            xs, got = chunk(c)
+            futs.append(pool.submit(check, c, xs, got))
+        for f in futs:
+            done += f.result()
+    assert done == 1 << 28
+
+
 def test_sin_cos_rejects_null(ctx):
     assert ctx.lib.zh_sin(ctx.handle, 4, None, None) != 0
     assert ctx.lib.zh_cos(ctx.handle, 0, None, None) == 0

@@ -94,9 +94,15 @@ for name, m, paint, reads in cases:
     for i in range(4):
         paint(out[i & 1])
     ctx.sync()
-    g = ctx.capture(lambda: [paint(out[i & 1]) for i in range(K)])
-    g.launch(); ctx.sync()
-    t0 = time.perf_counter(); g.launch(); ctx.sync(); dt = time.perf_counter() - t0
+    if os.environ.get("ZH_BENCH_EAGER") == "1":            # counter collection (rocprofv3 --pmc) wants plain launches
+        t0 = time.perf_counter()
+        for i in range(K):
+            paint(out[i & 1])
+        ctx.sync(); dt = time.perf_counter() - t0
+    else:
+        g = ctx.capture(lambda: [paint(out[i & 1]) for i in range(K)])
+        g.launch(); ctx.sync()
+        t0 = time.perf_counter(); g.launch(); ctx.sync(); dt = time.perf_counter() - t0
+        g.close()
     us = dt * 1e6 / K
     print("%-46s %10.1f %12.3e %10.2f" % (name, us, V * F / (us * 1e-6), (1 + reads) * V * F * 4 / (us * 1e-6) / 1e12))
-    g.close()

@@ -75,6 +75,14 @@ __global__ void __launch_bounds__(64) k_ops(float *out, unsigned iters, float a,
             if constexpr (KIND == 50) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[0]) : "v"(b) : "vcc");
             if constexpr (KIND == 51) asm volatile("v_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1" : "+v"(p[0]) : "v"(bb));
             if constexpr (KIND == 52) asm volatile("v_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0\n\tv_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0\n\tv_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0\n\tv_mul_f32 %0, 0x3e99999a, %0\n\tv_add_f32 %0, 0xb6800000, %0" : "+v"(x[0]) : "v"(b));
+            if constexpr (KIND == 53) asm volatile("v_fma_f64 %0, %0, %8, %8\n\tv_fma_f64 %1, %1, %8, %8\n\tv_fma_f64 %2, %2, %8, %8\n\tv_fma_f64 %3, %3, %8, %8\n\tv_fma_f64 %4, %4, %8, %8\n\tv_fma_f64 %5, %5, %8, %8\n\tv_fma_f64 %6, %6, %8, %8\n\tv_fma_f64 %7, %7, %8, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb), "v"(b));
+            if constexpr (KIND == 54) asm volatile("v_rndne_f64 %0, %0\n\tv_rndne_f64 %1, %1\n\tv_rndne_f64 %2, %2\n\tv_rndne_f64 %3, %3\n\tv_rndne_f64 %4, %4\n\tv_rndne_f64 %5, %5\n\tv_rndne_f64 %6, %6\n\tv_rndne_f64 %7, %7" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb), "v"(b));
+            if constexpr (KIND == 55) asm volatile("v_add_f64 %0, %0, %8\n\tv_add_f64 %1, %1, %8\n\tv_add_f64 %2, %2, %8\n\tv_add_f64 %3, %3, %8\n\tv_add_f64 %4, %4, %8\n\tv_add_f64 %5, %5, %8\n\tv_add_f64 %6, %6, %8\n\tv_add_f64 %7, %7, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb), "v"(b));
+            if constexpr (KIND == 56) asm volatile("v_cvt_f64_f32 %0, %8\n\tv_cvt_f64_f32 %1, %9\n\tv_cvt_f64_f32 %2, %10\n\tv_cvt_f64_f32 %3, %11\n\tv_cvt_f64_f32 %4, %12\n\tv_cvt_f64_f32 %5, %13\n\tv_cvt_f64_f32 %6, %14\n\tv_cvt_f64_f32 %7, %15" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(bb), "v"(b));
+            if constexpr (KIND == 57) asm volatile("v_cvt_f32_f64 %8, %0\n\tv_cvt_f32_f64 %9, %1\n\tv_cvt_f32_f64 %10, %2\n\tv_cvt_f32_f64 %11, %3\n\tv_cvt_f32_f64 %12, %4\n\tv_cvt_f32_f64 %13, %5\n\tv_cvt_f32_f64 %14, %6\n\tv_cvt_f32_f64 %15, %7" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(bb), "v"(b));
+            if constexpr (KIND == 58) asm volatile("v_cvt_i32_f64 %8, %0\n\tv_cvt_i32_f64 %9, %1\n\tv_cvt_i32_f64 %10, %2\n\tv_cvt_i32_f64 %11, %3\n\tv_cvt_i32_f64 %12, %4\n\tv_cvt_i32_f64 %13, %5\n\tv_cvt_i32_f64 %14, %6\n\tv_cvt_i32_f64 %15, %7" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(bb), "v"(b));
+            if constexpr (KIND == 59) asm volatile("v_cmp_gt_f64 vcc, %0, %8\n\tv_cmp_gt_f64 vcc, %1, %8\n\tv_cmp_gt_f64 vcc, %2, %8\n\tv_cmp_gt_f64 vcc, %3, %8\n\tv_cmp_gt_f64 vcc, %4, %8\n\tv_cmp_gt_f64 vcc, %5, %8\n\tv_cmp_gt_f64 vcc, %6, %8\n\tv_cmp_gt_f64 vcc, %7, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb) : "vcc");
+            if constexpr (KIND == 60) asm volatile("v_mov_b64 %0, %8\n\tv_mov_b64 %1, %8\n\tv_mov_b64 %2, %8\n\tv_mov_b64 %3, %8\n\tv_mov_b64 %4, %8\n\tv_mov_b64 %5, %8\n\tv_mov_b64 %6, %8\n\tv_mov_b64 %7, %8" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(bb), "v"(b));
         }
     }
     float s = 0;
@@ -161,6 +169,14 @@ int main() {
         run<50>(d, "dependent cmp->cndmask chain", 8, w, e0, e1);
         run<51>(d, "dependent f64 mul,add", 8, w, e0, e1);
         run<52>(d, "dependent mul,add w/ literals", 8, w, e0, e1);
+        run<53>(d, "v_fma_f64", 8, w, e0, e1);
+        run<54>(d, "v_rndne_f64", 8, w, e0, e1);
+        run<55>(d, "v_add_f64", 8, w, e0, e1);
+        run<56>(d, "v_cvt_f64_f32", 8, w, e0, e1);
+        run<57>(d, "v_cvt_f32_f64", 8, w, e0, e1);
+        run<58>(d, "v_cvt_i32_f64", 8, w, e0, e1);
+        run<59>(d, "v_cmp_gt_f64 ->vcc", 8, w, e0, e1);
+        run<60>(d, "v_mov_b64", 8, w, e0, e1);
     }
     return 0;
 }

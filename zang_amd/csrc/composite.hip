@@ -639,17 +639,26 @@ struct PMLane {
         step_phase(tm_i, tc_i);
         e0 = step_env();
     }
+    template <bool MAYBE_LARGE = true>
     static __device__ __forceinline__ float value(float tm_i, float tc_i, float e0) {
-        const float m = 0.0f + sine_osc_sin(tm_i + 0.0f);              // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
+        const float m = 0.0f + sine_osc_sin<MAYBE_LARGE>(tm_i + 0.0f);     // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
         const float ph = 0.0f + m * 1.0f;                              // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
-        const float c = 0.0f + sine_osc_sin(tc_i + ph);                // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
+        const float c = 0.0f + sine_osc_sin<MAYBE_LARGE>(tc_i + ph);       // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
         const float osc = 0.0f + c;                                    // PhaseModOscillator output (zeroed) += temps[1]   (:75)
         return osc * e0;                                               // multiply(out, temps[0], temps[1]) :126
     }
+    template <bool MAYBE_LARGE = true>
     __device__ __forceinline__ float frame() {
         float tm_i, tc_i, e0;
         step(tm_i, tc_i, e0);
-        return value(tm_i, tc_i, e0);
+        return value<MAYBE_LARGE>(tm_i, tc_i, e0);
+    }
+    // true (wave-wide) when neither sine's argument can reach zsinf's rare path in the next `frames` frames: both phases move
+    // by a constant per frame, the carrier's phase offset is a sine (|ph| <= 1); NaN compares false
+    __device__ __forceinline__ bool small_args(float frames) const {
+        const bool ok = __builtin_fabsf(tm) + frames * __builtin_fabsf(mod_freq * inv_sr) < kSineOscSmallT &&
+                        __builtin_fabsf(tc) + frames * __builtin_fabsf(t_step) + 1.0f < kSineOscSmallT;
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
     }
 
     // end of one paint call: envelope cascade, and both SineOsc `t - trunc(t)` wraps (SineOsc.zig:40)
@@ -676,10 +685,10 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
     pm_load(n, a, v);
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        val = n.frame();
-        return true;
-    });
+    (void)no_in;
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t) ZH_INLINE_LAMBDA { return n.small_args(8.0f); },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<false>(); return true; },      // no rare-path branch: one block
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<true>(); return true; });
     n.end();
     pm_store(n, a, v);
 }
@@ -715,10 +724,10 @@ __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__re
         n.step(tm_i, tc_i, e0);
     }
     const float *const *no_in = nullptr;
-    frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
-        val = n.frame();
-        return true;
-    });
+    (void)no_in;
+    frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1, [&](uint32_t) ZH_INLINE_LAMBDA { return n.small_args(8.0f); },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<false>(); return true; },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<true>(); return true; });
     if (f1 != end) return;
     n.end();
     const size_t V = a.V;

@@ -46,11 +46,19 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
     if (PB) { ins[FB ? 1 : 0] = phase.b.p; istr[FB ? 1 : 0] = phase.b.stride; }
     o.begin(sample_rate, FB ? 0.0f : freq.c.get(v));
     const float phase_c = PB ? 0.0f : phase.c.get(v);
-    frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, start, end,
-                           [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
-        val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
-        return true;
-    });
+    if constexpr (!FB && !PB) {
+        // chunks whose arguments stay far below zsinf's Payne-Hanek range (every chunk, in practice) run the sine without its
+        // rare-path branch: the eight sines of a chunk are then one basic block and interleave
+        frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t) ZH_INLINE_LAMBDA { return o.small_args(phase_c, 8.0f); },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.template frame<false, false>(0.0f, phase_c); return true; },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.template frame<false, true>(0.0f, phase_c); return true; });
+    } else {
+        frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, start, end,
+                               [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
+            val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
+            return true;
+        });
+    }
     o.end();
     t_io[v] = o.t;
 }
@@ -87,11 +95,17 @@ __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__
     if (FB) { ins[0] = freq.b.p; istr[0] = freq.b.stride; }
     if (PB) { ins[FB ? 1 : 0] = phase.b.p; istr[FB ? 1 : 0] = phase.b.stride; }
     const float phase_c = PB ? 0.0f : phase.c.get(v);
-    frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, f0, f1,
-                           [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
-        val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
-        return true;
-    });
+    if constexpr (!FB && !PB) {
+        frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1, [&](uint32_t) ZH_INLINE_LAMBDA { return o.small_args(phase_c, 8.0f); },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.template frame<false, false>(0.0f, phase_c); return true; },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.template frame<false, true>(0.0f, phase_c); return true; });
+    } else {
+        frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, f0, f1,
+                               [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
+            val = o.template frame<FB>(x[0], PB ? x[FB ? 1 : 0] : phase_c);
+            return true;
+        });
+    }
     if (f1 == end) { o.end(); t_out[v] = o.t; }
 }
 

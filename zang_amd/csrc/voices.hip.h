@@ -11,7 +11,10 @@
 #include "envelope.hip.h"
 
 // ---- SineOsc (src/modules/SineOsc.zig) -----------------------------------------------------------
-__device__ __forceinline__ float sine_osc_sin(float t) { return zsinf(t * 3.14159265358979323846f * 2.0f); }   // :4-6
+template <bool MAYBE_LARGE = true>
+__device__ __forceinline__ float sine_osc_sin(float t) { return zsinf<MAYBE_LARGE>(t * 3.14159265358979323846f * 2.0f); }   // :4-6
+// |t| below this keeps (t * pi) * 2 below kZSinNoLargeBelow: sine_osc_sin<false> is exact
+constexpr float kSineOscSmallT = 6.0e7f;
 
 struct SineOscLane {
     float t;                                                          // state (:16-22)
@@ -20,12 +23,18 @@ struct SineOscLane {
         t_step = freq_const / sample_rate;                            // :44 (unused when freq is a buffer)
         inv_sr = 1.0f / sample_rate;                                  // :66
     }
-    template <bool FB> __device__ __forceinline__ float frame(float freq_i, float phase_i) {
-        const float val = sine_osc_sin(t + phase_i);
+    template <bool FB, bool MAYBE_LARGE = true> __device__ __forceinline__ float frame(float freq_i, float phase_i) {
+        const float val = sine_osc_sin<MAYBE_LARGE>(t + phase_i);
         if (FB) t += freq_i * inv_sr; else t += t_step;
         return val;
     }
     __device__ __forceinline__ void end() { t = t - truncf(t); }      // :40
+    // constant frequency and phase: true (wave-wide) when no voice's sine argument can reach zsinf's rare path in the next
+    // `frames` frames (t moves by t_step a frame; NaN compares false) -- the chunk then runs frame<false, false>
+    __device__ __forceinline__ bool small_args(float phase_c, float frames) const {
+        const bool ok = __builtin_fabsf(t) + frames * __builtin_fabsf(t_step) + __builtin_fabsf(phase_c) < kSineOscSmallT;
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+    }
 };
 
 // ---- PulseOsc (src/modules/PulseOsc.zig) ---------------------------------------------------------

@@ -7,13 +7,15 @@
 // same published algorithms: f64 polynomial kernels after a Cody-Waite / Payne-Hanek
 // reduction for sin/cos, the f32 table+polynomial atanf, frexp/ldexp square-and-multiply
 // pow, xoshiro256++.  An f64 VALU operation issues in the 4.2-cycle class on gfx950 (measured,
-// profiles/r01/ubench), a plain f32 add / mul in 2.5: one sinf is ~50 instructions, 35 of them f64.
+// profiles/r01/ubench), a plain f32 add / mul in 2.5: one sinf was ~50 instructions, 35 of them f64 (24 since round 3:
+// multiply-add pairs fused where ALL 2^32 arguments give the same bits, zsincos_kernels below).
 // What can be changed without changing bits is the control flow: a wave's lanes sit in every range
 // of a libm routine at once, so the ranges are folded into straight-line code in which each lane
 // performs exactly its range's operations (sinf / cosf, atanf below).
 //
-// Everything here must be compiled with -ffp-contract=off (no fused multiply-add: Zig
-// emits none for these loops) and without fast-math.
+// Everything here must be compiled with -ffp-contract=off (no fused multiply-add by the compiler: Zig
+// emits none for these loops; the explicit __builtin_fma calls below are the exhaustively verified exceptions)
+// and without fast-math.
 #pragma once
 #include <hip/hip_runtime.h>
 #if !defined(__HIPCC_RTC__)
@@ -206,56 +208,79 @@ ZD int zrem_pio2f(float x, double *y) {
 // need it.  Then ONE evaluation of each kernel on y (z = y*y and w = z*z shared) and selects: the
 // kernels are exactly odd / even in floating point, so sindf(-y) = -sindf(y) and every negation is a
 // sign-bit flip of the result.
+template <bool MAYBE_LARGE = true>
 ZD int zreduce_pio2f(float x, uint32_t ix, double &y) {
     const double invpio2 = 6.36619772367581382433e-01, pio2 = 1.57079632679489661923,
-                 pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08, pio4 = 0x1.921fb6p-1;
+                 pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08,
+                 toint = 1.5 / 2.220446049250313e-16;
     const double xd = (double)x;
-    const double fn = __builtin_rint(xd * invpio2);
-    const double ys = xd - fn * pio2;
-    const double ym = xd - fn * pio2_1 - fn * pio2_1t;
+    // Round 3: every step below is the cheapest form that gives the SAME BITS as musl's for every f32 argument, decided by
+    // exhaustion (tools/ubench/sin_exhaustive.hip, all 2^32 patterns, sinf and cosf; profiles/r03/sin_exhaustive.txt):
+    //  * fn by musl's own magic-number rounding, x*invpio2 + 1.5*2^52 - 1.5*2^52, with the product fused into the add; the
+    //    integer n is then the low mantissa word of the sum (two's complement): no v_rndne_f64, no v_cvt_i32_f64;
+    //  * the products of both leaves fused into their subtractions;
+    //  * no "|y| > pi/4" correction test: musl says it "matters with directed rounding" -- under round-to-nearest it changes
+    //    no result; what is left of the rare path is |x| >= 2^28*pi/2 (Payne-Hanek), and inf / nan, whose y = x - x runs
+    //    through the kernels to the same NaN musl's early return gives.
+    const double fnm = __builtin_fma(xd, invpio2, toint);
+    const double fn = fnm - toint;
+    int n = (int)(uint32_t)__double_as_longlong(fnm);
+    const double ys = __builtin_fma(-fn, pio2, xd);                                        // xd - fn * pio2
+    const double ym = __builtin_fma(-fn, pio2_1t, __builtin_fma(-fn, pio2_1, xd));         // xd - fn * pio2_1 - fn * pio2_1t
     const bool small = ix <= 0x40e231d5;                              // |x| <= 9pi/4
-    int n = (int)fn;
     y = small ? ys : ym;
-    // finite |x| >= 2^28*pi/2, or a medium y that landed outside [-pi/4, pi/4] ("matters with directed rounding")
-    // (ints, not short-circuit logic: three compares and two scalar mask operations, no branches)
-    const int out_of_range = __builtin_fabs(ym) > pio4, large = (ix - 0x4dc90fdbu) < (0x7f800000u - 0x4dc90fdbu);
-    const bool rare = ((int)!small & (out_of_range | large)) != 0;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
-        if (rare) n = zrem_pio2f(x, &y);
+    // (the compare as a wave mask: the ballot of a combined per-lane bool costs a 0/1 select and a compare more)
+    // MAYBE_LARGE = false: the caller has established (wave-wide, for a whole chunk of frames: kZSinNoLargeBelow) that no
+    // argument reaches the rare path -- without its branch the sines of an unrolled chunk are one basic block
+    if (MAYBE_LARGE && __builtin_expect(__builtin_amdgcn_ballot_w64(ix > 0x4dc90fdau) != 0, 0)) {
+        if (ix > 0x4dc90fdau) n = zrem_pio2f(x, &y);                  // finite |x| >= 2^28*pi/2, inf, nan
     }
     return n;
 }
 
-ZD float zsinf(float x) {
+// The two polynomial kernels of musl's sinf / cosf on the reduced argument, both at once (z and w shared):
+//   __sindf(y) = (y + s*(S1 + z*S2)) + s*w*(S3 + z*S4),  s = z*y          __cosdf(y) = ((1 + z*C0) + w*C1) + (w*z)*(C2 + z*C3)
+// musl rounds every product and every sum (13 + 5 f64 operations with the reduction's); here every multiply-add pair is ONE
+// fused operation (nine fewer f64 instructions per sine).  A fused multiply-add skips one f64 rounding, which moves
+// the f32 result only if the f64 value then crosses a rounding boundary of the final conversion; whether that ever happens
+// is decided by exhaustion, not by argument: tools/ubench/sin_exhaustive.hip runs ALL 2^32 f32 bit patterns through musl's
+// operation order and through this form -- sinf and cosf, every leaf of the reduction -- and finds 0 differing results
+// (profiles/r03/sin_exhaustive.txt; each of the nine fusions alone, and all together; dropping the small leaf instead
+// differs for 2 arguments and is not done).  tests/test_gpu_math.py repeats a 2^28-argument stratified subset against the
+// oracle, which keeps musl's order.
+ZD void zsincos_kernels(double y, float &sv, float &cv) {
     const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
     const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57, C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
-    const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
-    double y;
-    const int n = zreduce_pio2f(x, ix, y);
     const double z = y * y, w = z * z, s = z * y;
-    const float sv = (float)((y + s * (S1 + z * S2)) + s * w * (S3 + z * S4));          // __sindf(y)
-    const float cv = (float)(((1.0 + z * C0) + w * C1) + (w * z) * (C2 + z * C3));      // __cosdf(y)
-    // n & 3: 0 sindf(y) | 1 cosdf(y) | 2 sindf(-y) = -sindf(y) | 3 -cosdf(y)
-    float r = zu2f(zf2u((n & 1) ? cv : sv) ^ ((uint32_t)(n & 2) << 30));
-    if (ix < 0x39800000) r = x;                               // |x| < 2^-12
-    if (ix >= 0x7f800000) r = x - x;                          // inf, nan
-    return r;
+    sv = (float)__builtin_fma(s * w, __builtin_fma(z, S4, S3), __builtin_fma(s, __builtin_fma(z, S2, S1), y));
+    cv = (float)__builtin_fma(w * z, __builtin_fma(z, C3, C2), __builtin_fma(w, C1, __builtin_fma(z, C0, 1.0)));
 }
 
-ZD float zcosf(float x) {
-    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
-    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57, C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
+// |x| below this (NaN excluded by the comparison) never takes the rare path: zsinf<false> / zcosf<false> are then exact
+constexpr float kZSinNoLargeBelow = 4.0e8f;                    // < 2^28 * pi/2 = 4.2166e8 (0x4dc90fdb)
+template <bool MAYBE_LARGE = true>
+ZD float zsinf(float x) {
     const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
     double y;
-    const int n = zreduce_pio2f(x, ix, y);
-    const double z = y * y, w = z * z, s = z * y;
-    const float sv = (float)((y + s * (S1 + z * S2)) + s * w * (S3 + z * S4));
-    const float cv = (float)(((1.0 + z * C0) + w * C1) + (w * z) * (C2 + z * C3));
+    const int n = zreduce_pio2f<MAYBE_LARGE>(x, ix, y);
+    float sv, cv;
+    zsincos_kernels(y, sv, cv);
+    // n & 3: 0 sindf(y) | 1 cosdf(y) | 2 sindf(-y) = -sindf(y) | 3 -cosdf(y)
+    float r = zu2f(zf2u((n & 1) ? cv : sv) ^ ((uint32_t)(n & 2) << 30));
+    if (ix < 0x39800000) r = x;                               // |x| < 2^-12 (needed for -0.0 alone: the kernel gives +0.0)
+    return r;                                                 // (inf, nan: y = x - x from the rare path, NaN through the kernel)
+}
+
+template <bool MAYBE_LARGE = true>
+ZD float zcosf(float x) {
+    const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
+    double y;
+    const int n = zreduce_pio2f<MAYBE_LARGE>(x, ix, y);
+    float sv, cv;
+    zsincos_kernels(y, sv, cv);
     // n & 3: 0 cosdf(y) | 1 sindf(-y) = -sindf(y) | 2 -cosdf(y) | 3 sindf(y)
     float r = zu2f(zf2u((n & 1) ? sv : cv) ^ ((uint32_t)((n + 1) & 2) << 30));
-    if (ix < 0x39800000) r = 1.0f;
-    if (ix >= 0x7f800000) r = x - x;
-    return r;
+    return r;                                                 // (|x| < 2^-12: the kernel rounds to 1.0f by itself; inf, nan as in zsinf)
 }
 
 // ---- atanf (f32 arithmetic throughout) ------------------------------------------------
