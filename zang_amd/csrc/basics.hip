@@ -207,6 +207,39 @@ __global__ void __launch_bounds__(64 * MIX_SEG) k_mix_pass2(const float *__restr
     }
 }
 
+// Pass 2 for the fused voice kernels (composite.hip k_nice_mix), whose partials are one row per WAVE of 64 voices -- four
+// times the rows of the block form, 16 MB per stereo buffer at 131,072 voices: a workgroup owns 16 frames of one channel and
+// splits the rows into 64 contiguous segments (one lane per (segment, frame): a wave reads 4 segments x 64 contiguous bytes
+// per step), segment sums combined in segment order by the first 16 lanes.  grid = (frames / 16, channels): 128 workgroups
+// per stereo buffer instead of 16 -- and both channels in ONE launch (a second pass2 launch was 5 us per buffer).
+// Fixed order => reproducible bits.
+constexpr int MIXW_SEG = 64, MIXW_F = 16;
+__global__ void __launch_bounds__(MIXW_SEG * MIXW_F) k_mix_pass2_wide(const float *__restrict__ partials, size_t channel_stride, uint32_t rows,
+                                                                      uint32_t nframes, float *__restrict__ dst0, float *__restrict__ dst1,
+                                                                      int zero_first) {
+    __shared__ float seg_sum[MIXW_SEG][MIXW_F];
+    const uint32_t fl = threadIdx.x % MIXW_F, seg = threadIdx.x / MIXW_F;
+    const uint32_t f = blockIdx.x * MIXW_F + fl;
+    const float *part = partials + (size_t)blockIdx.y * channel_stride;
+    float *dst = blockIdx.y ? dst1 : dst0;
+    const uint32_t per = (rows + MIXW_SEG - 1) / MIXW_SEG;
+    const uint32_t t0 = min(seg * per, rows), t1 = min(t0 + per, rows);
+    float s = 0.0f;
+    if (f < nframes) {
+        const float *p = part + (size_t)t0 * nframes + f;
+#pragma unroll 8
+        for (uint32_t t = t0; t < t1; t++, p += nframes) s += *p;
+    }
+    seg_sum[seg][fl] = s;
+    __syncthreads();
+    if (seg == 0 && f < nframes) {
+        float tot = seg_sum[0][fl];
+#pragma unroll
+        for (int k = 1; k < MIXW_SEG; k++) tot += seg_sum[k][fl];
+        dst[f] = (zero_first ? 0.0f : dst[f]) + tot;
+    }
+}
+
 // ZH_MIX_SEQUENTIAL: one lane per frame adds voice 0, 1, 2, ... in f32, the exact order of successive
 // `+=` paints onto one buffer in the reference (example_song.zig:340-346).  Each lane walks its
 // own image row, so this form is for small voice counts only (17 sub-voices in example_song).
@@ -264,6 +297,12 @@ int zh_mix_reserve(zh_ctx *ctx, size_t floats) { ZH_GUARD(ctx);
 void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
     hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 63) / 64), dim3(64 * MIX_SEG), 0, ctx->stream, partials, tiles,
                        nframes, dst, zero_first);
+}
+// channels = 1 or 2 (dst1 unused for 1): partials[channel][row][frame], rows summed in row order
+void zh_mix_pass2_wide_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes, float *dst0,
+                              float *dst1, int channels, int zero_first) {
+    hipLaunchKernelGGL(k_mix_pass2_wide, dim3((nframes + MIXW_F - 1) / MIXW_F, channels), dim3(MIXW_SEG * MIXW_F), 0, ctx->stream, partials,
+                       channel_stride, rows, nframes, dst0, dst1, zero_first);
 }
 void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
     zh_mix_pass2_launch_at(ctx, ctx->mix_partials, tiles, nframes, dst, zero_first);

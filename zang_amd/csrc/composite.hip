@@ -22,6 +22,8 @@
 int zh_mix_reserve(zh_ctx *ctx, size_t floats);
 void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first);
 void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, uint32_t nframes, float *dst, int zero_first);
+void zh_mix_pass2_wide_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes, float *dst0,
+                              float *dst1, int channels, int zero_first);
 
 struct zh_nice {
     zh_ctx *ctx;
@@ -96,42 +98,54 @@ struct NiceLaneT {
     // the frame whose phase counter is c, a pure function of c (the u32 counter of frame j is exactly
     // cnt + j*ifreq), so k_nice_spans_wave evaluates it for 64 frames at once.  tail(t0): the filter and
     // the envelope, which carry state from frame to frame; returns env*flt (the value added to out).
+    // (temps[0] = 0 + pulse, then * 0.5 :226: the `0 +` is not computed.  It changes the bits only of a pulse of -0.0 -- into
+    // +0.0 -- and this value's one and only use is the filter's `input + fcdcoffset` (Filter.zig:135, svf_step): a zero of
+    // either sign plus 2^-18 is 2^-18.  A silent voice (bad freq) yields ngain = +0.0.)
     __device__ __forceinline__ F osc(U c) const {
-        const F zero = zsplat<F>(0.0f);
-        const F pv = zero + pulse_sample<W>(k, c, g, ng);              // temps[0] = 0 (+ pulse); a silent voice (bad freq) leaves it 0
+        const F pv = pulse_sample<W>(k, c, g, ng);
         return pv * 0.5f;                                              // multiplyWithScalar :226
     }
     // tail = two chains that never read each other's state: the filter over the oscillator samples and
     // the envelope; their product is the value added to out.
+    // INTO_ZERO: the caller adds the frame's value to a ZERO (a ZERO_FIRST paint, the mixdown's `0.0f + x`).  The low-pass
+    // mix's own `0 +` (temps[1] was zeroed) is then not computed: it only turns a mix of -0.0 into +0.0, the product with
+    // the envelope is a zero of some sign either way (or the same NaN), and the caller's `0 + product` is +0.0 for both.
+    template <bool INTO_ZERO = false>
     __device__ __forceinline__ F tail_filter(F t0) {
         // temps[1] = 0 + low-pass(temps[0])   (Filter.zig:135-146 with l_mul = 1, b_mul = h_mul = 0)
         const SvfOutT<F> s = svf_step(l, b, t0, cut, res);
-        return svf_lowpass_into_zero(s.l, s.b);
+        if constexpr (INTO_ZERO) return s.l + s.b * 0.0f;
+        else return svf_lowpass_into_zero(s.l, s.b);
     }
     __device__ __forceinline__ F tail_env() { return env.frame_masked(); }   // temps[0] = 0 (+ envelope)
+    template <bool INTO_ZERO = false>
     __device__ __forceinline__ F tail(F t0) {
-        const F t1 = tail_filter(t0);
+        const F t1 = tail_filter<INTO_ZERO>(t0);
         const F e0 = tail_env();
         return e0 * t1;                                                // multiply :246: out += temps[0]*temps[1]
     }
+    template <bool INTO_ZERO = false>
     __device__ __forceinline__ F frame() {
         const F t0 = osc(cnt);
         cnt = cnt + k.ifreq;
-        return tail(t0);
+        return tail<INTO_ZERO>(t0);
     }
     // While no voice of a wave is inside a timed envelope stage (sustain: paintFlat's constant, Envelope.zig:68-70; idle or
     // the assert case: nothing painted) the envelope's frame changes no state and yields the same value every frame:
     // env_quiet() is that value, frame_quiet() the frame without the envelope's ~12 instructions.  Exactly what frame()
     // computes and commits in those modes (frame_masked: every update is a select on `toward`).
     __device__ __forceinline__ F env_quiet() const { return zbits_f(zbits_u(zsplat<F>(0.0f) + env.sustain_volume) & env.m_painted); }
+    template <bool INTO_ZERO = false>
     __device__ __forceinline__ F frame_quiet(F e0) {
         const F t0 = osc(cnt);
         cnt = cnt + k.ifreq;
-        return e0 * tail_filter(t0);
+        return e0 * tail_filter<INTO_ZERO>(t0);
     }
     // the same two with the carried-mask oscillator (roll_begin() first; every lane takes every frame)
-    __device__ __forceinline__ F frame_roll(PulseRoll &roll) { return tail(osc_next(roll)); }
-    __device__ __forceinline__ F frame_quiet_roll(F e0, PulseRoll &roll) { return e0 * tail_filter(osc_next(roll)); }
+    template <bool INTO_ZERO = false>
+    __device__ __forceinline__ F frame_roll(PulseRoll &roll) { return tail<INTO_ZERO>(osc_next(roll)); }
+    template <bool INTO_ZERO = false>
+    __device__ __forceinline__ F frame_quiet_roll(F e0, PulseRoll &roll) { return e0 * tail_filter<INTO_ZERO>(osc_next(roll)); }
     // The oscillator half for a walker in which every active lane takes every frame in order from a begin()
     // executed by all of them together (k_nice, k_nice_pc -- not the span kernels, whose lanes begin sub-spans
     // at different frames): the previous frame's half-period bit is carried as the wave's lane
@@ -141,8 +155,7 @@ struct NiceLaneT {
         roll = pulse_roll_init(k, cnt);
     }
     __device__ __forceinline__ F osc_next(PulseRoll &roll) {
-        const F zero = zsplat<F>(0.0f);
-        const F pv = zero + pulse_sample_roll(k, cnt, roll, g, ng);
+        const F pv = pulse_sample_roll(k, cnt, roll, g, ng);             // (no `0 +`: see osc())
         cnt = cnt + k.ifreq;
         return pv * 0.5f;
     }
@@ -470,15 +483,18 @@ __global__ void __launch_bounds__(256) k_nice_pc4(NiceArgs a, Img out, uint32_t 
     }
 }
 
-// Fused chain + voice mixdown.  A workgroup of 256 lanes = 256 voices.  Lanes render MIXF frames
-// into an LDS tile [wave][frame][lane] (row stride 65 floats: conflict-free column writes and
-// row reads), then every lane sums half a row -- lane (f, h) adds voices 32h..32h+31 of frame f
-// left to right -- and lanes 0..MIXF-1 combine the 8 half-row sums in (wave, half) order into
-// partials[block][frame].  One ds_write + one ds_read + one add per lane-frame, instead of a
-// 6-step cross-lane butterfly per frame.  The second mixdown pass (basics.hip) adds the block
-// partials in block order.  Fixed order => reproducible bits.
+// Fused chain + voice mixdown.  Every WAVE (64 voices) works on its own: lanes render MIXF frames into the wave's LDS tile
+// [frame][lane] (row stride 68 floats: column writes hit 64 consecutive banks, and the 16-byte row reads of eight
+// neighbouring lanes start 4 banks apart -- both conflict-free), then every lane sums half a row -- lane
+// (f, h) adds voices 32h..32h+31 of frame f left to right -- the two halves of a frame are added (h0 + h1) across the wave
+// and lanes 0..MIXF-1 write partials[wave][frame].  One ds_write + one ds_read + one add per lane-frame, instead of a 6-step
+// cross-lane butterfly per frame.  Round 3: nothing crosses waves any more -- the round-2 form combined the four waves of a
+// workgroup through LDS behind two __syncthreads per 32-frame chunk, and at the config-5 shard size (131,072 voices = two
+// waves per SIMD, each at its one-instruction-per-5-cycles issue limit) a wave waiting at a barrier is issue time nobody
+// else can use.  The second pass (basics.hip k_mix_pass2_wide) adds the wave partials in wave order, both channels in one
+// launch.  Fixed order => reproducible bits.
 constexpr int MIXF = 32;
-constexpr int MIXS = 65;
+constexpr int MIXS = 68;      // floats per tile row: 16-byte aligned rows, and 68 = 4 mod 32 keeps both access patterns conflict-free
 
 // C = output channels.  C = 1: partials[block][frame] = sum of the block's voices.  C = 2 (stereo,
 // examples/example_stereo.zig:92-98: `outputs[c] += voice * pan_c` per voice): the sum phase multiplies each
@@ -488,11 +504,13 @@ constexpr int MIXS = 65;
 template <int C, bool ROLL>
 __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
                                                   F32P gain_l, F32P gain_r) {
-    __shared__ float tile[4][MIXF][MIXS];
-    __shared__ float halfsum[C][MIXF][8];
+    __shared__ float tile_all[4][MIXF][MIXS];
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*tile)[MIXS] = tile_all[wave];                               // this wave's tile: no other wave touches it
     const uint32_t nframes = end - start;
+    const uint32_t wave_global = blockIdx.x * 4 + wave;
+    const size_t channel_stride = (size_t)gridDim.x * 4 * nframes;      // partials[channel][wave][frame]
     const bool live = v < a.V;
     // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
     // exec-mask region (an s_and_saveexec / branch / restore per frame: ~10 of ~85 instructions)
@@ -510,82 +528,91 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
     PulseRoll roll;
     n.roll_begin(roll);
-    float gl[C == 2 ? 32 : 1], gr[C == 2 ? 32 : 1];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 g2[C == 2 ? 32 : 1];                                             // {left, right} gain of each of the lane's 32 voices
     if constexpr (C == 2) {
-        const uint32_t v0 = blockIdx.x * 256 + wave * 64 + rh * 32;     // first of the 32 voices this lane adds up
+        // every lane needs the gains of the 32 voices it adds up: the workgroup's 256 pairs go through LDS once (two coalesced
+        // loads per lane instead of 64 scattered ones: 2 us per launch at 131,072 voices) -- the kernel's only workgroup barrier
+        __shared__ f2 gains[256];
+        gains[threadIdx.x] = live ? f2{gain_l.get(v), gain_r.get(v)} : f2{0.0f, 0.0f};   // (voices past the last: tile entries are 0.0f)
+        __syncthreads();
+        const f2 *mine = &gains[wave * 64 + rh * 32];                   // the 32 voices this lane adds up
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const bool in = v0 + j < a.V;                               // (their tile entries are 0.0f; the gain is never read out of range)
-            gl[j] = in ? gain_l.get(v0 + j) : 0.0f;
-            gr[j] = in ? gain_r.get(v0 + j) : 0.0f;
-        }
+        for (int j = 0; j < 32; j++) g2[j] = mine[j];
     }
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
         // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
         // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
-        const bool whole = f0 + MIXF <= end;                            // (block-uniform)
+        const bool whole = f0 + MIXF <= end;                            // (uniform)
         if (!__any(n.env.mode == ENV_MODE_TOWARD)) {
             const float e0 = n.env_quiet();
             if (whole) {
 #pragma unroll 4
                 for (int k = 0; k < MIXF; k++) {
-                    const float x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
-                    tile[wave][k][lane] = x;
+                    const float x = 0.0f + (ROLL ? n.template frame_quiet_roll<true>(e0, roll) : n.template frame_quiet<true>(e0));
+                    tile[k][lane] = x;
                 }
             } else {
                 for (int k = 0; k < MIXF; k++) {
                     float x = 0.0f;
-                    if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
-                    tile[wave][k][lane] = x;
+                    if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.template frame_quiet_roll<true>(e0, roll) : n.template frame_quiet<true>(e0));
+                    tile[k][lane] = x;
                 }
             }
         } else if (whole && n.env.quiet(MIXF)) {                          // no stage can end in this chunk: the envelope without its stage-end test
 #pragma unroll 4
             for (int k = 0; k < MIXF; k++) {
                 const float e0 = n.env.frame_masked_quiet();
-                const float x = 0.0f + (ROLL ? n.frame_quiet_roll(e0, roll) : n.frame_quiet(e0));
-                tile[wave][k][lane] = x;
+                const float x = 0.0f + (ROLL ? n.template frame_quiet_roll<true>(e0, roll) : n.template frame_quiet<true>(e0));
+                tile[k][lane] = x;
             }
         } else if (whole) {
 #pragma unroll 4
             for (int k = 0; k < MIXF; k++) {
-                const float x = 0.0f + (ROLL ? n.frame_roll(roll) : n.frame());   // the voice's own out (zeroed) += env*flt
-                tile[wave][k][lane] = x;
+                const float x = 0.0f + (ROLL ? n.template frame_roll<true>(roll) : n.template frame<true>());   // the voice's own out (zeroed) += env*flt
+                tile[k][lane] = x;
             }
         } else {
             for (int k = 0; k < MIXF; k++) {
                 float x = 0.0f;
-                if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.frame_roll(roll) : n.frame());
-                tile[wave][k][lane] = x;
+                if (__builtin_amdgcn_readfirstlane((int)(f0 + k < end))) x = 0.0f + (ROLL ? n.template frame_roll<true>(roll) : n.template frame<true>());
+                tile[k][lane] = x;
             }
         }
-        __syncthreads();
+        // the tile is this wave's own: its LDS writes above and reads below execute in program order, no workgroup barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
-            const float *row = &tile[wave][rf][rh * 32];
+            // the lane's half row: 32 voices = eight 16-byte LDS reads
+            const float4 *row4 = reinterpret_cast<const float4 *>(&tile[rf][rh * 32]);
+            float row[32];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const float4 x = row4[q]; row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w; }
+            float sl, sr = 0.0f;
             if constexpr (C == 1) {
-                float s = row[0];
+                sl = row[0];
 #pragma unroll
-                for (int j = 1; j < 32; j++) s += row[j];
-                halfsum[0][rf][wave * 2 + rh] = s;
+                for (int j = 1; j < 32; j++) sl += row[j];
             } else {
-                float sl = row[0] * gl[0], sr = row[0] * gr[0];        // zang.multiply: dest += a * b, no fused multiply-add
+                // zang.multiply: dest += a * b, the product rounded, then added (no fused multiply-add).  (Both channels in
+                // packed v_pk_mul_f32 / v_pk_add_f32 -- half the instructions -- measured SLOWER: 124 -> 135 us per buffer at
+                // 131,072 voices; the 31 dependent packed adds cost more than the two interleaved scalar chains.)
+                sl = row[0] * g2[0].x; sr = row[0] * g2[0].y;
 #pragma unroll
-                for (int j = 1; j < 32; j++) { sl += row[j] * gl[j]; sr += row[j] * gr[j]; }
-                halfsum[0][rf][wave * 2 + rh] = sl;
-                halfsum[1][rf][wave * 2 + rh] = sr;
+                for (int j = 1; j < 32; j++) { sl += row[j] * g2[j].x; sr += row[j] * g2[j].y; }
+            }
+            // frame rf's two half-row sums meet in lane rf: (voices 0..31) + (voices 32..63)
+            const float hl = __shfl_down(sl, 32);
+            const float hr = C == 2 ? __shfl_down(sr, 32) : 0.0f;
+            if (rh == 0 && f0 + rf < end) {
+                float *pw = partials + (size_t)wave_global * nframes + (f0 - start) + rf;
+                pw[0] = sl + hl;
+                if constexpr (C == 2) pw[channel_stride] = sr + hr;
             }
         }
-        __syncthreads();
-        if (threadIdx.x < MIXF * C && f0 + (threadIdx.x & (MIXF - 1)) < end) {
-            const uint32_t c = threadIdx.x / MIXF, fr = threadIdx.x & (MIXF - 1);
-            const float *w = halfsum[c][fr];
-            float s = w[0];
-#pragma unroll
-            for (int j = 1; j < 8; j++) s += w[j];
-            partials[((size_t)c * gridDim.x + blockIdx.x) * nframes + (f0 - start) + fr] = s;
-        }
-        // the next chunk's tile writes are ordered behind this chunk's reads by the barrier above
-        // (rows are only read before it) and halfsum is rewritten only after the next barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next chunk rewrites the tile after these reads
+        __builtin_amdgcn_wave_barrier();
     }
     if (live) nice_store(n, a, v);
 }
@@ -1477,25 +1504,25 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     if (m->n == 0) return ZH_OK;
     const uint32_t nframes = end - start;
     const uint32_t blocks = (m->n + 255) / 256;
-    const size_t per_channel = (size_t)blocks * (nframes ? nframes : 1);
+    const uint32_t rows = blocks * 4;                                   // one partial row per wave of 64 voices
+    const size_t per_channel = (size_t)rows * (nframes ? nframes : 1);
     int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1));
     if (rc) return rc;
     hipStream_t st = m->ctx->stream;
     NiceArgs a = nice_args(m, p, note_id_changed);
     float *part = m->ctx->mix_partials;
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
+    const char *pe = zh_env("ZH_NICE_MIX_LDS_PAD");
+    const uint32_t pad = pe ? (uint32_t)atoi(pe) : 0u;
     if (stereo) {
-        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<2, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
-        else hipLaunchKernelGGL((k_nice_mix<2, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
-        if (nframes) {
-            zh_mix_pass2_launch_at(m->ctx, part, blocks, nframes, mix_l + start, zf);
-            zh_mix_pass2_launch_at(m->ctx, part + per_channel, blocks, nframes, mix_r + start, zf);
-        }
+        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<2, true>), dim3(blocks), dim3(256), pad, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        else hipLaunchKernelGGL((k_nice_mix<2, false>), dim3(blocks), dim3(256), pad, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, mix_r + start, 2, zf);
     } else {
         const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
         if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<1, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
         else hipLaunchKernelGGL((k_nice_mix<1, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
-        if (nframes) zh_mix_pass2_launch_at(m->ctx, part, blocks, nframes, mix_l + start, zf);
+        if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, nullptr, 1, zf);
     }
     return zh_launch_status();
 }
