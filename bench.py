@@ -459,10 +459,27 @@ def parity_check(wl, ctx):
             "mismatching_samples": int((~same).sum()), "against": "oracle from the GPU's own carried state"}
 
 
-def traffic_record(args, V, F):
-    """HBM bytes per launch of the headline kernel from the committed rocprofv3 --pmc passes of this same workload
-    (counters cannot be read from inside the process): value + where it came from."""
-    if not (args.workload == "pulseosc" and V == 4096 and F == 1024):
+def traffic_record(args, V, F, kernel_hint=None):
+    """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same workload
+    (counters cannot be read from inside the process; tools/pmc_traffic.sh collects them: one pass per counter, FETCH_SIZE
+    doubled on gfx950): value + where it came from.  profiles/r03/pmc_traffic_<workload><voices>.json holds every kernel of a
+    step; `traffic` is the kernel that moves the most bytes, the step's total goes into the source record."""
+    if F != 1024:
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r03", f"pmc_traffic_{args.workload}{V}.json")
+    if os.path.exists(path):
+        rec = json.load(open(path))
+        ks = rec.get("kernels", {})
+        if ks:
+            name, k = max(ks.items(), key=lambda kv: kv[1]["write_bytes_per_launch"] + kv[1]["fetch_bytes_per_launch_corrected"])
+            per_launch = k["write_bytes_per_launch"] + k["fetch_bytes_per_launch_corrected"]
+            src = {"file": os.path.relpath(path, ROOT), "collected_at_commit": rec.get("commit"), "kernel": name,
+                   "how": "tools/pmc_traffic.sh (separate --pmc passes of WRITE_SIZE / FETCH_SIZE, FETCH_SIZE x2 on gfx950)",
+                   "hbm_bytes_per_step_all_kernels": rec.get("hbm_bytes_per_step"),
+                   "kernels_per_step": {n: v["hbm_bytes_per_step"] for n, v in ks.items()},
+                   "note": "a constant read from that file, not a counter of this run"}
+            return per_launch, src
+    if not (args.workload == "pulseosc" and V == 4096):
         return None, None
     for name in ("r02_pmc_pulseosc4096.json", "r01_pmc_pulseosc4096.json"):
         pmc = os.path.join(ROOT, "profiles", name)
