@@ -471,7 +471,9 @@ def traffic_record(args, V, F, kernel_hint=None):
         rec = json.load(open(path))
         ks = rec.get("kernels", {})
         if ks:
-            name, k = max(ks.items(), key=lambda kv: kv[1]["write_bytes_per_launch"] + kv[1]["fetch_bytes_per_launch_corrected"])
+            hint = (kernel_hint or "").split("<")[0]
+            named = {n: v for n, v in ks.items() if hint and hint in n}
+            name, k = max((named or ks).items(), key=lambda kv: kv[1]["write_bytes_per_launch"] + kv[1]["fetch_bytes_per_launch_corrected"])
             per_launch = k["write_bytes_per_launch"] + k["fetch_bytes_per_launch_corrected"]
             src = {"file": os.path.relpath(path, ROOT), "collected_at_commit": rec.get("commit"), "kernel": name,
                    "how": "tools/pmc_traffic.sh (separate --pmc passes of WRITE_SIZE / FETCH_SIZE, FETCH_SIZE x2 on gfx950)",
@@ -738,7 +740,7 @@ def main():
                 "ms_per_step_hip_events": {"median": statistics.median(evs), "min": min(evs), "max": max(evs)},
                 "note": "`value`, `ms_per_step` and `roofline` come from the first region only"}
 
-    traffic, traffic_src = traffic_record(args, V, F)
+    traffic, traffic_src = traffic_record(args, V, F, wl.kernel)
     total_units = world * V * F * K
     value = total_units / elapsed
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9

@@ -5,12 +5,9 @@ tag=${1:-r01}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-run() {  # name, bench args...
+run() {  # name, bench args...: profiled + unprofiled on this box, per-dispatch min / p50 (tools/prof_one.sh)
   name=$1; shift
-  d=$GRAFT_REPO_ROOT/gpurun_out/prof_tmp_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu --no-config5 --repeats 0 > $out/${name}_bench.json 2>/dev/null
-  cp $d/*/*kernel_stats.csv $out/${name}_kernel_stats.csv
-  rm -rf $d
+  bash $GRAFT_REPO_ROOT/tools/prof_one.sh profiles_$tag $name "$@" > /dev/null
 }
 run pulseosc4096
 run pulseosc65536 --voices 65536 --steps 100 --warmup 10
@@ -24,5 +21,4 @@ run nice_mix1M --workload nice_mix --voices 1048576 --steps 48 --warmup 48
 run script131072 --workload script --voices 131072 --steps 96 --warmup 48
 run noise_filter_fused131072 --workload noise_filter_fused --voices 131072 --steps 50 --warmup 10
 run noise_filter_fused4096 --workload noise_filter_fused
-for f in $out/*_bench.json; do tail -1 $f > $f.tmp; mv $f.tmp $f; done
 ls $out

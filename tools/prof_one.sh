@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box: rocprofv3 --kernel-trace --stats of one bench command -> gpurun_out/<tag>/<name>_kernel_stats.csv + the line it printed
+# GPU box: rocprofv3 --kernel-trace --stats of one bench command, then THE SAME command without the profiler on the same box
+# -> gpurun_out/<tag>/<name>_kernel_stats.csv (rocprofv3's own summary) and <name>_summary.json = {profiled line, unprofiled
+# line, per kernel: calls, average, min, p50, p90, max from the per-dispatch trace}.
 # usage: tools/prof_one.sh <tag> <name> [bench args...]
 tag=$1; name=$2; shift 2
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
@@ -7,6 +9,27 @@ cd /tmp && export TMPDIR=/tmp
 d=$out/tmp_$name
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu --no-config5 --repeats 0 > $out/${name}_bench.json 2>/dev/null
 cp $d/*/*kernel_stats.csv $out/${name}_kernel_stats.csv
-rm -rf $d
 tail -1 $out/${name}_bench.json > $out/${name}_bench.json.tmp; mv $out/${name}_bench.json.tmp $out/${name}_bench.json
-head -4 $out/${name}_kernel_stats.csv
+python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu --no-config5 2>/dev/null | tail -1 > $out/${name}_bench_unprofiled.json
+python3 - $d $out $name <<'PY'
+import csv, glob, json, statistics, sys
+d, out, name = sys.argv[1:4]
+per = {}
+for f in glob.glob(d + "/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        per.setdefault(r["Kernel_Name"].split("(")[0], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+ks = {}
+for k, v in per.items():
+    v.sort()
+    ks[k] = {"calls": len(v), "average_us": statistics.mean(v), "min_us": v[0], "p50_us": v[len(v) // 2], "p90_us": v[int(len(v) * 0.9)], "max_us": v[-1]}
+def line(p):
+    try:
+        return json.loads(open(p).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+res = {"profiled_line": line(f"{out}/{name}_bench.json"), "unprofiled_line_same_box": line(f"{out}/{name}_bench_unprofiled.json"), "kernels": ks}
+json.dump(res, open(f"{out}/{name}_summary.json", "w"), indent=1)
+for k, s in sorted(ks.items(), key=lambda kv: -kv[1]["average_us"] * kv[1]["calls"])[:4]:
+    print("%-70s calls %6d  avg %8.2f  min %8.2f  p50 %8.2f  p90 %8.2f  max %8.2f us" % (k[:70], s["calls"], s["average_us"], s["min_us"], s["p50_us"], s["p90_us"], s["max_us"]))
+PY
+rm -rf $d
