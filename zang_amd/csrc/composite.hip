@@ -1512,11 +1512,9 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     NiceArgs a = nice_args(m, p, note_id_changed);
     float *part = m->ctx->mix_partials;
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
-    const char *pe = zh_env("ZH_NICE_MIX_LDS_PAD");
-    const uint32_t pad = pe ? (uint32_t)atoi(pe) : 0u;
     if (stereo) {
-        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<2, true>), dim3(blocks), dim3(256), pad, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
-        else hipLaunchKernelGGL((k_nice_mix<2, false>), dim3(blocks), dim3(256), pad, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<2, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        else hipLaunchKernelGGL((k_nice_mix<2, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
         if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, mix_r + start, 2, zf);
     } else {
         const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
