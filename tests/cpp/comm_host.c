@@ -37,7 +37,8 @@ static int write_all(int fd, const void *p, size_t n) {
 static int run_rank(int rank, int world, int id_in, int id_out) {
     uint8_t id[ZH_COMM_ID_BYTES];
     zh_ctx *ctx = NULL;
-    CHECK(zh_create(&ctx, rank));
+    /* COMM_HOST_ONE_DEVICE=1: every rank on device 0 (an experiment: RCCL refuses communicators with a duplicate GPU) */
+    CHECK(zh_create(&ctx, getenv("COMM_HOST_ONE_DEVICE") ? 0 : rank));
     if (!zh_comm_available()) { fprintf(stderr, "rank %d: librccl: %s\n", rank, zh_comm_last_error()); return 1; }
     if (rank == 0) {
         CHECK(zh_comm_unique_id(id));

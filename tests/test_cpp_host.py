@@ -68,3 +68,19 @@ def test_c_comm_host_one_rank_without_python():
     r = subprocess.run([COMM_EXE, "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout + r.stderr
     assert "world 1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_comm_host_two_processes_rendezvous_on_one_device():
+    """Two rank PROCESSES on the one GPU of the box: rank 0's id travels over the pipe, both enter ncclCommInitRank and RCCL's
+    bootstrap brings them together -- far enough to find that they name the same device, which RCCL refuses ("invalid usage":
+    a communicator needs one GPU per rank).  Both ranks get that answer through the C ABI's error path (ZH_ERR_RCCL_BASE - 5,
+    zh_comm_last_error) and the host exits cleanly: no hang, no crash.  The cross-process half of the N > 1 path, as far as
+    one GPU can take it."""
+    _build_c(COMM_SRC, COMM_EXE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COMM_HOST_ONE_DEVICE="1")
+    r = subprocess.run([COMM_EXE, "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 1 and r.stdout.strip().endswith("FAIL"), r.stdout + r.stderr
+    for rank in (0, 1):
+        assert f"rank {rank}: zh_comm_create" in r.stderr and "-> -105" in r.stderr, r.stderr
+    assert r.stderr.count("ncclCommInitRank: invalid usage") == 2, r.stderr
