@@ -1112,13 +1112,26 @@ __global__ void __launch_bounds__(128) k_noise_filter_pc(uint64_t *__restrict__ 
 //                     stretches with one application of the T^256 jump table (noise_jump.hip.h; ~950 instructions);
 //   filter            the state-variable recurrence alone (svf_core: 15 instructions) -> (l, b, h) per sample;
 //   writer            the output mix, the `+=` and the image store (everything after the recurrence).
-// Rings: noise tiles [8][32 frames][64 voices] producer -> filter, (l, b, h) tiles [2][3][32][64] filter -> writer;
+// Rings: noise tiles [8][32 frames][64 voices] producer -> filter, (l, b) tiles [3][2][32][64] filter -> writer;
 // monotonic tile counters in LDS, polled (bounded) with s_sleep.  Measured per wave (s_memtime, 4,096 voices): the filter
 // wave is the busiest, 3,500 cycles per 32-frame tile of which 2,400 are its 481 VALU instructions.
 // A tile that holds one of Random.float's multi-draw samples (2^-41 per sample) leaves the other producers' stretches
 // misaligned from there on: the filter wave finishes that tile, keeps where the voice stands (frame, generator state
 // after the tile, filter state), the writer drops that lane's later stores, and at the end of the kernel the lane walks
 // the rest of its span sequentially.  Same per-voice operations in the same order => the bits of k_noise_filter.
+#if defined(ZH_NF_PROF)
+__device__ unsigned long long zh_dbg[16];
+extern "C" __attribute__((visibility("default"))) int zh_debug_counters(unsigned long long *out16, int reset) {
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(zh_dbg), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(zh_dbg), z, sizeof z); }
+    return 0;
+}
+#define ZH_DBG_ADD(i, v) do { if (lane == 0) atomicAdd(&zh_dbg[i], (unsigned long long)(v)); } while (0)
+#define ZH_DBG_NOW() __builtin_readcyclecounter()
+#else
+#define ZH_DBG_ADD(i, v) do { } while (0)
+#define ZH_DBG_NOW() 0ull
+#endif
 struct NfArgs {
     uint64_t *s[4];
     float *l, *b;
@@ -1136,7 +1149,7 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
     constexpr uint32_t CH = 32, NS = 8, ST = 4, NONE = 0xFFFFFFFFu, NP = kNfProducers, NT = 64 * (NP + 2);   // ST = tiles per stretch
     __shared__ uint4 tbl[kNoiseJumpEntries];
     __shared__ float4 tile[NS][CH / 4][64];                            // float4 = four frames of a lane side by side (one 16-byte access)
-    __shared__ float4 l_q[2][CH / 4][64], b_q[2][CH / 4][64];
+    __shared__ float4 l_q[3][CH / 4][64], b_q[3][CH / 4][64];          // three slots: the filter runs up to two tiles ahead of the writer
     __shared__ uint64_t after[NP][4][64];                              // per producer: generator state after its first multi-draw tile
     __shared__ uint32_t first_multi[NP][64];                           // per producer: that tile's index
     __shared__ uint32_t dead_from[64];                                 // first tile the writer must not store (NONE: all)
@@ -1206,12 +1219,14 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
                         at(t, k) = (0.0f + white) + kSvfDcOffset;
                     }
                 }
-                if (multi && !had_multi) {
+                const bool first = multi && !had_multi;
+                if (first) {
                     had_multi = true;
                     first_multi[wave][lane] = c;
                     after[wave][0][lane] = r.s0; after[wave][1][lane] = r.s1; after[wave][2][lane] = r.s2; after[wave][3][lane] = r.s3;
                 }
-                ring_publish(&ready[slot], c + 1, lane);
+                // (the flag tells the filter wave that first_multi is worth reading for this tile: 2^-41 per sample)
+                ring_publish(&ready[slot], (c + 1) | (__builtin_amdgcn_ballot_w64(first) != 0 ? kRingFlag : 0u), lane);
             }
             if (ST * (j + NP) < nt) noise_jump_apply(r, tbl);          // over the other two producers' stretches: 256 draws
         }
@@ -1220,19 +1235,32 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
         // (l after Filter.zig:142 and b after :139 go on to the writer, which redoes :143-144 from them and the noise tile:
         // two values per frame through LDS instead of three -- an LDS instruction costs a lone wave about three VALU issues)
         l = a.l[vc]; b = a.b[vc];
-        float4 fa[Q], fb[Q];                                           // the tile in hand / the next one
-        auto fetch = [&](uint32_t c, float4 (&x)[Q]) ZH_INLINE_LAMBDA {
-            if (c >= nt || !ok) return;
-            ok = ring_wait_ge(&ready[c & (NS - 1)], c + 1);
+        // Round 3: the ring counters are read A TILE AHEAD of their use.  A wave's LDS instructions return in order, so a
+        // counter load issued behind the sixteen 16-byte writes of a tile comes back after all of them: polled on the spot
+        // (round 2) the two waits and the write drain before the publish cost this wave ~1,000 of a tile's 3,500 cycles
+        // (measured with each compiled out: ready 7.0, writ_done 3.5, first_multi 1.3 us of 55).  Now a step loads, at its
+        // top, the counters the NEXT decisions need (is tile c + 2 in its slot? has the writer released the slot tile c + 1
+        // goes to?), computes its tile, and only then looks at them -- they are old by then, which is harmless for monotonic
+        // counters: a stale value can only send the wave to the polling loop it used to run every tile.  Three register
+        // buffers: the tile in hand, the next one (loaded during the previous step) and the one after.
+        float4 f0[Q], f1[Q], f2[Q];
+        uint32_t w0 = 0, w1 = 0, w2 = 0;                               // the ready word each buffer's tile was published with
+        auto load_tile = [&](uint32_t c, float4 (&x)[Q]) ZH_INLINE_LAMBDA {
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) x[q] = tile[c & (NS - 1)][q][lane];
         };
-        auto step = [&](uint32_t c, float4 (&cur)[Q], float4 (&nxt)[Q]) ZH_INLINE_LAMBDA {
+        bool writ_ok = true;                                           // the (l, b) slot of the step about to run is free
+        auto step = [&](uint32_t c, float4 (&cur)[Q], uint32_t wcur, float4 (&nxt2)[Q], uint32_t &wnxt2) ZH_INLINE_LAMBDA {
             const uint32_t nf = min(CH, n - c * CH), p = (c / ST) % NP;
-            fetch(c + 1, nxt);                                         // (the producers run up to NS tiles ahead: rarely a wait)
-            const bool multi = first_multi[p][lane] == c;
-            if (c >= 2 && ok) ok = ring_wait_ge(&writ_done, c - 1);    // the (l, b) slot's previous tile has been written out
-            float4 (*tl)[64] = l_q[c & 1], (*tb)[64] = b_q[c & 1];
+            // issued now, looked at after the tile's arithmetic
+            const uint32_t seen_ready = c + 2 < nt ? __atomic_load_n(&ready[(c + 2) & (NS - 1)], __ATOMIC_RELAXED) : 0u;
+            const uint32_t seen_writ = __atomic_load_n(&writ_done, __ATOMIC_RELAXED);
+            const bool multi = (wcur & kRingFlag) != 0 && first_multi[p][lane] == c;   // (wave-uniform guard: no LDS read per tile)
+            asm volatile("" ::: "memory");
+            { const unsigned long long t0 = ZH_DBG_NOW();
+            if (c >= 3 && !writ_ok && ok) { ok = ring_wait_ge(&writ_done, c - 2); ZH_DBG_ADD(2, 1); }    // the (l, b) slot's previous tile (c - 3) has been written out
+            ZH_DBG_ADD(3, ZH_DBG_NOW() - t0); }
+            float4 (*tl)[64] = l_q[c % 3], (*tb)[64] = b_q[c % 3];
             if (dead_tile != NONE) {
                 // stopped: (l, b) stay as they were after the multi-draw tile; the lane's later stores are dropped anyway
             } else if (nf == CH) {
@@ -1252,17 +1280,35 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
                     at(tl, k) = m.l; at(tb, k) = m.b1;
                 }
             }
-            ring_publish(&lbh_ready, c + 1, lane);
+            ring_publish_writes(&lbh_ready, c + 1, lane);              // (behind this wave's tile writes in its LDS queue: no drain)
             if (multi && dead_tile == NONE) {                          // this tile drew more than once per sample somewhere
                 dead_tile = c;
                 dead_from[lane] = c + 1;                               // (reaches the writer before tile c + 1 does)
             }
+            if (c + 2 < nt && ok) {                                    // tile c + 2 into the buffer that held tile c - 1
+                { const unsigned long long t0 = ZH_DBG_NOW();
+                wnxt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen_ready);
+                if (!ring_reached(wnxt2, c + 3)) { ok = ring_wait_ge(&ready[(c + 2) & (NS - 1)], c + 3, &wnxt2); ZH_DBG_ADD(0, 1); }
+                ZH_DBG_ADD(1, ZH_DBG_NOW() - t0); }
+                asm volatile("" ::: "memory");
+                load_tile(c + 2, nxt2);
+            }
+            writ_ok = (int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen_writ) - (c - 1)) >= 0;   // step c + 1 needs writ_done >= c - 1
         };
-        fetch(0, fa);
-        for (uint32_t c = 0; c < nt && ok; c += 2) {
-            step(c, fa, fb);
-            if (c + 1 < nt && ok) step(c + 1, fb, fa);
+        // the first two tiles: waited for on the spot
+        const unsigned long long tw0 = ZH_DBG_NOW();
+        ok = ring_wait_ge(&ready[0], 1, &w0);
+        ZH_DBG_ADD(4, ZH_DBG_NOW() - tw0);
+        load_tile(0, f0);
+        if (nt > 1 && ok) { ok = ring_wait_ge(&ready[1], 2, &w1); asm volatile("" ::: "memory"); load_tile(1, f1); }
+        const unsigned long long tl0 = ZH_DBG_NOW();
+        for (uint32_t c = 0; c < nt && ok; c += 3) {
+            step(c, f0, w0, f2, w2);
+            if (c + 1 < nt && ok) step(c + 1, f1, w1, f0, w0);
+            if (c + 2 < nt && ok) step(c + 2, f2, w2, f1, w1);
         }
+        ZH_DBG_ADD(5, ZH_DBG_NOW() - tl0);
+        ZH_DBG_ADD(6, 1);
     } else {
         // ---------------------------------------------------------------- writer: Filter.zig:143-144 again, mix, +=, store
         for (uint32_t c = 0; c < nt && ok; c++) {
@@ -1272,7 +1318,7 @@ __global__ void __launch_bounds__(64 * (kNfProducers + 2)) k_noise_filter_ring(c
             // loads return 0 and its stores are dropped
             const uint32_t voff = c >= dead_from[lane] ? 0x80000000u : vc * 4u;
             const zh_rsrc_t ro = make_rsrc(a.out.p + (size_t)(a.start + c * CH) * a.out.stride, CH * orow);
-            float4 (*ti)[64] = tile[c & (NS - 1)], (*tl)[64] = l_q[c & 1], (*tb)[64] = b_q[c & 1];
+            float4 (*ti)[64] = tile[c & (NS - 1)], (*tl)[64] = l_q[c % 3], (*tb)[64] = b_q[c % 3];
             auto one = [&](uint32_t k, float in, float lv, float b1, float o) ZH_INLINE_LAMBDA {
                 const SvfOut sv = svf_finish(lv, b1, in, cut, res);
                 const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
