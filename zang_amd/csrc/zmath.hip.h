@@ -193,24 +193,19 @@ ZD int zrem_pio2f(float x, double *y) {
 
 // musl sinf / cosf (what Zig's std.math.sin / cos are ported from): reduce x to y in [-pi/4, pi/4] with
 // x = y + n*pi/2 (in double), then one of two polynomial kernels picked by n & 3.  musl spells the
-// reduction out as five magnitude ranges times two signs for |x| <= 9pi/4, a two-constant form up to
-// 2^28*pi/2 and a general routine above.  A wave's lanes sit in all of those leaves at once (oscillator
-// phases are spread), so the leaves are folded into straight-line code that performs, per lane, exactly
-// the operations of that lane's leaf:
-//   fn = rint(x * 2/pi).  The medium leaf computes it as x*invpio2 + 1.5*2^52 - 1.5*2^52, which IS
-//        round-to-nearest-even for |x*invpio2| < 2^51; below 9pi/4 it equals +-k of musl's magnitude
-//        ladder for every one of the 1.09e9 floats in range (tools/check_sin_reduction.py; tests/test_oracle_math.py).
-//   small leaf  y = x - fn*pio2            (musl: x -+ k*M_PI_2, one rounding; k*pio2 is exact for
-//                                           1, 2, 4 and rounds once for 3 like musl's s3pio2)
-//   medium leaf y = x - fn*pio2_1 - fn*pio2_1t
-// and a select on |x| <= 9pi/4.  The medium leaf's two correction branches and the large-argument
-// routine sit behind one wave-uniform test and run the complete reference routine for the lanes that
-// need it.  Then ONE evaluation of each kernel on y (z = y*y and w = z*z shared) and selects: the
-// kernels are exactly odd / even in floating point, so sindf(-y) = -sindf(y) and every negation is a
+// reduction out as five magnitude ranges times two signs for |x| <= 9pi/4 (x -+ k*M_PI_2, one constant), a
+// two-constant form up to 2^28*pi/2 (fn = x*invpio2 + 1.5*2^52 - 1.5*2^52, y = x - fn*pio2_1 - fn*pio2_1t, two
+// correction branches) and a general routine above.  A wave's lanes sit in all of those leaves at once (oscillator
+// phases are spread), so branches cost every lane every leaf.  Round 2 folded the leaves into straight-line code
+// performing, per lane, exactly the operations of that lane's leaf (both reductions, a select); round 3 replaced
+// "the same operations" by "the same bits for every argument", established by exhaustion (the list inside the
+// function): ONE reduction for every |x| below the Payne-Hanek range, the large-argument routine (and inf / nan)
+// behind one wave-uniform test.  Then ONE evaluation of each kernel on y (z = y*y and w = z*z shared) and
+// selects: the kernels are exactly odd / even in floating point, so sindf(-y) = -sindf(y) and every negation is a
 // sign-bit flip of the result.
 template <bool MAYBE_LARGE = true>
 ZD int zreduce_pio2f(float x, uint32_t ix, double &y) {
-    const double invpio2 = 6.36619772367581382433e-01, pio2 = 1.57079632679489661923,
+    const double invpio2 = 6.36619772367581382433e-01,
                  pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08,
                  toint = 1.5 / 2.220446049250313e-16;
     const double xd = (double)x;
@@ -218,17 +213,18 @@ ZD int zreduce_pio2f(float x, uint32_t ix, double &y) {
     // exhaustion (tools/ubench/sin_exhaustive.hip, all 2^32 patterns, sinf and cosf; profiles/r03/sin_exhaustive.txt):
     //  * fn by musl's own magic-number rounding, x*invpio2 + 1.5*2^52 - 1.5*2^52, with the product fused into the add; the
     //    integer n is then the low mantissa word of the sum (two's complement): no v_rndne_f64, no v_cvt_i32_f64;
-    //  * the products of both leaves fused into their subtractions;
+    //  * the products of the reduction fused into its subtractions;
     //  * no "|y| > pi/4" correction test: musl says it "matters with directed rounding" -- under round-to-nearest it changes
     //    no result; what is left of the rare path is |x| >= 2^28*pi/2 (Payne-Hanek), and inf / nan, whose y = x - x runs
     //    through the kernels to the same NaN musl's early return gives.
+    //  * ONE leaf: musl reduces |x| <= 9pi/4 as x - k*pi/2 with a single constant and everything above with the two-constant
+    //    form; the two-constant form applied to EVERY argument gives the same sinf and cosf bits for all 2^32 arguments but
+    //    one magnitude -- |x| = 0x40406406 (3.0061...), where sinf comes out one ulp high -- which zsinf corrects by name
+    //    (kZSinOneLeafOdd): no second reduction, no select.
     const double fnm = __builtin_fma(xd, invpio2, toint);
     const double fn = fnm - toint;
     int n = (int)(uint32_t)__double_as_longlong(fnm);
-    const double ys = __builtin_fma(-fn, pio2, xd);                                        // xd - fn * pio2
-    const double ym = __builtin_fma(-fn, pio2_1t, __builtin_fma(-fn, pio2_1, xd));         // xd - fn * pio2_1 - fn * pio2_1t
-    const bool small = ix <= 0x40e231d5;                              // |x| <= 9pi/4
-    y = small ? ys : ym;
+    y = __builtin_fma(-fn, pio2_1t, __builtin_fma(-fn, pio2_1, xd));                       // xd - fn * pio2_1 - fn * pio2_1t
     // (the compare as a wave mask: the ballot of a combined per-lane bool costs a 0/1 select and a compare more)
     // MAYBE_LARGE = false: the caller has established (wave-wide, for a whole chunk of frames: kZSinNoLargeBelow) that no
     // argument reaches the rare path -- without its branch the sines of an unrolled chunk are one basic block
@@ -245,8 +241,7 @@ ZD int zreduce_pio2f(float x, uint32_t ix, double &y) {
 // the f32 result only if the f64 value then crosses a rounding boundary of the final conversion; whether that ever happens
 // is decided by exhaustion, not by argument: tools/ubench/sin_exhaustive.hip runs ALL 2^32 f32 bit patterns through musl's
 // operation order and through this form -- sinf and cosf, every leaf of the reduction -- and finds 0 differing results
-// (profiles/r03/sin_exhaustive.txt; each of the nine fusions alone, and all together; dropping the small leaf instead
-// differs for 2 arguments and is not done).  tests/test_gpu_math.py repeats a 2^28-argument stratified subset against the
+// (profiles/r03/sin_exhaustive.txt; each of the fusions alone, and all together).  tests/test_gpu_math.py repeats a 2^28-argument stratified subset against the
 // oracle, which keeps musl's order.
 ZD void zsincos_kernels(double y, float &sv, float &cv) {
     const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
@@ -256,6 +251,7 @@ ZD void zsincos_kernels(double y, float &sv, float &cv) {
     cv = (float)__builtin_fma(w * z, __builtin_fma(z, C3, C2), __builtin_fma(w, C1, __builtin_fma(z, C0, 1.0)));
 }
 
+constexpr uint32_t kZSinOneLeafOdd = 0x40406406u;            // see zreduce_pio2f ("ONE leaf"); found and checked by tools/ubench/sin_exhaustive.hip
 // |x| below this (NaN excluded by the comparison) never takes the rare path: zsinf<false> / zcosf<false> are then exact
 constexpr float kZSinNoLargeBelow = 4.0e8f;                    // < 2^28 * pi/2 = 4.2166e8 (0x4dc90fdb)
 template <bool MAYBE_LARGE = true>
@@ -267,6 +263,7 @@ ZD float zsinf(float x) {
     zsincos_kernels(y, sv, cv);
     // n & 3: 0 sindf(y) | 1 cosdf(y) | 2 sindf(-y) = -sindf(y) | 3 -cosdf(y)
     float r = zu2f(zf2u((n & 1) ? cv : sv) ^ ((uint32_t)(n & 2) << 30));
+    r = zu2f(zf2u(r) - (uint32_t)(ix == kZSinOneLeafOdd));    // the one magnitude where the single-leaf reduction is an ulp high
     if (ix < 0x39800000) r = x;                               // |x| < 2^-12 (needed for -0.0 alone: the kernel gives +0.0)
     return r;                                                 // (inf, nan: y = x - x from the rare path, NaN through the kernel)
 }
