@@ -52,8 +52,9 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         * previous paint call was given.  The reference recomputes a paint's per-voice constants on every call
         * (e.g. PulseOsc.zig:87-95); a module may instead reuse the ones that call left behind.  Honoured by the
         * constant-frequency PulseOsc / TriSawOsc paints, ignored elsewhere; results are bit-identical either way.
-        * A paint recorded into a graph with this flag uses the constants stored by the last unflagged eager paint
-        * before the replay. */ };
+        * A paint recorded into a graph with this flag uses the constants the module held when it was RECORDED (those of
+        * the last unflagged eager paint before the capture): from then on the module stores no new constants -- later
+        * unflagged paints compute theirs without keeping them, later flagged paints take the computing form. */ };
 
 typedef struct zh_ctx zh_ctx;
 

@@ -335,3 +335,40 @@ def test_graph_of_in_place_paints_survives_flipping_paints_between_replays(ctx):
             for a, b in zip(me, mg):
                 assert a.state().tobytes() == b.state().tobytes(), k
         g.close(); c2.close()
+
+
+def test_graph_with_params_unchanged_paint_keeps_its_constants(ctx):
+    """A recorded ZH_PAINT_PARAMS_UNCHANGED paint reads the module's constants table at every replay.  An eager paint with
+    OTHER params between replays must not rewrite it (it used to: the replays then rendered with the new constants while every
+    other param of the recorded call was the old one).  Twin module: the same sequence, all eager."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V = 1024
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
+        fr2, col2 = (fr * 1.5).contiguous(), (1.0 - col).contiguous()
+        sp = zang.Span(0, F)
+        me, mg = mod.PulseOsc(V, c2), mod.PulseOsc(V, c2)
+        a_e, a_g, b_e, b_g = (c2.image(F, V) for _ in range(4))
+        P = lambda m, f, c: m.Params(SR, zang.constant(f), c)
+        for m, img in ((me, a_e), (mg, a_g)):
+            m.paint(sp, [img], [], False, P(m, fr, col), zero_first=True)              # unflagged: stores the constants
+        c2.sync()
+        g = c2.capture(lambda: mg.paint(sp, [a_g], [], False, P(mg, fr, col), zero_first=True, params_unchanged=True))
+        for k in range(3):
+            me.paint(sp, [a_e], [], False, P(me, fr, col), zero_first=True); g.launch()
+            me.paint(sp, [b_e], [], False, P(me, fr2, col2), zero_first=True)          # other params, eager, unflagged
+            mg.paint(sp, [b_g], [], False, P(mg, fr2, col2), zero_first=True)
+            me.paint(sp, [a_e], [], False, P(me, fr, col), zero_first=True); g.launch()
+            mg_flagged = c2.image(F, V); me_flagged = c2.image(F, V)
+            me.paint(sp, [me_flagged], [], False, P(me, fr2, col2), zero_first=True, params_unchanged=(k > 0))
+            mg.paint(sp, [mg_flagged], [], False, P(mg, fr2, col2), zero_first=True, params_unchanged=(k > 0))
+            c2.sync()
+            for x, y in ((a_e, a_g), (b_e, b_g), (me_flagged, mg_flagged)):
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32)), k
+            assert me.state().tobytes() == mg.state().tobytes(), k
+        g.close(); c2.close()

@@ -26,6 +26,7 @@
 struct OscTable {
     uint32_t *words;             // [KW + 1][n]
     bool valid;
+    bool pinned;                 // a captured graph holds a table-form paint: the table's contents are frozen from then on
     float sample_rate;
     zh_f32 freq, color;
 };
@@ -497,7 +498,14 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
             const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
             OscArgs a;
             a.cnt_in = m->cnt[m->cur]; a.cnt_out = m->cnt[m->cur ^ 1];
-            a.tab = (use_tab || !ctx->capturing) ? m->tab.words : nullptr;   // a recorded setup-form paint never rewrites the table
+            // A recorded table-form paint reads the table at every replay, so once one has been captured nothing rewrites the
+            // table any more (an eager setup-form paint with other params between replays used to: the replays then rendered with
+            // THOSE constants): later unflagged paints compute their constants without storing them, and the host-side record is
+            // invalidated so that later flagged paints take the setup form too.  A recorded setup-form paint never wrote it.
+            if (use_tab && ctx->capturing) m->tab.pinned = true;
+            const bool write_tab = !use_tab && !ctx->capturing && !m->tab.pinned;
+            if (!use_tab && !ctx->capturing && m->tab.pinned) m->tab.valid = false;
+            a.tab = (use_tab || write_tab) ? m->tab.words : nullptr;
             a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.nb = cnt_b; a.prio = osc_prio() ? 1u : 0u;
             a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
             for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
@@ -544,7 +552,7 @@ template <class M> static int osc_common_check(M *m, uint32_t start, uint32_t en
 
 template <class M> static int osc_create_common(zh_ctx *ctx, M *m, uint32_t n, int kw) {
     m->ctx = ctx; m->n = n; m->cur = 0; m->cnt[0] = m->cnt[1] = nullptr; m->id = 0;
-    m->tab.words = nullptr; m->tab.valid = false;
+    m->tab.words = nullptr; m->tab.valid = false; m->tab.pinned = false;
     int rc = dev_alloc(&m->cnt[0], n);
     if (!rc) rc = dev_alloc(&m->cnt[1], n);
     if (!rc) rc = dev_alloc(&m->tab.words, (size_t)(kw + 1) * n);
