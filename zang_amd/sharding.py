@@ -65,16 +65,41 @@ class Comm:
             raise abi.ZangHipError("zh_comm: librccl is not available on every rank: " + self.lib.zh_comm_last_error().decode())
         uid = (C.c_uint8 * abi.COMM_ID_BYTES)()
         payload = [None]
+        err = None
         if self.rank == 0:
-            abi.check(self.lib.zh_comm_unique_id(uid), "zh_comm_unique_id")
-            payload = [bytes(uid)]
+            rc = self.lib.zh_comm_unique_id(uid)
+            if rc == abi.ZH_OK:
+                payload = [bytes(uid)]
+            else:
+                err = "zh_comm_unique_id failed: %d (%s)" % (rc, self.lib.zh_comm_last_error().decode())
         if self.world > 1:
             if not use_dist:
                 raise abi.ZangHipError("Comm(world > 1) needs torch.distributed as the host channel for the id")
-            dist.broadcast_object_list(payload, src=0, group=control_group)
+            dist.broadcast_object_list(payload, src=0, group=control_group)         # None = rank 0 could not make the id
+            if payload[0] is None:
+                raise abi.ZangHipError("zh_comm: " + (err or "rank 0 could not make the communicator id"))
             C.memmove(uid, payload[0], abi.COMM_ID_BYTES)
+        elif err:
+            raise abi.ZangHipError("zh_comm: " + err)
         h = C.c_void_p()
-        abi.check(self.lib.zh_comm_create(ctx.handle, self.world, self.rank, uid, C.byref(h)), "zh_comm_create")
+        rc = self.lib.zh_comm_create(ctx.handle, self.world, self.rank, uid, C.byref(h))
+        # every rank learns whether EVERY rank has its communicator (a rank that failed alone would leave the others waiting
+        # for it in the first collective)
+        good = 1 if rc == abi.ZH_OK else 0
+        if use_dist and self.world > 1:
+            import torch
+            t = torch.tensor([good], dtype=torch.int32)
+            if dist.get_backend(control_group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group)
+            good_all = int(t.item())
+        else:
+            good_all = good
+        if not good_all:
+            if good:
+                self.lib.zh_comm_destroy(h)
+            raise abi.ZangHipError("zh_comm_create failed on %s: %d (%s)" % ("this rank" if not good else "another rank", rc,
+                                                                            self.lib.zh_comm_last_error().decode()))
         self.handle = h
 
     def allreduce_mix(self, mix):
