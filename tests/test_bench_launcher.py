@@ -86,3 +86,29 @@ def test_gpus_flag_must_agree_with_world_size():
 def test_single_rank_without_gpu_fails_loudly():
     r = subprocess.run([sys.executable, BENCH, "--steps", "4", "--warmup", "0"], env=_env(), capture_output=True, text=True, timeout=100)
     assert r.returncode == 3 and "no HIP device" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+def test_two_emulated_ranks_on_one_gpu_run_the_whole_multi_gpu_path(exchange):
+    """GPU box (one GPU): `ZH_BENCH_EMULATE=1 bench.py --gpus 2` = two rank processes on device 0 with the driver's step
+    counts -- the N > 1 code path end to end (launcher, rendezvous, 20-step region captured as ONE graph, the exchange inside
+    the timed region, per-batch and per-buffer exchange timings, the shard without exchange, the scaling factor), gloo
+    standing in for RCCL (two ranks on one device cannot form an RCCL communicator: tests/test_cpp_host.py) and, for
+    `--exchange p2p`, the HIP-IPC slot exchange between the two processes."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--voices", "8192", "--exchange", exchange,
+                        "--repeats", "2"], capture_output=True, text=True, timeout=540, env=_env(ZH_BENCH_EMULATE="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["config"]["launch"] == "hipGraph x20 steps"
+    assert d["config"]["total_voices"] == 16384 and d["value"] > 0 and d["scaling"] == "weak"
+    c = d["collective"]
+    assert c["world_size_seen"] == 2 and c["in_timed_region"] and c["per"] == "20-buffer batch" and c["bytes"] == 20 * 2 * 1024 * 4
+    if exchange == "rccl":
+        assert "gloo" in c["backend"] and "ZH_BENCH_EMULATE" in c["note"]
+        assert c["per_buffer_form"]["bytes"] == 2 * 1024 * 4 and c["per_buffer_form"]["reduce_us"] > 0
+    else:
+        assert c["backend"] == "host barriers + HIP IPC"
+    assert d["single_gpu_shard"]["value"] > 0 and 0.5 < d["scaling_factor"] < 2.5
+    assert d["build"]["zh_version"].startswith("zang_hip")
