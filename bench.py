@@ -285,6 +285,15 @@ class Workload:
         else:
             self.m.paint_mix(self.span, t[0], new, P, zero_first=True)
 
+    def step_batch(self, B):
+        """B consecutive steps of the stereo mixdown workload as ONE launch (zh_nice_paint_mix_stereo_batch: what an offline
+        renderer that knows its params ahead would call; same bits as B single steps)."""
+        rows = [(self.nsteps + j) % 48 for j in range(B)]
+        flags = [self._note_on() for _ in range(B)]                # advances self.nsteps
+        Ps = [self.m.Params(SR, self.freq, on) for (on, _) in flags]
+        self.m.paint_mix_stereo_batch(self.span, [self.targets[r][0] for r in rows], [self.targets[r][1] for r in rows], self.gain_l, self.gain_r,
+                                      [new for (_, new) in flags], Ps, zero_first=True)
+
     def use_slots(self, slots):
         """Direct-write exchange: the mixdown kernels store into this rank's slot of the root's block instead of
         self.mixes (zang_amd.sharding.SlotExchange); call before capturing the graph."""
@@ -718,6 +727,39 @@ def main():
             if self.wl.slots is not None:
                 self.wl.slots.close()
 
+    def time_batched(run, nsteps):
+        """The same `nsteps` buffers of a stereo nice_mix Runner painted B per launch (extra key only: a step of `value` stays
+        one buffer per launch)."""
+        w = run.wl
+        if w.name != "nice_mix" or w.channels != 2 or args.eager or w.slots is not None:
+            return None
+        B = max(b for b in (8, 6, 5, 4, 3, 2, 1) if nsteps % b == 0)
+        if B == 1:
+            return None
+        def steps():
+            for _ in range(0, nsteps, B):
+                w.step_batch(B)
+        w.nsteps = 0
+        steps(); torch.cuda.synchronize()
+        w.nsteps = 0
+        g = ctx.capture(steps)
+        g.launch(); torch.cuda.synchronize()
+        e0, e1 = make_event(), make_event()
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        abi.check(lib.zh_event_record(ctx.handle, e0), "zh_event_record")
+        g.launch()
+        abi.check(lib.zh_event_record(ctx.handle, e1), "zh_event_record")
+        torch.cuda.synchronize()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        ms = C.c_float()
+        abi.check(lib.zh_event_elapsed_ms(e0, e1, C.byref(ms)), "zh_event_elapsed_ms")
+        lib.zh_event_destroy(e0); lib.zh_event_destroy(e1)
+        g.close()
+        return {"buffers_per_launch": B, "buffers": nsteps, "ms_per_buffer_wall": wall / nsteps * 1e3, "ms_per_buffer_hip_events": ms.value / nsteps,
+                "value_per_gpu": w.V * F * nsteps / wall,
+                "what": "zh_nice_paint_mix_stereo_batch: %d consecutive buffers per launch, state in registers between them, one second pass (same bits; no exchange)" % B}
+
     K = args.steps
     main_run = Runner(args.workload, V, K, exchange=args.exchange, slots=(args.exchange == "p2p" and world > 1 and args.workload == "nice_mix"))
     wl, G, graph = main_run.wl, main_run.G, main_run.graph
@@ -850,6 +892,11 @@ def main():
                 out["p2p_direct"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             dog.cancel()
 
+    if mixdown:
+        bt = time_batched(main_run, G if G else 48)
+        if bt:
+            out["batched_launches"] = bt
+
     if world == 1 and args.workload == "pulseosc" and not args.eager:
         # The same buffers painted through zh_pulseosc_paint_batch: B consecutive 1024-frame paints (same span and params,
         # buffer b into its own image) as ONE launch -- the phase of any frame is cnt + frames_before * ifreq exactly, so the
@@ -888,6 +935,9 @@ def main():
         out["config5_shard"] = {"workload": f"nice_mix: 131072 voices x {F} frames, {args.channels}-channel mixdown, no exchange (one GPU)",
                                 "value": 131072 * F * 96 / e5, "ms_per_step": e5 / 96 * 1e3, "steps": 96, "launch_ms_hip_events": m5 / 96,
                                 "realtime_voices_48k": 131072 * F * 96 / e5 / SR}
+        bt = time_batched(c5, 96)
+        if bt:
+            out["config5_shard"]["batched_launches"] = bt
         c5.close()
 
     if rank == 0 and world == 1 and not args.no_parity:

@@ -438,6 +438,16 @@ ZH_API int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t span_start, uint32_t sp
                                     zh_f32 gain_left, zh_f32 gain_right, zh_bool note_id_changed,
                                     const zh_nice_params *params, uint32_t flags);
 
+/* n_buffers consecutive zh_nice_paint_mix_stereo calls -- the host's loop over 1024-frame buffers (examples/write_wav.zig:58-93)
+ * of an offline render that knows its params ahead -- as ONE launch: buffer b paints [span_start, span_end) with params[b] and
+ * note_id_changed[b] into mix_left[b] / mix_right[b] (host arrays of n_buffers device pointers / structs); the voices' state
+ * stays in registers from buffer to buffer and the second mixdown pass runs once for all buffers.  Bit-identical to n_buffers
+ * single calls; the sample rate must be the same in every params[b] (ZH_ERR_UNSUPPORTED otherwise). */
+enum { ZH_MIX_MAX_BATCH = 16 };
+ZH_API int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t span_start, uint32_t span_end, uint32_t n_buffers,
+                                          float *const *mix_left, float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right,
+                                          const zh_bool *note_id_changed, const zh_nice_params *params, uint32_t flags);
+
 /* Per-voice span table: the output of NoteTracker -> PolyphonyDispatcher -> Trigger for one buffer
  * (examples/example_song.zig:326-349), i.e. for every voice up to `max_spans` sub-spans, ascending and
  * non-overlapping, each with the note's params and note_id_changed.  One launch then performs, per voice,

@@ -422,3 +422,34 @@ def test_nice_with_non_finite_and_huge_filter_states(ctx, oracle, form, monkeypa
         same(g2["flt"]["l"].astype(np.float32), np.array([r.flt.l for r in st], np.float32), "flt.l")
         same(g2["flt"]["b"].astype(np.float32), np.array([r.flt.b for r in st], np.float32), "flt.b")
     assert nans > 1000
+
+
+@pytest.mark.parametrize("V", [300, 4096])
+def test_nice_paint_mix_stereo_batch_equals_separate_calls(ctx, V):
+    """zh_nice_paint_mix_stereo_batch: n consecutive paints in one launch (state in registers from buffer to buffer, one
+    second pass) -- bit for bit the mixes and the final state of the n separate calls, with notes going on and off, a new note
+    and a frequency change between buffers, ZERO_FIRST and `+=`, and a sub-span."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    freq, color, u2, _ = workloads.voice_params(5, 3, V)
+    gl = util.dev((0.25 + 0.5 * u2).astype(np.float32)); gr = util.dev((0.75 - 0.5 * u2).astype(np.float32))
+    f1, f2 = util.dev(freq), util.dev((freq * np.float32(1.25)).astype(np.float32))
+    on_mix = util.dev((np.arange(V) % 3 != 0).astype(np.uint8))
+    ma, mb = mod.NiceInstrument(V, util.dev(color), ctx), mod.NiceInstrument(V, util.dev(color), ctx)
+    script = [(True, True, f1), (True, False, f1), (on_mix, False, f1), (False, False, f2), (True, True, f2), (False, False, f2), (on_mix, on_mix, f1)]
+    for (span, zf) in ((zang.Span(0, F), True), (zang.Span(100, 900), False)):
+        n = len(script)
+        la = torch.full((n, F), 0.5, device="cuda"); ra = torch.full((n, F), -0.25, device="cuda")
+        lb, rb = la.clone(), ra.clone()
+        P = [ma.Params(SR, f, on) for (on, _, f) in script]
+        for k, (on, nic, f) in enumerate(script):
+            ma.paint_mix_stereo(span, la[k], ra[k], gl, gr, nic, P[k], zero_first=zf)
+        mb.paint_mix_stereo_batch(span, [lb[k] for k in range(n)], [rb[k] for k in range(n)], gl, gr, [nic for (_, nic, _) in script], P, zero_first=zf)
+        ctx.sync()
+        assert float(la.abs().max()) > 0.5
+        assert torch.equal(la.view(torch.int32), lb.view(torch.int32)) and torch.equal(ra.view(torch.int32), rb.view(torch.int32))
+        assert ma.state().tobytes() == mb.state().tobytes()
+    # argument checks
+    from zang_amd import abi
+    with pytest.raises(abi.ZangHipError):
+        mb.paint_mix_stereo_batch(zang.Span(0, F), [lb[0], lb[1]], [rb[0], rb[1]], gl, gr, [False, False], [ma.Params(SR, f1, True), ma.Params(44100.0, f1, True)])

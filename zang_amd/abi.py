@@ -311,6 +311,7 @@ SIGNATURES = {
     "zh_comm_rank": (C.c_int, [vp]),
     "zh_allreduce_mix": (C.c_int, [vp, vp, C.c_size_t]),
     "zh_reduce_mix": (C.c_int, [vp, vp, C.c_size_t, u32]),
+    "zh_nice_paint_mix_stereo_batch": (C.c_int, [vp, u32, u32, u32, P(vp), P(vp), F32, F32, P(Bool), P(NiceParams), u32]),
     "zh_sineosc_create": (C.c_int, [vp, u32, P(vp)]),
     "zh_sineosc_destroy": (C.c_int, [vp]),
     "zh_sineosc_get_state": (C.c_int, [vp, vp]),

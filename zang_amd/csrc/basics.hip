@@ -214,14 +214,16 @@ __global__ void __launch_bounds__(64 * MIX_SEG) k_mix_pass2(const float *__restr
 // per stereo buffer instead of 16 -- and both channels in ONE launch (a second pass2 launch was 5 us per buffer).
 // Fixed order => reproducible bits.
 constexpr int MIXW_SEG = 64, MIXW_F = 16;
+// (grid.z = buffer of a batch: partials[buffer][channel][row][frame], one destination pair per buffer)
+constexpr int kMixMaxBatch = 16;
+struct MixDst { float *l[kMixMaxBatch], *r[kMixMaxBatch]; };
 __global__ void __launch_bounds__(MIXW_SEG * MIXW_F) k_mix_pass2_wide(const float *__restrict__ partials, size_t channel_stride, uint32_t rows,
-                                                                      uint32_t nframes, float *__restrict__ dst0, float *__restrict__ dst1,
-                                                                      int zero_first) {
+                                                                      uint32_t nframes, const MixDst d, int zero_first) {
     __shared__ float seg_sum[MIXW_SEG][MIXW_F];
     const uint32_t fl = threadIdx.x % MIXW_F, seg = threadIdx.x / MIXW_F;
     const uint32_t f = blockIdx.x * MIXW_F + fl;
-    const float *part = partials + (size_t)blockIdx.y * channel_stride;
-    float *dst = blockIdx.y ? dst1 : dst0;
+    const float *part = partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * channel_stride;
+    float *dst = blockIdx.y ? d.r[blockIdx.z] : d.l[blockIdx.z];
     const uint32_t per = (rows + MIXW_SEG - 1) / MIXW_SEG;
     const uint32_t t0 = min(seg * per, rows), t1 = min(t0 + per, rows);
     float s = 0.0f;
@@ -299,10 +301,16 @@ void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, 
                        nframes, dst, zero_first);
 }
 // channels = 1 or 2 (dst1 unused for 1): partials[channel][row][frame], rows summed in row order
+void zh_mix_pass2_wide_batch_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes,
+                                    float *const *dst0, float *const *dst1, uint32_t n_buffers, int channels, int zero_first) {
+    MixDst d;
+    for (int k = 0; k < kMixMaxBatch; k++) { d.l[k] = (uint32_t)k < n_buffers ? dst0[k] : nullptr; d.r[k] = ((uint32_t)k < n_buffers && dst1) ? dst1[k] : nullptr; }
+    hipLaunchKernelGGL(k_mix_pass2_wide, dim3((nframes + MIXW_F - 1) / MIXW_F, channels, n_buffers), dim3(MIXW_SEG * MIXW_F), 0, ctx->stream, partials,
+                       channel_stride, rows, nframes, d, zero_first);
+}
 void zh_mix_pass2_wide_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes, float *dst0,
                               float *dst1, int channels, int zero_first) {
-    hipLaunchKernelGGL(k_mix_pass2_wide, dim3((nframes + MIXW_F - 1) / MIXW_F, channels), dim3(MIXW_SEG * MIXW_F), 0, ctx->stream, partials,
-                       channel_stride, rows, nframes, dst0, dst1, zero_first);
+    zh_mix_pass2_wide_batch_launch(ctx, partials, channel_stride, rows, nframes, &dst0, dst1 ? &dst1 : nullptr, 1, channels, zero_first);
 }
 void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
     zh_mix_pass2_launch_at(ctx, ctx->mix_partials, tiles, nframes, dst, zero_first);

@@ -24,6 +24,8 @@ void zh_mix_pass2_launch(zh_ctx *ctx, uint32_t tiles, uint32_t nframes, float *d
 void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, uint32_t nframes, float *dst, int zero_first);
 void zh_mix_pass2_wide_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes, float *dst0,
                               float *dst1, int channels, int zero_first);
+void zh_mix_pass2_wide_batch_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes,
+                                    float *const *dst0, float *const *dst1, uint32_t n_buffers, int channels, int zero_first);
 
 struct zh_nice {
     zh_ctx *ctx;
@@ -175,11 +177,16 @@ struct NiceArgs {
 };
 
 // `v` = the lane's first voice (W = 2: even)
+// the seven state words a paint loads and stores (what carries a voice from one paint call to the next)
 template <int W>
-__device__ __forceinline__ void nice_load(NiceLaneT<W> &n, const NiceArgs &a, uint32_t v) {
+__device__ __forceinline__ void nice_load_state(NiceLaneT<W> &n, const NiceArgs &a, uint32_t v) {
     n.cnt = zload_u<W>(a.cnt, v); n.l = zload_f<W>(a.fl, v); n.b = zload_f<W>(a.fb, v);
     n.env.state = zload_u<W>(a.estate, v); n.env.t = zload_f<W>(a.et, v);
     n.env.last_value = zload_f<W>(a.elast, v); n.env.start = zload_f<W>(a.estart, v);
+}
+template <int W>
+__device__ __forceinline__ void nice_load(NiceLaneT<W> &n, const NiceArgs &a, uint32_t v) {
+    nice_load_state(n, a, v);
     n.begin(a.sample_rate, a.srf, a.sr8, zget_f32p<W>(a.freq, v), zload_f<W>(a.color, v), zget_boolp<W>(a.note_on, v), zget_boolp<W>(a.nic, v));
 }
 template <int W>
@@ -501,38 +508,12 @@ constexpr int MIXS = 68;      // floats per tile row: 16-byte aligned rows, and 
 // voice's sample by that voice's channel gain first -- a lane's 32 voices are the same in every chunk, so their
 // 2 x 32 gains sit in registers -- and partials are [channel][block][frame].
 // ROLL: the oscillator carries the previous frame's half-period bit as a lane mask (dsp.hip.h pulse_sample_roll).
-template <int C, bool ROLL>
-__global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
-                                                  F32P gain_l, F32P gain_r) {
-    __shared__ float tile_all[4][MIXF][MIXS];
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float (*tile)[MIXS] = tile_all[wave];                               // this wave's tile: no other wave touches it
-    const uint32_t nframes = end - start;
-    const uint32_t wave_global = blockIdx.x * 4 + wave;
-    const size_t channel_stride = (size_t)gridDim.x * 4 * nframes;      // partials[channel][wave][frame]
-    const bool live = v < a.V;
-    // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
-    // exec-mask region (an s_and_saveexec / branch / restore per frame: ~10 of ~85 instructions)
-    NiceLane n;
-    nice_load(n, a, live ? v : a.V - 1);
-    if (!live) {
-        // a lane past the last voice contributes +0.0 by construction rather than through a select per frame: a silent
-        // oscillator, a filter at rest (finite whatever voice V-1's state is) and an envelope that paints nothing --
-        // frame_masked() ANDs its value with m_painted, a mode of NONE never leaves NONE inside a paint, and
-        // 0.0f + (+0.0f * finite) = +0.0f
-        n.k.ifreq = 0u; n.k.brpt = 0u; n.k.gdf2 = 0.0f; n.k.cc121 = 0.0f; n.k.cc212 = 0.0f; n.g = n.ng = 0.0f;   // (as begin() silences a bad frequency)
-        n.l = n.b = 0.0f;
-        n.env.mode = ENV_MODE_NONE; n.env.m_painted = 0u;
-    }
-    const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
-    PulseRoll roll;
-    n.roll_begin(roll);
+// every lane needs the gains of the 32 voices it adds up: the workgroup's 256 pairs go through LDS once (two coalesced loads
+// per lane instead of 64 scattered ones: 2 us per launch at 131,072 voices) -- the kernel's only workgroup barrier
+template <int C, class G2>
+__device__ __forceinline__ void nice_mix_gains(G2 &g2, const F32P &gain_l, const F32P &gain_r, bool live, uint32_t v, uint32_t wave, uint32_t rh) {
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 g2[C == 2 ? 32 : 1];                                             // {left, right} gain of each of the lane's 32 voices
     if constexpr (C == 2) {
-        // every lane needs the gains of the 32 voices it adds up: the workgroup's 256 pairs go through LDS once (two coalesced
-        // loads per lane instead of 64 scattered ones: 2 us per launch at 131,072 voices) -- the kernel's only workgroup barrier
         __shared__ f2 gains[256];
         gains[threadIdx.x] = live ? f2{gain_l.get(v), gain_r.get(v)} : f2{0.0f, 0.0f};   // (voices past the last: tile entries are 0.0f)
         __syncthreads();
@@ -540,6 +521,13 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
 #pragma unroll
         for (int j = 0; j < 32; j++) g2[j] = mine[j];
     }
+}
+
+// One paint's frames of a wave: chunks of MIXF frames into the wave's tile, summed, partial rows written.  `pw` = this wave's
+// partial row of the paint (channel 0; channel 1 is channel_stride floats further).
+template <int C, bool ROLL, class G2>
+__device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, const G2 &g2, float (*tile)[MIXS], float *__restrict__ pw_row,
+                                                size_t channel_stride, uint32_t start, uint32_t end, uint32_t lane, uint32_t rf, uint32_t rh) {
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
         // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
         // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
@@ -606,13 +594,88 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
             const float hl = __shfl_down(sl, 32);
             const float hr = C == 2 ? __shfl_down(sr, 32) : 0.0f;
             if (rh == 0 && f0 + rf < end) {
-                float *pw = partials + (size_t)wave_global * nframes + (f0 - start) + rf;
+                float *pw = pw_row + (f0 - start) + rf;
                 pw[0] = sl + hl;
                 if constexpr (C == 2) pw[channel_stride] = sr + hr;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next chunk rewrites the tile after these reads
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the silent stand-in of a lane past the last voice (it runs voice V-1's params): contributes +0.0 by construction rather than
+// through a select per frame -- a silent oscillator, a filter at rest (finite whatever voice V-1's state is) and an envelope
+// that paints nothing: frame_masked() ANDs its value with m_painted, a mode of NONE never leaves NONE inside a paint, and
+// 0.0f + (+0.0f * finite) = +0.0f
+__device__ __forceinline__ void nice_silence(NiceLane &n) {
+    n.k.ifreq = 0u; n.k.brpt = 0u; n.k.gdf2 = 0.0f; n.k.cc121 = 0.0f; n.k.cc212 = 0.0f; n.g = n.ng = 0.0f;   // (as begin() silences a bad frequency)
+    n.l = n.b = 0.0f;
+    n.env.mode = ENV_MODE_NONE; n.env.m_painted = 0u;
+}
+
+template <int C, bool ROLL>
+__global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
+                                                  F32P gain_l, F32P gain_r) {
+    __shared__ float tile_all[4][MIXF][MIXS];
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*tile)[MIXS] = tile_all[wave];                               // this wave's tile: no other wave touches it
+    const uint32_t nframes = end - start;
+    const uint32_t wave_global = blockIdx.x * 4 + wave;
+    const size_t channel_stride = (size_t)gridDim.x * 4 * nframes;      // partials[channel][wave][frame]
+    const bool live = v < a.V;
+    // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
+    // exec-mask region (an s_and_saveexec / branch / restore per frame: ~10 of ~85 instructions)
+    NiceLane n;
+    nice_load(n, a, live ? v : a.V - 1);
+    if (!live) nice_silence(n);
+    const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;              // this lane's row / half in the sum phase
+    PulseRoll roll;
+    n.roll_begin(roll);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 g2[C == 2 ? 32 : 1];                                             // {left, right} gain of each of the lane's 32 voices
+    nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
+    nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials + (size_t)wave_global * nframes, channel_stride, start, end, lane, rf, rh);
+    if (live) nice_store(n, a, v);
+}
+
+// n_buffers consecutive paints of k_nice_mix in one launch (zh_nice_paint_mix_stereo_batch): the state words stay in
+// registers from buffer to buffer -- what a paint stores and the next one loads -- and begin() runs per buffer with that
+// buffer's params, exactly as separate launches would run it.  partials[buffer][channel][wave][frame].
+constexpr int kNiceMixMaxBatch = 16;
+struct NiceBatchArgs {
+    NiceArgs a;                                                        // state arrays, V, sample rate; freq / note_on / nic of buffer 0 unused
+    F32P freq[kNiceMixMaxBatch];
+    BoolP note_on[kNiceMixMaxBatch], nic[kNiceMixMaxBatch];
+    uint32_t nb;
+};
+template <int C, bool ROLL>
+__global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, uint32_t start, uint32_t end, float *__restrict__ partials,
+                                                        F32P gain_l, F32P gain_r) {
+    __shared__ float tile_all[4][MIXF][MIXS];
+    const NiceArgs &a = b.a;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*tile)[MIXS] = tile_all[wave];
+    const uint32_t nframes = end - start;
+    const uint32_t wave_global = blockIdx.x * 4 + wave;
+    const size_t channel_stride = (size_t)gridDim.x * 4 * nframes;
+    const bool live = v < a.V;
+    const uint32_t vc = live ? v : a.V - 1;
+    NiceLane n;
+    nice_load_state(n, a, vc);
+    const float color = a.color[vc];
+    const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 g2[C == 2 ? 32 : 1];
+    nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
+    for (uint32_t k = 0; k < b.nb; k++) {
+        n.begin(a.sample_rate, a.srf, a.sr8, b.freq[k].get(vc), color, b.note_on[k].get(vc), b.nic[k].get(vc));
+        if (!live) nice_silence(n);
+        PulseRoll roll;
+        n.roll_begin(roll);
+        nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials + ((size_t)k * C * gridDim.x * 4 + wave_global) * nframes, channel_stride, start, end, lane, rf, rh);
     }
     if (live) nice_store(n, a, v);
 }
@@ -1578,6 +1641,40 @@ int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mi
                              zh_f32 gain_right, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!mix_right) return ZH_ERR_INVALID;
     return nice_paint_mix_n(m, start, end, mix_left, mix_right, &gain_left, &gain_right, note_id_changed, p, flags);
+}
+
+int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uint32_t n_buffers, float *const *mix_left,
+                                   float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
+                                   const zh_nice_params *params, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    if (!m || !mix_left || !mix_right || !note_id_changed || !params || end < start || n_buffers > (uint32_t)kNiceMixMaxBatch) return ZH_ERR_INVALID;
+    for (uint32_t k = 0; k < n_buffers; k++) {
+        if (!mix_left[k] || !mix_right[k]) return ZH_ERR_INVALID;
+        // (one sample rate per batch: srf / sr8 are launch constants)
+        if (__builtin_bit_cast(uint32_t, params[k].sample_rate) != __builtin_bit_cast(uint32_t, params[0].sample_rate)) return ZH_ERR_UNSUPPORTED;
+    }
+    if (m->n == 0 || n_buffers == 0) return ZH_OK;
+    const uint32_t nframes = end - start;
+    const uint32_t blocks = (m->n + 255) / 256, rows = blocks * 4;
+    const size_t per_channel = (size_t)rows * (nframes ? nframes : 1);
+    int rc = zh_mix_reserve(m->ctx, per_channel * 2 * n_buffers);
+    if (rc) return rc;
+    NiceBatchArgs b;
+    b.a = nice_args(m, &params[0], note_id_changed[0]);
+    b.nb = n_buffers;
+    for (int k = 0; k < kNiceMixMaxBatch; k++) {
+        const uint32_t j = (uint32_t)k < n_buffers ? (uint32_t)k : 0u;
+        b.freq[k] = mk_f32(params[j].freq); b.note_on[k] = mk_bool(params[j].note_on); b.nic[k] = mk_bool(note_id_changed[j]);
+    }
+    float *part = m->ctx->mix_partials;
+    hipStream_t st = m->ctx->stream;
+    if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix_batch<2, true>), dim3(blocks), dim3(256), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right));
+    else hipLaunchKernelGGL((k_nice_mix_batch<2, false>), dim3(blocks), dim3(256), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right));
+    if (nframes) {
+        float *l[kNiceMixMaxBatch], *r[kNiceMixMaxBatch];
+        for (uint32_t k = 0; k < n_buffers; k++) { l[k] = mix_left[k] + start; r[k] = mix_right[k] + start; }
+        zh_mix_pass2_wide_batch_launch(m->ctx, part, per_channel, rows, nframes, l, r, n_buffers, 2, (int)(flags & ZH_PAINT_ZERO_FIRST));
+    }
+    return zh_launch_status();
 }
 
 static bool span_table_ok(const zh_span_table *t) {
