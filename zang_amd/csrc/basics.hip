@@ -208,13 +208,13 @@ __global__ void __launch_bounds__(64 * MIX_SEG) k_mix_pass2(const float *__restr
 }
 
 // Pass 2 for the fused voice kernels (composite.hip k_nice_mix), whose partials are one row per WAVE of 64 voices -- four
-// times the rows of the block form, 16 MB per stereo buffer at 131,072 voices: a workgroup owns 16 frames of one channel and
-// splits the rows into 64 contiguous segments (one lane per (segment, frame): a wave reads 4 segments x 64 contiguous bytes
-// per step), segment sums combined in segment order by the first 16 lanes.  grid = (frames / 16, channels): 128 workgroups
-// per stereo buffer instead of 16 -- and both channels in ONE launch (a second pass2 launch was 5 us per buffer).
-// Fixed order => reproducible bits.
-constexpr int MIXW_SEG = 64, MIXW_F = 16;
-// (grid.z = buffer of a batch: partials[buffer][channel][row][frame], one destination pair per buffer)
+// times the rows of the block form, 16 MB per stereo buffer at 131,072 voices -- laid out [channel][frame / G][row][frame % G], G = 8:
+// a workgroup owns G frames of one channel, i.e. ONE contiguous run of rows x 32 bytes; thread (q, fl) adds rows q, q + 128,
+// q + 256, ... of frame fl (a wave reads eight consecutive rows = 256 contiguous bytes per step), and the first G threads
+// combine the 128 strided sums in q order.  grid = (frames / G, channels, buffers): both channels (and all buffers of a batch)
+// in ONE launch (a second pass2 launch was 5 us per buffer).  Fixed order => reproducible bits.
+// (grid.z = buffer of a batch: partials[buffer][channel][...], one destination pair per buffer)
+constexpr int MIXW_F = kMixGroupFrames, MIXW_SEG = 1024 / MIXW_F;     // 8 frames x 128 row classes: 256 workgroups per stereo buffer of 1024 frames
 constexpr int kMixMaxBatch = 16;
 struct MixDst { float *l[kMixMaxBatch], *r[kMixMaxBatch]; };
 __global__ void __launch_bounds__(MIXW_SEG * MIXW_F) k_mix_pass2_wide(const float *__restrict__ partials, size_t channel_stride, uint32_t rows,
@@ -222,15 +222,13 @@ __global__ void __launch_bounds__(MIXW_SEG * MIXW_F) k_mix_pass2_wide(const floa
     __shared__ float seg_sum[MIXW_SEG][MIXW_F];
     const uint32_t fl = threadIdx.x % MIXW_F, seg = threadIdx.x / MIXW_F;
     const uint32_t f = blockIdx.x * MIXW_F + fl;
-    const float *part = partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * channel_stride;
+    const float *part = partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * channel_stride + (size_t)blockIdx.x * rows * MIXW_F;
     float *dst = blockIdx.y ? d.r[blockIdx.z] : d.l[blockIdx.z];
-    const uint32_t per = (rows + MIXW_SEG - 1) / MIXW_SEG;
-    const uint32_t t0 = min(seg * per, rows), t1 = min(t0 + per, rows);
     float s = 0.0f;
     if (f < nframes) {
-        const float *p = part + (size_t)t0 * nframes + f;
+        const float *p = part + (size_t)seg * MIXW_F + fl;
 #pragma unroll 8
-        for (uint32_t t = t0; t < t1; t++, p += nframes) s += *p;
+        for (uint32_t r = seg; r < rows; r += MIXW_SEG, p += MIXW_SEG * MIXW_F) s += *p;
     }
     seg_sum[seg][fl] = s;
     __syncthreads();

@@ -81,6 +81,10 @@ void zh_flipper_painted(zh_flipper *f);      // call right BEFORE flipping f->cu
 const char *zh_env(const char *name);       // getenv for the form switches read on the paint path: cached unless ZH_ENV_LIVE=1 (ctx.hip)
 uint32_t zh_range_frames(uint32_t V, uint32_t n, const char *env_name, uint32_t target_waves, uint32_t max_voices);
 
+// frames per group of the fused mixdown's partial layout [channel][frame / G][row][frame % G] (composite.hip writes, basics.hip
+// k_mix_pass2_wide reads: one second-pass workgroup per group and channel)
+constexpr int kMixGroupFrames = 8;
+
 struct zh_event {
     hipEvent_t ev;
 };

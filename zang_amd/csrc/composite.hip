@@ -524,10 +524,12 @@ __device__ __forceinline__ void nice_mix_gains(G2 &g2, const F32P &gain_l, const
 }
 
 // One paint's frames of a wave: chunks of MIXF frames into the wave's tile, summed, partial rows written.  `pw` = this wave's
-// partial row of the paint (channel 0; channel 1 is channel_stride floats further).
+// partial rows of the paint: `pw_paint` = the paint's channel-0 block laid out [frame / G][row][frame % G], G = kMixGroupFrames (a second-pass
+// workgroup's G frames of every row are one contiguous run), channel 1 channel_stride floats further; `wrow` = this wave's row.
 template <int C, bool ROLL, class G2>
-__device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, const G2 &g2, float (*tile)[MIXS], float *__restrict__ pw_row,
-                                                size_t channel_stride, uint32_t start, uint32_t end, uint32_t lane, uint32_t rf, uint32_t rh) {
+__device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, const G2 &g2, float (*tile)[MIXS], float *__restrict__ pw_paint,
+                                                size_t channel_stride, uint32_t rows, uint32_t wrow, uint32_t start, uint32_t end, uint32_t lane,
+                                                uint32_t rf, uint32_t rh) {
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
         // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
         // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
@@ -594,7 +596,8 @@ __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, co
             const float hl = __shfl_down(sl, 32);
             const float hr = C == 2 ? __shfl_down(sr, 32) : 0.0f;
             if (rh == 0 && f0 + rf < end) {
-                float *pw = pw_row + (f0 - start) + rf;
+                const uint32_t fr = (f0 - start) + rf;
+                float *pw = pw_paint + ((size_t)(fr / kMixGroupFrames) * rows + wrow) * kMixGroupFrames + (fr % kMixGroupFrames);
                 pw[0] = sl + hl;
                 if constexpr (C == 2) pw[channel_stride] = sr + hr;
             }
@@ -623,7 +626,8 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     float (*tile)[MIXS] = tile_all[wave];                               // this wave's tile: no other wave touches it
     const uint32_t nframes = end - start;
     const uint32_t wave_global = blockIdx.x * 4 + wave;
-    const size_t channel_stride = (size_t)gridDim.x * 4 * nframes;      // partials[channel][wave][frame]
+    const uint32_t rows = gridDim.x * 4;
+    const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;   // partials[channel][frame / G][wave][frame % G]
     const bool live = v < a.V;
     // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
     // exec-mask region (an s_and_saveexec / branch / restore per frame: ~10 of ~85 instructions)
@@ -636,7 +640,7 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 g2[C == 2 ? 32 : 1];                                             // {left, right} gain of each of the lane's 32 voices
     nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
-    nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials + (size_t)wave_global * nframes, channel_stride, start, end, lane, rf, rh);
+    nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, start, end, lane, rf, rh);
     if (live) nice_store(n, a, v);
 }
 
@@ -660,7 +664,8 @@ __global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, u
     float (*tile)[MIXS] = tile_all[wave];
     const uint32_t nframes = end - start;
     const uint32_t wave_global = blockIdx.x * 4 + wave;
-    const size_t channel_stride = (size_t)gridDim.x * 4 * nframes;
+    const uint32_t rows = gridDim.x * 4;
+    const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;
     const bool live = v < a.V;
     const uint32_t vc = live ? v : a.V - 1;
     NiceLane n;
@@ -675,7 +680,7 @@ __global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, u
         if (!live) nice_silence(n);
         PulseRoll roll;
         n.roll_begin(roll);
-        nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials + ((size_t)k * C * gridDim.x * 4 + wave_global) * nframes, channel_stride, start, end, lane, rf, rh);
+        nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials + (size_t)k * C * channel_stride, channel_stride, rows, wave_global, start, end, lane, rf, rh);
     }
     if (live) nice_store(n, a, v);
 }
@@ -1614,7 +1619,7 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     const uint32_t nframes = end - start;
     const uint32_t blocks = (m->n + 255) / 256;
     const uint32_t rows = blocks * 4;                                   // one partial row per wave of 64 voices
-    const size_t per_channel = (size_t)rows * (nframes ? nframes : 1);
+    const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);   // [frame / G][row][frame % G]
     int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1));
     if (rc) return rc;
     hipStream_t st = m->ctx->stream;
@@ -1655,7 +1660,7 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     if (m->n == 0 || n_buffers == 0) return ZH_OK;
     const uint32_t nframes = end - start;
     const uint32_t blocks = (m->n + 255) / 256, rows = blocks * 4;
-    const size_t per_channel = (size_t)rows * (nframes ? nframes : 1);
+    const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);
     int rc = zh_mix_reserve(m->ctx, per_channel * 2 * n_buffers);
     if (rc) return rc;
     NiceBatchArgs b;
