@@ -307,3 +307,180 @@ def test_lowpass_mix_into_a_zeroed_temp_in_three_operations():
             assert np.array_equal(six[~nan6].view(np.uint32), three[~nan3].view(np.uint32))
             assert nan6.any() and (six == 0).any() and np.isinf(l[~np.isnan(l)]).any()   # the corners are really visited
             x = draw()
+
+
+# ---------------------------------------------------------------------------------------------- round 3: the remaining modules
+def np_painter_toward(p, buf, i0, curve, goal):
+    """painter.zig:63-120 for one call: p = [t, last_value, start]; returns (i, finished)."""
+    if p[0] >= f32(1.0):
+        return i0, True
+    tag, dur = curve
+    if tag == 0:                                               # .instantaneous
+        p[0] = f32(1.0); p[1] = f32(goal)
+        return i0, True
+    t_step = f32(1.0) / (f32(dur) * SR)
+    finished, i = False, i0
+    while not finished and i < len(buf):
+        p[0] = p[0] + t_step
+        if p[0] >= f32(1.0):
+            p[0] = f32(1.0); finished = True
+        it = f32(1.0) - p[0]
+        tp = p[0] if tag == 1 else (f32(1.0) - it * it if tag == 2 else f32(1.0) - it * it * it)
+        p[1] = p[2] + tp * (f32(goal) - p[2])
+        buf[i] = buf[i] + p[1]
+        i += 1
+    return i, finished
+
+
+def test_portamento_over_the_painter(oracle):
+    """Portamento.zig:21-48: the curve only while the note stays on, newCurve on a new note, paintFlat once the goal is
+    reached -- written from those lines over a re-derived Painter; sub-span paints, all four curve tags."""
+    L = oracle.lib()
+    rng = np.random.default_rng(21)
+    for tag in (0, 1, 2, 3):
+        dur = f32(0.004) if tag else f32(0.0)
+        p = [f32(0), f32(0), f32(0)]
+        st = oracle.Portamento(); L.zo_portamento_init(C.byref(st))
+        ref = rng.uniform(-1, 1, 600).astype(np.float32); out = ref.copy()
+        script = [((0, 200), 440.0, True, False, True), ((200, 600), 440.0, True, True, False), ((0, 600), 660.0, True, True, True),
+                  ((0, 0), 100.0, True, True, False), ((50, 400), 220.0, False, True, False), ((0, 600), 330.0, True, False, True)]
+        for (s, e), goal, on, prev, nic in script:
+            curve = (tag, dur) if (on and prev) else (0, f32(0))
+            if on and nic:
+                p[2] = p[1]; p[0] = f32(0.0)                    # newCurve
+            view = ref[s:e]
+            i, fin = np_painter_toward(p, view, 0, curve, goal)
+            if fin:
+                view[i:] = view[i:] + f32(goal)                # paintFlat -> addScalarInto
+            L.zo_portamento_paint(C.byref(st), s, e, oracle.fptr(out), int(nic), SR, oracle.curve(tag, dur), goal, int(on), int(prev))
+            util.assert_bitexact(out, ref, f"portamento tag {tag} span {(s, e)}")
+            assert (f32(st.painter.t), f32(st.painter.last_value), f32(st.painter.start)) == (p[0], p[1], p[2])
+
+
+def test_cycle_gate_and_clip(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(22)
+    n = 700
+    # Cycle.zig:36-58: out += t; t += step (or speed[i] * isr); t -= trunc(t)
+    speeds = rng.uniform(-30, 5000, n).astype(np.float32)
+    for buf in (False, True):
+        t = f32(0.3); ref = np.zeros(n, np.float32)
+        step = f32(777.0) / SR; isr = f32(1.0) / SR
+        for i in range(n):
+            ref[i] = ref[i] + t
+            t = t + (speeds[i] * isr if buf else step)
+            t = t - np.trunc(t)
+        st = oracle.Cycle(0.3); out = np.zeros(n, np.float32)
+        L.zo_cycle_paint(C.byref(st), 0, n, oracle.fptr(out), SR, oracle.buffer(speeds) if buf else oracle.constant(777.0))
+        util.assert_bitexact(out, ref, "cycle"); assert f32(st.t) == t
+    # Gate.zig:27-29
+    base = rng.uniform(-1, 1, n).astype(np.float32)
+    for on in (0, 1):
+        out = base.copy(); L.zo_gate_paint(100, 600, oracle.fptr(out), on)
+        ref = base.copy()
+        if on: ref[100:600] = ref[100:600] + f32(1.0)
+        util.assert_bitexact(out, ref, "gate")
+    # Distortion.zig:41, 54-63 (clip): gain1 = pow(2, ingain * 8 - 2) from the oracle's pow (its own tests pin it); the loop here
+    inp = rng.uniform(-2, 2, n).astype(np.float32)
+    for ingain, outgain, offset in ((0.25, 0.8, 0.0), (0.6, 0.5, -0.3), (0.05, 1.0, 0.9)):
+        gain1 = f32(L.zo_math_powf(2.0, float(f32(ingain) * f32(8.0) - f32(2.0))))
+        offs = gain1 * f32(offset)
+        a = inp * gain1 + offs
+        b = np.where(a < f32(-1.0), f32(-1.0), np.where(a > f32(1.0), f32(1.0), a)).astype(np.float32)
+        ref = (base + f32(outgain) * b).astype(np.float32)
+        out = base.copy()
+        L.zo_distortion_paint(0, n, oracle.fptr(out), oracle.fptr(inp), oracle.DISTORTION_CLIP, ingain, outgain, offset)
+        util.assert_bitexact(out, ref, "distortion clip")
+        # overdrive (:44-52): atan in f64 numpy, 2 ulp
+        gain2 = f32(outgain) / f32(np.arctan(np.float64(gain1)))
+        refo = base.astype(np.float64) + np.float64(gain2) * np.arctan((inp * gain1 + offs).astype(np.float64))
+        out = base.copy()
+        L.zo_distortion_paint(0, n, oracle.fptr(out), oracle.fptr(inp), oracle.DISTORTION_OVERDRIVE, ingain, outgain, offset)
+        assert np.abs(out - refo).max() <= 4e-7 * max(1.0, np.abs(refo).max())
+
+
+def test_curve_smoothstep_and_linear_bit_for_bit(oracle):
+    """Curve.zig:90-121 for one whole-buffer paint from a new note (every curve span starts at its node's frame, start_x = 0):
+    linear `y += y_step`, smoothstep `x*x*(3 - 2x)*delta` with `x += x_step`, re-derived and compared bit for bit."""
+    L = oracle.lib()
+    nodes = [(0.0, 0.0), (0.5, 0.004), (-0.25, 0.0125), (1.0, 0.02)]
+    arr = (oracle.CurveNode * 4)(*[oracle.CurveNode(v, t) for v, t in nodes])
+    frames = [0, 192, 600, 960]                                # (pinned by test_curve_linear_matches_closed_form)
+    n = 1024
+    for fn in (0, 1):
+        ref = np.zeros(n, np.float32)
+        for (f0, f1), ((v0, _), (v1, _)) in zip(zip(frames, frames[1:]), zip(nodes, nodes[1:])):
+            start_x = f32(0) / f32(f1 - f0); x_step = f32(1.0) / f32(f1 - f0)
+            start_value, delta = f32(v0), f32(v1) - f32(v0)
+            if fn == 0:
+                y = start_value + start_x * delta; y_step = x_step * delta
+                for i in range(f0, f1):
+                    ref[i] = ref[i] + y; y = y + y_step
+            else:
+                x = start_x
+                for i in range(f0, f1):
+                    v = x * x * (f32(3.0) - f32(2.0) * x) * delta
+                    ref[i] = ref[i] + (start_value + v); x = x + x_step
+        st = oracle.CurveModule(); L.zo_curve_init(C.byref(st)); out = np.zeros(n, np.float32)
+        L.zo_curve_paint(C.byref(st), 0, n, oracle.fptr(out), 1, SR, fn, arr, 4)
+        util.assert_bitexact(out, ref, f"curve function {fn}")
+
+
+def test_white_noise_from_published_xoshiro_and_float_conversion(oracle):
+    """Noise.zig:22-53 over the un-vendored Zig std: DefaultPrng = xoshiro256++ seeded through SplitMix64 (Vigna's published
+    reference code), Random.float(f32) = 23 mantissa bits of one u64 draw under an exponent of 126 - clz(draw) (a second draw
+    when the first has >= 41 leading zeros), white = float * 2 - 1.  Python integers here; the oracle in C."""
+    M = (1 << 64) - 1
+    rotl = lambda x, k: ((x << k) | (x >> (64 - k))) & M
+
+    def splitmix(state):
+        state = (state + 0x9e3779b97f4a7c15) & M
+        z = state
+        z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M
+        z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M
+        return state, z ^ (z >> 31)
+
+    def seed(s0):
+        out = []
+        for _ in range(4):
+            s0, v = splitmix(s0)
+            out.append(v)
+        return out
+
+    def nxt(s):
+        r = (rotl((s[0] + s[3]) & M, 23) + s[0]) & M
+        t = (s[1] << 17) & M
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 45)
+        return r
+
+    clz64 = lambda x: 64 - x.bit_length()
+
+    def rfloat(s):
+        rand = nxt(s)
+        lz = clz64(rand)
+        if lz >= 41:
+            lz = 41 + clz64(nxt(s))
+        bits = ((126 - lz) << 23) | (rand & 0x7FFFFF)
+        return np.array([bits], np.uint32).view(np.float32)[0]
+
+    L = oracle.lib()
+    n = 400
+    for sd in (0, 1, 12345, (1 << 40) + 7):
+        s = seed(sd)
+        ref = np.array([rfloat(s) * f32(2.0) - f32(1.0) for _ in range(n)], np.float32)
+        st = oracle.Noise(); L.zo_noise_init(C.byref(st), sd); out = np.zeros(n, np.float32)
+        L.zo_noise_paint(C.byref(st), 0, n, oracle.fptr(out), oracle.NOISE_WHITE)
+        util.assert_bitexact(out, ref, f"white noise seed {sd}")
+        assert [int(x) for x in st.r] == s
+    # the second-draw branch: a state whose next draw is below 2^23 (found by walking the generator backwards in the GPU tests;
+    # here: force it by construction -- s0 = 0, s3 = k << 41 gives rotl(k << 41, 23) + 0 = k)
+    s = [0, 0x123456789abcdef, 0xfedcba987654321, 5 << 41]
+    st = oracle.Noise(); L.zo_noise_init(C.byref(st), 0)
+    for i in range(4):
+        st.r[i] = s[i]
+    out = np.zeros(3, np.float32)
+    L.zo_noise_paint(C.byref(st), 0, 3, oracle.fptr(out), oracle.NOISE_WHITE)
+    ref = np.array([rfloat(s) * f32(2.0) - f32(1.0) for _ in range(3)], np.float32)
+    util.assert_bitexact(out, ref, "second-draw branch"); assert [int(x) for x in st.r] == s
