@@ -238,11 +238,11 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
                 return n.env.quiet(8);
             },
             [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
-                const float t1 = n.tail_filter(n.osc_next(roll));
+                const float t1 = n.template tail_filter<ZF>(n.osc_next(roll));   // (ZERO_FIRST: the caller adds val to 0, see tail_filter)
                 val = (flat ? e0c : n.env.frame_masked_quiet()) * t1;   // NiceLane::tail
                 return true;
             },
-            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.tail(n.osc_next(roll)); return true; });
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template tail<ZF>(n.osc_next(roll)); return true; });
     } else {
         frame_loop<8, ZF, 0, W>(out.p, v, out.stride, no_in, nullptr, start, end, [&](uint32_t, const F (&)[1], F &val) ZH_INLINE_LAMBDA {
             val = n.frame();
