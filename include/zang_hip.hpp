@@ -46,6 +46,25 @@ public:
     void sync() { check(zh_sync(h_), "zh_sync"); }
 };
 
+// The multi-GPU exchange as a collective (zh_comm_*: RCCL over xGMI, one rank per process, enqueued on the context's
+// stream).  `id` = the 128 bytes rank 0 obtained from Comm::uniqueId() and handed to the other processes over any host
+// channel; the constructor blocks until all `world` ranks have called it.
+class Comm {
+    zh_comm *h_ = nullptr;
+
+public:
+    using Id = std::array<uint8_t, ZH_COMM_ID_BYTES>;
+    static bool available() { return zh_comm_available() == 1; }
+    static Id uniqueId() { Id id{}; check(zh_comm_unique_id(id.data()), "zh_comm_unique_id"); return id; }
+    Comm(Context &c, uint32_t world, uint32_t rank, const Id &id) { check(zh_comm_create(c.get(), world, rank, id.data(), &h_), "zh_comm_create"); }
+    ~Comm() { if (h_) zh_comm_destroy(h_); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    zh_comm *get() const { return h_; }
+    void allreduceMix(float *mix_dev, size_t n) { check(zh_allreduce_mix(h_, mix_dev, n), "zh_allreduce_mix"); }
+    void reduceMix(float *mix_dev, size_t n, uint32_t root) { check(zh_reduce_mix(h_, mix_dev, n, root), "zh_reduce_mix"); }
+};
+
 // A device sample image [frame][voice]: column v is what the reference calls one `[]f32` of voice v.
 class Image {
     Context &ctx_;
@@ -83,7 +102,13 @@ public:
     DeviceArray(const DeviceArray &) = delete;
     DeviceArray &operator=(const DeviceArray &) = delete;
     const T *get() const { return p_; }
+    T *get() { return p_; }
     size_t size() const { return n_; }
+    std::vector<T> download() const {
+        std::vector<T> host(n_);
+        check(zh_download(ctx_.get(), host.data(), p_, n_ * sizeof(T)), "zh_download");
+        return host;
+    }
 };
 
 // ---- values
@@ -194,6 +219,15 @@ inline void paintMixStereo(NiceInstrument &m, zang::Span span, float *mix_left_d
                            zh_bool note_id_changed, const NiceInstrument::Params &params, uint32_t flags = ZH_PAINT_ADD) {
     zang::check(zh_nice_paint_mix_stereo(m.get(), span.start, span.end, mix_left_dev, mix_right_dev, gain_left, gain_right, note_id_changed,
                                          &params, flags), "zh_nice_paint_mix_stereo");
+}
+// n consecutive paintMixStereo calls (per-buffer params and note_id_changed) as one launch: state in registers between buffers
+inline void paintMixStereoBatch(NiceInstrument &m, zang::Span span, const std::vector<float *> &mix_left_dev, const std::vector<float *> &mix_right_dev,
+                                zh_f32 gain_left, zh_f32 gain_right, const std::vector<zh_bool> &note_id_changed,
+                                const std::vector<NiceInstrument::Params> &params, uint32_t flags = ZH_PAINT_ADD) {
+    if (mix_left_dev.size() != params.size() || mix_right_dev.size() != params.size() || note_id_changed.size() != params.size())
+        throw zang::Error(ZH_ERR_INVALID, "paintMixStereoBatch: one mix pair, one note_id_changed and one Params per buffer");
+    zang::check(zh_nice_paint_mix_stereo_batch(m.get(), span.start, span.end, (uint32_t)params.size(), mix_left_dev.data(), mix_right_dev.data(),
+                                               gain_left, gain_right, note_id_changed.data(), params.data(), flags), "zh_nice_paint_mix_stereo_batch");
 }
 // n consecutive paints of a constant-frequency oscillator (same span and params, buffer b into outputs[b]) as one launch
 inline void paintBatch(PulseOsc &m, zang::Span span, const std::vector<zh_buf> &outputs, const PulseOsc::Params &params, uint32_t flags = ZH_PAINT_ADD) {

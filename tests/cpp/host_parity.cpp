@@ -114,6 +114,38 @@ int main() {
         } catch (const zang::Error &e) {
             printf("ok   out-of-range span rejected: %s\n", e.what());
         }
+        // the mixdown from C++: four buffers as separate calls and as one batch launch, then the exchange step through a one-rank
+        // RCCL communicator (the sum over one rank is the identity): same bits everywhere
+        {
+            const uint32_t B = 4;
+            mod::NiceInstrument ma(ctx, V, zang::f32(dcolor)), mb(ctx, V, zang::f32(dcolor));
+            zang::DeviceArray<float> la(ctx, std::vector<float>((size_t)B * F, 0.0f)), ra(ctx, std::vector<float>((size_t)B * F, 0.0f));
+            zang::DeviceArray<float> lb(ctx, std::vector<float>((size_t)B * F, 0.0f)), rb(ctx, std::vector<float>((size_t)B * F, 0.0f));
+            std::vector<mod::NiceInstrument::Params> ps;
+            std::vector<zh_bool> nics;
+            std::vector<float *> pl, pr;
+            for (uint32_t k = 0; k < B; k++) {
+                ps.push_back({SR, 0, zang::f32(dfreq), zang::boolean(k < 2)});
+                nics.push_back(zang::boolean(k == 0));
+                pl.push_back(lb.get() + (size_t)k * F); pr.push_back(rb.get() + (size_t)k * F);
+                mod::paintMixStereo(ma, {0, F}, la.get() + (size_t)k * F, ra.get() + (size_t)k * F, zang::f32(0.75f), zang::f32(0.25f), nics[k], ps[k], ZH_PAINT_ZERO_FIRST);
+            }
+            mod::paintMixStereoBatch(mb, {0, F}, pl, pr, zang::f32(0.75f), zang::f32(0.25f), nics, ps, ZH_PAINT_ZERO_FIRST);
+            ctx.sync();
+            ok &= same_bits(lb.download(), la.download(), "stereo mixdown, 4 buffers in one launch vs 4 launches (left)");
+            ok &= same_bits(rb.download(), ra.download(), "stereo mixdown, 4 buffers in one launch vs 4 launches (right)");
+            if (zang::Comm::available()) {
+                zang::Comm comm(ctx, 1, 0, zang::Comm::uniqueId());
+                comm.allreduceMix(lb.get(), (size_t)B * F);
+                comm.reduceMix(rb.get(), (size_t)B * F, 0);
+                ctx.sync();
+                ok &= same_bits(lb.download(), la.download(), "zh_allreduce_mix over a one-rank RCCL communicator (left block)");
+                ok &= same_bits(rb.download(), ra.download(), "zh_reduce_mix over a one-rank RCCL communicator (right block)");
+            } else {
+                printf("FAIL: librccl not available: %s\n", zh_comm_last_error());
+                ok = false;
+            }
+        }
     } catch (const std::exception &e) {
         printf("FAIL: %s\n", e.what());
         return 2;

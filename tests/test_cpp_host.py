@@ -47,7 +47,7 @@ def test_cpp_host_parity_program():
     _build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip().endswith("PASS") and r.stdout.count("bit-exact") == 8
+    assert r.stdout.strip().endswith("PASS") and r.stdout.count("bit-exact") == 12      # 8 paints + batch L/R + RCCL L/R
 
 
 @pytest.mark.gpu
