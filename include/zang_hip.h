@@ -181,7 +181,8 @@ ZH_API int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_
  *   per batch:   zh_nice_paint_mix[_stereo] ... ; zh_allreduce_mix(comm, mix, n)  or  zh_reduce_mix(..., root)
  * `mix` is a device float[n] of this rank's GPU (e.g. [buffers][channels][frames]); the sum order is RCCL's (ring /
  * tree by size), so unlike zh_sum_slots the bits may differ between world sizes.  Calls on one communicator must be
- * issued in the same order on every rank.  zh_comm_available() = 1 when librccl and its symbols were found. */
+ * issued in the same order on every rank.  The collectives may be recorded into a graph (zh_graph_begin_capture ...: RCCL
+ * supports stream capture), e.g. one per buffer next to the mixdown paints; creating / destroying a communicator may not.  zh_comm_available() = 1 when librccl and its symbols were found. */
 enum { ZH_COMM_ID_BYTES = 128 };
 typedef struct zh_comm zh_comm;
 ZH_API int  zh_comm_available(void);

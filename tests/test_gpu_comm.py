@@ -100,6 +100,42 @@ def test_collective_after_graph_replay_on_one_stream(ctx):
         comm.close(); g.close(); c2.close()
 
 
+def test_collective_recorded_inside_a_graph(ctx):
+    """One collective per buffer (the reference mixes per buffer, write_wav.zig:58-93) recorded INTO the hipGraph next to the
+    mixdown paints: zh_allreduce_mix on a capturing context becomes a graph node (RCCL supports stream capture), so a batch
+    of buffers with its exchanges replays with one host call.  One rank: the replays equal the eager batch without exchange."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads, sharding
+    V, B = 2048, 6
+    freq, color, u2, _ = workloads.voice_params(5, 0, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        dev = c2.device
+        col, fr, g1 = torch.from_numpy(color).to(dev), torch.from_numpy(freq).to(dev), torch.from_numpy(u2).to(dev)
+        me, mg = mod.NiceInstrument(V, col, c2), mod.NiceInstrument(V, col, c2)
+        mix_e = torch.zeros((B, 2, F), dtype=torch.float32, device=dev); mix_g = torch.zeros_like(mix_e)
+        sp = zang.Span(0, F)
+        comm = sharding.Comm(c2, world=1, rank=0)
+
+        def batch(m, mixes, exchange):
+            for b in range(B):
+                m.paint_mix_stereo(sp, mixes[b, 0], mixes[b, 1], g1, g1, b == 0, m.Params(SR, fr, b < B // 2), zero_first=True)
+                if exchange:
+                    comm.allreduce_mix(mixes[b])
+        batch(mg, mix_g, True); c2.sync()                 # (lazy allocations and RCCL's first launch outside the capture)
+        g = c2.capture(lambda: batch(mg, mix_g, True))
+        batch(me, mix_e, False)
+        for _ in range(3):
+            batch(me, mix_e, False)
+            g.launch()
+        c2.sync()
+        assert torch.equal(mix_e.view(torch.int32), mix_g.view(torch.int32))
+        assert me.state().tobytes() == mg.state().tobytes()
+        comm.close(); g.close(); c2.close()
+
+
 _TORCH_NCCL = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
