@@ -343,6 +343,27 @@ def test_gpu_pluck_note_cycle(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_sineosc_quiet_body_and_its_fallback(ctx):
+    """A SineOsc whose frequency is a constant this paint runs a frame body without the sine's rare-path branch when no
+    voice of its wave can reach that path; one voice with an absurd frequency (or a frequency buffer) sends the whole wave
+    through the general body.  Both against the oracle, and a module with two oscillators (Lead: a literal-frequency one
+    and the nested Pluck's)."""
+    on = np.ones(V, bool)
+    f = _freqs(5)
+    wild = f.copy()
+    wild[3] = 4.0e12                    # t moves 8.3e7 a frame: beyond kSineOscSmallT at once, Payne-Hanek arguments within the span
+    wild[40] = -2.5e13
+    wild2 = f.copy()
+    wild2[66] = np.inf                  # only the second wave leaves the quiet body
+    rng = np.random.default_rng(9)
+    img = rng.uniform(100, 2000, (V, F)).astype(np.float32)
+    for name in ("Pluck", "Lead"):
+        for freq in (f, wild, wild2, 440.0, img):
+            p = {"sample_rate": 48000.0, "freq": freq, "note_on": on}
+            _parity(ctx, name, [(0, 50, True, p), (50, F, False, p)])
+
+
+@pytest.mark.gpu
 def test_gpu_empty_span_still_runs_prologues(ctx):
     """paint over an empty span is not a no-op in the reference: Envelope's note-on prologue (Envelope.zig:41-50)
     and Portamento's newCurve run, and the next paint continues from there."""

@@ -1197,7 +1197,7 @@ extern "C" __attribute__((visibility("default"))) int zh_debug_counters(unsigned
 #define ZH_DBG_ADD(i, v) do { if (lane == 0) atomicAdd(&zh_dbg[i], (unsigned long long)(v)); } while (0)
 #define ZH_DBG_NOW() __builtin_readcyclecounter()
 #else
-#define ZH_DBG_ADD(i, v) do { } while (0)
+#define ZH_DBG_ADD(i, v) do { (void)sizeof(v); } while (0)
 #define ZH_DBG_NOW() 0ull
 #endif
 struct NfArgs {

@@ -69,6 +69,8 @@ __device__ __forceinline__ void zs_st_f(const ZsState &s, uint32_t word, uint32_
 __device__ __forceinline__ void zs_st_u(const ZsState &s, uint32_t word, uint32_t V, uint32_t v, uint32_t x) { if (uint32_t *p = zs_store_target(s)) zs_st_u(p, word, V, v, x); }
 __device__ __forceinline__ void zs_st_u64(const ZsState &s, uint32_t word, uint32_t V, uint32_t v, uint64_t x) { if (uint32_t *p = zs_store_target(s)) zs_st_u64(p, word, V, v, x); }
 
+template <bool B> struct zs_tag { static constexpr bool value = B; };   // selects one of a kernel's two frame bodies (zs_quiet)
+
 // std.math.max / min as the generated Zig calls them (codegen_zig.zig:186-187): comparison selects
 __device__ __forceinline__ float zs_max(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b; }

@@ -31,8 +31,10 @@ struct SineOscLane {
     __device__ __forceinline__ void end() { t = t - truncf(t); }      // :40
     // constant frequency and phase: true (wave-wide) when no voice's sine argument can reach zsinf's rare path in the next
     // `frames` frames (t moves by t_step a frame; NaN compares false) -- the chunk then runs frame<false, false>
-    __device__ __forceinline__ bool small_args(float phase_c, float frames) const {
-        const bool ok = __builtin_fabsf(t) + frames * __builtin_fabsf(t_step) + __builtin_fabsf(phase_c) < kSineOscSmallT;
+    __device__ __forceinline__ bool small_args(float phase_c, float frames) const { return small_args_step(t_step, phase_c, frames); }
+    // the same for a frequency buffer known to hold one value all span: `step` = that value * inv_sr
+    __device__ __forceinline__ bool small_args_step(float step, float phase_c, float frames) const {
+        const bool ok = __builtin_fabsf(t) + frames * __builtin_fabsf(step) + __builtin_fabsf(phase_c) < kSineOscSmallT;
         return __builtin_amdgcn_ballot_w64(!ok) == 0;
     }
 };

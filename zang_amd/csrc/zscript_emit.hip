@@ -336,6 +336,7 @@ struct Val {
     std::shared_ptr<Val> payload;  // enum payload (float) or null
     std::string count;             // curve node count expression
     bool computed = false;         // buf: derives from a module's output or a transcendental function (not just params / constants / + - * /)
+    std::string cob_b, cob_c;      // buf that is exactly a constant_or_buffer param's value: its "is a buffer" flag and its constant
 };
 
 size_t state_words(const std::string &name) {
@@ -360,6 +361,7 @@ struct Kernel {
     size_t words = 0, noise_fields = 0, uid = 0;
     bool rings = false;            // a delay ring lives in the state blob and is read and written inside the frame body
     bool walk_reads_computed = false;   // a builtin's frame-to-frame state is fed by a value computed in the frame body
+    Lines quiet_terms;             // wave-uniform tests (after the prologue): no SineOsc of constant freq / phase can reach zsinf's rare path
     std::string fresh(const std::string &stem) { uid++; return stem + std::to_string(uid); }
     size_t alloc(size_t n) { const size_t w = words; words += n; return w; }
 };
@@ -371,6 +373,7 @@ struct ModuleCtx {
     std::string outvar, nic, prefix;
     std::map<size_t, std::string> tnames;
     std::map<size_t, bool> heavy;  // temp index -> its current value derives from a module output / transcendental (Val.computed)
+    std::map<size_t, std::pair<std::string, std::string>> cobsrc;   // temp index -> (Val.cob_b, Val.cob_c) while it holds a cob param's value
     Lines *begin_sink, *end_sink;
     std::string rel = "(i - L.start)", length = "SPAN_LEN";
     const std::map<size_t, Val> *track = nullptr;
@@ -403,6 +406,8 @@ public:
             v.kind = Val::buf; v.expr = mc.tname(r.index);
             auto it = mc.heavy.find(r.index);
             v.computed = it == mc.heavy.end() ? true : it->second;
+            auto cs = mc.cobsrc.find(r.index);
+            if (cs != mc.cobsrc.end()) { v.cob_b = cs->second.first; v.cob_c = cs->second.second; }
             return v;
         }
         case RK::temp_float: v.kind = Val::flt; v.expr = mc.fname(r.index); return v;
@@ -429,6 +434,7 @@ public:
     static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy = false) {
         if (!d.output) {
             mc.heavy[d.index] = heavy;
+            mc.cobsrc.erase(d.index);
             const std::string t = mc.tname(d.index);
             if (zero_first) return {t + " = 0.0f;", t + " = " + t + " + (" + expr + ");"};
             return {t + " = " + expr + ";"};
@@ -499,7 +505,15 @@ public:
             decl.push_back("SineOscLane " + o + ";");
             ld_f("t", w);
             pro.push_back(o + ".begin(" + sr + ", " + f.c + ");");
-            value = o + ".frame<" + tf(f.is_buf) + ">(" + (f.is_buf ? f.i : "0.0f") + ", " + ph.i + ")";
+            // frequency and phase constant over the span (the frequency: a constant, or a constant_or_buffer param that is a
+            // constant this paint -- it reaches the oscillator as a temp, cob_to_buffer): the kernel gets a second frame body
+            // whose sine has no rare-path branch, taken when no voice of the wave can reach that path this span
+            // (SineOscLane::small_args)
+            const Val &fv = a["freq"];
+            const bool quiet = !ph.is_buf && mc.begin_sink == &k.pro && (!f.is_buf || !fv.cob_b.empty());
+            if (quiet && !f.is_buf) k.quiet_terms.push_back(o + ".small_args(" + ph.c + ", (float)SPAN_LEN)");
+            if (quiet && f.is_buf) k.quiet_terms.push_back("(!" + fv.cob_b + " && " + o + ".small_args_step(" + fv.cob_c + " * " + o + ".inv_sr, " + ph.c + ", (float)SPAN_LEN))");
+            value = o + ".frame<" + tf(f.is_buf) + (quiet ? ", !ZS_Q" : "") + ">(" + (f.is_buf ? f.i : "0.0f") + ", " + ph.i + ")";
             ends.push_back(o + ".end();");
         } else if (name == "Cycle") {
             const Cob sp = cob(a["speed"]);
@@ -616,6 +630,7 @@ public:
         std::string target;
         if (!ins.out.output) {
             mc.heavy[ins.out.index] = true;                          // a module's output
+            mc.cobsrc.erase(ins.out.index);
             target = mc.tname(ins.out.index);
             frame.insert(frame.begin(), target + " = 0.0f;");
         } else {
@@ -631,9 +646,19 @@ public:
     void instruction(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
         Kernel &k = mc.k;
         switch (ins.kind) {
-        case IK::copy_buffer: { const Val src = val(mc, ins.src); append(k.frame, put(mc, ins.out, src.expr, false, src.computed)); break; }
+        case IK::copy_buffer: {
+            const Val src = val(mc, ins.src);
+            append(k.frame, put(mc, ins.out, src.expr, false, src.computed));
+            if (!ins.out.output && !src.cob_b.empty()) mc.cobsrc[ins.out.index] = {src.cob_b, src.cob_c};
+            break;
+        }
         case IK::float_to_buffer: append(k.frame, put(mc, ins.out, val(mc, ins.src).expr, false)); break;
-        case IK::cob_to_buffer: append(k.frame, put(mc, ins.out, mc.env[ins.in_self_param].expr, false, mc.env[ins.in_self_param].computed)); break;
+        case IK::cob_to_buffer: {
+            const Val &src = mc.env[ins.in_self_param];
+            append(k.frame, put(mc, ins.out, src.expr, false, src.computed));
+            if (!ins.out.output && !src.cob_b.empty()) mc.cobsrc[ins.out.index] = {src.cob_b, src.cob_c};
+            break;
+        }
         case IK::arith_float: case IK::arith_float_float: {
             const std::string expr = ins.kind == IK::arith_float ? un(ins.op, val(mc, ins.a).expr) : bin(ins.op, val(mc, ins.a).expr, val(mc, ins.b).expr);
             if (mc.begin_sink == &k.pro) {
@@ -668,7 +693,7 @@ public:
             std::vector<Val> env;
             for (const Res &r : ins.args) env.push_back(val(mc, r));
             std::string outvar;
-            if (!ins.out.output) { mc.heavy[ins.out.index] = true; outvar = mc.tname(ins.out.index); k.frame.push_back(outvar + " = 0.0f;"); }
+            if (!ins.out.output) { mc.heavy[ins.out.index] = true; mc.cobsrc.erase(ins.out.index); outvar = mc.tname(ins.out.index); k.frame.push_back(outvar + " = 0.0f;"); }
             else outvar = mc.outvar;
             ModuleCtx sub(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", &mc);
             module_body(sub);
@@ -893,6 +918,7 @@ public:
                 k.rows.push_back(i);
                 k.pro.push_back(strf("const bool P%zu_b = L.p[%zu].is_buffer != 0; const float P%zu_c = zs_const(L.p[%zu], v);", i, i, i, i));
                 v.kind = Val::buf; v.expr = strf("(P%zu_b ? x[%zu] : P%zu_c)", i, j, i);         // cob_to_buffer's switch (codegen_zig.zig:130-143)
+                v.cob_b = strf("P%zu_b", i); v.cob_c = strf("P%zu_c", i);
                 break;
             }
             case PK::curve:
@@ -985,8 +1011,19 @@ public:
             for (size_t j = 0; j < k.rows.size(); j++) out.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu], ivo[%zu]);", j, k.rows[j], j, j));
             append(out, indent(k.pro));
             out.push_back(I + "bool zs_walk = false; (void)zs_walk;");
-            out.push_back(I + strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk,", unroll, nin));
-            out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
+            const bool two_bodies = !k.quiet_terms.empty();
+            const std::string loop_call = I + (two_bodies ? I : "") +
+                strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk,", unroll, nin);
+            if (two_bodies) {
+                std::string all;
+                for (const std::string &t : k.quiet_terms) all += (all.empty() ? "" : " && ") + t;
+                out.push_back(I + "const bool zs_quiet = " + all + ";");
+                out.push_back(I + strf("auto zs_body = [&](auto zs_q, uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
+                out.push_back(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;");
+            } else {
+                out.push_back(loop_call);
+                out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
+            }
             out.push_back(I + I + "(void)i; (void)x;");
             if (!k.temps.empty()) {
                 std::string decl = "float ";
@@ -994,7 +1031,17 @@ public:
                 out.push_back(I + I + decl + ";");
             }
             append(out, indent(indent(k.frame)));
-            out.push_back(I + "});");
+            if (two_bodies) {
+                out.push_back(I + "};");
+                for (int q = 1; q >= 0; q--) {
+                    out.push_back(I + (q ? "if (zs_quiet)" : "else"));
+                    out.push_back(loop_call);
+                    out.push_back(I + I + strf("                 [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<%s>{}, i, x, o); });",
+                                               ni, q ? "true" : "false"));
+                }
+            } else {
+                out.push_back(I + "});");
+            }
             append(out, indent(k.epi_ends));
             append(out, indent(k.epi_stores));
             out.push_back("}");
