@@ -361,6 +361,12 @@ def test_gpu_sineosc_quiet_body_and_its_fallback(ctx):
         for freq in (f, wild, wild2, 440.0, img):
             p = {"sample_rate": 48000.0, "freq": freq, "note_on": on}
             _parity(ctx, name, [(0, 50, True, p), (50, F, False, p)])
+    # the Envelope's half of the quiet body: at 1.5 kHz the attack is 30 frames and the decay 225, so chunks with a stage
+    # end (general body) sit between chunks without one (frame_quiet); voices released at different times
+    off = np.random.default_rng(3).random(V) < 0.5
+    for name in ("Pluck", "Lead", "Bell"):
+        p = lambda note_on: {"sample_rate": 1500.0, "freq": f * np.float32(0.01), "note_on": note_on}
+        _parity(ctx, name, [(0, 41, True, p(on)), (41, 70, False, p(on & ~off)), (70, F, False, p(~on))])
 
 
 @pytest.mark.gpu

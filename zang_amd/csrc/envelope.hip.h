@@ -190,6 +190,17 @@ struct EnvLaneT {
         if (walk) { frame_walk(); return zmask<M>(false); }
         return frame(val);
     }
+    // frame_s() for a generated kernel's two frame bodies: Q = the chunk passed quiet() (and is not a replay)
+    // (a replayed quiet chunk steps the clock only: frame_walk() brings last_value up to date at a stage end, and a quiet
+    // chunk has none)
+    template <bool Q> __device__ __forceinline__ M frame_sq(F &val, bool walk) {
+        if constexpr (Q) {
+            if (walk) { t = zsel(mode == u(ENV_MODE_TOWARD), t + cur_step, t); return zmask<M>(false); }
+            return frame_quiet(val);
+        } else {
+            return frame_s(val, walk);
+        }
+    }
     // frame_loop_gen (seq.hip.h): true = no voice ends a stage within the next n frames.  A TOWARD voice's clock after k
     // steps is at most t + k * step + k half-ulps of 1, so t + (n + 1) * step < 0.999 keeps it below 1 with a wide margin
     // (a NaN or infinite step fails the test and takes the exact path).

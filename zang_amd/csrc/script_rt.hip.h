@@ -78,9 +78,12 @@ __device__ __forceinline__ float zs_min(float a, float b) { return a < b ? a : b
 // frame_loop (seq.hip.h) for a body that accumulates into the output sample itself: a script module's
 // paint() may `+=` its output several times per frame.  f(frame, x[NIN], o&); `zf` = ZH_PAINT_ZERO_FIRST; `walk` is a flag
 // of the caller's that the body reads: true while the frames before a frame range are replayed for their state only.
-template <int CH, int NIN, class F>
+// `quiet(n)` (wave-uniform) is asked before every chunk of n = CH frames; where it holds the chunk runs `fq`, the body's
+// second instance (no rare-path sine branch, no envelope stage end: zscript_emit.hip quiet_terms), else `f`.
+template <int CH, int NIN, class F, class Q, class FQ>
 __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t v, size_t ostride, const float *const *in,
-                                              const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, bool &walk, F &&f) {
+                                              const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, bool &walk, F &&f,
+                                              Q &&quiet, FQ &&fq) {
     constexpr int NI = NIN > 0 ? NIN : 1;
     const uint32_t voff = v * 4u;                                   // rows through buffer descriptors: lanes.hip.h (zrow_*)
     const uint32_t orow = (uint32_t)ostride * 4u;
@@ -103,13 +106,24 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
 #pragma unroll
                 for (int k = 0; k < CH; k++) xr[j][k] = zrow_load<1>(ri, ivoff[j], k * irow);
             }
+            if (quiet(CH)) {                                            // (the replay too: a quiet chunk's walk is cheaper still)
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                float x[NI];
+                for (int k = 0; k < CH; k++) {
+                    float x[NI];
 #pragma unroll
-                for (int j = 0; j < NIN; j++) x[j] = xr[j][k];
-                float o = 0.0f;
-                f(r + k, x, o);
+                    for (int j = 0; j < NIN; j++) x[j] = xr[j][k];
+                    float o = 0.0f;
+                    fq(r + k, x, o);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    float x[NI];
+#pragma unroll
+                    for (int j = 0; j < NIN; j++) x[j] = xr[j][k];
+                    float o = 0.0f;
+                    f(r + k, x, o);
+                }
             }
         }
         for (; r < f0; r++) {
@@ -145,12 +159,22 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
         const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
         // compute the chunk, then store it (seq.hip.h frame_loop: a store after every frame would pin every load of the
         // body -- delay rings, track tables -- behind the previous frame's store)
+        if (quiet(CH)) {
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            float x[NI];
+            for (int k = 0; k < CH; k++) {
+                float x[NI];
 #pragma unroll
-            for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
-            f(i + k, x, oc[k]);
+                for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
+                fq(i + k, x, oc[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float x[NI];
+#pragma unroll
+                for (int j = 0; j < NIN; j++) x[j] = xc[j][k];
+                f(i + k, x, oc[k]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < CH; k++) zrow_store<1>(ro, voff, k * orow, oc[k]);
@@ -172,5 +196,11 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
         f(i, x, o);
         zrow_store<1>(ro, voff, 0, o);
     }
+}
+// one body for every chunk
+template <int CH, int NIN, class F>
+__device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t v, size_t ostride, const float *const *in,
+                                              const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, bool &walk, F &&f) {
+    zs_frame_loop<CH, NIN>(out, v, ostride, in, istride, ivoff, start, end, zf, walk, f, [](int) { return false; }, f);
 }
 #endif

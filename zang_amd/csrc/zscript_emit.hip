@@ -361,7 +361,8 @@ struct Kernel {
     size_t words = 0, noise_fields = 0, uid = 0;
     bool rings = false;            // a delay ring lives in the state blob and is read and written inside the frame body
     bool walk_reads_computed = false;   // a builtin's frame-to-frame state is fed by a value computed in the frame body
-    Lines quiet_terms;             // wave-uniform tests (after the prologue): no SineOsc of constant freq / phase can reach zsinf's rare path
+    Lines quiet_terms;             // wave-uniform tests over the next `zs_n` frames (a chunk): no SineOsc of constant freq / phase can
+                                   // reach zsinf's rare path, no Envelope ends a stage -- the chunk then runs the body's ZS_Q forms
     std::string fresh(const std::string &stem) { uid++; return stem + std::to_string(uid); }
     size_t alloc(size_t n) { const size_t w = words; words += n; return w; }
 };
@@ -507,12 +508,12 @@ public:
             pro.push_back(o + ".begin(" + sr + ", " + f.c + ");");
             // frequency and phase constant over the span (the frequency: a constant, or a constant_or_buffer param that is a
             // constant this paint -- it reaches the oscillator as a temp, cob_to_buffer): the kernel gets a second frame body
-            // whose sine has no rare-path branch, taken when no voice of the wave can reach that path this span
+            // whose sine has no rare-path branch, run for the chunks in which no voice of the wave can reach that path
             // (SineOscLane::small_args)
             const Val &fv = a["freq"];
             const bool quiet = !ph.is_buf && mc.begin_sink == &k.pro && (!f.is_buf || !fv.cob_b.empty());
-            if (quiet && !f.is_buf) k.quiet_terms.push_back(o + ".small_args(" + ph.c + ", (float)SPAN_LEN)");
-            if (quiet && f.is_buf) k.quiet_terms.push_back("(!" + fv.cob_b + " && " + o + ".small_args_step(" + fv.cob_c + " * " + o + ".inv_sr, " + ph.c + ", (float)SPAN_LEN))");
+            if (quiet && !f.is_buf) k.quiet_terms.push_back(o + ".small_args(" + ph.c + ", (float)zs_n)");
+            if (quiet && f.is_buf) k.quiet_terms.push_back("(!" + fv.cob_b + " && " + o + ".small_args_step(" + fv.cob_c + " * " + o + ".inv_sr, " + ph.c + ", (float)zs_n))");
             value = o + ".frame<" + tf(f.is_buf) + (quiet ? ", !ZS_Q" : "") + ">(" + (f.is_buf ? f.i : "0.0f") + ", " + ph.i + ")";
             ends.push_back(o + ".end();");
         } else if (name == "Cycle") {
@@ -575,7 +576,10 @@ public:
             frame.push_back("float " + pp.first + " = 0.0f;");
             // begin() only in the kernel's prologue (not per delay chunk / track sub-span): the frames a frame range
             // replays step the clock and the stage ends only (envelope.hip.h frame_walk)
-            const std::string step = mc.begin_sink == &k.pro ? "frame_s(" + pp.first + ", zs_walk)" : "frame(" + pp.first + ")";
+            // ... and the chunks in which no voice ends a stage run frame_quiet (no clamp, no stage-end test: the kernel's
+            // second frame body, see SineOsc above)
+            const std::string step = mc.begin_sink == &k.pro ? "frame_sq<ZS_Q>(" + pp.first + ", zs_walk)" : "frame(" + pp.first + ")";
+            if (mc.begin_sink == &k.pro) k.quiet_terms.push_back(o + ".quiet(zs_n)");
             frame.push_back("const bool " + pp.second + " = " + o + "." + step + ";");
             painted = pp.second; value = pp.first;
         } else if (name == "Gate") {
@@ -1012,12 +1016,12 @@ public:
             append(out, indent(k.pro));
             out.push_back(I + "bool zs_walk = false; (void)zs_walk;");
             const bool two_bodies = !k.quiet_terms.empty();
-            const std::string loop_call = I + (two_bodies ? I : "") +
+            const std::string loop_call = I +
                 strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk,", unroll, nin);
             if (two_bodies) {
                 std::string all;
                 for (const std::string &t : k.quiet_terms) all += (all.empty() ? "" : " && ") + t;
-                out.push_back(I + "const bool zs_quiet = " + all + ";");
+                out.push_back(I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + all + "; };");
                 out.push_back(I + strf("auto zs_body = [&](auto zs_q, uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
                 out.push_back(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;");
             } else {
@@ -1033,12 +1037,9 @@ public:
             append(out, indent(indent(k.frame)));
             if (two_bodies) {
                 out.push_back(I + "};");
-                for (int q = 1; q >= 0; q--) {
-                    out.push_back(I + (q ? "if (zs_quiet)" : "else"));
-                    out.push_back(loop_call);
-                    out.push_back(I + I + strf("                 [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<%s>{}, i, x, o); });",
-                                               ni, q ? "true" : "false"));
-                }
+                out.push_back(loop_call);
+                out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<false>{}, i, x, o); }, zs_quiet,", ni));
+                out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<true>{}, i, x, o); });", ni));
             } else {
                 out.push_back(I + "});");
             }
