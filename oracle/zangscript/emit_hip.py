@@ -38,6 +38,8 @@ class Val:
     count: str = ""                # curve node count expression
     enum: object = None            # BuiltinEnum
     computed: bool = False         # buf: derives from a module's output or a transcendental function (not just params / constants / + - * /)
+    cob_b: str = ""                # buf that is exactly a constant_or_buffer param's value: its "is a buffer" flag ...
+    cob_c: str = ""                # ... and its constant
 
 
 def f32_literal(x):
@@ -71,6 +73,7 @@ class _Kernel:
         self.uid = 0
         self.rings = False             # a delay ring lives in the state blob and is read and written inside the frame body
         self.walk_reads_computed = False   # a builtin's frame-to-frame state is fed by a value computed in the frame body
+        self.quiet_terms = []          # wave-uniform tests over the next `zs_n` frames: the chunk may run the body's ZS_Q forms
 
     def fresh(self, stem):
         self.uid += 1
@@ -89,6 +92,7 @@ class _ModuleCtx:
         self.k, self.module_index, self.env, self.outvar, self.nic, self.prefix = k, module_index, env, outvar, nic, prefix
         self.tnames, self.fnames = {}, {}
         self.heavy = {}                # temp index -> its current value derives from a module output / transcendental (Val.computed)
+        self.cobsrc = {}               # temp index -> (Val.cob_b, Val.cob_c) while it holds a cob param's value
         # where the per-paint prologue / epilogue of builtin calls goes: the kernel's own prologue and
         # epilogue, or -- inside a `delay` body, which the reference paints chunk by chunk -- the
         # chunk's; `rel` / `length` are the frame index within, and the length of, that paint call
@@ -116,7 +120,8 @@ class HipEmitter:
     def val(self, mc, r):
         k = r.kind
         if k == "temp_buffer":
-            return Val("buf", mc.tname(r.index), computed=mc.heavy.get(r.index, True))
+            cb, cc = mc.cobsrc.get(r.index, ("", ""))
+            return Val("buf", mc.tname(r.index), computed=mc.heavy.get(r.index, True), cob_b=cb, cob_c=cc)
         if k == "temp_float":
             return Val("float", mc.fname(r.index))
         if k == "literal_number":
@@ -156,6 +161,7 @@ class HipEmitter:
         op accumulates), outputs accumulate.  `heavy`: Val.computed of the value written."""
         if d.kind == "temp":
             mc.heavy[d.index] = heavy
+            mc.cobsrc.pop(d.index, None)
             t = mc.tname(d.index)
             if zero_first:
                 return ["%s = 0.0f;" % t, "%s = %s + (%s);" % (t, t, expr)]
@@ -202,7 +208,15 @@ class HipEmitter:
             decl.append("SineOscLane %s;" % o)
             ld_f("t", w)
             pro.append("%s.begin(%s, %s);" % (o, a["sample_rate"].expr, fc))
-            value = "%s.frame<%s>(%s, %s)" % (o, "true" if fb else "false", fi if fb else "0.0f", pi)
+            # frequency and phase constant over the span: the chunks in which no voice can reach the sine's rare path run the
+            # kernel's second frame body (zscript_emit.hip, the same lines)
+            fv = a["freq"]
+            quiet = (not pb) and mc.begin_sink is k.pro and ((not fb) or fv.cob_b != "")
+            if quiet and not fb:
+                k.quiet_terms.append("%s.small_args(%s, (float)zs_n)" % (o, pc))
+            if quiet and fb:
+                k.quiet_terms.append("(!%s && %s.small_args_step(%s * %s.inv_sr, %s, (float)zs_n))" % (fv.cob_b, o, fv.cob_c, o, pc))
+            value = "%s.frame<%s%s>(%s, %s)" % (o, "true" if fb else "false", ", !ZS_Q" if quiet else "", fi if fb else "0.0f", pi)
             ends.append("%s.end();" % o)
         elif name == "Cycle":
             sb, sc, si = cob(a["speed"])
@@ -263,7 +277,9 @@ class HipEmitter:
             cv, cp = k.fresh("cv"), k.fresh("cp")
             # begin() only in the kernel's prologue (not per delay chunk / track sub-span): the frames a frame range
             # replays step the clock and the stage ends only (envelope.hip.h frame_walk)
-            step = "frame_s(%s, zs_walk)" % cv if mc.begin_sink is k.pro else "frame(%s)" % cv
+            step = "frame_sq<ZS_Q>(%s, zs_walk)" % cv if mc.begin_sink is k.pro else "frame(%s)" % cv
+            if mc.begin_sink is k.pro:
+                k.quiet_terms.append("%s.quiet(zs_n)" % o)
             frame += ["float %s = 0.0f;" % cv, "const bool %s = %s.%s;" % (cp, o, step)]
             painted, value = cp, cv
         elif name == "Gate":
@@ -322,6 +338,7 @@ class HipEmitter:
         d = ins.out
         if d.kind == "temp":
             mc.heavy[d.index] = True                                 # a module's output
+            mc.cobsrc.pop(d.index, None)
             t = mc.tname(d.index)
             frame.insert(0, "%s = 0.0f;" % t)
             target = t
@@ -337,10 +354,15 @@ class HipEmitter:
         if kind == "copy_buffer":
             src = self.val(mc, ins.src)
             k.frame += self.put(mc, ins.out, src.expr, False, src.computed)
+            if ins.out.kind == "temp" and src.cob_b:
+                mc.cobsrc[ins.out.index] = (src.cob_b, src.cob_c)
         elif kind == "float_to_buffer":
             k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
         elif kind == "cob_to_buffer":
-            k.frame += self.put(mc, ins.out, mc.env[ins.in_self_param].expr, False, mc.env[ins.in_self_param].computed)
+            src = mc.env[ins.in_self_param]
+            k.frame += self.put(mc, ins.out, src.expr, False, src.computed)
+            if ins.out.kind == "temp" and src.cob_b:
+                mc.cobsrc[ins.out.index] = (src.cob_b, src.cob_c)
         elif kind in ("arith_float", "arith_float_float"):
             expr = (self.UN[ins.op] % self.val(mc, ins.a).expr if kind == "arith_float"
                     else self.BIN[ins.op] % (self.val(mc, ins.a).expr, self.val(mc, ins.b).expr))
@@ -372,6 +394,7 @@ class HipEmitter:
                 d = ins.out
                 if d.kind == "temp":
                     mc.heavy[d.index] = True
+                    mc.cobsrc.pop(d.index, None)
                     outvar = mc.tname(d.index)
                     k.frame.append("%s = 0.0f;" % outvar)
                 else:
@@ -558,7 +581,7 @@ class HipEmitter:
                 j = len(k.rows)
                 k.rows.append(i)
                 k.pro.append("const bool P%d_b = L.p[%d].is_buffer != 0; const float P%d_c = zs_const(L.p[%d], v);" % (i, i, i, i))
-                env.append(Val("buf", "(P%d_b ? x[%d] : P%d_c)" % (i, j, i)))     # cob_to_buffer's switch (codegen_zig.zig:130-143)
+                env.append(Val("buf", "(P%d_b ? x[%d] : P%d_c)" % (i, j, i), cob_b="P%d_b" % i, cob_c="P%d_c" % i))     # cob_to_buffer's switch (codegen_zig.zig:130-143)
             elif kind == "curve":
                 env.append(Val("curve", "reinterpret_cast<const zh_curve_node *>(L.p[%d].pf)" % i, count="L.p[%d].u" % i))
             else:
@@ -618,13 +641,26 @@ class HipEmitter:
                 out.append(I + "ins[%d] = zs_row(L.p[%d], v, istr[%d], ivo[%d]);" % (j, pi, j, j))
             out += [I + l for l in k.pro]
             out.append(I + "bool zs_walk = false; (void)zs_walk;")
-            out.append(I + "zs_frame_loop<%d, %d>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk," % (unroll, nin))
-            out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
+            loop_call = I + "zs_frame_loop<%d, %d>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk," % (unroll, nin)
+            two_bodies = bool(k.quiet_terms)
+            if two_bodies:
+                out.append(I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + " && ".join(k.quiet_terms) + "; };")
+                out.append(I + "auto zs_body = [&](auto zs_q, uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
+                out.append(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;")
+            else:
+                out.append(loop_call)
+                out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
             out.append(I + I + "(void)i; (void)x;")
             if k.temps:
                 out.append(I + I + "float " + ", ".join("%s = 0.0f" % t for t in k.temps) + ";")
             out += [I + I + l for l in k.frame]
-            out.append(I + "});")
+            if two_bodies:
+                out.append(I + "};")
+                out.append(loop_call)
+                out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<false>{}, i, x, o); }, zs_quiet," % ni)
+                out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<true>{}, i, x, o); });" % ni)
+            else:
+                out.append(I + "});")
             out += [I + l for l in k.epi_ends + k.epi_stores]
             out.append("}")
         tables = []
