@@ -169,7 +169,7 @@ def generate(seed):
     return "\n".join(text), "Main"
 
 
-def schedule(seed):
+def schedule(seed, F=F):
     """Random paints of one buffer: [(start, end, note_id_changed, params)], spans in order, some empty."""
     rng = np.random.default_rng(seed + 77777)
     cuts = sorted(int(c) for c in rng.integers(0, F + 1, int(rng.integers(1, 4))))
@@ -218,15 +218,20 @@ def _device_value(value):
     return value
 
 
-def run_case(ctx, seed, buffers=2):
+def run_case(ctx, seed, buffers=2, F=F, ranges=None):
     """One generated module, `buffers` consecutive buffers of random paints; raises AssertionError with the script text on
-    a mismatch.  Returns the script text."""
+    a mismatch.  `ranges`: ZH_SCRIPT_RANGES for the case (the library reads it per paint under ZH_ENV_LIVE=1) -- with
+    F >= 128 the kernels that allow it are launched as that many frame ranges.  Returns the script text."""
+    import os
     import torch
     from oracle import zangscript as zs
     from oracle import zs_interp
     from tests.util import from_image, to_image
     from zang_amd import script, zang
     text, name = generate(seed)
+    old = os.environ.get("ZH_SCRIPT_RANGES")
+    if ranges is not None:
+        os.environ["ZH_SCRIPT_RANGES"] = str(ranges)
     prog = script.ScriptProgram(text, ctx, only=[name])
     try:
         mod = prog.module(name, V, seed)
@@ -236,7 +241,7 @@ def run_case(ctx, seed, buffers=2):
             base = np.zeros((V, F), np.float32) if b % 2 == 0 else np.random.default_rng(seed + b).uniform(-1, 1, (V, F)).astype(np.float32)
             ref = base.copy()
             img = to_image(base)
-            for start, end, nic, params in schedule(seed * 16 + b):
+            for start, end, nic, params in schedule(seed * 16 + b, F):
                 dev = {kk: _device_value(vv) for kk, vv in params.items() if kk in order}
                 nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda() if isinstance(nic, np.ndarray) else nic
                 mod.paint(zang.Span(start, end), [img], None, nic_dev, dev)
@@ -248,8 +253,14 @@ def run_case(ctx, seed, buffers=2):
             if not np.array_equal(got.view(np.uint32), ref.view(np.uint32)):
                 bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
                 v0, f0 = bad[0]
-                raise AssertionError("seed %d buffer %d: %d samples differ, first at voice %d frame %d: got %r want %r\n%s"
-                                     % (seed, b, len(bad), v0, f0, got[v0, f0], ref[v0, f0], text))
+                raise AssertionError("seed %d buffer %d: %d samples differ (voices %s, frames %s), first at voice %d frame %d: got %r want %r\n%s"
+                                     % (seed, b, len(bad), sorted(set(int(q) for q in bad[:, 0]))[:12], sorted(set(int(q) for q in bad[:, 1]))[:40],
+                                        v0, f0, got[v0, f0], ref[v0, f0], text))
     finally:
         prog.close()
+        if ranges is not None:
+            if old is None:
+                del os.environ["ZH_SCRIPT_RANGES"]
+            else:
+                os.environ["ZH_SCRIPT_RANGES"] = old
     return text

@@ -30,13 +30,17 @@ ZL float zsel(bool m, float a, float b) { return m ? a : b; }
 ZL uint32_t zsel(bool m, uint32_t a, uint32_t b) { return m ? a : b; }
 ZL zf2 zsel(zm2 m, zf2 a, zf2 b) { return m ? a : b; }
 ZL zu2 zsel(zm2 m, zu2 a, zu2 b) { return m ? a : b; }
-// m ? a : b as ONE v_cndmask, whatever the optimizer thinks: given a select between two computed values LLVM often
-// rebuilds a branch -- an exec-mask region of ~6 scalar instructions per frame where a compare and a select would do
+// m ? a : b as a v_cndmask, whatever the optimizer thinks: given a select between two computed values LLVM often
+// rebuilds a branch (it sinks an expensive operand into one arm) -- an exec-mask region of ~6 scalar instructions per
+// frame where a compare and a select would do.  The empty asm makes both operands opaque values with nothing to sink;
+// the select itself stays the compiler's, which knows gfx950's wait states between the compare that writes the mask
+// SGPRs and the v_cndmask that reads them.  (Until round 3 this was the v_cndmask itself as inline asm with a ballot
+// operand: the hazard recognizer does not look inside an asm, and where the compare ended up right before it the
+// select read stale mask bits -- found by the random-script fuzz, tests/script_fuzz.py seed 1015.)
 #if defined(__HIP_DEVICE_COMPILE__)
 ZL float zsel_hard(bool m, float a, float b) {
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(__builtin_amdgcn_ballot_w64(m)));
-    return r;
+    asm("" : "+v"(a), "+v"(b));
+    return m ? a : b;
 }
 #else
 ZL float zsel_hard(bool m, float a, float b) { return m ? a : b; }
