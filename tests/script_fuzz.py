@@ -39,11 +39,14 @@ class Gen:
     # ---- constants (literals and the `k` param)
     def const(self, ctx, lo=-2.0, hi=2.0):
         r = self.rng.random()
-        if r < 0.6 or "k" not in ctx["consts"]:
+        if r < 0.6 or not ctx["consts"]:
             return self.lit(lo, hi)
+        c = self.pick(ctx["consts"])
+        if c == "pitch":
+            return "(pitch * 0.001)"
         if r < 0.8:
-            return "k"
-        return "(k * %s)" % self.lit(0.1, 1.5)
+            return c
+        return "(%s * %s)" % (c, self.lit(0.1, 1.5))
 
     # ---- frequencies: the cob param as it is (the generated kernels follow it), scaled, a literal, or a computed buffer
     def freq(self, ctx, depth):
@@ -149,7 +152,38 @@ class Gen:
             lines.append("%s    feedback (%s + feedback * %s)" % (indent, self.buf(inner, max(depth - 1, 0)), self.lit(0.1, 0.5)))
             lines.append("%send" % indent)
             ctx["lets"].append("wet")
+        if ctx.get("track_ok") and self.chance(0.3):
+            # a track: note events at times inside the buffers painted (two buffers of 96 / 256 frames at 48 kHz), the body
+            # painted sub-span by sub-span by the NoteTracker / Trigger walk; builtin calls inside begin per sub-span
+            inner = dict(ctx, consts=list(ctx["consts"]) + ["pitch"], lets=list(ctx["lets"]), track_ok=False, delay_ok=False, prefix=ctx["prefix"] + "k")
+            lines.append("%strk = from deftrack" % indent)
+            lines.append("%s    pitch: constant," % indent)
+            lines.append("%s    note_on: boolean," % indent)
+            lines.append("%sbegin" % indent)
+            t = 0.0 if self.chance(0.5) else float(self.rng.uniform(0.0, 0.001))
+            for _ in range(int(self.rng.integers(1, 6))):
+                lines.append("%s    %.6f (pitch=%s, note_on=%s)" % (indent, t, self.lit(100.0, 1500.0, 1), self.pick(("true", "true", "false"))))
+                t += float(self.rng.uniform(0.00002, 0.0015))
+            lines.append("%send, %s begin" % (indent, self.lit(0.5, 2.0, 3)))
+            for l in self.track_body(inner, max(depth - 1, 1), indent + "    "):
+                lines.append(l)
+            lines.append("%send" % indent)
+            ctx["lets"].append("trk")
         for _ in range(int(self.rng.integers(1, 3))):
+            lines.append("%sout %s" % (indent, self.buf(ctx, depth)))
+        return lines
+
+    def track_body(self, ctx, depth, indent):
+        lines = []
+        if self.chance(0.5):
+            lines.append("%sscale = pitch / 1000" % indent)
+            ctx["consts"] = list(ctx["consts"]) + ["scale"]
+        r = self.rng.random()
+        if r < 0.4:
+            osc = self.pick(("SineOsc(freq=pitch, phase=0)", "PulseOsc(freq=pitch, color=0.5)", "TriSawOsc(freq=pitch, color=%s)" % self.lit(0.0, 1.0, 2)))
+            lines.append("%sout %s * Envelope(attack=%s, decay=%s, release=%s, sustain_volume=%s, note_on)" % (
+                indent, osc, self.curve(), self.curve(), self.curve(), self.lit(0.2, 1.0, 2)))
+        else:
             lines.append("%sout %s" % (indent, self.buf(ctx, depth)))
         return lines
 
@@ -163,7 +197,7 @@ def generate(seed):
         ctx = {"bufs": ["freq"], "consts": [], "lets": [], "helpers": list(helpers), "prefix": "h%d_" % h}
         text += ["%s = defmodule" % name, "    freq: cob,", "    note_on: boolean,", "begin"] + g.body(ctx, 2) + ["end", ""]
         helpers.append(name)
-    ctx = {"bufs": ["freq", "x"], "consts": ["k"], "lets": [], "helpers": helpers, "prefix": "m", "portamento": True, "delay_ok": True}
+    ctx = {"bufs": ["freq", "x"], "consts": ["k"], "lets": [], "helpers": helpers, "prefix": "m", "portamento": True, "delay_ok": True, "track_ok": True}
     text += ["Main = defmodule", "    freq: cob,", "    x: waveform,", "    k: constant,", "    note_on: boolean,", "    prev_note_on: boolean,", "begin"]
     text += g.body(ctx, 3) + ["end", ""]
     return "\n".join(text), "Main"
@@ -218,17 +252,18 @@ def _device_value(value):
     return value
 
 
-def run_case(ctx, seed, buffers=2, F=F, ranges=None):
+def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None):
     """One generated module, `buffers` consecutive buffers of random paints; raises AssertionError with the script text on
     a mismatch.  `ranges`: ZH_SCRIPT_RANGES for the case (the library reads it per paint under ZH_ENV_LIVE=1) -- with
-    F >= 128 the kernels that allow it are launched as that many frame ranges.  Returns the script text."""
+    F >= 128 the kernels that allow it are launched as that many frame ranges.  `text`: a given script (module `Main` with
+    the generator's params) instead of the generated one; `seed` then only picks the paints.  Returns the script text."""
     import os
     import torch
     from oracle import zangscript as zs
     from oracle import zs_interp
     from tests.util import from_image, to_image
     from zang_amd import script, zang
-    text, name = generate(seed)
+    text, name = generate(seed) if text is None else (text, "Main")
     old = os.environ.get("ZH_SCRIPT_RANGES")
     if ranges is not None:
         os.environ["ZH_SCRIPT_RANGES"] = str(ranges)

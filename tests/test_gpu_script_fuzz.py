@@ -43,16 +43,29 @@ def test_gpu_random_script_parity_as_frame_ranges(ctx, seed):
 
 @pytest.mark.gpu
 def test_gpu_seed_1015_select_hazard(ctx):
-    """The case that exposed the inline-asm v_cndmask of round 2 (lanes.hip.h zsel_hard): TriSawOsc + pink Noise + Envelope
-    in one kernel put the compare that writes the mask SGPRs right before the asm, which the hazard recognizer does not
-    see into; lanes 32-63 of the first frame of every chunk took the stale mask."""
-    script_fuzz.run_case(ctx, 1015)
-    script_fuzz.run_case(ctx, 1015, F=256, ranges=3)
+    """The case that exposed the inline-asm v_cndmask of round 2 (lanes.hip.h zsel_hard): with a literal TriSawOsc color its
+    `"s"(ballot(true))` operand became the EXEC register itself in one place, and a v_cndmask_b32_e64 with EXEC as its mask
+    operand takes the upper half-wave's bits as zero (tools/ubench/select_hazard.hip): lanes 32-63 of the first frame of every
+    chunk painted the triangle branch's value."""
+    text = """Main = defmodule
+    freq: cob,
+    x: waveform,
+    k: constant,
+    note_on: boolean,
+    prev_note_on: boolean,
+begin
+    m1 = Gate(note_on)
+    out (TriSawOsc(freq=(207.0 + 196.1 * (freq - Gate(note_on))), color=0.993) * (Noise(color=.pink) / (2 + cos((Envelope(attack=.linear(0.00209), decay=.linear(0.00117), release=.squared(0.00244), sustain_volume=1, note_on) + m1)))))
+end
+"""
+    script_fuzz.run_case(ctx, 1015, text=text)
+    script_fuzz.run_case(ctx, 1015, F=256, ranges=3, text=text)
 
 
 def test_no_inline_asm_reads_an_sgpr():
-    """gfx950 needs wait states between a VALU that writes an SGPR and a VALU that reads it; the compiler inserts them for
-    its own instructions only.  No inline asm in the kernels may take a scalar ("s") operand."""
+    """For an "s" operand the compiler may hand an inline asm EXEC or VCC themselves (it did: see the test above), and what an
+    instruction makes of EXEC as an ordinary scalar operand is not what its SGPR copy gives.  No inline asm in the kernels
+    takes a scalar operand; selects and compares stay the compiler's."""
     import glob, os, re
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zang_amd", "csrc")
     bad = []

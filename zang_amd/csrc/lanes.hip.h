@@ -33,10 +33,13 @@ ZL zu2 zsel(zm2 m, zu2 a, zu2 b) { return m ? a : b; }
 // m ? a : b as a v_cndmask, whatever the optimizer thinks: given a select between two computed values LLVM often
 // rebuilds a branch (it sinks an expensive operand into one arm) -- an exec-mask region of ~6 scalar instructions per
 // frame where a compare and a select would do.  The empty asm makes both operands opaque values with nothing to sink;
-// the select itself stays the compiler's, which knows gfx950's wait states between the compare that writes the mask
-// SGPRs and the v_cndmask that reads them.  (Until round 3 this was the v_cndmask itself as inline asm with a ballot
-// operand: the hazard recognizer does not look inside an asm, and where the compare ended up right before it the
-// select read stale mask bits -- found by the random-script fuzz, tests/script_fuzz.py seed 1015.)
+// the select itself stays the compiler's.  (Until round 3 this was the v_cndmask itself as inline asm with
+// `"s"(ballot(m))` as its mask operand.  Where m is true at compile time -- a literal TriSawOsc color in a script --
+// ballot(true) IS the exec mask, and the compiler may hand the asm the EXEC register itself for an "s" operand; a
+// v_cndmask_b32_e64 whose mask operand is EXEC takes the mask bits of lanes 32-63 as zero on gfx950
+// (tools/ubench/select_hazard.hip: 32,768 of 32,768 wrong in the upper half-wave, none with a copy of EXEC in an SGPR
+// pair; the compiler's own selects use a register class without EXEC).  Found by the random-script fuzz,
+// tests/script_fuzz.py seed 1015.  No asm in csrc/ takes a scalar operand any more: test_no_inline_asm_reads_an_sgpr.)
 #if defined(__HIP_DEVICE_COMPILE__)
 ZL float zsel_hard(bool m, float a, float b) {
     asm("" : "+v"(a), "+v"(b));
