@@ -2,6 +2,7 @@
 (zh_script_load -> hiprtc) and paint them through the module call shape of the reference
 (SineOsc.zig:22-31; generated modules: codegen_zig.zig:558-563)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -41,7 +42,8 @@ class ScriptProgram:
             compiled = native.NativeScript(text, filename)
         except native.NativeScriptError as e:
             raise ScriptCompileError(str(e))
-        self.hip_source, self.meta = compiled.generate_hip(only=only)
+        # ZH_SCRIPT_UNROLL: frames per unrolled chunk of the generated kernels (an experiment knob; 0 / unset = the emitter's choice by body size)
+        self.hip_source, self.meta = compiled.generate_hip(only=only, unroll=int(os.environ.get("ZH_SCRIPT_UNROLL", "0")))
         compiled.close()
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
