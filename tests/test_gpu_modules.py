@@ -534,6 +534,54 @@ def test_sampler(ctx, oracle, fmt, loop, replay_form):
     util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sampler t")
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("loop", [False, True])
+@pytest.mark.parametrize("nframes", [2, 3, 5, 64, 700])
+def test_sampler_one_channel_pair_loads(ctx, oracle, fmt, loop, nframes, replay_form):
+    """One channel of u8 / s16: the interpolation's two samples come from one load (k_sampler's pair path).  Sample lengths
+    down to two frames (wraps every frame; |ratio| + 1 >= n sends a voice's wave through the general body), ratios from
+    1/12 to 6 and negative ones, play positions that start beyond the end and before the start, an s16 base that is not
+    2-byte aligned (general body), a retrigger in the middle buffer."""
+    from zang_amd import modules as mod, zang
+    V, in_rate = 134, 44100
+    raw = _pcm(fmt, nframes + 1, 1, 160 + fmt)
+    rng = np.random.default_rng(nframes * 7 + fmt)
+    rate = (in_rate / rng.uniform(1.0 / 12.0, 6.0, V)).astype(np.float32)
+    rate[:6] = [-44100.0, -9000.0, 44100.0, 44100.5, 500000.0, 7000.0]
+    t_start = rng.uniform(-3.0, nframes + 3.0, V).astype(np.float32)
+    t_start[70:] = 0.0
+    nic_script = [np.zeros(V, bool), rng.random(V) < 0.3, np.zeros(V, bool)]
+    for misaligned in ([False, True] if fmt == 1 else [False]):
+        data = np.ascontiguousarray(raw[1 if misaligned else 0:][: nframes * (fmt + 1)])
+        out0 = util.rng_buffers(62, V, F)
+        L = oracle.lib()
+        ref = out0.copy(); rt = np.zeros(V, np.float32)
+        for v in range(V):
+            st = oracle.Sampler(); L.zo_sampler_init(C.byref(st)); st.t = float(t_start[v])
+            for k, (s, e) in enumerate(util.SPANS_THREE):
+                p = oracle.SamplerParams(float(rate[v]), 1, in_rate, fmt, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, 0, int(loop))
+                L.zo_sampler_paint(C.byref(st), s, e, oracle.fptr(ref[v]), int(nic_script[k][v]), C.byref(p))
+            rt[v] = st.t
+        m = mod.Sampler(V, ctx)
+        st = m.state(); st["t"] = t_start; m.set_state(st)
+        out = util.to_image(out0)
+        if misaligned:                                 # a device buffer whose sample base sits at an odd address
+            import torch
+            holder = torch.zeros(data.size + 1, dtype=torch.uint8, device="cuda")
+            holder[1:] = torch.from_numpy(data).cuda()
+            dev_data = holder[1:]
+            assert dev_data.data_ptr() % 2 == 1
+        else:
+            dev_data = util.dev(data)
+        smp = m.Sample(1, in_rate, fmt, dev_data)
+        gr = util.dev(rate)
+        for k, (s, e) in enumerate(util.SPANS_THREE):
+            m.paint(zang.Span(s, e), [out], [], util.dev(nic_script[k].astype(np.uint8)), m.Params(gr, smp, 0, loop))
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"sampler mono fmt {fmt} loop {loop} n {nframes} misaligned {misaligned}")
+        util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sampler t")
+
+
 @pytest.mark.parametrize("fmt", [1, 3])
 def test_sampler_huge_play_positions(ctx, oracle, fmt, replay_form):
     """Play positions beyond the i32 range (set through the state): floor(t) converts to the saturation value, t0 + 1 wraps

@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
         // looped: @mod(t0 + 1, n) is @mod(t0, n) + 1, wrapped once -- except where t0 + 1 itself wraps (t0 = INT32_MAX: the
         // conversion's saturation value), whose remainder is the same for every frame
         const int32_t r_wrap = (LOOP && FMT != kSampleEmpty) ? sampler_mod(INT32_MIN, s.num_samples, s.inv_num_samples) : 0;
-        frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+        auto general = [&](float &val) ZH_INLINE_LAMBDA {
             const int32_t t0 = zf32_to_i32(floorf(t));
             const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
             const float tfrac = (float)t1 - t;                        // :121
@@ -832,8 +832,70 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
             }
             val = s0 * (1.0f - tfrac) + s1 * tfrac;
             t += ratio;
-            return true;
-        });
+        };
+        // One channel of u8 or aligned s16: the two samples of an interpolation are neighbours in memory, so ONE load
+        // fetches both (the gathers, not the arithmetic, bound this kernel: a 64-lane gather is 16 address cycles of the
+        // CU's texture path, two of them per sample).  The pair is read at rb = clamp(r0, 0, n - 2); d = r0 - rb says
+        // which halves the frame wants: 0 -> (lo, hi); 1 -> r0 is the last sample: (hi, looped ? sample 0 : nothing);
+        // -1 -> r0 = -1: (nothing, lo); else both indices are outside the data.  Chunks in which a play position could
+        // reach the float -> i32 conversion's saturation (|t| near 2^31: the looped path's r_wrap case) or in which the
+        // looped index cannot be stepped from the previous frame's (|ratio| + 1 >= n) take the general body.
+        constexpr bool kPairFmt = FMT == ZH_SAMPLE_U8 || FMT == ZH_SAMPLE_S16_LSB;
+        if (kPairFmt && s.num_channels == 1 && s.num_samples >= 2 && (FMT == ZH_SAMPLE_U8 || s.whole)) {
+            const int32_t n = s.num_samples;
+            const float s_first = sampler_at<FMT>(s, 0);
+            const bool step_ok = __builtin_fabsf(ratio) + 1.0f < (float)n;
+            bool have_prev = false;
+            int32_t t0_prev = 0, r0_prev = 0;
+            frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1,
+                [&](uint32_t) ZH_INLINE_LAMBDA {
+                    have_prev = false;
+                    const bool ok = step_ok && __builtin_fabsf(t) + 9.0f * __builtin_fabsf(ratio) < 2.0e9f;   // (a NaN fails)
+                    return __builtin_amdgcn_ballot_w64(!ok) == 0;
+                },
+                [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+                    const int32_t t0 = zf32_to_i32(floorf(t));
+                    const int32_t t1 = (int32_t)((uint32_t)t0 + 1u);
+                    const float tfrac = (float)t1 - t;                // :121
+                    int32_t r0 = t0;
+                    if constexpr (LOOP) {
+                        if (have_prev) {                              // @mod(t0, n) from the previous frame's: |t0 - t0_prev| < n
+                            r0 = r0_prev + (t0 - t0_prev);
+                            r0 = r0 >= n ? r0 - n : r0;
+                            r0 = r0 < 0 ? r0 + n : r0;
+                        } else {
+                            r0 = sampler_mod(t0, n, s.inv_num_samples);
+                        }
+                        t0_prev = t0; r0_prev = r0; have_prev = true;
+                    }
+                    const int32_t rb = min(max(r0, 0), n - 2);
+                    const int32_t d = r0 - rb;
+                    float lo, hi;
+                    if constexpr (FMT == ZH_SAMPLE_U8) {
+                        uint16_t w;
+                        __builtin_memcpy(&w, s.data + (size_t)rb, 2);
+                        lo = ((float)(w & 0xffu) - 127.5f) / 127.5f;
+                        hi = ((float)(w >> 8) - 127.5f) / 127.5f;
+                    } else {
+                        uint32_t w;
+                        __builtin_memcpy(&w, s.data + (size_t)rb * 2, 4);
+                        const float inv_max = 1.0f / 32768.0f;
+                        lo = (float)(int16_t)(w & 0xffffu) * inv_max;
+                        hi = (float)((int32_t)w >> 16) * inv_max;
+                    }
+                    const float s0 = d == 0 ? lo : (d == 1 ? hi : 0.0f);
+                    const float s1 = d == 0 ? hi : (d == 1 ? (LOOP ? s_first : 0.0f) : (d == -1 ? lo : 0.0f));
+                    val = s0 * (1.0f - tfrac) + s1 * tfrac;
+                    t += ratio;
+                    return true;
+                },
+                [&](uint32_t, float &val) ZH_INLINE_LAMBDA { general(val); return true; });
+        } else {
+            frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
+                general(val);
+                return true;
+            });
+        }
     }
     if (!last) return;
     // :133-135: compared against data.len in BYTES (reference quirk, kept)
