@@ -534,17 +534,17 @@ def test_sampler(ctx, oracle, fmt, loop, replay_form):
     util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sampler t")
 
 
-@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("fmt,channels", [(0, 1), (0, 2), (0, 4), (1, 1), (1, 2), (3, 1)])
 @pytest.mark.parametrize("loop", [False, True])
 @pytest.mark.parametrize("nframes", [2, 3, 5, 64, 700])
-def test_sampler_one_channel_pair_loads(ctx, oracle, fmt, loop, nframes, replay_form):
-    """One channel of u8 / s16: the interpolation's two samples come from one load (k_sampler's pair path).  Sample lengths
-    down to two frames (wraps every frame; |ratio| + 1 >= n sends a voice's wave through the general body), ratios from
-    1/12 to 6 and negative ones, play positions that start beyond the end and before the start, an s16 base that is not
-    2-byte aligned (general body), a retrigger in the middle buffer."""
+def test_sampler_pair_loads(ctx, oracle, fmt, channels, loop, nframes, replay_form):
+    """Frames of 1, 2 or 4 bytes: the interpolation's two samples come from one load of two frames (k_sampler's pair path).
+    Sample lengths down to two frames (wraps every frame; |ratio| + 1 >= n sends a voice's wave through the general body),
+    ratios from 1/12 to 6 and negative ones, play positions that start beyond the end and before the start, an s16 base
+    that is not 2-byte aligned (general body), the last channel of a frame, a retrigger in the middle buffer."""
     from zang_amd import modules as mod, zang
     V, in_rate = 134, 44100
-    raw = _pcm(fmt, nframes + 1, 1, 160 + fmt)
+    raw = _pcm(fmt, nframes + 1, channels, 160 + fmt)
     rng = np.random.default_rng(nframes * 7 + fmt)
     rate = (in_rate / rng.uniform(1.0 / 12.0, 6.0, V)).astype(np.float32)
     rate[:6] = [-44100.0, -9000.0, 44100.0, 44100.5, 500000.0, 7000.0]
@@ -552,14 +552,14 @@ def test_sampler_one_channel_pair_loads(ctx, oracle, fmt, loop, nframes, replay_
     t_start[70:] = 0.0
     nic_script = [np.zeros(V, bool), rng.random(V) < 0.3, np.zeros(V, bool)]
     for misaligned in ([False, True] if fmt == 1 else [False]):
-        data = np.ascontiguousarray(raw[1 if misaligned else 0:][: nframes * (fmt + 1)])
+        data = np.ascontiguousarray(raw[1 if misaligned else 0:][: nframes * channels * (fmt + 1)])
         out0 = util.rng_buffers(62, V, F)
         L = oracle.lib()
         ref = out0.copy(); rt = np.zeros(V, np.float32)
         for v in range(V):
             st = oracle.Sampler(); L.zo_sampler_init(C.byref(st)); st.t = float(t_start[v])
             for k, (s, e) in enumerate(util.SPANS_THREE):
-                p = oracle.SamplerParams(float(rate[v]), 1, in_rate, fmt, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, 0, int(loop))
+                p = oracle.SamplerParams(float(rate[v]), channels, in_rate, fmt, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, channels - 1, int(loop))
                 L.zo_sampler_paint(C.byref(st), s, e, oracle.fptr(ref[v]), int(nic_script[k][v]), C.byref(p))
             rt[v] = st.t
         m = mod.Sampler(V, ctx)
@@ -573,12 +573,12 @@ def test_sampler_one_channel_pair_loads(ctx, oracle, fmt, loop, nframes, replay_
             assert dev_data.data_ptr() % 2 == 1
         else:
             dev_data = util.dev(data)
-        smp = m.Sample(1, in_rate, fmt, dev_data)
+        smp = m.Sample(channels, in_rate, fmt, dev_data)
         gr = util.dev(rate)
         for k, (s, e) in enumerate(util.SPANS_THREE):
-            m.paint(zang.Span(s, e), [out], [], util.dev(nic_script[k].astype(np.uint8)), m.Params(gr, smp, 0, loop))
+            m.paint(zang.Span(s, e), [out], [], util.dev(nic_script[k].astype(np.uint8)), m.Params(gr, smp, channels - 1, loop))
         ctx.sync()
-        util.assert_bitexact(util.from_image(out), ref, f"sampler mono fmt {fmt} loop {loop} n {nframes} misaligned {misaligned}")
+        util.assert_bitexact(util.from_image(out), ref, f"sampler fmt {fmt} x {channels} loop {loop} n {nframes} misaligned {misaligned}")
         util.assert_bitexact(m.state()["t"].astype(np.float32), rt, "sampler t")
 
 

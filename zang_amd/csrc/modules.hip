@@ -727,6 +727,7 @@ struct SampleP {
 // format switch, the loop test and the bounds test as branches inside the frame loop every frame was its own basic
 // block and paid the full latency of its PCM gathers; as straight-line code the loads of a chunk's 8 frames overlap.
 // `whole`: the PCM base is aligned to the sample size, so a sample is one load instead of byte_count byte gathers.
+template <int N> struct zint { static constexpr int value = N; };
 constexpr int kSampleEmpty = -1;                                     // no samples: every read is 0 (and nothing is loaded)
 template <int FMT>
 __device__ __forceinline__ float sampler_decode(const uint8_t *data, size_t i, bool whole) {
@@ -833,16 +834,21 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
             val = s0 * (1.0f - tfrac) + s1 * tfrac;
             t += ratio;
         };
-        // One channel of u8 or aligned s16: the two samples of an interpolation are neighbours in memory, so ONE load
-        // fetches both (the gathers, not the arithmetic, bound this kernel: a 64-lane gather is 16 address cycles of the
-        // CU's texture path, two of them per sample).  The pair is read at rb = clamp(r0, 0, n - 2); d = r0 - rb says
-        // which halves the frame wants: 0 -> (lo, hi); 1 -> r0 is the last sample: (hi, looped ? sample 0 : nothing);
-        // -1 -> r0 = -1: (nothing, lo); else both indices are outside the data.  Chunks in which a play position could
-        // reach the float -> i32 conversion's saturation (|t| near 2^31: the looped path's r_wrap case) or in which the
-        // looped index cannot be stepped from the previous frame's (|ratio| + 1 >= n) take the general body.
-        constexpr bool kPairFmt = FMT == ZH_SAMPLE_U8 || FMT == ZH_SAMPLE_S16_LSB;
-        if (kPairFmt && s.num_channels == 1 && s.num_samples >= 2 && (FMT == ZH_SAMPLE_U8 || s.whole)) {
+        // Frames of 1, 2 or 4 bytes (u8 x 1 / 2 / 4 channels, aligned s16 x 1 / 2, aligned s32 x 1): the two samples of an
+        // interpolation sit in neighbouring frames, so ONE load of two frames fetches both (the gathers, not the arithmetic,
+        // bound this kernel: a 64-lane gather is 16 address cycles of the CU's texture path, two of them per sample).  The
+        // pair is read at frame rb = clamp(r0, 0, n - 2); d = r0 - rb says which halves the frame wants: 0 -> (lo, hi);
+        // 1 -> r0 is the last frame: (hi, looped ? frame 0 : nothing); -1 -> r0 = -1: (nothing, lo); else both indices are
+        // outside the data.  Chunks in which a play position could reach the float -> i32 conversion's saturation (|t| near
+        // 2^31: the looped path's r_wrap case) or in which the looped index cannot be stepped from the previous frame's
+        // (|ratio| + 1 >= n) take the general body.
+        constexpr int kBps = FMT == kSampleEmpty ? 0 : FMT + 1;
+        const uint32_t fb = s.num_channels * (uint32_t)kBps;          // bytes per frame
+        const bool pair_ok = kBps != 0 && kBps != 3 && (fb == 1 || fb == 2 || fb == 4) && s.num_samples >= 2 && (kBps == 1 || s.whole);
+        auto paired = [&](auto fb_tag) ZH_INLINE_LAMBDA {
+            constexpr int FB = decltype(fb_tag)::value;
             const int32_t n = s.num_samples;
+            const uint32_t sh = s.channel * 8u * (uint32_t)kBps;      // the channel's bit offset inside a frame
             const float s_first = sampler_at<FMT>(s, 0);
             const bool step_ok = __builtin_fabsf(ratio) + 1.0f < (float)n;
             bool have_prev = false;
@@ -870,18 +876,28 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
                     }
                     const int32_t rb = min(max(r0, 0), n - 2);
                     const int32_t d = r0 - rb;
+                    uint32_t w0, w1;                                  // frames rb and rb + 1
+                    if constexpr (FB == 1) {
+                        uint16_t w; __builtin_memcpy(&w, s.data + (size_t)rb, 2);
+                        w0 = w & 0xffu; w1 = w >> 8;
+                    } else if constexpr (FB == 2) {
+                        uint32_t w; __builtin_memcpy(&w, s.data + (size_t)rb * 2, 4);
+                        w0 = w & 0xffffu; w1 = w >> 16;
+                    } else {
+                        uint2 w; __builtin_memcpy(&w, s.data + (size_t)rb * 4, 8);
+                        w0 = w.x; w1 = w.y;
+                    }
+                    w0 >>= sh; w1 >>= sh;
                     float lo, hi;
                     if constexpr (FMT == ZH_SAMPLE_U8) {
-                        uint16_t w;
-                        __builtin_memcpy(&w, s.data + (size_t)rb, 2);
-                        lo = ((float)(w & 0xffu) - 127.5f) / 127.5f;
-                        hi = ((float)(w >> 8) - 127.5f) / 127.5f;
+                        lo = ((float)(w0 & 0xffu) - 127.5f) / 127.5f;
+                        hi = ((float)(w1 & 0xffu) - 127.5f) / 127.5f;
+                    } else if constexpr (FMT == ZH_SAMPLE_S16_LSB) {
+                        lo = (float)(int16_t)(w0 & 0xffffu) * (1.0f / 32768.0f);
+                        hi = (float)(int16_t)(w1 & 0xffffu) * (1.0f / 32768.0f);
                     } else {
-                        uint32_t w;
-                        __builtin_memcpy(&w, s.data + (size_t)rb * 2, 4);
-                        const float inv_max = 1.0f / 32768.0f;
-                        lo = (float)(int16_t)(w & 0xffffu) * inv_max;
-                        hi = (float)((int32_t)w >> 16) * inv_max;
+                        lo = (float)(int32_t)w0 * (1.0f / 2147483648.0f);
+                        hi = (float)(int32_t)w1 * (1.0f / 2147483648.0f);
                     }
                     const float s0 = d == 0 ? lo : (d == 1 ? hi : 0.0f);
                     const float s1 = d == 0 ? hi : (d == 1 ? (LOOP ? s_first : 0.0f) : (d == -1 ? lo : 0.0f));
@@ -890,7 +906,11 @@ __global__ void __launch_bounds__(kSeqBlock) k_sampler(const float *__restrict__
                     return true;
                 },
                 [&](uint32_t, float &val) ZH_INLINE_LAMBDA { general(val); return true; });
-        } else {
+        };
+        if (pair_ok && fb == 1) paired(zint<1>{});
+        else if (pair_ok && fb == 2) paired(zint<2>{});
+        else if (pair_ok) paired(zint<4>{});
+        else {
             frame_loop<8, ZF, 0>(out.p, v, out.stride, no_in, nullptr, f0, f1, [&](uint32_t, const float (&)[1], float &val) ZH_INLINE_LAMBDA {
                 general(val);
                 return true;
