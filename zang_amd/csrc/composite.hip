@@ -550,11 +550,20 @@ __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, co
                 }
             }
         } else if (whole && n.env.quiet(MIXF)) {                          // no stage can end in this chunk: the envelope without its stage-end test
+            if (__all(n.env.mode == ENV_MODE_TOWARD)) {                   // ... and every voice is inside a stage: nothing to select
 #pragma unroll 4
-            for (int k = 0; k < MIXF; k++) {
-                const float e0 = n.env.frame_masked_quiet();
-                const float x = 0.0f + (ROLL ? n.template frame_quiet_roll<true>(e0, roll) : n.template frame_quiet<true>(e0));
-                tile[k][lane] = x;
+                for (int k = 0; k < MIXF; k++) {
+                    const float e0 = n.env.frame_masked_all_toward_quiet();
+                    const float x = 0.0f + (ROLL ? n.template frame_quiet_roll<true>(e0, roll) : n.template frame_quiet<true>(e0));
+                    tile[k][lane] = x;
+                }
+            } else {
+#pragma unroll 4
+                for (int k = 0; k < MIXF; k++) {
+                    const float e0 = n.env.frame_masked_quiet();
+                    const float x = 0.0f + (ROLL ? n.template frame_quiet_roll<true>(e0, roll) : n.template frame_quiet<true>(e0));
+                    tile[k][lane] = x;
+                }
             }
         } else if (whole) {
 #pragma unroll 4

@@ -228,6 +228,15 @@ struct EnvLaneT {
         const F val = zsel(toward, lv, sustain_volume);
         return zbits_f(zbits_u(f(0.0f) + val) & m_painted);
     }
+    // frame_masked_quiet() where, besides, EVERY voice of the wave is in a timed stage (a chord's attack, its release): the
+    // mode compare, the three selects and the painted mask go; same operations on the same values for every lane
+    __device__ __forceinline__ F frame_masked_all_toward_quiet() {
+        const F tn = t + cur_step;
+        const F lv = start + curve(tn) * cur_delta;                // :114
+        t = tn;
+        last_value = lv;
+        return f(0.0f) + lv;
+    }
     // N calls of frame() / frame_masked() with the values discarded, where quiet(N) holds (a frame-range kernel's replay):
     // the clock is stepped N times, the curve is evaluated once, for the last of them
     template <int N> __device__ __forceinline__ void skip_quiet() {
