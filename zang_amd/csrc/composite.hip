@@ -231,15 +231,21 @@ __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_
         n.roll_begin(roll);
         bool flat = false;
         float e0c = 0.0f;
-        frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end,
+        frame_loop_gen2<8, ZF>(out.p, v, out.stride, start, end,
             [&](uint32_t) ZH_INLINE_LAMBDA {
                 flat = !zany_wave(n.env.mode == ENV_MODE_TOWARD);
-                if (flat) { e0c = n.env_quiet(); return true; }
-                return n.env.quiet(8);
+                if (flat) { e0c = n.env_quiet(); return 1; }
+                if (!n.env.quiet(8)) return 0;
+                return __all(n.env.mode == ENV_MODE_TOWARD) ? 2 : 1;      // 2: every voice inside a stage, nothing to select
             },
             [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
                 const float t1 = n.template tail_filter<ZF>(n.osc_next(roll));   // (ZERO_FIRST: the caller adds val to 0, see tail_filter)
                 val = (flat ? e0c : n.env.frame_masked_quiet()) * t1;   // NiceLane::tail
+                return true;
+            },
+            [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+                const float t1 = n.template tail_filter<ZF>(n.osc_next(roll));
+                val = n.env.frame_masked_all_toward_quiet() * t1;
                 return true;
             },
             [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template tail<ZF>(n.osc_next(roll)); return true; });
@@ -781,6 +787,36 @@ __device__ __forceinline__ void pm_store(const PMLane &n, const PMOscArgs &a, ui
     a.estate[v] = n.env.state; a.et[v] = n.env.t; a.elast[v] = n.env.last_value; a.estart[v] = n.env.start;
 }
 
+// The frames [f0, f1) of one voice column.  8-frame chunks: where no sine argument can reach zsinf's rare path and no
+// envelope stage can end, the frame is one straight-line block -- branch-free sines, and the envelope as a per-voice
+// constant (no voice of the wave inside a timed stage), without its selects (every voice inside one) or with them; every
+// other chunk takes the general frame.
+template <bool ZF>
+__device__ __forceinline__ void pm_paint_frames(PMLane &n, const Img &out, uint32_t v, uint32_t f0, uint32_t f1) {
+    bool flat = false;
+    float e0c = 0.0f;
+    frame_loop_gen2<8, ZF>(out.p, v, out.stride, f0, f1,
+        [&](uint32_t) ZH_INLINE_LAMBDA {
+            if (!n.small_args(8.0f) || !n.env.quiet(8)) return 0;
+            flat = !zany_wave(n.env.mode == ENV_MODE_TOWARD);
+            if (flat) { e0c = n.env.frame_masked_quiet(); return 1; }     // (changes nothing where no voice is in a stage)
+            return __all(n.env.mode == ENV_MODE_TOWARD) ? 2 : 1;
+        },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+            float tm_i, tc_i;
+            n.step_phase(tm_i, tc_i);
+            val = PMLane::value<false>(tm_i, tc_i, flat ? e0c : n.env.frame_masked_quiet());
+            return true;
+        },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+            float tm_i, tc_i;
+            n.step_phase(tm_i, tc_i);
+            val = PMLane::value<false>(tm_i, tc_i, n.env.frame_masked_all_toward_quiet());
+            return true;
+        },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<true>(); return true; });
+}
+
 template <bool ZF>
 __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint32_t start, uint32_t end) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
@@ -788,11 +824,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
     PMLane n;
     pm_load(n, a, v);
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
-    const float *const *no_in = nullptr;
-    (void)no_in;
-    frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t) ZH_INLINE_LAMBDA { return n.small_args(8.0f); },
-        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<false>(); return true; },      // no rare-path branch: one block
-        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<true>(); return true; });
+    pm_paint_frames<ZF>(n, out, v, start, end);
     n.end();
     pm_store(n, a, v);
 }
@@ -827,11 +859,7 @@ __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__re
         float tm_i, tc_i, e0;
         n.step(tm_i, tc_i, e0);
     }
-    const float *const *no_in = nullptr;
-    (void)no_in;
-    frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1, [&](uint32_t) ZH_INLINE_LAMBDA { return n.small_args(8.0f); },
-        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<false>(); return true; },
-        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<true>(); return true; });
+    pm_paint_frames<ZF>(n, out, v, f0, f1);
     if (f1 != end) return;
     n.end();
     const size_t V = a.V;

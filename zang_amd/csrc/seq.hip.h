@@ -167,6 +167,76 @@ __device__ __forceinline__ void frame_loop_gen(float *__restrict__ out, uint32_t
     }
 }
 
+// frame_loop_gen with TWO fast bodies: `quiet(i)` returns 0 (the chunk runs `slow`), 1 (`fast1`) or 2 (`fast2`), wave-uniform.
+template <int CH, bool ZF, class Q, class F1, class F2, class FS>
+__device__ __forceinline__ void frame_loop_gen2(float *__restrict__ out, uint32_t v, size_t ostride, uint32_t start, uint32_t end,
+                                                Q &&quiet, F1 &&fast1, F2 &&fast2, FS &&slow) {
+    const uint32_t n = end - start;
+    const uint32_t nfull = n / CH;
+    const uint32_t voff = v * 4u;
+    const uint32_t orow = (uint32_t)ostride * 4u;
+    float oc[CH];
+    uint32_t i = start;
+    if (nfull > 0 && !ZF) {
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+#pragma unroll
+        for (int k = 0; k < CH; k++) oc[k] = zrow_load<1>(ro, voff, k * orow);
+    }
+    for (uint32_t c = 0; c < nfull; c++, i += CH) {
+        float on[CH];
+        const bool more = c + 1 < nfull;
+        if (more && !ZF) {
+            const zh_rsrc_t rn = zrow_rsrc(out, ostride, i + CH);
+#pragma unroll
+            for (int k = 0; k < CH; k++) on[k] = zrow_load<1>(rn, voff, k * orow);
+        }
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        float res[CH];
+        bool pm[CH];
+        const int q = quiet(i);
+        if (q == 2) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float val = 0.0f;
+                pm[k] = fast2(i + k, val);
+                const float o = ZF ? 0.0f : oc[k];
+                res[k] = pm[k] ? o + val : o;
+            }
+        } else if (q == 1) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float val = 0.0f;
+                pm[k] = fast1(i + k, val);
+                const float o = ZF ? 0.0f : oc[k];
+                res[k] = pm[k] ? o + val : o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float val = 0.0f;
+                pm[k] = slow(i + k, val);
+                const float o = ZF ? 0.0f : oc[k];
+                res[k] = pm[k] ? o + val : o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (ZF || zany(pm[k])) zrow_store<1>(ro, voff, k * orow, res[k]);
+        if (more && !ZF) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) oc[k] = on[k];
+        }
+    }
+    for (; i < end; i++) {
+        const zh_rsrc_t ro = zrow_rsrc(out, ostride, i);
+        float val = 0.0f;
+        const bool painted = slow(i, val);
+        float o = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
+        o = painted ? o + val : o;
+        if (ZF || zany(painted)) zrow_store<1>(ro, voff, 0, o);
+    }
+}
+
 // A frame-range kernel's replay over an input image: consume(x) for rows 0 .. count-1 of one voice column, in order.  Two
 // batches of 16 rows: one is consumed while the next is in flight (two NAMED arrays, ping-pong by two -- a rotation over an
 // array of arrays ended up in scratch memory and was slower than no overlap at all).
