@@ -99,6 +99,46 @@ def test_fuzz_nice(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(4))
+def test_fuzz_pmosc(ctx, oracle, seed):
+    """PMOscInstrument: random sub-spans, per-voice frequencies and release times (down to stages a few frames long, so that
+    chunks with a stage end sit between quiet ones and, with a shared note pattern, chunks in which every voice is inside a
+    stage), note on / off / retrigger; both launch forms (frame ranges for few voices, the lane-per-voice walk)."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(2600 + seed)
+    V = int(rng.choice([1, 63, 64, 66, 130, 200]))
+    rel = rng.choice([0.0004, 0.002, 0.05, 0.4], V).astype(np.float32) * rng.uniform(0.5, 1.5, V).astype(np.float32)
+    L = oracle.lib()
+    st = [oracle.PMOscInstrument() for _ in range(V)]
+    for v in range(V):
+        L.zo_pmosc_init(C.byref(st[v]), float(rel[v]))
+    m = mod.PMOscInstrument(V, util.dev(rel), ctx)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32); t2 = np.zeros(F, np.float32)
+    img = util.rng_buffers(seed + 350, V, F)
+    on = False
+    for k, (a, b, zf) in enumerate(_calls_long(rng, 7)):
+        freq = (_freqs(rng, V) * np.float32(0.5)).astype(np.float32)
+        if rng.random() < 0.2:
+            freq[int(rng.integers(V))] = np.float32(rng.choice([0.0, -220.0, 3.0e12, 1.0e5]))
+        nic = bool(rng.random() < 0.4)
+        on = (not on) if rng.random() < 0.5 else on
+        if nic:
+            on = True
+        ref = img.copy()
+        if zf:
+            ref[:, a:b] = 0.0
+        for v in range(V):
+            L.zo_pmosc_paint(C.byref(st[v]), a, b, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(t2), int(nic), SR, float(freq[v]), int(on))
+        out = util.to_image(img)
+        m.paint(zang.Span(a, b), [out], None, nic, m.Params(SR, util.dev(freq), on), zero_first=zf)
+        ctx.sync()
+        util.assert_bitexact(util.from_image(out), ref, f"pmosc seed {seed} call {k} V={V} span {(a, b)} zf={zf} on={on} nic={nic}")
+        img = ref
+    gs = m.state()
+    util.assert_bitexact(gs["carrier"]["t"].astype(np.float32), np.array([r.carrier.t for r in st], np.float32), "carrier t")
+    util.assert_bitexact(gs["modulator"]["t"].astype(np.float32), np.array([r.modulator.t for r in st], np.float32), "modulator t")
+
+
+@pytest.mark.parametrize("seed", range(4))
 def test_fuzz_noise_filter(ctx, oracle, seed):
     from zang_amd import modules as mod, zang
     rng = np.random.default_rng(3000 + seed)

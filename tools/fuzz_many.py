@@ -9,7 +9,7 @@ from oracle import pyoracle
 ctx = zang_amd.Context(0)
 n = int(sys.argv[1]); bad = 0
 for seed in range(5, 5 + n):
-    for fn in (fz.test_fuzz_pulseosc, fz.test_fuzz_nice, fz.test_fuzz_noise_filter, fz.test_fuzz_noise, fz.test_fuzz_sineosc, fz.test_fuzz_sampler,
+    for fn in (fz.test_fuzz_pulseosc, fz.test_fuzz_nice, fz.test_fuzz_pmosc, fz.test_fuzz_noise_filter, fz.test_fuzz_noise, fz.test_fuzz_sineosc, fz.test_fuzz_sampler,
                fz.test_fuzz_envelope, fz.test_fuzz_decimator_portamento, fz.test_fuzz_osc_control_images, fz.test_fuzz_filter_and_echoes):
         try:
             fn(ctx, pyoracle, seed)
