@@ -337,8 +337,7 @@ def test_nice_two_voices_per_lane_variant_is_bit_identical():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
                         "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
+    util.assert_rerun_green(r, 2)
 
 
 @pytest.mark.gpu
@@ -353,8 +352,7 @@ def test_noise_filter_single_wave_form_is_bit_identical():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
                         "noise_filter_fused_equals_unfused or noise_filter_few_voices_short_spans"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "12 passed" in r.stdout
+    util.assert_rerun_green(r, 12)
 
 
 @pytest.mark.gpu
@@ -369,8 +367,7 @@ def test_nice_single_wave_form_is_bit_identical():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
                         "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules or nice_few_voices_short_spans"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "6 passed" in r.stdout
+    util.assert_rerun_green(r, 6)
 
 
 @pytest.mark.parametrize("form", ["default", "three_waves", "one_wave"])

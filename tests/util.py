@@ -51,3 +51,14 @@ def rng_buffers(seed, voices, frames, lo=-1.0, hi=1.0):
 
 SPANS_ONE = [(0, 1024)]
 SPANS_THREE = [(0, 200), (200, 777), (777, 1024)]
+
+
+def assert_rerun_green(r, at_least):
+    """A child `pytest` run of the same file with a form switch in its environment: exit code 0, nothing failed or errored, and
+    at least `at_least` tests really ran (a floor, not a count -- the files grow; a hard-coded count went stale in round 3 and
+    turned the driver's `-x` run red)."""
+    import re
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= at_least, r.stdout[-2000:]
+    assert not re.search(r"\d+ (failed|error)", r.stdout), r.stdout[-2000:]
