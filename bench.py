@@ -40,6 +40,20 @@ HBM_STORE_GBS = 6200.0  # same guide: measured plain-store rate ("achievable" wr
 SR = 48000.0
 
 
+PATTERN = 48            # buffers of the note on/off pattern of the nice / nice_mix / script workloads
+
+
+PREFLIGHT_FAILED = 5    # exit code of `--preflight` when a check fails (distinct from a crash (1), a bad flag (2), no device (3), the p2p watchdog (4))
+
+
+def pattern_steps(workload, steps):
+    """Timed steps for `--steps steps`: the note-pattern workloads time whole patterns (the next multiple of 48), every other
+    workload exactly `steps`.  The line reports the steps really timed as `steps` and the flag's value as `steps_requested`."""
+    if workload in ("nice", "nice_mix", "script"):
+        return max(1, -(-steps // PATTERN)) * PATTERN
+    return steps
+
+
 SCRIPT_MODULE = os.environ.get("ZH_SCRIPT_MODULE", "Lead")    # any module of tests/golden/script_modules.txt with (freq, note_on) params
 
 
@@ -60,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--ring-mib", type=int, default=512, help="bytes of distinct output images to rotate through")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline sample length")
     ap.add_argument("--repeats", type=int, default=None, help="further K-step regions timed after the first (default: up to 30 when the region is short)")
+    ap.add_argument("--no-rehearsal", action="store_true", help="skip the untimed rehearsal regions before the timed one")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of one buffer")
     ap.add_argument("--no-config5", action="store_true", help="N=1: skip the extra config-5 shard measurement")
@@ -67,6 +82,11 @@ def parse(argv=None):
                     help="N>1: after the line is complete, also measure the direct-write exchange beside the RCCL one (opt-in: a stalled "
                          "peer mapping ends the run with exit code 4 after --p2p-timeout, the line printed first)")
     ap.add_argument("--p2p-timeout", type=float, default=180.0, help="N>1 with --p2p-compare: seconds the comparison may take")
+    ap.add_argument("--preflight", action="store_true",
+                    help="no timing: check the multi-GPU plumbing first -- `tests/cpp/comm_host N` (N rank processes form an RCCL "
+                         "communicator through the C ABI and sum a block) as a child process, then one HIP-IPC slot round trip per peer "
+                         "(zh_ipc_alloc / zh_ipc_open / peer store / zh_sum_slots); prints pass/fail per rank as one JSON line; exit code "
+                         "%d on any failure" % PREFLIGHT_FAILED)
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
     return ap.parse_args(argv)
@@ -124,6 +144,99 @@ def spawn_ranks(n, argv):
     if rc:
         sys.stderr.write(f"bench.py: a rank exited with code {rc}\n")
     return rc
+
+
+def comm_host_exe():
+    """tests/cpp/comm_host, built from tests/cpp/comm_host.c against the library beside it when missing or stale (gcc only)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "comm_host.c")
+    exe = os.path.join(ROOT, "tests", "cpp", "comm_host")
+    libso = os.path.join(ROOT, "zang_amd", "libzang_hip.so")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(libso)):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        subprocess.check_call(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src,
+                               "-L" + os.path.join(ROOT, "zang_amd"), "-lzang_hip", "-Wl,-rpath," + os.path.join(ROOT, "zang_amd"),
+                               "-L" + rocm + "/lib", "-Wl,-rpath," + rocm + "/lib", "-o", exe])
+    return exe
+
+
+def preflight_comm_host(n):
+    """`comm_host n` as a fresh child process (this process need not have touched a GPU): n rank processes, rank r on GPU r,
+    RCCL through the C ABI, all-reduce and reduce of the bench's [48][2][1024] block checked on every rank."""
+    import subprocess
+    try:
+        r = subprocess.run([comm_host_exe(), str(n)], capture_output=True, text=True, timeout=240,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        ok = r.returncode == 0 and r.stdout.strip().endswith("PASS")
+        return {"ranks": n, "ok": ok, "exit_code": r.returncode, "output": (r.stdout + r.stderr).strip()[-600:]}
+    except Exception as e:      # noqa: BLE001  (a hung rendezvous ends in TimeoutExpired: reported, not raised)
+        return {"ranks": n, "ok": False, "exit_code": None, "output": f"{type(e).__name__}: {e}"[:600]}
+
+
+def preflight_rank(args, world, rank, local_rank, emulate):
+    """The per-rank half of `--preflight`: gloo rendezvous, a context on this rank's GPU, one SlotExchange round trip (the root
+    allocates a slot per rank, every peer maps it with zh_ipc_open and stores a rank-dependent pattern into its slot through
+    the mapping, the root adds the slots in rank order), pass/fail gathered per rank.  Returns the process exit code."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rec = {"rank": rank, "device": None, "ok": False, "error": None}
+    comm_rec = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if rank == 0 and os.environ.get("ZH_PREFLIGHT_COMM_DONE") != "1":
+        # under torch.distributed.run there is no parent of ours: rank 0 starts comm_host before it touches a GPU itself
+        n = min(world, torch.cuda.device_count()) if emulate else world
+        comm_rec = preflight_comm_host(max(n, 1))
+    if world > 1:
+        dist.init_process_group("gloo")
+    try:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device")
+        dev = 0 if (world == 1 or emulate) else local_rank
+        rec["device"] = dev
+        if dev >= torch.cuda.device_count():
+            raise RuntimeError(f"needs GPU {dev}, this node shows {torch.cuda.device_count()}")
+        torch.cuda.set_device(dev)
+        import zang_amd
+        from zang_amd import abi, sharding
+        ctx = zang_amd.Context(dev)
+        rec["zh_comm_available"] = int(ctx.lib.zh_comm_available())
+        if world > 1:
+            n = 2 * args.frames
+            ex = sharding.SlotExchange(ctx, n, control_group=dist.group.WORLD)       # raises on EVERY rank if any rank failed
+            mine = (np.arange(n, dtype=np.float32) % 251) * (rank + 1)
+            abi.check(ctx.lib.zh_upload(ctx.handle, C.c_void_p(ex.slot().addr), mine.ctypes.data, n * 4), "zh_upload into the root's slot")
+            dst = torch.zeros(n, dtype=torch.float32, device=ctx.device) if rank == 0 else None
+            ex.finish(dst)
+            if rank == 0:
+                want = (np.arange(n, dtype=np.float32) % 251) * (world * (world + 1) // 2)
+                if not np.array_equal(dst.cpu().numpy(), want):
+                    raise RuntimeError("the rank-ordered sum of the slots is wrong")
+            ex.close()
+            rec["ipc"] = "root of the slot block" if rank == 0 else "zh_ipc_open + peer store: summed correctly by the root"
+        rec["ok"] = True
+    except Exception as e:      # noqa: BLE001
+        rec["error"] = f"{type(e).__name__}: {e}"[:300]
+    recs = [rec]
+    if world > 1:
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+    code = 0
+    if rank == 0:
+        ok = all(r["ok"] for r in recs) and (comm_rec is None or comm_rec["ok"])
+        line = {"preflight": {"ok": ok, "world": world, "ranks": recs}}
+        if comm_rec is not None:
+            line["preflight"]["comm_host"] = comm_rec
+        print(json.dumps(line), flush=True)
+        code = 0 if ok else PREFLIGHT_FAILED
+    if world > 1:
+        flag = [code]
+        dist.broadcast_object_list(flag, src=0)
+        code = flag[0]
+        dist.destroy_process_group()
+    return code
 
 
 class Workload:
@@ -220,10 +333,11 @@ class Workload:
         no remainder of the timed steps has to be launched one by one from Python (~2x slower per step at the
         16 MiB size).  (Any count works: the oscillators' double-buffered state is reconciled by zh_graph_launch.)"""
         if self.name in ("nice", "nice_mix", "script"):
-            # the note on/off pattern repeats every 48 buffers; a timed region shorter than that (the driver's 20 steps)
-            # is captured whole -- buffers 0..K-1 of the pattern (note on: attack, decay, sustain) -- so that it replays
-            # as one graph instead of K launches from Python
-            return steps if 2 <= steps < 48 else 48
+            # the note on/off pattern repeats every 48 buffers (note on for 0-23: attack, decay, sustain; off for 24-47:
+            # release, idle) and the release buffers cost ~20 % more than the sustain ones: the graph is always the WHOLE
+            # pattern, and a timed region is a whole number of patterns (pattern_steps) -- round 3 captured only buffers
+            # 0..K-1 for K < 48, which kept the release stage out of the driver's 20-step region (VERDICT r3 weak 8)
+            return PATTERN
         if os.environ.get("ZH_BENCH_G"):
             return int(os.environ["ZH_BENCH_G"])   # experiments
         g = max(self.nring, 2)
@@ -468,6 +582,53 @@ def parity_check(wl, ctx):
             "mismatching_samples": int((~same).sum()), "against": "oracle from the GPU's own carried state"}
 
 
+def parity_check_mix(wl, ctx, n=64):
+    """The same for the mixdown workload, which has no per-voice image: `n` voices on a stride through the
+    shard, two per launch -- zh_nice_paint_mix_stereo with ONE-HOT channel gains (left = voice a, right = voice b: every other
+    voice enters the sum as x * 0 = +-0, the chosen one as x * 1 = x, so the channel IS that voice's samples whatever the
+    summation order), every launch from the state the timed steps left behind (set_state), against the oracle started from
+    that state.  Values compared (a +-0 sum has no sign to keep); the run ends on the carried state again."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    if wl.name != "nice_mix" or wl.channels != 2:
+        return None
+    from oracle import pyoracle as po
+    L = po.lib()
+    V, F = wl.V, wl.F
+    idx = np.arange(0, V, max(1, V // n))[:n]
+    if len(idx) % 2:
+        idx = idx[:-1]
+    ctx.sync()
+    st = wl.m.state()
+    left = torch.zeros(F, dtype=torch.float32, device=ctx.device); right = torch.zeros_like(left)
+    P = wl.m.Params(SR, wl.freq, True)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32); ref = np.zeros(F, np.float32)
+    bad, checked, peak = 0, 0, 0.0
+    for a, b in idx.reshape(-1, 2):
+        gl = torch.zeros(V, dtype=torch.float32, device=ctx.device); gr = torch.zeros_like(gl)
+        gl[int(a)] = 1.0; gr[int(b)] = 1.0
+        wl.m.set_state(st)
+        wl.m.paint_mix_stereo(wl.span, left, right, gl, gr, True, P, zero_first=True)
+        ctx.sync()
+        for v, got in ((int(a), left.cpu().numpy()), (int(b), right.cpu().numpy())):
+            o = po.NiceInstrument()
+            L.zo_nice_init(C.byref(o), float(wl.color_h[v]))
+            o.osc.cnt = int(st["osc"]["cnt"][v])
+            o.flt.l, o.flt.b = float(st["flt"]["l"][v]), float(st["flt"]["b"][v])
+            e = st["env"]
+            o.env.state = int(e["state"][v])
+            o.env.painter.t, o.env.painter.last_value, o.env.painter.start = float(e["t"][v]), float(e["last_value"][v]), float(e["start"][v])
+            ref[:] = 0
+            L.zo_nice_paint(C.byref(o), 0, F, po.fptr(ref), po.fptr(t0), po.fptr(t1), 1, SR, float(wl.freq_h[v]), 1)
+            bad += int((got != ref).sum())
+            peak = max(peak, float(np.abs(ref).max()))
+            checked += 1
+    wl.m.set_state(st)
+    return {"checked_voices": checked, "frames": F, "bitexact": bad == 0, "mismatching_samples": bad, "peak_abs_sample": peak,
+            "against": "oracle from the GPU's own carried state; each voice isolated by one-hot channel gains of the fused mixdown kernel"}
+
+
 def traffic_record(args, V, F, kernel_hint=None):
     """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same workload
     (counters cannot be read from inside the process; tools/pmc_traffic.sh collects them: one pass per counter, FETCH_SIZE
@@ -556,7 +717,8 @@ def dry_run(args, world, rank):
     ok = bool((mixes == world * (world + 1) / 2).all())
     seen = torch.ones(1); dist.all_reduce(seen)
     if rank == 0:
-        print(json.dumps({"metric": "voice-samples/sec", "value": 0.0, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps,
+        print(json.dumps({"metric": "voice-samples/sec", "value": 0.0, "unit": "voice-samples/s", "n_gpus": world,
+                          "steps": pattern_steps(args.workload, args.steps), "steps_requested": args.steps,
                           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "none", "dry_run": "no GPU on this box: launcher + rendezvous + exchange step only, nothing painted",
                           "config": {"workload": f"{args.workload}: dry run", "parallelism": f"voices sharded x{world}"},
@@ -571,6 +733,18 @@ def main():
     argv = sys.argv[1:]
     args = parse(argv)
     env_world = os.environ.get("WORLD_SIZE")
+    if args.preflight and env_world is None and (args.gpus or 1) > 1:
+        # parent: comm_host first (its own process tree), then the rank processes for the IPC round trips
+        emu = os.environ.get("ZH_BENCH_EMULATE") == "1"
+        n = args.gpus
+        if emu:
+            import torch
+            n = max(1, min(n, torch.cuda.device_count()))        # counting devices does not initialise the GPU
+        rec = preflight_comm_host(n)
+        sys.stderr.write("bench.py --preflight: comm_host %d: %s\n" % (n, "PASS" if rec["ok"] else "FAIL " + rec["output"][-300:]))
+        os.environ["ZH_PREFLIGHT_COMM_DONE"] = "1"
+        rc = spawn_ranks(args.gpus, argv)
+        sys.exit(rc or (0 if rec["ok"] else PREFLIGHT_FAILED))
     if env_world is None and (args.gpus or 1) > 1:
         sys.exit(spawn_ranks(args.gpus, argv))       # parent: nothing below runs in it
     world = int(env_world or 1)
@@ -580,6 +754,8 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.preflight:
+        sys.exit(preflight_rank(args, world, rank, local_rank, os.environ.get("ZH_BENCH_EMULATE") == "1"))
     if args.workload is None:
         args.workload = "pulseosc" if world == 1 else "nice_mix"
     if args.voices is None:
@@ -640,6 +816,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # torch.cuda.synchronize() without its Python wrapper (lazy-init check + a device context manager around the same call)
+    _device_sync = getattr(torch._C, "_cuda_synchronize", None) or torch.cuda.synchronize
+
     def make_event():
         h = C.c_void_p()
         abi.check(lib.zh_event_create(ctx.handle, C.byref(h)), "zh_event_create")
@@ -679,6 +858,8 @@ def main():
                     wl.nsteps = 0               # the graph holds buffers 0..G-1 of the note pattern
                 wl.batch_rows = min(self.G, 48)
                 self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)])
+            # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
+            # refuses events recorded by graph nodes on this ROCm: "invalid resource handle", profiles/r04/probe_region.txt)
             self.ev0, self.ev1 = make_event(), make_event()
 
         def run_steps(self, n):
@@ -703,20 +884,38 @@ def main():
             torch.cuda.synchronize()
 
         def region(self, K):
-            torch.cuda.synchronize()
+            sync = _device_sync
+            sync()
             barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            sync()
+            one_launch = self.graph is not None and K == self.G and world == 1
+            rec, h, e0, e1 = lib.zh_event_record, ctx.handle, self.ev0, self.ev1
+            launch, gh = lib.zh_graph_launch, (self.graph.handle if self.graph is not None else None)
             # HIP events on the launch stream bracket exactly the K timed steps: device time per
             # launch = elapsed / K (includes the ~1 us inter-kernel boundaries, so it can only
             # under-state the kernel's own rate; profiles/ holds the rocprofv3 per-kernel average).
-            abi.check(lib.zh_event_record(ctx.handle, self.ev0), "zh_event_record")
-            self.run_steps(K)
-            abi.check(lib.zh_event_record(ctx.handle, self.ev1), "zh_event_record")
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
+            if one_launch:
+                # the driver's short region: K steps = one graph replay.  Nothing but the four calls between the two clock
+                # reads (their return codes are looked at after the clock stops): the interpreter's own work on the timed
+                # path was 4 us of a 100 us region (tools/probe_region.py, profiles/r04/probe_region.txt)
+                t0 = time.perf_counter()
+                r0 = rec(h, e0)
+                r1 = launch(h, gh)
+                r2 = rec(h, e1)
+                sync()
+                elapsed = time.perf_counter() - t0
+                for r, what in ((r0, "zh_event_record"), (r1, "zh_graph_launch"), (r2, "zh_event_record")):
+                    abi.check(r, what)
+            else:
+                t0 = time.perf_counter()
+                abi.check(rec(h, e0), "zh_event_record")
+                self.run_steps(K)
+                abi.check(rec(h, e1), "zh_event_record")
+                sync()
+                barrier()
+                if world > 1:
+                    sync()
+                elapsed = time.perf_counter() - t0
             ms = C.c_float()
             abi.check(lib.zh_event_elapsed_ms(self.ev0, self.ev1, C.byref(ms)), "zh_event_elapsed_ms")
             return max_over_ranks(elapsed), ms.value
@@ -760,36 +959,62 @@ def main():
                 "value_per_gpu": w.V * F * nsteps / wall,
                 "what": "zh_nice_paint_mix_stereo_batch: %d consecutive buffers per launch, state in registers between them, one second pass (same bits; no exchange)" % B}
 
-    K = args.steps
-    main_run = Runner(args.workload, V, K, exchange=args.exchange, slots=(args.exchange == "p2p" and world > 1 and args.workload == "nice_mix"))
+    K_req = args.steps
+    K = pattern_steps(args.workload, K_req)          # the note-pattern workloads time whole 48-buffer patterns
+    mixdown = args.workload == "nice_mix"
+    main_run = Runner(args.workload, V, K, exchange=args.exchange, slots=(args.exchange == "p2p" and world > 1 and mixdown))
     wl, G, graph = main_run.wl, main_run.G, main_run.graph
     main_run.warm(args.warmup)
+    # Untimed rehearsals of the timed region, same code path: the W warm-up steps of a 4 us kernel are 20 us of
+    # device work after seconds of set-up, and the first region then ran on a GPU and a host path still coming out of idle -- 7 %
+    # slower than the median of the repeats, 111 against 98 us after 200 ms of idle in tools/probe_region.py.  At least 3 regions
+    # and 25 ms; nothing from them enters the line except their count.
+    def rehearse(run, k):
+        if args.no_rehearsal:
+            return 0
+        e3 = sum(run.region(k)[0] for _ in range(3))               # max over ranks: the same number on every rank,
+        n = 3 + min(997, max(0, int((0.025 - e3) / (e3 / 3))))      # so every rank runs the same count of regions
+        for _ in range(n - 3):
+            run.region(k)
+        return n
+    rehearsals = rehearse(main_run, K)
     elapsed, ev_ms = main_run.region(K)              # THE timed region of the contract: exactly K steps
     step_ms_events = ev_ms / K
 
     # Further regions of exactly K steps, each bracketed the same way: a short region (the driver's 20 steps of a
     # 4 us kernel = 0.1 ms) is dominated by the launch ramp and the synchronize, and one sample of it is noisy.
+    # With several GPUs every repeat is a PAIR -- the region with the exchange, then the same K steps without it -- so that
+    # `single_gpu_shard` and `scaling_factor` are medians of interleaved regions, never one sample each.
+    import statistics
+    paired = world > 1 and mixdown
     R = args.repeats if args.repeats is not None else (min(30, max(0, int(0.5 / max(elapsed, 1e-4)))) if elapsed < 0.1 else 0)
+    if paired:
+        R = max(R, 5)
     reps = None
+    walls, evs, walls_nox = [], [], []
+    for _ in range(R):
+        e, m = main_run.region(K)
+        walls.append(e / K * 1e3); evs.append(m / K)
+        if paired:
+            main_run.with_exchange = False
+            e, _ = main_run.region(K)
+            main_run.with_exchange = True
+            walls_nox.append(e / K * 1e3)
+
+    def spread(xs):
+        return {"median": statistics.median(xs), "min": min(xs), "max": max(xs)}
     if R > 0:
-        import statistics
-        walls, evs = [], []
-        for _ in range(R):
-            e, m = main_run.region(K)
-            walls.append(e / K * 1e3); evs.append(m / K)
-        reps = {"regions": R, "steps_per_region": K,
-                "ms_per_step_wall": {"median": statistics.median(walls), "min": min(walls), "max": max(walls)},
-                "ms_per_step_hip_events": {"median": statistics.median(evs), "min": min(evs), "max": max(evs)},
+        reps = {"regions": R, "steps_per_region": K, "ms_per_step_wall": spread(walls), "ms_per_step_hip_events": spread(evs),
+                "ms_per_step_wall_all": [round(w, 6) for w in walls],
                 "note": "`value`, `ms_per_step` and `roofline` come from the first region only"}
 
     traffic, traffic_src = traffic_record(args, V, F, wl.kernel)
     total_units = world * V * F * K
     value = total_units / elapsed
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
-    mixdown = args.workload == "nice_mix"
     out = {
         "metric": "voice-samples/sec", "value": value, "unit": "voice-samples/s",
-        "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "n_gpus": world, "steps": K, "warmup": args.warmup, "rehearsal_regions": rehearsals,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {V} voices/GPU x {F} frames, " +
@@ -804,6 +1029,11 @@ def main():
                      "rocprofv3_kernel_average": rocprof_record(args, V)},
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }
+    if K != K_req:
+        out["steps_requested"] = K_req
+        out["config"]["pattern"] = (f"--steps {K_req} -> {K} timed steps: the note pattern is {PATTERN} buffers (note on 0-23: attack, decay, "
+                                    f"sustain; off 24-47: release, idle) and a timed region is whole patterns, buffers 0..{PATTERN - 1} in order; "
+                                    "`steps`, `ms_per_step` and `value` are of the steps really timed")
     if mixdown:
         out["config"]["channels"] = args.channels
         out["roofline"]["note"] = ("the mixdown workload writes 4 KiB per channel per buffer: `achieved` is the EQUIVALENT write rate "
@@ -815,16 +1045,27 @@ def main():
         # ---- the exchange step on its own, and the same shard without it (scaling factor) ----
         rows = wl.batch_rows
         nbytes = wl.mixes[:rows].numel() * 4
-        n_ex = 20
+        n_ex = 24
 
         def time_exchange(fn):
-            fn(); torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            """`n_ex` samples of one exchange each (stream drained and ranks aligned before every sample, slowest rank per
+            sample): median / min / max in microseconds -- a single figure hid a first-call outlier in round 3."""
+            fn(); torch.cuda.synchronize()
+            per = []
             for _ in range(n_ex):
+                torch.cuda.synchronize(); barrier()
+                t0 = time.perf_counter()
                 fn()
-            torch.cuda.synchronize()
-            return max_over_ranks((time.perf_counter() - t0) / n_ex) * 1e6
-        reduce_us = time_exchange(wl.exchange)
+                torch.cuda.synchronize()
+                per.append(time.perf_counter() - t0)
+            if world > 1:
+                t = torch.tensor(per, dtype=torch.float64, device="cpu" if emulate else "cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                per = t.tolist()
+            per = [x * 1e6 for x in per]
+            return {"median": statistics.median(per), "min": min(per), "max": max(per), "samples": n_ex}
+        reduce_stat = time_exchange(wl.exchange)
+        reduce_us = reduce_stat["median"]
         seen = torch.ones(1, device="cpu" if emulate else "cuda"); dist.all_reduce(seen)
         if wl.slots is not None:
             backend, kind = "host barriers + HIP IPC", "direct stores into the root's slots + rank-ordered sum (zh_sum_slots), host barriers"
@@ -834,30 +1075,36 @@ def main():
         else:
             backend, kind = "torch.distributed " + dist.get_backend(), "all_reduce(sum)"
         out["collective"] = {"backend": backend, "kind": kind, "world_size_seen": int(seen.item()),
-                             "bytes": nbytes, "per": f"{rows}-buffer batch", "reduce_us": reduce_us, "in_timed_region": True,
-                             "reduce_us_per_buffer": reduce_us / rows}
+                             "bytes": nbytes, "per": f"{rows}-buffer batch", "reduce_us": reduce_us, "reduce_us_spread": reduce_stat,
+                             "in_timed_region": True, "reduce_us_per_buffer": reduce_us / rows}
         if comm_note:
             out["collective"]["note"] = comm_note
         if wl.slots is None:
             # the same sum as ONE COLLECTIVE PER BUFFER (4-8 KiB each, the reference's per-buffer mix) -- which
             # granularity is latency-bound: `rows` small collectives against one of rows x the bytes
-            per_buf_us = time_exchange(wl.exchange_per_buffer) / rows
+            pb = time_exchange(wl.exchange_per_buffer)
+            per_buf_us = pb["median"] / rows
             out["collective"]["per_buffer_form"] = {"bytes": nbytes // rows, "reduce_us": per_buf_us,
+                                                    "reduce_us_spread": {k: (v / rows if k != "samples" else v) for k, v in pb.items()},
                                                     "x_batch_form_per_buffer": per_buf_us / (reduce_us / rows),
                                                     "what": f"one all-reduce per buffer, {rows} back to back on the launch stream, per collective"}
             if wl.comm is not None:
                 # and the torch.distributed form of the batch collective beside the library's
                 keep = wl.comm
                 wl.comm = None
-                out["collective"]["torch_distributed_form_reduce_us"] = time_exchange(wl.exchange)
+                out["collective"]["torch_distributed_form_reduce_us"] = time_exchange(wl.exchange)["median"]
                 wl.comm = keep
-        main_run.with_exchange = False
-        e1, _ = main_run.region(K)
-        main_run.with_exchange = True
-        single = V * F * K / e1
-        out["single_gpu_shard"] = {"value": single, "ms_per_step": e1 / K * 1e3,
-                                   "what": "the same K steps on every rank without the exchange (slowest rank)"}
-        out["scaling_factor"] = value / single
+        # medians of the R interleaved region pairs above (with the exchange / without it), slowest rank per region
+        med_with, med_nox = statistics.median(walls), statistics.median(walls_nox)
+        single = V * F / (med_nox * 1e-3)
+        out["single_gpu_shard"] = {"value": single, "ms_per_step": med_nox, "ms_per_step_spread": spread(walls_nox), "regions": R,
+                                   "what": "the same K steps on every rank without the exchange (slowest rank), median of the regions "
+                                           "interleaved with the `repeats` regions"}
+        ratios = sorted(world * b / a for a, b in zip(walls, walls_nox))
+        out["scaling_factor"] = world * med_nox / med_with
+        out["scaling_factor_spread"] = {"min": ratios[0], "max": ratios[-1], "pairs": R,
+                                        "what": "world x (ms without exchange) / (ms with exchange), pair by pair; `scaling_factor` uses the two medians"}
+        out["value_median_of_repeats"] = world * V * F / (med_with * 1e-3)
         out["realtime_voices_48k"] = value / SR
         if args.p2p_compare and wl.slots is None:
             # the alternative SURVEY.md 8e asks to measure beside the collective.  It is the comparison, not the
@@ -931,17 +1178,24 @@ def main():
         # the 1-GPU shard of config 5 (what every rank of the N>1 run renders), for the scaling ratio
         c5 = Runner("nice_mix", 131072, 96)
         c5.warm(48)
-        e5, m5 = c5.region(96)
+        c5_rehearsals = rehearse(c5, 96)
+        e5s = [c5.region(96) for _ in range(5)]
+        e5, m5 = e5s[0]
         out["config5_shard"] = {"workload": f"nice_mix: 131072 voices x {F} frames, {args.channels}-channel mixdown, no exchange (one GPU)",
                                 "value": 131072 * F * 96 / e5, "ms_per_step": e5 / 96 * 1e3, "steps": 96, "launch_ms_hip_events": m5 / 96,
+                                "pattern": "two whole 48-buffer note patterns per region (attack, decay, sustain, release, idle)",
+                                "ms_per_step_5_regions": spread([e / 96 * 1e3 for e, _ in e5s]), "rehearsal_regions": c5_rehearsals,
                                 "realtime_voices_48k": 131072 * F * 96 / e5 / SR}
         bt = time_batched(c5, 96)
         if bt:
             out["config5_shard"]["batched_launches"] = bt
+        if not args.no_parity:
+            out["config5_shard"]["parity"] = parity_check_mix(c5.wl, ctx)
         c5.close()
 
-    if rank == 0 and world == 1 and not args.no_parity:
-        out["parity"] = parity_check(wl, ctx)
+    if rank == 0 and not args.no_parity and (world == 1 or mixdown):
+        # (N > 1: rank 0's shard of the mixdown workload; local launches only, the other ranks wait at the last barrier)
+        out["parity"] = parity_check_mix(wl, ctx) if mixdown else parity_check(wl, ctx)
     if rank == 0 and world == 1 and not args.no_cpu:
         cb = cpu_baseline(args, wl)
         if cb:

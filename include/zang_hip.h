@@ -182,7 +182,14 @@ ZH_API int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_
  * `mix` is a device float[n] of this rank's GPU (e.g. [buffers][channels][frames]); the sum order is RCCL's (ring /
  * tree by size), so unlike zh_sum_slots the bits may differ between world sizes.  Calls on one communicator must be
  * issued in the same order on every rank.  The collectives may be recorded into a graph (zh_graph_begin_capture ...: RCCL
- * supports stream capture), e.g. one per buffer next to the mixdown paints; creating / destroying a communicator may not.  zh_comm_available() = 1 when librccl and its symbols were found. */
+ * supports stream capture), e.g. one per buffer next to the mixdown paints; creating / destroying a communicator may not.  zh_comm_available() = 1 when librccl and its symbols were found.
+ * ALL OR NONE: zh_comm_create is a rendezvous with no timeout -- the ranks that reach RCCL's bootstrap wait there until all
+ * `world` of them have.  It can return early on ONE rank without entering the bootstrap (ZH_ERR_UNSUPPORTED during a graph
+ * capture, ZH_ERR_INVALID for bad arguments / out of memory, ZH_ERR_COMM when librccl is missing), and the others would then wait
+ * for ever.  The host must therefore agree over its own channel BEFORE calling it that every rank (a) sees zh_comm_available()
+ * == 1, (b) is not capturing and (c) got the id -- zang_amd.sharding.Comm does exactly that with a MIN all-reduce of the
+ * flags; tests/cpp/comm_host.c relies on pipe EOF (a rank that dies closes its ends, the parent stops handing out the id, the
+ * waiting ranks read EOF and leave) -- and should run the first create under a watchdog of its own (`bench.py --preflight`). */
 enum { ZH_COMM_ID_BYTES = 128 };
 typedef struct zh_comm zh_comm;
 ZH_API int  zh_comm_available(void);

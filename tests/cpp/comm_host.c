@@ -4,6 +4,7 @@
  * "any host channel" of include/zang_hip.h), every rank fills a [48][2][1024] block with values that depend on its
  * rank, runs zh_allreduce_mix and zh_reduce_mix on its context's stream and checks the sums (small integers: exact
  * in any order).  Exit code 0 and "PASS" when every rank agrees. */
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -73,6 +74,7 @@ static int run_rank(int rank, int world, int id_in, int id_out) {
 int main(int argc, char **argv) {
     const int world = argc > 1 ? atoi(argv[1]) : 1;
     if (world < 1 || world > 64) { fprintf(stderr, "usage: comm_host [ranks]\n"); return 2; }
+    signal(SIGPIPE, SIG_IGN);                         /* a dead rank's pipe is an error return, not the parent's death */
     int up[2], down[64][2];
     pid_t pid[64];
     if (pipe(up)) return 2;
@@ -80,11 +82,21 @@ int main(int argc, char **argv) {
     for (int r = 0; r < world; r++) {
         pid[r] = fork();
         if (pid[r] < 0) return 2;
-        if (pid[r] == 0) _exit(run_rank(r, world, r ? down[r][0] : -1, up[1]));
+        if (pid[r] == 0) {
+            /* a rank keeps only its own ends: the id pipe's write end lives in rank 0 alone, so that a rank 0 that dies before
+             * writing the id is an EOF for the parent, and a parent that gives up is an EOF for the waiting ranks */
+            close(up[0]);
+            if (r != 0) close(up[1]);
+            for (int q = 1; q < world; q++) { close(down[q][1]); if (q != r) close(down[q][0]); }
+            _exit(run_rank(r, world, r ? down[r][0] : -1, r ? -1 : up[1]));
+        }
     }
+    close(up[1]);                                     /*  the parent holds no write end of `up`, no read end of `down` */
+    for (int r = 1; r < world; r++) close(down[r][0]);
     uint8_t id[ZH_COMM_ID_BYTES];
     int rc = read_all(up[0], id, sizeof id) ? 1 : 0;
     for (int r = 1; r < world && !rc; r++) rc |= write_all(down[r][1], id, sizeof id) ? 1 : 0;
+    for (int r = 1; r < world; r++) close(down[r][1]);            /* no id to hand on (rc != 0): the ranks read EOF and leave */
     for (int r = 0; r < world; r++) {
         int st = 0;
         waitpid(pid[r], &st, 0);

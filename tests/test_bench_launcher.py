@@ -44,7 +44,7 @@ def test_gpus_flag_spawns_ranks_dry_run():
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     line = _last_json(r.stdout)
-    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["n_gpus"] == 2 and line["steps"] == 48 and line["steps_requested"] == 20 and line["warmup"] == 5   # whole note patterns
     assert line["collective"]["world_size_seen"] == 2 and line["collective"]["sum_correct"] is True
     assert line["value"] == 0.0 and "dry_run" in line            # nothing was painted and the line says so
     assert line["config"]["workload"].startswith("nice_mix")     # N > 1 defaults to config 5
@@ -93,7 +93,7 @@ def test_single_rank_without_gpu_fails_loudly():
 @pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 def test_two_emulated_ranks_on_one_gpu_run_the_whole_multi_gpu_path(exchange):
     """GPU box (one GPU): `ZH_BENCH_EMULATE=1 bench.py --gpus 2` = two rank processes on device 0 with the driver's step
-    counts -- the N > 1 code path end to end (launcher, rendezvous, 20-step region captured as ONE graph, the exchange inside
+    counts -- the N > 1 code path end to end (launcher, rendezvous, the 48-buffer pattern captured as ONE graph, the exchange inside
     the timed region, per-batch and per-buffer exchange timings, the shard without exchange, the scaling factor), gloo
     standing in for RCCL (two ranks on one device cannot form an RCCL communicator: tests/test_cpp_host.py) and, for
     `--exchange p2p`, the HIP-IPC slot exchange between the two processes."""
@@ -101,10 +101,13 @@ def test_two_emulated_ranks_on_one_gpu_run_the_whole_multi_gpu_path(exchange):
                         "--repeats", "2"], capture_output=True, text=True, timeout=540, env=_env(ZH_BENCH_EMULATE="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["config"]["launch"] == "hipGraph x20 steps"
+    # `--steps 20` on the note-pattern workload = one whole 48-buffer pattern (the release stage is inside the timed region)
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["steps_requested"] == 20 and d["config"]["launch"] == "hipGraph x48 steps"
+    assert "pattern" in d["config"] and d["rehearsal_regions"] >= 3
     assert d["config"]["total_voices"] == 16384 and d["value"] > 0 and d["scaling"] == "weak"
     c = d["collective"]
-    assert c["world_size_seen"] == 2 and c["in_timed_region"] and c["per"] == "20-buffer batch" and c["bytes"] == 20 * 2 * 1024 * 4
+    assert c["world_size_seen"] == 2 and c["in_timed_region"] and c["per"] == "48-buffer batch" and c["bytes"] == 48 * 2 * 1024 * 4
+    assert c["reduce_us_spread"]["samples"] >= 20 and c["reduce_us_spread"]["min"] <= c["reduce_us"] <= c["reduce_us_spread"]["max"]
     if exchange == "rccl":
         assert "gloo" in c["backend"] and "ZH_BENCH_EMULATE" in c["note"]
         assert c["per_buffer_form"]["bytes"] == 2 * 1024 * 4 and c["per_buffer_form"]["reduce_us"] > 0
@@ -113,4 +116,38 @@ def test_two_emulated_ranks_on_one_gpu_run_the_whole_multi_gpu_path(exchange):
     # structure only: a wall-clock ratio of two ranks time-slicing one device is not a parity fact
     import math
     assert d["single_gpu_shard"]["value"] > 0 and math.isfinite(d["scaling_factor"]) and d["scaling_factor"] > 0
+    assert d["single_gpu_shard"]["regions"] >= 5 and d["scaling_factor_spread"]["pairs"] >= 5          # medians, not one sample each
+    assert d["parity"]["bitexact"] is True and d["parity"]["checked_voices"] == 64
     assert d["build"]["zh_version"].startswith("zang_hip")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_preflight_two_emulated_ranks():
+    """`bench.py --gpus 2 --preflight` on the one GPU of the box: comm_host as a child process (ONE rank here: RCCL refuses two
+    ranks on one device), then two rank processes with one HIP-IPC slot round trip per peer; one JSON line, exit code 0."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--preflight"], capture_output=True, text=True, timeout=540, env=_env(ZH_BENCH_EMULATE="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "comm_host 1: PASS" in r.stderr
+    d = _last_json(r.stdout)["preflight"]
+    assert d["ok"] is True and d["world"] == 2 and [x["ok"] for x in d["ranks"]] == [True, True]
+    assert "zh_ipc_open" in d["ranks"][1]["ipc"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_preflight_one_rank():
+    r = subprocess.run([sys.executable, BENCH, "--preflight"], capture_output=True, text=True, timeout=540, env=_env())
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _last_json(r.stdout)["preflight"]
+    assert d["ok"] is True and d["comm_host"]["ok"] is True and d["comm_host"]["ranks"] == 1
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(_gpu_here(), reason="needs a box without a GPU")
+def test_preflight_fails_with_its_own_exit_code_without_a_gpu():
+    """No GPU here: comm_host's ranks cannot create a context, the rank's own check finds no device -> one line, exit code 5."""
+    r = subprocess.run([sys.executable, BENCH, "--preflight"], capture_output=True, text=True, timeout=280, env=_env())
+    assert r.returncode == 5, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _last_json(r.stdout)["preflight"]
+    assert d["ok"] is False and d["ranks"][0]["ok"] is False and "no HIP device" in d["ranks"][0]["error"]

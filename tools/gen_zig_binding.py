@@ -52,7 +52,9 @@ MODULES = [
 HOST_MODULES = ["sineosc", "pulseosc", "trisawosc", "noise", "envelope", "gate", "filter", "sampler", "decimator", "distortion"]
 # pointer parameters that address MANY elements (everything else of struct type points at one)
 MANY_NAMES = {"outputs", "temps", "host", "filter", "impulses"}
-MANY_SPECIAL = {("zh_script_module_paint", "params"), ("zh_polyphony_dispatcher_dispatch", "out")}
+MANY_SPECIAL = {("zh_script_module_paint", "params"), ("zh_polyphony_dispatcher_dispatch", "out"),
+                # the batch call reads n_buffers elements of each
+                ("zh_nice_paint_mix_stereo_batch", "note_id_changed"), ("zh_nice_paint_mix_stereo_batch", "params")}
 # scalar pointer parameters that are a single out value, not an array
 ONE_SCALAR = {"ms", "state_words", "noise_fields", "n_params", "num_temps", "code_size_out"}
 
