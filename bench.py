@@ -87,6 +87,9 @@ def parse(argv=None):
                          "communicator through the C ABI and sum a block) as a child process, then one HIP-IPC slot round trip per peer "
                          "(zh_ipc_alloc / zh_ipc_open / peer store / zh_sum_slots); prints pass/fail per rank as one JSON line; exit code "
                          "%d on any failure" % PREFLIGHT_FAILED)
+    ap.add_argument("--tolerant", action="store_true",
+                    help="noise_filter / noise_filter_fused: paint with ZH_PAINT_TOLERANT (opt-in time-parallel Filter forms, 1e-5 of the "
+                         "signal's peak instead of bits; csrc/filter_tp.hip.h); the line says so in config.tolerant")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
     return ap.parse_args(argv)
@@ -242,9 +245,10 @@ def preflight_rank(args, world, rank, local_rank, emulate):
 class Workload:
     """Builds the module(s), resident params and the per-step callable for one rank."""
 
-    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None, channels=1, exchange="rccl"):
+    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None, channels=1, exchange="rccl", tolerant=False):
         import torch
         self.world = world
+        self.tolerant = bool(tolerant)
         self.channels, self.exchange_kind = channels, exchange
         self.slots = None
         self.comm = None                # sharding.Comm (the library's RCCL communicator) when --exchange rccl
@@ -277,7 +281,7 @@ class Workload:
             self.res = torch.from_numpy((0.9 * u3)).to(dev)
             self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.temp = ctx.image(F, V, pad=pad)
-            self.kernel = "k_filter"
+            self.kernel = "k_filter_tp" if (self.tolerant and V <= 16384) else "k_filter"
             self.step = self._step_noise_filter
         elif name == "noise_filter_fused":
             self.m = mod.NoiseFilter(V, ctx, first_seed=first_voice)
@@ -287,6 +291,8 @@ class Workload:
             self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
             self.kernel = "k_noise_filter_ring" if V <= 16384 else ("k_noise_filter_pc" if V <= 65536 else "k_noise_filter")     # the library's choice by voice count
+            if self.tolerant and V <= 16384:
+                self.kernel = "k_nf_tp_b"
             self.step = self._step_noise_filter_fused
         elif name == "script":
             # a zangscript module compiled to ONE fused kernel at start-up (hiprtc): `Lead` of the repo's test
@@ -366,14 +372,14 @@ class Workload:
         mod_n.paint(self.span, [self.temp], [], False, mod_n.Params(mod_n.white), zero_first=True)
         mod_f.paint(self.span, [self._next()], [], False,
                     mod_f.Params(self.temp, mod_f.low_pass, zang.constant(self.cutoff), zang.constant(self.res)),
-                    zero_first=True)
+                    zero_first=True, tolerant=self.tolerant)
 
     @staticmethod
     def m_white():
         return 0                                # Noise.Color.white
 
     def _step_noise_filter_fused(self):
-        self.m.paint(self.span, [self._next()], None, False, self.params, zero_first=True)
+        self.m.paint(self.span, [self._next()], None, False, self.params, zero_first=True, tolerant=self.tolerant)
 
     def _note_on(self):
         # config 5: note on for buffers 0-23, then off (attack -> decay -> sustain -> release), repeating
@@ -838,7 +844,7 @@ def main():
 
         def __init__(self, name, voices, steps, exchange="rccl", slots=False):
             self.wl = Workload(name, ctx, voices, F, first_voice=rank * voices, ring_bytes=args.ring_mib << 20, world=world,
-                               pad=args.pad_voices, channels=args.channels, exchange=exchange)
+                               pad=args.pad_voices, channels=args.channels, exchange=exchange, tolerant=args.tolerant)
             wl = self.wl
             wl.comm = comm if exchange == "rccl" else None
             self.with_exchange = True
@@ -1029,6 +1035,8 @@ def main():
                      "rocprofv3_kernel_average": rocprof_record(args, V)},
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }
+    if args.tolerant:
+        out["config"]["tolerant"] = "ZH_PAINT_TOLERANT: the Filter as chunks at once, samples within 1e-5 of the voice's peak (not bit-exact)"
     if K != K_req:
         out["steps_requested"] = K_req
         out["config"]["pattern"] = (f"--steps {K_req} -> {K} timed steps: the note pattern is {PATTERN} buffers (note on 0-23: attack, decay, "

@@ -47,14 +47,23 @@ enum { ZH_OK = 0, ZH_ERR_INVALID = -1, ZH_ERR_UNSUPPORTED = -2, ZH_ERR_NO_DEVICE
 enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference contract) */
        ZH_PAINT_ZERO_FIRST = 1,  /* zang.zero(span,out) then paint, in one kernel (basics.zig:12) */
        /* (2 = ZH_MIX_SEQUENTIAL, a zh_mixdown_voices flag) */
-       ZH_PAINT_PARAMS_UNCHANGED = 4
+       ZH_PAINT_PARAMS_UNCHANGED = 4,
+       ZH_PAINT_TOLERANT = 8
        /* The caller states that `params` -- scalars AND the contents of every per-voice array -- are what this module's
         * previous paint call was given.  The reference recomputes a paint's per-voice constants on every call
         * (e.g. PulseOsc.zig:87-95); a module may instead reuse the ones that call left behind.  Honoured by the
         * constant-frequency PulseOsc / TriSawOsc paints, ignored elsewhere; results are bit-identical either way.
         * A paint recorded into a graph with this flag uses the constants the module held when it was RECORDED (those of
         * the last unflagged eager paint before the capture): from then on the module stores no new constants -- later
-        * unflagged paints compute theirs without keeping them, later flagged paints take the computing form. */ };
+        * unflagged paints compute theirs without keeping them, later flagged paints take the computing form.
+        *
+        * ZH_PAINT_TOLERANT (opt-in): the caller accepts results within 1e-5 of the signal's peak instead of the reference's bits
+        * (north_star: "1e-5 relative f32", bits only for Gate and Decimator).  Honoured by zh_filter_paint and
+        * zh_noise_filter_paint (white noise) with constant cutoff and resonance at up to 16,384 voices, where the span is then
+        * filtered as 8-32 frame chunks at once (csrc/filter_tp.hip.h: zero-state responses, a 2 x 2 transition power in f64,
+        * then the reference's own recurrence per chunk; measured error <= 2.6e-6 of the voice's peak, 2-5 x faster); ignored
+        * elsewhere (every other form stays bit-exact, and so does a tolerant paint's first chunk).  The noise samples of the
+        * fused voice and every module state's MEANING are unchanged; the filter state after the span carries the same error. */ };
 
 typedef struct zh_ctx zh_ctx;
 

@@ -62,3 +62,33 @@ def assert_rerun_green(r, at_least):
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= at_least, r.stdout[-2000:]
     assert not re.search(r"\d+ (failed|error)", r.stdout), r.stdout[-2000:]
+
+
+def peak_relative_error(gpu, ref, s=None, e=None, scale_extra=None):
+    """The tolerant forms' metric (csrc/filter_tp.hip.h): per voice (row), max |gpu - ref| over frames [s, e) divided by the
+    voice's peak |ref| over the same frames -- "1e-5 relative" to the signal rather than to each sample (a per-sample
+    relative error is unbounded at a zero crossing).  Samples where both are non-finite count as equal; a finite / non-finite
+    disagreement is returned separately.  `scale_extra` (per voice): a further magnitude the voice's scale may not be below --
+    the filter's state: a low-pass settled on silence paints l ~ 3e-9 out of a state b ~ 4e-5 (the dc offset over the cutoff),
+    and its rounding is that of the state it is computed from.  Returns (per-voice ratios, disagreements, fraction of samples
+    inside assert_close's per-sample metric)."""
+    g = np.asarray(gpu, dtype=np.float64)[:, s:e]; r = np.asarray(ref, dtype=np.float64)[:, s:e]
+    with np.errstate(invalid="ignore", over="ignore"):
+        fin = np.isfinite(g) & np.isfinite(r)
+        both_bad = ~np.isfinite(g) & ~np.isfinite(r)
+        err = np.where(fin, np.abs(g - r), 0.0)
+        peak = np.max(np.where(np.isfinite(r), np.abs(r), 0.0), axis=1)
+        if scale_extra is not None:
+            peak = np.maximum(peak, np.where(np.isfinite(scale_extra), np.abs(scale_extra), 0.0))
+        ratio = err.max(axis=1) / np.maximum(peak, 1e-300)
+        ratio = np.where(err.max(axis=1) == 0, 0.0, ratio)
+        inside = (err <= RTOL * np.maximum(np.abs(np.where(fin, r, 0.0)), FLOOR)) | both_bad
+    return ratio, int((~fin & ~both_bad).sum()), float(inside.mean()) if inside.size else 1.0
+
+
+def assert_peak_close(gpu, ref, what="", rtol=RTOL, s=None, e=None, scale_extra=None):
+    ratio, disagree, _ = peak_relative_error(gpu, ref, s, e, scale_extra)
+    assert disagree == 0, f"{what}: {disagree} samples finite on one side only"
+    worst = int(np.argmax(ratio))
+    assert ratio[worst] <= rtol, f"{what}: voice {worst} is off by {ratio[worst]:.3e} of its peak (allowed {rtol:g})"
+    return float(ratio[worst])

@@ -16,6 +16,7 @@ ZH_ERR_COMM, ZH_ERR_RCCL_BASE = -4, -100
 COMM_ID_BYTES = 128
 PAINT_ADD, PAINT_ZERO_FIRST = 0, 1
 PAINT_PARAMS_UNCHANGED = 4
+PAINT_TOLERANT = 8
 MIX_SEQUENTIAL = 2
 AUDIO_SIGNED8, AUDIO_SIGNED16_LSB = 0, 1
 COB_CONSTANT, COB_BUFFER = 0, 1

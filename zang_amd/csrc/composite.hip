@@ -14,6 +14,8 @@
 #include "envelope.hip.h"
 #include "voices.hip.h"
 #include "noise_jump.hip.h"
+#define ZH_FILTER_TP_NOISE 1
+#include "filter_tp.hip.h"
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -1090,6 +1092,8 @@ __global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP
 struct zh_noise_filter {
     zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *nb; /* [7][n] */ float *l, *b;
     uint32_t *err;               // k_noise_filter_ring: a ring wait ran into its bound (reported by get_state)
+    // ZH_PAINT_TOLERANT (filter_tp.hip.h): scratch of the two-pass form, allocated by the first tolerant paint outside a capture
+    uint64_t *tp_cs; float2 *tp_e; uint32_t *tp_flag; uint32_t tp_serial;
 };
 
 __global__ void k_nf_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, uint32_t n, uint64_t first_seed) {
@@ -1506,6 +1510,7 @@ static void nf_free(zh_noise_filter *m) {
     for (auto &x : m->s) (void)hipFree(x);
     (void)hipFree(m->nb); (void)hipFree(m->l); (void)hipFree(m->b);
     (void)hipFree(m->err);
+    (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag);
 }
 
 __global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
@@ -1843,6 +1848,39 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     case ZH_FILTER_HIGH_PASS: h_mul = 1.0f; break;
     case ZH_FILTER_NOTCH: l_mul = 1.0f; h_mul = 1.0f; break;
     default: l_mul = 1.0f; b_mul = 1.0f; h_mul = 1.0f; break;
+    }
+    // ZH_PAINT_TOLERANT, white noise, few voices: the span as 32..128-frame chunks at once, two passes (filter_tp.hip.h).  Pieces
+    // of <= 32 chunks; L (a multiple of 32, the jump tables' step) by voice count: ~2,048 waves in flight.
+    if ((flags & ZH_PAINT_TOLERANT) && !pink && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
+        const uint32_t Cw = zh_tp_chunks(m->n, "ZH_NF_TP_MAX", 1024);                  // chunks wanted for a 1,024-frame buffer
+        const uint4 *tables = Cw >= 2 ? zh_noise_jump_tables(m->ctx) : nullptr;
+        if (tables && !m->tp_cs && !m->ctx->capturing) {
+            int arc = dev_alloc(&m->tp_cs, (size_t)kNfTpMaxChunks * 4 * m->n);
+            if (!arc) arc = dev_alloc(&m->tp_e, (size_t)(kNfTpMaxChunks + 1) * m->n);
+            if (!arc) arc = dev_alloc(&m->tp_flag, m->n);
+            if (!arc) arc = (int)hipMemsetAsync(m->tp_flag, 0, (size_t)m->n * 4, st);
+            if (arc) { (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; (void)hipGetLastError(); }
+        }
+        if (tables && m->tp_cs) {
+            const uint32_t L = 32u * max(1u, 32u / Cw);                                 // a multiple of 32 draws: the jump tables' step
+            NfTpArgs a;
+            for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
+            a.l = m->l; a.b = m->b; a.cs = m->tp_cs; a.e = m->tp_e; a.flag = m->tp_flag; a.tables = tables;
+            a.V = m->n; a.L = L; a.out = out;
+            a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
+            const uint32_t piece = min(kNfTpMaxChunks * L, (uint32_t)kNoiseJumpTables * 32u + L);   // chunk starts within the tables' reach
+            for (uint32_t s0 = start; s0 < end; s0 += piece) {
+                a.start = s0; a.end = min(s0 + piece, end);
+                a.C = (a.end - a.start + L - 1) / L;
+                if (++m->tp_serial == 0) m->tp_serial = 1;
+                a.serial = m->tp_serial;
+                const dim3 grid((m->n + 255) / 256, a.C);
+                hipLaunchKernelGGL(k_nf_tp_a, grid, dim3(256), 0, st, a);
+                if (zf) hipLaunchKernelGGL(k_nf_tp_b<true>, grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(k_nf_tp_b<false>, grid, dim3(256), 0, st, a);
+            }
+            return zh_launch_status();
+        }
     }
     // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at
     // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both

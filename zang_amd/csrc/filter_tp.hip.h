@@ -1,0 +1,312 @@
+// filter_tp.hip.h -- the TOLERANT, time-parallel forms of the Filter (src/modules/Filter.zig:74-151) for few voices
+// (ZH_PAINT_TOLERANT).  Opt-in: every default form in this library is bit-exact, and so are these for the
+// first chunk of a span; north_star asks 1e-5 relative for the Filter, bits only for Gate and Decimator.
+//
+// With constant cutoff and resonance the 2x-oversampled state-variable step (:135-144) is ONE affine map of the state:
+//     (l, b)' = A (l, b) + g(in)           A = A(cut, res), 2 x 2, the same for every frame of the span
+// so the state after L frames is A^L (l, b) + e, where e is what the same L inputs leave behind from a ZERO state.  A span is
+// cut into C chunks of L frames that run at once, one wave per (64 voices, chunk):
+//   pass 1   every chunk runs the reference's f32 recurrence from a zero state over its own inputs -> e_j          (L steps)
+//   scan     s_0 = the module's state; s_j = A^L s_{j-1} + e_{j-1}: A from the step run on unit states, A^L by squaring, the
+//            products and sums in f64 (C - 1 steps of a 2 x 2 product)
+//   pass 2   every chunk runs THE REFERENCE'S OWN recurrence again, from round_f32(s_j), and paints          (L steps)
+// The chain a voice waits for is 2 L + C steps instead of C L.  Inside a chunk the arithmetic is the reference's, operation for
+// operation; what differs is the chunk's start state: the reference reached it through L more roundings of its own, the scan
+// through the roundings of pass 1 -- two f32 evaluations of the same real number, each within a few ulp * sqrt(L) of it.
+// Measured against the oracle (tools/exp/filter_tp_error.py on the CPU, tests/test_gpu_tolerant.py on the device): the
+// largest error of any sample is <= 2.6e-6 of the voice's peak over the span for every case tried (config 3's parameter range, res 0.9
+// and 1.0, cutoff 0 / 1e-4 / 1.0, inputs scaled by 1e-30 .. 1e30) -- inside 1e-5 relative to the signal.  It is NOT inside
+// tests/util.py's per-sample metric |err| <= 1e-5 max(|ref|, 1e-3) near zero crossings (1-3 % of the samples): there the metric's
+// tolerance is 1e-8 against a signal of order 1, below one ulp of the state the sample was computed from, which no
+// re-association of the recurrence can meet.  DESIGN.md 5a states both figures.
+//
+// Both users run it as TWO kernels over a grid of (256 voices, chunk) workgroups, e_j through a module-owned scratch in HBM:
+// k_filter_tp_a / _b   Filter module, input image (read by both passes, the second time from L2).
+// k_nf_tp_a / _b       the fused white Noise -> Filter voice (config 3): the noise of chunk j needs the generator's state j L draws
+//                      ahead = one application of the jump table T^(jL) (noise_jump.hip.h, 32 KB of LDS; one table per
+//                      workgroup, hence the grid's shape); the chunk-start generator states go through the scratch too and pass
+//                      B generates the chunk's noise again (30 instructions a sample against 8 bytes of traffic).  The noise
+//                      itself is exact.
+// A wave64 instruction occupies its SIMD for four cycles however many waves share the SIMD: once every SIMD has a wave, what a
+// launch costs is its total instruction count, so the per-chunk extras (a jump: ~700 instructions; the scan) set the chunk
+// length -- not "as many chunks as possible".
+#pragma once
+#include "common.hip.h"
+#include "zmath.hip.h"
+#include "dsp.hip.h"
+#include "lanes.hip.h"
+#include "noise_jump.hip.h"
+
+struct Svf2x2 { double a00, a01, a10, a11; };
+// A(cut, res): the step of Filter.zig:135-144 without its inputs (in = 0, no dc offset), on the unit states, in f64
+__device__ __forceinline__ Svf2x2 svf_hom(float cutf, float resf) {
+    const double c = cutf, r = resf;
+    auto hs = [&](double l, double b, double &lo, double &bo) ZH_INLINE_LAMBDA {
+        l = l + c * b;                                                // :138
+        b = b + c * (-(b * r) - l);                                   // :139
+        l = l + c * b;                                                // :142
+        const double h = -(b * r) - l;                                // :143
+        b = b + c * h;                                                // :144
+        lo = l; bo = b;
+    };
+    Svf2x2 a;
+    hs(1.0, 0.0, a.a00, a.a10);
+    hs(0.0, 1.0, a.a01, a.a11);
+    return a;
+}
+__device__ __forceinline__ Svf2x2 svf_mul(const Svf2x2 &x, const Svf2x2 &y) {
+    return Svf2x2{x.a00 * y.a00 + x.a01 * y.a10, x.a00 * y.a01 + x.a01 * y.a11, x.a10 * y.a00 + x.a11 * y.a10, x.a10 * y.a01 + x.a11 * y.a11};
+}
+// a^n, n >= 1 wave-uniform
+__device__ __forceinline__ Svf2x2 svf_pow(Svf2x2 a, uint32_t n) {
+    Svf2x2 r{1.0, 0.0, 0.0, 1.0};
+    for (;;) {
+        if (n & 1u) r = svf_mul(a, r);
+        n >>= 1;
+        if (!n) break;
+        a = svf_mul(a, a);
+    }
+    return r;
+}
+// s_j from s_0 and the zero-state end states e_0 .. e_{j-1} of the (equally long) chunks before it.  fetch(i) -> e_i for ANY
+// i < NMAX (slots past j hold something readable and are ignored): all NMAX values are requested before the first is used --
+// fetched one by one inside the j-step loop, every global load is a round trip of its own.  A^L is formed in f64 (squaring
+// multiplies its error) and rounded once; the j steps are plain f32 products and sums -- as accurate as f64 steps against the
+// reference (which is f32 itself; tools/exp/filter_tp_error.py) at a quarter of their issue time.
+template <uint32_t NMAX, class Fetch>
+__device__ __forceinline__ void svf_scan(float &l, float &b, float cut, float res, uint32_t L, uint32_t j, Fetch fetch) {
+    if (j == 0) return;                                               // the first chunk starts from the module's state itself: exact
+    float2 e[NMAX];
+#pragma unroll
+    for (uint32_t i = 0; i < NMAX; i++) e[i] = fetch(i);
+    const Svf2x2 md = svf_pow(svf_hom(cut, res), L);
+    const float m00 = (float)md.a00, m01 = (float)md.a01, m10 = (float)md.a10, m11 = (float)md.a11;
+#pragma unroll
+    for (uint32_t i = 0; i < NMAX; i++)
+        if (i < j) {                                                  // wave-uniform
+            const float nl = (m00 * l + m01 * b) + e[i].x;
+            const float nb = (m10 * l + m11 * b) + e[i].y;
+            l = nl; b = nb;
+        }
+}
+
+constexpr uint32_t kTpMaxChunks = 32;    // chunks per launch; a module's scratch holds this many slots whatever a launch uses
+
+#if !defined(ZH_DEVICE_ONLY)
+// chunks for a span of n frames of V voices: enough for ~2,048 waves (two per SIMD), 2..32; 0 = too many voices for the form
+static inline uint32_t zh_tp_chunks(uint32_t V, const char *max_env, uint32_t n) {
+    const uint32_t G = (V + 63) / 64;
+    const char *me = zh_env(max_env);                                 // largest voice count that takes the time-parallel form
+    const uint32_t tp_max = me ? (uint32_t)strtoul(me, nullptr, 10) : 16384u;
+    if (V > tp_max || G > 1024) return 0;
+    const char *we = zh_env("ZH_TP_WAVES");                           // experiments: waves a launch should reach
+    const uint32_t waves = we ? (uint32_t)strtoul(we, nullptr, 10) : 2048u;
+    uint32_t C = (waves + G - 1) / G;
+    C = C < 2 ? 2 : (C > kTpMaxChunks ? kTpMaxChunks : C);
+    return C > n ? n : C;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------- Filter module
+// Two kernels, grid: x = 256-voice groups, y = chunk; block = 256 -- a chunk's waves go wherever there is room (a workgroup of
+// all the chunks of 64 voices, exchanging e_j through LDS, kept 64 CUs busy and 192 idle at 4,096 voices: 17 us).  e_j and the
+// span's start state go through the module's scratch `e` ([chunks + 1][V]: slot 0 = start state, slot j + 1 = e_j); pass B
+// reads its inputs again (from L2).
+struct FilterTpArgs {
+    float *l, *b;
+    float2 *e;
+    uint32_t V, start, end, L;
+    Img out;
+    CImg input;
+    float l_mul, b_mul, h_mul;
+    F32P cutoff, res;
+};
+// body(k, in) for the frames [f0, f1) of one lane, in = input + fcdcoffset (:135): 8-row tiles, the tile's loads ahead of its use
+template <class Body>
+__device__ __forceinline__ void tp_input_tiles(const CImg &input, uint32_t voff, uint32_t f0, uint32_t f1, Body body) {
+    const uint32_t irow = (uint32_t)input.stride * 4u;
+    uint32_t f = f0;
+    for (; f + 8 <= f1; f += 8) {
+        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, f);
+        float x[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) x[q] = zrow_load<1>(ri, voff, q * irow) + kSvfDcOffset;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) body(f + q, x[q]);
+    }
+    if (f < f1) {
+        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, f);
+        for (uint32_t q = 0; f + q < f1; q++) body(f + q, zrow_load<1>(ri, voff, q * irow) + kSvfDcOffset);
+    }
+}
+template <int DUMMY = 0>
+__global__ void __launch_bounds__(256) k_filter_tp_a(const FilterTpArgs a) {
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    if (j == 0) a.e[v] = make_float2(a.l[v], a.b[v]);
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
+    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
+    float l = 0.0f, b = 0.0f;
+    tp_input_tiles(a.input, v * 4u, f0, f1, [&](uint32_t, float in) ZH_INLINE_LAMBDA { svf_core(l, b, in, cut, res); });
+    a.e[(size_t)(j + 1) * a.V + v] = make_float2(l, b);
+}
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_filter_tp_b(const FilterTpArgs a) {
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    const size_t V = a.V;
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);
+    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);
+    const float2 s0 = a.e[v];
+    float l = s0.x, b = s0.y;
+    svf_scan<kTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
+    const uint32_t voff = v * 4u;
+    tp_input_tiles(a.input, voff, f0, f1, [&](uint32_t f, float in) ZH_INLINE_LAMBDA {
+        const SvfOut sv = svf_core(l, b, in, cut, res);               // :138-144
+        const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
+        const float base = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
+        zrow_store<1>(ro, voff, 0, base + val);
+    });
+    if (f1 == a.end && f1 > f0) { a.l[v] = l; a.b[v] = b; }
+}
+
+#if !defined(ZH_DEVICE_ONLY)
+// Launches the span as pieces of <= 32 chunks.  false = not taken (too many voices, a short span): the caller paints with its
+// exact form.  `e` = the module's scratch, (kTpMaxChunks + 1) * V float2.
+static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float2 *e, uint32_t V, Img out, CImg in, uint32_t start, uint32_t end, bool zf,
+                                       float l_mul, float b_mul, float h_mul, F32P cut, F32P res) {
+    if (end - start < 64) return false;
+    const uint32_t C = zh_tp_chunks(V, "ZH_FILTER_TP_MAX", end - start);
+    if (C < 2) return false;
+    const uint32_t piece = 4096;                                      // frames per launch pair: chunks of <= 128 frames
+    FilterTpArgs a;
+    a.l = l; a.b = b; a.e = e; a.V = V; a.out = out; a.input = in; a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = cut; a.res = res;
+    for (uint32_t s = start; s < end; s += piece) {
+        a.start = s; a.end = min(s + piece, end);
+        a.L = (a.end - a.start + C - 1) / C;
+        const dim3 grid((V + 255) / 256, (a.end - a.start + a.L - 1) / a.L);
+        hipLaunchKernelGGL(k_filter_tp_a<0>, grid, dim3(256), 0, st, a);
+        if (zf) hipLaunchKernelGGL(k_filter_tp_b<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_filter_tp_b<false>, grid, dim3(256), 0, st, a);
+    }
+    return true;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------- white Noise -> Filter
+#if defined(ZH_FILTER_TP_NOISE)          // (composite.hip only: the kernels below are not templates)
+constexpr uint32_t kNfTpMaxChunks = kTpMaxChunks;
+struct NfTpArgs {
+    uint64_t *s[4];              // the voices' generator states (Noise.zig:9): read by pass A, written once by pass B
+    float *l, *b;                // filter state
+    uint64_t *cs;                // scratch [C][4][V]: generator state at the start of chunk j
+    float2 *e;                   // scratch [C + 1][V]: slot 0 = the filter state at span start, slot j + 1 = e_j
+    uint32_t *flag;              // scratch [V]: == serial when a multi-draw sample (Random.float, 2^-41 per sample) was seen in THIS paint
+    uint32_t serial;             // this paint's number (host counter, never 0; flags are never cleared: an old number is "not flagged",
+                                 // and a graph replayed with the number it was recorded with at worst sees a stale flag and walks that
+                                 // voice sequentially -- the exact path -- once more)
+    const uint4 *tables;         // T^(32 k), k = 1..63
+    uint32_t V, start, end, L, C;
+    Img out;
+    float l_mul, b_mul, h_mul;
+    F32P cutoff, res;
+};
+
+// grid: x = 256-voice groups, y = chunk; block = 256.  Pass A: jump to the chunk's first draw, keep that state, zero-state response.
+__global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
+    __shared__ uint4 tbl[kNoiseJumpEntries];
+    const uint32_t j = blockIdx.y;
+    if (j > 0) {                                                      // block-uniform
+        const uint4 *t = a.tables + (size_t)(j * (a.L / 32) - 1) * kNoiseJumpEntries;
+        uint4 w[kNoiseJumpEntries / 256];                             // the thread's eight entries requested together, then parked
+#pragma unroll
+        for (int q = 0; q < kNoiseJumpEntries / 256; q++) w[q] = t[q * 256 + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < kNoiseJumpEntries / 256; q++) tbl[q * 256 + threadIdx.x] = w[q];
+        __syncthreads();
+    }
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    ZXoshiro r{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+    if (j > 0) noise_jump_apply(r, tbl);
+    const size_t V = a.V;
+    uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+    cs[0] = r.s0; cs[V] = r.s1; cs[2 * V] = r.s2; cs[3 * V] = r.s3;
+    if (j == 0) a.e[v] = make_float2(a.l[v], a.b[v]);
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end), nf = f1 - f0;
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
+    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
+    float l = 0.0f, b = 0.0f;
+    bool multi = false;
+#pragma unroll 8
+    for (uint32_t k = 0; k < nf; k++) {
+        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;   // Noise.zig:51
+        const float temp = 0.0f + white;                              // zero(temp); temp += noise
+        svf_step(l, b, temp, cut, res);                               // Filter.zig:135-144
+    }
+    a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
+    if (multi) a.flag[v] = a.serial;                                      // (every later chunk of this voice started at the wrong draw)
+}
+
+// Pass B, same grid: scan, then the reference's recurrence over the regenerated noise of the chunk.  A flagged voice is painted
+// whole by its chunk-0 lane, sequentially from the module's state -- the reference's own walk, bit for bit.
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
+    const uint32_t j = blockIdx.y;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    const size_t V = a.V;
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);
+    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);
+    const uint32_t voff = v * 4u, orow = (uint32_t)a.out.stride * 4u;
+    const bool flagged = a.flag[v] == a.serial;
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);     // workgroup-uniform: the frame loops stay scalar
+    const uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+    ZXoshiro r{cs[0], cs[V], cs[2 * V], cs[3 * V]};
+    const float2 s0 = a.e[v];
+    float l = s0.x, b = s0.y;
+    svf_scan<kNfTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
+    auto frame = [&](const zh_rsrc_t &ro, uint32_t k, float base, bool store) ZH_INLINE_LAMBDA {
+        const float white = zrandom_float32(r) * 2.0f - 1.0f;       // Noise.zig:51
+        const float temp = 0.0f + white;                             // zero(temp); temp += noise
+        const SvfOut sv = svf_step(l, b, temp, cut, res);            // Filter.zig:135-144
+        const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
+        if (store) zrow_store<1>(ro, voff, k * orow, base + val);
+    };
+    // (8 rows per descriptor: 32-bit offsets, common.hip.h kMaxRowStride)
+    uint32_t c0 = f0;
+    for (; c0 + 8 <= f1; c0 += 8) {
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
+        float base[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) base[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) frame(ro, k, base[k], !flagged);
+    }
+    if (c0 < f1) {
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
+        for (uint32_t k = 0; c0 + k < f1; k++) frame(ro, k, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow), !flagged);
+    }
+    if (!flagged && f1 == a.end && f1 > f0) {                         // whoever painted the span's last frame leaves the states
+        a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
+        a.l[v] = l; a.b[v] = b;
+    }
+    // A flagged voice (one of its draws took Random.float's second draw: every later chunk started at the wrong one) is painted
+    // whole by its chunk-0 lane, sequentially from the module's state: the reference's own walk, bit for bit.
+    if (j == 0 && __builtin_amdgcn_ballot_w64(flagged) != 0) {
+        if (flagged) {
+            r = ZXoshiro{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+            l = s0.x; b = s0.y;
+            for (uint32_t f = a.start; f < a.end; f++) {
+                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
+                frame(ro, 0, ZF ? 0.0f : zrow_load<1>(ro, voff, 0), true);
+            }
+            a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
+            a.l[v] = l; a.b[v] = b;
+        }
+    }
+}
+#endif   // ZH_FILTER_TP_NOISE

@@ -14,6 +14,7 @@
 #include "seq.hip.h"
 #include "envelope.hip.h"
 #include "voices.hip.h"
+#include "filter_tp.hip.h"
 #include <vector>
 
 template <typename T> static int upload_field(zh_ctx *ctx, T *dev, const std::vector<T> &h) {
@@ -527,7 +528,8 @@ __global__ void __launch_bounds__(256) k_gate(uint32_t V, Img out, uint32_t star
 }
 
 // =================================================================== Filter
-struct zh_filter { zh_ctx *ctx; uint32_t n; float *l, *b; };
+struct zh_filter { zh_ctx *ctx; uint32_t n; float *l, *b;
+                   float2 *tp_e; };   // ZH_PAINT_TOLERANT scratch (filter_tp.hip.h), allocated by the first tolerant paint outside a capture
 
 template <bool ZF, bool CB, bool RB>
 __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out,
@@ -1509,7 +1511,7 @@ int zh_filter_create(zh_ctx *ctx, uint32_t n, zh_filter **out) { ZH_GUARD(ctx);
 int zh_filter_destroy(zh_filter *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->l); (void)hipFree(m->b);
+    (void)hipFree(m->l); (void)hipFree(m->b); (void)hipFree(m->tp_e);
     delete m;
     return ZH_OK;
 }
@@ -1571,6 +1573,13 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 32768u;
     const char *pe16 = zh_env("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
     const uint32_t pc16_max = pe16 ? (uint32_t)atoi(pe16) : (pe && pc_max == 0 ? 0u : 65536u);   // (ZH_FILTER_PC_MAX=0 alone switches both off)     // 36,864 / 49,152 / 65,536 voices: 97 / 103 / 116 us in one wave, 72 / 79 / 104; 81,920: 126 against 168
+    // ZH_PAINT_TOLERANT, few voices: the span as chunks at once (filter_tp.hip.h); every other case paints with an exact form
+    if ((flags & ZH_PAINT_TOLERANT) && !cb && !rb && !bufs_alias(p->input, outputs[0])) {
+        if (!m->tp_e && !m->ctx->capturing && zh_tp_chunks(m->n, "ZH_FILTER_TP_MAX", end - start) >= 2 &&
+            dev_alloc(&m->tp_e, (size_t)(kTpMaxChunks + 1) * m->n) != ZH_OK) { m->tp_e = nullptr; (void)hipGetLastError(); }
+        if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut.c, res.c))
+            return zh_launch_status();
+    }
     if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
         const dim3 grid((m->n + 63) / 64);
         if (m->n <= pc_max) {

@@ -218,9 +218,10 @@ class Filter(_Module):
         cutoff: Any
         res: Any
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT (opt-in, 1e-5 of the signal's peak instead of bits; include/zang_hip.h)."""
         cp = abi.FilterParams(as_buf(params.input), params.type, 0, params.cutoff, params.res)
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
     @staticmethod
     def cutoffFromFrequency(frequency, sample_rate, ctx=None):
@@ -489,9 +490,10 @@ class NoiseFilter(_Module):
     def __init__(self, n_voices, ctx=None, first_seed=0):
         super().__init__(n_voices, ctx, C.c_uint64(first_seed))
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT (opt-in, 1e-5 of the signal's peak instead of bits; include/zang_hip.h)."""
         cp = abi.NoiseFilterParams(params.color, params.type, as_f32(params.cutoff), as_f32(params.res))
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
 
 class PMOscInstrument(_Module):
