@@ -124,7 +124,8 @@ ZH_API int  zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t
  * flips it holds, and zh_graph_launch copies the live counters over first when eager paints or other graphs
  * have left them in the other buffer -- any number of paints may be captured, and replays and eager paints mix freely.)
  * The voice mixdown's scratch must already be large enough (paint once eagerly first): it cannot grow while
- * a capture is recording (ZH_ERR_UNSUPPORTED). */
+ * a capture is recording (ZH_ERR_UNSUPPORTED).  Destroy a graph BEFORE the context it was captured on (zh_graph_destroy tells the
+ * context that one holder of its retired scratch blocks is gone), as with the modules. */
 typedef struct zh_graph zh_graph;
 ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
 ZH_API int  zh_graph_end_capture(zh_ctx *ctx, zh_graph **out);
@@ -460,6 +461,12 @@ ZH_API int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t span_start, uint32_t sp
  * note_id_changed[b] into mix_left[b] / mix_right[b] (host arrays of n_buffers device pointers / structs); the voices' state
  * stays in registers from buffer to buffer and the second mixdown pass runs once for all buffers.  Bit-identical to n_buffers
  * single calls; the sample rate must be the same in every params[b] (ZH_ERR_UNSUPPORTED otherwise). */
+/* Scratch: the fused mixdown keeps per-context partial rows in HBM -- frames (rounded up to 8) x rows x channels x 4 bytes per
+ * buffer, rows = one per 256 voices from 65,536 voices up and one per 64 voices below (ZH_NICE_MIX_WG_MIN): 4 MiB per stereo
+ * buffer of 1,024 frames at 131,072 voices, 32 MiB at 1,048,576; a batch reserves n_buffers times that (512 MiB for 16 buffers at
+ * 1 Mi voices).  The block only grows, on the first call that needs more (never inside a capture: ZH_ERR_UNSUPPORTED -- make one
+ * eager call of the size first); an outgrown block is freed at once unless a captured graph of the context is alive, then when
+ * the last one is destroyed. */
 enum { ZH_MIX_MAX_BATCH = 16 };
 ZH_API int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t span_start, uint32_t span_end, uint32_t n_buffers,
                                           float *const *mix_left, float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right,

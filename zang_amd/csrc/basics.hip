@@ -281,14 +281,17 @@ __global__ void __launch_bounds__(256) k_mix_down(uint8_t *__restrict__ dst, con
 int zh_mix_reserve(zh_ctx *ctx, size_t floats) { ZH_GUARD(ctx);
     if (ctx->mix_partials_floats >= floats) return ZH_OK;
     // Growing: never while the stream is capturing (an allocation cannot be recorded, and a synchronise would
-    // invalidate the capture) -- reserve with an eager call of the same size first.  The old block is retired, not
-    // freed: a graph captured earlier keeps its pointer in its mixdown nodes (freed at zh_destroy).
+    // invalidate the capture) -- reserve with an eager call of the same size first.  While a captured graph lives, the old block
+    // is retired, not freed: the graph keeps its pointer in its mixdown nodes (freed when the context's last graph is destroyed).
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (ctx->capturing || (hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone))
         return ZH_ERR_UNSUPPORTED;
     float *p = nullptr;
     ZH_TRY(hipMalloc((void **)&p, floats * sizeof(float)));
-    if (ctx->mix_partials) ctx->mix_retired.push_back(ctx->mix_partials);
+    if (ctx->mix_partials) {
+        if (ctx->graphs_live) ctx->mix_retired.push_back(ctx->mix_partials);   // a live graph may name it in its mixdown nodes
+        else (void)hipFree(ctx->mix_partials);                                 // nobody else can (hipFree waits for the work in flight)
+    }
     ctx->mix_partials = p;
     ctx->mix_partials_floats = floats;
     return ZH_OK;

@@ -43,12 +43,14 @@ struct zh_ctx {
     float *mix_partials;
     size_t mix_partials_floats;
     std::vector<float *> mix_retired;
+    uint32_t graphs_live;        // graphs captured on this context and not yet destroyed: only they can still name a retired block
     bool capturing;
     std::vector<zh_flip_use> capture_log;
     void *noise_jump;            // xoshiro256++ jump tables (noise_jump.hip), built on first use, freed with the context
 };
 
 struct zh_graph {
+    zh_ctx *ctx;
     hipGraph_t graph;
     hipGraphExec_t exec;
     std::vector<zh_flip_use> flips;

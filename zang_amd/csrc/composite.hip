@@ -534,10 +534,16 @@ __device__ __forceinline__ void nice_mix_gains(G2 &g2, const F32P &gain_l, const
 // One paint's frames of a wave: chunks of MIXF frames into the wave's tile, summed, partial rows written.  `pw` = this wave's
 // partial rows of the paint: `pw_paint` = the paint's channel-0 block laid out [frame / G][row][frame % G], G = kMixGroupFrames (a second-pass
 // workgroup's G frames of every row are one contiguous run), channel 1 channel_stride floats further; `wrow` = this wave's row.
-template <int C, bool ROLL, class G2>
+// WG (round 4): the four waves' row sums of a chunk meet in LDS and ONE row per workgroup goes to HBM -- a quarter of the partial
+// rows written and read back -- for one workgroup barrier per 32-frame chunk, in the sum phase only: `wsum`
+// = [2][4][C][MIXF], the chunk's parity picks the half (a wave may be a whole chunk ahead of the slowest: it has passed the
+// previous barrier, so every wave has finished combining the chunk before that).  `wrow` is then the workgroup's row and
+// `rows` the number of workgroups.  Row order inside a workgroup: ((w0 + w1) + w2) + w3.
+template <int C, bool ROLL, bool WG, class G2>
 __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, const G2 &g2, float (*tile)[MIXS], float *__restrict__ pw_paint,
                                                 size_t channel_stride, uint32_t rows, uint32_t wrow, uint32_t start, uint32_t end, uint32_t lane,
-                                                uint32_t rf, uint32_t rh) {
+                                                uint32_t rf, uint32_t rh, float (*wsum)[4][C][MIXF] = nullptr, uint32_t wave = 0) {
+    uint32_t parity = 0;
     for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
         // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
         // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
@@ -612,11 +618,29 @@ __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, co
             // frame rf's two half-row sums meet in lane rf: (voices 0..31) + (voices 32..63)
             const float hl = __shfl_down(sl, 32);
             const float hr = C == 2 ? __shfl_down(sr, 32) : 0.0f;
-            if (rh == 0 && f0 + rf < end) {
-                const uint32_t fr = (f0 - start) + rf;
-                float *pw = pw_paint + ((size_t)(fr / kMixGroupFrames) * rows + wrow) * kMixGroupFrames + (fr % kMixGroupFrames);
-                pw[0] = sl + hl;
-                if constexpr (C == 2) pw[channel_stride] = sr + hr;
+            if constexpr (!WG) {
+                if (rh == 0 && f0 + rf < end) {
+                    const uint32_t fr = (f0 - start) + rf;
+                    float *pw = pw_paint + ((size_t)(fr / kMixGroupFrames) * rows + wrow) * kMixGroupFrames + (fr % kMixGroupFrames);
+                    pw[0] = sl + hl;
+                    if constexpr (C == 2) pw[channel_stride] = sr + hr;
+                }
+            } else {
+                if (rh == 0) {
+                    wsum[parity][wave][0][rf] = sl + hl;
+                    if constexpr (C == 2) wsum[parity][wave][1][rf] = sr + hr;
+                }
+                __syncthreads();
+                // wave w combines the chunk's frames 8w .. 8w+7: lanes 0-7 the first channel, 8-15 the second; eight lanes = 32
+                // contiguous bytes of the workgroup's row (MIXF / 4 == kMixGroupFrames)
+                static_assert(MIXF / 4 == kMixGroupFrames, "one frame group per wave");
+                const uint32_t q = lane & 7, c = lane >> 3, fw = wave * 8 + q;
+                if (c < (uint32_t)C && f0 + fw < end) {
+                    const float t = ((wsum[parity][0][c][fw] + wsum[parity][1][c][fw]) + wsum[parity][2][c][fw]) + wsum[parity][3][c][fw];
+                    const uint32_t fr = (f0 - start) + fw;
+                    pw_paint[c * channel_stride + ((size_t)(fr / kMixGroupFrames) * rows + wrow) * kMixGroupFrames + (fr % kMixGroupFrames)] = t;
+                }
+                parity ^= 1u;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next chunk rewrites the tile after these reads
@@ -634,16 +658,17 @@ __device__ __forceinline__ void nice_silence(NiceLane &n) {
     n.env.mode = ENV_MODE_NONE; n.env.m_painted = 0u;
 }
 
-template <int C, bool ROLL>
+template <int C, bool ROLL, bool WG = false>
 __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
                                                   F32P gain_l, F32P gain_r) {
     __shared__ float tile_all[4][MIXF][MIXS];
+    __shared__ float wsum[WG ? 2 : 1][4][C][MIXF];
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*tile)[MIXS] = tile_all[wave];                               // this wave's tile: no other wave touches it
     const uint32_t nframes = end - start;
-    const uint32_t wave_global = blockIdx.x * 4 + wave;
-    const uint32_t rows = gridDim.x * 4;
+    const uint32_t wave_global = WG ? blockIdx.x : blockIdx.x * 4 + wave;
+    const uint32_t rows = WG ? gridDim.x : gridDim.x * 4;
     const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;   // partials[channel][frame / G][wave][frame % G]
     const bool live = v < a.V;
     // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
@@ -657,7 +682,7 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 g2[C == 2 ? 32 : 1];                                             // {left, right} gain of each of the lane's 32 voices
     nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
-    nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, start, end, lane, rf, rh);
+    nice_mix_frames<C, ROLL, WG>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
     if (live) nice_store(n, a, v);
 }
 
@@ -671,17 +696,18 @@ struct NiceBatchArgs {
     BoolP note_on[kNiceMixMaxBatch], nic[kNiceMixMaxBatch];
     uint32_t nb;
 };
-template <int C, bool ROLL>
+template <int C, bool ROLL, bool WG = false>
 __global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, uint32_t start, uint32_t end, float *__restrict__ partials,
                                                         F32P gain_l, F32P gain_r) {
     __shared__ float tile_all[4][MIXF][MIXS];
+    __shared__ float wsum[WG ? 2 : 1][4][C][MIXF];
     const NiceArgs &a = b.a;
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*tile)[MIXS] = tile_all[wave];
     const uint32_t nframes = end - start;
-    const uint32_t wave_global = blockIdx.x * 4 + wave;
-    const uint32_t rows = gridDim.x * 4;
+    const uint32_t wave_global = WG ? blockIdx.x : blockIdx.x * 4 + wave;
+    const uint32_t rows = WG ? gridDim.x : gridDim.x * 4;
     const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;
     const bool live = v < a.V;
     const uint32_t vc = live ? v : a.V - 1;
@@ -697,7 +723,7 @@ __global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, u
         if (!live) nice_silence(n);
         PulseRoll roll;
         n.roll_begin(roll);
-        nice_mix_frames<C, ROLL>(n, roll, g2, tile, partials + (size_t)k * C * channel_stride, channel_stride, rows, wave_global, start, end, lane, rf, rh);
+        nice_mix_frames<C, ROLL, WG>(n, roll, g2, tile, partials + (size_t)k * C * channel_stride, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
     }
     if (live) nice_store(n, a, v);
 }
@@ -1653,6 +1679,15 @@ static bool nice_mix_roll() {
     const bool v = e ? atoi(e) != 0 : true;   // A/B switch: 149.6 vs 148.2 us at 131,072 voices, 908 vs 890 us at 1,048,576
     return v;
 }
+// One partial row per workgroup (a barrier per chunk in the sum phase) or one per wave.  A/B on one box (tools/ab_env.sh,
+// profiles/r04/ab_nice_mix_wg.txt): 131,072 voices 108.5 -> 107.9 us per buffer all-in with a quarter of the partial traffic;
+// 4,096 voices 99.3 -> 104.4 (sixteen workgroups on 256 CUs: the barrier couples waves that otherwise run at their own pace).
+// ZH_NICE_MIX_WG_MIN = the smallest voice count that combines per workgroup.
+static bool nice_mix_wg(uint32_t n_voices) {
+    const char *e = zh_env("ZH_NICE_MIX_WG_MIN");
+    const uint32_t wg_min = e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u;
+    return n_voices >= wg_min;
+}
 static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
                             const zh_f32 *gain_r, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
     const bool stereo = mix_r != nullptr;
@@ -1660,7 +1695,8 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     if (m->n == 0) return ZH_OK;
     const uint32_t nframes = end - start;
     const uint32_t blocks = (m->n + 255) / 256;
-    const uint32_t rows = blocks * 4;                                   // one partial row per wave of 64 voices
+    const bool wg = nice_mix_wg(m->n);
+    const uint32_t rows = wg ? blocks : blocks * 4;                     // one partial row per workgroup (256 voices) / per wave of 64 voices
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);   // [frame / G][row][frame % G]
     int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1));
     if (rc) return rc;
@@ -1668,16 +1704,20 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     NiceArgs a = nice_args(m, p, note_id_changed);
     float *part = m->ctx->mix_partials;
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
+#define ZH_NMIX(C_, ROLL_, WG_, GL_, GR_) hipLaunchKernelGGL((k_nice_mix<C_, ROLL_, WG_>), dim3(blocks), dim3(256), 0, st, a, start, end, part, GL_, GR_)
+    const bool roll = nice_mix_roll();
     if (stereo) {
-        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<2, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
-        else hipLaunchKernelGGL((k_nice_mix<2, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, mk_f32(*gain_l), mk_f32(*gain_r));
+        const F32P gl = mk_f32(*gain_l), gr = mk_f32(*gain_r);
+        if (wg) { if (roll) ZH_NMIX(2, true, true, gl, gr); else ZH_NMIX(2, false, true, gl, gr); }
+        else { if (roll) ZH_NMIX(2, true, false, gl, gr); else ZH_NMIX(2, false, false, gl, gr); }
         if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, mix_r + start, 2, zf);
     } else {
         const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
-        if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix<1, true>), dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
-        else hipLaunchKernelGGL((k_nice_mix<1, false>), dim3(blocks), dim3(256), 0, st, a, start, end, part, none, none);
+        if (wg) { if (roll) ZH_NMIX(1, true, true, none, none); else ZH_NMIX(1, false, true, none, none); }
+        else { if (roll) ZH_NMIX(1, true, false, none, none); else ZH_NMIX(1, false, false, none, none); }
         if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, nullptr, 1, zf);
     }
+#undef ZH_NMIX
     return zh_launch_status();
 }
 int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_bool note_id_changed,
@@ -1701,7 +1741,8 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     }
     if (m->n == 0 || n_buffers == 0) return ZH_OK;
     const uint32_t nframes = end - start;
-    const uint32_t blocks = (m->n + 255) / 256, rows = blocks * 4;
+    const bool wg = nice_mix_wg(m->n);
+    const uint32_t blocks = (m->n + 255) / 256, rows = wg ? blocks : blocks * 4;
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);
     int rc = zh_mix_reserve(m->ctx, per_channel * 2 * n_buffers);
     if (rc) return rc;
@@ -1714,8 +1755,10 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     }
     float *part = m->ctx->mix_partials;
     hipStream_t st = m->ctx->stream;
-    if (nice_mix_roll()) hipLaunchKernelGGL((k_nice_mix_batch<2, true>), dim3(blocks), dim3(256), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right));
-    else hipLaunchKernelGGL((k_nice_mix_batch<2, false>), dim3(blocks), dim3(256), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right));
+#define ZH_NMIXB(ROLL_, WG_) hipLaunchKernelGGL((k_nice_mix_batch<2, ROLL_, WG_>), dim3(blocks), dim3(256), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right))
+    if (wg) { if (nice_mix_roll()) ZH_NMIXB(true, true); else ZH_NMIXB(false, true); }
+    else { if (nice_mix_roll()) ZH_NMIXB(true, false); else ZH_NMIXB(false, false); }
+#undef ZH_NMIXB
     if (nframes) {
         float *l[kNiceMixMaxBatch], *r[kNiceMixMaxBatch];
         for (uint32_t k = 0; k < n_buffers; k++) { l[k] = mix_left[k] + start; r[k] = mix_right[k] + start; }

@@ -273,8 +273,10 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
     zh_graph *zg = new (std::nothrow) zh_graph();
     if (!zg) { hipGraphDestroy(g); return ZH_ERR_INVALID; }
     zg->graph = g;
+    zg->ctx = ctx;
     hipError_t e = hipGraphInstantiate(&zg->exec, g, nullptr, nullptr, 0);
     if (e != hipSuccess) { hipGraphDestroy(g); delete zg; return (int)e; }
+    ctx->graphs_live++;
     zg->flips.swap(log);
     *out = zg;
     return ZH_OK;
@@ -304,9 +306,17 @@ int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) { ZH_GUARD(ctx);
 
 int zh_graph_destroy(zh_graph *graph) {
     if (!graph) return ZH_ERR_INVALID;
+    zh_ctx *ctx = graph->ctx;
+    ZH_GUARD(ctx);
     hipGraphExecDestroy(graph->exec);
     hipGraphDestroy(graph->graph);
     delete graph;
+    // the last graph is gone: nothing can name a retired scratch block any more (a host that went from single paints
+    // to batches kept every outgrown block until zh_destroy).  hipFree waits for the work in flight.
+    if (ctx && ctx->graphs_live && --ctx->graphs_live == 0) {
+        for (float *p : ctx->mix_retired) (void)hipFree(p);
+        ctx->mix_retired.clear();
+    }
     return ZH_OK;
 }
 
