@@ -45,9 +45,12 @@ def test_sin_cos_bitexact(ctx, oracle, name):
     assert bad.size == 0, (name, bad.size, [(hex(int(xs[i:i + 1].view(np.uint32)[0])), float(got[i]), float(ref[i])) for i in bad[:8]])
 
 
-@pytest.mark.parametrize("name", ["sin", "cos"])
+@pytest.mark.parametrize("name", ["sin", "cos", "atan"])
 def test_sin_cos_stratified_2_to_28(ctx, oracle, name):
-    """Round 3: the device's sinf / cosf fuse multiply-add pairs and take fn from musl's magic-number rounding (csrc/zmath.hip.h
+    """(atan, round 4: zatanf takes its range's coefficients from a row instead of selects and divides with v_rcp_f32 + one residual
+    correction -- forms tools/ubench/atan_exhaustive.hip holds against musl's branchy order for ALL 2^32 arguments on the device,
+    profiles/r04/atan_exhaustive.txt; the same stratified check against the host oracle.)
+    Round 3: the device's sinf / cosf fuse multiply-add pairs and take fn from musl's magic-number rounding (csrc/zmath.hip.h
     zsincos_kernels / zreduce_pio2f) -- forms that tools/ubench/sin_exhaustive.hip holds against musl's operation order for ALL
     2^32 arguments on the device.  Here a 2^28-argument stratified subset (every 16th bit pattern, the offset rotating so that
     all 16 residues are visited) against the ORACLE's musl restatement on the host: every exponent, both signs, every leaf."""

@@ -180,7 +180,7 @@ static void run(const char *name, bool quick) {
     hipFree(out);
     printf("%-58s flags %7d: %llu differing", name, FL, host.bad);
     if (host.bad) { printf(" (first x = 0x%08x;", host.first); for (unsigned long long k = 0; k < host.bad && k < 3; k++) printf(" x=0x%08x want 0x%08x got 0x%08x", host.list[k], host.want[k], host.got[k]); printf(")"); }
-    printf("   | %.1f ps per atanf (2^28 evaluations x 4)\n", ms * 1e9 / 4.0 / (double)(1u << 28));
+    printf("   | %.3f ms per 2^28 evaluations (%.2f ps each)\n", ms / 4.0, ms * 1e9 / 4.0 / (double)(1u << 28));
     fflush(stdout);
 }
 
@@ -196,6 +196,7 @@ int main(int argc, char **argv) {
     run<FASTDIV>("FASTDIV rcp + Newton + residual", quick);
     run<RCP1>("RCP1 rcp + residual", quick);
     run<UNIFIED | FASTDIV>("UNIFIED+FASTDIV", quick);
+    run<UNIFIED | RCP1>("UNIFIED+RCP1 (the library's form since round 4)", quick);
     run<ROWS | FASTDIV>("ROWS+FASTDIV", quick);
     run<ROWS | INDEXSUM | FASTDIV>("ROWS+INDEXSUM+FASTDIV", quick);
     run<ROWS | INDEXSUM | RCP1>("ROWS+INDEXSUM+RCP1", quick);
@@ -204,5 +205,8 @@ int main(int argc, char **argv) {
     run<POLY_C>("POLY_C fma(w, aT3, aT1)", quick);
     run<NOTINY>("NOTINY no |x| < 2^-12 early return", quick);
     run<ROWS | NOTINY>("ROWS+NOTINY", quick);
+    run<ROWS | NOTINY | FASTDIV>("ROWS+NOTINY+FASTDIV", quick);
+    run<ROWS | NOTINY | RCP1>("ROWS+NOTINY+RCP1", quick);
+    run<ROWS | NOTINY | RCP1 | INDEXSUM>("ROWS+NOTINY+RCP1+INDEXSUM", quick);
     return 0;
 }

@@ -283,9 +283,18 @@ ZD float zcosf(float x) {
 // ---- atanf (f32 arithmetic throughout) ------------------------------------------------
 // musl atanf: five magnitude ranges, four of them reducing x by a different quotient before one shared
 // polynomial.  Distortion's overdrive calls it per sample on arbitrary signal values, so a wave's lanes sit in all
-// ranges at once; as branches every range's divide ran for every wave.  Folded like sinf: each range's numerator
-// and denominator are computed with exactly that range's operations (a handful of adds / multiplies), ONE divide
-// serves whichever the lane selects, then the shared polynomial and selects for the tails.
+// ranges at once; as branches every range's divide ran for every wave.  Round 2 folded it like sinf: each range's numerator
+// and denominator by selects, ONE divide, then the shared polynomial and selects for the tails.
+// Round 4, decided by exhaustion (tools/ubench/atan_exhaustive.hip, profiles/r04/atan_exhaustive.txt: all 2^32 arguments
+// against musl's own branchy order, 0 differing results for every step taken):
+//   * UNIFIED: the three quotient ranges as num = |x| - c, den = 1 + c |x| with c = 1/2, 1, 3/2 -- the first is musl's
+//     (2x - 1) / (2 + x) scaled by an exact 1/2 (same quotient bits), c |x| is exact for 1/2 and 1 and musl's own rounded product
+//     for 3/2 -- so one select picks c and two more the -1 / |x| range: 4 selects instead of 6;
+//   * RCP1: the divide as v_rcp_f32 and ONE residual correction of the quotient, fma(fma(-den, q, num), r, q): correctly
+//     rounded for every operand pair atanf forms (denominators in [1, 2^26]: no scaling, no fix-up) -- 4 instructions for ~10.
+// Also bit-identical but not taken: one coefficient row per range instead of selects (fast in the sweep's loop, but the rows
+// become per-lane loads from a constant table: Distortion's overdrive at 131,072 voices went 232 -> 465 us).  Rejected by the
+// sweep: each of the three polynomial fusions (34 / 2,876 / 256 differing arguments), dropping the |x| < 2^-12 early return (-0.0).
 ZD float zatanf(float x) {
     const float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f,
                 aT3 = -1.0648017377e-01f, aT4 = 6.1687607318e-02f;
@@ -293,13 +302,16 @@ ZD float zatanf(float x) {
     const bool sign = (ux >> 31) != 0;
     const float ax = fabsf(x);
     const bool r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000;   // |x| < 11/16, < 19/16, < 39/16
-    // id 0: (2x-1)/(2+x)   id 1: (x-1)/(x+1)   id 2: (x-1.5)/(1+1.5x)   id 3: -1/x
-    const float num = r1 ? (r0 ? 2.0f * ax - 1.0f : ax - 1.0f) : (r2 ? ax - 1.5f : -1.0f);
-    const float den = r1 ? (r0 ? 2.0f + ax : ax + 1.0f) : (r2 ? 1.0f + 1.5f * ax : ax);
+    // id 0: (x-1/2)/(1+x/2)   id 1: (x-1)/(1+x)   id 2: (x-3/2)/(1+3x/2)   id 3: -1/x
+    const float c = r0 ? 0.5f : (r1 ? 1.0f : 1.5f);
+    const float num = r2 ? ax - c : -1.0f;
+    const float den = r2 ? 1.0f + c * ax : ax;
     const float hi = r1 ? (r0 ? 4.6364760399e-01f : 7.8539812565e-01f) : (r2 ? 9.8279368877e-01f : 1.5707962513e+00f);
     const float lo = r1 ? (r0 ? 5.0121582440e-09f : 3.7748947079e-08f) : (r2 ? 3.4473217170e-08f : 7.5497894159e-08f);
     const bool direct = ix < 0x3ee00000;                              // |x| < 7/16: id = -1, x itself (signed)
-    const float xr = direct ? x : num / den;
+    const float rc = __builtin_amdgcn_rcpf(den);
+    const float q = num * rc;
+    const float xr = direct ? x : __builtin_fmaf(__builtin_fmaf(-den, q, num), rc, q);
     const float z = xr * xr;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * aT4));
