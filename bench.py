@@ -642,7 +642,9 @@ def traffic_record(args, V, F, kernel_hint=None):
     step; `traffic` is the kernel that moves the most bytes, the step's total goes into the source record."""
     if F != 1024:
         return None, None
-    path = os.path.join(ROOT, "profiles", "r03", f"pmc_traffic_{args.workload}{V}.json")
+    tol = "_tolerant" if getattr(args, "tolerant", False) else ""
+    path = next((p for p in (os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_{args.workload}{V}{tol}.json") for rnd in ("r04", "r03")) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r04", f"pmc_traffic_{args.workload}{V}{tol}.json"))
     if os.path.exists(path):
         rec = json.load(open(path))
         ks = rec.get("kernels", {})
@@ -676,7 +678,9 @@ def rocprof_record(args, V):
     tag = {4096: "4096", 65536: "65536", 131072: "131072", 1048576: "1M"}.get(V)
     if tag is None:
         return None
-    for rnd in ("r03", "r02", "r01"):
+    if getattr(args, "tolerant", False):
+        tag += "_tolerant"
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, f"{args.workload}{tag}_kernel_stats.csv")
         if not os.path.exists(path):
             continue

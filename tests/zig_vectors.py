@@ -215,13 +215,29 @@ def expected(name, rec):
             n = po.Noise(); L.zo_noise_init(C.byref(n), 100 + k)
             L.zo_noise_paint(C.byref(n), 0, 512, po.fptr(w[k * 512:(k + 1) * 512]), po.NOISE_WHITE)
         exp["white_seeds100to107_x512"] = w
+    elif name == "math2":
+        x = rec["sin_pio2_x"]
+        y = np.zeros_like(x)
+        L.zo_math_sinf_n(po.fptr(x), po.fptr(y), x.size); exp["sin_pio2"] = y.copy()
+        L.zo_math_cosf_n(po.fptr(x), po.fptr(y), x.size); exp["cos_pio2"] = y.copy()
+        py = rec["pow2_y"]
+        y = np.zeros_like(py)
+        L.zo_math_pow2f_n(po.fptr(py), po.fptr(y), py.size); exp["pow2"] = y.copy()
+        st = rec["rare_states"]
+        w = np.zeros(st.size, np.float32)
+        for c in range(st.size // 4):
+            n = po.Noise()
+            for q in range(4):
+                n.r[q] = int(st[c * 4 + q])
+            L.zo_noise_paint(C.byref(n), 0, 4, po.fptr(w[c * 4:c * 4 + 4]), po.NOISE_WHITE)
+        exp["rare_white"] = w
     else:
         raise KeyError("no case named %r in tests/zig_vectors.py" % name)
     return exp
 
 
 def _is_libm(name, record):
-    return record != "white_seeds100to107_x512" and any(name.startswith(p) and (r is None or r == record) for p, r in LIBM)
+    return record not in ("white_seeds100to107_x512", "rare_white") and any(name.startswith(p) and (r is None or r == record) for p, r in LIBM)
 
 
 def compare(name, rec, rtol=1e-5, floor=1e-3):
@@ -300,7 +316,41 @@ def case_inputs():
     mix = fill(F, 2400, -6, 6); mix[3] = np.nan; mix[4] = np.inf; mix[5] = -np.inf
     cases["mixdown"] = dict(mix=mix)
     cases["math"] = dict(sin_x=fill(4096, 2500, -40, 40))
+    cases["math2"] = math2_inputs()
     return cases
+
+
+def splitmix_seq(seed, n):
+    """dump_vectors.zig `splitmix(&st)` called n times from st = seed"""
+    out, st, M = [], seed, (1 << 64) - 1
+    for _ in range(n):
+        st = (st + 0x9E3779B97F4A7C15) & M
+        z = st
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        out.append(z ^ (z >> 31))
+    return out
+
+
+def math2_inputs():
+    """dump_vectors.zig mathProbes2's inputs: multiples of pi/2 at -4..+4 ulps, pow(2, .) exponents, crafted generator states."""
+    base = (np.arange(1, 456, dtype=np.float64) * 1.5707963267948966).astype(np.float32).view(np.uint32)
+    x = np.zeros(4096, np.uint32)
+    x[:4095] = (base[:, None].astype(np.int64) + np.arange(-4, 5, dtype=np.int64)[None, :]).reshape(-1).astype(np.uint32)
+    py = fill(4096, 2600, -2.5, 6.5)
+    n = 0
+    for e in range(-2, 7):
+        for q in range(4):
+            off = np.float32(1.0) / np.float32(1 << (17 + q))
+            py[n] = np.float32(e) + off; py[n + 1] = np.float32(e) - off
+            n += 2
+    sm = splitmix_seq(2700, 80)
+    st = np.zeros(160, np.uint64)
+    for c in range(40):
+        kk = c % 10
+        st[c * 4 + 1] = sm[2 * c] | 1; st[c * 4 + 2] = sm[2 * c + 1] | 1
+        st[c * 4 + 3] = (1 << kk) if kk < 9 else (1 << 41)
+    return dict(sin_pio2_x=x.view(np.float32), pow2_y=py, rare_states=st)
 
 
 def write_oracle_vectors(directory):

@@ -11,15 +11,27 @@ run() {  # name, bench args...
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu --no-parity --eager > /dev/null 2>&1
   cp $d/*/*counter_collection.csv $out/${name}_counters.csv 2>/dev/null
 }
-run nice131072 --workload nice --voices 131072 --steps 20 --warmup 4
-run nice_mix1M --workload nice_mix --voices 1048576 --steps 10 --warmup 2
-run noise_filter_fused131072 --workload noise_filter_fused --voices 131072 --steps 20 --warmup 4
+run2() {  # the second counter set of the same workload (its own pass): wave cycles, any-instruction activity, waits, LDS
+  name=$1; shift
+  d=/tmp/pmcb_$name
+  rm -rf $d
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu --no-parity --eager > /dev/null 2>&1
+  cp $d/*/*counter_collection.csv $out/${name}_counters_b.csv 2>/dev/null
+}
+run nice_mix131072 --workload nice_mix --voices 131072 --steps 48 --warmup 0 --no-rehearsal --repeats 0
+run2 nice_mix131072 --workload nice_mix --voices 131072 --steps 48 --warmup 0 --no-rehearsal --repeats 0
+run nice131072 --workload nice --voices 131072 --steps 48 --warmup 0 --no-rehearsal --repeats 0
+run nice_mix1M --workload nice_mix --voices 1048576 --steps 48 --warmup 0 --no-rehearsal --repeats 0
+run noise_filter_fused131072 --workload noise_filter_fused --voices 131072 --steps 20 --warmup 4 --no-rehearsal --repeats 0
 python3 - $out <<'PY'
 import csv, glob, json, statistics, sys, os
 out = sys.argv[1]
 res = {}
 for f in sorted(glob.glob(out + "/*_counters.csv")):
     rows = list(csv.DictReader(open(f)))
+    fb = f.replace("_counters.csv", "_counters_b.csv")
+    if os.path.exists(fb):
+        rows += list(csv.DictReader(open(fb)))
     byk = {}
     for r in rows:
         k = r["Kernel_Name"].split("(")[0]
@@ -35,6 +47,10 @@ for f in sorted(glob.glob(out + "/*_counters.csv")):
         m["cycles_per_xcd"] = gui
         m["valu_busy_pct"] = 100.0 * m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024 / gui if gui else None     # rocprof's VALUBusy, SIMD_NUM = 1024
         m["cycles_per_valu_inst_per_simd"] = gui * 1024 / m["SQ_INSTS_VALU"] if m.get("SQ_INSTS_VALU") else None
+        if m.get("SQ_WAVE_CYCLES"):
+            m["wave_cycles_waiting_pct"] = 100.0 * m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"]
+            m["wave_cycles_issuing_pct"] = 100.0 * m.get("SQ_ACTIVE_INST_ANY", 0) / m["SQ_WAVE_CYCLES"]
+            m["lds_insts_per_wave"] = m.get("SQ_INSTS_LDS", 0) / waves if waves else None
         res[os.path.basename(f).replace("_counters.csv", "") + ":" + k] = m
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -21,4 +21,7 @@ run nice_mix1M --workload nice_mix --voices 1048576 --steps 48 --warmup 48
 run script131072 --workload script --voices 131072 --steps 96 --warmup 48
 run noise_filter_fused131072 --workload noise_filter_fused --voices 131072 --steps 50 --warmup 10
 run noise_filter_fused4096 --workload noise_filter_fused
+run noise_filter_fused4096_tolerant --workload noise_filter_fused --tolerant
+run noise_filter4096_tolerant --workload noise_filter --tolerant
+run nice_mix4096 --workload nice_mix --steps 96 --warmup 48
 ls $out

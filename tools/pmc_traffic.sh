@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in WRITE_SIZE FETCH_SIZE; do
   d=/tmp/pmct_${name}_$c; rm -rf $d
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --steps $steps --warmup 0 --eager --no-cpu --no-parity --no-config5 --repeats 0 > $out/${name}_run_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --steps $steps --warmup 0 --eager --no-cpu --no-parity --no-config5 --repeats 0 --no-rehearsal > $out/${name}_run_$c.log 2>&1
 done
 python3 - $name $commit $steps "$*" $out <<'PY'
 import csv, glob, json, statistics, sys

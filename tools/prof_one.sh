@@ -28,6 +28,23 @@ def line(p):
     except Exception:
         return None
 res = {"profiled_line": line(f"{out}/{name}_bench.json"), "unprofiled_line_same_box": line(f"{out}/{name}_bench_unprofiled.json"), "kernels": ks}
+# the lines embed `roofline.rocprofv3_kernel_average`, which bench.py reads from the COMMITTED profiles -- one collection behind
+# the file written here.  Put this collection's own figure (the kernel_stats.csv beside the summary) in its place, and say so.
+try:
+    rows = list(csv.DictReader(open(f"{out}/{name}_kernel_stats.csv")))
+    top = max(rows, key=lambda r: float(r.get("TotalDurationNs", 0) or 0))
+    own = {"file": f"{name}_kernel_stats.csv (this collection)", "kernel": top.get("Name", "")[:80], "calls": int(float(top.get("Calls", 0) or 0)),
+           "average_us": float(top.get("AverageNs", 0) or 0) / 1e3}
+    for key in ("profiled_line", "unprofiled_line_same_box"):
+        if res[key] and "roofline" in res[key]:
+            res[key]["roofline"]["rocprofv3_kernel_average"] = own
+    for fn in (f"{out}/{name}_bench.json", f"{out}/{name}_bench_unprofiled.json"):
+        d = line(fn)
+        if d and "roofline" in d:
+            d["roofline"]["rocprofv3_kernel_average"] = own
+            open(fn, "w").write(json.dumps(d) + "\n")
+except Exception as e:      # noqa: BLE001
+    res["rocprofv3_kernel_average_note"] = f"not rewritten: {e}"
 json.dump(res, open(f"{out}/{name}_summary.json", "w"), indent=1)
 for k, s in sorted(ks.items(), key=lambda kv: -kv[1]["average_us"] * kv[1]["calls"])[:4]:
     print("%-70s calls %6d  avg %8.2f  min %8.2f  p50 %8.2f  p90 %8.2f  max %8.2f us" % (k[:70], s["calls"], s["average_us"], s["min_us"], s["p50_us"], s["p90_us"], s["max_us"]))

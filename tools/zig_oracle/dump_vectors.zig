@@ -540,6 +540,74 @@ fn mathProbes(dir: std.fs.Dir) !void {
     try o.f32s("white_seeds100to107_x512", &r);
 }
 
+// The three places where a restatement of Zig's std could differ silently (VERDICT r3 item 8), pinned by name:
+//   * @sin / @cos at and around multiples of pi/2 (SineOsc.zig:5): the reduction's quadrant decisions and its smallest results;
+//   * std.math.pow(f32, 2.0, y) at NON-integer y over Distortion.zig:41's range (y = ingain * 8 - 2) and a hair off the integers;
+//   * Random.float(f32)'s rare paths (Noise.zig:51): draws with 32..40 leading zeros (the general exponent form) and with 41 or
+//     more (a second draw), reached through crafted Xoshiro256 states {0, a, b, 1 << k}: next() = rotl(s0 + s3, 23) + s0.
+fn mathProbes2(dir: std.fs.Dir) !void {
+    var o = try Out.open(dir, "math2");
+    defer o.close();
+    var x: [4096]f32 = undefined;
+    var y: [4096]f32 = undefined;
+    // 455 multiples of pi/2, each at -4 .. +4 ulps (4095 values; the last slot is 0)
+    var i: usize = 0;
+    var k: u32 = 1;
+    while (k <= 455) : (k += 1) {
+        const base: f32 = @floatCast(@as(f64, @floatFromInt(k)) * 1.5707963267948966);
+        const bits: u32 = @bitCast(base);
+        var d: i32 = -4;
+        while (d <= 4) : (d += 1) {
+            x[i] = @bitCast(bits +% @as(u32, @bitCast(d)));
+            i += 1;
+        }
+    }
+    x[4095] = 0.0;
+    try o.f32s("sin_pio2_x", &x);
+    for (x, 0..) |v, j| y[j] = std.math.sin(v);
+    try o.f32s("sin_pio2", &y);
+    for (x, 0..) |v, j| y[j] = std.math.cos(v);
+    try o.f32s("cos_pio2", &y);
+    // exponents of pow(2, .): Distortion's range, and the integers -2 .. 6 at +- 2^-20 .. 2^-17 in the first 72 slots
+    fill(&x, 2600, -2.5, 6.5);
+    var n: usize = 0;
+    var e: i32 = -2;
+    while (e <= 6) : (e += 1) {
+        var q: u5 = 0;
+        while (q < 4) : (q += 1) {
+            const off: f32 = 1.0 / @as(f32, @floatFromInt(@as(u32, 1) << (17 + q)));
+            x[n] = @as(f32, @floatFromInt(e)) + off;
+            x[n + 1] = @as(f32, @floatFromInt(e)) - off;
+            n += 2;
+        }
+    }
+    try o.f32s("pow2_y", &x);
+    for (x, 0..) |v, j| y[j] = std.math.pow(f32, 2.0, v);
+    try o.f32s("pow2", &y);
+    // Random.float's rare paths: 10 values of s3 x 4 (a, b) pairs, 4 draws each
+    var states: [40 * 4]u64 = undefined;
+    var white: [40 * 4]f32 = undefined;
+    var st: u64 = 2700;
+    var c: usize = 0;
+    while (c < 40) : (c += 1) {
+        const kk: u6 = @intCast(c % 10);
+        const s3: u64 = if (kk < 9) (@as(u64, 1) << kk) else (@as(u64, 1) << 41);
+        const a = splitmix(&st) | 1;
+        const b = splitmix(&st) | 1;
+        states[c * 4 + 0] = 0;
+        states[c * 4 + 1] = a;
+        states[c * 4 + 2] = b;
+        states[c * 4 + 3] = s3;
+        var prng = std.rand.DefaultPrng.init(0);
+        prng.s = .{ 0, a, b, s3 };
+        const rnd = prng.random();
+        var d: usize = 0;
+        while (d < 4) : (d += 1) white[c * 4 + d] = rnd.float(f32) * 2.0 - 1.0;
+    }
+    try o.put("rare_states", u64, &states);
+    try o.f32s("rare_white", &white);
+}
+
 pub fn main() !void {
     var gpa = std.heap.GeneralPurposeAllocator(.{}){};
     defer _ = gpa.deinit();
@@ -561,5 +629,6 @@ pub fn main() !void {
     try instruments(dir);
     try basicsAndMixdown(dir);
     try mathProbes(dir);
+    try mathProbes2(dir);
     std.debug.print("wrote vector files to {s}\n", .{path});
 }

@@ -777,19 +777,19 @@ struct PMLane {
         step_phase(tm_i, tc_i);
         e0 = step_env();
     }
-    template <bool MAYBE_LARGE = true>
+    template <int SINMODE = 1>          // voices.hip.h sine_osc_sin: 1 musl's sinf, 0 without its rare-path branch, 2 ZH_PAINT_TOLERANT
     static __device__ __forceinline__ float value(float tm_i, float tc_i, float e0) {
-        const float m = 0.0f + sine_osc_sin<MAYBE_LARGE>(tm_i + 0.0f);     // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
+        const float m = 0.0f + sine_osc_sin<SINMODE>(tm_i + 0.0f);     // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
         const float ph = 0.0f + m * 1.0f;                              // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
-        const float c = 0.0f + sine_osc_sin<MAYBE_LARGE>(tc_i + ph);       // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
+        const float c = 0.0f + sine_osc_sin<SINMODE>(tc_i + ph);       // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
         const float osc = 0.0f + c;                                    // PhaseModOscillator output (zeroed) += temps[1]   (:75)
         return osc * e0;                                               // multiply(out, temps[0], temps[1]) :126
     }
-    template <bool MAYBE_LARGE = true>
+    template <int SINMODE = 1>
     __device__ __forceinline__ float frame() {
         float tm_i, tc_i, e0;
         step(tm_i, tc_i, e0);
-        return value<MAYBE_LARGE>(tm_i, tc_i, e0);
+        return value<SINMODE>(tm_i, tc_i, e0);
     }
     // true (wave-wide) when neither sine's argument can reach zsinf's rare path in the next `frames` frames: both phases move
     // by a constant per frame, the carrier's phase offset is a sine (|ph| <= 1); NaN compares false
@@ -819,13 +819,15 @@ __device__ __forceinline__ void pm_store(const PMLane &n, const PMOscArgs &a, ui
 // envelope stage can end, the frame is one straight-line block -- branch-free sines, and the envelope as a per-voice
 // constant (no voice of the wave inside a timed stage), without its selects (every voice inside one) or with them; every
 // other chunk takes the general frame.
-template <bool ZF>
+// TOL (ZH_PAINT_TOLERANT): both sines by zsinf_tol (zmath.hip.h) -- it looks after large arguments itself.
+template <bool ZF, bool TOL = false>
 __device__ __forceinline__ void pm_paint_frames(PMLane &n, const Img &out, uint32_t v, uint32_t f0, uint32_t f1) {
     bool flat = false;
     float e0c = 0.0f;
+    constexpr int SM_FAST = TOL ? 2 : 0, SM_ANY = TOL ? 2 : 1;
     frame_loop_gen2<8, ZF>(out.p, v, out.stride, f0, f1,
         [&](uint32_t) ZH_INLINE_LAMBDA {
-            if (!n.small_args(8.0f) || !n.env.quiet(8)) return 0;
+            if ((!TOL && !n.small_args(8.0f)) || !n.env.quiet(8)) return 0;
             flat = !zany_wave(n.env.mode == ENV_MODE_TOWARD);
             if (flat) { e0c = n.env.frame_masked_quiet(); return 1; }     // (changes nothing where no voice is in a stage)
             return __all(n.env.mode == ENV_MODE_TOWARD) ? 2 : 1;
@@ -833,26 +835,26 @@ __device__ __forceinline__ void pm_paint_frames(PMLane &n, const Img &out, uint3
         [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
             float tm_i, tc_i;
             n.step_phase(tm_i, tc_i);
-            val = PMLane::value<false>(tm_i, tc_i, flat ? e0c : n.env.frame_masked_quiet());
+            val = PMLane::value<SM_FAST>(tm_i, tc_i, flat ? e0c : n.env.frame_masked_quiet());
             return true;
         },
         [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
             float tm_i, tc_i;
             n.step_phase(tm_i, tc_i);
-            val = PMLane::value<false>(tm_i, tc_i, n.env.frame_masked_all_toward_quiet());
+            val = PMLane::value<SM_FAST>(tm_i, tc_i, n.env.frame_masked_all_toward_quiet());
             return true;
         },
-        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<true>(); return true; });
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template frame<SM_ANY>(); return true; });
 }
 
-template <bool ZF>
+template <bool ZF, bool TOL = false>
 __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint32_t start, uint32_t end) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
     if (v >= a.V) return;
     PMLane n;
     pm_load(n, a, v);
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
-    pm_paint_frames<ZF>(n, out, v, start, end);
+    pm_paint_frames<ZF, TOL>(n, out, v, start, end);
     n.end();
     pm_store(n, a, v);
 }
@@ -862,7 +864,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_pmosc(PMOscArgs a, Img out, uint3
 // frame's value is two musl sines on top of them (~150): a range REPLAYS the walk of the frames before it (step(), values
 // discarded) and then paints its own frames exactly like k_pmosc.  The range that ends the span writes the end state to
 // `next` ([6][V]), the other half of the module's double buffer (the host flips: zh_flipper).
-template <bool ZF>
+template <bool ZF, bool TOL = false>
 __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__restrict__ next, Img out, uint32_t start, uint32_t end, uint32_t ch) {
     const uint32_t v = blockIdx.x * 64 + threadIdx.x;
     if (v >= a.V) return;
@@ -887,7 +889,7 @@ __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__re
         float tm_i, tc_i, e0;
         n.step(tm_i, tc_i, e0);
     }
-    pm_paint_frames<ZF>(n, out, v, f0, f1);
+    pm_paint_frames<ZF, TOL>(n, out, v, f0, f1);
     if (f1 != end) return;
     n.end();
     const size_t V = a.V;
@@ -2042,14 +2044,20 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
         uint32_t *next = m->cnt[m->cur ^ 1];
-        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+        if (flags & ZH_PAINT_TOLERANT) {
+            if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL((k_pmosc_ranges<true, true>), grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+            else hipLaunchKernelGGL((k_pmosc_ranges<false, true>), grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+        } else if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
         else hipLaunchKernelGGL(k_pmosc_ranges<false>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
         zh_flipper_painted(m);
         m->cur ^= 1;
         m->view();
         return zh_launch_status();
     }
-    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    if (flags & ZH_PAINT_TOLERANT) {
+        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL((k_pmosc<true, true>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+        else hipLaunchKernelGGL((k_pmosc<false, true>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    } else if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
     else hipLaunchKernelGGL(k_pmosc<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
     return zh_launch_status();
 }

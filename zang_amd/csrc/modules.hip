@@ -33,7 +33,7 @@ struct zh_sineosc : zh_flipper {
     float *t() const { return reinterpret_cast<float *>(cnt[cur]); }
 };
 
-template <bool ZF, bool FB, bool PB>
+template <bool ZF, bool FB, bool PB, bool TOL = false>
 __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io, uint32_t V, Img out, uint32_t start,
                                                        uint32_t end, float sample_rate, CobP freq, CobP phase) {
     const uint32_t v = blockIdx.x * kSeqBlock + threadIdx.x;
@@ -47,7 +47,13 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
     if (PB) { ins[FB ? 1 : 0] = phase.b.p; istr[FB ? 1 : 0] = phase.b.stride; }
     o.begin(sample_rate, FB ? 0.0f : freq.c.get(v));
     const float phase_c = PB ? 0.0f : phase.c.get(v);
-    if constexpr (!FB && !PB) {
+    if constexpr (TOL) {
+        frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, start, end,
+                               [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
+            val = o.template frame<FB, 2>(FB ? x[0] : 0.0f, PB ? x[FB ? 1 : 0] : phase_c);
+            return true;
+        });
+    } else if constexpr (!FB && !PB) {
         // chunks whose arguments stay far below zsinf's Payne-Hanek range (every chunk, in practice) run the sine without its
         // rare-path branch: the eight sines of a chunk are then one basic block and interleave
         frame_loop_gen<8, ZF>(out.p, v, out.stride, start, end, [&](uint32_t) ZH_INLINE_LAMBDA { return o.small_args(phase_c, 8.0f); },
@@ -69,7 +75,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
 // range first REPLAYS those additions (one dependent add per earlier frame: cheap beside the ~50 instructions of a musl
 // sine) and then paints its own frames exactly like k_sineosc; the range that ends the span publishes the wrapped phase.
 // Every frame is written once, so `+=` paints need no scratch.  147 -> see DESIGN.md 5a at 4,096 voices.
-template <bool ZF, bool FB, bool PB>
+template <bool ZF, bool FB, bool PB, bool TOL = false>
 __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
                                                        uint32_t start, uint32_t end, uint32_t ch, float sample_rate, CobP freq, CobP phase) {
     const uint32_t v = blockIdx.x * 64 + threadIdx.x;
@@ -96,7 +102,13 @@ __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__
     if (FB) { ins[0] = freq.b.p; istr[0] = freq.b.stride; }
     if (PB) { ins[FB ? 1 : 0] = phase.b.p; istr[FB ? 1 : 0] = phase.b.stride; }
     const float phase_c = PB ? 0.0f : phase.c.get(v);
-    if constexpr (!FB && !PB) {
+    if constexpr (TOL) {
+        frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, f0, f1,
+                               [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
+            val = o.template frame<FB, 2>(FB ? x[0] : 0.0f, PB ? x[FB ? 1 : 0] : phase_c);
+            return true;
+        });
+    } else if constexpr (!FB && !PB) {
         frame_loop_gen<8, ZF>(out.p, v, out.stride, f0, f1, [&](uint32_t) ZH_INLINE_LAMBDA { return o.small_args(phase_c, 8.0f); },
             [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.template frame<false, false>(0.0f, phase_c); return true; },
             [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = o.template frame<false, true>(0.0f, phase_c); return true; });
@@ -1207,6 +1219,7 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     if (m->n == 0) return ZH_OK;
     zh_flipper_used(m);                     // a capture must know the state buffer this paint starts from, flip or not (ctx.hip)
     const bool zf = flags & ZH_PAINT_ZERO_FIRST;
+    const bool tol = (flags & ZH_PAINT_TOLERANT) != 0;                               // the sine in f32 (zmath.hip.h zsinf_tol); the phase walk is exact
     hipStream_t st = m->ctx->stream;
     const bool fb = p->freq.tag == ZH_COB_BUFFER, pb = p->phase.tag == ZH_COB_BUFFER;
     Img out = mk_img(outputs[0]);
@@ -1221,30 +1234,34 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
         const float *t_in = m->t();
         float *t_out = reinterpret_cast<float *>(m->cnt[m->cur ^ 1]);
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
-#define ZH_SINE_R(FB, PB)                                                                                           \
+#define ZH_SINE_R2(FB, PB, TOL)                                                                                     \
     do {                                                                                                            \
-        if (zf) hipLaunchKernelGGL((k_sineosc_ranges<true, FB, PB>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph); \
-        else hipLaunchKernelGGL((k_sineosc_ranges<false, FB, PB>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph);  \
+        if (zf) hipLaunchKernelGGL((k_sineosc_ranges<true, FB, PB, TOL>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph); \
+        else hipLaunchKernelGGL((k_sineosc_ranges<false, FB, PB, TOL>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph);  \
     } while (0)
+#define ZH_SINE_R(FB, PB) do { if (tol) ZH_SINE_R2(FB, PB, true); else ZH_SINE_R2(FB, PB, false); } while (0)
         if (fb && pb) ZH_SINE_R(true, true);
         else if (fb) ZH_SINE_R(true, false);
         else if (pb) ZH_SINE_R(false, true);
         else ZH_SINE_R(false, false);
 #undef ZH_SINE_R
+#undef ZH_SINE_R2
         zh_flipper_painted(m);
         m->cur ^= 1;
         return zh_launch_status();
     }
-#define ZH_SINE(FB, PB)                                                                                             \
+#define ZH_SINE2(FB, PB, TOL)                                                                                       \
     do {                                                                                                            \
-        if (zf) hipLaunchKernelGGL((k_sineosc<true, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph); \
-        else hipLaunchKernelGGL((k_sineosc<false, FB, PB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph);  \
+        if (zf) hipLaunchKernelGGL((k_sineosc<true, FB, PB, TOL>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph); \
+        else hipLaunchKernelGGL((k_sineosc<false, FB, PB, TOL>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph);  \
     } while (0)
+#define ZH_SINE(FB, PB) do { if (tol) ZH_SINE2(FB, PB, true); else ZH_SINE2(FB, PB, false); } while (0)
     if (fb && pb) ZH_SINE(true, true);
     else if (fb) ZH_SINE(true, false);
     else if (pb) ZH_SINE(false, true);
     else ZH_SINE(false, false);
 #undef ZH_SINE
+#undef ZH_SINE2
     return zh_launch_status();
 }
 

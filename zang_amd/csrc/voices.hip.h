@@ -11,8 +11,14 @@
 #include "envelope.hip.h"
 
 // ---- SineOsc (src/modules/SineOsc.zig) -----------------------------------------------------------
-template <bool MAYBE_LARGE = true>
-__device__ __forceinline__ float sine_osc_sin(float t) { return zsinf<MAYBE_LARGE>(t * 3.14159265358979323846f * 2.0f); }   // :4-6
+// SINMODE: 1 = musl's sinf for every argument, 0 = the same without its rare-path branch (the caller has checked the argument
+// range), 2 = ZH_PAINT_TOLERANT's zsinf_tol (zmath.hip.h) of the same rounded argument
+template <int SINMODE = 1>
+__device__ __forceinline__ float sine_osc_sin(float t) {
+    const float x = t * 3.14159265358979323846f * 2.0f;              // :4-6
+    if constexpr (SINMODE == 2) return zsinf_tol(x);
+    else return zsinf<SINMODE != 0>(x);
+}
 // |t| below this keeps (t * pi) * 2 below kZSinNoLargeBelow: sine_osc_sin<false> is exact
 constexpr float kSineOscSmallT = 6.0e7f;
 
@@ -23,8 +29,8 @@ struct SineOscLane {
         t_step = freq_const / sample_rate;                            // :44 (unused when freq is a buffer)
         inv_sr = 1.0f / sample_rate;                                  // :66
     }
-    template <bool FB, bool MAYBE_LARGE = true> __device__ __forceinline__ float frame(float freq_i, float phase_i) {
-        const float val = sine_osc_sin<MAYBE_LARGE>(t + phase_i);
+    template <bool FB, int SINMODE = 1> __device__ __forceinline__ float frame(float freq_i, float phase_i) {
+        const float val = sine_osc_sin<SINMODE>(t + phase_i);
         if (FB) t += freq_i * inv_sr; else t += t_step;
         return val;
     }

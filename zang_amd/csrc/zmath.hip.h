@@ -268,6 +268,30 @@ ZD float zsinf(float x) {
     return r;                                                 // (inf, nan: y = x - x from the rare path, NaN through the kernel)
 }
 
+// ZH_PAINT_TOLERANT (opt-in; include/zang_hip.h): sin(x) in f32 alone -- k = rint(x / pi), r = x - k pi by two fused steps
+// (pi as a float pair: the first step is exact, the pair is good for |k| < 2^20), the odd Taylor polynomial to r^11 on
+// [-pi/2, pi/2] (last term (pi/2)^13 / 13! = 5.7e-8), the sign from k's low bit: 17 f32 instructions for musl's 34 (15 of them
+// f64).  Within 2.4e-7 of musl's sinf of the SAME argument for |x| < 2^20 (tests/test_gpu_tolerant.py sweeps it); arguments
+// beyond, inf and nan take the exact routine (a wave-uniform branch).  What a SineOsc feeds it is the reference's own rounded
+// argument ((t + phase) * pi) * 2, so the argument's rounding -- the larger effect, 3e-5 at x = 600 -- is reproduced, not skipped.
+ZD float zsinf_tol(float x) {
+    const float inv_pi = 0.31830988618379067154f, pi_hi = 3.14159274101257324219f, pi_lo = -8.74227765734758577e-8f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(x) < 1048576.0f)) != 0, 0)) {
+        if (!(__builtin_fabsf(x) < 1048576.0f)) return zsinf<true>(x);
+    }
+    const float kf = __builtin_rintf(x * inv_pi);
+    float r = __builtin_fmaf(-kf, pi_hi, x);
+    r = __builtin_fmaf(-kf, pi_lo, r);
+    const float z = r * r;
+    float p = -2.50521083854417187751e-8f;                            // -1/11!
+    p = __builtin_fmaf(p, z, 2.75573192239858906526e-6f);             //  1/9!
+    p = __builtin_fmaf(p, z, -1.98412698412698412698e-4f);            // -1/7!
+    p = __builtin_fmaf(p, z, 8.33333333333333333333e-3f);             //  1/5!
+    p = __builtin_fmaf(p, z, -1.66666666666666666667e-1f);            // -1/3!
+    const float sv = __builtin_fmaf(r * z, p, r);
+    return zu2f(zf2u(sv) ^ ((uint32_t)(int)kf << 31));
+}
+
 template <bool MAYBE_LARGE = true>
 ZD float zcosf(float x) {
     const uint32_t ux = zf2u(x), ix = ux & 0x7fffffff;
