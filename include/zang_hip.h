@@ -58,12 +58,15 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         * unflagged paints compute theirs without keeping them, later flagged paints take the computing form.
         *
         * ZH_PAINT_TOLERANT (opt-in): the caller accepts results within 1e-5 of the signal's peak instead of the reference's bits
-        * (north_star: "1e-5 relative f32", bits only for Gate and Decimator).  Honoured by zh_filter_paint and
-        * zh_noise_filter_paint (white noise) with constant cutoff and resonance at up to 16,384 voices, where the span is then
-        * filtered as 8-32 frame chunks at once (csrc/filter_tp.hip.h: zero-state responses, a 2 x 2 transition power in f64,
-        * then the reference's own recurrence per chunk; measured error <= 2.6e-6 of the voice's peak, 2-5 x faster); ignored
-        * elsewhere (every other form stays bit-exact, and so does a tolerant paint's first chunk).  The noise samples of the
-        * fused voice and every module state's MEANING are unchanged; the filter state after the span carries the same error. */ };
+        * (north_star: "1e-5 relative f32", bits only for Gate and Decimator).  Honoured by
+        *  - zh_filter_paint and zh_noise_filter_paint (white noise) with constant cutoff and resonance at up to 16,384 voices,
+        *    where the span is then filtered as 32-128-frame chunks at once (csrc/filter_tp.hip.h: zero-state responses, a 2 x 2
+        *    transition power, then the reference's own recurrence per chunk; measured error <= 3.3e-6 of the voice's peak,
+        *    2.5-3 x faster); the noise samples and generator states are exact, the filter state carries the samples' error;
+        *  - zh_sineosc_paint and zh_pmosc_paint (its carrier) at any voice count: the sine of the reference's own rounded
+        *    argument in f32 (csrc/zmath.hip.h zsinf_tol: 17 instructions for musl's 34, 15 of them f64; within 4e-7 of it);
+        *    phase and envelope states stay exact.
+        * Ignored elsewhere: every other form stays bit-exact, and so does a tolerant Filter paint's first chunk. */ };
 
 typedef struct zh_ctx zh_ctx;
 

@@ -327,3 +327,96 @@ def test_noise_filter_tolerant_in_a_graph(ctx, oracle):
         assert [[int(x) for x in row] for row in gs["noise"]["r"]] == [list(n.r) for n in nzs]
         g.close()
         c2.close()
+
+
+# ------------------------------------------------------------------ the f32 sine (SineOsc, PMOscInstrument)
+def test_tolerant_sine_against_musl_over_its_range(ctx, oracle):
+    """zsinf_tol through a SineOsc with a phase image chosen so that (t + phase) * pi * 2 sweeps the arguments: dense over
+    |x| < 700 (the oscillators' range), sparse up to 2^20, and beyond it / inf / nan, where the exact routine takes over.  The
+    oracle is given the same images, so the argument's own rounding is the reference's: the comparison is of the sine alone."""
+    from zang_amd import modules as mod, zang
+    V, Fs = 512, 1024
+    rng = np.random.default_rng(5)
+    ph = rng.uniform(-110.0, 110.0, (V, Fs)).astype(np.float32)                    # x up to ~690
+    ph[0] = rng.uniform(-1.6e5, 1.6e5, Fs).astype(np.float32)                     # x up to ~1e6: around the 2^20 switch
+    ph[1] = (rng.uniform(-1, 1, Fs) * 1e9).astype(np.float32)                     # far beyond: exact path
+    ph[2, :8] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-30, -1e-30, 0.25]
+    ph[3] = (np.arange(Fs, dtype=np.float64) * 0.25 + rng.integers(-2, 3, Fs) * 2.0 ** -22).astype(np.float32)   # multiples of pi/2, and a hair off
+    L = oracle.lib()
+    ref = np.zeros((V, Fs), np.float32)
+    for v in range(V):
+        st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st))
+        L.zo_sineosc_paint(C.byref(st), 0, Fs, oracle.fptr(ref[v]), SR, oracle.constant(0.0), oracle.buffer(ph[v]))
+    m = mod.SineOsc(V, ctx)
+    out = ctx.image(Fs, V, fill=0.0)
+    m.paint(zang.Span(0, Fs), [out], [], False, m.Params(SR, zang.constant(0.0), zang.buffer(util.to_image(ph))), tolerant=True)
+    ctx.sync()
+    got = util.from_image(out)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        err = np.where(np.isnan(ref), 0.0, np.abs(got.astype(np.float64) - ref.astype(np.float64)))
+    assert err.max() <= 4e-7, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    util.assert_bitexact(np.nan_to_num(got[1]), np.nan_to_num(ref[1]), "beyond 2^20: the exact routine")
+
+
+@pytest.mark.parametrize("fk,pk", [("c", "c"), ("c", "b"), ("b", "c"), ("b", "b")])
+@pytest.mark.parametrize("V", [200, 40000])
+def test_sineosc_tolerant(ctx, oracle, fk, pk, V):
+    """Every param path, += and three sub-spans with carried state, a voice count that takes frame ranges and one that does
+    not: samples within 1e-5 (measured < 4e-7), the phase state bit-exact."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(77)
+    idx = np.arange(V) if V <= 256 else np.arange(0, V, 199)
+    freq = rng.uniform(20.0, 6000.0, V).astype(np.float32); phase = rng.uniform(-1, 1, V).astype(np.float32)
+    fbuf = rng.uniform(20.0, 6000.0, (V, F)).astype(np.float32); pbuf = rng.uniform(-1, 1, (V, F)).astype(np.float32)
+    out0 = util.rng_buffers(3, V, F)
+    L = oracle.lib()
+    ref = out0[idx].copy(); rt = np.zeros(len(idx), np.float32)
+    for k, v in enumerate(idx):
+        st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st))
+        for (s, e) in util.SPANS_THREE:
+            L.zo_sineosc_paint(C.byref(st), s, e, oracle.fptr(ref[k]), SR, oracle.buffer(fbuf[v]) if fk == "b" else oracle.constant(freq[v]),
+                               oracle.buffer(pbuf[v]) if pk == "b" else oracle.constant(phase[v]))
+        rt[k] = st.t
+    m = mod.SineOsc(V, ctx)
+    out = util.to_image(out0)
+    gf = zang.buffer(util.to_image(fbuf)) if fk == "b" else zang.constant(util.dev(freq))
+    gp = zang.buffer(util.to_image(pbuf)) if pk == "b" else zang.constant(util.dev(phase))
+    for (s, e) in util.SPANS_THREE:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(SR, gf, gp), tolerant=True)
+    ctx.sync()
+    got = util.from_image(out)[idx]
+    assert np.abs(got.astype(np.float64) - ref).max() <= 1e-5
+    assert np.abs(got.astype(np.float64) - ref).max() <= 1e-6, "measured bound"
+    util.assert_bitexact(m.state()["t"][idx].astype(np.float32), rt, "SineOsc t (exact in tolerant mode)")
+
+
+@pytest.mark.parametrize("V", [300, 70000])
+def test_pmosc_tolerant(ctx, oracle, V):
+    """PMOscInstrument with the carrier's sine tolerant (the modulator's stays musl's: csrc/composite.hip PMLane::value says why)
+    over a note script with retrigger and release: samples within 1e-5 of the oracle, phases and envelope state bit-exact."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(78)
+    idx = np.arange(V) if V <= 512 else np.arange(0, V, 331)
+    freq = rng.uniform(50.0, 3000.0, V).astype(np.float32)
+    rel = rng.uniform(0.05, 1.0, V).astype(np.float32)
+    script = [((0, 1024), True, True), ((0, 1024), True, False), ((0, 500), False, False), ((500, 1024), True, True), ((0, 1024), False, False)]
+    L = oracle.lib()
+    sts = []
+    for v in idx:
+        st = oracle.PMOscInstrument(); L.zo_pmosc_init(C.byref(st), float(rel[v])); sts.append(st)
+    m = mod.PMOscInstrument(V, util.dev(rel), ctx)
+    gf = util.dev(freq)
+    t = [np.zeros(F, np.float32) for _ in range(3)]
+    for ((s, e), on, nic) in script:
+        ref = np.zeros((len(idx), F), np.float32)
+        for k, v in enumerate(idx):
+            L.zo_pmosc_paint(C.byref(sts[k]), s, e, oracle.fptr(ref[k]), oracle.fptr(t[0]), oracle.fptr(t[1]), oracle.fptr(t[2]), int(nic), SR, float(freq[v]), int(on))
+        out = ctx.image(F, V, fill=0.0)
+        m.paint(zang.Span(s, e), [out], None, nic, m.Params(SR, gf, on), tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)[idx]
+        assert np.abs(got.astype(np.float64) - ref).max() <= 1e-5, ((s, e), np.abs(got.astype(np.float64) - ref).max())
+    gs = m.state()
+    util.assert_bitexact(gs["carrier"]["t"][idx].astype(np.float32), np.array([r.carrier.t for r in sts], np.float32), "carrier t")
+    util.assert_bitexact(gs["modulator"]["t"][idx].astype(np.float32), np.array([r.modulator.t for r in sts], np.float32), "modulator t")

@@ -37,6 +37,8 @@ def case(name, m, paint, reads=0):
 
 m = mod.SineOsc(V, ctx); case("SineOsc const freq / const phase", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), zang.constant(0.0)), zero_first=True))
 m = mod.SineOsc(V, ctx); case("SineOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), zang.constant(0.0)), zero_first=True), 1)
+m = mod.SineOsc(V, ctx); case("SineOsc const / const, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), zang.constant(0.0)), zero_first=True, tolerant=True))
+m = mod.SineOsc(V, ctx); case("SineOsc freq image, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), zang.constant(0.0)), zero_first=True, tolerant=True), 1)
 m = mod.PulseOsc(V, ctx); case("PulseOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
 m = mod.PulseOsc(V, ctx); case("PulseOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
 m = mod.TriSawOsc(V, ctx); case("TriSawOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
@@ -59,6 +61,9 @@ m = mod.Distortion(V, ctx); case("Distortion clip", m, lambda o, m=m: m.paint(sp
 m = mod.NiceInstrument(V, color, ctx); case("NiceInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, freq, True), zero_first=True))
 rel = torch.full((V,), 0.3, dtype=torch.float32, device=dev)
 m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True))
+m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument, ZH_PAINT_TOLERANT (carrier)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True, tolerant=True))
+if V <= 16384:
+    m = mod.Filter(V, ctx); case("Filter low-pass const, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.low_pass, zang.constant(cutoff), zang.constant(res)), zero_first=True, tolerant=True), 1)
 
 m = mod.SimpleDelay(V, 300, ctx); case("SimpleDelay(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp), zero_first=True), 3)
 m = mod.FilteredEchoes(V, 300, ctx); case("FilteredEchoes(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True), 3)

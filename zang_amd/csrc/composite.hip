@@ -777,11 +777,15 @@ struct PMLane {
         step_phase(tm_i, tc_i);
         e0 = step_env();
     }
-    template <int SINMODE = 1>          // voices.hip.h sine_osc_sin: 1 musl's sinf, 0 without its rare-path branch, 2 ZH_PAINT_TOLERANT
+    // SINMODE (voices.hip.h sine_osc_sin): 1 musl's sinf, 0 without its rare-path branch; + 2 = ZH_PAINT_TOLERANT: the CARRIER's
+    // sine in f32.  The modulator's stays musl's: its value is added to the carrier's phase BEFORE that sum is rounded to f32, and
+    // with the phase at 64 (a 3 kHz note at the end of a buffer) one ulp of the sum is 4.8e-5 of a cycle's argument -- a modulator
+    // off by 3e-7 flips that rounding for 4 % of the samples (tests/test_gpu_tolerant.py measured 5e-5 before this was kept exact).
+    template <int SINMODE = 1>
     static __device__ __forceinline__ float value(float tm_i, float tc_i, float e0) {
-        const float m = 0.0f + sine_osc_sin<SINMODE>(tm_i + 0.0f);     // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
+        const float m = 0.0f + sine_osc_sin<(SINMODE & 1)>(tm_i + 0.0f);   // modulator.paint -> temps[1] (zeroed): sin(t + 0.0)
         const float ph = 0.0f + m * 1.0f;                              // temps[0] = 0 + temps[1] * multiplier (1.0)   (:64-66)
-        const float c = 0.0f + sine_osc_sin<SINMODE>(tc_i + ph);       // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
+        const float c = 0.0f + sine_osc_sin<(SINMODE & 2) ? 2 : SINMODE>(tc_i + ph);   // carrier.paint -> temps[1] (zeroed): sin(t + phase[i])
         const float osc = 0.0f + c;                                    // PhaseModOscillator output (zeroed) += temps[1]   (:75)
         return osc * e0;                                               // multiply(out, temps[0], temps[1]) :126
     }
@@ -819,15 +823,15 @@ __device__ __forceinline__ void pm_store(const PMLane &n, const PMOscArgs &a, ui
 // envelope stage can end, the frame is one straight-line block -- branch-free sines, and the envelope as a per-voice
 // constant (no voice of the wave inside a timed stage), without its selects (every voice inside one) or with them; every
 // other chunk takes the general frame.
-// TOL (ZH_PAINT_TOLERANT): both sines by zsinf_tol (zmath.hip.h) -- it looks after large arguments itself.
+// TOL (ZH_PAINT_TOLERANT): the carrier's sine by zsinf_tol (zmath.hip.h); see PMLane::value.
 template <bool ZF, bool TOL = false>
 __device__ __forceinline__ void pm_paint_frames(PMLane &n, const Img &out, uint32_t v, uint32_t f0, uint32_t f1) {
     bool flat = false;
     float e0c = 0.0f;
-    constexpr int SM_FAST = TOL ? 2 : 0, SM_ANY = TOL ? 2 : 1;
+    constexpr int SM_FAST = TOL ? 2 : 0, SM_ANY = TOL ? 3 : 1;
     frame_loop_gen2<8, ZF>(out.p, v, out.stride, f0, f1,
         [&](uint32_t) ZH_INLINE_LAMBDA {
-            if ((!TOL && !n.small_args(8.0f)) || !n.env.quiet(8)) return 0;
+            if (!n.small_args(8.0f) || !n.env.quiet(8)) return 0;
             flat = !zany_wave(n.env.mode == ENV_MODE_TOWARD);
             if (flat) { e0c = n.env.frame_masked_quiet(); return 1; }     // (changes nothing where no voice is in a stage)
             return __all(n.env.mode == ENV_MODE_TOWARD) ? 2 : 1;

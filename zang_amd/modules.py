@@ -99,9 +99,10 @@ class SineOsc(_Module):
         freq: Any   # zang.constant(...) | zang.buffer(...)
         phase: Any
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT -- the sine in f32 (within 1e-5 of the peak, measured 3e-7); the phase state stays exact."""
         cp = abi.SineOscParams(params.sample_rate, 0, params.freq, params.phase)
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
 
 class PulseOsc(_Module):
@@ -516,9 +517,10 @@ class PMOscInstrument(_Module):
     def init(cls, n_voices, release_duration, ctx=None):
         return cls(n_voices, release_duration, ctx)
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT -- the carrier's sine in f32; phases and envelope state stay exact."""
         cp = abi.PMOscParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
     def paint_spans(self, span, outputs, temps, sample_rate, table, zero_first=False):
         """Render every voice's Trigger sub-spans of this buffer in one launch (zang_amd.spans.SpanTable)."""
