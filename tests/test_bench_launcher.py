@@ -151,3 +151,23 @@ def test_preflight_fails_with_its_own_exit_code_without_a_gpu():
     assert r.returncode == 5, r.stdout[-2000:] + r.stderr[-2000:]
     d = _last_json(r.stdout)["preflight"]
     assert d["ok"] is False and d["ranks"][0]["ok"] is False and "no HIP device" in d["ranks"][0]["error"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_the_drivers_own_command_line_for_n_ranks_on_a_gpu_box():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2
+    --steps 20 --warmup 5` -- the driver's launch form for N > 1 -- with the two ranks emulated on the box's one GPU: rank 0
+    prints exactly one JSON line with the whole N > 1 structure, the other rank prints nothing on stdout, exit code 0."""
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--voices", "8192"],
+                       env=_env(ZH_BENCH_EMULATE="1"), capture_output=True, text=True, timeout=540, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["steps_requested"] == 20 and d["warmup"] == 5 and d["value"] > 0
+    for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "collective",
+                "single_gpu_shard", "scaling_factor", "parity", "build"):
+        assert key in d, key
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["config"]["workload"].startswith("nice_mix")
+    assert d["collective"]["world_size_seen"] == 2 and d["parity"]["bitexact"] is True

@@ -420,3 +420,61 @@ def test_pmosc_tolerant(ctx, oracle, V):
     gs = m.state()
     util.assert_bitexact(gs["carrier"]["t"][idx].astype(np.float32), np.array([r.carrier.t for r in sts], np.float32), "carrier t")
     util.assert_bitexact(gs["modulator"]["t"][idx].astype(np.float32), np.array([r.modulator.t for r in sts], np.float32), "modulator t")
+
+
+# ------------------------------------------------------------------ NiceInstrument (the fused Osc + Env + Filter voice) at few voices
+NICE_SCRIPT = [((0, 1024), 1, 1), ((0, 1024), 1, 0), ((0, 500), 1, 0), ((500, 1024), 0, 0), ((0, 1024), 0, 0),
+               ((0, 300), 0, 0), ((300, 1024), 1, 1), ((0, 1024), 1, 0), ((0, 90), 1, 0)]          # (the last span is under 128 frames: exact form)
+
+
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("V", [300, 4096, 16384])
+def test_nice_tolerant(ctx, oracle, V, zero_first):
+    """k_nice_tp_a / _b against the oracle's unfused composition over a note script (attack, decay, sustain, release, retrigger,
+    sub-spans; silent voices): samples within 1e-5 of the voice's peak, the first chunk bit-exact, oscillator counter and envelope
+    state bit-exact after every paint, filter state within the samples' tolerance."""
+    from zang_amd import modules as mod, zang, workloads
+    freq, color, _, _ = workloads.voice_params(5, 0, V)
+    freq[:3] = [7000.0, -3.0, 0.5]          # silent / silent / very low
+    idx = np.arange(V) if V <= 512 else np.unique(np.concatenate([np.arange(0, V, 97), [0, 1, 2, V - 1]]))
+    L = oracle.lib()
+    sts = []
+    for v in idx:
+        st = oracle.NiceInstrument(); L.zo_nice_init(C.byref(st), float(color[v])); sts.append(st)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    m = mod.NiceInstrument(V, util.dev(color), ctx)
+    gf = util.dev(freq)
+    base = util.rng_buffers(21, V, F)
+    G = (V + 63) // 64
+    Cn = max(2, min(32, (2048 + G - 1) // G))
+    for k, ((s, e), on, nic) in enumerate(NICE_SCRIPT):
+        ref = base[idx].copy()
+        if zero_first:
+            ref[:, s:e] = 0.0
+        for q, v in enumerate(idx):
+            L.zo_nice_paint(C.byref(sts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), nic, SR, float(freq[v]), on)
+        out = util.to_image(base)
+        m.paint(zang.Span(s, e), [out], None, bool(nic), m.Params(SR, gf, bool(on)), zero_first=zero_first, tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)[idx]
+        tag = f"nice tolerant V={V} paint {k} span {(s, e)}"
+        if e - s < 128:
+            util.assert_bitexact(got, ref, tag + " (short span: exact form)")
+        else:
+            Lc = (((e - s) + min(Cn, e - s) - 1) // min(Cn, e - s) + 7) // 8 * 8
+            util.assert_bitexact(got[:, s:s + Lc], ref[:, s:s + Lc], tag + " first chunk")
+            rl = np.array([r.flt.l for r in sts], np.float32); rb = np.array([r.flt.b for r in sts], np.float32)
+            util.assert_peak_close(got, ref, tag, s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb)))
+        st = m.state()
+        assert [int(x) for x in st["osc"]["cnt"][idx]] == [r.osc.cnt for r in sts], tag
+        assert [int(x) for x in st["env"]["state"][idx]] == [r.env.state for r in sts], tag
+        util.assert_bitexact(st["env"]["t"][idx].astype(np.float32), np.array([r.env.painter.t for r in sts], np.float32), tag + " env t")
+        util.assert_bitexact(st["env"]["last_value"][idx].astype(np.float32), np.array([r.env.painter.last_value for r in sts], np.float32), tag + " env last_value")
+        util.assert_bitexact(st["env"]["start"][idx].astype(np.float32), np.array([r.env.painter.start for r in sts], np.float32), tag + " env start")
+        rl = np.array([r.flt.l for r in sts], np.float64); rb = np.array([r.flt.b for r in sts], np.float64)
+        scale = np.maximum(np.maximum(np.abs(rl), np.abs(rb)), 1e-3)
+        assert (np.abs(st["flt"]["l"][idx] - rl) <= 2e-5 * scale).all() and (np.abs(st["flt"]["b"][idx] - rb) <= 2e-5 * scale).all(), tag + " filter state"
+        # carry the reference's filter state on (the tolerance is per paint)
+        for q, v in enumerate(idx):
+            st["flt"]["l"][v] = sts[q].flt.l; st["flt"]["b"][v] = sts[q].flt.b
+        m.set_state(st)

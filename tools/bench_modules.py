@@ -59,6 +59,8 @@ m = mod.Decimator(V, ctx); case("Decimator", m, lambda o, m=m: m.paint(span, [o]
 m = mod.Distortion(V, ctx); case("Distortion overdrive", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.overdrive, 0.5, 0.5, 0.0), zero_first=True), 1)
 m = mod.Distortion(V, ctx); case("Distortion clip", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.clip, 0.5, 0.5, 0.0), zero_first=True), 1)
 m = mod.NiceInstrument(V, color, ctx); case("NiceInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, freq, True), zero_first=True))
+if V <= 16384:
+    m = mod.NiceInstrument(V, color, ctx); case("NiceInstrument, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, freq, True), zero_first=True, tolerant=True))
 rel = torch.full((V,), 0.3, dtype=torch.float32, device=dev)
 m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True))
 m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument, ZH_PAINT_TOLERANT (carrier)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True, tolerant=True))

@@ -37,6 +37,7 @@ struct zh_nice {
     float *fl, *fb;               // flt
     uint32_t *estate;             // env
     float *et, *elast, *estart;
+    uint32_t *tp;                 // ZH_PAINT_TOLERANT scratch (k_nice_tp_a / _b), allocated by the first tolerant paint outside a capture
 };
 
 // The six state words per voice (carrier.t, modulator.t, envelope {state, t, last_value, start}) are one [6][n] block, double-
@@ -726,6 +727,131 @@ __global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, u
         nice_mix_frames<C, ROLL, WG>(n, roll, g2, tile, partials + (size_t)k * C * channel_stride, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
     }
     if (live) nice_store(n, a, v);
+}
+
+// ------------------------------------------------------------------ NiceInstrument, ZH_PAINT_TOLERANT (few voices)
+// The time-parallel Filter of filter_tp.hip.h inside the fused voice: the oscillator's counter at any frame is exact integer
+// arithmetic (cnt + j * ifreq), the filter's parameters are constant over a paint (cutoffFromFrequency(freq * 8), res 0.7), so a
+// chunk can compute its filter's zero-state response on its own (pass A) and, after the scan, run the reference's own frame from
+// the chunk's start state (pass B).  The envelope is a clock and a state machine that depend on nothing but time: the chunk-0
+// lane of every voice walks it over the WHOLE span once in pass A (eight clock steps and one curve evaluation per quiet chunk,
+// frame by frame around a stage end) and leaves its four state words at every chunk boundary -- one walk of the span per voice
+// instead of one replay per chunk.  Pass B re-derives the running stage from those words (EnvLaneT::resolve: a function of the
+// state, the clock and the params).  Oscillator, envelope and both their states are exact; the filter and the product carry the
+// tolerant Filter's error (<= 1e-5 of the voice's peak, measured ~1e-6).
+// Scratch words per voice: 7 (the state at span start: pass B's lanes load it while the last chunk's lane stores the live arrays)
+// + 4 per chunk (envelope) + 2 per chunk + 2 (filter e_j, slot 0 = start state).
+constexpr uint32_t kNiceTpMaxChunks = kTpMaxChunks;
+constexpr uint32_t kNiceTpWords = 7 + 4 * kNiceTpMaxChunks + 2 * (kNiceTpMaxChunks + 1);
+struct NiceTpArgs {
+    NiceArgs a;                  // the live state arrays + params
+    uint32_t *tp;                // [kNiceTpWords][V]
+    uint32_t start, end, L;
+    Img out;
+};
+__device__ __forceinline__ uint32_t *nice_tp_state0(const NiceTpArgs &t, uint32_t w) { return t.tp + (size_t)w * t.a.V; }
+__device__ __forceinline__ uint32_t *nice_tp_env(const NiceTpArgs &t, uint32_t j, uint32_t w) { return t.tp + (size_t)(7 + 4 * j + w) * t.a.V; }
+__device__ __forceinline__ float2 *nice_tp_e(const NiceTpArgs &t, uint32_t slot) {
+    return reinterpret_cast<float2 *>(t.tp + (size_t)(7 + 4 * kNiceTpMaxChunks) * t.a.V) + (size_t)slot * t.a.V;
+}
+__device__ __forceinline__ void nice_tp_put_env(const NiceTpArgs &t, uint32_t j, uint32_t v, const NiceLane &n) {
+    nice_tp_env(t, j, 0)[v] = n.env.state; nice_tp_env(t, j, 1)[v] = __builtin_bit_cast(uint32_t, n.env.t);
+    nice_tp_env(t, j, 2)[v] = __builtin_bit_cast(uint32_t, n.env.last_value); nice_tp_env(t, j, 3)[v] = __builtin_bit_cast(uint32_t, n.env.start);
+}
+
+// grid: x = 256-voice groups, y = chunk; block = 256
+__global__ void __launch_bounds__(256) k_nice_tp_a(const NiceTpArgs t) {
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    const NiceArgs &a = t.a;
+    if (v >= a.V) return;
+    NiceLane n;
+    nice_load(n, a, v);                                                // the span's start state, begin() with this paint's params
+    const uint32_t cnt0 = n.cnt;
+    const uint32_t f0 = min(t.start + j * t.L, t.end), f1 = min(f0 + t.L, t.end);
+    if (j == 0) {
+        // the start state as the paint found it (before begin()): what pass B's lanes begin() from
+        nice_tp_state0(t, 0)[v] = a.cnt[v]; nice_tp_state0(t, 1)[v] = __builtin_bit_cast(uint32_t, a.fl[v]); nice_tp_state0(t, 2)[v] = __builtin_bit_cast(uint32_t, a.fb[v]);
+        nice_tp_state0(t, 3)[v] = a.estate[v]; nice_tp_state0(t, 4)[v] = __builtin_bit_cast(uint32_t, a.et[v]);
+        nice_tp_state0(t, 5)[v] = __builtin_bit_cast(uint32_t, a.elast[v]); nice_tp_state0(t, 6)[v] = __builtin_bit_cast(uint32_t, a.estart[v]);
+        nice_tp_e(t, 0)[v] = make_float2(n.l, n.b);
+    }
+    // the filter's zero-state response over this chunk's oscillator samples
+    float l = 0.0f, b = 0.0f;
+    uint32_t c = cnt0 + (f0 - t.start) * n.k.ifreq;                    // exact: the counter of frame f0 (a silent voice's ifreq is 0)
+#pragma unroll 8
+    for (uint32_t f = f0; f < f1; f++) {
+        svf_step(l, b, n.osc(c), n.cut, n.res);                        // NiceLane::tail_filter's recurrence
+        c += n.k.ifreq;
+    }
+    nice_tp_e(t, j + 1)[v] = make_float2(l, b);
+    if (j != 0) return;
+    // the envelope over the whole span, its state left at every chunk boundary (the first chunk's is begin()'s own)
+    nice_tp_put_env(t, 0, v, n);
+    const uint32_t nchunks = (t.end - t.start + t.L - 1) / t.L;
+    for (uint32_t q = 1; q < nchunks; q++) {
+        uint32_t i = 0;
+        for (; i + 8 <= t.L; i += 8) {
+            if (n.env.quiet(8)) n.env.template skip_quiet<8>();
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) (void)n.env.frame_masked();
+            }
+        }
+        for (; i < t.L; i++) (void)n.env.frame_masked();
+        nice_tp_put_env(t, q, v, n);
+    }
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_nice_tp_b(const NiceTpArgs t) {
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    const NiceArgs &a = t.a;
+    if (v >= a.V) return;
+    const uint32_t f0 = min(t.start + j * t.L, t.end), f1 = min(f0 + t.L, t.end);
+    if (f1 == f0) return;
+    NiceArgs a0 = a;                                                   // load from the copy pass A made of the start state
+    a0.cnt = nice_tp_state0(t, 0); a0.fl = reinterpret_cast<float *>(nice_tp_state0(t, 1)); a0.fb = reinterpret_cast<float *>(nice_tp_state0(t, 2));
+    a0.estate = nice_tp_state0(t, 3); a0.et = reinterpret_cast<float *>(nice_tp_state0(t, 4));
+    a0.elast = reinterpret_cast<float *>(nice_tp_state0(t, 5)); a0.estart = reinterpret_cast<float *>(nice_tp_state0(t, 6));
+    NiceLane n;
+    nice_load(n, a0, v);
+    n.cnt = n.cnt + (f0 - t.start) * n.k.ifreq;
+    {   // the filter's state at the chunk's first frame
+        const float2 s0 = nice_tp_e(t, 0)[v];
+        n.l = s0.x; n.b = s0.y;
+        const float2 *e = nice_tp_e(t, 1) + v;
+        const size_t V = a.V;
+        svf_scan<kNiceTpMaxChunks - 1>(n.l, n.b, n.cut, n.res, t.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return e[(size_t)i * V]; });
+    }
+    // the envelope at the chunk's first frame: the four state words of pass A's walk, the running stage re-derived from them
+    n.env.state = nice_tp_env(t, j, 0)[v]; n.env.t = __builtin_bit_cast(float, nice_tp_env(t, j, 1)[v]);
+    n.env.last_value = __builtin_bit_cast(float, nice_tp_env(t, j, 2)[v]); n.env.start = __builtin_bit_cast(float, nice_tp_env(t, j, 3)[v]);
+    n.env.resolve(true);
+    n.env.refresh_derived();
+    // the frames, exactly as k_nice paints them
+    PulseRoll roll;
+    n.roll_begin(roll);
+    bool flat = false;
+    float e0c = 0.0f;
+    frame_loop_gen2<8, ZF>(t.out.p, v, t.out.stride, f0, f1,
+        [&](uint32_t) ZH_INLINE_LAMBDA {
+            flat = !zany_wave(n.env.mode == ENV_MODE_TOWARD);
+            if (flat) { e0c = n.env_quiet(); return 1; }
+            if (!n.env.quiet(8)) return 0;
+            return __all(n.env.mode == ENV_MODE_TOWARD) ? 2 : 1;
+        },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+            const float t1 = n.template tail_filter<ZF>(n.osc_next(roll));
+            val = (flat ? e0c : n.env.frame_masked_quiet()) * t1;
+            return true;
+        },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA {
+            const float t1 = n.template tail_filter<ZF>(n.osc_next(roll));
+            val = n.env.frame_masked_all_toward_quiet() * t1;
+            return true;
+        },
+        [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template tail<ZF>(n.osc_next(roll)); return true; });
+    if (f1 == t.end) nice_store(n, a, v);                              // whoever painted the span's last frame leaves the states
 }
 
 // ------------------------------------------------------------------ PMOscInstrument voice
@@ -1574,6 +1700,7 @@ static NiceArgs nice_args(zh_nice *m, const zh_nice_params *p, zh_bool nic) {
 static void nice_free(zh_nice *m) {
     (void)hipFree(m->color); (void)hipFree(m->cnt); (void)hipFree(m->fl); (void)hipFree(m->fb);
     (void)hipFree(m->estate); (void)hipFree(m->et); (void)hipFree(m->elast); (void)hipFree(m->estart);
+    (void)hipFree(m->tp);
 }
 static void pmosc_free(zh_pmosc *m) { (void)hipFree(m->release_duration); (void)hipFree(m->cnt[0]); (void)hipFree(m->cnt[1]); }
 
@@ -1584,7 +1711,7 @@ int zh_nice_create(zh_ctx *ctx, uint32_t n, zh_f32 color, zh_nice **out) { ZH_GU
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_nice *m = new (std::nothrow) zh_nice();
     if (!m) return ZH_ERR_INVALID;
-    *m = zh_nice{ctx, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    *m = zh_nice{ctx, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int rc = dev_alloc(&m->color, n);
     if (!rc) rc = dev_alloc(&m->cnt, n);
     if (!rc) rc = dev_alloc(&m->fl, n);
@@ -1656,6 +1783,20 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     NiceArgs a = nice_args(m, p, note_id_changed);
     const Img out = mk_img(outputs[0]);
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
+    // ZH_PAINT_TOLERANT, few voices: the span as chunks at once, two passes (k_nice_tp_a / _b); spans of one launch pair
+    if ((flags & ZH_PAINT_TOLERANT) && end - start >= 128 && end - start <= kNiceTpMaxChunks * 128u) {
+        const uint32_t C = zh_tp_chunks(m->n, "ZH_NICE_TP_MAX", end - start);
+        if (C >= 2 && !m->tp && !m->ctx->capturing && dev_alloc(&m->tp, (size_t)kNiceTpWords * m->n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
+        if (C >= 2 && m->tp) {
+            NiceTpArgs t;
+            t.a = a; t.tp = m->tp; t.start = start; t.end = end; t.L = ((end - start + C - 1) / C + 7) / 8 * 8; t.out = out;   // whole 8-frame groups per chunk
+            const dim3 grid((m->n + 255) / 256, (end - start + t.L - 1) / t.L);
+            hipLaunchKernelGGL(k_nice_tp_a, grid, dim3(256), 0, st, t);
+            if (zf) hipLaunchKernelGGL(k_nice_tp_b<true>, grid, dim3(256), 0, st, t);
+            else hipLaunchKernelGGL(k_nice_tp_b<false>, grid, dim3(256), 0, st, t);
+            return zh_launch_status();
+        }
+    }
     if (nice_pairable(a) && aligned8(out.p) && out.stride % 2 == 0) {
         const dim3 grid = seq_grid(m->n / 2);
         if (zf) hipLaunchKernelGGL((k_nice<true, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);

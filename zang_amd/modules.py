@@ -373,9 +373,11 @@ class NiceInstrument(_Module):
     def init(cls, n_voices, color, ctx=None):
         return cls(n_voices, color, ctx)
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT -- few voices: the filter as chunks at once (1e-5 of the voice's peak); oscillator and
+        envelope, and their states, stay exact."""
         cp = abi.NiceParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
     def paint_spans(self, span, outputs, temps, sample_rate, table, zero_first=False):
         """Render every voice's Trigger sub-spans of this buffer in one launch (zang_amd.spans.SpanTable)."""
