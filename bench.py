@@ -88,7 +88,7 @@ def parse(argv=None):
                          "(zh_ipc_alloc / zh_ipc_open / peer store / zh_sum_slots); prints pass/fail per rank as one JSON line; exit code "
                          "%d on any failure" % PREFLIGHT_FAILED)
     ap.add_argument("--tolerant", action="store_true",
-                    help="noise_filter / noise_filter_fused: paint with ZH_PAINT_TOLERANT (opt-in time-parallel Filter forms, 1e-5 of the "
+                    help="noise_filter / noise_filter_fused / nice: paint with ZH_PAINT_TOLERANT (opt-in time-parallel Filter forms, 1e-5 of the "
                          "signal's peak instead of bits; csrc/filter_tp.hip.h); the line says so in config.tolerant")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
@@ -309,6 +309,8 @@ class Workload:
             self.m = mod.NiceInstrument(V, self.color, ctx)
             self.ring = [ctx.image(F, V, pad=pad) for _ in range(nring)]
             self.kernel = "k_nice_pc4" if V <= 32768 else ("k_nice_pc" if V <= 65536 else "k_nice")     # the library's choice by voice count
+            if self.tolerant and V <= 16384:
+                self.kernel = "k_nice_tp_b"
             self.step = self._step_nice
             self.nsteps = 0
         else:
@@ -389,7 +391,7 @@ class Workload:
 
     def _step_nice(self):
         on, new = self._note_on()
-        self.m.paint(self.span, [self._next()], [], new, self.m.Params(SR, self.freq, on), zero_first=True)
+        self.m.paint(self.span, [self._next()], [], new, self.m.Params(SR, self.freq, on), zero_first=True, tolerant=self.tolerant)
 
     def _step_script(self):
         on, new = self._note_on()

@@ -96,6 +96,27 @@ def main():
             ctx.sync()
             show(f"Noise->Filter, {V} voices, buffer {p + 1} (states carried by the GPU)", util.from_image(out), ref)
 
+    # NiceInstrument at few voices: a note script, states carried by the GPU
+    for V in (4096, 16384):
+        from zang_amd import workloads
+        freq, color, _, _ = workloads.voice_params(5, 0, V)
+        idx = np.arange(0, V, max(1, V // 512))
+        sts = []
+        for v in idx:
+            st = oracle.NiceInstrument(); L.zo_nice_init(C.byref(st), float(color[v])); sts.append(st)
+        m = mod.NiceInstrument(V, util.dev(color), ctx)
+        gf = util.dev(freq)
+        t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+        for k, (on, nic, what) in enumerate([(1, 1, "attack + decay"), (1, 0, "sustain"), (0, 0, "release"), (0, 0, "release, idle"), (1, 1, "retrigger")]):
+            ref = np.zeros((len(idx), F), np.float32)
+            for q, v in enumerate(idx):
+                L.zo_nice_paint(C.byref(sts[q]), 0, F, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), nic, SR, float(freq[v]), on)
+            out = ctx.image(F, V)
+            m.paint(zang.Span(0, F), [out], None, bool(nic), m.Params(SR, gf, bool(on)), zero_first=True, tolerant=True)
+            ctx.sync()
+            rl = np.array([r.flt.l for r in sts], np.float32); rb = np.array([r.flt.b for r in sts], np.float32)
+            show(f"NiceInstrument, {V} voices, buffer {k + 1}: {what} (states carried by the GPU)", util.from_image(out)[idx], ref, np.maximum(np.abs(rl), np.abs(rb)))
+
 
 if __name__ == "__main__":
     main()

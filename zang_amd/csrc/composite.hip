@@ -789,15 +789,22 @@ __global__ void __launch_bounds__(256) k_nice_tp_a(const NiceTpArgs t) {
     nice_tp_put_env(t, 0, v, n);
     const uint32_t nchunks = (t.end - t.start + t.L - 1) / t.L;
     for (uint32_t q = 1; q < nchunks; q++) {
-        uint32_t i = 0;
-        for (; i + 8 <= t.L; i += 8) {
-            if (n.env.quiet(8)) n.env.template skip_quiet<8>();
-            else {
+        // no voice of the wave inside a timed stage (a held note's sustain, an idle voice): a chunk of frames changes nothing;
+        // no stage can end within the chunk: the clocks step, one curve evaluation per eight frames, no test in between;
+        // else eight frames at a time with the test, frame by frame around a stage end
+        if (zany_wave(n.env.mode == ENV_MODE_TOWARD)) {
+            if (n.env.quiet((int)t.L)) {
+                for (uint32_t i = 0; i < t.L; i += 8) n.env.template skip_quiet<8>();
+            } else {
+                for (uint32_t i = 0; i < t.L; i += 8) {
+                    if (n.env.quiet(8)) n.env.template skip_quiet<8>();
+                    else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) (void)n.env.frame_masked();
+                        for (int k = 0; k < 8; k++) (void)n.env.frame_masked();
+                    }
+                }
             }
         }
-        for (; i < t.L; i++) (void)n.env.frame_masked();
         nice_tp_put_env(t, q, v, n);
     }
 }
@@ -2045,7 +2052,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
         const uint32_t Cw = zh_tp_chunks(m->n, "ZH_NF_TP_MAX", 1024);                  // chunks wanted for a 1,024-frame buffer
         const uint4 *tables = Cw >= 2 ? zh_noise_jump_tables(m->ctx) : nullptr;
         if (tables && !m->tp_cs && !m->ctx->capturing) {
-            int arc = dev_alloc(&m->tp_cs, (size_t)kNfTpMaxChunks * 4 * m->n);
+            int arc = dev_alloc(&m->tp_cs, (size_t)(kNfTpMaxChunks + 1) * 4 * m->n);     // + the state after the span (parked-noise form)
             if (!arc) arc = dev_alloc(&m->tp_e, (size_t)(kNfTpMaxChunks + 1) * m->n);
             if (!arc) arc = dev_alloc(&m->tp_flag, m->n);
             if (!arc) arc = (int)hipMemsetAsync(m->tp_flag, 0, (size_t)m->n * 4, st);
@@ -2065,9 +2072,13 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
                 if (++m->tp_serial == 0) m->tp_serial = 1;
                 a.serial = m->tp_serial;
                 const dim3 grid((m->n + 255) / 256, a.C);
-                hipLaunchKernelGGL(k_nf_tp_a, grid, dim3(256), 0, st, a);
-                if (zf) hipLaunchKernelGGL(k_nf_tp_b<true>, grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL(k_nf_tp_b<false>, grid, dim3(256), 0, st, a);
+                const char *pe = zh_env("ZH_NF_TP_PARK");                                // experiments: park the noise in the output rows (ZERO_FIRST paints)
+                const bool park = zf && pe && atoi(pe) != 0;
+                if (park) hipLaunchKernelGGL(k_nf_tp_a<true>, grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(k_nf_tp_a<false>, grid, dim3(256), 0, st, a);
+                if (park) hipLaunchKernelGGL((k_nf_tp_b<true, true>), grid, dim3(256), 0, st, a);
+                else if (zf) hipLaunchKernelGGL((k_nf_tp_b<true, false>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_nf_tp_b<false, false>), grid, dim3(256), 0, st, a);
             }
             return zh_launch_status();
         }

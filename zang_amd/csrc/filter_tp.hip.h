@@ -216,6 +216,10 @@ struct NfTpArgs {
 };
 
 // grid: x = 256-voice groups, y = chunk; block = 256.  Pass A: jump to the chunk's first draw, keep that state, zero-state response.
+// PARK (a ZERO_FIRST paint: the output rows will be overwritten anyway): the chunk's noise samples are parked in the output image
+// itself, and pass B reads them back (4 bytes a sample, from L2 / Infinity Cache) instead of generating them a second time
+// (30 instructions a sample).
+template <bool PARK>
 __global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
     __shared__ uint4 tbl[kNoiseJumpEntries];
     const uint32_t j = blockIdx.y;
@@ -241,19 +245,35 @@ __global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
     const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
     float l = 0.0f, b = 0.0f;
     bool multi = false;
-#pragma unroll 8
-    for (uint32_t k = 0; k < nf; k++) {
-        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;   // Noise.zig:51
-        const float temp = 0.0f + white;                              // zero(temp); temp += noise
-        svf_step(l, b, temp, cut, res);                               // Filter.zig:135-144
+    const uint32_t voff = v * 4u, orow = (uint32_t)a.out.stride * 4u;
+    uint32_t k = 0;
+    for (; k + 8 <= nf; k += 8) {                                     // (8 rows per descriptor: 32-bit offsets)
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f0 + k);
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;   // Noise.zig:51
+            const float temp = 0.0f + white;                          // zero(temp); temp += noise
+            if (PARK) zrow_store<1>(ro, voff, q * orow, temp);
+            svf_step(l, b, temp, cut, res);                           // Filter.zig:135-144
+        }
+    }
+    for (; k < nf; k++) {
+        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
+        const float temp = 0.0f + white;
+        if (PARK) zrow_store<1>(zrow_rsrc(a.out.p, a.out.stride, f0 + k), voff, 0, temp);
+        svf_step(l, b, temp, cut, res);
     }
     a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
+    if (PARK && f1 == a.end && nf > 0) {                              // the state after the span's last draw: pass B does not draw when the noise is parked
+        uint64_t *ce = a.cs + (size_t)a.C * 4 * V + v;
+        ce[0] = r.s0; ce[V] = r.s1; ce[2 * V] = r.s2; ce[3 * V] = r.s3;
+    }
     if (multi) a.flag[v] = a.serial;                                      // (every later chunk of this voice started at the wrong draw)
 }
 
 // Pass B, same grid: scan, then the reference's recurrence over the regenerated noise of the chunk.  A flagged voice is painted
 // whole by its chunk-0 lane, sequentially from the module's state -- the reference's own walk, bit for bit.
-template <bool ZF>
+template <bool ZF, bool PARKED = false>
 __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
     const uint32_t j = blockIdx.y;
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -269,26 +289,36 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
     const float2 s0 = a.e[v];
     float l = s0.x, b = s0.y;
     svf_scan<kNfTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
-    auto frame = [&](const zh_rsrc_t &ro, uint32_t k, float base, bool store) ZH_INLINE_LAMBDA {
-        const float white = zrandom_float32(r) * 2.0f - 1.0f;       // Noise.zig:51
-        const float temp = 0.0f + white;                             // zero(temp); temp += noise
+    // `given`: with PARKED noise (ZF: pass A left the chunk's samples in the output rows) the row's value IS the filter's input
+    // and the base of the sum is zero; otherwise the sample is generated again and the row's value is the base
+    auto frame = [&](const zh_rsrc_t &ro, uint32_t k, float given, bool store, bool parked) ZH_INLINE_LAMBDA {
+        float temp;
+        if (parked) temp = given;
+        else {
+            const float white = zrandom_float32(r) * 2.0f - 1.0f;   // Noise.zig:51
+            temp = 0.0f + white;                                     // zero(temp); temp += noise
+        }
         const SvfOut sv = svf_step(l, b, temp, cut, res);            // Filter.zig:135-144
         const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
-        if (store) zrow_store<1>(ro, voff, k * orow, base + val);
+        if (store) zrow_store<1>(ro, voff, k * orow, ((ZF || parked) ? 0.0f : given) + val);
     };
     // (8 rows per descriptor: 32-bit offsets, common.hip.h kMaxRowStride)
     uint32_t c0 = f0;
     for (; c0 + 8 <= f1; c0 += 8) {
         const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
-        float base[8];
+        float row[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) base[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow);
+        for (uint32_t k = 0; k < 8; k++) row[k] = (ZF && !PARKED) ? 0.0f : zrow_load<1>(ro, voff, k * orow);     // PARKED: the noise; else the `+=` base
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) frame(ro, k, base[k], !flagged);
+        for (uint32_t k = 0; k < 8; k++) frame(ro, k, row[k], !flagged, PARKED);
     }
     if (c0 < f1) {
         const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
-        for (uint32_t k = 0; c0 + k < f1; k++) frame(ro, k, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow), !flagged);
+        for (uint32_t k = 0; c0 + k < f1; k++) frame(ro, k, (ZF && !PARKED) ? 0.0f : zrow_load<1>(ro, voff, k * orow), !flagged, PARKED);
+    }
+    if (PARKED && !flagged && f1 == a.end && f1 > f0) {               // (the generator's state after the span: pass A left it behind chunk C - 1's)
+        const uint64_t *ce = a.cs + (size_t)a.C * 4 * V + v;
+        r = ZXoshiro{ce[0], ce[V], ce[2 * V], ce[3 * V]};
     }
     if (!flagged && f1 == a.end && f1 > f0) {                         // whoever painted the span's last frame leaves the states
         a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
@@ -302,7 +332,7 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
             l = s0.x; b = s0.y;
             for (uint32_t f = a.start; f < a.end; f++) {
                 const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
-                frame(ro, 0, ZF ? 0.0f : zrow_load<1>(ro, voff, 0), true);
+                frame(ro, 0, ZF ? 0.0f : zrow_load<1>(ro, voff, 0), true, false);
             }
             a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
             a.l[v] = l; a.b[v] = b;
