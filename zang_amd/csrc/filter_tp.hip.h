@@ -27,9 +27,10 @@
 //                      workgroup, hence the grid's shape); the chunk-start generator states go through the scratch too and pass
 //                      B generates the chunk's noise again (30 instructions a sample against 8 bytes of traffic).  The noise
 //                      itself is exact.
-// A wave64 instruction occupies its SIMD for four cycles however many waves share the SIMD: once every SIMD has a wave, what a
-// launch costs is its total instruction count, so the per-chunk extras (a jump: ~700 instructions; the scan) set the chunk
-// length -- not "as many chunks as possible".
+// A lone wave issues an instruction every ~5 cycles, two waves on a SIMD interleave (2.7 cycles per plain instruction), more add
+// nothing (tools/ubench/valu_ops.hip): the launches aim at ~2,048 waves, and from there what a launch costs is its total
+// instruction count, so the per-chunk extras (a jump: ~700 instructions; the scan) set the chunk length -- not "as many chunks
+// as possible".
 #pragma once
 #include "common.hip.h"
 #include "zmath.hip.h"
