@@ -10,6 +10,7 @@ run() {  # name, bench args...: profiled + unprofiled on this box, per-dispatch 
   bash $GRAFT_REPO_ROOT/tools/prof_one.sh profiles_$tag $name "$@" > /dev/null
 }
 run pulseosc4096
+run pulseosc4096_driver_args --steps 20 --warmup 5      # the driver's own arguments: the 20-step region, its rehearsals and the batched-launch extra
 run pulseosc65536 --voices 65536 --steps 100 --warmup 10
 run pulseosc1M --voices 1048576 --steps 40 --warmup 4
 run noise_filter4096 --workload noise_filter
