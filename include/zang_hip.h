@@ -65,6 +65,8 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *    2.5-3 x faster); the noise samples and generator states are exact, the filter state carries the samples' error;
         *  - zh_nice_paint at up to 16,384 voices, spans of 128-4,096 frames: the same for the fused voice's filter (oscillator,
         *    envelope and their states exact: the envelope is walked once per voice ahead of the chunks);
+        *  - zh_noise_paint with ZH_NOISE_PINK at up to 16,384 voices: Kellett's six one-pole taps as chunks at once over exactly
+        *    generated white noise (white noise itself, and the generator's state, are always exact);
         *  - zh_sineosc_paint and zh_pmosc_paint (its carrier) at any voice count: the sine of the reference's own rounded
         *    argument in f32 (csrc/zmath.hip.h zsinf_tol: 17 instructions for musl's 34, 15 of them f64; within 4e-7 of it);
         *    phase and envelope states stay exact.

@@ -478,3 +478,60 @@ def test_nice_tolerant(ctx, oracle, V, zero_first):
         for q, v in enumerate(idx):
             st["flt"]["l"][v] = sts[q].flt.l; st["flt"]["b"][v] = sts[q].flt.b
         m.set_state(st)
+
+
+# ------------------------------------------------------------------ pink Noise
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("V", [300, 4096, 16384])
+def test_pink_noise_tolerant(ctx, oracle, V, zero_first):
+    """k_pink_tp_a / _b against the oracle's Noise.paint(.pink): samples within 1e-5 of the voice's peak, the first chunk bit-exact,
+    generator states exact, voices crafted onto Random.float's second draw bit-exact whole, taps set through set_state honoured
+    (Noise.zig:55 reads self.b; :68 never writes it back)."""
+    from zang_amd import modules as mod, zang
+    from tests.test_gpu_modules import _xoshiro_step_back
+    first = 4000
+    rng = np.random.default_rng(123)
+    L = oracle.lib()
+    idx = np.arange(V) if V <= 512 else np.unique(np.concatenate([np.arange(0, V, 61), [5, 46, 87, 128, 169, 210, 251]]))
+    nzs = []
+    for v in idx:
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + int(v)); nzs.append(nz)
+    crafted = {5 + 41 * i: k for i, k in enumerate([0, 31, 32, 63, 64, 500, 1023])}
+    pos = {int(v): q for q, v in enumerate(idx)}
+    m = mod.Noise(V, ctx, first_seed=first)
+    st = m.state()
+    for v, k in crafted.items():
+        back = _xoshiro_step_back([0, int(rng.integers(1, 1 << 63)), int(rng.integers(1, 1 << 63)), 1 << 41], k)
+        for i in range(4):
+            nzs[pos[v]].r[i] = back[i]
+        st["r"][v] = [int(x) for x in back]
+    taps = rng.uniform(-0.5, 0.5, (V, 7)).astype(np.float32)          # non-zero taps at span start (a host that set them)
+    for q, v in enumerate(idx):
+        for t in range(7):
+            nzs[q].b[t] = float(taps[v, t])
+    st["b"] = taps
+    m.set_state(st)
+    out0 = util.rng_buffers(14, V, F)
+    Lc = 32 * max(1, 32 // max(2, min(32, (2048 + (V + 63) // 64 - 1) // ((V + 63) // 64))))
+    for n_span, (s, e) in enumerate([(0, 1024), (0, 1024), (100, 612), (612, 1001), (0, 70)]):
+        ref = out0[idx].copy()
+        if zero_first:
+            ref[:, s:e] = 0.0
+        for q in range(len(idx)):
+            L.zo_noise_paint(C.byref(nzs[q]), s, e, oracle.fptr(ref[q]), 1)
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(m.pink), zero_first=zero_first, tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)[idx]
+        tag = f"pink tolerant V={V} span {(s, e)}"
+        if e - s < 128:
+            util.assert_bitexact(got, ref, tag + " (short span: exact form)")
+        else:
+            util.assert_bitexact(got[:, s:s + Lc], ref[:, s:s + Lc], tag + " first chunk")
+            util.assert_peak_close(got, ref, tag, s=s, e=e)
+            if n_span == 0:
+                cq = [pos[v] for v in sorted(crafted)]
+                util.assert_bitexact(got[cq], ref[cq], tag + " multi-draw voices (sequential walk)")
+        gs = m.state()
+        assert [[int(x) for x in gs["r"][v]] for v in idx] == [list(n.r) for n in nzs], f"generator states after span {(s, e)}"
+        util.assert_bitexact(gs["b"][idx].astype(np.float32), taps[idx], "the taps are never written back (Noise.zig:68)")

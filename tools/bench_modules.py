@@ -43,6 +43,8 @@ m = mod.PulseOsc(V, ctx); case("PulseOsc const freq (chunked)", m, lambda o, m=m
 m = mod.PulseOsc(V, ctx); case("PulseOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
 m = mod.TriSawOsc(V, ctx); case("TriSawOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
 m = mod.TriSawOsc(V, ctx); case("TriSawOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
+if V <= 16384:
+    m = mod.Noise(V, ctx); case("Noise pink, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(m.pink), zero_first=True, tolerant=True))
 m = mod.Noise(V, ctx); case("Noise white", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(m.white), zero_first=True))
 m = mod.Noise(V, ctx); case("Noise pink", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(m.pink), zero_first=True))
 m = mod.Envelope(V, ctx)

@@ -96,6 +96,21 @@ def main():
             ctx.sync()
             show(f"Noise->Filter, {V} voices, buffer {p + 1} (states carried by the GPU)", util.from_image(out), ref)
 
+    # pink Noise (Kellett's taps as chunks at once over exact white noise)
+    for V in (4096, 16384):
+        m = mod.Noise(V, ctx, first_seed=0)
+        nzs = []
+        for v in range(V):
+            nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), v); nzs.append(nz)
+        for p in range(2):
+            ref = np.zeros((V, F), np.float32)
+            for v in range(V):
+                L.zo_noise_paint(C.byref(nzs[v]), 0, F, oracle.fptr(ref[v]), 1)
+            out = ctx.image(F, V)
+            m.paint(zang.Span(0, F), [out], None, False, m.Params(m.pink), zero_first=True, tolerant=True)
+            ctx.sync()
+            show(f"Noise pink, {V} voices, buffer {p + 1}", util.from_image(out), ref)
+
     # NiceInstrument at few voices: a note script, states carried by the GPU
     for V in (4096, 16384):
         from zang_amd import workloads

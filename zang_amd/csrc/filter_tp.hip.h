@@ -341,3 +341,132 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
     }
 }
 #endif   // ZH_FILTER_TP_NOISE
+
+// ---------------------------------------------------------------------------------------------------- pink Noise
+// Paul Kellett's filter (Noise.zig:58-66) is six decoupled one-pole taps b_k' = a_k b_k + c_k w over the white samples, a seventh
+// value that is last frame's white sample times a constant, and a left-to-right sum: every tap is its own affine map with a
+// CONSTANT a_k, so the time-parallel scheme above applies tap by tap (A^L is the scalar a_k^L), and b[6] needs no scan at all --
+// a chunk's start value is the previous chunk's last white sample * 0.115926, which that chunk's pass A leaves behind exactly.
+// The white samples themselves (generator jumps, multi-draw voices walked sequentially by their chunk-0 lane) are exact, as in
+// the fused Noise -> Filter voice.  (Noise.zig:68: the taps are never written back -- a paint leaves only the generator's state.)
+#if defined(ZH_FILTER_TP_PINK)            // (modules.hip only: the kernels below are not templates)
+struct PinkTpArgs {
+    uint64_t *s[4];              // generator states: read by pass A, written once by pass B
+    const float *b0;             // [7][V]: the module's taps at span start (Noise.zig:55 `var b = self.b`)
+    uint64_t *cs;                // scratch [C][4][V]: generator state at the start of chunk j
+    float *e;                    // scratch [C][7][V]: chunk j's zero-state tap values after its last frame, and its b[6] (exact)
+    uint32_t *flag;              // scratch [V]: == serial when a multi-draw sample was seen in this paint
+    uint32_t serial;
+    const uint4 *tables;
+    uint32_t V, start, end, L, C;
+    Img out;
+};
+__device__ __forceinline__ void pink_coeffs(float (&a)[6]) {
+    a[0] = 0.99886f; a[1] = 0.99332f; a[2] = 0.96900f; a[3] = 0.86650f; a[4] = 0.55000f; a[5] = -0.7616f;
+}
+
+__global__ void __launch_bounds__(256) k_pink_tp_a(const PinkTpArgs a) {
+    __shared__ uint4 tbl[kNoiseJumpEntries];
+    const uint32_t j = blockIdx.y;
+    if (j > 0) {                                                      // block-uniform
+        const uint4 *t = a.tables + (size_t)(j * (a.L / 32) - 1) * kNoiseJumpEntries;
+        uint4 w[kNoiseJumpEntries / 256];
+#pragma unroll
+        for (int q = 0; q < kNoiseJumpEntries / 256; q++) w[q] = t[q * 256 + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < kNoiseJumpEntries / 256; q++) tbl[q * 256 + threadIdx.x] = w[q];
+        __syncthreads();
+    }
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    ZXoshiro r{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+    if (j > 0) noise_jump_apply(r, tbl);
+    const size_t V = a.V;
+    uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+    cs[0] = r.s0; cs[V] = r.s1; cs[2 * V] = r.s2; cs[3 * V] = r.s3;
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end), nf = f1 - f0;
+    float b[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool multi = false;
+#pragma unroll 8
+    for (uint32_t k = 0; k < nf; k++) {
+        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;   // Noise.zig:58
+        (void)pink_step(b, white);                                    // :59-66 from zero taps: the chunk's zero-state response
+    }
+    float *e = a.e + (size_t)j * 7 * V + v;
+#pragma unroll
+    for (int q = 0; q < 7; q++) e[(size_t)q * V] = b[q];
+    if (multi) a.flag[v] = a.serial;
+}
+
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_pink_tp_b(const PinkTpArgs a) {
+    const uint32_t j = blockIdx.y;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    const size_t V = a.V;
+    const uint32_t voff = v * 4u, orow = (uint32_t)a.out.stride * 4u;
+    const bool flagged = a.flag[v] == a.serial;
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);     // workgroup-uniform
+    const uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+    ZXoshiro r{cs[0], cs[V], cs[2 * V], cs[3 * V]};
+    float b[7], b_span[7];
+#pragma unroll
+    for (int q = 0; q < 7; q++) b[q] = b_span[q] = a.b0[(size_t)q * V + v];
+    if (j > 0) {
+        // every earlier chunk's end values requested before the first is used (kTpMaxChunks - 1 slots, the rest ignored)
+        float e[kTpMaxChunks - 1][6];
+#pragma unroll
+        for (uint32_t i = 0; i < kTpMaxChunks - 1; i++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) e[i][q] = a.e[((size_t)i * 7 + q) * V + v];
+        float ac[6];
+        pink_coeffs(ac);
+        float m[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {                                 // a_k^L by squaring in f64, rounded once
+            double p = 1.0, x = (double)ac[q];
+            for (uint32_t n = a.L;;) { if (n & 1u) p *= x; n >>= 1; if (!n) break; x *= x; }
+            m[q] = (float)p;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kTpMaxChunks - 1; i++)
+            if (i < j) {                                              // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 6; q++) b[q] = m[q] * b[q] + e[i][q];
+            }
+        b[6] = a.e[((size_t)(j - 1) * 7 + 6) * V + v];                // the previous chunk's last white * 0.115926: exact
+    }
+    auto frame = [&](const zh_rsrc_t &ro, uint32_t k, float base, bool store) ZH_INLINE_LAMBDA {
+        const float white = zrandom_float32(r) * 2.0f - 1.0f;       // Noise.zig:58
+        const float val = pink_step(b, white);                       // :59-66
+        if (store) zrow_store<1>(ro, voff, k * orow, base + val);
+    };
+    uint32_t c0 = f0;
+    for (; c0 + 8 <= f1; c0 += 8) {
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
+        float base[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) base[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) frame(ro, k, base[k], !flagged);
+    }
+    if (c0 < f1) {
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
+        for (uint32_t k = 0; c0 + k < f1; k++) frame(ro, k, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow), !flagged);
+    }
+    if (!flagged && f1 == a.end && f1 > f0) { a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3; }   // Noise.zig:71 (:68: not the taps)
+    if (j == 0 && __builtin_amdgcn_ballot_w64(flagged) != 0) {        // a multi-draw voice: the reference's own walk over the whole span
+        if (flagged) {
+            r = ZXoshiro{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+#pragma unroll
+            for (int q = 0; q < 7; q++) b[q] = b_span[q];
+            for (uint32_t f = a.start; f < a.end; f++) {
+                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
+                frame(ro, 0, ZF ? 0.0f : zrow_load<1>(ro, voff, 0), true);
+            }
+            a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
+        }
+    }
+}
+#endif   // ZH_FILTER_TP_PINK
+

@@ -14,6 +14,7 @@
 #include "seq.hip.h"
 #include "envelope.hip.h"
 #include "voices.hip.h"
+#define ZH_FILTER_TP_PINK 1
 #include "filter_tp.hip.h"
 #include <vector>
 
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
     if constexpr (TOL) {
         frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, start, end,
                                [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
-            val = o.template frame<FB, 2>(FB ? x[0] : 0.0f, PB ? x[FB ? 1 : 0] : phase_c);
+            val = o.template frame<FB, 2>(FB ? x[0] : 0.0f, PB ? x[(FB && NIN > 1) ? 1 : 0] : phase_c);
             return true;
         });
     } else if constexpr (!FB && !PB) {
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__
     if constexpr (TOL) {
         frame_loop<8, ZF, NIN>(out.p, v, out.stride, ins, istr, f0, f1,
                                [&](uint32_t, const float (&x)[NIN > 0 ? NIN : 1], float &val) ZH_INLINE_LAMBDA {
-            val = o.template frame<FB, 2>(FB ? x[0] : 0.0f, PB ? x[FB ? 1 : 0] : phase_c);
+            val = o.template frame<FB, 2>(FB ? x[0] : 0.0f, PB ? x[(FB && NIN > 1) ? 1 : 0] : phase_c);
             return true;
         });
     } else if constexpr (!FB && !PB) {
@@ -129,6 +130,8 @@ struct zh_noise {
     // ADD paint is rendered into before it is added to the output
     uint64_t *nx[4]; uint32_t *flag; zh_buf scratch;
     uint32_t *err;               // k_pink_pipe: a ring wait ran into its bound (never in a correct run; reported by get_state)
+    // ZH_PAINT_TOLERANT pink noise (filter_tp.hip.h k_pink_tp_a / _b): scratch, allocated by the first tolerant paint outside a capture
+    uint64_t *tp_cs; float *tp_e; uint32_t *tp_flag; uint32_t tp_serial;
 };
 // noise_jump.hip
 uint32_t zh_noise_range_frames(uint32_t V, uint32_t n);
@@ -1270,12 +1273,14 @@ static void noise_free(zh_noise *m) {
     for (auto &x : m->s) (void)hipFree(x);
     for (auto &x : m->nx) (void)hipFree(x);
     (void)hipFree(m->b); (void)hipFree(m->flag); (void)hipFree(m->scratch.ptr); (void)hipFree(m->err);
+    (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag);
 }
 int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_noise *m = new (std::nothrow) zh_noise();
     if (!m) return ZH_ERR_INVALID;
     m->ctx = ctx; m->n = n; m->b = nullptr; m->flag = nullptr; m->err = nullptr;
+    m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; m->tp_serial = 0;
     for (int i = 0; i < 4; i++) m->s[i] = m->nx[i] = nullptr;
     memset(&m->scratch, 0, sizeof m->scratch);
     int rc = 0;
@@ -1340,8 +1345,39 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     // Few voices: the white samples as many frame ranges of the span at once (noise_jump.hip).  White noise with zero +
     // paint writes the output directly; the reference's `+=` onto existing content, and pink noise, render the white into a
     // module-owned image first (the repair of a multi-draw voice needs the noise on its own) and add / filter it from there.
-    const uint32_t ch = zh_noise_range_frames(m->n, end - start);
     const bool pink = p->color == ZH_NOISE_PINK;
+    // ZH_PAINT_TOLERANT, pink, few voices: the taps as chunks at once over exactly generated white noise (k_pink_tp_a / _b)
+    if ((flags & ZH_PAINT_TOLERANT) && pink && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
+        const uint32_t Cw = zh_tp_chunks(m->n, "ZH_PINK_TP_MAX", 1024);
+        const uint4 *tables = Cw >= 2 ? zh_noise_jump_tables(m->ctx) : nullptr;
+        if (tables && !m->tp_cs && !m->ctx->capturing) {
+            int arc = dev_alloc(&m->tp_cs, (size_t)kTpMaxChunks * 4 * m->n);
+            if (!arc) arc = dev_alloc(&m->tp_e, (size_t)kTpMaxChunks * 7 * m->n);
+            if (!arc) arc = dev_alloc(&m->tp_flag, m->n);
+            if (!arc) arc = (int)hipMemsetAsync(m->tp_flag, 0, (size_t)m->n * 4, st);
+            if (arc) { (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; (void)hipGetLastError(); }
+        }
+        if (tables && m->tp_cs) {
+            const uint32_t L = 32u * max(1u, 32u / Cw);
+            PinkTpArgs a;
+            for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
+            a.b0 = m->b; a.cs = m->tp_cs; a.e = m->tp_e; a.flag = m->tp_flag; a.tables = tables;
+            a.V = m->n; a.L = L; a.out = mk_img(outputs[0]);
+            const uint32_t piece = min(kTpMaxChunks * L, (uint32_t)kNoiseJumpTables * 32u + L);
+            for (uint32_t s0 = start; s0 < end; s0 += piece) {
+                a.start = s0; a.end = min(s0 + piece, end);
+                a.C = (a.end - a.start + L - 1) / L;
+                if (++m->tp_serial == 0) m->tp_serial = 1;
+                a.serial = m->tp_serial;
+                const dim3 grid((m->n + 255) / 256, a.C);
+                hipLaunchKernelGGL(k_pink_tp_a, grid, dim3(256), 0, st, a);
+                if (zf) hipLaunchKernelGGL(k_pink_tp_b<true>, grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(k_pink_tp_b<false>, grid, dim3(256), 0, st, a);
+            }
+            return zh_launch_status();
+        }
+    }
+    const uint32_t ch = zh_noise_range_frames(m->n, end - start);
     // pink, 1,024 / 4,096 / 16,384 / 32,768 voices: 124 / 116 / 118 / 130 us in one loop, 57 / 67 / 84 / 161 us as white ranges +
     // the seven-stage chain (the white kernel is 10-29 us of that), 43 / 54 / 68 / 123 us as white ranges + k_pink_taps
     const char *pe = pink ? zh_env("ZH_PINK_PIPE_MAX") : nullptr;     // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)

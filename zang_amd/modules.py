@@ -167,8 +167,10 @@ class Noise(_Module):
     def __init__(self, n_voices, ctx=None, first_seed=0):
         super().__init__(n_voices, ctx, C.c_uint64(first_seed))
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
-        self._paint(span, outputs, temps, note_id_changed, abi.NoiseParams(params.color), zero_first)
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT -- pink noise at few voices: the taps as chunks at once over exactly generated white
+        noise (1e-5 of the voice's peak); white noise and the generator's state are always exact."""
+        self._paint(span, outputs, temps, note_id_changed, abi.NoiseParams(params.color), zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
 
 class Envelope(_Module):
