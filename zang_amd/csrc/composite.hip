@@ -1834,8 +1834,8 @@ static bool nice_mix_roll() {
     return v;
 }
 // One partial row per workgroup (a barrier per chunk in the sum phase) or one per wave.  A/B on one box (tools/ab_env.sh,
-// profiles/r04/ab_nice_mix_wg.txt): 131,072 voices 108.5 -> 107.9 us per buffer all-in with a quarter of the partial traffic;
-// 4,096 voices 99.3 -> 104.4 (sixteen workgroups on 256 CUs: the barrier couples waves that otherwise run at their own pace).
+// profiles/r04/ab_nice_mix_wg.txt): 131,072 voices 108.45 -> 108.35 us per buffer all-in (0.6 us in an earlier comparison) with a quarter of
+// the partial traffic; 4,096 voices 99.3 -> 104.6 (sixteen workgroups on 256 CUs: the barrier couples waves that otherwise run at their own pace).
 // ZH_NICE_MIX_WG_MIN = the smallest voice count that combines per workgroup.
 static bool nice_mix_wg(uint32_t n_voices) {
     const char *e = zh_env("ZH_NICE_MIX_WG_MIN");
