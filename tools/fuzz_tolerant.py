@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""GPU box: random cases of the ZH_PAINT_TOLERANT forms against the oracle -- voice counts on both sides of every chunk-count
+boundary (and of the forms' 16,384-voice limit, where the exact forms must answer bit for bit), random span sequences with carried
+state, every filter type, += and ZERO_FIRST, parameter draws that include the clamped ranges.  Checked per paint: samples within
+1e-5 of the voice's peak (the larger of output peak and filter-state magnitude), rows outside the span untouched, generator /
+oscillator / envelope states exact.  usage: fuzz_tolerant.py N [first_seed]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", ROOT))
+import numpy as np
+
+SR, F = 48000.0, 1024
+
+
+def spans_for(rng):
+    out = []
+    for _ in range(int(rng.integers(2, 5))):
+        a = int(rng.integers(0, 900)); b = int(rng.integers(a, 1025))
+        if rng.random() < 0.4:
+            a, b = 0, 1024
+        out.append((a, b))
+    return out
+
+
+def pick_voices(rng):
+    return int(rng.choice([1, 63, 64, 65, 200, 1000, 4096, 4100, 8192, 8256, 12000, 16384, 16400, 20000]))
+
+
+def sample(V, rng, n=96):
+    return np.arange(V) if V <= n else np.unique(rng.integers(0, V, n))
+
+
+def main():
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    from oracle import pyoracle as oracle
+    from tests import util
+    ctx = zang_amd.default_context()
+    L = oracle.lib()
+    n = int(sys.argv[1]); first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = 0
+    worst = 0.0
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        kind = ["filter", "noise_filter", "nice", "pink", "sine"][seed % 5]
+        V = pick_voices(rng)
+        zf = bool(rng.integers(0, 2))
+        idx = sample(V, rng)
+        base = util.rng_buffers(seed, V, F)
+        tag = f"seed {seed} {kind} V={V} zf={zf}"
+        try:
+            if kind == "filter":
+                ftype = int(rng.integers(1, 6))
+                cut = rng.uniform(-0.1, 1.1, V).astype(np.float32); res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+                inp = util.rng_buffers(seed + 7, V, F, -1.0, 1.0) * np.float32(rng.choice([1.0, 1.0, 1e-6, 1e6]))
+                sts = []
+                for v in idx:
+                    st = oracle.Filter(); L.zo_filter_init(C.byref(st)); sts.append(st)
+                m = mod.Filter(V, ctx)
+                gi = util.to_image(inp); dc, dr = util.dev(cut), util.dev(res)
+                for (s, e) in spans_for(rng):
+                    ref = base[idx].copy()
+                    if zf:
+                        ref[:, s:e] = 0.0
+                    for q, v in enumerate(idx):
+                        L.zo_filter_paint(C.byref(sts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(inp[v]), ftype, oracle.constant(cut[v]), oracle.constant(res[v]))
+                    out = util.to_image(base)
+                    m.paint(zang.Span(s, e), [out], [], False, m.Params(gi, ftype, zang.constant(dc), zang.constant(dr)), zero_first=zf, tolerant=True)
+                    ctx.sync()
+                    got = util.from_image(out)[idx]
+                    rl = np.array([t.l for t in sts], np.float32); rb = np.array([t.b for t in sts], np.float32)
+                    if V > 16384 or e - s < 64:
+                        util.assert_bitexact(got, ref, tag + f" span {(s, e)}: exact form")
+                    else:
+                        util.assert_bitexact(got[:, :s], ref[:, :s], tag); util.assert_bitexact(got[:, e:], ref[:, e:], tag)
+                        worst = max(worst, util.assert_peak_close(got, ref, tag + f" span {(s, e)}", s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb))))
+                    st = m.state()
+                    for q, v in enumerate(idx):
+                        st["l"][v] = rl[q]; st["b"][v] = rb[q]
+                    m.set_state(st)
+            elif kind in ("noise_filter", "pink"):
+                fseed = int(rng.integers(0, 1 << 20))
+                ftype = int(rng.integers(1, 6))
+                cut = rng.uniform(0.0, 1.0, V).astype(np.float32); res = rng.uniform(0.0, 0.95, V).astype(np.float32)
+                nzs, fls = [], []
+                for v in idx:
+                    nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), fseed + int(v)); nzs.append(nz)
+                    fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+                m = mod.NoiseFilter(V, ctx, first_seed=fseed) if kind == "noise_filter" else mod.Noise(V, ctx, first_seed=fseed)
+                gc, gr = util.dev(cut), util.dev(res)
+                temp = np.zeros(F, np.float32)
+                for (s, e) in spans_for(rng):
+                    ref = base[idx].copy()
+                    if zf:
+                        ref[:, s:e] = 0.0
+                    for q, v in enumerate(idx):
+                        if kind == "pink":
+                            L.zo_noise_paint(C.byref(nzs[q]), s, e, oracle.fptr(ref[q]), 1)
+                        else:
+                            L.zo_zero(s, e, oracle.fptr(temp))
+                            L.zo_noise_paint(C.byref(nzs[q]), s, e, oracle.fptr(temp), 0)
+                            L.zo_filter_paint(C.byref(fls[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(temp), ftype, oracle.constant(cut[v]), oracle.constant(res[v]))
+                    out = util.to_image(base)
+                    if kind == "pink":
+                        m.paint(zang.Span(s, e), [out], None, False, m.Params(m.pink), zero_first=zf, tolerant=True)
+                    else:
+                        m.paint(zang.Span(s, e), [out], None, False, m.Params(0, ftype, gc, gr), zero_first=zf, tolerant=True)
+                    ctx.sync()
+                    got = util.from_image(out)[idx]
+                    rl = np.array([t.l for t in fls], np.float32); rb = np.array([t.b for t in fls], np.float32)
+                    if V > 16384 or e - s < 128:
+                        util.assert_bitexact(got, ref, tag + f" span {(s, e)}: exact form")
+                    else:
+                        util.assert_bitexact(got[:, :s], ref[:, :s], tag); util.assert_bitexact(got[:, e:], ref[:, e:], tag)
+                        worst = max(worst, util.assert_peak_close(got, ref, tag + f" span {(s, e)}", s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb))))
+                    gs = m.state()
+                    r = gs["noise"]["r"] if kind == "noise_filter" else gs["r"]
+                    assert [[int(x) for x in r[v]] for v in idx] == [list(z.r) for z in nzs], tag + " generator states"
+                    if kind == "noise_filter":
+                        for q, v in enumerate(idx):
+                            gs["flt"]["l"][v] = rl[q]; gs["flt"]["b"][v] = rb[q]
+                        m.set_state(gs)
+            elif kind == "nice":
+                freq, color, _, _ = workloads.voice_params(5, int(rng.integers(0, 1000)), V)
+                freq = (freq * np.float32(rng.choice([1.0, 0.25, 3.0]))).astype(np.float32)
+                sts = []
+                for v in idx:
+                    st = oracle.NiceInstrument(); L.zo_nice_init(C.byref(st), float(color[v])); sts.append(st)
+                m = mod.NiceInstrument(V, util.dev(color), ctx)
+                gf = util.dev(freq)
+                t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+                on = 1
+                for k, (s, e) in enumerate(spans_for(rng)):
+                    nic = int(k == 0 or rng.random() < 0.3)
+                    on = int(rng.random() < 0.7) if not nic else 1
+                    ref = base[idx].copy()
+                    if zf:
+                        ref[:, s:e] = 0.0
+                    for q, v in enumerate(idx):
+                        L.zo_nice_paint(C.byref(sts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), nic, SR, float(freq[v]), on)
+                    out = util.to_image(base)
+                    m.paint(zang.Span(s, e), [out], None, bool(nic), m.Params(SR, gf, bool(on)), zero_first=zf, tolerant=True)
+                    ctx.sync()
+                    got = util.from_image(out)[idx]
+                    rl = np.array([t.flt.l for t in sts], np.float32); rb = np.array([t.flt.b for t in sts], np.float32)
+                    if V > 16384 or e - s < 128:
+                        util.assert_bitexact(got, ref, tag + f" span {(s, e)}: exact form")
+                    else:
+                        worst = max(worst, util.assert_peak_close(got, ref, tag + f" span {(s, e)}", s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb))))
+                    st = m.state()
+                    assert [int(x) for x in st["osc"]["cnt"][idx]] == [t.osc.cnt for t in sts], tag + " osc"
+                    assert [int(x) for x in st["env"]["state"][idx]] == [t.env.state for t in sts], tag + " env state"
+                    util.assert_bitexact(st["env"]["t"][idx].astype(np.float32), np.array([t.env.painter.t for t in sts], np.float32), tag + " env t")
+                    for q, v in enumerate(idx):
+                        st["flt"]["l"][v] = rl[q]; st["flt"]["b"][v] = rb[q]
+                    m.set_state(st)
+            else:
+                freq = rng.uniform(-10.0, 8000.0, V).astype(np.float32); phase = rng.uniform(-2, 2, V).astype(np.float32)
+                pbuf = (rng.uniform(-1, 1, (V, F)) * rng.choice([1.0, 30.0, 1e5])).astype(np.float32)
+                usebuf = bool(rng.integers(0, 2))
+                sts = []
+                for v in idx:
+                    st = oracle.SineOsc(); L.zo_sineosc_init(C.byref(st)); sts.append(st)
+                m = mod.SineOsc(V, ctx)
+                gp = zang.buffer(util.to_image(pbuf)) if usebuf else zang.constant(util.dev(phase))
+                for (s, e) in spans_for(rng):
+                    ref = base[idx].copy()
+                    if zf:
+                        ref[:, s:e] = 0.0
+                    for q, v in enumerate(idx):
+                        L.zo_sineosc_paint(C.byref(sts[q]), s, e, oracle.fptr(ref[q]), SR, oracle.constant(freq[v]), oracle.buffer(pbuf[v]) if usebuf else oracle.constant(phase[v]))
+                    out = util.to_image(base)
+                    m.paint(zang.Span(s, e), [out], [], False, m.Params(SR, zang.constant(util.dev(freq)), gp), zero_first=zf, tolerant=True)
+                    ctx.sync()
+                    got = util.from_image(out)[idx]
+                    err = np.abs(got.astype(np.float64) - ref).max() if e > s else 0.0
+                    assert err <= 1e-5, tag + f" span {(s, e)}: {err}"
+                    worst = max(worst, err)
+                    util.assert_bitexact(m.state()["t"][idx].astype(np.float32), np.array([t.t for t in sts], np.float32), tag + " t")
+        except AssertionError as ex:
+            bad += 1
+            print("FAIL", tag, str(ex)[:400])
+    print("seeds", n, "from", first, "failures", bad, "worst error / peak %.2e" % worst)
+
+
+if __name__ == "__main__":
+    main()
