@@ -168,3 +168,30 @@ def test_torch_nccl_backend_one_rank(ctx):
         port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-c", _TORCH_NCCL % (ROOT, port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_comm_create_times_out_when_a_rank_never_arrives():
+    """zh_comm_create is a rendezvous: rank 0 of a world of 2 whose partner never calls it.  With ZH_COMM_TIMEOUT_S=4 the call comes
+    back with ZH_ERR_COMM and a message instead of hanging (in a child process: the helper thread that sits in RCCL's bootstrap
+    stays behind, and the child leaves through os._exit)."""
+    code = r'''
+import ctypes as C, os, sys, time
+sys.path.insert(0, %r)
+import zang_amd
+from zang_amd import abi
+ctx = zang_amd.default_context()
+lib = ctx.lib
+uid = (C.c_uint8 * abi.COMM_ID_BYTES)()
+assert lib.zh_comm_unique_id(uid) == 0
+h = C.c_void_p()
+t0 = time.time()
+rc = lib.zh_comm_create(ctx.handle, 2, 0, uid, C.byref(h))
+dt = time.time() - t0
+print("rc", rc, "seconds %%.1f" %% dt, "message:", lib.zh_comm_last_error().decode())
+sys.stdout.flush()
+os._exit(0 if (rc == abi.ZH_ERR_COMM and 3.0 < dt < 60.0 and not h.value) else 1)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, ZH_COMM_TIMEOUT_S="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert "no rendezvous within 4 s" in r.stdout

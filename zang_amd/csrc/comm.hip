@@ -6,6 +6,11 @@
 // librccl is opened with dlopen at first use (like hiprtc in script.hip) so that the library itself does not depend
 // on it: a single-GPU host never loads it.
 #include "common.hip.h"
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -146,9 +151,42 @@ int zh_comm_create(zh_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t *id
     c->ctx = ctx; c->comm = nullptr; c->world = world; c->rank = rank;
     ncclUniqueId id;
     memcpy(id.internal, id128, ZH_COMM_ID_BYTES);
-    // blocks until every rank of `world` has called it with the same id (RCCL's bootstrap); the device is ctx's
-    const int rc = r.comm_init_rank(&c->comm, (int)world, id, (int)rank);
-    if (rc != kNcclSuccess) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    // ncclCommInitRank blocks until every rank of `world` has called it with the same id (RCCL's bootstrap); the device is ctx's.
+    // A rank that never arrives (it failed earlier, or returned early from this very function: include/zang_hip.h "ALL OR NONE")
+    // would leave the others here for ever: the call runs on a helper thread and this one waits ZH_COMM_TIMEOUT_S seconds for it
+    // (default 180; 0 = wait without limit, on this thread).  On a timeout the helper stays behind (detached, it may never
+    // return) and the caller gets ZH_ERR_COMM with the reason -- a hang turned into an error the host can act on.
+    const char *te = getenv("ZH_COMM_TIMEOUT_S");
+    const double limit = te ? atof(te) : 180.0;
+    if (!(limit > 0.0)) {
+        const int rc = r.comm_init_rank(&c->comm, (int)world, id, (int)rank);
+        if (rc != kNcclSuccess) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+        *out = c;
+        return ZH_OK;
+    }
+    struct Shared { std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; ncclComm_t comm = nullptr; };
+    auto sh = std::make_shared<Shared>();
+    const int device = ctx->device;
+    std::thread([sh, &r, world, id, rank, device]() {
+        (void)hipSetDevice(device);
+        ncclComm_t cm = nullptr;
+        const int rc = r.comm_init_rank(&cm, (int)world, id, (int)rank);
+        std::lock_guard<std::mutex> lk(sh->mu);
+        sh->rc = rc; sh->comm = cm; sh->done = true;
+        sh->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(sh->mu);
+        if (!sh->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return sh->done; })) {
+            delete c;
+            char msg[200];
+            snprintf(msg, sizeof msg, "zh_comm_create: rank %u of %u saw no rendezvous within %.0f s (ZH_COMM_TIMEOUT_S): has every rank called it with the same id?", rank, world, limit);
+            g_last_error = msg;
+            return ZH_ERR_COMM;
+        }
+        if (sh->rc != kNcclSuccess) { delete c; return rccl_fail("ncclCommInitRank", sh->rc); }
+        c->comm = sh->comm;
+    }
     *out = c;
     return ZH_OK;
 }
