@@ -157,24 +157,53 @@ def test_filter_tolerant_long_span_in_pieces(ctx, oracle):
     util.assert_bitexact(util.from_image(out)[:, 20:20 + 128], steps[0][0][:, 20:20 + 128], "first chunk")      # 4,096 frames as 32 chunks of 128
 
 
-def test_tolerant_flag_changes_nothing_where_it_is_not_honoured(ctx, oracle):
-    """Control-image cutoff, too many voices, bypass: the flag is accepted and the exact forms run -- bit-exact."""
+@pytest.mark.parametrize("ck,rk", [("b", "c"), ("c", "b"), ("b", "b")])
+@pytest.mark.parametrize("ftype,shape", [(1, "noise"), (3, "sweep"), (5, "sweep")])
+def test_filter_tolerant_control_images(ctx, oracle, ck, rk, ftype, shape):
+    """Cutoff and / or resonance from control images: the step's matrix changes every frame, a chunk's transition is the product of
+    its frames' matrices (carried as two more recurrences on the unit states).  Per-frame white noise in the images (the worst
+    case) and smooth sweeps (an envelope-driven filter); every image path, += over three sub-spans with carried state."""
     from zang_amd import modules as mod, zang
-    V = 128
-    rng = np.random.default_rng(12)
-    cut = rng.uniform(0, 1, V).astype(np.float32); res = rng.uniform(0, 1, V).astype(np.float32)
-    cbuf = rng.uniform(0, 1, (V, F)).astype(np.float32)
+    V = 640
+    rng = np.random.default_rng(900 + ftype)
+    cut = rng.uniform(0.0, 1.0, V).astype(np.float32); res = rng.uniform(0.0, 0.95, V).astype(np.float32)
+    if shape == "noise":
+        cbuf = rng.uniform(-0.1, 1.1, (V, F)).astype(np.float32); rbuf = rng.uniform(-0.1, 1.1, (V, F)).astype(np.float32)
+    else:
+        t = np.arange(F, dtype=np.float32)[None, :] / F
+        cbuf = (0.02 + 0.6 * np.abs(np.sin(2 * np.pi * (t * rng.uniform(0.5, 3.0, (V, 1)) + rng.random((V, 1)))))).astype(np.float32)
+        rbuf = (0.1 + 0.8 * t * rng.random((V, 1))).astype(np.float32)
     inp = util.rng_buffers(3, V, F); out0 = util.rng_buffers(4, V, F)
     L = oracle.lib()
-    ref = out0.copy()
+    sts = []
     for v in range(V):
-        st = oracle.Filter(); L.zo_filter_init(C.byref(st))
-        L.zo_filter_paint(C.byref(st), 0, F, oracle.fptr(ref[v]), oracle.fptr(inp[v]), 1, oracle.buffer(cbuf[v]), oracle.constant(res[v]))
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st)); sts.append(st)
     m = mod.Filter(V, ctx)
-    out = util.to_image(out0)
-    m.paint(zang.Span(0, F), [out], [], False, m.Params(util.to_image(inp), 1, zang.buffer(util.to_image(cbuf)), zang.constant(util.dev(res))), tolerant=True)
-    ctx.sync()
-    util.assert_bitexact(util.from_image(out), ref, "cutoff image + tolerant flag")
+    gi, gc, gr = util.to_image(inp), util.to_image(cbuf), util.to_image(rbuf)
+    dc, dr = util.dev(cut), util.dev(res)
+    for (s, e) in [(0, 1024), (0, 1024), (100, 612), (612, 1000)]:
+        ref = out0.copy()
+        for v in range(V):
+            L.zo_filter_paint(C.byref(sts[v]), s, e, oracle.fptr(ref[v]), oracle.fptr(inp[v]), ftype,
+                              oracle.buffer(cbuf[v]) if ck == "b" else oracle.constant(cut[v]), oracle.buffer(rbuf[v]) if rk == "b" else oracle.constant(res[v]))
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(gi, ftype, zang.buffer(gc) if ck == "b" else zang.constant(dc), zang.buffer(gr) if rk == "b" else zang.constant(dr)), tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)
+        rl = np.array([t_.l for t_ in sts], np.float32); rb = np.array([t_.b for t_ in sts], np.float32)
+        tag = f"filter images {ck}{rk} type {ftype} {shape} span {(s, e)}"
+        util.assert_bitexact(got[:, :s], ref[:, :s], tag); util.assert_bitexact(got[:, e:], ref[:, e:], tag)
+        Lc = _chunk_len(V, e - s)
+        util.assert_bitexact(got[:, s:s + Lc], ref[:, s:s + Lc], tag + " first chunk")
+        util.assert_peak_close(got, ref, tag, s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb)))
+        st = m.state(); st["l"] = rl; st["b"] = rb; m.set_state(st)
+
+
+def test_tolerant_flag_changes_nothing_where_it_is_not_honoured(ctx, oracle):
+    """Too many voices, bypass: the flag is accepted and the exact forms run -- bit-exact."""
+    from zang_amd import modules as mod, zang
+    rng = np.random.default_rng(12)
+    L = oracle.lib()
     # 20,000 voices: above the time-parallel form's limit
     V2 = 20000
     idx = np.arange(0, V2, 157)
@@ -190,6 +219,14 @@ def test_tolerant_flag_changes_nothing_where_it_is_not_honoured(ctx, oracle):
         st = oracle.Filter(); L.zo_filter_init(C.byref(st))
         L.zo_filter_paint(C.byref(st), 0, F, oracle.fptr(ref2[k]), oracle.fptr(inp2[v]), 3, oracle.constant(cut2[v]), oracle.constant(res2[v]))
     util.assert_bitexact(got, ref2, "20,000 voices + tolerant flag")
+    # bypass: out += in
+    V = 128
+    inp = util.rng_buffers(3, V, F); out0 = util.rng_buffers(4, V, F)
+    m = mod.Filter(V, ctx)
+    out = util.to_image(out0)
+    m.paint(zang.Span(0, F), [out], [], False, m.Params(util.to_image(inp), 0, zang.constant(0.3), zang.constant(0.3)), tolerant=True)
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), (out0 + inp).astype(np.float32), "bypass + tolerant flag")
 
 
 # ------------------------------------------------------------------ the fused white Noise -> Filter voice (config 3)

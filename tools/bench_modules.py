@@ -54,6 +54,8 @@ def _env(o, m=m):
     m.paint(span, [o], [], k == 0, m.Params(SR, zang.PaintCurve.cubed(0.01), zang.PaintCurve.cubed(0.1), zang.PaintCurve.cubed(0.05), 0.8, k < 4), zero_first=True)
 case("Envelope (cubed, note on 4 buffers / off 4)", m, _env)
 m = mod.Gate(V, ctx); case("Gate", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(True), zero_first=True))
+cbuf = ctx.image(F, V); cbuf.copy_((cutoff[None, :] * (0.5 + 0.5 * torch.linspace(0, 1, F, device=dev)[:, None])).expand(F, V))      # a cutoff sweep (control image)
+m = mod.Filter(V, ctx); case("Filter low-pass, cutoff image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.low_pass, zang.buffer(cbuf), zang.constant(res)), zero_first=True), 2)
 m = mod.Filter(V, ctx); case("Filter low-pass, const cutoff / res", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.low_pass, zang.constant(cutoff), zang.constant(res)), zero_first=True), 1)
 m = mod.Sampler(V, ctx); smp = m.Sample(1, 44100, m.signed16_lsb, pcm)
 case("Sampler s16 mono, resampled, loop", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, smp, 0, True), zero_first=True))
@@ -67,6 +69,7 @@ rel = torch.full((V,), 0.3, dtype=torch.float32, device=dev)
 m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument (fused)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True))
 m = mod.PMOscInstrument(V, rel, ctx); case("PMOscInstrument, ZH_PAINT_TOLERANT (carrier)", m, lambda o, m=m: m.paint(span, [o], None, False, m.Params(SR, freq, True), zero_first=True, tolerant=True))
 if V <= 16384:
+    m = mod.Filter(V, ctx); case("Filter low-pass, cutoff image, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.low_pass, zang.buffer(cbuf), zang.constant(res)), zero_first=True, tolerant=True), 2)
     m = mod.Filter(V, ctx); case("Filter low-pass const, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, m.low_pass, zang.constant(cutoff), zang.constant(res)), zero_first=True, tolerant=True), 1)
 
 m = mod.SimpleDelay(V, 300, ctx); case("SimpleDelay(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp), zero_first=True), 3)

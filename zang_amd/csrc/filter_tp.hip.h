@@ -116,56 +116,98 @@ static inline uint32_t zh_tp_chunks(uint32_t V, const char *max_env, uint32_t n)
 struct FilterTpArgs {
     float *l, *b;
     float2 *e;
+    float4 *m;                   // control-image cutoff / resonance: chunk j's transition matrix (slot j), [chunks][V]
     uint32_t V, start, end, L;
     Img out;
     CImg input;
     float l_mul, b_mul, h_mul;
-    F32P cutoff, res;
+    CobP cutoff, res;
 };
-// body(k, in) for the frames [f0, f1) of one lane, in = input + fcdcoffset (:135): 8-row tiles, the tile's loads ahead of its use
-template <class Body>
-__device__ __forceinline__ void tp_input_tiles(const CImg &input, uint32_t voff, uint32_t f0, uint32_t f1, Body body) {
-    const uint32_t irow = (uint32_t)input.stride * 4u;
+// body(f, in, cutoff_i, res_i) for the frames [f0, f1) of one lane, in = input + fcdcoffset (:135): 8-row tiles, the tile's loads
+// ahead of its use.  CB / RB: the cutoff / resonance come from control images (clamped per frame, Filter.zig:126-128).
+template <bool CB, bool RB, class Body>
+__device__ __forceinline__ void tp_input_tiles(const FilterTpArgs &a, uint32_t voff, uint32_t f0, uint32_t f1, float cut_c, float res_c, Body body) {
+    const uint32_t irow = (uint32_t)a.input.stride * 4u, crow = (uint32_t)a.cutoff.b.stride * 4u, rrow = (uint32_t)a.res.b.stride * 4u;
+    auto clampcut = [](float x) ZH_INLINE_LAMBDA { return zclampf(x, 0.0f, 1.0f); };
+    auto clampres = [](float x) ZH_INLINE_LAMBDA { return 1.0f - zclampf(x, 0.0f, 1.0f); };
     uint32_t f = f0;
     for (; f + 8 <= f1; f += 8) {
-        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, f);
-        float x[8];
+        const zh_rsrc_t ri = zrow_rsrc(a.input.p, a.input.stride, f);
+        float x[8], c[8], r[8];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) x[q] = zrow_load<1>(ri, voff, q * irow) + kSvfDcOffset;
+        for (uint32_t q = 0; q < 8; q++) {
+            x[q] = zrow_load<1>(ri, voff, q * irow) + kSvfDcOffset;
+            if (CB) c[q] = zrow_load<1>(zrow_rsrc(a.cutoff.b.p, a.cutoff.b.stride, f), voff, q * crow);
+            if (RB) r[q] = zrow_load<1>(zrow_rsrc(a.res.b.p, a.res.b.stride, f), voff, q * rrow);
+        }
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) body(f + q, x[q]);
+        for (uint32_t q = 0; q < 8; q++) body(f + q, x[q], CB ? clampcut(c[q]) : cut_c, RB ? clampres(r[q]) : res_c);
     }
-    if (f < f1) {
-        const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, f);
-        for (uint32_t q = 0; f + q < f1; q++) body(f + q, zrow_load<1>(ri, voff, q * irow) + kSvfDcOffset);
+    for (; f < f1; f++) {
+        const float x = zrow_load<1>(zrow_rsrc(a.input.p, a.input.stride, f), voff, 0) + kSvfDcOffset;
+        const float c = CB ? clampcut(zrow_load<1>(zrow_rsrc(a.cutoff.b.p, a.cutoff.b.stride, f), voff, 0)) : cut_c;
+        const float r = RB ? clampres(zrow_load<1>(zrow_rsrc(a.res.b.p, a.res.b.stride, f), voff, 0)) : res_c;
+        body(f, x, c, r);
     }
 }
-template <int DUMMY = 0>
+// the step of Filter.zig:135-144 without its inputs (in = 0, no dc offset): the homogeneous part, in f32 like the step itself
+__device__ __forceinline__ void svf_hom_step(float &l, float &b, float cut, float res) {
+    l = l + cut * b;                                                  // :138
+    b = b + cut * (-(b * res) - l);                                   // :139
+    l = l + cut * b;                                                  // :142
+    const float h = -(b * res) - l;                                   // :143
+    b = b + cut * h;                                                  // :144
+}
+// Pass A.  With control images the step's matrix changes from frame to frame, so a chunk's transition is the PRODUCT of its
+// frames' matrices: the chunk also carries the two unit states through the homogeneous step (two more recurrences) and leaves
+// the four numbers they end on -- the columns of that product -- beside e_j.
+template <bool CB, bool RB>
 __global__ void __launch_bounds__(256) k_filter_tp_a(const FilterTpArgs a) {
     const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= a.V) return;
     if (j == 0) a.e[v] = make_float2(a.l[v], a.b[v]);
     const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);
-    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
-    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
+    const float cut = CB ? 0.0f : zclampf(a.cutoff.c.get(v), 0.0f, 1.0f);          // Filter.zig:114
+    const float res = RB ? 0.0f : 1.0f - zclampf(a.res.c.get(v), 0.0f, 1.0f);      // :118
     float l = 0.0f, b = 0.0f;
-    tp_input_tiles(a.input, v * 4u, f0, f1, [&](uint32_t, float in) ZH_INLINE_LAMBDA { svf_core(l, b, in, cut, res); });
+    float ul = 1.0f, ub = 0.0f, wl = 0.0f, wb = 1.0f;                               // the unit states (CB || RB)
+    tp_input_tiles<CB, RB>(a, v * 4u, f0, f1, cut, res, [&](uint32_t, float in, float c, float r) ZH_INLINE_LAMBDA {
+        svf_core(l, b, in, c, r);
+        if (CB || RB) { svf_hom_step(ul, ub, c, r); svf_hom_step(wl, wb, c, r); }
+    });
     a.e[(size_t)(j + 1) * a.V + v] = make_float2(l, b);
+    if (CB || RB) a.m[(size_t)j * a.V + v] = make_float4(ul, wl, ub, wb);            // (m00, m01, m10, m11)
 }
-template <bool ZF>
+template <bool ZF, bool CB, bool RB>
 __global__ void __launch_bounds__(256) k_filter_tp_b(const FilterTpArgs a) {
     const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= a.V) return;
     const size_t V = a.V;
     const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);
-    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);
-    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);
+    const float cut = CB ? 0.0f : zclampf(a.cutoff.c.get(v), 0.0f, 1.0f);
+    const float res = RB ? 0.0f : 1.0f - zclampf(a.res.c.get(v), 0.0f, 1.0f);
     const float2 s0 = a.e[v];
     float l = s0.x, b = s0.y;
-    svf_scan<kTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
+    if constexpr (CB || RB) {
+        if (j > 0) {                                                  // s_j = M_{j-1} s_{j-1} + e_{j-1}, every operand requested first
+            float2 e[kTpMaxChunks - 1];
+            float4 m[kTpMaxChunks - 1];
+#pragma unroll
+            for (uint32_t i = 0; i < kTpMaxChunks - 1; i++) { e[i] = a.e[(size_t)(i + 1) * V + v]; m[i] = a.m[(size_t)i * V + v]; }
+#pragma unroll
+            for (uint32_t i = 0; i < kTpMaxChunks - 1; i++)
+                if (i < j) {                                          // wave-uniform
+                    const float nl = (m[i].x * l + m[i].y * b) + e[i].x;
+                    const float nb = (m[i].z * l + m[i].w * b) + e[i].y;
+                    l = nl; b = nb;
+                }
+        }
+    } else {
+        svf_scan<kTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
+    }
     const uint32_t voff = v * 4u;
-    tp_input_tiles(a.input, voff, f0, f1, [&](uint32_t f, float in) ZH_INLINE_LAMBDA {
-        const SvfOut sv = svf_core(l, b, in, cut, res);               // :138-144
+    tp_input_tiles<CB, RB>(a, voff, f0, f1, cut, res, [&](uint32_t f, float in, float c, float r) ZH_INLINE_LAMBDA {
+        const SvfOut sv = svf_core(l, b, in, c, r);                   // :138-144
         const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
         const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
         const float base = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
@@ -175,23 +217,35 @@ __global__ void __launch_bounds__(256) k_filter_tp_b(const FilterTpArgs a) {
 }
 
 #if !defined(ZH_DEVICE_ONLY)
+// floats of scratch per voice: (kTpMaxChunks + 1) float2 of e, then kTpMaxChunks float4 of transition matrices
+constexpr size_t kFilterTpFloats = (size_t)(kTpMaxChunks + 1) * 2 + (size_t)kTpMaxChunks * 4;
 // Launches the span as pieces of <= 32 chunks.  false = not taken (too many voices, a short span): the caller paints with its
-// exact form.  `e` = the module's scratch, (kTpMaxChunks + 1) * V float2.
-static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float2 *e, uint32_t V, Img out, CImg in, uint32_t start, uint32_t end, bool zf,
-                                       float l_mul, float b_mul, float h_mul, F32P cut, F32P res) {
+// exact form.  `scratch` = the module's, kFilterTpFloats * V floats.
+static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float *scratch, uint32_t V, Img out, CImg in, uint32_t start, uint32_t end, bool zf,
+                                       float l_mul, float b_mul, float h_mul, CobP cut, CobP res) {
     if (end - start < 64) return false;
     const uint32_t C = zh_tp_chunks(V, "ZH_FILTER_TP_MAX", end - start);
     if (C < 2) return false;
     const uint32_t piece = 4096;                                      // frames per launch pair: chunks of <= 128 frames
     FilterTpArgs a;
-    a.l = l; a.b = b; a.e = e; a.V = V; a.out = out; a.input = in; a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = cut; a.res = res;
+    a.l = l; a.b = b; a.e = reinterpret_cast<float2 *>(scratch); a.m = reinterpret_cast<float4 *>(scratch + (size_t)(kTpMaxChunks + 1) * 2 * V);
+    a.V = V; a.out = out; a.input = in; a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = cut; a.res = res;
+    const bool cb = cut.is_buffer != 0, rb = res.is_buffer != 0;
     for (uint32_t s = start; s < end; s += piece) {
         a.start = s; a.end = min(s + piece, end);
         a.L = (a.end - a.start + C - 1) / C;
         const dim3 grid((V + 255) / 256, (a.end - a.start + a.L - 1) / a.L);
-        hipLaunchKernelGGL(k_filter_tp_a<0>, grid, dim3(256), 0, st, a);
-        if (zf) hipLaunchKernelGGL(k_filter_tp_b<true>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_filter_tp_b<false>, grid, dim3(256), 0, st, a);
+#define ZH_FTP(CB_, RB_)                                                                                   \
+        do {                                                                                               \
+            hipLaunchKernelGGL((k_filter_tp_a<CB_, RB_>), grid, dim3(256), 0, st, a);                      \
+            if (zf) hipLaunchKernelGGL((k_filter_tp_b<true, CB_, RB_>), grid, dim3(256), 0, st, a);        \
+            else hipLaunchKernelGGL((k_filter_tp_b<false, CB_, RB_>), grid, dim3(256), 0, st, a);          \
+        } while (0)
+        if (cb && rb) ZH_FTP(true, true);
+        else if (cb) ZH_FTP(true, false);
+        else if (rb) ZH_FTP(false, true);
+        else ZH_FTP(false, false);
+#undef ZH_FTP
     }
     return true;
 }

@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) k_gate(uint32_t V, Img out, uint32_t star
 
 // =================================================================== Filter
 struct zh_filter { zh_ctx *ctx; uint32_t n; float *l, *b;
-                   float2 *tp_e; };   // ZH_PAINT_TOLERANT scratch (filter_tp.hip.h), allocated by the first tolerant paint outside a capture
+                   float *tp_e; };    // ZH_PAINT_TOLERANT scratch (filter_tp.hip.h kFilterTpFloats per voice), allocated by the first tolerant paint outside a capture
 
 template <bool ZF, bool CB, bool RB>
 __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out,
@@ -1627,10 +1627,11 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     const char *pe16 = zh_env("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
     const uint32_t pc16_max = pe16 ? (uint32_t)atoi(pe16) : (pe && pc_max == 0 ? 0u : 65536u);   // (ZH_FILTER_PC_MAX=0 alone switches both off)     // 36,864 / 49,152 / 65,536 voices: 97 / 103 / 116 us in one wave, 72 / 79 / 104; 81,920: 126 against 168
     // ZH_PAINT_TOLERANT, few voices: the span as chunks at once (filter_tp.hip.h); every other case paints with an exact form
-    if ((flags & ZH_PAINT_TOLERANT) && !cb && !rb && !bufs_alias(p->input, outputs[0])) {
+    if ((flags & ZH_PAINT_TOLERANT) && !bufs_alias(p->input, outputs[0]) && !cob_aliases(p->cutoff, outputs[0]) && !cob_aliases(p->res, outputs[0]) &&
+        outputs[0].stride <= (1u << 24) && p->input.stride <= (1u << 24) && (!cb || p->cutoff.buffer.stride <= (1u << 24)) && (!rb || p->res.buffer.stride <= (1u << 24))) {
         if (!m->tp_e && !m->ctx->capturing && zh_tp_chunks(m->n, "ZH_FILTER_TP_MAX", end - start) >= 2 &&
-            dev_alloc(&m->tp_e, (size_t)(kTpMaxChunks + 1) * m->n) != ZH_OK) { m->tp_e = nullptr; (void)hipGetLastError(); }
-        if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut.c, res.c))
+            dev_alloc(&m->tp_e, kFilterTpFloats * m->n) != ZH_OK) { m->tp_e = nullptr; (void)hipGetLastError(); }
+        if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut, res))
             return zh_launch_status();
     }
     if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
