@@ -114,6 +114,32 @@ int main() {
         } catch (const zang::Error &e) {
             printf("ok   out-of-range span rejected: %s\n", e.what());
         }
+        // the opt-in tolerant form from C++: flags = ZH_PAINT_ZERO_FIRST | ZH_PAINT_TOLERANT (include/zang_hip.h): north_star's 1e-5,
+        // here measured against the oracle relative to each voice's peak over the span
+        {
+            mod::NiceInstrument tol(ctx, V, zang::f32(dcolor));
+            std::vector<zo_nice_instrument> st(V);
+            for (uint32_t v = 0; v < V; v++) zo_nice_init(&st[v], color[v]);
+            double worst = 0.0;
+            const Call two[] = {{{0, F}, true, true}, {{0, F}, false, false}};
+            for (const Call &c : two) {
+                tol.paint(c.span, {fused_out}, {t0, t1}, zang::boolean(c.nic), {SR, 0, zang::f32(dfreq), zang::boolean(c.note_on)}, ZH_PAINT_ZERO_FIRST | ZH_PAINT_TOLERANT);
+                ctx.sync();
+                const std::vector<float> got = fused_out.download();
+                std::vector<float> ref((size_t)V * F, 0.0f);
+                for (uint32_t v = 0; v < V; v++) {
+                    zo_nice_paint(&st[v], 0, F, &ref[(size_t)v * F], rt0.data(), rt1.data(), c.nic ? 1 : 0, SR, freq[v], c.note_on ? 1 : 0);
+                    double peak = fmax(fabs((double)st[v].flt.l), fabs((double)st[v].flt.b)), err = 0.0;
+                    for (uint32_t f = 0; f < F; f++) {
+                        peak = fmax(peak, fabs((double)ref[(size_t)v * F + f]));
+                        err = fmax(err, fabs((double)got[(size_t)v * F + f] - (double)ref[(size_t)v * F + f]));
+                    }
+                    if (peak > 0.0) worst = fmax(worst, err / peak);
+                }
+            }
+            if (worst <= 1e-5) printf("ok   zh_nice_paint with ZH_PAINT_TOLERANT: worst sample %.2e of its voice's peak (allowed 1e-5)\n", worst);
+            else { printf("FAIL: tolerant paint off by %.2e of the peak\n", worst); ok = false; }
+        }
         // the mixdown from C++: four buffers as separate calls and as one batch launch, then the exchange step through a one-rank
         // RCCL communicator (the sum over one rank is the identity): same bits everywhere
         {

@@ -48,6 +48,7 @@ def test_cpp_host_parity_program():
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("PASS") and r.stdout.count("bit-exact") == 12      # 8 paints + batch L/R + RCCL L/R
+    assert "zh_nice_paint with ZH_PAINT_TOLERANT: worst sample" in r.stdout             # the opt-in flag from a compiled host
 
 
 @pytest.mark.gpu
