@@ -206,9 +206,10 @@ ZH_API int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_
  * for ever.  The host must therefore agree over its own channel BEFORE calling it that every rank (a) sees zh_comm_available()
  * == 1, (b) is not capturing and (c) got the id -- zang_amd.sharding.Comm does exactly that with a MIN all-reduce of the
  * flags; tests/cpp/comm_host.c relies on pipe EOF (a rank that dies closes its ends, the parent stops handing out the id, the
- * waiting ranks read EOF and leave).  Since round 4 the rendezvous itself has a limit: ZH_COMM_TIMEOUT_S seconds (default 180;
- * 0 = none), after which zh_comm_create returns ZH_ERR_COMM and zh_comm_last_error() says so -- a rank left alone gets an error it
- * can act on instead of a hang (`bench.py --preflight` runs the whole hand-shake before anything is timed). */
+ * waiting ranks read EOF and leave).  Opt-in since round 4: with ZH_COMM_TIMEOUT_S=<seconds> in the environment the rendezvous has
+ * a limit, after which zh_comm_create returns ZH_ERR_COMM and zh_comm_last_error() says so (the communicator is then created on a
+ * helper thread that stays behind on a timeout: meant for a host that would rather fail than wait and is about to exit;
+ * `bench.py --preflight` runs the whole hand-shake in child processes before anything is timed). */
 enum { ZH_COMM_ID_BYTES = 128 };
 typedef struct zh_comm zh_comm;
 ZH_API int  zh_comm_available(void);
