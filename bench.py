@@ -88,7 +88,7 @@ def parse(argv=None):
                          "(zh_ipc_alloc / zh_ipc_open / peer store / zh_sum_slots); prints pass/fail per rank as one JSON line; exit code "
                          "%d on any failure" % PREFLIGHT_FAILED)
     ap.add_argument("--tolerant", action="store_true",
-                    help="noise_filter / noise_filter_fused / nice: paint with ZH_PAINT_TOLERANT (opt-in time-parallel Filter forms, 1e-5 of the "
+                    help="noise_filter / noise_filter_fused / nice / nice_mix (few voices): paint with ZH_PAINT_TOLERANT (opt-in time-parallel Filter forms, 1e-5 of the "
                          "signal's peak instead of bits; csrc/filter_tp.hip.h); the line says so in config.tolerant")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
@@ -403,9 +403,9 @@ class Workload:
         t = self.targets[row]
         P = self.m.Params(SR, self.freq, on)
         if self.channels == 2:
-            self.m.paint_mix_stereo(self.span, t[0], t[1], self.gain_l, self.gain_r, new, P, zero_first=True)
+            self.m.paint_mix_stereo(self.span, t[0], t[1], self.gain_l, self.gain_r, new, P, zero_first=True, tolerant=self.tolerant)
         else:
-            self.m.paint_mix(self.span, t[0], new, P, zero_first=True)
+            self.m.paint_mix(self.span, t[0], new, P, zero_first=True, tolerant=self.tolerant)
 
     def step_batch(self, B):
         """B consecutive steps of the stereo mixdown workload as ONE launch (zh_nice_paint_mix_stereo_batch: what an offline

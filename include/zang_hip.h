@@ -63,8 +63,9 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *    where the span is then filtered as 32-128-frame chunks at once (csrc/filter_tp.hip.h: zero-state responses, a 2 x 2
         *    transition power, then the reference's own recurrence per chunk; measured error <= 5.8e-6 of the voice's peak over 7,200 random cases,
         *    2.5-3 x faster); the noise samples and generator states are exact, the filter state carries the samples' error;
-        *  - zh_nice_paint at up to 16,384 voices, spans of 128-4,096 frames: the same for the fused voice's filter (oscillator,
-        *    envelope and their states exact: the envelope is walked once per voice ahead of the chunks);
+        *  - zh_nice_paint, zh_nice_paint_mix and zh_nice_paint_mix_stereo at up to 16,384 voices, spans of 128-4,096 frames: the same
+        *    for the fused voice's filter (oscillator, envelope and their states exact: the envelope is walked once per voice ahead
+        *    of the chunks);
         *  - zh_noise_paint with ZH_NOISE_PINK at up to 16,384 voices: Kellett's six one-pole taps as chunks at once over exactly
         *    generated white noise (white noise itself, and the generator's state, are always exact);
         *  - zh_sineosc_paint and zh_pmosc_paint (its carrier) at any voice count: the sine of the reference's own rounded

@@ -572,3 +572,42 @@ def test_pink_noise_tolerant(ctx, oracle, V, zero_first):
         gs = m.state()
         assert [[int(x) for x in gs["r"][v]] for v in idx] == [list(n.r) for n in nzs], f"generator states after span {(s, e)}"
         util.assert_bitexact(gs["b"][idx].astype(np.float32), taps[idx], "the taps are never written back (Noise.zig:68)")
+
+
+@pytest.mark.parametrize("V", [1000, 4096])
+def test_nice_mix_tolerant(ctx, oracle, V):
+    """zh_nice_paint_mix / _stereo with the flag at few voices (k_nice_tp_a + k_nice_mix_tp_b) against the exact form of the same
+    calls on a twin module: every mixed sample within 1e-5 of the SUM of the voices' peaks times their gains (each voice carries its own
+    tolerance into the sum), rows outside the span untouched, oscillator and envelope states identical, over a note script."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    freq, color, u2, _ = workloads.voice_params(5, 3, V)
+    gl = (0.25 + 0.5 * u2).astype(np.float32); gr = (0.75 - 0.5 * u2).astype(np.float32)
+    gc = util.dev(color)
+    me, mt, mv = mod.NiceInstrument(V, gc, ctx), mod.NiceInstrument(V, gc, ctx), mod.NiceInstrument(V, gc, ctx)
+    m1e, m1t = mod.NiceInstrument(V, gc, ctx), mod.NiceInstrument(V, gc, ctx)
+    gf, dgl, dgr = util.dev(freq), util.dev(gl), util.dev(gr)
+    img = ctx.image(F, V)
+    for k, ((s, e), on, nic) in enumerate(NICE_SCRIPT[:8]):
+        P = me.Params(SR, gf, bool(on))
+        le = torch.full((F,), 0.5, device="cuda"); re_ = torch.full((F,), -0.25, device="cuda")
+        lt = le.clone(); rt = re_.clone(); oe = torch.zeros(F, device="cuda"); ot = torch.zeros(F, device="cuda")
+        me.paint_mix_stereo(zang.Span(s, e), le, re_, dgl, dgr, bool(nic), P)
+        mt.paint_mix_stereo(zang.Span(s, e), lt, rt, dgl, dgr, bool(nic), P, tolerant=True)
+        m1e.paint_mix(zang.Span(s, e), oe, bool(nic), P, zero_first=True)
+        m1t.paint_mix(zang.Span(s, e), ot, bool(nic), P, zero_first=True, tolerant=True)
+        mv.paint(zang.Span(s, e), [img], None, bool(nic), P, zero_first=True)          # the voices themselves, for the bound
+        ctx.sync()
+        peak = img[s:e].abs().amax(dim=0).double().cpu().numpy() if e > s else np.zeros(V)
+        for got, want, g, what in ((lt, le, gl, "left"), (rt, re_, gr, "right"), (ot, oe, np.ones(V, np.float32), "mono")):
+            got = got.cpu().numpy().astype(np.float64); want = want.cpu().numpy().astype(np.float64)
+            assert np.array_equal(got[:s], want[:s]) and np.array_equal(got[e:], want[e:]), (k, what)
+            bound = 1e-5 * float((peak * np.abs(g)).sum()) + 1e-6
+            assert np.abs(got - want).max() <= bound, (k, what, np.abs(got - want).max(), bound)
+            assert np.abs(got - want).max() <= 0.1 * bound + 4 * np.sqrt(V) * 6e-8 * max(1.0, float(np.abs(want).max())), (k, what, "measured margin")
+        se, st_ = me.state(), mt.state()
+        assert np.array_equal(se["osc"]["cnt"], st_["osc"]["cnt"]) and np.array_equal(se["env"]["state"], st_["env"]["state"])
+        assert np.array_equal(se["env"]["t"].view(np.uint32), st_["env"]["t"].view(np.uint32))
+        for mm in (mt, m1t):                                     # the exact twin's filter state on (the tolerance is per paint)
+            ss = mm.state(); ss["flt"] = se["flt"]; mm.set_state(ss)
+        ss = m1e.state(); s1 = m1t.state(); s1["flt"] = ss["flt"]; m1t.set_state(s1)

@@ -543,9 +543,11 @@ __device__ __forceinline__ void nice_mix_gains(G2 &g2, const F32P &gain_l, const
 template <int C, bool ROLL, bool WG, class G2>
 __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, const G2 &g2, float (*tile)[MIXS], float *__restrict__ pw_paint,
                                                 size_t channel_stride, uint32_t rows, uint32_t wrow, uint32_t start, uint32_t end, uint32_t lane,
-                                                uint32_t rf, uint32_t rh, float (*wsum)[4][C][MIXF] = nullptr, uint32_t wave = 0) {
+                                                uint32_t rf, uint32_t rh, float (*wsum)[4][C][MIXF] = nullptr, uint32_t wave = 0, uint32_t first = 0xFFFFFFFFu) {
+    // `first` (a chunk of a time-parallel paint, k_nice_mix_tp_b): the frames [first, end) of a span that starts at `start` -- the
+    // partial rows are indexed from the span's start
     uint32_t parity = 0;
-    for (uint32_t f0 = start; f0 < end; f0 += MIXF) {
+    for (uint32_t f0 = first == 0xFFFFFFFFu ? start : first; f0 < end; f0 += MIXF) {
         // a stage can only end inside a chunk, never begin: a wave with no voice in a timed stage at the chunk's first frame
         // (the 18 sustain buffers of a held note, an idle voice) skips the envelope for the whole chunk
         const bool whole = f0 + MIXF <= end;                            // (uniform)
@@ -859,6 +861,51 @@ __global__ void __launch_bounds__(256) k_nice_tp_b(const NiceTpArgs t) {
         },
         [&](uint32_t, float &val) ZH_INLINE_LAMBDA { val = n.template tail<ZF>(n.osc_next(roll)); return true; });
     if (f1 == t.end) nice_store(n, a, v);                              // whoever painted the span's last frame leaves the states
+}
+
+// The mixdown workload with the flag (zh_nice_paint_mix[_stereo], few voices): pass A is k_nice_tp_a; pass B sets a chunk's voices up
+// like k_nice_tp_b and runs the fused mixdown's own frame code (nice_mix_frames) over the chunk's frames -- 32-frame tiles, so the
+// chunks are multiples of 32 frames -- one partial row per wave, then the ordinary second pass.
+template <int C, bool ROLL>
+__global__ void __launch_bounds__(256) k_nice_mix_tp_b(const NiceTpArgs t, float *__restrict__ partials, F32P gain_l, F32P gain_r) {
+    __shared__ float tile_all[4][MIXF][MIXS];
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    const NiceArgs &a = t.a;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*tile)[MIXS] = tile_all[wave];
+    const uint32_t nframes = t.end - t.start;
+    const uint32_t wave_global = blockIdx.x * 4 + wave, rows = gridDim.x * 4;
+    const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;
+    const bool live = v < a.V;
+    const uint32_t vc = live ? v : a.V - 1;
+    const uint32_t f0 = min(t.start + j * t.L, t.end), f1 = min(f0 + t.L, t.end);
+    NiceArgs a0 = a;                                                   // the start state as pass A copied it
+    a0.cnt = nice_tp_state0(t, 0); a0.fl = reinterpret_cast<float *>(nice_tp_state0(t, 1)); a0.fb = reinterpret_cast<float *>(nice_tp_state0(t, 2));
+    a0.estate = nice_tp_state0(t, 3); a0.et = reinterpret_cast<float *>(nice_tp_state0(t, 4));
+    a0.elast = reinterpret_cast<float *>(nice_tp_state0(t, 5)); a0.estart = reinterpret_cast<float *>(nice_tp_state0(t, 6));
+    NiceLane n;
+    nice_load(n, a0, vc);
+    n.cnt = n.cnt + (f0 - t.start) * n.k.ifreq;
+    {
+        const float2 s0 = nice_tp_e(t, 0)[vc];
+        n.l = s0.x; n.b = s0.y;
+        const float2 *e = nice_tp_e(t, 1) + vc;
+        const size_t V = a.V;
+        svf_scan<kNiceTpMaxChunks - 1>(n.l, n.b, n.cut, n.res, t.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return e[(size_t)i * V]; });
+    }
+    n.env.state = nice_tp_env(t, j, 0)[vc]; n.env.t = __builtin_bit_cast(float, nice_tp_env(t, j, 1)[vc]);
+    n.env.last_value = __builtin_bit_cast(float, nice_tp_env(t, j, 2)[vc]); n.env.start = __builtin_bit_cast(float, nice_tp_env(t, j, 3)[vc]);
+    n.env.resolve(true);
+    n.env.refresh_derived();
+    if (!live) nice_silence(n);
+    const uint32_t rf = lane & (MIXF - 1), rh = lane >> 5;
+    PulseRoll roll;
+    n.roll_begin(roll);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 g2[C == 2 ? 32 : 1];
+    nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
+    nice_mix_frames<C, ROLL, false>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, t.start, f1, lane, rf, rh, nullptr, 0, f0);
+    if (live && f1 == t.end && f1 > f0) nice_store(n, a, v);
 }
 
 // ------------------------------------------------------------------ PMOscInstrument voice
@@ -1858,6 +1905,30 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     NiceArgs a = nice_args(m, p, note_id_changed);
     float *part = m->ctx->mix_partials;
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
+    // ZH_PAINT_TOLERANT, few voices: the span as chunks at once (k_nice_tp_a, k_nice_mix_tp_b), chunks of whole 32-frame tiles
+    if ((flags & ZH_PAINT_TOLERANT) && !wg && nframes >= 128 && nframes <= kNiceTpMaxChunks * 128u) {
+        const uint32_t Cn = zh_tp_chunks(m->n, "ZH_NICE_TP_MAX", nframes);
+        if (Cn >= 2 && !m->tp && !m->ctx->capturing && dev_alloc(&m->tp, (size_t)kNiceTpWords * m->n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
+        if (Cn >= 2 && m->tp) {
+            NiceTpArgs t;
+            t.a = a; t.tp = m->tp; t.start = start; t.end = end; t.L = ((nframes + Cn - 1) / Cn + MIXF - 1) / MIXF * MIXF; t.out = Img{nullptr, 0};
+            const dim3 grid(blocks, (nframes + t.L - 1) / t.L);
+            hipLaunchKernelGGL(k_nice_tp_a, grid, dim3(256), 0, st, t);
+            const bool roll = nice_mix_roll();
+            if (stereo) {
+                const F32P gl = mk_f32(*gain_l), gr = mk_f32(*gain_r);
+                if (roll) hipLaunchKernelGGL((k_nice_mix_tp_b<2, true>), grid, dim3(256), 0, st, t, part, gl, gr);
+                else hipLaunchKernelGGL((k_nice_mix_tp_b<2, false>), grid, dim3(256), 0, st, t, part, gl, gr);
+                zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, mix_r + start, 2, zf);
+            } else {
+                const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
+                if (roll) hipLaunchKernelGGL((k_nice_mix_tp_b<1, true>), grid, dim3(256), 0, st, t, part, none, none);
+                else hipLaunchKernelGGL((k_nice_mix_tp_b<1, false>), grid, dim3(256), 0, st, t, part, none, none);
+                zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, nullptr, 1, zf);
+            }
+            return zh_launch_status();
+        }
+    }
 #define ZH_NMIX(C_, ROLL_, WG_, GL_, GR_) hipLaunchKernelGGL((k_nice_mix<C_, ROLL_, WG_>), dim3(blocks), dim3(256), 0, st, a, start, end, part, GL_, GR_)
     const bool roll = nice_mix_roll();
     if (stereo) {

@@ -387,19 +387,19 @@ class NiceInstrument(_Module):
                                           float(sample_rate), C.byref(table.c), abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
         abi.check(rc, "zh_nice_paint_spans")
 
-    def paint_mix(self, span, mix, note_id_changed, params, zero_first=False):
+    def paint_mix(self, span, mix, note_id_changed, params, zero_first=False, tolerant=False):
         """The fused chain followed by the voice mixdown into mix[frames] (device float32)."""
         cp = abi.NiceParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
         rc = self.lib.zh_nice_paint_mix(self.handle, span.start, span.end, mix.data_ptr(), as_bool(note_id_changed),
-                                        C.byref(cp), abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+                                        C.byref(cp), (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | (abi.PAINT_TOLERANT if tolerant else 0))
         abi.check(rc, "zh_nice_paint_mix")
 
-    def paint_mix_stereo(self, span, mix_left, mix_right, gain_left, gain_right, note_id_changed, params, zero_first=False):
+    def paint_mix_stereo(self, span, mix_left, mix_right, gain_left, gain_right, note_id_changed, params, zero_first=False, tolerant=False):
         """Two channels: mix_c[f] (+)= sum over voices of voice[f] * gain_c[voice] (examples/example_stereo.zig:92-98)."""
         cp = abi.NiceParams(params.sample_rate, 0, as_f32(params.freq), as_bool(params.note_on))
         rc = self.lib.zh_nice_paint_mix_stereo(self.handle, span.start, span.end, mix_left.data_ptr(), mix_right.data_ptr(),
                                                as_f32(gain_left), as_f32(gain_right), as_bool(note_id_changed), C.byref(cp),
-                                               abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+                                               (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | (abi.PAINT_TOLERANT if tolerant else 0))
         abi.check(rc, "zh_nice_paint_mix_stereo")
 
     def paint_mix_stereo_batch(self, span, mix_lefts, mix_rights, gain_left, gain_right, note_id_changeds, paramses, zero_first=False):
