@@ -9,6 +9,7 @@
 #include "common.hip.h"
 #include "zmath.hip.h"
 #include "dsp.hip.h"
+#include "filter_tp.hip.h"
 #include <vector>
 
 struct DelayState {
@@ -18,7 +19,8 @@ struct DelayState {
 };
 
 struct zh_delay { zh_ctx *ctx; DelayState d; };
-struct zh_filtered_echoes { zh_ctx *ctx; DelayState d; float *l, *b; };
+struct zh_filtered_echoes { zh_ctx *ctx; DelayState d; float *l, *b;
+                            float *tp; };   // ZH_PAINT_TOLERANT scratch (kFeTpFloats per voice), allocated by the first tolerant paint outside a capture
 
 // The reference moves data in chunks of <= delay_samples frames: read the ring for the whole chunk, then write it
 // (delay.zig:28-89).  Within such a chunk every frame touches a different ring slot, each last written at least
@@ -390,6 +392,122 @@ __global__ void __launch_bounds__(192) k_filtered_echoes_pc(DelayState d, float 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- FilteredEchoes, tolerant
+// ZH_PAINT_TOLERANT at few voices (filter_tp.hip.h).  Over a piece of at most delay_samples frames every frame reads a ring slot
+// that was written before the piece began (delay.zig:28-89: a slot is read delay_samples frames after it was written), so the
+// filter's input ((0 + ring) * feedback + x, examples/modules.zig:425-436) is known for the whole piece up front and the
+// piece is an ordinary constant-parameter Filter paint: chunks at once from a zero state (pass A), the scan of the chunk-start
+// states, the reference's own recurrence again from them (pass B), which also does the `+=` and writes temp1 into the ring
+// (:448-452).  A span longer than the delay is painted as successive pieces (a launch pair each).  Inside a chunk the
+// arithmetic is the reference's; what is tolerant is each chunk's start state, as for the Filter module.
+// Scratch per voice: (kTpMaxChunks + 1) float2 -- slot 0 = the filter state at the piece's start, slot j + 1 = e_j -- and the
+// ring index at the piece's start (pass B's last chunk moves the module's index while other chunks still need the old one).
+constexpr size_t kFeTpFloats = (size_t)(kTpMaxChunks + 1) * 2 + 1;
+struct FeTpArgs {
+    DelayState d;
+    float *l, *b;
+    float2 *e;
+    uint32_t *idx0;
+    uint32_t start, end, L;
+    Img out;
+    CImg input;
+    F32P feedback, cutoff;
+};
+// body(f, k, delayed, x, base, ro, rr, rows) for the frames [f0, f1) of one lane, 8-frame tiles with the tile's loads ahead of
+// its use.  rows: the wave's voices share one ring index and the tile's eight slots do not wrap -> ring rows addressed like
+// image rows (descriptor rr, row k); otherwise per-lane slot arithmetic (slot_ptr).
+template <bool BASE, class Body>
+__device__ __forceinline__ void fe_tp_tiles(const FeTpArgs &a, uint32_t v, uint32_t idx0, uint32_t f0, uint32_t f1, Body body) {
+    const uint32_t D = a.d.delay_samples, voff = v * 4u;
+    const uint32_t rrow = a.d.n * 4u, irow = (uint32_t)a.input.stride * 4u, orow = (uint32_t)a.out.stride * 4u;
+    const bool uni = __builtin_amdgcn_ballot_w64(idx0 != (uint32_t)__builtin_amdgcn_readfirstlane((int)idx0)) == 0;
+    auto slot_of = [&](uint32_t f) ZH_INLINE_LAMBDA {                   // f - start < D and idx0 < D: one conditional subtraction
+        const uint32_t s = idx0 + (f - a.start);
+        return (s >= D || s < idx0) ? s - D : s;
+    };
+    uint32_t f = f0;
+    for (; f + 8 <= f1; f += 8) {
+        const zh_rsrc_t ri = zrow_rsrc(a.input.p, a.input.stride, f), ro = zrow_rsrc(a.out.p, a.out.stride, f);
+        const uint32_t sl0 = slot_of(f), s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl0);
+        const bool rows = uni && s0 + 8 <= D && s0 + 8 > s0;           // wave-uniform
+        const zh_rsrc_t rr = zrow_rsrc(a.d.ring, a.d.n, rows ? s0 : 0u);
+        float dl[8], x[8], base[8];
+        float *sp[8];
+        if (rows) {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) { dl[k] = zrow_load<1>(rr, voff, k * rrow); sp[k] = nullptr; }
+        } else {
+            uint32_t sl = sl0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                sp[k] = a.d.ring + (size_t)sl * a.d.n + v;
+                dl[k] = *sp[k];
+                sl = sl + 1 == D ? 0 : sl + 1;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            x[k] = zrow_load<1>(ri, voff, k * irow);
+            base[k] = BASE ? zrow_load<1>(ro, voff, k * orow) : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) body(k, dl[k], x[k], base[k], ro, rr, rows, sp[k]);
+    }
+    for (; f < f1; f++) {
+        const zh_rsrc_t ri = zrow_rsrc(a.input.p, a.input.stride, f), ro = zrow_rsrc(a.out.p, a.out.stride, f);
+        float *sp = a.d.ring + (size_t)slot_of(f) * a.d.n + v;
+        body(0u, *sp, zrow_load<1>(ri, voff, 0), BASE ? zrow_load<1>(ro, voff, 0) : 0.0f, ro, ro, false, sp);
+    }
+}
+__device__ __forceinline__ float fe_filter_input(float delayed, float x, float feedback) {
+    float t0 = 0.0f + delayed;                                        // zero(temp0); readDelayBuffer (examples/modules.zig:425-428)
+    t0 = t0 * feedback;                                               // multiplyWithScalar (:433)
+    return t0 + x;                                                    // addInto (:436)
+}
+// grid: x = 256-voice groups, y = chunk; block = 256
+__global__ void __launch_bounds__(256) k_fe_tp_a(const FeTpArgs a) {
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x, V = a.d.n;
+    if (v >= V) return;
+    const uint32_t idx0 = a.d.index[v];
+    if (j == 0) { a.e[v] = make_float2(a.l[v], a.b[v]); a.idx0[v] = idx0; }
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);
+    const float feedback = a.feedback.get(v);
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
+    const float res = 1.0f - zclampf(0.0f, 0.0f, 1.0f);               // res = constant(0.0) (:441) -> Filter.zig:118
+    float l = 0.0f, b = 0.0f;
+    fe_tp_tiles<false>(a, v, idx0, f0, f1, [&](uint32_t, float delayed, float x, float, const zh_rsrc_t &, const zh_rsrc_t &, bool, float *) ZH_INLINE_LAMBDA {
+        svf_step(l, b, fe_filter_input(delayed, x, feedback), cut, res);
+    });
+    a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
+}
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_fe_tp_b(const FeTpArgs a) {
+    const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.d.n) return;
+    const size_t V = a.d.n;
+    const uint32_t idx0 = a.idx0[v], D = a.d.delay_samples;
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);
+    const float feedback = a.feedback.get(v);
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);
+    const float res = 1.0f - zclampf(0.0f, 0.0f, 1.0f);
+    const float2 s0 = a.e[v];
+    float l = s0.x, b = s0.y;
+    svf_scan<kTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
+    const uint32_t voff = v * 4u, rrow = a.d.n * 4u, orow = (uint32_t)a.out.stride * 4u;
+    fe_tp_tiles<!ZF>(a, v, idx0, f0, f1, [&](uint32_t k, float delayed, float x, float base, const zh_rsrc_t &ro, const zh_rsrc_t &rr, bool rows, float *sp) ZH_INLINE_LAMBDA {
+        const SvfOut s = svf_step(l, b, fe_filter_input(delayed, x, feedback), cut, res);   // Filter.paint low_pass (Filter.zig:135-146)
+        const float t1 = svf_lowpass_into_zero(s.l, s.b);             // zero(temp1); += (:439)
+        zrow_store<1>(ro, voff, k * orow, base + t1);                 // addInto(output, temp1) (:448)
+        if (rows) zrow_store<1>(rr, voff, k * rrow, t1);              // writeDelayBuffer(temp1) (:452)
+        else *sp = t1;
+    });
+    if (f1 == a.end && f1 > f0) {
+        a.l[v] = l; a.b[v] = b;
+        const uint32_t s = idx0 + (a.end - a.start);                  // <= delay_samples frames per piece
+        a.d.index[v] = (s >= D || s < idx0) ? s - D : s;
+    }
+}
+
 // the chunked form needs a delay of at least a chunk and an input image that does not overlap the output image
 static bool delay_can_chunk(const DelayState &d, const zh_buf &out, const zh_buf &in) {
     if (d.delay_samples < 8) return false;
@@ -492,7 +610,7 @@ int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, z
     if (!ctx || !out || delay_samples == 0) return ZH_ERR_INVALID;
     zh_filtered_echoes *m = new (std::nothrow) zh_filtered_echoes();
     if (!m) return ZH_ERR_INVALID;
-    m->ctx = ctx; m->l = m->b = nullptr;
+    m->ctx = ctx; m->l = m->b = nullptr; m->tp = nullptr;
     int rc = delay_alloc(ctx, m->d, n, delay_samples);
     if (!rc) rc = dev_alloc(&m->l, n);
     if (!rc) rc = dev_alloc(&m->b, n);
@@ -505,7 +623,7 @@ int zh_filtered_echoes_create(zh_ctx *ctx, uint32_t n, uint32_t delay_samples, z
 int zh_filtered_echoes_destroy(zh_filtered_echoes *m) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m) return ZH_ERR_INVALID;
     (void)hipStreamSynchronize(m->ctx->stream);
-    delay_free(m->d); (void)hipFree(m->l); (void)hipFree(m->b);
+    delay_free(m->d); (void)hipFree(m->l); (void)hipFree(m->b); (void)hipFree(m->tp);
     delete m;
     return ZH_OK;
 }
@@ -537,6 +655,31 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->d.n, end) || !buf_covers(p->input, m->d.n, end)) return ZH_ERR_INVALID;
     if (m->d.n == 0 || end == start) return ZH_OK;
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
+    // ZH_PAINT_TOLERANT, few voices: pieces of <= delay_samples frames, each a time-parallel Filter paint (k_fe_tp_a / _b above).
+    // Not for a span of many pieces (a delay much shorter than the span: a launch pair per piece) -- the exact forms below then.
+    if ((flags & ZH_PAINT_TOLERANT) && chunked && end - start >= 64) {
+        const uint32_t n = end - start, D = m->d.delay_samples, piece = D < 4096u ? D : 4096u;
+        const uint32_t C = zh_tp_chunks(m->d.n, "ZH_ECHOES_TP_MAX", piece < n ? piece : n);
+        if (C >= 2 && piece >= 64 && (n + piece - 1) / piece <= 4) {
+            if (!m->tp && !m->ctx->capturing && dev_alloc(&m->tp, kFeTpFloats * m->d.n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
+            if (m->tp) {
+                FeTpArgs a;
+                a.d = m->d; a.l = m->l; a.b = m->b; a.e = reinterpret_cast<float2 *>(m->tp);
+                a.idx0 = reinterpret_cast<uint32_t *>(m->tp + (size_t)(kTpMaxChunks + 1) * 2 * m->d.n);
+                a.out = mk_img(outputs[0]); a.input = mk_cimg(p->input); a.feedback = mk_f32(p->feedback_volume); a.cutoff = mk_f32(p->cutoff);
+                for (uint32_t s = start; s < end; s += piece) {
+                    a.start = s; a.end = end - s > piece ? s + piece : end;
+                    const uint32_t len = a.end - a.start, c = C < len ? C : len;
+                    a.L = (len + c - 1) / c;
+                    const dim3 grid((m->d.n + 255) / 256, (len + a.L - 1) / a.L);
+                    hipLaunchKernelGGL(k_fe_tp_a, grid, dim3(256), 0, m->ctx->stream, a);
+                    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_fe_tp_b<true>, grid, dim3(256), 0, m->ctx->stream, a);
+                    else hipLaunchKernelGGL(k_fe_tp_b<false>, grid, dim3(256), 0, m->ctx->stream, a);
+                }
+                return zh_launch_status();
+            }
+        }
+    }
     // delay 300, one wave per 64 voices -> three: 1,024 / 4,096 / 16,384 / 32,768 / 65,536 voices 88 / 91 / 103 / 194 / 263 ->
     // 56 / 57 / 62 / 110 / 215 us; at 131,072 voices the one-wave form is ahead (406 against 461)
     const char *pe = zh_env("ZH_ECHOES_PC_MAX");                        // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
