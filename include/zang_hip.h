@@ -70,7 +70,11 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *    generated white noise (white noise itself, and the generator's state, are always exact);
         *  - zh_sineosc_paint and zh_pmosc_paint (its carrier) at any voice count: the sine of the reference's own rounded
         *    argument in f32 (csrc/zmath.hip.h zsinf_tol: 17 instructions for musl's 34, 15 of them f64; within 4e-7 of it);
-        *    phase and envelope states stay exact.
+        *    phase and envelope states stay exact;
+        *  - zh_filtered_echoes_paint at up to 6,144 voices when the span is at most three delay lengths (input image not the
+        *    output image): over a piece of <= delay_samples frames the ring's slots were all written before the piece, so the
+        *    filter's input is known up front and the piece is filtered as chunks at once (csrc/delay.hip k_fe_tp_a / _b); the
+        *    ring carries a paint's error into later ones (measured <= 4.5e-6 of the peak over 200 buffers, feedback 0.9).
         * Ignored elsewhere: every other form stays bit-exact, and so does a tolerant Filter paint's first chunk. */ };
 
 typedef struct zh_ctx zh_ctx;

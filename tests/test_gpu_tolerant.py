@@ -611,3 +611,99 @@ def test_nice_mix_tolerant(ctx, oracle, V):
         for mm in (mt, m1t):                                     # the exact twin's filter state on (the tolerance is per paint)
             ss = mm.state(); ss["flt"] = se["flt"]; mm.set_state(ss)
         ss = m1e.state(); s1 = m1t.state(); s1["flt"] = ss["flt"]; m1t.set_state(s1)
+
+
+FE_SPANS = [(0, 1024), (0, 1024), (100, 612), (612, 1000), (5, 170), (170, 200), (0, 1024)]
+
+
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("D,V,per_voice_index", [(400, 96, False), (1024, 320, False), (2000, 96, True), (15000, 130, False), (600, 130, True)])
+def test_filtered_echoes_tolerant(ctx, oracle, D, V, per_voice_index, zero_first):
+    """FilteredEchoes with the flag (delay.hip k_fe_tp_a / _b): pieces of <= delay_samples frames, each a time-parallel Filter
+    paint whose input -- the ring times the feedback plus the input image -- is known up front.  Seven paints in a row on the
+    module's OWN ring and filter state (the ring carries a paint's error into the next one, times the feedback and through the
+    filter): every sample within 1e-5 of the voice's peak (output or filter state), the first chunk of the first paint exact,
+    ring indices identical, the ring within the same bound."""
+    from zang_amd import abi, modules as mod, zang
+    rng = np.random.default_rng(77 + D)
+    fb = rng.uniform(0.1, 0.9, V).astype(np.float32); cutoff = rng.uniform(0.05, 1.0, V).astype(np.float32)
+    inp = [util.rng_buffers(120 + k, V, F) for k in range(len(FE_SPANS))]
+    out0 = util.rng_buffers(105, V, F)
+    idx = rng.integers(0, D, V).astype(np.uint32) if per_voice_index else np.zeros(V, np.uint32)
+    rings0 = rng.uniform(-1, 1, (V, D)).astype(np.float32)
+    L = oracle.lib()
+    ref = [out0.copy() for _ in FE_SPANS]
+    rings = rings0.copy(); rst = [[] for _ in FE_SPANS]
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    for v in range(V):
+        d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[v]), D)
+        rings[v] = rings0[v]; d.index = int(idx[v])
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
+        for k, (s, e) in enumerate(FE_SPANS):
+            if zero_first:
+                ref[k][v][s:e] = 0.0
+            L.zo_filtered_echoes_paint(C.byref(d), C.byref(fl), s, e, oracle.fptr(ref[k][v]), oracle.fptr(t0), oracle.fptr(t1),
+                                       oracle.fptr(inp[k][v]), float(fb[v]), float(cutoff[v]))
+            rst[k].append((d.index, fl.l, fl.b))
+    m = mod.FilteredEchoes(V, D, ctx)
+    flt = np.zeros(V, dtype=np.dtype(abi.FilterState))
+    abi.check(ctx.lib.zh_filtered_echoes_set_state(m.handle, rings0.ctypes.data, idx.ctypes.data, flt.ctypes.data), "set_state")
+    gfb, gc = util.dev(fb), util.dev(cutoff)
+    worst = 0.0
+    for k, (s, e) in enumerate(FE_SPANS):
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(util.to_image(inp[k]), gfb, gc), zero_first=zero_first, tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)
+        tag = f"filtered echoes tolerant D={D} V={V} paint {k} span {(s, e)} zf={zero_first}"
+        util.assert_bitexact(got[:, :s], ref[k][:, :s], tag + " before"); util.assert_bitexact(got[:, e:], ref[k][:, e:], tag + " after")
+        rl = np.array([r[1] for r in rst[k]], np.float32); rb = np.array([r[2] for r in rst[k]], np.float32)
+        if e - s < 64:
+            if k == 0:
+                util.assert_bitexact(got, ref[k], tag + " (short span: exact form)")
+        elif k == 0:
+            piece = min(D, 4096, e - s)
+            G = (V + 63) // 64; Cn = min(max(2, min(32, (2048 + G - 1) // G)), piece)
+            Lc = (piece + Cn - 1) // Cn
+            util.assert_bitexact(got[:, s:s + Lc], ref[k][:, s:s + Lc], tag + " first chunk")
+        worst = max(worst, util.assert_peak_close(got, ref[k], tag, s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb))))
+        _, gidx, gflt = m.state()
+        assert [int(x) for x in gidx] == [r[0] for r in rst[k]], tag + " ring index"
+    grings, _, gflt = m.state()
+    peak = np.maximum(np.abs(rings).max(axis=1), 1e-30)
+    assert (np.abs(grings.astype(np.float64) - rings).max(axis=1) <= 1e-5 * peak).all(), "ring"
+    assert worst > 0.0 or D < 64, "the tolerant form was not taken"
+    print(f"filtered echoes tolerant D={D} V={V} zf={zero_first}: worst {worst:.2e} of the peak")
+
+
+def test_filtered_echoes_tolerant_short_delay_and_alias_stay_exact(ctx, oracle):
+    """A delay much shorter than the span (more than three pieces) and an input image that is the output image keep their exact
+    forms under the flag."""
+    from zang_amd import modules as mod, zang
+    V, D = 96, 300
+    rng = np.random.default_rng(9)
+    fb = rng.uniform(0.1, 0.9, V).astype(np.float32); cutoff = rng.uniform(0.05, 1.0, V).astype(np.float32)
+    inp = util.rng_buffers(130, V, F); out0 = util.rng_buffers(131, V, F)
+    L = oracle.lib()
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    ref = out0.copy(); ref_alias = inp.copy()
+    for v in range(V):
+        ring = np.zeros(D, np.float32)
+        d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(ring), D)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl))
+        L.zo_filtered_echoes_paint(C.byref(d), C.byref(fl), 0, F, oracle.fptr(ref[v]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(inp[v]), float(fb[v]), float(cutoff[v]))
+        ring2 = np.zeros(2000, np.float32)
+        d2 = oracle.Delay(); L.zo_delay_init(C.byref(d2), oracle.fptr(ring2), 2000)
+        fl2 = oracle.Filter(); L.zo_filter_init(C.byref(fl2))
+        L.zo_filtered_echoes_paint(C.byref(d2), C.byref(fl2), 0, F, oracle.fptr(ref_alias[v]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(ref_alias[v]), float(fb[v]), float(cutoff[v]))
+    gfb, gc = util.dev(fb), util.dev(cutoff)
+    m = mod.FilteredEchoes(V, D, ctx)
+    out = util.to_image(out0)
+    m.paint(zang.Span(0, F), [out], None, False, m.Params(util.to_image(inp), gfb, gc), tolerant=True)
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, "delay 300, 1,024 frames: exact form under the flag")
+    m2 = mod.FilteredEchoes(V, 2000, ctx)
+    io = util.to_image(inp)
+    m2.paint(zang.Span(0, F), [io], None, False, m2.Params(io, gfb, gc), tolerant=True)
+    ctx.sync()
+    util.assert_bitexact(util.from_image(io), ref_alias, "input image = output image: exact form under the flag")

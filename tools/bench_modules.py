@@ -74,6 +74,11 @@ if V <= 16384:
 
 m = mod.SimpleDelay(V, 300, ctx); case("SimpleDelay(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp), zero_first=True), 3)
 m = mod.FilteredEchoes(V, 300, ctx); case("FilteredEchoes(300)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True), 3)
+if V <= 16384:
+    m = mod.FilteredEchoes(V, 600, ctx); case("FilteredEchoes(600)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True), 3)
+    m = mod.FilteredEchoes(V, 600, ctx); case("FilteredEchoes(600), ZH_PAINT_TOLERANT (two pieces)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True, tolerant=True), 3)
+    m = mod.FilteredEchoes(V, 15000, ctx); case("FilteredEchoes(15000)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True), 3)
+    m = mod.FilteredEchoes(V, 15000, ctx); case("FilteredEchoes(15000), ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(inp, 0.6, 0.1), zero_first=True, tolerant=True), 3)
 crv = torch.tensor([[0.0, 0.0], [1.0, 0.005], [0.3, 0.012], [0.8, 0.02], [0.0, 0.05]], dtype=torch.float32, device=dev)
 m = mod.Curve(V, ctx)
 _crv_k = [0]

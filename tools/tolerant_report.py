@@ -133,5 +133,36 @@ def main():
             show(f"NiceInstrument, {V} voices, buffer {k + 1}: {what} (states carried by the GPU)", util.from_image(out)[idx], ref, np.maximum(np.abs(rl), np.abs(rb)))
 
 
+    # FilteredEchoes: the ring carries a buffer's error into later ones (times the feedback, through the filter): 40 buffers in a
+    # row on the GPU's own ring and filter state, the worst buffers shown
+    for V, D, fbv in ((4096, 15000, 0.6), (1024, 600, 0.9), (1024, 2000, 0.99)):
+        rngf = np.random.default_rng(D)
+        fb = np.full(V, fbv, np.float32); cutoff = rngf.uniform(0.05, 1.0, V).astype(np.float32)
+        idx = np.arange(0, V, max(1, V // 256))
+        rings = np.zeros((len(idx), D), np.float32)
+        ds, fls = [], []
+        for q in range(len(idx)):
+            d = oracle.Delay(); L.zo_delay_init(C.byref(d), oracle.fptr(rings[q]), D); ds.append(d)
+            fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+        m = mod.FilteredEchoes(V, D, ctx)
+        gfb, gc = util.dev(fb), util.dev(cutoff)
+        t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+        worst = []
+        for k in range(40):
+            x = util.rng_buffers(900 + k, V, F) if k < 30 else np.zeros((V, F), np.float32)     # then the echoes ring out
+            ref = np.zeros((len(idx), F), np.float32)
+            for q, v in enumerate(idx):
+                L.zo_filtered_echoes_paint(C.byref(ds[q]), C.byref(fls[q]), 0, F, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(x[v]), float(fb[v]), float(cutoff[v]))
+            out = ctx.image(F, V)
+            m.paint(zang.Span(0, F), [out], None, False, m.Params(util.to_image(x), gfb, gc), zero_first=True, tolerant=True)
+            ctx.sync()
+            rl = np.array([t.l for t in fls], np.float32); rb = np.array([t.b for t in fls], np.float32)
+            got = util.from_image(out)[idx]
+            ratio, _, _ = util.peak_relative_error(got, ref, scale_extra=np.maximum(np.abs(rl), np.abs(rb)))
+            worst.append((float(ratio.max()), k, got, ref, np.maximum(np.abs(rl), np.abs(rb))))
+        for w, k, got, ref, extra in sorted(worst, key=lambda t: -t[0])[:2] + [worst[-1]]:
+            show(f"FilteredEchoes({D}), feedback {fbv}, {V} voices, buffer {k + 1} of 40", got, ref, extra)
+
+
 if __name__ == "__main__":
     main()

@@ -656,11 +656,12 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     if (m->d.n == 0 || end == start) return ZH_OK;
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
     // ZH_PAINT_TOLERANT, few voices: pieces of <= delay_samples frames, each a time-parallel Filter paint (k_fe_tp_a / _b above).
-    // Not for a span of many pieces (a delay much shorter than the span: a launch pair per piece) -- the exact forms below then.
+    // Not for a span of more than three pieces (a delay much shorter than the span): a launch pair per piece, ~10 us each at
+    // 4,096 voices -- 1,024 frames over a delay of 300 took 42 us as four pieces against the exact form's 44.
     if ((flags & ZH_PAINT_TOLERANT) && chunked && end - start >= 64) {
         const uint32_t n = end - start, D = m->d.delay_samples, piece = D < 4096u ? D : 4096u;
-        const uint32_t C = zh_tp_chunks(m->d.n, "ZH_ECHOES_TP_MAX", piece < n ? piece : n);
-        if (C >= 2 && piece >= 64 && (n + piece - 1) / piece <= 4) {
+        const uint32_t C = zh_tp_chunks(m->d.n, "ZH_ECHOES_TP_MAX", piece < n ? piece : n, 6144u);   // (six image streams: level with the exact form at 8,192 voices, HBM-bound behind it from 16,384)
+        if (C >= 2 && piece >= 64 && (n + piece - 1) / piece <= 3) {
             if (!m->tp && !m->ctx->capturing && dev_alloc(&m->tp, kFeTpFloats * m->d.n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
             if (m->tp) {
                 FeTpArgs a;

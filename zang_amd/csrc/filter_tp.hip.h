@@ -95,10 +95,10 @@ constexpr uint32_t kTpMaxChunks = 32;    // chunks per launch; a module's scratc
 
 #if !defined(ZH_DEVICE_ONLY)
 // chunks for a span of n frames of V voices: enough for ~2,048 waves (two per SIMD), 2..32; 0 = too many voices for the form
-static inline uint32_t zh_tp_chunks(uint32_t V, const char *max_env, uint32_t n) {
+static inline uint32_t zh_tp_chunks(uint32_t V, const char *max_env, uint32_t n, uint32_t max_default = 16384u) {
     const uint32_t G = (V + 63) / 64;
     const char *me = zh_env(max_env);                                 // largest voice count that takes the time-parallel form
-    const uint32_t tp_max = me ? (uint32_t)strtoul(me, nullptr, 10) : 16384u;
+    const uint32_t tp_max = me ? (uint32_t)strtoul(me, nullptr, 10) : max_default;
     if (V > tp_max || G > 1024) return 0;
     const char *we = zh_env("ZH_TP_WAVES");                           // experiments: waves a launch should reach
     const uint32_t waves = we ? (uint32_t)strtoul(we, nullptr, 10) : 2048u;

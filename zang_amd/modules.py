@@ -474,9 +474,11 @@ class FilteredEchoes(_Module):
         abi.check(self.lib.zh_filtered_echoes_get_state(self.handle, rings.ctypes.data, index.ctypes.data, flt.ctypes.data), "get_state")
         return rings, index, flt
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """tolerant=True: ZH_PAINT_TOLERANT -- few voices: pieces of <= delay_samples frames, the filter of each as chunks at once
+        (1e-5 of the voice's peak; include/zang_hip.h)."""
         cp = abi.FilteredEchoesParams(as_buf(params.input), as_f32(params.feedback_volume), as_f32(params.cutoff))
-        self._paint(span, outputs, temps, note_id_changed, cp, zero_first)
+        self._paint(span, outputs, temps, note_id_changed, cp, zero_first, abi.PAINT_TOLERANT if tolerant else 0)
 
 
 class NoiseFilter(_Module):
