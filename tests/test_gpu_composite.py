@@ -106,9 +106,11 @@ def test_nice_equals_gpu_unfused_modules(ctx):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
-@pytest.mark.parametrize("wg_min", [None, "0"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup
+@pytest.mark.parametrize("wg_min", [None, "0", "wg8"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup; "wg8": per 512-thread workgroup
 def test_nice_paint_mix(ctx, oracle, wg_min, monkeypatch):
-    if wg_min is not None:
+    if wg_min == "wg8":
+        monkeypatch.setenv("ZH_NICE_MIX_WG8_MIN", "0")
+    elif wg_min is not None:
         monkeypatch.setenv("ZH_NICE_MIX_WG_MIN", wg_min)
     import torch
     from zang_amd import modules as mod, zang, workloads
@@ -134,13 +136,15 @@ def test_nice_paint_mix(ctx, oracle, wg_min, monkeypatch):
     assert np.array_equal(m1.state(), m2.state())
 
 
-@pytest.mark.parametrize("wg_min", [None, "0"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup
+@pytest.mark.parametrize("wg_min", [None, "0", "wg8"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup; "wg8": per 512-thread workgroup
 def test_nice_paint_mix_stereo(ctx, oracle, wg_min, monkeypatch):
     """Two channels (examples/example_stereo.zig:84-98 with a constant pan per voice): every voice is added to the left
     channel times its left gain and to the right channel times (1 - left); the per-voice products are f32, their sum
     over the voices is checked against the f64 sum with the sqrt(V) * eps bound; with both gains 1.0 the two channels
     equal the mono mixdown bit for bit (x * 1.0 == x, same summation order)."""
-    if wg_min is not None:
+    if wg_min == "wg8":
+        monkeypatch.setenv("ZH_NICE_MIX_WG8_MIN", "0")
+    elif wg_min is not None:
         monkeypatch.setenv("ZH_NICE_MIX_WG_MIN", wg_min)
     import torch
     from zang_amd import modules as mod, zang, workloads
@@ -428,12 +432,14 @@ def test_nice_with_non_finite_and_huge_filter_states(ctx, oracle, form, monkeypa
 
 
 @pytest.mark.parametrize("V", [300, 4096])
-@pytest.mark.parametrize("wg_min", [None, "0"])
+@pytest.mark.parametrize("wg_min", [None, "0", "wg8"])
 def test_nice_paint_mix_stereo_batch_equals_separate_calls(ctx, V, wg_min, monkeypatch):
     """zh_nice_paint_mix_stereo_batch: n consecutive paints in one launch (state in registers from buffer to buffer, one
     second pass) -- bit for bit the mixes and the final state of the n separate calls, with notes going on and off, a new note
     and a frequency change between buffers, ZERO_FIRST and `+=`, and a sub-span."""
-    if wg_min is not None:
+    if wg_min == "wg8":
+        monkeypatch.setenv("ZH_NICE_MIX_WG8_MIN", "0")
+    elif wg_min is not None:
         monkeypatch.setenv("ZH_NICE_MIX_WG_MIN", wg_min)
     import torch
     from zang_amd import modules as mod, zang, workloads

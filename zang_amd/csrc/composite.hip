@@ -523,7 +523,7 @@ template <int C, class G2>
 __device__ __forceinline__ void nice_mix_gains(G2 &g2, const F32P &gain_l, const F32P &gain_r, bool live, uint32_t v, uint32_t wave, uint32_t rh) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     if constexpr (C == 2) {
-        __shared__ f2 gains[256];
+        __shared__ f2 gains[512];                                       // (a workgroup is 256 threads, or 512: NW = 8)
         gains[threadIdx.x] = live ? f2{gain_l.get(v), gain_r.get(v)} : f2{0.0f, 0.0f};   // (voices past the last: tile entries are 0.0f)
         __syncthreads();
         const f2 *mine = &gains[wave * 64 + rh * 32];                   // the 32 voices this lane adds up
@@ -539,11 +539,13 @@ __device__ __forceinline__ void nice_mix_gains(G2 &g2, const F32P &gain_l, const
 // rows written and read back -- for one workgroup barrier per 32-frame chunk, in the sum phase only: `wsum`
 // = [2][4][C][MIXF], the chunk's parity picks the half (a wave may be a whole chunk ahead of the slowest: it has passed the
 // previous barrier, so every wave has finished combining the chunk before that).  `wrow` is then the workgroup's row and
-// `rows` the number of workgroups.  Row order inside a workgroup: ((w0 + w1) + w2) + w3.
-template <int C, bool ROLL, bool WG, class G2>
+// `rows` the number of workgroups.  Row order inside a workgroup: ((w0 + w1) + w2) + w3 ...  NW = waves per workgroup: 0 = no combine
+// (one row per wave), 4, or 8 (512-thread workgroups: an eighth of the rows; ZH_NICE_MIX_WG8_MIN).
+template <int C, bool ROLL, int NW, class G2>
 __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, const G2 &g2, float (*tile)[MIXS], float *__restrict__ pw_paint,
                                                 size_t channel_stride, uint32_t rows, uint32_t wrow, uint32_t start, uint32_t end, uint32_t lane,
-                                                uint32_t rf, uint32_t rh, float (*wsum)[4][C][MIXF] = nullptr, uint32_t wave = 0, uint32_t first = 0xFFFFFFFFu) {
+                                                uint32_t rf, uint32_t rh, float (*wsum)[NW ? NW : 4][C][MIXF] = nullptr, uint32_t wave = 0, uint32_t first = 0xFFFFFFFFu) {
+    constexpr bool WG = NW != 0;
     // `first` (a chunk of a time-parallel paint, k_nice_mix_tp_b): the frames [first, end) of a span that starts at `start` -- the
     // partial rows are indexed from the span's start
     uint32_t parity = 0;
@@ -634,12 +636,15 @@ __device__ __forceinline__ void nice_mix_frames(NiceLane &n, PulseRoll &roll, co
                     if constexpr (C == 2) wsum[parity][wave][1][rf] = sr + hr;
                 }
                 __syncthreads();
-                // wave w combines the chunk's frames 8w .. 8w+7: lanes 0-7 the first channel, 8-15 the second; eight lanes = 32
-                // contiguous bytes of the workgroup's row (MIXF / 4 == kMixGroupFrames)
-                static_assert(MIXF / 4 == kMixGroupFrames, "one frame group per wave");
-                const uint32_t q = lane & 7, c = lane >> 3, fw = wave * 8 + q;
+                // wave w combines the chunk's frames FW w .. FW w + FW - 1 (FW = 8 with four waves, 4 with eight): lanes 0 .. FW-1 the
+                // first channel, FW .. 2 FW - 1 the second; FW lanes = 4 FW contiguous bytes of the workgroup's row
+                constexpr uint32_t FW = MIXF / (NW ? NW : 4);
+                static_assert(kMixGroupFrames % FW == 0, "a wave's frames stay inside one frame group");
+                const uint32_t q = lane % FW, c = lane / FW, fw = wave * FW + q;
                 if (c < (uint32_t)C && f0 + fw < end) {
-                    const float t = ((wsum[parity][0][c][fw] + wsum[parity][1][c][fw]) + wsum[parity][2][c][fw]) + wsum[parity][3][c][fw];
+                    float t = wsum[parity][0][c][fw] + wsum[parity][1][c][fw];
+#pragma unroll
+                    for (int w = 2; w < (NW ? NW : 4); w++) t += wsum[parity][w][c][fw];          // ((w0 + w1) + w2) + ...
                     const uint32_t fr = (f0 - start) + fw;
                     pw_paint[c * channel_stride + ((size_t)(fr / kMixGroupFrames) * rows + wrow) * kMixGroupFrames + (fr % kMixGroupFrames)] = t;
                 }
@@ -661,17 +666,19 @@ __device__ __forceinline__ void nice_silence(NiceLane &n) {
     n.env.mode = ENV_MODE_NONE; n.env.m_painted = 0u;
 }
 
-template <int C, bool ROLL, bool WG = false>
-__global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
-                                                  F32P gain_l, F32P gain_r) {
-    __shared__ float tile_all[4][MIXF][MIXS];
-    __shared__ float wsum[WG ? 2 : 1][4][C][MIXF];
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+template <int C, bool ROLL, int NW = 0>
+__global__ void __launch_bounds__(NW == 8 ? 512 : 256) k_nice_mix(NiceArgs a, uint32_t start, uint32_t end, float *__restrict__ partials,
+                                                                  F32P gain_l, F32P gain_r) {
+    constexpr bool WG = NW != 0;
+    constexpr int NWV = NW ? NW : 4;                                    // waves per workgroup
+    __shared__ float tile_all[NWV][MIXF][MIXS];
+    __shared__ float wsum[WG ? 2 : 1][NWV][C][MIXF];
+    const uint32_t v = blockIdx.x * (NWV * 64) + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*tile)[MIXS] = tile_all[wave];                               // this wave's tile: no other wave touches it
     const uint32_t nframes = end - start;
-    const uint32_t wave_global = WG ? blockIdx.x : blockIdx.x * 4 + wave;
-    const uint32_t rows = WG ? gridDim.x : gridDim.x * 4;
+    const uint32_t wave_global = WG ? blockIdx.x : blockIdx.x * NWV + wave;
+    const uint32_t rows = WG ? gridDim.x : gridDim.x * NWV;
     const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;   // partials[channel][frame / G][wave][frame % G]
     const bool live = v < a.V;
     // lanes past the last voice run voice V-1 again and contribute 0.0f: the frame loop below then needs no per-lane
@@ -685,7 +692,7 @@ __global__ void __launch_bounds__(256) k_nice_mix(NiceArgs a, uint32_t start, ui
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 g2[C == 2 ? 32 : 1];                                             // {left, right} gain of each of the lane's 32 voices
     nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
-    nice_mix_frames<C, ROLL, WG>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
+    nice_mix_frames<C, ROLL, NW>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
     if (live) nice_store(n, a, v);
 }
 
@@ -699,18 +706,20 @@ struct NiceBatchArgs {
     BoolP note_on[kNiceMixMaxBatch], nic[kNiceMixMaxBatch];
     uint32_t nb;
 };
-template <int C, bool ROLL, bool WG = false>
-__global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, uint32_t start, uint32_t end, float *__restrict__ partials,
-                                                        F32P gain_l, F32P gain_r) {
-    __shared__ float tile_all[4][MIXF][MIXS];
-    __shared__ float wsum[WG ? 2 : 1][4][C][MIXF];
+template <int C, bool ROLL, int NW = 0>
+__global__ void __launch_bounds__(NW == 8 ? 512 : 256) k_nice_mix_batch(const NiceBatchArgs b, uint32_t start, uint32_t end, float *__restrict__ partials,
+                                                                        F32P gain_l, F32P gain_r) {
+    constexpr bool WG = NW != 0;
+    constexpr int NWV = NW ? NW : 4;
+    __shared__ float tile_all[NWV][MIXF][MIXS];
+    __shared__ float wsum[WG ? 2 : 1][NWV][C][MIXF];
     const NiceArgs &a = b.a;
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t v = blockIdx.x * (NWV * 64) + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*tile)[MIXS] = tile_all[wave];
     const uint32_t nframes = end - start;
-    const uint32_t wave_global = WG ? blockIdx.x : blockIdx.x * 4 + wave;
-    const uint32_t rows = WG ? gridDim.x : gridDim.x * 4;
+    const uint32_t wave_global = WG ? blockIdx.x : blockIdx.x * NWV + wave;
+    const uint32_t rows = WG ? gridDim.x : gridDim.x * NWV;
     const size_t channel_stride = (size_t)((nframes + kMixGroupFrames - 1) / kMixGroupFrames) * rows * kMixGroupFrames;
     const bool live = v < a.V;
     const uint32_t vc = live ? v : a.V - 1;
@@ -726,7 +735,7 @@ __global__ void __launch_bounds__(256) k_nice_mix_batch(const NiceBatchArgs b, u
         if (!live) nice_silence(n);
         PulseRoll roll;
         n.roll_begin(roll);
-        nice_mix_frames<C, ROLL, WG>(n, roll, g2, tile, partials + (size_t)k * C * channel_stride, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
+        nice_mix_frames<C, ROLL, NW>(n, roll, g2, tile, partials + (size_t)k * C * channel_stride, channel_stride, rows, wave_global, start, end, lane, rf, rh, wsum, wave);
     }
     if (live) nice_store(n, a, v);
 }
@@ -904,7 +913,7 @@ __global__ void __launch_bounds__(256) k_nice_mix_tp_b(const NiceTpArgs t, float
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 g2[C == 2 ? 32 : 1];
     nice_mix_gains<C>(g2, gain_l, gain_r, live, v, wave, rh);
-    nice_mix_frames<C, ROLL, false>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, t.start, f1, lane, rf, rh, nullptr, 0, f0);
+    nice_mix_frames<C, ROLL, 0>(n, roll, g2, tile, partials, channel_stride, rows, wave_global, t.start, f1, lane, rf, rh, nullptr, 0, f0);
     if (live && f1 == t.end && f1 > f0) nice_store(n, a, v);
 }
 
@@ -1884,10 +1893,17 @@ static bool nice_mix_roll() {
 // profiles/r04/ab_nice_mix_wg.txt): 131,072 voices 108.45 -> 108.35 us per buffer all-in (0.6 us in an earlier comparison) with a quarter of
 // the partial traffic; 4,096 voices 99.3 -> 104.6 (sixteen workgroups on 256 CUs: the barrier couples waves that otherwise run at their own pace).
 // ZH_NICE_MIX_WG_MIN = the smallest voice count that combines per workgroup.
-static bool nice_mix_wg(uint32_t n_voices) {
+// ZH_NICE_MIX_WG8_MIN = the smallest voice count whose workgroups are eight waves (512 threads, one row per 512 voices: the
+// partial rows are then 2.1 MB of the 131,072-voice buffer's ~14 MB instead of 4.2 of ~18).  OFF by default: the barrier over
+// eight waves costs more than the rows save -- 107.5 -> 109.6 us per buffer, four alternating runs on one box
+// (profiles/r04/ab_nice_mix_wg8.txt); traffic is not this kernel's bound (0.17 TB/s).
+// Returns the waves per combining workgroup: 0 (a row per wave), 4 or 8.
+static int nice_mix_wg(uint32_t n_voices) {
     const char *e = zh_env("ZH_NICE_MIX_WG_MIN");
     const uint32_t wg_min = e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u;
-    return n_voices >= wg_min;
+    const char *e8 = zh_env("ZH_NICE_MIX_WG8_MIN");
+    const uint32_t wg8_min = e8 ? (uint32_t)strtoul(e8, nullptr, 10) : 0xFFFFFFFFu;
+    return n_voices >= wg8_min ? 8 : (n_voices >= wg_min ? 4 : 0);
 }
 static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
                             const zh_f32 *gain_r, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
@@ -1895,9 +1911,10 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     if (!m || !mix_l || !p || end < start) return ZH_ERR_INVALID;
     if (m->n == 0) return ZH_OK;
     const uint32_t nframes = end - start;
-    const uint32_t blocks = (m->n + 255) / 256;
-    const bool wg = nice_mix_wg(m->n);
-    const uint32_t rows = wg ? blocks : blocks * 4;                     // one partial row per workgroup (256 voices) / per wave of 64 voices
+    const int wg = nice_mix_wg(m->n);
+    const uint32_t bs = wg == 8 ? 512u : 256u;
+    const uint32_t blocks = (m->n + bs - 1) / bs;
+    const uint32_t rows = wg ? blocks : blocks * 4;                     // one partial row per workgroup (256 / 512 voices) / per wave of 64 voices
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);   // [frame / G][row][frame % G]
     int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1));
     if (rc) return rc;
@@ -1929,19 +1946,19 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
             return zh_launch_status();
         }
     }
-#define ZH_NMIX(C_, ROLL_, WG_, GL_, GR_) hipLaunchKernelGGL((k_nice_mix<C_, ROLL_, WG_>), dim3(blocks), dim3(256), 0, st, a, start, end, part, GL_, GR_)
+#define ZH_NMIX(C_, ROLL_, NW_, GL_, GR_) hipLaunchKernelGGL((k_nice_mix<C_, ROLL_, NW_>), dim3(blocks), dim3(bs), 0, st, a, start, end, part, GL_, GR_)
+#define ZH_NMIX_W(C_, ROLL_, GL_, GR_) do { if (wg == 8) ZH_NMIX(C_, ROLL_, 8, GL_, GR_); else if (wg) ZH_NMIX(C_, ROLL_, 4, GL_, GR_); else ZH_NMIX(C_, ROLL_, 0, GL_, GR_); } while (0)
     const bool roll = nice_mix_roll();
     if (stereo) {
         const F32P gl = mk_f32(*gain_l), gr = mk_f32(*gain_r);
-        if (wg) { if (roll) ZH_NMIX(2, true, true, gl, gr); else ZH_NMIX(2, false, true, gl, gr); }
-        else { if (roll) ZH_NMIX(2, true, false, gl, gr); else ZH_NMIX(2, false, false, gl, gr); }
+        if (roll) ZH_NMIX_W(2, true, gl, gr); else ZH_NMIX_W(2, false, gl, gr);
         if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, mix_r + start, 2, zf);
     } else {
         const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
-        if (wg) { if (roll) ZH_NMIX(1, true, true, none, none); else ZH_NMIX(1, false, true, none, none); }
-        else { if (roll) ZH_NMIX(1, true, false, none, none); else ZH_NMIX(1, false, false, none, none); }
+        if (roll) ZH_NMIX_W(1, true, none, none); else ZH_NMIX_W(1, false, none, none);
         if (nframes) zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, nullptr, 1, zf);
     }
+#undef ZH_NMIX_W
 #undef ZH_NMIX
     return zh_launch_status();
 }
@@ -1966,8 +1983,9 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     }
     if (m->n == 0 || n_buffers == 0) return ZH_OK;
     const uint32_t nframes = end - start;
-    const bool wg = nice_mix_wg(m->n);
-    const uint32_t blocks = (m->n + 255) / 256, rows = wg ? blocks : blocks * 4;
+    const int wg = nice_mix_wg(m->n);
+    const uint32_t bs = wg == 8 ? 512u : 256u;
+    const uint32_t blocks = (m->n + bs - 1) / bs, rows = wg ? blocks : blocks * 4;
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);
     int rc = zh_mix_reserve(m->ctx, per_channel * 2 * n_buffers);
     if (rc) return rc;
@@ -1980,9 +1998,10 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     }
     float *part = m->ctx->mix_partials;
     hipStream_t st = m->ctx->stream;
-#define ZH_NMIXB(ROLL_, WG_) hipLaunchKernelGGL((k_nice_mix_batch<2, ROLL_, WG_>), dim3(blocks), dim3(256), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right))
-    if (wg) { if (nice_mix_roll()) ZH_NMIXB(true, true); else ZH_NMIXB(false, true); }
-    else { if (nice_mix_roll()) ZH_NMIXB(true, false); else ZH_NMIXB(false, false); }
+#define ZH_NMIXB(ROLL_, NW_) hipLaunchKernelGGL((k_nice_mix_batch<2, ROLL_, NW_>), dim3(blocks), dim3(bs), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right))
+    if (wg == 8) { if (nice_mix_roll()) ZH_NMIXB(true, 8); else ZH_NMIXB(false, 8); }
+    else if (wg) { if (nice_mix_roll()) ZH_NMIXB(true, 4); else ZH_NMIXB(false, 4); }
+    else { if (nice_mix_roll()) ZH_NMIXB(true, 0); else ZH_NMIXB(false, 0); }
 #undef ZH_NMIXB
     if (nframes) {
         float *l[kNiceMixMaxBatch], *r[kNiceMixMaxBatch];
