@@ -89,7 +89,7 @@ def parse(argv=None):
                          "%d on any failure" % PREFLIGHT_FAILED)
     ap.add_argument("--tolerant", action="store_true",
                     help="noise_filter / noise_filter_fused / nice / nice_mix (few voices): paint with ZH_PAINT_TOLERANT (opt-in time-parallel Filter forms, 1e-5 of the "
-                         "signal's peak instead of bits; csrc/filter_tp.hip.h); the line says so in config.tolerant")
+                         "signal's peak instead of bits; csrc/filter_tp.hip.h); script: the module's sines that may be f32; the line says so in config.tolerant")
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of hipGraph replay")
     ap.add_argument("--pad-voices", type=int, default=None, help="row padding of the output images in voices (default: the library's choice, Context.image)")
     return ap.parse_args(argv)
@@ -395,7 +395,7 @@ class Workload:
 
     def _step_script(self):
         on, new = self._note_on()
-        self.m.paint(self.span, [self._next()], None, new, {"sample_rate": SR, "freq": self.freq, "note_on": on}, zero_first=True)
+        self.m.paint(self.span, [self._next()], None, new, {"sample_rate": SR, "freq": self.freq, "note_on": on}, zero_first=True, tolerant=self.tolerant)
 
     def _step_nice_mix(self):
         row = self.nsteps % 48
@@ -1042,7 +1042,8 @@ def main():
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }
     if args.tolerant:
-        out["config"]["tolerant"] = "ZH_PAINT_TOLERANT: the Filter as chunks at once, samples within 1e-5 of the voice's peak (not bit-exact)"
+        out["config"]["tolerant"] = ("ZH_PAINT_TOLERANT: the sines that reach the output through scaling and adding alone in f32 (not bit-exact)" if args.workload == "script"
+                                     else "ZH_PAINT_TOLERANT: the Filter as chunks at once, samples within 1e-5 of the voice's peak (not bit-exact)")
     if K != K_req:
         out["steps_requested"] = K_req
         out["config"]["pattern"] = (f"--steps {K_req} -> {K} timed steps: the note pattern is {PATTERN} buffers (note on 0-23: attack, decay, "

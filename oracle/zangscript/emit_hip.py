@@ -18,6 +18,7 @@ modules calling script modules are inlined.  `delay` keeps its ring in the per-v
 call (`from ... begin`) keeps NoteTracker + Trigger per voice and walks their sub-spans.  What the backend
 cannot express (more than 16 params, a zero-sample delay) raises HipBackendError, reported per module."""
 import os
+import re
 from dataclasses import dataclass
 
 from .errors import ScriptError
@@ -40,6 +41,7 @@ class Val:
     computed: bool = False         # buf: derives from a module's output or a transcendental function (not just params / constants / + - * /)
     cob_b: str = ""                # buf that is exactly a constant_or_buffer param's value: its "is a buffer" flag ...
     cob_c: str = ""                # ... and its constant
+    sines: int = 0                 # buf: the sine sources (bit per SineOsc call / sin(), _Kernel.nsines) whose results flow into it
 
 
 def f32_literal(x):
@@ -57,6 +59,15 @@ TRACK_WORDS = 3                       # NoteTracker {next_song_event, t} + Trigg
 # the params of a builtin that its state recurrence reads every frame
 STATE_INPUTS = {"SineOsc": ("freq",), "PulseOsc": ("freq",), "TriSawOsc": ("freq",), "Cycle": ("speed",),
                 "Filter": ("input", "cutoff", "res"), "Decimator": ("input",)}
+# ZH_PAINT_TOLERANT (include/zang_hip.h): a sine may be evaluated in f32 (zmath.hip.h zsinf_tol, within 2.4e-7 of musl's) when its
+# error can only be scaled and added on its way to the output -- through + - * neg abs min max, copies, a Filter's or a Decimator's
+# `input`, a delay ring written (not read: a ring's content is of unknown origin, ALL_SINES).  Every other place a value can go is a
+# SINK that keeps the sines reaching it exact: any other builtin param (an oscillator's freq / phase: the error would be integrated
+# or -- PMOscInstrument, DESIGN.md 5a -- multiplied by the carrier's slope at a large argument; a Distortion's input: gain up to
+# 64), the argument of sin / cos / sqrt, a divisor, both operands of pow.
+LINEAR_INPUTS = {("Filter", "input"), ("Decimator", "input")}
+ALL_SINES = (1 << 64) - 1
+MAX_SINES = 63                        # sources beyond this many in one kernel stay exact
 
 
 class _Kernel:
@@ -74,6 +85,8 @@ class _Kernel:
         self.rings = False             # a delay ring lives in the state blob and is read and written inside the frame body
         self.walk_reads_computed = False   # a builtin's frame-to-frame state is fed by a value computed in the frame body
         self.quiet_terms = []          # wave-uniform tests over the next `zs_n` frames: the chunk may run the body's ZS_Q forms
+        self.nsines = 0                # sine sources met so far (SineOsc calls and sin() of a buffer)
+        self.exact_sines = 0           # ... and the ones that reach a sink (LINEAR_INPUTS above)
 
     def fresh(self, stem):
         self.uid += 1
@@ -84,6 +97,17 @@ class _Kernel:
         self.words += n
         return w
 
+    def sine_source(self):
+        """-> (id, bit) of a new sine source; (None, 0) = one too many: emitted exact"""
+        if self.nsines >= MAX_SINES:
+            return None, 0
+        self.nsines += 1
+        return self.nsines - 1, 1 << (self.nsines - 1)
+
+    def sink(self, v):
+        if v.kind == "buf":
+            self.exact_sines |= v.sines
+
 
 class _ModuleCtx:
     """One (possibly inlined) instance of a script module."""
@@ -93,6 +117,8 @@ class _ModuleCtx:
         self.tnames, self.fnames = {}, {}
         self.heavy = {}                # temp index -> its current value derives from a module output / transcendental (Val.computed)
         self.cobsrc = {}               # temp index -> (Val.cob_b, Val.cob_c) while it holds a cob param's value
+        self.srcs = {}                 # temp index -> Val.sines of its current value (unknown temp: ALL_SINES)
+        self.outsines = 0              # Val.sines of everything added to this module's output so far
         # where the per-paint prologue / epilogue of builtin calls goes: the kernel's own prologue and
         # epilogue, or -- inside a `delay` body, which the reference paints chunk by chunk -- the
         # chunk's; `rel` / `length` are the frame index within, and the length of, that paint call
@@ -121,7 +147,7 @@ class HipEmitter:
         k = r.kind
         if k == "temp_buffer":
             cb, cc = mc.cobsrc.get(r.index, ("", ""))
-            return Val("buf", mc.tname(r.index), computed=mc.heavy.get(r.index, True), cob_b=cb, cob_c=cc)
+            return Val("buf", mc.tname(r.index), computed=mc.heavy.get(r.index, True), cob_b=cb, cob_c=cc, sines=mc.srcs.get(r.index, ALL_SINES))
         if k == "temp_float":
             return Val("float", mc.fname(r.index))
         if k == "literal_number":
@@ -156,16 +182,18 @@ class HipEmitter:
 
     # ---- destinations
     @staticmethod
-    def put(mc, d, expr, zero_first, heavy=False):
+    def put(mc, d, expr, zero_first, heavy=False, sines=0):
         """`dest (+)= expr` with the reference's zeroing: temps are assigned (after zang.zero when the
-        op accumulates), outputs accumulate.  `heavy`: Val.computed of the value written."""
+        op accumulates), outputs accumulate.  `heavy`: Val.computed of the value written, `sines`: its Val.sines."""
         if d.kind == "temp":
             mc.heavy[d.index] = heavy
+            mc.srcs[d.index] = sines
             mc.cobsrc.pop(d.index, None)
             t = mc.tname(d.index)
             if zero_first:
                 return ["%s = 0.0f;" % t, "%s = %s + (%s);" % (t, t, expr)]
             return ["%s = %s;" % (t, expr)]
+        mc.outsines |= sines
         return ["%s = %s + (%s);" % (mc.outvar, mc.outvar, expr)]
 
     UN = {"abs": "fabsf(%s)", "cos": "zcosf(%s)", "neg": "-(%s)", "sin": "zsinf(%s)", "sqrt": "sqrtf(%s)"}
@@ -183,6 +211,12 @@ class HipEmitter:
         for pname in STATE_INPUTS.get(name, ()):
             if a[pname].kind == "buf" and a[pname].computed:
                 k.walk_reads_computed = True
+        out_sines = 0                                            # Val.sines of the module's output
+        for pname, v in a.items():
+            if (name, pname) in LINEAR_INPUTS:
+                out_sines |= v.sines if v.kind == "buf" else 0
+            else:
+                k.sink(v)
         o = k.fresh("m")
         w = k.alloc(STATE_WORDS[name])
         decl, pro, frame = k.pro, mc.begin_sink, []      # lane object + state loads | per-paint prologue | per frame
@@ -216,7 +250,10 @@ class HipEmitter:
                 k.quiet_terms.append("%s.small_args(%s, (float)zs_n)" % (o, pc))
             if quiet and fb:
                 k.quiet_terms.append("(!%s && %s.small_args_step(%s * %s.inv_sr, %s, (float)zs_n))" % (fv.cob_b, o, fv.cob_c, o, pc))
-            value = "%s.frame<%s%s>(%s, %s)" % (o, "true" if fb else "false", ", !ZS_Q" if quiet else "", fi if fb else "0.0f", pi)
+            sid, bit = k.sine_source()
+            out_sines |= bit
+            mode = (", !ZS_Q" if quiet else "") if sid is None else "\x01O%d|%s\x02" % (sid, "!ZS_Q" if quiet else "1")   # resolved by generate()
+            value = "%s.frame<%s%s>(%s, %s)" % (o, "true" if fb else "false", mode, fi if fb else "0.0f", pi)
             ends.append("%s.end();" % o)
         elif name == "Cycle":
             sb, sc, si = cob(a["speed"])
@@ -338,11 +375,13 @@ class HipEmitter:
         d = ins.out
         if d.kind == "temp":
             mc.heavy[d.index] = True                                 # a module's output
+            mc.srcs[d.index] = out_sines
             mc.cobsrc.pop(d.index, None)
             t = mc.tname(d.index)
             frame.insert(0, "%s = 0.0f;" % t)
             target = t
         else:
+            mc.outsines |= out_sines
             target = mc.outvar
         add = "%s = %s + (%s);" % (target, target, value)
         frame.append("if (%s) %s" % (painted, add) if painted else add)
@@ -353,14 +392,14 @@ class HipEmitter:
         k, kind = mc.k, ins.kind
         if kind == "copy_buffer":
             src = self.val(mc, ins.src)
-            k.frame += self.put(mc, ins.out, src.expr, False, src.computed)
+            k.frame += self.put(mc, ins.out, src.expr, False, src.computed, src.sines)
             if ins.out.kind == "temp" and src.cob_b:
                 mc.cobsrc[ins.out.index] = (src.cob_b, src.cob_c)
         elif kind == "float_to_buffer":
             k.frame += self.put(mc, ins.out, self.val(mc, ins.src).expr, False)
         elif kind == "cob_to_buffer":
             src = mc.env[ins.in_self_param]
-            k.frame += self.put(mc, ins.out, src.expr, False, src.computed)
+            k.frame += self.put(mc, ins.out, src.expr, False, src.computed, src.sines)
             if ins.out.kind == "temp" and src.cob_b:
                 mc.cobsrc[ins.out.index] = (src.cob_b, src.cob_c)
         elif kind in ("arith_float", "arith_float_float"):
@@ -373,17 +412,33 @@ class HipEmitter:
                 mc.begin_sink.append("%s = %s;" % (mc.fname(ins.out), expr))
         elif kind == "arith_buffer":
             va = self.val(mc, ins.a)
-            k.frame += self.put(mc, ins.out, self.UN[ins.op] % va.expr, False, va.computed or ins.op in ("sin", "cos"))
+            expr, sines = self.UN[ins.op] % va.expr, va.sines
+            if ins.op in ("sin", "cos", "sqrt"):
+                k.sink(va)
+                sines = 0
+                if ins.op == "sin":
+                    sid, sines = k.sine_source()
+                    if sid is not None:
+                        expr = "\x01F%d|%s\x02" % (sid, va.expr)          # zsinf(...) / its tolerant form: resolved by generate()
+            k.frame += self.put(mc, ins.out, expr, False, va.computed or ins.op in ("sin", "cos"), sines)
         elif kind in ("arith_float_buffer", "arith_buffer_float", "arith_buffer_buffer"):
             va, vb = self.val(mc, ins.a), self.val(mc, ins.b)
             a, b = va.expr, vb.expr
             heavy = va.computed or vb.computed or ins.op == "pow"
+            sines = (va.sines if va.kind == "buf" else 0) | (vb.sines if vb.kind == "buf" else 0)
+            if ins.op == "pow":
+                k.sink(va)
+                k.sink(vb)
+                sines = 0
+            elif ins.op == "div":
+                k.sink(vb)
+                sines = va.sines if va.kind == "buf" else 0
             if ins.op in ("add", "mul"):
                 if kind == "arith_float_buffer":
                     a, b = b, a                                  # addScalar / multiplyScalar(dest, buffer, float)
-                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), True, heavy)
+                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), True, heavy, sines)
             else:
-                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), False, heavy)
+                k.frame += self.put(mc, ins.out, self.BIN[ins.op] % (a, b), False, heavy, sines)
         elif kind == "call":
             callee_index = mr.fields[ins.field_index]
             callee = self.s.modules[callee_index]
@@ -401,6 +456,10 @@ class HipEmitter:
                     outvar = mc.outvar
                 sub = _ModuleCtx(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", parent=mc)
                 self.module_body(sub)
+                if d.kind == "temp":
+                    mc.srcs[d.index] = sub.outsines
+                else:
+                    mc.outsines |= sub.outsines
         elif kind == "track_call":
             self.track_call(mc, mr, ins)
         elif kind == "delay":
@@ -428,6 +487,7 @@ class HipEmitter:
         if ins.out.kind == "temp":
             k.frame.append("%s = 0.0f;" % mc.tname(ins.out.index))   # zang.zero(span, dest) (:396-399)
         fb, fbout = mc.tname(ins.feedback_temp), mc.tname(ins.feedback_out_temp)
+        mc.srcs[ins.feedback_temp] = ALL_SINES                       # what a ring holds is of unknown origin
         begins, ends, body = [], [], []
         saved = (mc.begin_sink, mc.end_sink, mc.rel, mc.length, k.frame)
         rel, length = "%s_rel" % d, "%s_len" % d
@@ -643,22 +703,44 @@ class HipEmitter:
             out.append(I + "bool zs_walk = false; (void)zs_walk;")
             loop_call = I + "zs_frame_loop<%d, %d>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk," % (unroll, nin)
             two_bodies = bool(k.quiet_terms)
-            if two_bodies:
+            # the sine sources that reach no sink: under ZH_PAINT_TOLERANT their f32 form (a second instance of the frame body,
+            # chosen once per paint: ZS_T).  A kernel without one reads as before.
+            tolerant = set(i for i in range(k.nsines) if not (k.exact_sines >> i) & 1)
+            frame = [resolve_sines(l, tolerant) for l in k.frame]
+            lam = I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA " % ni
+            if tolerant:
+                if two_bodies:
+                    out.append(I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + " && ".join(k.quiet_terms) + "; };")
+                out.append(I + "auto zs_body = [&](auto zs_q, auto zs_t, uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
+                out.append(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;")
+                out.append(I + I + "constexpr bool ZS_T = decltype(zs_t)::value; (void)ZS_T;")
+            elif two_bodies:
                 out.append(I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + " && ".join(k.quiet_terms) + "; };")
                 out.append(I + "auto zs_body = [&](auto zs_q, uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
                 out.append(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;")
             else:
                 out.append(loop_call)
-                out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA {" % ni)
+                out.append(lam + "{")
             out.append(I + I + "(void)i; (void)x;")
             if k.temps:
                 out.append(I + I + "float " + ", ".join("%s = 0.0f" % t for t in k.temps) + ";")
-            out += [I + I + l for l in k.frame]
-            if two_bodies:
+            out += [I + I + l for l in frame]
+            if tolerant:
+                out.append(I + "};")
+                for t in ("true", "false"):
+                    out.append(I + ("if (L.flags & ZH_PAINT_TOLERANT) {" if t == "true" else "} else {"))
+                    out.append(loop_call)
+                    if two_bodies:
+                        out.append(lam + "{ zs_body(zs_tag<false>{}, zs_tag<%s>{}, i, x, o); }, zs_quiet," % t)
+                        out.append(lam + "{ zs_body(zs_tag<true>{}, zs_tag<%s>{}, i, x, o); });" % t)
+                    else:
+                        out.append(lam + "{ zs_body(zs_tag<false>{}, zs_tag<%s>{}, i, x, o); });" % t)
+                out.append(I + "}")
+            elif two_bodies:
                 out.append(I + "};")
                 out.append(loop_call)
-                out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<false>{}, i, x, o); }, zs_quiet," % ni)
-                out.append(I + "                     [&](uint32_t i, const float (&x)[%d], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<true>{}, i, x, o); });" % ni)
+                out.append(lam + "{ zs_body(zs_tag<false>{}, i, x, o); }, zs_quiet,")
+                out.append(lam + "{ zs_body(zs_tag<true>{}, i, x, o); });")
             else:
                 out.append(I + "});")
             out += [I + l for l in k.epi_ends + k.epi_stores]
@@ -668,6 +750,22 @@ class HipEmitter:
             tables += self.track_tables(ti)
         out[table_at:table_at] = tables
         return "\n".join(out) + "\n", meta
+
+
+_SINE_MARK = re.compile("\x01([OF])(\\d+)\\|([^\x02]*)\x02")
+
+
+def resolve_sines(line, tolerant):
+    """The sine placeholders of a frame-body line (call_builtin's SineOsc, instruction()'s sin) as code, now that the kernel's sinks are
+    known: the exact text for a source that reaches a sink, the ZS_T-switched one otherwise."""
+    def rep(m):
+        kind, tol, payload = m.group(1), int(m.group(2)) in tolerant, m.group(3)
+        if kind == "O":                                           # SineOscLane::frame's SINMODE argument (voices.hip.h)
+            if payload == "1":
+                return ", (ZS_T ? 2 : 1)" if tol else ""
+            return ", (ZS_T ? 2 : (int)!ZS_Q)" if tol else ", !ZS_Q"
+        return "(ZS_T ? zsinf_tol(%s) : zsinf(%s))" % (payload, payload) if tol else "zsinf(%s)" % payload
+    return _SINE_MARK.sub(rep, line)
 
 
 def generate_hip(script, only=None):

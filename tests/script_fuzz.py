@@ -252,11 +252,14 @@ def _device_value(value):
     return value
 
 
-def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None):
+def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, worst=None):
     """One generated module, `buffers` consecutive buffers of random paints; raises AssertionError with the script text on
     a mismatch.  `ranges`: ZH_SCRIPT_RANGES for the case (the library reads it per paint under ZH_ENV_LIVE=1) -- with
     F >= 128 the kernels that allow it are launched as that many frame ranges.  `text`: a given script (module `Main` with
-    the generator's params) instead of the generated one; `seed` then only picks the paints.  Returns the script text."""
+    the generator's params) instead of the generated one; `seed` then only picks the paints.  Returns the script text.
+    `tolerant`: paint with ZH_PAINT_TOLERANT and ask, per voice and buffer, for every sample within 1e-5 of the largest of the voice's peak, its inputs' magnitudes and 1
+    and the same finite / non-finite pattern instead of bits (kernels without a tolerant sine still answer bit for bit); `worst`
+    (a one-element list) collects the largest ratio seen."""
     import os
     import torch
     from oracle import zangscript as zs
@@ -276,15 +279,37 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None):
             base = np.zeros((V, F), np.float32) if b % 2 == 0 else np.random.default_rng(seed + b).uniform(-1, 1, (V, F)).astype(np.float32)
             ref = base.copy()
             img = to_image(base)
+            scale = np.ones(V)              # tolerant: the largest magnitude on the voice's signal path -- its inputs too (terms that cancel:
+                                            # `out 0.84 - freq` then `out freq - x` leaves 1.4 out of sums rounded at 1,386, seed 209)
             for start, end, nic, params in schedule(seed * 16 + b, F):
+                for kk, vv in params.items():
+                    if kk in order and kk != "sample_rate" and isinstance(vv, (np.ndarray, float, np.floating)) and getattr(vv, "dtype", np.dtype(np.float32)) != np.bool_:
+                        mag = np.abs(np.asarray(vv, np.float64))
+                        mag = np.where(np.isfinite(mag), mag, 0.0)
+                        scale = np.maximum(scale, mag.reshape(V, -1).max(axis=1) if mag.ndim >= 1 and mag.shape[0] == V else float(mag.max()))
                 dev = {kk: _device_value(vv) for kk, vv in params.items() if kk in order}
                 nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda() if isinstance(nic, np.ndarray) else nic
-                mod.paint(zang.Span(start, end), [img], None, nic_dev, dev)
+                mod.paint(zang.Span(start, end), [img], None, nic_dev, dev, tolerant=tolerant)
                 for v in range(V):
                     voices[v].paint(start, end, ref[v], bool(nic[v]) if isinstance(nic, np.ndarray) else nic,
                                     [_per_voice(params[kk], v) for kk in order])
             ctx.sync()
             got = from_image(img)
+            if tolerant and "ZS_T" in prog.hip_source:
+                a, g = ref.astype(np.float64), got.astype(np.float64)
+                with np.errstate(invalid="ignore", over="ignore"):
+                    fin = np.isfinite(a)
+                    same_pattern = np.array_equal(fin, np.isfinite(g))
+                    peak = np.maximum(np.where(fin, np.abs(a), 0.0).max(axis=1), scale)
+                    ratio = float((np.where(fin & np.isfinite(g), np.abs(a - g), 0.0).max(axis=1) / peak).max())
+                if worst is not None:
+                    worst[0] = max(worst[0], ratio)
+                if not same_pattern or ratio > 1e-5:
+                    raise AssertionError("seed %d buffer %d, ZH_PAINT_TOLERANT: off by %.2e of the voice's scale (finite patterns %s)\n%s"
+                                         % (seed, b, ratio, "equal" if same_pattern else "DIFFER", text))
+                # the next buffer starts from the tolerant kernel's own state: the oracle's voices are not re-synchronised (a Filter's
+                # state and a delay ring carry the difference on, scaled like the signal)
+                continue
             if not np.array_equal(got.view(np.uint32), ref.view(np.uint32)):
                 bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
                 v0, f0 = bad[0]

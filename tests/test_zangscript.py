@@ -326,6 +326,40 @@ def _freqs(seed=1):
     return np.random.default_rng(seed).uniform(60, 3000, V).astype(np.float32)
 
 
+def _tolerant_parity(ctx, name, paints, expect_tolerant, first_seed=0):
+    """The same paints on two instances of one loaded kernel, one with ZH_PAINT_TOLERANT: per voice and paint, every sample within
+    1e-5 of the larger of the voice's peak over the span and 1 (a unit-amplitude sine's f32 form is within 2.4e-7 of musl's; the
+    module scales it) -- and identical bits when the emitter found no sine that may be tolerant.  Returns the worst ratio."""
+    import torch
+    from tests.util import from_image, to_image
+    from zang_amd import script, zang
+    prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
+    assert ("ZS_T" in prog.hip_source) == expect_tolerant, name
+    exact, tol = prog.module(name, V, first_seed), prog.module(name, V, first_seed)
+    worst = 0.0
+    for start, end, nic, params in paints:
+        dev = {k: _device_value(None, v) for k, v in params.items()}
+        nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda() if isinstance(nic, np.ndarray) else nic
+        ie, it = to_image(np.zeros((V, F), np.float32)), to_image(np.zeros((V, F), np.float32))
+        exact.paint(zang.Span(start, end), [ie], None, nic_dev, dev)
+        tol.paint(zang.Span(start, end), [it], None, nic_dev, dev, tolerant=True)
+        ctx.sync()
+        a, b = from_image(ie).astype(np.float64), from_image(it).astype(np.float64)
+        if not expect_tolerant:
+            assert np.array_equal(from_image(ie).view(np.uint32), from_image(it).view(np.uint32)), name
+            continue
+        assert np.array_equal(a[:, :start], b[:, :start]) and np.array_equal(a[:, end:], b[:, end:]), name
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b)), name
+        if end > start:
+            peak = np.maximum(np.where(fin, np.abs(a), 0.0)[:, start:end].max(axis=1), 1.0)
+            ratio = (np.where(fin, np.abs(a - b), 0.0)[:, start:end].max(axis=1) / peak).max()
+            assert ratio <= 1e-5, (name, start, end, ratio)
+            worst = max(worst, ratio)
+    prog.close()
+    return worst
+
+
 @pytest.mark.gpu
 def test_gpu_doubler_const_and_buffer(ctx):
     rng = np.random.default_rng(0)
@@ -759,3 +793,34 @@ def test_gpu_script_in_place_param_image_keeps_one_walk(ctx, ranges, monkeypatch
         ctx.sync()
         assert_bitexact(from_image(img), ref, "in-place Stages paint %d" % k)
     prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_script_tolerant_sines(ctx):
+    """ZH_PAINT_TOLERANT on generated kernels (csrc/zscript_emit.hip: the sines that reach the output through scaling and adding
+    alone take their f32 form): Pluck's oscillator, CycleSine's sin(), Bell's and Lead's carriers -- their modulators reach a `phase`
+    and stay exact --, the LFO and the plucked voice inside EchoLead's delay, a track's notes; kernels with no such sine (Buzz: its
+    only sine is a vibrato on two oscillators' freq; Maths; Echo) answer bit for bit."""
+    rng = np.random.default_rng(41)
+    on = np.ones(V, bool)
+    f = _freqs(4)
+    p = lambda note_on: {"sample_rate": 48000.0, "freq": f, "note_on": note_on}
+    cycle = [(0, 64, True, p(on)), (64, 80, False, p(~on)), (80, F, True, p(on)), (0, F, False, p(on))]
+    worst = {}
+    for name in ("Pluck", "Bell", "Lead", "EchoLead"):
+        worst[name] = _tolerant_parity(ctx, name, cycle, True)
+    ph = rng.uniform(0, 1, (V, F)).astype(np.float32)
+    worst["CycleSine"] = _tolerant_parity(ctx, "CycleSine", [(0, 33, False, {"sample_rate": 44100.0, "freq": _freqs(), "phase": ph}),
+                                                             (33, F, False, {"sample_rate": 44100.0, "freq": rng.uniform(50, 900, (V, F)).astype(np.float32), "phase": 0.25})], True)
+    x = rng.uniform(-8, 8, (V, F)).astype(np.float32)
+    x[3] = rng.uniform(-2000, 2000, F).astype(np.float32)
+    x[2, :6] = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 3e20], np.float32)
+    worst["Trig"] = _tolerant_parity(ctx, "Trig", [(0, F, False, {"sample_rate": 48000.0, "x": x})], True)
+    speed = rng.uniform(0.5, 3.0, V).astype(np.float32)
+    q = {"sample_rate": 44100.0, "speed": speed}
+    worst["LateJingle"] = _tolerant_parity(ctx, "LateJingle", [(0, 50, False, q), (50, F, False, q), (0, F, True, q)], True)
+    assert max(worst.values()) > 0.0, "no tolerant sine ran"
+    print("script kernels, tolerant against exact, worst error / max(peak, 1):", {k: "%.1e" % v for k, v in worst.items()})
+    _tolerant_parity(ctx, "Buzz", [(0, F, True, {"sample_rate": 48000.0, "freq": f, "color": 0.3, "note_on": on})], False)
+    xin = rng.uniform(-1, 1, (V, F)).astype(np.float32)
+    _tolerant_parity(ctx, "Echo", [(0, F, False, {"sample_rate": 48000.0, "input": xin, "echo_volume": 0.5, "ftype": ("low_pass", None)})], False)

@@ -100,7 +100,14 @@ def _pluck(o, m=m):
     k = _pl_k[0] % 8; _pl_k[0] += 1
     m.paint(span, [o], None, k == 0, {"sample_rate": SR, "freq": freq, "note_on": on_dev if k < 4 else off_dev}, zero_first=True)
 case("script Pluck (note on 4 buffers / off 4)", m, _pluck)
+m = _prog.module("Pluck", V, 0)
+_pt_k = [0]
+def _pluck_tol(o, m=m):
+    k = _pt_k[0] % 8; _pt_k[0] += 1
+    m.paint(span, [o], None, k == 0, {"sample_rate": SR, "freq": freq, "note_on": on_dev if k < 4 else off_dev}, zero_first=True, tolerant=True)
+case("script Pluck, ZH_PAINT_TOLERANT", m, _pluck_tol)
 m = _prog.module("CycleSine", V, 0); case("script CycleSine (sin of Cycle + phase)", m, lambda o, m=m: m.paint(span, [o], None, False, {"sample_rate": SR, "freq": 3.0, "phase": 0.25}, zero_first=True))
+m = _prog.module("CycleSine", V, 0); case("script CycleSine, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], None, False, {"sample_rate": SR, "freq": 3.0, "phase": 0.25}, zero_first=True, tolerant=True))
 
 print("# %d voices x %d frames per paint, %d paints per graph, one MI355X" % (V, F, K))
 print("%-46s %10s %12s %10s" % ("module", "us/paint", "v-samples/s", "HBM TB/s"))

@@ -337,7 +337,20 @@ struct Val {
     std::string count;             // curve node count expression
     bool computed = false;         // buf: derives from a module's output or a transcendental function (not just params / constants / + - * /)
     std::string cob_b, cob_c;      // buf that is exactly a constant_or_buffer param's value: its "is a buffer" flag and its constant
+    uint64_t sines = 0;            // buf: the sine sources (bit per SineOsc call / sin(), Kernel::nsines) whose results flow into it
 };
+
+// ZH_PAINT_TOLERANT (include/zang_hip.h): a sine may be evaluated in f32 (zmath.hip.h zsinf_tol, within 2.4e-7 of musl's) when its
+// error can only be scaled and added on its way to the output -- through + - * neg abs min max, copies, a Filter's or a Decimator's
+// `input`, a delay ring written (not read: a ring's content is of unknown origin, kAllSines).  Every other place a value can go is a
+// SINK that keeps the sines reaching it exact: any other builtin param (an oscillator's freq / phase: the error would be integrated
+// or -- PMOscInstrument, DESIGN.md 5a -- multiplied by the carrier's slope at a large argument; a Distortion's input: gain up to
+// 64), the argument of sin / cos / sqrt, a divisor, both operands of pow.
+const uint64_t kAllSines = ~0ull;
+const size_t kMaxSines = 63;          // sources beyond this many in one kernel stay exact
+static bool linear_input(const std::string &module, const std::string &param) {
+    return (module == "Filter" || module == "Decimator") && param == "input";
+}
 
 size_t state_words(const std::string &name) {
     static const std::map<std::string, size_t> w = {{"SineOsc", 1}, {"PulseOsc", 1}, {"TriSawOsc", 2}, {"Noise", 8}, {"Envelope", 4}, {"Gate", 0},
@@ -363,8 +376,17 @@ struct Kernel {
     bool walk_reads_computed = false;   // a builtin's frame-to-frame state is fed by a value computed in the frame body
     Lines quiet_terms;             // wave-uniform tests over the next `zs_n` frames (a chunk): no SineOsc of constant freq / phase can
                                    // reach zsinf's rare path, no Envelope ends a stage -- the chunk then runs the body's ZS_Q forms
+    size_t nsines = 0;             // sine sources met so far (SineOsc calls and sin() of a buffer)
+    uint64_t exact_sines = 0;      // ... and the ones that reach a sink (linear_input above)
     std::string fresh(const std::string &stem) { uid++; return stem + std::to_string(uid); }
     size_t alloc(size_t n) { const size_t w = words; words += n; return w; }
+    // a new sine source: its id, or -1 = one too many (emitted exact); `bit` = its Val.sines bit
+    long sine_source(uint64_t &bit) {
+        if (nsines >= kMaxSines) { bit = 0; return -1; }
+        bit = 1ull << nsines;
+        return (long)nsines++;
+    }
+    void sink(const Val &v) { if (v.kind == Val::buf) exact_sines |= v.sines; }
 };
 
 struct ModuleCtx {
@@ -375,6 +397,8 @@ struct ModuleCtx {
     std::map<size_t, std::string> tnames;
     std::map<size_t, bool> heavy;  // temp index -> its current value derives from a module output / transcendental (Val.computed)
     std::map<size_t, std::pair<std::string, std::string>> cobsrc;   // temp index -> (Val.cob_b, Val.cob_c) while it holds a cob param's value
+    std::map<size_t, uint64_t> srcs;   // temp index -> Val.sines of its current value (unknown temp: kAllSines)
+    uint64_t outsines = 0;             // Val.sines of everything added to this module's output so far
     Lines *begin_sink, *end_sink;
     std::string rel = "(i - L.start)", length = "SPAN_LEN";
     const std::map<size_t, Val> *track = nullptr;
@@ -395,6 +419,30 @@ struct ModuleCtx {
     std::string fname(size_t i) const { return prefix + "f" + std::to_string(i); }
 };
 
+// The sine placeholders of a frame-body line (call_builtin's SineOsc, instruction()'s sin) as code, now that the kernel's sinks are
+// known: the exact text for a source that reaches a sink, the ZS_T-switched one otherwise.
+static std::string resolve_sines(const std::string &line, uint64_t tolerant) {
+    std::string out;
+    size_t at = 0;
+    for (;;) {
+        const size_t b = line.find('\x01', at);
+        if (b == std::string::npos) { out += line.substr(at); return out; }
+        const size_t bar = line.find('|', b), e = line.find('\x02', b);
+        out += line.substr(at, b - at);
+        const char kind = line[b + 1];
+        const unsigned long sid = strtoul(line.substr(b + 2, bar - b - 2).c_str(), nullptr, 10);
+        const std::string payload = line.substr(bar + 1, e - bar - 1);
+        const bool tol = (tolerant >> sid) & 1;
+        if (kind == 'O') {                                              // SineOscLane::frame's SINMODE argument (voices.hip.h)
+            if (payload == "1") out += tol ? ", (ZS_T ? 2 : 1)" : "";
+            else out += tol ? ", (ZS_T ? 2 : (int)!ZS_Q)" : ", !ZS_Q";
+        } else {
+            out += tol ? "(ZS_T ? zsinf_tol(" + payload + ") : zsinf(" + payload + "))" : "zsinf(" + payload + ")";
+        }
+        at = e + 1;
+    }
+}
+
 class HipEmitter {
 public:
     const CompiledScript &s;
@@ -407,6 +455,8 @@ public:
             v.kind = Val::buf; v.expr = mc.tname(r.index);
             auto it = mc.heavy.find(r.index);
             v.computed = it == mc.heavy.end() ? true : it->second;
+            auto ss = mc.srcs.find(r.index);
+            v.sines = ss == mc.srcs.end() ? kAllSines : ss->second;
             auto cs = mc.cobsrc.find(r.index);
             if (cs != mc.cobsrc.end()) { v.cob_b = cs->second.first; v.cob_c = cs->second.second; }
             return v;
@@ -432,14 +482,16 @@ public:
         return v.tag;
     }
     static std::string enum_payload(const Val &v) { return v.payload ? v.payload->expr : "0.0f"; }
-    static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy = false) {
+    static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy = false, uint64_t sines = 0) {
         if (!d.output) {
             mc.heavy[d.index] = heavy;
+            mc.srcs[d.index] = sines;
             mc.cobsrc.erase(d.index);
             const std::string t = mc.tname(d.index);
             if (zero_first) return {t + " = 0.0f;", t + " = " + t + " + (" + expr + ");"};
             return {t + " = " + expr + ";"};
         }
+        mc.outsines |= sines;
         return {mc.outvar + " = " + mc.outvar + " + (" + expr + ");"};
     }
     static std::string un(const std::string &op, const std::string &a) {
@@ -478,6 +530,11 @@ public:
                     if (it != a.end() && it->second.kind == Val::buf && it->second.computed) k.walk_reads_computed = true;
                 }
         }
+        uint64_t out_sines = 0;                                          // Val.sines of the module's output
+        for (const auto &pv : a) {
+            if (linear_input(name, pv.first)) out_sines |= pv.second.kind == Val::buf ? pv.second.sines : 0;
+            else k.sink(pv.second);
+        }
         const std::string o = k.fresh("m");
         const size_t w = k.alloc(state_words(name));
         Lines &decl = k.pro, &pro = *mc.begin_sink, &ends = *mc.end_sink, &epi = k.epi_stores;
@@ -514,7 +571,11 @@ public:
             const bool quiet = !ph.is_buf && mc.begin_sink == &k.pro && (!f.is_buf || !fv.cob_b.empty());
             if (quiet && !f.is_buf) k.quiet_terms.push_back(o + ".small_args(" + ph.c + ", (float)zs_n)");
             if (quiet && f.is_buf) k.quiet_terms.push_back("(!" + fv.cob_b + " && " + o + ".small_args_step(" + fv.cob_c + " * " + o + ".inv_sr, " + ph.c + ", (float)zs_n))");
-            value = o + ".frame<" + tf(f.is_buf) + (quiet ? ", !ZS_Q" : "") + ">(" + (f.is_buf ? f.i : "0.0f") + ", " + ph.i + ")";
+            uint64_t bit = 0;
+            const long sid = k.sine_source(bit);
+            out_sines |= bit;
+            const std::string mode = sid < 0 ? std::string(quiet ? ", !ZS_Q" : "") : strf("\x01" "O%ld|%s\x02", sid, quiet ? "!ZS_Q" : "1");   // resolved by generate()
+            value = o + ".frame<" + tf(f.is_buf) + mode + ">(" + (f.is_buf ? f.i : "0.0f") + ", " + ph.i + ")";
             ends.push_back(o + ".end();");
         } else if (name == "Cycle") {
             const Cob sp = cob(a["speed"]);
@@ -634,10 +695,12 @@ public:
         std::string target;
         if (!ins.out.output) {
             mc.heavy[ins.out.index] = true;                          // a module's output
+            mc.srcs[ins.out.index] = out_sines;
             mc.cobsrc.erase(ins.out.index);
             target = mc.tname(ins.out.index);
             frame.insert(frame.begin(), target + " = 0.0f;");
         } else {
+            mc.outsines |= out_sines;
             target = mc.outvar;
         }
         const std::string addl = target + " = " + target + " + (" + value + ");";
@@ -652,14 +715,14 @@ public:
         switch (ins.kind) {
         case IK::copy_buffer: {
             const Val src = val(mc, ins.src);
-            append(k.frame, put(mc, ins.out, src.expr, false, src.computed));
+            append(k.frame, put(mc, ins.out, src.expr, false, src.computed, src.sines));
             if (!ins.out.output && !src.cob_b.empty()) mc.cobsrc[ins.out.index] = {src.cob_b, src.cob_c};
             break;
         }
         case IK::float_to_buffer: append(k.frame, put(mc, ins.out, val(mc, ins.src).expr, false)); break;
         case IK::cob_to_buffer: {
             const Val &src = mc.env[ins.in_self_param];
-            append(k.frame, put(mc, ins.out, src.expr, false, src.computed));
+            append(k.frame, put(mc, ins.out, src.expr, false, src.computed, src.sines));
             if (!ins.out.output && !src.cob_b.empty()) mc.cobsrc[ins.out.index] = {src.cob_b, src.cob_c};
             break;
         }
@@ -675,18 +738,32 @@ public:
         }
         case IK::arith_buffer: {
             const Val va = val(mc, ins.a);
-            append(k.frame, put(mc, ins.out, un(ins.op, va.expr), false, va.computed || ins.op == "sin" || ins.op == "cos"));
+            std::string expr = un(ins.op, va.expr);
+            uint64_t sines = va.sines;
+            if (ins.op == "sin" || ins.op == "cos" || ins.op == "sqrt") {
+                k.sink(va);
+                sines = 0;
+                if (ins.op == "sin") {
+                    const long sid = k.sine_source(sines);
+                    if (sid >= 0) expr = strf("\x01" "F%ld|", sid) + va.expr + "\x02";            // zsinf(...) / its tolerant form: resolved by generate()
+                }
+            }
+            append(k.frame, put(mc, ins.out, expr, false, va.computed || ins.op == "sin" || ins.op == "cos", sines));
             break;
         }
         case IK::arith_float_buffer: case IK::arith_buffer_float: case IK::arith_buffer_buffer: {
             const Val va = val(mc, ins.a), vb = val(mc, ins.b);
             std::string a = va.expr, b = vb.expr;
             const bool heavy = va.computed || vb.computed || ins.op == "pow";
+            const uint64_t sa = va.kind == Val::buf ? va.sines : 0, sb = vb.kind == Val::buf ? vb.sines : 0;
+            uint64_t sines = sa | sb;
+            if (ins.op == "pow") { k.sink(va); k.sink(vb); sines = 0; }
+            else if (ins.op == "div") { k.sink(vb); sines = sa; }
             if (ins.op == "add" || ins.op == "mul") {
                 if (ins.kind == IK::arith_float_buffer) std::swap(a, b);       // addScalar / multiplyScalar(dest, buffer, float)
-                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), true, heavy));
+                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), true, heavy, sines));
             } else {
-                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), false, heavy));
+                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), false, heavy, sines));
             }
             break;
         }
@@ -701,6 +778,8 @@ public:
             else outvar = mc.outvar;
             ModuleCtx sub(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", &mc);
             module_body(sub);
+            if (!ins.out.output) mc.srcs[ins.out.index] = sub.outsines;
+            else mc.outsines |= sub.outsines;
             break;
         }
         case IK::track_call: track_call(mc, mr, ins); break;
@@ -718,6 +797,7 @@ public:
         k.epi_stores.push_back(strf("zs_st_u(L.state, %zu, V, v, %s_idx);", w_idx, d.c_str()));
         if (!ins.out.output) k.frame.push_back(mc.tname(ins.out.index) + " = 0.0f;");             // zang.zero(span, dest) (:396-399)
         const std::string fb = mc.tname(ins.feedback_temp), fbout = mc.tname(ins.feedback_out_temp);
+        mc.srcs[ins.feedback_temp] = kAllSines;                          // what a ring holds is of unknown origin
         Lines begins, ends, body;
         Lines *sb = mc.begin_sink, *se = mc.end_sink;
         const std::string srel = mc.rel, slen = mc.length;
@@ -1018,15 +1098,27 @@ public:
             const bool two_bodies = !k.quiet_terms.empty();
             const std::string loop_call = I +
                 strf("zs_frame_loop<%d, %zu>(L.out, v, L.ostride, ins, istr, ivo, L.start, L.end, (L.flags & ZH_PAINT_ZERO_FIRST) != 0, zs_walk,", unroll, nin);
-            if (two_bodies) {
-                std::string all;
-                for (const std::string &t : k.quiet_terms) all += (all.empty() ? "" : " && ") + t;
+            // the sine sources that reach no sink: under ZH_PAINT_TOLERANT their f32 form (a second instance of the frame body,
+            // chosen once per paint: ZS_T).  A kernel without one reads as before.
+            uint64_t tolerant = 0;
+            for (size_t i = 0; i < k.nsines; i++) if (!((k.exact_sines >> i) & 1)) tolerant |= 1ull << i;
+            Lines frame_lines;
+            for (const std::string &l : k.frame) frame_lines.push_back(resolve_sines(l, tolerant));
+            const std::string lam = I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA ", ni);
+            std::string all;
+            for (const std::string &t : k.quiet_terms) all += (all.empty() ? "" : " && ") + t;
+            if (tolerant) {
+                if (two_bodies) out.push_back(I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + all + "; };");
+                out.push_back(I + strf("auto zs_body = [&](auto zs_q, auto zs_t, uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
+                out.push_back(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;");
+                out.push_back(I + I + "constexpr bool ZS_T = decltype(zs_t)::value; (void)ZS_T;");
+            } else if (two_bodies) {
                 out.push_back(I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + all + "; };");
                 out.push_back(I + strf("auto zs_body = [&](auto zs_q, uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
                 out.push_back(I + I + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;");
             } else {
                 out.push_back(loop_call);
-                out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA {", ni));
+                out.push_back(lam + "{");
             }
             out.push_back(I + I + "(void)i; (void)x;");
             if (!k.temps.empty()) {
@@ -1034,12 +1126,25 @@ public:
                 for (size_t j = 0; j < k.temps.size(); j++) decl += (j ? ", " : "") + k.temps[j] + " = 0.0f";
                 out.push_back(I + I + decl + ";");
             }
-            append(out, indent(indent(k.frame)));
-            if (two_bodies) {
+            append(out, indent(indent(frame_lines)));
+            if (tolerant) {
+                out.push_back(I + "};");
+                for (const char *t : {"true", "false"}) {
+                    out.push_back(I + (std::string(t) == "true" ? "if (L.flags & ZH_PAINT_TOLERANT) {" : "} else {"));
+                    out.push_back(loop_call);
+                    if (two_bodies) {
+                        out.push_back(lam + strf("{ zs_body(zs_tag<false>{}, zs_tag<%s>{}, i, x, o); }, zs_quiet,", t));
+                        out.push_back(lam + strf("{ zs_body(zs_tag<true>{}, zs_tag<%s>{}, i, x, o); });", t));
+                    } else {
+                        out.push_back(lam + strf("{ zs_body(zs_tag<false>{}, zs_tag<%s>{}, i, x, o); });", t));
+                    }
+                }
+                out.push_back(I + "}");
+            } else if (two_bodies) {
                 out.push_back(I + "};");
                 out.push_back(loop_call);
-                out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<false>{}, i, x, o); }, zs_quiet,", ni));
-                out.push_back(I + strf("                     [&](uint32_t i, const float (&x)[%zu], float &o) ZH_INLINE_LAMBDA { zs_body(zs_tag<true>{}, i, x, o); });", ni));
+                out.push_back(lam + "{ zs_body(zs_tag<false>{}, i, x, o); }, zs_quiet,");
+                out.push_back(lam + "{ zs_body(zs_tag<true>{}, i, x, o); });");
             } else {
                 out.push_back(I + "});");
             }

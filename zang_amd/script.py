@@ -156,8 +156,11 @@ class ScriptModule:
                 p.f = float(payload) if payload is not None else 0.0
         return p
 
-    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False):
-        """params: dict by name (sample_rate included), like the reference's Params struct literal."""
+    def paint(self, span, outputs, temps, note_id_changed, params, zero_first=False, tolerant=False):
+        """params: dict by name (sample_rate included), like the reference's Params struct literal.
+        tolerant=True: ZH_PAINT_TOLERANT -- the module's sines that reach the output through scaling and adding alone (not another
+        oscillator's freq / phase, a distortion, a divisor ...: csrc/zscript_emit.hip) are evaluated in f32; all state that is not a
+        Filter's or a delay ring's stays exact."""
         keep = []
         arr = (abi.ScriptParam * abi.SCRIPT_MAX_PARAMS)()
         for i, (name, kind, enum) in enumerate(self.params):
@@ -169,7 +172,7 @@ class ScriptModule:
             raise KeyError("module %s has no param(s) %s" % (self.name, sorted(extra)))
         ob = as_buf(outputs[0])
         nic = as_bool(note_id_changed)
-        flags = abi.PAINT_ZERO_FIRST if zero_first else 0
+        flags = (abi.PAINT_ZERO_FIRST if zero_first else 0) | (abi.PAINT_TOLERANT if tolerant else 0)
         abi.check(self.lib.zh_script_module_paint(self.handle, span.start, span.end, C.byref(ob), nic, arr, len(self.params), flags),
                   "zh_script_module_paint")
         self._keep = (keep, outputs, note_id_changed)
