@@ -805,7 +805,9 @@ __global__ void __launch_bounds__(256) k_nice_tp_a(const NiceTpArgs t) {
         // else eight frames at a time with the test, frame by frame around a stage end
         if (zany_wave(n.env.mode == ENV_MODE_TOWARD)) {
             if (n.env.quiet((int)t.L)) {
-                for (uint32_t i = 0; i < t.L; i += 8) n.env.template skip_quiet<8>();
+                // (the curve once, for the state the chunk leaves: last_value is rewritten from the clock by whatever reads it next)
+                for (uint32_t i = 8; i < t.L; i += 8) n.env.template skip_clock<8>();
+                n.env.template skip_quiet<8>();
             } else {
                 for (uint32_t i = 0; i < t.L; i += 8) {
                     if (n.env.quiet(8)) n.env.template skip_quiet<8>();
@@ -1067,10 +1069,17 @@ __global__ void __launch_bounds__(64) k_pmosc_ranges(PMOscArgs a, uint32_t *__re
     n.begin(a.sample_rate, a.freq.get(v), a.release_duration[v], a.note_on.get(v), a.nic.get(v));
     // the replay: 8 frames at a time where no voice of the wave can end an envelope stage (EnvLaneT::quiet) -- then only the
     // three clocks step (the envelope's value is evaluated once per chunk, for the state it leaves) -- frame by frame otherwise
+    // (32 at a time while that holds: the test costs as much as four frames' clocks; last_value is not kept up during the replay --
+    // every frame painted afterwards rewrites it from the clock before anything reads it, and every range paints at least one)
     uint32_t i = start;
+    for (; i + 32 <= f0 && n.env.quiet(32); i += 32) {
+        n.env.template skip_clock<32>();
+#pragma unroll
+        for (int k = 0; k < 32; k++) { float tm_i, tc_i; n.step_phase(tm_i, tc_i); }
+    }
     for (; i + 8 <= f0; i += 8) {
         if (n.env.quiet(8)) {
-            n.env.template skip_quiet<8>();
+            n.env.template skip_clock<8>();
 #pragma unroll
             for (int k = 0; k < 8; k++) { float tm_i, tc_i; n.step_phase(tm_i, tc_i); }
         } else {

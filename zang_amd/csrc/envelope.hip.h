@@ -247,6 +247,16 @@ struct EnvLaneT {
         t = zsel(toward, tt, t);
         last_value = zsel(toward, start + curve(tt) * cur_delta, last_value);
     }
+    // skip_quiet() without last_value: frame() and frame_quiet() rewrite a TOWARD voice's last_value from the clock before anything
+    // reads it (a stage end's `start = last_value` comes after that frame's own update), so a replay that is FOLLOWED by at least
+    // one painted frame before the state is stored -- k_envelope_ranges: every range paints a frame of its own -- steps the clock alone
+    template <int N> __device__ __forceinline__ void skip_clock() {
+        const M toward = mode == u(ENV_MODE_TOWARD);
+        F tt = t;
+#pragma unroll
+        for (int k = 0; k < N; k++) tt = tt + cur_step;
+        t = zsel(toward, tt, t);
+    }
     // frame() for the callers that want `painted ? 0.0f + value : 0.0f` (the zeroed temp a composite paints the
     // envelope into): the select is an AND with m_painted, and no mode compare is needed for it
     __device__ __forceinline__ F frame_masked() {

@@ -499,8 +499,10 @@ __global__ void __launch_bounds__(64) k_envelope_ranges(const uint32_t *__restri
     env_load(e, p, v);
     e.begin(nic.get(v));
     uint32_t i = start;
+    // (32 frames per test where that holds: a test is six instructions and a scalar branch, as much as eight clock steps)
+    for (; i + 32 <= f0 && e.quiet(32); i += 32) e.template skip_clock<32>();
     for (; i + 8 <= f0; i += 8) {
-        if (e.quiet(8)) e.template skip_quiet<8>();
+        if (e.quiet(8)) e.template skip_clock<8>();
         else {
 #pragma unroll
             for (int k = 0; k < 8; k++) { float val; (void)e.frame(val); }
