@@ -824,3 +824,34 @@ def test_gpu_script_tolerant_sines(ctx):
     _tolerant_parity(ctx, "Buzz", [(0, F, True, {"sample_rate": 48000.0, "freq": f, "color": 0.3, "note_on": on})], False)
     xin = rng.uniform(-1, 1, (V, F)).astype(np.float32)
     _tolerant_parity(ctx, "Echo", [(0, F, False, {"sample_rate": 48000.0, "input": xin, "echo_volume": 0.5, "ftype": ("low_pass", None)})], False)
+
+
+def _stored_words(hip, name):
+    """the state words zs_paint_<name>'s epilogue stores"""
+    import re
+    i = hip.index("zs_paint_%s(" % name)
+    body = hip[i:hip.index("\n}\n", i)]
+    words = set()
+    for m in re.finditer(r"zs_st_(f|u|u64)\(L\.state, (\d+), V, v,", body):
+        w = int(m.group(2))
+        words |= {w, w + 1} if m.group(1) == "u64" else {w}
+    return words
+
+
+def test_every_state_word_is_stored_by_a_range_capable_kernel():
+    """A launch as frame ranges stores the end state into the OTHER blob and the host flips (csrc/script.hip: no copy of the start
+    state): every state word must then be written by the epilogue -- all of the repo's script modules and 150 generated ones."""
+    import re
+    from tests import script_fuzz
+    texts = [SCRIPT] + [script_fuzz.generate(seed)[0] for seed in range(3000, 3150)]
+    checked = 0
+    for text in texts:
+        hip, meta = zs.generate_hip(zs.compile(text, "t"))
+        for name, m in meta.items():
+            if "error" in m:
+                continue
+            ok = re.search(r"zs_ranges_ok_%s = (\d)u;" % name, hip)
+            if ok and ok.group(1) == "1":
+                assert _stored_words(hip, name) == set(range(m["state_words"])), name
+                checked += 1
+    assert checked > 100
