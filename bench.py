@@ -245,9 +245,10 @@ def preflight_rank(args, world, rank, local_rank, emulate):
 class Workload:
     """Builds the module(s), resident params and the per-step callable for one rank."""
 
-    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None, channels=1, exchange="rccl", tolerant=False):
+    def __init__(self, name, ctx, V, F, first_voice, ring_bytes, world=1, pad=None, channels=1, exchange="rccl", tolerant=False, multi=None):
         import torch
         self.world = world
+        self.multi = (world > 1) if multi is None else bool(multi)     # the exchange step runs (ZH_BENCH_ONE_RANK_DIST: with a world of one)
         self.tolerant = bool(tolerant)
         self.channels, self.exchange_kind = channels, exchange
         self.slots = None
@@ -428,7 +429,7 @@ class Workload:
         all-reduce per buffer would be pure latency (~20-40 us against 170 us of rendering), so the 48 buffers of a
         batch go in ONE all-reduce of [48][channels][frames] (192 KiB per channel) after the batch's launches -- an
         offline renderer only needs the mixed audio once the batch is done."""
-        if self.name != "nice_mix" or self.world <= 1:
+        if self.name != "nice_mix" or not self.multi:
             return
         block = self.mixes[:self.batch_rows]
         if self.slots is not None:
@@ -760,6 +761,11 @@ def main():
     if env_world is None and (args.gpus or 1) > 1:
         sys.exit(spawn_ranks(args.gpus, argv))       # parent: nothing below runs in it
     world = int(env_world or 1)
+    # ZH_BENCH_ONE_RANK_DIST=1 (under torch.distributed.run with ONE process): this rank takes the N > 1 code path as it is --
+    # torch.distributed's nccl (= RCCL) process group and the gloo control group, the library's own RCCL communicator, the
+    # exchange inside the timed region, the paired regions -- with a world of one.  What a one-GPU box can run of the path the
+    # driver's scaling run takes (tests/test_bench_launcher.py); ZH_BENCH_EMULATE is the other half (two ranks, gloo).
+    dist_on = world > 1 or os.environ.get("ZH_BENCH_ONE_RANK_DIST") == "1"
     if args.gpus is not None and args.gpus != world:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
                          f"or under torch.distributed.run with --nproc-per-node equal to --gpus\n")
@@ -769,9 +775,9 @@ def main():
     if args.preflight:
         sys.exit(preflight_rank(args, world, rank, local_rank, os.environ.get("ZH_BENCH_EMULATE") == "1"))
     if args.workload is None:
-        args.workload = "pulseosc" if world == 1 else "nice_mix"
+        args.workload = "nice_mix" if dist_on else "pulseosc"
     if args.voices is None:
-        args.voices = 131072 if (args.workload == "nice_mix" and world > 1) else 4096
+        args.voices = 131072 if (args.workload == "nice_mix" and dist_on) else 4096
     if args.steps is None:
         args.steps = 960 if args.workload in ("nice", "nice_mix", "script") else 1000
     import torch
@@ -789,7 +795,7 @@ def main():
         sys.stderr.write(f"bench.py: rank {rank} needs GPU {device_index} but this node shows {torch.cuda.device_count()}\n")
         sys.exit(3)
     ctl = None
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(device_index)
@@ -813,7 +819,7 @@ def main():
     # --exchange rccl: the library's own communicator (zh_comm_*, librccl opened by libzang_hip.so); torch.distributed only
     # carries rank 0's 128-byte id.  Two ranks emulated on one device cannot form an RCCL communicator: gloo stays there.
     comm, comm_note = None, None
-    if world > 1 and args.exchange == "rccl" and args.workload == "nice_mix":
+    if dist_on and args.exchange == "rccl" and args.workload == "nice_mix":
         if emulate:
             comm_note = "ZH_BENCH_EMULATE: ranks share one device, no RCCL communicator; torch.distributed gloo instead"
         else:
@@ -825,7 +831,7 @@ def main():
                 sys.stderr.write(f"bench.py rank {rank}: {comm_note}\n")
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     # torch.cuda.synchronize() without its Python wrapper (lazy-init check + a device context manager around the same call)
@@ -837,7 +843,7 @@ def main():
         return h
 
     def max_over_ranks(x):
-        if world > 1:
+        if dist_on:
             t = torch.tensor([x], dtype=torch.float64, device="cpu" if emulate else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -849,7 +855,7 @@ def main():
         (max over ranks) and by HIP events on the launch stream."""
 
         def __init__(self, name, voices, steps, exchange="rccl", slots=False):
-            self.wl = Workload(name, ctx, voices, F, first_voice=rank * voices, ring_bytes=args.ring_mib << 20, world=world,
+            self.wl = Workload(name, ctx, voices, F, first_voice=rank * voices, ring_bytes=args.ring_mib << 20, world=world, multi=dist_on,
                                pad=args.pad_voices, channels=args.channels, exchange=exchange, tolerant=args.tolerant)
             wl = self.wl
             wl.comm = comm if exchange == "rccl" else None
@@ -900,7 +906,7 @@ def main():
             sync()
             barrier()
             sync()
-            one_launch = self.graph is not None and K == self.G and world == 1
+            one_launch = self.graph is not None and K == self.G and not dist_on
             rec, h, e0, e1 = lib.zh_event_record, ctx.handle, self.ev0, self.ev1
             launch, gh = lib.zh_graph_launch, (self.graph.handle if self.graph is not None else None)
             # HIP events on the launch stream bracket exactly the K timed steps: device time per
@@ -925,7 +931,7 @@ def main():
                 abi.check(rec(h, e1), "zh_event_record")
                 sync()
                 barrier()
-                if world > 1:
+                if dist_on:
                     sync()
                 elapsed = time.perf_counter() - t0
             ms = C.c_float()
@@ -974,7 +980,7 @@ def main():
     K_req = args.steps
     K = pattern_steps(args.workload, K_req)          # the note-pattern workloads time whole 48-buffer patterns
     mixdown = args.workload == "nice_mix"
-    main_run = Runner(args.workload, V, K, exchange=args.exchange, slots=(args.exchange == "p2p" and world > 1 and mixdown))
+    main_run = Runner(args.workload, V, K, exchange=args.exchange, slots=(args.exchange == "p2p" and dist_on and mixdown))
     wl, G, graph = main_run.wl, main_run.G, main_run.graph
     main_run.warm(args.warmup)
     # Untimed rehearsals of the timed region, same code path: the W warm-up steps of a 4 us kernel are 20 us of
@@ -998,7 +1004,7 @@ def main():
     # With several GPUs every repeat is a PAIR -- the region with the exchange, then the same K steps without it -- so that
     # `single_gpu_shard` and `scaling_factor` are medians of interleaved regions, never one sample each.
     import statistics
-    paired = world > 1 and mixdown
+    paired = dist_on and mixdown
     R = args.repeats if args.repeats is not None else (min(30, max(0, int(0.5 / max(elapsed, 1e-4)))) if elapsed < 0.1 else 0)
     if paired:
         R = max(R, 5)
@@ -1056,7 +1062,7 @@ def main():
     if reps:
         out["repeats"] = reps
 
-    if world > 1 and mixdown:
+    if dist_on and mixdown:
         # ---- the exchange step on its own, and the same shard without it (scaling factor) ----
         rows = wl.batch_rows
         nbytes = wl.mixes[:rows].numel() * 4
@@ -1073,7 +1079,7 @@ def main():
                 fn()
                 torch.cuda.synchronize()
                 per.append(time.perf_counter() - t0)
-            if world > 1:
+            if dist_on:
                 t = torch.tensor(per, dtype=torch.float64, device="cpu" if emulate else "cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 per = t.tolist()
@@ -1221,7 +1227,7 @@ def main():
     out["build"] = build_record(lib)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -61,7 +61,7 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         * (north_star: "1e-5 relative f32", bits only for Gate and Decimator).  Honoured by
         *  - zh_filter_paint (constant or control-image cutoff / resonance) and zh_noise_filter_paint (white noise) at up to 16,384 voices,
         *    where the span is then filtered as 32-128-frame chunks at once (csrc/filter_tp.hip.h: zero-state responses, a 2 x 2
-        *    transition power, then the reference's own recurrence per chunk; measured error <= 5.8e-6 of the voice's peak over 7,200 random cases,
+        *    transition power, then the reference's own recurrence per chunk; measured error <= 7.3e-6 of the voice's peak over 9,200 random cases,
         *    2.5-3 x faster); the noise samples and generator states are exact, the filter state carries the samples' error;
         *  - zh_nice_paint, zh_nice_paint_mix and zh_nice_paint_mix_stereo at up to 16,384 voices, spans of 128-4,096 frames: the same
         *    for the fused voice's filter (oscillator, envelope and their states exact: the envelope is walked once per voice ahead

@@ -171,3 +171,24 @@ def test_the_drivers_own_command_line_for_n_ranks_on_a_gpu_box():
         assert key in d, key
     assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["config"]["workload"].startswith("nice_mix")
     assert d["collective"]["world_size_seen"] == 2 and d["parity"]["bitexact"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_one_rank_takes_the_real_rccl_path_of_the_n_rank_line():
+    """ZH_BENCH_ONE_RANK_DIST=1 under the driver's launch form with one process: the N > 1 code path as the scaling run takes it
+    -- torch.distributed's nccl (= RCCL) process group with `device_id`, the gloo control group, the library's own RCCL
+    communicator (zh_comm_*, librccl opened by libzang_hip.so), its all-reduce right behind the batch's kernels in the timed
+    region, the paired regions, the parity check of the shard -- with a world of one.  (Two ranks on one device cannot form an
+    RCCL communicator: that half runs over gloo in the tests above.)"""
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "1", "--steps", "20", "--warmup", "5", "--voices", "8192", "--no-cpu"],
+                       env=_env(ZH_BENCH_ONE_RANK_DIST="1"), capture_output=True, text=True, timeout=540, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 48 and d["value"] > 0 and d["config"]["workload"].startswith("nice_mix")
+    c = d["collective"]
+    assert c["world_size_seen"] == 1 and c["reduce_us"] > 0 and "rccl" in (c["backend"] + c.get("kind", "")).lower(), c
+    assert "zh_comm" in json.dumps(c) or "library" in json.dumps(c), c          # the library's communicator, not the torch fallback
+    assert d["scaling_factor"] > 0 and d["parity"]["bitexact"] is True
