@@ -455,6 +455,46 @@ def test_filter(ctx, oracle, ftype, ck, rk):
     util.assert_bitexact(st["b"].astype(np.float32), rb, "filter b")
 
 
+@pytest.mark.parametrize("form", ["pipeline", "walk"])
+@pytest.mark.parametrize("zero_first", [False, True])
+@pytest.mark.parametrize("ck,rk", [("b", "c"), ("c", "b"), ("b", "b")])
+@pytest.mark.parametrize("ftype", [1, 3, 5])
+def test_filter_control_images_both_forms(ctx, oracle, ftype, ck, rk, zero_first, form, monkeypatch):
+    """Cutoff and / or resonance as control images at a small voice count: the three-wave pipeline with the images' rows as tiles of
+    their own (k_filter_pc_ctl: 32-frame tiles with one image, 16 with both) and the one-wave walk (ZH_FILTER_PC_CTL_MAX=0) against
+    the oracle -- per-frame values outside [0, 1] (clamped), ragged spans, a span under 64 frames (the walk anyway), a voice count
+    that is not a multiple of 64, += and ZERO_FIRST, carried state."""
+    from zang_amd import modules as mod, zang
+    if form == "walk":
+        monkeypatch.setenv("ZH_FILTER_PC_CTL_MAX", "0")
+    V = 200
+    rng = np.random.default_rng(57)
+    cut = rng.uniform(-0.1, 1.1, V).astype(np.float32); res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+    cbuf = rng.uniform(-0.1, 1.1, (V, F)).astype(np.float32); rbuf = rng.uniform(-0.1, 1.1, (V, F)).astype(np.float32)
+    cbuf[:, 300:340] = np.linspace(0.0, 1.0, 40, dtype=np.float32)[None, :]          # a sweep inside the noise
+    inp = util.rng_buffers(58, V, F); out0 = util.rng_buffers(59, V, F)
+    spans = [(0, 1024), (0, 1024), (100, 612), (612, 1000), (5, 170), (170, 200), (200, 329), (0, 1007)]
+    L = oracle.lib()
+    ref = out0.copy(); rl = np.zeros(V, np.float32); rb = np.zeros(V, np.float32)
+    for v in range(V):
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st))
+        for (s, e) in spans:
+            if zero_first:
+                ref[v][s:e] = 0.0
+            L.zo_filter_paint(C.byref(st), s, e, oracle.fptr(ref[v]), oracle.fptr(inp[v]), ftype, _cob(oracle, ck, cut[v], cbuf[v]), _cob(oracle, rk, res[v], rbuf[v]))
+        rl[v], rb[v] = st.l, st.b
+    m = mod.Filter(V, ctx)
+    out = util.to_image(out0); gi = util.to_image(inp); gc, gr = util.to_image(cbuf), util.to_image(rbuf)
+    dc, dr = util.dev(cut), util.dev(res)
+    for (s, e) in spans:
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(gi, ftype, _gcob(zang, ck, dc, gc), _gcob(zang, rk, dr, gr)), zero_first=zero_first)
+    ctx.sync()
+    util.assert_bitexact(util.from_image(out), ref, f"filter type {ftype} cutoff {ck} res {rk} {form}")
+    st = m.state()
+    util.assert_bitexact(st["l"].astype(np.float32), rl, "filter l")
+    util.assert_bitexact(st["b"].astype(np.float32), rb, "filter b")
+
+
 def test_filter_and_distortion_in_place(ctx, oracle):
     """The input image IS the output image (`out += f(out)`): every frame's input is read before its output is written,
     in the oracle's scalar loop and in the device's chunked loops (a chunk's loads precede its stores; the next chunk's

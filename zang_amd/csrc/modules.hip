@@ -711,6 +711,179 @@ __global__ void __launch_bounds__(192) k_filter_pc(float *__restrict__ l_io, flo
     if (live && role == 1) { l_io[v] = o.l; b_io[v] = o.b; }
 }
 
+// k_filter_pc with the cutoff and / or the resonance as control images (a filter sweep: Filter.zig:120-129 clamps them per frame): the
+// loader fetches their rows beside the input's, clamps, and publishes them as tiles of their own; the recurrence wave takes a frame's
+// cut / res from registers like its input (one more 16-byte LDS read per four frames and image), the writer reads the same tiles
+// three steps later (four-deep rings, like in_q).  The one-wave walk this replaces took 95.5 us per 1,024 frames at 4,096 voices
+// (the exact form of the table's "Filter low-pass, cutoff image" row).  CH = 32 with one image (96 KB of LDS), 16 with both (64 KB).
+template <bool ZF, uint32_t CH, bool CB, bool RB>
+__global__ void __launch_bounds__(192) k_filter_pc_ctl(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out, CImg input,
+                                                       uint32_t start, uint32_t end, float l_mul, float b_mul, float h_mul, CobP cutoff, CobP res_p) {
+    static_assert(CB || RB, "constant cutoff and resonance: k_filter_pc");
+    constexpr uint32_t Q = CH / 4;
+    __shared__ float4 in_q[4][Q][64], cut_q[CB ? 4 : 1][Q][64], res_q[RB ? 4 : 1][Q][64], l_q[2][Q][64], b_q[2][Q][64];
+    const uint32_t lane = threadIdx.x & 63, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 loader, 1 filter, 2 writer
+    const uint32_t v = blockIdx.x * 64 + lane;
+    const bool live = v < V;
+    const uint32_t vc = live ? v : V - 1;
+    const uint32_t n = end - start, nchunks = (n + CH - 1) / CH;
+    const uint32_t voff = vc * 4u, orow = (uint32_t)out.stride * 4u, irow = (uint32_t)input.stride * 4u;
+    const uint32_t crow = CB ? (uint32_t)cutoff.b.stride * 4u : 0u, rrow = RB ? (uint32_t)res_p.b.stride * 4u : 0u;
+    FilterLane o;
+    o.l = l_io[vc]; o.b = b_io[vc];
+    o.begin(ZH_FILTER_LOW_PASS, CB ? 0.0f : cutoff.c.get(vc), RB ? 0.0f : res_p.c.get(vc));   // the constant one's cut / res (:114, :118)
+    auto clampcut = [](float x) ZH_INLINE_LAMBDA { return zclampf(x, 0.0f, 1.0f); };            // :126
+    auto clampres = [](float x) ZH_INLINE_LAMBDA { return 1.0f - zclampf(x, 0.0f, 1.0f); };     // :128
+    auto frames = [&](uint32_t c) ZH_INLINE_LAMBDA { return c < nchunks ? min(CH, n - c * CH) : 0u; };
+    auto at = [&](float4 (*t)[64], uint32_t k) ZH_INLINE_LAMBDA -> float & { return reinterpret_cast<float *>(&t[k >> 2][lane])[k & 3]; };
+    const uint32_t last = nchunks + 2;
+    if (role == 0) {
+        float xa[CH], xb[CH], ca[CB ? CH : 1], cb_[CB ? CH : 1], ra[RB ? CH : 1], rb_[RB ? CH : 1];
+        auto request = [&](uint32_t c, float (&x)[CH], float (&cu)[CB ? CH : 1], float (&re)[RB ? CH : 1]) ZH_INLINE_LAMBDA {
+            if (frames(c) == CH) {
+                const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) x[k] = zrow_load<1>(ri, voff, k * irow);
+                if constexpr (CB) {
+                    const zh_rsrc_t rc = zrow_rsrc(cutoff.b.p, cutoff.b.stride, start + c * CH);
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) cu[k] = zrow_load<1>(rc, voff, k * crow);
+                }
+                if constexpr (RB) {
+                    const zh_rsrc_t rr = zrow_rsrc(res_p.b.p, res_p.b.stride, start + c * CH);
+#pragma unroll
+                    for (uint32_t k = 0; k < CH; k++) re[k] = zrow_load<1>(rr, voff, k * rrow);
+                }
+            }
+        };
+        auto publish = [&](uint32_t c, float (&x)[CH], float (&cu)[CB ? CH : 1], float (&re)[RB ? CH : 1]) ZH_INLINE_LAMBDA {
+            const uint32_t nf = frames(c);
+            float4 (*t)[64] = in_q[c & 3];
+            float4 (*tc)[64] = cut_q[CB ? (c & 3) : 0], (*tr)[64] = res_q[RB ? (c & 3) : 0];
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) {
+                    t[q][lane] = make_float4(x[4 * q] + kSvfDcOffset, x[4 * q + 1] + kSvfDcOffset, x[4 * q + 2] + kSvfDcOffset, x[4 * q + 3] + kSvfDcOffset);
+                    if constexpr (CB) tc[q][lane] = make_float4(clampcut(cu[4 * q]), clampcut(cu[4 * q + 1]), clampcut(cu[4 * q + 2]), clampcut(cu[4 * q + 3]));
+                    if constexpr (RB) tr[q][lane] = make_float4(clampres(re[4 * q]), clampres(re[4 * q + 1]), clampres(re[4 * q + 2]), clampres(re[4 * q + 3]));
+                }
+            } else {
+                const zh_rsrc_t ri = zrow_rsrc(input.p, input.stride, start + c * CH);
+                for (uint32_t k = 0; k < nf; k++) {
+                    at(t, k) = zrow_load<1>(ri, voff, k * irow) + kSvfDcOffset;
+                    if constexpr (CB) at(tc, k) = clampcut(zrow_load<1>(zrow_rsrc(cutoff.b.p, cutoff.b.stride, start + c * CH), voff, k * crow));
+                    if constexpr (RB) at(tr, k) = clampres(zrow_load<1>(zrow_rsrc(res_p.b.p, res_p.b.stride, start + c * CH), voff, k * rrow));
+                }
+            }
+            request(c + 2, x, cu, re);
+        };
+        request(0, xa, ca, ra); request(1, xb, cb_, rb_);
+        for (uint32_t c = 0; c <= last; c += 2) {
+            if (c < nchunks) publish(c, xa, ca, ra);
+            __syncthreads();
+            if (c + 1 <= last) {
+                if (c + 1 < nchunks) publish(c + 1, xb, cb_, rb_);
+                __syncthreads();
+            }
+        }
+    } else if (role == 1) {
+        float4 fa[Q], fb[Q], ca[CB ? Q : 1], cb_[CB ? Q : 1], ra[RB ? Q : 1], rb_[RB ? Q : 1];     // the tile in hand / the next one
+#pragma unroll
+        for (uint32_t q = 0; q < Q; q++) fa[q] = fb[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t q = 0; q < (CB ? Q : 1); q++) ca[q] = cb_[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t q = 0; q < (RB ? Q : 1); q++) ra[q] = rb_[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto step = [&](uint32_t c, float4 (&cur)[Q], float4 (&nxt)[Q], float4 (&ccur)[CB ? Q : 1], float4 (&cnxt)[CB ? Q : 1],
+                        float4 (&rcur)[RB ? Q : 1], float4 (&rnxt)[RB ? Q : 1]) ZH_INLINE_LAMBDA {
+            if (c == 0 || c > nchunks + 1) return;
+            const float4 (*tn)[64] = in_q[(c - 1) & 3];              // (complete only if that tile is a whole one: otherwise unused)
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) nxt[q] = tn[q][lane];
+            if constexpr (CB) {
+                const float4 (*tcn)[64] = cut_q[(c - 1) & 3];
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) cnxt[q] = tcn[q][lane];
+            }
+            if constexpr (RB) {
+                const float4 (*trn)[64] = res_q[(c - 1) & 3];
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) rnxt[q] = trn[q][lane];
+            }
+            if (c == 1) return;
+            const uint32_t d = c - 2, nf = frames(d);
+            float4 (*tl)[64] = l_q[d & 1], (*tb)[64] = b_q[d & 1];
+            if (nf == CH) {
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) {
+                    const SvfMid m0 = svf_core_mid(o.l, o.b, cur[q].x, CB ? ccur[q].x : o.cut, RB ? rcur[q].x : o.res);
+                    const SvfMid m1 = svf_core_mid(o.l, o.b, cur[q].y, CB ? ccur[q].y : o.cut, RB ? rcur[q].y : o.res);
+                    const SvfMid m2 = svf_core_mid(o.l, o.b, cur[q].z, CB ? ccur[q].z : o.cut, RB ? rcur[q].z : o.res);
+                    const SvfMid m3 = svf_core_mid(o.l, o.b, cur[q].w, CB ? ccur[q].w : o.cut, RB ? rcur[q].w : o.res);
+                    tl[q][lane] = make_float4(m0.l, m1.l, m2.l, m3.l);
+                    tb[q][lane] = make_float4(m0.b1, m1.b1, m2.b1, m3.b1);
+                }
+            } else {                                                  // (the last tile: the loader has stopped, its buffers stay)
+                float4 (*ti)[64] = in_q[d & 3];
+                float4 (*tc)[64] = cut_q[CB ? (d & 3) : 0], (*tr)[64] = res_q[RB ? (d & 3) : 0];
+                for (uint32_t k = 0; k < nf; k++) {
+                    const SvfMid m = svf_core_mid(o.l, o.b, at(ti, k), CB ? at(tc, k) : o.cut, RB ? at(tr, k) : o.res);
+                    at(tl, k) = m.l; at(tb, k) = m.b1;
+                }
+            }
+        };
+        for (uint32_t c = 0; c <= last; c += 2) {
+            step(c, fa, fb, ca, cb_, ra, rb_);
+            __syncthreads();
+            if (c + 1 <= last) {
+                step(c + 1, fb, fa, cb_, ca, rb_, ra);
+                __syncthreads();
+            }
+        }
+    } else {
+        float bn[CH];                                                 // the output rows of the tile after the one in hand
+        for (uint32_t c = 0; c <= last; c++) {
+            if (c > 2) {
+                const uint32_t d = c - 3, nf = frames(d);
+                const zh_rsrc_t ro = zrow_rsrc(out.p, out.stride, start + d * CH);
+                float4 (*ti)[64] = in_q[d & 3], (*tl)[64] = l_q[d & 1], (*tb)[64] = b_q[d & 1];
+                float4 (*tc)[64] = cut_q[CB ? (d & 3) : 0], (*tr)[64] = res_q[RB ? (d & 3) : 0];
+                auto one = [&](uint32_t k, float in, float l, float b1, float cu, float re, float base) ZH_INLINE_LAMBDA {
+                    const SvfOut sv = svf_finish(l, b1, in, cu, re);
+                    const float val = sv.l * l_mul + sv.b * b_mul + sv.h * h_mul;    // :146
+                    if (live) zrow_store<1>(ro, voff, k * orow, base + val);
+                };
+                if (nf == CH) {
+                    float4 xi[Q], xl[Q], xb[Q], xc[CB ? Q : 1], xr[RB ? Q : 1];
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++) {
+                        xi[q] = ti[q][lane]; xl[q] = tl[q][lane]; xb[q] = tb[q][lane];
+                        if constexpr (CB) xc[q] = tc[q][lane];
+                        if constexpr (RB) xr[q] = tr[q][lane];
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++) {
+                        one(4 * q, xi[q].x, xl[q].x, xb[q].x, CB ? xc[CB ? q : 0].x : o.cut, RB ? xr[RB ? q : 0].x : o.res, ZF ? 0.0f : bn[4 * q]);
+                        one(4 * q + 1, xi[q].y, xl[q].y, xb[q].y, CB ? xc[CB ? q : 0].y : o.cut, RB ? xr[RB ? q : 0].y : o.res, ZF ? 0.0f : bn[4 * q + 1]);
+                        one(4 * q + 2, xi[q].z, xl[q].z, xb[q].z, CB ? xc[CB ? q : 0].z : o.cut, RB ? xr[RB ? q : 0].z : o.res, ZF ? 0.0f : bn[4 * q + 2]);
+                        one(4 * q + 3, xi[q].w, xl[q].w, xb[q].w, CB ? xc[CB ? q : 0].w : o.cut, RB ? xr[RB ? q : 0].w : o.res, ZF ? 0.0f : bn[4 * q + 3]);
+                    }
+                } else {
+                    for (uint32_t k = 0; k < nf; k++)
+                        one(k, at(ti, k), at(tl, k), at(tb, k), CB ? at(tc, k) : o.cut, RB ? at(tr, k) : o.res, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow));
+                }
+            }
+            if (!ZF && c >= 2 && frames(c - 2) == CH) {               // the output rows of the tile written at the next step
+                const zh_rsrc_t rn = zrow_rsrc(out.p, out.stride, start + (c - 2) * CH);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; k++) bn[k] = zrow_load<1>(rn, voff, k * orow);
+            }
+            __syncthreads();
+        }
+    }
+    if (live && role == 1) { l_io[v] = o.l; b_io[v] = o.b; }
+}
+
 __global__ void k_cutoff_from_frequency(uint32_t n, float *__restrict__ out, const float *__restrict__ freq, float sample_rate) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = zcutoff_from_frequency(freq[i], sample_rate);
@@ -1636,7 +1809,10 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
         if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut, res))
             return zh_launch_status();
     }
-    if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0])) {
+    // (a tile's 32 rows are addressed with 32-bit offsets from one descriptor: row strides up to 2^24 voices)
+    const bool tile_strides_ok = outputs[0].stride <= (1u << 24) && p->input.stride <= (1u << 24) && (!cb || p->cutoff.buffer.stride <= (1u << 24)) &&
+                                 (!rb || p->res.buffer.stride <= (1u << 24));
+    if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0]) && tile_strides_ok) {
         const dim3 grid((m->n + 63) / 64);
         if (m->n <= pc_max) {
             if (zf) hipLaunchKernelGGL((k_filter_pc<true, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
@@ -1646,6 +1822,27 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
             else hipLaunchKernelGGL((k_filter_pc<false, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
         }
         return zh_launch_status();
+    }
+    // control images at few voices: the same pipeline with the images' rows as tiles of their own (k_filter_pc_ctl; a cutoff sweep at
+    // 4,096 / 16,384 / 32,768 voices: 95.5 / 101.7 / 139.9 us as the one-wave walk, 46.8 / 48.9 / 98.4; 65,536: 160 against 195 --
+    // the walk).  ZH_FILTER_PC_CTL_MAX = largest voice count (0 = never).
+    {
+        const char *ce = zh_env("ZH_FILTER_PC_CTL_MAX");
+        const uint32_t ctl_max = ce ? (uint32_t)atoi(ce) : 32768u;
+        if ((cb || rb) && m->n <= ctl_max && end - start >= 64 && !bufs_alias(p->input, outputs[0]) && !cob_aliases(p->cutoff, outputs[0]) &&
+            !cob_aliases(p->res, outputs[0]) && tile_strides_ok) {
+            const dim3 grid((m->n + 63) / 64);
+#define ZH_FPCC(CH_, CB_, RB_)                                                                                       \
+            do {                                                                                                     \
+                if (zf) hipLaunchKernelGGL((k_filter_pc_ctl<true, CH_, CB_, RB_>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
+                else hipLaunchKernelGGL((k_filter_pc_ctl<false, CH_, CB_, RB_>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
+            } while (0)
+            if (cb && rb) ZH_FPCC(16, true, true);
+            else if (cb) ZH_FPCC(32, true, false);
+            else ZH_FPCC(32, false, true);
+#undef ZH_FPCC
+            return zh_launch_status();
+        }
     }
     if (cb && rb) ZH_FILTER(true, true);
     else if (cb) ZH_FILTER(true, false);
