@@ -412,10 +412,11 @@ def test_fuzz_osc_control_images(ctx, oracle, seed):
     util.assert_bitexact(mt_.state()["t"].astype(np.float32), np.array([x.t for x in ts], np.float32), "trisaw t")
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(8))
 def test_fuzz_filter_and_echoes(ctx, oracle, seed):
-    """Filter (every type, constant parameters = the three-wave pipeline, or a cutoff image = the one-wave walk; inputs with
-    huge and tiny samples) and FilteredEchoes (delays either side of the pipeline's 192-frame minimum) over random spans."""
+    """Filter (every type; constant parameters = the three-wave pipeline, a cutoff and / or a resonance image = the same pipeline with
+    the images' rows as tiles, k_filter_pc_ctl; spans under 64 frames = the one-wave walk; inputs with huge and tiny samples) and
+    FilteredEchoes (delays either side of the pipeline's 192-frame minimum) over random spans."""
     from zang_amd import modules as mod, zang
     rng = np.random.default_rng(9000 + seed)
     V = int(rng.choice([1, 3, 64, 70, 150]))
@@ -430,24 +431,27 @@ def test_fuzz_filter_and_echoes(ctx, oracle, seed):
         inp = rng.uniform(-1, 1, (V, F)).astype(np.float32)
         inp[rng.random((V, F)) < 0.01] *= np.float32(1e30)
         inp[rng.random((V, F)) < 0.01] *= np.float32(1e-30)
-        res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
         cut_image = rng.random() < 0.3
         cutoff = rng.uniform(-0.1, 1.1, (V, F) if cut_image else V).astype(np.float32)
+        res_image = seed >= 4 and rng.random() < 0.3                  # (seeds 0-3 keep the draws they had before round 4)
+        res = rng.uniform(-0.1, 1.1, (V, F) if res_image else V).astype(np.float32)
         ref = img.copy()
         if zf:
             ref[:, a:b] = 0.0
         with np.errstate(all="ignore"):
             for v in range(V):
                 L.zo_filter_paint(C.byref(fls[v]), a, b, oracle.fptr(ref[v]), oracle.fptr(inp[v]), ftype,
-                                  oracle.buffer(cutoff[v]) if cut_image else oracle.constant(cutoff[v]), oracle.constant(res[v]))
+                                  oracle.buffer(cutoff[v]) if cut_image else oracle.constant(cutoff[v]),
+                                  oracle.buffer(res[v]) if res_image else oracle.constant(res[v]))
         out = util.to_image(img)
         gc = zang.buffer(util.to_image(cutoff)) if cut_image else zang.constant(util.dev(cutoff))
-        m.paint(zang.Span(a, b), [out], [], False, m.Params(util.to_image(inp), ftype, gc, zang.constant(util.dev(res))), zero_first=zf)
+        gr = zang.buffer(util.to_image(res)) if res_image else zang.constant(util.dev(res))
+        m.paint(zang.Span(a, b), [out], [], False, m.Params(util.to_image(inp), ftype, gc, gr), zero_first=zf)
         ctx.sync()
         got = util.from_image(out)
         nan = np.isnan(ref)
         assert np.array_equal(np.isnan(got), nan), f"filter seed {seed} call {k}: NaN positions"
-        util.assert_bitexact(np.where(nan, np.float32(0), got), np.where(nan, np.float32(0), ref), f"filter seed {seed} call {k} V={V} span {(a, b)} zf={zf} type={ftype} image={cut_image}")
+        util.assert_bitexact(np.where(nan, np.float32(0), got), np.where(nan, np.float32(0), ref), f"filter seed {seed} call {k} V={V} span {(a, b)} zf={zf} type={ftype} images={cut_image, res_image}")
         img = np.where(nan, np.float32(0), ref)                       # (the next call adds onto finite values again)
         fl_l = np.array([f.l for f in fls], np.float32)
         if not np.all(np.isfinite(fl_l)) or not np.all(np.isfinite(np.array([f.b for f in fls], np.float32))):
