@@ -574,6 +574,94 @@ def test_pink_noise_tolerant(ctx, oracle, V, zero_first):
         util.assert_bitexact(gs["b"][idx].astype(np.float32), taps[idx], "the taps are never written back (Noise.zig:68)")
 
 
+@pytest.mark.parametrize("V,Fl", [(300, 2048), (300, 4096), (4096, 2048), (4096, 4096), (16384, 2304)])
+def test_pink_noise_tolerant_spans_longer_than_one_launch(ctx, oracle, V, Fl):
+    """a tolerant pink paint longer than one launch pair's reach (1,024 frames at 4,096 voices) is several
+    pieces, and the taps run over the WHOLE span (Noise.zig:55-68) -- every piece used to restart them from the module's stored
+    taps.  Two consecutive spans, non-zero stored taps, one voice crafted onto Random.float's second draw inside the second
+    piece (walked sequentially: bit-exact whole), generator states exact, stored taps untouched.  V = 16,384: chunks of 128
+    frames, whose 17th would have started beyond the jump tables."""
+    from zang_amd import modules as mod, zang
+    from tests.test_gpu_modules import _xoshiro_step_back
+    first = 9100
+    rng = np.random.default_rng(321)
+    L = oracle.lib()
+    idx = np.arange(V) if V <= 512 else np.unique(np.concatenate([np.arange(0, V, 97), [5, V - 1]]))
+    pos = {int(v): q for q, v in enumerate(idx)}
+    nzs = []
+    for v in idx:
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + int(v)); nzs.append(nz)
+    m = mod.Noise(V, ctx, first_seed=first)
+    st = m.state()
+    k_multi = Fl - 300                                                # a frame of the LAST piece
+    back = _xoshiro_step_back([0, int(rng.integers(1, 1 << 63)), int(rng.integers(1, 1 << 63)), 1 << 41], k_multi)
+    for i in range(4):
+        nzs[pos[5]].r[i] = back[i]
+    st["r"][5] = [int(x) for x in back]
+    taps = rng.uniform(-0.5, 0.5, (V, 7)).astype(np.float32)
+    for q, v in enumerate(idx):
+        for t in range(7):
+            nzs[q].b[t] = float(taps[v, t])
+    st["b"] = taps
+    m.set_state(st)
+    out0 = util.rng_buffers(15, V, Fl)
+    for n_span, (s, e) in enumerate([(0, Fl), (3, Fl - 1)]):
+        ref = out0[idx].copy()
+        ref[:, s:e] = 0.0
+        for q in range(len(idx)):
+            L.zo_noise_paint(C.byref(nzs[q]), s, e, oracle.fptr(ref[q]), 1)
+        out = util.to_image(out0)
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(m.pink), zero_first=True, tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)[idx]
+        tag = f"pink tolerant V={V} long span {(s, e)}"
+        util.assert_bitexact(got[:, :s], ref[:, :s], tag); util.assert_bitexact(got[:, e:], ref[:, e:], tag)
+        util.assert_peak_close(got, ref, tag, s=s, e=e)
+        for a in range(s, e, 512):                                    # ... and piece by piece: a restarted tap is O(1) of a piece's peak
+            util.assert_peak_close(got, ref, tag + f" frames {a}..", s=a, e=min(a + 512, e), rtol=4e-5)
+        if n_span == 0:
+            util.assert_bitexact(got[pos[5]], ref[pos[5]], tag + " multi-draw voice (sequential walk over every piece)")
+        gs = m.state()
+        assert [[int(x) for x in gs["r"][v]] for v in idx] == [list(n.r) for n in nzs], f"generator states after span {(s, e)}"
+        util.assert_bitexact(gs["b"][idx].astype(np.float32), taps[idx], "the taps are never written back (Noise.zig:68)")
+
+
+def test_noise_filter_tolerant_chunk_starts_stay_inside_the_jump_tables(ctx, oracle):
+    """16,384 voices = chunks of 128 frames; a piece of 2,144 frames had a 17th chunk whose jump table
+    (index 63) does not exist.  A 2,304-frame span against the oracle on a voice sample, generator states exact on all of them."""
+    from zang_amd import modules as mod, zang
+    V, Fl, first = 16384, 2304, 12000
+    rng = np.random.default_rng(77)
+    L = oracle.lib()
+    idx = np.unique(np.concatenate([np.arange(0, V, 131), [V - 1]]))
+    cutoff = np.array([L.zo_filter_cutoff_from_frequency(float(200.0 + 7800.0 * u), SR) for u in rng.random(V)], np.float32)
+    res = (0.9 * rng.random(V)).astype(np.float32)
+    m = mod.NoiseFilter(V, ctx, first_seed=first)
+    out = ctx.image(Fl, V, fill=0.0)
+    ref = np.zeros((len(idx), Fl), np.float32)
+    temp = np.zeros(Fl, np.float32)
+    nzs, fls = [], []
+    for q, v in enumerate(idx):
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + int(v)); nzs.append(nz)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+    for n_span, (s, e) in enumerate([(0, Fl), (10, Fl - 5)]):
+        for q, v in enumerate(idx):
+            ref[q, s:e] = 0.0
+            L.zo_zero(s, e, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nzs[q]), s, e, oracle.fptr(temp), 0)
+            L.zo_filter_paint(C.byref(fls[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(temp), 1, oracle.constant(cutoff[v]), oracle.constant(res[v]))
+        m.paint(zang.Span(s, e), [out], None, False, m.Params(0, 1, util.dev(cutoff), util.dev(res)), zero_first=True, tolerant=True)
+        ctx.sync()
+        got = util.from_image(out)[idx]
+        gs = m.state()
+        assert [[int(x) for x in gs["noise"]["r"][v]] for v in idx] == [list(n.r) for n in nzs], f"generator states after span {(s, e)}"
+        util.assert_peak_close(got, ref, f"noise_filter tolerant V={V} span {(s, e)}", s=s, e=e,
+                               scale_extra=np.maximum(np.abs([f.l for f in fls]), np.abs([f.b for f in fls])))
+        for q, v in enumerate(idx):                                   # the next span starts from the reference's filter state on both sides
+            gs["flt"]["l"][v] = fls[q].l; gs["flt"]["b"][v] = fls[q].b
+        m.set_state(gs)
+
+
 @pytest.mark.parametrize("V", [1000, 4096])
 def test_nice_mix_tolerant(ctx, oracle, V):
     """zh_nice_paint_mix / _stereo with the flag at few voices (k_nice_tp_a + k_nice_mix_tp_b) against the exact form of the same

@@ -2164,7 +2164,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             a.l = m->l; a.b = m->b; a.cs = m->tp_cs; a.e = m->tp_e; a.flag = m->tp_flag; a.tables = tables;
             a.V = m->n; a.L = L; a.out = out;
             a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
-            const uint32_t piece = min(kNfTpMaxChunks * L, (uint32_t)kNoiseJumpTables * 32u + L);   // chunk starts within the tables' reach
+            const uint32_t piece = min(kNfTpMaxChunks * L, ((uint32_t)kNoiseJumpTables * 32u / L) * L + L);   // chunk starts within the tables' reach: (C - 1) * L / 32 <= kNoiseJumpTables
             for (uint32_t s0 = start; s0 < end; s0 += piece) {
                 a.start = s0; a.end = min(s0 + piece, end);
                 a.C = (a.end - a.start + L - 1) / L;

@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
 struct PinkTpArgs {
     uint64_t *s[4];              // generator states: read by pass A, written once by pass B
     const float *b0;             // [7][V]: the module's taps at span start (Noise.zig:55 `var b = self.b`)
+    float *b_end;                // [7][V]: the taps after this launch's last frame (the next piece of the same span starts from them)
     uint64_t *cs;                // scratch [C][4][V]: generator state at the start of chunk j
     float *e;                    // scratch [C][7][V]: chunk j's zero-state tap values after its last frame, and its b[6] (exact)
     uint32_t *flag;              // scratch [V]: == serial when a multi-draw sample was seen in this paint
@@ -508,7 +509,11 @@ __global__ void __launch_bounds__(256) k_pink_tp_b(const PinkTpArgs a) {
         const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
         for (uint32_t k = 0; c0 + k < f1; k++) frame(ro, k, ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow), !flagged);
     }
-    if (!flagged && f1 == a.end && f1 > f0) { a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3; }   // Noise.zig:71 (:68: not the taps)
+    if (!flagged && f1 == a.end && f1 > f0) {                         // Noise.zig:71 (:68: the MODULE's taps stay as they were)
+        a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
+#pragma unroll
+        for (int q = 0; q < 7; q++) a.b_end[(size_t)q * V + v] = b[q];
+    }
     if (j == 0 && __builtin_amdgcn_ballot_w64(flagged) != 0) {        // a multi-draw voice: the reference's own walk over the whole span
         if (flagged) {
             r = ZXoshiro{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
@@ -519,6 +524,8 @@ __global__ void __launch_bounds__(256) k_pink_tp_b(const PinkTpArgs a) {
                 frame(ro, 0, ZF ? 0.0f : zrow_load<1>(ro, voff, 0), true);
             }
             a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
+#pragma unroll
+            for (int q = 0; q < 7; q++) a.b_end[(size_t)q * V + v] = b[q];
         }
     }
 }

@@ -132,6 +132,7 @@ struct zh_noise {
     uint32_t *err;               // k_pink_pipe: a ring wait ran into its bound (never in a correct run; reported by get_state)
     // ZH_PAINT_TOLERANT pink noise (filter_tp.hip.h k_pink_tp_a / _b): scratch, allocated by the first tolerant paint outside a capture
     uint64_t *tp_cs; float *tp_e; uint32_t *tp_flag; uint32_t tp_serial;
+    float *tp_taps;              // [2][7][n]: the taps a tolerant pink paint's piece ends on, read by the span's next piece (Noise.zig:55: `var b` runs over the whole span)
 };
 // noise_jump.hip
 uint32_t zh_noise_range_frames(uint32_t V, uint32_t n);
@@ -1448,14 +1449,14 @@ static void noise_free(zh_noise *m) {
     for (auto &x : m->s) (void)hipFree(x);
     for (auto &x : m->nx) (void)hipFree(x);
     (void)hipFree(m->b); (void)hipFree(m->flag); (void)hipFree(m->scratch.ptr); (void)hipFree(m->err);
-    (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag);
+    (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); (void)hipFree(m->tp_taps);
 }
 int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     zh_noise *m = new (std::nothrow) zh_noise();
     if (!m) return ZH_ERR_INVALID;
     m->ctx = ctx; m->n = n; m->b = nullptr; m->flag = nullptr; m->err = nullptr;
-    m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; m->tp_serial = 0;
+    m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; m->tp_serial = 0; m->tp_taps = nullptr;
     for (int i = 0; i < 4; i++) m->s[i] = m->nx[i] = nullptr;
     memset(&m->scratch, 0, sizeof m->scratch);
     int rc = 0;
@@ -1529,8 +1530,9 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
             int arc = dev_alloc(&m->tp_cs, (size_t)kTpMaxChunks * 4 * m->n);
             if (!arc) arc = dev_alloc(&m->tp_e, (size_t)kTpMaxChunks * 7 * m->n);
             if (!arc) arc = dev_alloc(&m->tp_flag, m->n);
+            if (!arc) arc = dev_alloc(&m->tp_taps, (size_t)2 * 7 * m->n);
             if (!arc) arc = (int)hipMemsetAsync(m->tp_flag, 0, (size_t)m->n * 4, st);
-            if (arc) { (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; (void)hipGetLastError(); }
+            if (arc) { (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); (void)hipFree(m->tp_taps); m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; m->tp_taps = nullptr; (void)hipGetLastError(); }
         }
         if (tables && m->tp_cs) {
             const uint32_t L = 32u * max(1u, 32u / Cw);
@@ -1538,9 +1540,14 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
             for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
             a.b0 = m->b; a.cs = m->tp_cs; a.e = m->tp_e; a.flag = m->tp_flag; a.tables = tables;
             a.V = m->n; a.L = L; a.out = mk_img(outputs[0]);
-            const uint32_t piece = min(kTpMaxChunks * L, (uint32_t)kNoiseJumpTables * 32u + L);
-            for (uint32_t s0 = start; s0 < end; s0 += piece) {
+            const uint32_t piece = min(kTpMaxChunks * L, ((uint32_t)kNoiseJumpTables * 32u / L) * L + L);   // (C - 1) * L / 32 <= kNoiseJumpTables
+            // The taps run over the WHOLE span (Noise.zig:55-68) and are never stored in the module: a piece leaves the taps it ends
+            // on in tp_taps[piece & 1] and the next piece starts from them (every piece used to restart from m->b).
+            uint32_t pc = 0;
+            for (uint32_t s0 = start; s0 < end; s0 += piece, pc++) {
                 a.start = s0; a.end = min(s0 + piece, end);
+                a.b0 = pc == 0 ? m->b : m->tp_taps + (size_t)((pc - 1) & 1u) * 7 * m->n;
+                a.b_end = m->tp_taps + (size_t)(pc & 1u) * 7 * m->n;
                 a.C = (a.end - a.start + L - 1) / L;
                 if (++m->tp_serial == 0) m->tp_serial = 1;
                 a.serial = m->tp_serial;
