@@ -868,6 +868,7 @@ def main():
             # hipGraph and replayed.
             self.G = wl.graph_steps(steps) if not args.eager else 0
             self.graph = None
+            self.graph_nodes, self.graph_lanes = 0, 1
             if self.G:
                 for _ in range(self.G):          # one eager pass first: lazy allocations happen outside capture
                     wl.step()
@@ -875,7 +876,11 @@ def main():
                 if hasattr(wl, "nsteps"):
                     wl.nsteps = 0               # the graph holds buffers 0..G-1 of the note pattern
                 wl.batch_rows = min(self.G, 48)
-                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)])
+                # pulseosc: ZH_CAPTURE_CONCURRENT -- the steps' paints (params unchanged: the phase at any frame is the entry counter +
+                # frames * ifreq exactly, PulseOsc.zig:111) are recorded as parallel branches on the context's stream and two forked
+                # ones, plus one node that publishes the advanced counters; every step stays its own launch of one buffer
+                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], concurrent=(name == "pulseosc" and os.environ.get("ZH_BENCH_IN_ORDER") != "1"))
+                self.graph_nodes, self.graph_lanes = self.graph.info()
             # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
             # refuses events recorded by graph nodes on this ROCm: "invalid resource handle", profiles/r04/probe_region.txt)
             self.ev0, self.ev1 = make_event(), make_event()
@@ -1039,7 +1044,11 @@ def main():
                                (f"fused Osc+Env+Filter voices + {args.channels}-channel voice mixdown per {F}-frame buffer, 48 kHz (BASELINE configs[4])" if mixdown
                                 else f"zero+paint per {F}-frame buffer, 48 kHz"),
                    "voices_per_gpu": V, "total_voices": V * world, "frames": F, "ring_images": wl.nring,
-                   "launch": "eager" if graph is None else f"hipGraph x{G} steps", "parallelism": f"voices sharded x{world}"},
+                   "launch": "eager" if graph is None else (f"hipGraph x{G} steps" + (
+                       f" recorded with ZH_CAPTURE_CONCURRENT: one kernel node per step on {main_run.graph_lanes} parallel branches (the context's stream + "
+                       f"{main_run.graph_lanes - 1} forked) + 1 node that publishes the phase counters; {main_run.graph_nodes} nodes" if main_run.graph_lanes > 1
+                       else f" in recorded order ({main_run.graph_nodes} nodes)")),
+                   "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": wl.kernel,
                      "frac_of_measured_store_rate": achieved / HBM_STORE_GBS,   # also quote / 6200 "achievable"

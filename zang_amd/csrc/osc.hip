@@ -115,6 +115,8 @@ struct OscArgs {
     uint32_t *cnt_out;
     uint32_t *tab;               // [KW + 1][V] or nullptr
     uint32_t V, start, end, fc, stride, nb, prio;
+    uint32_t fbase0;             // frames this module painted earlier in the same capture epoch (cnt_in is the epoch-entry counter)
+    uint32_t publish;            // 0: a lane paint of a concurrent capture -- cnt_out is left alone (k_osc_publish advances it once)
     float srf, sr8;
     F32P freq, color;
     float *img[kOscMaxBatch];
@@ -198,11 +200,11 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     const uint32_t nfr = end - start;
     const uint32_t c0 = start + chunk * fc;
     const uint32_t c1 = min(c0 + fc, end);
-    const uint32_t fbase = blockIdx.z * nfr + (c0 - start);               // frames painted before this chunk, batch-wide
+    const uint32_t fbase = a.fbase0 + blockIdx.z * nfr + (c0 - start);    // frames painted before this chunk: epoch- and batch-wide
     typename OSC::R roll[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { cnt[j] = cnt0[j] + fbase * k[j].ifreq; roll[j] = OSC::roll_init(k[j], cnt[j]); }
-    if (chunk == 0 && blockIdx.z == 0) {
+    if (chunk == 0 && blockIdx.z == 0 && a.publish) {
         const uint32_t total = a.nb * nfr;
         uint4 o;
         o.x = bad[0] ? cnt0[0] : cnt0[0] + total * k[0].ifreq;
@@ -421,6 +423,23 @@ __global__ void __launch_bounds__(256) k_commit_f32(float *__restrict__ dst, con
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
+// The one node that ends an epoch of a ZH_CAPTURE_CONCURRENT capture (ctx.hip zh_lanes_barrier) for an oscillator whose
+// table-form paints were recorded as parallel branches: cnt += frames * ifreq for every voice in range (a voice with a bad
+// frequency neither paints nor advances, PulseOsc.zig:82-84 / TriSawOsc.zig:84-86), in place -- every branch has been joined.
+__global__ void __launch_bounds__(256) k_osc_publish(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tab, uint32_t V, uint32_t ifreq_word,
+                                                     uint32_t bad_word, uint32_t frames) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const uint32_t ifreq = tab[(size_t)ifreq_word * V + v];
+    if (tab[(size_t)bad_word * V + v] == 0) cnt[v] += frames * ifreq;
+}
+template <class OSC, class M> static void osc_publish(zh_flipper *f, uint32_t frames, hipStream_t st) {
+    M *m = static_cast<M *>(f);
+    using K = typename OSC::K;
+    hipLaunchKernelGGL(k_osc_publish, dim3((m->n + 255) / 256), dim3(256), 0, st, m->cnt[m->cur], m->tab.words, m->n,
+                       (uint32_t)(offsetof(K, ifreq) / 4), (uint32_t)(sizeof(K) / 4), frames);
+}
+
 // Frames per lane for the chunked kernels.  PulseOsc, measured (tools/sweep_osc_fc.sh, 1024-frame images): 4 frames per
 // lane is the best or within 5 % of the best at every voice count from 4,096 to 1 Mi and 11-15 % better than 64 between
 // 65,536 and 524,288 voices (short waves interleave their ALU and store phases better, and the blocks sweep the image in
@@ -496,8 +515,25 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
         for (uint32_t b0 = 0; b0 < nb; b0 += kOscMaxBatch) {
             const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
+            // A table-form paint of a ZH_CAPTURE_CONCURRENT capture depends on nothing recorded before it: it reads the counters the
+            // epoch opened on plus the frames this module has painted since, is recorded on one of the capture's lanes, and leaves
+            // the counters alone (k_osc_publish advances them once, when the epoch ends).  No flip.
+            hipStream_t lane = nullptr;
+            if (use_tab && ctx->capturing) {
+                const float *lo = outs[b0].ptr, *hi = outs[b0].ptr;
+                for (uint32_t b = 0; b < cnt_b; b++) {
+                    const float *p0 = outs[b0 + b].ptr + (size_t)start * outs[b0 + b].stride, *p1 = outs[b0 + b].ptr + (size_t)end * outs[b0 + b].stride;
+                    if (b == 0 || p0 < lo) lo = p0;
+                    if (b == 0 || p1 > hi) hi = p1;
+                }
+                lane = zh_lanes_pick(ctx, lo, hi);
+            }
+            if (!lane && ctx->epoch_open) zh_lanes_barrier(ctx);     // an ordered paint of this module: after the lanes, from published counters
+            if (lane) st = lane;
             OscArgs a;
             a.cnt_in = m->cnt[m->cur]; a.cnt_out = m->cnt[m->cur ^ 1];
+            a.fbase0 = lane ? zh_lanes_frames(ctx, m) : 0u;
+            a.publish = lane ? 0u : 1u;
             // A recorded table-form paint reads the table at every replay, so once one has been captured nothing rewrites the
             // table any more (an eager setup-form paint with other params between replays used to: the replays then rendered with
             // THOSE constants): later unflagged paints compute their constants without storing them, and the host-side record is
@@ -522,11 +558,17 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
 #undef ZH_LAUNCH_O4B
             // the setup form stored this call's constants (ordered before any later paint on the stream)
             if (!use_tab && a.tab) { m->tab.valid = true; m->tab.sample_rate = sample_rate; m->tab.freq = freq; m->tab.color = color; }
+            if (lane) {
+                zh_lanes_painted(ctx, m, cnt_b * (end - start), &osc_publish<OSC, M>);
+                st = ctx->stream;
+                continue;
+            }
             // the batch advanced the state like cnt_b paints in a row but wrote it once, into the other buffer
             zh_flipper_painted(m);
             m->cur ^= 1;
         }
     } else {
+        if (ctx->epoch_open) zh_lanes_barrier(ctx);
         dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
         for (uint32_t b = 0; b < nb; b++) {
             const uint32_t *ci = m->cnt[m->cur];
@@ -605,6 +647,7 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
     if (p->freq.tag == ZH_COB_CONSTANT) {
         launch_osc_const<PulseOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
+        if (m->ctx->epoch_open) zh_lanes_barrier(m->ctx);
         const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:122
         const float sr8 = p->sample_rate / 8.0f;              // :134
         const F32P col = mk_f32(p->color);
@@ -632,12 +675,12 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
     return zh_launch_status();
 }
 int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                             // PulseOsc.zig:52-53
     return pulseosc_paint_n(m, start, end, outputs, 1, p, flags);
 }
 int zh_pulseosc_paint_batch(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t n_buffers,
-                            const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+                            const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
     return pulseosc_paint_n(m, start, end, outputs, n_buffers, p, flags);
 }
 
@@ -695,6 +738,7 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
     if (p->freq.tag == ZH_COB_CONSTANT) {
         launch_osc_const<TriSawOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
+        if (m->ctx->epoch_open) zh_lanes_barrier(m->ctx);
         bool aliased = false;
         for (uint32_t b = 0; b < nb; b++) aliased = aliased || bufs_alias(p->freq.buffer, outputs[b]);
         // 4,096 voices: 106.6 us with per-lane branches in the waveform, 71.3 straight-line, 46.4 as 16 frame ranges (8 / 32 /
@@ -735,12 +779,12 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
     return zh_launch_status();
 }
 int zh_trisawosc_paint(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                             // TriSawOsc.zig:54-55
     return trisawosc_paint_n(m, start, end, outputs, 1, p, flags);
 }
 int zh_trisawosc_paint_batch(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t n_buffers,
-                             const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+                             const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
     return trisawosc_paint_n(m, start, end, outputs, n_buffers, p, flags);
 }
 

@@ -45,9 +45,11 @@ class Context:
             self.lib.zh_destroy(self.handle)
             self.handle = None
 
-    def capture(self, fn):
-        """Record everything fn() enqueues on this context into a hipGraph; returns a Graph."""
-        abi.check(self.lib.zh_graph_begin_capture(self.handle), "zh_graph_begin_capture")
+    def capture(self, fn, concurrent=False):
+        """Record everything fn() enqueues on this context into a hipGraph; returns a Graph.  `concurrent`:
+        ZH_CAPTURE_CONCURRENT -- nothing but calls on this context touches its stream inside fn(), and the library may record
+        independent paints as parallel branches (include/zang_hip.h)."""
+        abi.check(self.lib.zh_graph_begin_capture_flags(self.handle, abi.ZH_CAPTURE_CONCURRENT if concurrent else 0), "zh_graph_begin_capture_flags")
         g = C.c_void_p()
         try:
             fn()
@@ -83,6 +85,12 @@ class Graph:
 
     def launch(self):
         abi.check(self.ctx.lib.zh_graph_launch(self.ctx.handle, self.handle), "zh_graph_launch")
+
+    def info(self):
+        """(nodes in the recorded graph, streams its paints were spread over)"""
+        n, l = C.c_uint32(), C.c_uint32()
+        abi.check(self.ctx.lib.zh_graph_info(self.handle, C.byref(n), C.byref(l)), "zh_graph_info")
+        return n.value, l.value
 
     def close(self):
         if self.handle:
