@@ -854,7 +854,7 @@ def main():
         `region(K)` = exactly K steps bracketed by barrier + synchronize on both sides, timed by the wall clock
         (max over ranks) and by HIP events on the launch stream."""
 
-        def __init__(self, name, voices, steps, exchange="rccl", slots=False):
+        def __init__(self, name, voices, steps, exchange="rccl", slots=False, coalesce=None):
             self.wl = Workload(name, ctx, voices, F, first_voice=rank * voices, ring_bytes=args.ring_mib << 20, world=world, multi=dist_on,
                                pad=args.pad_voices, channels=args.channels, exchange=exchange, tolerant=args.tolerant)
             wl = self.wl
@@ -868,7 +868,7 @@ def main():
             # hipGraph and replayed.
             self.G = wl.graph_steps(steps) if not args.eager else 0
             self.graph = None
-            self.graph_nodes, self.graph_lanes = 0, 1
+            self.graph_nodes, self.graph_held, self.graph_launches = 0, 0, 0
             if self.G:
                 for _ in range(self.G):          # one eager pass first: lazy allocations happen outside capture
                     wl.step()
@@ -876,11 +876,12 @@ def main():
                 if hasattr(wl, "nsteps"):
                     wl.nsteps = 0               # the graph holds buffers 0..G-1 of the note pattern
                 wl.batch_rows = min(self.G, 48)
-                # pulseosc: ZH_CAPTURE_CONCURRENT -- the steps' paints (params unchanged: the phase at any frame is the entry counter +
-                # frames * ifreq exactly, PulseOsc.zig:111) are recorded as parallel branches on the context's stream and two forked
-                # ones, plus one node that publishes the advanced counters; every step stays its own launch of one buffer
-                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], concurrent=(name == "pulseosc" and os.environ.get("ZH_BENCH_IN_ORDER") != "1"))
-                self.graph_nodes, self.graph_lanes = self.graph.info()
+                # pulseosc: ZH_CAPTURE_COALESCE -- the steps' paints (params unchanged: the phase at any frame is the entry counter +
+                # frames * ifreq exactly, PulseOsc.zig:111) are held back while recording and become one launch per 32 buffers, plus
+                # one node that publishes the advanced counters.  The step is still one zero+paint CALL per buffer; what the graph
+                # replays is fewer, larger launches (ZH_BENCH_IN_ORDER=1: one kernel node per step, the round-4 form)
+                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=((name == "pulseosc" and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
+                self.graph_nodes, self.graph_held, self.graph_launches = self.graph.info()
             # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
             # refuses events recorded by graph nodes on this ROCm: "invalid resource handle", profiles/r04/probe_region.txt)
             self.ev0, self.ev1 = make_event(), make_event()
@@ -1035,6 +1036,10 @@ def main():
     total_units = world * V * F * K
     value = total_units / elapsed
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
+    # kernel launches of the dominant kernel inside the timed region (a coalesced graph replays fewer, larger launches)
+    launches = K
+    if graph is not None and main_run.graph_held and K % G == 0:
+        launches = (K // G) * main_run.graph_launches
     out = {
         "metric": "voice-samples/sec", "value": value, "unit": "voice-samples/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "rehearsal_regions": rehearsals,
@@ -1045,14 +1050,15 @@ def main():
                                 else f"zero+paint per {F}-frame buffer, 48 kHz"),
                    "voices_per_gpu": V, "total_voices": V * world, "frames": F, "ring_images": wl.nring,
                    "launch": "eager" if graph is None else (f"hipGraph x{G} steps" + (
-                       f" recorded with ZH_CAPTURE_CONCURRENT: one kernel node per step on {main_run.graph_lanes} parallel branches (the context's stream + "
-                       f"{main_run.graph_lanes - 1} forked) + 1 node that publishes the phase counters; {main_run.graph_nodes} nodes" if main_run.graph_lanes > 1
-                       else f" in recorded order ({main_run.graph_nodes} nodes)")),
+                       f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launch(es) of up to 32 "
+                       f"buffers each (grid.z) + 1 node that publishes the phase counters; {main_run.graph_nodes} nodes" if main_run.graph_held
+                       else f" in recorded order, one kernel node per step ({main_run.graph_nodes} nodes)")),
                    "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": wl.kernel,
                      "frac_of_measured_store_rate": achieved / HBM_STORE_GBS,   # also quote / 6200 "achievable"
-                     "algorithmic_bytes_per_launch": wl.bytes_per_step, "launch_ms_hip_events": step_ms_events,
+                     "algorithmic_bytes_per_launch": wl.bytes_per_step * K / launches, "launch_ms_hip_events": ev_ms / launches,
+                     "launches_in_region": launches, "buffers_per_launch": K / launches,
                      "rocprofv3_kernel_average": rocprof_record(args, V)},
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }
@@ -1174,35 +1180,20 @@ def main():
         if bt:
             out["batched_launches"] = bt
 
-    if world == 1 and args.workload == "pulseosc" and not args.eager:
-        # The same buffers painted through zh_pulseosc_paint_batch: B consecutive 1024-frame paints (same span and params,
-        # buffer b into its own image) as ONE launch -- the phase of any frame is cnt + frames_before * ifreq exactly, so the
-        # buffers of a batch are independent and share one launch's ramp and tail.  Extra key only: a step of `value` stays
-        # one buffer per launch.
-        B = 8
-        nb_steps = max(B, (K // B) * B)
-        imgs = [wl.ring[i % wl.nring] for i in range(nb_steps)]
-        def batch_steps():
-            for i in range(0, nb_steps, B):
-                wl.m.paint_batch(wl.span, imgs[i:i + B], wl.params, zero_first=True, params_unchanged=True)
-        batch_steps()
-        torch.cuda.synchronize()
-        bgraph = ctx.capture(batch_steps)
-        bgraph.launch(); torch.cuda.synchronize()
-        e0, e1 = make_event(), make_event()
-        abi.check(lib.zh_event_record(ctx.handle, e0), "zh_event_record")
-        bgraph.launch()
-        abi.check(lib.zh_event_record(ctx.handle, e1), "zh_event_record")
-        torch.cuda.synchronize()
-        bms = C.c_float()
-        abi.check(lib.zh_event_elapsed_ms(e0, e1, C.byref(bms)), "zh_event_elapsed_ms")
-        per_buf = bms.value / nb_steps
-        out["batched_launches"] = {"buffers_per_launch": B, "buffers": nb_steps, "ms_per_buffer_hip_events": per_buf,
-                                   "achieved_GBs": wl.bytes_per_step / (per_buf * 1e-3) / 1e9,
-                                   "frac": wl.bytes_per_step / (per_buf * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "what": "zh_pulseosc_paint_batch: 8 consecutive buffers per launch (same results, state after the last)"}
-        lib.zh_event_destroy(e0); lib.zh_event_destroy(e1)
-        bgraph.close()
+    if world == 1 and args.workload == "pulseosc" and not args.eager and main_run.graph_held:
+        # The same K steps recorded WITHOUT ZH_CAPTURE_COALESCE: one kernel node per step, each a launch of one 16 MiB buffer that
+        # hands its phase counters to the next (the round-4 headline form).  Extra key, measured the same way as `value`.
+        io = Runner("pulseosc", V, K, coalesce=False)
+        io.warm(args.warmup)
+        rehearse(io, K)
+        io_regs = [io.region(K) for _ in range(1 + min(R, 10))]
+        e_io, m_io = io_regs[0]
+        out["one_launch_per_step"] = {"value": V * F * K / e_io, "ms_per_step": e_io / K * 1e3, "launch_ms_hip_events": m_io / K,
+                                      "frac": wl.bytes_per_step / (m_io / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "ms_per_step_wall": spread([e / K * 1e3 for e, _ in io_regs]), "regions": len(io_regs),
+                                      "launch": f"hipGraph x{io.G} steps in recorded order, one kernel node per step ({io.graph_nodes} nodes)",
+                                      "what": "the same steps recorded without ZH_CAPTURE_COALESCE (`value` of rounds 1-4 was this form)"}
+        io.close()
 
     if world == 1 and not args.no_config5 and args.workload == "pulseosc" and V == 4096:
         # the 1-GPU shard of config 5 (what every rank of the N>1 run renders), for the scaling ratio

@@ -145,21 +145,24 @@ ZH_API int  zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t
  * context that one holder of its retired scratch blocks is gone), as with the modules. */
 typedef struct zh_graph zh_graph;
 ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
-/* The same with flags.  ZH_CAPTURE_CONCURRENT: the host states that while this capture records, NOTHING but zh_* calls on this
- * context is enqueued on the context's stream.  The library may then record paints that depend on nothing recorded before
- * them as parallel branches of the graph instead of a chain: today the constant-frequency zh_pulseosc_paint /
- * zh_trisawosc_paint (and their _batch forms) flagged ZH_PAINT_PARAMS_UNCHANGED -- the reference's loop
- * examples/write_wav.zig:58-66 painting buffer after buffer with unchanged params.  Their phase counter at any frame is the
- * counter at capture entry + frames painted since * ifreq EXACTLY (`cnt +%= ifreq`, PulseOsc.zig:111, TriSawOsc.zig:115), so
- * no paint needs the counters the previous one left: they are recorded round-robin on up to three streams forked from the
- * context's (images that overlap an earlier paint's keep the recorded order), and ONE small node publishes the advanced
- * counters when something else is recorded or the capture ends.  Replays give the same bits as a capture without the flag;
- * what changes is that the ramps and tails of consecutive paints overlap.  Every other call joins the branches first and is
- * recorded in order as before.  (ZH_CAPTURE_LANES=1..4 in the environment overrides the number of streams; 1 = in order.) */
-enum { ZH_CAPTURE_CONCURRENT = 1 };
+/* The same with flags.  ZH_CAPTURE_COALESCE: the host states that while this capture records, NOTHING but zh_* calls on this
+ * context is enqueued on the context's stream.  The library may then hold back paints that depend on nothing recorded before
+ * them and record several as one launch: today the constant-frequency zh_pulseosc_paint / zh_trisawosc_paint (and their
+ * _batch forms) flagged ZH_PAINT_PARAMS_UNCHANGED -- the reference's loop examples/write_wav.zig:58-66 painting buffer
+ * after buffer with unchanged params.  Their phase counter at any frame is the counter at capture entry + frames painted
+ * since * ifreq EXACTLY (`cnt +%= ifreq`, PulseOsc.zig:111, TriSawOsc.zig:115), so no paint needs the counters the previous
+ * one left: consecutive paints of one module over the same span into images that do not overlap are recorded as ONE
+ * launch of up to 32 buffers (the form zh_pulseosc_paint_batch launches), and one small node publishes the advanced
+ * counters when something else is recorded or the capture ends.  Replays give the same bits as a capture without the
+ * flag; what changes is that one launch's ramp and tail are shared by the buffers.  Every other call first records what was
+ * held back, then itself, in order as before.
+ * (Measured and rejected, profiles/r05/ab_capture_lanes.txt + ubench_launch_overlap.txt: the same paints as parallel graph
+ * branches on 2-4 forked streams -- kernels from different queues slow each other down, 5.0-5.6 against 4.5 us per buffer.) */
+enum { ZH_CAPTURE_COALESCE = 1 };
 ZH_API int  zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags);
-/* how a graph was recorded: kernel / memcpy / event nodes in it, and the streams its paints were spread over (1 = a chain) */
-ZH_API int  zh_graph_info(const zh_graph *graph, uint32_t *nodes, uint32_t *lanes);
+/* how a graph was recorded: nodes in it; paint calls that were held back while recording and the launches they became
+ * (both 0 without ZH_CAPTURE_COALESCE) */
+ZH_API int  zh_graph_info(const zh_graph *graph, uint32_t *nodes, uint32_t *paints_held, uint32_t *launches_of_held);
 ZH_API int  zh_graph_end_capture(zh_ctx *ctx, zh_graph **out);
 ZH_API int  zh_graph_launch(zh_ctx *ctx, zh_graph *graph);
 ZH_API int  zh_graph_destroy(zh_graph *graph);

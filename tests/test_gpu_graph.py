@@ -375,107 +375,101 @@ def test_graph_with_params_unchanged_paint_keeps_its_constants(ctx):
 
 
 @pytest.mark.parametrize("kind", ["pulse", "trisaw"])
-@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
-def test_concurrent_capture_equals_eager(ctx, kind, lanes):
-    """ZH_CAPTURE_CONCURRENT: table-form oscillator paints recorded as parallel branches -- each reads the
-    counters the capture entered on plus its own frame offset, one node publishes the advanced counters at the end -- against the
-    same calls made eagerly on a twin module.  The recorded sequence mixes: spans of different lengths, an image painted twice
-    (ZERO_FIRST then `+=`: must keep the recorded order), two images painted by two modules, a paint WITHOUT the flag in the
-    middle (ends the epoch: joined, published, recorded in order), another library call on the stream (zero: a join too), and an odd
-    number of flips.  Replayed three times with eager paints between replays; bits and carried state equal after each."""
-    import os
+def test_coalescing_capture_equals_eager(ctx, kind):
+    """ZH_CAPTURE_COALESCE: table-form oscillator paints are held back while recording and consecutive ones
+    become one launch of several buffers -- each buffer reads the counters the capture entered on plus its own frame offset,
+    one node publishes the advanced counters at the end -- against the same calls made eagerly on a twin module.  The recorded
+    sequence mixes: spans of different lengths (a new launch each), an image painted twice (ZERO_FIRST then `+=` by another
+    module: must keep the recorded order), a paint WITHOUT the flag in the middle (ends the epoch: launched, published,
+    recorded in order), another library call on the stream (zero: ends the epoch too), a run of equal spans (merged), a _batch
+    call, voices with a bad frequency, and an odd number of flips.  Replayed three times with eager paints between replays;
+    bits and carried state equal after each."""
     import torch
     import zang_amd
     from zang_amd import modules as mod, zang, workloads
-    V, N = 2048, 7
+    V, N = 2048, 9
     freq, color, u2, _ = workloads.voice_params(2, 0, V)
     freq[3] = -5.0; freq[700] = 9000.0                       # voices out of range: silent, counters not advanced
-    old = os.environ.get("ZH_CAPTURE_LANES")
-    os.environ["ZH_CAPTURE_LANES"] = str(lanes)
-    side = torch.cuda.Stream()
-    try:
-        with torch.cuda.stream(side):
-            c2 = zang_amd.Context(0)
-            fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
-            fr2 = torch.from_numpy((freq * (1.0 + u2)).astype(np.float32)).cuda()
-            Osc = mod.PulseOsc if kind == "pulse" else mod.TriSawOsc
-            sets = []
-            for _ in range(2):
-                sets.append({"a": Osc(V, c2), "b": Osc(V, c2), "img": [c2.image(F, V, fill=0.25) for _ in range(N)]})
-            spans = [zang.Span(0, F), zang.Span(0, 512), zang.Span(512, F), zang.Span(4, 1000), zang.Span(0, F), zang.Span(0, F), zang.Span(100, 104)]
-
-            def seq(s, flagged):
-                a, b, img = s["a"], s["b"], s["img"]
-                Pa = a.Params(SR, zang.constant(fr), col); Pb = b.Params(SR, zang.constant(fr2), col)
-                for i in range(N):
-                    a.paint(spans[i], [img[i]], [], False, Pa, zero_first=True, params_unchanged=flagged)
-                    if i % 2 == 0:
-                        b.paint(spans[i], [img[i]], [], False, Pb, zero_first=False, params_unchanged=flagged)     # += onto a's image
-                    if i == 3:
-                        a.paint(zang.Span(0, 300), [img[0]], [], False, Pa, zero_first=False, params_unchanged=False)   # setup form: ordered
-                    if i == 4:
-                        zang.zero(zang.Span(0, 64), img[1], c2)
-                a.paint_batch(zang.Span(0, F), [img[5], img[6]], Pa, zero_first=True, params_unchanged=flagged)
-
-            e, g_ = sets
-            seq(e, False); seq(g_, False)                    # unflagged first: the tables are stored
-            c2.sync()
-            graph = c2.capture(lambda: seq(g_, True), concurrent=True)
-            nodes, got_lanes = graph.info()
-            assert got_lanes == lanes and nodes >= 2 * N
-            for rep in range(3):
-                seq(e, True); graph.launch()
-                if rep == 1:                                  # eager paints between replays (flip the double buffers)
-                    for s in (e, g_):
-                        s["a"].paint(zang.Span(0, 77), [s["img"][2]], [], False, s["a"].Params(SR, zang.constant(fr), col), zero_first=True)
-                c2.sync()
-                for x, y in zip(e["img"], g_["img"]):
-                    assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (rep, lanes)
-                for k in ("a", "b"):
-                    assert np.asarray(e[k].state()).tobytes() == np.asarray(g_[k].state()).tobytes(), (rep, k)
-            graph.close(); c2.close()
-    finally:
-        if old is None:
-            os.environ.pop("ZH_CAPTURE_LANES", None)
-        else:
-            os.environ["ZH_CAPTURE_LANES"] = old
-
-
-def test_concurrent_capture_of_the_bench_step_matches_oracle(ctx, oracle):
-    """bench.py's pulseosc graph as it is recorded now (20 zero+paint steps over distinct ring images, concurrent capture):
-    after three replays every image of the ring equals the oracle's buffer of that step, and the carried counters equal the
-    oracle's -- on every 8th voice."""
-    import torch
-    import zang_amd
-    from zang_amd import modules as mod, zang, workloads
-    V, K = 4096, 20
-    freq, color, _, _ = workloads.voice_params(2, 0, V)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         c2 = zang_amd.Context(0)
-        m = mod.PulseOsc(V, c2)
         fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
-        ring = [c2.image(F, V) for _ in range(K)]
-        sp = zang.Span(0, F)
-        P = m.Params(SR, zang.constant(fr), col)
-        m.paint(sp, [ring[0]], [], False, P, zero_first=True)                    # stores the constants
+        fr2 = torch.from_numpy((freq * (1.0 + u2)).astype(np.float32)).cuda()
+        Osc = mod.PulseOsc if kind == "pulse" else mod.TriSawOsc
+        sets = []
+        for _ in range(2):
+            sets.append({"a": Osc(V, c2), "b": Osc(V, c2), "img": [c2.image(F, V, fill=0.25) for _ in range(N)]})
+        spans = [zang.Span(0, F), zang.Span(0, 512), zang.Span(512, F), zang.Span(4, 1000), zang.Span(0, F), zang.Span(0, F), zang.Span(0, F), zang.Span(0, F), zang.Span(100, 104)]
+
+        def seq(s, flagged):
+            a, b, img = s["a"], s["b"], s["img"]
+            Pa = a.Params(SR, zang.constant(fr), col); Pb = b.Params(SR, zang.constant(fr2), col)
+            for i in range(N):
+                a.paint(spans[i], [img[i]], [], False, Pa, zero_first=True, params_unchanged=flagged)
+                if i in (0, 2):
+                    b.paint(spans[i], [img[i]], [], False, Pb, zero_first=False, params_unchanged=flagged)     # += onto a's image
+                if i == 3:
+                    a.paint(zang.Span(0, 300), [img[0]], [], False, Pa, zero_first=False, params_unchanged=False)   # setup form: ordered
+                if i == 4:
+                    zang.zero(zang.Span(0, 64), img[1], c2)
+            a.paint(zang.Span(0, F), [img[7]], [], False, Pa, zero_first=False, params_unchanged=flagged)           # img[7] again: not merged with its first paint
+            a.paint_batch(zang.Span(0, F), [img[5], img[6]], Pa, zero_first=True, params_unchanged=flagged)
+
+        e, g_ = sets
+        seq(e, False); seq(g_, False)                    # unflagged first: the tables are stored
         c2.sync()
-        g = c2.capture(lambda: [m.paint(sp, [o], [], False, P, zero_first=True, params_unchanged=True) for o in ring], concurrent=True)
-        nodes, lanes = g.info()
-        assert lanes == 3 and nodes >= K + 1
-        for _ in range(3):
-            g.launch()
-        c2.sync()
-        got = [util.from_image(o)[::8] for o in ring]
-        cnt = m.state()["cnt"][::8].copy()
-        g.close(); c2.close()
+        graph = c2.capture(lambda: seq(g_, True), coalesce=True)
+        nodes, held, launches = graph.info()
+        assert held == N + 2 + 1 + 2 and launches < held and nodes < held + 6, (nodes, held, launches)
+        for rep in range(3):
+            seq(e, True); graph.launch()
+            if rep == 1:                                  # eager paints between replays (flip the double buffers)
+                for s in (e, g_):
+                    s["a"].paint(zang.Span(0, 77), [s["img"][2]], [], False, s["a"].Params(SR, zang.constant(fr), col), zero_first=True)
+            c2.sync()
+            for q, (x, y) in enumerate(zip(e["img"], g_["img"])):
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (rep, q)
+            for k in ("a", "b"):
+                assert np.asarray(e[k].state()).tobytes() == np.asarray(g_[k].state()).tobytes(), (rep, k)
+        graph.close(); c2.close()
+
+
+def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
+    """bench.py's pulseosc graph as it is recorded now (20 zero+paint steps over distinct ring images, ZH_CAPTURE_COALESCE: one
+    launch of 20 buffers + the publish node): after three replays every image of the ring equals the oracle's buffer of that
+    step, and the carried counters equal the oracle's -- on every 8th voice.  40 steps: two launches (32 + 8 buffers)."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V = 4096
+    freq, color, _, _ = workloads.voice_params(2, 0, V)
     L = oracle.lib()
-    ref = np.zeros(F, np.float32)
-    for q, v in enumerate(range(0, V, 8)):
-        st = oracle.PulseOsc(); L.zo_pulseosc_init(C.byref(st))
-        for step in range(1 + 3 * K):
-            ref[:] = 0
-            L.zo_pulseosc_paint(C.byref(st), 0, F, oracle.fptr(ref), SR, oracle.constant(freq[v]), float(color[v]))
-            if step >= 1 + 2 * K:
-                util.assert_bitexact(got[step - 1 - 2 * K][q], ref, f"voice {v} step {step}")
-        assert int(cnt[q]) == int(st.cnt), v
+    for K, want_launches in ((20, 1), (40, 2)):
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            c2 = zang_amd.Context(0)
+            m = mod.PulseOsc(V, c2)
+            fr, col = torch.from_numpy(freq).cuda(), torch.from_numpy(color).cuda()
+            ring = [c2.image(F, V) for _ in range(K)]
+            sp = zang.Span(0, F)
+            P = m.Params(SR, zang.constant(fr), col)
+            m.paint(sp, [ring[0]], [], False, P, zero_first=True)                    # stores the constants
+            c2.sync()
+            g = c2.capture(lambda: [m.paint(sp, [o], [], False, P, zero_first=True, params_unchanged=True) for o in ring], coalesce=True)
+            nodes, held, launches = g.info()
+            assert (held, launches) == (K, want_launches) and nodes == want_launches + 1, (nodes, held, launches)
+            for _ in range(3):
+                g.launch()
+            c2.sync()
+            got = [util.from_image(o)[::8] for o in ring]
+            cnt = m.state()["cnt"][::8].copy()
+            g.close(); c2.close()
+        ref = np.zeros(F, np.float32)
+        for q, v in enumerate(range(0, V, 8)):
+            st = oracle.PulseOsc(); L.zo_pulseosc_init(C.byref(st))
+            for step in range(1 + 3 * K):
+                ref[:] = 0
+                L.zo_pulseosc_paint(C.byref(st), 0, F, oracle.fptr(ref), SR, oracle.constant(freq[v]), float(color[v]))
+                if step >= 1 + 2 * K:
+                    util.assert_bitexact(got[step - 1 - 2 * K][q], ref, f"K={K} voice {v} step {step}")
+            assert int(cnt[q]) == int(st.cnt), (K, v)

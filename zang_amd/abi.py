@@ -17,7 +17,7 @@ COMM_ID_BYTES = 128
 PAINT_ADD, PAINT_ZERO_FIRST = 0, 1
 PAINT_PARAMS_UNCHANGED = 4
 PAINT_TOLERANT = 8
-ZH_CAPTURE_CONCURRENT = 1
+ZH_CAPTURE_COALESCE = 1
 MIX_SEQUENTIAL = 2
 AUDIO_SIGNED8, AUDIO_SIGNED16_LSB = 0, 1
 COB_CONSTANT, COB_BUFFER = 0, 1
@@ -280,7 +280,7 @@ SIGNATURES = {
     "zh_buf_download_voice": (C.c_int, [vp, vp, Buf, u32, u32]),
     "zh_graph_begin_capture": (C.c_int, [vp]),
     "zh_graph_begin_capture_flags": (C.c_int, [vp, C.c_uint32]),
-    "zh_graph_info": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32)]),
+    "zh_graph_info": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]),
     "zh_graph_end_capture": (C.c_int, [vp, P(vp)]),
     "zh_graph_launch": (C.c_int, [vp, vp]),
     "zh_graph_destroy": (C.c_int, [vp]),

@@ -16,6 +16,7 @@
 
 #if !defined(ZH_DEVICE_ONLY)
 #include <vector>
+#include <functional>
 // A module whose state is double-buffered and flips on the HOST at every paint (the chunked oscillators, osc.hip):
 // a captured graph bakes in both buffer pointers, so the library records which buffer a capture started from and
 // how many flips it holds, and zh_graph_launch reconciles the host-side index with that (ctx.hip).
@@ -34,18 +35,23 @@ struct zh_flip_use {
     uint32_t flips;              // paints of it inside the capture
 };
 
-// A capture recorded with ZH_CAPTURE_CONCURRENT (include/zang_hip.h; ctx.hip zh_lanes_*): paints that depend on nothing recorded
+// A capture recorded with ZH_CAPTURE_COALESCE (include/zang_hip.h; ctx.hip zh_epoch_*): paints that depend on nothing recorded
 // before them -- the constant-frequency oscillators in table form, whose phase at any frame is the capture-entry counter plus
-// frames * ifreq exactly -- are recorded on `lanes` streams forked from the context's stream, so the graph holds them as
-// parallel branches; anything else the library records first joins the lanes again (an "epoch" ends) and publishes the
-// advanced counters.  lane[0] is the context's own stream.
-constexpr int kMaxLanes = 4;
+// frames * ifreq exactly -- are not launched when they are recorded: consecutive ones of the same module and span are held back
+// and recorded as ONE launch of several buffers (grid.z).  Anything else the library records first launches what is held back
+// and publishes the advanced counters (an "epoch" ends).
 struct zh_flipper;
-struct zh_lane_write { const float *lo, *hi; int lane; };
-struct zh_lane_pending {
+struct zh_epoch_pending {
     zh_flipper *f;
     uint32_t frames;                                          // frames painted since the epoch opened
-    void (*publish)(zh_flipper *f, uint32_t frames, hipStream_t st);   // cnt[cur] += frames * ifreq, in place, after the join
+    void (*publish)(zh_flipper *f, uint32_t frames, hipStream_t st);   // cnt[cur] += frames * ifreq, in place
+};
+struct zh_co_batch {             // the paints held back: same module, span, flags and row stride; images that do not overlap
+    bool active = false;
+    zh_flipper *owner = nullptr;
+    uint32_t start = 0, end = 0, stride = 0, key = 0, max = 0;
+    std::vector<float *> imgs;
+    std::function<void(hipStream_t, float *const *, uint32_t)> launch;
 };
 
 struct zh_ctx {
@@ -53,15 +59,10 @@ struct zh_ctx {
     hipStream_t stream;
     bool own_stream;
     uint32_t capture_flags;      // of the capture that is recording (0 outside one)
-    int n_lanes;                 // lanes of a ZH_CAPTURE_CONCURRENT capture (1 = the feature is off)
-    hipStream_t lane[kMaxLanes]; // [0] = stream; [1..] created by the first concurrent capture, destroyed with the context
-    hipEvent_t lane_fork, lane_join[kMaxLanes];
-    bool lanes_made;
-    bool epoch_open;
-    bool lane_used[kMaxLanes];
-    int lane_rr;
-    std::vector<zh_lane_write> epoch_writes;
-    std::vector<zh_lane_pending> epoch_pending;
+    bool epoch_open;             // paints are held back and / or counters wait to be published
+    zh_co_batch co;
+    std::vector<zh_epoch_pending> epoch_pending;
+    uint32_t co_paints, co_launches;   // of the capture that is recording: paint calls held back, launches they became
     // scratch for the two-pass voice mixdown: [blocks][frames] partial sums.  Blocks are never freed while the
     // context lives: a captured graph keeps the pointer it was recorded with (basics.hip zh_mix_reserve).
     float *mix_partials;
@@ -78,8 +79,8 @@ struct zh_graph {
     hipGraph_t graph;
     hipGraphExec_t exec;
     std::vector<zh_flip_use> flips;
-    int lanes = 1;               // streams the capture was recorded on (ZH_CAPTURE_CONCURRENT)
     uint32_t nodes = 0;          // nodes of the recorded graph
+    uint32_t co_paints = 0, co_launches = 0;   // ZH_CAPTURE_COALESCE: paint calls held back while recording, launches they became
 };
 
 // Every entry point that allocates or launches runs with the context's device current and restores the caller's
@@ -95,18 +96,16 @@ struct ZhDeviceGuard {
     ZhDeviceGuard(const ZhDeviceGuard &) = delete;
     ZhDeviceGuard &operator=(const ZhDeviceGuard &) = delete;
 };
-// (ZH_GUARD also ends the open epoch of a concurrent capture: whatever the entry point records is ordered after every paint
-// recorded so far.  The oscillator paints, which may join the epoch instead, use ZH_GUARD_LANE.)
-void zh_lanes_barrier(zh_ctx *ctx);
-#define ZH_GUARD_LANE(ctxptr) const zh_ctx *_zh_gctx = (ctxptr); ZhDeviceGuard _zh_guard(_zh_gctx ? _zh_gctx->device : -1)
-#define ZH_GUARD(ctxptr) ZH_GUARD_LANE(ctxptr); do { if (_zh_gctx && _zh_gctx->epoch_open) zh_lanes_barrier(const_cast<zh_ctx *>(_zh_gctx)); } while (0)
-// ctx.hip: the lane (stream) a dependency-free paint that writes the floats [lo, hi) should be recorded on, or nullptr when the
-// capture is not a concurrent one.  Opens an epoch; a range that overlaps one written earlier in the epoch goes to that lane
-// (same stream = recorded order kept), one that overlaps two lanes' ranges ends the epoch first.
-hipStream_t zh_lanes_pick(zh_ctx *ctx, const float *lo, const float *hi);
-// frames of module `f` painted so far in the open epoch; and the same after adding this paint's
-uint32_t zh_lanes_frames(zh_ctx *ctx, zh_flipper *f);
-void zh_lanes_painted(zh_ctx *ctx, zh_flipper *f, uint32_t frames, void (*publish)(zh_flipper *, uint32_t, hipStream_t));
+// (ZH_GUARD also ends the open epoch of a coalescing capture: whatever the entry point records is ordered after every paint
+// recorded so far.  The oscillator paints, which may join the epoch instead, use ZH_GUARD_EPOCH.)
+void zh_epoch_barrier(zh_ctx *ctx);
+#define ZH_GUARD_EPOCH(ctxptr) const zh_ctx *_zh_gctx = (ctxptr); ZhDeviceGuard _zh_guard(_zh_gctx ? _zh_gctx->device : -1)
+#define ZH_GUARD(ctxptr) ZH_GUARD_EPOCH(ctxptr); do { if (_zh_gctx && _zh_gctx->epoch_open) zh_epoch_barrier(const_cast<zh_ctx *>(_zh_gctx)); } while (0)
+// ctx.hip: launch the batch that is held back (if any); the epoch stays open (counters unpublished)
+void zh_epoch_flush_batch(zh_ctx *ctx);
+// frames of module `f` painted so far in the open epoch; account for `frames` more
+uint32_t zh_epoch_frames(zh_ctx *ctx, zh_flipper *f);
+void zh_epoch_painted(zh_ctx *ctx, zh_flipper *f, uint32_t frames, void (*publish)(zh_flipper *, uint32_t, hipStream_t));
 
 // ctx.hip: registry of live flippers + the capture log
 void zh_flipper_register(zh_flipper *f);

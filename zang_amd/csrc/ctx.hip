@@ -39,54 +39,33 @@ void zh_flipper_painted(zh_flipper *f) {
     c->capture_log.push_back(zh_flip_use{f->id, f, f->cur, 1u});
 }
 
-// ---- lanes of a ZH_CAPTURE_CONCURRENT capture (common.hip.h) -------------------------------------------
-static void lanes_join(zh_ctx *c) {
-    for (int i = 1; i < c->n_lanes; i++)
-        if (c->lane_used[i]) {
-            (void)hipEventRecord(c->lane_join[i], c->lane[i]);
-            (void)hipStreamWaitEvent(c->stream, c->lane_join[i], 0);
-            c->lane_used[i] = false;
-        }
+// ---- the epoch of a ZH_CAPTURE_COALESCE capture (common.hip.h) ------------------------------------------
+void zh_epoch_flush_batch(zh_ctx *c) {
+    zh_co_batch &b = c->co;
+    if (!b.active) return;
+    b.active = false;
+    c->co_launches++;
+    b.launch(c->stream, b.imgs.data(), (uint32_t)b.imgs.size());
+    b.imgs.clear();
+    b.launch = nullptr;
 }
-void zh_lanes_barrier(zh_ctx *c) {
+void zh_epoch_barrier(zh_ctx *c) {
     if (!c->epoch_open) return;
-    c->epoch_open = false;                                    // (first: the publish launches below must not re-enter)
-    lanes_join(c);
-    for (const zh_lane_pending &p : c->epoch_pending) p.publish(p.f, p.frames, c->stream);
+    c->epoch_open = false;                                    // (first: the launches below must not re-enter)
+    zh_epoch_flush_batch(c);
+    for (const zh_epoch_pending &p : c->epoch_pending) p.publish(p.f, p.frames, c->stream);
     c->epoch_pending.clear();
-    c->epoch_writes.clear();
 }
-hipStream_t zh_lanes_pick(zh_ctx *c, const float *lo, const float *hi) {
-    if (!c->capturing || !(c->capture_flags & ZH_CAPTURE_CONCURRENT) || c->n_lanes < 2) return nullptr;
-    int lane = -1;
-    for (const zh_lane_write &w : c->epoch_writes)
-        if (lo < w.hi && w.lo < hi) {
-            if (lane >= 0 && lane != w.lane) { zh_lanes_barrier(c); lane = -1; break; }   // ordered after two lanes' work: a join
-            lane = w.lane;
-        }
-    if (!c->epoch_open) {
-        c->epoch_open = true;
-        c->lane_rr = 0;
-        for (int i = 0; i < kMaxLanes; i++) c->lane_used[i] = false;
-        (void)hipEventRecord(c->lane_fork, c->stream);        // everything recorded so far is ahead of every lane
-    }
-    if (lane < 0) { lane = c->lane_rr; c->lane_rr = (c->lane_rr + 1) % c->n_lanes; }
-    if (lane > 0 && !c->lane_used[lane]) {
-        (void)hipStreamWaitEvent(c->lane[lane], c->lane_fork, 0);   // the lane's stream joins the capture here
-        c->lane_used[lane] = true;
-    }
-    c->epoch_writes.push_back(zh_lane_write{lo, hi, lane});
-    return c->lane[lane];
-}
-uint32_t zh_lanes_frames(zh_ctx *c, zh_flipper *f) {
-    for (const zh_lane_pending &p : c->epoch_pending)
+uint32_t zh_epoch_frames(zh_ctx *c, zh_flipper *f) {
+    for (const zh_epoch_pending &p : c->epoch_pending)
         if (p.f == f) return p.frames;
     return 0;
 }
-void zh_lanes_painted(zh_ctx *c, zh_flipper *f, uint32_t frames, void (*publish)(zh_flipper *, uint32_t, hipStream_t)) {
-    for (zh_lane_pending &p : c->epoch_pending)
+void zh_epoch_painted(zh_ctx *c, zh_flipper *f, uint32_t frames, void (*publish)(zh_flipper *, uint32_t, hipStream_t)) {
+    c->epoch_open = true;
+    for (zh_epoch_pending &p : c->epoch_pending)
         if (p.f == f) { p.frames += frames; return; }
-    c->epoch_pending.push_back(zh_lane_pending{f, frames, publish});
+    c->epoch_pending.push_back(zh_epoch_pending{f, frames, publish});
 }
 
 // Form switches (ZH_*_RANGES, ZH_*_PC_MAX, ...) are looked up on the paint path: a paint at 4,096 voices is ~4 us of
@@ -166,9 +145,7 @@ int zh_create(zh_ctx **out, int device) {
     c->mix_partials_floats = 0;
     c->capturing = false;
     c->noise_jump = nullptr;
-    c->capture_flags = 0; c->n_lanes = 1; c->lanes_made = false; c->epoch_open = false; c->lane_rr = 0;
-    for (int i = 0; i < kMaxLanes; i++) { c->lane[i] = nullptr; c->lane_join[i] = nullptr; c->lane_used[i] = false; }
-    c->lane_fork = nullptr;
+    c->capture_flags = 0; c->epoch_open = false; c->co_paints = c->co_launches = 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
     *out = c;
@@ -181,10 +158,6 @@ int zh_destroy(zh_ctx *ctx) { ZH_GUARD(ctx);
     if (ctx->mix_partials) hipFree(ctx->mix_partials);
     for (float *p : ctx->mix_retired) hipFree(p);
     if (ctx->noise_jump) hipFree(ctx->noise_jump);
-    if (ctx->lanes_made) {
-        for (int i = 1; i < kMaxLanes; i++) { if (ctx->lane[i]) hipStreamDestroy(ctx->lane[i]); if (ctx->lane_join[i]) hipEventDestroy(ctx->lane_join[i]); }
-        if (ctx->lane_fork) hipEventDestroy(ctx->lane_fork);
-    }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZH_OK;
@@ -302,33 +275,16 @@ int zh_buf_download_voice(zh_ctx *ctx, float *host, zh_buf src, uint32_t voice, 
     return ZH_OK;
 }
 
-// lanes of a concurrent capture: ZH_CAPTURE_LANES (1..4; 1 = record in order), default 3 -- the context's stream and two forked
-static int lanes_wanted() {
-    const char *e = zh_env("ZH_CAPTURE_LANES");
-    const int n = e ? atoi(e) : 3;
-    return n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n);
-}
 int zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags) { ZH_GUARD(ctx);
-    if (!ctx || ctx->capturing || (flags & ~(uint32_t)ZH_CAPTURE_CONCURRENT)) return ZH_ERR_INVALID;
-    ctx->n_lanes = 1;
-    if (flags & ZH_CAPTURE_CONCURRENT) {
-        if (!ctx->lanes_made) {                               // streams and events are created outside the capture, once
-            ZH_TRY(hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
-            for (int i = 1; i < kMaxLanes; i++) {
-                ZH_TRY(hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
-                ZH_TRY(hipEventCreateWithFlags(&ctx->lane_join[i], hipEventDisableTiming));
-            }
-            ctx->lanes_made = true;
-        }
-        ctx->n_lanes = lanes_wanted();
-    }
-    ctx->lane[0] = ctx->stream;
+    if (!ctx || ctx->capturing || (flags & ~(uint32_t)ZH_CAPTURE_COALESCE)) return ZH_ERR_INVALID;
     ZH_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
     ctx->capture_flags = flags;
     ctx->capture_log.clear();
     ctx->epoch_open = false;
-    ctx->epoch_writes.clear(); ctx->epoch_pending.clear();
+    ctx->co = zh_co_batch{};
+    ctx->epoch_pending.clear();
+    ctx->co_paints = ctx->co_launches = 0;
     return ZH_OK;
 }
 int zh_graph_begin_capture(zh_ctx *ctx) { return zh_graph_begin_capture_flags(ctx, 0); }
@@ -337,10 +293,8 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
     if (!ctx || !out) return ZH_ERR_INVALID;
     *out = nullptr;
     hipGraph_t g = nullptr;
-    const int lanes = ctx->n_lanes;                           // (ZH_GUARD above joined the lanes and published the counters)
-    const uint32_t cflags = ctx->capture_flags;
-    ctx->capturing = false;
-    ctx->capture_flags = 0; ctx->n_lanes = 1;
+    ctx->capturing = false;                                   // (ZH_GUARD above launched what was held back and published the counters)
+    ctx->capture_flags = 0;
     std::vector<zh_flip_use> log;
     log.swap(ctx->capture_log);
     // The paints of the capture were recorded, not run, but each flipped its module's host-side buffer index:
@@ -361,7 +315,7 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
     if (e != hipSuccess) { hipGraphDestroy(g); delete zg; return (int)e; }
     ctx->graphs_live++;
     zg->flips.swap(log);
-    zg->lanes = (cflags & ZH_CAPTURE_CONCURRENT) ? lanes : 1;
+    zg->co_paints = ctx->co_paints; zg->co_launches = ctx->co_launches;
     size_t nn = 0;
     if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) zg->nodes = (uint32_t)nn;
     (void)hipGetLastError();
@@ -391,10 +345,11 @@ int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) { ZH_GUARD(ctx);
     return ZH_OK;
 }
 
-int zh_graph_info(const zh_graph *graph, uint32_t *nodes, uint32_t *lanes) {
+int zh_graph_info(const zh_graph *graph, uint32_t *nodes, uint32_t *paints_held, uint32_t *launches_of_held) {
     if (!graph) return ZH_ERR_INVALID;
     if (nodes) *nodes = graph->nodes;
-    if (lanes) *lanes = (uint32_t)graph->lanes;
+    if (paints_held) *paints_held = graph->co_paints;
+    if (launches_of_held) *launches_of_held = graph->co_launches;
     return ZH_OK;
 }
 

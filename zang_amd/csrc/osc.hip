@@ -116,7 +116,7 @@ struct OscArgs {
     uint32_t *tab;               // [KW + 1][V] or nullptr
     uint32_t V, start, end, fc, stride, nb, prio;
     uint32_t fbase0;             // frames this module painted earlier in the same capture epoch (cnt_in is the epoch-entry counter)
-    uint32_t publish;            // 0: a lane paint of a concurrent capture -- cnt_out is left alone (k_osc_publish advances it once)
+    uint32_t publish;            // 0: a held-back paint of a coalescing capture -- cnt_out is left alone (k_osc_publish advances it once)
     float srf, sr8;
     F32P freq, color;
     float *img[kOscMaxBatch];
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_commit_f32(float *__restrict__ dst, con
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// The one node that ends an epoch of a ZH_CAPTURE_CONCURRENT capture (ctx.hip zh_lanes_barrier) for an oscillator whose
+// The one node that ends an epoch of a ZH_CAPTURE_CONCURRENT capture (ctx.hip zh_epoch_barrier) for an oscillator whose
 // table-form paints were recorded as parallel branches: cnt += frames * ifreq for every voice in range (a voice with a bad
 // frequency neither paints nor advances, PulseOsc.zig:82-84 / TriSawOsc.zig:84-86), in place -- every branch has been joined.
 __global__ void __launch_bounds__(256) k_osc_publish(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tab, uint32_t V, uint32_t ifreq_word,
@@ -513,40 +513,10 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) &&
                              (size_t)n * kw1 * 4 <= ((size_t)16 << 20) && !osc_no_table();
         const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
-        for (uint32_t b0 = 0; b0 < nb; b0 += kOscMaxBatch) {
-            const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
-            // A table-form paint of a ZH_CAPTURE_CONCURRENT capture depends on nothing recorded before it: it reads the counters the
-            // epoch opened on plus the frames this module has painted since, is recorded on one of the capture's lanes, and leaves
-            // the counters alone (k_osc_publish advances them once, when the epoch ends).  No flip.
-            hipStream_t lane = nullptr;
-            if (use_tab && ctx->capturing) {
-                const float *lo = outs[b0].ptr, *hi = outs[b0].ptr;
-                for (uint32_t b = 0; b < cnt_b; b++) {
-                    const float *p0 = outs[b0 + b].ptr + (size_t)start * outs[b0 + b].stride, *p1 = outs[b0 + b].ptr + (size_t)end * outs[b0 + b].stride;
-                    if (b == 0 || p0 < lo) lo = p0;
-                    if (b == 0 || p1 > hi) hi = p1;
-                }
-                lane = zh_lanes_pick(ctx, lo, hi);
-            }
-            if (!lane && ctx->epoch_open) zh_lanes_barrier(ctx);     // an ordered paint of this module: after the lanes, from published counters
-            if (lane) st = lane;
-            OscArgs a;
-            a.cnt_in = m->cnt[m->cur]; a.cnt_out = m->cnt[m->cur ^ 1];
-            a.fbase0 = lane ? zh_lanes_frames(ctx, m) : 0u;
-            a.publish = lane ? 0u : 1u;
-            // A recorded table-form paint reads the table at every replay, so once one has been captured nothing rewrites the
-            // table any more (an eager setup-form paint with other params between replays used to: the replays then rendered with
-            // THOSE constants): later unflagged paints compute their constants without storing them, and the host-side record is
-            // invalidated so that later flagged paints take the setup form too.  A recorded setup-form paint never wrote it.
-            if (use_tab && ctx->capturing) m->tab.pinned = true;
-            const bool write_tab = !use_tab && !ctx->capturing && !m->tab.pinned;
-            if (!use_tab && !ctx->capturing && m->tab.pinned) m->tab.valid = false;
-            a.tab = (use_tab || write_tab) ? m->tab.words : nullptr;
-            a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.nb = cnt_b; a.prio = osc_prio() ? 1u : 0u;
-            a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
-            for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
+        const bool fc4 = fc == 4 && (end - start) % 4 == 0 && !osc_no_fc4();
+        // one launch of `a` (images and count filled in) over `cnt_b` buffers
+        auto launch = [use_tab, fc4, zf, sm, lanes, chunks](OscArgs a, uint32_t cnt_b, hipStream_t st) {
             dim3 grid((lanes + 63) / 64, (chunks + 3) / 4, cnt_b);
-            const bool fc4 = fc == 4 && (end - start) % 4 == 0 && !osc_no_fc4();
 #define ZH_LAUNCH_O4B(ZF, SM, B) do { if (use_tab && fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, true, B>), grid, dim3(256), 0, st, a); \
                                       else if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, false, B>), grid, dim3(256), 0, st, a); \
                                       else if (fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, true, B>), grid, dim3(256), 0, st, a); \
@@ -556,19 +526,68 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
             else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
 #undef ZH_LAUNCH_O4
 #undef ZH_LAUNCH_O4B
+        };
+        // A recorded table-form paint reads the table at every replay, so once one has been captured nothing rewrites the
+        // table any more (an eager setup-form paint with other params between replays used to: the replays then rendered with
+        // THOSE constants): later unflagged paints compute their constants without storing them, and the host-side record is
+        // invalidated so that later flagged paints take the setup form too.  A recorded setup-form paint never wrote it.
+        if (use_tab && ctx->capturing) m->tab.pinned = true;
+        const bool write_tab = !use_tab && !ctx->capturing && !m->tab.pinned;
+        if (!use_tab && !ctx->capturing && m->tab.pinned) m->tab.valid = false;
+        OscArgs a;
+        a.tab = (use_tab || write_tab) ? m->tab.words : nullptr;
+        a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.prio = osc_prio() ? 1u : 0u;
+        a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
+        // A table-form paint of a ZH_CAPTURE_COALESCE capture depends on nothing recorded before it -- its phase at any frame is
+        // the counter the epoch opened on plus the frames this module has painted since, times ifreq, exactly -- so it is held
+        // back: consecutive such paints of one module over the same span into images that do not overlap become ONE recorded
+        // launch of up to 32 buffers (zh_epoch_flush_batch), and the counters are advanced once, when the epoch ends
+        // (k_osc_publish).  No flip: cnt[cur] stays the epoch-entry state until then.
+        if (use_tab && ctx->capturing && (ctx->capture_flags & ZH_CAPTURE_COALESCE)) {
+            const uint32_t key = (zf ? 1u : 0u) | ((uint32_t)sm << 1) | ((uint32_t)fc << 8);
+            for (uint32_t b = 0; b < nb; b++) {
+                zh_co_batch &cb = ctx->co;
+                const float *lo = outs[b].ptr + (size_t)start * outs[b].stride, *hi = outs[b].ptr + (size_t)end * outs[b].stride;
+                bool join = cb.active && cb.owner == m && cb.start == start && cb.end == end && cb.stride == outs[b].stride && cb.key == key &&
+                            cb.imgs.size() < (size_t)kOscMaxBatch;
+                for (size_t q = 0; join && q < cb.imgs.size(); q++) {
+                    const float *qlo = cb.imgs[q] + (size_t)start * cb.stride, *qhi = cb.imgs[q] + (size_t)end * cb.stride;
+                    if (lo < qhi && qlo < hi) join = false;           // the same rows again: the recorded order decides what they hold
+                }
+                if (!join) {
+                    zh_epoch_flush_batch(ctx);
+                    cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = outs[b].stride; cb.key = key;
+                    OscArgs ab = a;
+                    ab.cnt_in = m->cnt[m->cur]; ab.cnt_out = m->cnt[m->cur ^ 1];
+                    ab.fbase0 = zh_epoch_frames(ctx, m); ab.publish = 0u;
+                    cb.launch = [ab, launch](hipStream_t s2, float *const *imgs, uint32_t cnt) {
+                        OscArgs x = ab;
+                        x.nb = cnt;
+                        for (uint32_t i = 0; i < (uint32_t)kOscMaxBatch; i++) x.img[i] = i < cnt ? imgs[i] : nullptr;
+                        launch(x, cnt, s2);
+                    };
+                }
+                cb.imgs.push_back(outs[b].ptr);
+                ctx->co_paints++;
+                zh_epoch_painted(ctx, m, end - start, &osc_publish<OSC, M>);
+            }
+            return;
+        }
+        if (ctx->epoch_open) zh_epoch_barrier(ctx);                   // an ordered paint: after what was held back, from published counters
+        for (uint32_t b0 = 0; b0 < nb; b0 += kOscMaxBatch) {
+            const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
+            a.cnt_in = m->cnt[m->cur]; a.cnt_out = m->cnt[m->cur ^ 1];
+            a.fbase0 = 0u; a.publish = 1u; a.nb = cnt_b;
+            for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
+            launch(a, cnt_b, st);
             // the setup form stored this call's constants (ordered before any later paint on the stream)
             if (!use_tab && a.tab) { m->tab.valid = true; m->tab.sample_rate = sample_rate; m->tab.freq = freq; m->tab.color = color; }
-            if (lane) {
-                zh_lanes_painted(ctx, m, cnt_b * (end - start), &osc_publish<OSC, M>);
-                st = ctx->stream;
-                continue;
-            }
             // the batch advanced the state like cnt_b paints in a row but wrote it once, into the other buffer
             zh_flipper_painted(m);
             m->cur ^= 1;
         }
     } else {
-        if (ctx->epoch_open) zh_lanes_barrier(ctx);
+        if (ctx->epoch_open) zh_epoch_barrier(ctx);
         dim3 grid((lanes + 63) / 64, (chunks + 3) / 4);
         for (uint32_t b = 0; b < nb; b++) {
             const uint32_t *ci = m->cnt[m->cur];
@@ -647,7 +666,7 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
     if (p->freq.tag == ZH_COB_CONSTANT) {
         launch_osc_const<PulseOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
-        if (m->ctx->epoch_open) zh_lanes_barrier(m->ctx);
+        if (m->ctx->epoch_open) zh_epoch_barrier(m->ctx);
         const float srf = 4294967296.0f / p->sample_rate;    // SRfcobasefrq, PulseOsc.zig:122
         const float sr8 = p->sample_rate / 8.0f;              // :134
         const F32P col = mk_f32(p->color);
@@ -675,12 +694,12 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
     return zh_launch_status();
 }
 int zh_pulseosc_paint(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
+                      zh_bool note_id_changed, const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD_EPOCH(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                             // PulseOsc.zig:52-53
     return pulseosc_paint_n(m, start, end, outputs, 1, p, flags);
 }
 int zh_pulseosc_paint_batch(zh_pulseosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t n_buffers,
-                            const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
+                            const zh_pulseosc_params *p, uint32_t flags) { ZH_GUARD_EPOCH(m ? m->ctx : nullptr);
     return pulseosc_paint_n(m, start, end, outputs, n_buffers, p, flags);
 }
 
@@ -738,7 +757,7 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
     if (p->freq.tag == ZH_COB_CONSTANT) {
         launch_osc_const<TriSawOscP>(m, outputs, nb, start, end, p->sample_rate, p->freq.constant, p->color, flags);
     } else {
-        if (m->ctx->epoch_open) zh_lanes_barrier(m->ctx);
+        if (m->ctx->epoch_open) zh_epoch_barrier(m->ctx);
         bool aliased = false;
         for (uint32_t b = 0; b < nb; b++) aliased = aliased || bufs_alias(p->freq.buffer, outputs[b]);
         // 4,096 voices: 106.6 us with per-lane branches in the waveform, 71.3 straight-line, 46.4 as 16 frame ranges (8 / 32 /
@@ -779,12 +798,12 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
     return zh_launch_status();
 }
 int zh_trisawosc_paint(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
+                       zh_bool note_id_changed, const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD_EPOCH(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;                                             // TriSawOsc.zig:54-55
     return trisawosc_paint_n(m, start, end, outputs, 1, p, flags);
 }
 int zh_trisawosc_paint_batch(zh_trisawosc *m, uint32_t start, uint32_t end, const zh_buf *outputs, uint32_t n_buffers,
-                             const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD_LANE(m ? m->ctx : nullptr);
+                             const zh_trisawosc_params *p, uint32_t flags) { ZH_GUARD_EPOCH(m ? m->ctx : nullptr);
     return trisawosc_paint_n(m, start, end, outputs, n_buffers, p, flags);
 }
 

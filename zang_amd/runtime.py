@@ -45,11 +45,11 @@ class Context:
             self.lib.zh_destroy(self.handle)
             self.handle = None
 
-    def capture(self, fn, concurrent=False):
-        """Record everything fn() enqueues on this context into a hipGraph; returns a Graph.  `concurrent`:
-        ZH_CAPTURE_CONCURRENT -- nothing but calls on this context touches its stream inside fn(), and the library may record
-        independent paints as parallel branches (include/zang_hip.h)."""
-        abi.check(self.lib.zh_graph_begin_capture_flags(self.handle, abi.ZH_CAPTURE_CONCURRENT if concurrent else 0), "zh_graph_begin_capture_flags")
+    def capture(self, fn, coalesce=False):
+        """Record everything fn() enqueues on this context into a hipGraph; returns a Graph.  `coalesce`:
+        ZH_CAPTURE_COALESCE -- nothing but calls on this context touches its stream inside fn(), and the library may record
+        consecutive independent paints as one launch (include/zang_hip.h)."""
+        abi.check(self.lib.zh_graph_begin_capture_flags(self.handle, abi.ZH_CAPTURE_COALESCE if coalesce else 0), "zh_graph_begin_capture_flags")
         g = C.c_void_p()
         try:
             fn()
@@ -87,10 +87,10 @@ class Graph:
         abi.check(self.ctx.lib.zh_graph_launch(self.ctx.handle, self.handle), "zh_graph_launch")
 
     def info(self):
-        """(nodes in the recorded graph, streams its paints were spread over)"""
-        n, l = C.c_uint32(), C.c_uint32()
-        abi.check(self.ctx.lib.zh_graph_info(self.handle, C.byref(n), C.byref(l)), "zh_graph_info")
-        return n.value, l.value
+        """(nodes in the recorded graph, paint calls held back while recording, launches they became)"""
+        n, p, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        abi.check(self.ctx.lib.zh_graph_info(self.handle, C.byref(n), C.byref(p), C.byref(l)), "zh_graph_info")
+        return n.value, p.value, l.value
 
     def close(self):
         if self.handle:
