@@ -909,6 +909,8 @@ def main():
 
         def region(self, K):
             sync = _device_sync
+            if self.wl.comm is not None:
+                self.wl.comm.check()                  # zh_comm_check: an asynchronous RCCL error (a dead peer) ends the run here, not in a hang
             sync()
             barrier()
             sync()
@@ -1052,7 +1054,8 @@ def main():
                    "launch": "eager" if graph is None else (f"hipGraph x{G} steps" + (
                        f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launch(es) of up to 32 "
                        f"buffers each (grid.z) + 1 node that publishes the phase counters; {main_run.graph_nodes} nodes" if main_run.graph_held
-                       else f" in recorded order, one kernel node per step ({main_run.graph_nodes} nodes)")),
+                       else "")),
+                   "graph_nodes": main_run.graph_nodes,
                    "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": wl.kernel,
@@ -1191,7 +1194,7 @@ def main():
         out["one_launch_per_step"] = {"value": V * F * K / e_io, "ms_per_step": e_io / K * 1e3, "launch_ms_hip_events": m_io / K,
                                       "frac": wl.bytes_per_step / (m_io / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "ms_per_step_wall": spread([e / K * 1e3 for e, _ in io_regs]), "regions": len(io_regs),
-                                      "launch": f"hipGraph x{io.G} steps in recorded order, one kernel node per step ({io.graph_nodes} nodes)",
+                                      "launch": f"hipGraph x{io.G} steps", "graph_nodes": io.graph_nodes,
                                       "what": "the same steps recorded without ZH_CAPTURE_COALESCE (`value` of rounds 1-4 was this form)"}
         io.close()
 

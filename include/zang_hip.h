@@ -40,7 +40,7 @@ extern "C" {
 #define ZH_API __attribute__((visibility("default")))
 
 enum { ZH_OK = 0, ZH_ERR_INVALID = -1, ZH_ERR_UNSUPPORTED = -2, ZH_ERR_NO_DEVICE = -3,
-       ZH_ERR_COMM = -4,          /* librccl could not be loaded (zh_comm_last_error says why) */
+       ZH_ERR_COMM = -4,          /* librccl could not be loaded, or a rendezvous ran out of time (zh_comm_last_error says which) */
        ZH_ERR_RCCL_BASE = -100    /* an RCCL call failed: the code is ZH_ERR_RCCL_BASE - ncclResult_t */ };
 
 /* paint flags */
@@ -222,22 +222,26 @@ ZH_API int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_
  * librccl is opened with dlopen on first use (env ZH_RCCL_LIB overrides the search: the copy already in the process,
  * then the sibling of the loaded HIP runtime, then the ROCm installation's).
  *   rank 0:      zh_comm_unique_id(id)  -> hand the 128 bytes to every other process (any host channel)
- *   every rank:  zh_comm_create(ctx, world, rank, id, &comm)     (blocks until all `world` ranks have called it)
+ *   every rank:  zh_comm_create(ctx, world, rank, id, &comm)     (returns when all `world` ranks have called it, or at the limit)
  *   per batch:   zh_nice_paint_mix[_stereo] ... ; zh_allreduce_mix(comm, mix, n)  or  zh_reduce_mix(..., root)
  * `mix` is a device float[n] of this rank's GPU (e.g. [buffers][channels][frames]); the sum order is RCCL's (ring /
  * tree by size), so unlike zh_sum_slots the bits may differ between world sizes.  Calls on one communicator must be
  * issued in the same order on every rank.  The collectives may be recorded into a graph (zh_graph_begin_capture ...: RCCL
  * supports stream capture), e.g. one per buffer next to the mixdown paints; creating / destroying a communicator may not.  zh_comm_available() = 1 when librccl and its symbols were found.
- * ALL OR NONE: zh_comm_create is a rendezvous with no timeout -- the ranks that reach RCCL's bootstrap wait there until all
- * `world` of them have.  It can return early on ONE rank without entering the bootstrap (ZH_ERR_UNSUPPORTED during a graph
- * capture, ZH_ERR_INVALID for bad arguments / out of memory, ZH_ERR_COMM when librccl is missing), and the others would then wait
- * for ever.  The host must therefore agree over its own channel BEFORE calling it that every rank (a) sees zh_comm_available()
- * == 1, (b) is not capturing and (c) got the id -- zang_amd.sharding.Comm does exactly that with a MIN all-reduce of the
- * flags; tests/cpp/comm_host.c relies on pipe EOF (a rank that dies closes its ends, the parent stops handing out the id, the
- * waiting ranks read EOF and leave).  Opt-in since round 4: with ZH_COMM_TIMEOUT_S=<seconds> in the environment the rendezvous has
- * a limit, after which zh_comm_create returns ZH_ERR_COMM and zh_comm_last_error() says so (the communicator is then created on a
- * helper thread that stays behind on a timeout: meant for a host that would rather fail than wait and is about to exit;
- * `bench.py --preflight` runs the whole hand-shake in child processes before anything is timed). */
+ * BOUNDED RENDEZVOUS: zh_comm_create meets the other ranks in RCCL's bootstrap.  The communicator is created non-blocking
+ * (ncclCommInitRankConfig, blocking = 0) and the calling thread polls ncclCommGetAsyncError; when not every rank has arrived
+ * within the limit -- 180 s by default, zh_comm_set_timeout(seconds) or ZH_COMM_TIMEOUT_S in the environment change it,
+ * <= 0 = wait for ever -- the half-made communicator is ended with ncclCommAbort and the call returns ZH_ERR_COMM with the
+ * reason in zh_comm_last_error().  No helper thread, nothing left behind: the host may retry with a fresh id.
+ * It can also return early on ONE rank without entering the bootstrap (ZH_ERR_UNSUPPORTED during a graph capture,
+ * ZH_ERR_INVALID for bad arguments / out of memory, ZH_ERR_COMM when librccl is missing): the others then run into the limit.
+ * A host that would rather not wait agrees over its own channel BEFORE calling it that every rank (a) sees
+ * zh_comm_available() == 1, (b) is not capturing and (c) got the id -- zang_amd.sharding.Comm does exactly that with a MIN
+ * all-reduce of the flags; tests/cpp/comm_host.c relies on pipe EOF.
+ * AFTER CREATION: zh_comm_check(comm) surfaces ncclCommGetAsyncError -- ZH_OK while nothing is wrong (an operation still in
+ * progress is not an error), ZH_ERR_RCCL_BASE - x once a peer died or a transport failed; call it between batches (bench.py
+ * does once per timed region).  zh_comm_abort(comm) ends a communicator whose peers may be gone without the collective
+ * hand-shake of zh_comm_destroy. */
 enum { ZH_COMM_ID_BYTES = 128 };
 typedef struct zh_comm zh_comm;
 ZH_API int  zh_comm_available(void);
@@ -246,7 +250,10 @@ ZH_API int  zh_comm_version(void);             /* ncclGetVersion, 0 if unavailab
 ZH_API const char *zh_comm_last_error(void);   /* text of this thread's last ZH_ERR_COMM / ZH_ERR_RCCL_BASE-x result */
 ZH_API int  zh_comm_unique_id(uint8_t *id128 /* out: ZH_COMM_ID_BYTES */);
 ZH_API int  zh_comm_create(zh_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t *id128, zh_comm **out);
+ZH_API int  zh_comm_set_timeout(double seconds);   /* process-wide limit of the rendezvous and of calls RCCL answers "in progress" */
+ZH_API int  zh_comm_check(zh_comm *comm);
 ZH_API int  zh_comm_destroy(zh_comm *comm);    /* synchronises the context's stream first */
+ZH_API int  zh_comm_abort(zh_comm *comm);      /* ncclCommAbort: no hand-shake, nothing synchronised */
 ZH_API int  zh_comm_world(const zh_comm *comm);
 ZH_API int  zh_comm_rank(const zh_comm *comm);
 ZH_API int  zh_allreduce_mix(zh_comm *comm, float *mix, size_t n);                 /* every rank ends with the sum */

@@ -37,7 +37,7 @@ def ctx():
 # last, so that nothing outside the paint path can keep the parity tests from running.
 _FIRST = ["test_gpu_basics", "test_gpu_osc", "test_gpu_modules", "test_gpu_composite", "test_gpu_dispatch", "test_gpu_fullsize",
           "test_gpu_spans", "test_gpu_delay", "test_gpu_math", "test_song", "test_zangscript"]
-_LAST = ["test_bench_launcher", "test_cpp_host", "test_gpu_comm"]
+_LAST = ["test_bench_launcher", "test_cpp_host", "test_gpu_comm", "test_gpu_multidevice"]
 
 
 def _order_key(item):

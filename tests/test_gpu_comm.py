@@ -171,27 +171,39 @@ def test_torch_nccl_backend_one_rank(ctx):
 
 
 def test_comm_create_times_out_when_a_rank_never_arrives():
-    """zh_comm_create is a rendezvous: rank 0 of a world of 2 whose partner never calls it.  With ZH_COMM_TIMEOUT_S=4 the call comes
-    back with ZH_ERR_COMM and a message instead of hanging (in a child process: the helper thread that sits in RCCL's bootstrap
-    stays behind, and the child leaves through os._exit)."""
+    """zh_comm_create is a rendezvous: rank 0 of a world of 2 whose partner never calls it.  The rendezvous is bounded BY DEFAULT
+    (180 s; non-blocking ncclCommInitRankConfig polled through ncclCommGetAsyncError, ncclCommAbort at the limit): here the limit
+    is set to 4 s through the API -- no environment variable -- and the call comes back with ZH_ERR_COMM and a message.  The
+    same process then creates a one-rank communicator and runs a collective on it: nothing was left behind."""
     code = r'''
 import ctypes as C, os, sys, time
 sys.path.insert(0, %r)
+assert "ZH_COMM_TIMEOUT_S" not in os.environ
+import torch
 import zang_amd
-from zang_amd import abi
+from zang_amd import abi, sharding
 ctx = zang_amd.default_context()
 lib = ctx.lib
 uid = (C.c_uint8 * abi.COMM_ID_BYTES)()
 assert lib.zh_comm_unique_id(uid) == 0
+assert lib.zh_comm_set_timeout(4.0) == 0
 h = C.c_void_p()
 t0 = time.time()
 rc = lib.zh_comm_create(ctx.handle, 2, 0, uid, C.byref(h))
 dt = time.time() - t0
 print("rc", rc, "seconds %%.1f" %% dt, "message:", lib.zh_comm_last_error().decode())
+ok = rc == abi.ZH_ERR_COMM and 3.0 < dt < 60.0 and not h.value
+lib.zh_comm_set_timeout(120.0)
+comm = sharding.Comm(ctx, world=1, rank=0)
+x = torch.arange(1024, dtype=torch.float32, device=ctx.device)
+comm.allreduce_mix(x); ctx.sync(); comm.check()
+ok = ok and bool((x.cpu() == torch.arange(1024, dtype=torch.float32)).all())
+comm.close()
+print("after the timeout: one-rank communicator ok")
 sys.stdout.flush()
-os._exit(0 if (rc == abi.ZH_ERR_COMM and 3.0 < dt < 60.0 and not h.value) else 1)
+os._exit(0 if ok else 1)
 ''' % ROOT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
-                       env=dict(os.environ, ZH_COMM_TIMEOUT_S="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    env = {k: v for k, v in os.environ.items() if k != "ZH_COMM_TIMEOUT_S"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
-    assert "no rendezvous within 4 s" in r.stdout
+    assert "no rendezvous within 4 s" in r.stdout and "one-rank communicator ok" in r.stdout

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "zang_hip.h")
 OUT = os.path.join(ROOT, "bindings", "zang_hip.zig")
 
-SCALARS = {"int": "c_int", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "uint8_t": "u8", "float": "f32",
+SCALARS = {"int": "c_int", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "uint8_t": "u8", "float": "f32", "double": "f64",
            "size_t": "usize", "char": "u8"}
 WORDS = {"sineosc": "SineOsc", "pulseosc": "PulseOsc", "trisawosc": "TriSawOsc", "pmosc": "PMOsc", "f32": "F32", "cob": "Cob",
          "hcob": "HCob", "hcurve": "HCurve", "iap": "Iap", "zscript": "ZScript", "ipc": "Ipc"}

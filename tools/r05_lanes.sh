@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the forked-stream form this script measured was removed after this run: commit 5cdbd17 holds it; result: profiles/r05/ab_capture_lanes.txt)
 # round 5: the concurrent-capture form of the headline against the in-order form, at the driver's arguments
 mkdir -p gpurun_out/r05
 cd "$GRAFT_REPO_ROOT" || exit 1

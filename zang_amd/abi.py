@@ -310,6 +310,9 @@ SIGNATURES = {
     "zh_comm_last_error": (C.c_char_p, []),
     "zh_comm_unique_id": (C.c_int, [vp]),
     "zh_comm_create": (C.c_int, [vp, u32, u32, vp, P(vp)]),
+    "zh_comm_set_timeout": (C.c_int, [C.c_double]),
+    "zh_comm_check": (C.c_int, [vp]),
+    "zh_comm_abort": (C.c_int, [vp]),
     "zh_comm_destroy": (C.c_int, [vp]),
     "zh_comm_world": (C.c_int, [vp]),
     "zh_comm_rank": (C.c_int, [vp]),

@@ -7,8 +7,6 @@
 // on it: a single-GPU host never loads it.
 #include "common.hip.h"
 #include <chrono>
-#include <condition_variable>
-#include <memory>
 #include <mutex>
 #include <thread>
 #include <dlfcn.h>
@@ -23,7 +21,11 @@ namespace {
 // the handful of declarations of <rccl/rccl.h> this file uses (RCCL 2.x ABI)
 typedef struct ncclComm *ncclComm_t;
 struct ncclUniqueId { char internal[ZH_COMM_ID_BYTES]; };
-enum { kNcclSuccess = 0, kNcclSum = 0, kNcclFloat32 = 7 };
+enum { kNcclSuccess = 0, kNcclInProgress = 7, kNcclSum = 0, kNcclFloat32 = 7 };
+// ncclConfig_t as RCCL 2.14 first published it: {size, magic, version, blocking}.  ncclCommInitRankConfig reads `size` bytes
+// and takes every later field's default, so this prefix is accepted by every RCCL from 2.14 on -- the process may hold
+// torch's bundled 2.26 or the ROCm installation's 2.27, whose full structs differ.
+struct NcclConfigPrefix { size_t size; unsigned int magic; unsigned int version; int blocking; };
 
 struct Rccl {
     void *lib = nullptr;
@@ -31,6 +33,9 @@ struct Rccl {
     int (*get_version)(int *) = nullptr;
     int (*get_unique_id)(ncclUniqueId *) = nullptr;
     int (*comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*comm_init_rank_config)(ncclComm_t *, int, ncclUniqueId, int, void *) = nullptr;
+    int (*comm_get_async_error)(ncclComm_t, int *) = nullptr;
+    int (*comm_finalize)(ncclComm_t) = nullptr;
     int (*comm_destroy)(ncclComm_t) = nullptr;
     int (*comm_abort)(ncclComm_t) = nullptr;
     int (*all_reduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -80,6 +85,9 @@ Rccl &rccl() {
         ZH_SYM(get_version, "ncclGetVersion");
         ZH_SYM(get_unique_id, "ncclGetUniqueId");
         ZH_SYM(comm_init_rank, "ncclCommInitRank");
+        ZH_SYM(comm_init_rank_config, "ncclCommInitRankConfig");
+        ZH_SYM(comm_get_async_error, "ncclCommGetAsyncError");
+        ZH_SYM(comm_finalize, "ncclCommFinalize");
         ZH_SYM(comm_destroy, "ncclCommDestroy");
         ZH_SYM(comm_abort, "ncclCommAbort");
         ZH_SYM(all_reduce, "ncclAllReduce");
@@ -107,7 +115,34 @@ struct zh_comm {
     zh_ctx *ctx;
     ncclComm_t comm;
     uint32_t world, rank;
+    bool nonblocking;            // created through ncclCommInitRankConfig(blocking = 0): calls may answer ncclInProgress
 };
+
+namespace {
+// seconds a rendezvous (and any later call that answers "in progress") may take: zh_comm_set_timeout, else ZH_COMM_TIMEOUT_S,
+// else 180.  <= 0 = no limit.
+double g_timeout_s = -1.0;
+bool g_timeout_set = false;
+double comm_timeout() {
+    if (g_timeout_set) return g_timeout_s;
+    const char *te = getenv("ZH_COMM_TIMEOUT_S");
+    return te ? atof(te) : 180.0;
+}
+// Wait until the communicator's asynchronous state leaves ncclInProgress.  Returns the state, or kNcclInProgress on a timeout.
+int comm_wait(ncclComm_t cm, double limit) {
+    Rccl &r = rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+        int state = kNcclSuccess;
+        const int rc = r.comm_get_async_error(cm, &state);
+        if (rc != kNcclSuccess) return rc;
+        if (state != kNcclInProgress) return state;
+        if (limit > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return kNcclInProgress;
+        if (spin < 200) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(spin < 2000 ? 50 : 1000));
+    }
+}
+}   // namespace
 
 extern "C" {
 
@@ -151,46 +186,71 @@ int zh_comm_create(zh_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t *id
     c->ctx = ctx; c->comm = nullptr; c->world = world; c->rank = rank;
     ncclUniqueId id;
     memcpy(id.internal, id128, ZH_COMM_ID_BYTES);
-    // ncclCommInitRank blocks until every rank of `world` has called it with the same id (RCCL's bootstrap); the device is ctx's.
-    // A rank that never arrives (it failed earlier, or returned early from this very function: include/zang_hip.h "ALL OR NONE")
-    // would leave the others here for ever: the call runs on a helper thread and this one waits ZH_COMM_TIMEOUT_S seconds for it
-    // (OPT-IN: unset or 0 = wait without limit, on this thread -- creating the communicator on a helper thread made
-    // tests/cpp/comm_host hang once in four runs somewhere after the create, so it is not the default).  On a timeout the helper
-    // stays behind (detached, it may never return) and the caller gets ZH_ERR_COMM with the reason: for a host that would rather
-    // fail than wait, and is about to exit.
-    const char *te = getenv("ZH_COMM_TIMEOUT_S");
-    const double limit = te ? atof(te) : 0.0;
-    if (!(limit > 0.0)) {
+    // The rendezvous is bounded by default: the communicator is created NON-BLOCKING
+    // (ncclCommInitRankConfig, blocking = 0), the calling thread polls ncclCommGetAsyncError until the bootstrap has met every
+    // rank, and after comm_timeout() seconds (default 180) gives up with ncclCommAbort -- which RCCL supports on a communicator
+    // that is still initialising -- and ZH_ERR_COMM.  A rank that never arrives (it failed earlier, or returned early from this
+    // very function: include/zang_hip.h "ALL OR NONE") no longer leaves the others waiting for ever, and no helper thread stays
+    // behind (round 4's opt-in form detached one inside ncclCommInitRank).  A librccl without the three entry
+    // points (before 2.14) falls back to the blocking ncclCommInitRank.
+    const double limit = comm_timeout();
+    if (!r.comm_init_rank_config || !r.comm_get_async_error || !r.comm_abort) {
         const int rc = r.comm_init_rank(&c->comm, (int)world, id, (int)rank);
         if (rc != kNcclSuccess) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+        c->nonblocking = false;
         *out = c;
         return ZH_OK;
     }
-    struct Shared { std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; ncclComm_t comm = nullptr; };
-    auto sh = std::make_shared<Shared>();
-    const int device = ctx->device;
-    std::thread([sh, &r, world, id, rank, device]() {
-        (void)hipSetDevice(device);
-        ncclComm_t cm = nullptr;
-        const int rc = r.comm_init_rank(&cm, (int)world, id, (int)rank);
-        std::lock_guard<std::mutex> lk(sh->mu);
-        sh->rc = rc; sh->comm = cm; sh->done = true;
-        sh->cv.notify_all();
-    }).detach();
-    {
-        std::unique_lock<std::mutex> lk(sh->mu);
-        if (!sh->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return sh->done; })) {
-            delete c;
-            char msg[200];
-            snprintf(msg, sizeof msg, "zh_comm_create: rank %u of %u saw no rendezvous within %.0f s (ZH_COMM_TIMEOUT_S): has every rank called it with the same id?", rank, world, limit);
-            g_last_error = msg;
-            return ZH_ERR_COMM;
-        }
-        if (sh->rc != kNcclSuccess) { delete c; return rccl_fail("ncclCommInitRank", sh->rc); }
-        c->comm = sh->comm;
+    NcclConfigPrefix cfg{sizeof(NcclConfigPrefix), 0xcafebeefu, 21400u, 0};
+    int rc = r.comm_init_rank_config(&c->comm, (int)world, id, (int)rank, &cfg);
+    if (rc != kNcclSuccess && rc != kNcclInProgress) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    c->nonblocking = true;
+    rc = c->comm ? comm_wait(c->comm, limit) : rc;
+    if (rc == kNcclInProgress) {
+        if (c->comm) (void)r.comm_abort(c->comm);
+        delete c;
+        char msg[240];
+        snprintf(msg, sizeof msg, "zh_comm_create: rank %u of %u saw no rendezvous within %.0f s (zh_comm_set_timeout / ZH_COMM_TIMEOUT_S): has every rank "
+                 "called it with the same id?  The communicator was aborted.", rank, world, limit);
+        g_last_error = msg;
+        return ZH_ERR_COMM;
+    }
+    if (rc != kNcclSuccess) {
+        if (c->comm) (void)r.comm_abort(c->comm);
+        delete c;
+        return rccl_fail("ncclCommInitRank", rc);
     }
     *out = c;
     return ZH_OK;
+}
+
+int zh_comm_set_timeout(double seconds) {
+    g_timeout_s = seconds; g_timeout_set = true;
+    return ZH_OK;
+}
+
+// Asynchronous errors of a live communicator (a peer that died, a failed transport): ZH_OK while there is none -- an
+// operation still in progress is not an error -- else ZH_ERR_RCCL_BASE - state with the text in zh_comm_last_error().
+int zh_comm_check(zh_comm *comm) {
+    if (!comm) return ZH_ERR_INVALID;
+    Rccl &r = rccl();
+    if (!r.comm_get_async_error) return ZH_OK;
+    int state = kNcclSuccess;
+    const int rc = r.comm_get_async_error(comm->comm, &state);
+    if (rc != kNcclSuccess) return rccl_fail("ncclCommGetAsyncError", rc);
+    if (state != kNcclSuccess && state != kNcclInProgress) return rccl_fail("asynchronous RCCL error", state);
+    return ZH_OK;
+}
+
+// End a communicator whose peers may be gone: ncclCommAbort (no collective hand-shake), nothing synchronised.
+int zh_comm_abort(zh_comm *comm) {
+    if (!comm) return ZH_OK;
+    ZH_GUARD(comm->ctx);
+    Rccl &r = rccl();
+    int rc = kNcclSuccess;
+    if (r.ok && comm->comm) rc = r.comm_abort ? r.comm_abort(comm->comm) : r.comm_destroy(comm->comm);
+    delete comm;
+    return rc == kNcclSuccess ? ZH_OK : rccl_fail("ncclCommAbort", rc);
 }
 
 int zh_comm_destroy(zh_comm *comm) {
@@ -200,7 +260,13 @@ int zh_comm_destroy(zh_comm *comm) {
     int rc = kNcclSuccess;
     if (r.ok && comm->comm) {
         (void)hipStreamSynchronize(comm->ctx->stream);      // nothing of ours is still in flight on the communicator
-        rc = r.comm_destroy(comm->comm);
+        if (comm->nonblocking && r.comm_finalize) {           // the documented order for a non-blocking communicator
+            rc = r.comm_finalize(comm->comm);
+            if (rc == kNcclInProgress || rc == kNcclSuccess) rc = comm_wait(comm->comm, 30.0);
+            if (rc == kNcclInProgress) rc = kNcclSuccess;     // (destroy below ends it either way)
+        }
+        const int rd = r.comm_destroy(comm->comm);
+        if (rc == kNcclSuccess && rd != kNcclInProgress) rc = rd;
     }
     delete comm;
     return rc == kNcclSuccess ? ZH_OK : rccl_fail("ncclCommDestroy", rc);
@@ -213,7 +279,8 @@ int zh_allreduce_mix(zh_comm *comm, float *mix, size_t n) {
     if (!comm || (!mix && n)) return ZH_ERR_INVALID;
     ZH_GUARD(comm->ctx);
     if (n == 0) return ZH_OK;
-    const int rc = rccl().all_reduce(mix, mix, n, kNcclFloat32, kNcclSum, comm->comm, comm->ctx->stream);
+    int rc = rccl().all_reduce(mix, mix, n, kNcclFloat32, kNcclSum, comm->comm, comm->ctx->stream);
+    if (rc == kNcclInProgress && comm->nonblocking) rc = comm_wait(comm->comm, comm_timeout());   // the enqueue completes in the background
     return rc == kNcclSuccess ? ZH_OK : rccl_fail("ncclAllReduce", rc);
 }
 
@@ -221,7 +288,8 @@ int zh_reduce_mix(zh_comm *comm, float *mix, size_t n, uint32_t root) {
     if (!comm || (!mix && n) || root >= comm->world) return ZH_ERR_INVALID;
     ZH_GUARD(comm->ctx);
     if (n == 0) return ZH_OK;
-    const int rc = rccl().reduce(mix, mix, n, kNcclFloat32, kNcclSum, (int)root, comm->comm, comm->ctx->stream);
+    int rc = rccl().reduce(mix, mix, n, kNcclFloat32, kNcclSum, (int)root, comm->comm, comm->ctx->stream);
+    if (rc == kNcclInProgress && comm->nonblocking) rc = comm_wait(comm->comm, comm_timeout());
     return rc == kNcclSuccess ? ZH_OK : rccl_fail("ncclReduce", rc);
 }
 

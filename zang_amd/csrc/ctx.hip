@@ -123,7 +123,7 @@ const char *zh_error_string(int err) {
     case ZH_ERR_INVALID: return "invalid argument";
     case ZH_ERR_UNSUPPORTED: return "unsupported";
     case ZH_ERR_NO_DEVICE: return "no HIP device";
-    case ZH_ERR_COMM: return "librccl could not be loaded (zh_comm_last_error)";
+    case ZH_ERR_COMM: return "RCCL unavailable or rendezvous failed (zh_comm_last_error)";
     default:
         if (err <= ZH_ERR_RCCL_BASE && err > ZH_ERR_RCCL_BASE - 64) return "an RCCL call failed (zh_comm_last_error)";
         return err > 0 ? hipGetErrorString((hipError_t)err) : "unknown error";

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_commit_f32(float *__restrict__ dst, con
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// The one node that ends an epoch of a ZH_CAPTURE_CONCURRENT capture (ctx.hip zh_epoch_barrier) for an oscillator whose
+// The one node that ends an epoch of a ZH_CAPTURE_COALESCE capture (ctx.hip zh_epoch_barrier) for an oscillator whose
 // table-form paints were recorded as parallel branches: cnt += frames * ifreq for every voice in range (a voice with a bad
 // frequency neither paints nor advances, PulseOsc.zig:82-84 / TriSawOsc.zig:84-86), in place -- every branch has been joined.
 __global__ void __launch_bounds__(256) k_osc_publish(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tab, uint32_t V, uint32_t ifreq_word,

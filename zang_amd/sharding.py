@@ -112,9 +112,20 @@ class Comm:
         self._abi.check(self.lib.zh_reduce_mix(self.handle, C.c_void_p(mix.data_ptr()), mix.numel(), root), "zh_reduce_mix")
         return mix
 
+    def check(self):
+        """Raise if RCCL has recorded an asynchronous error on this communicator (a peer that died, a failed transport):
+        zh_comm_check = ncclCommGetAsyncError.  Cheap; call it between batches."""
+        self._abi.check(self.lib.zh_comm_check(self.handle), "zh_comm_check: " + self.lib.zh_comm_last_error().decode())
+
     def close(self):
         if self.handle is not None:
             self.lib.zh_comm_destroy(self.handle)
+            self.handle = None
+
+    def abort(self):
+        """End the communicator without the collective hand-shake of close() (peers may be gone)."""
+        if self.handle is not None:
+            self.lib.zh_comm_abort(self.handle)
             self.handle = None
 
 
