@@ -293,7 +293,7 @@ class Workload:
             self.params = self.m.Params(self.m_white(), mod.Filter.low_pass, self.cutoff, self.res)
             self.kernel = "k_noise_filter_ring" if V <= 16384 else ("k_noise_filter_pc" if V <= 65536 else "k_noise_filter")     # the library's choice by voice count
             if self.tolerant and V <= 16384:
-                self.kernel = "k_nf_tp1"
+                self.kernel = "k_nf_tp_b"
             self.step = self._step_noise_filter_fused
         elif name == "script":
             # a zangscript module compiled to ONE fused kernel at start-up (hiprtc): `Lead` of the repo's test

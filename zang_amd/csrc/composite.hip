@@ -1322,10 +1322,8 @@ __global__ void __launch_bounds__(64) k_pmosc_spans_wave(PMOscArgs a, SpanTableP
 struct zh_noise_filter {
     zh_ctx *ctx; uint32_t n; uint64_t *s[4]; float *nb; /* [7][n] */ float *l, *b;
     uint32_t *err;               // k_noise_filter_ring: a ring wait ran into its bound (reported by get_state)
-    // ZH_PAINT_TOLERANT (filter_tp.hip.h k_nf_tp1): one block of scratch, allocated by the first tolerant paint outside a capture:
-    // e [32][n] u64, start states [32][n] u64, chunk flags [32][W][2] u64, scanner flags [W][2] u64, {launch number, finished} u32
-    uint64_t *tp_x;
-    uint32_t tp_cap;             // workgroups of k_nf_tp1 resident at once (0 = not asked yet)
+    // ZH_PAINT_TOLERANT (filter_tp.hip.h): scratch of the two-pass form, allocated by the first tolerant paint outside a capture
+    uint64_t *tp_cs; float2 *tp_e; uint32_t *tp_flag; uint32_t tp_serial;
 };
 
 __global__ void k_nf_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, uint32_t n, uint64_t first_seed) {
@@ -1742,7 +1740,7 @@ static void nf_free(zh_noise_filter *m) {
     for (auto &x : m->s) (void)hipFree(x);
     (void)hipFree(m->nb); (void)hipFree(m->l); (void)hipFree(m->b);
     (void)hipFree(m->err);
-    (void)hipFree(m->tp_x);
+    (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag);
 }
 
 __global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
@@ -2147,48 +2145,38 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     case ZH_FILTER_NOTCH: l_mul = 1.0f; h_mul = 1.0f; break;
     default: l_mul = 1.0f; b_mul = 1.0f; h_mul = 1.0f; break;
     }
-    // ZH_PAINT_TOLERANT, white noise, few voices: the span as 32..128-frame chunks at once, ONE launch per piece of <= 32 chunks
-    // (filter_tp.hip.h k_nf_tp1).  L (a multiple of 32, the jump tables' step) by voice count: ~2,048 waves in flight; a piece
-    // never holds more workgroups than are resident at once (its chunk-0 workgroups wait for the others).
+    // ZH_PAINT_TOLERANT, white noise, few voices: the span as 32..128-frame chunks at once, two passes (filter_tp.hip.h).  Pieces
+    // of <= 32 chunks; L (a multiple of 32, the jump tables' step) by voice count: ~2,048 waves in flight.
     if ((flags & ZH_PAINT_TOLERANT) && !pink && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
         const uint32_t Cw = zh_tp_chunks(m->n, "ZH_NF_TP_MAX", 1024);                  // chunks wanted for a 1,024-frame buffer
         const uint4 *tables = Cw >= 2 ? zh_noise_jump_tables(m->ctx) : nullptr;
-        const uint32_t per = (m->n + 255u) / 256u, W = per * 4u;
-        const size_t x_words = (size_t)kNfTpMaxChunks * m->n * 2 + (size_t)kNfTpMaxChunks * W * 2 + (size_t)W * 2 + 1;
-        if (tables && !m->tp_x && !m->ctx->capturing) {
-            int arc = dev_alloc(&m->tp_x, x_words);
-            if (!arc) arc = (int)hipMemsetAsync(m->tp_x, 0, x_words * 8, st);
-            if (arc) { (void)hipFree(m->tp_x); m->tp_x = nullptr; (void)hipGetLastError(); }
+        if (tables && !m->tp_cs && !m->ctx->capturing) {
+            int arc = dev_alloc(&m->tp_cs, (size_t)kNfTpMaxChunks * 4 * m->n);
+            if (!arc) arc = dev_alloc(&m->tp_e, (size_t)(kNfTpMaxChunks + 1) * m->n);
+            if (!arc) arc = dev_alloc(&m->tp_flag, m->n);
+            if (!arc) arc = (int)hipMemsetAsync(m->tp_flag, 0, (size_t)m->n * 4, st);
+            if (arc) { (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; (void)hipGetLastError(); }
         }
-        const uint32_t NB = max(1u, 32u / max(Cw, 1u));                               // L = 32 NB draws: the jump tables' step
-        if (tables && m->tp_x && NB <= 4) {
-            const uint32_t L = 32u * NB;
-            if (!m->tp_cap) {
-                m->tp_cap = NB == 1 ? zh_tp1_resident_workgroups(k_nf_tp1<true, 1>, m->ctx->device) : NB == 2 ? zh_tp1_resident_workgroups(k_nf_tp1<true, 2>, m->ctx->device)
-                          : NB == 3 ? zh_tp1_resident_workgroups(k_nf_tp1<true, 3>, m->ctx->device) : zh_tp1_resident_workgroups(k_nf_tp1<true, 4>, m->ctx->device);
-                if (!m->tp_cap) m->tp_cap = 1;                                         // (asked once; 1 = the form is never taken)
+        if (tables && m->tp_cs) {
+            const uint32_t L = 32u * max(1u, 32u / Cw);                                 // a multiple of 32 draws: the jump tables' step
+            NfTpArgs a;
+            for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
+            a.l = m->l; a.b = m->b; a.cs = m->tp_cs; a.e = m->tp_e; a.flag = m->tp_flag; a.tables = tables;
+            a.V = m->n; a.L = L; a.out = out;
+            a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
+            const uint32_t piece = min(kNfTpMaxChunks * L, ((uint32_t)kNoiseJumpTables * 32u / L) * L + L);   // chunk starts within the tables' reach: (C - 1) * L / 32 <= kNoiseJumpTables
+            for (uint32_t s0 = start; s0 < end; s0 += piece) {
+                a.start = s0; a.end = min(s0 + piece, end);
+                a.C = (a.end - a.start + L - 1) / L;
+                if (++m->tp_serial == 0) m->tp_serial = 1;
+                a.serial = m->tp_serial;
+                a.per = (m->n + 255u) / 256u;
+                const dim3 grid(((a.C + 7u) / 8u) * 8u * a.per);                         // chunk j of every group on XCD j % 8 (nf_tp_block)
+                hipLaunchKernelGGL(k_nf_tp_a, grid, dim3(256), 0, st, a);
+                if (zf) hipLaunchKernelGGL(k_nf_tp_b<true>, grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(k_nf_tp_b<false>, grid, dim3(256), 0, st, a);
             }
-            // chunks per launch: <= 32, chunk starts within the jump tables' reach ((C - 1) * NB <= kNoiseJumpTables), every workgroup resident
-            const uint32_t cmax = min(min(kNfTpMaxChunks, (uint32_t)kNoiseJumpTables / NB + 1u), m->tp_cap / per);
-            if (cmax >= 2 && (end - start + L - 1) / L >= 2) {
-                NfTp1Args a;
-                for (int i = 0; i < 4; i++) a.s[i] = m->s[i];
-                a.l = m->l; a.b = m->b; a.tables = tables;
-                a.e = m->tp_x; a.st = a.e + (size_t)kNfTpMaxChunks * m->n; a.eflag = a.st + (size_t)kNfTpMaxChunks * m->n;
-                a.sflag = a.eflag + (size_t)kNfTpMaxChunks * W * 2; a.sync = reinterpret_cast<uint32_t *>(a.sflag + (size_t)W * 2);
-                a.V = m->n; a.per = per; a.W = W; a.out = out;
-                a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
-                const uint32_t piece = cmax * L;
-                for (uint32_t s0 = start; s0 < end; s0 += piece) {
-                    a.start = s0; a.end = min(s0 + piece, end);
-                    a.C = (a.end - a.start + L - 1) / L;                                  // (a tail of one chunk: chunk 0 alone, exact)
-                    const dim3 grid(((a.C + 7u) / 8u) * 8u * per);
-#define ZH_NFTP1(NB_) do { if (zf) hipLaunchKernelGGL((k_nf_tp1<true, NB_>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_nf_tp1<false, NB_>), grid, dim3(256), 0, st, a); } while (0)
-                    if (NB == 1) ZH_NFTP1(1); else if (NB == 2) ZH_NFTP1(2); else if (NB == 3) ZH_NFTP1(3); else ZH_NFTP1(4);
-#undef ZH_NFTP1
-                }
-                return zh_launch_status();
-            }
+            return zh_launch_status();
         }
     }
     // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at

@@ -37,7 +37,6 @@
 #include "dsp.hip.h"
 #include "lanes.hip.h"
 #include "noise_jump.hip.h"
-#include "tp_xchg.hip.h"
 
 struct Svf2x2 { double a00, a01, a10, a11; };
 // A(cut, res): the step of Filter.zig:135-144 without its inputs (in = 0, no dc offset), on the unit states, in f64
@@ -252,51 +251,9 @@ static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float
 }
 #endif
 
-// ---------------------------------------------------------------------------------------------------- white Noise -> Filter
-#if defined(ZH_FILTER_TP_NOISE)          // (composite.hip only)
-constexpr uint32_t kNfTpMaxChunks = kTpMaxChunks;
-template <uint32_t I> struct TpIdx { static constexpr uint32_t value = I; };
-// ONE launch (round 5; rounds 3-4 ran this as two kernels with the chunk states, the generator states and every e_j going
-// through HBM between them, and generated every chunk's noise twice).  Workgroup = (256 voices, chunk j); chunk 0's workgroups
-// double as the scanners:
-//   chunk j >= 1   jump the generator to the chunk's first draw (one table per workgroup, in LDS), generate the chunk's noise ONCE
-//                  into registers, run the zero-state recurrence over it -> e_j, publish e_j (tp_xchg.hip.h); wait for the chunk's
-//                  start state from the scanner; run the reference's own recurrence over the SAME registers from it and paint.
-//   chunk 0        has no jump and starts from the module's state itself: it paints its frames at once (exact), which also gives
-//                  s_1 exactly; then it gathers e_1 .. e_{C-2} of its 64 voices, folds s_{j+1} = M s_j + e_j (M = A^L formed in f64,
-//                  rounded once; the steps in f32, as the two-kernel form did), publishes every s_j and raises the wave's flag.
-//   multi-draw     a chunk that sees one of Random.float's second draws (2^-41 per sample) says so in its flag; the scanner
-//                  collects the lane masks, hands them on with the start states, the voice's chunk lanes then store nothing, and
-//                  the scanner's own lane walks the voice from the end of chunk 0 to the end of the span sequentially --
-//                  the reference's own walk, bit for bit.
-// Chunk j of every voice group runs on XCD j % 8 (block -> (chunk, group) mapping below), so a jump table is fetched into ONE
-// XCD's L2 instead of all eight.  Every workgroup of the launch must be resident at once (chunk 0 waits for chunks that are
-// dispatched after it): the host sizes the launch by zh_tp1_resident_workgroups.
-struct NfTp1Args {
-    uint64_t *s[4];              // the voices' generator states (Noise.zig:9)
-    float *l, *b;                // filter state
-    uint64_t *e;                 // scratch [C][V]: e_j packed {l, b}
-    uint64_t *st;                // scratch [C][V]: chunk j's start state, published by the scanner
-    uint64_t *eflag;             // scratch [C][W][2]
-    uint64_t *sflag;             // scratch [W][2]
-    uint32_t *sync;              // {launch number, finished workgroups}
-    const uint4 *tables;         // T^(32 k), k = 1..63
-    uint32_t V, start, end, C, per, W;   // per = 256-voice groups, W = 64-voice waves
-    Img out;
-    float l_mul, b_mul, h_mul;
-    F32P cutoff, res;
-};
-
-// LDS of a workgroup: the jump table (32 KiB), whose space the chunk's noise takes over once every thread has jumped
-// ([frame][thread] floats: 32 KiB per 32 frames).  At least 64 KiB are declared whatever NB is, so that a CU (160 KiB) holds
-// at most two workgroups and the dispatcher spreads a 512-workgroup launch two per CU (three on some CUs and one on others
-// made the slowest chunk 40 % later than the median, profiles/r05/nftp1_trace_4096.txt).  NB >= 3 (96 / 128 KiB of noise)
-// keeps the chunk-start generator state instead and draws the chunk's noise a second time.
 // Eight consecutive white samples as Noise.paint adds them to a zeroed temp (Noise.zig:51).  The common case of Random.float
-// (the draw's high word is non-zero) has no test per sample: a compare and a scalar branch after EVERY sample cost more than the
-// sample's arithmetic (tools/exp: the frame loops ran at ~7 cycles per instruction with them).  The tile's minimum high word
-// is tested once; when it is zero (2^-32 per sample) the tile is drawn again with the careful form, which also reports a
-// second draw (2^-41) in `multi`.
+// (the draw's high word is non-zero) has no test per sample; the tile's minimum high word is tested once, and when it is zero
+// (2^-32 per sample) the tile is drawn again with the careful form, which also reports a second draw (2^-41) in `multi`.
 __device__ __forceinline__ void noise_tile8(ZXoshiro &r, float (&t)[8], bool &multi) {
     const ZXoshiro r0 = r;
     uint32_t hmin = 0xffffffffu;
@@ -308,191 +265,135 @@ __device__ __forceinline__ void noise_tile8(ZXoshiro &r, float (&t)[8], bool &mu
         for (int q = 0; q < 8; q++) t[q] = 0.0f + (zrandom_float32_multi(r, multi) * 2.0f - 1.0f);
     }
 }
-
-template <int NB> struct NfTp1Lds { static constexpr bool kKeep = NB <= 2; static constexpr uint32_t kUint4 = kNoiseJumpEntries * 2u; };
-
-template <bool ZF, int NB>                // chunks of L = 32 * NB frames
-__global__ void __launch_bounds__(256, 2) k_nf_tp1(const NfTp1Args a) {
-    __shared__ uint4 tbl[NfTp1Lds<NB>::kUint4];
-    constexpr uint32_t L = 32u * NB;
-    constexpr bool KEEP = NfTp1Lds<NB>::kKeep;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+// block -> (chunk j, 256-voice group g), both passes: a one-dimensional grid of ceil(C / 8) * 8 * per blocks in which chunk j of
+// every group lands on XCD j % 8 (blocks are dealt round-robin over the eight XCDs): the 32 KiB jump table of a chunk is then read
+// into ONE XCD's L2 instead of all eight (8.4 MB of the 36 MB a buffer moved in round 4, pmc_traffic_noise_filter_fused4096_tolerant
+// .json), and pass B finds the chunk's generator state, which pass A left in that same L2.  (Pink Noise below: the same.)
+template <class A> __device__ __forceinline__ bool nf_tp_block(const A &a, uint32_t &j, uint32_t &g) {
     const uint32_t id = blockIdx.x, band = id / (8u * a.per), rr = id % (8u * a.per);
-    const uint32_t j = band * 8u + (rr & 7u), g = rr >> 3;
-    if (j >= a.C) return;                                             // (the last band of a launch whose C is not a multiple of 8)
-    const uint32_t v = g * 256u + tid;
-    const bool live = v < a.V;
-    const uint32_t vc = live ? v : a.V - 1u;                          // a dead lane computes on a live voice's data and stores nothing
-    const uint32_t w = g * 4u + (tid >> 6);
-    const size_t V = a.V;
-    const uint32_t tag = tp_launch_tag(a.sync);
-    if (j > 0) {                                                      // block-uniform
-        const uint4 *t = a.tables + (size_t)(j * NB - 1u) * kNoiseJumpEntries;
-        uint4 q8[kNoiseJumpEntries / 256];                            // the thread's eight entries requested together, then parked
+    j = band * 8u + (rr & 7u); g = rr >> 3;
+    return j < a.C;
+}
+
+// ---------------------------------------------------------------------------------------------------- white Noise -> Filter
+#if defined(ZH_FILTER_TP_NOISE)          // (composite.hip only: the kernels below are not templates)
+constexpr uint32_t kNfTpMaxChunks = kTpMaxChunks;
+struct NfTpArgs {
+    uint64_t *s[4];              // the voices' generator states (Noise.zig:9): read by pass A, written once by pass B
+    float *l, *b;                // filter state
+    uint64_t *cs;                // scratch [C][4][V]: generator state at the start of chunk j
+    float2 *e;                   // scratch [C + 1][V]: slot 0 = the filter state at span start, slot j + 1 = e_j
+    uint32_t *flag;              // scratch [V]: == serial when a multi-draw sample (Random.float, 2^-41 per sample) was seen in THIS paint
+    uint32_t serial;             // this paint's number (host counter, never 0; flags are never cleared: an old number is "not flagged",
+                                 // and a graph replayed with the number it was recorded with at worst sees a stale flag and walks that
+                                 // voice sequentially -- the exact path -- once more)
+    const uint4 *tables;         // T^(32 k), k = 1..63
+    uint32_t V, start, end, L, C, per;   // per = 256-voice groups
+    Img out;
+    float l_mul, b_mul, h_mul;
+    F32P cutoff, res;
+};
+
+// block = 256.  Pass A: jump to the chunk's first draw, keep that state, zero-state response.
+__global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
+    __shared__ uint4 tbl[kNoiseJumpEntries];
+    uint32_t j, g;
+    if (!nf_tp_block(a, j, g)) return;                                // (block-uniform)
+    if (j > 0) {
+        const uint4 *t = a.tables + (size_t)(j * (a.L / 32) - 1) * kNoiseJumpEntries;
+        uint4 w[kNoiseJumpEntries / 256];                             // the thread's eight entries requested together, then parked
 #pragma unroll
-        for (int q = 0; q < kNoiseJumpEntries / 256; q++) q8[q] = t[q * 256 + tid];
+        for (int q = 0; q < kNoiseJumpEntries / 256; q++) w[q] = t[q * 256 + threadIdx.x];
 #pragma unroll
-        for (int q = 0; q < kNoiseJumpEntries / 256; q++) tbl[q * 256 + tid] = q8[q];
+        for (int q = 0; q < kNoiseJumpEntries / 256; q++) tbl[q * 256 + threadIdx.x] = w[q];
         __syncthreads();
     }
-    ZXoshiro r{a.s[0][vc], a.s[1][vc], a.s[2][vc], a.s[3][vc]};
-    const float cut = zclampf(a.cutoff.get(vc), 0.0f, 1.0f);          // Filter.zig:114
-    const float res = 1.0f - zclampf(a.res.get(vc), 0.0f, 1.0f);      // :118
-    const uint32_t f0 = min(a.start + j * L, a.end), f1 = min(f0 + L, a.end), nf = f1 - f0;   // workgroup-uniform
-    const uint32_t orow = (uint32_t)a.out.stride * 4u, voff = v * 4u;
-    const float l_mul = a.l_mul, b_mul = a.b_mul, h_mul = a.h_mul;
-    float l, b;
+    const uint32_t v = g * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    ZXoshiro r{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+    if (j > 0) noise_jump_apply(r, tbl);
+    const size_t V = a.V;
+    uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+    cs[0] = r.s0; cs[V] = r.s1; cs[2 * V] = r.s2; cs[3 * V] = r.s3;
+    if (j == 0) a.e[v] = make_float2(a.l[v], a.b[v]);
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end), nf = f1 - f0;
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
+    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
+    float l = 0.0f, b = 0.0f;
     bool multi = false;
-    if (j > 0) {
-        noise_jump_apply(r, tbl);
-        const ZXoshiro r_chunk = r;                                   // (!KEEP: the chunk's noise is drawn a second time from here)
-        if (KEEP) __syncthreads();                                    // every thread is done with the table: its space now holds the noise
-        float *wn = reinterpret_cast<float *>(tbl) + tid;             // wn[k * 256]
-        l = 0.0f; b = 0.0f;
-        uint32_t k = 0;
-        for (; k + 8u <= nf; k += 8u) {
-            float t[8];
-            noise_tile8(r, t, multi);                                 // zero(temp); temp += noise
+    uint32_t k = 0;
+    for (; k + 8 <= nf; k += 8) {
+        float t[8];
+        noise_tile8(r, t, multi);                                     // zero(temp); temp += noise
 #pragma unroll
-            for (uint32_t q = 0; q < 8; q++) {
-                if (KEEP) wn[(k + q) * 256u] = t[q];
-                svf_step(l, b, t[q], cut, res);                       // Filter.zig:135-144 from a zero state: e_j
-            }
-        }
-        for (; k < nf; k++) {
-            const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
-            const float temp = 0.0f + white;
-            if (KEEP) wn[k * 256u] = temp;
-            svf_step(l, b, temp, cut, res);
-        }
-        if (live) tp_store8(a.e + (size_t)j * V + v, tp_pack(l, b));
-        tp_drain();
-        const uint64_t mm = __builtin_amdgcn_ballot_w64(multi && live);
-        if (lane == 0) tp_flag_set(a.eflag + ((size_t)j * a.W + w) * 2u, tag, mm);
-        const uint64_t flagged = tp_flag_wait(a.sflag + (size_t)w * 2u, tag);
-        tp_unpack(tp_load8(a.st + (size_t)j * V + vc), l, b);
-        const bool wr = live && !((flagged >> lane) & 1ull);
-        ZXoshiro r2 = r_chunk;
-        bool multi2 = false;
-        // ALL: every lane of the wave writes (the common case, decided once per wave): no exec-mask region around each store
-        auto second_half = [&](auto all_c) ZH_INLINE_LAMBDA {
-            constexpr bool ALL = decltype(all_c)::value != 0u;
-            auto frame = [&](const zh_rsrc_t &ro, float temp, uint32_t q, float base) ZH_INLINE_LAMBDA {
-                const SvfOut sv = svf_step(l, b, temp, cut, res);     // :135-144: the reference's recurrence, from s_j
-                const float val = sv.l * l_mul + sv.b * b_mul + sv.h * h_mul;   // :146
-                if (ALL || wr) zrow_store<1>(ro, voff, q * orow, base + val);
-            };
-            uint32_t kk = 0;
-            for (; kk + 8u <= nf; kk += 8u) {                         // (8 rows per descriptor: 32-bit offsets, common.hip.h kMaxRowStride)
-                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f0 + kk);
-                float base[8], t[8];
+        for (uint32_t q = 0; q < 8; q++) svf_step(l, b, t[q], cut, res);   // Filter.zig:135-144
+    }
+    for (; k < nf; k++) {
+        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
+        svf_step(l, b, 0.0f + white, cut, res);
+    }
+    a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
+    if (multi) a.flag[v] = a.serial;                                      // (every later chunk of this voice started at the wrong draw)
+}
+
+// Pass B, same grid: scan, then the reference's recurrence over the regenerated noise of the chunk.  A flagged voice is painted
+// whole by its chunk-0 lane, sequentially from the module's state -- the reference's own walk, bit for bit.
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
+    uint32_t j, g;
+    if (!nf_tp_block(a, j, g)) return;
+    const uint32_t v = g * 256 + threadIdx.x;
+    if (v >= a.V) return;
+    const size_t V = a.V;
+    const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);
+    const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);
+    const uint32_t voff = v * 4u, orow = (uint32_t)a.out.stride * 4u;
+    const bool flagged = a.flag[v] == a.serial;
+    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);     // workgroup-uniform: the frame loops stay scalar
+    const uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+    ZXoshiro r{cs[0], cs[V], cs[2 * V], cs[3 * V]};
+    const float2 s0 = a.e[v];
+    float l = s0.x, b = s0.y;
+    svf_scan<kNfTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
+    auto frame = [&](const zh_rsrc_t &ro, uint32_t k, float temp, float base, bool store) ZH_INLINE_LAMBDA {
+        const SvfOut sv = svf_step(l, b, temp, cut, res);            // Filter.zig:135-144
+        const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
+        if (store) zrow_store<1>(ro, voff, k * orow, base + val);
+    };
+    // (8 rows per descriptor: 32-bit offsets, common.hip.h kMaxRowStride)
+    bool multi = false;                                              // (pass A has reported it already)
+    uint32_t c0 = f0;
+    for (; c0 + 8 <= f1; c0 += 8) {
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
+        float row[8], t[8];
 #pragma unroll
-                for (uint32_t q = 0; q < 8; q++) base[q] = (!ZF && (ALL || wr)) ? zrow_load<1>(ro, voff, q * orow) : 0.0f;
-                if (KEEP) {
+        for (uint32_t k = 0; k < 8; k++) row[k] = ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow);     // the `+=` base
+        noise_tile8(r, t, multi);                                    // Noise.zig:51: zero(temp); temp += noise
 #pragma unroll
-                    for (uint32_t q = 0; q < 8; q++) t[q] = wn[(kk + q) * 256u];
-                } else noise_tile8(r2, t, multi2);
-#pragma unroll
-                for (uint32_t q = 0; q < 8; q++) frame(ro, t[q], q, base[q]);
+        for (uint32_t k = 0; k < 8; k++) frame(ro, k, t[k], row[k], !flagged);
+    }
+    if (c0 < f1) {
+        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, c0);
+        for (uint32_t k = 0; c0 + k < f1; k++) frame(ro, k, 0.0f + (zrandom_float32(r) * 2.0f - 1.0f), ZF ? 0.0f : zrow_load<1>(ro, voff, k * orow), !flagged);
+    }
+    if (!flagged && f1 == a.end && f1 > f0) {                         // whoever painted the span's last frame leaves the states
+        a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
+        a.l[v] = l; a.b[v] = b;
+    }
+    // A flagged voice (one of its draws took Random.float's second draw: every later chunk started at the wrong one) is painted
+    // whole by its chunk-0 lane, sequentially from the module's state: the reference's own walk, bit for bit.
+    if (j == 0 && __builtin_amdgcn_ballot_w64(flagged) != 0) {
+        if (flagged) {
+            r = ZXoshiro{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+            l = s0.x; b = s0.y;
+            for (uint32_t f = a.start; f < a.end; f++) {
+                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
+                frame(ro, 0, 0.0f + (zrandom_float32(r) * 2.0f - 1.0f), ZF ? 0.0f : zrow_load<1>(ro, voff, 0), true);
             }
-            if (kk < nf) {
-                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f0 + kk);
-                for (uint32_t q = 0; kk + q < nf; q++) {
-                    const float temp = KEEP ? wn[(kk + q) * 256u] : 0.0f + (zrandom_float32(r2) * 2.0f - 1.0f);
-                    frame(ro, temp, q, (!ZF && (ALL || wr)) ? zrow_load<1>(ro, voff, q * orow) : 0.0f);
-                }
-            }
-        };
-        if (__builtin_amdgcn_ballot_w64(!wr) == 0) second_half(TpIdx<1>{}); else second_half(TpIdx<0>{});
-        if (wr && f1 == a.end && nf > 0) {                            // whoever painted the span's last frame leaves the states
-            a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
-            a.l[v] = l; a.b[v] = b;
-        }
-    } else {
-        // ---- chunk 0: its own frames, exactly; then the scan for its 64 voices
-        l = a.l[vc]; b = a.b[vc];
-        auto first_chunk = [&](auto all_c) ZH_INLINE_LAMBDA {
-            constexpr bool ALL = decltype(all_c)::value != 0u;
-            auto frame0 = [&](const zh_rsrc_t &ro, float temp, uint32_t q, float base) ZH_INLINE_LAMBDA {
-                const SvfOut sv = svf_step(l, b, temp, cut, res);
-                const float val = sv.l * l_mul + sv.b * b_mul + sv.h * h_mul;
-                if (ALL || live) zrow_store<1>(ro, voff, q * orow, base + val);
-            };
-            uint32_t k = 0;
-            for (; k + 8u <= nf; k += 8u) {
-                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f0 + k);
-                float base[8], t[8];
-#pragma unroll
-                for (uint32_t q = 0; q < 8; q++) base[q] = (!ZF && (ALL || live)) ? zrow_load<1>(ro, voff, q * orow) : 0.0f;
-                noise_tile8(r, t, multi);
-#pragma unroll
-                for (uint32_t q = 0; q < 8; q++) frame0(ro, t[q], q, base[q]);
-            }
-            if (k < nf) {
-                const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f0 + k);
-                for (uint32_t q = 0; k + q < nf; q++) {
-                    const float temp = 0.0f + (zrandom_float32_multi(r, multi) * 2.0f - 1.0f);
-                    frame0(ro, temp, q, (!ZF && (ALL || live)) ? zrow_load<1>(ro, voff, q * orow) : 0.0f);
-                }
-            }
-        };
-        if (__builtin_amdgcn_ballot_w64(!live) == 0) first_chunk(TpIdx<1>{}); else first_chunk(TpIdx<0>{});
-        const float l1 = l, b1 = b;                                   // s_1, exact
-        // M = A^L while the other chunks are still in their first half
-        const Svf2x2 md = svf_pow(svf_hom(cut, res), L);
-        const float m00 = (float)md.a00, m01 = (float)md.a01, m10 = (float)md.a10, m11 = (float)md.a11;
-        // every other chunk's flag for this wave: lane i polls chunk i's
-        uint64_t mymask = 0;
-        {
-            bool ok = !(lane >= 1u && lane < a.C);
-            for (;;) {
-                if (!ok) ok = tp_flag_try(a.eflag + ((size_t)lane * a.W + w) * 2u, tag, mymask);
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                tp_sleep();
-            }
-        }
-        uint64_t flagged = __builtin_amdgcn_ballot_w64(multi && live);
-        {
-            const uint32_t mlo = (uint32_t)mymask, mhi = (uint32_t)(mymask >> 32);
-            for (uint32_t i = 1; i < a.C; i++)                        // (uniform lane index)
-                flagged |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)i) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)i) << 32);
-        }
-        uint64_t ev[kNfTpMaxChunks];
-#pragma unroll
-        for (uint32_t i = 1; i < kNfTpMaxChunks; i++) ev[i] = i + 1u < a.C ? tp_load8(a.e + (size_t)i * V + vc) : 0ull;   // e_{C-1} is not needed
-        float sl = l1, sb = b1;
-#pragma unroll
-        for (uint32_t i = 1; i < kNfTpMaxChunks; i++)
-            if (i < a.C) {                                            // uniform
-                if (live) tp_store8(a.st + (size_t)i * V + v, tp_pack(sl, sb));   // chunk i starts from s_i
-                float el, eb;
-                tp_unpack(ev[i], el, eb);
-                const float nl = (m00 * sl + m01 * sb) + el;          // s_{i+1} = M s_i + e_i
-                const float nb = (m10 * sl + m11 * sb) + eb;
-                sl = nl; sb = nb;
-            }
-        tp_drain();
-        if (lane == 0) tp_flag_set(a.sflag + (size_t)w * 2u, tag, flagged);
-        const bool mine = live && ((flagged >> lane) & 1ull);
-        if (flagged != 0) {                                           // a multi-draw voice: the reference's own walk from the end of chunk 0
-            if (mine) {
-                for (uint32_t f = f1; f < a.end; f++) {
-                    const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
-                    const float base = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
-                    const float white = zrandom_float32(r) * 2.0f - 1.0f;
-                    const SvfOut sv = svf_step(l, b, 0.0f + white, cut, res);
-                    zrow_store<1>(ro, voff, 0, base + (sv.l * l_mul + sv.b * b_mul + sv.h * h_mul));
-                }
-                a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
-                a.l[v] = l; a.b[v] = b;
-            }
-        }
-        if (live && !mine && f1 == a.end && nf > 0) {                 // (a piece of one chunk: chunk 0 alone paints it, exactly)
             a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
             a.l[v] = l; a.b[v] = b;
         }
     }
-    tp_launch_done(a.sync, tag, a.C * a.per);
 }
 #endif   // ZH_FILTER_TP_NOISE
 
@@ -513,7 +414,7 @@ struct PinkTpArgs {
     uint32_t *flag;              // scratch [V]: == serial when a multi-draw sample was seen in this paint
     uint32_t serial;
     const uint4 *tables;
-    uint32_t V, start, end, L, C;
+    uint32_t V, start, end, L, C, per;   // per = 256-voice groups
     Img out;
 };
 __device__ __forceinline__ void pink_coeffs(float (&a)[6]) {
@@ -522,7 +423,8 @@ __device__ __forceinline__ void pink_coeffs(float (&a)[6]) {
 
 __global__ void __launch_bounds__(256) k_pink_tp_a(const PinkTpArgs a) {
     __shared__ uint4 tbl[kNoiseJumpEntries];
-    const uint32_t j = blockIdx.y;
+    uint32_t j, g;
+    if (!nf_tp_block(a, j, g)) return;                                // chunk j of every group on XCD j % 8
     if (j > 0) {                                                      // block-uniform
         const uint4 *t = a.tables + (size_t)(j * (a.L / 32) - 1) * kNoiseJumpEntries;
         uint4 w[kNoiseJumpEntries / 256];
@@ -532,7 +434,7 @@ __global__ void __launch_bounds__(256) k_pink_tp_a(const PinkTpArgs a) {
         for (int q = 0; q < kNoiseJumpEntries / 256; q++) tbl[q * 256 + threadIdx.x] = w[q];
         __syncthreads();
     }
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t v = g * 256 + threadIdx.x;
     if (v >= a.V) return;
     ZXoshiro r{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
     if (j > 0) noise_jump_apply(r, tbl);
@@ -555,8 +457,9 @@ __global__ void __launch_bounds__(256) k_pink_tp_a(const PinkTpArgs a) {
 
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_pink_tp_b(const PinkTpArgs a) {
-    const uint32_t j = blockIdx.y;
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    uint32_t j, g;
+    if (!nf_tp_block(a, j, g)) return;
+    const uint32_t v = g * 256 + threadIdx.x;
     if (v >= a.V) return;
     const size_t V = a.V;
     const uint32_t voff = v * 4u, orow = (uint32_t)a.out.stride * 4u;

@@ -1551,7 +1551,8 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                 a.C = (a.end - a.start + L - 1) / L;
                 if (++m->tp_serial == 0) m->tp_serial = 1;
                 a.serial = m->tp_serial;
-                const dim3 grid((m->n + 255) / 256, a.C);
+                a.per = (m->n + 255u) / 256u;
+                const dim3 grid(((a.C + 7u) / 8u) * 8u * a.per);                         // filter_tp.hip.h nf_tp_block
                 hipLaunchKernelGGL(k_pink_tp_a, grid, dim3(256), 0, st, a);
                 if (zf) hipLaunchKernelGGL(k_pink_tp_b<true>, grid, dim3(256), 0, st, a);
                 else hipLaunchKernelGGL(k_pink_tp_b<false>, grid, dim3(256), 0, st, a);
