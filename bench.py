@@ -557,7 +557,7 @@ def parity_check(wl, ctx):
     import ctypes as C
     import numpy as np
     import torch
-    if wl.name not in ("pulseosc", "nice"):
+    if wl.name not in ("pulseosc", "nice", "noise_filter_fused"):
         return None
     from oracle import pyoracle as po
     L = po.lib()
@@ -567,8 +567,11 @@ def parity_check(wl, ctx):
     out = wl.ring[0]
     if wl.name == "pulseosc":
         wl.m.paint(wl.span, [out], [], False, wl.params, zero_first=True)
+    elif wl.name == "noise_filter_fused":
+        wl.m.paint(wl.span, [out], None, False, wl.params, zero_first=True, tolerant=wl.tolerant)
+        cut_h, res_h = wl.cutoff.cpu().numpy(), wl.res.cpu().numpy()
     else:
-        wl.m.paint(wl.span, [out], [], True, wl.m.Params(SR, wl.freq, True), zero_first=True)
+        wl.m.paint(wl.span, [out], [], True, wl.m.Params(SR, wl.freq, True), zero_first=True, tolerant=wl.tolerant)
     ctx.sync()
     got = out[:, torch.from_numpy(sample).to(out.device)].cpu().numpy().T
     ref = np.zeros((len(sample), F), np.float32)
@@ -577,6 +580,16 @@ def parity_check(wl, ctx):
         if wl.name == "pulseosc":
             o = po.PulseOsc(int(st["cnt"][v]))
             L.zo_pulseosc_paint(C.byref(o), 0, F, po.fptr(ref[k]), SR, po.constant(float(wl.freq_h[v])), float(wl.color_h[v]))
+        elif wl.name == "noise_filter_fused":
+            nz = po.Noise(); fl = po.Filter()
+            for i in range(4):
+                nz.r[i] = int(st["noise"]["r"][v][i])
+            for i in range(7):
+                nz.b[i] = float(st["noise"]["b"][v][i])
+            fl.l, fl.b = float(st["flt"]["l"][v]), float(st["flt"]["b"][v])
+            t0[:] = 0
+            L.zo_noise_paint(C.byref(nz), 0, F, po.fptr(t0), 0)
+            L.zo_filter_paint(C.byref(fl), 0, F, po.fptr(ref[k]), po.fptr(t0), 1, po.constant(float(cut_h[v])), po.constant(float(res_h[v])))
         else:
             o = po.NiceInstrument()
             L.zo_nice_init(C.byref(o), float(wl.color_h[v]))
@@ -587,8 +600,20 @@ def parity_check(wl, ctx):
             o.env.painter.t, o.env.painter.last_value, o.env.painter.start = float(e["t"][v]), float(e["last_value"][v]), float(e["start"][v])
             L.zo_nice_paint(C.byref(o), 0, F, po.fptr(ref[k]), po.fptr(t0), po.fptr(t1), 1, SR, float(wl.freq_h[v]), 1)
     same = got.view(np.uint32) == ref.view(np.uint32)
-    return {"checked_voices": int(len(sample)), "frames": F, "bitexact": bool(same.all()),
-            "mismatching_samples": int((~same).sum()), "against": "oracle from the GPU's own carried state"}
+    rec = {"checked_voices": int(len(sample)), "frames": F, "bitexact": bool(same.all()),
+           "mismatching_samples": int((~same).sum()), "against": "oracle from the GPU's own carried state"}
+    if wl.tolerant and wl.name in ("nice", "noise_filter_fused"):
+        # ZH_PAINT_TOLERANT's contract (include/zang_hip.h): every sample within 1e-5 of the voice's PEAK over the paint, from the
+        # same start state; beside it the share of samples inside SURVEY.md 8d's per-sample metric |err| <= 1e-5 max(|ref|, 1e-3)
+        #  -- near zero crossings that metric asks for less than one ulp of the filter's state
+        g64, r64 = got.astype(np.float64), ref.astype(np.float64)
+        err = np.abs(g64 - r64)
+        peak = np.maximum(np.abs(r64).max(axis=1), 1e-300)
+        rec["tolerant"] = {"worst_error_over_voice_peak": float((err.max(axis=1) / peak).max()), "allowed": 1e-5,
+                           "within": bool(((err.max(axis=1) / peak) <= 1e-5).all()),
+                           "fraction_inside_per_sample_metric": float((err <= 1e-5 * np.maximum(np.abs(r64), 1e-3)).mean()),
+                           "fraction_bitexact": float(same.mean())}
+    return rec
 
 
 def parity_check_mix(wl, ctx, n=64):

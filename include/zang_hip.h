@@ -80,7 +80,18 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *    take the f32 sine; one that reaches anything else -- another oscillator's freq or phase, a Distortion, a divisor, pow,
         *    sqrt, sin / cos -- stays exact (csrc/zscript_emit.hip decides per call when the kernel is generated).  The error is
         *    relative to the largest magnitude on the voice's signal path: where large terms cancel it is that of the terms.
-        * Ignored elsewhere: every other form stays bit-exact, and so does a tolerant Filter paint's first chunk. */ };
+        * Ignored elsewhere: every other form stays bit-exact, and so does a tolerant Filter paint's first chunk.
+        * THE BOUND IS PER PAINT, from the state the paint starts on: every sample within 1e-5 of the voice's peak of what the
+        * reference paints from that same state.  The filter state a tolerant paint leaves carries the paint's error into the next
+        * one.  With damping (a resonance input below 1) that error decays, and a run whose state is carried on the GPU stays
+        * inside 1e-5 against the reference carried on its own side (tests/test_gpu_tolerant.py: 200 buffers, Filter / Noise ->
+        * Filter / NiceInstrument over config 3's parameter range).  In the undamped corner (resonance input >= 1 clamps the
+        * damping to zero, Filter.zig:118) the filter is a lossless resonator and ANY two f32 evaluation orders of its recurrence
+        * -- the reference's loop against this library's chunks, or against exact arithmetic -- drift apart like a random walk,
+        * ~6e-8 * sqrt(5 * frames) of the state's amplitude (profiles/r05/tolerant_error_floor.txt: chunk start states computed
+        * exactly are no closer to the reference than the f32 ones), and a phase difference of a resonator shows as a sample
+        * difference that keeps growing: a carried run there departs from the reference by a few 1e-6 of the amplitude per
+        * 1,024-frame buffer (tested: within 1e-5 * buffers), whatever form paints it. */ };
 
 typedef struct zh_ctx zh_ctx;
 
