@@ -107,6 +107,14 @@ class PMOscInstrument(C.Structure):
     _fields_ = [("release_duration", C.c_float), ("carrier", SineOsc), ("modulator", SineOsc), ("env", Envelope)]
 
 
+class FilteredSawtooth(C.Structure):      # examples/modules.zig:141-143
+    _fields_ = [("osc", TriSawOsc), ("env", Envelope), ("flt", Filter)]
+
+
+class HardSquare(C.Structure):            # examples/modules.zig:260-261 (Gate has no state)
+    _fields_ = [("osc", PulseOsc)]
+
+
 COB_CONSTANT, COB_BUFFER = 0, 1
 CURVE_INSTANTANEOUS, CURVE_LINEAR, CURVE_SQUARED, CURVE_CUBED = 0, 1, 2, 3
 NOISE_WHITE, NOISE_PINK = 0, 1
@@ -174,6 +182,11 @@ def lib():
         "zo_distortion_paint": (None, [z, z, _F, _F, u32, f, f, f]),
         "zo_nice_init": (None, [C.POINTER(NiceInstrument), f]),
         "zo_nice_paint": (None, [C.POINTER(NiceInstrument), z, z, _F, _F, _F, i32, f, f, i32]),
+        "zo_filtered_sawtooth_init": (None, [C.POINTER(FilteredSawtooth)]),
+        "zo_filtered_sawtooth_paint": (None, [C.POINTER(FilteredSawtooth), z, z, _F, _F, _F, _F, i32, f, Cob, i32]),
+        "zo_hard_square_init": (None, [C.POINTER(HardSquare)]),
+        "zo_hard_square_paint": (None, [C.POINTER(HardSquare), z, z, _F, _F, _F, i32, f, f, i32]),
+        "zo_note_c5": (f, []),
         "zo_pmosc_init": (None, [C.POINTER(PMOscInstrument), f]),
         "zo_pmosc_paint": (None, [C.POINTER(PMOscInstrument), z, z, _F, _F, _F, _F, i32, f, f, i32]),
         "zo_mixdown_s16lsb": (None, [C.POINTER(C.c_uint8), _F, z, z, z, f]),

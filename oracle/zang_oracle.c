@@ -572,6 +572,46 @@ void zo_nice_paint(zo_nice_instrument *self, size_t start, size_t end, float *ou
     zo_multiply(start, end, out0, temp0, temp1);
 }
 
+/* note_frequencies.c5 (src/zang-12tet.zig:3-7,96): pow(f32, pow(f32, 2, 1/12), 3), evaluated by the Zig compiler with std.math.pow */
+float zo_note_c5(void) { return zr_powf(zr_powf(2.0f, 1.0f / 12.0f), 3.0f); }
+
+/* FilteredSawtoothInstrument (examples/modules.zig:130-187): TriSawOsc(color 0) * 1.5, Envelope(cubed .025 / .1 / 1.0,
+ * sustain 0.5), multiply, Filter(low_pass, cutoffFromFrequency(440 * c5), res 0.7) into the output.  `freq` is the
+ * reference's ConstantOrBuffer. */
+void zo_filtered_sawtooth_init(zo_filtered_sawtooth *s) {            /* :145-151 */
+    zo_trisawosc_init(&s->osc); zo_envelope_init(&s->env); zo_filter_init(&s->flt);
+}
+void zo_filtered_sawtooth_paint(zo_filtered_sawtooth *self, size_t start, size_t end, float *out0,
+                                float *temp0, float *temp1, float *temp2, int note_id_changed,
+                                float sample_rate, zo_cob freq, int note_on) {
+    zo_zero(start, end, temp0);                                                          /* :161 */
+    zo_trisawosc_paint(&self->osc, start, end, temp0, sample_rate, freq, 0.0f);          /* :162-166 */
+    zo_multiply_with_scalar(start, end, temp0, 1.5f);                                    /* :167 boost sawtooth volume */
+    zo_zero(start, end, temp1);                                                          /* :168 */
+    zo_envelope_params ep = { sample_rate, { ZO_CURVE_CUBED, 0.025f }, { ZO_CURVE_CUBED, 0.1f },
+                              { ZO_CURVE_CUBED, 1.0f }, 0.5f, note_on };
+    zo_envelope_paint(&self->env, start, end, temp1, note_id_changed, &ep);              /* :169-176 */
+    zo_zero(start, end, temp2);                                                          /* :177 */
+    zo_multiply(start, end, temp2, temp0, temp1);                                        /* :178 */
+    /* note_frequencies.c5 = semitone +3 of the a4-relative table, examples/common/note_frequencies.zig */
+    zo_cob cut = { ZO_COB_CONSTANT, zo_filter_cutoff_from_frequency(440.0f * zo_note_c5(), sample_rate), NULL };
+    zo_cob res = { ZO_COB_CONSTANT, 0.7f, NULL };
+    zo_filter_paint(&self->flt, start, end, out0, temp2, ZO_FILTER_LOW_PASS, cut, res);  /* :179-187 */
+}
+
+/* HardSquareInstrument (examples/modules.zig:250-289): PulseOsc(color 0.5) times Gate, multiplied INTO the output. */
+void zo_hard_square_init(zo_hard_square *s) { zo_pulseosc_init(&s->osc); }                /* :263-268 (Gate has no state) */
+void zo_hard_square_paint(zo_hard_square *self, size_t start, size_t end, float *out0, float *temp0, float *temp1,
+                          int note_id_changed, float sample_rate, float freq, int note_on) {
+    (void)note_id_changed;
+    zo_zero(start, end, temp0);                                                          /* :278 */
+    zo_cob f = { ZO_COB_CONSTANT, freq, NULL };
+    zo_pulseosc_paint(&self->osc, start, end, temp0, sample_rate, f, 0.5f);              /* :279-283 */
+    zo_zero(start, end, temp1);                                                          /* :284 */
+    zo_gate_paint(start, end, temp1, note_on);                                           /* :285-287 */
+    zo_multiply(start, end, out0, temp0, temp1);                                         /* :288 */
+}
+
 void zo_pmosc_init(zo_pmosc_instrument *p, float release_duration) { /* examples/modules.zig:93-99 */
     p->release_duration = release_duration;
     zo_sineosc_init(&p->carrier); zo_sineosc_init(&p->modulator); zo_envelope_init(&p->env);

@@ -51,6 +51,8 @@ typedef struct { zo_painter painter; } zo_portamento;      /* Portamento.zig:13 
 typedef struct { float *ring; size_t delay_samples; size_t index; } zo_delay;   /* Delay(n), src/zang/delay.zig:9-10 */
 typedef struct { float color; zo_pulseosc osc; zo_filter flt; zo_envelope env; } zo_nice_instrument;
 typedef struct { float release_duration; zo_sineosc carrier, modulator; zo_envelope env; } zo_pmosc_instrument;
+typedef struct { zo_trisawosc osc; zo_envelope env; zo_filter flt; } zo_filtered_sawtooth;   /* examples/modules.zig:141-143 */
+typedef struct { zo_pulseosc osc; } zo_hard_square;                                        /* examples/modules.zig:260-261 */
 
 void zo_zero(size_t start, size_t end, float *dest);
 void zo_set(size_t start, size_t end, float *dest, float a);
@@ -86,6 +88,13 @@ void zo_distortion_paint(size_t start, size_t end, float *output, const float *i
 void zo_nice_init(zo_nice_instrument *n, float color);
 void zo_nice_paint(zo_nice_instrument *self, size_t start, size_t end, float *out0, float *temp0, float *temp1,
                    int note_id_changed, float sample_rate, float freq, int note_on);
+void zo_filtered_sawtooth_init(zo_filtered_sawtooth *s);
+void zo_filtered_sawtooth_paint(zo_filtered_sawtooth *self, size_t start, size_t end, float *out0, float *temp0, float *temp1, float *temp2,
+                                int note_id_changed, float sample_rate, zo_cob freq, int note_on);
+void zo_hard_square_init(zo_hard_square *s);
+void zo_hard_square_paint(zo_hard_square *self, size_t start, size_t end, float *out0, float *temp0, float *temp1,
+                          int note_id_changed, float sample_rate, float freq, int note_on);
+float zo_note_c5(void);
 void zo_pmosc_init(zo_pmosc_instrument *p, float release_duration);
 void zo_pmosc_paint(zo_pmosc_instrument *self, size_t start, size_t end, float *out0, float *temp0, float *temp1,
                     float *temp2, int note_id_changed, float sample_rate, float freq, int note_on);

@@ -1,0 +1,137 @@
+"""GPU: the reference's two remaining composite recipes as GENERATED kernels.
+
+examples/modules.zig:130-187 (FilteredSawtoothInstrument: TriSawOsc * 1.5, Envelope, multiply, low-pass Filter into the output)
+and :250-289 (HardSquareInstrument: PulseOsc times Gate, multiplied into the output) are written in zangscript in
+tests/golden/script_modules.txt, compiled by the library's own front end + HIP emitter into ONE fused kernel each, and compared
+bit for bit with the oracle's UNFUSED composition of the same module calls through temps (oracle/zang_oracle.c
+zo_filtered_sawtooth_paint / zo_hard_square_paint, which follow the reference line by line) -- recipes the reference defines
+and the emitter has never seen, at 4,096 and 131,072 voices, over three sub-spans per buffer and a note script (retrigger, release,
+silent voices), with a constant and a buffer frequency, into zeroed and into live output."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SR, F = 48000.0, 1024
+SCRIPT = open(os.path.join(ROOT, "tests", "golden", "script_modules.txt")).read()
+SUBSPANS = util.SPANS_THREE                      # (0, 200), (200, 777), (777, 1024)
+
+
+def _voices(V):
+    """every voice up to 512, a stride sample above (the oracle is one CPU thread)"""
+    return np.arange(V) if V <= 512 else np.unique(np.concatenate([np.arange(0, V, max(1, V // 384)), [0, 1, 2, 3, V - 1]]))
+
+
+def _note_script(rng, V, buffers):
+    """per buffer and sub-span: note_on [V] bool, note_id_changed [V] bool -- a note per voice starting in buffer 0, released in a
+    random later sub-span, some voices retriggered, some never playing"""
+    steps = buffers * len(SUBSPANS)
+    off_at = rng.integers(1, steps + 2, V)              # the step at which the note is released (steps + 1: held throughout)
+    retrig = np.where(rng.random(V) < 0.25, rng.integers(2, steps, V), steps + 5)
+    silent = rng.random(V) < 0.05
+    out = []
+    for k in range(steps):
+        on = (k < off_at) | (k >= retrig)
+        on &= ~silent
+        nic = (k == 0) | (k == retrig)
+        out.append((on, nic))
+    return out
+
+
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("freq_kind", ["constant", "buffer"])
+@pytest.mark.parametrize("V", [4096, 131072])
+def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(ctx, oracle, V, freq_kind, zero_first):
+    if V == 131072 and (freq_kind == "buffer") != zero_first:
+        pytest.skip("at 131,072 voices: constant + live output and buffer + zeroed output (two 512 MiB images per case)")
+    import torch
+    from zang_amd import script, zang
+    rng = np.random.default_rng(V + (7 if freq_kind == "buffer" else 0))
+    L = oracle.lib()
+    idx = _voices(V)
+    name = "FilteredSawtoothCtl" if freq_kind == "buffer" else "FilteredSawtooth"      # one script module per arm of the reference's ConstantOrBuffer
+    prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
+    m = prog.module(name, V)
+    freq = rng.uniform(40.0, 5000.0, V).astype(np.float32)
+    freq[:4] = [-3.0, 7000.0, 0.25, 5999.0]           # silent (freq < 0), silent (> sr / 8), very low, just in range
+    cutoff = float(L.zo_filter_cutoff_from_frequency(float(np.float32(440.0) * np.float32(L.zo_note_c5())), SR))   # examples/modules.zig:179-183
+    buffers = 2
+    notes = _note_script(rng, V, buffers)
+    base = rng.uniform(-1, 1, (len(idx), F)).astype(np.float32)
+    insts = []
+    for v in idx:
+        st = oracle.FilteredSawtooth(); L.zo_filtered_sawtooth_init(C.byref(st)); insts.append(st)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32); t2 = np.zeros(F, np.float32)
+    gfreq = util.dev(freq)
+    k = 0
+    for b in range(buffers):
+        if freq_kind == "buffer":                       # a per-frame frequency image: vibrato around the voice's frequency
+            fimg_h = (freq[idx, None] * (1.0 + 0.02 * np.sin(np.arange(F)[None, :] * 0.01 + b))).astype(np.float32)
+            fimg = torch.empty((F, V), dtype=torch.float32, device=ctx.device)
+            fimg[:] = gfreq[None, :]
+            fimg[:, torch.from_numpy(idx).to(ctx.device)] = torch.from_numpy(np.ascontiguousarray(fimg_h.T)).to(ctx.device)
+        ref = base.copy()
+        out = torch.zeros((F, V), dtype=torch.float32, device=ctx.device)
+        out[:, torch.from_numpy(idx).to(ctx.device)] = torch.from_numpy(np.ascontiguousarray(base.T)).to(ctx.device)
+        for (s, e) in SUBSPANS:
+            on, nic = notes[k]; k += 1
+            if zero_first:
+                ref[:, s:e] = 0.0
+            for q, v in enumerate(idx):
+                f = oracle.buffer(fimg_h[q]) if freq_kind == "buffer" else oracle.constant(freq[v])
+                L.zo_filtered_sawtooth_paint(C.byref(insts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), oracle.fptr(t2),
+                                             int(nic[v]), SR, f, int(on[v]))
+            m.paint(zang.Span(s, e), [out], None, torch.from_numpy(nic.astype(np.uint8)).to(ctx.device),
+                    {"sample_rate": SR, "freq": fimg if freq_kind == "buffer" else gfreq, "note_on": torch.from_numpy(on.astype(np.uint8)).to(ctx.device),
+                     "cutoff": cutoff}, zero_first=zero_first)
+        ctx.sync()
+        got = out[:, torch.from_numpy(idx).to(ctx.device)].cpu().numpy().T
+        util.assert_bitexact(np.ascontiguousarray(got), ref, f"FilteredSawtooth V={V} freq {freq_kind} zf={zero_first} buffer {b}")
+        assert float(np.abs(ref).max()) > 0.01
+    prog.close()
+
+
+@pytest.mark.parametrize("zero_first", [True, False])
+@pytest.mark.parametrize("V", [4096, 131072])
+def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, oracle, V, zero_first):
+    import torch
+    from zang_amd import script, zang
+    rng = np.random.default_rng(V + 1)
+    L = oracle.lib()
+    idx = _voices(V)
+    prog = script.ScriptProgram(SCRIPT, ctx, only=["HardSquare"])
+    m = prog.module("HardSquare", V)
+    freq = rng.uniform(40.0, 5000.0, V).astype(np.float32)
+    freq[:4] = [-3.0, 7000.0, 0.25, 5999.0]
+    buffers = 2
+    notes = _note_script(rng, V, buffers)
+    base = rng.uniform(-1, 1, (len(idx), F)).astype(np.float32)
+    insts = []
+    for v in idx:
+        st = oracle.HardSquare(); L.zo_hard_square_init(C.byref(st)); insts.append(st)
+    t0 = np.zeros(F, np.float32); t1 = np.zeros(F, np.float32)
+    gfreq = util.dev(freq)
+    sel = torch.from_numpy(idx).to(ctx.device)
+    k = 0
+    for b in range(buffers):
+        ref = base.copy()
+        out = torch.zeros((F, V), dtype=torch.float32, device=ctx.device)
+        out[:, sel] = torch.from_numpy(np.ascontiguousarray(base.T)).to(ctx.device)
+        for (s, e) in SUBSPANS:
+            on, nic = notes[k]; k += 1
+            if zero_first:
+                ref[:, s:e] = 0.0
+            for q, v in enumerate(idx):
+                L.zo_hard_square_paint(C.byref(insts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), int(nic[v]), SR, float(freq[v]), int(on[v]))
+            m.paint(zang.Span(s, e), [out], None, torch.from_numpy(nic.astype(np.uint8)).to(ctx.device),
+                    {"sample_rate": SR, "freq": gfreq, "note_on": torch.from_numpy(on.astype(np.uint8)).to(ctx.device)}, zero_first=zero_first)
+        ctx.sync()
+        got = out[:, sel].cpu().numpy().T
+        util.assert_bitexact(np.ascontiguousarray(got), ref, f"HardSquare V={V} zf={zero_first} buffer {b}")
+        assert float(np.abs(ref).max()) > 0.5
+    prog.close()

@@ -90,7 +90,7 @@ def test_error_location_and_carets():
 def test_instruction_lists_and_temps():
     s = zs.compile(SCRIPT)
     names = [n for n, _ in s.exported_modules]
-    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle", "Trig", "Shapes"]
+    assert names == ["Doubler", "Pluck", "CycleSine", "Bell", "Lead", "Hiss", "Buzz", "Crush", "Glide", "Sweep", "Maths", "Echo", "EchoLead", "Coin", "Jingle", "LateJingle", "Trig", "Shapes", "FilteredSawtooth", "FilteredSawtoothCtl", "HardSquare"]
     r = s.module_results[s.module_index("Doubler")]
     assert (r.num_temps, r.num_temp_floats, [i.kind for i in r.instructions]) == (1, 0, ["cob_to_buffer", "arith_buffer_float"])
     assert r.instructions[1].out.kind == "output"           # written straight into the result location

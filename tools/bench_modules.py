@@ -91,7 +91,7 @@ m = mod.Portamento(V, ctx); case("Portamento cubed", m, lambda o, m=m: m.paint(s
 
 # generated script kernels (tests/golden/script_modules.txt): compiled at run time through hiprtc
 from zang_amd import script as zscript
-_prog = zscript.ScriptProgram(open(os.path.join(ROOT, "tests", "golden", "script_modules.txt")).read(), ctx, only=["Pluck", "CycleSine"])
+_prog = zscript.ScriptProgram(open(os.path.join(ROOT, "tests", "golden", "script_modules.txt")).read(), ctx, only=["Pluck", "CycleSine", "FilteredSawtooth", "HardSquare"])
 on_dev = torch.ones(V, dtype=torch.uint8, device=dev)
 off_dev = torch.zeros(V, dtype=torch.uint8, device=dev)
 m = _prog.module("Pluck", V, 0)
@@ -106,6 +106,19 @@ def _pluck_tol(o, m=m):
     k = _pt_k[0] % 8; _pt_k[0] += 1
     m.paint(span, [o], None, k == 0, {"sample_rate": SR, "freq": freq, "note_on": on_dev if k < 4 else off_dev}, zero_first=True, tolerant=True)
 case("script Pluck, ZH_PAINT_TOLERANT", m, _pluck_tol)
+# the reference's remaining composite recipes as generated kernels (examples/modules.zig:130-187, 250-289; tests/test_gpu_script_composites.py)
+m = _prog.module("FilteredSawtooth", V, 0)
+_fs_k = [0]
+def _fsaw(o, m=m):
+    k = _fs_k[0] % 8; _fs_k[0] += 1
+    m.paint(span, [o], None, k == 0, {"sample_rate": SR, "freq": freq, "note_on": on_dev if k < 4 else off_dev, "cutoff": 0.07}, zero_first=True)
+case("script FilteredSawtooth (reference recipe)", m, _fsaw)
+m = _prog.module("HardSquare", V, 0)
+_hs_k = [0]
+def _hsq(o, m=m):
+    k = _hs_k[0] % 8; _hs_k[0] += 1
+    m.paint(span, [o], None, k == 0, {"sample_rate": SR, "freq": freq, "note_on": on_dev if k < 4 else off_dev}, zero_first=True)
+case("script HardSquare (reference recipe)", m, _hsq)
 m = _prog.module("CycleSine", V, 0); case("script CycleSine (sin of Cycle + phase)", m, lambda o, m=m: m.paint(span, [o], None, False, {"sample_rate": SR, "freq": 3.0, "phase": 0.25}, zero_first=True))
 m = _prog.module("CycleSine", V, 0); case("script CycleSine, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], None, False, {"sample_rate": SR, "freq": 3.0, "phase": 0.25}, zero_first=True, tolerant=True))
 
