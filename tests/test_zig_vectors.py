@@ -16,7 +16,7 @@ ZIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zi
 
 def test_machinery_on_oracle_made_files(tmp_path, oracle):
     names = zv.write_oracle_vectors(str(tmp_path))
-    assert len(names) == 107
+    assert len(names) == 119
     for name in names:
         rec = zv.read(os.path.join(str(tmp_path), name + ".zgv"))
         report = zv.compare(name, rec)

@@ -25,7 +25,7 @@ RETRIGGER_SCRIPT = [(0, 300, True, True), (300, 600, True, True), (600, 1024, Fa
 SCRIPTS = [NOTE_SCRIPT, RETRIGGER_SCRIPT]
 # records compared with the 1e-5 tolerance instead of bit for bit: (case prefix, record name or None = every float record)
 LIBM = [("sineosc_", None), ("pmosc_", None), ("distortion_overdrive", None), ("distortion_clip", None), ("math", None),
-        ("filter_cutoff_from_frequency", None), ("nice_", None)]
+        ("filter_cutoff_from_frequency", None), ("nice_", None), ("fsaw_", None)]
 
 
 def read(path):
@@ -186,6 +186,25 @@ def expected(name, rec):
             exp.update(state_t=_f32(m.carrier.t, m.modulator.t))
         exp.update(out=np.concatenate(halves), state_stage=np.array([m.env.state], np.uint32),
                    state_painter=_f32(m.env.painter.t, m.env.painter.last_value, m.env.painter.start))
+    elif name.startswith(("fsaw_", "hsq_")):
+        script = SCRIPTS[int(name.split("_")[1])]
+        sr, freq, _ = (float(x) for x in rec["params"])
+        t = [np.zeros(F, np.float32) for _ in range(3)]
+        halves = [out[:F].copy(), out[F:].copy()]
+        if name.startswith("fsaw_"):
+            m = po.FilteredSawtooth(); L.zo_filtered_sawtooth_init(C.byref(m))
+            for s, e, on, nic in script:
+                h = 1 if s >= F else 0
+                L.zo_filtered_sawtooth_paint(C.byref(m), s - h * F, e - h * F, po.fptr(halves[h]), po.fptr(t[0]), po.fptr(t[1]), po.fptr(t[2]), int(nic), sr,
+                                             po.constant(freq), int(on))
+            exp.update(out=np.concatenate(halves), state_cnt=np.array([m.osc.cnt], np.uint32), state_lb=_f32(m.flt.l, m.flt.b),
+                       state_stage=np.array([m.env.state], np.uint32), state_painter=_f32(m.env.painter.t, m.env.painter.last_value, m.env.painter.start))
+        else:
+            m = po.HardSquare(); L.zo_hard_square_init(C.byref(m))
+            for s, e, on, nic in script:
+                h = 1 if s >= F else 0
+                L.zo_hard_square_paint(C.byref(m), s - h * F, e - h * F, po.fptr(halves[h]), po.fptr(t[0]), po.fptr(t[1]), int(nic), sr, freq, int(on))
+            exp.update(out=np.concatenate(halves), state_cnt=np.array([m.osc.cnt], np.uint32))
     elif name == "basics":
         a, b, d = rec["a"], rec["b"], rec["dest0"]
         s, e = 100, 900
@@ -312,6 +331,8 @@ def case_inputs():
             color = np.float32(0.3) + np.float32(0.2) * np.float32(fi)
             cases[f"nice_{ki}_{fi}"] = dict(out0=fill(2 * F, 2100 + ki * 4 + fi, -1, 1), params=_f32(SR, freq, color))
             cases[f"pmosc_{ki}_{fi}"] = dict(out0=fill(2 * F, 2200 + ki * 4 + fi, -1, 1), params=_f32(SR, np.float32(freq) * np.float32(0.5), 0.4))
+            cases[f"fsaw_{ki}_{fi}"] = dict(out0=fill(2 * F, 2600 + ki * 4 + fi, -1, 1), params=_f32(SR, freq, 0.0))      # examples/modules.zig:130-187
+            cases[f"hsq_{ki}_{fi}"] = dict(out0=fill(2 * F, 2700 + ki * 4 + fi, -1, 1), params=_f32(SR, freq, 0.0))       # examples/modules.zig:250-289
     cases["basics"] = dict(a=fill(F, 2300, -2, 2), b=fill(F, 2301, -2, 2), dest0=fill(F, 2302, -2, 2))
     mix = fill(F, 2400, -6, 6); mix[3] = np.nan; mix[4] = np.inf; mix[5] = -np.inf
     cases["mixdown"] = dict(mix=mix)

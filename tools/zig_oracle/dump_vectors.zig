@@ -454,6 +454,50 @@ fn instruments(dir: std.fs.Dir) !void {
                 try o.put("state_stage", u32, &[_]u32{@intFromEnum(m.env.state)});
                 try o.f32s("state_painter", &[_]f32{ m.env.painter.t, m.env.painter.last_value, m.env.painter.start });
             }
+            {
+                // examples/modules.zig:130-187 (round 5: the recipes tests/test_gpu_script_composites.py holds the generated kernels to)
+                var nb: [64]u8 = undefined;
+                const name = try std.fmt.bufPrint(&nb, "fsaw_{d}_{d}", .{ ki, fi });
+                var out: [2 * F]f32 = undefined;
+                var t0: [F]f32 = undefined;
+                var t1: [F]f32 = undefined;
+                var t2: [F]f32 = undefined;
+                fill(&out, 2600 + ki * 4 + fi, -1.0, 1.0);
+                var o = try Out.open(dir, name);
+                defer o.close();
+                try o.f32s("out0", &out);
+                try o.f32s("params", &[_]f32{ SR, freq, 0.0 });
+                var m = ex.FilteredSawtoothInstrument.init();
+                for (script) |st| {
+                    const base: usize = if (st.s >= F) F else 0;
+                    m.paint(zang.Span.init(st.s - base, st.e - base), .{out[base .. base + F]}, .{ &t0, &t1, &t2 }, st.nic, .{ .sample_rate = SR, .freq = zang.constant(freq), .note_on = st.on });
+                }
+                try o.f32s("out", &out);
+                try o.put("state_cnt", u32, &[_]u32{m.osc.cnt});
+                try o.f32s("state_lb", &[_]f32{ m.flt.l, m.flt.b });
+                try o.put("state_stage", u32, &[_]u32{@intFromEnum(m.env.state)});
+                try o.f32s("state_painter", &[_]f32{ m.env.painter.t, m.env.painter.last_value, m.env.painter.start });
+            }
+            {
+                // examples/modules.zig:250-289
+                var nb: [64]u8 = undefined;
+                const name = try std.fmt.bufPrint(&nb, "hsq_{d}_{d}", .{ ki, fi });
+                var out: [2 * F]f32 = undefined;
+                var t0: [F]f32 = undefined;
+                var t1: [F]f32 = undefined;
+                fill(&out, 2700 + ki * 4 + fi, -1.0, 1.0);
+                var o = try Out.open(dir, name);
+                defer o.close();
+                try o.f32s("out0", &out);
+                try o.f32s("params", &[_]f32{ SR, freq, 0.0 });
+                var m = ex.HardSquareInstrument.init();
+                for (script) |st| {
+                    const base: usize = if (st.s >= F) F else 0;
+                    m.paint(zang.Span.init(st.s - base, st.e - base), .{out[base .. base + F]}, .{ &t0, &t1 }, st.nic, .{ .sample_rate = SR, .freq = freq, .note_on = st.on });
+                }
+                try o.f32s("out", &out);
+                try o.put("state_cnt", u32, &[_]u32{m.osc.cnt});
+            }
         }
     }
 }
