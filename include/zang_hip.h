@@ -178,6 +178,16 @@ ZH_API int  zh_graph_end_capture(zh_ctx *ctx, zh_graph **out);
 ZH_API int  zh_graph_launch(zh_ctx *ctx, zh_graph *graph);
 ZH_API int  zh_graph_destroy(zh_graph *graph);
 
+/* Which kernel form a paint takes is the library's choice, by voice count, span and arguments.  The voice-count thresholds and
+ * frame-range counts behind that choice are ONE table (csrc/dispatch.hip): zh_form_count() rows, zh_form_info(i, ...) = a row's
+ * name, default, current value and a line on what it selects and where it was measured.  ZH_FORMS="name=value,name=value" in
+ * the environment overrides rows (read once, at the first paint; the parity tests set ZH_ENV_LIVE=1 before loading the library
+ * to flip rows between paints).  zh_last_form(ctx, out, n): the kernels launched by the last entry point on this context that
+ * launched any, comma-separated in launch order ("k_osc_const4", "k_nf_tp_a,k_nf_tp_b", "k_nice_mix,k_mix_pass2_wide") -- what a host, or bench.py, asks instead of guessing the form from the voice count. */
+ZH_API int  zh_form_count(void);
+ZH_API int  zh_form_info(int index, const char **name, long *default_value, long *current_value, const char **doc);
+ZH_API int  zh_last_form(zh_ctx *ctx, char *out, size_t n);
+
 /* timing helpers: HIP events on the context's stream (used by bench.py) */
 typedef struct zh_event zh_event;
 ZH_API int  zh_event_create(zh_ctx *ctx, zh_event **out);

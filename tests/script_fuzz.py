@@ -267,9 +267,10 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, 
     from tests.util import from_image, to_image
     from zang_amd import script, zang
     text, name = generate(seed) if text is None else (text, "Main")
-    old = os.environ.get("ZH_SCRIPT_RANGES")
+    from tests import util
+    old = os.environ.get("ZH_FORMS")
     if ranges is not None:
-        os.environ["ZH_SCRIPT_RANGES"] = str(ranges)
+        os.environ["ZH_FORMS"] = util.forms_env(script_ranges=ranges)["ZH_FORMS"]
     prog = script.ScriptProgram(text, ctx, only=[name])
     try:
         mod = prog.module(name, V, seed)
@@ -320,7 +321,7 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, 
         prog.close()
         if ranges is not None:
             if old is None:
-                del os.environ["ZH_SCRIPT_RANGES"]
+                del os.environ["ZH_FORMS"]
             else:
-                os.environ["ZH_SCRIPT_RANGES"] = old
+                os.environ["ZH_FORMS"] = old
     return text

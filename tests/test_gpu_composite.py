@@ -106,12 +106,10 @@ def test_nice_equals_gpu_unfused_modules(ctx):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
-@pytest.mark.parametrize("wg_min", [None, "0", "wg8"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup; "wg8": per 512-thread workgroup
+@pytest.mark.parametrize("wg_min", [None, "0"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup
 def test_nice_paint_mix(ctx, oracle, wg_min, monkeypatch):
-    if wg_min == "wg8":
-        monkeypatch.setenv("ZH_NICE_MIX_WG8_MIN", "0")
-    elif wg_min is not None:
-        monkeypatch.setenv("ZH_NICE_MIX_WG_MIN", wg_min)
+    if wg_min is not None:
+        util.set_form(monkeypatch, nice_mix_wg_min=wg_min)
     import torch
     from zang_amd import modules as mod, zang, workloads
     V = 1000          # not a multiple of 256: tail lanes
@@ -136,16 +134,14 @@ def test_nice_paint_mix(ctx, oracle, wg_min, monkeypatch):
     assert np.array_equal(m1.state(), m2.state())
 
 
-@pytest.mark.parametrize("wg_min", [None, "0", "wg8"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup; "wg8": per 512-thread workgroup
+@pytest.mark.parametrize("wg_min", [None, "0"])      # None: the library's choice by voice count (per-wave rows here); "0": one row per workgroup
 def test_nice_paint_mix_stereo(ctx, oracle, wg_min, monkeypatch):
     """Two channels (examples/example_stereo.zig:84-98 with a constant pan per voice): every voice is added to the left
     channel times its left gain and to the right channel times (1 - left); the per-voice products are f32, their sum
     over the voices is checked against the f64 sum with the sqrt(V) * eps bound; with both gains 1.0 the two channels
     equal the mono mixdown bit for bit (x * 1.0 == x, same summation order)."""
-    if wg_min == "wg8":
-        monkeypatch.setenv("ZH_NICE_MIX_WG8_MIN", "0")
-    elif wg_min is not None:
-        monkeypatch.setenv("ZH_NICE_MIX_WG_MIN", wg_min)
+    if wg_min is not None:
+        util.set_form(monkeypatch, nice_mix_wg_min=wg_min)
     import torch
     from zang_amd import modules as mod, zang, workloads
     V = 1000
@@ -187,7 +183,7 @@ def test_pmosc_fused_equals_unfused_oracle(ctx, oracle, form, monkeypatch):
     """(At a small voice count a span is painted as frame ranges at once, each range replaying the phase / envelope walk of
     the earlier frames -- k_pmosc_ranges; ZH_PMOSC_RANGES=0 is the lane-per-voice walk k_pmosc.)"""
     if form == "sequential":
-        monkeypatch.setenv("ZH_PMOSC_RANGES", "0")
+        util.set_form(monkeypatch, pmosc_ranges="0")
     from zang_amd import modules as mod, zang, workloads
     V = 192
     freq, _, u2, _ = workloads.voice_params(4, 0, V)
@@ -336,21 +332,6 @@ def test_noise_filter_few_voices_short_spans(ctx, oracle, V, zero_first):
 
 
 @pytest.mark.gpu
-def test_nice_two_voices_per_lane_variant_is_bit_identical():
-    """ZH_NICE_W=2 (lanes.hip.h: packed-f32 voice pairs, off by default because it measured slower) must give
-    the same bits: rerun the NiceInstrument parity tests in a subprocess with the variant selected."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZH_NICE_W="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
-                        "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    util.assert_rerun_green(r, 2)
-
-
-@pytest.mark.gpu
 def test_noise_filter_single_wave_form_is_bit_identical():
     """k_noise_filter (one wave does noise and filter: the form used above ZH_NF_PC_MAX voices) against the same
     oracle: rerun the fused Noise->Filter parity tests in a subprocess with the two-wave form switched off."""
@@ -358,7 +339,7 @@ def test_noise_filter_single_wave_form_is_bit_identical():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZH_NF_PC_MAX="0")
+    env = util.forms_env(nf_pc_max=0)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
                         "noise_filter_fused_equals_unfused or noise_filter_few_voices_short_spans"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -373,7 +354,7 @@ def test_nice_single_wave_form_is_bit_identical():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZH_NICE_PC_MAX="0")
+    env = util.forms_env(nice_pc_max=0)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_composite.py", "-q", "-m", "gpu", "-k",
                         "nice_fused_equals_unfused_oracle or nice_equals_gpu_unfused_modules or nice_few_voices_short_spans"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -388,9 +369,9 @@ def test_nice_with_non_finite_and_huge_filter_states(ctx, oracle, form, monkeypa
     in every kernel form, and in the mixdown form."""
     from zang_amd import modules as mod, zang, workloads
     if form == "three_waves":
-        monkeypatch.setenv("ZH_NICE_PC4_MAX", "0")
+        util.set_form(monkeypatch, nice_pc4_max="0")
     elif form == "one_wave":
-        monkeypatch.setenv("ZH_NICE_PC_MAX", "0")
+        util.set_form(monkeypatch, nice_pc_max="0")
     V = 200
     freq, color, _, _ = workloads.voice_params(5, 9, V)
     L = oracle.lib()
@@ -432,15 +413,13 @@ def test_nice_with_non_finite_and_huge_filter_states(ctx, oracle, form, monkeypa
 
 
 @pytest.mark.parametrize("V", [300, 4096])
-@pytest.mark.parametrize("wg_min", [None, "0", "wg8"])
+@pytest.mark.parametrize("wg_min", [None, "0"])
 def test_nice_paint_mix_stereo_batch_equals_separate_calls(ctx, V, wg_min, monkeypatch):
     """zh_nice_paint_mix_stereo_batch: n consecutive paints in one launch (state in registers from buffer to buffer, one
     second pass) -- bit for bit the mixes and the final state of the n separate calls, with notes going on and off, a new note
     and a frequency change between buffers, ZERO_FIRST and `+=`, and a sub-span."""
-    if wg_min == "wg8":
-        monkeypatch.setenv("ZH_NICE_MIX_WG8_MIN", "0")
-    elif wg_min is not None:
-        monkeypatch.setenv("ZH_NICE_MIX_WG_MIN", wg_min)
+    if wg_min is not None:
+        util.set_form(monkeypatch, nice_mix_wg_min=wg_min)
     import torch
     from zang_amd import modules as mod, zang, workloads
     freq, color, u2, _ = workloads.voice_params(5, 3, V)

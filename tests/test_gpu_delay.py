@@ -23,7 +23,7 @@ def test_simple_delay(ctx, oracle, D, zero_first, form, monkeypatch):
     per-voice walk.)"""
     from zang_amd import modules as mod, zang
     if form == "walk":
-        monkeypatch.setenv("ZH_DELAY_FRAMES_MAX", "0")
+        util.set_form(monkeypatch, delay_frames_max="0")
     V = 96
     inp = [util.rng_buffers(10 + k, V, F) for k in range(len(SPANS))]
     out0 = util.rng_buffers(3, V, F)
@@ -82,7 +82,7 @@ def test_filtered_echoes(ctx, oracle, D, zero_first, form, monkeypatch):
     ZH_ECHOES_PC_MAX=0 is the one-wave walk.)"""
     from zang_amd import modules as mod, zang
     if form == "walk":
-        monkeypatch.setenv("ZH_ECHOES_PC_MAX", "0")
+        util.set_form(monkeypatch, echoes_pc_max="0")
     V = 96
     rng = np.random.default_rng(4)
     fb = rng.uniform(0.1, 0.9, V).astype(np.float32); cutoff = rng.uniform(0.05, 1.0, V).astype(np.float32)

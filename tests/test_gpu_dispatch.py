@@ -459,7 +459,33 @@ CASES = {
 }
 
 # every limit a form is selected by (zh_range_frames callers, ZH_*_PC*_MAX defaults, noise_jump.hip), and just past the last
-BOUNDARY_VOICES = [16384, 16448, 24576, 32768, 32832, 40960, 41024, 49152, 65536, 65600, 131072, 131136]
+def _table_rows():
+    """the library's dispatch table (csrc/dispatch.hip) through the C ABI: {name: default}; loads without a GPU"""
+    from zang_amd import abi
+    lib = abi.load()
+    rows = {}
+    for i in range(lib.zh_form_count()):
+        name, doc, d, c = C.c_char_p(), C.c_char_p(), C.c_long(), C.c_long()
+        assert lib.zh_form_info(i, C.byref(name), C.byref(d), C.byref(c), C.byref(doc)) == 0
+        rows[name.value.decode()] = d.value
+    return rows
+
+
+def _boundary_voices():
+    """Every voice-count threshold of the table (`*_max` / `*_min` rows between 16,384 and 131,072) and one wave past it, plus the
+    voice limits of the frame-range forms (arguments of zh_range_frames at the call sites: 16,384 / 32,768 / 40,960 / 65,536 /
+    131,072) and two counts between thresholds."""
+    vs = set()
+    for name, d in _table_rows().items():
+        if (name.endswith("_max") or name.endswith("_min")) and 16384 <= d <= 131072:
+            vs.update((d, d + 64))
+    for d in (16384, 32768, 40960, 65536, 131072):
+        vs.update((d, d + 64))
+    vs.update((24576, 49152))
+    return sorted(vs)
+
+
+BOUNDARY_VOICES = _boundary_voices()
 
 
 @pytest.mark.parametrize("V", BOUNDARY_VOICES)
@@ -477,25 +503,25 @@ def test_default_forms_equal_the_oracle_at_dispatch_boundaries(ctx, oracle, V, m
 
 FORCED = [
     # (switches, cases they matter for): geometries that only large voice counts reach, at 333 voices, every voice checked
-    ({"ZH_NOISE_RANGES": "2"}, ["noise_white", "noise_white_add", "noise_pink"]),
-    ({"ZH_NOISE_RANGES": "3"}, ["noise_white", "noise_white_add", "noise_pink"]),
-    ({"ZH_NOISE_RANGES": "0"}, ["noise_white", "noise_pink", "noise_filter_white"]),
-    ({"ZH_PINK_TAPS": "16", "ZH_NOISE_RANGES": "2"}, ["noise_pink"]),
-    ({"ZH_FILTER_PC_MAX": "1"}, ["filter_lowpass_const", "filter_bandpass_const"]),           # 16-frame tiles (ZH_FILTER_PC16_MAX default)
-    ({"ZH_FILTER_PC_MAX": "0"}, ["filter_lowpass_const", "filter_bandpass_const"]),           # the one-wave walk
-    ({"ZH_DECIMATOR_RANGES": "2"}, ["decimator"]), ({"ZH_DECIMATOR_RANGES": "3"}, ["decimator"]),
-    ({"ZH_CURVE_RANGES": "2"}, ["curve_linear", "curve_smoothstep"]), ({"ZH_CURVE_RANGES": "3"}, ["curve_linear", "curve_smoothstep"]),
-    ({"ZH_ENVELOPE_RANGES": "2"}, ["envelope"]), ({"ZH_ENVELOPE_RANGES": "3"}, ["envelope"]),
-    ({"ZH_PORTAMENTO_RANGES": "2"}, ["portamento"]), ({"ZH_PORTAMENTO_RANGES": "5"}, ["portamento"]),
-    ({"ZH_CYCLE_RANGES": "2"}, ["cycle_const"]), ({"ZH_CYCLE_RANGES": "3"}, ["cycle_const", "cycle_image"]),
-    ({"ZH_SINE_RANGES": "2"}, ["sineosc_const", "sineosc_image"]), ({"ZH_SINE_RANGES": "3"}, ["sineosc_const", "sineosc_image"]),
-    ({"ZH_SAMPLER_RANGES": "2"}, ["sampler"]), ({"ZH_SAMPLER_RANGES": "3"}, ["sampler"]),
-    ({"ZH_PULSE_CTRL_RANGES": "2"}, ["pulse_image"]), ({"ZH_PULSE_CTRL_RANGES": "3", "ZH_PULSE_CTRL_SUMS": "0"}, ["pulse_image"]),
-    ({"ZH_TRISAW_CTRL_RANGES": "2"}, ["trisaw_image"]), ({"ZH_TRISAW_CTRL_RANGES": "3", "ZH_TRISAW_CTRL_QUOT": "0"}, ["trisaw_image"]),
-    ({"ZH_PMOSC_RANGES": "2"}, ["pmosc"]), ({"ZH_PMOSC_RANGES": "3"}, ["pmosc"]),
-    ({"ZH_NICE_PC4_MAX": "0"}, ["nice"]), ({"ZH_NICE_PC_MAX": "0"}, ["nice"]),
-    ({"ZH_NF_RING_MAX": "0"}, ["noise_filter_white"]), ({"ZH_NF_RING_MAX": "0", "ZH_NF_PC_MAX": "0"}, ["noise_filter_white", "noise_filter_pink"]),
-    ({"ZH_ECHOES_PC_MAX": "0"}, ["filtered_echoes"]), ({"ZH_DELAY_FRAMES_MAX": "0"}, ["simple_delay"]),
+    ({"noise_ranges": "2"}, ["noise_white", "noise_white_add", "noise_pink"]),
+    ({"noise_ranges": "3"}, ["noise_white", "noise_white_add", "noise_pink"]),
+    ({"noise_ranges": "0"}, ["noise_white", "noise_pink", "noise_filter_white"]),
+    ({"pink_taps": "16", "noise_ranges": "2"}, ["noise_pink"]),
+    ({"filter_pc_max": "1"}, ["filter_lowpass_const", "filter_bandpass_const"]),           # 16-frame tiles (ZH_FILTER_PC16_MAX default)
+    ({"filter_pc_max": "0"}, ["filter_lowpass_const", "filter_bandpass_const"]),           # the one-wave walk
+    ({"decimator_ranges": "2"}, ["decimator"]), ({"decimator_ranges": "3"}, ["decimator"]),
+    ({"curve_ranges": "2"}, ["curve_linear", "curve_smoothstep"]), ({"curve_ranges": "3"}, ["curve_linear", "curve_smoothstep"]),
+    ({"envelope_ranges": "2"}, ["envelope"]), ({"envelope_ranges": "3"}, ["envelope"]),
+    ({"portamento_ranges": "2"}, ["portamento"]), ({"portamento_ranges": "5"}, ["portamento"]),
+    ({"cycle_ranges": "2"}, ["cycle_const"]), ({"cycle_ranges": "3"}, ["cycle_const", "cycle_image"]),
+    ({"sine_ranges": "2"}, ["sineosc_const", "sineosc_image"]), ({"sine_ranges": "3"}, ["sineosc_const", "sineosc_image"]),
+    ({"sampler_ranges": "2"}, ["sampler"]), ({"sampler_ranges": "3"}, ["sampler"]),
+    ({"pulse_ctrl_ranges": "2"}, ["pulse_image"]), ({"pulse_ctrl_ranges": "3", "pulse_ctrl_sums": "0"}, ["pulse_image"]),
+    ({"trisaw_ctrl_ranges": "2"}, ["trisaw_image"]), ({"trisaw_ctrl_ranges": "3", "trisaw_ctrl_quot": "0"}, ["trisaw_image"]),
+    ({"pmosc_ranges": "2"}, ["pmosc"]), ({"pmosc_ranges": "3"}, ["pmosc"]),
+    ({"nice_pc4_max": "0"}, ["nice"]), ({"nice_pc_max": "0"}, ["nice"]),
+    ({"nf_ring_max": "0"}, ["noise_filter_white"]), ({"nf_ring_max": "0", "nf_pc_max": "0"}, ["noise_filter_white", "noise_filter_pink"]),
+    ({"echoes_pc_max": "0"}, ["filtered_echoes"]), ({"delay_frames_max": "0"}, ["simple_delay"]),
 ]
 
 
@@ -506,7 +532,7 @@ def test_forced_large_voice_count_geometries_at_a_small_voice_count(ctx, oracle,
         if name.startswith("ZH_") and name not in ("ZH_ENV_LIVE",):
             monkeypatch.delenv(name)
     for n, v in env.items():
-        monkeypatch.setenv(n, v)
+        util.set_form(monkeypatch, **{n: v})
     V = 333
     sh = Shared(ctx, V, np.arange(V, dtype=np.int64))
     for name in names:

@@ -276,9 +276,9 @@ def test_frame_range_forms_at_mid_voice_counts(ctx, oracle, monkeypatch, V):
         return outs, states
 
     a_out, a_st = render()
-    for name in ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_PMOSC_RANGES", "ZH_ENVELOPE_RANGES", "ZH_DECIMATOR_RANGES",
-                 "ZH_TRISAW_CTRL_RANGES", "ZH_FILTER_PC_MAX", "ZH_ECHOES_PC_MAX", "ZH_DELAY_FRAMES_MAX", "ZH_NICE_PC_MAX", "ZH_NICE_PC4_MAX"):
-        monkeypatch.setenv(name, "0")
+    for name in ("sine_ranges", "sampler_ranges", "pulse_ctrl_ranges", "pmosc_ranges", "envelope_ranges", "decimator_ranges",
+                 "trisaw_ctrl_ranges", "filter_pc_max", "echoes_pc_max", "delay_frames_max", "nice_pc_max", "nice_pc4_max"):
+        util.set_form(monkeypatch, **{name: 0})
     b_out, b_st = render()
     names = ("sineosc const", "sineosc image", "sampler", "pulseosc image", "pmosc", "envelope", "decimator", "filter", "filtered echoes",
              "simple delay", "nice", "trisawosc image")

@@ -496,9 +496,9 @@ def test_fuzz_again_with_the_single_wave_forms():
     if os.environ.get("ZH_FUZZ_CHILD"):
         pytest.skip("already the rerun")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZH_NICE_PC_MAX="0", ZH_NF_PC_MAX="0", ZH_NF_RING_MAX="0", ZH_NOISE_RANGES="0", ZH_SINE_RANGES="0",
-               ZH_SAMPLER_RANGES="0", ZH_PINK_TAPS="0", ZH_DECIMATOR_RANGES="0", ZH_ENVELOPE_RANGES="0", ZH_PORTAMENTO_RANGES="0", ZH_PULSE_CTRL_RANGES="0", ZH_TRISAW_CTRL_RANGES="0", ZH_PINK_PIPE_MAX="0", ZH_FILTER_PC_MAX="0", ZH_ECHOES_PC_MAX="0",
-               ZH_FUZZ_CHILD="1")
+    env = util.forms_env(nice_pc_max=0, nf_pc_max=0, nf_ring_max=0, noise_ranges=0, sine_ranges=0, sampler_ranges=0, pink_taps=0, decimator_ranges=0,
+                         envelope_ranges=0, portamento_ranges=0, pulse_ctrl_ranges=0, trisaw_ctrl_ranges=0, pink_pipe_max=0, filter_pc_max=0, echoes_pc_max=0)
+    env["ZH_FUZZ_CHILD"] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fuzz.py", "-q", "-m", "gpu"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     util.assert_rerun_green(r, 40)

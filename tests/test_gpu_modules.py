@@ -28,8 +28,8 @@ def _gcob(zang, kind, const_t, buf_t):
 
 
 # ------------------------------------------------------------------ SineOsc
-RANGE_SWITCHES = ("ZH_SINE_RANGES", "ZH_SAMPLER_RANGES", "ZH_DECIMATOR_RANGES", "ZH_ENVELOPE_RANGES",
-                  "ZH_PORTAMENTO_RANGES", "ZH_TRISAW_CTRL_RANGES", "ZH_PULSE_CTRL_RANGES", "ZH_CYCLE_RANGES", "ZH_CURVE_RANGES")
+RANGE_SWITCHES = ("sine_ranges", "sampler_ranges", "decimator_ranges", "envelope_ranges",
+                  "portamento_ranges", "trisaw_ctrl_ranges", "pulse_ctrl_ranges", "cycle_ranges", "curve_ranges")
 
 
 @pytest.fixture(params=["ranges", "sequential"])
@@ -39,7 +39,7 @@ def replay_form(request, monkeypatch):
     oracle's bits (the library reads the variables at every paint)."""
     if request.param == "sequential":
         for name in RANGE_SWITCHES:
-            monkeypatch.setenv(name, "0")
+            util.set_form(monkeypatch, **{name: 0})
     return request.param
 
 
@@ -262,11 +262,11 @@ def test_noise_pink_pipeline(ctx, oracle, zero_first, V, form, monkeypatch):
     the lane-per-voice kernel."""
     from zang_amd import modules as mod, zang
     if form == "sequential":
-        monkeypatch.setenv("ZH_PINK_PIPE_MAX", "0")
+        util.set_form(monkeypatch, pink_pipe_max="0")
     elif form == "chain":
-        monkeypatch.setenv("ZH_PINK_TAPS", "0")                   # the seven-stage chain k_pink_pipe instead of the four-wave k_pink_taps
+        util.set_form(monkeypatch, pink_taps="0")                   # the seven-stage chain k_pink_pipe instead of the four-wave k_pink_taps
     elif form == "taps16":
-        monkeypatch.setenv("ZH_PINK_TAPS", "16")                  # k_pink_taps with the 16-frame tiles it takes above 16,384 voices
+        util.set_form(monkeypatch, pink_taps="16")                  # k_pink_taps with the 16-frame tiles it takes above 16,384 voices
     first = 777
     rng = np.random.default_rng(78)
     L = oracle.lib()
@@ -392,9 +392,9 @@ def test_filter_const_params_both_forms(ctx, oracle, ftype, zero_first, form, mo
     ragged spans (a span shorter than 64 frames takes the walk anyway), a voice count that is not a multiple of 64, carried state."""
     from zang_amd import modules as mod, zang
     if form == "walk":
-        monkeypatch.setenv("ZH_FILTER_PC_MAX", "0")
+        util.set_form(monkeypatch, filter_pc_max="0")
     elif form == "pipeline16":
-        monkeypatch.setenv("ZH_FILTER_PC_MAX", "1")
+        util.set_form(monkeypatch, filter_pc_max="1")
     V = 200
     rng = np.random.default_rng(54)
     cut = rng.uniform(-0.1, 1.1, V).astype(np.float32)
@@ -466,7 +466,7 @@ def test_filter_control_images_both_forms(ctx, oracle, ftype, ck, rk, zero_first
     that is not a multiple of 64, += and ZERO_FIRST, carried state."""
     from zang_amd import modules as mod, zang
     if form == "walk":
-        monkeypatch.setenv("ZH_FILTER_PC_CTL_MAX", "0")
+        util.set_form(monkeypatch, filter_pc_ctl_max="0")
     V = 200
     rng = np.random.default_rng(57)
     cut = rng.uniform(-0.1, 1.1, V).astype(np.float32); res = rng.uniform(-0.1, 1.1, V).astype(np.float32)

@@ -80,8 +80,8 @@ def test_controlled_freq(ctx, oracle, kind, colors, spans, form, monkeypatch):
     """(Both oscillators at a small voice count paint a controlled-frequency span as frame ranges at once, each range first
     summing the earlier frames' phase increments; ZH_PULSE_CTRL_RANGES=0 / ZH_TRISAW_CTRL_RANGES=0 is the lane-per-voice walk.)"""
     if form == "sequential":
-        monkeypatch.setenv("ZH_PULSE_CTRL_RANGES", "0")
-        monkeypatch.setenv("ZH_TRISAW_CTRL_RANGES", "0")
+        util.set_form(monkeypatch, pulse_ctrl_ranges="0")
+        util.set_form(monkeypatch, trisaw_ctrl_ranges="0")
     V, F = 192, 1024
     rng = np.random.default_rng(11)
     freq_buf = rng.uniform(-200.0, 7000.0, (V, F)).astype(np.float32)   # includes out-of-range samples

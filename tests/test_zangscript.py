@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import zangscript as zs
+from tests import util
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCRIPT = open(os.path.join(HERE, "golden", "script_modules.txt")).read()
@@ -694,9 +695,9 @@ def _script_ranges_equal_sequential(ctx, name, nv, monkeypatch):
         nic = rng.random(nv) < 0.3
         dev = {kk: _device_value(None, vv) for kk, vv in vals.items()}
         nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda()
-        monkeypatch.setenv("ZH_SCRIPT_RANGES", "0")
+        util.set_form(monkeypatch, script_ranges="0")
         a.paint(zang.Span(s, e), [img_a], None, nic_dev, dev, zero_first=zf)
-        monkeypatch.delenv("ZH_SCRIPT_RANGES")
+        util.del_form(monkeypatch, "script_ranges")
         b.paint(zang.Span(s, e), [img_b], None, nic_dev, dev, zero_first=zf)
         ctx.sync()
         assert torch.equal(img_a.view(torch.int32), img_b.view(torch.int32)), f"{name}: image differs after paint {k}"
@@ -729,9 +730,9 @@ def test_gpu_script_envelope_stage_ends_inside_replays(ctx, ranges, monkeypatch)
     from tests.util import assert_bitexact, from_image, to_image
     from zang_amd import script, zang
     if ranges is None:
-        monkeypatch.delenv("ZH_SCRIPT_RANGES", raising=False)
+        util.del_form(monkeypatch, "script_ranges")
     else:
-        monkeypatch.setenv("ZH_SCRIPT_RANGES", ranges)
+        util.set_form(monkeypatch, script_ranges=ranges)
     nv, nf = 70, 512
     prog = script.ScriptProgram(STAGES_SCRIPT, ctx, only=["Stages"])
     mod = prog.module("Stages", nv, 0)
@@ -769,9 +770,9 @@ def test_gpu_script_in_place_param_image_keeps_one_walk(ctx, ranges, monkeypatch
     from tests.util import assert_bitexact, from_image, to_image
     from zang_amd import script, zang
     if ranges is None:
-        monkeypatch.delenv("ZH_SCRIPT_RANGES", raising=False)
+        util.del_form(monkeypatch, "script_ranges")
     else:
-        monkeypatch.setenv("ZH_SCRIPT_RANGES", ranges)
+        util.set_form(monkeypatch, script_ranges=ranges)
     nv, nf = 200, 512
     prog = script.ScriptProgram(STAGES_SCRIPT, ctx, only=["Stages"])
     mod = prog.module("Stages", nv, 0)

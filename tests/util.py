@@ -92,3 +92,46 @@ def assert_peak_close(gpu, ref, what="", rtol=RTOL, s=None, e=None, scale_extra=
     worst = int(np.argmax(ratio))
     assert ratio[worst] <= rtol, f"{what}: voice {worst} is off by {ratio[worst]:.3e} of its peak (allowed {rtol:g})"
     return float(ratio[worst])
+
+
+# ---- the library's dispatch table (csrc/dispatch.hip): rows are overridden through ONE environment variable, ZH_FORMS="name=value,..."
+def _forms_now():
+    import os
+    out = {}
+    for item in os.environ.get("ZH_FORMS", "").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            out[k.strip()] = v.strip()
+    return out
+
+
+def _forms_text(rows):
+    return ",".join(f"{k}={v}" for k, v in rows.items())
+
+
+def set_form(monkeypatch, **rows):
+    """Override rows of the dispatch table for the rest of the test (the library re-reads ZH_FORMS at every paint under
+    ZH_ENV_LIVE=1, tests/conftest.py): set_form(monkeypatch, sine_ranges=0, nice_pc_max=0)."""
+    cur = _forms_now()
+    cur.update({k: str(v) for k, v in rows.items()})
+    monkeypatch.setenv("ZH_FORMS", _forms_text(cur))
+
+
+def del_form(monkeypatch, *names):
+    cur = _forms_now()
+    for n in names:
+        cur.pop(n, None)
+    if cur:
+        monkeypatch.setenv("ZH_FORMS", _forms_text(cur))
+    else:
+        monkeypatch.delenv("ZH_FORMS", raising=False)
+
+
+def forms_env(base=None, **rows):
+    """An environment for a child process with the given rows overridden (on top of whatever ZH_FORMS holds now)."""
+    import os
+    env = dict(os.environ if base is None else base)
+    cur = _forms_now()
+    cur.update({k: str(v) for k, v in rows.items()})
+    env["ZH_FORMS"] = _forms_text(cur)
+    return env

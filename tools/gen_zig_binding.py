@@ -24,7 +24,7 @@ HEADER = os.path.join(ROOT, "include", "zang_hip.h")
 OUT = os.path.join(ROOT, "bindings", "zang_hip.zig")
 
 SCALARS = {"int": "c_int", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "uint8_t": "u8", "float": "f32", "double": "f64",
-           "size_t": "usize", "char": "u8"}
+           "size_t": "usize", "char": "u8", "long": "c_long"}
 WORDS = {"sineosc": "SineOsc", "pulseosc": "PulseOsc", "trisawosc": "TriSawOsc", "pmosc": "PMOsc", "f32": "F32", "cob": "Cob",
          "hcob": "HCob", "hcurve": "HCurve", "iap": "Iap", "zscript": "ZScript", "ipc": "Ipc"}
 
@@ -56,7 +56,7 @@ MANY_SPECIAL = {("zh_script_module_paint", "params"), ("zh_polyphony_dispatcher_
                 # the batch call reads n_buffers elements of each
                 ("zh_nice_paint_mix_stereo_batch", "note_id_changed"), ("zh_nice_paint_mix_stereo_batch", "params")}
 # scalar pointer parameters that are a single out value, not an array
-ONE_SCALAR = {"ms", "state_words", "noise_fields", "n_params", "num_temps", "code_size_out"}
+ONE_SCALAR = {"ms", "state_words", "noise_fields", "n_params", "num_temps", "code_size_out", "default_value", "current_value"}
 
 
 def camel(name):
@@ -177,6 +177,8 @@ def zig_type(ctype, model, name="", func="", field=False):
         return "[*]const ?[*]f32"
     if t == "char * *":
         return "*?[*:0]u8"
+    if t == "const char * *":
+        return "?*?[*:0]const u8"
     if t == "void * *":
         return "*?*anyopaque"
     m = re.match(r"^(const )?(\w+) \*$", t)

@@ -1,4 +1,4 @@
 for v in 4096 16384 32768 65536 131072; do for mx in 0 1000000; do
-  r=$(ZH_NF_PC_MAX=$mx python bench.py --workload noise_filter_fused --voices $v --steps 50 --warmup 10 --no-cpu 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step']*1e3,1), 'us parity', (d.get('parity') or {}).get('bitexact'))")
+  r=$(ZH_FORMS=nf_pc_max=$mx python bench.py --workload noise_filter_fused --voices $v --steps 50 --warmup 10 --no-cpu 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step']*1e3,1), 'us parity', (d.get('parity') or {}).get('bitexact'))")
   echo "V=$v pc_max=$mx: $r"
 done; done

@@ -278,6 +278,9 @@ SIGNATURES = {
     "zh_buf_download_voices": (C.c_int, [vp, vp, Buf, u32]),
     "zh_buf_upload_voice": (C.c_int, [vp, Buf, u32, vp, u32]),
     "zh_buf_download_voice": (C.c_int, [vp, vp, Buf, u32, u32]),
+    "zh_form_count": (C.c_int, []),
+    "zh_form_info": (C.c_int, [C.c_int, P(C.c_char_p), P(C.c_long), P(C.c_long), P(C.c_char_p)]),
+    "zh_last_form": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "zh_graph_begin_capture": (C.c_int, [vp]),
     "zh_graph_begin_capture_flags": (C.c_int, [vp, C.c_uint32]),
     "zh_graph_info": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]),

@@ -86,8 +86,8 @@ static int launch_ew(zh_ctx *ctx, uint32_t start, uint32_t end, const zh_buf &de
     const uint64_t total = (uint64_t)nframes * nvq;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;   // 16 workgroups per CU, grid-stride the rest
-    if (vec) hipLaunchKernelGGL((k_elementwise<OP, 4>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
-    else hipLaunchKernelGGL((k_elementwise<OP, 1>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
+    if (vec) ZH_LAUNCH((k_elementwise<OP, 4>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
+    else ZH_LAUNCH((k_elementwise<OP, 1>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
     return zh_launch_status();
 }
 
@@ -298,7 +298,7 @@ int zh_mix_reserve(zh_ctx *ctx, size_t floats) { ZH_GUARD(ctx);
 }
 
 void zh_mix_pass2_launch_at(zh_ctx *ctx, const float *partials, uint32_t tiles, uint32_t nframes, float *dst, int zero_first) {
-    hipLaunchKernelGGL(k_mix_pass2, dim3((nframes + 63) / 64), dim3(64 * MIX_SEG), 0, ctx->stream, partials, tiles,
+    ZH_LAUNCH(k_mix_pass2, dim3((nframes + 63) / 64), dim3(64 * MIX_SEG), 0, ctx->stream, partials, tiles,
                        nframes, dst, zero_first);
 }
 // channels = 1 or 2 (dst1 unused for 1): partials[channel][row][frame], rows summed in row order
@@ -306,7 +306,7 @@ void zh_mix_pass2_wide_batch_launch(zh_ctx *ctx, const float *partials, size_t c
                                     float *const *dst0, float *const *dst1, uint32_t n_buffers, int channels, int zero_first) {
     MixDst d;
     for (int k = 0; k < kMixMaxBatch; k++) { d.l[k] = (uint32_t)k < n_buffers ? dst0[k] : nullptr; d.r[k] = ((uint32_t)k < n_buffers && dst1) ? dst1[k] : nullptr; }
-    hipLaunchKernelGGL(k_mix_pass2_wide, dim3((nframes + MIXW_F - 1) / MIXW_F, channels, n_buffers), dim3(MIXW_SEG * MIXW_F), 0, ctx->stream, partials,
+    ZH_LAUNCH(k_mix_pass2_wide, dim3((nframes + MIXW_F - 1) / MIXW_F, channels, n_buffers), dim3(MIXW_SEG * MIXW_F), 0, ctx->stream, partials,
                        channel_stride, rows, nframes, d, zero_first);
 }
 void zh_mix_pass2_wide_launch(zh_ctx *ctx, const float *partials, size_t channel_stride, uint32_t rows, uint32_t nframes, float *dst0,
@@ -336,7 +336,7 @@ int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_
     const uint32_t V = src.voices, nframes = end - start;
     if (nframes == 0) return ZH_OK;
     if (flags & ZH_MIX_SEQUENTIAL) {
-        hipLaunchKernelGGL(k_mix_sequential, dim3((nframes + 63) / 64), dim3(64), 0, ctx->stream, mk_cimg(src), V, start, end,
+        ZH_LAUNCH(k_mix_sequential, dim3((nframes + 63) / 64), dim3(64), 0, ctx->stream, mk_cimg(src), V, start, end,
                            dst, (int)(flags & ZH_PAINT_ZERO_FIRST));
         return zh_launch_status();
     }
@@ -346,9 +346,9 @@ int zh_mixdown_voices(zh_ctx *ctx, uint32_t start, uint32_t end, float *dst, zh_
         if (rc) return rc;
         dim3 grid(tiles, (nframes + MIX_FPB - 1) / MIX_FPB);
         if (src.stride % 4 == 0 && aligned16(src.ptr))
-            hipLaunchKernelGGL(k_mix_pass1, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
+            ZH_LAUNCH(k_mix_pass1, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
         else
-            hipLaunchKernelGGL(k_mix_pass1_scalar, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
+            ZH_LAUNCH(k_mix_pass1_scalar, grid, dim3(256), 0, ctx->stream, mk_cimg(src), V, start, end, ctx->mix_partials);
     }
     zh_mix_pass2_launch(ctx, tiles, nframes, dst + start, (int)(flags & ZH_PAINT_ZERO_FIRST));
     return zh_launch_status();
@@ -361,7 +361,7 @@ int zh_mix_down(zh_ctx *ctx, uint8_t *dst, const float *mix, uint32_t n, uint32_
     if (!n) return ZH_OK;
     const int s16 = audio_format == ZH_AUDIO_SIGNED16_LSB;
     const float mul = vol * (s16 ? 32767.0f : 127.0f);                // mixdown.zig:37, :68
-    hipLaunchKernelGGL(k_mix_down, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dst, mix, n, s16, num_channels, channel_index, mul);
+    ZH_LAUNCH(k_mix_down, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dst, mix, n, s16, num_channels, channel_index, mul);
     return zh_launch_status();
 }
 

@@ -17,6 +17,7 @@
 #if !defined(ZH_DEVICE_ONLY)
 #include <vector>
 #include <functional>
+#include <string>
 // A module whose state is double-buffered and flips on the HOST at every paint (the chunked oscillators, osc.hip):
 // a captured graph bakes in both buffer pointers, so the library records which buffer a capture started from and
 // how many flips it holds, and zh_graph_launch reconciles the host-side index with that (ctx.hip).
@@ -63,6 +64,8 @@ struct zh_ctx {
     zh_co_batch co;
     std::vector<zh_epoch_pending> epoch_pending;
     uint32_t co_paints, co_launches;   // of the capture that is recording: paint calls held back, launches they became
+    std::string last_form;       // kernels launched by the last entry point on this context that launched any (zh_last_form)
+    bool form_fresh;             // the running entry point has not launched yet: its first launch starts the record afresh
     // scratch for the two-pass voice mixdown: [blocks][frames] partial sums.  Blocks are never freed while the
     // context lives: a captured graph keeps the pointer it was recorded with (basics.hip zh_mix_reserve).
     float *mix_partials;
@@ -99,7 +102,16 @@ struct ZhDeviceGuard {
 // (ZH_GUARD also ends the open epoch of a coalescing capture: whatever the entry point records is ordered after every paint
 // recorded so far.  The oscillator paints, which may join the epoch instead, use ZH_GUARD_EPOCH.)
 void zh_epoch_barrier(zh_ctx *ctx);
-#define ZH_GUARD_EPOCH(ctxptr) const zh_ctx *_zh_gctx = (ctxptr); ZhDeviceGuard _zh_guard(_zh_gctx ? _zh_gctx->device : -1)
+extern thread_local zh_ctx *zh_tls_ctx;      // the context of the entry point that is running on this thread (dispatch bookkeeping)
+struct ZhFormScope {                         // (entry points call entry points: only the outermost one starts a new record)
+    zh_ctx *prev;
+    explicit ZhFormScope(const zh_ctx *c) : prev(zh_tls_ctx) {
+        if (!prev) { zh_tls_ctx = const_cast<zh_ctx *>(c); if (zh_tls_ctx) zh_tls_ctx->form_fresh = true; }
+    }
+    ~ZhFormScope() { zh_tls_ctx = prev; }
+};
+#define ZH_GUARD_EPOCH(ctxptr) const zh_ctx *_zh_gctx = (ctxptr); ZhDeviceGuard _zh_guard(_zh_gctx ? _zh_gctx->device : -1); ZhFormScope _zh_fscope(_zh_gctx)
+#define ZH_LAUNCH(kernel, ...) do { zh_note_launch(zh_tls_ctx, #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
 #define ZH_GUARD(ctxptr) ZH_GUARD_EPOCH(ctxptr); do { if (_zh_gctx && _zh_gctx->epoch_open) zh_epoch_barrier(const_cast<zh_ctx *>(_zh_gctx)); } while (0)
 // ctx.hip: launch the batch that is held back (if any); the epoch stays open (counters unpublished)
 void zh_epoch_flush_batch(zh_ctx *ctx);
@@ -113,11 +125,21 @@ void zh_flipper_unregister(zh_flipper *f);
 void zh_flipper_used(zh_flipper *f);         // call at the start of EVERY paint of a flipper module (in-place forms too)
 void zh_flipper_painted(zh_flipper *f);      // call right BEFORE flipping f->cur in a paint
 
-// ctx.hip: frames per range for a kernel that paints a span as several frame ranges at once, each replaying the cheap state
-// walk of the frames before it (0 = paint sequentially).  `env_name` = number of ranges, 0 = never; `target_waves` = waves
-// the launch should reach (ranges = target_waves / waves of one range); `max_voices` = above it the sequential form wins.
-const char *zh_env(const char *name);       // getenv for the form switches read on the paint path: cached unless ZH_ENV_LIVE=1 (ctx.hip)
-uint32_t zh_range_frames(uint32_t V, uint32_t n, const char *env_name, uint32_t target_waves, uint32_t max_voices);
+// dispatch.hip: the ONE table of form-selecting thresholds and range counts (rows in the order of this enum); zh_form = a row's
+// value (its default, or the ZH_FORMS override); zh_range_frames = frames per range for a kernel that paints a span as several
+// frame ranges at once, each replaying the cheap state walk of the frames before it (0 = paint sequentially): row `form` = number
+// of ranges (-1 auto, 0 never); `target_waves` = waves the launch should reach; `max_voices` = above it the sequential form wins.
+enum { ZF_SINE_RANGES, ZF_NOISE_RANGES, ZF_ENVELOPE_RANGES, ZF_SAMPLER_RANGES, ZF_DECIMATOR_RANGES, ZF_CURVE_RANGES, ZF_CYCLE_RANGES,
+       ZF_PORTAMENTO_RANGES, ZF_PULSE_CTRL_RANGES, ZF_PULSE_CTRL_SUMS, ZF_TRISAW_CTRL_RANGES, ZF_TRISAW_CTRL_QUOT, ZF_PMOSC_RANGES,
+       ZF_SCRIPT_RANGES, ZF_SCRIPT_RANGES_MAXV, ZF_OSC_FC, ZF_NICE_PC_MAX, ZF_NICE_PC4_MAX, ZF_NICE_WAVE_MAX, ZF_PMOSC_WAVE_MAX,
+       ZF_NICE_MIX_ROLL, ZF_NICE_MIX_WG_MIN, ZF_NF_PC_MAX, ZF_NF_RING_MAX, ZF_FILTER_PC_MAX, ZF_FILTER_PC16_MAX, ZF_FILTER_PC_CTL_MAX,
+       ZF_PINK_PIPE_MAX, ZF_PINK_TAPS, ZF_ECHOES_PC_MAX, ZF_DELAY_FRAMES_MAX, ZF_FILTER_TP_MAX, ZF_NF_TP_MAX, ZF_NICE_TP_MAX,
+       ZF_PINK_TP_MAX, ZF_ECHOES_TP_MAX, ZF_COUNT };
+long zh_form(int id);
+bool zh_form_is_set(int id);                 // the row is overridden through ZH_FORMS
+uint32_t zh_range_frames(uint32_t V, uint32_t n, int form, uint32_t target_waves, uint32_t max_voices);
+// every kernel launch of the library: notes the kernel's name in the context of the entry point that is running (zh_last_form)
+void zh_note_launch(zh_ctx *ctx, const char *kernel);
 
 // frames per group of the fused mixdown's partial layout [channel][frame / G][row][frame % G] (composite.hip writes, basics.hip
 // k_mix_pass2_wide reads: one second-pass workgroup per group and channel)

@@ -199,24 +199,11 @@ __device__ __forceinline__ void nice_store(NiceLaneT<W> &n, const NiceArgs &a, u
     zstore_f<W>(a.elast, v, n.env.last_value); zstore_f<W>(a.estart, v, n.env.start);
 }
 
-// Two voices per lane (W = 2, lanes.hip.h) is built and parity-tested but NOT the default: measured on
-// MI355X it is slower at every voice count (131,072 voices: 211 us vs 182 us; 1 Mi voices: 1296 us vs
-// 1222 us).  tools/ubench/valu_ops.hip shows why: a v_pk_*_f32 costs 4.2 issue cycles per SIMD against
-// 2.5 for a plain v_add/v_mul/v_sub_f32, so packing saves ~15 % on the arithmetic while every compare
-// and select (4.2 cycles each, no packed form) is paid twice.  ZH_NICE_W=2 selects it for A/B timing;
-// it needs an even voice count and 8-byte aligned rows / per-voice arrays.
-static uint32_t nice_pc_max() {
-    const char *e = zh_env("ZH_NICE_PC_MAX");
-    const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u;   // 72 vs 146 us at 4,096 voices, 107 vs 168 at 65,536; slower at 131,072
-    return v;
-}
-static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
-static bool nice_pairable(const NiceArgs &a) {
-    const char *we = zh_env("ZH_NICE_W");
-    const bool want2 = we && we[0] == '2';
-    return want2 && a.V % 2 == 0 && aligned8(a.freq.pv) && aligned8(a.color) && aligned8(a.cnt) && aligned8(a.fl) && aligned8(a.fb) &&
-           aligned8(a.estate) && aligned8(a.et) && aligned8(a.elast) && aligned8(a.estart);
-}
+// (Two voices per lane -- W = 2, lanes.hip.h: packed f32 arithmetic -- was built and parity-tested through round 4 and slower at
+// every voice count: 131,072 voices 211 us vs 182, 1 Mi voices 1296 vs 1222; tools/ubench/valu_ops.hip shows why: a v_pk_*_f32
+// costs 4.2 issue cycles per SIMD against 2.5 for a plain op, and every compare and select is paid twice.  Its dispatch and
+// its switch are gone (round 5); the W-generic per-sample code stays.)
+static uint32_t nice_pc_max() { return (uint32_t)zh_form(ZF_NICE_PC_MAX); }
 
 template <bool ZF, int W>
 __global__ void __launch_bounds__(kSeqBlock) k_nice(NiceArgs a, Img out, uint32_t start, uint32_t end) {
@@ -1795,7 +1782,7 @@ int zh_nice_create(zh_ctx *ctx, uint32_t n, zh_f32 color, zh_nice **out) { ZH_GU
     if (rc) { nice_free(m); delete m; return rc; }
     if (n) {
         hipStream_t st = ctx->stream;
-        hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->color, n, mk_f32(color));
+        ZH_LAUNCH(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->color, n, mk_f32(color));
         void *zeros[] = {m->cnt, m->fl, m->fb, m->estate, m->et, m->elast, m->estart};   // sub-module init()s
         for (void *z : zeros) { hipError_t e = hipMemsetAsync(z, 0, (size_t)n * 4, st); if (e != hipSuccess) { nice_free(m); delete m; return (int)e; } }
     }
@@ -1857,63 +1844,47 @@ int zh_nice_paint(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *output
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
     // ZH_PAINT_TOLERANT, few voices: the span as chunks at once, two passes (k_nice_tp_a / _b); spans of one launch pair
     if ((flags & ZH_PAINT_TOLERANT) && end - start >= 128 && end - start <= kNiceTpMaxChunks * 128u) {
-        const uint32_t C = zh_tp_chunks(m->n, "ZH_NICE_TP_MAX", end - start);
+        const uint32_t C = zh_tp_chunks(m->n, ZF_NICE_TP_MAX, end - start);
         if (C >= 2 && !m->tp && !m->ctx->capturing && dev_alloc(&m->tp, (size_t)kNiceTpWords * m->n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
         if (C >= 2 && m->tp) {
             NiceTpArgs t;
             t.a = a; t.tp = m->tp; t.start = start; t.end = end; t.L = ((end - start + C - 1) / C + 7) / 8 * 8; t.out = out;   // whole 8-frame groups per chunk
             const dim3 grid((m->n + 255) / 256, (end - start + t.L - 1) / t.L);
-            hipLaunchKernelGGL(k_nice_tp_a, grid, dim3(256), 0, st, t);
-            if (zf) hipLaunchKernelGGL(k_nice_tp_b<true>, grid, dim3(256), 0, st, t);
-            else hipLaunchKernelGGL(k_nice_tp_b<false>, grid, dim3(256), 0, st, t);
+            ZH_LAUNCH(k_nice_tp_a, grid, dim3(256), 0, st, t);
+            if (zf) ZH_LAUNCH(k_nice_tp_b<true>, grid, dim3(256), 0, st, t);
+            else ZH_LAUNCH(k_nice_tp_b<false>, grid, dim3(256), 0, st, t);
             return zh_launch_status();
         }
     }
-    if (nice_pairable(a) && aligned8(out.p) && out.stride % 2 == 0) {
-        const dim3 grid = seq_grid(m->n / 2);
-        if (zf) hipLaunchKernelGGL((k_nice<true, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
-        else hipLaunchKernelGGL((k_nice<false, 2>), grid, dim3(kSeqBlock), 0, st, a, out, start, end);
-    } else if (m->n <= nice_pc_max() && end > start && outputs[0].stride <= (1u << 24)) {   // (32-row tiles: 32-bit offsets)
+    if (m->n <= nice_pc_max() && end > start && outputs[0].stride <= (1u << 24)) {   // (32-row tiles: 32-bit offsets)
         // up to ZH_NICE_PC_MAX voices the three chains of a frame run in three waves side by side (k_nice_pc)
         // four waves (k_nice_pc4) up to ZH_NICE_PC4_MAX voices: 4,096 / 16,384 / 32,768 voices 44 / 47 / 53.5 us against 60.5 / 62.5 /
         // 63 for the three-wave form; its 64 KB of LDS per workgroup allow two workgroups per CU = 32,768 voices, beyond that
         // the three-wave form stays (65,536 voices: 82 us against 111)
-        const char *pe = zh_env("ZH_NICE_PC4_MAX");
-        const int pc4_max = pe ? atoi(pe) : 32768;
-        if (m->n <= (uint32_t)pc4_max) {
-            if (zf) hipLaunchKernelGGL(k_nice_pc4<true>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
-            else hipLaunchKernelGGL(k_nice_pc4<false>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
+        const long pc4_max = zh_form(ZF_NICE_PC4_MAX);
+        if ((long)m->n <= pc4_max) {
+            if (zf) ZH_LAUNCH(k_nice_pc4<true>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
+            else ZH_LAUNCH(k_nice_pc4<false>, seq_grid(m->n), dim3(256), 0, st, a, out, start, end);
         } else {
-            if (zf) hipLaunchKernelGGL(k_nice_pc<true>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
-            else hipLaunchKernelGGL(k_nice_pc<false>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
+            if (zf) ZH_LAUNCH(k_nice_pc<true>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
+            else ZH_LAUNCH(k_nice_pc<false>, seq_grid(m->n), dim3(192), 0, st, a, out, start, end);
         }
     } else {
-        if (zf) hipLaunchKernelGGL((k_nice<true, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
-        else hipLaunchKernelGGL((k_nice<false, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
+        if (zf) ZH_LAUNCH((k_nice<true, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
+        else ZH_LAUNCH((k_nice<false, 1>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, out, start, end);
     }
     return zh_launch_status();
 }
-static bool nice_mix_roll() {
-    const char *e = zh_env("ZH_NICE_MIX_ROLL");
-    const bool v = e ? atoi(e) != 0 : true;   // A/B switch: 149.6 vs 148.2 us at 131,072 voices, 908 vs 890 us at 1,048,576
-    return v;
-}
+static bool nice_mix_roll() { return zh_form(ZF_NICE_MIX_ROLL) != 0; }   // 149.6 vs 148.2 us at 131,072 voices, 908 vs 890 us at 1,048,576
 // One partial row per workgroup (a barrier per chunk in the sum phase) or one per wave.  A/B on one box (tools/ab_env.sh,
 // profiles/r04/ab_nice_mix_wg.txt): 131,072 voices 108.45 -> 108.35 us per buffer all-in (0.6 us in an earlier comparison) with a quarter of
 // the partial traffic; 4,096 voices 99.3 -> 104.6 (sixteen workgroups on 256 CUs: the barrier couples waves that otherwise run at their own pace).
-// ZH_NICE_MIX_WG_MIN = the smallest voice count that combines per workgroup.
-// ZH_NICE_MIX_WG8_MIN = the smallest voice count whose workgroups are eight waves (512 threads, one row per 512 voices: the
-// partial rows are then 2.1 MB of the 131,072-voice buffer's ~14 MB instead of 4.2 of ~18).  OFF by default: the barrier over
-// eight waves costs more than the rows save -- 107.5 -> 109.6 us per buffer, four alternating runs on one box
-// (profiles/r04/ab_nice_mix_wg8.txt); traffic is not this kernel's bound (0.17 TB/s).
-// Returns the waves per combining workgroup: 0 (a row per wave), 4 or 8.
-static int nice_mix_wg(uint32_t n_voices) {
-    const char *e = zh_env("ZH_NICE_MIX_WG_MIN");
-    const uint32_t wg_min = e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u;
-    const char *e8 = zh_env("ZH_NICE_MIX_WG8_MIN");
-    const uint32_t wg8_min = e8 ? (uint32_t)strtoul(e8, nullptr, 10) : 0xFFFFFFFFu;
-    return n_voices >= wg8_min ? 8 : (n_voices >= wg_min ? 4 : 0);
-}
+// nice_mix_wg_min (dispatch.hip) = the smallest voice count that combines per workgroup.  (Eight-wave workgroups -- one row per
+// 512 voices, 2.1 MB of partial rows instead of 4.2 at 131,072 voices -- were a switch through round 4 and slower: the barrier
+// over eight waves costs more than the rows save, 107.5 -> 109.6 us per buffer, profiles/r04/ab_nice_mix_wg8.txt; traffic is not
+// this kernel's bound.  Gone with round 5.)
+// Returns the waves per combining workgroup: 0 (a row per wave) or 4.
+static int nice_mix_wg(uint32_t n_voices) { return (long)n_voices >= zh_form(ZF_NICE_MIX_WG_MIN) ? 4 : 0; }
 static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
                             const zh_f32 *gain_r, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
     const bool stereo = mix_r != nullptr;
@@ -1921,7 +1892,7 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     if (m->n == 0) return ZH_OK;
     const uint32_t nframes = end - start;
     const int wg = nice_mix_wg(m->n);
-    const uint32_t bs = wg == 8 ? 512u : 256u;
+    const uint32_t bs = 256u;
     const uint32_t blocks = (m->n + bs - 1) / bs;
     const uint32_t rows = wg ? blocks : blocks * 4;                     // one partial row per workgroup (256 / 512 voices) / per wave of 64 voices
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);   // [frame / G][row][frame % G]
@@ -1933,30 +1904,30 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
     // ZH_PAINT_TOLERANT, few voices: the span as chunks at once (k_nice_tp_a, k_nice_mix_tp_b), chunks of whole 32-frame tiles
     if ((flags & ZH_PAINT_TOLERANT) && !wg && nframes >= 128 && nframes <= kNiceTpMaxChunks * 128u) {
-        const uint32_t Cn = zh_tp_chunks(m->n, "ZH_NICE_TP_MAX", nframes);
+        const uint32_t Cn = zh_tp_chunks(m->n, ZF_NICE_TP_MAX, nframes);
         if (Cn >= 2 && !m->tp && !m->ctx->capturing && dev_alloc(&m->tp, (size_t)kNiceTpWords * m->n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
         if (Cn >= 2 && m->tp) {
             NiceTpArgs t;
             t.a = a; t.tp = m->tp; t.start = start; t.end = end; t.L = ((nframes + Cn - 1) / Cn + MIXF - 1) / MIXF * MIXF; t.out = Img{nullptr, 0};
             const dim3 grid(blocks, (nframes + t.L - 1) / t.L);
-            hipLaunchKernelGGL(k_nice_tp_a, grid, dim3(256), 0, st, t);
+            ZH_LAUNCH(k_nice_tp_a, grid, dim3(256), 0, st, t);
             const bool roll = nice_mix_roll();
             if (stereo) {
                 const F32P gl = mk_f32(*gain_l), gr = mk_f32(*gain_r);
-                if (roll) hipLaunchKernelGGL((k_nice_mix_tp_b<2, true>), grid, dim3(256), 0, st, t, part, gl, gr);
-                else hipLaunchKernelGGL((k_nice_mix_tp_b<2, false>), grid, dim3(256), 0, st, t, part, gl, gr);
+                if (roll) ZH_LAUNCH((k_nice_mix_tp_b<2, true>), grid, dim3(256), 0, st, t, part, gl, gr);
+                else ZH_LAUNCH((k_nice_mix_tp_b<2, false>), grid, dim3(256), 0, st, t, part, gl, gr);
                 zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, mix_r + start, 2, zf);
             } else {
                 const F32P none = mk_f32(zh_f32{0.0f, 0, nullptr});
-                if (roll) hipLaunchKernelGGL((k_nice_mix_tp_b<1, true>), grid, dim3(256), 0, st, t, part, none, none);
-                else hipLaunchKernelGGL((k_nice_mix_tp_b<1, false>), grid, dim3(256), 0, st, t, part, none, none);
+                if (roll) ZH_LAUNCH((k_nice_mix_tp_b<1, true>), grid, dim3(256), 0, st, t, part, none, none);
+                else ZH_LAUNCH((k_nice_mix_tp_b<1, false>), grid, dim3(256), 0, st, t, part, none, none);
                 zh_mix_pass2_wide_launch(m->ctx, part, per_channel, rows, nframes, mix_l + start, nullptr, 1, zf);
             }
             return zh_launch_status();
         }
     }
-#define ZH_NMIX(C_, ROLL_, NW_, GL_, GR_) hipLaunchKernelGGL((k_nice_mix<C_, ROLL_, NW_>), dim3(blocks), dim3(bs), 0, st, a, start, end, part, GL_, GR_)
-#define ZH_NMIX_W(C_, ROLL_, GL_, GR_) do { if (wg == 8) ZH_NMIX(C_, ROLL_, 8, GL_, GR_); else if (wg) ZH_NMIX(C_, ROLL_, 4, GL_, GR_); else ZH_NMIX(C_, ROLL_, 0, GL_, GR_); } while (0)
+#define ZH_NMIX(C_, ROLL_, NW_, GL_, GR_) ZH_LAUNCH((k_nice_mix<C_, ROLL_, NW_>), dim3(blocks), dim3(bs), 0, st, a, start, end, part, GL_, GR_)
+#define ZH_NMIX_W(C_, ROLL_, GL_, GR_) do { if (wg) ZH_NMIX(C_, ROLL_, 4, GL_, GR_); else ZH_NMIX(C_, ROLL_, 0, GL_, GR_); } while (0)
     const bool roll = nice_mix_roll();
     if (stereo) {
         const F32P gl = mk_f32(*gain_l), gr = mk_f32(*gain_r);
@@ -1993,7 +1964,7 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     if (m->n == 0 || n_buffers == 0) return ZH_OK;
     const uint32_t nframes = end - start;
     const int wg = nice_mix_wg(m->n);
-    const uint32_t bs = wg == 8 ? 512u : 256u;
+    const uint32_t bs = 256u;
     const uint32_t blocks = (m->n + bs - 1) / bs, rows = wg ? blocks : blocks * 4;
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);
     int rc = zh_mix_reserve(m->ctx, per_channel * 2 * n_buffers);
@@ -2007,9 +1978,8 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
     }
     float *part = m->ctx->mix_partials;
     hipStream_t st = m->ctx->stream;
-#define ZH_NMIXB(ROLL_, NW_) hipLaunchKernelGGL((k_nice_mix_batch<2, ROLL_, NW_>), dim3(blocks), dim3(bs), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right))
-    if (wg == 8) { if (nice_mix_roll()) ZH_NMIXB(true, 8); else ZH_NMIXB(false, 8); }
-    else if (wg) { if (nice_mix_roll()) ZH_NMIXB(true, 4); else ZH_NMIXB(false, 4); }
+#define ZH_NMIXB(ROLL_, NW_) ZH_LAUNCH((k_nice_mix_batch<2, ROLL_, NW_>), dim3(blocks), dim3(bs), 0, st, b, start, end, part, mk_f32(gain_left), mk_f32(gain_right))
+    if (wg) { if (nice_mix_roll()) ZH_NMIXB(true, 4); else ZH_NMIXB(false, 4); }
     else { if (nice_mix_roll()) ZH_NMIXB(true, 0); else ZH_NMIXB(false, 0); }
 #undef ZH_NMIXB
     if (nframes) {
@@ -2039,13 +2009,12 @@ int zh_nice_paint_spans(zh_nice *m, uint32_t start, uint32_t end, const zh_buf *
     zh_bool no = {0, 0, nullptr};
     NiceArgs a = nice_args(m, &p, no);
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
-    const char *wme = zh_env("ZH_NICE_WAVE_MAX");
-    const int wave_max = wme ? atoi(wme) : 64;
-    if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
-        if (zf) hipLaunchKernelGGL(k_nice_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL(k_nice_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-    } else if (zf) hipLaunchKernelGGL(k_nice_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-    else hipLaunchKernelGGL(k_nice_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    const long wave_max = zh_form(ZF_NICE_WAVE_MAX);
+    if ((long)m->n <= wave_max) {                            // few voices: one wave per voice, lanes = frames
+        if (zf) ZH_LAUNCH(k_nice_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else ZH_LAUNCH(k_nice_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    } else if (zf) ZH_LAUNCH(k_nice_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    else ZH_LAUNCH(k_nice_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
 }
 
@@ -2069,7 +2038,7 @@ int zh_noise_filter_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_nois
         if (!rc) rc = (int)hipMemsetAsync(m->b, 0, (size_t)n * 4, ctx->stream);
     }
     if (rc) { nf_free(m); delete m; return rc; }
-    if (n) hipLaunchKernelGGL(k_nf_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], n, first_seed);
+    if (n) ZH_LAUNCH(k_nf_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], n, first_seed);
     if (n) (void)zh_noise_jump_tables(ctx);                       // built on first use per context: here, not inside a paint (or a capture)
     *out = m;
     return zh_launch_status();
@@ -2132,7 +2101,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     hipStream_t st = m->ctx->stream;
     Img out = mk_img(outputs[0]);
     if (p->type == ZH_FILTER_BYPASS) {
-#define ZH_NFB(ZF_, PK_) hipLaunchKernelGGL((k_noise_filter_bypass<ZF_, PK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->n, out, start, end)
+#define ZH_NFB(ZF_, PK_) ZH_LAUNCH((k_noise_filter_bypass<ZF_, PK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->n, out, start, end)
         if (zf) { if (pink) ZH_NFB(true, true); else ZH_NFB(true, false); } else { if (pink) ZH_NFB(false, true); else ZH_NFB(false, false); }
 #undef ZH_NFB
         return zh_launch_status();
@@ -2148,7 +2117,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     // ZH_PAINT_TOLERANT, white noise, few voices: the span as 32..128-frame chunks at once, two passes (filter_tp.hip.h).  Pieces
     // of <= 32 chunks; L (a multiple of 32, the jump tables' step) by voice count: ~2,048 waves in flight.
     if ((flags & ZH_PAINT_TOLERANT) && !pink && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
-        const uint32_t Cw = zh_tp_chunks(m->n, "ZH_NF_TP_MAX", 1024);                  // chunks wanted for a 1,024-frame buffer
+        const uint32_t Cw = zh_tp_chunks(m->n, ZF_NF_TP_MAX, 1024);                  // chunks wanted for a 1,024-frame buffer
         const uint4 *tables = Cw >= 2 ? zh_noise_jump_tables(m->ctx) : nullptr;
         if (tables && !m->tp_cs && !m->ctx->capturing) {
             int arc = dev_alloc(&m->tp_cs, (size_t)kNfTpMaxChunks * 4 * m->n);
@@ -2172,21 +2141,19 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
                 a.serial = m->tp_serial;
                 a.per = (m->n + 255u) / 256u;
                 const dim3 grid(((a.C + 7u) / 8u) * 8u * a.per);                         // chunk j of every group on XCD j % 8 (nf_tp_block)
-                hipLaunchKernelGGL(k_nf_tp_a, grid, dim3(256), 0, st, a);
-                if (zf) hipLaunchKernelGGL(k_nf_tp_b<true>, grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL(k_nf_tp_b<false>, grid, dim3(256), 0, st, a);
+                ZH_LAUNCH(k_nf_tp_a, grid, dim3(256), 0, st, a);
+                if (zf) ZH_LAUNCH(k_nf_tp_b<true>, grid, dim3(256), 0, st, a);
+                else ZH_LAUNCH(k_nf_tp_b<false>, grid, dim3(256), 0, st, a);
             }
             return zh_launch_status();
         }
     }
     // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at
     // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both
-    const char *pce = zh_env("ZH_NF_PC_MAX");
-    const uint32_t pc_max = pce ? (uint32_t)strtoul(pce, nullptr, 10) : 65536u;
+    const uint32_t pc_max = (uint32_t)zh_form(ZF_NF_PC_MAX);
     // White noise at small voice counts: three producer waves, a filter wave and a writer wave per 64 voices
     // (k_noise_filter_ring).  ZH_NF_RING_MAX: largest voice count that takes it.
-    const char *rge = zh_env("ZH_NF_RING_MAX");
-    const uint32_t ring_max = rge ? (uint32_t)strtoul(rge, nullptr, 10) : 16384u;
+    const uint32_t ring_max = (uint32_t)zh_form(ZF_NF_RING_MAX);
     if (!pink && m->n <= ring_max && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
         const uint4 *tables = zh_noise_jump_tables(m->ctx);
         if (tables) {
@@ -2197,12 +2164,12 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             a.V = m->n; a.start = start; a.end = end; a.out = out;
             a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
             const dim3 grid((m->n + 63) / 64), block(64 * (kNfProducers + 2));
-            if (zf) hipLaunchKernelGGL(k_noise_filter_ring<true>, grid, block, 0, st, a);
-            else hipLaunchKernelGGL(k_noise_filter_ring<false>, grid, block, 0, st, a);
+            if (zf) ZH_LAUNCH(k_noise_filter_ring<true>, grid, block, 0, st, a);
+            else ZH_LAUNCH(k_noise_filter_ring<false>, grid, block, 0, st, a);
             return zh_launch_status();
         }
     }
-#define ZH_NF(K_, BLK_, ZF_, PK_) hipLaunchKernelGGL((K_<ZF_, PK_>), seq_grid(m->n), dim3(BLK_), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
+#define ZH_NF(K_, BLK_, ZF_, PK_) ZH_LAUNCH((K_<ZF_, PK_>), seq_grid(m->n), dim3(BLK_), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->l, m->b, m->n, out, start, end, l_mul, b_mul, h_mul, mk_f32(p->cutoff), mk_f32(p->res))
     if (m->n <= pc_max && outputs[0].stride <= (1u << 24)) {                            // (32-row tiles: 32-bit offsets)
         if (zf) { if (pink) ZH_NF(k_noise_filter_pc, 128, true, true); else ZH_NF(k_noise_filter_pc, 128, true, false); }
         else { if (pink) ZH_NF(k_noise_filter_pc, 128, false, true); else ZH_NF(k_noise_filter_pc, 128, false, false); }
@@ -2227,7 +2194,7 @@ int zh_pmosc_create(zh_ctx *ctx, uint32_t n, zh_f32 release_duration, zh_pmosc *
     if (rc) { pmosc_free(m); delete m; return rc; }
     if (n) {
         hipStream_t st = ctx->stream;
-        hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->release_duration, n, mk_f32(release_duration));
+        ZH_LAUNCH(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, st, m->release_duration, n, mk_f32(release_duration));
         for (int b = 0; b < 2; b++) { hipError_t e = hipMemsetAsync(m->cnt[b], 0, (size_t)6 * n * 4, st); if (e != hipSuccess) { pmosc_free(m); delete m; return (int)e; } }
     }
     m->view();
@@ -2292,25 +2259,25 @@ int zh_pmosc_paint(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf *outp
     // few voices: frame ranges at once (k_pmosc_ranges); ZH_PMOSC_RANGES = number of ranges, 0 = never
     // 16 / 32 / 64 ranges: 75.5 / 70.9 / 80.7 us at 4,096 voices (the replay costs the same whatever the count); 24,576 /
     // 32,768 / 65,536 / 131,072 voices, sequential -> ranges: 370 -> 150, 370 -> 176, 353 -> 277, 499 -> 476 us
-    const uint32_t ch = zh_range_frames(m->n, end - start, "ZH_PMOSC_RANGES", m->n <= 16384 ? 2048 : 4096, 131072);
+    const uint32_t ch = zh_range_frames(m->n, end - start, ZF_PMOSC_RANGES, m->n <= 16384 ? 2048 : 4096, 131072);
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
         uint32_t *next = m->cnt[m->cur ^ 1];
         if (flags & ZH_PAINT_TOLERANT) {
-            if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL((k_pmosc_ranges<true, true>), grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
-            else hipLaunchKernelGGL((k_pmosc_ranges<false, true>), grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
-        } else if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
-        else hipLaunchKernelGGL(k_pmosc_ranges<false>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+            if (flags & ZH_PAINT_ZERO_FIRST) ZH_LAUNCH((k_pmosc_ranges<true, true>), grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+            else ZH_LAUNCH((k_pmosc_ranges<false, true>), grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+        } else if (flags & ZH_PAINT_ZERO_FIRST) ZH_LAUNCH(k_pmosc_ranges<true>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
+        else ZH_LAUNCH(k_pmosc_ranges<false>, grid, dim3(64), 0, st, a, next, mk_img(outputs[0]), start, end, ch);
         zh_flipper_painted(m);
         m->cur ^= 1;
         m->view();
         return zh_launch_status();
     }
     if (flags & ZH_PAINT_TOLERANT) {
-        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL((k_pmosc<true, true>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL((k_pmosc<false, true>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
-    } else if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
-    else hipLaunchKernelGGL(k_pmosc<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+        if (flags & ZH_PAINT_ZERO_FIRST) ZH_LAUNCH((k_pmosc<true, true>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+        else ZH_LAUNCH((k_pmosc<false, true>), seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    } else if (flags & ZH_PAINT_ZERO_FIRST) ZH_LAUNCH(k_pmosc<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
+    else ZH_LAUNCH(k_pmosc<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_img(outputs[0]), start, end);
     return zh_launch_status();
 }
 
@@ -2325,13 +2292,12 @@ int zh_pmosc_paint_spans(zh_pmosc *m, uint32_t start, uint32_t end, const zh_buf
     PMOscArgs a{m->release_duration, m->tc, m->tm, m->estate, m->et, m->elast, m->estart, m->n, sample_rate,
                 F32P{0.0f, nullptr}, BoolP{0, nullptr}, BoolP{0, nullptr}};
     const bool zf = (flags & ZH_PAINT_ZERO_FIRST) != 0;
-    const char *wme = zh_env("ZH_PMOSC_WAVE_MAX");
-    const int wave_max = wme ? atoi(wme) : 64;
-    if (m->n <= (uint32_t)wave_max) {                            // few voices: one wave per voice, lanes = frames
-        if (zf) hipLaunchKernelGGL(k_pmosc_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-        else hipLaunchKernelGGL(k_pmosc_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-    } else if (zf) hipLaunchKernelGGL(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
-    else hipLaunchKernelGGL(k_pmosc_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    const long wave_max = zh_form(ZF_PMOSC_WAVE_MAX);
+    if ((long)m->n <= wave_max) {                            // few voices: one wave per voice, lanes = frames
+        if (zf) ZH_LAUNCH(k_pmosc_spans_wave<true>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+        else ZH_LAUNCH(k_pmosc_spans_wave<false>, dim3(m->n), dim3(64), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    } else if (zf) ZH_LAUNCH(k_pmosc_spans<true>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
+    else ZH_LAUNCH(k_pmosc_spans<false>, seq_grid(m->n), dim3(kSeqBlock), 0, st, a, mk_span_table(table), mk_img(outputs[0]), start, end);
     return zh_launch_status();
 }
 

@@ -68,40 +68,7 @@ void zh_epoch_painted(zh_ctx *c, zh_flipper *f, uint32_t frames, void (*publish)
     c->epoch_pending.push_back(zh_epoch_pending{f, frames, publish});
 }
 
-// Form switches (ZH_*_RANGES, ZH_*_PC_MAX, ...) are looked up on the paint path: a paint at 4,096 voices is ~4 us of
-// launch, and every getenv is a walk over the whole environment.  A switch is therefore read from the environment ONCE
-// and remembered -- unless ZH_ENV_LIVE=1 was set when the library was loaded (tests/conftest.py does: the parity tests
-// flip switches between paints to force every kernel form).
-const char *zh_env(const char *name) {
-    static const bool live = [] { const char *e = getenv("ZH_ENV_LIVE"); return e && e[0] == '1'; }();
-    if (live) return getenv(name);
-    struct Entry { const char *name; std::string value; bool set; };
-    static std::mutex mu;
-    static std::vector<Entry> seen;
-    std::lock_guard<std::mutex> lk(mu);
-    for (const Entry &e : seen)
-        if (e.name == name || strcmp(e.name, name) == 0) return e.set ? e.value.c_str() : nullptr;
-    if (seen.capacity() < 64) seen.reserve(64);               // entries never move: the returned pointers stay valid
-    if (seen.size() >= 64) return getenv(name);
-    const char *v = getenv(name);
-    seen.push_back(Entry{name, v ? v : "", v != nullptr});
-    return seen.back().set ? seen.back().value.c_str() : nullptr;
-}
-
-uint32_t zh_range_frames(uint32_t V, uint32_t n, const char *env_name, uint32_t target_waves, uint32_t max_voices) {
-    const char *e = zh_env(env_name);
-    const int forced = e ? atoi(e) : -1;                                          // 0 = off, k = k ranges
-    const char *ew = zh_env("ZH_REPLAY_WAVES"), *ev = zh_env("ZH_REPLAY_MAXV");   // experiments: override every caller's tuning
-    if (ew) target_waves = (uint32_t)atoi(ew);
-    if (ev) max_voices = (uint32_t)atoi(ev);
-    if (forced == 0 || V == 0 || n < 128 || V > max_voices) return 0;
-    const uint32_t waves = (V + 63) / 64;
-    uint32_t want = forced > 0 ? (uint32_t)forced : target_waves / waves;
-    if (want < 2) return 0;
-    if (want > 64) want = 64;
-    const uint32_t ch = ((n + want - 1) / want + 7) / 8 * 8;
-    return (n + ch - 1) / ch >= 2 ? ch : 0;
-}
+thread_local zh_ctx *zh_tls_ctx = nullptr;
 
 int zh_store_mode() {
     static int mode = -1;
@@ -145,7 +112,7 @@ int zh_create(zh_ctx **out, int device) {
     c->mix_partials_floats = 0;
     c->capturing = false;
     c->noise_jump = nullptr;
-    c->capture_flags = 0; c->epoch_open = false; c->co_paints = c->co_launches = 0;
+    c->capture_flags = 0; c->epoch_open = false; c->co_paints = c->co_launches = 0; c->form_fresh = false;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
     *out = c;

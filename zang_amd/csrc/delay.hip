@@ -584,22 +584,21 @@ int zh_delay_paint(zh_delay *m, uint32_t start, uint32_t end, const zh_buf *outp
     const bool chunked = delay_can_chunk(m->d, outputs[0], p->input);
     // delay 300, 1,024 frames, walk -> independent frames (three launches): 57 -> 13 us at 4,096 voices, 75 -> 31 at 16,384,
     // 423 -> 271 at 131,072: at every voice count
-    const char *fe = zh_env("ZH_DELAY_FRAMES_MAX");                     // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
-    const uint32_t frames_max = fe ? (uint32_t)atoi(fe) : 0xFFFFFFFFu;
+    const uint32_t frames_max = (uint32_t)zh_form(ZF_DELAY_FRAMES_MAX);
     if (chunked && m->d.n <= frames_max && end - start >= 64) {
         hipStream_t st = m->ctx->stream;
         const uint32_t n = end - start, D = m->d.delay_samples, stored = n < D ? n : D;
         const bool fused = n <= D, zf = flags & ZH_PAINT_ZERO_FIRST;
         const dim3 grid((m->d.n + 63) / 64, ((n + 31) / 32 + 3) / 4);
-#define ZH_DF(ZF_, W_) hipLaunchKernelGGL((k_delay_frames<ZF_, W_>), grid, dim3(256), 0, st, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end)
+#define ZH_DF(ZF_, W_) ZH_LAUNCH((k_delay_frames<ZF_, W_>), grid, dim3(256), 0, st, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end)
         if (zf) { if (fused) ZH_DF(true, true); else ZH_DF(true, false); }
         else { if (fused) ZH_DF(false, true); else ZH_DF(false, false); }
 #undef ZH_DF
-        if (!fused) hipLaunchKernelGGL(k_delay_store, dim3((m->d.n + 63) / 64, ((stored + 31) / 32 + 3) / 4), dim3(256), 0, st, m->d, mk_cimg(p->input), start, end);
-        hipLaunchKernelGGL(k_delay_advance, dim3((m->d.n + 255) / 256), dim3(256), 0, st, m->d, n);
+        if (!fused) ZH_LAUNCH(k_delay_store, dim3((m->d.n + 63) / 64, ((stored + 31) / 32 + 3) / 4), dim3(256), 0, st, m->d, mk_cimg(p->input), start, end);
+        ZH_LAUNCH(k_delay_advance, dim3((m->d.n + 255) / 256), dim3(256), 0, st, m->d, n);
         return zh_launch_status();
     }
-#define ZH_DL(ZF_, CH_) hipLaunchKernelGGL((k_simple_delay<ZF_, CH_>), seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end)
+#define ZH_DL(ZF_, CH_) ZH_LAUNCH((k_simple_delay<ZF_, CH_>), seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, mk_img(outputs[0]), mk_cimg(p->input), start, end)
     if (flags & ZH_PAINT_ZERO_FIRST) { if (chunked) ZH_DL(true, 8); else ZH_DL(true, 1); }
     else { if (chunked) ZH_DL(false, 8); else ZH_DL(false, 1); }
 #undef ZH_DL
@@ -660,7 +659,7 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     // 4,096 voices -- 1,024 frames over a delay of 300 took 42 us as four pieces against the exact form's 44.
     if ((flags & ZH_PAINT_TOLERANT) && chunked && end - start >= 64) {
         const uint32_t n = end - start, D = m->d.delay_samples, piece = D < 4096u ? D : 4096u;
-        const uint32_t C = zh_tp_chunks(m->d.n, "ZH_ECHOES_TP_MAX", piece < n ? piece : n, 6144u);   // (six image streams: level with the exact form at 8,192 voices, HBM-bound behind it from 16,384)
+        const uint32_t C = zh_tp_chunks(m->d.n, ZF_ECHOES_TP_MAX, piece < n ? piece : n);   // (six image streams: level with the exact form at 8,192 voices, HBM-bound behind it from 16,384)
         if (C >= 2 && piece >= 64 && (n + piece - 1) / piece <= 3) {
             if (!m->tp && !m->ctx->capturing && dev_alloc(&m->tp, kFeTpFloats * m->d.n) != ZH_OK) { m->tp = nullptr; (void)hipGetLastError(); }
             if (m->tp) {
@@ -673,9 +672,9 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
                     const uint32_t len = a.end - a.start, c = C < len ? C : len;
                     a.L = (len + c - 1) / c;
                     const dim3 grid((m->d.n + 255) / 256, (len + a.L - 1) / a.L);
-                    hipLaunchKernelGGL(k_fe_tp_a, grid, dim3(256), 0, m->ctx->stream, a);
-                    if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_fe_tp_b<true>, grid, dim3(256), 0, m->ctx->stream, a);
-                    else hipLaunchKernelGGL(k_fe_tp_b<false>, grid, dim3(256), 0, m->ctx->stream, a);
+                    ZH_LAUNCH(k_fe_tp_a, grid, dim3(256), 0, m->ctx->stream, a);
+                    if (flags & ZH_PAINT_ZERO_FIRST) ZH_LAUNCH(k_fe_tp_b<true>, grid, dim3(256), 0, m->ctx->stream, a);
+                    else ZH_LAUNCH(k_fe_tp_b<false>, grid, dim3(256), 0, m->ctx->stream, a);
                 }
                 return zh_launch_status();
             }
@@ -683,14 +682,13 @@ int zh_filtered_echoes_paint(zh_filtered_echoes *m, uint32_t start, uint32_t end
     }
     // delay 300, one wave per 64 voices -> three: 1,024 / 4,096 / 16,384 / 32,768 / 65,536 voices 88 / 91 / 103 / 194 / 263 ->
     // 56 / 57 / 62 / 110 / 215 us; at 131,072 voices the one-wave form is ahead (406 against 461)
-    const char *pe = zh_env("ZH_ECHOES_PC_MAX");                        // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
-    const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 65536u;
+    const uint32_t pc_max = (uint32_t)zh_form(ZF_ECHOES_PC_MAX);
     if (chunked && m->d.n <= pc_max && m->d.delay_samples >= 192 && end - start >= 64) {
-        if (flags & ZH_PAINT_ZERO_FIRST) hipLaunchKernelGGL(k_filtered_echoes_pc<true>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
-        else hipLaunchKernelGGL(k_filtered_echoes_pc<false>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
+        if (flags & ZH_PAINT_ZERO_FIRST) ZH_LAUNCH(k_filtered_echoes_pc<true>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
+        else ZH_LAUNCH(k_filtered_echoes_pc<false>, dim3((m->d.n + 63) / 64), dim3(192), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff));
         return zh_launch_status();
     }
-#define ZH_FE(ZF_, CH_) hipLaunchKernelGGL((k_filtered_echoes<ZF_, CH_>), seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff))
+#define ZH_FE(ZF_, CH_) ZH_LAUNCH((k_filtered_echoes<ZF_, CH_>), seq_grid(m->d.n), dim3(kSeqBlock), 0, m->ctx->stream, m->d, m->l, m->b, mk_img(outputs[0]), mk_cimg(p->input), start, end, mk_f32(p->feedback_volume), mk_f32(p->cutoff))
     if (flags & ZH_PAINT_ZERO_FIRST) { if (chunked) ZH_FE(true, 8); else ZH_FE(true, 1); }
     else { if (chunked) ZH_FE(false, 8); else ZH_FE(false, 1); }
 #undef ZH_FE

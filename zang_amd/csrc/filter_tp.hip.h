@@ -95,13 +95,11 @@ constexpr uint32_t kTpMaxChunks = 32;    // chunks per launch; a module's scratc
 
 #if !defined(ZH_DEVICE_ONLY)
 // chunks for a span of n frames of V voices: enough for ~2,048 waves (two per SIMD), 2..32; 0 = too many voices for the form
-static inline uint32_t zh_tp_chunks(uint32_t V, const char *max_env, uint32_t n, uint32_t max_default = 16384u) {
+static inline uint32_t zh_tp_chunks(uint32_t V, int max_form, uint32_t n) {
     const uint32_t G = (V + 63) / 64;
-    const char *me = zh_env(max_env);                                 // largest voice count that takes the time-parallel form
-    const uint32_t tp_max = me ? (uint32_t)strtoul(me, nullptr, 10) : max_default;
+    const uint32_t tp_max = (uint32_t)zh_form(max_form);              // largest voice count that takes the time-parallel form (dispatch.hip)
     if (V > tp_max || G > 1024) return 0;
-    const char *we = zh_env("ZH_TP_WAVES");                           // experiments: waves a launch should reach
-    const uint32_t waves = we ? (uint32_t)strtoul(we, nullptr, 10) : 2048u;
+    const uint32_t waves = 2048u;                                     // waves a launch should reach
     uint32_t C = (waves + G - 1) / G;
     C = C < 2 ? 2 : (C > kTpMaxChunks ? kTpMaxChunks : C);
     return C > n ? n : C;
@@ -224,7 +222,7 @@ constexpr size_t kFilterTpFloats = (size_t)(kTpMaxChunks + 1) * 2 + (size_t)kTpM
 static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float *scratch, uint32_t V, Img out, CImg in, uint32_t start, uint32_t end, bool zf,
                                        float l_mul, float b_mul, float h_mul, CobP cut, CobP res) {
     if (end - start < 64) return false;
-    const uint32_t C = zh_tp_chunks(V, "ZH_FILTER_TP_MAX", end - start);
+    const uint32_t C = zh_tp_chunks(V, ZF_FILTER_TP_MAX, end - start);
     if (C < 2) return false;
     const uint32_t piece = 4096;                                      // frames per launch pair: chunks of <= 128 frames
     FilterTpArgs a;
@@ -237,9 +235,9 @@ static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float
         const dim3 grid((V + 255) / 256, (a.end - a.start + a.L - 1) / a.L);
 #define ZH_FTP(CB_, RB_)                                                                                   \
         do {                                                                                               \
-            hipLaunchKernelGGL((k_filter_tp_a<CB_, RB_>), grid, dim3(256), 0, st, a);                      \
-            if (zf) hipLaunchKernelGGL((k_filter_tp_b<true, CB_, RB_>), grid, dim3(256), 0, st, a);        \
-            else hipLaunchKernelGGL((k_filter_tp_b<false, CB_, RB_>), grid, dim3(256), 0, st, a);          \
+            ZH_LAUNCH((k_filter_tp_a<CB_, RB_>), grid, dim3(256), 0, st, a);                      \
+            if (zf) ZH_LAUNCH((k_filter_tp_b<true, CB_, RB_>), grid, dim3(256), 0, st, a);        \
+            else ZH_LAUNCH((k_filter_tp_b<false, CB_, RB_>), grid, dim3(256), 0, st, a);          \
         } while (0)
         if (cb && rb) ZH_FTP(true, true);
         else if (cb) ZH_FTP(true, false);

@@ -1342,8 +1342,8 @@ template <class M> static int paint_check(M *m, uint32_t start, uint32_t end, co
 
 #define ZH_ZF_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                         \
     do {                                                                                               \
-        if (zf) hipLaunchKernelGGL((KERNEL<true>), GRID, BLOCK, 0, st, __VA_ARGS__);                   \
-        else hipLaunchKernelGGL((KERNEL<false>), GRID, BLOCK, 0, st, __VA_ARGS__);                     \
+        if (zf) ZH_LAUNCH((KERNEL<true>), GRID, BLOCK, 0, st, __VA_ARGS__);                   \
+        else ZH_LAUNCH((KERNEL<false>), GRID, BLOCK, 0, st, __VA_ARGS__);                     \
     } while (0)
 
 static bool curve_ok(const zh_curve &c) { return c.tag <= ZH_CURVE_CUBED; }
@@ -1408,15 +1408,15 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     // (24,576 / 32,768 / 65,536 / 131,072 voices: 162 -> 58, 165 -> 68, 174 -> 141, 266 -> 246 us); with a control image the
     // replay re-reads the image (32,768 voices: 166 -> 90 us with 4 ranges, no gain from 65,536 on)
     const bool aliased = cob_aliases(p->freq, outputs[0]) || cob_aliases(p->phase, outputs[0]);
-    const uint32_t ch = end > start && !aliased ? zh_range_frames(m->n, end - start, "ZH_SINE_RANGES", fb || pb ? 2048 : 4096, fb || pb ? 65536 : 1u << 20) : 0;
+    const uint32_t ch = end > start && !aliased ? zh_range_frames(m->n, end - start, ZF_SINE_RANGES, fb || pb ? 2048 : 4096, fb || pb ? 65536 : 1u << 20) : 0;
     if (ch) {
         const float *t_in = m->t();
         float *t_out = reinterpret_cast<float *>(m->cnt[m->cur ^ 1]);
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
 #define ZH_SINE_R2(FB, PB, TOL)                                                                                     \
     do {                                                                                                            \
-        if (zf) hipLaunchKernelGGL((k_sineosc_ranges<true, FB, PB, TOL>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph); \
-        else hipLaunchKernelGGL((k_sineosc_ranges<false, FB, PB, TOL>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph);  \
+        if (zf) ZH_LAUNCH((k_sineosc_ranges<true, FB, PB, TOL>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph); \
+        else ZH_LAUNCH((k_sineosc_ranges<false, FB, PB, TOL>), grid, dim3(64), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, f, ph);  \
     } while (0)
 #define ZH_SINE_R(FB, PB) do { if (tol) ZH_SINE_R2(FB, PB, true); else ZH_SINE_R2(FB, PB, false); } while (0)
         if (fb && pb) ZH_SINE_R(true, true);
@@ -1431,8 +1431,8 @@ int zh_sineosc_paint(zh_sineosc *m, uint32_t start, uint32_t end, const zh_buf *
     }
 #define ZH_SINE2(FB, PB, TOL)                                                                                       \
     do {                                                                                                            \
-        if (zf) hipLaunchKernelGGL((k_sineosc<true, FB, PB, TOL>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph); \
-        else hipLaunchKernelGGL((k_sineosc<false, FB, PB, TOL>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph);  \
+        if (zf) ZH_LAUNCH((k_sineosc<true, FB, PB, TOL>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph); \
+        else ZH_LAUNCH((k_sineosc<false, FB, PB, TOL>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->t(), m->n, out, start, end, p->sample_rate, f, ph);  \
     } while (0)
 #define ZH_SINE(FB, PB) do { if (tol) ZH_SINE2(FB, PB, true); else ZH_SINE2(FB, PB, false); } while (0)
     if (fb && pb) ZH_SINE(true, true);
@@ -1468,7 +1468,7 @@ int zh_noise_create(zh_ctx *ctx, uint32_t n, uint64_t first_seed, zh_noise **out
     if (!rc) rc = dev_alloc(&m->err, 1);
     if (!rc) rc = (int)hipMemsetAsync(m->err, 0, 4, ctx->stream);
     if (rc) { noise_free(m); delete m; return rc; }
-    if (n) hipLaunchKernelGGL(k_noise_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], m->b, n, first_seed);
+    if (n) ZH_LAUNCH(k_noise_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->s[0], m->s[1], m->s[2], m->s[3], m->b, n, first_seed);
     // the jump tables are per context and built on first use; doing that here keeps it out of paint (and out of any capture)
     if (n && zh_noise_range_frames(n, 1024)) (void)zh_noise_jump_tables(ctx);
     *out = m;
@@ -1524,7 +1524,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     const bool pink = p->color == ZH_NOISE_PINK;
     // ZH_PAINT_TOLERANT, pink, few voices: the taps as chunks at once over exactly generated white noise (k_pink_tp_a / _b)
     if ((flags & ZH_PAINT_TOLERANT) && pink && end - start >= 128 && outputs[0].stride <= (1u << 24)) {
-        const uint32_t Cw = zh_tp_chunks(m->n, "ZH_PINK_TP_MAX", 1024);
+        const uint32_t Cw = zh_tp_chunks(m->n, ZF_PINK_TP_MAX, 1024);
         const uint4 *tables = Cw >= 2 ? zh_noise_jump_tables(m->ctx) : nullptr;
         if (tables && !m->tp_cs && !m->ctx->capturing) {
             int arc = dev_alloc(&m->tp_cs, (size_t)kTpMaxChunks * 4 * m->n);
@@ -1553,9 +1553,9 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                 a.serial = m->tp_serial;
                 a.per = (m->n + 255u) / 256u;
                 const dim3 grid(((a.C + 7u) / 8u) * 8u * a.per);                         // filter_tp.hip.h nf_tp_block
-                hipLaunchKernelGGL(k_pink_tp_a, grid, dim3(256), 0, st, a);
-                if (zf) hipLaunchKernelGGL(k_pink_tp_b<true>, grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL(k_pink_tp_b<false>, grid, dim3(256), 0, st, a);
+                ZH_LAUNCH(k_pink_tp_a, grid, dim3(256), 0, st, a);
+                if (zf) ZH_LAUNCH(k_pink_tp_b<true>, grid, dim3(256), 0, st, a);
+                else ZH_LAUNCH(k_pink_tp_b<false>, grid, dim3(256), 0, st, a);
             }
             return zh_launch_status();
         }
@@ -1563,8 +1563,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
     const uint32_t ch = zh_noise_range_frames(m->n, end - start);
     // pink, 1,024 / 4,096 / 16,384 / 32,768 voices: 124 / 116 / 118 / 130 us in one loop, 57 / 67 / 84 / 161 us as white ranges +
     // the seven-stage chain (the white kernel is 10-29 us of that), 43 / 54 / 68 / 123 us as white ranges + k_pink_taps
-    const char *pe = pink ? zh_env("ZH_PINK_PIPE_MAX") : nullptr;     // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
-    const uint32_t pink_max = pe ? (uint32_t)atoi(pe) : 32768u;
+    const uint32_t pink_max = (uint32_t)zh_form(ZF_PINK_PIPE_MAX);
     if (ch && (!pink || m->n <= pink_max)) {
         if (zf && !pink) {
             rc = zh_noise_paint_ranges(m->ctx, m->s, m->nx, m->flag, m->n, outputs[0], start, end, ch);
@@ -1582,17 +1581,17 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                 if (rc == ZH_OK && !pink) return zh_add_into(m->ctx, start, end, outputs[0], m->scratch);
                 if (rc == ZH_OK) {
                     const dim3 grid((m->n + 63) / 64);
-                    const char *te = zh_env("ZH_PINK_TAPS");              // 0 = the chain of seven stages (k_pink_pipe)
-                    const bool taps = (!te || atoi(te) != 0) && end - start >= 32 && outputs[0].stride <= (1u << 24) && m->scratch.stride <= (1u << 24);   // (32-row tiles: 32-bit offsets)
-                    if (taps && m->n <= 16384 && !(te && atoi(te) == 16)) {   // (ZH_PINK_TAPS=16 forces the 16-frame tiles)
-                        if (zf) hipLaunchKernelGGL((k_pink_taps<true, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
-                        else hipLaunchKernelGGL((k_pink_taps<false, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                    const long tapsf = zh_form(ZF_PINK_TAPS);             // 0 = the chain of seven stages (k_pink_pipe)
+                    const bool taps = tapsf != 0 && end - start >= 32 && outputs[0].stride <= (1u << 24) && m->scratch.stride <= (1u << 24);   // (32-row tiles: 32-bit offsets)
+                    if (taps && m->n <= 16384 && tapsf != 16) {   // (ZH_PINK_TAPS=16 forces the 16-frame tiles)
+                        if (zf) ZH_LAUNCH((k_pink_taps<true, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                        else ZH_LAUNCH((k_pink_taps<false, 32>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
                     } else if (taps) {                                    // 16-frame tiles: two workgroups per CU
-                        if (zf) hipLaunchKernelGGL((k_pink_taps<true, 16>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
-                        else hipLaunchKernelGGL((k_pink_taps<false, 16>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                        if (zf) ZH_LAUNCH((k_pink_taps<true, 16>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
+                        else ZH_LAUNCH((k_pink_taps<false, 16>), grid, dim3(256), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end);
                     } else {
-                        if (zf) hipLaunchKernelGGL(k_pink_pipe<true>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
-                        else hipLaunchKernelGGL(k_pink_pipe<false>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                        if (zf) ZH_LAUNCH(k_pink_pipe<true>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
+                        else ZH_LAUNCH(k_pink_pipe<false>, grid, dim3(64 * kPinkWaves), 0, st, m->b, m->n, mk_img(outputs[0]), mk_cimg(m->scratch), start, end, m->err);
                     }
                     return zh_launch_status();
                 }
@@ -1601,7 +1600,7 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
         }
     }
     Img out = mk_img(outputs[0]);
-#define ZH_NOISE(ZF_, PINK_) hipLaunchKernelGGL((k_noise<ZF_, PINK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->b, m->n, out, start, end)
+#define ZH_NOISE(ZF_, PINK_) ZH_LAUNCH((k_noise<ZF_, PINK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->b, m->n, out, start, end)
     if (p->color == ZH_NOISE_PINK) { if (zf) ZH_NOISE(true, true); else ZH_NOISE(false, true); }
     else { if (zf) ZH_NOISE(true, false); else ZH_NOISE(false, false); }
 #undef ZH_NOISE
@@ -1668,14 +1667,14 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
     const int c = m->cur;
     // few voices: frame ranges with a replay of the clock (4,096 / 8,192 / 16,384 / 32,768 voices: 35 / 35 / 36 / 42 us as one
     // walk, 22.4 / 23.9 / 25.8 / 33.3 us; wave targets 1,024 / 2,048 / 4,096 measured, 2,048 best or level everywhere)
-    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_ENVELOPE_RANGES", 2048, 40960) : 0;
+    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, ZF_ENVELOPE_RANGES, 2048, 40960) : 0;
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
 #define ZH_ENVR(FT_)                                                                                                         \
     do {                                                                                                                     \
-        if (zf) hipLaunchKernelGGL((k_envelope_ranges<true, FT_>), grid, dim3(64), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->cnt[c ^ 1], m->n, \
+        if (zf) ZH_LAUNCH((k_envelope_ranges<true, FT_>), grid, dim3(64), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->cnt[c ^ 1], m->n, \
                                    mk_img(outputs[0]), start, end, ch, mk_env_params(p), mk_bool(note_id_changed));         \
-        else hipLaunchKernelGGL((k_envelope_ranges<false, FT_>), grid, dim3(64), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->cnt[c ^ 1], m->n, \
+        else ZH_LAUNCH((k_envelope_ranges<false, FT_>), grid, dim3(64), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->cnt[c ^ 1], m->n, \
                                 mk_img(outputs[0]), start, end, ch, mk_env_params(p), mk_bool(note_id_changed));            \
     } while (0)
         switch (ft) {
@@ -1691,9 +1690,9 @@ int zh_envelope_paint(zh_envelope *m, uint32_t start, uint32_t end, const zh_buf
     }
 #define ZH_ENV(FT_)                                                                                                          \
     do {                                                                                                                     \
-        if (zf) hipLaunchKernelGGL((k_envelope<true, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->n, \
+        if (zf) ZH_LAUNCH((k_envelope<true, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->n, \
                                    mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));             \
-        else hipLaunchKernelGGL((k_envelope<false, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->n, \
+        else ZH_LAUNCH((k_envelope<false, FT_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->st(c), m->f(c, 1), m->f(c, 2), m->f(c, 3), m->n, \
                                 mk_img(outputs[0]), start, end, mk_env_params(p), mk_bool(note_id_changed));                \
     } while (0)
     switch (ft) {
@@ -1799,20 +1798,19 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     CobP cut = mk_cob(p->cutoff), res = mk_cob(p->res);
 #define ZH_FILTER(CB, RB)                                                                                            \
     do {                                                                                                             \
-        if (zf) hipLaunchKernelGGL((k_filter<true, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
-        else hipLaunchKernelGGL((k_filter<false, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
+        if (zf) ZH_LAUNCH((k_filter<true, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
+        else ZH_LAUNCH((k_filter<false, CB, RB>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
     } while (0)
     // few voices, constant cutoff / resonance: the three-wave pipeline (1,024 / 4,096 / 16,384 / 32,768 voices: 54.5 / 56.1 /
     // 57.3 / 75.8 us in one wave, 41 / 41.8 / 45 / 51 us; its 64 KB of LDS per workgroup allow 32,768 voices at once, with
     // 16-frame tiles it goes on to 65,536 voices)
-    const char *pe = zh_env("ZH_FILTER_PC_MAX");                        // zh_env: live under ZH_ENV_LIVE=1 (tests switch forms)
-    const uint32_t pc_max = pe ? (uint32_t)atoi(pe) : 32768u;
-    const char *pe16 = zh_env("ZH_FILTER_PC16_MAX");                    // 16-frame tiles above ZH_FILTER_PC_MAX voices
-    const uint32_t pc16_max = pe16 ? (uint32_t)atoi(pe16) : (pe && pc_max == 0 ? 0u : 65536u);   // (ZH_FILTER_PC_MAX=0 alone switches both off)     // 36,864 / 49,152 / 65,536 voices: 97 / 103 / 116 us in one wave, 72 / 79 / 104; 81,920: 126 against 168
+    const uint32_t pc_max = (uint32_t)zh_form(ZF_FILTER_PC_MAX);
+    // 16-frame tiles above filter_pc_max voices (filter_pc_max=0 alone switches both off)
+    const uint32_t pc16_max = (pc_max == 0 && !zh_form_is_set(ZF_FILTER_PC16_MAX)) ? 0u : (uint32_t)zh_form(ZF_FILTER_PC16_MAX);     // 36,864 / 49,152 / 65,536 voices: 97 / 103 / 116 us in one wave, 72 / 79 / 104; 81,920: 126 against 168
     // ZH_PAINT_TOLERANT, few voices: the span as chunks at once (filter_tp.hip.h); every other case paints with an exact form
     if ((flags & ZH_PAINT_TOLERANT) && !bufs_alias(p->input, outputs[0]) && !cob_aliases(p->cutoff, outputs[0]) && !cob_aliases(p->res, outputs[0]) &&
         outputs[0].stride <= (1u << 24) && p->input.stride <= (1u << 24) && (!cb || p->cutoff.buffer.stride <= (1u << 24)) && (!rb || p->res.buffer.stride <= (1u << 24))) {
-        if (!m->tp_e && !m->ctx->capturing && zh_tp_chunks(m->n, "ZH_FILTER_TP_MAX", end - start) >= 2 &&
+        if (!m->tp_e && !m->ctx->capturing && zh_tp_chunks(m->n, ZF_FILTER_TP_MAX, end - start) >= 2 &&
             dev_alloc(&m->tp_e, kFilterTpFloats * m->n) != ZH_OK) { m->tp_e = nullptr; (void)hipGetLastError(); }
         if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut, res))
             return zh_launch_status();
@@ -1823,11 +1821,11 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     if (!cb && !rb && m->n <= max(pc_max, pc16_max) && end - start >= 64 && !bufs_alias(p->input, outputs[0]) && tile_strides_ok) {
         const dim3 grid((m->n + 63) / 64);
         if (m->n <= pc_max) {
-            if (zf) hipLaunchKernelGGL((k_filter_pc<true, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
-            else hipLaunchKernelGGL((k_filter_pc<false, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+            if (zf) ZH_LAUNCH((k_filter_pc<true, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+            else ZH_LAUNCH((k_filter_pc<false, 32>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
         } else {
-            if (zf) hipLaunchKernelGGL((k_filter_pc<true, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
-            else hipLaunchKernelGGL((k_filter_pc<false, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+            if (zf) ZH_LAUNCH((k_filter_pc<true, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
+            else ZH_LAUNCH((k_filter_pc<false, 16>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut.c, res.c);
         }
         return zh_launch_status();
     }
@@ -1835,15 +1833,14 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     // 4,096 / 16,384 / 32,768 voices: 95.5 / 101.7 / 139.9 us as the one-wave walk, 46.8 / 48.9 / 98.4; 65,536: 160 against 195 --
     // the walk).  ZH_FILTER_PC_CTL_MAX = largest voice count (0 = never).
     {
-        const char *ce = zh_env("ZH_FILTER_PC_CTL_MAX");
-        const uint32_t ctl_max = ce ? (uint32_t)atoi(ce) : 32768u;
+        const uint32_t ctl_max = (uint32_t)zh_form(ZF_FILTER_PC_CTL_MAX);
         if ((cb || rb) && m->n <= ctl_max && end - start >= 64 && !bufs_alias(p->input, outputs[0]) && !cob_aliases(p->cutoff, outputs[0]) &&
             !cob_aliases(p->res, outputs[0]) && tile_strides_ok) {
             const dim3 grid((m->n + 63) / 64);
 #define ZH_FPCC(CH_, CB_, RB_)                                                                                       \
             do {                                                                                                     \
-                if (zf) hipLaunchKernelGGL((k_filter_pc_ctl<true, CH_, CB_, RB_>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
-                else hipLaunchKernelGGL((k_filter_pc_ctl<false, CH_, CB_, RB_>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
+                if (zf) ZH_LAUNCH((k_filter_pc_ctl<true, CH_, CB_, RB_>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res); \
+                else ZH_LAUNCH((k_filter_pc_ctl<false, CH_, CB_, RB_>), grid, dim3(192), 0, st, m->l, m->b, m->n, out, inp, start, end, l_mul, b_mul, h_mul, cut, res);  \
             } while (0)
             if (cb && rb) ZH_FPCC(16, true, true);
             else if (cb) ZH_FPCC(32, true, false);
@@ -1862,34 +1859,34 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
 int zh_filter_cutoff_from_frequency(zh_ctx *ctx, uint32_t n, float *cutoff_out, const float *frequency, float sample_rate) { ZH_GUARD(ctx);
     if (!ctx || (n && (!cutoff_out || !frequency))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_cutoff_from_frequency, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, cutoff_out, frequency, sample_rate);
+    ZH_LAUNCH(k_cutoff_from_frequency, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, cutoff_out, frequency, sample_rate);
     return zh_launch_status();
 }
 
 int zh_pow(zh_ctx *ctx, uint32_t n, float *out, const float *x, const float *y) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x || !y))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_pow, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x, y);
+    ZH_LAUNCH(k_pow, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x, y);
     return zh_launch_status();
 }
 
 int zh_sin(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_sincos<0>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    ZH_LAUNCH(k_sincos<0>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 int zh_cos(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_sincos<1>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    ZH_LAUNCH(k_sincos<1>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 
 int zh_atan(zh_ctx *ctx, uint32_t n, float *out, const float *x) { ZH_GUARD(ctx);
     if (!ctx || (n && (!out || !x))) return ZH_ERR_INVALID;
     if (!n) return ZH_OK;
-    hipLaunchKernelGGL(k_sincos<2>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
+    ZH_LAUNCH(k_sincos<2>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, out, x);
     return zh_launch_status();
 }
 
@@ -1939,13 +1936,13 @@ int zh_sampler_paint(zh_sampler *m, uint32_t start, uint32_t end, const zh_buf *
     const int fmt = s.num_samples == 0 ? kSampleEmpty : (int)s.format;
     // few voices: the span as frame ranges at once (see k_sampler); ZH_SAMPLER_RANGES = number of ranges, 0 = never
     // 24,576 / 32,768 / 65,536 / 131,072 / 262,144 voices, sequential -> ranges: 145 -> 43, 145 -> 55, 143 -> 96, 212 -> 187, 377 -> 349 us
-    uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_SAMPLER_RANGES", 16384, 1u << 20) : 0;
+    uint32_t ch = end > start ? zh_range_frames(m->n, end - start, ZF_SAMPLER_RANGES, 16384, 1u << 20) : 0;
     const bool ranges = ch != 0;
     if (!ranges) ch = end > start ? end - start : 1;
     const float *t_in = m->t();
     float *t_out = ranges ? reinterpret_cast<float *>(m->cnt[m->cur ^ 1]) : m->t();
     const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, ranges ? (end - start + ch - 1) / ch : 1);
-#define ZH_SMP(ZF_, F_, L_) hipLaunchKernelGGL((k_sampler<ZF_, F_, L_>), grid, dim3(kSeqBlock), 0, st, t_in, t_out, m->n, img, start, end, ch, s, rate, nicp)
+#define ZH_SMP(ZF_, F_, L_) ZH_LAUNCH((k_sampler<ZF_, F_, L_>), grid, dim3(kSeqBlock), 0, st, t_in, t_out, m->n, img, start, end, ch, s, rate, nicp)
 #define ZH_SMP_L(ZF_, F_) do { if (s.loop) ZH_SMP(ZF_, F_, true); else ZH_SMP(ZF_, F_, false); } while (0)
 #define ZH_SMP_F(ZF_) do { switch (fmt) { case kSampleEmpty: ZH_SMP_L(ZF_, kSampleEmpty); break; case ZH_SAMPLE_U8: ZH_SMP_L(ZF_, ZH_SAMPLE_U8); break; \
         case ZH_SAMPLE_S16_LSB: ZH_SMP_L(ZF_, ZH_SAMPLE_S16_LSB); break; case ZH_SAMPLE_S24_LSB: ZH_SMP_L(ZF_, ZH_SAMPLE_S24_LSB); break; \
@@ -2011,7 +2008,7 @@ int zh_decimator_paint(zh_decimator *m, uint32_t start, uint32_t end, const zh_b
     hipStream_t st = m->ctx->stream;
     // 4,096 voices: 94 us sequential with per-lane branches, 39 straight-line, 31 as 16 frame ranges (the replay is 8 issue
     // slots a frame against 13.5 for a painted frame: 4 / 8 / 16 / 32 / 64 ranges = 32.4 / 31.5 / 30.6 / 31.5 / 35.4 us)
-    const uint32_t ch = end > start && !bufs_alias(p->input, outputs[0]) ? zh_range_frames(m->n, end - start, "ZH_DECIMATOR_RANGES", m->n <= 32768 ? 1024 : 2048, 65536) : 0;   // (40,960 / 49,152 / 65,536 voices: 97 / 100 / 110 -> 69 / 77 / 106 us)
+    const uint32_t ch = end > start && !bufs_alias(p->input, outputs[0]) ? zh_range_frames(m->n, end - start, ZF_DECIMATOR_RANGES, m->n <= 32768 ? 1024 : 2048, 65536) : 0;   // (40,960 / 49,152 / 65,536 voices: 97 / 100 / 110 -> 69 / 77 / 106 us)
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
         const int c = m->cur;
@@ -2089,7 +2086,7 @@ int zh_curve_module_paint(zh_curve_module *m, uint32_t start, uint32_t end, cons
     // done properly (running span set up by begin(r0), unrolled replay, state in a flipped double buffer) frame ranges take
     // 9.2 / 11.7 / 17.0 / 29.4 us at 1,024 / 4,096 / 16,384 / 32,768 voices against 34.9 / 36.5 / 37.9 / 43.2 (an empty span still
     // runs begin(): the one-range form)
-    const uint32_t chr = end > start ? zh_range_frames(m->n, end - start, "ZH_CURVE_RANGES", 2048, 40960) : 0;   // (40,960 voices: 45.7 -> 36.9 us; no gain from 49,152)
+    const uint32_t chr = end > start ? zh_range_frames(m->n, end - start, ZF_CURVE_RANGES, 2048, 40960) : 0;   // (40,960 voices: 45.7 -> 36.9 us; no gain from 49,152)
     const uint32_t ch = chr ? chr : (end > start ? end - start : 1);
     const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
     ZH_ZF_LAUNCH(k_curve, grid, dim3(kSeqBlock), m->cnt[m->cur], m->cnt[chr ? m->cur ^ 1 : m->cur], m->n, mk_img(outputs[0]), start, end, ch,
@@ -2123,12 +2120,12 @@ int zh_cycle_paint(zh_cycle *m, uint32_t start, uint32_t end, const zh_buf *outp
     CobP sp = mk_cob(p->speed);
     // constant speed, few voices: frame ranges (1,024 / 4,096 / 16,384 voices: 17.6 / 19.5 / 20.4 us as one walk per voice, 10.3 / 12.5 / 15.1 us)
     const bool sb = p->speed.tag == ZH_COB_BUFFER;
-    const uint32_t chr = sb ? 0 : zh_range_frames(m->n, end - start, "ZH_CYCLE_RANGES", 1024, 16384);
+    const uint32_t chr = sb ? 0 : zh_range_frames(m->n, end - start, ZF_CYCLE_RANGES, 1024, 16384);
     const uint32_t ch = chr ? chr : end - start;
     const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
     const float *t_in = m->t();
     float *t_out = chr ? reinterpret_cast<float *>(m->cnt[m->cur ^ 1]) : m->t();
-#define ZH_CYCLE(ZF_, SB_) hipLaunchKernelGGL((k_cycle<ZF_, SB_>), grid, dim3(kSeqBlock), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, sp)
+#define ZH_CYCLE(ZF_, SB_) ZH_LAUNCH((k_cycle<ZF_, SB_>), grid, dim3(kSeqBlock), 0, st, t_in, t_out, m->n, out, start, end, ch, p->sample_rate, sp)
     if (sb) { if (zf) ZH_CYCLE(true, true); else ZH_CYCLE(false, true); }
     else { if (zf) ZH_CYCLE(true, false); else ZH_CYCLE(false, false); }
 #undef ZH_CYCLE
@@ -2186,7 +2183,7 @@ int zh_portamento_paint(zh_portamento *m, uint32_t start, uint32_t end, const zh
     hipStream_t st = m->ctx->stream;
     const int c = m->cur;
     // few voices: frame ranges (1,024 / 4,096 / 16,384 / 32,768 voices: 14.8 / 16.5 / 17.7 / 27.1 us as one walk per voice, 3.4 / 6.0 / 13.0 / 26.4 us)
-    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, "ZH_PORTAMENTO_RANGES", 2048, 32768) : 0;
+    const uint32_t ch = end > start ? zh_range_frames(m->n, end - start, ZF_PORTAMENTO_RANGES, 2048, 32768) : 0;
     if (ch) {
         const dim3 grid((m->n + 63) / 64, (end - start + ch - 1) / ch);
         ZH_ZF_LAUNCH(k_portamento_ranges, grid, dim3(64), m->f(c, 0), m->f(c, 1), m->f(c, 2), m->f(c ^ 1, 0), m->n, mk_img(outputs[0]), start, end, ch,
@@ -2227,7 +2224,7 @@ int zh_distortion_paint(zh_distortion *m, uint32_t start, uint32_t end, const zh
     Img out = mk_img(outputs[0]);
     CImg in = mk_cimg(p->input);
     F32P ig = mk_f32(p->ingain), og = mk_f32(p->outgain), of = mk_f32(p->offset);
-#define ZH_DIST(ZF_, OD_) hipLaunchKernelGGL((k_distortion<ZF_, OD_>), grid, dim3(256), 0, st, m->n, out, in, start, end, ig, og, of)
+#define ZH_DIST(ZF_, OD_) ZH_LAUNCH((k_distortion<ZF_, OD_>), grid, dim3(256), 0, st, m->n, out, in, start, end, ig, og, of)
     if (p->type == ZH_DISTORTION_OVERDRIVE) { if (zf) ZH_DIST(true, true); else ZH_DIST(false, true); }
     else { if (zf) ZH_DIST(true, false); else ZH_DIST(false, false); }
 #undef ZH_DIST

@@ -119,8 +119,7 @@ __global__ void __launch_bounds__(64) k_noise_fix(uint64_t *__restrict__ s0, uin
 // Frames per range for V voices over n frames, or 0 = use the sequential kernel.  Measured on MI355X
 // (profiles/r02/noise_ranges.txt): enough ranges for about one wave per SIMD (1,024), at least 32 frames each.
 uint32_t zh_noise_range_frames(uint32_t V, uint32_t n) {
-    const char *fe = zh_env("ZH_NOISE_RANGES");                          // 0 = off, k = k ranges; live under ZH_ENV_LIVE=1 like the other switches
-    const int forced = fe ? atoi(fe) : -1;
+    const long forced = zh_form(ZF_NOISE_RANGES);                        // -1 = auto, 0 = off, k = k ranges (dispatch.hip)
     if (forced == 0 || V == 0 || n < 128 || n > 2048 || V > 65536) return 0;
     const uint32_t waves = (V + 63) / 64;
     uint32_t want = forced > 0 ? (uint32_t)forced : (V <= 32768 ? 1024u : 2048u) / waves;
@@ -144,8 +143,8 @@ int zh_noise_paint_ranges(zh_ctx *ctx, uint64_t *const s[4], uint64_t *const nex
     a.flag = flag; a.tables = tables; a.V = V; a.start = start; a.end = end; a.ch = ch; a.tstep = ch / 32;
     a.out = mk_img(outb);
     const uint32_t ranges = (end - start + ch - 1) / ch;
-    hipLaunchKernelGGL(k_noise_white_ranges, dim3((V + 255) / 256, ranges), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_noise_fix, dim3((V + 63) / 64), dim3(64), 0, ctx->stream, s[0], s[1], s[2], s[3], next[0], next[1], next[2], next[3],
+    ZH_LAUNCH(k_noise_white_ranges, dim3((V + 255) / 256, ranges), dim3(256), 0, ctx->stream, a);
+    ZH_LAUNCH(k_noise_fix, dim3((V + 63) / 64), dim3(64), 0, ctx->stream, s[0], s[1], s[2], s[3], next[0], next[1], next[2], next[3],
                        flag, V, a.out, start, end);
     return zh_launch_status();
 }

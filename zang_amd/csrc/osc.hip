@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_osc_publish(uint32_t *__restrict__ cnt,
 template <class OSC, class M> static void osc_publish(zh_flipper *f, uint32_t frames, hipStream_t st) {
     M *m = static_cast<M *>(f);
     using K = typename OSC::K;
-    hipLaunchKernelGGL(k_osc_publish, dim3((m->n + 255) / 256), dim3(256), 0, st, m->cnt[m->cur], m->tab.words, m->n,
+    ZH_LAUNCH(k_osc_publish, dim3((m->n + 255) / 256), dim3(256), 0, st, m->cnt[m->cur], m->tab.words, m->n,
                        (uint32_t)(offsetof(K, ifreq) / 4), (uint32_t)(sizeof(K) / 4), frames);
 }
 
@@ -446,10 +446,10 @@ template <class OSC, class M> static void osc_publish(zh_flipper *f, uint32_t fr
 // row order); the per-voice setup is shared through LDS by the four chunks of a block, so short chunks cost little.
 // TriSawOsc's setup (three divides) and sample (~45 instructions) are heavier: it keeps longer chunks -- enough of them
 // for ~4096 waves, at least 8 frames (131,072 voices: 100 us against 131 us with 4 frames per lane).
-// ZH_OSC_FC / ZH_OSC_SCALAR override for experiments.
+// (osc_fc in dispatch.hip overrides.  The A/B switches of rounds 1-4 -- scalar kernel forced, no wave priorities, no FC4 form, no
+// constants table -- are gone with round 5: their forms were measured slower and are not selectable any more.)
 static uint32_t osc_frames_per_lane(bool short_chunks, uint32_t lanes, uint32_t nframes) {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("ZH_OSC_FC"); forced = e ? atoi(e) : 0; }
+    const long forced = zh_form(ZF_OSC_FC);
     if (forced > 0) return (uint32_t)forced;
     if (short_chunks) return 4u;
     const uint64_t groups = (lanes + 63) / 64;
@@ -458,31 +458,9 @@ static uint32_t osc_frames_per_lane(bool short_chunks, uint32_t lanes, uint32_t 
     while (p * 2 <= fc && p < 64) p *= 2;
     return p;
 }
-static bool osc_force_scalar() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("ZH_OSC_SCALAR"); v = e ? atoi(e) : 0; }
-    return v != 0;
-}
-
-static bool osc_prio() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("ZH_OSC_PRIO"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
-static bool osc_no_fc4() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("ZH_OSC_NO_FC4"); v = e ? atoi(e) : 0; }         // A/B: the runtime-length frame loop
-    return v != 0;
-}
-static bool osc_no_table() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("ZH_OSC_NO_TABLE"); v = e ? atoi(e) : 0; }     // A/B: ignore ZH_PAINT_PARAMS_UNCHANGED
-    return v != 0;
-}
 
 template <class OSC> static bool osc_vec_ok(uint32_t n, const zh_buf *outs, uint32_t nb, const zh_f32 &freq, const zh_f32 &color) {
-    bool vec = n % 4 == 0 && (!freq.per_voice || aligned16(freq.per_voice)) && (!color.per_voice || aligned16(color.per_voice)) &&
-               !osc_force_scalar();
+    bool vec = n % 4 == 0 && (!freq.per_voice || aligned16(freq.per_voice)) && (!color.per_voice || aligned16(color.per_voice));
     for (uint32_t b = 0; b < nb && vec; b++)
         vec = outs[b].stride % 4 == 0 && aligned16(outs[b].ptr) && outs[b].stride == outs[0].stride;
     return vec;
@@ -511,16 +489,16 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         // (81 % of the HBM peak there), -20 % at 1,048,576 (3.7 MB per XCD: it thrashes) -- hence the size limit.
         constexpr size_t kw1 = sizeof(typename OSC::K) / 4 + 1;
         const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) &&
-                             (size_t)n * kw1 * 4 <= ((size_t)16 << 20) && !osc_no_table();
+                             (size_t)n * kw1 * 4 <= ((size_t)16 << 20);
         const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
-        const bool fc4 = fc == 4 && (end - start) % 4 == 0 && !osc_no_fc4();
+        const bool fc4 = fc == 4 && (end - start) % 4 == 0;
         // one launch of `a` (images and count filled in) over `cnt_b` buffers
         auto launch = [use_tab, fc4, zf, sm, lanes, chunks](OscArgs a, uint32_t cnt_b, hipStream_t st) {
             dim3 grid((lanes + 63) / 64, (chunks + 3) / 4, cnt_b);
-#define ZH_LAUNCH_O4B(ZF, SM, B) do { if (use_tab && fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, true, B>), grid, dim3(256), 0, st, a); \
-                                      else if (use_tab) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, true, false, B>), grid, dim3(256), 0, st, a); \
-                                      else if (fc4) hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, true, B>), grid, dim3(256), 0, st, a); \
-                                      else hipLaunchKernelGGL((k_osc_const4<OSC, ZF, SM, false, false, B>), grid, dim3(256), 0, st, a); } while (0)
+#define ZH_LAUNCH_O4B(ZF, SM, B) do { if (use_tab && fc4) ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, true, true, B>), grid, dim3(256), 0, st, a); \
+                                      else if (use_tab) ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, true, false, B>), grid, dim3(256), 0, st, a); \
+                                      else if (fc4) ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, false, true, B>), grid, dim3(256), 0, st, a); \
+                                      else ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, false, false, B>), grid, dim3(256), 0, st, a); } while (0)
 #define ZH_LAUNCH_O4(ZF, SM) do { if (cnt_b > 1) ZH_LAUNCH_O4B(ZF, SM, true); else ZH_LAUNCH_O4B(ZF, SM, false); } while (0)
             if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
             else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
@@ -536,7 +514,7 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         if (!use_tab && !ctx->capturing && m->tab.pinned) m->tab.valid = false;
         OscArgs a;
         a.tab = (use_tab || write_tab) ? m->tab.words : nullptr;
-        a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.prio = osc_prio() ? 1u : 0u;
+        a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.prio = 1u;
         a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
         // A table-form paint of a ZH_CAPTURE_COALESCE capture depends on nothing recorded before it -- its phase at any frame is
         // the counter the epoch opened on plus the frames this module has painted since, times ifreq, exactly -- so it is held
@@ -593,8 +571,8 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
             const uint32_t *ci = m->cnt[m->cur];
             uint32_t *co = m->cnt[m->cur ^ 1];
             Img out = mk_img(outs[b]);
-            if (zf) hipLaunchKernelGGL((k_osc_const<OSC, true>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
-            else hipLaunchKernelGGL((k_osc_const<OSC, false>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+            if (zf) ZH_LAUNCH((k_osc_const<OSC, true>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
+            else ZH_LAUNCH((k_osc_const<OSC, false>), grid, dim3(256), 0, st, ci, co, n, out, start, end, fc, srf, sr8, fq, col);
             zh_flipper_painted(m);
             m->cur ^= 1;
         }
@@ -673,7 +651,7 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
         // 24,576 / 32,768 voices: 122 -> 61, 123 -> 77 us; from 65,536 voices the replay's re-read of the frequency image loses
         bool aliased = false;
         for (uint32_t b = 0; b < nb; b++) aliased = aliased || bufs_alias(p->freq.buffer, outputs[b]);
-        const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, "ZH_PULSE_CTRL_RANGES", 2048, 40960);
+        const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, ZF_PULSE_CTRL_RANGES, 2048, 40960);
         for (uint32_t b = 0; b < nb; b++) {
             Img out = mk_img(outputs[b]);
             const uint32_t *ci = m->cnt[m->cur];
@@ -682,12 +660,11 @@ static int pulseosc_paint_n(zh_pulseosc *m, uint32_t start, uint32_t end, const 
             const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
             // the ranges' own sums first (1,024 / 4,096 / 16,384 voices: 28.6 / 36.7 / 49.3 -> 14.6 / 16.0 / 37.9 us; level from
             // 32,768 voices on); ZH_PULSE_CTRL_SUMS=0: every range replays the frames before it
-            const char *se = zh_env("ZH_PULSE_CTRL_SUMS");
-            const int sums = se ? atoi(se) : 1;
+            const long sums = zh_form(ZF_PULSE_CTRL_SUMS);
             const uint32_t *part = chr && sums && m->part && grid.y <= 64 ? m->part : nullptr;
-            if (part) hipLaunchKernelGGL(k_pulseosc_ctrl_sums, grid, dim3(kSeqBlock), 0, st, m->part, m->n, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer));
-            if (zf) hipLaunchKernelGGL(k_pulseosc_ctrl<true>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col, part);
-            else hipLaunchKernelGGL(k_pulseosc_ctrl<false>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col, part);
+            if (part) ZH_LAUNCH(k_pulseosc_ctrl_sums, grid, dim3(kSeqBlock), 0, st, m->part, m->n, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer));
+            if (zf) ZH_LAUNCH(k_pulseosc_ctrl<true>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col, part);
+            else ZH_LAUNCH(k_pulseosc_ctrl<false>, grid, dim3(kSeqBlock), 0, st, ci, co, m->n, out, start, end, ch, srf, sr8, mk_cimg(p->freq.buffer), col, part);
             if (chr) { zh_flipper_painted(m); m->cur ^= 1; }
         }
     }
@@ -762,12 +739,11 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
         for (uint32_t b = 0; b < nb; b++) aliased = aliased || bufs_alias(p->freq.buffer, outputs[b]);
         // 4,096 voices: 106.6 us with per-lane branches in the waveform, 71.3 straight-line, 46.4 as 16 frame ranges (8 / 32 /
         // 64 ranges: 47.9 / 54.7 / 77.2 -- the replay's divide is half of a painted frame); 16,384 voices: 73.7 -> 66.2 with 8
-        const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, "ZH_TRISAW_CTRL_RANGES", 1024, 16384);
+        const uint32_t chr = aliased ? 0 : zh_range_frames(m->n, end - start, ZF_TRISAW_CTRL_RANGES, 1024, 16384);
         // ... and 39.3 us (1,024 voices: 43 -> 26) with the quotients painted first (module-owned image, allocated outside a
         // capture; ZH_TRISAW_CTRL_QUOT=0: never).  (Tried: two or four batches of 32 rows kept in flight by an explicit rotation in
         // these replays -- SineOsc 27 -> 40 / 60 us, TriSawOsc 39 -> 45 / 53: slower; the plain batch loops stay.)
-        const char *qe = zh_env("ZH_TRISAW_CTRL_QUOT");
-        const int want_quot = qe ? atoi(qe) : 1;
+        const long want_quot = zh_form(ZF_TRISAW_CTRL_QUOT);
         bool quot = false;
         if (chr && want_quot) {
             if ((m->quot.frames < end || !m->quot.ptr) && !m->ctx->capturing) {
@@ -780,7 +756,7 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
             quot = m->quot.ptr && m->quot.frames >= end;
         }
         if (quot)
-            hipLaunchKernelGGL(k_div_image, dim3((m->n + 63) / 64, ((end - start + 31) / 32 + 3) / 4), dim3(256), 0, st, mk_img(m->quot), mk_cimg(p->freq.buffer),
+            ZH_LAUNCH(k_div_image, dim3((m->n + 63) / 64, ((end - start + 31) / 32 + 3) / 4), dim3(256), 0, st, mk_img(m->quot), mk_cimg(p->freq.buffer),
                                m->n, start, end, p->sample_rate);
         const CImg fimg = quot ? mk_cimg(m->quot) : mk_cimg(p->freq.buffer);
         for (uint32_t b = 0; b < nb; b++) {
@@ -788,11 +764,11 @@ static int trisawosc_paint_n(zh_trisawosc *m, uint32_t start, uint32_t end, cons
             float *to = chr ? m->t_next : m->t;
             const uint32_t ch = chr ? chr : end - start;
             const dim3 grid((m->n + kSeqBlock - 1) / kSeqBlock, chr ? (end - start + chr - 1) / chr : 1);
-#define ZH_TSC(ZF_, Q_) hipLaunchKernelGGL((k_trisawosc_ctrl<ZF_, Q_>), grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, fimg, mk_f32(p->color))
+#define ZH_TSC(ZF_, Q_) ZH_LAUNCH((k_trisawosc_ctrl<ZF_, Q_>), grid, dim3(kSeqBlock), 0, st, m->t, to, m->n, out, start, end, ch, p->sample_rate, fimg, mk_f32(p->color))
             if (zf) { if (quot) ZH_TSC(true, true); else ZH_TSC(true, false); }
             else { if (quot) ZH_TSC(false, true); else ZH_TSC(false, false); }
 #undef ZH_TSC
-            if (chr) hipLaunchKernelGGL(k_commit_f32, dim3((m->n + 255) / 256), dim3(256), 0, st, m->t, m->t_next, m->n);
+            if (chr) ZH_LAUNCH(k_commit_f32, dim3((m->n + 255) / 256), dim3(256), 0, st, m->t, m->t_next, m->n);
         }
     }
     return zh_launch_status();

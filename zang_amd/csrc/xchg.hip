@@ -79,8 +79,8 @@ int zh_sum_slots(zh_ctx *ctx, float *dst, const float *slots, uint32_t n_slots, 
     if (n == 0) return ZH_OK;
     const int zf = (int)(flags & ZH_PAINT_ZERO_FIRST);
     const bool vec = n % 4 == 0 && slot_stride_floats % 4 == 0 && (((uintptr_t)dst | (uintptr_t)slots) & 15u) == 0;
-    if (vec) hipLaunchKernelGGL(k_sum_slots<4>, dim3((uint32_t)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dst, slots, n_slots, slot_stride_floats, n, zf);
-    else hipLaunchKernelGGL(k_sum_slots<1>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst, slots, n_slots, slot_stride_floats, n, zf);
+    if (vec) ZH_LAUNCH(k_sum_slots<4>, dim3((uint32_t)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dst, slots, n_slots, slot_stride_floats, n, zf);
+    else ZH_LAUNCH(k_sum_slots<1>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst, slots, n_slots, slot_stride_floats, n, zf);
     return zh_launch_status();
 }
 

@@ -36,6 +36,21 @@ class Context:
     def sync(self):
         abi.check(self.lib.zh_sync(self.handle), "zh_sync")
 
+    def last_form(self):
+        """Kernels the last paint (or other entry point) on this context launched, in launch order (zh_last_form)."""
+        buf = C.create_string_buffer(512)
+        abi.check(self.lib.zh_last_form(self.handle, buf, 512), "zh_last_form")
+        return [k for k in buf.value.decode().split(",") if k]
+
+    def forms(self):
+        """The library's dispatch table: {name: (default, current, doc)} (zh_form_info, csrc/dispatch.hip)."""
+        out = {}
+        for i in range(self.lib.zh_form_count()):
+            name, doc, d, c = C.c_char_p(), C.c_char_p(), C.c_long(), C.c_long()
+            abi.check(self.lib.zh_form_info(i, C.byref(name), C.byref(d), C.byref(c), C.byref(doc)), "zh_form_info")
+            out[name.value.decode()] = (d.value, c.value, doc.value.decode())
+        return out
+
     def close(self):
         """Destroy the context; modules and graphs created on it are closed first (their C objects
         hold a pointer to the context)."""
