@@ -679,7 +679,15 @@ class HipEmitter:
             # is shared by two CUs
             unroll = int(os.environ.get("ZH_SCRIPT_UNROLL", "0")) or (8 if len(k.frame) <= 40 else 4 if len(k.frame) <= 100 else 2)
             I = "    "
+            # state words the epilogue stores (the loader takes the frame-range form only when it is every word: csrc/zscript_emit.hip)
+            stored = set()
+            for ln in k.epi_ends + k.epi_stores:
+                for mt in re.finditer(r"zs_st_(f|u|u64)\(L\.state, ([0-9]+), V, v,", ln):
+                    w = int(mt.group(2))
+                    stored |= {w, w + 1} if mt.group(1) == "u64" else {w}
+            stored = {w for w in stored if w < k.words}
             out += ["", 'extern "C" __device__ const uint32_t zs_ranges_ok_%s = %du;' % (name, 0 if (k.rings or k.walk_reads_computed) else 1),
+                    'extern "C" __device__ const uint32_t zs_state_words_stored_%s = %du;' % (name, len(stored)),
                     'extern "C" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {' % name,
                     I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;", I + "if (v >= V) return;",
                     I + "for (uint32_t w = 0; w < %du; w++) st[(size_t)w * V + v] = 0u;" % k.words]

@@ -473,3 +473,33 @@ def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
                 if step >= 1 + 2 * K:
                     util.assert_bitexact(got[step - 1 - 2 * K][q], ref, f"K={K} voice {v} step {step}")
             assert int(cnt[q]) == int(st.cnt), (K, v)
+
+
+def test_graph_destroyed_after_its_context_is_harmless():
+    """the documented order is graphs before their context, but a host written against the earlier rounds destroyed the
+    context first -- zh_graph_destroy then dereferenced freed memory.  zh_destroy now makes its live graphs forget it: a late
+    zh_graph_destroy frees the graph alone, and launching such a graph is refused (through the C ABI directly: the Python
+    Context closes its children first)."""
+    import torch
+    from zang_amd import abi
+    lib = abi.load()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        h = C.c_void_p()
+        assert lib.zh_create(C.byref(h), 0) == 0
+        assert lib.zh_set_stream(h, C.c_void_p(side.cuda_stream)) == 0
+        img = torch.zeros((64, 256), dtype=torch.float32, device="cuda")
+        buf = abi.Buf(img.data_ptr(), 256, 64, 256, 0)
+        assert lib.zh_graph_begin_capture(h) == 0
+        assert lib.zh_zero(h, 0, 64, buf) == 0
+        g = C.c_void_p()
+        assert lib.zh_graph_end_capture(h, C.byref(g)) == 0
+        assert lib.zh_graph_launch(h, g) == 0
+        assert lib.zh_sync(h) == 0
+        h2 = C.c_void_p()
+        assert lib.zh_create(C.byref(h2), 0) == 0
+        assert lib.zh_graph_launch(h2, g) == abi.ZH_ERR_INVALID          # another context's graph
+        assert lib.zh_destroy(h) == 0                                      # the context first ...
+        assert lib.zh_graph_launch(h2, g) == abi.ZH_ERR_INVALID
+        assert lib.zh_graph_destroy(g) == 0                                # ... then its graph: nothing of the context is touched
+        assert lib.zh_destroy(h2) == 0

@@ -72,6 +72,7 @@ struct zh_ctx {
     size_t mix_partials_floats;
     std::vector<float *> mix_retired;
     uint32_t graphs_live;        // graphs captured on this context and not yet destroyed: only they can still name a retired block
+    std::vector<struct zh_graph *> graphs;   // ... themselves: zh_destroy clears their `ctx`, so that a graph destroyed AFTER its context touches nothing of it
     bool capturing;
     std::vector<zh_flip_use> capture_log;
     void *noise_jump;            // xoshiro256++ jump tables (noise_jump.hip), built on first use, freed with the context

@@ -122,6 +122,10 @@ int zh_create(zh_ctx **out, int device) {
 int zh_destroy(zh_ctx *ctx) { ZH_GUARD(ctx);
     if (!ctx) return ZH_ERR_INVALID;
     hipStreamSynchronize(ctx->stream);
+    // graphs that outlive their context (the documented order is graphs first; a host written against rounds 1-3 may not keep it):
+    // they forget the context, and zh_graph_destroy then frees the graph alone (it used to dereference the freed context)
+    for (zh_graph *g : ctx->graphs) g->ctx = nullptr;
+    ctx->graphs.clear();
     if (ctx->mix_partials) hipFree(ctx->mix_partials);
     for (float *p : ctx->mix_retired) hipFree(p);
     if (ctx->noise_jump) hipFree(ctx->noise_jump);
@@ -281,6 +285,7 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
     hipError_t e = hipGraphInstantiate(&zg->exec, g, nullptr, nullptr, 0);
     if (e != hipSuccess) { hipGraphDestroy(g); delete zg; return (int)e; }
     ctx->graphs_live++;
+    ctx->graphs.push_back(zg);
     zg->flips.swap(log);
     zg->co_paints = ctx->co_paints; zg->co_launches = ctx->co_launches;
     size_t nn = 0;
@@ -291,7 +296,7 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
 }
 
 int zh_graph_launch(zh_ctx *ctx, zh_graph *graph) { ZH_GUARD(ctx);
-    if (!ctx || !graph || ctx->capturing) return ZH_ERR_INVALID;
+    if (!ctx || !graph || ctx->capturing || graph->ctx != ctx) return ZH_ERR_INVALID;     // (graph->ctx is null once its context was destroyed)
     // A replay reads each chunked oscillator's phase counters from the buffer the capture started on.  Paints since
     // then (eager ones, or another graph with an odd number of them) may have left the live state in the other
     // buffer: copy it over first (n * 4 bytes, enqueued ahead of the replay), then account for the replay's flips.
@@ -329,6 +334,10 @@ int zh_graph_destroy(zh_graph *graph) {
     delete graph;
     // the last graph is gone: nothing can name a retired scratch block any more (a host that went from single paints
     // to batches kept every outgrown block until zh_destroy).  hipFree waits for the work in flight.
+    if (ctx) {
+        for (size_t i = 0; i < ctx->graphs.size(); i++)
+            if (ctx->graphs[i] == graph) { ctx->graphs.erase(ctx->graphs.begin() + (long)i); break; }
+    }
     if (ctx && ctx->graphs_live && --ctx->graphs_live == 0) {
         for (float *p : ctx->mix_retired) (void)hipFree(p);
         ctx->mix_retired.clear();

@@ -11,7 +11,9 @@
 
 // The [word][voice] state blob of a script module.  A kernel launched with gridDim.y > 1 paints the span as gridDim.y
 // frame ranges at once (zs_frame_loop below): every range loads the span's start state from `cur`, and only the range
-// that ends the span stores -- into `next`, which the loader copies over `cur` afterwards (script.hip).
+// that ends the span stores -- EVERY state word, into `next` -- and the loader then flips the two blobs on the host
+// (script.hip, zh_flipper; the emitter exports the count of stored words, zs_state_words_stored_<name>, and the loader takes
+// the range form only when it equals the module's state words).
 struct ZsState {
     uint32_t *cur, *next;
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)

@@ -11,6 +11,7 @@
 
 #include "../../include/zang_hip.h"
 #include "zscript.hpp"
+#include <regex>
 
 namespace zs {
 namespace {
@@ -1065,6 +1066,26 @@ public:
             // 1: the paint kernel may be launched as frame ranges (script_rt.hip.h zs_frame_loop); 0: its frame body writes memory
             // (a delay ring), or replaying its state walk would cost as much as painting (see call_builtin)
             out.push_back(strf("extern \"C\" __device__ const uint32_t zs_ranges_ok_%s = %uu;", nc, (k.rings || k.walk_reads_computed) ? 0u : 1u));
+            {
+                // how many of the module's state words the kernel's epilogue stores.  A launch as frame ranges writes the end state into
+                // the OTHER blob and the host flips (script.hip): that is only right when EVERY word is stored, so the loader takes the
+                // range form only where this count equals the module's state words (the invariant was pinned by a CPU test
+                // of the emitter alone).
+                std::vector<bool> stored(k.words, false);
+                static const std::regex re("zs_st_(f|u|u64)\\(L\\.state, ([0-9]+), V, v,");
+                auto scan = [&](const Lines &ls) {
+                    for (const std::string &ln : ls)
+                        for (std::sregex_iterator it(ln.begin(), ln.end(), re), end; it != end; ++it) {
+                            const size_t w = (size_t)std::stoul((*it)[2].str());
+                            if (w < stored.size()) stored[w] = true;
+                            if ((*it)[1].str() == "u64" && w + 1 < stored.size()) stored[w + 1] = true;
+                        }
+                };
+                scan(k.epi_ends); scan(k.epi_stores);
+                size_t n_stored = 0;
+                for (bool b : stored) n_stored += b ? 1 : 0;
+                out.push_back(strf("extern \"C\" __device__ const uint32_t zs_state_words_stored_%s = %zuu;", nc, n_stored));
+            }
             out.push_back(strf("extern \"C\" __global__ void zs_init_%s(uint32_t *__restrict__ st, uint32_t V, uint64_t first_seed) {", nc));
             out.push_back(I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;");
             out.push_back(I + "if (v >= V) return;");
