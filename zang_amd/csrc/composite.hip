@@ -2141,9 +2141,10 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
                 a.serial = m->tp_serial;
                 a.per = (m->n + 255u) / 256u;
                 const dim3 grid(((a.C + 7u) / 8u) * 8u * a.per);                         // chunk j of every group on XCD j % 8 (nf_tp_block)
+                const dim3 grid_b(8u * a.C * ((a.per + 7u) / 8u));                         // every chunk of a voice group on XCD g % 8 (nf_tp_block_b)
                 ZH_LAUNCH(k_nf_tp_a, grid, dim3(256), 0, st, a);
-                if (zf) ZH_LAUNCH(k_nf_tp_b<true>, grid, dim3(256), 0, st, a);
-                else ZH_LAUNCH(k_nf_tp_b<false>, grid, dim3(256), 0, st, a);
+                if (zf) ZH_LAUNCH(k_nf_tp_b<true>, grid_b, dim3(256), 0, st, a);
+                else ZH_LAUNCH(k_nf_tp_b<false>, grid_b, dim3(256), 0, st, a);
             }
             return zh_launch_status();
         }

@@ -272,6 +272,15 @@ template <class A> __device__ __forceinline__ bool nf_tp_block(const A &a, uint3
     j = band * 8u + (rr & 7u); g = rr >> 3;
     return j < a.C;
 }
+// ... and pass B the other way round: every chunk of voice group g on XCD g % 8 (grid of 8 * C * ceil(per / 8) blocks).  Pass B reads
+// the e_i of EVERY earlier chunk of its voices: with the groups' chunks on one XCD each 2 KiB block of e is fetched into one L2 once
+// and hit by the other chunks (measured with pass A's mapping in pass B too: 13 MB of reads per buffer instead of 5,
+// profiles/r05/pmc_traffic_noise_filter_fused4096_tolerant.json history in NOTES.md).
+template <class A> __device__ __forceinline__ bool nf_tp_block_b(const A &a, uint32_t &j, uint32_t &g) {
+    const uint32_t id = blockIdx.x, k = id >> 3;
+    j = k % a.C; g = (k / a.C) * 8u + (id & 7u);
+    return g < a.per;
+}
 
 // ---------------------------------------------------------------------------------------------------- white Noise -> Filter
 #if defined(ZH_FILTER_TP_NOISE)          // (composite.hip only: the kernels below are not templates)
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
     uint32_t j, g;
-    if (!nf_tp_block(a, j, g)) return;
+    if (!nf_tp_block_b(a, j, g)) return;
     const uint32_t v = g * 256 + threadIdx.x;
     if (v >= a.V) return;
     const size_t V = a.V;
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__(256) k_pink_tp_a(const PinkTpArgs a) {
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_pink_tp_b(const PinkTpArgs a) {
     uint32_t j, g;
-    if (!nf_tp_block(a, j, g)) return;
+    if (!nf_tp_block_b(a, j, g)) return;
     const uint32_t v = g * 256 + threadIdx.x;
     if (v >= a.V) return;
     const size_t V = a.V;

@@ -1553,9 +1553,10 @@ int zh_noise_paint(zh_noise *m, uint32_t start, uint32_t end, const zh_buf *outp
                 a.serial = m->tp_serial;
                 a.per = (m->n + 255u) / 256u;
                 const dim3 grid(((a.C + 7u) / 8u) * 8u * a.per);                         // filter_tp.hip.h nf_tp_block
+                const dim3 grid_b(8u * a.C * ((a.per + 7u) / 8u));                         // nf_tp_block_b
                 ZH_LAUNCH(k_pink_tp_a, grid, dim3(256), 0, st, a);
-                if (zf) ZH_LAUNCH(k_pink_tp_b<true>, grid, dim3(256), 0, st, a);
-                else ZH_LAUNCH(k_pink_tp_b<false>, grid, dim3(256), 0, st, a);
+                if (zf) ZH_LAUNCH(k_pink_tp_b<true>, grid_b, dim3(256), 0, st, a);
+                else ZH_LAUNCH(k_pink_tp_b<false>, grid_b, dim3(256), 0, st, a);
             }
             return zh_launch_status();
         }
