@@ -63,7 +63,7 @@ STATE_INPUTS = {"SineOsc": ("freq",), "PulseOsc": ("freq",), "TriSawOsc": ("freq
 # error can only be scaled and added on its way to the output -- through + - * neg abs min max, copies, a Filter's or a Decimator's
 # `input`, a delay ring written (not read: a ring's content is of unknown origin, ALL_SINES).  Every other place a value can go is a
 # SINK that keeps the sines reaching it exact: any other builtin param (an oscillator's freq / phase: the error would be integrated
-# or -- PMOscInstrument, DESIGN.md 5a -- multiplied by the carrier's slope at a large argument; a Distortion's input: gain up to
+# or -- PMOscInstrument, profiles/r04/NOTES.md 5a -- multiplied by the carrier's slope at a large argument; a Distortion's input: gain up to
 # 64), the argument of sin / cos / sqrt, a divisor, both operands of pow.
 LINEAR_INPUTS = {("Filter", "input"), ("Decimator", "input")}
 ALL_SINES = (1 << 64) - 1

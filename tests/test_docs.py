@@ -42,3 +42,36 @@ def test_at_most_thirty_environment_switches_in_the_library():
         if os.path.isfile(f) and f.endswith((".hip", ".h", ".hpp")):
             names |= set(re.findall(r'"(ZH_[A-Z0-9_]+)"', open(f, errors="ignore").read()))
     assert len(names) <= 30, sorted(names)
+
+
+def test_design_and_readme_are_pages_not_notebooks():
+    """DESIGN.md is the CURRENT state in at most 400 lines of at most 160 columns (history lives in
+    profiles/rNN/NOTES.md), README.md a page with tables."""
+    for name, max_lines in (("DESIGN.md", 400), ("README.md", 120)):
+        lines = open(os.path.join(ROOT, name)).read().split("\n")
+        assert len(lines) <= max_lines, (name, len(lines))
+        wide = [(i + 1, len(ln)) for i, ln in enumerate(lines) if len(ln) > 160]
+        assert not wide, (name, wide[:5])
+
+
+def test_every_file_design_md_cites_exists():
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = []
+    for m in re.finditer(r"`([A-Za-z0-9_./*{},-]+)`", text):
+        tok = m.group(1)
+        if "/" not in tok and not tok.endswith((".md", ".py", ".txt", ".json", ".csv", ".hip", ".h", ".hpp", ".zig", ".c", ".cpp", ".so")):
+            continue
+        if tok.startswith(("src/", "examples/")) or "rNN" in tok or tok.startswith("/"):
+            continue                                              # reference paths, placeholders
+        tok = tok.split("::")[0]
+        cands = [tok, os.path.join("profiles", "r05", tok), os.path.join("zang_amd", "csrc", tok), os.path.join("zang_amd", tok),
+                 os.path.join("tests", tok), os.path.join("tools", tok), os.path.join("include", tok)]
+        if "{" in tok:                                            # zang_amd/{abi,zang,...}.py
+            head, rest = tok.split("{", 1)
+            alts, tail = rest.split("}", 1)
+            ok = all(glob.glob(os.path.join(ROOT, head + a + tail)) or glob.glob(os.path.join(ROOT, "profiles", "r05", head + a + tail)) for a in alts.split(","))
+        else:
+            ok = any(glob.glob(os.path.join(ROOT, c)) for c in cands)
+        if not ok:
+            missing.append(tok)
+    assert not missing, sorted(set(missing))

@@ -50,7 +50,7 @@ def test_chunked_filter_is_within_the_tolerance_of_the_oracle(oracle, ftype, mul
 
 
 def test_the_per_sample_metric_cannot_be_met_near_zero_crossings(oracle):
-    """The written counter-example: inside 1e-5 of the peak everywhere, yet some samples near zero crossings miss
+    """The written counter-example (profiles/r04/NOTES.md 5a): inside 1e-5 of the peak everywhere, yet some samples near zero crossings miss
     tests/util.py's per-sample metric, whose tolerance there (1e-8) is below one ulp of the O(1) state they are computed from."""
     V = 64
     rng = np.random.default_rng(3)

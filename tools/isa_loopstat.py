@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per kernel of a device assembly listing: the largest innermost loop's instruction count, how many of them are
 exec-mask / branch instructions, VALU instructions and memory instructions -- the quickest way to see a per-lane `if` that
-became an exec-mask region in a frame loop.
+became an exec-mask region in a frame loop (profiles/r04/NOTES.md 5a).
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -S --cuda-device-only \\
           -o /tmp/modules.s zang_amd/csrc/modules.hip

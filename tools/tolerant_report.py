@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU: how far the ZH_PAINT_TOLERANT forms (csrc/filter_tp.hip.h) are from the oracle, case by case -- the numbers DESIGN.md 5a
+"""GPU: how far the ZH_PAINT_TOLERANT forms (csrc/filter_tp.hip.h) are from the oracle, case by case -- the numbers profiles/r04/NOTES.md 5a
 quotes (profiles/r04/tolerant_error.txt).  Per case: the worst voice's max |gpu - oracle| over the span relative to that voice's
 peak (the form's contract: <= 1e-5), the median voice, the share of samples inside tests/util.py's PER-SAMPLE metric
 |err| <= 1e-5 max(|ref|, 1e-3) -- which no re-association of an f32 recurrence meets near zero crossings: the counter-example the

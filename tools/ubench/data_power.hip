@@ -1,5 +1,5 @@
 // GPU box: hipcc -O3 --offload-arch=gfx950 -o tools/ubench/data_power tools/ubench/data_power.hip && tools/ubench/data_power
-// Does the shader clock of a full-chip VALU kernel depend on the DATA it computes on?  (the config-5 kernels'
+// Does the shader clock of a full-chip VALU kernel depend on the DATA it computes on?  (profiles/r04/NOTES.md 5a: the config-5 kernels'
 // per-buffer time drifts inside one envelope stage, where the instruction stream does not change.)  One kernel, 2,048 waves
 // (two per SIMD), a fixed stream of dependent v_mul_f32 / v_add_f32 on eight registers per lane for ~500 us, twenty launches back to back (the second round prints them one by one); the operands
 // are (a) zeros, (b) small round numbers (few mantissa bits set), (c) random mantissas around 1.  clock64() counts shader

@@ -18,7 +18,7 @@
 // and 1.0, cutoff 0 / 1e-4 / 1.0, inputs scaled by 1e-30 .. 1e30) -- inside 1e-5 relative to the signal.  It is NOT inside
 // tests/util.py's per-sample metric |err| <= 1e-5 max(|ref|, 1e-3) near zero crossings (1-3 % of the samples): there the metric's
 // tolerance is 1e-8 against a signal of order 1, below one ulp of the state the sample was computed from, which no
-// re-association of the recurrence can meet.  DESIGN.md 5a states both figures.
+// re-association of the recurrence can meet.  profiles/r04/NOTES.md 5a states both figures.
 //
 // Both users run it as TWO kernels over a grid of (256 voices, chunk) workgroups, e_j through a module-owned scratch in HBM:
 // k_filter_tp_a / _b   Filter module, input image (read by both passes, the second time from L2).

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_sineosc(float *__restrict__ t_io,
 // the span's start phase after f0 - start additions of `t_step` (or of `freq[i] * inv_sr`), each rounded to f32 -- so a
 // range first REPLAYS those additions (one dependent add per earlier frame: cheap beside the ~50 instructions of a musl
 // sine) and then paints its own frames exactly like k_sineosc; the range that ends the span publishes the wrapped phase.
-// Every frame is written once, so `+=` paints need no scratch.  147 -> see DESIGN.md 5a at 4,096 voices.
+// Every frame is written once, so `+=` paints need no scratch.  147 -> see profiles/r04/NOTES.md 5a at 4,096 voices.
 template <bool ZF, bool FB, bool PB, bool TOL = false>
 __global__ void __launch_bounds__(64) k_sineosc_ranges(const float *__restrict__ t_in, float *__restrict__ t_out, uint32_t V, Img out,
                                                        uint32_t start, uint32_t end, uint32_t ch, float sample_rate, CobP freq, CobP phase) {

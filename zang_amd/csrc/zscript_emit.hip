@@ -345,7 +345,7 @@ struct Val {
 // error can only be scaled and added on its way to the output -- through + - * neg abs min max, copies, a Filter's or a Decimator's
 // `input`, a delay ring written (not read: a ring's content is of unknown origin, kAllSines).  Every other place a value can go is a
 // SINK that keeps the sines reaching it exact: any other builtin param (an oscillator's freq / phase: the error would be integrated
-// or -- PMOscInstrument, DESIGN.md 5a -- multiplied by the carrier's slope at a large argument; a Distortion's input: gain up to
+// or -- PMOscInstrument, profiles/r04/NOTES.md 5a -- multiplied by the carrier's slope at a large argument; a Distortion's input: gain up to
 // 64), the argument of sin / cos / sqrt, a divisor, both operands of pow.
 const uint64_t kAllSines = ~0ull;
 const size_t kMaxSines = 63;          // sources beyond this many in one kernel stay exact
