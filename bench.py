@@ -847,6 +847,7 @@ def main():
         else:
             from zang_amd import sharding
             try:
+                lib.zh_comm_set_timeout(90.0)            # the rendezvous is bounded (180 s by default): a bench run fails over sooner
                 comm = sharding.Comm(ctx, control_group=ctl)
             except Exception as e:      # noqa: BLE001  (every rank raises together: Comm agrees on availability first)
                 comm_note = f"zh_comm unavailable ({type(e).__name__}: {e}); torch.distributed nccl instead"[:300]
