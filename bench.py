@@ -906,9 +906,8 @@ def main():
                     wl.nsteps = 0               # the graph holds buffers 0..G-1 of the note pattern
                 wl.batch_rows = min(self.G, 48)
                 # pulseosc: ZH_CAPTURE_COALESCE -- the steps' paints (params unchanged: the phase at any frame is the entry counter +
-                # frames * ifreq exactly, PulseOsc.zig:111) are held back while recording and become one launch per 32 buffers, plus
-                # one node that publishes the advanced counters.  The step is still one zero+paint CALL per buffer; what the graph
-                # replays is fewer, larger launches (ZH_BENCH_IN_ORDER=1: one kernel node per step, the round-4 form)
+                # frames * ifreq exactly, PulseOsc.zig:111) are held back while recording and become one launch per <= 32 buffers.  The
+                # step is still one zero+paint CALL per buffer; what the graph replays is fewer, larger launches (ZH_BENCH_IN_ORDER=1: one kernel node per step, the round-4 form)
                 self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=((name == "pulseosc" and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
                 self.graph_nodes, self.graph_held, self.graph_launches = self.graph.info()
             # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
@@ -1086,8 +1085,8 @@ def main():
                                 else f"zero+paint per {F}-frame buffer, 48 kHz"),
                    "voices_per_gpu": V, "total_voices": V * world, "frames": F, "ring_images": wl.nring,
                    "launch": "eager" if graph is None else (f"hipGraph x{G} steps" + (
-                       f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launch(es) of up to 32 "
-                       f"buffers each (grid.z) + 1 node that publishes the phase counters; {main_run.graph_nodes} nodes" if main_run.graph_held
+                       f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launches of up to 32 "
+                       f"buffers each (grid.z; an even number, so that a replay ends on the counter buffer it began on); {main_run.graph_nodes} nodes" if main_run.graph_held
                        else "")),
                    "graph_nodes": main_run.graph_nodes,
                    "parallelism": f"voices sharded x{world}"},

@@ -168,10 +168,12 @@ ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
  * after buffer with unchanged params.  Their phase counter at any frame is the counter at capture entry + frames painted
  * since * ifreq EXACTLY (`cnt +%= ifreq`, PulseOsc.zig:111, TriSawOsc.zig:115), so no paint needs the counters the previous
  * one left: consecutive paints of one module over the same span into images that do not overlap are recorded as ONE
- * launch of up to 32 buffers (the form zh_pulseosc_paint_batch launches), and one small node publishes the advanced
- * counters when something else is recorded or the capture ends.  Replays give the same bits as a capture without the
- * flag; what changes is that one launch's ramp and tail are shared by the buffers.  Every other call first records what was
- * held back, then itself, in order as before.
+ * launch of up to 32 buffers (exactly the launch zh_pulseosc_paint_batch makes: counters read once, written once).  When
+ * something else is recorded, or the capture ends, what is held back goes out -- as two launches of half the buffers each
+ * where one would leave the module's double-buffered counters on the other side (a replay then ends on the buffer it began
+ * on and nothing has to be copied).  Replays give the same bits as a capture without the flag; what changes is that one
+ * launch's ramp and tail are shared by the buffers.  Every other call first records what was held back, then itself, in
+ * order as before.
  * (Measured and rejected, profiles/r05/ab_capture_lanes.txt + ubench_launch_overlap.txt: the same paints as parallel graph
  * branches on 2-4 forked streams -- kernels from different queues slow each other down, 5.0-5.6 against 4.5 us per buffer.) */
 enum { ZH_CAPTURE_COALESCE = 1 };

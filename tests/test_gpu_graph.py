@@ -377,8 +377,8 @@ def test_graph_with_params_unchanged_paint_keeps_its_constants(ctx):
 @pytest.mark.parametrize("kind", ["pulse", "trisaw"])
 def test_coalescing_capture_equals_eager(ctx, kind):
     """ZH_CAPTURE_COALESCE: table-form oscillator paints are held back while recording and consecutive ones
-    become one launch of several buffers -- each buffer reads the counters the capture entered on plus its own frame offset,
-    one node publishes the advanced counters at the end -- against the same calls made eagerly on a twin module.  The recorded
+    become one launch of several buffers (the zh_*_paint_batch launch: counters read once, written once, one flip) -- against
+    the same calls made eagerly on a twin module.  The recorded
     sequence mixes: spans of different lengths (a new launch each), an image painted twice (ZERO_FIRST then `+=` by another
     module: must keep the recorded order), a paint WITHOUT the flag in the middle (ends the epoch: launched, published,
     recorded in order), another library call on the stream (zero: ends the epoch too), a run of equal spans (merged), a _batch
@@ -435,16 +435,17 @@ def test_coalescing_capture_equals_eager(ctx, kind):
 
 
 def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
-    """bench.py's pulseosc graph as it is recorded now (20 zero+paint steps over distinct ring images, ZH_CAPTURE_COALESCE: one
-    launch of 20 buffers + the publish node): after three replays every image of the ring equals the oracle's buffer of that
-    step, and the carried counters equal the oracle's -- on every 8th voice.  40 steps: two launches (32 + 8 buffers)."""
+    """bench.py's pulseosc graph as it is recorded now (20 zero+paint steps over distinct ring images, ZH_CAPTURE_COALESCE: two
+    launches of 10 buffers, so that a replay ends on the counter buffer it began on): after three replays every image of the
+    ring equals the oracle's buffer of that step, and the carried counters equal the oracle's -- on every 8th voice.  40 steps:
+    32 + 8 buffers; 33 steps: 32 + 1, an odd number of flips, reconciled by zh_graph_launch."""
     import torch
     import zang_amd
     from zang_amd import modules as mod, zang, workloads
     V = 4096
     freq, color, _, _ = workloads.voice_params(2, 0, V)
     L = oracle.lib()
-    for K, want_launches in ((20, 1), (40, 2)):
+    for K, want_launches in ((20, 2), (40, 2), (33, 3)):        # 10 + 10; 32 + 8; 32, then 1 alone (odd: zh_graph_launch copies the counters)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             c2 = zang_amd.Context(0)
@@ -457,7 +458,7 @@ def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
             c2.sync()
             g = c2.capture(lambda: [m.paint(sp, [o], [], False, P, zero_first=True, params_unchanged=True) for o in ring], coalesce=True)
             nodes, held, launches = g.info()
-            assert (held, launches) == (K, want_launches) and nodes == want_launches + 1, (nodes, held, launches)
+            assert (held, launches) == (K, want_launches) and nodes == want_launches, (nodes, held, launches)
             for _ in range(3):
                 g.launch()
             c2.sync()

@@ -40,13 +40,8 @@ struct zh_flip_use {
 // before them -- the constant-frequency oscillators in table form, whose phase at any frame is the capture-entry counter plus
 // frames * ifreq exactly -- are not launched when they are recorded: consecutive ones of the same module and span are held back
 // and recorded as ONE launch of several buffers (grid.z).  Anything else the library records first launches what is held back
-// and publishes the advanced counters (an "epoch" ends).
+// (an "epoch" ends).
 struct zh_flipper;
-struct zh_epoch_pending {
-    zh_flipper *f;
-    uint32_t frames;                                          // frames painted since the epoch opened
-    void (*publish)(zh_flipper *f, uint32_t frames, hipStream_t st);   // cnt[cur] += frames * ifreq, in place
-};
 struct zh_co_batch {             // the paints held back: same module, span, flags and row stride; images that do not overlap
     bool active = false;
     zh_flipper *owner = nullptr;
@@ -60,9 +55,8 @@ struct zh_ctx {
     hipStream_t stream;
     bool own_stream;
     uint32_t capture_flags;      // of the capture that is recording (0 outside one)
-    bool epoch_open;             // paints are held back and / or counters wait to be published
+    bool epoch_open;             // paints are held back
     zh_co_batch co;
-    std::vector<zh_epoch_pending> epoch_pending;
     uint32_t co_paints, co_launches;   // of the capture that is recording: paint calls held back, launches they became
     std::string last_form;       // kernels launched by the last entry point on this context that launched any (zh_last_form)
     bool form_fresh;             // the running entry point has not launched yet: its first launch starts the record afresh
@@ -114,11 +108,9 @@ struct ZhFormScope {                         // (entry points call entry points:
 #define ZH_GUARD_EPOCH(ctxptr) const zh_ctx *_zh_gctx = (ctxptr); ZhDeviceGuard _zh_guard(_zh_gctx ? _zh_gctx->device : -1); ZhFormScope _zh_fscope(_zh_gctx)
 #define ZH_LAUNCH(kernel, ...) do { zh_note_launch(zh_tls_ctx, #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
 #define ZH_GUARD(ctxptr) ZH_GUARD_EPOCH(ctxptr); do { if (_zh_gctx && _zh_gctx->epoch_open) zh_epoch_barrier(const_cast<zh_ctx *>(_zh_gctx)); } while (0)
-// ctx.hip: launch the batch that is held back (if any); the epoch stays open (counters unpublished)
-void zh_epoch_flush_batch(zh_ctx *ctx);
-// frames of module `f` painted so far in the open epoch; account for `frames` more
-uint32_t zh_epoch_frames(zh_ctx *ctx, zh_flipper *f);
-void zh_epoch_painted(zh_ctx *ctx, zh_flipper *f, uint32_t frames, void (*publish)(zh_flipper *, uint32_t, hipStream_t));
+// ctx.hip: launch the batch that is held back (if any).  `last` = the epoch ends here: the batch may go out as two launches so
+// that its module's flips in the capture stay even (osc.hip launch_osc_const)
+void zh_epoch_flush_batch(zh_ctx *ctx, bool last);
 
 // ctx.hip: registry of live flippers + the capture log
 void zh_flipper_register(zh_flipper *f);

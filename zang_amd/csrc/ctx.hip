@@ -40,32 +40,30 @@ void zh_flipper_painted(zh_flipper *f) {
 }
 
 // ---- the epoch of a ZH_CAPTURE_COALESCE capture (common.hip.h) ------------------------------------------
-void zh_epoch_flush_batch(zh_ctx *c) {
+void zh_epoch_flush_batch(zh_ctx *c, bool last) {
     zh_co_batch &b = c->co;
     if (!b.active) return;
     b.active = false;
-    c->co_launches++;
-    b.launch(c->stream, b.imgs.data(), (uint32_t)b.imgs.size());
+    const uint32_t n = (uint32_t)b.imgs.size();
+    uint32_t flips = 0;
+    for (const zh_flip_use &u : c->capture_log)
+        if (u.f == b.owner) flips = u.flips;
+    if (last && n >= 2 && ((flips + 1u) & 1u)) {              // one launch would leave an odd number of flips: two halves instead
+        const uint32_t h = n / 2;
+        c->co_launches += 2;
+        b.launch(c->stream, b.imgs.data(), h);
+        b.launch(c->stream, b.imgs.data() + h, n - h);
+    } else {
+        c->co_launches++;
+        b.launch(c->stream, b.imgs.data(), n);
+    }
     b.imgs.clear();
     b.launch = nullptr;
 }
 void zh_epoch_barrier(zh_ctx *c) {
     if (!c->epoch_open) return;
     c->epoch_open = false;                                    // (first: the launches below must not re-enter)
-    zh_epoch_flush_batch(c);
-    for (const zh_epoch_pending &p : c->epoch_pending) p.publish(p.f, p.frames, c->stream);
-    c->epoch_pending.clear();
-}
-uint32_t zh_epoch_frames(zh_ctx *c, zh_flipper *f) {
-    for (const zh_epoch_pending &p : c->epoch_pending)
-        if (p.f == f) return p.frames;
-    return 0;
-}
-void zh_epoch_painted(zh_ctx *c, zh_flipper *f, uint32_t frames, void (*publish)(zh_flipper *, uint32_t, hipStream_t)) {
-    c->epoch_open = true;
-    for (zh_epoch_pending &p : c->epoch_pending)
-        if (p.f == f) { p.frames += frames; return; }
-    c->epoch_pending.push_back(zh_epoch_pending{f, frames, publish});
+    zh_epoch_flush_batch(c, true);
 }
 
 thread_local zh_ctx *zh_tls_ctx = nullptr;
@@ -254,7 +252,6 @@ int zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags) { ZH_GUARD(ctx);
     ctx->capture_log.clear();
     ctx->epoch_open = false;
     ctx->co = zh_co_batch{};
-    ctx->epoch_pending.clear();
     ctx->co_paints = ctx->co_launches = 0;
     return ZH_OK;
 }

@@ -115,8 +115,6 @@ struct OscArgs {
     uint32_t *cnt_out;
     uint32_t *tab;               // [KW + 1][V] or nullptr
     uint32_t V, start, end, fc, stride, nb, prio;
-    uint32_t fbase0;             // frames this module painted earlier in the same capture epoch (cnt_in is the epoch-entry counter)
-    uint32_t publish;            // 0: a held-back paint of a coalescing capture -- cnt_out is left alone (k_osc_publish advances it once)
     float srf, sr8;
     F32P freq, color;
     float *img[kOscMaxBatch];
@@ -200,11 +198,11 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     const uint32_t nfr = end - start;
     const uint32_t c0 = start + chunk * fc;
     const uint32_t c1 = min(c0 + fc, end);
-    const uint32_t fbase = a.fbase0 + blockIdx.z * nfr + (c0 - start);    // frames painted before this chunk: epoch- and batch-wide
+    const uint32_t fbase = blockIdx.z * nfr + (c0 - start);               // frames painted before this chunk, batch-wide
     typename OSC::R roll[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { cnt[j] = cnt0[j] + fbase * k[j].ifreq; roll[j] = OSC::roll_init(k[j], cnt[j]); }
-    if (chunk == 0 && blockIdx.z == 0 && a.publish) {
+    if (chunk == 0 && blockIdx.z == 0) {
         const uint32_t total = a.nb * nfr;
         uint4 o;
         o.x = bad[0] ? cnt0[0] : cnt0[0] + total * k[0].ifreq;
@@ -423,23 +421,6 @@ __global__ void __launch_bounds__(256) k_commit_f32(float *__restrict__ dst, con
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// The one node that ends an epoch of a ZH_CAPTURE_COALESCE capture (ctx.hip zh_epoch_barrier) for an oscillator whose
-// table-form paints were recorded as parallel branches: cnt += frames * ifreq for every voice in range (a voice with a bad
-// frequency neither paints nor advances, PulseOsc.zig:82-84 / TriSawOsc.zig:84-86), in place -- every branch has been joined.
-__global__ void __launch_bounds__(256) k_osc_publish(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tab, uint32_t V, uint32_t ifreq_word,
-                                                     uint32_t bad_word, uint32_t frames) {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    const uint32_t ifreq = tab[(size_t)ifreq_word * V + v];
-    if (tab[(size_t)bad_word * V + v] == 0) cnt[v] += frames * ifreq;
-}
-template <class OSC, class M> static void osc_publish(zh_flipper *f, uint32_t frames, hipStream_t st) {
-    M *m = static_cast<M *>(f);
-    using K = typename OSC::K;
-    ZH_LAUNCH(k_osc_publish, dim3((m->n + 255) / 256), dim3(256), 0, st, m->cnt[m->cur], m->tab.words, m->n,
-                       (uint32_t)(offsetof(K, ifreq) / 4), (uint32_t)(sizeof(K) / 4), frames);
-}
-
 // Frames per lane for the chunked kernels.  PulseOsc, measured (tools/sweep_osc_fc.sh, 1024-frame images): 4 frames per
 // lane is the best or within 5 % of the best at every voice count from 4,096 to 1 Mi and 11-15 % better than 64 between
 // 65,536 and 524,288 voices (short waves interleave their ALU and store phases better, and the blocks sweep the image in
@@ -516,11 +497,14 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         a.tab = (use_tab || write_tab) ? m->tab.words : nullptr;
         a.V = n; a.start = start; a.end = end; a.fc = fc; a.stride = outs[0].stride; a.prio = 1u;
         a.srf = srf; a.sr8 = sr8; a.freq = fq; a.color = col;
-        // A table-form paint of a ZH_CAPTURE_COALESCE capture depends on nothing recorded before it -- its phase at any frame is
-        // the counter the epoch opened on plus the frames this module has painted since, times ifreq, exactly -- so it is held
-        // back: consecutive such paints of one module over the same span into images that do not overlap become ONE recorded
-        // launch of up to 32 buffers (zh_epoch_flush_batch), and the counters are advanced once, when the epoch ends
-        // (k_osc_publish).  No flip: cnt[cur] stays the epoch-entry state until then.
+        // A table-form paint of a ZH_CAPTURE_COALESCE capture is HELD BACK: consecutive such paints of one module over the same
+        // span into images that do not overlap become ONE recorded launch of up to 32 buffers -- exactly what
+        // zh_*_paint_batch launches: the phase of frame i of buffer b is cnt0 + (b * frames + i) * ifreq, the counters are read
+        // from cnt[cur] and written to the other buffer once, and the module flips once per launch.  When the epoch ends
+        // (zh_epoch_barrier: another call on the context, or the end of the capture) the last batch is recorded as TWO launches of
+        // half the buffers each if one launch would leave the capture with an odd number of flips: a replay then ends on the
+        // buffer it started from and zh_graph_launch has no counters to copy (an odd count costs a 16 KiB copy per replay; a
+        // separate publish node cost 4.4 us of a 61 us replay in the first version of this path).
         if (use_tab && ctx->capturing && (ctx->capture_flags & ZH_CAPTURE_COALESCE)) {
             const uint32_t key = (zf ? 1u : 0u) | ((uint32_t)sm << 1) | ((uint32_t)fc << 8);
             for (uint32_t b = 0; b < nb; b++) {
@@ -533,29 +517,30 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
                     if (lo < qhi && qlo < hi) join = false;           // the same rows again: the recorded order decides what they hold
                 }
                 if (!join) {
-                    zh_epoch_flush_batch(ctx);
+                    zh_epoch_flush_batch(ctx, false);
                     cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = outs[b].stride; cb.key = key;
-                    OscArgs ab = a;
-                    ab.cnt_in = m->cnt[m->cur]; ab.cnt_out = m->cnt[m->cur ^ 1];
-                    ab.fbase0 = zh_epoch_frames(ctx, m); ab.publish = 0u;
-                    cb.launch = [ab, launch](hipStream_t s2, float *const *imgs, uint32_t cnt) {
+                    ctx->epoch_open = true;
+                    const OscArgs ab = a;
+                    cb.launch = [ab, launch, m](hipStream_t s2, float *const *imgs, uint32_t cnt) {
                         OscArgs x = ab;
+                        x.cnt_in = m->cnt[m->cur]; x.cnt_out = m->cnt[m->cur ^ 1];
                         x.nb = cnt;
                         for (uint32_t i = 0; i < (uint32_t)kOscMaxBatch; i++) x.img[i] = i < cnt ? imgs[i] : nullptr;
                         launch(x, cnt, s2);
+                        zh_flipper_painted(m);                        // (like every batch paint: the state moved to the other buffer)
+                        m->cur ^= 1;
                     };
                 }
                 cb.imgs.push_back(outs[b].ptr);
                 ctx->co_paints++;
-                zh_epoch_painted(ctx, m, end - start, &osc_publish<OSC, M>);
             }
             return;
         }
-        if (ctx->epoch_open) zh_epoch_barrier(ctx);                   // an ordered paint: after what was held back, from published counters
+        if (ctx->epoch_open) zh_epoch_barrier(ctx);                   // an ordered paint: after what was held back
         for (uint32_t b0 = 0; b0 < nb; b0 += kOscMaxBatch) {
             const uint32_t cnt_b = nb - b0 < (uint32_t)kOscMaxBatch ? nb - b0 : (uint32_t)kOscMaxBatch;
             a.cnt_in = m->cnt[m->cur]; a.cnt_out = m->cnt[m->cur ^ 1];
-            a.fbase0 = 0u; a.publish = 1u; a.nb = cnt_b;
+            a.nb = cnt_b;
             for (uint32_t b = 0; b < (uint32_t)kOscMaxBatch; b++) a.img[b] = b < cnt_b ? outs[b0 + b].ptr : nullptr;
             launch(a, cnt_b, st);
             // the setup form stored this call's constants (ordered before any later paint on the stream)
