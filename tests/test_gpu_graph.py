@@ -438,14 +438,14 @@ def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
     """bench.py's pulseosc graph as it is recorded now (20 zero+paint steps over distinct ring images, ZH_CAPTURE_COALESCE: two
     launches of 10 buffers, so that a replay ends on the counter buffer it began on): after three replays every image of the
     ring equals the oracle's buffer of that step, and the carried counters equal the oracle's -- on every 8th voice.  40 steps:
-    32 + 8 buffers; 33 steps: 32 + 1, an odd number of flips, reconciled by zh_graph_launch."""
+    32 + 8 buffers; 33 steps: 32 + 1; one step: an odd number of flips, reconciled by zh_graph_launch."""
     import torch
     import zang_amd
     from zang_amd import modules as mod, zang, workloads
     V = 4096
     freq, color, _, _ = workloads.voice_params(2, 0, V)
     L = oracle.lib()
-    for K, want_launches in ((20, 2), (40, 2), (33, 3)):        # 10 + 10; 32 + 8; 32, then 1 alone (odd: zh_graph_launch copies the counters)
+    for K, want_launches in ((20, 2), (40, 2), (33, 2), (1, 1)):     # 10 + 10; 32 + 8; 32 + 1; one paint alone (odd: zh_graph_launch copies the counters)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             c2 = zang_amd.Context(0)
