@@ -908,7 +908,9 @@ def main():
                 # pulseosc: ZH_CAPTURE_COALESCE -- the steps' paints (params unchanged: the phase at any frame is the entry counter +
                 # frames * ifreq exactly, PulseOsc.zig:111) are held back while recording and become one launch per <= 32 buffers.  The
                 # step is still one zero+paint CALL per buffer; what the graph replays is fewer, larger launches (ZH_BENCH_IN_ORDER=1: one kernel node per step, the round-4 form)
-                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=((name == "pulseosc" and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
+                # nice_mix (stereo): the same flag holds back zh_nice_paint_mix_stereo calls -- up to 8 consecutive buffers per launch, the launch
+                # zh_nice_paint_mix_stereo_batch makes (state words in registers from buffer to buffer, one second pass; same bits)
+                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=(((name == "pulseosc" or (name == "nice_mix" and args.channels == 2 and not args.tolerant)) and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
                 self.graph_nodes, self.graph_held, self.graph_launches = self.graph.info()
             # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
             # refuses events recorded by graph nodes on this ROCm: "invalid resource handle", profiles/r04/probe_region.txt)
@@ -1085,9 +1087,10 @@ def main():
                                 else f"zero+paint per {F}-frame buffer, 48 kHz"),
                    "voices_per_gpu": V, "total_voices": V * world, "frames": F, "ring_images": wl.nring,
                    "launch": "eager" if graph is None else (f"hipGraph x{G} steps" + (
-                       f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launches of up to 32 "
-                       f"buffers each (grid.z; an even number, so that a replay ends on the counter buffer it began on); {main_run.graph_nodes} nodes" if main_run.graph_held
-                       else "")),
+                       f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launches of up to " +
+                       ("8 consecutive buffers each (k_nice_mix_batch: the voices' state stays in registers from buffer to buffer)" if mixdown else
+                        "32 buffers each (grid.z; an even number, so that a replay ends on the counter buffer it began on)") +
+                       f"; {main_run.graph_nodes} nodes" if main_run.graph_held else "")),
                    "graph_nodes": main_run.graph_nodes,
                    "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

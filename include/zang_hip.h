@@ -174,6 +174,11 @@ ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
  * on and nothing has to be copied).  Replays give the same bits as a capture without the flag; what changes is that one
  * launch's ramp and tail are shared by the buffers.  Every other call first records what was held back, then itself, in
  * order as before.
+ * Also held back: zh_nice_paint_mix_stereo (not ZH_PAINT_TOLERANT).  Its paints DO depend on each other (the voices' state), so
+ * they are not reordered: consecutive ones of one instrument over one span with the same gains into different mix rows become the
+ * launch zh_nice_paint_mix_stereo_batch makes, up to 8 buffers each -- the state words stay in registers from buffer to buffer and
+ * the second pass runs once (105 against 108 us per buffer at 131,072 voices; same bits).  The partial-sum scratch for 8 buffers
+ * is reserved by every eager stereo mixdown paint, i.e. by the eager pass a host makes before recording anyway.
  * (Measured and rejected, profiles/r05/ab_capture_lanes.txt + ubench_launch_overlap.txt: the same paints as parallel graph
  * branches on 2-4 forked streams -- kernels from different queues slow each other down, 5.0-5.6 against 4.5 us per buffer.) */
 enum { ZH_CAPTURE_COALESCE = 1 };

@@ -102,7 +102,7 @@ def test_two_emulated_ranks_on_one_gpu_run_the_whole_multi_gpu_path(exchange):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = _last_json(r.stdout)
     # `--steps 20` on the note-pattern workload = one whole 48-buffer pattern (the release stage is inside the timed region)
-    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["steps_requested"] == 20 and d["config"]["launch"] == "hipGraph x48 steps"
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["steps_requested"] == 20 and d["config"]["launch"].startswith("hipGraph x48 steps")
     assert "pattern" in d["config"] and d["rehearsal_regions"] >= 3
     assert d["config"]["total_voices"] == 16384 and d["value"] > 0 and d["scaling"] == "weak"
     c = d["collective"]

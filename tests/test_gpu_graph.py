@@ -476,6 +476,57 @@ def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
             assert int(cnt[q]) == int(st.cnt), (K, v)
 
 
+@pytest.mark.parametrize("V", [300, 4096])
+def test_coalesced_nice_mixdowns_equal_separate_calls(V):
+    """ZH_CAPTURE_COALESCE also holds back zh_nice_paint_mix_stereo: consecutive mixdowns of one instrument over one span with the
+    same gains become launches of up to 8 buffers (the launch zh_nice_paint_mix_stereo_batch makes).  The replayed graph leaves
+    bit for bit the mixes and the state of the same calls made one by one -- notes going on and off, a new note and a frequency
+    change between buffers; a paint into a row the batch already holds, a change of gains and a different span each end the batch."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    freq, color, u2, _ = workloads.voice_params(5, 3, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        gl = util.dev((0.25 + 0.5 * u2).astype(np.float32)); gr = util.dev((0.75 - 0.5 * u2).astype(np.float32))
+        f1, f2 = util.dev(freq), util.dev((freq * np.float32(1.25)).astype(np.float32))
+        on_mix = util.dev((np.arange(V) % 3 != 0).astype(np.uint8))
+        ma, mb = mod.NiceInstrument(V, util.dev(color), c2), mod.NiceInstrument(V, util.dev(color), c2)
+        script = [(True, True, f1), (True, False, f1), (on_mix, False, f1), (False, False, f2), (True, True, f2), (False, False, f2), (on_mix, on_mix, f1),
+                  (True, False, f1), (True, True, f2), (on_mix, False, f2), (False, False, f2)]
+        n = len(script)                                                  # 11 buffers: 8 + 3
+        sp = zang.Span(0, F)
+        la = torch.full((n + 3, F), 0.5, device="cuda"); ra = torch.full((n + 3, F), -0.25, device="cuda")
+        lb, rb = la.clone(), ra.clone()
+        P = [ma.Params(SR, f, on) for (on, _, f) in script]
+
+        def seq(m, l, r):
+            for k, (on, nic, f) in enumerate(script):
+                m.paint_mix_stereo(sp, l[k], r[k], gl, gr, nic, P[k], zero_first=True)
+            m.paint_mix_stereo(sp, l[n - 1], r[n - 1], gl, gr, False, P[0])                     # `+=` into a row of the open batch: a new batch
+            m.paint_mix_stereo(sp, l[n], r[n], gr, gl, False, P[1], zero_first=True)            # other gains: a new batch
+            m.paint_mix_stereo(zang.Span(100, 900), l[n + 1], r[n + 1], gr, gl, False, P[2])    # another span: a new batch
+            m.paint_mix_stereo(zang.Span(100, 900), l[n + 2], r[n + 2], gr, gl, True, P[3])     # ... which this one joins
+
+        seq(ma, la, ra)                                                  # eager, one by one (and sizes the scratch)
+        seq(mb, lb, rb)
+        c2.sync()
+        sa, sb = ma.state().tobytes(), mb.state().tobytes()
+        assert sa == sb
+        g = c2.capture(lambda: seq(mb, lb, rb), coalesce=True)
+        nodes, held, launches = g.info()
+        assert held == n + 4 and launches == 5, (nodes, held, launches)   # 8 + 3, then 1, 1, 2
+        for _ in range(2):
+            seq(ma, la, ra)
+            g.launch()
+        c2.sync()
+        assert float(la.abs().max()) > 0.5
+        assert torch.equal(la.view(torch.int32), lb.view(torch.int32)) and torch.equal(ra.view(torch.int32), rb.view(torch.int32))
+        assert ma.state().tobytes() == mb.state().tobytes() and ma.state().tobytes() != sa
+        g.close(); c2.close()
+
+
 def test_graph_destroyed_after_its_context_is_harmless():
     """the documented order is graphs before their context, but a host written against the earlier rounds destroyed the
     context first -- zh_graph_destroy then dereferenced freed memory.  zh_destroy now makes its live graphs forget it: a late

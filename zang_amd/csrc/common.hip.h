@@ -44,8 +44,9 @@ struct zh_flip_use {
 struct zh_flipper;
 struct zh_co_batch {             // the paints held back: same module, span, flags and row stride; images that do not overlap
     bool active = false;
-    zh_flipper *owner = nullptr;
+    const void *owner = nullptr;
     uint32_t start = 0, end = 0, stride = 0, key = 0, max = 0;
+    bool flips = false;          // every launch of the batch flips its module's double-buffered state (the oscillators): keep the count even
     std::vector<float *> imgs;
     std::function<void(hipStream_t, float *const *, uint32_t)> launch;
 };

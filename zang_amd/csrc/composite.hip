@@ -7,6 +7,7 @@
 // multiply-add is fused (-ffp-contract=off).  The two temps of a NiceInstrument voice never
 // touch HBM: per voice-sample the kernel writes 4 B (or nothing, in the mix variant).
 #include "common.hip.h"
+#include <memory>
 #include "ring.hip.h"
 #include "zmath.hip.h"
 #include "dsp.hip.h"
@@ -1885,6 +1886,7 @@ static bool nice_mix_roll() { return zh_form(ZF_NICE_MIX_ROLL) != 0; }   // 149.
 // this kernel's bound.  Gone with round 5.)
 // Returns the waves per combining workgroup: 0 (a row per wave) or 4.
 static int nice_mix_wg(uint32_t n_voices) { return (long)n_voices >= zh_form(ZF_NICE_MIX_WG_MIN) ? 4 : 0; }
+constexpr uint32_t kNiceCoalesceReserve = 8;
 static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix_l, float *mix_r, const zh_f32 *gain_l,
                             const zh_f32 *gain_r, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) {
     const bool stereo = mix_r != nullptr;
@@ -1896,7 +1898,8 @@ static int nice_paint_mix_n(zh_nice *m, uint32_t start, uint32_t end, float *mix
     const uint32_t blocks = (m->n + bs - 1) / bs;
     const uint32_t rows = wg ? blocks : blocks * 4;                     // one partial row per workgroup (256 / 512 voices) / per wave of 64 voices
     const size_t per_channel = (size_t)rows * kMixGroupFrames * ((nframes + kMixGroupFrames - 1) / kMixGroupFrames ? (nframes + kMixGroupFrames - 1) / kMixGroupFrames : 1);   // [frame / G][row][frame % G]
-    int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1));
+    // (stereo: room for the 8 buffers a coalescing capture merges, reserved while the scratch may still grow)
+    int rc = zh_mix_reserve(m->ctx, per_channel * (stereo ? 2 : 1) * (stereo && !m->ctx->capturing ? kNiceCoalesceReserve : 1u));
     if (rc) return rc;
     hipStream_t st = m->ctx->stream;
     NiceArgs a = nice_args(m, p, note_id_changed);
@@ -1946,15 +1949,67 @@ int zh_nice_paint_mix(zh_nice *m, uint32_t start, uint32_t end, float *mix, zh_b
                       const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
     return nice_paint_mix_n(m, start, end, mix, nullptr, nullptr, nullptr, note_id_changed, p, flags);
 }
+// A stereo mixdown paint of a ZH_CAPTURE_COALESCE capture is held back (common.hip.h zh_co_batch): consecutive ones of one module over the
+// same span with the same gains and flags into different mix rows become ONE launch of up to 8 buffers -- the launch
+// zh_nice_paint_mix_stereo_batch makes (the state words stay in registers from buffer to buffer, one second pass): same bits,
+// 108.4 -> 105.1 us per buffer at 131,072 voices.  The partial-sum scratch is sized for 8 buffers by every eager stereo paint (it
+// cannot grow while a capture records); a batch the scratch cannot hold goes out buffer by buffer.
+constexpr uint32_t kNiceCoalesceMax = 8;
+static int nice_paint_mix_batch_impl(zh_nice *m, uint32_t start, uint32_t end, uint32_t n_buffers, float *const *mix_left,
+                                     float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
+                                     const zh_nice_params *params, uint32_t flags);
+struct NiceHeld { float *l, *r; zh_bool nic; zh_nice_params p; };
+static bool same_f32(const zh_f32 &a, const zh_f32 &b) {
+    return a.per_voice == b.per_voice && (a.per_voice || __builtin_bit_cast(uint32_t, a.value) == __builtin_bit_cast(uint32_t, b.value));
+}
 int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mix_left, float *mix_right, zh_f32 gain_left,
-                             zh_f32 gain_right, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+                             zh_f32 gain_right, zh_bool note_id_changed, const zh_nice_params *p, uint32_t flags) { ZH_GUARD_EPOCH(m ? m->ctx : nullptr);
     if (!mix_right) return ZH_ERR_INVALID;
-    return nice_paint_mix_n(m, start, end, mix_left, mix_right, &gain_left, &gain_right, note_id_changed, p, flags);
+    zh_ctx *ctx = m ? m->ctx : nullptr;
+    const bool hold = ctx && ctx->capturing && (ctx->capture_flags & ZH_CAPTURE_COALESCE) && mix_left && p && end > start && m->n &&
+                      !(flags & ZH_PAINT_TOLERANT);
+    if (!hold) {
+        if (ctx && ctx->epoch_open) zh_epoch_barrier(ctx);
+        return nice_paint_mix_n(m, start, end, mix_left, mix_right, &gain_left, &gain_right, note_id_changed, p, flags);
+    }
+    static thread_local std::shared_ptr<std::vector<NiceHeld>> held;        // the items of the batch that is being held back on this thread
+    static thread_local zh_f32 held_gl, held_gr;
+    zh_co_batch &cb = ctx->co;
+    const uint32_t key = flags ^ __builtin_bit_cast(uint32_t, p->sample_rate);
+    bool join = cb.active && cb.owner == m && cb.start == start && cb.end == end && cb.key == key && held && held->size() < kNiceCoalesceMax &&
+                same_f32(held_gl, gain_left) && same_f32(held_gr, gain_right);
+    for (size_t q = 0; join && q < held->size(); q++) {
+        const float *rows[2] = {(*held)[q].l, (*held)[q].r};
+        for (const float *x : rows)                                     // the same mix row again: the recorded order decides what it holds
+            if ((mix_left < x + end && x < mix_left + end) || (mix_right < x + end && x < mix_right + end)) join = false;
+    }
+    if (!join) {
+        zh_epoch_flush_batch(ctx, false);
+        held = std::make_shared<std::vector<NiceHeld>>();
+        held_gl = gain_left; held_gr = gain_right;
+        cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = 0; cb.key = key; cb.flips = false;
+        ctx->epoch_open = true;
+        std::shared_ptr<std::vector<NiceHeld>> items = held;
+        cb.launch = [m, start, end, gain_left, gain_right, flags, items](hipStream_t, float *const *, uint32_t cnt) {
+            const std::vector<NiceHeld> &v = *items;
+            float *l[kNiceCoalesceMax], *r[kNiceCoalesceMax];
+            zh_bool nic[kNiceCoalesceMax];
+            zh_nice_params ps[kNiceCoalesceMax];
+            for (uint32_t i = 0; i < cnt; i++) { l[i] = v[i].l; r[i] = v[i].r; nic[i] = v[i].nic; ps[i] = v[i].p; }
+            int rc = cnt > 1 ? nice_paint_mix_batch_impl(m, start, end, cnt, l, r, gain_left, gain_right, nic, ps, flags) : ZH_ERR_UNSUPPORTED;
+            if (rc != ZH_OK)                                            // one buffer, or a scratch too small for the batch: buffer by buffer
+                for (uint32_t i = 0; i < cnt; i++) (void)nice_paint_mix_n(m, start, end, l[i], r[i], &gain_left, &gain_right, nic[i], &ps[i], flags);
+        };
+    }
+    held->push_back(NiceHeld{mix_left, mix_right, note_id_changed, *p});
+    cb.imgs.push_back(mix_left);
+    ctx->co_paints++;
+    return ZH_OK;
 }
 
-int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uint32_t n_buffers, float *const *mix_left,
-                                   float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
-                                   const zh_nice_params *params, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+static int nice_paint_mix_batch_impl(zh_nice *m, uint32_t start, uint32_t end, uint32_t n_buffers, float *const *mix_left,
+                                     float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
+                                     const zh_nice_params *params, uint32_t flags) {
     if (!m || !mix_left || !mix_right || !note_id_changed || !params || end < start || n_buffers > (uint32_t)kNiceMixMaxBatch) return ZH_ERR_INVALID;
     for (uint32_t k = 0; k < n_buffers; k++) {
         if (!mix_left[k] || !mix_right[k]) return ZH_ERR_INVALID;
@@ -1988,6 +2043,12 @@ int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uin
         zh_mix_pass2_wide_batch_launch(m->ctx, part, per_channel, rows, nframes, l, r, n_buffers, 2, (int)(flags & ZH_PAINT_ZERO_FIRST));
     }
     return zh_launch_status();
+}
+
+int zh_nice_paint_mix_stereo_batch(zh_nice *m, uint32_t start, uint32_t end, uint32_t n_buffers, float *const *mix_left,
+                                   float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
+                                   const zh_nice_params *params, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+    return nice_paint_mix_batch_impl(m, start, end, n_buffers, mix_left, mix_right, gain_left, gain_right, note_id_changed, params, flags);
 }
 
 static bool span_table_ok(const zh_span_table *t) {

@@ -47,8 +47,8 @@ void zh_epoch_flush_batch(zh_ctx *c, bool last) {
     const uint32_t n = (uint32_t)b.imgs.size();
     uint32_t flips = 0;
     for (const zh_flip_use &u : c->capture_log)
-        if (u.f == b.owner) flips = u.flips;
-    if (last && n >= 2 && ((flips + 1u) & 1u)) {              // one launch would leave an odd number of flips: two halves instead
+        if ((const void *)u.f == b.owner) flips = u.flips;
+    if (b.flips && last && n >= 2 && ((flips + 1u) & 1u)) {              // one launch would leave an odd number of flips: two halves instead
         const uint32_t h = n / 2;
         c->co_launches += 2;
         b.launch(c->stream, b.imgs.data(), h);

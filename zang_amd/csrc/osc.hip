@@ -518,7 +518,7 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
                 }
                 if (!join) {
                     zh_epoch_flush_batch(ctx, false);
-                    cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = outs[b].stride; cb.key = key;
+                    cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = outs[b].stride; cb.key = key; cb.flips = true;
                     ctx->epoch_open = true;
                     const OscArgs ab = a;
                     cb.launch = [ab, launch, m](hipStream_t s2, float *const *imgs, uint32_t cnt) {
