@@ -66,6 +66,11 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *  - zh_nice_paint, zh_nice_paint_mix and zh_nice_paint_mix_stereo at up to 16,384 voices, spans of 128-4,096 frames: the same
         *    for the fused voice's filter (oscillator, envelope and their states exact: the envelope is walked once per voice ahead
         *    of the chunks);
+        *  - zh_nice_paint_mix, zh_nice_paint_mix_stereo and zh_nice_paint_mix_stereo_batch ABOVE 16,384 voices: the exact kernel's own
+        *    source compiled with multiply-adds fused (csrc/nice_mix_fma.hip: a v_fma_f32 rounds once where the reference rounds
+        *    twice; 27 % fewer instructions on a kernel bound by the instructions it issues: 85 against 105 us per buffer at 131,072
+        *    voices); phase counters, envelope stages and envelope clocks stay exact; measured error of a mixed sample 1e-3 of the
+        *    bound (the sum of the voices' tolerances) over 24 carried buffers;
         *  - zh_noise_paint with ZH_NOISE_PINK at up to 16,384 voices: Kellett's six one-pole taps as chunks at once over exactly
         *    generated white noise (white noise itself, and the generator's state, are always exact);
         *  - zh_sineosc_paint and zh_pmosc_paint (its carrier) at any voice count: the sine of the reference's own rounded
@@ -174,7 +179,7 @@ ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
  * on and nothing has to be copied).  Replays give the same bits as a capture without the flag; what changes is that one
  * launch's ramp and tail are shared by the buffers.  Every other call first records what was held back, then itself, in
  * order as before.
- * Also held back: zh_nice_paint_mix_stereo (not ZH_PAINT_TOLERANT).  Its paints DO depend on each other (the voices' state), so
+ * Also held back: zh_nice_paint_mix_stereo (flagged ZH_PAINT_TOLERANT only from 65,536 voices on).  Its paints DO depend on each other (the voices' state), so
  * they are not reordered: consecutive ones of one instrument over one span with the same gains into different mix rows become the
  * launch zh_nice_paint_mix_stereo_batch makes, up to 8 buffers each -- the state words stay in registers from buffer to buffer and
  * the second pass runs once (105 against 108 us per buffer at 131,072 voices; same bits).  The partial-sum scratch for 8 buffers

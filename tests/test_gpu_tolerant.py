@@ -664,10 +664,11 @@ def test_noise_filter_tolerant_chunk_starts_stay_inside_the_jump_tables(ctx, ora
         m.set_state(gs)
 
 
-@pytest.mark.parametrize("V", [1000, 4096])
+@pytest.mark.parametrize("V", [1000, 4096, 20000, 70000])
 def test_nice_mix_tolerant(ctx, oracle, V):
-    """zh_nice_paint_mix / _stereo with the flag at few voices (k_nice_tp_a + k_nice_mix_tp_b) against the exact form of the same
-    calls on a twin module: every mixed sample within 1e-5 of the SUM of the voices' peaks times their gains (each voice carries its own
+    """zh_nice_paint_mix / _stereo with the flag at few voices (k_nice_tp_a + k_nice_mix_tp_b) and above nice_tp_max voices (k_nice_mix_fma:
+    the exact kernel's source compiled with multiply-adds fused, per wave at 20,000 voices, per workgroup at 70,000) against the exact form of
+    the same calls on a twin module: every mixed sample within 1e-5 of the SUM of the voices' peaks times their gains (each voice carries its own
     tolerance into the sum), rows outside the span untouched, oscillator and envelope states identical, over a note script."""
     import torch
     from zang_amd import modules as mod, zang, workloads
@@ -684,6 +685,8 @@ def test_nice_mix_tolerant(ctx, oracle, V):
         lt = le.clone(); rt = re_.clone(); oe = torch.zeros(F, device="cuda"); ot = torch.zeros(F, device="cuda")
         me.paint_mix_stereo(zang.Span(s, e), le, re_, dgl, dgr, bool(nic), P)
         mt.paint_mix_stereo(zang.Span(s, e), lt, rt, dgl, dgr, bool(nic), P, tolerant=True)
+        if e > s:
+            assert ctx.last_form()[0] == ("k_nice_mix_fma" if V > 16384 else "k_nice_tp_a" if e - s >= 128 else "k_nice_mix"), (ctx.last_form(), V, s, e)
         m1e.paint_mix(zang.Span(s, e), oe, bool(nic), P, zero_first=True)
         m1t.paint_mix(zang.Span(s, e), ot, bool(nic), P, zero_first=True, tolerant=True)
         mv.paint(zang.Span(s, e), [img], None, bool(nic), P, zero_first=True)          # the voices themselves, for the bound
@@ -701,6 +704,51 @@ def test_nice_mix_tolerant(ctx, oracle, V):
         for mm in (mt, m1t):                                     # the exact twin's filter state on (the tolerance is per paint)
             ss = mm.state(); ss["flt"] = se["flt"]; mm.set_state(ss)
         ss = m1e.state(); s1 = m1t.state(); s1["flt"] = ss["flt"]; m1t.set_state(s1)
+
+
+def test_nice_mix_fma_carried_and_batched(ctx):
+    """The fused-multiply-add mixdown over 24 consecutive buffers on its OWN carried state (note on, held, released, a new note), one
+    buffer per launch and eight per launch (zh_nice_paint_mix_stereo_batch flagged tolerant: k_nice_mix_batch_fma), against the exact
+    form of the same calls: every mixed sample of every buffer within 1e-5 of the sum of the voices' peaks times their gains; phase
+    counters, envelope stage and envelope clock identical to the exact form's at the end."""
+    import torch
+    from zang_amd import modules as mod, zang, workloads
+    V, B = 70000, 24
+    freq, color, u2, _ = workloads.voice_params(5, 3, V)
+    gl = (0.25 + 0.5 * u2).astype(np.float32); gr = (0.75 - 0.5 * u2).astype(np.float32)
+    gc, gf, dgl, dgr = util.dev(color), util.dev(freq), util.dev(gl), util.dev(gr)
+    me, m1, m8, mv = (mod.NiceInstrument(V, gc, ctx) for _ in range(4))
+    sp = zang.Span(0, F)
+    script = [(b < 14 or b >= 20, b in (0, 20)) for b in range(B)]            # (note_on, new note)
+    P = [me.Params(SR, gf, on) for (on, _) in script]
+    mixes = {k: torch.zeros((B, 2, F), device="cuda") for k in ("e", "1", "8")}
+    img = ctx.image(F, V)
+    bound = np.zeros(B)
+    for b, (on, nic) in enumerate(script):
+        me.paint_mix_stereo(sp, mixes["e"][b, 0], mixes["e"][b, 1], dgl, dgr, nic, P[b], zero_first=True)
+        m1.paint_mix_stereo(sp, mixes["1"][b, 0], mixes["1"][b, 1], dgl, dgr, nic, P[b], zero_first=True, tolerant=True)
+        assert ctx.last_form()[0] == "k_nice_mix_fma"
+        mv.paint(sp, [img], None, nic, P[b], zero_first=True)
+        peak = img.abs().amax(dim=0).double()
+        bound[b] = 1e-5 * float((peak * torch.from_numpy(np.maximum(gl, gr)).cuda().double()).sum()) + 1e-6
+    for b0 in range(0, B, 8):
+        m8.paint_mix_stereo_batch(sp, [mixes["8"][b, 0] for b in range(b0, b0 + 8)], [mixes["8"][b, 1] for b in range(b0, b0 + 8)], dgl, dgr,
+                                  [nic for (_, nic) in script[b0:b0 + 8]], P[b0:b0 + 8], zero_first=True, tolerant=True)
+        assert ctx.last_form()[0] == "k_nice_mix_batch_fma"
+    ctx.sync()
+    want = mixes["e"].double().cpu().numpy()
+    assert np.abs(want).max() > 10.0
+    worst = 0.0
+    for k in ("1", "8"):
+        err = np.abs(mixes[k].double().cpu().numpy() - want).max(axis=(1, 2))
+        assert (err <= bound).all(), (k, err / bound)
+        worst = max(worst, float((err / bound).max()))
+    print("fma mixdown, 24 carried buffers: worst error / bound = %.3g" % worst)
+    se = me.state()
+    for mm in (m1, m8):
+        st_ = mm.state()
+        assert np.array_equal(se["osc"]["cnt"], st_["osc"]["cnt"]) and np.array_equal(se["env"]["state"], st_["env"]["state"])
+        assert np.array_equal(se["env"]["t"].view(np.uint32), st_["env"]["t"].view(np.uint32))
 
 
 FE_SPANS = [(0, 1024), (0, 1024), (100, 612), (612, 1000), (5, 170), (170, 200), (0, 1024)]

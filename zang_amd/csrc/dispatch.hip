@@ -56,6 +56,7 @@ const FormRow kForms[ZF_COUNT] = {
     /* ZF_NICE_TP_MAX        */ {"nice_tp_max", 16384, "... NiceInstrument and its fused mixdown"},
     /* ZF_PINK_TP_MAX        */ {"pink_tp_max", 16384, "... pink Noise"},
     /* ZF_ECHOES_TP_MAX      */ {"echoes_tp_max", 6144, "... FilteredEchoes (six image streams: level with the exact form at 8,192 voices)"},
+    /* ZF_NICE_MIX_FMA       */ {"nice_mix_fma", 1, "ZH_PAINT_TOLERANT fused mixdown above nice_tp_max voices: 1 = the kernel compiled with multiply-adds fused (nice_mix_fma.hip), 0 = the exact kernel"},
 };
 
 struct Overrides { bool set[ZF_COUNT]; long val[ZF_COUNT]; };

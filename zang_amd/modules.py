@@ -402,9 +402,10 @@ class NiceInstrument(_Module):
                                                (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | (abi.PAINT_TOLERANT if tolerant else 0))
         abi.check(rc, "zh_nice_paint_mix_stereo")
 
-    def paint_mix_stereo_batch(self, span, mix_lefts, mix_rights, gain_left, gain_right, note_id_changeds, paramses, zero_first=False):
+    def paint_mix_stereo_batch(self, span, mix_lefts, mix_rights, gain_left, gain_right, note_id_changeds, paramses, zero_first=False, tolerant=False):
         """len(paramses) consecutive paint_mix_stereo calls in ONE launch (zh_nice_paint_mix_stereo_batch): call b with
-        paramses[b] / note_id_changeds[b] into mix_lefts[b] / mix_rights[b]; same bits as the separate calls."""
+        paramses[b] / note_id_changeds[b] into mix_lefts[b] / mix_rights[b]; same bits as the separate calls.
+        `tolerant`: the kernel with multiply-adds fused (within 1e-5 of the voices' peaks, not the reference's bits)."""
         n = len(paramses)
         assert n == len(mix_lefts) == len(mix_rights) == len(note_id_changeds) and n <= 16
         ls = (C.c_void_p * n)(*[t.data_ptr() for t in mix_lefts])
@@ -412,7 +413,7 @@ class NiceInstrument(_Module):
         nics = (abi.Bool * n)(*[as_bool(x) for x in note_id_changeds])
         cps = (abi.NiceParams * n)(*[abi.NiceParams(p.sample_rate, 0, as_f32(p.freq), as_bool(p.note_on)) for p in paramses])
         rc = self.lib.zh_nice_paint_mix_stereo_batch(self.handle, span.start, span.end, n, ls, rs, as_f32(gain_left), as_f32(gain_right),
-                                                     nics, cps, abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD)
+                                                     nics, cps, (abi.PAINT_ZERO_FIRST if zero_first else abi.PAINT_ADD) | (abi.PAINT_TOLERANT if tolerant else 0))
         abi.check(rc, "zh_nice_paint_mix_stereo_batch")
 
 
