@@ -527,6 +527,64 @@ def test_coalesced_nice_mixdowns_equal_separate_calls(V):
         g.close(); c2.close()
 
 
+def test_two_contexts_record_coalescing_captures_interleaved():
+    """What is held back belongs to the context that records it: two contexts on one thread, their coalescing captures interleaved
+    call by call (mixdowns on one, oscillator paints and mixdowns on the other), replay what the same calls made one by one leave."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang, workloads
+    V, K = 300, 5
+    freq, color, u2, _ = workloads.voice_params(5, 3, V)
+    sp = zang.Span(0, F)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cs, eager, rec, mixes = [], [], [], []
+    for st in streams:
+        with torch.cuda.stream(st):
+            c = zang_amd.Context(0)
+            cs.append(c)
+            eager.append(mod.NiceInstrument(V, util.dev(color), c)); rec.append(mod.NiceInstrument(V, util.dev(color), c))
+            mixes.append((torch.zeros((K, 2, F), device="cuda"), torch.zeros((K, 2, F), device="cuda")))
+    gl = util.dev((0.25 + 0.5 * u2).astype(np.float32)); gr = util.dev((0.75 - 0.5 * u2).astype(np.float32)); gf = util.dev(freq)
+
+    def call(i, m, k, which):
+        with torch.cuda.stream(streams[i]):
+            mx = mixes[i][which]
+            m.paint_mix_stereo(sp, mx[k, 0], mx[k, 1], gl, gr, k == 0, m.Params(SR, gf, k < 3), zero_first=True)
+
+    for i in (0, 1):                                                     # eager passes: the scratch is sized, both twins on the same state
+        for k in range(K):
+            call(i, eager[i], k, 0); call(i, rec[i], k, 1)
+    for c in cs:
+        c.sync()
+    from zang_amd import abi
+    for c in cs:
+        abi.check(c.lib.zh_graph_begin_capture_flags(c.handle, abi.ZH_CAPTURE_COALESCE), "begin")
+    for k in range(K):                                                   # interleaved: context 0, context 1, context 0, ...
+        call(0, rec[0], k, 1); call(1, rec[1], k, 1)
+    graphs = []
+    for c in cs:
+        g = C.c_void_p()
+        abi.check(c.lib.zh_graph_end_capture(c.handle, C.byref(g)), "end")
+        graphs.append(g)
+    for i in (0, 1):
+        for k in range(K):
+            call(i, eager[i], k, 0)
+        with torch.cuda.stream(streams[i]):
+            abi.check(cs[i].lib.zh_graph_launch(cs[i].handle, graphs[i]), "launch")
+    for c in cs:
+        c.sync()
+    for i in (0, 1):
+        nodes, held, launches = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        abi.check(cs[i].lib.zh_graph_info(graphs[i], C.byref(nodes), C.byref(held), C.byref(launches)), "info")
+        assert (held.value, launches.value) == (K, 1), (held.value, launches.value)
+        assert float(mixes[i][0].abs().max()) > 0.5
+        assert torch.equal(mixes[i][0].view(torch.int32), mixes[i][1].view(torch.int32)), i
+        assert eager[i].state().tobytes() == rec[i].state().tobytes()
+        cs[i].lib.zh_graph_destroy(graphs[i])
+    for c in cs:
+        c.close()
+
+
 def test_graph_destroyed_after_its_context_is_harmless():
     """the documented order is graphs before their context, but a host written against the earlier rounds destroyed the
     context first -- zh_graph_destroy then dereferenced freed memory.  zh_destroy now makes its live graphs forget it: a late

@@ -17,6 +17,7 @@
 #if !defined(ZH_DEVICE_ONLY)
 #include <vector>
 #include <functional>
+#include <memory>
 #include <string>
 // A module whose state is double-buffered and flips on the HOST at every paint (the chunked oscillators, osc.hip):
 // a captured graph bakes in both buffer pointers, so the library records which buffer a capture started from and
@@ -48,6 +49,7 @@ struct zh_co_batch {             // the paints held back: same module, span, fla
     uint32_t start = 0, end = 0, stride = 0, key = 0, max = 0;
     bool flips = false;          // every launch of the batch flips its module's double-buffered state (the oscillators): keep the count even
     std::vector<float *> imgs;
+    std::shared_ptr<void> items;  // what else the owner keeps per held paint (composite.hip: the mixdowns' params)
     std::function<void(hipStream_t, float *const *, uint32_t)> launch;
 };
 

@@ -1581,6 +1581,7 @@ static int nice_paint_mix_batch_impl(zh_nice *m, uint32_t start, uint32_t end, u
                                      float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
                                      const zh_nice_params *params, uint32_t flags);
 struct NiceHeld { float *l, *r; zh_bool nic; zh_nice_params p; };
+struct NiceHeldBatch { std::vector<NiceHeld> v; zh_f32 gl, gr; };
 static bool same_f32(const zh_f32 &a, const zh_f32 &b) {
     return a.per_voice == b.per_voice && (a.per_voice || __builtin_bit_cast(uint32_t, a.value) == __builtin_bit_cast(uint32_t, b.value));
 }
@@ -1594,26 +1595,26 @@ int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mi
         if (ctx && ctx->epoch_open) zh_epoch_barrier(ctx);
         return nice_paint_mix_n(m, start, end, mix_left, mix_right, &gain_left, &gain_right, note_id_changed, p, flags);
     }
-    static thread_local std::shared_ptr<std::vector<NiceHeld>> held;        // the items of the batch that is being held back on this thread
-    static thread_local zh_f32 held_gl, held_gr;
     zh_co_batch &cb = ctx->co;
+    std::shared_ptr<NiceHeldBatch> held = cb.active && cb.owner == m ? std::static_pointer_cast<NiceHeldBatch>(cb.items) : nullptr;
     const uint32_t key = flags ^ __builtin_bit_cast(uint32_t, p->sample_rate);
-    bool join = cb.active && cb.owner == m && cb.start == start && cb.end == end && cb.key == key && held && held->size() < kNiceCoalesceMax &&
-                same_f32(held_gl, gain_left) && same_f32(held_gr, gain_right);
-    for (size_t q = 0; join && q < held->size(); q++) {
-        const float *rows[2] = {(*held)[q].l, (*held)[q].r};
+    bool join = held && cb.start == start && cb.end == end && cb.key == key && held->v.size() < kNiceCoalesceMax &&
+                same_f32(held->gl, gain_left) && same_f32(held->gr, gain_right);
+    for (size_t q = 0; join && q < held->v.size(); q++) {
+        const float *rows[2] = {held->v[q].l, held->v[q].r};
         for (const float *x : rows)                                     // the same mix row again: the recorded order decides what it holds
             if ((mix_left < x + end && x < mix_left + end) || (mix_right < x + end && x < mix_right + end)) join = false;
     }
     if (!join) {
         zh_epoch_flush_batch(ctx, false);
-        held = std::make_shared<std::vector<NiceHeld>>();
-        held_gl = gain_left; held_gr = gain_right;
+        held = std::make_shared<NiceHeldBatch>();
+        held->gl = gain_left; held->gr = gain_right;
+        cb.items = held;
         cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = 0; cb.key = key; cb.flips = false;
         ctx->epoch_open = true;
-        std::shared_ptr<std::vector<NiceHeld>> items = held;
+        std::shared_ptr<NiceHeldBatch> items = held;
         cb.launch = [m, start, end, gain_left, gain_right, flags, items](hipStream_t, float *const *, uint32_t cnt) {
-            const std::vector<NiceHeld> &v = *items;
+            const std::vector<NiceHeld> &v = items->v;
             float *l[kNiceCoalesceMax], *r[kNiceCoalesceMax];
             zh_bool nic[kNiceCoalesceMax];
             zh_nice_params ps[kNiceCoalesceMax];
@@ -1623,7 +1624,7 @@ int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mi
                 for (uint32_t i = 0; i < cnt; i++) (void)nice_paint_mix_n(m, start, end, l[i], r[i], &gain_left, &gain_right, nic[i], &ps[i], flags);
         };
     }
-    held->push_back(NiceHeld{mix_left, mix_right, note_id_changed, *p});
+    held->v.push_back(NiceHeld{mix_left, mix_right, note_id_changed, *p});
     cb.imgs.push_back(mix_left);
     ctx->co_paints++;
     return ZH_OK;

@@ -58,6 +58,7 @@ void zh_epoch_flush_batch(zh_ctx *c, bool last) {
         b.launch(c->stream, b.imgs.data(), n);
     }
     b.imgs.clear();
+    b.items.reset();
     b.launch = nullptr;
 }
 void zh_epoch_barrier(zh_ctx *c) {
