@@ -143,7 +143,7 @@ ZH_API int  zh_free(zh_ctx *ctx, void *dev_ptr);
 ZH_API int  zh_upload(zh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);    /* synchronous */
 ZH_API int  zh_download(zh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  /* synchronous */
 
-/* out->stride >= voices: rows that would be a multiple of 64 KiB are padded by 1 KiB (HBM bank spreading); always
+/* out->stride >= voices: rows that would be a multiple of 64 KiB are padded by 4 KiB (HBM bank spreading); always
  * address a sample as ptr[frame * stride + voice]. */
 ZH_API int  zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames);
 ZH_API int  zh_buf_free(zh_ctx *ctx, zh_buf *buf);

@@ -97,7 +97,7 @@ def test_buf_alloc_stride_and_round_trip(ctx, V):
     abi.check(lib.zh_buf_alloc(ctx.handle, C.byref(b), V, frames), "zh_buf_alloc")
     try:
         assert b.voices == V and b.frames == frames
-        assert b.stride == (V + 256 if (V * 4) % 65536 == 0 else V)
+        assert b.stride == (V + 1024 if (V * 4) % 65536 == 0 else V)
         rng = np.random.default_rng(V)
         host = rng.standard_normal((V, frames)).astype(np.float32)
         abi.check(lib.zh_buf_upload_voices(ctx.handle, b, host.ctypes.data, frames), "upload")

@@ -277,4 +277,6 @@ template <int SM> __device__ inline void store1(float *, zh_rsrc_t, uint32_t, fl
 
 #if !defined(ZH_DEVICE_ONLY)
 int zh_store_mode();   // ctx.hip: ZH_STORE_MODE env (default ST_SC1)
+int zh_store_mode_env();   // ... -1 when the variable is not set
+constexpr uint32_t kRowPadVoices = 1024;   // zh_buf_alloc: padding of rows that are a multiple of 64 KiB (zang_amd/runtime.py image_row_pad: the same)
 #endif

@@ -69,15 +69,17 @@ void zh_epoch_barrier(zh_ctx *c) {
 
 thread_local zh_ctx *zh_tls_ctx = nullptr;
 
-int zh_store_mode() {
-    static int mode = -1;
-    if (mode < 0) {
+// ZH_STORE_MODE: -1 = not set (the launcher's own choice), else 0..3
+int zh_store_mode_env() {
+    static int mode = -2;
+    if (mode == -2) {
         const char *e = getenv("ZH_STORE_MODE");
-        mode = e ? atoi(e) : ST_SC1;
-        if (mode < 0 || mode > 3) mode = ST_SC1;
+        mode = e ? atoi(e) : -1;
+        if (mode < -1 || mode > 3) mode = -1;
     }
     return mode;
 }
+int zh_store_mode() { const int m = zh_store_mode_env(); return m < 0 ? ST_SC1 : m; }
 
 extern "C" {
 
@@ -187,9 +189,10 @@ int zh_buf_alloc(zh_ctx *ctx, zh_buf *out, uint32_t voices, uint32_t frames) { Z
     if (!ctx || !out) return ZH_ERR_INVALID;
     memset(out, 0, sizeof *out);
     // A lane-per-voice kernel's consecutive stores are one row apart.  When a row is a multiple of 64 KiB they all
-    // land on the same HBM channel and bank; 1 KiB of padding per row spreads them (measured on the chunked
-    // oscillator: 65,536 voices 57.6 -> 54.4 us, 1 Mi voices 799 -> 768 us per 1024-frame image).
-    const uint32_t stride = (voices != 0 && ((size_t)voices * sizeof(float)) % 65536 == 0) ? voices + 256 : voices;
+    // land on the same HBM channel and bank; padding per row spreads them.  4 KiB (1 KiB until round 5): with the chunked
+    // oscillator's three-frame chunks no power-of-two voice count from 16,384 to 524,288 falls below 0.83 of the HBM peak
+    // (1 KiB: 0.63 at 32,768 voices, 0.72 at 131,072; profiles/r05/osc_large_voice_counts.txt).
+    const uint32_t stride = (voices != 0 && ((size_t)voices * sizeof(float)) % 65536 == 0) ? voices + kRowPadVoices : voices;
     void *p = nullptr;
     int rc = zh_malloc(ctx, &p, (size_t)stride * frames * sizeof(float));
     if (rc) return rc;

@@ -35,7 +35,7 @@ const FormRow kForms[ZF_COUNT] = {
     /* ZF_PMOSC_RANGES       */ {"pmosc_ranges", -1, "PMOscInstrument: frame ranges (k_pmosc_ranges); auto: ~2,048-4,096 waves up to 131,072 voices"},
     /* ZF_SCRIPT_RANGES      */ {"script_ranges", -1, "generated script kernels: frame ranges for modules without a delay ring; auto: by voice count"},
     /* ZF_SCRIPT_RANGES_MAXV */ {"script_ranges_maxv", 131072, "... the largest voice count that takes them"},
-    /* ZF_OSC_FC             */ {"osc_fc", 0, "constant-frequency PulseOsc / TriSawOsc: frames per lane of the chunked kernel; 0 = 4 for PulseOsc, 8-64 by voice count for TriSawOsc (tools/sweep_osc_fc.sh)"},
+    /* ZF_OSC_FC             */ {"osc_fc", 0, "constant-frequency PulseOsc / TriSawOsc: frames per lane of the chunked kernel; 0 = PulseOsc 4, from 16,384 voices 3 with non-temporal stores (profiles/r05/osc_large_voice_counts.txt); TriSawOsc 8-64 by voice count (tools/sweep_osc_fc.sh)"},
     /* ZF_NICE_PC_MAX        */ {"nice_pc_max", 65536, "NiceInstrument: up to here the oscillator, envelope and filter chains run in three waves side by side (k_nice_pc: 72 vs 146 us at 4,096 voices, 107 vs 168 at 65,536; slower at 131,072)"},
     /* ZF_NICE_PC4_MAX       */ {"nice_pc4_max", 32768, "... and up to here in four (k_nice_pc4: 44 / 47 / 53.5 us at 4,096 / 16,384 / 32,768 voices against 60.5 / 62.5 / 63)"},
     /* ZF_NICE_WAVE_MAX      */ {"nice_wave_max", 64, "zh_nice_paint_spans: up to here one WAVE per voice, lanes = frames (k_nice_spans_wave)"},

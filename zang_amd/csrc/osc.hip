@@ -432,7 +432,11 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 static uint32_t osc_frames_per_lane(bool short_chunks, uint32_t lanes, uint32_t nframes) {
     const long forced = zh_form(ZF_OSC_FC);
     if (forced > 0) return (uint32_t)forced;
-    if (short_chunks) return 4u;
+    // PulseOsc: 4 frames per lane; from 16,384 voices (4,096 lanes) 3 -- an odd number of rows between a lane's chunks spreads a
+    // workgroup's rows over the HBM channels whatever the row stride, and with non-temporal stores (launch_osc_const) the paint
+    // holds 0.83-0.86 of the HBM peak from 16,384 to 786,432 voices where 4 frames + write-through stores gave 0.63-0.83 by
+    // voice count (profiles/r05/osc_large_voice_counts.txt).  Level at 4,096 voices: the headline size keeps 4.
+    if (short_chunks) return lanes >= 4096u ? 3u : 4u;
     const uint64_t groups = (lanes + 63) / 64;
     const uint64_t fc = (groups * nframes) / 4096u;
     uint32_t p = 8;
@@ -471,7 +475,9 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         constexpr size_t kw1 = sizeof(typename OSC::K) / 4 + 1;
         const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) &&
                              (size_t)n * kw1 * 4 <= ((size_t)16 << 20);
-        const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN : zh_store_mode();
+        // stores: ZH_STORE_MODE when set; else write-through (sc1), and non-temporal for the three-frame chunks of many voices
+        const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN
+                       : zh_store_mode_env() >= 0 ? zh_store_mode_env() : (OSC::kShortChunks && lanes >= 4096u && fc == 3) ? ST_NT : ST_SC1;
         const bool fc4 = fc == 4 && (end - start) % 4 == 0;
         // one launch of `a` (images and count filled in) over `cnt_b` buffers
         auto launch = [use_tab, fc4, zf, sm, lanes, chunks](OscArgs a, uint32_t cnt_b, hipStream_t st) {

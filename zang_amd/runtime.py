@@ -89,8 +89,8 @@ class Context:
 
 def image_row_pad(voices):
     """Row padding (in voices) Context.image gives an image by default: zh_buf_alloc's rule (ctx.hip) -- rows that
-    are a multiple of 64 KiB get 1 KiB more, so that a lane's consecutive frames do not all map to one HBM bank."""
-    return 256 if voices and (voices * 4) % 65536 == 0 else 0
+    are a multiple of 64 KiB get 4 KiB more, so that a lane's consecutive frames do not all map to one HBM bank."""
+    return 1024 if voices and (voices * 4) % 65536 == 0 else 0
 
 
 class Graph:
