@@ -473,11 +473,12 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         // it pays while an XCD's eighth of it stays in that XCD's 4 MiB L2: measured +3 ... +10 % up to 524,288 voices
         // (81 % of the HBM peak there), -20 % at 1,048,576 (3.7 MB per XCD: it thrashes) -- hence the size limit.
         constexpr size_t kw1 = sizeof(typename OSC::K) / 4 + 1;
-        const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) &&
-                             (size_t)n * kw1 * 4 <= ((size_t)16 << 20);
-        // stores: ZH_STORE_MODE when set; else write-through (sc1), and non-temporal for the three-frame chunks of many voices
+        const bool table_fits = (size_t)n * kw1 * 4 <= ((size_t)16 << 20);
+        const bool use_tab = (flags & ZH_PAINT_PARAMS_UNCHANGED) && m->tab.words && table_matches(m->tab, sample_rate, freq, color) && table_fits;
+        // stores: ZH_STORE_MODE when set; else write-through (sc1), and non-temporal for the three-frame chunks of many voices up to
+        // the table's size limit (above it -- 786,432 / 1,048,576 voices -- sc1 again: 0.84 against 0.72 of the HBM peak)
         const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN
-                       : zh_store_mode_env() >= 0 ? zh_store_mode_env() : (OSC::kShortChunks && lanes >= 4096u && fc == 3) ? ST_NT : ST_SC1;
+                       : zh_store_mode_env() >= 0 ? zh_store_mode_env() : (OSC::kShortChunks && lanes >= 4096u && fc == 3 && table_fits) ? ST_NT : ST_SC1;
         const bool fc4 = fc == 4 && (end - start) % 4 == 0;
         // one launch of `a` (images and count filled in) over `cnt_b` buffers
         auto launch = [use_tab, fc4, zf, sm, lanes, chunks](OscArgs a, uint32_t cnt_b, hipStream_t st) {
