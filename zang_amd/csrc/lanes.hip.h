@@ -124,9 +124,14 @@ template <int W> ZL typename LaneT<W>::F zrow_load(zh_rsrc_t r, uint32_t voff, u
     if constexpr (W == 1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
     else return __builtin_bit_cast(zf2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+// Image rows are written once per paint and not read again by the kernel that writes them: non-temporal stores (aux bit 1 = nt on
+// gfx940+).  Against plain stores, alternating on one box (profiles/r05/ab_row_store_nt.txt): the module table at 4,096 voices 2-15 %
+// faster on every row that stores through here (Envelope 11.3 -> 9.7 us, Sampler 12.6 -> 10.9, PulseOsc with a frequency image 15.9 ->
+// 13.5), 1-4 % at 131,072 voices; config 3 unfused (Noise -> temp -> Filter) 59.9 -> 53.9 us, fused 52.6 -> 51.0.
+constexpr int kRowStoreAux = 2;
 template <int W> ZL void zrow_store(zh_rsrc_t r, uint32_t voff, uint32_t soff, typename LaneT<W>::F x) {
-    if constexpr (W == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(zu2, x), r, voff, soff, 0);
+    if constexpr (W == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, voff, soff, kRowStoreAux);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(zu2, x), r, voff, soff, kRowStoreAux);
 }
 #else   // host pass: kernels are only parsed, never run
 ZL zh_rsrc_t zrow_rsrc(const float *, size_t, uint32_t) { return 0; }
