@@ -21,7 +21,10 @@ dev = ctx.device
 freq_h, color_h, u2, u3 = workloads.voice_params(5, 0, V)
 freq, color = torch.from_numpy(freq_h).to(dev), torch.from_numpy(color_h).to(dev)
 span = zang.Span(0, F)
-out = [ctx.image(F, V) for _ in range(2)]
+# output images: a ring of 512 MiB (2 .. 32 images) so that a paint's stores go to HBM, not to a 256 MiB Infinity Cache that still holds
+# the image from two paints ago (at 4,096 voices an image is 16 MiB)
+NOUT = max(2, min(32, (512 << 20) // (F * V * 4)))
+out = [ctx.image(F, V) for _ in range(NOUT)]
 inp = ctx.image(F, V); inp.uniform_(-1.0, 1.0)
 fbuf = ctx.image(F, V); fbuf.copy_(freq[None, :].expand(F, V))          # a frequency control image
 pcm = torch.from_numpy(np.random.default_rng(1).integers(-20000, 20000, 48000, dtype=np.int16).view(np.uint8).copy()).to(dev)
@@ -35,6 +38,15 @@ def case(name, m, paint, reads=0):
     cases.append((name, m, paint, reads))
 
 
+# basics.zig: pure bandwidth; `reads` = images read beside the one written (the destination of a `+=` counts)
+inp2 = ctx.image(F, V); inp2.uniform_(-1.0, 1.0)
+case("zero", None, lambda o: zang.zero(span, o, ctx), 0)
+case("set (per-voice scalar)", None, lambda o: zang.set(span, o, color, ctx), 0)
+case("copy", None, lambda o: zang.copy(span, o, inp, ctx), 1)
+case("addInto (dest += a)", None, lambda o: zang.addInto(span, o, inp, ctx), 2)
+case("add (dest += a + b)", None, lambda o: zang.add(span, o, inp, inp2, ctx), 3)
+case("multiply (dest += a * b)", None, lambda o: zang.multiply(span, o, inp, inp2, ctx), 3)
+case("multiplyWithScalar (dest *= s)", None, lambda o: zang.multiplyWithScalar(span, o, 0.5, ctx), 1)
 m = mod.SineOsc(V, ctx); case("SineOsc const freq / const phase", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), zang.constant(0.0)), zero_first=True))
 m = mod.SineOsc(V, ctx); case("SineOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), zang.constant(0.0)), zero_first=True), 1)
 m = mod.SineOsc(V, ctx); case("SineOsc const / const, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), zang.constant(0.0)), zero_first=True, tolerant=True))
@@ -129,15 +141,15 @@ for name, m, paint, reads in cases:
     if ONLY and not any(k in name for k in ONLY.split("|")):
         continue
     for i in range(4):
-        paint(out[i & 1])
+        paint(out[i % NOUT])
     ctx.sync()
     if os.environ.get("ZH_BENCH_EAGER") == "1":            # counter collection (rocprofv3 --pmc) wants plain launches
         t0 = time.perf_counter()
         for i in range(K):
-            paint(out[i & 1])
+            paint(out[i % NOUT])
         ctx.sync(); dt = time.perf_counter() - t0
     else:
-        g = ctx.capture(lambda: [paint(out[i & 1]) for i in range(K)])
+        g = ctx.capture(lambda: [paint(out[i % NOUT]) for i in range(K)])
         g.launch(); ctx.sync()
         t0 = time.perf_counter(); g.launch(); ctx.sync(); dt = time.perf_counter() - t0
         g.close()
