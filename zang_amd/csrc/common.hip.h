@@ -268,11 +268,14 @@ __device__ __forceinline__ void store1(float *p, zh_rsrc_t rsrc, uint32_t byte_o
     else if constexpr (SM == ST_SC1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, byte_off, 0, 16);
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, byte_off, 0, 17);
 }
+// an image sample written once and not read again by this kernel: non-temporal (lanes.hip.h zrow_store: the same through a descriptor)
+__device__ __forceinline__ void store_row(float *p, float v) { __builtin_nontemporal_store(v, p); }
 // the same write-through store through a flat global address (no descriptor: any image size, lane-varying rows)
 __device__ __forceinline__ void store4_sc1(float *p, zv4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 #else   // host pass: kernels are only parsed, never run
 typedef int zh_rsrc_t;
 __device__ inline void store4_sc1(float *, zv4f) {}
+__device__ inline void store_row(float *, float) {}
 __device__ inline zh_rsrc_t make_rsrc(const void *, uint32_t) { return 0; }
 template <int SM> __device__ inline void store4(float *, zh_rsrc_t, uint32_t, zv4f) {}
 template <int SM> __device__ inline void store1(float *, zh_rsrc_t, uint32_t, float) {}

@@ -56,14 +56,14 @@ __global__ void __launch_bounds__(kSeqBlock) k_simple_delay(DelayState d, Img ou
         }
 #pragma unroll
         for (uint32_t k = 0; k < CH; k++) {
-            o[(size_t)k * out.stride] = old[k] + delayed[k];
+            store_row(o + (size_t)k * out.stride, old[k] + delayed[k]);
             *slot[k] = x[k];                                          // writeDelayBuffer: ring = input
         }
     }
     for (; i < end; i++, o += out.stride, in += input.stride) {
         float *slot = ring + (size_t)idx * d.n;
         const float delayed = *slot;
-        *o = (ZF ? 0.0f : *o) + delayed;
+        store_row(o, (ZF ? 0.0f : *o) + delayed);
         *slot = *in;
         idx = delay_next<CH>(idx, d.delay_samples);
     }
@@ -103,14 +103,14 @@ __global__ void __launch_bounds__(256) k_delay_frames(DelayState d, Img out, CIm
         }
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
-            o[(size_t)k * out.stride] = base[k] + delayed[k];
+            store_row(o + (size_t)k * out.stride, base[k] + delayed[k]);
             if (WRITE) *rs[k] = x[k];                                 // writeDelayBuffer (:62-89)
         }
     }
     for (; j < j1; j++, o += out.stride, in += input.stride) {
         float *rs = d.ring + (size_t)slot * d.n + v;
         const float delayed = j < D ? *rs : *(in - (size_t)D * input.stride);
-        *o = (ZF ? 0.0f : *o) + delayed;
+        store_row(o, (ZF ? 0.0f : *o) + delayed);
         if (WRITE) *rs = *in;
         slot = slot + 1 == D ? 0 : slot + 1;
     }
@@ -186,14 +186,14 @@ __global__ void __launch_bounds__(kSeqBlock) k_filtered_echoes(DelayState d, flo
         for (uint32_t k = 0; k < CH; k++) t1[k] = one(delayed[k], x[k]);
 #pragma unroll
         for (uint32_t k = 0; k < CH; k++) {
-            o[(size_t)k * out.stride] = old[k] + t1[k];               // addInto(output, temp1) (:448)
+            store_row(o + (size_t)k * out.stride, old[k] + t1[k]);      // addInto(output, temp1) (:448)
             *slot[k] = t1[k];                                         // writeDelayBuffer(temp1) (:452)
         }
     }
     for (; i < end; i++, o += out.stride, in += input.stride) {
         float *slot = ring + (size_t)idx * d.n;
         const float t1 = one(*slot, *in);
-        *o = (ZF ? 0.0f : *o) + t1;
+        store_row(o, (ZF ? 0.0f : *o) + t1);
         *slot = t1;
         idx = delay_next<CH>(idx, d.delay_samples);
     }

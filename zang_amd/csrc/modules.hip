@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) k_gate(uint32_t V, Img out, uint32_t star
 #pragma unroll
         for (int k = 0; k < 8; k++) base[k] = ZF ? 0.0f : o[(size_t)k * out.stride];
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[(size_t)k * out.stride] = on ? base[k] + 1.0f : base[k];
+        for (int k = 0; k < 8; k++) o[(size_t)k * out.stride] = on ? base[k] + 1.0f : base[k];   // (plain stores: non-temporal ones measured 9.5 % slower at 131,072 voices, 3.6 % faster at 4,096)
     }
     for (; i < c1; i++, o += out.stride) {
         const float base = ZF ? 0.0f : *o;
@@ -1211,9 +1211,9 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
 #pragma unroll
         for (int k = 0; k < 8; k++) { x[k] = in[(size_t)k * input.stride]; old[k] = ZF ? 0.0f : o[(size_t)k * out.stride]; }
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[(size_t)k * out.stride] = old[k] + d.frame(x[k]);
+        for (int k = 0; k < 8; k++) store_row(o + (size_t)k * out.stride, old[k] + d.frame(x[k]));
     }
-    for (; i < c1; i++, o += out.stride, in += input.stride) *o = (ZF ? 0.0f : *o) + d.frame(*in);
+    for (; i < c1; i++, o += out.stride, in += input.stride) store_row(o, (ZF ? 0.0f : *o) + d.frame(*in));
 }
 
 // =================================================================== Curve
