@@ -35,9 +35,12 @@ def _gpu_op(ctx, name, span, dest, a, b, sc):
 
 
 @pytest.mark.parametrize("name", OPS)
-@pytest.mark.parametrize("V,per_voice", [(256, True), (256, False), (67, True)])   # 67: scalar-lane path
-def test_basics_bitexact(ctx, oracle, name, V, per_voice):
+@pytest.mark.parametrize("V,per_voice,rows", [(256, True, False), (256, False, False), (67, True, False),   # 67: scalar-lane path
+                                              (256, True, True), (1000, False, True)])   # rows: the many-voices form (basics_rows_min), forced
+def test_basics_bitexact(ctx, oracle, name, V, per_voice, rows, monkeypatch):
     from zang_amd import zang
+    if rows:
+        util.set_form(monkeypatch, basics_rows_min="1")
     F, s, e = 300, 17, 283
     dest = util.rng_buffers(1, V, F); a = util.rng_buffers(2, V, F); b = util.rng_buffers(3, V, F)
     sc = np.random.default_rng(4).uniform(-2, 2, V).astype(np.float32)
@@ -48,7 +51,34 @@ def test_basics_bitexact(ctx, oracle, name, V, per_voice):
     gd, ga, gb = util.to_image(dest), util.to_image(a), util.to_image(b)
     _gpu_op(ctx, name, zang.Span(s, e), gd, ga, gb, util.dev(sc) if per_voice else float(sc[0]))
     ctx.sync()
+    assert ctx.last_form() == ["k_elementwise_chunks" if rows else "k_elementwise"]
     util.assert_bitexact(util.from_image(gd), ref, name)
+
+
+@pytest.mark.parametrize("V", [32768, 32768 + 64])
+def test_basics_many_voices_default_form(ctx, oracle, V):
+    """From basics_rows_min voices (32,768) the operations take the row-chunk form by default (k_elementwise_chunks): every operation on
+    a ragged span against the oracle on a stride of voices plus the edges, and the rows outside the span untouched."""
+    import torch
+    from zang_amd import zang
+    F, s, e = 40, 3, 38
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    dest0 = torch.rand(F, V, device="cuda", generator=g) * 2 - 1
+    ga = ctx.image(F, V); ga.copy_(torch.rand(F, V, device="cuda", generator=g) * 2 - 1)
+    gb = ctx.image(F, V); gb.copy_(torch.rand(F, V, device="cuda", generator=g) * 2 - 1)
+    sc = np.random.default_rng(4).uniform(-2, 2, V).astype(np.float32)
+    idx = np.unique(np.concatenate([np.arange(0, V, 509), [0, 1, 255, 256, 257, V - 257, V - 2, V - 1]]))
+    tidx = torch.from_numpy(idx).cuda()
+    a_h = np.ascontiguousarray(ga[:, tidx].cpu().numpy().T); b_h = np.ascontiguousarray(gb[:, tidx].cpu().numpy().T)
+    for name in OPS:
+        gd = ctx.image(F, V); gd.copy_(dest0)
+        _gpu_op(ctx, name, zang.Span(s, e), gd, ga, gb, util.dev(sc))
+        ctx.sync()
+        assert ctx.last_form() == ["k_elementwise_chunks"], (name, ctx.last_form())
+        ref = np.ascontiguousarray(dest0[:, tidx].cpu().numpy().T)
+        _oracle_op(oracle, name, s, e, ref, a_h, b_h, sc[idx])
+        util.assert_bitexact(np.ascontiguousarray(gd[:, tidx].cpu().numpy().T), ref, name)
+        assert torch.equal(gd[:s], dest0[:s]) and torch.equal(gd[e:], dest0[e:]), name
 
 
 def test_basics_empty_span_and_errors(ctx):

@@ -2,6 +2,7 @@
 // images, plus the voice mixdown.  Pure HBM streaming: 16 B per lane where the images
 // allow it (4 consecutive voices of one frame), scalar lanes otherwise.
 #include "common.hip.h"
+#include <stdlib.h>
 
 enum EwOp { OP_ZERO, OP_SET, OP_COPY, OP_ADD, OP_ADD_INTO, OP_ADD_SCALAR, OP_ADD_SCALAR_INTO,
             OP_MUL, OP_MUL_WITH, OP_MUL_SCALAR, OP_MUL_WITH_SCALAR };
@@ -31,36 +32,98 @@ template <int OP> __device__ __forceinline__ float ew_apply(float d, float a, fl
 }
 
 // VEC = 4: a thread owns 4 consecutive voices of one frame (float4); VEC = 1: one voice.
+// A workgroup is TX x (256 / TX) threads: x = voice quads (TX = 2^tx_log2 <= 256, the smallest power of two that covers the row, so
+// that narrow images keep every lane busy), y = frames; blockIdx.y strides over the frames, R rows per step with their loads ahead of
+// the arithmetic.  (Round 5: the earlier flat index paid a 64-bit division per element -- ~100 instructions against one 16-byte
+// store: zero / set at 131,072 voices 104 -> see profiles/r05/ab_basics_2d.txt.)
 template <int OP, int VEC>
 __global__ void __launch_bounds__(256) k_elementwise(Img dst, CImg a, CImg b, F32P s, uint32_t start,
-                                                     uint32_t nframes, uint32_t nvq /* voices / VEC */) {
+                                                     uint32_t nframes, uint32_t nvq /* voices / VEC */, uint32_t tx_log2) {
     using T = OpTraits<OP>;
-    const uint64_t total = (uint64_t)nframes * nvq;
-    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += step) {
-        const uint32_t f = start + (uint32_t)(idx / nvq);
-        const uint32_t v = (uint32_t)(idx % nvq) * VEC;
-        if constexpr (VEC == 4) {
-            float4 d = {0, 0, 0, 0}, av = {0, 0, 0, 0}, bv = {0, 0, 0, 0}, sv = {s.value, s.value, s.value, s.value};
-            if constexpr (T::reads_dst) d = *reinterpret_cast<const float4 *>(dst.at(f, v));
-            if constexpr (T::uses_a) av = *reinterpret_cast<const float4 *>(a.at(f, v));
-            if constexpr (T::uses_b) bv = *reinterpret_cast<const float4 *>(b.at(f, v));
-            if constexpr (T::uses_s) if (s.pv) sv = *reinterpret_cast<const float4 *>(s.pv + v);
-            float4 r;
-            r.x = ew_apply<OP>(d.x, av.x, bv.x, sv.x);
-            r.y = ew_apply<OP>(d.y, av.y, bv.y, sv.y);
-            r.z = ew_apply<OP>(d.z, av.z, bv.z, sv.z);
-            r.w = ew_apply<OP>(d.w, av.w, bv.w, sv.w);
-            // write-through (sc1): the image drains to HBM while the kernel runs instead of at its end -- 4,096 voices 10-21 % faster on
-            // every operation, 16,384 voices 2-12 %, level at 131,072 (alternating A/B, profiles/r05/ab_basics_sc1.txt)
-            store4_sc1(dst.at(f, v), zv4f{r.x, r.y, r.z, r.w});
-        } else {
-            float d = 0, av = 0, bv = 0, sv = s.value;
-            if constexpr (T::reads_dst) d = *dst.at(f, v);
-            if constexpr (T::uses_a) av = *a.at(f, v);
-            if constexpr (T::uses_b) bv = *b.at(f, v);
-            if constexpr (T::uses_s) sv = s.get(v);
-            *dst.at(f, v) = ew_apply<OP>(d, av, bv, sv);
+    constexpr int R = 4;
+    const uint32_t tx = threadIdx.x & ((1u << tx_log2) - 1u), ty = threadIdx.x >> tx_log2, TY = 256u >> tx_log2;
+    const uint32_t q = (blockIdx.x << tx_log2) + tx;
+    if (q >= nvq) return;
+    const uint32_t v = q * VEC;
+    const uint32_t rstep = gridDim.y * TY;
+    if constexpr (VEC == 4) {
+        zv4f sv = {s.value, s.value, s.value, s.value};
+        if constexpr (T::uses_s) if (s.pv) sv = *reinterpret_cast<const zv4f *>(s.pv + v);
+        for (uint32_t r0 = blockIdx.y * TY + ty; r0 < nframes; r0 += rstep * R) {
+            zv4f d[R], av[R], bv[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t r = r0 + k * rstep;
+                d[k] = av[k] = bv[k] = zv4f{0, 0, 0, 0};
+                if (r < nframes) {
+                    if constexpr (T::reads_dst) d[k] = *reinterpret_cast<const zv4f *>(dst.at(start + r, v));
+                    if constexpr (T::uses_a) av[k] = *reinterpret_cast<const zv4f *>(a.at(start + r, v));
+                    if constexpr (T::uses_b) bv[k] = *reinterpret_cast<const zv4f *>(b.at(start + r, v));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t r = r0 + k * rstep;
+                if (r < nframes) {
+                    zv4f o;
+                    o.x = ew_apply<OP>(d[k].x, av[k].x, bv[k].x, sv.x);
+                    o.y = ew_apply<OP>(d[k].y, av[k].y, bv[k].y, sv.y);
+                    o.z = ew_apply<OP>(d[k].z, av[k].z, bv[k].z, sv.z);
+                    o.w = ew_apply<OP>(d[k].w, av[k].w, bv[k].w, sv.w);
+                    // write-through (sc1): the image drains to HBM while the kernel runs instead of at its end -- 4,096 voices 10-21 % faster
+                    // on every operation, 16,384 voices 2-12 %, level at 131,072 (alternating A/B, profiles/r05/ab_basics_sc1.txt)
+                    store4_sc1(dst.at(start + r, v), o);
+                }
+            }
+        }
+    } else {
+        const float sv = T::uses_s ? s.get(v) : 0.0f;
+        for (uint32_t r = blockIdx.y * TY + ty; r < nframes; r += rstep) {
+            float d = 0, av = 0, bv = 0;
+            if constexpr (T::reads_dst) d = *dst.at(start + r, v);
+            if constexpr (T::uses_a) av = *a.at(start + r, v);
+            if constexpr (T::uses_b) bv = *b.at(start + r, v);
+            *dst.at(start + r, v) = ew_apply<OP>(d, av, bv, sv);
+        }
+    }
+}
+
+// Many voices (basics_rows_min, dispatch.hip): the chunked oscillator's launch shape -- a wave owns RC consecutive rows of a 256-voice
+// column, a workgroup four consecutive chunks, no loop.  The same bytes in the same 16-byte stores, but spread over the HBM channels the
+// way k_osc_const4's are: at 131,072 voices zero 104 -> 87 us, copy 219 -> 178, addInto 322 -> 280, add 428 -> 382; from 32,768 voices
+// on never slower, below it slower (4,096 voices: addInto 8.2 -> 10.2 us) -- profiles/r05/ab_basics_rows.txt.
+template <int OP, int RC, int SM>
+__global__ void __launch_bounds__(256) k_elementwise_chunks(Img dst, CImg a, CImg b, F32P s, uint32_t start, uint32_t nframes, uint32_t nvq) {
+    using T = OpTraits<OP>;
+    const uint32_t q = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (q >= nvq) return;
+    const uint32_t v = q * 4, r0 = chunk * RC;
+    zv4f sv = {s.value, s.value, s.value, s.value};
+    if constexpr (T::uses_s) if (s.pv) sv = *reinterpret_cast<const zv4f *>(s.pv + v);
+    zv4f d[RC], av[RC], bv[RC];
+#pragma unroll
+    for (int k = 0; k < RC; k++) {
+        const uint32_t r = r0 + k;
+        d[k] = av[k] = bv[k] = zv4f{0, 0, 0, 0};
+        if (r < nframes) {
+            if constexpr (T::reads_dst) d[k] = *reinterpret_cast<const zv4f *>(dst.at(start + r, v));
+            if constexpr (T::uses_a) av[k] = *reinterpret_cast<const zv4f *>(a.at(start + r, v));
+            if constexpr (T::uses_b) bv[k] = *reinterpret_cast<const zv4f *>(b.at(start + r, v));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RC; k++) {
+        const uint32_t r = r0 + k;
+        if (r < nframes) {
+            zv4f o;
+            o.x = ew_apply<OP>(d[k].x, av[k].x, bv[k].x, sv.x);
+            o.y = ew_apply<OP>(d[k].y, av[k].y, bv[k].y, sv.y);
+            o.z = ew_apply<OP>(d[k].z, av[k].z, bv[k].z, sv.z);
+            o.w = ew_apply<OP>(d[k].w, av[k].w, bv[k].w, sv.w);
+            if constexpr (SM == ST_NT) __builtin_nontemporal_store(o, reinterpret_cast<zv4f *>(dst.at(start + r, v)));
+            else if constexpr (SM == ST_SC1) store4_sc1(dst.at(start + r, v), o);
+            else *reinterpret_cast<zv4f *>(dst.at(start + r, v)) = o;
         }
     }
 }
@@ -85,11 +148,20 @@ static int launch_ew(zh_ctx *ctx, uint32_t start, uint32_t end, const zh_buf &de
     if (T::uses_b) vec = vec && (b->stride % 4 == 0) && aligned16(b->ptr);
     if (T::uses_s && sp.pv) vec = vec && aligned16(sp.pv);
     const uint32_t nvq = vec ? V / 4 : V;
-    const uint64_t total = (uint64_t)nframes * nvq;
-    uint64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 workgroups per CU, grid-stride the rest
-    if (vec) ZH_LAUNCH((k_elementwise<OP, 4>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
-    else ZH_LAUNCH((k_elementwise<OP, 1>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
+    uint32_t tx_log2 = 0;
+    while (tx_log2 < 8 && (1u << tx_log2) < nvq) tx_log2++;
+    const uint32_t TX = 1u << tx_log2, TY = 256u / TX;
+    const uint32_t gx = (nvq + TX - 1) / TX;
+    uint32_t gy = (nframes + TY - 1) / TY;                            // about 16 workgroups per CU; the rows stride over the rest
+    const uint32_t gy_max = gx >= 256u * 16u ? 1u : (256u * 16u + gx - 1) / gx;
+    if (gy > gy_max) gy = gy_max;
+    if (vec && (long)V >= zh_form(ZF_BASICS_ROWS_MIN)) {
+        const dim3 g((nvq + 63) / 64, ((nframes + 2) / 3 + 3) / 4);
+        ZH_LAUNCH((k_elementwise_chunks<OP, 3, ST_SC1>), g, dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq);
+        return zh_launch_status();
+    }
+    if (vec) ZH_LAUNCH((k_elementwise<OP, 4>), dim3(gx, gy), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq, tx_log2);
+    else ZH_LAUNCH((k_elementwise<OP, 1>), dim3(gx, gy), dim3(256), 0, ctx->stream, d, ai, bi, sp, start, nframes, nvq, tx_log2);
     return zh_launch_status();
 }
 

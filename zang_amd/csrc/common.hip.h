@@ -130,7 +130,7 @@ enum { ZF_SINE_RANGES, ZF_NOISE_RANGES, ZF_ENVELOPE_RANGES, ZF_SAMPLER_RANGES, Z
        ZF_SCRIPT_RANGES, ZF_SCRIPT_RANGES_MAXV, ZF_OSC_FC, ZF_NICE_PC_MAX, ZF_NICE_PC4_MAX, ZF_NICE_WAVE_MAX, ZF_PMOSC_WAVE_MAX,
        ZF_NICE_MIX_ROLL, ZF_NICE_MIX_WG_MIN, ZF_NF_PC_MAX, ZF_NF_RING_MAX, ZF_FILTER_PC_MAX, ZF_FILTER_PC16_MAX, ZF_FILTER_PC_CTL_MAX,
        ZF_PINK_PIPE_MAX, ZF_PINK_TAPS, ZF_ECHOES_PC_MAX, ZF_DELAY_FRAMES_MAX, ZF_FILTER_TP_MAX, ZF_NF_TP_MAX, ZF_NICE_TP_MAX,
-       ZF_PINK_TP_MAX, ZF_ECHOES_TP_MAX, ZF_NICE_MIX_FMA, ZF_COUNT };
+       ZF_PINK_TP_MAX, ZF_ECHOES_TP_MAX, ZF_NICE_MIX_FMA, ZF_BASICS_ROWS_MIN, ZF_COUNT };
 long zh_form(int id);
 bool zh_form_is_set(int id);                 // the row is overridden through ZH_FORMS
 uint32_t zh_range_frames(uint32_t V, uint32_t n, int form, uint32_t target_waves, uint32_t max_voices);
@@ -271,7 +271,10 @@ __device__ __forceinline__ void store1(float *p, zh_rsrc_t rsrc, uint32_t byte_o
 // an image sample written once and not read again by this kernel: non-temporal (lanes.hip.h zrow_store: the same through a descriptor)
 __device__ __forceinline__ void store_row(float *p, float v) { __builtin_nontemporal_store(v, p); }
 // the same write-through store through a flat global address (no descriptor: any image size, lane-varying rows)
-__device__ __forceinline__ void store4_sc1(float *p, zv4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// (inline assembly: the compiler's hazard recognizer does not look inside it.  gfx940+ needs two wait states between a store of more than
+// 64 bits and a VALU write of its data registers -- without the s_nop the next instruction's result went out as the first component:
+// found by tests/test_gpu_basics.py::test_basics_many_voices_default_form.)
+__device__ __forceinline__ void store4_sc1(float *p, zv4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 #else   // host pass: kernels are only parsed, never run
 typedef int zh_rsrc_t;
 __device__ inline void store4_sc1(float *, zv4f) {}
