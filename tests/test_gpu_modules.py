@@ -361,9 +361,9 @@ def test_envelope_off_while_idle_and_release_note_on(ctx, oracle):
 
 
 # ------------------------------------------------------------------ Gate
-def test_gate_bitexact(ctx, oracle):
+@pytest.mark.parametrize("V", [200, 201, 1028])     # 201: one voice per lane (k_gate); the others four per lane (k_gate4)
+def test_gate_bitexact(ctx, oracle, V):
     from zang_amd import modules as mod, zang
-    V = 200
     on = np.random.default_rng(2).random(V) < 0.5
     out0 = util.rng_buffers(4, V, F)
     ref = out0.copy()
@@ -376,6 +376,7 @@ def test_gate_bitexact(ctx, oracle):
     out2 = util.to_image(out0)
     m.paint(zang.Span(10, 1000), [out2], [], False, m.Params(util.dev(on.astype(np.uint8))), zero_first=True)
     ctx.sync()
+    assert ctx.last_form() == ["k_gate4" if V % 4 == 0 else "k_gate"]
     util.assert_bitexact(util.from_image(out), ref, "gate")
     ref2 = out0.copy(); ref2[:, 10:1000] = on[:, None].astype(np.float32)
     util.assert_bitexact(util.from_image(out2), ref2, "gate zero_first")
