@@ -75,3 +75,21 @@ def test_every_file_design_md_cites_exists():
         if not ok:
             missing.append(tok)
     assert not missing, sorted(set(missing))
+
+
+def test_inline_assembly_memory_instructions_carry_their_wait_states():
+    """The compiler's hazard recognizer does not look inside inline assembly: on gfx940+ a store of more than 64 bits needs two wait
+    states before a VALU write of its data registers (round 5: store4_sc1 without them sent the NEXT instruction's result out as the first
+    component, in one kernel shape out of three).  Every inline-assembly store / load in csrc/ must be followed by an s_nop in the same
+    statement."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zang_amd", "csrc")
+    bad = []
+    for path in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        for m in re.finditer(r'asm\s+volatile\s*\(\s*"([^"]*)"', open(path).read()):
+            text = m.group(1)
+            if re.search(r"\b(global|buffer|flat|scratch)_(store|load|atomic)", text) and "s_nop" not in text:
+                bad.append((os.path.basename(path), text[:60]))
+    assert not bad, bad
