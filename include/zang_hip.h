@@ -79,7 +79,8 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *  - zh_filtered_echoes_paint at up to 6,144 voices when the span is at most three delay lengths (input image not the
         *    output image): over a piece of <= delay_samples frames the ring's slots were all written before the piece, so the
         *    filter's input is known up front and the piece is filtered as chunks at once (csrc/delay.hip k_fe_tp_a / _b); the
-        *    ring carries a paint's error into later ones (measured <= 4.5e-6 of the peak over 200 buffers, feedback 0.9);
+        *    ring carries a paint's error into later ones (measured <= 4.5e-6 of the peak over 200 buffers, feedback 0.9; over 300 further
+        *    fuzz seeds of 3-7 carried paints each, 4,096 voices, one voice reached 1.01e-5: profiles/r05/fuzz_long.txt);
         *  - zh_script_module_paint at any voice count: the generated kernel's SineOsc calls and sin() whose result reaches the
         *    output through scaling and adding alone (+ - * neg abs min max, a Filter's or Decimator's input, a delay ring written)
         *    take the f32 sine; one that reaches anything else -- another oscillator's freq or phase, a Distortion, a divisor, pow,

@@ -203,8 +203,11 @@ def main():
                     _, gidx, _ = m.state()
                     assert [int(x) for x in gidx[idx]] == [d.index for d in ds], tag + " ring index"
                 grings, _, _ = m.state()
-                scale = np.maximum(np.abs(rings).max(axis=1), 1e-30)
-                assert (np.abs(grings[idx].astype(np.float64) - rings).max(axis=1) <= 1e-5 * scale).all(), tag + f" D={D} ring"
+                # (the ring holds input + feedback * FILTERED echo: its error scales with the filter's state like the samples' does --
+                # at a cutoff of 0.001 the band state is ~1,000 x the signal; seed 50033 measured the ring against its own peak alone)
+                scale = np.maximum(np.maximum(np.abs(rings).max(axis=1), np.maximum(np.abs(rl), np.abs(rb))), 1e-30)
+                rerr = np.abs(grings[idx].astype(np.float64) - rings).max(axis=1) / scale
+                assert (rerr <= 1e-5).all(), tag + f" D={D} ring: worst {rerr.max():.3e} of the ring's peak (voice {int(idx[int(rerr.argmax())])}, feedback {float(fb[idx[int(rerr.argmax())]]):.3f}, cutoff {float(cutoff[idx[int(rerr.argmax())]]):.3f})"
             else:
                 freq = rng.uniform(-10.0, 8000.0, V).astype(np.float32); phase = rng.uniform(-2, 2, V).astype(np.float32)
                 pbuf = (rng.uniform(-1, 1, (V, F)) * rng.choice([1.0, 30.0, 1e5])).astype(np.float32)
