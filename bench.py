@@ -917,9 +917,11 @@ def main():
                 # pulseosc: ZH_CAPTURE_COALESCE -- the steps' paints (params unchanged: the phase at any frame is the entry counter +
                 # frames * ifreq exactly, PulseOsc.zig:111) are held back while recording and become one launch per <= 32 buffers.  The
                 # step is still one zero+paint CALL per buffer; what the graph replays is fewer, larger launches (ZH_BENCH_IN_ORDER=1: one kernel node per step, the round-4 form)
+                # noise_filter_fused --tolerant: under the same flag consecutive paints are recorded PIPELINED (pass A of buffer n + 1 beside pass B of
+                # buffer n, on the context's side stream: csrc/composite.hip zh_noise_filter_paint); nothing is held back, so graph_held stays 0
                 # nice_mix (stereo): the same flag holds back zh_nice_paint_mix_stereo calls -- up to 8 consecutive buffers per launch, the launch
                 # zh_nice_paint_mix_stereo_batch makes (state words in registers from buffer to buffer, one second pass; same bits)
-                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=(((name == "pulseosc" or (name == "nice_mix" and args.channels == 2)) and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
+                self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=(((name == "pulseosc" or (name == "nice_mix" and args.channels == 2) or (name == "noise_filter_fused" and self.wl.tolerant)) and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
                 self.graph_nodes, self.graph_held, self.graph_launches = self.graph.info()
             # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
             # refuses events recorded by graph nodes on this ROCm: "invalid resource handle", profiles/r04/probe_region.txt)
@@ -1079,7 +1081,8 @@ def main():
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
     # kernel launches of the dominant kernel inside the timed region (a coalesced graph replays fewer, larger launches)
     launches = K
-    if graph is not None and main_run.graph_held and K % G == 0:
+    pipelined = graph is not None and main_run.graph_held > 0 and args.workload == "noise_filter_fused"     # (one fused launch per buffer + the last pass B)
+    if graph is not None and main_run.graph_held and K % G == 0 and not pipelined:
         launches = (K // G) * main_run.graph_launches
     if traffic is not None and launches != K:
         # the PMC passes run one buffer per launch (--eager); a coalesced launch moves that per buffer (the 114 KiB constants table and
@@ -1099,7 +1102,9 @@ def main():
                        f" recorded with ZH_CAPTURE_COALESCE: the {main_run.graph_held} paint calls became {main_run.graph_launches} kernel launches of up to " +
                        ("8 consecutive buffers each (k_nice_mix_batch: the voices' state stays in registers from buffer to buffer)" if mixdown else
                         "32 buffers each (grid.z; an even number, so that a replay ends on the counter buffer it began on)") +
-                       f"; {main_run.graph_nodes} nodes" if main_run.graph_held else "")),
+                       f"; {main_run.graph_nodes} nodes" if (main_run.graph_held and not pipelined) else
+                       (f" recorded with ZH_CAPTURE_COALESCE, pipelined: pass B of buffer n and pass A of buffer n + 1 in one launch (k_nf_tp_ba), "
+                        f"{main_run.graph_launches} launches for the {main_run.graph_held} paint calls" if pipelined else ""))),
                    "graph_nodes": main_run.graph_nodes,
                    "parallelism": f"voices sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -185,6 +185,12 @@ ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
  * launch zh_nice_paint_mix_stereo_batch makes, up to 8 buffers each -- the state words stay in registers from buffer to buffer and
  * the second pass runs once (105 against 108 us per buffer at 131,072 voices; same bits).  The partial-sum scratch for 8 buffers
  * is reserved by every eager stereo mixdown paint, i.e. by the eager pass a host makes before recording anyway.
+ * And PIPELINED: consecutive zh_noise_filter_paint calls flagged ZH_PAINT_TOLERANT (white noise, the two-pass form, one piece each) are
+ * recorded so that the second pass of paint n and the first pass of paint n + 1 are ONE launch (the first pass of a paint needs nothing
+ * the second pass of the paint before it makes: it starts from the generator state the previous first pass predicted).  17.9 against
+ * 20.5 us per buffer at 4,096 voices; the values are those of the paints recorded one after the other, except that a voice that met one
+ * of Random.float's multi-draw samples (2^-41 per sample) is walked sequentially -- the reference's exact walk -- in every later paint
+ * of the chain (profiles/r05/probe_overlap_nf.txt).
  * (Measured and rejected, profiles/r05/ab_capture_lanes.txt + ubench_launch_overlap.txt: the same paints as parallel graph
  * branches on 2-4 forked streams -- kernels from different queues slow each other down, 5.0-5.6 against 4.5 us per buffer.) */
 enum { ZH_CAPTURE_COALESCE = 1 };

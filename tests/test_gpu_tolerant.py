@@ -366,6 +366,92 @@ def test_noise_filter_tolerant_in_a_graph(ctx, oracle):
         c2.close()
 
 
+@pytest.mark.parametrize("V", [300, 4096])
+def test_noise_filter_tolerant_pipelined_recording(ctx, oracle, V):
+    """Recorded with ZH_CAPTURE_COALESCE, consecutive tolerant paints are pipelined: pass B of paint n goes out in one launch with pass A
+    of paint n + 1 (k_nf_tp_ba), which starts from the generator state pass A of paint n PREDICTED.  Seven paints (six into a ring, one
+    sub-span, an exact paint in the middle that ends the chain) recorded once and replayed three times against a twin module that makes
+    the same calls one by one: the same bits, samples and states.  One voice is given a generator state whose draw 2,500 from now is one
+    of Random.float's multi-draw samples: the prediction is wrong from there on, and that voice must still equal the twin in the paint
+    that holds the sample and be the ORACLE's exact walk in every later paint of the chain."""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang
+    from tests.test_gpu_dispatch import _crafted_noise_state
+    first = 77
+    rng = np.random.default_rng(9)
+    cutoff = rng.uniform(0.02, 0.6, V).astype(np.float32); res = rng.uniform(0, 0.9, V).astype(np.float32)
+    vx = 201                                                             # the crafted voice
+    L = oracle.lib()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)
+        ma, mb = mod.NoiseFilter(V, c2, first_seed=first), mod.NoiseFilter(V, c2, first_seed=first)
+        gc, gr = util.dev(cutoff), util.dev(res)
+        P = ma.Params(0, 1, gc, gr)
+        ra = [c2.image(F, V, fill=0.25) for _ in range(7)]; rb = [c2.image(F, V, fill=0.25) for _ in range(7)]
+        sp = zang.Span(0, F)
+
+        def seq(m, ring):
+            m.paint(sp, [ring[0]], None, False, P, zero_first=True, tolerant=True)
+            m.paint(sp, [ring[1]], None, False, P, zero_first=True, tolerant=True)
+            m.paint(zang.Span(100, 900), [ring[2]], None, False, P, tolerant=True)                 # `+=`, a sub-span
+            m.paint(sp, [ring[3]], None, False, P, zero_first=True, tolerant=True)
+            m.paint(sp, [ring[4]], None, False, P, zero_first=True)                                # exact: ends the chain
+            m.paint(sp, [ring[5]], None, False, P, zero_first=True, tolerant=True)                 # a new chain
+            m.paint(sp, [ring[6]], None, False, P, zero_first=True, tolerant=True)
+
+        seq(ma, ra); seq(mb, rb)                                         # eager: the scratch is allocated outside the capture
+        c2.sync()
+        for m in (ma, mb):                                               # draw 2,500 from here = inside the third paint of the next sequence
+            st = m.state()
+            st["noise"]["r"][vx] = _crafted_noise_state(2500, 5)
+            m.set_state(st)
+        # the oracle's walk of the crafted voice over one sequence, from the same state
+        stx = ma.state()
+        nz = oracle.Noise(); fl = oracle.Filter()
+        for i in range(4):
+            nz.r[i] = int(stx["noise"]["r"][vx][i])
+        fl.l, fl.b = float(stx["flt"]["l"][vx]), float(stx["flt"]["b"][vx])
+        temp = np.zeros(F, np.float32)
+        want_x = []
+        for k, (s, e, zf) in enumerate([(0, F, True), (0, F, True), (100, 900, False), (0, F, True), (0, F, True), (0, F, True), (0, F, True)]):
+            ref = np.zeros(F, np.float32) if zf else np.full(F, 0.25, np.float32)
+            L.zo_zero(s, e, oracle.fptr(temp))
+            L.zo_noise_paint(C.byref(nz), s, e, oracle.fptr(temp), 0)
+            L.zo_filter_paint(C.byref(fl), s, e, oracle.fptr(ref), oracle.fptr(temp), 1, oracle.constant(cutoff[vx]), oracle.constant(res[vx]))
+            want_x.append(ref)
+        g = c2.capture(lambda: seq(mb, rb), coalesce=True)
+        nodes, held, launches = g.info()
+        assert held == 6 and launches == 8 and nodes == 9, (nodes, held, launches)       # chains of 4 and 2 paints: 5 + 3 launches, + the exact paint
+        for rep in range(3):
+            for im in ra + rb:
+                im.fill_(0.25)
+            seq(ma, ra)
+            g.launch()
+            c2.sync()
+            others = torch.ones(V, dtype=torch.bool, device="cuda"); others[vx] = False
+            for k in range(7):
+                assert torch.equal(ra[k][:, others].view(torch.int32), rb[k][:, others].view(torch.int32)), (rep, k)
+            if rep == 0:
+                # the crafted voice: paints 0-2 as the twin's; the multi-draw sample sits in paint 2 (draws 2,048 .. 2,847), which both forms
+                # walk exactly; paint 3 (same chain, wrong prediction) must be the oracle's exact walk in the recorded form
+                for k in (0, 1, 2):
+                    assert torch.equal(ra[k][:, vx].view(torch.int32), rb[k][:, vx].view(torch.int32)), k
+                util.assert_bitexact(rb[2][:, vx].cpu().numpy(), want_x[2], "crafted voice, the paint with the multi-draw sample")
+                util.assert_bitexact(rb[3][:, vx].cpu().numpy(), want_x[3], "crafted voice, the next paint of the chain: the exact walk")
+                util.assert_bitexact(rb[4][:, vx].cpu().numpy(), want_x[4], "crafted voice, the exact paint")
+            sa, sb = ma.state(), mb.state()
+            assert sa["noise"]["r"].tobytes() == sb["noise"]["r"].tobytes(), rep
+            if rep > 0:                                                  # (in replay 0 the crafted voice's filter state differs: exact walk against chunks)
+                assert sa["flt"].tobytes() == sb["flt"].tobytes(), rep
+            else:
+                keep = np.ones(V, bool); keep[vx] = False
+                assert sa["flt"][keep].tobytes() == sb["flt"][keep].tobytes()
+                sb["flt"][vx] = sa["flt"][vx]; mb.set_state(sb)          # the crafted voice's filter state: the twin's, for the later replays
+        g.close(); c2.close()
+
+
 # ------------------------------------------------------------------ the f32 sine (SineOsc, PMOscInstrument)
 def test_tolerant_sine_against_musl_over_its_range(ctx, oracle):
     """zsinf_tol through a SineOsc with a phase image chosen so that (t + phase) * pi * 2 sweeps the arguments: dense over

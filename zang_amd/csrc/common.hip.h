@@ -71,6 +71,7 @@ struct zh_ctx {
     uint32_t graphs_live;        // graphs captured on this context and not yet destroyed: only they can still name a retired block
     std::vector<struct zh_graph *> graphs;   // ... themselves: zh_destroy clears their `ctx`, so that a graph destroyed AFTER its context touches nothing of it
     bool capturing;
+    uint32_t capture_serial;     // counts the captures begun on this context (a module's pipeline chain belongs to one capture)
     std::vector<zh_flip_use> capture_log;
     void *noise_jump;            // xoshiro256++ jump tables (noise_jump.hip), built on first use, freed with the context
 };

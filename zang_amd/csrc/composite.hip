@@ -927,6 +927,11 @@ struct zh_noise_filter {
     uint32_t *err;               // k_noise_filter_ring: a ring wait ran into its bound (reported by get_state)
     // ZH_PAINT_TOLERANT (filter_tp.hip.h): scratch of the two-pass form, allocated by the first tolerant paint outside a capture
     uint64_t *tp_cs; float2 *tp_e; uint32_t *tp_flag; uint32_t tp_serial;
+    // ... recorded PIPELINED in a ZH_CAPTURE_COALESCE capture (zh_noise_filter_paint): a second scratch set, the generator states pass A
+    // predicts for the next paint, and where the chain of the recording capture stands
+    uint64_t *tp_cs2; float2 *tp_e2; uint32_t *tp_flag2;
+    uint64_t *tp_pred[2][4];
+    uint32_t pipe_capture, pipe_n;   // capture_serial of the chain, paints in it so far (0: the next pipelined paint starts a chain)
 };
 
 __global__ void k_nf_seed(uint64_t *s0, uint64_t *s1, uint64_t *s2, uint64_t *s3, uint32_t n, uint64_t first_seed) {
@@ -1344,6 +1349,8 @@ static void nf_free(zh_noise_filter *m) {
     (void)hipFree(m->nb); (void)hipFree(m->l); (void)hipFree(m->b);
     (void)hipFree(m->err);
     (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag);
+    (void)hipFree(m->tp_cs2); (void)hipFree(m->tp_e2); (void)hipFree(m->tp_flag2);
+    for (auto &set : m->tp_pred) for (auto &x : set) (void)hipFree(x);
 }
 
 __global__ void k_fill_f32(float *p, uint32_t n, F32P src) {
@@ -1760,6 +1767,7 @@ int zh_noise_filter_get_state(zh_noise_filter *m, zh_noise_filter_state *host) {
 }
 int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *host) { ZH_GUARD(m ? m->ctx : nullptr);
     if (!m || !host) return ZH_ERR_INVALID;
+    m->pipe_n = 0;                                                    // (a pipelined recording's next paint starts from this state)
     const uint32_t n = m->n;
     std::vector<uint64_t> s(n);
     std::vector<float> nb((size_t)7 * n), l(n), b(n);
@@ -1778,7 +1786,7 @@ int zh_noise_filter_set_state(zh_noise_filter *m, const zh_noise_filter_state *h
     return rc;
 }
 int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, const zh_buf *outputs, const zh_buf *temps,
-                          zh_bool note_id_changed, const zh_noise_filter_params *p, uint32_t flags) { ZH_GUARD(m ? m->ctx : nullptr);
+                          zh_bool note_id_changed, const zh_noise_filter_params *p, uint32_t flags) { ZH_GUARD_EPOCH(m ? m->ctx : nullptr);
     (void)temps; (void)note_id_changed;
     if (!m || !outputs || !p || end < start || !buf_covers(outputs[0], m->n, end)) return ZH_ERR_INVALID;
     if (p->color > ZH_NOISE_PINK || p->type > ZH_FILTER_ALL_PASS) return ZH_ERR_INVALID;
@@ -1786,7 +1794,11 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
     const bool zf = flags & ZH_PAINT_ZERO_FIRST, pink = p->color == ZH_NOISE_PINK;
     hipStream_t st = m->ctx->stream;
     Img out = mk_img(outputs[0]);
+    // the pipelined recording's chain (below): any paint that is not its next link ends it
+    const uint32_t chain_n = (m->ctx->capturing && m->pipe_capture == m->ctx->capture_serial) ? m->pipe_n : 0u;
+    m->pipe_n = 0;
     if (p->type == ZH_FILTER_BYPASS) {
+        if (m->ctx->epoch_open) zh_epoch_barrier(m->ctx);
 #define ZH_NFB(ZF_, PK_) ZH_LAUNCH((k_noise_filter_bypass<ZF_, PK_>), seq_grid(m->n), dim3(kSeqBlock), 0, st, m->s[0], m->s[1], m->s[2], m->s[3], m->nb, m->n, out, start, end)
         if (zf) { if (pink) ZH_NFB(true, true); else ZH_NFB(true, false); } else { if (pink) ZH_NFB(false, true); else ZH_NFB(false, false); }
 #undef ZH_NFB
@@ -1811,6 +1823,16 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             if (!arc) arc = dev_alloc(&m->tp_flag, m->n);
             if (!arc) arc = (int)hipMemsetAsync(m->tp_flag, 0, (size_t)m->n * 4, st);
             if (arc) { (void)hipFree(m->tp_cs); (void)hipFree(m->tp_e); (void)hipFree(m->tp_flag); m->tp_cs = nullptr; m->tp_e = nullptr; m->tp_flag = nullptr; (void)hipGetLastError(); }
+            // what a pipelined recording needs beside it (optional: without it the paints are recorded one after the other)
+            if (!arc) {
+                int prc = dev_alloc(&m->tp_cs2, (size_t)kNfTpMaxChunks * 4 * m->n);
+                if (!prc) prc = dev_alloc(&m->tp_e2, (size_t)(kNfTpMaxChunks + 1) * m->n);
+                if (!prc) prc = dev_alloc(&m->tp_flag2, m->n);
+                if (!prc) prc = (int)hipMemsetAsync(m->tp_flag2, 0, (size_t)m->n * 4, st);
+                for (int q = 0; q < 2 && !prc; q++)
+                    for (int i = 0; i < 4 && !prc; i++) prc = dev_alloc(&m->tp_pred[q][i], m->n);
+                if (prc) { (void)hipFree(m->tp_cs2); m->tp_cs2 = nullptr; (void)hipGetLastError(); }   // (tp_cs2 == null: not pipelined; the rest is freed with the module)
+            }
         }
         if (tables && m->tp_cs) {
             const uint32_t L = 32u * max(1u, 32u / Cw);                                 // a multiple of 32 draws: the jump tables' step
@@ -1820,6 +1842,55 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             a.V = m->n; a.L = L; a.out = out;
             a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = mk_f32(p->cutoff); a.res = mk_f32(p->res);
             const uint32_t piece = min(kNfTpMaxChunks * L, ((uint32_t)kNoiseJumpTables * 32u / L) * L + L);   // chunk starts within the tables' reach: (C - 1) * L / 32 <= kNoiseJumpTables
+            for (int i = 0; i < 4; i++) { a.s_in[i] = m->s[i]; a.pred[i] = nullptr; }
+            a.e_next0 = nullptr; a.flag_next = nullptr; a.serial_next = 0; a.snapshot = 1;
+            // Recorded in a ZH_CAPTURE_COALESCE capture, consecutive one-piece paints are PIPELINED: pass B of paint n is held back (common.hip.h
+            // zh_co_batch) until the next paint of this module arrives, and then goes out in ONE launch with that paint's pass A
+            // (k_nf_tp_ba) -- pass A of paint n + 1 needs nothing pass B of paint n makes (NfTpArgs), so one's launch ramp, table load and
+            // jump hide behind the other's frame loops.  When anything else is recorded, or the capture ends, the held pass B goes out on
+            // its own.  Same kernels' code, same values as the paints one after the other; a voice that met one of Random.float's
+            // multi-draw samples (2^-41 per sample) is walked sequentially -- the reference's own walk -- in every later paint of the chain.
+            zh_ctx *ctx = m->ctx;
+            if (ctx->capturing && (ctx->capture_flags & ZH_CAPTURE_COALESCE) && m->tp_cs2 && end - start <= piece) {
+                struct Pending { NfTpArgs b; uint32_t grid_b; bool zf; };
+                zh_co_batch &cb = ctx->co;
+                std::shared_ptr<Pending> pend = cb.active && cb.owner == m ? std::static_pointer_cast<Pending>(cb.items) : nullptr;
+                const bool chained = pend && chain_n > 0;
+                if (!chained && ctx->epoch_open) zh_epoch_barrier(ctx);                               // (another module's held batch: in order)
+                const uint32_t n = chained ? chain_n : 0u, q = n & 1u;
+                a.start = start; a.end = end; a.C = (end - start + L - 1) / L;
+                if (++m->tp_serial == 0) m->tp_serial = 1;
+                a.serial = m->tp_serial;
+                a.serial_next = m->tp_serial + 1u == 0u ? 1u : m->tp_serial + 1u;
+                a.per = (m->n + 255u) / 256u;
+                a.cs = q ? m->tp_cs2 : m->tp_cs; a.e = q ? m->tp_e2 : m->tp_e; a.flag = q ? m->tp_flag2 : m->tp_flag;
+                a.e_next0 = q ? m->tp_e : m->tp_e2; a.flag_next = q ? m->tp_flag : m->tp_flag2;
+                a.snapshot = n == 0;
+                for (int i = 0; i < 4; i++) { a.s_in[i] = n == 0 ? m->s[i] : m->tp_pred[q ^ 1u][i]; a.pred[i] = m->tp_pred[q][i]; }
+                const uint32_t grid_a = ((a.C + 7u) / 8u) * 8u * a.per, grid_b = 8u * a.C * ((a.per + 7u) / 8u);
+                if (chained) {                                                                          // pass B of paint n - 1 + this paint's pass A
+                    const Pending pb = *pend;
+                    cb.active = false; cb.imgs.clear(); cb.items.reset(); cb.launch = nullptr;        // (taken over: not launched by the flush)
+                    ctx->co_launches++;
+                    if (pb.zf) ZH_LAUNCH(k_nf_tp_ba<true>, dim3(pb.grid_b + grid_a), dim3(256), 0, st, pb.b, a, grid_a);
+                    else ZH_LAUNCH(k_nf_tp_ba<false>, dim3(pb.grid_b + grid_a), dim3(256), 0, st, pb.b, a, grid_a);
+                } else {
+                    ctx->co_launches++;
+                    ZH_LAUNCH(k_nf_tp_a, dim3(grid_a), dim3(256), 0, st, a);
+                }
+                auto np = std::make_shared<Pending>(Pending{a, grid_b, zf});
+                cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = 0; cb.key = 0; cb.flips = false;
+                cb.items = np; cb.imgs.assign(1, out.p);
+                cb.launch = [np](hipStream_t s2, float *const *, uint32_t) {
+                    if (np->zf) ZH_LAUNCH(k_nf_tp_b<true>, dim3(np->grid_b), dim3(256), 0, s2, np->b);
+                    else ZH_LAUNCH(k_nf_tp_b<false>, dim3(np->grid_b), dim3(256), 0, s2, np->b);
+                };
+                ctx->epoch_open = true;
+                ctx->co_paints++;
+                m->pipe_capture = ctx->capture_serial; m->pipe_n = n + 1;
+                return zh_launch_status();
+            }
+            if (ctx->epoch_open) zh_epoch_barrier(ctx);
             for (uint32_t s0 = start; s0 < end; s0 += piece) {
                 a.start = s0; a.end = min(s0 + piece, end);
                 a.C = (a.end - a.start + L - 1) / L;
@@ -1835,6 +1906,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             return zh_launch_status();
         }
     }
+    if (m->ctx->epoch_open) zh_epoch_barrier(m->ctx);                 // an ordered paint: after what was held back
     // up to ZH_NF_PC_MAX voices (default 65,536: measured 75 vs 110 us at 4,096 voices, 111 vs 133 us at 65,536, equal at
     // 131,072) the noise and the filter run in two waves side by side (k_noise_filter_pc); above, one wave does both
     const uint32_t pc_max = (uint32_t)zh_form(ZF_NF_PC_MAX);

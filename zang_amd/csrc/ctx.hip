@@ -112,6 +112,7 @@ int zh_create(zh_ctx **out, int device) {
     c->mix_partials = nullptr;
     c->mix_partials_floats = 0;
     c->capturing = false;
+    c->capture_serial = 0;
     c->noise_jump = nullptr;
     c->capture_flags = 0; c->epoch_open = false; c->co_paints = c->co_launches = 0; c->form_fresh = false;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -252,6 +253,7 @@ int zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags) { ZH_GUARD(ctx);
     if (!ctx || ctx->capturing || (flags & ~(uint32_t)ZH_CAPTURE_COALESCE)) return ZH_ERR_INVALID;
     ZH_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
+    ctx->capture_serial++;
     ctx->capture_flags = flags;
     ctx->capture_log.clear();
     ctx->epoch_open = false;

@@ -267,8 +267,8 @@ __device__ __forceinline__ void noise_tile8(ZXoshiro &r, float (&t)[8], bool &mu
 // every group lands on XCD j % 8 (blocks are dealt round-robin over the eight XCDs): the 32 KiB jump table of a chunk is then read
 // into ONE XCD's L2 instead of all eight (8.4 MB of the 36 MB a buffer moved in round 4, pmc_traffic_noise_filter_fused4096_tolerant
 // .json), and pass B finds the chunk's generator state, which pass A left in that same L2.  (Pink Noise below: the same.)
-template <class A> __device__ __forceinline__ bool nf_tp_block(const A &a, uint32_t &j, uint32_t &g) {
-    const uint32_t id = blockIdx.x, band = id / (8u * a.per), rr = id % (8u * a.per);
+template <class A> __device__ __forceinline__ bool nf_tp_block(const A &a, uint32_t &j, uint32_t &g, uint32_t id = blockIdx.x) {
+    const uint32_t band = id / (8u * a.per), rr = id % (8u * a.per);
     j = band * 8u + (rr & 7u); g = rr >> 3;
     return j < a.C;
 }
@@ -276,8 +276,8 @@ template <class A> __device__ __forceinline__ bool nf_tp_block(const A &a, uint3
 // the e_i of EVERY earlier chunk of its voices: with the groups' chunks on one XCD each 2 KiB block of e is fetched into one L2 once
 // and hit by the other chunks (measured with pass A's mapping in pass B too: 13 MB of reads per buffer instead of 5,
 // profiles/r05/pmc_traffic_noise_filter_fused4096_tolerant.json history in NOTES.md).
-template <class A> __device__ __forceinline__ bool nf_tp_block_b(const A &a, uint32_t &j, uint32_t &g) {
-    const uint32_t id = blockIdx.x, k = id >> 3;
+template <class A> __device__ __forceinline__ bool nf_tp_block_b(const A &a, uint32_t &j, uint32_t &g, uint32_t id = blockIdx.x) {
+    const uint32_t k = id >> 3;
     j = k % a.C; g = (k / a.C) * 8u + (id & 7u);
     return g < a.per;
 }
@@ -287,6 +287,17 @@ template <class A> __device__ __forceinline__ bool nf_tp_block_b(const A &a, uin
 constexpr uint32_t kNfTpMaxChunks = kTpMaxChunks;
 struct NfTpArgs {
     uint64_t *s[4];              // the voices' generator states (Noise.zig:9): read by pass A, written once by pass B
+    // Pipelined recording (composite.hip zh_noise_filter_paint, ZH_CAPTURE_COALESCE): pass A of paint n + 1 runs BESIDE pass B of paint n (k_nf_tp_ba).
+    // It then starts from the generator state pass A of paint n predicted (`s_in`; equal to what pass B writes unless a multi-draw
+    // sample was seen) and leaves its own prediction in `pred`; pass B leaves the filter state for the next paint in the OTHER scratch
+    // set's slot 0 (`e_next0`: pass A of the next paint must not wait for it) and, when it had to walk a voice sequentially, flags that
+    // voice for the next paint as well (`flag_next`, `serial_next`): that paint's pass A has started from a wrong prediction.
+    const uint64_t *s_in[4];     // pass A's start states (== s outside a pipeline)
+    uint64_t *pred[4];           // pass A: the generator state after the span's last draw, or null
+    float2 *e_next0;             // pass B: the next paint's slot 0, or null
+    uint32_t *flag_next;
+    uint32_t serial_next;
+    uint32_t snapshot;           // pass A: copy (l, b) into slot 0 (the first paint of a pipeline, and every paint outside one)
     float *l, *b;                // filter state
     uint64_t *cs;                // scratch [C][4][V]: generator state at the start of chunk j
     float2 *e;                   // scratch [C + 1][V]: slot 0 = the filter state at span start, slot j + 1 = e_j
@@ -302,10 +313,9 @@ struct NfTpArgs {
 };
 
 // block = 256.  Pass A: jump to the chunk's first draw, keep that state, zero-state response.
-__global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
-    __shared__ uint4 tbl[kNoiseJumpEntries];
+__device__ __forceinline__ void nf_tp_a_run(const NfTpArgs &a, uint32_t bid, uint4 *tbl) {
     uint32_t j, g;
-    if (!nf_tp_block(a, j, g)) return;                                // (block-uniform)
+    if (!nf_tp_block(a, j, g, bid)) return;                           // (block-uniform)
     if (j > 0) {
         const uint4 *t = a.tables + (size_t)(j * (a.L / 32) - 1) * kNoiseJumpEntries;
         uint4 w[kNoiseJumpEntries / 256];                             // the thread's eight entries requested together, then parked
@@ -317,12 +327,12 @@ __global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
     }
     const uint32_t v = g * 256 + threadIdx.x;
     if (v >= a.V) return;
-    ZXoshiro r{a.s[0][v], a.s[1][v], a.s[2][v], a.s[3][v]};
+    ZXoshiro r{a.s_in[0][v], a.s_in[1][v], a.s_in[2][v], a.s_in[3][v]};
     if (j > 0) noise_jump_apply(r, tbl);
     const size_t V = a.V;
     uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
     cs[0] = r.s0; cs[V] = r.s1; cs[2 * V] = r.s2; cs[3 * V] = r.s3;
-    if (j == 0) a.e[v] = make_float2(a.l[v], a.b[v]);
+    if (j == 0 && a.snapshot) a.e[v] = make_float2(a.l[v], a.b[v]);
     const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end), nf = f1 - f0;
     const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
     const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
@@ -341,14 +351,19 @@ __global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
     }
     a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
     if (multi) a.flag[v] = a.serial;                                      // (every later chunk of this voice started at the wrong draw)
+    if (a.pred[0] && f1 == a.end && nf > 0) { a.pred[0][v] = r.s0; a.pred[1][v] = r.s1; a.pred[2][v] = r.s2; a.pred[3][v] = r.s3; }
+}
+__global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
+    __shared__ uint4 tbl[kNoiseJumpEntries];
+    nf_tp_a_run(a, blockIdx.x, tbl);
 }
 
 // Pass B, same grid: scan, then the reference's recurrence over the regenerated noise of the chunk.  A flagged voice is painted
 // whole by its chunk-0 lane, sequentially from the module's state -- the reference's own walk, bit for bit.
 template <bool ZF>
-__global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
+__device__ __forceinline__ void nf_tp_b_run(const NfTpArgs &a, uint32_t bid) {
     uint32_t j, g;
-    if (!nf_tp_block_b(a, j, g)) return;
+    if (!nf_tp_block_b(a, j, g, bid)) return;
     const uint32_t v = g * 256 + threadIdx.x;
     if (v >= a.V) return;
     const size_t V = a.V;
@@ -386,6 +401,7 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
     if (!flagged && f1 == a.end && f1 > f0) {                         // whoever painted the span's last frame leaves the states
         a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
         a.l[v] = l; a.b[v] = b;
+        if (a.e_next0) a.e_next0[v] = make_float2(l, b);
     }
     // A flagged voice (one of its draws took Random.float's second draw: every later chunk started at the wrong one) is painted
     // whole by its chunk-0 lane, sequentially from the module's state: the reference's own walk, bit for bit.
@@ -399,8 +415,21 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) {
             }
             a.s[0][v] = r.s0; a.s[1][v] = r.s1; a.s[2][v] = r.s2; a.s[3][v] = r.s3;
             a.l[v] = l; a.b[v] = b;
+            if (a.e_next0) { a.e_next0[v] = make_float2(l, b); a.flag_next[v] = a.serial_next; }
         }
     }
+}
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) { nf_tp_b_run<ZF>(a, blockIdx.x); }
+// Pass B of one paint and pass A of the NEXT in one launch (composite.hip zh_noise_filter_paint, pipelined recording): blocks
+// [0, a_blocks) are pass A's grid (the longer lanes: dispatched first), the rest pass B's -- neither needs anything the other makes
+// (NfTpArgs), so one's launch ramp, table load and jump hide behind the other's frame loops.  a_blocks is a multiple of 8: both keep
+// their block -> XCD mapping.
+template <bool ZF>
+__global__ void __launch_bounds__(256) k_nf_tp_ba(const NfTpArgs b, const NfTpArgs a, uint32_t a_blocks) {
+    __shared__ uint4 tbl[kNoiseJumpEntries];
+    if (blockIdx.x < a_blocks) nf_tp_a_run(a, blockIdx.x, tbl);
+    else nf_tp_b_run<ZF>(b, blockIdx.x - a_blocks);
 }
 #endif   // ZH_FILTER_TP_NOISE
 
