@@ -1867,7 +1867,8 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
                 a.e_next0 = q ? m->tp_e : m->tp_e2; a.flag_next = q ? m->tp_flag : m->tp_flag2;
                 a.snapshot = n == 0;
                 for (int i = 0; i < 4; i++) { a.s_in[i] = n == 0 ? m->s[i] : m->tp_pred[q ^ 1u][i]; a.pred[i] = m->tp_pred[q][i]; }
-                const uint32_t grid_a = ((a.C + 7u) / 8u) * 8u * a.per, grid_b = 8u * a.C * ((a.per + 7u) / 8u);
+                const uint32_t Ca = (a.C + kNfTpFusedSub - 1) / kNfTpFusedSub;                       // pass A's slots in the shared launch
+                const uint32_t grid_a1 = ((a.C + 7u) / 8u) * 8u * a.per, grid_a = ((Ca + 7u) / 8u) * 8u * a.per, grid_b = 8u * a.C * ((a.per + 7u) / 8u);
                 if (chained) {                                                                          // pass B of paint n - 1 + this paint's pass A
                     const Pending pb = *pend;
                     cb.active = false; cb.imgs.clear(); cb.items.reset(); cb.launch = nullptr;        // (taken over: not launched by the flush)
@@ -1876,7 +1877,7 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
                     else ZH_LAUNCH(k_nf_tp_ba<false>, dim3(pb.grid_b + grid_a), dim3(256), 0, st, pb.b, a, grid_a);
                 } else {
                     ctx->co_launches++;
-                    ZH_LAUNCH(k_nf_tp_a, dim3(grid_a), dim3(256), 0, st, a);
+                    ZH_LAUNCH(k_nf_tp_a, dim3(grid_a1), dim3(256), 0, st, a);
                 }
                 auto np = std::make_shared<Pending>(Pending{a, grid_b, zf});
                 cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = 0; cb.key = 0; cb.flips = false;

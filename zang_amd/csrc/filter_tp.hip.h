@@ -285,6 +285,7 @@ template <class A> __device__ __forceinline__ bool nf_tp_block_b(const A &a, uin
 // ---------------------------------------------------------------------------------------------------- white Noise -> Filter
 #if defined(ZH_FILTER_TP_NOISE)          // (composite.hip only: the kernels below are not templates)
 constexpr uint32_t kNfTpMaxChunks = kTpMaxChunks;
+constexpr uint32_t kNfTpFusedSub = 2;   // chunks per pass-A lane in k_nf_tp_ba
 struct NfTpArgs {
     uint64_t *s[4];              // the voices' generator states (Noise.zig:9): read by pass A, written once by pass B
     // Pipelined recording (composite.hip zh_noise_filter_paint, ZH_CAPTURE_COALESCE): pass A of paint n + 1 runs BESIDE pass B of paint n (k_nf_tp_ba).
@@ -307,15 +308,24 @@ struct NfTpArgs {
                                  // voice sequentially -- the exact path -- once more)
     const uint4 *tables;         // T^(32 k), k = 1..63
     uint32_t V, start, end, L, C, per;   // per = 256-voice groups
+    struct Slots { uint32_t C, per; };   // (what nf_tp_block maps a block id over: pass A of the shared launch has C / SUB slots)
     Img out;
     float l_mul, b_mul, h_mul;
     F32P cutoff, res;
 };
 
 // block = 256.  Pass A: jump to the chunk's first draw, keep that state, zero-state response.
+// SUB chunks per lane, one after the other (the generator simply runs on; the zero-state response restarts): in the launch shared with pass B
+// (k_nf_tp_ba) the chip is full either way, and two chunks per lane halve the table loads and jumps -- ~950 instructions per lane
+// against 1,440 for a chunk's 32 frames.
+template <uint32_t SUB>
 __device__ __forceinline__ void nf_tp_a_run(const NfTpArgs &a, uint32_t bid, uint4 *tbl) {
-    uint32_t j, g;
-    if (!nf_tp_block(a, j, g, bid)) return;                           // (block-uniform)
+    uint32_t jp, g;
+    {
+        NfTpArgs::Slots sl{(a.C + SUB - 1) / SUB, a.per};
+        if (!nf_tp_block(sl, jp, g, bid)) return;                     // (block-uniform)
+    }
+    uint32_t j = jp * SUB;
     if (j > 0) {
         const uint4 *t = a.tables + (size_t)(j * (a.L / 32) - 1) * kNoiseJumpEntries;
         uint4 w[kNoiseJumpEntries / 256];                             // the thread's eight entries requested together, then parked
@@ -330,32 +340,36 @@ __device__ __forceinline__ void nf_tp_a_run(const NfTpArgs &a, uint32_t bid, uin
     ZXoshiro r{a.s_in[0][v], a.s_in[1][v], a.s_in[2][v], a.s_in[3][v]};
     if (j > 0) noise_jump_apply(r, tbl);
     const size_t V = a.V;
-    uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
-    cs[0] = r.s0; cs[V] = r.s1; cs[2 * V] = r.s2; cs[3 * V] = r.s3;
     if (j == 0 && a.snapshot) a.e[v] = make_float2(a.l[v], a.b[v]);
-    const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end), nf = f1 - f0;
     const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);           // Filter.zig:114
     const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);       // :118
-    float l = 0.0f, b = 0.0f;
     bool multi = false;
-    uint32_t k = 0;
-    for (; k + 8 <= nf; k += 8) {
-        float t[8];
-        noise_tile8(r, t, multi);                                     // zero(temp); temp += noise
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) svf_step(l, b, t[q], cut, res);   // Filter.zig:135-144
+    for (uint32_t sub = 0; sub < SUB; sub++, j++) {
+        if (j >= a.C) break;                                          // (block-uniform)
+        uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
+        cs[0] = r.s0; cs[V] = r.s1; cs[2 * V] = r.s2; cs[3 * V] = r.s3;
+        const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end), nf = f1 - f0;
+        float l = 0.0f, b = 0.0f;
+        uint32_t k = 0;
+        for (; k + 8 <= nf; k += 8) {
+            float t[8];
+            noise_tile8(r, t, multi);                                 // zero(temp); temp += noise
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) svf_step(l, b, t[q], cut, res);   // Filter.zig:135-144
+        }
+        for (; k < nf; k++) {
+            const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
+            svf_step(l, b, 0.0f + white, cut, res);
+        }
+        a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
+        if (a.pred[0] && f1 == a.end && nf > 0) { a.pred[0][v] = r.s0; a.pred[1][v] = r.s1; a.pred[2][v] = r.s2; a.pred[3][v] = r.s3; }
     }
-    for (; k < nf; k++) {
-        const float white = zrandom_float32_multi(r, multi) * 2.0f - 1.0f;
-        svf_step(l, b, 0.0f + white, cut, res);
-    }
-    a.e[(size_t)(j + 1) * V + v] = make_float2(l, b);
-    if (multi) a.flag[v] = a.serial;                                      // (every later chunk of this voice started at the wrong draw)
-    if (a.pred[0] && f1 == a.end && nf > 0) { a.pred[0][v] = r.s0; a.pred[1][v] = r.s1; a.pred[2][v] = r.s2; a.pred[3][v] = r.s3; }
+    if (multi) a.flag[v] = a.serial;                                  // (every later chunk of this voice started at the wrong draw)
 }
 __global__ void __launch_bounds__(256) k_nf_tp_a(const NfTpArgs a) {
     __shared__ uint4 tbl[kNoiseJumpEntries];
-    nf_tp_a_run(a, blockIdx.x, tbl);
+    nf_tp_a_run<1>(a, blockIdx.x, tbl);
 }
 
 // Pass B, same grid: scan, then the reference's recurrence over the regenerated noise of the chunk.  A flagged voice is painted
@@ -428,7 +442,7 @@ __global__ void __launch_bounds__(256) k_nf_tp_b(const NfTpArgs a) { nf_tp_b_run
 template <bool ZF>
 __global__ void __launch_bounds__(256) k_nf_tp_ba(const NfTpArgs b, const NfTpArgs a, uint32_t a_blocks) {
     __shared__ uint4 tbl[kNoiseJumpEntries];
-    if (blockIdx.x < a_blocks) nf_tp_a_run(a, blockIdx.x, tbl);
+    if (blockIdx.x < a_blocks) nf_tp_a_run<kNfTpFusedSub>(a, blockIdx.x, tbl);
     else nf_tp_b_run<ZF>(b, blockIdx.x - a_blocks);
 }
 #endif   // ZH_FILTER_TP_NOISE
