@@ -187,7 +187,7 @@ ZH_API int  zh_graph_begin_capture(zh_ctx *ctx);
  * is reserved by every eager stereo mixdown paint, i.e. by the eager pass a host makes before recording anyway.
  * And PIPELINED: consecutive zh_noise_filter_paint calls flagged ZH_PAINT_TOLERANT (white noise, the two-pass form, one piece each) are
  * recorded so that the second pass of paint n and the first pass of paint n + 1 are ONE launch (the first pass of a paint needs nothing
- * the second pass of the paint before it makes: it starts from the generator state the previous first pass predicted).  17.9 against
+ * the second pass of the paint before it makes: it starts from the generator state the previous first pass predicted).  16 against
  * 20.5 us per buffer at 4,096 voices; the values are those of the paints recorded one after the other, except that a voice that met one
  * of Random.float's multi-draw samples (2^-41 per sample) is walked sequentially -- the reference's exact walk -- in every later paint
  * of the chain (profiles/r05/probe_overlap_nf.txt).
