@@ -699,6 +699,14 @@ ZH_API void zh_zscript_free_text(char *text);
 ZH_API int zh_zscript_generate_zig(zh_zscript *z, char **text_out);
 /* only_csv: comma-separated exported module names, NULL = all; unroll: frames per unrolled chunk, 0 = automatic */
 ZH_API int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unroll, char **text_out);
+/* The same with more kernel forms per module.  ZH_ZSCRIPT_FORM_ROLES: next to zs_paint_<name> (one wave per 64 voices, the
+ * whole frame body in every lane) a zs_paint_pc_<name> for FEW voices -- one workgroup of several waves per 64 voices, the
+ * body's builtin calls (codegen.zig:70-121: the instruction list being scheduled) dealt to producer / recurrence / writer
+ * waves that hand values on through LDS tiles, as the hand-written composites do (examples/modules.zig:130-187 is the
+ * acceptance recipe).  Same operations on the same values in the same order: same bits.  zh_script_module_paint picks
+ * the form (dispatch table rows script_pc / script_pc_maxv). */
+#define ZH_ZSCRIPT_FORM_ROLES 1u
+ZH_API int zh_zscript_generate_hip_forms(zh_zscript *z, const char *only_csv, int unroll, uint32_t forms, char **text_out);
 /* per module of the last zh_zscript_generate_hip: what zh_script_module_create / _paint need */
 ZH_API uint32_t zh_zscript_module_count(zh_zscript *z);
 ZH_API int zh_zscript_module_info(zh_zscript *z, uint32_t i, char *name, size_t name_cap, uint32_t *state_words, uint32_t *noise_fields,

@@ -252,14 +252,15 @@ def _device_value(value):
     return value
 
 
-def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, worst=None):
+def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, worst=None, roles=None):
     """One generated module, `buffers` consecutive buffers of random paints; raises AssertionError with the script text on
     a mismatch.  `ranges`: ZH_SCRIPT_RANGES for the case (the library reads it per paint under ZH_ENV_LIVE=1) -- with
     F >= 128 the kernels that allow it are launched as that many frame ranges.  `text`: a given script (module `Main` with
     the generator's params) instead of the generated one; `seed` then only picks the paints.  Returns the script text.
     `tolerant`: paint with ZH_PAINT_TOLERANT and ask, per voice and buffer, for every sample within 1e-5 of the largest of the voice's peak, its inputs' magnitudes and 1
     and the same finite / non-finite pattern instead of bits (kernels without a tolerant sine still answer bit for bit); `worst`
-    (a one-element list) collects the largest ratio seen."""
+    (a one-element list) collects the largest ratio seen.  `roles`: 1 = every paint through the role-wave form (zs_paint_pc_<name>,
+    dispatch row script_pc), 0 = never; the kernels that ran are checked through zh_last_form."""
     import os
     import torch
     from oracle import zangscript as zs
@@ -269,9 +270,15 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, 
     text, name = generate(seed) if text is None else (text, "Main")
     from tests import util
     old = os.environ.get("ZH_FORMS")
+    rows = {}
     if ranges is not None:
-        os.environ["ZH_FORMS"] = util.forms_env(script_ranges=ranges)["ZH_FORMS"]
+        rows["script_ranges"] = ranges
+    if roles is not None:
+        rows["script_pc"] = roles
+    if rows:
+        os.environ["ZH_FORMS"] = util.forms_env(**rows)["ZH_FORMS"]
     prog = script.ScriptProgram(text, ctx, only=[name])
+    has_roles = ("zs_paint_pc_" + name) in prog.hip_source
     try:
         mod = prog.module(name, V, seed)
         voices = zs_interp.make_voices(zs.compile(text, "fuzz"), name, V, seed)
@@ -291,6 +298,9 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, 
                 dev = {kk: _device_value(vv) for kk, vv in params.items() if kk in order}
                 nic_dev = torch.from_numpy(nic.astype(np.uint8)).cuda() if isinstance(nic, np.ndarray) else nic
                 mod.paint(zang.Span(start, end), [img], None, nic_dev, dev, tolerant=tolerant)
+                if roles is not None:
+                    ran = ctx.last_form()
+                    assert any("zs_paint_pc_" in kname for kname in ran) == bool(roles and has_roles), (roles, has_roles, ran)
                 for v in range(V):
                     voices[v].paint(start, end, ref[v], bool(nic[v]) if isinstance(nic, np.ndarray) else nic,
                                     [_per_voice(params[kk], v) for kk in order])
@@ -319,7 +329,7 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, 
                                         v0, f0, got[v0, f0], ref[v0, f0], text))
     finally:
         prog.close()
-        if ranges is not None:
+        if rows:
             if old is None:
                 del os.environ["ZH_FORMS"]
             else:

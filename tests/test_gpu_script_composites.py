@@ -43,14 +43,25 @@ def _note_script(rng, V, buffers):
     return out
 
 
+def _check_form(ctx, roles, name):
+    """the kernel the last paint launched is the form the case asked for (zh_last_form)"""
+    ran = ctx.last_form()
+    if roles is not None:
+        assert any(k == "zs_paint_pc_" + name for k in ran) == bool(roles), (roles, ran)
+
+
+# roles: the role-wave form of the generated kernel (zs_paint_pc_<name>) forced on (1), off (0), or the library's own choice
+@pytest.mark.parametrize("roles", [None, 0, 1])
 @pytest.mark.parametrize("zero_first", [True, False])
 @pytest.mark.parametrize("freq_kind", ["constant", "buffer"])
 @pytest.mark.parametrize("V", [4096, 131072])
-def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(ctx, oracle, V, freq_kind, zero_first):
-    if V == 131072 and (freq_kind == "buffer") != zero_first:
-        pytest.skip("at 131,072 voices: constant + live output and buffer + zeroed output (two 512 MiB images per case)")
+def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(ctx, oracle, monkeypatch, V, freq_kind, zero_first, roles):
+    if V == 131072 and ((freq_kind == "buffer") != zero_first or roles is not None):
+        pytest.skip("at 131,072 voices: constant + live output and buffer + zeroed output (two 512 MiB images per case), the library's own form")
     import torch
     from zang_amd import script, zang
+    if roles is not None:
+        util.set_form(monkeypatch, script_pc=roles)
     rng = np.random.default_rng(V + (7 if freq_kind == "buffer" else 0))
     L = oracle.lib()
     idx = _voices(V)
@@ -89,6 +100,7 @@ def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(
             m.paint(zang.Span(s, e), [out], None, torch.from_numpy(nic.astype(np.uint8)).to(ctx.device),
                     {"sample_rate": SR, "freq": fimg if freq_kind == "buffer" else gfreq, "note_on": torch.from_numpy(on.astype(np.uint8)).to(ctx.device),
                      "cutoff": cutoff}, zero_first=zero_first)
+            _check_form(ctx, roles, name)
         ctx.sync()
         got = out[:, torch.from_numpy(idx).to(ctx.device)].cpu().numpy().T
         util.assert_bitexact(np.ascontiguousarray(got), ref, f"FilteredSawtooth V={V} freq {freq_kind} zf={zero_first} buffer {b}")
@@ -96,11 +108,16 @@ def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(
     prog.close()
 
 
+@pytest.mark.parametrize("roles", [None, 1])
 @pytest.mark.parametrize("zero_first", [True, False])
 @pytest.mark.parametrize("V", [4096, 131072])
-def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, oracle, V, zero_first):
+def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, oracle, monkeypatch, V, zero_first, roles):
+    if V == 131072 and roles is not None:
+        pytest.skip("at 131,072 voices: the library's own form")
     import torch
     from zang_amd import script, zang
+    if roles is not None:
+        util.set_form(monkeypatch, script_pc=roles)
     rng = np.random.default_rng(V + 1)
     L = oracle.lib()
     idx = _voices(V)
@@ -130,6 +147,7 @@ def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, o
                 L.zo_hard_square_paint(C.byref(insts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(t0), oracle.fptr(t1), int(nic[v]), SR, float(freq[v]), int(on[v]))
             m.paint(zang.Span(s, e), [out], None, torch.from_numpy(nic.astype(np.uint8)).to(ctx.device),
                     {"sample_rate": SR, "freq": gfreq, "note_on": torch.from_numpy(on.astype(np.uint8)).to(ctx.device)}, zero_first=zero_first)
+            _check_form(ctx, roles, "HardSquare")
         ctx.sync()
         got = out[:, sel].cpu().numpy().T
         util.assert_bitexact(np.ascontiguousarray(got), ref, f"HardSquare V={V} zf={zero_first} buffer {b}")

@@ -42,6 +42,15 @@ def test_gpu_random_script_parity_as_frame_ranges(ctx, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(20, 44))
+def test_gpu_random_script_parity_role_waves(ctx, seed):
+    """Every paint forced through the role-wave form (zs_paint_pc_<name>: the body's units dealt to producer / recurrence /
+    writer waves, values handed on through LDS tiles): spans shorter than a tile, partial last tiles, live and zeroed output,
+    input images, delays and nested modules as the generator makes them; 96- and 256-frame buffers."""
+    script_fuzz.run_case(ctx, seed, roles=1, F=96 if seed % 2 else 256)
+
+
+@pytest.mark.gpu
 def test_gpu_seed_1015_select_hazard(ctx):
     """The case that exposed the inline-asm v_cndmask of round 2 (lanes.hip.h zsel_hard): with a literal TriSawOsc color its
     `"s"(ballot(true))` operand became the EXEC register itself in one place, and a v_cndmask_b32_e64 with EXEC as its mask

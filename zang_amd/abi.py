@@ -396,6 +396,7 @@ SIGNATURES = {
     "zh_zscript_free_text": (None, [vp]),
     "zh_zscript_generate_zig": (C.c_int, [vp, P(vp)]),
     "zh_zscript_generate_hip": (C.c_int, [vp, C.c_char_p, C.c_int, P(vp)]),
+    "zh_zscript_generate_hip_forms": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_uint32, P(vp)]),
     "zh_zscript_module_count": (u32, [vp]),
     "zh_zscript_module_info": (C.c_int, [vp, u32, C.c_char_p, C.c_size_t, P(u32), P(u32), P(u32), C.c_char_p, C.c_size_t]),
     "zh_zscript_module_param": (C.c_int, [vp, u32, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),

@@ -217,4 +217,155 @@ __device__ __forceinline__ void zs_frame_loop(float *__restrict__ out, uint32_t 
                                               const size_t *istride, const uint32_t *ivoff, uint32_t start, uint32_t end, bool zf, bool &walk, F &&f) {
     zs_frame_loop<CH, NIN>(out, v, ostride, in, istride, ivoff, start, end, zf, walk, f, [](int) { return false; }, f);
 }
+// ---- the role-wave form of a generated kernel (zs_paint_pc_<name>; zscript_emit.hip plan_roles) -------------------------
+// Few voices: one workgroup of several waves owns 64 voices, and the frame body's units (builtin modules, arithmetic)
+// are dealt to ROLES -- waves that each run their own part of every frame and hand values on through LDS tiles, float4 =
+// four frames of a lane side by side ([frame / 4][lane]), CH frames per tile.  Role r works on tile (step - lag(r)); one
+// barrier per step; a value handed from role a to role b lives in lag(b) - lag(a) + 1 tile buffers.  The loader roles fetch the
+// input rows (and the live output rows of a paint without ZH_PAINT_ZERO_FIRST) one tile ahead, the writer role -- the
+// last -- owns `o`: every `+=` into the output in the order the script gives, then the row store.  Lanes past the last voice
+// run voice V - 1 again (same loads, same values, same address), so nothing inside a chain is masked.
+// Same per-voice operations on the same values in the same order as the lane form => same bits.
+struct ZsTileRef { uint32_t off, depth; };     // off: float4 index of buffer 0 in the workgroup's LDS; a buffer = [CH / 4][64] float4
+
+__device__ __forceinline__ float &zs_comp(float4 &q, int k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
+__device__ __forceinline__ float zs_comp(const float4 &q, int k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
+
+// the pipeline of one role: f / fq(frame, zin[NIN], zout[NOUT], o&) -- fq where quiet(4) holds for the next four frames.
+// WR: the writer role -- `o` starts as 0 (zf) or as the LAST input tile's value (the live output row the loader fetched),
+// and is stored to the output image after the frame.
+// K > 1: the role runs in K waves (`rep` = 0 .. K - 1) that each compute the values of every K-th group of four frames and only
+// WALK the others -- the body with its results dropped, of which the compiler keeps what carries state (a phase counter's add,
+// an envelope's clock), like the replay of a frame range (zs_frame_loop).  The emitter replicates only roles whose walk is cheap.
+template <int CH_, int NIN, int NOUT, int UQ, bool WR, int K, class F, class QT, class FQ>
+__device__ __forceinline__ void zs_role_run(float4 *lds, uint32_t lane, uint32_t lag, uint32_t rep, uint32_t steps, uint32_t start, uint32_t n_frames,
+                                            const ZsTileRef *tin, const ZsTileRef *tout, float *__restrict__ out, size_t ostride, uint32_t voff, bool zf,
+                                            F &&f, QT &&quiet, FQ &&fq) {
+    constexpr uint32_t CH = CH_, Q = CH / 4, TILE = Q * 64;
+    constexpr int NI = NIN > 0 ? NIN : 1, NO = NOUT > 0 ? NOUT : 1;
+    const uint32_t nchunks = (n_frames + CH - 1) / CH;
+    const uint32_t orow = (uint32_t)ostride * 4u;
+    uint32_t bi[NI], bo[NO];
+#pragma unroll
+    for (int j = 0; j < NI; j++) bi[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NO; j++) bo[j] = 0;
+    for (uint32_t c = 0; c < steps; c++) {
+        if (c >= lag && c - lag < nchunks) {
+            const uint32_t d = c - lag, nf = min(CH, n_frames - d * CH), base = start + d * CH;
+            const float4 *ti[NI];
+            float4 *to[NO];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) ti[j] = lds + tin[j].off + bi[j] * TILE + lane;
+#pragma unroll
+            for (int j = 0; j < NOUT; j++) to[j] = lds + tout[j].off + bo[j] * TILE + lane;
+            if (nf == CH) {
+                float4 a[NI];
+#pragma unroll
+                for (int j = 0; j < NIN; j++) a[j] = ti[j][0];
+#pragma unroll UQ
+                for (uint32_t q = 0; q < Q; q++) {
+                    float4 an[NI];                                    // the next four frames' values: fetched while these compute
+                    if (q + 1 < Q) {
+#pragma unroll
+                        for (int j = 0; j < NIN; j++) an[j] = ti[j][(q + 1) * 64];
+                    }
+                    float4 b[NO];
+                    float o4[4];
+                    auto quad = [&](auto &&g, auto keep) ZH_INLINE_LAMBDA {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float zi[NI], zo[NO];
+#pragma unroll
+                            for (int j = 0; j < NIN; j++) zi[j] = zs_comp(a[j], k);
+                            o4[k] = (WR && !zf) ? zi[NI - 1] : 0.0f;
+                            g(base + 4 * q + k, zi, zo, o4[k]);
+                            if constexpr (decltype(keep)::value) {
+#pragma unroll
+                                for (int j = 0; j < NOUT; j++) zs_comp(b[j], k) = zo[j];
+                            }
+                        }
+                    };
+                    if (K == 1 || q % K == rep) {
+                        if (quiet(4)) quad(fq, zs_tag<true>{}); else quad(f, zs_tag<true>{});
+#pragma unroll
+                        for (int j = 0; j < NOUT; j++) to[j][q * 64] = b[j];
+                    } else {
+                        if (quiet(4)) quad(fq, zs_tag<false>{}); else quad(f, zs_tag<false>{});
+                    }
+                    if (WR) {
+                        const zh_rsrc_t ro = zrow_rsrc(out, ostride, base + 4 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) zrow_store<1>(ro, voff, k * orow, o4[k]);
+                    }
+                    if (q + 1 < Q) {
+#pragma unroll
+                        for (int j = 0; j < NIN; j++) a[j] = an[j];
+                    }
+                }
+            } else {                                                  // the span's last, partial tile: frame by frame
+                for (uint32_t k = 0; k < nf; k++) {
+                    float zi[NI], zo[NO];
+#pragma unroll
+                    for (int j = 0; j < NIN; j++) zi[j] = reinterpret_cast<const float *>(&ti[j][(k >> 2) * 64])[k & 3];
+                    float o = (WR && !zf) ? zi[NI - 1] : 0.0f;
+                    f(base + k, zi, zo, o);
+                    if (K == 1 || rep == 0) {                          // (the partial tile is replica 0's)
+#pragma unroll
+                        for (int j = 0; j < NOUT; j++) reinterpret_cast<float *>(&to[j][(k >> 2) * 64])[k & 3] = zo[j];
+                    }
+                    if (WR) zrow_store<1>(zrow_rsrc(out, ostride, base + k), voff, 0, o);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NIN; j++) bi[j] = bi[j] + 1 == tin[j].depth ? 0 : bi[j] + 1;
+#pragma unroll
+            for (int j = 0; j < NOUT; j++) bo[j] = bo[j] + 1 == tout[j].depth ? 0 : bo[j] + 1;
+        }
+        __syncthreads();
+    }
+}
+
+// A loader role: NR image rows per frame -- input images of the script module's params, or the live output image -- into
+// their tiles, one tile ahead of the step that publishes it: source j publishes tile d in step d + lag[j] (one step before its first
+// reader) and requests tile d + 1 in that same step.  A row source with stride 0 (a constant's dummy row, a zeroed output) is
+// neither loaded nor written: its readers select the constant / start from 0 and discard what the tile holds.
+template <int CH_, int NR>
+__device__ __forceinline__ void zs_loader_run(float4 *lds, uint32_t lane, uint32_t steps, uint32_t start, uint32_t n_frames, const ZsTileRef *tout,
+                                              const float *const *src, const size_t *stride, const uint32_t *voff, const uint32_t *lag) {
+    constexpr uint32_t CH = CH_, Q = CH / 4, TILE = Q * 64;
+    const uint32_t nchunks = (n_frames + CH - 1) / CH;
+    float r[NR][CH];
+    uint32_t bo[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) bo[j] = 0;
+    auto request = [&](int j, uint32_t d) ZH_INLINE_LAMBDA {
+        if (stride[j] == 0) return;                                   // (kernel-uniform)
+        const uint32_t nf = min(CH, n_frames - d * CH), base = start + d * CH;
+        const zh_rsrc_t ri = zrow_rsrc(src[j], stride[j], base);
+        const uint32_t irow = (uint32_t)stride[j] * 4u;
+        if (nf == CH) {
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) r[j][k] = zrow_load<1>(ri, voff[j], k * irow);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < CH; k++) r[j][k] = k < nf ? zrow_load<1>(ri, voff[j], k * irow) : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NR; j++) if (lag[j] == 0 && nchunks > 0) request(j, 0);
+    for (uint32_t c = 0; c < steps; c++) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            if (c >= lag[j] && c - lag[j] < nchunks && stride[j] != 0) {
+                float4 *t = lds + tout[j].off + bo[j] * TILE + lane;
+#pragma unroll
+                for (uint32_t q = 0; q < Q; q++) t[q * 64] = make_float4(r[j][4 * q], r[j][4 * q + 1], r[j][4 * q + 2], r[j][4 * q + 3]);
+                bo[j] = bo[j] + 1 == tout[j].depth ? 0 : bo[j] + 1;
+            }
+            if (c + 1 >= lag[j] && c + 1 - lag[j] < nchunks) request(j, c + 1 - lag[j]);
+        }
+        __syncthreads();
+    }
+}
 #endif

@@ -140,6 +140,6 @@ std::unique_ptr<CompiledScript> compile(const std::string &contents, const std::
 std::string generate_zig(const CompiledScript &cs);
 struct HipParam { std::string name, kind, enum_name; };
 struct HipModuleMeta { std::string name, error; size_t state_words = 0, noise_fields = 0, num_temps = 0; std::vector<HipParam> params; };
-std::string generate_hip(const CompiledScript &cs, const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override);
+std::string generate_hip(const CompiledScript &cs, const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override, unsigned forms = 0);
 
 }  // namespace zs

@@ -11,6 +11,7 @@
 
 #include "../../include/zang_hip.h"
 #include "zscript.hpp"
+#include <algorithm>
 #include <regex>
 
 namespace zs {
@@ -364,10 +365,43 @@ const size_t kTrackWords = 3;                                       // NoteTrack
 
 struct InitItem { bool noise; size_t word; size_t k; float value; };
 
+// One step of the frame body as the role-wave form deals it out (plan_roles below): a builtin's frame, one arithmetic
+// instruction, or a whole delay / track construct (opaque).  `text` is what the lane form's body holds for it.
+struct Unit {
+    Lines text;
+    Lines body;                    // role form, for a unit that ends in a plain add into the output: the same without that add ...
+    std::string zo, zp;            // ... its value and (builtins that can paint nothing) its painted flag go to the writer role in these
+    bool opaque = false;           // a delay / track construct: conditionals around inner units, taken whole
+    bool stateful = false;         // owns frame-to-frame state (a lane object, a ring, a track): lives in exactly one role
+    int cost = 1;                  // ~VALU instructions per frame
+    int walk = 0;                  // ... of which carry state from frame to frame (what a frame whose value nobody wants still costs)
+    std::vector<size_t> ends, stores, quiets;   // the lines of Kernel::epi_ends / epi_stores / quiet_terms that belong to it
+};
+struct Mark { size_t ends, stores, quiets, units, frame; };
+
 struct Kernel {
     std::string name;
     std::vector<HipParam> params;
     Lines pro, frame, epi_ends, epi_stores;
+    std::vector<Unit> units;       // the frame body again, unit by unit (k.frame == the units' texts in order)
+    Mark mark() const { return Mark{epi_ends.size(), epi_stores.size(), quiet_terms.size(), units.size(), frame.size()}; }
+    void unit_done(const Mark &m, Unit u) {
+        for (size_t i = m.ends; i < epi_ends.size(); i++) u.ends.push_back(i);
+        for (size_t i = m.stores; i < epi_stores.size(); i++) u.stores.push_back(i);
+        for (size_t i = m.quiets; i < quiet_terms.size(); i++) u.quiets.push_back(i);
+        units.push_back(std::move(u));
+    }
+    // the units made since `m` (the inside of a delay / track construct) become one opaque unit: everything appended to `frame` since
+    void collapse(const Mark &m) {
+        Unit u;
+        u.opaque = u.stateful = true;
+        u.cost = 4;
+        for (size_t i = m.units; i < units.size(); i++) u.cost += units[i].cost;
+        u.walk = u.cost;
+        units.resize(m.units);
+        u.text.assign(frame.begin() + (long)m.frame, frame.end());
+        unit_done(m, std::move(u));
+    }
     std::vector<InitItem> init;
     std::set<size_t> tracks;
     Lines temps;
@@ -483,7 +517,7 @@ public:
         return v.tag;
     }
     static std::string enum_payload(const Val &v) { return v.payload ? v.payload->expr : "0.0f"; }
-    static Lines put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy = false, uint64_t sines = 0) {
+    static Lines put_lines(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy, uint64_t sines) {
         if (!d.output) {
             mc.heavy[d.index] = heavy;
             mc.srcs[d.index] = sines;
@@ -494,6 +528,28 @@ public:
         }
         mc.outsines |= sines;
         return {mc.outvar + " = " + mc.outvar + " + (" + expr + ");"};
+    }
+    // one arithmetic / copy instruction into the frame body, and its unit (`cost`: ~VALU instructions of `expr`)
+    static void put(ModuleCtx &mc, const Dest &d, const std::string &expr, bool zero_first, bool heavy = false, uint64_t sines = 0, int cost = 1) {
+        Kernel &k = mc.k;
+        const Mark mk = k.mark();
+        Unit u;
+        u.text = put_lines(mc, d, expr, zero_first, heavy, sines);
+        u.cost = cost + (zero_first ? 1 : 0);
+        if (d.output && mc.outvar == "o") {                           // `o = o + (expr);`: the value travels, the add is the writer's
+            u.zo = k.fresh("zo");
+            u.body = {u.zo + " = " + expr + ";"};
+        }
+        append(k.frame, u.text);
+        k.unit_done(mk, std::move(u));
+    }
+    static int op_cost(const std::string &op) {                     // ~VALU instructions (zmath.hip.h)
+        if (op == "sin" || op == "cos") return 36;
+        if (op == "pow") return 90;
+        if (op == "div") return 10;
+        if (op == "sqrt") return 8;
+        if (op == "max" || op == "min") return 2;
+        return 1;
     }
     static std::string un(const std::string &op, const std::string &a) {
         if (op == "abs") return "fabsf(" + a + ")";
@@ -514,6 +570,7 @@ public:
 
     void call_builtin(ModuleCtx &mc, const Instr &ins, const Module &callee, const std::vector<Res> &args) {
         Kernel &k = mc.k;
+        const Mark mk = k.mark();
         const std::string &name = callee.builtin_name;
         std::map<std::string, Val> a;
         for (size_t i = 0; i < callee.params.size(); i++) a[callee.params[i].name] = val(mc, args[i]);
@@ -705,10 +762,45 @@ public:
             target = mc.outvar;
         }
         const std::string addl = target + " = " + target + " + (" + value + ");";
+        Unit u;
+        u.stateful = state_words(name) > 0;
+        u.cost = builtin_cost(name, a, u.walk);
+        if (target == "o") {                                         // the role form: value and painted flag travel, the add is the writer's
+            u.zo = k.fresh("zo");
+            Lines body = frame;
+            body.push_back(u.zo + " = " + value + ";");
+            if (!painted.empty()) {
+                u.zp = k.fresh("zp");
+                body.push_back(u.zp + " = (" + painted + ") ? 1.0f : 0.0f;");
+            }
+            u.body.push_back("{");
+            append(u.body, indent(body));
+            u.body.push_back("}");
+        }
         frame.push_back(painted.empty() ? addl : "if (" + painted + ") " + addl);
-        k.frame.push_back("{");
-        append(k.frame, indent(frame));
-        k.frame.push_back("}");
+        u.text.push_back("{");
+        append(u.text, indent(frame));
+        u.text.push_back("}");
+        append(k.frame, u.text);
+        k.unit_done(mk, std::move(u));
+    }
+    // ~VALU instructions of one frame of a builtin as a lone wave's role compiles it (tools/isa_loopstat.py style counts of generated
+    // role kernels: TriSawOsc 42, Filter 21, Envelope 13 quiet / 39 around a stage end); `walk` = the part that carries its state
+    static int builtin_cost(const std::string &name, std::map<std::string, Val> &a, int &walk) {
+        auto is_buf = [&](const char *p) { auto it = a.find(p); return it != a.end() && it->second.kind == Val::buf; };
+        auto ret = [&](int cost, int w) { walk = w; return cost; };
+        if (name == "SineOsc") return is_buf("freq") ? ret(42, 3) : ret(40, 2);
+        if (name == "PulseOsc") return is_buf("freq") ? ret(34, 34) : ret(16, 2);
+        if (name == "TriSawOsc") return is_buf("freq") ? ret(24, 12) : ret(42, 2);
+        if (name == "Noise") return a["color"].tag_literal && a["color"].tag == "white" ? ret(24, 20) : ret(44, 20);
+        if (name == "Envelope") return ret(22, 14);
+        if (name == "Filter") { const int c = 21 + (is_buf("cutoff") ? 3 : 0) + (is_buf("res") ? 4 : 0); return ret(c, c); }
+        if (name == "Decimator") return ret(8, 8);
+        if (name == "Distortion") return a["type"].tag_literal && a["type"].tag == "clip" ? ret(6, 0) : ret(40, 0);
+        if (name == "Portamento") return ret(14, 9);
+        if (name == "Curve") return ret(10, 4);
+        if (name == "Cycle") return ret(5, 5);
+        return ret(2, 0);                                            // Gate
     }
 
     void instruction(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
@@ -716,14 +808,14 @@ public:
         switch (ins.kind) {
         case IK::copy_buffer: {
             const Val src = val(mc, ins.src);
-            append(k.frame, put(mc, ins.out, src.expr, false, src.computed, src.sines));
+            put(mc, ins.out, src.expr, false, src.computed, src.sines);
             if (!ins.out.output && !src.cob_b.empty()) mc.cobsrc[ins.out.index] = {src.cob_b, src.cob_c};
             break;
         }
-        case IK::float_to_buffer: append(k.frame, put(mc, ins.out, val(mc, ins.src).expr, false)); break;
+        case IK::float_to_buffer: put(mc, ins.out, val(mc, ins.src).expr, false); break;
         case IK::cob_to_buffer: {
             const Val &src = mc.env[ins.in_self_param];
-            append(k.frame, put(mc, ins.out, src.expr, false, src.computed, src.sines));
+            put(mc, ins.out, src.expr, false, src.computed, src.sines);
             if (!ins.out.output && !src.cob_b.empty()) mc.cobsrc[ins.out.index] = {src.cob_b, src.cob_c};
             break;
         }
@@ -749,7 +841,7 @@ public:
                     if (sid >= 0) expr = strf("\x01" "F%ld|", sid) + va.expr + "\x02";            // zsinf(...) / its tolerant form: resolved by generate()
                 }
             }
-            append(k.frame, put(mc, ins.out, expr, false, va.computed || ins.op == "sin" || ins.op == "cos", sines));
+            put(mc, ins.out, expr, false, va.computed || ins.op == "sin" || ins.op == "cos", sines, op_cost(ins.op));
             break;
         }
         case IK::arith_float_buffer: case IK::arith_buffer_float: case IK::arith_buffer_buffer: {
@@ -762,9 +854,9 @@ public:
             else if (ins.op == "div") { k.sink(vb); sines = sa; }
             if (ins.op == "add" || ins.op == "mul") {
                 if (ins.kind == IK::arith_float_buffer) std::swap(a, b);       // addScalar / multiplyScalar(dest, buffer, float)
-                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), true, heavy, sines));
+                put(mc, ins.out, bin(ins.op, a, b), true, heavy, sines, op_cost(ins.op));
             } else {
-                append(k.frame, put(mc, ins.out, bin(ins.op, a, b), false, heavy, sines));
+                put(mc, ins.out, bin(ins.op, a, b), false, heavy, sines, op_cost(ins.op));
             }
             break;
         }
@@ -775,8 +867,14 @@ public:
             std::vector<Val> env;
             for (const Res &r : ins.args) env.push_back(val(mc, r));
             std::string outvar;
-            if (!ins.out.output) { mc.heavy[ins.out.index] = true; mc.cobsrc.erase(ins.out.index); outvar = mc.tname(ins.out.index); k.frame.push_back(outvar + " = 0.0f;"); }
-            else outvar = mc.outvar;
+            if (!ins.out.output) {
+                mc.heavy[ins.out.index] = true; mc.cobsrc.erase(ins.out.index); outvar = mc.tname(ins.out.index);
+                const Mark mk = k.mark();
+                Unit u;
+                u.text = {outvar + " = 0.0f;"};
+                append(k.frame, u.text);
+                k.unit_done(mk, std::move(u));
+            } else outvar = mc.outvar;
             ModuleCtx sub(k, callee_index, env, outvar, mc.nic, k.fresh(mc.prefix + "c") + "_", &mc);
             module_body(sub);
             if (!ins.out.output) mc.srcs[ins.out.index] = sub.outsines;
@@ -790,6 +888,7 @@ public:
 
     void delay(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
         Kernel &k = mc.k;
+        const Mark mk = k.mark();
         const size_t n = mr.delays[ins.delay_index];
         if (n < 1) throw HipBackendError{"delay of 0 samples"};
         const size_t w_idx = k.alloc(1), w_ring = k.alloc(n);
@@ -838,10 +937,12 @@ public:
         k.frame.push_back(slot + " = zf2u(" + fbout + ");");                                       // writeDelayBuffer (delay.zig:62-89)
         k.frame.push_back(strf("%s_idx = %s_idx + 1u == %zuu ? 0u : %s_idx + 1u;", d.c_str(), d.c_str(), n, d.c_str()));
         if (!ends.empty()) { k.frame.push_back("if (" + rel + " + 1u == " + length + ") {"); append(k.frame, indent(ends)); k.frame.push_back("}"); }
+        k.collapse(mk);
     }
 
     void track_call(ModuleCtx &mc, const ModuleResult &mr, const Instr &ins) {
         Kernel &k = mc.k;
+        const Mark mk = k.mark();
         const size_t ti = ins.track_index;
         const Track &track = s.pr.tracks[ti];
         const Module &module = s.pr.modules[mc.module_index];
@@ -920,6 +1021,7 @@ public:
         append(k.frame, indent(ends));
         k.frame.push_back(I + t + "_k++;");
         k.frame.push_back("}");
+        k.collapse(mk);
     }
 
     Lines track_tables(size_t ti) {
@@ -1025,7 +1127,422 @@ public:
         module_body(mc);
     }
 
-    std::string generate(const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override) {
+    // ================================================================ the role-wave form (script_rt.hip.h zs_role_run)
+    // The frame body's units dealt to waves.  plan: (1) every unit's exposed temp reads / writes, input rows and use of `o`, from its
+    // text (the names are unique identifiers); (2) reaching definitions in body order; (3) roles: a unit that touches `o`, or reads
+    // what such a unit wrote, is the WRITER's (the last role); pure cheap arithmetic on params / input rows alone FLOATS (copied into
+    // every role that reads it); a heavy or stateful unit opens a new role while the budget lasts; everything else joins the
+    // role of a producer it reads from -- one that none of its other producers depends on, the cheapest such.  The role graph
+    // stays acyclic by construction; a role's lag is its longest path from the sources, then as late as its consumers allow
+    // (fewer tile buffers).  A value that crosses roles is stored to its tile right after the defining unit and loaded right
+    // before the first unit of the consumer role that reads it.
+    struct RUnit {
+        Lines lines;
+        std::set<std::string> reads, writes;
+        std::set<size_t> rows;
+        bool touches_o = false, stateful = false, opaque = false, floating = false;
+        int cost = 1, walk = 0, role = -1;
+        std::vector<size_t> ends, stores, quiets;
+    };
+    struct Role {
+        std::vector<size_t> items;         // unit indices in body order (floating units: copies)
+        std::set<int> preds;
+        int cost = 0, lag = 0;
+        int walk = 0, rep = 1;             // the state-carrying part of `cost`; the waves the role runs in (zs_role_run K)
+        std::vector<size_t> tin, tout;     // transfer indices, in the order of zin[] / zout[]
+    };
+    struct Transfer {
+        long def;                          // defining unit, or -1 - j: input row j, or kOIn: the live output row
+        std::string var;
+        int from = 0;                      // producing role (loader sources: -1)
+        std::set<int> to;
+        int depth = 2, src_lag = 0;
+        size_t off = 0;
+    };
+    static constexpr long kOIn = -1000000;
+    static constexpr int kMaxProducers = 5;
+
+    template <class CB> static void scan_idents(const std::string &l, size_t from, size_t to, CB &&cb) {
+        size_t i = from;
+        while (i < to) {
+            const char c = l[i];
+            if ((c >= '0' && c <= '9')) {                                // a numeric literal (0x1.8p+0f ...): not identifiers
+                size_t j = i + 1;
+                while (j < to && (isalnum((unsigned char)l[j]) || l[j] == '.' || ((l[j] == '+' || l[j] == '-') && (l[j - 1] == 'p' || l[j - 1] == 'P' || l[j - 1] == 'e' || l[j - 1] == 'E')))) j++;
+                i = j;
+            } else if (isalpha((unsigned char)c) || c == '_') {
+                size_t j = i + 1;
+                while (j < to && (isalnum((unsigned char)l[j]) || l[j] == '_')) j++;
+                const bool member = i > 0 && l[i - 1] == '.';
+                if (!member) cb(l.substr(i, j - i), i, j);
+                i = j;
+            } else {
+                i++;
+            }
+        }
+    }
+    static void analyze(RUnit &u, const std::set<std::string> &temps) {
+        std::set<std::string> written;
+        auto read = [&](const std::string &id, size_t, size_t e, const std::string &l) {
+            if (id == "o") { u.touches_o = true; return; }
+            if (id == "x" && e < l.size() && l[e] == '[') { u.rows.insert((size_t)strtoul(l.c_str() + e + 1, nullptr, 10)); return; }
+            if (!temps.count(id)) return;
+            if (u.opaque) { u.reads.insert(id); u.writes.insert(id); return; }
+            if (!written.count(id)) u.reads.insert(id);
+        };
+        for (const std::string &l : u.lines) {
+            size_t p = l.find_first_not_of(' ');
+            if (p == std::string::npos) continue;
+            size_t cond0 = 0, cond1 = 0;
+            bool conditional = false;
+            if (!u.opaque && l.compare(p, 4, "if (") == 0) {
+                int depth = 0;
+                size_t q = p + 3;
+                for (; q < l.size(); q++) { if (l[q] == '(') depth++; else if (l[q] == ')' && --depth == 0) break; }
+                cond0 = p + 4; cond1 = q; conditional = true;
+                p = l.find_first_not_of(' ', q + 1);
+                if (p == std::string::npos) p = l.size();
+            }
+            std::string target;
+            size_t rhs = p;
+            if (!u.opaque) {
+                size_t j = p;
+                while (j < l.size() && (isalnum((unsigned char)l[j]) || l[j] == '_')) j++;
+                const std::string id = l.substr(p, j - p);
+                if (l.compare(j, 3, " = ") == 0 && (temps.count(id) || id == "o")) { target = id; rhs = j + 3; }
+            }
+            scan_idents(l, cond0, cond1, [&](const std::string &id, size_t b, size_t e) { read(id, b, e, l); });
+            scan_idents(l, rhs, l.size(), [&](const std::string &id, size_t b, size_t e) { read(id, b, e, l); });
+            if (target == "o") u.touches_o = true;
+            else if (!target.empty()) {
+                if (conditional && !written.count(target)) u.reads.insert(target);   // keeps its old value where the condition fails
+                written.insert(target);
+                u.writes.insert(target);
+            }
+        }
+    }
+
+    // the text of zs_paint_pc_<name> and its launch record, or {} when the module has no use for the form
+    Lines role_kernel(const Kernel &k, size_t nin, size_t ni, const Lines &preamble) {
+        // ---- (1) units
+        std::set<std::string> temps(k.temps.begin(), k.temps.end());
+        std::vector<RUnit> us;
+        for (const Unit &u : k.units) {
+            RUnit r;
+            r.stateful = u.stateful; r.opaque = u.opaque; r.cost = u.cost; r.walk = u.walk;
+            r.ends = u.ends; r.stores = u.stores; r.quiets = u.quiets;
+            if (u.zo.empty()) {
+                r.lines = u.text;
+                us.push_back(std::move(r));
+            } else {                                                     // producer part + the writer's add
+                temps.insert(u.zo);
+                if (!u.zp.empty()) temps.insert(u.zp);
+                r.lines = u.body;
+                us.push_back(std::move(r));
+                RUnit w;
+                w.cost = 1;
+                w.lines = {(u.zp.empty() ? std::string() : "if (" + u.zp + " != 0.0f) ") + "o = o + (" + u.zo + ");"};
+                us.push_back(std::move(w));
+            }
+        }
+        for (RUnit &u : us) analyze(u, temps);
+        const size_t n = us.size();
+        // ---- (2) reaching definitions: deps[u] = (defining unit, temp)
+        std::vector<std::vector<std::pair<size_t, std::string>>> deps(n);
+        {
+            std::map<std::string, size_t> last;
+            for (size_t i = 0; i < n; i++) {
+                for (const std::string &t : us[i].reads) { auto it = last.find(t); if (it != last.end()) deps[i].push_back({it->second, t}); }
+                for (const std::string &t : us[i].writes) last[t] = i;
+            }
+        }
+        // ---- (3) roles.  Role 0 is the writer.
+        std::vector<Role> roles(1);
+        auto reaches = [&](int a, int b) {                               // a path a -> ... -> b in the role graph
+            std::vector<int> stack = {b};
+            std::set<int> seen;
+            while (!stack.empty()) {
+                const int r = stack.back(); stack.pop_back();
+                if (r == a) return true;
+                if (!seen.insert(r).second) continue;
+                for (int p : roles[(size_t)r].preds) stack.push_back(p);
+            }
+            return false;
+        };
+        for (size_t i = 0; i < n; i++) {
+            RUnit &u = us[i];
+            std::set<int> P;                                             // the roles it reads from (through floating units: theirs -- none)
+            bool all_floating = true;
+            for (const auto &d : deps[i]) {
+                if (us[d.first].floating) continue;
+                all_floating = false;
+                P.insert(us[d.first].role);
+            }
+            if (u.touches_o || P.count(0)) { u.role = 0; }
+            else if (!u.stateful && !u.opaque && u.cost < 8 && all_floating) { u.floating = true; continue; }
+            else {
+                const bool anchor = u.cost >= 12 || (u.stateful && P.empty());
+                if (anchor && (int)roles.size() - 1 < kMaxProducers) {
+                    roles.emplace_back();
+                    u.role = (int)roles.size() - 1;
+                } else {
+                    std::vector<int> cand;
+                    if (P.empty()) { for (int r = 1; r < (int)roles.size(); r++) cand.push_back(r); }
+                    else {
+                        for (int r : P) {
+                            bool sink = true;
+                            for (int q : P) if (q != r && reaches(r, q)) sink = false;
+                            if (sink) cand.push_back(r);
+                        }
+                    }
+                    if (cand.empty()) { roles.emplace_back(); u.role = (int)roles.size() - 1; }
+                    else {
+                        int best = cand[0];
+                        for (int r : cand) if (roles[(size_t)r].cost < roles[(size_t)best].cost) best = r;
+                        u.role = best;
+                    }
+                }
+            }
+            Role &R = roles[(size_t)u.role];
+            for (int p : P) if (p != u.role) R.preds.insert(p);
+            R.cost += u.cost;
+        }
+        const int NR = (int)roles.size();
+        if (NR < 2) return {};                                           // nothing but the writer: the lane form is the same thing
+        // items: the role's units in body order, each preceded by the floating units it reads (once per role)
+        {
+            std::vector<std::set<size_t>> have((size_t)NR);
+            // (recursive lambda through a std::function-free trick: explicit stack)
+            for (size_t i = 0; i < n; i++) {
+                if (us[i].floating) continue;
+                const int r = us[i].role;
+                std::vector<size_t> need, stack = {i};
+                while (!stack.empty()) {
+                    const size_t x = stack.back(); stack.pop_back();
+                    for (const auto &d : deps[x])
+                        if (us[d.first].floating && !have[(size_t)r].count(d.first)) { have[(size_t)r].insert(d.first); need.push_back(d.first); stack.push_back(d.first); }
+                }
+                std::sort(need.begin(), need.end());
+                for (size_t f : need) { roles[(size_t)r].items.push_back(f); roles[(size_t)r].cost += us[f].cost; }
+                roles[(size_t)r].items.push_back(i);
+            }
+        }
+        // lags: longest path from the sources (a role that reads an input row or the live output sits behind its loader), then
+        // as late as the consumers allow
+        std::vector<std::set<size_t>> role_rows((size_t)NR);
+        for (int r = 0; r < NR; r++) for (size_t i : roles[(size_t)r].items) role_rows[(size_t)r].insert(us[i].rows.begin(), us[i].rows.end());
+        {
+            std::vector<int> order;                                      // topological (preds first)
+            std::vector<int> state((size_t)NR, 0);
+            std::vector<std::pair<int, bool>> stack;
+            for (int r = 0; r < NR; r++) stack.push_back({r, false});
+            while (!stack.empty()) {
+                auto [r, done] = stack.back(); stack.pop_back();
+                if (done) { order.push_back(r); continue; }
+                if (state[(size_t)r]) continue;
+                state[(size_t)r] = 1;
+                stack.push_back({r, true});
+                for (int p : roles[(size_t)r].preds) if (!state[(size_t)p]) stack.push_back({p, false});
+            }
+            for (int r : order) {
+                int lag = (!role_rows[(size_t)r].empty() || r == 0) ? 1 : 0;
+                for (int p : roles[(size_t)r].preds) lag = std::max(lag, roles[(size_t)p].lag + 1);
+                roles[(size_t)r].lag = lag;
+            }
+            for (auto it = order.rbegin(); it != order.rend(); ++it) {
+                const int r = *it;
+                int latest = -1;
+                for (int s = 0; s < NR; s++) if (roles[(size_t)s].preds.count(r)) latest = latest < 0 ? roles[(size_t)s].lag - 1 : std::min(latest, roles[(size_t)s].lag - 1);
+                if (latest > roles[(size_t)r].lag) roles[(size_t)r].lag = latest;
+            }
+        }
+        const int max_lag = roles[0].lag;
+        // ---- transfers
+        std::vector<Transfer> tr;
+        auto transfer = [&](long def, const std::string &var, int from, int to) -> size_t {
+            for (size_t t = 0; t < tr.size(); t++) if (tr[t].def == def && tr[t].var == var) { tr[t].to.insert(to); return t; }
+            Transfer x; x.def = def; x.var = var; x.from = from; x.to.insert(to);
+            tr.push_back(x);
+            return tr.size() - 1;
+        };
+        for (int r = 0; r < NR; r++) {
+            for (size_t j : role_rows[(size_t)r]) transfer(-1 - (long)j, strf("x[%zu]", j), -1, r);
+            for (size_t i : roles[(size_t)r].items)
+                for (const auto &d : deps[i])
+                    if (!us[d.first].floating && us[d.first].role != r) transfer((long)d.first, d.second, us[d.first].role, r);
+        }
+        const size_t oin = transfer(kOIn, "o", -1, 0);                   // last: the launch leaves its buffers out when the paint zeroes first
+        size_t bufs_no_oin = 0, bufs = 0;
+        for (size_t t = 0; t < tr.size(); t++) {
+            Transfer &x = tr[t];
+            int first = 1 << 30, last = 0;
+            for (int r : x.to) { first = std::min(first, roles[(size_t)r].lag); last = std::max(last, roles[(size_t)r].lag); }
+            x.src_lag = x.from < 0 ? first - 1 : roles[(size_t)x.from].lag;
+            x.depth = last - x.src_lag + 1;
+            x.off = bufs;
+            bufs += (size_t)x.depth;
+            if (t != oin) bufs_no_oin = bufs;
+        }
+        int ch = 32;
+        while (ch > 4 && bufs * (size_t)ch * 256 > 65536) ch /= 2;      // a buffer is [ch / 4][64] float4
+        if (bufs * (size_t)ch * 256 > 65536) return {};
+        const size_t tile = (size_t)ch / 4 * 64;
+        for (int r = 0; r < NR; r++) {
+            Role &R = roles[(size_t)r];
+            for (size_t t = 0; t < tr.size(); t++) {
+                if (t != oin && tr[t].to.count(r)) R.tin.push_back(t);
+                if (tr[t].from == r) R.tout.push_back(t);
+            }
+            if (r == 0) R.tin.push_back(oin);
+        }
+        // loader waves: up to four sources each
+        std::vector<std::vector<size_t>> loaders;
+        for (size_t t = 0; t < tr.size(); t++) {
+            if (tr[t].from >= 0) continue;
+            if (loaders.empty() || loaders.back().size() == 4) loaders.emplace_back();
+            loaders.back().push_back(t);
+        }
+        // a role whose frames cost far more to compute than to walk runs in several waves, each computing every K-th group of
+        // four frames (zs_role_run): until it is no slower than the slowest role that can not be split
+        size_t nwaves = loaders.size() + (size_t)NR;
+        {
+            int pace = 14;
+            std::vector<bool> can((size_t)NR, false);
+            for (int r = 0; r < NR; r++) {
+                Role &R = roles[(size_t)r];
+                bool ok = r != 0;
+                for (size_t i : R.items) { R.walk += us[i].walk; if (us[i].opaque) ok = false; }
+                can[(size_t)r] = ok && R.walk * 2 <= R.cost;
+                pace = std::max(pace, can[(size_t)r] ? R.walk : R.cost);
+            }
+            for (int r = 1; r < NR; r++) {
+                Role &R = roles[(size_t)r];
+                if (!can[(size_t)r]) continue;
+                while (R.rep < 4 && nwaves < 16 && R.walk + (R.cost - R.walk) / R.rep > pace + pace / 8) { R.rep++; nwaves++; }
+            }
+        }
+        int total = 0, longest = 0;
+        for (int r = 0; r < NR; r++) { total += roles[(size_t)r].cost; longest = std::max(longest, roles[(size_t)r].walk + (roles[(size_t)r].cost - roles[(size_t)r].walk) / roles[(size_t)r].rep); }
+        // worth it where the lane form can not take frame ranges and the longest role is well below the whole body
+        const bool hint = (k.rings || k.walk_reads_computed) && longest * 10 <= total * 7;
+
+        // ---- text
+        const std::string I = "    ";
+        const char *nc = k.name.c_str();
+        Lines out;
+        out.push_back(strf("// role-wave form: %zu waves (%zu loader, %d roles, the last the writer), %d frames per tile, %zu tile buffers", nwaves, loaders.size(), NR, ch, bufs));
+        out.push_back(strf("extern \"C\" __device__ const uint32_t zs_pc_info_%s[4] = {%zuu, %zuu, %zuu, %uu};", nc, nwaves * 64, bufs * (size_t)ch * 256,
+                           bufs_no_oin * (size_t)ch * 256, hint ? 1u : 0u));
+        out.push_back(strf("extern \"C\" __global__ void __launch_bounds__(%zu) zs_paint_pc_%s(const ZsLaunch L) {", nwaves * 64, nc));
+        out.push_back(I + "extern __shared__ float4 zs_lds[];");
+        out.push_back(I + "const uint32_t zs_lane = threadIdx.x & 63u, zs_role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));");
+        out.push_back(I + "const uint32_t V = L.V;");
+        out.push_back(I + "const uint32_t zs_v0 = blockIdx.x * 64 + zs_lane;");
+        out.push_back(I + "const bool zs_live = zs_v0 < V;");
+        out.push_back(I + "const uint32_t v = zs_live ? zs_v0 : V - 1;      // a lane past the last voice runs voice V - 1 again");
+        append(out, preamble);
+        out.push_back(I + "const bool zs_walk = false; (void)zs_walk;");
+        out.push_back(I + "const uint32_t zs_nfr = L.end - L.start;");
+        out.push_back(I + strf("const uint32_t zs_steps = (zs_nfr + %du) / %du + %du;", ch - 1, ch, max_lag));
+        out.push_back(I + "const bool zs_zf = (L.flags & ZH_PAINT_ZERO_FIRST) != 0;");
+        auto tile_list = [&](const std::vector<size_t> &ts) {
+            std::string s;
+            for (size_t t : ts) s += (s.empty() ? "" : ", ") + strf("{%zuu, %du}", tr[t].off * tile, tr[t].depth);
+            return s.empty() ? std::string("{0u, 1u}") : s;
+        };
+        size_t wave = 0;
+        for (const auto &ld : loaders) {
+            out.push_back(I + (wave ? "} else if" : "if") + strf(" (zs_role == %zuu) {", wave));
+            std::string src, str, vof, lag;
+            for (size_t t : ld) {
+                const bool o = tr[t].def == kOIn;
+                const size_t j = o ? 0 : (size_t)(-1 - tr[t].def);
+                src += (src.empty() ? "" : ", ") + (o ? std::string("L.out") : strf("ins[%zu]", j));
+                str += (str.empty() ? "" : ", ") + (o ? std::string("zs_zf ? (size_t)0 : (size_t)L.ostride") : strf("istr[%zu]", j));
+                vof += (vof.empty() ? "" : ", ") + (o ? std::string("v * 4u") : strf("ivo[%zu]", j));
+                lag += (lag.empty() ? "" : ", ") + strf("%du", tr[t].src_lag);
+            }
+            out.push_back(I + I + strf("const ZsTileRef zs_to[%zu] = {", ld.size()) + tile_list(ld) + "};");
+            out.push_back(I + I + strf("const float *zs_src[%zu] = {", ld.size()) + src + "};");
+            out.push_back(I + I + strf("const size_t zs_str[%zu] = {", ld.size()) + str + "};");
+            out.push_back(I + I + strf("const uint32_t zs_vof[%zu] = {", ld.size()) + vof + "};");
+            out.push_back(I + I + strf("const uint32_t zs_lag[%zu] = {", ld.size()) + lag + "};");
+            out.push_back(I + I + strf("zs_loader_run<%d, %zu>(zs_lds, zs_lane, zs_steps, L.start, zs_nfr, zs_to, zs_src, zs_str, zs_vof, zs_lag);", ch, ld.size()));
+            wave++;
+        }
+        // the producer roles in index order, the writer last
+        std::vector<int> seq;
+        for (int r = 1; r < NR; r++) seq.push_back(r);
+        seq.push_back(0);
+        for (int r : seq) {
+            const Role &R = roles[(size_t)r];
+            if (R.rep == 1) out.push_back(I + (wave ? "} else if" : "if") + strf(" (zs_role == %zuu) {", wave) + strf("      // lag %d, ~%d instructions per frame", R.lag, R.cost));
+            else out.push_back(I + (wave ? "} else if" : "if") + strf(" (zs_role >= %zuu && zs_role < %zuu) {", wave, wave + (size_t)R.rep) +
+                               strf("      // lag %d, ~%d instructions per frame, ~%d of them state: %d waves, each computes every %s group of four frames", R.lag, R.cost, R.walk, R.rep,
+                                    R.rep == 2 ? "second" : R.rep == 3 ? "third" : "fourth"));
+            out.push_back(I + I + strf("const uint32_t zs_rep = zs_role - %zuu; (void)zs_rep;", wave));
+            wave += (size_t)R.rep;
+            const size_t NIN = R.tin.size(), NOUT = R.tout.size();
+            out.push_back(I + I + strf("const ZsTileRef zs_ti[%zu] = {", NIN ? NIN : 1) + tile_list(R.tin) + "};");
+            out.push_back(I + I + strf("const ZsTileRef zs_to[%zu] = {", NOUT ? NOUT : 1) + tile_list(R.tout) + "};");
+            Lines quiet;
+            for (size_t i : R.items) for (size_t q : us[i].quiets) quiet.push_back(k.quiet_terms[q]);
+            std::string all;
+            for (const std::string &t : quiet) all += (all.empty() ? "" : " && ") + t;
+            const bool two = !quiet.empty();
+            if (two) out.push_back(I + I + "auto zs_quiet = [&](int zs_n) ZH_INLINE_LAMBDA -> bool { return " + all + "; };");
+            else out.push_back(I + I + "auto zs_quiet = [](int) ZH_INLINE_LAMBDA -> bool { return false; };");
+            out.push_back(I + I + strf("auto zs_body = [&](auto zs_q, uint32_t i, const float (&zs_in)[%zu], float (&zs_out)[%zu], float &o) ZH_INLINE_LAMBDA {", NIN ? NIN : 1, NOUT ? NOUT : 1));
+            const std::string B = I + I + I;
+            out.push_back(B + "constexpr bool ZS_Q = decltype(zs_q)::value; (void)ZS_Q;");
+            out.push_back(B + "(void)i; (void)zs_in; (void)zs_out; (void)o;");
+            out.push_back(B + strf("float x[%zu]; (void)x;", ni));
+            {
+                std::string decl;
+                for (const std::string &t : temps) decl += (decl.empty() ? "float " : ", ") + t + " = 0.0f";
+                if (!decl.empty()) out.push_back(B + decl + ";");
+                std::string use;
+                for (const std::string &t : temps) use += "(void)" + t + "; ";
+                if (!use.empty()) out.push_back(B + use);
+            }
+            std::set<size_t> loaded;
+            for (size_t a = 0; a < NIN; a++) if (tr[R.tin[a]].def < 0 && tr[R.tin[a]].def != kOIn) { out.push_back(B + tr[R.tin[a]].var + strf(" = zs_in[%zu];", a)); loaded.insert(R.tin[a]); }
+            for (size_t i : R.items) {
+                for (const auto &d : deps[i]) {
+                    if (us[d.first].floating || us[d.first].role == r) continue;
+                    for (size_t a = 0; a < NIN; a++) {
+                        const Transfer &x = tr[R.tin[a]];
+                        if (x.def == (long)d.first && x.var == d.second && loaded.insert(R.tin[a]).second) out.push_back(B + x.var + strf(" = zs_in[%zu];", a));
+                    }
+                }
+                for (const std::string &l : us[i].lines) out.push_back(B + resolve_sines(l, 0));
+                for (size_t b = 0; b < NOUT; b++) if (tr[R.tout[b]].def == (long)i) out.push_back(B + strf("zs_out[%zu] = ", b) + tr[R.tout[b]].var + ";");
+            }
+            out.push_back(I + I + "};");
+            // quads per unrolled step of a tile by body size (the lane form's rule, scaled: a quad is four frames)
+            size_t body_lines = 0;
+            for (size_t i : R.items) body_lines += us[i].lines.size();
+            const int uq = body_lines <= 12 ? ch / 4 : body_lines <= 40 ? 2 : 1;
+            const std::string lam = strf("[&](uint32_t i, const float (&a)[%zu], float (&b)[%zu], float &o) ZH_INLINE_LAMBDA ", NIN ? NIN : 1, NOUT ? NOUT : 1);
+            out.push_back(I + I + strf("zs_role_run<%d, %zu, %zu, %d, %s, %d>(zs_lds, zs_lane, %du, zs_rep, zs_steps, L.start, zs_nfr, zs_ti, zs_to, L.out, L.ostride, v * 4u, zs_zf,", ch, NIN, NOUT,
+                                       R.rep > 1 ? std::max(uq / R.rep * R.rep, R.rep) : uq, r == 0 ? "true" : "false", R.rep, R.lag));
+            out.push_back(I + I + I + lam + "{ zs_body(zs_tag<false>{}, i, a, b, o); }, zs_quiet,");
+            out.push_back(I + I + I + lam + strf("{ zs_body(zs_tag<%s>{}, i, a, b, o); });", two ? "true" : "false"));
+            Lines fin;
+            for (size_t i : R.items) for (size_t e : us[i].ends) fin.push_back(k.epi_ends[e]);
+            for (size_t i : R.items) for (size_t e : us[i].stores) fin.push_back(k.epi_stores[e]);
+            if (!fin.empty()) {
+                out.push_back(I + I + (R.rep > 1 ? "if (zs_live && zs_rep == 0u) {" : "if (zs_live) {"));
+                for (const std::string &l : fin) out.push_back(I + I + I + l);
+                out.push_back(I + I + "}");
+            }
+        }
+        out.push_back(I + "}");
+        out.push_back("}");
+        return out;
+    }
+
+    std::string generate(const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override, unsigned forms) {
         Lines out = {"// generated by zang_amd.zangscript (HIP backend) -- compile with zh_script_load / zh_script_compile",
                      "#include \"script_rt.hip.h\"", ""};
         for (size_t ci = 0; ci < s.pr.curves.size(); ci++) {
@@ -1105,16 +1622,18 @@ public:
             out.push_back(I + "const uint32_t v = blockIdx.x * 64 + threadIdx.x;");
             out.push_back(I + "const uint32_t V = L.V;");
             out.push_back(I + "if (v >= V) return;");
-            out.push_back(I + "const bool NIC = L.nic.get(v);");
-            out.push_back(I + "const uint32_t SPAN_LEN = L.end - L.start;");
-            out.push_back(I + "(void)NIC; (void)SPAN_LEN;");
+            Lines preamble;                                              // (shared with the role-wave form)
+            preamble.push_back(I + "const bool NIC = L.nic.get(v);");
+            preamble.push_back(I + "const uint32_t SPAN_LEN = L.end - L.start;");
+            preamble.push_back(I + "(void)NIC; (void)SPAN_LEN;");
             std::string nulls, zeros;
             for (size_t j = 0; j < ni; j++) { nulls += j ? ", nullptr" : "nullptr"; zeros += j ? ", 0" : "0"; }
-            out.push_back(I + strf("const float *ins[%zu] = {", ni) + nulls + "};");
-            out.push_back(I + strf("size_t istr[%zu] = {", ni) + zeros + "};");
-            out.push_back(I + strf("uint32_t ivo[%zu] = {", ni) + zeros + "};");
-            for (size_t j = 0; j < k.rows.size(); j++) out.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu], ivo[%zu]);", j, k.rows[j], j, j));
-            append(out, indent(k.pro));
+            preamble.push_back(I + strf("const float *ins[%zu] = {", ni) + nulls + "};");
+            preamble.push_back(I + strf("size_t istr[%zu] = {", ni) + zeros + "};");
+            preamble.push_back(I + strf("uint32_t ivo[%zu] = {", ni) + zeros + "};");
+            for (size_t j = 0; j < k.rows.size(); j++) preamble.push_back(I + strf("ins[%zu] = zs_row(L.p[%zu], v, istr[%zu], ivo[%zu]);", j, k.rows[j], j, j));
+            append(preamble, indent(k.pro));
+            append(out, preamble);
             out.push_back(I + "bool zs_walk = false; (void)zs_walk;");
             const bool two_bodies = !k.quiet_terms.empty();
             const std::string loop_call = I +
@@ -1172,6 +1691,10 @@ public:
             append(out, indent(k.epi_ends));
             append(out, indent(k.epi_stores));
             out.push_back("}");
+            if (forms & ZH_ZSCRIPT_FORM_ROLES) {
+                const Lines pc = role_kernel(k, nin, ni, preamble);
+                if (!pc.empty()) { out.push_back(""); append(out, pc); }
+            }
         }
         Lines tables;
         for (size_t ti : used_tracks) append(tables, track_tables(ti));
@@ -1185,8 +1708,8 @@ public:
 }  // namespace
 
 std::string generate_zig(const CompiledScript &cs) { return ZigEmitter(cs).generate(); }
-std::string generate_hip(const CompiledScript &cs, const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override) {
-    return HipEmitter(cs).generate(only, meta, unroll_override);
+std::string generate_hip(const CompiledScript &cs, const std::set<std::string> *only, std::vector<HipModuleMeta> &meta, int unroll_override, unsigned forms) {
+    return HipEmitter(cs).generate(only, meta, unroll_override, forms);
 }
 
 }  // namespace zs
@@ -1241,6 +1764,9 @@ int zh_zscript_generate_zig(zh_zscript *z, char **text_out) {
     return *text_out ? ZH_OK : ZH_ERR_INVALID;
 }
 int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unroll, char **text_out) {
+    return zh_zscript_generate_hip_forms(z, only_csv, unroll, 0u, text_out);
+}
+int zh_zscript_generate_hip_forms(zh_zscript *z, const char *only_csv, int unroll, uint32_t forms, char **text_out) {
     if (!z || !text_out) return ZH_ERR_INVALID;
     std::set<std::string> only;
     if (only_csv) {
@@ -1251,7 +1777,7 @@ int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unroll, cha
         }
     }
     z->meta.clear();
-    *text_out = dup_text(zs::generate_hip(*z->cs, only_csv ? &only : nullptr, z->meta, unroll));
+    *text_out = dup_text(zs::generate_hip(*z->cs, only_csv ? &only : nullptr, z->meta, unroll, forms));
     return *text_out ? ZH_OK : ZH_ERR_INVALID;
 }
 uint32_t zh_zscript_module_count(zh_zscript *z) { return z ? (uint32_t)z->meta.size() : 0; }

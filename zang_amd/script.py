@@ -34,7 +34,7 @@ def compile_hip(hip_source):
 class ScriptProgram:
     """One script: front-end result + the loaded hipModule."""
 
-    def __init__(self, text, ctx=None, filename="script.txt", only=None):
+    def __init__(self, text, ctx=None, filename="script.txt", only=None, forms=native.FORM_ROLES):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.text, self.filename = text, filename
@@ -43,7 +43,8 @@ class ScriptProgram:
         except native.NativeScriptError as e:
             raise ScriptCompileError(str(e))
         # ZH_SCRIPT_UNROLL: frames per unrolled chunk of the generated kernels (an experiment knob; 0 / unset = the emitter's choice by body size)
-        self.hip_source, self.meta = compiled.generate_hip(only=only, unroll=int(os.environ.get("ZH_SCRIPT_UNROLL", "0")))
+        # forms: FORM_ROLES = every module also as a role-wave kernel for few voices (zs_paint_pc_<name>; the library picks per paint)
+        self.hip_source, self.meta = compiled.generate_hip(only=only, unroll=int(os.environ.get("ZH_SCRIPT_UNROLL", "0")), forms=forms)
         compiled.close()
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)

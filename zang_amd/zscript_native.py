@@ -39,6 +39,9 @@ def _package_bits(packages):
     return bits
 
 
+FORM_ROLES = 1          # ZH_ZSCRIPT_FORM_ROLES
+
+
 class NativeScript:
     def __init__(self, contents, filename="script.txt", packages=DEFAULT_PACKAGES):
         self.lib = abi.load()
@@ -60,9 +63,10 @@ class NativeScript:
     def generate_zig(self):
         return self._text(self.lib.zh_zscript_generate_zig)
 
-    def generate_hip(self, only=None, unroll=0):
-        """-> (text, meta) with meta[name] = {"state_words", "params": [(name, kind, enum name)], "noise_fields"} or {"error"}"""
-        text = self._text(self.lib.zh_zscript_generate_hip, None if only is None else ",".join(only).encode(), int(unroll))
+    def generate_hip(self, only=None, unroll=0, forms=0):
+        """-> (text, meta) with meta[name] = {"state_words", "params": [(name, kind, enum name)], "noise_fields"} or {"error"}
+        forms: FORM_ROLES = also the role-wave kernels for few voices (zs_paint_pc_<name>, include/zang_hip.h)"""
+        text = self._text(self.lib.zh_zscript_generate_hip_forms, None if only is None else ",".join(only).encode(), int(unroll), int(forms))
         meta = {}
         name, err = C.create_string_buffer(256), C.create_string_buffer(1024)
         kind, en = C.create_string_buffer(64), C.create_string_buffer(64)
