@@ -705,7 +705,11 @@ ZH_API int zh_zscript_generate_hip(zh_zscript *z, const char *only_csv, int unro
  * waves that hand values on through LDS tiles, as the hand-written composites do (examples/modules.zig:130-187 is the
  * acceptance recipe).  Same operations on the same values in the same order: same bits.  zh_script_module_paint picks
  * the form (dispatch table rows script_pc / script_pc_maxv). */
-#define ZH_ZSCRIPT_FORM_ROLES 1u
+/* ZH_ZSCRIPT_FORM_ROLES: for every module that has more than one role.  ZH_ZSCRIPT_FORM_ROLES_WORTH: only where the emitter's
+ * estimate says it pays (a chain that can not be cut into frame ranges, the longest role well below the whole body): about half
+ * the hiprtc time of the former (profiles/r06/script_compile_times.txt). */
+#define ZH_ZSCRIPT_FORM_ROLES 1
+#define ZH_ZSCRIPT_FORM_ROLES_WORTH 2
 ZH_API int zh_zscript_generate_hip_forms(zh_zscript *z, const char *only_csv, int unroll, uint32_t forms, char **text_out);
 /* per module of the last zh_zscript_generate_hip: what zh_script_module_create / _paint need */
 ZH_API uint32_t zh_zscript_module_count(zh_zscript *z);

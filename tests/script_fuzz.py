@@ -277,7 +277,8 @@ def run_case(ctx, seed, buffers=2, F=F, ranges=None, text=None, tolerant=False, 
         rows["script_pc"] = roles
     if rows:
         os.environ["ZH_FORMS"] = util.forms_env(**rows)["ZH_FORMS"]
-    prog = script.ScriptProgram(text, ctx, only=[name])
+    from zang_amd import zscript_native as native
+    prog = script.ScriptProgram(text, ctx, only=[name], **({"forms": native.FORM_ROLES} if roles else {}))
     has_roles = ("zs_paint_pc_" + name) in prog.hip_source
     try:
         mod = prog.module(name, V, seed)

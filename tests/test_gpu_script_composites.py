@@ -50,6 +50,14 @@ def _check_form(ctx, roles, name):
         assert any(k == "zs_paint_pc_" + name for k in ran) == bool(roles), (roles, ran)
 
 
+def _check_default_form(ctx, name, V, span):
+    """the library's own choice: the role-wave form for the reference's filtered recipe up to script_pc_maxv voices (spans of at
+    least 64 frames), the lane form above and for a recipe without a chain (HardSquare: frame ranges do better)"""
+    ran = ctx.last_form()
+    want = name.startswith("FilteredSawtooth") and V <= ctx.forms()["script_pc_maxv"][1] and span[1] - span[0] >= 64
+    assert any(k == "zs_paint_pc_" + name for k in ran) == want, (name, V, span, ran)
+
+
 # roles: the role-wave form of the generated kernel (zs_paint_pc_<name>) forced on (1), off (0), or the library's own choice
 @pytest.mark.parametrize("roles", [None, 0, 1])
 @pytest.mark.parametrize("zero_first", [True, False])
@@ -66,7 +74,8 @@ def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(
     L = oracle.lib()
     idx = _voices(V)
     name = "FilteredSawtoothCtl" if freq_kind == "buffer" else "FilteredSawtooth"      # one script module per arm of the reference's ConstantOrBuffer
-    prog = script.ScriptProgram(SCRIPT, ctx, only=[name])
+    from zang_amd import zscript_native as native
+    prog = script.ScriptProgram(SCRIPT, ctx, only=[name], forms=native.FORM_ROLES if roles else native.FORM_ROLES_WORTH)
     m = prog.module(name, V)
     freq = rng.uniform(40.0, 5000.0, V).astype(np.float32)
     freq[:4] = [-3.0, 7000.0, 0.25, 5999.0]           # silent (freq < 0), silent (> sr / 8), very low, just in range
@@ -101,6 +110,8 @@ def test_filtered_sawtooth_generated_kernel_equals_the_unfused_reference_recipe(
                     {"sample_rate": SR, "freq": fimg if freq_kind == "buffer" else gfreq, "note_on": torch.from_numpy(on.astype(np.uint8)).to(ctx.device),
                      "cutoff": cutoff}, zero_first=zero_first)
             _check_form(ctx, roles, name)
+            if roles is None:
+                _check_default_form(ctx, name, V, (s, e))
         ctx.sync()
         got = out[:, torch.from_numpy(idx).to(ctx.device)].cpu().numpy().T
         util.assert_bitexact(np.ascontiguousarray(got), ref, f"FilteredSawtooth V={V} freq {freq_kind} zf={zero_first} buffer {b}")
@@ -121,7 +132,8 @@ def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, o
     rng = np.random.default_rng(V + 1)
     L = oracle.lib()
     idx = _voices(V)
-    prog = script.ScriptProgram(SCRIPT, ctx, only=["HardSquare"])
+    from zang_amd import zscript_native as native
+    prog = script.ScriptProgram(SCRIPT, ctx, only=["HardSquare"], forms=native.FORM_ROLES if roles else native.FORM_ROLES_WORTH)
     m = prog.module("HardSquare", V)
     freq = rng.uniform(40.0, 5000.0, V).astype(np.float32)
     freq[:4] = [-3.0, 7000.0, 0.25, 5999.0]
@@ -148,6 +160,8 @@ def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, o
             m.paint(zang.Span(s, e), [out], None, torch.from_numpy(nic.astype(np.uint8)).to(ctx.device),
                     {"sample_rate": SR, "freq": gfreq, "note_on": torch.from_numpy(on.astype(np.uint8)).to(ctx.device)}, zero_first=zero_first)
             _check_form(ctx, roles, "HardSquare")
+            if roles is None:
+                _check_default_form(ctx, "HardSquare", V, (s, e))
         ctx.sync()
         got = out[:, sel].cpu().numpy().T
         util.assert_bitexact(np.ascontiguousarray(got), ref, f"HardSquare V={V} zf={zero_first} buffer {b}")

@@ -134,3 +134,63 @@ def test_differential_fuzz_python_vs_native():
         assert r1 == r2, src
         ok += r1[0] == "ok"
     assert ok > 50
+
+
+# ---- the role-wave form (ZH_ZSCRIPT_FORM_ROLES: zs_paint_pc_<name>, csrc/zscript_emit.hip plan / role_kernel) ----
+def _role_section(hip, name):
+    i = hip.index("// role-wave form", hip.index("void __launch_bounds__(64) zs_paint_%s(" % name))
+    j = hip.find("\nextern \"C\" __device__ const uint32_t zs_ranges_ok_", i)
+    return hip[i:] if j < 0 else hip[i:j]
+
+
+def test_role_form_leaves_the_lane_kernels_text_alone():
+    """forms = ROLES adds kernels; every line of the lane-form text is still there, in order, and the metadata is the same"""
+    nat = native.NativeScript(SCRIPT)
+    a, ma = nat.generate_hip()
+    b, mb = nat.generate_hip(forms=native.FORM_ROLES)
+    assert ma == mb
+    it = iter(b.split("\n"))
+    assert all(any(l == m for m in it) for l in a.split("\n")), "a lane-form line is missing or out of order"
+    assert "zs_paint_pc_" in b and "zs_paint_pc_" not in a
+
+
+def test_role_form_of_the_reference_recipe():
+    """FilteredSawtooth (examples/modules.zig:130-187): oscillator, envelope, the filter's recurrence and the writer are roles of
+    their own; the oscillator (42 instructions a frame, 2 of them state) runs in several waves; the Filter is dealt out in three
+    parts (input + offset with the producer, the recurrence alone, the mix with the writer); every state word is stored once."""
+    import re
+    nat = native.NativeScript(SCRIPT)
+    hip, _ = nat.generate_hip(only=["FilteredSawtooth"], forms=native.FORM_ROLES)
+    sec = _role_section(hip, "FilteredSawtooth")
+    head = sec.split("\n")[0]
+    m = re.match(r"// role-wave form: (\d+) waves \((\d+) loader, (\d+) roles, the last the writer\), (\d+) frames per tile, (\d+) tile buffers", head)
+    assert m, head
+    waves, loaders, roles, ch, bufs = map(int, m.groups())
+    assert roles == 4 and loaders == 1 and waves > loaders + roles and ch in (16, 32)
+    info = re.search(r"zs_pc_info_FilteredSawtooth\[4\] = \{(\d+)u, (\d+)u, (\d+)u, (\d+)u\}", sec)
+    threads, lds, lds_zf, hint = map(int, info.groups())
+    assert threads == waves * 64 and lds == bufs * ch * 256 and lds_zf < lds <= 65536 and hint == 1
+    assert re.search(r"\.pre\(t\d+\);", sec) and ".core<false, false>(" in sec and ".mix(" in sec
+    # the recurrence role holds the core and nothing else that computes
+    core_role = [blk for blk in sec.split("} else if")[1:] if ".core<" in blk]
+    assert len(core_role) == 1 and ".frame" not in core_role[0] and ".mix(" not in core_role[0] and ".pre(" not in core_role[0]
+    stores = re.findall(r"zs_st_[fu]\(L\.state, (\d+), V, v,", sec)
+    assert sorted(map(int, stores)) == list(range(8))
+
+
+def test_role_form_compiles_for_gfx950():
+    """every module of the test script and a few random ones (delays, tracks, nested modules: opaque units), through hiprtc"""
+    from tests import script_fuzz
+    from zang_amd import script
+    nat = native.NativeScript(SCRIPT)
+    hip, meta = nat.generate_hip(forms=native.FORM_ROLES)
+    assert script.compile_hip(hip) > 10000
+    n_pc = hip.count(") zs_paint_pc_")
+    assert n_pc >= 5, n_pc
+    for seed in (0, 2, 9):
+        text, name = script_fuzz.generate(seed)
+        f = native.NativeScript(text, "fuzz")
+        src, _ = f.generate_hip(only=[name], forms=native.FORM_ROLES)
+        f.close()
+        assert "zs_paint_pc_" + name in src
+        assert script.compile_hip(src) > 10000

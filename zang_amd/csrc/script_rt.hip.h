@@ -250,7 +250,13 @@ __device__ __forceinline__ void zs_role_run(float4 *lds, uint32_t lane, uint32_t
     for (int j = 0; j < NI; j++) bi[j] = 0;
 #pragma unroll
     for (int j = 0; j < NO; j++) bo[j] = 0;
+#if defined(ZS_PC_TRACE)                                             // tools/exp/role_probe.py: cycles between barriers against cycles in all
+    unsigned long long zs_busy = 0, zs_t_begin = __builtin_readcyclecounter(), zs_t0 = zs_t_begin;
+#endif
     for (uint32_t c = 0; c < steps; c++) {
+#if defined(ZS_PC_TRACE)
+        zs_t0 = __builtin_readcyclecounter();
+#endif
         if (c >= lag && c - lag < nchunks) {
             const uint32_t d = c - lag, nf = min(CH, n_frames - d * CH), base = start + d * CH;
             const float4 *ti[NI];
@@ -263,6 +269,7 @@ __device__ __forceinline__ void zs_role_run(float4 *lds, uint32_t lane, uint32_t
                 float4 a[NI];
 #pragma unroll
                 for (int j = 0; j < NIN; j++) a[j] = ti[j][0];
+                const bool qtile = quiet((int)CH);                    // the whole tile quiet: no test per group of four frames
 #pragma unroll UQ
                 for (uint32_t q = 0; q < Q; q++) {
                     float4 an[NI];                                    // the next four frames' values: fetched while these compute
@@ -287,11 +294,11 @@ __device__ __forceinline__ void zs_role_run(float4 *lds, uint32_t lane, uint32_t
                         }
                     };
                     if (K == 1 || q % K == rep) {
-                        if (quiet(4)) quad(fq, zs_tag<true>{}); else quad(f, zs_tag<true>{});
+                        if (qtile || quiet(4)) quad(fq, zs_tag<true>{}); else quad(f, zs_tag<true>{});
 #pragma unroll
                         for (int j = 0; j < NOUT; j++) to[j][q * 64] = b[j];
                     } else {
-                        if (quiet(4)) quad(fq, zs_tag<false>{}); else quad(f, zs_tag<false>{});
+                        if (qtile || quiet(4)) quad(fq, zs_tag<false>{}); else quad(f, zs_tag<false>{});
                     }
                     if (WR) {
                         const zh_rsrc_t ro = zrow_rsrc(out, ostride, base + 4 * q);
@@ -322,8 +329,16 @@ __device__ __forceinline__ void zs_role_run(float4 *lds, uint32_t lane, uint32_t
 #pragma unroll
             for (int j = 0; j < NOUT; j++) bo[j] = bo[j] + 1 == tout[j].depth ? 0 : bo[j] + 1;
         }
+#if defined(ZS_PC_TRACE)
+        zs_busy += __builtin_readcyclecounter() - zs_t0;
+#endif
         __syncthreads();
     }
+#if defined(ZS_PC_TRACE)
+    if (blockIdx.x == 0 && lane == 0)
+        printf("role wave %u (lag %u, rep %u of %d%s): busy %llu of %llu cycles\n", (unsigned)(threadIdx.x >> 6), lag, rep, K, WR ? ", writer" : "", zs_busy,
+               (unsigned long long)(__builtin_readcyclecounter() - zs_t_begin));
+#endif
 }
 
 // A loader role: NR image rows per frame -- input images of the script module's params, or the live output image -- into

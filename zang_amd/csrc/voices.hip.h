@@ -201,6 +201,19 @@ struct FilterLane {
         const SvfOut s = svf_step(l, b, x, cut, res);                 // :135-144
         return s.l * l_mul + s.b * b_mul + s.h * h_mul;               // :146
     }
+    // frame() in three parts, for the role-wave form of a generated kernel (zscript_emit.hip), which deals them to different
+    // waves: pre() is a function of the input sample alone, core() carries (l, b), post() is the mix.  post(x, core(pre(x))) is
+    // frame(x): the same operations on the same values.
+    __device__ __forceinline__ float pre(float x) const { return x + kSvfDcOffset; }                        // :135
+    template <bool CB, bool RB> __device__ __forceinline__ SvfOut core(float in, float cutoff_i, float res_i) {
+        if (bypass) return SvfOut{0.0f, 0.0f, 0.0f};
+        if (CB) cut = zclampf(cutoff_i, 0.0f, 1.0f);
+        if (RB) res = 1.0f - zclampf(res_i, 0.0f, 1.0f);
+        return svf_core(l, b, in, cut, res);                          // :138-144
+    }
+    __device__ __forceinline__ float mix(float sl, float sb, float sh) const { return sl * l_mul + sb * b_mul + sh * h_mul; }   // :146
+    __device__ __forceinline__ float post(float x, float sl, float sb, float sh) const { return bypass ? x : mix(sl, sb, sh); }  // :91-97
+
 };
 
 // ---- Decimator (src/modules/Decimator.zig) -------------------------------------------------------

@@ -367,10 +367,18 @@ struct InitItem { bool noise; size_t word; size_t k; float value; };
 
 // One step of the frame body as the role-wave form deals it out (plan_roles below): a builtin's frame, one arithmetic
 // instruction, or a whole delay / track construct (opaque).  `text` is what the lane form's body holds for it.
+struct Part {                      // a unit's piece for the role-wave form
+    Lines lines;
+    int cost = 1, walk = 0;
+    bool stateful = false;
+    bool owner = false;            // the piece that owns the unit's state: its end / store / quiet lines go where it goes
+};
 struct Unit {
     Lines text;
-    Lines body;                    // role form, for a unit that ends in a plain add into the output: the same without that add ...
-    std::string zo, zp;            // ... its value and (builtins that can paint nothing) its painted flag go to the writer role in these
+    // role form: the unit in pieces that may go to different roles -- a plain add into the output as (value [, painted flag]) for
+    // the writer role's add; a Filter as (input + offset) / the (l, b) recurrence / the mix.  Empty: `text` is the one piece.
+    std::vector<Part> parts;
+    std::vector<std::string> ztemps;   // frame-local names the pieces hand values on in
     bool opaque = false;           // a delay / track construct: conditionals around inner units, taken whole
     bool stateful = false;         // owns frame-to-frame state (a lane object, a ring, a track): lives in exactly one role
     int cost = 1;                  // ~VALU instructions per frame
@@ -414,6 +422,8 @@ struct Kernel {
     size_t nsines = 0;             // sine sources met so far (SineOsc calls and sin() of a buffer)
     uint64_t exact_sines = 0;      // ... and the ones that reach a sink (linear_input above)
     std::string fresh(const std::string &stem) { uid++; return stem + std::to_string(uid); }
+    size_t zuid = 0;               // (the role form's own names count apart: the lane form's text does not depend on them)
+    std::string zfresh(const std::string &stem) { zuid++; return stem + std::to_string(zuid); }
     size_t alloc(size_t n) { const size_t w = words; words += n; return w; }
     // a new sine source: its id, or -1 = one too many (emitted exact); `bit` = its Val.sines bit
     long sine_source(uint64_t &bit) {
@@ -537,8 +547,13 @@ public:
         u.text = put_lines(mc, d, expr, zero_first, heavy, sines);
         u.cost = cost + (zero_first ? 1 : 0);
         if (d.output && mc.outvar == "o") {                           // `o = o + (expr);`: the value travels, the add is the writer's
-            u.zo = k.fresh("zo");
-            u.body = {u.zo + " = " + expr + ";"};
+            const std::string zo = k.zfresh("zo");
+            u.ztemps.push_back(zo);
+            Part a, w;
+            a.lines = {zo + " = " + expr + ";"};
+            a.cost = u.cost; a.owner = true;
+            w.lines = {"o = o + (" + zo + ");"};
+            u.parts = {a, w};
         }
         append(k.frame, u.text);
         k.unit_done(mk, std::move(u));
@@ -765,17 +780,56 @@ public:
         Unit u;
         u.stateful = state_words(name) > 0;
         u.cost = builtin_cost(name, a, u.walk);
-        if (target == "o") {                                         // the role form: value and painted flag travel, the add is the writer's
-            u.zo = k.fresh("zo");
-            Lines body = frame;
-            body.push_back(u.zo + " = " + value + ";");
-            if (!painted.empty()) {
-                u.zp = k.fresh("zp");
-                body.push_back(u.zp + " = (" + painted + ") ? 1.0f : 0.0f;");
+        // the role form's pieces.  The add into `o` is always the writer's: the value (and the painted flag of a builtin that can
+        // paint nothing) travels to it.
+        auto writer_add = [&](const std::string &val, const std::string &flag) {
+            const std::string zo = k.zfresh("zo");
+            u.ztemps.push_back(zo);
+            Lines give = {zo + " = " + val + ";"};
+            Part w;
+            w.lines = {"o = o + (" + zo + ");"};
+            if (!flag.empty()) {
+                const std::string zp = k.zfresh("zp");
+                u.ztemps.push_back(zp);
+                give.push_back(zp + " = (" + flag + ") ? 1.0f : 0.0f;");
+                w.lines = {"if (" + zp + " != 0.0f) o = o + (" + zo + ");"};
             }
-            u.body.push_back("{");
-            append(u.body, indent(body));
-            u.body.push_back("}");
+            return std::make_pair(give, w);
+        };
+        if (name == "Filter") {
+            // (input + offset), a function of the input sample alone, joins the role that makes the input; the (l, b) recurrence is a
+            // role of its own; the mix goes with its consumer (FilterLane::pre / core / post: frame() in three parts)
+            const Cob c = cob(a["cutoff"]), r = cob(a["res"]);
+            const std::string fi = k.zfresh("zfi"), fl = k.zfresh("zfl"), fb = k.zfresh("zfb"), fh = k.zfresh("zfh");
+            for (const std::string &t : {fi, fl, fb, fh}) u.ztemps.push_back(t);
+            Part pa, pb, pc;
+            pa.lines = {fi + " = " + o + ".pre(" + a["input"].expr + ");"};
+            pa.cost = 1;
+            pb.lines = {"{", "    const SvfOut zs_s = " + o + ".core<" + tf(c.is_buf) + ", " + tf(r.is_buf) + ">(" + fi + ", " + (c.is_buf ? c.i : "0.0f") + ", " + (r.is_buf ? r.i : "0.0f") + ");",
+                        "    " + fl + " = zs_s.l;", "    " + fb + " = zs_s.b;", "    " + fh + " = zs_s.h;", "}"};      // (one statement per line: analyze())
+            pb.cost = pb.walk = u.cost - 6; pb.stateful = pb.owner = true;
+            // (a literal type other than bypass: the mix does not read the input sample)
+            const bool never_bypass = a["type"].tag_literal && a["type"].tag != "bypass";
+            const std::string mix = never_bypass ? o + ".mix(" + fl + ", " + fb + ", " + fh + ")" : o + ".post(" + a["input"].expr + ", " + fl + ", " + fb + ", " + fh + ")";
+            pc.cost = 5;
+            if (target == "o") {
+                auto gw = writer_add(mix, "");
+                pc.lines = gw.first;
+                u.parts = {pa, pb, pc, gw.second};
+            } else {
+                pc.lines = {target + " = 0.0f;", target + " = " + target + " + (" + mix + ");"};
+                u.parts = {pa, pb, pc};
+            }
+        } else if (target == "o") {
+            auto gw = writer_add(value, painted);
+            Lines body = frame;
+            append(body, gw.first);
+            Part pa;
+            pa.lines.push_back("{");
+            append(pa.lines, indent(body));
+            pa.lines.push_back("}");
+            pa.cost = u.cost; pa.walk = u.walk; pa.stateful = u.stateful; pa.owner = true;
+            u.parts = {pa, gw.second};
         }
         frame.push_back(painted.empty() ? addl : "if (" + painted + ") " + addl);
         u.text.push_back("{");
@@ -793,7 +847,7 @@ public:
         if (name == "PulseOsc") return is_buf("freq") ? ret(34, 34) : ret(16, 2);
         if (name == "TriSawOsc") return is_buf("freq") ? ret(24, 12) : ret(42, 2);
         if (name == "Noise") return a["color"].tag_literal && a["color"].tag == "white" ? ret(24, 20) : ret(44, 20);
-        if (name == "Envelope") return ret(22, 14);
+        if (name == "Envelope") return ret(16, 5);                   // (a walked group of four quiet frames: four clock steps, one curve)
         if (name == "Filter") { const int c = 21 + (is_buf("cutoff") ? 3 : 0) + (is_buf("res") ? 4 : 0); return ret(c, c); }
         if (name == "Decimator") return ret(8, 8);
         if (name == "Distortion") return a["type"].tag_literal && a["type"].tag == "clip" ? ret(6, 0) : ret(40, 0);
@@ -1149,6 +1203,7 @@ public:
         std::set<int> preds;
         int cost = 0, lag = 0;
         int walk = 0, rep = 1;             // the state-carrying part of `cost`; the waves the role runs in (zs_role_run K)
+        int walk_sum = 0;                  // (while roles are being dealt: `walk` of the units so far)
         std::vector<size_t> tin, tout;     // transfer indices, in the order of zin[] / zout[]
     };
     struct Transfer {
@@ -1223,26 +1278,26 @@ public:
     }
 
     // the text of zs_paint_pc_<name> and its launch record, or {} when the module has no use for the form
-    Lines role_kernel(const Kernel &k, size_t nin, size_t ni, const Lines &preamble) {
+    Lines role_kernel(const Kernel &k, size_t nin, size_t ni, const Lines &preamble, size_t lds_budget, bool &worth) {
         // ---- (1) units
         std::set<std::string> temps(k.temps.begin(), k.temps.end());
         std::vector<RUnit> us;
         for (const Unit &u : k.units) {
-            RUnit r;
-            r.stateful = u.stateful; r.opaque = u.opaque; r.cost = u.cost; r.walk = u.walk;
-            r.ends = u.ends; r.stores = u.stores; r.quiets = u.quiets;
-            if (u.zo.empty()) {
+            temps.insert(u.ztemps.begin(), u.ztemps.end());
+            if (u.parts.empty()) {
+                RUnit r;
+                r.stateful = u.stateful; r.opaque = u.opaque; r.cost = u.cost; r.walk = u.walk;
+                r.ends = u.ends; r.stores = u.stores; r.quiets = u.quiets;
                 r.lines = u.text;
                 us.push_back(std::move(r));
-            } else {                                                     // producer part + the writer's add
-                temps.insert(u.zo);
-                if (!u.zp.empty()) temps.insert(u.zp);
-                r.lines = u.body;
+                continue;
+            }
+            for (const Part &p : u.parts) {
+                RUnit r;
+                r.stateful = p.stateful; r.cost = p.cost; r.walk = p.walk;
+                if (p.owner) { r.ends = u.ends; r.stores = u.stores; r.quiets = u.quiets; }
+                r.lines = p.lines;
                 us.push_back(std::move(r));
-                RUnit w;
-                w.cost = 1;
-                w.lines = {(u.zp.empty() ? std::string() : "if (" + u.zp + " != 0.0f) ") + "o = o + (" + u.zo + ");"};
-                us.push_back(std::move(w));
             }
         }
         for (RUnit &u : us) analyze(u, temps);
@@ -1271,15 +1326,35 @@ public:
         };
         for (size_t i = 0; i < n; i++) {
             RUnit &u = us[i];
-            std::set<int> P;                                             // the roles it reads from (through floating units: theirs -- none)
-            bool all_floating = true;
-            for (const auto &d : deps[i]) {
-                if (us[d.first].floating) continue;
-                all_floating = false;
-                P.insert(us[d.first].role);
+            std::set<int> P;                                             // the roles it reads from (through floating units: what those read from)
+            {
+                std::vector<size_t> stack = {i};
+                std::set<size_t> seen;
+                while (!stack.empty()) {
+                    const size_t x = stack.back(); stack.pop_back();
+                    for (const auto &d : deps[x]) {
+                        if (!us[d.first].floating) P.insert(us[d.first].role);
+                        else if (seen.insert(d.first).second) stack.push_back(d.first);
+                    }
+                }
+            }
+            // cheap pure arithmetic FLOATS -- it is copied into every role that reads its result -- when it reads params and input
+            // rows alone, or when the one role it could join is a recurrence (every instruction there is on the span's critical
+            // path: a Filter's mix goes to the role that wants the mix, at the price of handing on l, b and h instead of one value)
+            auto recurrence = [&](int r) { return r > 0 && roles[(size_t)r].cost > 0 && roles[(size_t)r].walk_sum == roles[(size_t)r].cost; };
+            bool floats = !u.stateful && !u.opaque && !u.touches_o && u.cost < 8 && !P.count(0);
+            if (floats && !P.empty()) {
+                floats = false;
+                std::vector<int> sinks;
+                for (int r : P) {
+                    bool sink = true;
+                    for (int q : P) if (q != r && reaches(r, q)) sink = false;
+                    if (sink) sinks.push_back(r);
+                }
+                if (sinks.size() == 1 && recurrence(sinks[0])) floats = true;
             }
             if (u.touches_o || P.count(0)) { u.role = 0; }
-            else if (!u.stateful && !u.opaque && u.cost < 8 && all_floating) { u.floating = true; continue; }
+            else if (floats) { u.floating = true; continue; }
             else {
                 const bool anchor = u.cost >= 12 || (u.stateful && P.empty());
                 if (anchor && (int)roles.size() - 1 < kMaxProducers) {
@@ -1306,6 +1381,7 @@ public:
             Role &R = roles[(size_t)u.role];
             for (int p : P) if (p != u.role) R.preds.insert(p);
             R.cost += u.cost;
+            R.walk_sum += u.walk;
         }
         const int NR = (int)roles.size();
         if (NR < 2) return {};                                           // nothing but the writer: the lane form is the same thing
@@ -1322,10 +1398,12 @@ public:
                     for (const auto &d : deps[x])
                         if (us[d.first].floating && !have[(size_t)r].count(d.first)) { have[(size_t)r].insert(d.first); need.push_back(d.first); stack.push_back(d.first); }
                 }
-                std::sort(need.begin(), need.end());
                 for (size_t f : need) { roles[(size_t)r].items.push_back(f); roles[(size_t)r].cost += us[f].cost; }
                 roles[(size_t)r].items.push_back(i);
             }
+            // BODY ORDER, copies included: temps are reused names, and a copy run later than its place in the body would overwrite a
+            // newer value of the name it writes (Bell: `t0 = freq` after `t0 = 1 + 0.03 * sine` -- tests/test_zangscript.py)
+            for (Role &R : roles) std::sort(R.items.begin(), R.items.end());
         }
         // lags: longest path from the sources (a role that reads an input row or the live output sits behind its loader), then
         // as late as the consumers allow
@@ -1384,8 +1462,8 @@ public:
             if (t != oin) bufs_no_oin = bufs;
         }
         int ch = 32;
-        while (ch > 4 && bufs * (size_t)ch * 256 > 65536) ch /= 2;      // a buffer is [ch / 4][64] float4
-        if (bufs * (size_t)ch * 256 > 65536) return {};
+        while (ch > 4 && bufs * (size_t)ch * 256 > lds_budget) ch /= 2;      // a buffer is [ch / 4][64] float4
+        if (bufs * (size_t)ch * 256 > lds_budget) return {};
         const size_t tile = (size_t)ch / 4 * 64;
         for (int r = 0; r < NR; r++) {
             Role &R = roles[(size_t)r];
@@ -1418,13 +1496,15 @@ public:
             for (int r = 1; r < NR; r++) {
                 Role &R = roles[(size_t)r];
                 if (!can[(size_t)r]) continue;
-                while (R.rep < 4 && nwaves < 16 && R.walk + (R.cost - R.walk) / R.rep > pace + pace / 8) { R.rep++; nwaves++; }
+                // (2 or 4 waves: a tile's groups of four frames must divide evenly, the step waits for the slowest wave)
+                while (R.rep < 4 && R.rep * 2 <= ch / 4 && nwaves + (size_t)R.rep <= 16 && R.walk + (R.cost - R.walk) / R.rep > pace + pace / 8) { nwaves += (size_t)R.rep; R.rep *= 2; }
             }
         }
         int total = 0, longest = 0;
         for (int r = 0; r < NR; r++) { total += roles[(size_t)r].cost; longest = std::max(longest, roles[(size_t)r].walk + (roles[(size_t)r].cost - roles[(size_t)r].walk) / roles[(size_t)r].rep); }
         // worth it where the lane form can not take frame ranges and the longest role is well below the whole body
         const bool hint = (k.rings || k.walk_reads_computed) && longest * 10 <= total * 7;
+        worth = hint;
 
         // ---- text
         const std::string I = "    ";
@@ -1691,9 +1771,10 @@ public:
             append(out, indent(k.epi_ends));
             append(out, indent(k.epi_stores));
             out.push_back("}");
-            if (forms & ZH_ZSCRIPT_FORM_ROLES) {
-                const Lines pc = role_kernel(k, nin, ni, preamble);
-                if (!pc.empty()) { out.push_back(""); append(out, pc); }
+            if (forms & (ZH_ZSCRIPT_FORM_ROLES | ZH_ZSCRIPT_FORM_ROLES_WORTH)) {
+                bool worth = false;
+                const Lines pc = role_kernel(k, nin, ni, preamble, (forms & 4u) ? 131072 : 65536, worth);    // (bit 2: an experiment, tools/r06_roles2.sh)
+                if (!pc.empty() && ((forms & ZH_ZSCRIPT_FORM_ROLES) || worth)) { out.push_back(""); append(out, pc); }
             }
         }
         Lines tables;

@@ -34,7 +34,7 @@ def compile_hip(hip_source):
 class ScriptProgram:
     """One script: front-end result + the loaded hipModule."""
 
-    def __init__(self, text, ctx=None, filename="script.txt", only=None, forms=native.FORM_ROLES):
+    def __init__(self, text, ctx=None, filename="script.txt", only=None, forms=native.FORM_ROLES_WORTH, hip_patch=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.text, self.filename = text, filename
@@ -43,9 +43,13 @@ class ScriptProgram:
         except native.NativeScriptError as e:
             raise ScriptCompileError(str(e))
         # ZH_SCRIPT_UNROLL: frames per unrolled chunk of the generated kernels (an experiment knob; 0 / unset = the emitter's choice by body size)
-        # forms: FORM_ROLES = every module also as a role-wave kernel for few voices (zs_paint_pc_<name>; the library picks per paint)
+        # forms: FORM_ROLES_WORTH = modules the emitter expects to gain from it also as a role-wave kernel for few voices (zs_paint_pc_<name>;
+        # the library picks per paint); FORM_ROLES = every module (the parity tests force the form)
+        forms = int(os.environ.get("ZH_SCRIPT_FORMS", forms))       # (an experiment knob like ZH_SCRIPT_UNROLL)
         self.hip_source, self.meta = compiled.generate_hip(only=only, unroll=int(os.environ.get("ZH_SCRIPT_UNROLL", "0")), forms=forms)
         compiled.close()
+        if hip_patch is not None:                               # experiments (tools/exp/role_probe.py): the generated text, edited
+            self.hip_source = hip_patch(self.hip_source)
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
         rc = self.lib.zh_script_load(self.ctx.handle, self.hip_source.encode(), C.byref(h), log, len(log))

@@ -39,7 +39,8 @@ def _package_bits(packages):
     return bits
 
 
-FORM_ROLES = 1          # ZH_ZSCRIPT_FORM_ROLES
+FORM_ROLES = 1          # ZH_ZSCRIPT_FORM_ROLES: a role-wave kernel for every module that has more than one role
+FORM_ROLES_WORTH = 2    # ZH_ZSCRIPT_FORM_ROLES_WORTH: only where the emitter expects it to pay
 
 
 class NativeScript:
