@@ -613,6 +613,60 @@ def parity_check(wl, ctx):
     return rec
 
 
+def parity_check_graph(run, ctx, max_voices=256):
+    """The timed graph itself against the oracle (parity_check paints eagerly and never ran the coalesced or the pipelined
+    launches): the state before one more replay, the replay, then buffer G - 1 of it (the last image it painted) against the oracle
+    walked G buffers from that state -- `max_voices` voices on a stride (the oracle paints every buffer up to the last).
+    Bit-exact, or for ZH_PAINT_TOLERANT within 1e-5 of the voice's peak per buffer carried."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    wl, G = run.wl, run.G
+    if run.graph is None or wl.name not in ("pulseosc", "noise_filter_fused") or not hasattr(wl, "graph_first_image"):
+        return None
+    from oracle import pyoracle as po
+    L = po.lib()
+    V, F = wl.V, wl.F
+    sample = np.arange(V) if V <= max_voices else np.unique(np.linspace(0, V - 1, max_voices).astype(np.int64))
+    st = wl.m.state()
+    run.graph.launch()
+    ctx.sync()
+    out = wl.ring[(wl.graph_first_image + G - 1) % wl.nring]
+    got = out[:, torch.from_numpy(sample).to(out.device)].cpu().numpy().T
+    ref = np.zeros((len(sample), F), np.float32)
+    t0 = np.zeros(F, np.float32)
+    if wl.name == "noise_filter_fused":
+        cut_h, res_h = wl.cutoff.cpu().numpy(), wl.res.cpu().numpy()
+    for k, v in enumerate(sample):
+        if wl.name == "pulseosc":
+            o = po.PulseOsc(int(st["cnt"][v]))
+            for _ in range(G):
+                ref[k] = 0
+                L.zo_pulseosc_paint(C.byref(o), 0, F, po.fptr(ref[k]), SR, po.constant(float(wl.freq_h[v])), float(wl.color_h[v]))
+        else:
+            nz = po.Noise(); fl = po.Filter()
+            for i in range(4):
+                nz.r[i] = int(st["noise"]["r"][v][i])
+            for i in range(7):
+                nz.b[i] = float(st["noise"]["b"][v][i])
+            fl.l, fl.b = float(st["flt"]["l"][v]), float(st["flt"]["b"][v])
+            for _ in range(G):
+                t0[:] = 0; ref[k] = 0
+                L.zo_noise_paint(C.byref(nz), 0, F, po.fptr(t0), 0)
+                L.zo_filter_paint(C.byref(fl), 0, F, po.fptr(ref[k]), po.fptr(t0), 1, po.constant(float(cut_h[v])), po.constant(float(res_h[v])))
+    same = got.view(np.uint32) == ref.view(np.uint32)
+    rec = {"checked_voices": int(len(sample)), "buffer_of_the_replay": G - 1, "frames": F, "bitexact": bool(same.all()), "mismatching_samples": int((~same).sum()),
+           "kernels": ["%s x%d" % kn for kn in run.graph_kernels],
+           "against": "oracle walked %d buffers from the state before the replay" % G}
+    if wl.tolerant:
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        peak = np.maximum(np.abs(ref.astype(np.float64)).max(axis=1), 1e-300)
+        worst = float((err.max(axis=1) / peak).max())
+        rec["tolerant"] = {"worst_error_over_voice_peak": worst, "allowed": 1e-5 * G, "within": worst <= 1e-5 * G,
+                           "what": "carried over the replay's %d buffers from one start state: 1e-5 of the peak per buffer" % G}
+    return rec
+
+
 def parity_check_mix(wl, ctx, n=64):
     """The same for the mixdown workload, which has no per-voice image: `n` voices on a stride through the
     shard, two per launch -- zh_nice_paint_mix_stereo with ONE-HOT channel gains (left = voice a, right = voice b: every other
@@ -669,7 +723,7 @@ def parity_check_mix(wl, ctx, n=64):
     return rec
 
 
-def traffic_record(args, V, F, kernel_hint=None):
+def traffic_record(args, V, F, kernel_hint=None, batch=False, driver_form=False, pipelined=False):
     """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same workload
     (counters cannot be read from inside the process; tools/pmc_traffic.sh collects them: one pass per counter, FETCH_SIZE
     doubled on gfx950): value + where it came from.  profiles/r03/pmc_traffic_<workload><voices>.json holds every kernel of a
@@ -677,20 +731,44 @@ def traffic_record(args, V, F, kernel_hint=None):
     if F != 1024:
         return None, None
     tol = "_tolerant" if getattr(args, "tolerant", False) else ""
-    path = next((p for p in (os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_{args.workload}{V}{tol}.json") for rnd in ("r05", "r04", "r03")) if os.path.exists(p)),
-                os.path.join(ROOT, "profiles", "r05", f"pmc_traffic_{args.workload}{V}{tol}.json"))
+    # the PMC passes of the form that ran: `_driver_args` = the recorded, coalesced graph at the driver's arguments (tools/pmc_traffic.sh
+    # with PMC_GRAPH=1: counters of the launches a replay makes), else one launch per buffer (--eager)
+    names = ([f"pmc_traffic_{args.workload}{V}{tol}_driver_args.json"] if (driver_form or batch or pipelined) else []) + [f"pmc_traffic_{args.workload}{V}{tol}.json"]
+    path = next((p for p in (os.path.join(ROOT, "profiles", rnd, fn) for rnd in ("r06", "r05", "r04", "r03") for fn in names) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r05", names[-1]))
     if os.path.exists(path):
         rec = json.load(open(path))
         ks = rec.get("kernels", {})
         if ks:
-            hint = (kernel_hint or "").split("<")[0]
+            hint = (kernel_hint or "").split("<")[0].split("[")[0]
             named = {n: v for n, v in ks.items() if hint and hint in n}
-            name, k = max((named or ks).items(), key=lambda kv: kv[1]["write_bytes_per_launch"] + kv[1]["fetch_bytes_per_launch_corrected"])
-            per_launch = k["write_bytes_per_launch"] + k["fetch_bytes_per_launch_corrected"]
+            if hint in BATCH_SUFFIX and named:
+                suffix = BATCH_SUFFIX[hint][0 if batch else 1].split("(")[0]
+                inst = {n: v for n, v in named.items() if n.rstrip().endswith(suffix)}
+                if not inst and batch:
+                    named = {}              # only one-buffer launches were counted: the caller scales them (see `traffic` below)
+                else:
+                    named = inst or named
+            total = lambda v: v["write_bytes_per_launch"] + v["fetch_bytes_per_launch_corrected"]
+            if pipelined and hint.endswith("_tp_ba") and not named:
+                # the fused launch (pass B of buffer n + pass A of buffer n + 1) moves what the two kernels move: their sum
+                parts = {n: v for n, v in ks.items() if "_tp_a" in n or "_tp_b" in n}
+                if parts:
+                    per_launch = sum(total(v) for v in parts.values())
+                    src = {"file": os.path.relpath(path, ROOT), "collected_at_commit": rec.get("commit"), "kernel": hint + " = " + " + ".join(sorted(parts)),
+                           "how": "tools/pmc_traffic.sh (separate --pmc passes of WRITE_SIZE / FETCH_SIZE, FETCH_SIZE x2 on gfx950)",
+                           "kernels_per_step": {n: v["hbm_bytes_per_step"] for n, v in ks.items()},
+                           "note": "a constant read from that file, not a counter of this run; pass A + pass B counted as separate launches and added"}
+                    return per_launch, src
+            if not named and batch:
+                named = {n: v for n, v in ks.items() if hint and hint in n}
+            name, k = max((named or ks).items(), key=lambda kv: total(kv[1]))
+            per_launch = total(k)
             src = {"file": os.path.relpath(path, ROOT), "collected_at_commit": rec.get("commit"), "kernel": name,
                    "how": "tools/pmc_traffic.sh (separate --pmc passes of WRITE_SIZE / FETCH_SIZE, FETCH_SIZE x2 on gfx950)",
                    "hbm_bytes_per_step_all_kernels": rec.get("hbm_bytes_per_step"),
                    "kernels_per_step": {n: v["hbm_bytes_per_step"] for n, v in ks.items()},
+                   "buffers_per_counted_launch": k.get("buffers_per_launch", 1),
                    "note": "a constant read from that file, not a counter of this run"}
             return per_launch, src
     if not (args.workload == "pulseosc" and V == 4096):
@@ -705,26 +783,56 @@ def traffic_record(args, V, F, kernel_hint=None):
     return None, None
 
 
-def rocprof_record(args, V):
-    """The rocprofv3 --kernel-trace --stats average of the dominant kernel for this workload, if a committed
-    summary exists (profiles/r02 first) -- the figure `roofline.launch_ms_hip_events` should agree with."""
+# kernels whose instantiations differ in a trailing template argument that zh_graph_kernels reports as "[batch]": the suffix of the
+# rocprofv3 name of the instantiation that paints several buffers per launch / one buffer
+BATCH_SUFFIX = {"k_osc_const4": ("true>(OscArgs)", "false>(OscArgs)")}
+
+
+def select_kernel_row(rows, kernel, batch=False, launch_us=None):
+    """Which row of a rocprofv3 kernel_stats.csv is the kernel the timed launches ran.  `kernel`: the name the library reported
+    (zh_graph_kernels / zh_last_form: no template arguments); `batch`: the several-buffers-per-launch instantiation; `launch_us`:
+    the HIP-event time per launch of this run.  Rows of that kernel, then the instantiation by its suffix where the family is known
+    (BATCH_SUFFIX), else the row whose average is nearest the HIP-event time; -> (row, how) or (None, why)."""
+    base = (kernel or "").split("<")[0].split("[")[0]
+    if not base:
+        return None, "no kernel name"
+    named = [r for r in rows if (" " + base + "<") in (" " + r.get("Name", "")) or (" " + base + "(") in (" " + r.get("Name", ""))]
+    if not named:
+        return None, "no row of " + base
+    if base in BATCH_SUFFIX:
+        suffix = BATCH_SUFFIX[base][0 if batch else 1]
+        inst = [r for r in named if r["Name"].rstrip().endswith(suffix)]
+        if inst:
+            return max(inst, key=lambda r: float(r.get("TotalDurationNs", 0) or 0)), "the %s instantiation of %s (..%s)" % ("batch" if batch else "one-buffer", base, suffix)
+    if len(named) > 1 and launch_us:
+        return min(named, key=lambda r: abs(float(r.get("AverageNs", 0) or 0) / 1e3 - launch_us)), "the instantiation of %s nearest this run's HIP-event time per launch" % base
+    return max(named, key=lambda r: float(r.get("TotalDurationNs", 0) or 0)), "the only / largest row of " + base
+
+
+def rocprof_record(args, V, kernel=None, batch=False, launch_us=None, driver_form=False):
+    """The rocprofv3 --kernel-trace --stats average of the kernel the timed launches ran (select_kernel_row), from the committed summary of
+    this workload -- collected at the driver's arguments (`*_driver_args_kernel_stats.csv`) when this run is the driver's form -- the
+    figure `roofline.launch_ms_hip_events` should agree with and `roofline.frac_kernel` is made from."""
     import csv
     tag = {4096: "4096", 65536: "65536", 131072: "131072", 1048576: "1M"}.get(V)
     if tag is None:
         return None
     if getattr(args, "tolerant", False):
         tag += "_tolerant"
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, f"{args.workload}{tag}_kernel_stats.csv")
-        if not os.path.exists(path):
-            continue
-        best = None
-        for row in csv.DictReader(open(path)):
-            if best is None or float(row.get("TotalDurationNs", 0) or 0) > float(best.get("TotalDurationNs", 0) or 0):
-                best = row
-        if best:
-            return {"file": f"profiles/{rnd}/{args.workload}{tag}_kernel_stats.csv", "kernel": best.get("Name", "")[:80],
-                    "calls": int(float(best.get("Calls", 0) or 0)), "average_us": float(best.get("AverageNs", 0) or 0) / 1e3}
+    names = ([f"{args.workload}{tag}_driver_args_kernel_stats.csv"] if driver_form else []) + [f"{args.workload}{tag}_kernel_stats.csv"]
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
+        for fn in names:
+            path = os.path.join(ROOT, "profiles", rnd, fn)
+            if not os.path.exists(path):
+                continue
+            rows = list(csv.DictReader(open(path)))
+            best, how = select_kernel_row(rows, kernel, batch, launch_us)
+            if best is None:                                   # (no name from the library: the row with the largest total, as before)
+                best = max(rows, key=lambda r: float(r.get("TotalDurationNs", 0) or 0)) if rows else None
+                how = "the row with the largest total duration (" + how + ")"
+            if best:
+                return {"file": f"profiles/{rnd}/{fn}", "kernel": best.get("Name", "")[:96], "selected": how,
+                        "calls": int(float(best.get("Calls", 0) or 0)), "average_us": float(best.get("AverageNs", 0) or 0) / 1e3}
     return None
 
 
@@ -900,6 +1008,7 @@ def main():
             # hipGraph and replayed.
             self.G = wl.graph_steps(steps) if not args.eager else 0
             self.graph = None
+            self.graph_kernels = []
             self.graph_nodes, self.graph_held, self.graph_launches = 0, 0, 0
             if self.G:
                 for _ in range(self.G):          # one eager pass first: lazy allocations happen outside capture
@@ -921,8 +1030,16 @@ def main():
                 # buffer n, on the context's side stream: csrc/composite.hip zh_noise_filter_paint); nothing is held back, so graph_held stays 0
                 # nice_mix (stereo): the same flag holds back zh_nice_paint_mix_stereo calls -- up to 8 consecutive buffers per launch, the launch
                 # zh_nice_paint_mix_stereo_batch makes (state words in registers from buffer to buffer, one second pass; same bits)
+                wl.graph_first_image = wl.i                   # buffer j of a replay lands in ring[(this + j) % nring]
                 self.graph = ctx.capture(lambda: [wl.step() for _ in range(self.G)], coalesce=(((name == "pulseosc" or (name == "nice_mix" and args.channels == 2) or (name == "noise_filter_fused" and self.wl.tolerant)) and os.environ.get("ZH_BENCH_IN_ORDER") != "1") if coalesce is None else coalesce))
                 self.graph_nodes, self.graph_held, self.graph_launches = self.graph.info()
+                # what a replay RUNS: the kernels launched while recording (zh_graph_kernels) -- a paint that was held back went out
+                # later, in another shape, than the eager pass above showed (the line named k_nf_tp_b for k_nf_tp_ba launches)
+                self.graph_kernels = self.graph.kernels()
+                if self.graph_kernels:
+                    wl.kernels_launched = ["%s x%d" % kn for kn in self.graph_kernels]
+                    dom = max(self.graph_kernels, key=lambda kn: (kn[0].endswith("_tp_ba"), kn[1] * (3 if "[batch]" in kn[0] else 1)))
+                    wl.kernel, wl.kernel_batch = dom[0].split("[")[0], "[batch]" in dom[0]
             # (event records captured INTO the graph would take two host calls off the timed path, but hipEventElapsedTime
             # refuses events recorded by graph nodes on this ROCm: "invalid resource handle", profiles/r04/probe_region.txt)
             self.ev0, self.ev1 = make_event(), make_event()
@@ -1075,7 +1192,6 @@ def main():
                 "ms_per_step_wall_all": [round(w, 6) for w in walls],
                 "note": "`value`, `ms_per_step` and `roofline` come from the first region only"}
 
-    traffic, traffic_src = traffic_record(args, V, F, wl.kernel)
     total_units = world * V * F * K
     value = total_units / elapsed
     achieved = wl.bytes_per_step / (step_ms_events * 1e-3) / 1e9
@@ -1084,13 +1200,23 @@ def main():
     pipelined = graph is not None and main_run.graph_held > 0 and args.workload == "noise_filter_fused"     # (one fused launch per buffer + the last pass B)
     if graph is not None and main_run.graph_held and K % G == 0 and not pipelined:
         launches = (K // G) * main_run.graph_launches
+    batch = bool(getattr(wl, "kernel_batch", False))
+    driver_form = (K_req, args.warmup) == (20, 5)
+    traffic, traffic_src = traffic_record(args, V, F, wl.kernel, batch=batch, driver_form=driver_form, pipelined=pipelined)
     if traffic is not None and launches != K:
-        # the PMC passes run one buffer per launch (--eager); a coalesced launch moves that per buffer (the 114 KiB constants table and
-        # the counters are read once per launch instead of once per buffer: the product is an upper bound by < 1 %)
-        traffic = traffic * K / launches
-        traffic_src["note"] += "; counted per one-buffer launch and multiplied by the buffers of a coalesced launch"
+        per = traffic_src.get("buffers_per_counted_launch", 1)
+        if per != K / launches:
+            # counted on launches of `per` buffers; this run's launches paint K / launches each (the 114 KiB constants table and the
+            # counters are read once per launch: scaling by buffers is an upper bound by < 1 %)
+            traffic = traffic * (K / launches) / per
+            traffic_src["note"] += "; counted per launch of %g buffer(s) and scaled to the %g buffers of this run's launches" % (per, K / launches)
+    rp = rocprof_record(args, V, kernel=wl.kernel, batch=batch, launch_us=ev_ms / launches * 1e3, driver_form=driver_form)
     out = {
         "metric": "voice-samples/sec", "value": value, "unit": "voice-samples/s",
+        # what one step of `value` is on the device (the form changed in round 5 under the same name): rounds 1-4 = "one launch per step"
+        "value_form": ("eager: one launch per step" if graph is None else
+                       "hipGraph, ZH_CAPTURE_COALESCE: %g buffers per launch" % (K / launches) if launches != K else
+                       "hipGraph, ZH_CAPTURE_COALESCE: pass B of buffer n + pass A of buffer n + 1 per launch" if pipelined else "hipGraph: one kernel node per step"),
         "n_gpus": world, "steps": K, "warmup": args.warmup, "rehearsal_regions": rehearsals,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -1112,7 +1238,9 @@ def main():
                      "frac_of_measured_store_rate": achieved / HBM_STORE_GBS,   # also quote / 6200 "achievable"
                      "algorithmic_bytes_per_launch": wl.bytes_per_step * K / launches, "launch_ms_hip_events": ev_ms / launches,
                      "launches_in_region": launches, "buffers_per_launch": K / launches,
-                     "rocprofv3_kernel_average": rocprof_record(args, V)},
+                     # the same bytes over the rocprofv3 per-kernel average of the instantiation that ran (no inter-launch gaps): the kernel's own rate
+                     "frac_kernel": (wl.bytes_per_step * K / launches / (rp["average_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp and rp.get("average_us") else None,
+                     "rocprofv3_kernel_average": rp},
         "equiv_write_GBs_whole_job": value * 4 / 1e9,
     }
     if args.tolerant:
@@ -1285,6 +1413,11 @@ def main():
     if rank == 0 and not args.no_parity and (world == 1 or mixdown):
         # (N > 1: rank 0's shard of the mixdown workload; local launches only, the other ranks wait at the last barrier)
         out["parity"] = parity_check_mix(wl, ctx) if mixdown else parity_check(wl, ctx)
+        if world == 1 and graph is not None and not mixdown:
+            # ... and the LAST buffer of one more replay of the timed graph itself -- the coalesced / pipelined launches the line is about
+            pg = parity_check_graph(main_run, ctx)
+            if pg:
+                out["parity_of_a_graph_replay"] = pg
     if rank == 0 and world == 1 and not args.no_cpu:
         cb = cpu_baseline(args, wl)
         if cb:

@@ -198,6 +198,10 @@ ZH_API int  zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags);
 /* how a graph was recorded: nodes in it; paint calls that were held back while recording and the launches they became
  * (both 0 without ZH_CAPTURE_COALESCE) */
 ZH_API int  zh_graph_info(const zh_graph *graph, uint32_t *nodes, uint32_t *paints_held, uint32_t *launches_of_held);
+/* the kernels a replay of the graph runs, in order of first launch while recording, with their counts: "k_osc_const4[batch] x2",
+ * "k_nf_tp_a x1,k_nf_tp_ba x19,k_nf_tp_b x1" ([batch]: the instantiation that paints several buffers per launch).  What
+ * bench.py's roofline record names: zh_last_form after a paint CALL says nothing about a paint that was held back. */
+ZH_API int  zh_graph_kernels(const zh_graph *graph, char *out, size_t n);
 ZH_API int  zh_graph_end_capture(zh_ctx *ctx, zh_graph **out);
 ZH_API int  zh_graph_launch(zh_ctx *ctx, zh_graph *graph);
 ZH_API int  zh_graph_destroy(zh_graph *graph);

@@ -284,6 +284,7 @@ SIGNATURES = {
     "zh_graph_begin_capture": (C.c_int, [vp]),
     "zh_graph_begin_capture_flags": (C.c_int, [vp, C.c_uint32]),
     "zh_graph_info": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]),
+    "zh_graph_kernels": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "zh_graph_end_capture": (C.c_int, [vp, P(vp)]),
     "zh_graph_launch": (C.c_int, [vp, vp]),
     "zh_graph_destroy": (C.c_int, [vp]),

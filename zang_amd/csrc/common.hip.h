@@ -15,6 +15,7 @@
 #include "../../include/zang_hip.h"
 
 #if !defined(ZH_DEVICE_ONLY)
+#include <utility>
 #include <vector>
 #include <functional>
 #include <memory>
@@ -73,6 +74,9 @@ struct zh_ctx {
     bool capturing;
     uint32_t capture_serial;     // counts the captures begun on this context (a module's pipeline chain belongs to one capture)
     std::vector<zh_flip_use> capture_log;
+    // the kernels launched while the capture was recording, in order of first launch, with their counts (zh_graph_kernels): what
+    // a replay of the graph runs -- a held-back batch goes out under the entry point that ends it, not under the paint call
+    std::vector<std::pair<std::string, uint32_t>> capture_kernels;
     void *noise_jump;            // xoshiro256++ jump tables (noise_jump.hip), built on first use, freed with the context
 };
 
@@ -83,6 +87,7 @@ struct zh_graph {
     std::vector<zh_flip_use> flips;
     uint32_t nodes = 0;          // nodes of the recorded graph
     uint32_t co_paints = 0, co_launches = 0;   // ZH_CAPTURE_COALESCE: paint calls held back while recording, launches they became
+    std::vector<std::pair<std::string, uint32_t>> kernels;   // zh_ctx::capture_kernels of the capture
 };
 
 // Every entry point that allocates or launches runs with the context's device current and restores the caller's
@@ -137,6 +142,9 @@ bool zh_form_is_set(int id);                 // the row is overridden through ZH
 uint32_t zh_range_frames(uint32_t V, uint32_t n, int form, uint32_t target_waves, uint32_t max_voices);
 // every kernel launch of the library: notes the kernel's name in the context of the entry point that is running (zh_last_form)
 void zh_note_launch(zh_ctx *ctx, const char *kernel);
+// a word on the NEXT launch for a capture's kernel list (zh_graph_kernels): "batch" = the instantiation that paints several buffers
+// (the kernel name alone is the same: the template arguments at a launch site are names, not values)
+extern thread_local const char *zh_tls_launch_detail;
 
 // frames per group of the fused mixdown's partial layout [channel][frame / G][row][frame % G] (composite.hip writes, basics.hip
 // k_mix_pass2_wide reads: one second-pass workgroup per group and channel)

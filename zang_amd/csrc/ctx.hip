@@ -259,6 +259,7 @@ int zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags) { ZH_GUARD(ctx);
     ctx->epoch_open = false;
     ctx->co = zh_co_batch{};
     ctx->co_paints = ctx->co_launches = 0;
+    ctx->capture_kernels.clear();
     return ZH_OK;
 }
 int zh_graph_begin_capture(zh_ctx *ctx) { return zh_graph_begin_capture_flags(ctx, 0); }
@@ -291,6 +292,7 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
     ctx->graphs.push_back(zg);
     zg->flips.swap(log);
     zg->co_paints = ctx->co_paints; zg->co_launches = ctx->co_launches;
+    zg->kernels.swap(ctx->capture_kernels);
     size_t nn = 0;
     if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) zg->nodes = (uint32_t)nn;
     (void)hipGetLastError();
@@ -325,6 +327,19 @@ int zh_graph_info(const zh_graph *graph, uint32_t *nodes, uint32_t *paints_held,
     if (nodes) *nodes = graph->nodes;
     if (paints_held) *paints_held = graph->co_paints;
     if (launches_of_held) *launches_of_held = graph->co_launches;
+    return ZH_OK;
+}
+
+int zh_graph_kernels(const zh_graph *graph, char *out, size_t n) {
+    if (!graph || !out || n == 0) return ZH_ERR_INVALID;
+    std::string s;
+    for (const auto &kv : graph->kernels) {
+        if (!s.empty()) s += ',';
+        s += kv.first + " x" + std::to_string(kv.second);
+    }
+    const size_t k = s.size() < n - 1 ? s.size() : n - 1;
+    memcpy(out, s.data(), k);
+    out[k] = 0;
     return ZH_OK;
 }
 

@@ -113,8 +113,23 @@ uint32_t zh_range_frames(uint32_t V, uint32_t n, int form, uint32_t target_waves
     return (n + ch - 1) / ch >= 2 ? ch : 0;
 }
 
+thread_local const char *zh_tls_launch_detail = nullptr;
+
 void zh_note_launch(zh_ctx *ctx, const char *kernel) {
+    const char *detail = zh_tls_launch_detail;
+    zh_tls_launch_detail = nullptr;
     if (!ctx) return;
+    if (ctx->capturing) {                                     // the capture's own list: every launch counted, the detail kept
+        const char *b0 = kernel;
+        while (*b0 == '(' || *b0 == ' ') b0++;
+        size_t n0 = 0;
+        while (b0[n0] && b0[n0] != '<' && b0[n0] != ')' && b0[n0] != ' ') n0++;
+        std::string key(b0, n0);
+        if (detail) { key += '['; key += detail; key += ']'; }
+        bool found = false;
+        for (auto &kv : ctx->capture_kernels) if (kv.first == key) { kv.second++; found = true; break; }
+        if (!found && ctx->capture_kernels.size() < 64) ctx->capture_kernels.emplace_back(key, 1u);
+    }
     std::string &f = ctx->last_form;
     if (ctx->form_fresh) { f.clear(); ctx->form_fresh = false; }
     if (f.size() > 480) return;

@@ -487,7 +487,7 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
                                       else if (use_tab) ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, true, false, B>), grid, dim3(256), 0, st, a); \
                                       else if (fc4) ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, false, true, B>), grid, dim3(256), 0, st, a); \
                                       else ZH_LAUNCH((k_osc_const4<OSC, ZF, SM, false, false, B>), grid, dim3(256), 0, st, a); } while (0)
-#define ZH_LAUNCH_O4(ZF, SM) do { if (cnt_b > 1) ZH_LAUNCH_O4B(ZF, SM, true); else ZH_LAUNCH_O4B(ZF, SM, false); } while (0)
+#define ZH_LAUNCH_O4(ZF, SM) do { if (cnt_b > 1) { zh_tls_launch_detail = "batch"; ZH_LAUNCH_O4B(ZF, SM, true); } else ZH_LAUNCH_O4B(ZF, SM, false); } while (0)
             if (zf) { if (sm == ST_PLAIN) ZH_LAUNCH_O4(true, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(true, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(true, ST_SC1); else ZH_LAUNCH_O4(true, ST_SC0SC1); }
             else    { if (sm == ST_PLAIN) ZH_LAUNCH_O4(false, ST_PLAIN); else if (sm == ST_NT) ZH_LAUNCH_O4(false, ST_NT); else if (sm == ST_SC1) ZH_LAUNCH_O4(false, ST_SC1); else ZH_LAUNCH_O4(false, ST_SC0SC1); }
 #undef ZH_LAUNCH_O4

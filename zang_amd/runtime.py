@@ -107,6 +107,18 @@ class Graph:
         abi.check(self.ctx.lib.zh_graph_info(self.handle, C.byref(n), C.byref(p), C.byref(l)), "zh_graph_info")
         return n.value, p.value, l.value
 
+    def kernels(self):
+        """[(kernel, launches)] a replay of the graph runs, in order of first launch while recording (zh_graph_kernels);
+        "k_osc_const4[batch]" = the instantiation that paints several buffers per launch"""
+        buf = C.create_string_buffer(2048)
+        abi.check(self.ctx.lib.zh_graph_kernels(self.handle, buf, len(buf)), "zh_graph_kernels")
+        out = []
+        for item in buf.value.decode().split(","):
+            if item:
+                name, _, n = item.rpartition(" x")
+                out.append((name, int(n)))
+        return out
+
     def close(self):
         if self.handle:
             self.ctx.lib.zh_graph_destroy(self.handle)
