@@ -475,6 +475,41 @@ def test_coalescing_capture_of_the_bench_step_matches_oracle(ctx, oracle):
                     util.assert_bitexact(got[step - 1 - 2 * K][q], ref, f"K={K} voice {v} step {step}")
             assert int(cnt[q]) == int(st.cnt), (K, v)
 
+@pytest.mark.gpu
+def test_coalescing_capture_refuses_a_mixdown_its_scratch_cannot_hold():
+    """ADVICE r5 (composite.hip): in a ZH_CAPTURE_COALESCE capture zh_nice_paint_mix_stereo used to return ZH_OK as soon as it held
+    the paint back, and the launch made later on its behalf dropped its error -- with no partial-sum scratch reserved (it cannot grow
+    while a capture records) the recorded graph silently lacked the paint.  The paint call itself now answers, as in a capture
+    without the flag; after an eager paint has sized the scratch the same capture records, and replays the eager result."""
+    import torch
+    import zang_amd
+    from zang_amd import abi, modules as mod, zang, workloads
+    V = 4096
+    freq, color, u2, _ = workloads.voice_params(5, 1, V)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0)                                         # a fresh context: no scratch yet
+        gl = util.dev((0.25 + 0.5 * u2).astype(np.float32)); gr = util.dev((0.75 - 0.5 * u2).astype(np.float32))
+        m = mod.NiceInstrument(V, util.dev(color), c2)
+        sp = zang.Span(0, F)
+        l = torch.zeros((2, F), device="cuda"); r = torch.zeros((2, F), device="cuda")
+        P = m.Params(SR, util.dev(freq), True)
+        two = lambda: [m.paint_mix_stereo(sp, l[k], r[k], gl, gr, k == 0, P, zero_first=True) for k in range(2)]
+        for coalesce in (False, True):
+            with pytest.raises(abi.ZangHipError):
+                c2.capture(two, coalesce=coalesce)
+        st0 = m.state()
+        two(); c2.sync()                                                 # eager: reserves
+        want_l, want_r = l.clone(), r.clone()
+        m.set_state(st0)
+        l.zero_(); r.zero_()
+        g = c2.capture(two, coalesce=True)
+        assert g.info()[1] == 2 and [k for k, _ in g.kernels()][0].startswith("k_nice_mix")
+        g.launch(); c2.sync()
+        assert torch.equal(l.view(torch.int32), want_l.view(torch.int32)) and torch.equal(r.view(torch.int32), want_r.view(torch.int32))
+        g.close(); c2.close()
+
+
 
 @pytest.mark.parametrize("V", [300, 4096])
 def test_coalesced_nice_mixdowns_equal_separate_calls(V):

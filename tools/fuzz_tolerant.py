@@ -34,6 +34,18 @@ def sample(V, rng, n=96):
     return np.arange(V) if V <= n else np.unique(rng.integers(0, V, n))
 
 
+def tiny_cutoffs(rng, cut, idx):
+    """Half of the seeds: some of the SAMPLED voices (the ones the oracle checks) get a clamped cutoff log-uniform in 3e-8 .. 1e-2 --
+    the region below kTpExactCutBelow = 2^-9 (csrc/filter_tp.hip.h), where the output is the filter's dc-offset ramp and a chunked
+    evaluation departs from the reference's own f32 accumulation (round 5's known exception): those voices take the exact walk now.
+    The uniform draw of the other params reaches that region in 1 of ~1e5 voices."""
+    if rng.random() < 0.5:
+        for v in idx:
+            if rng.random() < 0.15:
+                cut[v] = np.float32(10.0 ** rng.uniform(-7.5, -2.0))
+    return cut
+
+
 def main():
     import zang_amd
     from zang_amd import modules as mod, zang, workloads
@@ -60,6 +72,7 @@ def main():
                 ftype = int(rng.integers(1, 6))
                 cut = rng.uniform(-0.1, 1.1, V).astype(np.float32); res = rng.uniform(-0.1, 1.1, V).astype(np.float32)
                 inp = util.rng_buffers(seed + 7, V, F, -1.0, 1.0) * np.float32(rng.choice([1.0, 1.0, 1e-6, 1e6]))
+                cut = tiny_cutoffs(rng, cut, idx)
                 sts = []
                 for v in idx:
                     st = oracle.Filter(); L.zo_filter_init(C.byref(st)); sts.append(st)
@@ -89,6 +102,7 @@ def main():
                 fseed = int(rng.integers(0, 1 << 20))
                 ftype = int(rng.integers(1, 6))
                 cut = rng.uniform(0.0, 1.0, V).astype(np.float32); res = rng.uniform(0.0, 0.95, V).astype(np.float32)
+                cut = tiny_cutoffs(rng, cut, idx)
                 nzs, fls = [], []
                 for v in idx:
                     nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), fseed + int(v)); nzs.append(nz)
@@ -130,6 +144,10 @@ def main():
             elif kind == "nice":
                 freq, color, _, _ = workloads.voice_params(5, int(rng.integers(0, 1000)), V)
                 freq = (freq * np.float32(rng.choice([1.0, 0.25, 3.0]))).astype(np.float32)
+                if rng.random() < 0.5:                                  # sub-audio voices: the filter's cutoff, cutoffFromFrequency(8 f), below 2^-9
+                    for v in idx:
+                        if rng.random() < 0.1:
+                            freq[v] = np.float32(10.0 ** rng.uniform(-3.0, 0.6))
                 sts = []
                 for v in idx:
                     st = oracle.NiceInstrument(); L.zo_nice_init(C.byref(st), float(color[v])); sts.append(st)
@@ -165,7 +183,7 @@ def main():
                 D = int(rng.choice([64, 100, 300, 342, 512, 600, 1023, 1024, 1025, 2000, 5000, 15000]))
                 if V * D > 4e7:
                     D = 2000                                             # (the ring: D x V floats, fetched after every span)
-                fb = rng.uniform(0.0, 0.95, V).astype(np.float32); cutoff = rng.uniform(-0.1, 1.1, V).astype(np.float32)
+                fb = rng.uniform(0.0, 0.95, V).astype(np.float32); cutoff = tiny_cutoffs(rng, rng.uniform(-0.1, 1.1, V).astype(np.float32), idx)
                 ridx = rng.integers(0, D, V).astype(np.uint32) if rng.random() < 0.3 else np.full(V, int(rng.integers(0, D)), np.uint32)
                 rings0 = rng.uniform(-1, 1, (V, D)).astype(np.float32)
                 rings = rings0[idx].copy(); ds, fls = [], []

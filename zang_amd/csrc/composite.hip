@@ -373,6 +373,19 @@ __device__ __forceinline__ void nice_tp_put_env(const NiceTpArgs &t, uint32_t j,
     nice_tp_env(t, j, 2)[v] = __builtin_bit_cast(uint32_t, n.env.last_value); nice_tp_env(t, j, 3)[v] = __builtin_bit_cast(uint32_t, n.env.start);
 }
 
+// A voice whose filter cutoff is near zero (filter_tp.hip.h kTpExactCutBelow; here cutoffFromFrequency(8 x freq): a voice below ~4 Hz)
+// takes no chunk start state from the scan: its lane replays the filter over the frames before its chunk from the span's start
+// state -- the reference's own recurrence over the same oscillator samples (the counter of any frame is exact), bit for bit.
+__device__ __forceinline__ void nice_tp_exact_start(NiceLane &n, float2 s0, uint32_t cnt_start, uint32_t frames_before) {
+    if (!(n.cut < kTpExactCutBelow)) return;
+    float l = s0.x, b = s0.y;
+    uint32_t c = cnt_start;
+    for (uint32_t f = 0; f < frames_before; f++) {
+        svf_step(l, b, n.osc(c), n.cut, n.res);                        // NiceLane::tail_filter's recurrence (k_nice_tp_a)
+        c += n.k.ifreq;
+    }
+    n.l = l; n.b = b;
+}
 // grid: x = 256-voice groups, y = chunk; block = 256
 __global__ void __launch_bounds__(256) k_nice_tp_a(const NiceTpArgs t) {
     const uint32_t j = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
@@ -438,6 +451,7 @@ __global__ void __launch_bounds__(256) k_nice_tp_b(const NiceTpArgs t) {
     a0.elast = reinterpret_cast<float *>(nice_tp_state0(t, 5)); a0.estart = reinterpret_cast<float *>(nice_tp_state0(t, 6));
     NiceLane n;
     nice_load(n, a0, v);
+    const uint32_t cnt_f0 = n.cnt;
     n.cnt = n.cnt + (f0 - t.start) * n.k.ifreq;
     {   // the filter's state at the chunk's first frame
         const float2 s0 = nice_tp_e(t, 0)[v];
@@ -445,6 +459,7 @@ __global__ void __launch_bounds__(256) k_nice_tp_b(const NiceTpArgs t) {
         const float2 *e = nice_tp_e(t, 1) + v;
         const size_t V = a.V;
         svf_scan<kNiceTpMaxChunks - 1>(n.l, n.b, n.cut, n.res, t.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return e[(size_t)i * V]; });
+        nice_tp_exact_start(n, s0, cnt_f0, f0 - t.start);
     }
     // the envelope at the chunk's first frame: the four state words of pass A's walk, the running stage re-derived from them
     n.env.state = nice_tp_env(t, j, 0)[v]; n.env.t = __builtin_bit_cast(float, nice_tp_env(t, j, 1)[v]);
@@ -499,6 +514,7 @@ __global__ void __launch_bounds__(256) k_nice_mix_tp_b(const NiceTpArgs t, float
     a0.elast = reinterpret_cast<float *>(nice_tp_state0(t, 5)); a0.estart = reinterpret_cast<float *>(nice_tp_state0(t, 6));
     NiceLane n;
     nice_load(n, a0, vc);
+    const uint32_t cnt_f0 = n.cnt;
     n.cnt = n.cnt + (f0 - t.start) * n.k.ifreq;
     {
         const float2 s0 = nice_tp_e(t, 0)[vc];
@@ -506,6 +522,7 @@ __global__ void __launch_bounds__(256) k_nice_mix_tp_b(const NiceTpArgs t, float
         const float2 *e = nice_tp_e(t, 1) + vc;
         const size_t V = a.V;
         svf_scan<kNiceTpMaxChunks - 1>(n.l, n.b, n.cut, n.res, t.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return e[(size_t)i * V]; });
+        nice_tp_exact_start(n, s0, cnt_f0, f0 - t.start);
     }
     n.env.state = nice_tp_env(t, j, 0)[vc]; n.env.t = __builtin_bit_cast(float, nice_tp_env(t, j, 1)[vc]);
     n.env.last_value = __builtin_bit_cast(float, nice_tp_env(t, j, 2)[vc]); n.env.start = __builtin_bit_cast(float, nice_tp_env(t, j, 3)[vc]);
@@ -1588,7 +1605,7 @@ static int nice_paint_mix_batch_impl(zh_nice *m, uint32_t start, uint32_t end, u
                                      float *const *mix_right, zh_f32 gain_left, zh_f32 gain_right, const zh_bool *note_id_changed,
                                      const zh_nice_params *params, uint32_t flags);
 struct NiceHeld { float *l, *r; zh_bool nic; zh_nice_params p; };
-struct NiceHeldBatch { std::vector<NiceHeld> v; zh_f32 gl, gr; };
+struct NiceHeldBatch { std::vector<NiceHeld> v; zh_f32 gl, gr; uint32_t flags, sample_rate_bits; };   // (what a joining paint must share, each compared on its own)
 static bool same_f32(const zh_f32 &a, const zh_f32 &b) {
     return a.per_voice == b.per_voice && (a.per_voice || __builtin_bit_cast(uint32_t, a.value) == __builtin_bit_cast(uint32_t, b.value));
 }
@@ -1598,14 +1615,24 @@ int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mi
     zh_ctx *ctx = m ? m->ctx : nullptr;
     const bool hold = ctx && ctx->capturing && (ctx->capture_flags & ZH_CAPTURE_COALESCE) && mix_left && p && end > start && m->n &&
                       (!(flags & ZH_PAINT_TOLERANT) || nice_mix_wg(m->n));      // (a tolerant paint of few voices takes the chunked form, alone)
-    if (!hold) {
+    // Held back, the paint is launched later, by whatever ends the batch, and this call has long returned: so everything the launch
+    // could refuse is looked at NOW -- the partial-sum scratch cannot grow while a capture records (zh_mix_reserve), and a paint whose
+    // one buffer it cannot hold is not held: it goes out in order and this call returns what the launch says, as in a capture without
+    // the flag (the recorded graph silently lacked such paints).
+    bool fits = false;
+    if (hold) {
+        const uint32_t blocks = (m->n + 255u) / 256u, rows = nice_mix_wg(m->n) ? blocks : blocks * 4;
+        const uint32_t groups = (end - start + kMixGroupFrames - 1) / kMixGroupFrames;
+        fits = (size_t)rows * kMixGroupFrames * groups * 2 <= ctx->mix_partials_floats;
+    }
+    if (!hold || !fits) {
         if (ctx && ctx->epoch_open) zh_epoch_barrier(ctx);
         return nice_paint_mix_n(m, start, end, mix_left, mix_right, &gain_left, &gain_right, note_id_changed, p, flags);
     }
     zh_co_batch &cb = ctx->co;
     std::shared_ptr<NiceHeldBatch> held = cb.active && cb.owner == m ? std::static_pointer_cast<NiceHeldBatch>(cb.items) : nullptr;
-    const uint32_t key = flags ^ __builtin_bit_cast(uint32_t, p->sample_rate);
-    bool join = held && cb.start == start && cb.end == end && cb.key == key && held->v.size() < kNiceCoalesceMax &&
+    const uint32_t sr_bits = __builtin_bit_cast(uint32_t, p->sample_rate);
+    bool join = held && cb.start == start && cb.end == end && held->flags == flags && held->sample_rate_bits == sr_bits && held->v.size() < kNiceCoalesceMax &&
                 same_f32(held->gl, gain_left) && same_f32(held->gr, gain_right);
     for (size_t q = 0; join && q < held->v.size(); q++) {
         const float *rows[2] = {held->v[q].l, held->v[q].r};
@@ -1615,9 +1642,9 @@ int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mi
     if (!join) {
         zh_epoch_flush_batch(ctx, false);
         held = std::make_shared<NiceHeldBatch>();
-        held->gl = gain_left; held->gr = gain_right;
+        held->gl = gain_left; held->gr = gain_right; held->flags = flags; held->sample_rate_bits = sr_bits;
         cb.items = held;
-        cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = 0; cb.key = key; cb.flips = false;
+        cb.active = true; cb.owner = m; cb.start = start; cb.end = end; cb.stride = 0; cb.key = 0; cb.flips = false;
         ctx->epoch_open = true;
         std::shared_ptr<NiceHeldBatch> items = held;
         cb.launch = [m, start, end, gain_left, gain_right, flags, items](hipStream_t, float *const *, uint32_t cnt) {
@@ -1627,8 +1654,12 @@ int zh_nice_paint_mix_stereo(zh_nice *m, uint32_t start, uint32_t end, float *mi
             zh_nice_params ps[kNiceCoalesceMax];
             for (uint32_t i = 0; i < cnt; i++) { l[i] = v[i].l; r[i] = v[i].r; nic[i] = v[i].nic; ps[i] = v[i].p; }
             int rc = cnt > 1 ? nice_paint_mix_batch_impl(m, start, end, cnt, l, r, gain_left, gain_right, nic, ps, flags) : ZH_ERR_UNSUPPORTED;
-            if (rc != ZH_OK)                                            // one buffer, or a scratch too small for the batch: buffer by buffer
-                for (uint32_t i = 0; i < cnt; i++) (void)nice_paint_mix_n(m, start, end, l[i], r[i], &gain_left, &gain_right, nic[i], &ps[i], flags);
+            if (rc != ZH_OK) {                                          // one buffer, or a scratch too small for the batch: buffer by buffer
+                for (uint32_t i = 0; i < cnt; i++) {
+                    rc = nice_paint_mix_n(m, start, end, l[i], r[i], &gain_left, &gain_right, nic[i], &ps[i], flags);
+                    if (rc != ZH_OK && !m->ctx->deferred_error) m->ctx->deferred_error = rc;    // (zh_graph_end_capture returns it)
+                }
+            }
         };
     }
     held->v.push_back(NiceHeld{mix_left, mix_right, note_id_changed, *p});
@@ -1852,6 +1883,12 @@ int zh_noise_filter_paint(zh_noise_filter *m, uint32_t start, uint32_t end, cons
             // multi-draw samples (2^-41 per sample) is walked sequentially -- the reference's own walk -- in every later paint of the chain.
             zh_ctx *ctx = m->ctx;
             if (ctx->capturing && (ctx->capture_flags & ZH_CAPTURE_COALESCE) && m->tp_cs2 && end - start <= piece) {
+                {   // (pass A and pass B of two buffers share the launch: the chip is full with longer chunks too, and every chunk less
+                    // saves 40 bytes of scratch traffic per voice -- nf_tp_pipe_frames)
+                    const uint32_t want = (uint32_t)zh_form(ZF_NF_TP_PIPE_FRAMES) / 32u * 32u;
+                    if (want >= 32u && want <= 512u && (end - start + want - 1) / want >= 2u && ((end - start + want - 1) / want - 1) * (want / 32u) <= (uint32_t)kNoiseJumpTables) a.L = want;
+                }
+                const uint32_t L = a.L;
                 struct Pending { NfTpArgs b; uint32_t grid_b; bool zf; };
                 zh_co_batch &cb = ctx->co;
                 std::shared_ptr<Pending> pend = cb.active && cb.owner == m ? std::static_pointer_cast<Pending>(cb.items) : nullptr;

@@ -260,6 +260,7 @@ int zh_graph_begin_capture_flags(zh_ctx *ctx, uint32_t flags) { ZH_GUARD(ctx);
     ctx->co = zh_co_batch{};
     ctx->co_paints = ctx->co_launches = 0;
     ctx->capture_kernels.clear();
+    ctx->deferred_error = 0;
     return ZH_OK;
 }
 int zh_graph_begin_capture(zh_ctx *ctx) { return zh_graph_begin_capture_flags(ctx, 0); }
@@ -282,6 +283,14 @@ int zh_graph_end_capture(zh_ctx *ctx, zh_graph **out) { ZH_GUARD(ctx);
         }
     }
     ZH_TRY(hipStreamEndCapture(ctx->stream, &g));
+    if (ctx->deferred_error) {                                // a held-back paint failed when it was finally launched: no graph
+        const int rc = ctx->deferred_error;
+        ctx->deferred_error = 0;
+        ctx->capture_kernels.clear();
+        if (g) hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc;
+    }
     zh_graph *zg = new (std::nothrow) zh_graph();
     if (!zg) { hipGraphDestroy(g); return ZH_ERR_INVALID; }
     zg->graph = g;

@@ -494,17 +494,32 @@ __global__ void __launch_bounds__(256) k_fe_tp_b(const FeTpArgs a) {
     float l = s0.x, b = s0.y;
     svf_scan<kTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
     const uint32_t voff = v * 4u, rrow = a.d.n * 4u, orow = (uint32_t)a.out.stride * 4u;
-    fe_tp_tiles<!ZF>(a, v, idx0, f0, f1, [&](uint32_t k, float delayed, float x, float base, const zh_rsrc_t &ro, const zh_rsrc_t &rr, bool rows, float *sp) ZH_INLINE_LAMBDA {
+    // a cutoff near zero: not as chunks -- the voice's chunk-0 lane walks the piece frame by frame (filter_tp.hip.h kTpExactCutBelow)
+    const bool exact_v = cut < kTpExactCutBelow;
+    bool store = !exact_v;
+    auto body = [&](uint32_t k, float delayed, float x, float base, const zh_rsrc_t &ro, const zh_rsrc_t &rr, bool rows, float *sp) ZH_INLINE_LAMBDA {
         const SvfOut s = svf_step(l, b, fe_filter_input(delayed, x, feedback), cut, res);   // Filter.paint low_pass (Filter.zig:135-146)
         const float t1 = svf_lowpass_into_zero(s.l, s.b);             // zero(temp1); += (:439)
-        zrow_store<1>(ro, voff, k * orow, base + t1);                 // addInto(output, temp1) (:448)
-        if (rows) zrow_store<1>(rr, voff, k * rrow, t1);              // writeDelayBuffer(temp1) (:452)
-        else *sp = t1;
-    });
-    if (f1 == a.end && f1 > f0) {
+        if (store) {
+            zrow_store<1>(ro, voff, k * orow, base + t1);             // addInto(output, temp1) (:448)
+            if (rows) zrow_store<1>(rr, voff, k * rrow, t1);          // writeDelayBuffer(temp1) (:452)
+            else *sp = t1;
+        }
+    };
+    fe_tp_tiles<!ZF>(a, v, idx0, f0, f1, body);
+    auto leave = [&]() ZH_INLINE_LAMBDA {
         a.l[v] = l; a.b[v] = b;
         const uint32_t s = idx0 + (a.end - a.start);                  // <= delay_samples frames per piece
         a.d.index[v] = (s >= D || s < idx0) ? s - D : s;
+    };
+    if (!exact_v && f1 == a.end && f1 > f0) leave();
+    if (j == 0 && __builtin_amdgcn_ballot_w64(exact_v) != 0) {
+        if (exact_v) {                                                // (a piece is <= delay_samples frames: every slot it reads was written before it)
+            l = s0.x; b = s0.y;
+            store = true;
+            fe_tp_tiles<!ZF>(a, v, idx0, a.start, a.end, body);
+            leave();
+        }
     }
 }
 

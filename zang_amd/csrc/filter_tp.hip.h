@@ -92,6 +92,12 @@ __device__ __forceinline__ void svf_scan(float &l, float &b, float cut, float re
 }
 
 constexpr uint32_t kTpMaxChunks = 32;    // chunks per launch; a module's scratch holds this many slots whatever a launch uses
+// A voice whose clamped cutoff is below this is NOT painted as chunks: its chunk-0 lane walks the span frame by frame from the
+// module's state -- the reference's own recurrence, bit for bit.  Near a zero cutoff the output is the filter's dc-offset ramp,
+// the reference's f32 accumulation of that nearly constant increment drifts systematically from exact arithmetic, and no chunked
+// evaluation follows it (round 5: 1.9e-5 of the peak at cutoff 6e-6; tools/exp/filter_tp_error.py over log-uniform cutoffs: up to
+// 1e-4 below 1e-4, under 1e-5 from 1e-3 on).  2^-9 = cutoffFromFrequency(15 Hz at 48 kHz): below the audio band.
+constexpr float kTpExactCutBelow = 0.001953125f;
 
 #if !defined(ZH_DEVICE_ONLY)
 // chunks for a span of n frames of V voices: enough for ~2,048 waves (two per SIMD), 2..32; 0 = too many voices for the form
@@ -115,6 +121,8 @@ struct FilterTpArgs {
     float *l, *b;
     float2 *e;
     float4 *m;                   // control-image cutoff / resonance: chunk j's transition matrix (slot j), [chunks][V]
+    uint32_t *flag;              // [V]: == serial when a frame of the cutoff IMAGE was below kTpExactCutBelow in this piece (pass A -> pass B)
+    uint32_t serial;             // this piece's number (never 0; flags are never cleared: an old number is "not flagged")
     uint32_t V, start, end, L;
     Img out;
     CImg input;
@@ -169,10 +177,13 @@ __global__ void __launch_bounds__(256) k_filter_tp_a(const FilterTpArgs a) {
     const float res = RB ? 0.0f : 1.0f - zclampf(a.res.c.get(v), 0.0f, 1.0f);      // :118
     float l = 0.0f, b = 0.0f;
     float ul = 1.0f, ub = 0.0f, wl = 0.0f, wb = 1.0f;                               // the unit states (CB || RB)
+    float cmin = 1.0f;
     tp_input_tiles<CB, RB>(a, v * 4u, f0, f1, cut, res, [&](uint32_t, float in, float c, float r) ZH_INLINE_LAMBDA {
         svf_core(l, b, in, c, r);
+        if (CB) cmin = c < cmin ? c : cmin;
         if (CB || RB) { svf_hom_step(ul, ub, c, r); svf_hom_step(wl, wb, c, r); }
     });
+    if (CB && cmin < kTpExactCutBelow) a.flag[v] = a.serial;                         // (pass B walks this voice: kTpExactCutBelow)
     a.e[(size_t)(j + 1) * a.V + v] = make_float2(l, b);
     if (CB || RB) a.m[(size_t)j * a.V + v] = make_float4(ul, wl, ub, wb);            // (m00, m01, m10, m11)
 }
@@ -204,22 +215,35 @@ __global__ void __launch_bounds__(256) k_filter_tp_b(const FilterTpArgs a) {
         svf_scan<kTpMaxChunks - 1>(l, b, cut, res, a.L, j, [&](uint32_t i) ZH_INLINE_LAMBDA { return a.e[(size_t)(i + 1) * V + v]; });
     }
     const uint32_t voff = v * 4u;
-    tp_input_tiles<CB, RB>(a, voff, f0, f1, cut, res, [&](uint32_t f, float in, float c, float r) ZH_INLINE_LAMBDA {
+    // a cutoff near zero (constant: this voice's; image: a frame of this piece): not as chunks, see kTpExactCutBelow
+    const bool exact_v = CB ? a.flag[v] == a.serial : cut < kTpExactCutBelow;
+    auto frame = [&](uint32_t f, float in, float c, float r, bool store) ZH_INLINE_LAMBDA {
         const SvfOut sv = svf_core(l, b, in, c, r);                   // :138-144
         const float val = sv.l * a.l_mul + sv.b * a.b_mul + sv.h * a.h_mul;   // :146
-        const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
-        const float base = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
-        zrow_store<1>(ro, voff, 0, base + val);
-    });
-    if (f1 == a.end && f1 > f0) { a.l[v] = l; a.b[v] = b; }
+        if (store) {
+            const zh_rsrc_t ro = zrow_rsrc(a.out.p, a.out.stride, f);
+            const float base = ZF ? 0.0f : zrow_load<1>(ro, voff, 0);
+            zrow_store<1>(ro, voff, 0, base + val);
+        }
+    };
+    tp_input_tiles<CB, RB>(a, voff, f0, f1, cut, res, [&](uint32_t f, float in, float c, float r) ZH_INLINE_LAMBDA { frame(f, in, c, r, !exact_v); });
+    if (!exact_v && f1 == a.end && f1 > f0) { a.l[v] = l; a.b[v] = b; }
+    if (j == 0 && __builtin_amdgcn_ballot_w64(exact_v) != 0) {
+        if (exact_v) {                                                // the reference's own walk over the piece, from the module's state
+            l = s0.x; b = s0.y;
+            tp_input_tiles<CB, RB>(a, voff, a.start, a.end, cut, res, [&](uint32_t f, float in, float c, float r) ZH_INLINE_LAMBDA { frame(f, in, c, r, true); });
+            a.l[v] = l; a.b[v] = b;
+        }
+    }
 }
 
 #if !defined(ZH_DEVICE_ONLY)
 // floats of scratch per voice: (kTpMaxChunks + 1) float2 of e, then kTpMaxChunks float4 of transition matrices
-constexpr size_t kFilterTpFloats = (size_t)(kTpMaxChunks + 1) * 2 + (size_t)kTpMaxChunks * 4;
+constexpr size_t kFilterTpFloats = (size_t)(kTpMaxChunks + 1) * 2 + (size_t)kTpMaxChunks * 4 + 1;   // ... and one word of flag (zeroed by whoever allocates)
+constexpr size_t kFilterTpFlagAt = (size_t)(kTpMaxChunks + 1) * 2 + (size_t)kTpMaxChunks * 4;         // (floats per voice before the flags)
 // Launches the span as pieces of <= 32 chunks.  false = not taken (too many voices, a short span): the caller paints with its
 // exact form.  `scratch` = the module's, kFilterTpFloats * V floats.
-static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float *scratch, uint32_t V, Img out, CImg in, uint32_t start, uint32_t end, bool zf,
+static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float *scratch, uint32_t &serial, uint32_t V, Img out, CImg in, uint32_t start, uint32_t end, bool zf,
                                        float l_mul, float b_mul, float h_mul, CobP cut, CobP res) {
     if (end - start < 64) return false;
     const uint32_t C = zh_tp_chunks(V, ZF_FILTER_TP_MAX, end - start);
@@ -227,10 +251,13 @@ static inline bool zh_filter_tp_launch(hipStream_t st, float *l, float *b, float
     const uint32_t piece = 4096;                                      // frames per launch pair: chunks of <= 128 frames
     FilterTpArgs a;
     a.l = l; a.b = b; a.e = reinterpret_cast<float2 *>(scratch); a.m = reinterpret_cast<float4 *>(scratch + (size_t)(kTpMaxChunks + 1) * 2 * V);
+    a.flag = reinterpret_cast<uint32_t *>(scratch + kFilterTpFlagAt * V);
     a.V = V; a.out = out; a.input = in; a.l_mul = l_mul; a.b_mul = b_mul; a.h_mul = h_mul; a.cutoff = cut; a.res = res;
     const bool cb = cut.is_buffer != 0, rb = res.is_buffer != 0;
     for (uint32_t s = start; s < end; s += piece) {
         a.start = s; a.end = min(s + piece, end);
+        if (++serial == 0) serial = 1;
+        a.serial = serial;
         a.L = (a.end - a.start + C - 1) / C;
         const dim3 grid((V + 255) / 256, (a.end - a.start + a.L - 1) / a.L);
 #define ZH_FTP(CB_, RB_)                                                                                   \
@@ -384,7 +411,8 @@ __device__ __forceinline__ void nf_tp_b_run(const NfTpArgs &a, uint32_t bid) {
     const float cut = zclampf(a.cutoff.get(v), 0.0f, 1.0f);
     const float res = 1.0f - zclampf(a.res.get(v), 0.0f, 1.0f);
     const uint32_t voff = v * 4u, orow = (uint32_t)a.out.stride * 4u;
-    const bool flagged = a.flag[v] == a.serial;
+    // walked frame by frame by its chunk-0 lane: a voice that met a multi-draw sample, and a voice whose cutoff is near zero (kTpExactCutBelow)
+    const bool flagged = a.flag[v] == a.serial || cut < kTpExactCutBelow;
     const uint32_t f0 = min(a.start + j * a.L, a.end), f1 = min(f0 + a.L, a.end);     // workgroup-uniform: the frame loops stay scalar
     const uint64_t *cs = a.cs + (size_t)j * 4 * V + v;
     ZXoshiro r{cs[0], cs[V], cs[2 * V], cs[3 * V]};

@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(256) k_gate4(uint32_t nvq, Img out, uint32_t s
 
 // =================================================================== Filter
 struct zh_filter { zh_ctx *ctx; uint32_t n; float *l, *b;
-                   float *tp_e; };    // ZH_PAINT_TOLERANT scratch (filter_tp.hip.h kFilterTpFloats per voice), allocated by the first tolerant paint outside a capture
+                   float *tp_e; uint32_t tp_serial = 0; };    // ZH_PAINT_TOLERANT scratch (filter_tp.hip.h kFilterTpFloats per voice), allocated by the first tolerant paint outside a capture
 
 template <bool ZF, bool CB, bool RB>
 __global__ void __launch_bounds__(kSeqBlock) k_filter(float *__restrict__ l_io, float *__restrict__ b_io, uint32_t V, Img out,
@@ -1843,8 +1843,9 @@ int zh_filter_paint(zh_filter *m, uint32_t start, uint32_t end, const zh_buf *ou
     if ((flags & ZH_PAINT_TOLERANT) && !bufs_alias(p->input, outputs[0]) && !cob_aliases(p->cutoff, outputs[0]) && !cob_aliases(p->res, outputs[0]) &&
         outputs[0].stride <= (1u << 24) && p->input.stride <= (1u << 24) && (!cb || p->cutoff.buffer.stride <= (1u << 24)) && (!rb || p->res.buffer.stride <= (1u << 24))) {
         if (!m->tp_e && !m->ctx->capturing && zh_tp_chunks(m->n, ZF_FILTER_TP_MAX, end - start) >= 2 &&
-            dev_alloc(&m->tp_e, kFilterTpFloats * m->n) != ZH_OK) { m->tp_e = nullptr; (void)hipGetLastError(); }
-        if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut, res))
+            (dev_alloc(&m->tp_e, kFilterTpFloats * m->n) != ZH_OK ||
+             hipMemsetAsync(m->tp_e + kFilterTpFlagAt * m->n, 0, (size_t)m->n * 4, st) != hipSuccess)) { (void)hipFree(m->tp_e); m->tp_e = nullptr; (void)hipGetLastError(); }
+        if (m->tp_e && zh_filter_tp_launch(st, m->l, m->b, m->tp_e, m->tp_serial, m->n, out, inp, start, end, zf, l_mul, b_mul, h_mul, cut, res))
             return zh_launch_status();
     }
     // (a tile's 32 rows are addressed with 32-bit offsets from one descriptor: row strides up to 2^24 voices)
