@@ -78,6 +78,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of one buffer")
     ap.add_argument("--no-config5", action="store_true", help="N=1: skip the extra config-5 shard measurement")
+    ap.add_argument("--no-config4", action="store_true", help="N=1: skip the extra config-4 measurement (60 s of the generated song, GPU and oracle)")
     ap.add_argument("--p2p-compare", action="store_true",
                     help="N>1: after the line is complete, also measure the direct-write exchange beside the RCCL one (opt-in: a stalled "
                          "peer mapping ends the run with exit code 4 after --p2p-timeout, the line printed first)")
@@ -610,6 +611,40 @@ def parity_check(wl, ctx):
                            "within": bool(((err.max(axis=1) / peak) <= 1e-5).all()),
                            "fraction_inside_per_sample_metric": float((err <= 1e-5 * np.maximum(np.abs(r64), 1e-3)).mean()),
                            "fraction_bitexact": float(same.mean())}
+    return rec
+
+
+def config4_record(ctx, seconds=60.0, with_oracle=True):
+    """BASELINE configs[3] beside the headline (extra key): `seconds` of the repo-authored song (tools/gen_song.py: the reference song's
+    grammar and statistics; 17 sub-voices) rendered offline on the GPU -- scheduling on the host, one launch per 1..N buffers, mixDown to
+    s16 -- and, as its CPU baseline, by the oracle-side renderer on one host thread; the two s16 payloads compared byte for byte."""
+    import contextlib
+    import importlib.util
+    import io
+    from zang_amd import song
+    spec = importlib.util.spec_from_file_location("gen_song", os.path.join(ROOT, "tools", "gen_song.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gen.main(2900, 20240915)
+    text = buf.getvalue()
+    nbuf = int(seconds * SR) // 1024
+    audio_s = nbuf * 1024 / SR
+    r = song.SongRenderer(text, ctx)
+    r.render_buffer(); ctx.sync()                        # first-launch costs
+    r = song.SongRenderer(text, ctx)
+    t0 = time.perf_counter()
+    got = r.render(audio_s)
+    gpu_s = time.perf_counter() - t0
+    rec = {"workload": "example_song-like offline render (tools/gen_song.py, 2,900 rows), 17 sub-voices (3 PMOsc + 14 NiceInstrument), %d buffers = %.1f s of audio" % (nbuf, audio_s),
+           "gpu_seconds": gpu_s, "x_realtime_gpu": audio_s / gpu_s, "payload_bytes": len(got)}
+    if with_oracle:
+        from oracle import pyoracle as po                 # (the checker and the CPU baseline of this key; nothing above used it)
+        from tests.test_song import _oracle_song_render
+        t0 = time.perf_counter()
+        ref = _oracle_song_render(po, r.notes, song.EXAMPLE_SONG_INSTRUMENTS, nbuf)
+        cpu_s = time.perf_counter() - t0
+        rec.update({"oracle_seconds_1_thread": cpu_s, "x_realtime_oracle": audio_s / cpu_s, "payload_identical": got == ref})
     return rec
 
 
@@ -1409,6 +1444,12 @@ def main():
             if not args.no_parity:
                 out["config5_shard"]["tolerant_form"]["parity"] = parity_check_mix(c5t.wl, ctx)
             c5t.close()
+
+    if world == 1 and not args.no_config4 and not args.no_config5 and args.workload == "pulseosc" and V == 4096:
+        try:
+            out["config4"] = config4_record(ctx, with_oracle=not args.no_cpu)
+        except Exception as e:          # noqa: BLE001  (an extra key: reported, never fatal)
+            out["config4"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0 and not args.no_parity and (world == 1 or mixdown):
         # (N > 1: rank 0's shard of the mixdown workload; local launches only, the other ranks wait at the last barrier)

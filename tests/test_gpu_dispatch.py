@@ -537,3 +537,20 @@ def test_forced_large_voice_count_geometries_at_a_small_voice_count(ctx, oracle,
     sh = Shared(ctx, V, np.arange(V, dtype=np.int64))
     for name in names:
         CASES[name](ctx, oracle, sh)
+
+
+@pytest.mark.parametrize("V", [1280, 4100])
+def test_distortion_chunked_form_forced_at_a_small_voice_count(ctx, oracle, V, monkeypatch):
+    """k_distortion_chunks (four voices per lane, the per-voice constants once per workgroup through LDS; default from
+    distortion_rows_min voices) forced at voice counts whose last workgroup is partial: both types, `+=` after ZERO_FIRST, every voice
+    against the oracle bit for bit; the kernel that ran is checked."""
+    for name in list(__import__("os").environ):
+        if name.startswith("ZH_") and name not in ("ZH_ENV_LIVE",):
+            monkeypatch.delenv(name)
+    util.set_form(monkeypatch, distortion_rows_min=0)
+    sh = Shared(ctx, V, np.arange(V, dtype=np.int64))
+    case_stateless(ctx, oracle, sh)
+    assert ctx.last_form() == ["k_distortion_chunks"], ctx.last_form()
+    util.set_form(monkeypatch, distortion_rows_min=1 << 30)
+    case_stateless(ctx, oracle, sh)
+    assert ctx.last_form() == ["k_distortion"], ctx.last_form()

@@ -1033,3 +1033,154 @@ def test_tolerant_carried_run_in_the_undamped_corner(ctx, oracle):
         if k % 7 == 0 or k == NBUF - 1:
             print(f"  undamped carried run, buffer {k:2d}: worst {ratio.max():.3e}  median voice {np.median(ratio):.3e}  (allowed {allowed:.1e})")
     print(f"undamped carried run: worst error / allowed = {worst_ratio:.2f}")
+
+
+# ------------------------------------------------------------------ cutoffs near zero: walked, not chunked (kTpExactCutBelow)
+TINY = np.array([3e-8, 6.1e-6, 1e-5, 9.9e-5, 1e-3, 0.0019], np.float32)      # below 2^-9; 6.1e-6 = round 5's known exception (seed 46855)
+
+
+def _tiny_cutoffs(V, rng, cut):
+    where = np.unique(rng.integers(0, V, 24))[:len(TINY) * 3]
+    for k, v in enumerate(where):
+        cut[v] = TINY[k % len(TINY)]
+    return where
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6])
+@pytest.mark.parametrize("ftype", [1, 3, 5])
+def test_filter_tolerant_near_zero_cutoff_is_walked_exactly(ctx, oracle, ftype, scale):
+    """A voice whose clamped cutoff is below 2^-9 takes no chunk start state: its chunk-0 lane walks the span with the reference's own
+    recurrence.  Those voices are BIT-exact (samples and state) whatever the input's scale -- with an input below the dc offset the
+    output is the offset's ramp, where round 5's chunked evaluation was off by 1.9e-5 of the peak -- and every other voice of the same
+    paint stays inside the tolerant contract."""
+    from zang_amd import modules as mod, zang
+    V = 4096
+    rng = np.random.default_rng(46855 + ftype)
+    cut = rng.uniform(0.01, 1.0, V).astype(np.float32); res = rng.uniform(0.0, 1.0, V).astype(np.float32)
+    tiny = _tiny_cutoffs(V, rng, cut)
+    idx = np.unique(np.concatenate([tiny, rng.integers(0, V, 64)]))
+    inp = (util.rng_buffers(8, V, F) * np.float32(scale)).astype(np.float32)
+    out0 = util.rng_buffers(9, V, F)
+    L = oracle.lib()
+    sts = []
+    for v in idx:
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st)); sts.append(st)
+    m = mod.Filter(V, ctx)
+    gi = util.to_image(inp); dc, dr = util.dev(cut), util.dev(res)
+    out = util.to_image(out0)
+    ref = out0[idx].copy()
+    tq = np.isin(idx, tiny)
+    for (s, e) in [(15, 897), (0, 1024), (300, 1000)]:
+        for q, v in enumerate(idx):
+            L.zo_filter_paint(C.byref(sts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(inp[v]), ftype, oracle.constant(cut[v]), oracle.constant(res[v]))
+        m.paint(zang.Span(s, e), [out], [], False, m.Params(gi, ftype, zang.constant(dc), zang.constant(dr)), tolerant=True)
+        ctx.sync()
+        assert any("k_filter_tp_b" in k for k in ctx.last_form()), ctx.last_form()
+        got = util.from_image(out)[idx]
+        tag = f"filter type {ftype}, input x{scale:g}, span {(s, e)}"
+        util.assert_bitexact(got[tq], ref[tq], tag + ": voices with a cutoff below 2^-9")
+        rl = np.array([t.l for t in sts], np.float32); rb = np.array([t.b for t in sts], np.float32)
+        st = m.state()
+        util.assert_bitexact(st["l"][idx][tq].astype(np.float32), rl[tq], tag + ": their l"); util.assert_bitexact(st["b"][idx][tq].astype(np.float32), rb[tq], tag + ": their b")
+        util.assert_peak_close(got, ref, tag, s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb)))
+        full = util.from_image(out)
+        full[idx] = ref                                                    # carry the reference on (the tolerance is per paint)
+        out = util.to_image(full)
+        for q, v in enumerate(idx):
+            st["l"][v] = rl[q]; st["b"][v] = rb[q]
+        m.set_state(st)
+
+
+def test_filter_tolerant_cutoff_image_dipping_to_zero_is_walked_exactly(ctx, oracle):
+    """the same with the cutoff as a control image: a voice whose image holds a frame below 2^-9 anywhere in the piece is flagged by
+    pass A and walked by pass B (bit-exact); the others are painted as chunks"""
+    from zang_amd import modules as mod, zang
+    V = 2048
+    rng = np.random.default_rng(77)
+    res = rng.uniform(0.0, 0.9, V).astype(np.float32)
+    cimg = rng.uniform(0.02, 0.9, (V, F)).astype(np.float32)
+    dips = np.unique(rng.integers(0, V, 20))
+    for k, v in enumerate(dips):                                           # a sweep up from (nearly) zero, a short dip, a constant tiny value
+        if k % 3 == 0:
+            cimg[v] = np.linspace(1e-6, 0.5, F, dtype=np.float32)
+        elif k % 3 == 1:
+            cimg[v, 500:520] = 1e-4
+        else:
+            cimg[v] = 6.1e-6
+    idx = np.unique(np.concatenate([dips, rng.integers(0, V, 48)]))
+    inp = util.rng_buffers(18, V, F)
+    out0 = np.zeros((V, F), np.float32)
+    L = oracle.lib()
+    sts = []
+    for v in idx:
+        st = oracle.Filter(); L.zo_filter_init(C.byref(st)); sts.append(st)
+    m = mod.Filter(V, ctx)
+    out = util.to_image(out0)
+    ref = out0[idx].copy()
+    s, e = 0, 1024
+    for q, v in enumerate(idx):
+        L.zo_filter_paint(C.byref(sts[q]), s, e, oracle.fptr(ref[q]), oracle.fptr(inp[v]), 1, oracle.buffer(cimg[v]), oracle.constant(res[v]))
+    m.paint(zang.Span(s, e), [out], [], False, m.Params(util.to_image(inp), 1, zang.buffer(util.to_image(cimg)), zang.constant(util.dev(res))), tolerant=True)
+    ctx.sync()
+    assert any("k_filter_tp_b" in k for k in ctx.last_form()), ctx.last_form()
+    got = util.from_image(out)[idx]
+    dq = np.isin(idx, dips)
+    util.assert_bitexact(got[dq], ref[dq], "cutoff images that dip below 2^-9")
+    rl = np.array([t.l for t in sts], np.float32); rb = np.array([t.b for t in sts], np.float32)
+    util.assert_peak_close(got, ref, "cutoff image", s=s, e=e, scale_extra=np.maximum(np.abs(rl), np.abs(rb)))
+    assert not np.array_equal(got[~dq].view(np.uint32), ref[~dq].view(np.uint32)), "the other voices should have been painted as chunks (tolerant, not bit-exact)"
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_noise_filter_tolerant_near_zero_cutoff_is_walked_exactly(ctx, oracle, pipelined):
+    """the fused Noise -> Filter voice: cutoffs below 2^-9 take the sequential walk that multi-draw voices take (bit-exact, states too),
+    eager and in the pipelined recording (k_nf_tp_ba)"""
+    import torch
+    import zang_amd
+    from zang_amd import modules as mod, zang
+    V, first = 4096, 900
+    rng = np.random.default_rng(5)
+    cut = rng.uniform(0.02, 1.0, V).astype(np.float32); res = rng.uniform(0.0, 0.9, V).astype(np.float32)
+    tiny = _tiny_cutoffs(V, rng, cut)
+    idx = np.unique(np.concatenate([tiny, rng.integers(0, V, 48)]))
+    tq = np.isin(idx, tiny)
+    L = oracle.lib()
+    nzs, fls = [], []
+    for v in idx:
+        nz = oracle.Noise(); L.zo_noise_init(C.byref(nz), first + int(v)); nzs.append(nz)
+        fl = oracle.Filter(); L.zo_filter_init(C.byref(fl)); fls.append(fl)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = zang_amd.Context(0) if pipelined else ctx
+        m = mod.NoiseFilter(V, c2, first_seed=first)
+        gc, gr = util.dev(cut), util.dev(res)
+        imgs = [c2.image(F, V) for _ in range(3)]
+        P = m.Params(0, 1, gc, gr)
+        paint_all = lambda: [m.paint(zang.Span(0, F), [imgs[k]], None, False, P, zero_first=True, tolerant=True) for k in range(3)]
+        if pipelined:
+            st0 = m.state()
+            paint_all(); c2.sync()                                         # eager once: the scratch sets
+            m.set_state(st0)
+            g = c2.capture(paint_all, coalesce=True)
+            assert any(k.startswith("k_nf_tp_ba") for k, _ in g.kernels()), g.kernels()
+            g.launch()
+        else:
+            paint_all()
+        c2.sync()
+        temp = np.zeros(F, np.float32)
+        for k in range(3):
+            ref = np.zeros((len(idx), F), np.float32)
+            for q, v in enumerate(idx):
+                L.zo_zero(0, F, oracle.fptr(temp))
+                L.zo_noise_paint(C.byref(nzs[q]), 0, F, oracle.fptr(temp), 0)
+                L.zo_filter_paint(C.byref(fls[q]), 0, F, oracle.fptr(ref[q]), oracle.fptr(temp), 1, oracle.constant(cut[v]), oracle.constant(res[v]))
+            got = util.from_image(imgs[k])[idx]
+            util.assert_bitexact(got[tq], ref[tq], f"buffer {k}: voices with a cutoff below 2^-9 (pipelined={pipelined})")
+            # (carried over three buffers from one start state: the tolerance per buffer)
+            err = np.abs(got.astype(np.float64) - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1e-30)
+            assert (err <= 1e-5 * (k + 1)).all(), (k, float(err.max()))
+        gs = m.state()
+        util.assert_bitexact(gs["flt"]["l"][idx][tq].astype(np.float32), np.array([f.l for f in fls], np.float32)[tq], "their filter state")
+        assert [[int(x) for x in gs["noise"]["r"][v]] for v in idx] == [list(n.r) for n in nzs]
+        if pipelined:
+            g.close(); c2.close()

@@ -1242,6 +1242,54 @@ __global__ void __launch_bounds__(256) k_distortion(uint32_t V, Img out, CImg in
     for (; i < c1; i++, o += out.stride, in += input.stride) store_row(o, (ZF ? 0.0f : *o) + d.frame(*in));
 }
 
+// Many voices (distortion_rows_min, dispatch.hip): the chunked oscillator's launch shape, like the basics.zig operations take from
+// 32,768 voices (basics.hip k_elementwise_chunks) -- four voices per lane, 16-byte loads and write-through stores, a wave = RC consecutive
+// rows of a 256-voice column, a workgroup four consecutive chunks.  The per-voice constants (gain1 = pow(2, ingain * 8 - 2), the
+// overdrive's outgain / atan(gain1): Distortion.zig:41-45) cost a powf and an atanf: computed ONCE per workgroup, thread t for voice
+// base + t, and handed to the lanes through LDS -- per lane and chunk they made this shape slower than one voice per lane
+// (profiles/r05/ab_gate4.txt).  Same DistortionLane::begin / frame per voice: same bits.
+template <bool ZF, bool OVERDRIVE, int RC>
+__global__ void __launch_bounds__(256) k_distortion_chunks(uint32_t V, Img out, CImg input, uint32_t start, uint32_t nframes,
+                                                           F32P ingain, F32P outgain, F32P offset) {
+    __shared__ __attribute__((aligned(16))) float sk[3][256];
+    const uint32_t vbase = blockIdx.x * 256, lane = threadIdx.x & 63;
+    {
+        const uint32_t sv = vbase + threadIdx.x;
+        if (sv < V) {
+            DistortionLane d;
+            d.begin(OVERDRIVE ? ZH_DISTORTION_OVERDRIVE : ZH_DISTORTION_CLIP, ingain.get(sv), outgain.get(sv), offset.get(sv));
+            sk[0][threadIdx.x] = d.gain1; sk[1][threadIdx.x] = d.offs; sk[2][threadIdx.x] = d.gain2;
+        }
+    }
+    __syncthreads();
+    const uint32_t v = vbase + lane * 4;
+    if (v >= V) return;                                               // V % 4 == 0 on this path
+    const zv4f g1 = *reinterpret_cast<const zv4f *>(&sk[0][lane * 4]), of = *reinterpret_cast<const zv4f *>(&sk[1][lane * 4]),
+               g2 = *reinterpret_cast<const zv4f *>(&sk[2][lane * 4]);
+    DistortionLane d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { d[j].overdrive = OVERDRIVE; d[j].gain1 = g1[j]; d[j].offs = of[j]; d[j].gain2 = g2[j]; }
+    const uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6), r0 = chunk * RC;
+    zv4f x[RC], old[RC];
+#pragma unroll
+    for (int k = 0; k < RC; k++) {
+        x[k] = old[k] = zv4f{0, 0, 0, 0};
+        if (r0 + k < nframes) {
+            x[k] = *reinterpret_cast<const zv4f *>(input.at(start + r0 + k, v));
+            if (!ZF) old[k] = *reinterpret_cast<const zv4f *>(out.at(start + r0 + k, v));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RC; k++) {
+        if (r0 + k < nframes) {
+            zv4f o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = old[k][j] + d[j].frame(x[k][j]);
+            store4_sc1(out.at(start + r0 + k, v), o);
+        }
+    }
+}
+
 // =================================================================== Curve
 // state double-buffered like zh_envelope's: four words per voice, [t n][current_song_note n][offset n][next_song_note n]
 struct zh_curve_module : zh_flipper {};
@@ -2257,6 +2305,18 @@ int zh_distortion_paint(zh_distortion *m, uint32_t start, uint32_t end, const zh
     Img out = mk_img(outputs[0]);
     CImg in = mk_cimg(p->input);
     F32P ig = mk_f32(p->ingain), og = mk_f32(p->outgain), of = mk_f32(p->offset);
+    // many voices, rows that take 16-byte accesses: the chunked shape (k_distortion_chunks)
+    if ((long)m->n >= zh_form(ZF_DISTORTION_ROWS_MIN) && m->n % 4 == 0 && outputs[0].stride % 4 == 0 && p->input.stride % 4 == 0 &&
+        ((uintptr_t)outputs[0].ptr & 15u) == 0 && ((uintptr_t)p->input.ptr & 15u) == 0) {
+        constexpr int RC = 3;
+        const uint32_t nframes = end - start;
+        const dim3 g((m->n + 255) / 256, ((nframes + RC - 1) / RC + 3) / 4);
+#define ZH_DISTC(ZF_, OD_) ZH_LAUNCH((k_distortion_chunks<ZF_, OD_, RC>), g, dim3(256), 0, st, m->n, out, in, start, nframes, ig, og, of)
+        if (p->type == ZH_DISTORTION_OVERDRIVE) { if (zf) ZH_DISTC(true, true); else ZH_DISTC(false, true); }
+        else { if (zf) ZH_DISTC(true, false); else ZH_DISTC(false, false); }
+#undef ZH_DISTC
+        return zh_launch_status();
+    }
 #define ZH_DIST(ZF_, OD_) ZH_LAUNCH((k_distortion<ZF_, OD_>), grid, dim3(256), 0, st, m->n, out, in, start, end, ig, og, of)
     if (p->type == ZH_DISTORTION_OVERDRIVE) { if (zf) ZH_DIST(true, true); else ZH_DIST(false, true); }
     else { if (zf) ZH_DIST(true, false); else ZH_DIST(false, false); }

@@ -267,15 +267,18 @@ __device__ __forceinline__ void zs_role_run(float4 *lds, uint32_t lane, uint32_t
             for (int j = 0; j < NOUT; j++) to[j] = lds + tout[j].off + bo[j] * TILE + lane;
             if (nf == CH) {
                 float4 a[NI];
+                constexpr int NLD = WR ? NIN - 1 : NIN;                 // (the writer's last tile is the live output row: not read when the paint zeroes first)
 #pragma unroll
-                for (int j = 0; j < NIN; j++) a[j] = ti[j][0];
+                for (int j = 0; j < NLD; j++) a[j] = ti[j][0];
+                if (WR) a[NI - 1] = zf ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ti[NI - 1][0];
                 const bool qtile = quiet((int)CH);                    // the whole tile quiet: no test per group of four frames
 #pragma unroll UQ
                 for (uint32_t q = 0; q < Q; q++) {
                     float4 an[NI];                                    // the next four frames' values: fetched while these compute
                     if (q + 1 < Q) {
 #pragma unroll
-                        for (int j = 0; j < NIN; j++) an[j] = ti[j][(q + 1) * 64];
+                        for (int j = 0; j < NLD; j++) an[j] = ti[j][(q + 1) * 64];
+                        if (WR) an[NI - 1] = zf ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ti[NI - 1][(q + 1) * 64];
                     }
                     float4 b[NO];
                     float o4[4];
