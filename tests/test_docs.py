@@ -93,3 +93,18 @@ def test_inline_assembly_memory_instructions_carry_their_wait_states():
             if re.search(r"\b(global|buffer|flat|scratch)_(store|load|atomic)", text) and "s_nop" not in text:
                 bad.append((os.path.basename(path), text[:60]))
     assert not bad, bad
+
+
+def test_entry_point_and_form_counts_in_the_docs_are_the_headers():
+    """DESIGN.md said 214 entry points where the header had 215.  The counts quoted in DESIGN.md and README.md are
+    checked against include/zang_hip.h and the library's own dispatch table."""
+    text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "zang_hip.h")).read(), flags=re.S)
+    n_api = len(re.findall(r"\bZH_API\b[^;{]*\(", text))
+    from zang_amd import abi
+    n_forms = abi.load().zh_form_count()
+    for name in ("DESIGN.md", "README.md"):
+        doc = open(os.path.join(ROOT, name)).read()
+        for m in re.finditer(r"(\d+) entry points", doc):
+            assert int(m.group(1)) == n_api, (name, m.group(0), n_api)
+        for m in re.finditer(r"\((\d+) rows", doc):
+            assert int(m.group(1)) == n_forms, (name, m.group(0), n_forms)

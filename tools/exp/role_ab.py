@@ -36,8 +36,8 @@ def value(name, kind, enum):
         return fimg if "freq" in name else img
     if kind == "constant_or_buffer":
         return torch.from_numpy(rng.uniform(100.0, 2000.0, V).astype(np.float32)).to(dev) if "freq" in name else 0.4
-    if kind == "curve":
-        return [(0.0, 0.0), (0.01, 1.0), (0.2, 0.3), (1.0, 0.0)]
+    if kind == "curve":                                     # a device array of (value, t) pairs: nothing is uploaded while a capture records
+        return torch.tensor([0.0, 0.0, 1.0, 0.01, 0.3, 0.2, 0.0, 1.0], dtype=torch.float32, device=dev)
     labels = native.ENUM_LABELS[enum]
     return (labels[1] if len(labels) > 1 else labels[0], 0.05)
 

@@ -139,7 +139,7 @@ enum { ZF_SINE_RANGES, ZF_NOISE_RANGES, ZF_ENVELOPE_RANGES, ZF_SAMPLER_RANGES, Z
        ZF_SCRIPT_RANGES, ZF_SCRIPT_RANGES_MAXV, ZF_OSC_FC, ZF_NICE_PC_MAX, ZF_NICE_PC4_MAX, ZF_NICE_WAVE_MAX, ZF_PMOSC_WAVE_MAX,
        ZF_NICE_MIX_ROLL, ZF_NICE_MIX_WG_MIN, ZF_NF_PC_MAX, ZF_NF_RING_MAX, ZF_FILTER_PC_MAX, ZF_FILTER_PC16_MAX, ZF_FILTER_PC_CTL_MAX,
        ZF_PINK_PIPE_MAX, ZF_PINK_TAPS, ZF_ECHOES_PC_MAX, ZF_DELAY_FRAMES_MAX, ZF_FILTER_TP_MAX, ZF_NF_TP_MAX, ZF_NICE_TP_MAX,
-       ZF_PINK_TP_MAX, ZF_ECHOES_TP_MAX, ZF_NICE_MIX_FMA, ZF_BASICS_ROWS_MIN, ZF_SCRIPT_PC, ZF_SCRIPT_PC_MAXV, ZF_NF_TP_PIPE_FRAMES, ZF_DISTORTION_ROWS_MIN, ZF_COUNT };
+       ZF_PINK_TP_MAX, ZF_ECHOES_TP_MAX, ZF_NICE_MIX_FMA, ZF_BASICS_ROWS_MIN, ZF_SCRIPT_PC, ZF_SCRIPT_PC_MAXV, ZF_NF_TP_PIPE_FRAMES, ZF_DISTORTION_ROWS_MIN, ZF_DISTORTION_RC, ZF_COUNT };
 long zh_form(int id);
 bool zh_form_is_set(int id);                 // the row is overridden through ZH_FORMS
 uint32_t zh_range_frames(uint32_t V, uint32_t n, int form, uint32_t target_waves, uint32_t max_voices);

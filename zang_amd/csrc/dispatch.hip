@@ -61,7 +61,8 @@ const FormRow kForms[ZF_COUNT] = {
     /* ZF_SCRIPT_PC          */ {"script_pc", -1, "generated script kernels: the role-wave form (zs_paint_pc_<name>: the body's builtin calls as producer / recurrence / writer waves over LDS tiles); auto: where the emitter found the lane form unable to take frame ranges and the longest role well below the whole body; 0 = never, 1 = every module that has the form"},
     /* ZF_SCRIPT_PC_MAXV     */ {"script_pc_maxv", 65536, "... the largest voice count that takes it (FilteredSawtooth: 52.6 / 54.7 / 74.9 / 130.6 us at 4,096 / 16,384 / 32,768 / 65,536 voices against 188-199 in one wave per 64 voices; slower at 131,072)"},
     /* ZF_NF_TP_PIPE_FRAMES  */ {"nf_tp_pipe_frames", 0, "ZH_PAINT_TOLERANT Noise -> Filter voice recorded pipelined (ZH_CAPTURE_COALESCE, k_nf_tp_ba): frames per chunk, a multiple of 32; 0 = as outside a pipeline (32 at 4,096 voices)"},
-    /* ZF_DISTORTION_ROWS_MIN */ {"distortion_rows_min", 32768, "Distortion: from here four voices per lane, three consecutive rows of a 256-voice column per wave, the per-voice constants once per workgroup through LDS (k_distortion_chunks) instead of one voice per lane"},
+    /* ZF_DISTORTION_ROWS_MIN */ {"distortion_rows_min", 32768, "Distortion clip: from here four voices per lane, three consecutive rows of a 256-voice column per wave, the per-voice constants once per workgroup through LDS (k_distortion_chunks: 224 -> 178 us at 131,072 voices); the overdrive too when this row is set by hand (no faster: 239 against 244-250 us)"},
+    /* ZF_DISTORTION_RC      */ {"distortion_rc", 0, "... rows per wave of that form: 3 (0), 6 or 8"},
 };
 
 struct Overrides { bool set[ZF_COUNT]; long val[ZF_COUNT]; };

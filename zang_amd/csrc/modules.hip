@@ -2305,15 +2305,21 @@ int zh_distortion_paint(zh_distortion *m, uint32_t start, uint32_t end, const zh
     Img out = mk_img(outputs[0]);
     CImg in = mk_cimg(p->input);
     F32P ig = mk_f32(p->ingain), og = mk_f32(p->outgain), of = mk_f32(p->offset);
-    // many voices, rows that take 16-byte accesses: the chunked shape (k_distortion_chunks)
-    if ((long)m->n >= zh_form(ZF_DISTORTION_ROWS_MIN) && m->n % 4 == 0 && outputs[0].stride % 4 == 0 && p->input.stride % 4 == 0 &&
+    // many voices, rows that take 16-byte accesses: the chunked shape (k_distortion_chunks).  Clip only by default: at 131,072 voices
+    // 224 -> 178 us (6.0 TB/s); the overdrive (an atanf per sample: issue time beside the stream) is no faster in it at any chunk
+    // length, 238.6 against 244-250 us (profiles/r06/ab_distortion.txt) -- it takes the shape only where the row is set by hand (tests).
+    if ((long)m->n >= zh_form(ZF_DISTORTION_ROWS_MIN) && (p->type == ZH_DISTORTION_CLIP || zh_form_is_set(ZF_DISTORTION_ROWS_MIN)) && m->n % 4 == 0 && outputs[0].stride % 4 == 0 && p->input.stride % 4 == 0 &&
         ((uintptr_t)outputs[0].ptr & 15u) == 0 && ((uintptr_t)p->input.ptr & 15u) == 0) {
-        constexpr int RC = 3;
         const uint32_t nframes = end - start;
-        const dim3 g((m->n + 255) / 256, ((nframes + RC - 1) / RC + 3) / 4);
-#define ZH_DISTC(ZF_, OD_) ZH_LAUNCH((k_distortion_chunks<ZF_, OD_, RC>), g, dim3(256), 0, st, m->n, out, in, start, nframes, ig, og, of)
-        if (p->type == ZH_DISTORTION_OVERDRIVE) { if (zf) ZH_DISTC(true, true); else ZH_DISTC(false, true); }
-        else { if (zf) ZH_DISTC(true, false); else ZH_DISTC(false, false); }
+        // rows per wave (distortion_rc; 0 = 3): the setup is amortised over more rows, the loads in flight per wave grow with them
+        const long rcf = zh_form(ZF_DISTORTION_RC);
+        const int rc = rcf == 6 ? 6 : rcf == 8 ? 8 : 3;
+        const dim3 g((m->n + 255) / 256, ((nframes + rc - 1) / rc + 3) / 4);
+#define ZH_DISTC(ZF_, OD_, RC_) ZH_LAUNCH((k_distortion_chunks<ZF_, OD_, RC_>), g, dim3(256), 0, st, m->n, out, in, start, nframes, ig, og, of)
+#define ZH_DISTR(ZF_, OD_) do { if (rc == 3) ZH_DISTC(ZF_, OD_, 3); else if (rc == 6) ZH_DISTC(ZF_, OD_, 6); else ZH_DISTC(ZF_, OD_, 8); } while (0)
+        if (p->type == ZH_DISTORTION_OVERDRIVE) { if (zf) ZH_DISTR(true, true); else ZH_DISTR(false, true); }
+        else { if (zf) ZH_DISTR(true, false); else ZH_DISTR(false, false); }
+#undef ZH_DISTR
 #undef ZH_DISTC
         return zh_launch_status();
     }
