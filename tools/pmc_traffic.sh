@@ -33,7 +33,7 @@ kernels = {}
 total = 0.0
 for k, d in per.items():
     n = max(len(v) for v in d.values())
-    if n < (2 if graph else steps // 2):                # set-up kernels (fills, seeds, tables): not part of a step
+    if n < (2 if graph else steps // 2) or k.startswith("__amd_rocclr") or "at::native" in k:    # set-up kernels (fills, seeds, tables, torch's own): not part of a step
         continue
     w = statistics.mean(d.get("WRITE_SIZE", [0.0])) * 1024.0          # the counters are in KiB
     f = statistics.mean(d.get("FETCH_SIZE", [0.0])) * 1024.0 * 2.0    # gfx950 correction
