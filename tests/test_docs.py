@@ -64,12 +64,13 @@ def test_every_file_design_md_cites_exists():
         if tok.startswith(("src/", "examples/")) or "rNN" in tok or tok.startswith("/"):
             continue                                              # reference paths, placeholders
         tok = tok.split("::")[0]
-        cands = [tok, os.path.join("profiles", "r05", tok), os.path.join("zang_amd", "csrc", tok), os.path.join("zang_amd", tok),
+        cands = [tok, os.path.join("profiles", "r06", tok), os.path.join("profiles", "r05", tok), os.path.join("zang_amd", "csrc", tok), os.path.join("zang_amd", tok),
                  os.path.join("tests", tok), os.path.join("tools", tok), os.path.join("include", tok)]
         if "{" in tok:                                            # zang_amd/{abi,zang,...}.py
             head, rest = tok.split("{", 1)
             alts, tail = rest.split("}", 1)
-            ok = all(glob.glob(os.path.join(ROOT, head + a + tail)) or glob.glob(os.path.join(ROOT, "profiles", "r05", head + a + tail)) for a in alts.split(","))
+            ok = all(glob.glob(os.path.join(ROOT, head + a + tail)) or glob.glob(os.path.join(ROOT, "profiles", "r06", head + a + tail)) or
+                     glob.glob(os.path.join(ROOT, "profiles", "r05", head + a + tail)) for a in alts.split(","))
         else:
             ok = any(glob.glob(os.path.join(ROOT, c)) for c in cands)
         if not ok:
