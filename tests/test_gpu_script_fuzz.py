@@ -51,6 +51,16 @@ def test_gpu_random_script_parity_role_waves(ctx, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [12032, 12155])
+def test_gpu_role_waves_filter_into_an_inlined_modules_output(ctx, seed):
+    """Found by the round's last soak (tools/fuzz_scripts.py 200 12000, the library's own choice of form): `out -abs(x)` then
+    `out Filter(...)` inside a helper module that is inlined into a temp of its caller -- the Filter's mix piece of the role-wave form
+    zeroed that temp first, as for a temp of its own module (codegen_zig.zig:284-291 zeroes only those), and the first `out` was lost."""
+    script_fuzz.run_case(ctx, seed, roles=1, F=256 if seed % 2 else 96)
+    script_fuzz.run_case(ctx, seed, F=256 if seed % 2 else 96)          # ... and in the form the library picks itself
+
+
+@pytest.mark.gpu
 def test_gpu_seed_1015_select_hazard(ctx):
     """The case that exposed the inline-asm v_cndmask of round 2 (lanes.hip.h zsel_hard): with a literal TriSawOsc color its
     `"s"(ballot(true))` operand became the EXEC register itself in one place, and a v_cndmask_b32_e64 with EXEC as its mask

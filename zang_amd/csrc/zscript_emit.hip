@@ -817,7 +817,9 @@ public:
                 pc.lines = gw.first;
                 u.parts = {pa, pb, pc, gw.second};
             } else {
-                pc.lines = {target + " = 0.0f;", target + " = " + target + " + (" + mix + ");"};
+                // (zang.zero(dest) only for a temp of THIS module; an inlined module's output, a temp of its caller, accumulates -- codegen_zig.zig:284-291)
+                if (!ins.out.output) pc.lines.push_back(target + " = 0.0f;");
+                pc.lines.push_back(target + " = " + target + " + (" + mix + ");");
                 u.parts = {pa, pb, pc};
             }
         } else if (target == "o") {
