@@ -1463,6 +1463,13 @@ def main():
         cb = cpu_baseline(args, wl)
         if cb:
             out["cpu_baseline"] = cb
+    # whoever reads SCALE first: the N = 1 line is config 2, the N > 1 lines are config 5 -- their ratio is not a scaling figure
+    if world == 1 and "config5_shard" in out:
+        out["scaling_anchor"] = ("config5_shard.value of THIS line (one GPU's shard of config 5, no exchange) is what the N > 1 lines' `value` / N compares with; "
+                                 "`value` here is config 2 (4,096 PulseOsc voices), a different workload: value(N) / value(1) is meaningless")
+    elif dist_on and mixdown:
+        out["scaling_anchor"] = ("this line's own `scaling_factor` (world x time without the exchange / time with it) and `single_gpu_shard`, or the N = 1 line's "
+                                 "`config5_shard.value`; the N = 1 line's `value` is config 2, a different workload")
     main_run.close()
     if comm is not None:
         comm.close()

@@ -47,12 +47,17 @@ class ScriptProgram:
         # the library picks per paint); FORM_ROLES = every module (the parity tests force the form)
         forms = int(os.environ.get("ZH_SCRIPT_FORMS", forms))       # (an experiment knob like ZH_SCRIPT_UNROLL)
         self.hip_source, self.meta = compiled.generate_hip(only=only, unroll=int(os.environ.get("ZH_SCRIPT_UNROLL", "0")), forms=forms)
-        compiled.close()
         if hip_patch is not None:                               # experiments (tools/exp/role_probe.py): the generated text, edited
             self.hip_source = hip_patch(self.hip_source)
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
         rc = self.lib.zh_script_load(self.ctx.handle, self.hip_source.encode(), C.byref(h), log, len(log))
+        if rc != 0 and forms and hip_patch is None:
+            # the lane kernels alone: a role-wave kernel hiprtc refuses must not take the patch away (none has been seen to)
+            self.role_form_error = log.value.decode(errors="replace")
+            self.hip_source, self.meta = compiled.generate_hip(only=only, unroll=int(os.environ.get("ZH_SCRIPT_UNROLL", "0")), forms=0)
+            rc = self.lib.zh_script_load(self.ctx.handle, self.hip_source.encode(), C.byref(h), log, len(log))
+        compiled.close()
         if rc != 0:
             raise ScriptCompileError("zh_script_load failed (%d):\n%s" % (rc, log.value.decode(errors="replace")))
         self.handle = h
