@@ -167,3 +167,39 @@ def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, o
         util.assert_bitexact(np.ascontiguousarray(got), ref, f"HardSquare V={V} zf={zero_first} buffer {b}")
         assert float(np.abs(ref).max()) > 0.5
     prog.close()
+
+
+@pytest.mark.parametrize("V", [1, 63, 64, 65, 200, 4160])
+def test_role_wave_form_equals_the_lane_form_at_odd_voice_counts_and_spans(ctx, monkeypatch, V):
+    """zs_paint_pc_<name> against zs_paint_<name> (which the tests above hold against the oracle), bit for bit, where the workgroup
+    geometry has edges: fewer voices than a wave, a partial last workgroup, spans shorter than a tile, ending inside a tile, starting
+    off zero; `+=` onto live output; the frequency as an image; state carried from paint to paint in each form."""
+    import torch
+    from zang_amd import script, zang, zscript_native as native
+    rng = np.random.default_rng(V)
+    spans = [(0, 1024), (0, 5), (5, 37), (37, 100), (100, 1001), (1001, 1024), (3, 3), (0, 1024)]
+    for name in ("FilteredSawtooth", "FilteredSawtoothCtl", "Bell"):
+        prog = script.ScriptProgram(SCRIPT, ctx, only=[name], forms=native.FORM_ROLES)
+        freq = util.dev(rng.uniform(40.0, 5000.0, V).astype(np.float32))
+        fimg = torch.from_numpy(rng.uniform(40.0, 5000.0, (F, V)).astype(np.float32)).to(ctx.device)
+        on = torch.from_numpy((rng.random(V) < 0.8).astype(np.uint8)).to(ctx.device)
+        base = torch.from_numpy(rng.uniform(-1, 1, (F, V)).astype(np.float32)).to(ctx.device)
+        outs, states = [], []
+        for roles in (0, 1):
+            util.set_form(monkeypatch, script_pc=roles)
+            m = prog.module(name, V)
+            out = base.clone()
+            for k, (s, e) in enumerate(spans):
+                p = {"sample_rate": SR, "note_on": on, "freq": fimg if name == "FilteredSawtoothCtl" else freq}
+                if name != "Bell":
+                    p["cutoff"] = 0.07
+                m.paint(zang.Span(s, e), [out], None, k in (0, 4), p, zero_first=(k % 3 == 0))
+                ran = ctx.last_form()
+                assert (ran == ["zs_paint_pc_" + name]) == bool(roles), (roles, ran)
+            ctx.sync()
+            outs.append(out.cpu().numpy()); states.append(m.get_state())
+            m.close()
+        util.assert_bitexact(outs[1], outs[0], f"{name} V={V}: role-wave form against lane form")
+        assert np.array_equal(states[0], states[1]), f"{name} V={V}: state words"
+        assert float(np.abs(outs[0]).max()) > 0.01
+        prog.close()
