@@ -675,6 +675,9 @@ typedef struct zh_script_module zh_script_module;   /* n_voices instances of one
 ZH_API int zh_script_compile(const char *hip_source, void **code_out, size_t *code_size_out, char *log, size_t log_cap);
 ZH_API void zh_script_free_code(void *code);
 ZH_API int zh_script_load(zh_ctx *ctx, const char *hip_source, zh_script **out, char *log, size_t log_cap);
+/* ... or from the code object zh_script_compile returned earlier -- compiled once, offline (hiprtc needs no GPU), like the reference
+ * compiles a script to Zig before the program is built (examples/example_script.zig:6-8): no hiprtc at run time (1-4 s per module). */
+ZH_API int zh_script_load_code(zh_ctx *ctx, const void *code, size_t code_size, zh_script **out);
 ZH_API int zh_script_destroy(zh_script *s);
 /* `name` = the exported module's global name; `state_words` = 32-bit state words per voice as reported by the
  * front-end; Noise fields are seeded first_seed + voice * n_noise_fields + k (Noise.zig:25-29: one counter tick

@@ -203,3 +203,32 @@ def test_role_wave_form_equals_the_lane_form_at_odd_voice_counts_and_spans(ctx, 
         assert np.array_equal(states[0], states[1]), f"{name} V={V}: state words"
         assert float(np.abs(outs[0]).max()) > 0.01
         prog.close()
+
+
+def test_a_script_compiled_once_is_loaded_from_its_code_object(ctx, tmp_path):
+    """zh_script_compile -> a gfx950 code object kept on disk -> zh_script_load_code: the reference's compile-once flow
+    (examples/example_script.zig:6-8: zangc runs before the program is built).  The second program never calls hiprtc and paints the
+    same bits, lane kernel and role-wave kernel; something that is not a code object is refused."""
+    import ctypes
+    import torch
+    from zang_amd import abi, script, zang
+    V = 300
+    rng = np.random.default_rng(3)
+    freq = util.dev(rng.uniform(40.0, 5000.0, V).astype(np.float32))
+    outs = []
+    for k in range(2):
+        prog = script.ScriptProgram(SCRIPT, ctx, only=["FilteredSawtooth"], code_cache=str(tmp_path))
+        assert prog.loaded_from_cache == (k == 1)
+        m = prog.module("FilteredSawtooth", V)
+        out = torch.zeros((F, V), dtype=torch.float32, device=ctx.device)
+        for (s, e) in SUBSPANS:
+            m.paint(zang.Span(s, e), [out], None, s == 0, {"sample_rate": SR, "freq": freq, "note_on": True, "cutoff": 0.07}, zero_first=True)
+        assert ctx.last_form() == ["zs_paint_pc_FilteredSawtooth"]
+        ctx.sync()
+        outs.append(out.cpu().numpy())
+        prog.close()
+    util.assert_bitexact(outs[1], outs[0], "loaded from the cached code object")
+    assert len(list(tmp_path.glob("zs_*.hsaco"))) == 1
+    h = ctypes.c_void_p()
+    junk = b"not a code object" * 8
+    assert ctx.lib.zh_script_load_code(ctx.handle, junk, len(junk), ctypes.byref(h)) == abi.ZH_ERR_INVALID

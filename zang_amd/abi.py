@@ -405,6 +405,7 @@ SIGNATURES = {
     "zh_script_compile": (C.c_int, [C.c_char_p, P(vp), P(C.c_size_t), C.c_char_p, C.c_size_t]),
     "zh_script_free_code": (None, [vp]),
     "zh_script_load": (C.c_int, [vp, C.c_char_p, P(vp), C.c_char_p, C.c_size_t]),
+    "zh_script_load_code": (C.c_int, [vp, vp, C.c_size_t, P(vp)]),
     "zh_script_destroy": (C.c_int, [vp]),
     "zh_script_module_create": (C.c_int, [vp, C.c_char_p, u32, u32, u64, P(vp)]),
     "zh_script_module_destroy": (C.c_int, [vp]),

@@ -34,7 +34,7 @@ def compile_hip(hip_source):
 class ScriptProgram:
     """One script: front-end result + the loaded hipModule."""
 
-    def __init__(self, text, ctx=None, filename="script.txt", only=None, forms=native.FORM_ROLES_WORTH, hip_patch=None):
+    def __init__(self, text, ctx=None, filename="script.txt", only=None, forms=native.FORM_ROLES_WORTH, hip_patch=None, code_cache=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.text, self.filename = text, filename
@@ -51,6 +51,35 @@ class ScriptProgram:
             self.hip_source = hip_patch(self.hip_source)
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
+        # code_cache = a directory: the compiled code object is kept there under the hash of the generated text (+ the library's version)
+        # and loaded with zh_script_load_code next time -- the reference's compile-once flow; hiprtc takes 1-4 s per module
+        self.loaded_from_cache = False
+        cache_file = None
+        if code_cache is not None and hip_patch is None:
+            import hashlib
+            key = hashlib.sha256(self.hip_source.encode() + b"\0" + self.lib.zh_version()).hexdigest()[:32]
+            cache_file = os.path.join(code_cache, "zs_%s.hsaco" % key)
+            if os.path.exists(cache_file):
+                blob = open(cache_file, "rb").read()
+                if self.lib.zh_script_load_code(self.ctx.handle, blob, len(blob), C.byref(h)) == 0:
+                    compiled.close()
+                    self.handle, self._modules, self.loaded_from_cache = h, [], True
+                    self.ctx._children.add(self)
+                    return
+        if cache_file is not None:
+            code, n = C.c_void_p(), C.c_size_t()
+            if self.lib.zh_script_compile(self.hip_source.encode(), C.byref(code), C.byref(n), log, len(log)) == 0:
+                blob = C.string_at(code, n.value)
+                self.lib.zh_script_free_code(code)
+                os.makedirs(code_cache, exist_ok=True)
+                tmp = cache_file + ".%d.tmp" % os.getpid()
+                open(tmp, "wb").write(blob)
+                os.replace(tmp, cache_file)
+                if self.lib.zh_script_load_code(self.ctx.handle, blob, len(blob), C.byref(h)) == 0:
+                    compiled.close()
+                    self.handle, self._modules = h, []
+                    self.ctx._children.add(self)
+                    return
         rc = self.lib.zh_script_load(self.ctx.handle, self.hip_source.encode(), C.byref(h), log, len(log))
         if rc != 0 and forms and hip_patch is None:
             # the lane kernels alone: a role-wave kernel hiprtc refuses must not take the patch away (none has been seen to)
