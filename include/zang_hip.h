@@ -87,11 +87,11 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *    sqrt, sin / cos -- stays exact (csrc/zscript_emit.hip decides per call when the kernel is generated).  The error is
         *    relative to the largest magnitude on the voice's signal path: where large terms cancel it is that of the terms.
         * Ignored elsewhere: every other form stays bit-exact, and so does a tolerant Filter paint's first chunk.
-        * KNOWN EXCEPTION (1 voice-paint in ~960,000 of tools/fuzz_tolerant.py's 10,000 seeds, profiles/r05/fuzz_tolerant_10000.txt):
-        * a cutoff within ~1e-5 of zero with an input below the filter's dc offset -- the output is then the offset's own ramp,
-        * the reference's f32 accumulation of that nearly constant increment drifts SYSTEMATICALLY from exact arithmetic (1.7e-5
-        * of the peak over 880 frames) and a chunked evaluation, which is closer to exact, departs from it by that much (1.9e-5
-        * measured).  Everywhere else the worst over those seeds is 5.4e-6.
+        * NO EXCEPTION to the bound (round 5 had one): a voice whose clamped cutoff falls below 2^-9 anywhere in the paint
+        * (csrc/filter_tp.hip.h kTpExactCutBelow) is not painted as chunks -- the reference's f32 accumulation of that nearly
+        * constant increment drifts systematically from exact arithmetic and a chunked evaluation would depart from it by up to
+        * 1.9e-5 of the peak; one lane walks that voice's frames in the reference's own order instead (bit-exact), in the same
+        * launch.  Worst over tools/fuzz_tolerant.py's 10,000 seeds: 7.2e-6 of the peak (profiles/r06/fuzz_tolerant_10000.txt).
         * THE BOUND IS PER PAINT, from the state the paint starts on: every sample within 1e-5 of the voice's peak of what the
         * reference paints from that same state.  The filter state a tolerant paint leaves carries the paint's error into the next
         * one.  With damping (a resonance input below 1) that error decays, and a run whose state is carried on the GPU stays
