@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: the filter recurrence with packed products (tools/ubench/pk_svf.hip), then config 3 exact (k_noise_filter_ring) with the
-# library in the tree against another build (zang_amd/libzang_hip_base.so), alternating.  -> gpurun_out/r06_pk/
+# library in the tree against another build (zang_amd/libzang_hip_base.so: `git stash; make -C zang_amd/csrc; cp zang_amd/libzang_hip.so
+# zang_amd/libzang_hip_base.so; git stash pop; make -C zang_amd/csrc` before the call), alternating.  -> gpurun_out/r06_pk/
 set -u
 O=gpurun_out/r06_pk; mkdir -p $O
 timeout 120 tools/ubench/pk_svf > $O/ubench_pk_svf.txt 2>&1; cat $O/ubench_pk_svf.txt
