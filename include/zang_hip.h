@@ -86,6 +86,8 @@ enum { ZH_PAINT_ADD = 0,         /* out[i] += value          (the reference cont
         *    take the f32 sine; one that reaches anything else -- another oscillator's freq or phase, a Distortion, a divisor, pow,
         *    sqrt, sin / cos -- stays exact (csrc/zscript_emit.hip decides per call when the kernel is generated).  The error is
         *    relative to the largest magnitude on the voice's signal path: where large terms cancel it is that of the terms.
+        *    (The role-wave form of a generated kernel, zs_paint_pc_<name>, taken at few voices, carries no f32 sine: a tolerant
+        *    paint that takes it has the exact bits.)
         * Ignored elsewhere: every other form stays bit-exact, and so does a tolerant Filter paint's first chunk.
         * NO EXCEPTION to the bound (round 5 had one): a voice whose clamped cutoff falls below 2^-9 anywhere in the paint
         * (csrc/filter_tp.hip.h kTpExactCutBelow) is not painted as chunks -- the reference's f32 accumulation of that nearly

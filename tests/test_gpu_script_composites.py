@@ -205,6 +205,59 @@ def test_role_wave_form_equals_the_lane_form_at_odd_voice_counts_and_spans(ctx, 
         prog.close()
 
 
+@pytest.mark.parametrize("V", [64, 1000])
+def test_role_wave_form_equals_the_lane_form_in_place_and_tolerant(ctx, monkeypatch, V):
+    """Two uses the tests above do not make of zs_paint_pc_<name>: the frequency image IS the output image (its loader role reads a row
+    tiles before the writer role adds into it -- as the one-walk form reads a sample before it adds to it), and ZH_PAINT_TOLERANT:
+    the role-wave kernels carry no f32 sine (csrc/zscript_emit.hip role_kernel resolves every sine exactly), so a tolerant paint that
+    takes them has the EXACT lane kernel's bits -- the flag is a permission (include/zang_hip.h), and the lane kernel that uses it
+    stays within 1e-5 of them."""
+    import torch
+    from zang_amd import script, zang, zscript_native as native
+    rng = np.random.default_rng(V + 5)
+    spans = [(0, 1024), (0, 70), (70, 1024), (0, 1024)]
+    for name, tolerant, in_place in (("FilteredSawtoothCtl", False, True), ("Bell", True, False), ("FilteredSawtoothCtl", True, True)):
+        prog = script.ScriptProgram(SCRIPT, ctx, only=[name], forms=native.FORM_ROLES)
+        freq = util.dev(rng.uniform(40.0, 5000.0, V).astype(np.float32))
+        on = torch.from_numpy((rng.random(V) < 0.8).astype(np.uint8)).to(ctx.device)
+        base = torch.from_numpy(rng.uniform(40.0, 5000.0, (F, V)).astype(np.float32)).to(ctx.device)
+        outs, states = [], []
+        for roles in (0, 1):
+            util.set_form(monkeypatch, script_pc=roles)
+            m = prog.module(name, V)
+            out = base.clone()
+            for k, (s, e) in enumerate(spans):
+                p = {"sample_rate": SR, "note_on": on, "freq": out if in_place else freq}
+                if name != "Bell":
+                    p["cutoff"] = 0.07
+                m.paint(zang.Span(s, e), [out], None, k == 0, p, tolerant=tolerant and bool(roles))   # lane form: exact
+                ran = ctx.last_form()
+                assert (ran == ["zs_paint_pc_" + name]) == bool(roles), (roles, ran)
+                if in_place and k < len(spans) - 1:
+                    ctx.sync()
+                    out.copy_(base)                                    # (frequencies again, not frequencies + signal)
+            ctx.sync()
+            outs.append(out.cpu().numpy()); states.append(m.get_state())
+            m.close()
+        util.assert_bitexact(outs[1], outs[0], f"{name} V={V} tolerant={tolerant} in_place={in_place}: role-wave form against lane form")
+        assert np.array_equal(states[0], states[1]), f"{name} V={V}: state words"
+        assert float(np.abs(outs[0] - base.cpu().numpy()).max()) > 0.01
+        if tolerant and name == "Bell":                                 # ... and the lane kernel's f32 sines, from the same start
+            util.set_form(monkeypatch, script_pc=0)
+            pair = []
+            for tol in (True, False):
+                m = prog.module(name, V)
+                out = torch.zeros_like(base)
+                m.paint(zang.Span(0, 1024), [out], None, True, {"sample_rate": SR, "note_on": on, "freq": freq}, tolerant=tol)
+                ctx.sync()
+                pair.append(out.cpu().numpy().astype(np.float64))
+                m.close()
+            peak = np.maximum(np.abs(pair[1]).max(axis=0), 1e-30)
+            worst = float((np.abs(pair[0] - pair[1]).max(axis=0) / peak).max())
+            assert 0.0 < worst <= 1e-5, worst
+        prog.close()
+
+
 def test_a_script_compiled_once_is_loaded_from_its_code_object(ctx, tmp_path):
     """zh_script_compile -> a gfx950 code object kept on disk -> zh_script_load_code: the reference's compile-once flow
     (examples/example_script.zig:6-8: zangc runs before the program is built).  The second program never calls hiprtc and paints the

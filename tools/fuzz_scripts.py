@@ -1,6 +1,6 @@
-"""GPU box: tests/script_fuzz.py over any number of further seeds (odd seeds: 256-frame buffers as 3-7 frame ranges).  usage: fuzz_scripts.py N [first_seed [tolerant | roles]]
+"""GPU box: tests/script_fuzz.py over any number of further seeds (odd seeds: 256-frame buffers as 3-7 frame ranges).  usage: fuzz_scripts.py N [first_seed [tolerant | roles | roles_tolerant]]
 (tolerant: every paint with ZH_PAINT_TOLERANT, checked to 1e-5 of max(the voice's peak, 1) instead of bits;
- roles: every paint forced through the role-wave form, zs_paint_pc_<name>, 96- and 256-frame buffers)"""
+ roles: every paint forced through the role-wave form, zs_paint_pc_<name>, 96- and 256-frame buffers; roles_tolerant: both)"""
 import os, sys
 os.environ["ZH_ENV_LIVE"] = "1"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -8,14 +8,14 @@ import zang_amd
 from tests import script_fuzz
 ctx = zang_amd.default_context()
 n = int(sys.argv[1]); first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-tol = len(sys.argv) > 3 and sys.argv[3] == "tolerant"
-roles = len(sys.argv) > 3 and sys.argv[3] == "roles"
+tol = len(sys.argv) > 3 and sys.argv[3] in ("tolerant", "roles_tolerant")
+roles = len(sys.argv) > 3 and sys.argv[3] in ("roles", "roles_tolerant")
 worst = [0.0]
 bad = 0
 for seed in range(first, first + n):
     try:
         if roles:
-            script_fuzz.run_case(ctx, seed, roles=1, F=96 if seed % 2 else 256)
+            script_fuzz.run_case(ctx, seed, roles=1, F=96 if seed % 2 else 256, tolerant=tol, worst=worst)
         elif seed % 2:
             script_fuzz.run_case(ctx, seed, F=256, ranges=3 + seed % 5, tolerant=tol, worst=worst)
         else:
