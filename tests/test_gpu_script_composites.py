@@ -169,7 +169,7 @@ def test_hard_square_generated_kernel_equals_the_unfused_reference_recipe(ctx, o
     prog.close()
 
 
-@pytest.mark.parametrize("V", [1, 63, 64, 65, 200, 4160])
+@pytest.mark.parametrize("V", [1, 63, 64, 65, 200, 4160, 65536])
 def test_role_wave_form_equals_the_lane_form_at_odd_voice_counts_and_spans(ctx, monkeypatch, V):
     """zs_paint_pc_<name> against zs_paint_<name> (which the tests above hold against the oracle), bit for bit, where the workgroup
     geometry has edges: fewer voices than a wave, a partial last workgroup, spans shorter than a tile, ending inside a tile, starting
