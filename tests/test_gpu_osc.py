@@ -61,6 +61,29 @@ def test_const_freq_bitexact(ctx, oracle, kind, spans):
     assert [int(x) for x in gst["cnt"]] == [s[0] for s in rst]
 
 
+@pytest.mark.parametrize("V", [1024, 67])
+@pytest.mark.parametrize("zero_first", [False, True])
+def test_trisaw_sawtooth_waves(ctx, oracle, V, zero_first):
+    """color <= 0 (brpt == 0): a wave whose voices are ALL sawtooths takes trisaw_sample_saw (csrc/voices.hip.h: the two flat arms
+    alone); here every voice is one, or whole waves are and others are mixed (one lane group of the four-voices-per-lane kernel holds 256
+    voices, the one-voice-per-lane kernel 64), with silent voices, wraps every other sample (freq = sr / 8) and a tiny frequency."""
+    from zang_amd import workloads
+    F = 1024
+    freq, color, _, _ = workloads.voice_params(2, 7, V)
+    for colors in (np.zeros(V, np.float32), None):
+        c = color.copy() if colors is None else colors
+        if colors is None:
+            c[:512] = 0.0                                               # two all-sawtooth lane groups, then the generator's colors
+            c[5] = -0.3; c[6] = -0.0
+        f = freq.copy()
+        f[:6] = [6000.0, 6000.5, -1.0, 0.0, 0.001, 5999.9]
+        out0 = None if zero_first else util.rng_buffers(8, V, F)        # (the three spans cover the buffer: ZERO_FIRST over garbage = `+=` over zeros)
+        ref, rst = _oracle_osc(oracle, "trisaw", V, F, util.SPANS_THREE, f, c, out0=out0)
+        got, gst = _gpu_osc(ctx, "trisaw", V, F, util.SPANS_THREE, f, c, out0=util.rng_buffers(9, V, F) if zero_first else out0, zero_first=zero_first)
+        util.assert_bitexact(got, ref, f"trisaw sawtooth V={V} zf={zero_first}")
+        assert [int(x) for x in gst["cnt"]] == [s[0] for s in rst]
+
+
 @pytest.mark.parametrize("kind", ["pulse", "trisaw"])
 def test_const_freq_zero_first(ctx, oracle, kind):
     from zang_amd import workloads

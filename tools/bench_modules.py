@@ -54,6 +54,7 @@ m = mod.SineOsc(V, ctx); case("SineOsc freq image, ZH_PAINT_TOLERANT", m, lambda
 m = mod.PulseOsc(V, ctx); case("PulseOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
 m = mod.PulseOsc(V, ctx); case("PulseOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
 m = mod.TriSawOsc(V, ctx); case("TriSawOsc const freq (chunked)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), color), zero_first=True))
+m = mod.TriSawOsc(V, ctx); case("TriSawOsc const freq, color 0 (sawtooth)", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.constant(freq), 0.0), zero_first=True))
 m = mod.TriSawOsc(V, ctx); case("TriSawOsc freq image", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(SR, zang.buffer(fbuf), color), zero_first=True), 1)
 if V <= 16384:
     m = mod.Noise(V, ctx); case("Noise pink, ZH_PAINT_TOLERANT", m, lambda o, m=m: m.paint(span, [o], [], False, m.Params(m.pink), zero_first=True, tolerant=True))

@@ -61,6 +61,7 @@ struct PulseOscP {        // policy for the chunked kernels
     static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return pulse_sample(k, cnt); }
     // walking consecutive frames: the previous frame's half-period bit is carried instead of recomputed
     static constexpr bool kShortChunks = true;              // osc_frames_per_lane
+    static constexpr bool kSawShortChunks = false;
     using R = PulseRoll;
     static __device__ __forceinline__ R roll_init(const K &k, uint32_t cnt) { return pulse_roll_init(k, cnt); }
     static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &r) { return pulse_sample_roll(k, cnt, r); }
@@ -359,9 +360,10 @@ struct TriSawOscP {
     static __device__ __forceinline__ void setup(K &k, float srf, float freq, float color) { trisaw_setup(k, srf, freq, color); }
     static __device__ __forceinline__ float sample(const K &k, uint32_t cnt) { return trisaw_sample(k, cnt); }
     static constexpr bool kShortChunks = false;
-    using R = int;                                          // nothing carried
-    static __device__ __forceinline__ R roll_init(const K &, uint32_t) { return 0; }
-    static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &) { return trisaw_sample(k, cnt); }
+    static constexpr bool kSawShortChunks = true;           // ... unless the paint is a sawtooth for every voice (launch_osc_const)
+    using R = bool;                                         // wave-uniform: every voice a sawtooth (voices.hip.h trisaw_sample_saw)
+    static __device__ __forceinline__ R roll_init(const K &k, uint32_t) { return trisaw_all_saw(k); }
+    static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &saw) { return saw ? trisaw_sample_saw(k, cnt) : trisaw_sample(k, cnt); }
 };
 
 // TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt
@@ -466,7 +468,10 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
     const F32P fq = mk_f32(freq), col = mk_f32(color);
     const bool vec = osc_vec_ok<OSC>(n, outs, nb, freq, color);
     const uint32_t lanes = vec ? n / 4 : n;
-    const uint32_t fc = osc_frames_per_lane(OSC::kShortChunks, lanes, end - start);
+    // a TriSawOsc paint whose color is one value <= 0 for all voices is a sawtooth everywhere (voices.hip.h trisaw_sample_saw: 9 instructions
+    // a sample instead of 33): light enough for PulseOsc's short chunks and non-temporal stores
+    const bool short_chunks = OSC::kShortChunks || (OSC::kSawShortChunks && !color.per_voice && color.value <= 0.0f);
+    const uint32_t fc = osc_frames_per_lane(short_chunks, lanes, end - start);
     const uint32_t chunks = (end - start + fc - 1) / fc;
     if (vec) {
         // The table is read by every frame-chunk wave of a voice group, always on the same XCD (grid.x is a multiple of 8), so
@@ -478,7 +483,7 @@ static void launch_osc_const(M *m, const zh_buf *outs, uint32_t nb, uint32_t sta
         // stores: ZH_STORE_MODE when set; else write-through (sc1), and non-temporal for the three-frame chunks of many voices up to
         // the table's size limit (above it -- 786,432 / 1,048,576 voices -- sc1 again: 0.84 against 0.72 of the HBM peak)
         const int sm = ((size_t)fc * outs[0].stride * 4 >> 32) ? ST_PLAIN
-                       : zh_store_mode_env() >= 0 ? zh_store_mode_env() : (OSC::kShortChunks && lanes >= 4096u && fc == 3 && table_fits) ? ST_NT : ST_SC1;
+                       : zh_store_mode_env() >= 0 ? zh_store_mode_env() : (short_chunks && lanes >= 4096u && fc == 3 && table_fits) ? ST_NT : ST_SC1;
         const bool fc4 = fc == 4 && (end - start) % 4 == 0;
         // one launch of `a` (images and count filled in) over `cnt_b` buffers
         auto launch = [use_tab, fc4, zf, sm, lanes, chunks](OscArgs a, uint32_t cnt_b, hipStream_t st) {

@@ -121,6 +121,19 @@ __device__ __forceinline__ float trisaw_sample(const TriSawK &k, uint32_t cnt) {
     const float v = (b0 == b1) ? flat : ramp;
     return gain + v;
 }
+// color <= 0, the sawtooth (the reference's own recipes use it: examples/modules.zig:163, example_detuned.zig:71): brpt == 0, so
+// `cnt < brpt` is false for every cnt, the state (:101-104) is 0b000 or 0b100 and only the two flat arms with c2 can be selected --
+// trisaw_sample's own expressions for them, 15 instructions instead of 36.  Taken when EVERY voice of the wave is a sawtooth
+// (trisaw_all_saw: a wave-uniform branch, no per-lane select).
+__device__ __forceinline__ bool trisaw_all_saw(const TriSawK &k) { return __builtin_amdgcn_ballot_w64(k.brpt != 0u) == 0; }
+__device__ __forceinline__ float trisaw_sample_saw(const TriSawK &k, uint32_t cnt) {
+    const float gain = 0.7f;
+    const float p = zutof23(cnt) - k.col;
+    const bool b2 = cnt < k.ifreq;
+    const float flat_nowrap = k.c2 * (p + p - k.f);
+    const float flat_wrap = -k.rcpf * (gain + k.c2 * k.omf * (p + p + k.omf));
+    return gain + (b2 ? flat_wrap : flat_nowrap);
+}
 // the naive saw / triangle of the controlled-frequency path (:120-156): uses the f32 phase, ignores cnt
 // (every arm computed, then selected: `saw` and the triangle's three pieces differ from lane to lane, and per-lane
 // branches cost more exec-mask instructions than the two multiplies an arm is)
@@ -140,13 +153,15 @@ struct TriSawOscLane {
     TriSawK k;
     float sample_rate;
     bool bad, saw;
+    bool all_saw;                                                     // wave-uniform: every voice of the wave has brpt == 0
     __device__ __forceinline__ void begin_const(float sr, float freq, float color) {
         bad = freq < 0 || freq > sr / 8.0f;                           // :84-86
         trisaw_setup(k, 4294967296.0f / sr, freq, color);
+        all_saw = trisaw_all_saw(k);
     }
     __device__ __forceinline__ bool frame_const(float &val) {
         if (bad) return false;
-        val = trisaw_sample(k, cnt);
+        val = all_saw ? trisaw_sample_saw(k, cnt) : trisaw_sample(k, cnt);
         cnt += k.ifreq;
         return true;
     }

@@ -847,7 +847,11 @@ public:
         auto ret = [&](int cost, int w) { walk = w; return cost; };
         if (name == "SineOsc") return is_buf("freq") ? ret(42, 3) : ret(40, 2);
         if (name == "PulseOsc") return is_buf("freq") ? ret(34, 34) : ret(16, 2);
-        if (name == "TriSawOsc") return is_buf("freq") ? ret(24, 12) : ret(42, 2);
+        if (name == "TriSawOsc") {
+            if (is_buf("freq")) return ret(24, 12);
+            const std::string &c = a["color"].expr;                  // a literal 0: the sawtooth's two arms alone (voices.hip.h trisaw_sample_saw)
+            return c == "0x0.0p+0f" || c == "-0x0.0p+0f" ? ret(17, 2) : ret(42, 2);
+        }
         if (name == "Noise") return a["color"].tag_literal && a["color"].tag == "white" ? ret(24, 20) : ret(44, 20);
         if (name == "Envelope") return ret(16, 5);                   // (a walked group of four quiet frames: four clock steps, one curve)
         if (name == "Filter") { const int c = 21 + (is_buf("cutoff") ? 3 : 0) + (is_buf("res") ? 4 : 0); return ret(c, c); }
