@@ -74,7 +74,10 @@ class Gen:
             ph = self.lit(-1.0, 1.0) if self.chance(0.6) or depth == 0 else "(%s * %s)" % (self.lit(0.05, 0.5), self.buf(ctx, depth - 1))
             return "SineOsc(freq=%s, phase=%s)" % (self.freq(ctx, depth), ph)
         if n in ("PulseOsc", "TriSawOsc"):
-            return "%s(freq=%s, color=%s)" % (n, self.freq(ctx, depth), self.lit(0.0, 1.0, 3))
+            f, c = self.freq(ctx, depth), self.lit(0.0, 1.0, 3)
+            if n == "TriSawOsc" and float(c) < 0.15:                    # the sawtooth (brpt == 0: voices.hip.h trisaw_sample_saw) now and then
+                c = "0"
+            return "%s(freq=%s, color=%s)" % (n, f, c)
         if n == "Noise":
             self.noise += 1
             return "Noise(color=.%s)" % self.pick(("white", "pink"))

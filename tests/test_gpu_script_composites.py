@@ -52,9 +52,12 @@ def _check_form(ctx, roles, name):
 
 def _check_default_form(ctx, name, V, span):
     """the library's own choice: the role-wave form for the reference's filtered recipe up to script_pc_maxv voices (spans of at
-    least 64 frames), the lane form above and for a recipe without a chain (HardSquare: frame ranges do better)"""
+    least 64 frames) -- up to half of it for the variant with a frequency image, whose role form does 1.6 x the body's work (the
+    emitter's second hint bit, csrc/zscript_emit.hip role_kernel) -- the lane form above and for a recipe without a chain (HardSquare:
+    frame ranges do better)"""
     ran = ctx.last_form()
-    want = name.startswith("FilteredSawtooth") and V <= ctx.forms()["script_pc_maxv"][1] and span[1] - span[0] >= 64
+    maxv = ctx.forms()["script_pc_maxv"][1]
+    want = name.startswith("FilteredSawtooth") and V <= (maxv if name == "FilteredSawtooth" else maxv // 2) and span[1] - span[0] >= 64
     assert any(k == "zs_paint_pc_" + name for k in ran) == want, (name, V, span, ran)
 
 
@@ -203,6 +206,37 @@ def test_role_wave_form_equals_the_lane_form_at_odd_voice_counts_and_spans(ctx, 
         assert np.array_equal(states[0], states[1]), f"{name} V={V}: state words"
         assert float(np.abs(outs[0]).max()) > 0.01
         prog.close()
+
+
+def test_the_library_picks_the_form_by_voice_count_and_the_emitters_two_hints(ctx):
+    """Up to script_pc_maxv / 2 voices every module with the first hint bit paints in the role-wave form; from there to script_pc_maxv only
+    those with the second one (FilteredSawtooth, Glide: 181 -> 110 us and 163 -> 122 us at 65,536 voices; Hiss, whose noise role is walked
+    by four waves, and Bell with its twelve waves would lose there: profiles/r06/role_ab_65536.txt); above it none; a module without the
+    first bit never."""
+    import re
+    import torch
+    from zang_amd import script, zang
+    prog = script.ScriptProgram(SCRIPT, ctx, only=["FilteredSawtooth", "Glide", "Hiss", "Bell", "Pluck"])
+    bits = {n: int(re.search(r"zs_pc_info_%s\[4\] = \{\d+u, \d+u, \d+u, (\d)u\}" % n, prog.hip_source).group(1)) for n in ("FilteredSawtooth", "Glide", "Hiss", "Bell")}
+    assert bits == {"FilteredSawtooth": 3, "Glide": 3, "Hiss": 1, "Bell": 1}, bits
+    assert "zs_paint_pc_Pluck" not in prog.hip_source                  # (FORM_ROLES_WORTH: no role-wave kernel is generated for it at all)
+    maxv = ctx.forms()["script_pc_maxv"][1]
+    for V in (maxv // 2, maxv // 2 + 64, maxv, maxv + 64):
+        out = ctx.image(256, V)
+        on = torch.ones(V, dtype=torch.uint8, device=ctx.device)
+        for name in ("FilteredSawtooth", "Glide", "Hiss", "Bell", "Pluck"):
+            m = prog.module(name, V)
+            p = {}
+            for pname, kind, enum in m.params:                         # something valid for every param, whatever the module
+                p[pname] = (SR if pname == "sample_rate" else on if kind == "boolean" else ".low_pass" if enum == "FilterType" else
+                            220.0 if pname in ("freq", "goal") else 0.1)
+            m.paint(zang.Span(0, 256), [out], None, True, p, zero_first=True)
+            ran = ctx.last_form()
+            want = name != "Pluck" and (V <= maxv // 2 or (bits[name] & 2 and V <= maxv))
+            assert (ran == ["zs_paint_pc_" + name]) == bool(want), (name, V, ran)
+            m.close()
+    ctx.sync()
+    prog.close()
 
 
 @pytest.mark.parametrize("V", [64, 1000])

@@ -49,6 +49,7 @@ for name in sorted(prog.meta):
     if "error" in m_ or ("zs_paint_pc_" + name + "(") not in prog.hip_source:
         continue
     hint = int(re.search(r"zs_pc_info_%s\[4\] = \{\d+u, \d+u, \d+u, (\d)u\}" % name, prog.hip_source).group(1))
+    hint = (hint & 1) if V <= 32768 else (hint >> 1) & 1            # (bit 1: still worth it above half of script_pc_maxv)
     desc = re.search(r"// role-wave form: ([^\n]*)\nextern \"C\" __device__ const uint32_t zs_pc_info_%s\[" % name, prog.hip_source).group(1)
     res = []
     for pc in (0, 1):

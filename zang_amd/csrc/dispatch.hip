@@ -35,7 +35,7 @@ const FormRow kForms[ZF_COUNT] = {
     /* ZF_PMOSC_RANGES       */ {"pmosc_ranges", -1, "PMOscInstrument: frame ranges (k_pmosc_ranges); auto: ~2,048-4,096 waves up to 131,072 voices"},
     /* ZF_SCRIPT_RANGES      */ {"script_ranges", -1, "generated script kernels: frame ranges for modules without a delay ring; auto: by voice count"},
     /* ZF_SCRIPT_RANGES_MAXV */ {"script_ranges_maxv", 131072, "... the largest voice count that takes them"},
-    /* ZF_OSC_FC             */ {"osc_fc", 0, "constant-frequency PulseOsc / TriSawOsc: frames per lane of the chunked kernel; 0 = PulseOsc 4, from 16,384 voices 3 with non-temporal stores (profiles/r05/osc_large_voice_counts.txt); TriSawOsc 8-64 by voice count (tools/sweep_osc_fc.sh)"},
+    /* ZF_OSC_FC             */ {"osc_fc", 0, "constant-frequency PulseOsc / TriSawOsc: frames per lane of the chunked kernel; 0 = PulseOsc 4, from 16,384 voices 3 with non-temporal stores (profiles/r05/osc_large_voice_counts.txt); TriSawOsc 8-64 by voice count (tools/sweep_osc_fc.sh), PulseOsc's when the paint is a sawtooth for every voice (one color <= 0)"},
     /* ZF_NICE_PC_MAX        */ {"nice_pc_max", 65536, "NiceInstrument: up to here the oscillator, envelope and filter chains run in three waves side by side (k_nice_pc: 72 vs 146 us at 4,096 voices, 107 vs 168 at 65,536; slower at 131,072)"},
     /* ZF_NICE_PC4_MAX       */ {"nice_pc4_max", 32768, "... and up to here in four (k_nice_pc4: 44 / 47 / 53.5 us at 4,096 / 16,384 / 32,768 voices against 60.5 / 62.5 / 63)"},
     /* ZF_NICE_WAVE_MAX      */ {"nice_wave_max", 64, "zh_nice_paint_spans: up to here one WAVE per voice, lanes = frames (k_nice_spans_wave)"},
@@ -59,7 +59,7 @@ const FormRow kForms[ZF_COUNT] = {
     /* ZF_NICE_MIX_FMA       */ {"nice_mix_fma", 1, "ZH_PAINT_TOLERANT fused mixdown above nice_tp_max voices: 1 = the kernel compiled with multiply-adds fused (nice_mix_fma.hip), 0 = the exact kernel"},
     /* ZF_BASICS_ROWS_MIN    */ {"basics_rows_min", 32768, "basics.zig operations (zero, set, copy, add ..., multiply ...): from here three consecutive rows of a 256-voice column per wave (k_elementwise_chunks) instead of the row-striding loop: 131,072 voices 12-23 % faster"},
     /* ZF_SCRIPT_PC          */ {"script_pc", -1, "generated script kernels: the role-wave form (zs_paint_pc_<name>: the body's builtin calls as producer / recurrence / writer waves over LDS tiles); auto: where the emitter found the lane form unable to take frame ranges and the longest role well below the whole body; 0 = never, 1 = every module that has the form"},
-    /* ZF_SCRIPT_PC_MAXV     */ {"script_pc_maxv", 65536, "... the largest voice count that takes it (FilteredSawtooth: 52.6 / 54.7 / 74.9 / 130.6 us at 4,096 / 16,384 / 32,768 / 65,536 voices against 188-199 in one wave per 64 voices; slower at 131,072)"},
+    /* ZF_SCRIPT_PC_MAXV     */ {"script_pc_maxv", 65536, "... the largest voice count that takes it -- half of it for a module whose role form does more than 1.25 x the body's work or needs more than 9 waves (FilteredSawtooth: 53 / 57 / 66 / 110 us at 4,096 / 16,384 / 32,768 / 65,536 voices against 172-181 in one wave per 64 voices; slower at 131,072)"},
     /* ZF_NF_TP_PIPE_FRAMES  */ {"nf_tp_pipe_frames", 0, "ZH_PAINT_TOLERANT Noise -> Filter voice recorded pipelined (ZH_CAPTURE_COALESCE, k_nf_tp_ba): frames per chunk, a multiple of 32; 0 = as outside a pipeline (32 at 4,096 voices)"},
     /* ZF_DISTORTION_ROWS_MIN */ {"distortion_rows_min", 32768, "Distortion clip: from here four voices per lane, three consecutive rows of a 256-voice column per wave, the per-voice constants once per workgroup through LDS (k_distortion_chunks: 224 -> 178 us at 131,072 voices); the overdrive too when this row is set by hand (no faster: 239 against 244-250 us)"},
     /* ZF_DISTORTION_RC      */ {"distortion_rc", 0, "... rows per wave of that form: 3 (0), 6 or 8"},

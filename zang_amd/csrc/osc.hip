@@ -17,6 +17,7 @@
 #include "seq.hip.h"
 #include "voices.hip.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 // Per-voice constants of the constant-frequency path, kept from one paint to the next ([KW + 1][n]: the policy's K
@@ -65,6 +66,9 @@ struct PulseOscP {        // policy for the chunked kernels
     using R = PulseRoll;
     static __device__ __forceinline__ R roll_init(const K &k, uint32_t cnt) { return pulse_roll_init(k, cnt); }
     static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &r) { return pulse_sample_roll(k, cnt, r); }
+    static constexpr bool kHasFast = false;                 // (no second form of the frame loops)
+    template <bool FAST> static __device__ __forceinline__ float sample_f(const K &k, uint32_t cnt, R &r) { return pulse_sample_roll(k, cnt, r); }
+    static __device__ __forceinline__ bool fast(const R (&)[4]) { return false; }
 };
 
 struct TriSawOscP;        // defined below
@@ -224,20 +228,39 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
     const uint32_t wc0 = start + wchunk * fc;
     const zh_rsrc_t rsrc = make_rsrc(img + (size_t)wc0 * os, (uint32_t)((size_t)fc * os * 4));
     uint32_t boff = lane * 16 + (uint32_t)((size_t)vbase * 4);
-    // Common case, decided per wave: no silent voice among the wave's 256.  In ZERO_FIRST mode the
-    // stored value is then `0.0f + val`, which equals `val` bit for bit: every arm of sample() ends in
-    // `x + gain`, `x - gain` or `gain + x` with gain = 0.7, and an IEEE sum is -0.0 only if both addends
-    // are -0.0, so val is never -0.0 (the one input 0.0f + x changes); NaNs pass through unchanged.
-    if (!__any(bad[0] || bad[1] || bad[2] || bad[3])) {
-        if constexpr (FC4) {
+    // (the frame loops once per form of the sample: OSC::fast -- every voice of the wave a sawtooth, TriSawOsc -- picks the light one)
+    auto frames = [&](auto fast_tag) ZH_INLINE_LAMBDA {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        // Common case, decided per wave: no silent voice among the wave's 256.  In ZERO_FIRST mode the
+        // stored value is then `0.0f + val`, which equals `val` bit for bit: every arm of sample() ends in
+        // `x + gain`, `x - gain` or `gain + x` with gain = 0.7, and an IEEE sum is -0.0 only if both addends
+        // are -0.0, so val is never -0.0 (the one input 0.0f + x changes); NaNs pass through unchanged.
+        if (!__any(bad[0] || bad[1] || bad[2] || bad[3])) {
+            if constexpr (FC4) {
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++, o += os, boff += (uint32_t)os * 4) {
+                for (uint32_t i = 0; i < 4; i++, o += os, boff += (uint32_t)os * 4) {
+                    zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (!ZF) acc = *reinterpret_cast<const zv4f *>(o);
+                    float val[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        val[j] = OSC::template sample_f<FAST>(k[j], cnt[j], roll[j]);
+                        cnt[j] += k[j].ifreq;
+                    }
+                    if (ZF) { acc.x = val[0]; acc.y = val[1]; acc.z = val[2]; acc.w = val[3]; }
+                    else { acc.x += val[0]; acc.y += val[1]; acc.z += val[2]; acc.w += val[3]; }
+                    store4<SM>(o, rsrc, boff, acc);
+                }
+                return;
+            }
+#pragma unroll 2
+            for (uint32_t i = c0; i < c1; i++, o += os, boff += (uint32_t)os * 4) {
                 zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (!ZF) acc = *reinterpret_cast<const zv4f *>(o);
                 float val[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    val[j] = OSC::sample_roll(k[j], cnt[j], roll[j]);
+                    val[j] = OSC::template sample_f<FAST>(k[j], cnt[j], roll[j]);
                     cnt[j] += k[j].ifreq;
                 }
                 if (ZF) { acc.x = val[0]; acc.y = val[1]; acc.z = val[2]; acc.w = val[3]; }
@@ -253,32 +276,21 @@ __global__ void __launch_bounds__(256) k_osc_const4(const OscArgs a) {
             float val[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                val[j] = OSC::sample_roll(k[j], cnt[j], roll[j]);
+                val[j] = OSC::template sample_f<FAST>(k[j], cnt[j], roll[j]);
                 cnt[j] += k[j].ifreq;
             }
-            if (ZF) { acc.x = val[0]; acc.y = val[1]; acc.z = val[2]; acc.w = val[3]; }
-            else { acc.x += val[0]; acc.y += val[1]; acc.z += val[2]; acc.w += val[3]; }
+            // a silent voice (bad freq) paints nothing: out unchanged (ADD) / zero (ZERO_FIRST)
+            acc.x = bad[0] ? acc.x : acc.x + val[0];
+            acc.y = bad[1] ? acc.y : acc.y + val[1];
+            acc.z = bad[2] ? acc.z : acc.z + val[2];
+            acc.w = bad[3] ? acc.w : acc.w + val[3];
             store4<SM>(o, rsrc, boff, acc);
         }
-        return;
+    };
+    if constexpr (OSC::kHasFast) {
+        if (OSC::fast(roll)) { frames(std::true_type{}); return; }
     }
-#pragma unroll 2
-    for (uint32_t i = c0; i < c1; i++, o += os, boff += (uint32_t)os * 4) {
-        zv4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (!ZF) acc = *reinterpret_cast<const zv4f *>(o);
-        float val[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            val[j] = OSC::sample_roll(k[j], cnt[j], roll[j]);
-            cnt[j] += k[j].ifreq;
-        }
-        // a silent voice (bad freq) paints nothing: out unchanged (ADD) / zero (ZERO_FIRST)
-        acc.x = bad[0] ? acc.x : acc.x + val[0];
-        acc.y = bad[1] ? acc.y : acc.y + val[1];
-        acc.z = bad[2] ? acc.z : acc.z + val[2];
-        acc.w = bad[3] ? acc.w : acc.w + val[3];
-        store4<SM>(o, rsrc, boff, acc);
-    }
+    frames(std::false_type{});
 }
 
 // Controlled frequency (PulseOsc.zig:116-157).  One kernel, two launch shapes: sequential (grid.y = 1, ch = the span,
@@ -364,6 +376,10 @@ struct TriSawOscP {
     using R = bool;                                         // wave-uniform: every voice a sawtooth (voices.hip.h trisaw_sample_saw)
     static __device__ __forceinline__ R roll_init(const K &k, uint32_t) { return trisaw_all_saw(k); }
     static __device__ __forceinline__ float sample_roll(const K &k, uint32_t cnt, R &saw) { return saw ? trisaw_sample_saw(k, cnt) : trisaw_sample(k, cnt); }
+    // k_osc_const4: the four voices of a lane decide together, ONE wave-uniform condition, and the frame loops exist once per form
+    static constexpr bool kHasFast = true;
+    template <bool FAST> static __device__ __forceinline__ float sample_f(const K &k, uint32_t cnt, R &) { return FAST ? trisaw_sample_saw(k, cnt) : trisaw_sample(k, cnt); }
+    static __device__ __forceinline__ bool fast(const R (&r)[4]) { return r[0] && r[1] && r[2] && r[3]; }
 };
 
 // TriSawOsc.zig:120-156: naive saw / triangle from an f32 phase; ignores cnt

@@ -1511,6 +1511,14 @@ public:
         // worth it where the lane form can not take frame ranges and the longest role is well below the whole body
         const bool hint = (k.rings || k.walk_reads_computed) && longest * 10 <= total * 7;
         worth = hint;
+        // ... and still where a wave per SIMD or more of the lane form fits the chip (above half of script_pc_maxv: script.hip): there
+        // the role form's WORK counts, not only its longest role -- a role walked by K waves repeats its state steps K times -- and every
+        // wave more is one more at the step's barrier.  Measured at 65,536 voices (profiles/r06/role_ab_65536.txt): the modules with
+        // work <= 1.25 x the body's, at most 9 waves and a longest role under 2/7 of the body win (FilteredSawtooth 181 -> 110 us, Sweep,
+        // Glide, Buzz), the others lose or tie (Hiss 256 -> 357: its noise is walked four times).
+        int work = 0;
+        for (int r = 0; r < NR; r++) work += roles[(size_t)r].rep * roles[(size_t)r].walk + (roles[(size_t)r].cost - roles[(size_t)r].walk);
+        const bool hint_many = hint && work * 4 <= total * 5 && nwaves <= 9 && longest * 7 <= total * 2;
 
         // ---- text
         const std::string I = "    ";
@@ -1518,7 +1526,7 @@ public:
         Lines out;
         out.push_back(strf("// role-wave form: %zu waves (%zu loader, %d roles, the last the writer), %d frames per tile, %zu tile buffers", nwaves, loaders.size(), NR, ch, bufs));
         out.push_back(strf("extern \"C\" __device__ const uint32_t zs_pc_info_%s[4] = {%zuu, %zuu, %zuu, %uu};", nc, nwaves * 64, bufs * (size_t)ch * 256,
-                           bufs_no_oin * (size_t)ch * 256, hint ? 1u : 0u));
+                           bufs_no_oin * (size_t)ch * 256, (hint ? 1u : 0u) | (hint_many ? 2u : 0u)));
         out.push_back(strf("extern \"C\" __global__ void __launch_bounds__(%zu) zs_paint_pc_%s(const ZsLaunch L) {", nwaves * 64, nc));
         out.push_back(I + "extern __shared__ float4 zs_lds[];");
         out.push_back(I + "const uint32_t zs_lane = threadIdx.x & 63u, zs_role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));");
